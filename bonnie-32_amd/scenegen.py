@@ -1,0 +1,164 @@
+"""Deterministic synthetic scenes for the rasterizer hot path.
+
+PRNG = splitmix64 used as a counter-based generator: draw k of stream `seed` is mix(seed + (k+1)*GAMMA);
+uniform floats are (x >> 40) * 2**-24 (exact in f32).  All geometry arithmetic is explicit numpy float32,
+so the same seed gives bit-identical scenes on every box with this image.
+
+Configs (BASELINE.json `configs`):
+  C1  320x240,     2 000 tris, mean bbox  ~64 px, 64x64 4-bit atlas      (plumbing + golden fixture)
+  C2  320x240,   100 000 tris, mean bbox  ~16 px, 64x64 4-bit atlas
+  C3  2560x1920, 1 000 000 tris, mean bbox ~48 px, 256x256 8-bit atlas   (headline, HBM-roofline run)
+  C4  = C3 sharded over 8 GPUs (screen bands)
+  C5  2560x1920, 1 000 000 tris, mean bbox ~400 px, 64 discrete depths   (painter's-sort / overdraw stress)
+"""
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+
+from . import abi
+from .types import (Camera, Color, IndexedTexture, Light, RasterSettings, Texture15, make_faces, make_vertices)
+
+GAMMA = np.uint64(0x9E3779B97F4A7C15)
+BASE_SEED = 0xB0771E32
+
+CONFIGS = {
+    "C1": dict(width=320, height=240, n_tris=2_000, bbox_px=64.0, atlas=64, clut=16, depths=0, config_id=1),
+    "C2": dict(width=320, height=240, n_tris=100_000, bbox_px=16.0, atlas=64, clut=16, depths=0, config_id=2),
+    "C3": dict(width=2560, height=1920, n_tris=1_000_000, bbox_px=48.0, atlas=256, clut=256, depths=0, config_id=3),
+    "C5": dict(width=2560, height=1920, n_tris=1_000_000, bbox_px=400.0, atlas=256, clut=256, depths=64, config_id=5),
+}
+CONFIGS["C4"] = dict(CONFIGS["C3"])  # same scene, band-sharded over GPUs
+
+
+def splitmix64(seed, n, offset=0):
+    """n draws (uint64) of stream `seed`, starting at draw index `offset`."""
+    with np.errstate(over="ignore"):
+        k = np.arange(offset + 1, offset + n + 1, dtype=np.uint64)
+        z = np.uint64(seed & 0xFFFFFFFFFFFFFFFF) + k * GAMMA
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def uniform01(seed, n, offset=0):
+    """n floats in [0,1): (x >> 40) * 2^-24, exact in f32."""
+    return ((splitmix64(seed, n, offset) >> np.uint64(40)).astype(np.float32) * np.float32(2.0 ** -24)).astype(np.float32)
+
+
+@dataclass
+class Scene:
+    name: str
+    width: int
+    height: int
+    vertices: np.ndarray
+    faces: np.ndarray
+    textures: List[Texture15]
+    indexed_textures: List[IndexedTexture]
+    camera: Camera
+    settings: RasterSettings
+    clear_color: Color = field(default_factory=lambda: Color(20, 22, 28))  # game/renderer.rs:95
+    fog: Optional[tuple] = None
+
+    @property
+    def n_tris(self):
+        return len(self.faces)
+
+
+def make_atlas(seed, size, clut_len, stp=False):
+    """size x size index atlas (one byte/texel, uniform indices) + CLUT: entry 0 = 0x0000 (transparent),
+    others uniform 15-bit with bit 15 clear (or set on every 4th entry when stp=True)."""
+    idx = (splitmix64(seed ^ 0x7E87, size * size) % np.uint64(clut_len)).astype(np.uint8)
+    clut = (splitmix64(seed ^ 0xC107, clut_len) & np.uint64(0x7FFF)).astype(np.uint16)
+    clut[0] = 0
+    if stp:
+        clut[3::4] |= np.uint16(0x8000)
+    return IndexedTexture(size, size, idx, clut, abi.OPAQUE)
+
+
+def make_scene(config="C1", n_tris=None, seed=None, variant="bench", width=None, height=None, bbox_px=None):
+    """Build one synthetic scene.
+
+    variant: "bench"  -> SURVEY §8 benchmark settings (painter's, shading None)
+             "gouraud"-> reference default light (directional (-1,-1,-1)*0.7, ambient 0.3), Gouraud
+             "blend"  -> 10% of faces blend_mode=Average on an STP-bit CLUT + a second texture whose
+                         blend_mode is Add (exercises the transparent partition and blend_rgb555)
+             "float"  -> use_fixed_point=False (float projection, math.rs:117-136)
+    """
+    cfg = dict(CONFIGS[config])
+    if n_tris is not None:
+        cfg["n_tris"] = int(n_tris)
+    if width is not None:
+        cfg["width"], cfg["height"] = int(width), int(height)
+    if bbox_px is not None:
+        cfg["bbox_px"] = float(bbox_px)
+    W, H, N = cfg["width"], cfg["height"], cfg["n_tris"]
+    seed = (BASE_SEED + cfg["config_id"]) if seed is None else seed
+    f32 = np.float32
+
+    U = uniform01(seed, N * 24).reshape(N, 24)
+    vs = f32((f32(min(W, H)) / f32(2.0)) * f32(0.75))
+    px = U[:, 0] * f32(W)
+    py = U[:, 1] * f32(H)
+    if cfg["depths"]:
+        level = np.floor(U[:, 2] * f32(cfg["depths"])).astype(np.float32)
+        cz = f32(400.0) + level * f32(5600.0 / cfg["depths"])
+    else:
+        cz = f32(400.0) + U[:, 2] * f32(5600.0)
+    k = (cz + f32(5.0)) / f32(4.0)                      # world units per projected unit at this depth
+    cx = (px - f32(W / 2)) / vs * k
+    cy = (py - f32(H / 2)) / vs * k
+    r_world = f32(np.sqrt(cfg["bbox_px"])) / vs * k     # 3 uniform offsets in [-r,r] => E[bbox side] = r
+
+    verts = make_vertices(3 * N)
+    off = (U[:, 3:12] * f32(2.0) - f32(1.0)).reshape(N, 3, 3) * r_world[:, None, None]
+    centre = np.stack([cx, cy, cz], axis=1)[:, None, :]
+    verts["pos"] = (centre + off).astype(np.float32).reshape(3 * N, 3)
+    verts["uv"] = (U[:, 12:18] * f32(3.0) - f32(1.0)).reshape(3 * N, 2)       # [-1, 2): exercises rem_euclid
+    verts["normal"] = np.array([0.0, 0.0, -1.0], np.float32)
+    col = (splitmix64(seed ^ 0xC0105, 9 * N) >> np.uint64(56)).astype(np.uint8).reshape(3 * N, 3)
+    verts["r"], verts["g"], verts["b"] = col[:, 0], col[:, 1], col[:, 2]
+    verts["blend"] = abi.OPAQUE
+
+    faces = make_faces(N, texture_id=0)
+    faces["v"] = np.arange(3 * N, dtype=np.uint32).reshape(N, 3)
+
+    atlas = make_atlas(seed, cfg["atlas"], cfg["clut"], stp=(variant == "blend"))
+    indexed = [atlas]
+    settings = RasterSettings.benchmark()
+    if variant == "gouraud":
+        settings.shading = abi.SHADE_GOURAUD
+        settings.lights = [Light.directional((-1.0, -1.0, -1.0), 0.7)]
+        settings.ambient = 0.3
+        nrm = (uniform01(seed ^ 0x4047, 9 * N).reshape(3 * N, 3) * f32(2.0) - f32(1.0)).astype(np.float32)
+        verts["normal"] = nrm
+    elif variant == "blend":
+        sel = uniform01(seed ^ 0xB1E4D, N)
+        faces["blend_mode"] = np.where(sel < 0.10, abi.AVERAGE, abi.OPAQUE).astype(np.uint8)
+        t2 = make_atlas(seed ^ 0x2222, cfg["atlas"], cfg["clut"], stp=True)
+        t2.blend_mode = abi.ADD
+        indexed.append(t2)
+        faces["texture_id"] = np.where((sel >= 0.10) & (sel < 0.15), 1, 0).astype(np.uint32)
+        faces["black_transparent"] = np.where(sel > 0.9, 0, 1).astype(np.uint8)
+        faces["editor_alpha"] = np.where((sel >= 0.15) & (sel < 0.18), 128, 255).astype(np.uint8)
+    elif variant == "float":
+        settings.use_fixed_point = False
+    elif variant != "bench":
+        raise ValueError(variant)
+
+    textures = [t.to_texture15() for t in indexed]
+    return Scene(f"{config}:{variant}:{N}", W, H, verts, faces, textures, indexed, Camera(), settings)
+
+
+def cube_scene(width=320, height=240):
+    """The reference-authored fixture: create_test_cube (draw.rs:138-214) + Texture15::checkerboard
+    (types.rs:702-711), camera pulled back along -z, Gouraud default light, painter's."""
+    from .types import create_test_cube
+    v, f = create_test_cube()
+    tex = Texture15.checkerboard(32, 32, 0x7FFF, 0x3DEF)
+    s = RasterSettings.benchmark()
+    s.shading = abi.SHADE_GOURAUD
+    s.lights = [Light.directional((-1.0, -1.0, -1.0), 0.7)]
+    cam = Camera(position=(0.7, -0.9, -4.5))
+    return Scene("cube", width, height, v, f, [tex], [], cam, s)

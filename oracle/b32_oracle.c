@@ -1,0 +1,691 @@
+/*
+ * b32_oracle.c — CPU restatement of bonnie-32's `render_mesh_15` hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this.  The product library (bonnie-32_amd/csrc) never links, calls or falls back to it.
+ *
+ * PARITY STATUS: "parity unpinned" at the pixel level by the reference itself — the reference holds no
+ * test that pins a rendered pixel and it is Rust, which cannot be built in this image.
+ * What pins this file instead: (1) the reference's own unit-test vectors for fixed.rs/math.rs
+ * (tests/test_oracle_kats.py), (2) the psx-spx UNR table and dither matrix the reference's comments name,
+ * (3) an independent numpy restatement (oracle/np_model.py) that must agree bit-for-bit on whole frames.
+ *
+ * Every function cites the reference file:line it follows (paths relative to /root/reference).
+ * Build: gcc -O2 -std=c11 -ffp-contract=off -fno-fast-math -msse2 -mfpmath=sse (scalar SSE2, no FMA — the
+ * reference's release profile is x86-64 baseline, Cargo.toml:52-54).
+ *
+ * Rust semantics encoded once in the helpers below:
+ *   - `f as i32 / as u8 / as usize` saturate and map NaN to 0 (Rust reference: "Numeric cast").
+ *   - f32::min/max ignore a NaN operand; f32::clamp propagates NaN.
+ *   - release build: integer overflow wraps (`-x`, `<<`, `abs`), exactly where the source does not say wrapping_*.
+ *   - slice::sort_by is stable; Iterator::partition keeps relative order.
+ */
+#include "../include/b32raster.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define EXPORT __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------ Rust cast / float helpers */
+static inline int32_t f2i32_sat(float f) {
+    if (f != f) return 0;
+    if (f >= 2147483648.0f) return INT32_MAX;
+    if (f <= -2147483648.0f) return INT32_MIN;
+    return (int32_t)f;
+}
+static inline uint8_t f2u8_sat(float f) {
+    if (f != f) return 0;
+    if (f >= 255.0f) return 255;
+    if (f <= 0.0f) return 0;
+    return (uint8_t)f;
+}
+static inline uint64_t f2usize_sat(float f) {
+    if (f != f) return 0;
+    if (f <= 0.0f) return 0;
+    if (f >= 18446744073709551616.0f) return UINT64_MAX;
+    return (uint64_t)f;
+}
+static inline float rmin(float a, float b) { /* f32::min */
+    if (a != a) return b;
+    if (b != b) return a;
+    return a < b ? a : b;
+}
+static inline float rmax(float a, float b) { /* f32::max */
+    if (a != a) return b;
+    if (b != b) return a;
+    return a > b ? a : b;
+}
+static inline float rclamp(float x, float lo, float hi) { /* f32::clamp */
+    if (x < lo) return lo;
+    if (x > hi) return hi;
+    return x;
+}
+static inline float rem_euclid1(float x) { /* f32::rem_euclid(1.0): r = x % 1.0; if r < 0 { r + 1.0 } */
+    float r = fmodf(x, 1.0f);
+    return r < 0.0f ? r + 1.0f : r;
+}
+static inline int32_t wrap_add(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
+static inline int32_t wrap_sub(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
+static inline int32_t wrap_neg(int32_t a) { return (int32_t)(0u - (uint32_t)a); }
+
+/* ------------------------------------------------------------------ fixed.rs */
+
+/* UNR_TABLE, fixed.rs:20-31 */
+static uint8_t g_unr[257];
+static int g_unr_ready = 0;
+static void unr_init(void) {
+    if (g_unr_ready) return;
+    for (uint32_t i = 0; i < 257; ++i) {
+        uint32_t div = i + 256;
+        uint32_t quotient = 262144u / div;
+        int32_t val = (int32_t)((quotient + 1) / 2) - 257;
+        g_unr[i] = val > 0 ? (uint8_t)val : 0;
+    }
+    g_unr_ready = 1;
+}
+EXPORT uint8_t b32o_unr_table(uint32_t i) { unr_init(); return g_unr[i <= 256 ? i : 256]; }
+
+/* Fixed32::from_f32, fixed.rs:125-127 */
+EXPORT int32_t b32o_fixed_from_f32(float f) { return f2i32_sat(f * 4096.0f); }
+/* Fixed32::from_int, fixed.rs:119-121 (release: shift wraps) */
+static inline int32_t fixed_from_int(int32_t n) { return (int32_t)((uint32_t)n << 12); }
+/* Fixed32::to_f32, fixed.rs:131-133 */
+static inline float fixed_to_f32(int32_t v) { return (float)v / 4096.0f; }
+/* Fixed32::mul_fixed, fixed.rs:161-165 */
+EXPORT int32_t b32o_fixed_mul(int32_t a, int32_t b) {
+    int64_t r = ((int64_t)a * (int64_t)b) >> 12;
+    return (int32_t)r;
+}
+/* Fixed32::div_unr, fixed.rs:178-230 */
+EXPORT int32_t b32o_fixed_div_unr(int32_t self, int32_t divisor) {
+    unr_init();
+    if (divisor == 0) return 0;
+    int result_negative = (self < 0) != (divisor < 0);
+    uint64_t num = (uint64_t)(self < 0 ? (0u - (uint32_t)self) : (uint32_t)self);     /* unsigned_abs */
+    uint32_t den = divisor < 0 ? (0u - (uint32_t)divisor) : (uint32_t)divisor;
+    if (den == 0) return 0;
+    uint32_t z = (uint32_t)__builtin_clz(den);
+    uint64_t d_norm = (uint64_t)den << z;
+    uint64_t d16 = d_norm >> 16;
+    uint64_t ti = (d16 - 0x7FC0ull) >> 7;                                             /* wrapping_sub */
+    if (ti > 256) ti = 256;
+    uint64_t u_val = (uint64_t)g_unr[ti] + 0x101;
+    uint64_t nr1 = (0x2000080ull - d16 * u_val) >> 8;
+    uint64_t nr2 = (0x80ull + nr1 * u_val) >> 8;
+    uint64_t raw = num * nr2;
+    uint32_t shift = 36u - z;
+    uint64_t magnitude;
+    if (shift < 64) {
+        uint64_t rounding = shift > 0 ? (1ull << (shift - 1)) : 0;
+        magnitude = (raw + rounding) >> shift;
+    } else {
+        magnitude = 0;
+    }
+    int32_t clamped = (int32_t)(magnitude < (uint64_t)INT32_MAX ? magnitude : (uint64_t)INT32_MAX);
+    return result_negative ? -clamped : clamped;
+}
+
+typedef struct { int32_t x, y, z; } FixedVec3;
+/* FixedVec3::from_vec3, fixed.rs:291-297 */
+static inline FixedVec3 fv_from(const float v[3]) {
+    FixedVec3 r = { b32o_fixed_from_f32(v[0]), b32o_fixed_from_f32(v[1]), b32o_fixed_from_f32(v[2]) };
+    return r;
+}
+/* FixedVec3::dot, fixed.rs:311-313: x*ox + y*oy + z*oz with wrapping adds (fixed.rs:236-238) */
+static inline int32_t fv_dot(FixedVec3 a, FixedVec3 b) {
+    return wrap_add(wrap_add(b32o_fixed_mul(a.x, b.x), b32o_fixed_mul(a.y, b.y)), b32o_fixed_mul(a.z, b.z));
+}
+
+/* project_fixed, fixed.rs:424-441 = transform_to_camera_space :362-381 + project_to_screen :390-420 */
+EXPORT void b32o_project_fixed(const float world_pos[3], const float camera_pos[3],
+                               const float basis_x[3], const float basis_y[3], const float basis_z[3],
+                               uint32_t width, uint32_t height, int32_t* sx, int32_t* sy, float* depth) {
+    FixedVec3 wp = fv_from(world_pos), cp = fv_from(camera_pos);
+    FixedVec3 rel = { wrap_sub(wp.x, cp.x), wrap_sub(wp.y, cp.y), wrap_sub(wp.z, cp.z) };
+    FixedVec3 bx = fv_from(basis_x), by = fv_from(basis_y), bz = fv_from(basis_z);
+    FixedVec3 cam = { fv_dot(rel, bx), fv_dot(rel, by), fv_dot(rel, bz) };
+
+    int32_t distance = b32o_fixed_from_f32(5.0f);
+    int32_t scale = b32o_fixed_from_f32(4.0f);
+    uint32_t mn = width < height ? width : height;
+    int32_t viewport_scale = b32o_fixed_from_f32(((float)mn / 2.0f) * 0.75f);
+    int32_t half_w = fixed_from_int((int32_t)width / 2);
+    int32_t half_h = fixed_from_int((int32_t)height / 2);
+    int32_t denom = wrap_add(cam.z, distance);
+    /* i32::abs wraps for i32::MIN in release -> stays negative -> "< 256" is true */
+    int32_t adenom = denom < 0 ? wrap_neg(denom) : denom;
+    if (adenom < 256) {
+        *sx = half_w >> 12; *sy = half_h >> 12; *depth = fixed_to_f32(cam.z);
+        return;
+    }
+    int32_t proj_x = b32o_fixed_div_unr(b32o_fixed_mul(cam.x, scale), denom);
+    int32_t proj_y = b32o_fixed_div_unr(b32o_fixed_mul(cam.y, scale), denom);
+    int32_t screen_x = wrap_add(b32o_fixed_mul(proj_x, viewport_scale), half_w);
+    int32_t screen_y = wrap_add(b32o_fixed_mul(proj_y, viewport_scale), half_h);
+    *sx = screen_x >> 12; *sy = screen_y >> 12; *depth = fixed_to_f32(cam.z);
+}
+
+/* ------------------------------------------------------------------ math.rs */
+typedef struct { float x, y, z; } V3;
+static inline V3 v3(float x, float y, float z) { V3 r = { x, y, z }; return r; }
+static inline V3 v3p(const float p[3]) { V3 r = { p[0], p[1], p[2] }; return r; }
+/* Vec3::dot, math.rs:23-25: (x*ox + y*oy) + z*oz */
+static inline float v3dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline V3 v3sub(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }     /* math.rs:71-79 */
+static inline V3 v3add(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }     /* math.rs:60-69 */
+static inline V3 v3scale(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }      /* math.rs:51-57 */
+static inline float v3len(V3 a) { return sqrtf(v3dot(a, a)); }                          /* math.rs:35-37 */
+static inline V3 v3normalize(V3 a) {                                                    /* math.rs:39-49 */
+    float l = v3len(a);
+    if (l == 0.0f) return v3(0, 0, 0);
+    return v3(a.x / l, a.y / l, a.z / l);
+}
+/* perspective_transform, math.rs:103-109 */
+static inline V3 perspective_transform(V3 v, V3 cx, V3 cy, V3 cz) {
+    return v3(v3dot(v, cx), v3dot(v, cy), v3dot(v, cz));
+}
+/* project, math.rs:117-136 */
+static inline V3 project_float(V3 v, uint32_t width, uint32_t height) {
+    const float ud = 5.0f;
+    float us = ud - 1.0f;
+    uint32_t mn = width < height ? width : height;
+    float vs = ((float)mn / 2.0f) * 0.75f;
+    float denom = v.z + ud;
+    if (fabsf(denom) < 0.001f) return v3((float)width / 2.0f, (float)height / 2.0f, v.z);
+    return v3((v.x * us) / denom * vs + ((float)width / 2.0f),
+              (v.y * us) / denom * vs + ((float)height / 2.0f),
+              denom);
+}
+/* project_ortho, math.rs:140-148 */
+static inline V3 project_ortho(V3 v, float zoom, float cx, float cy, uint32_t width, uint32_t height) {
+    return v3((v.x - cx) * zoom + ((float)width / 2.0f),
+              -(v.y - cy) * zoom + ((float)height / 2.0f),
+              v.z);
+}
+
+/* ------------------------------------------------------------------ types.rs Color15 / Texture15 */
+static inline uint8_t c15_r5(uint16_t c) { return (uint8_t)((c >> 10) & 0x1F); }   /* types.rs:119-121 */
+static inline uint8_t c15_g5(uint16_t c) { return (uint8_t)((c >> 5) & 0x1F); }    /* types.rs:125-127 */
+static inline uint8_t c15_b5(uint16_t c) { return (uint8_t)(c & 0x1F); }           /* types.rs:131-133 */
+/* expand_5_to_8, render.rs:1161-1163 == Color15::r8, types.rs:137-141 */
+static inline uint8_t expand_5_to_8(uint8_t v5) { return (uint8_t)((v5 << 3) | (v5 >> 2)); }
+/* Color15::new_semi, types.rs:41-56 */
+static inline uint16_t c15_new_semi(uint8_t r, uint8_t g, uint8_t b, int semi) {
+    uint16_t c = (uint16_t)(((uint16_t)(r > 31 ? 31 : r) << 10) | ((uint16_t)(g > 31 ? 31 : g) << 5) | (uint16_t)(b > 31 ? 31 : b));
+    if (semi) c |= 0x8000;
+    return c;
+}
+/* Color15::to_rgba, types.rs:220-226 */
+EXPORT void b32o_color15_to_rgba(uint16_t c, uint8_t out[4]) {
+    if (c == 0) { out[0] = out[1] = out[2] = out[3] = 0; return; }
+    out[0] = expand_5_to_8(c15_r5(c)); out[1] = expand_5_to_8(c15_g5(c)); out[2] = expand_5_to_8(c15_b5(c)); out[3] = 255;
+}
+/* Texture15::sample, types.rs:671-681 */
+EXPORT uint16_t b32o_texture15_sample(const uint16_t* pixels, uint32_t width, uint32_t height, float u, float v) {
+    if (width == 0 || height == 0 || pixels == NULL) return 0;
+    float uw = rem_euclid1(u), vw = rem_euclid1(v);
+    uint64_t tx = f2usize_sat(uw * (float)width);  if (tx > width - 1) tx = width - 1;
+    uint64_t ty = f2usize_sat(vw * (float)height); if (ty > height - 1) ty = height - 1;
+    return pixels[ty * width + tx];
+}
+/* Clut::lookup, types.rs:390-397 + IndexedAtlas::to_texture15, modeler/mesh_editor.rs:669-682 */
+EXPORT void b32o_expand_indexed(const uint8_t* indices, uint32_t n, const uint16_t* clut, uint32_t clut_len, uint16_t* out) {
+    for (uint32_t i = 0; i < n; ++i) out[i] = indices[i] < clut_len ? clut[indices[i]] : 0;
+}
+
+/* ------------------------------------------------------------------ render.rs colour helpers */
+/* blend_rgb555, render.rs:1093-1145 */
+EXPORT void b32o_blend_rgb555(uint8_t fr, uint8_t fg, uint8_t fb, uint8_t br, uint8_t bg, uint8_t bb, uint32_t mode, uint8_t out[3]) {
+    uint8_t f5[3] = { (uint8_t)(fr >> 3), (uint8_t)(fg >> 3), (uint8_t)(fb >> 3) };
+    uint8_t b5[3] = { (uint8_t)(br >> 3), (uint8_t)(bg >> 3), (uint8_t)(bb >> 3) };
+    for (int i = 0; i < 3; ++i) {
+        uint8_t r5;
+        switch (mode) {
+            default:
+            case B32_BLEND_OPAQUE:      r5 = f5[i]; break;
+            case B32_BLEND_AVERAGE:     { uint16_t s = (uint16_t)((b5[i] + f5[i]) / 2); r5 = (uint8_t)(s > 31 ? 31 : s); } break;
+            case B32_BLEND_ADD:         { uint16_t s = (uint16_t)(b5[i] + f5[i]); r5 = (uint8_t)(s > 31 ? 31 : s); } break;
+            case B32_BLEND_SUBTRACT:    { int16_t s = (int16_t)(b5[i] - f5[i]); r5 = (uint8_t)(s < 0 ? 0 : s); } break;
+            case B32_BLEND_ADD_QUARTER: { uint16_t s = (uint16_t)(b5[i] + f5[i] / 4); r5 = (uint8_t)(s > 31 ? 31 : s); } break;
+            case B32_BLEND_ERASE:       r5 = b5[i]; break;
+        }
+        out[i] = (uint8_t)(r5 << 3);
+    }
+}
+/* PS1_DITHER_MATRIX, render.rs:1150-1155 */
+static const int8_t PS1_DITHER_MATRIX[4][4] = {
+    { -4,  0, -3,  1 },
+    {  2, -2,  3, -1 },
+    { -3,  1, -4,  0 },
+    {  3, -1,  2, -2 },
+};
+EXPORT int32_t b32o_dither_offset(uint32_t x, uint32_t y) { return PS1_DITHER_MATRIX[y & 3][x & 3]; }
+/* dither_and_quantize, render.rs:1173-1182 */
+EXPORT void b32o_dither_and_quantize(uint8_t r8, uint8_t g8, uint8_t b8, uint32_t x, uint32_t y, uint8_t out5[3]) {
+    int32_t off = PS1_DITHER_MATRIX[y & 3][x & 3];
+    int32_t c[3] = { r8, g8, b8 };
+    for (int i = 0; i < 3; ++i) {
+        int32_t q = (c[i] + off) >> 3;
+        out5[i] = (uint8_t)(q < 0 ? 0 : (q > 31 ? 31 : q));
+    }
+}
+
+/* ------------------------------------------------------------------ lighting, render.rs:1013-1071 */
+typedef struct { float r, g, b; } Shade;
+static int shade_multi_light_color(V3 normal, V3 world_pos, const B32Light* lights, uint32_t n_lights, float ambient, Shade* out) {
+    float tr = ambient, tg = ambient, tb = ambient;
+    for (uint32_t i = 0; i < n_lights; ++i) {
+        const B32Light* l = &lights[i];
+        if (!l->enabled) continue;
+        float contribution;
+        if (l->type == B32_LIGHT_DIRECTIONAL) {
+            V3 neg_dir = v3scale(v3p(l->direction), -1.0f);
+            float n_dot_l = rmax(v3dot(normal, neg_dir), 0.0f);
+            contribution = n_dot_l * l->intensity;
+        } else if (l->type == B32_LIGHT_POINT) {
+            V3 to_light = v3sub(v3p(l->position), world_pos);
+            float dist = v3len(to_light);
+            if (dist > l->radius || dist < 0.001f) {
+                contribution = 0.0f;
+            } else {
+                float attenuation = 1.0f - (dist / l->radius);
+                float n_dot_l = rmax(v3dot(normal, v3normalize(to_light)), 0.0f);
+                contribution = n_dot_l * l->intensity * attenuation * attenuation;
+            }
+        } else {
+            return B32_E_UNSUPPORTED; /* Spot uses acos (render.rs:1047): not bit-portable */
+        }
+        float lr = (float)l->r / 255.0f, lg = (float)l->g / 255.0f, lb = (float)l->b / 255.0f;
+        tr += contribution * lr; tg += contribution * lg; tb += contribution * lb;
+    }
+    out->r = rmin(tr, 1.0f); out->g = rmin(tg, 1.0f); out->b = rmin(tb, 1.0f);
+    return B32_OK;
+}
+
+/* ------------------------------------------------------------------ fog, render.rs:2266-2293 */
+static inline float calculate_fog_factor(float z, float fog_start, float fog_falloff) {
+    if (z <= fog_start) return 0.0f;
+    if (fog_falloff <= 0.0f) return 1.0f;
+    return rmin((z - fog_start) / fog_falloff, 1.0f);
+}
+typedef struct { uint8_t r, g, b, blend; } Col;
+static inline Col apply_fog_to_color(Col c, Col fog, float f) {
+    if (f <= 0.0f) return c;
+    if (f >= 1.0f) return fog;
+    float inv = 1.0f - f;
+    Col o;
+    o.r = f2u8_sat((float)c.r * inv + (float)fog.r * f);
+    o.g = f2u8_sat((float)c.g * inv + (float)fog.g * f);
+    o.b = f2u8_sat((float)c.b * inv + (float)fog.b * f);
+    o.blend = B32_BLEND_OPAQUE; /* Color::new, types.rs:771-773 */
+    return o;
+}
+static inline int col_eq(Col a, Col b) { return a.r == b.r && a.g == b.g && a.b == b.b && a.blend == b.blend; }
+
+/* ------------------------------------------------------------------ Surface, render.rs:975-1000 */
+typedef struct {
+    V3 v1, v2, v3;          /* screen */
+    V3 w1, w2, w3;          /* world pos */
+    V3 wn1, wn2, wn3;       /* world normals */
+    float uv1[2], uv2[2], uv3[2];
+    Col vc1, vc2, vc3;
+    uint32_t face_idx;
+    uint8_t black_transparent, has_transparency, blend_mode, editor_alpha;
+} Surface;
+
+typedef struct {
+    uint8_t* pixels;
+    float*   zbuffer;       /* may be NULL when !use_zbuffer */
+    uint32_t width, height;
+    uint64_t fragments;
+} FB;
+
+/* Framebuffer::set_pixel_15, render.rs:445-454 */
+static inline void set_pixel_15(FB* fb, uint32_t x, uint32_t y, uint16_t color) {
+    if (x < fb->width && y < fb->height) {
+        size_t idx = ((size_t)y * fb->width + x) * 4;
+        b32o_color15_to_rgba(color, &fb->pixels[idx]);
+    }
+}
+/* Framebuffer::set_pixel_blended_15, render.rs:479-502 */
+static inline void set_pixel_blended_15(FB* fb, uint32_t x, uint32_t y, uint16_t color, uint32_t mode) {
+    if (x < fb->width && y < fb->height) {
+        size_t idx = ((size_t)y * fb->width + x) * 4;
+        uint8_t rgb[3];
+        uint8_t r8 = expand_5_to_8(c15_r5(color)), g8 = expand_5_to_8(c15_g5(color)), b8 = expand_5_to_8(c15_b5(color));
+        if (color & 0x8000) b32o_blend_rgb555(r8, g8, b8, fb->pixels[idx], fb->pixels[idx + 1], fb->pixels[idx + 2], mode, rgb);
+        else { rgb[0] = r8; rgb[1] = g8; rgb[2] = b8; }
+        fb->pixels[idx] = rgb[0]; fb->pixels[idx + 1] = rgb[1]; fb->pixels[idx + 2] = rgb[2]; fb->pixels[idx + 3] = 255;
+    }
+}
+/* Framebuffer::set_pixel_xray_15, render.rs:507-526 */
+static inline void set_pixel_xray_15(FB* fb, uint32_t x, uint32_t y, uint16_t color) {
+    if (x < fb->width && y < fb->height) {
+        size_t idx = ((size_t)y * fb->width + x) * 4;
+        uint8_t c8[3] = { expand_5_to_8(c15_r5(color)), expand_5_to_8(c15_g5(color)), expand_5_to_8(c15_b5(color)) };
+        for (int i = 0; i < 3; ++i) fb->pixels[idx + i] = (uint8_t)(((uint16_t)c8[i] + (uint16_t)fb->pixels[idx + i]) / 2);
+        fb->pixels[idx + 3] = 255;
+    }
+}
+/* Framebuffer::set_pixel_with_editor_alpha_15, render.rs:567-591 (alpha==0 / bounds checked by caller path too) */
+static inline void editor_alpha_store(FB* fb, size_t idx, uint16_t color, uint32_t mode, uint8_t editor_alpha) {
+    uint8_t back[3] = { fb->pixels[idx], fb->pixels[idx + 1], fb->pixels[idx + 2] };
+    uint8_t ps1[3];
+    uint8_t r8 = expand_5_to_8(c15_r5(color)), g8 = expand_5_to_8(c15_g5(color)), b8 = expand_5_to_8(c15_b5(color));
+    if ((color & 0x8000) && mode != B32_BLEND_OPAQUE) b32o_blend_rgb555(r8, g8, b8, back[0], back[1], back[2], mode, ps1);
+    else { ps1[0] = r8; ps1[1] = g8; ps1[2] = b8; }
+    uint16_t a = editor_alpha, inv_a = (uint16_t)(255 - a);
+    for (int i = 0; i < 3; ++i) fb->pixels[idx + i] = (uint8_t)((uint16_t)((uint16_t)ps1[i] * a + (uint16_t)back[i] * inv_a) / 255);
+    fb->pixels[idx + 3] = 255;
+}
+
+/* rasterize_triangle_15, render.rs:1440-1714 */
+static int rasterize_triangle_15(FB* fb, const Surface* s, const B32Texture15* texture, uint32_t face_blend_mode,
+                                 int black_transparent, const B32Settings* st, int skip_z_write) {
+    uint32_t blend_mode = texture ? texture->blend_mode : face_blend_mode;                      /* :1450-1452 */
+
+    /* bounding box :1455-1458 */
+    uint64_t min_x = f2usize_sat(rmax(rmin(rmin(s->v1.x, s->v2.x), s->v3.x), 0.0f));
+    uint64_t max_x = f2usize_sat(rmin(rmax(rmax(s->v1.x, s->v2.x), s->v3.x) + 1.0f, (float)fb->width));
+    uint64_t min_y = f2usize_sat(rmax(rmin(rmin(s->v1.y, s->v2.y), s->v3.y), 0.0f));
+    uint64_t max_y = f2usize_sat(rmin(rmax(rmax(s->v1.y, s->v2.y), s->v3.y) + 1.0f, (float)fb->height));
+    if (min_x >= max_x || min_y >= max_y) return B32_OK;                                         /* :1461-1463 */
+
+    Shade flat_shade = { 1.0f, 1.0f, 1.0f };                                                     /* :1466-1472 */
+    if (st->shading == B32_SHADE_FLAT) {
+        V3 center_pos = v3scale(v3add(v3add(s->w1, s->w2), s->w3), 1.0f / 3.0f);
+        V3 world_normal = v3normalize(v3scale(v3add(v3add(s->wn1, s->wn2), s->wn3), 1.0f / 3.0f));
+        int rc = shade_multi_light_color(world_normal, center_pos, st->lights, st->n_lights, st->ambient, &flat_shade);
+        if (rc) return rc;
+    }
+    Shade gs1 = { 0, 0, 0 }, gs2 = { 0, 0, 0 }, gs3 = { 0, 0, 0 };                               /* :1475-1483 */
+    if (st->shading == B32_SHADE_GOURAUD) {
+        int rc = shade_multi_light_color(s->wn1, s->w1, st->lights, st->n_lights, st->ambient, &gs1);
+        if (!rc) rc = shade_multi_light_color(s->wn2, s->w2, st->lights, st->n_lights, st->ambient, &gs2);
+        if (!rc) rc = shade_multi_light_color(s->wn3, s->w3, st->lights, st->n_lights, st->ambient, &gs3);
+        if (rc) return rc;
+    }
+    int needs_dither = st->dithering && (st->shading == B32_SHADE_GOURAUD || texture != NULL       /* :1487-1492 */
+                                         || !col_eq(s->vc1, s->vc2) || !col_eq(s->vc2, s->vc3));
+
+    V3 v1 = s->v1, v2 = s->v2, v3_ = s->v3;
+    float area = (v2.y - v3_.y) * (v1.x - v3_.x) + (v3_.x - v2.x) * (v1.y - v3_.y);              /* :1500 */
+    if (fabsf(area) < 0.00001f) return B32_OK;                                                   /* :1501-1503 */
+    float inv_area = 1.0f / area;
+    float a0 = v2.y - v3_.y, b0 = v3_.x - v2.x, a1 = v3_.y - v1.y, b1 = v1.x - v3_.x;            /* :1507-1510 */
+    float start_x = (float)min_x, start_y = (float)min_y;
+    float w0_row = a0 * (start_x - v3_.x) + b0 * (start_y - v3_.y);                              /* :1517 */
+    float w1_row = a1 * (start_x - v3_.x) + b1 * (start_y - v3_.y);                              /* :1518 */
+
+    for (uint64_t y = min_y; y < max_y; ++y) {                                                   /* :1530 */
+        float w0 = w0_row, w1 = w1_row;
+        for (uint64_t x = min_x; x < max_x; ++x) {
+            float bc_x = w0 * inv_area;
+            float bc_y = w1 * inv_area;
+            float bc_z = 1.0f - bc_x - bc_y;
+            const float ERR = -0.0001f;
+            if (bc_x >= ERR && bc_y >= ERR && bc_z >= ERR) {                                      /* :1542 */
+                float inv_z1 = 1.0f / v1.z, inv_z2 = 1.0f / v2.z, inv_z3 = 1.0f / v3_.z;         /* :1546-1550 */
+                float inv_z_interp = bc_x * inv_z1 + bc_y * inv_z2 + bc_z * inv_z3;
+                float z = 1.0f / inv_z_interp;
+                if (st->use_zbuffer && !st->xray_mode) {                                          /* :1553-1560 */
+                    size_t idx = (size_t)y * fb->width + x;
+                    if (z >= fb->zbuffer[idx]) { w0 += a0; w1 += a1; continue; }
+                }
+                float u, v;
+                if (st->affine_textures) {                                                        /* :1563-1567 */
+                    u = bc_x * s->uv1[0] + bc_y * s->uv2[0] + bc_z * s->uv3[0];
+                    v = bc_x * s->uv1[1] + bc_y * s->uv2[1] + bc_z * s->uv3[1];
+                } else {                                                                          /* :1568-1579 */
+                    float u_over_z = bc_x * s->uv1[0] * inv_z1 + bc_y * s->uv2[0] * inv_z2 + bc_z * s->uv3[0] * inv_z3;
+                    float v_over_z = bc_x * s->uv1[1] * inv_z1 + bc_y * s->uv2[1] * inv_z2 + bc_z * s->uv3[1] * inv_z3;
+                    u = u_over_z / inv_z_interp;
+                    v = v_over_z / inv_z_interp;
+                }
+                uint16_t color = texture ? b32o_texture15_sample(texture->pixels, texture->width, texture->height, u, 1.0f - v)
+                                         : (uint16_t)0x7FFF;                                      /* :1582-1586 */
+                int is_black = c15_r5(color) == 0 && c15_g5(color) == 0 && c15_b5(color) == 0;    /* :1591 */
+                if (color == 0) {                                                                 /* :1592-1602 */
+                    if (is_black && !black_transparent) color = 0x8000;
+                    else { w0 += a0; w1 += a1; continue; }
+                } else if (black_transparent && is_black) {                                       /* :1603-1608 */
+                    w0 += a0; w1 += a1; continue;
+                }
+                uint8_t tex_r8 = expand_5_to_8(c15_r5(color)), tex_g8 = expand_5_to_8(c15_g5(color)), tex_b8 = expand_5_to_8(c15_b5(color));
+                uint8_t vertex_r = f2u8_sat(bc_x * (float)s->vc1.r + bc_y * (float)s->vc2.r + bc_z * (float)s->vc3.r); /* :1618-1620 */
+                uint8_t vertex_g = f2u8_sat(bc_x * (float)s->vc1.g + bc_y * (float)s->vc2.g + bc_z * (float)s->vc3.g);
+                uint8_t vertex_b = f2u8_sat(bc_x * (float)s->vc1.b + bc_y * (float)s->vc2.b + bc_z * (float)s->vc3.b);
+                uint32_t m;
+                m = ((uint32_t)tex_r8 * vertex_r) / 128; uint8_t mod_r8 = (uint8_t)(m > 255 ? 255 : m); /* :1624-1626 */
+                m = ((uint32_t)tex_g8 * vertex_g) / 128; uint8_t mod_g8 = (uint8_t)(m > 255 ? 255 : m);
+                m = ((uint32_t)tex_b8 * vertex_b) / 128; uint8_t mod_b8 = (uint8_t)(m > 255 ? 255 : m);
+                float shade_r, shade_g, shade_b;                                                  /* :1629-1640 */
+                if (st->shading == B32_SHADE_NONE) { shade_r = shade_g = shade_b = 1.0f; }
+                else if (st->shading == B32_SHADE_FLAT) { shade_r = flat_shade.r; shade_g = flat_shade.g; shade_b = flat_shade.b; }
+                else {
+                    shade_r = bc_x * gs1.r + bc_y * gs2.r + bc_z * gs3.r;
+                    shade_g = bc_x * gs1.g + bc_y * gs2.g + bc_z * gs3.g;
+                    shade_b = bc_x * gs1.b + bc_y * gs2.b + bc_z * gs3.b;
+                }
+                uint8_t shaded_r8 = f2u8_sat(rmin((float)mod_r8 * rclamp(shade_r, 0.0f, 2.0f), 255.0f)); /* :1643-1645 */
+                uint8_t shaded_g8 = f2u8_sat(rmin((float)mod_g8 * rclamp(shade_g, 0.0f, 2.0f), 255.0f));
+                uint8_t shaded_b8 = f2u8_sat(rmin((float)mod_b8 * rclamp(shade_b, 0.0f, 2.0f), 255.0f));
+                uint8_t q5[3];
+                if (needs_dither) b32o_dither_and_quantize(shaded_r8, shaded_g8, shaded_b8, (uint32_t)x, (uint32_t)y, q5); /* :1649-1654 */
+                else { q5[0] = shaded_r8 >> 3; q5[1] = shaded_g8 >> 3; q5[2] = shaded_b8 >> 3; }
+                int is_all_black = q5[0] == 0 && q5[1] == 0 && q5[2] == 0;                        /* :1659-1661 */
+                int semi = (color & 0x8000) != 0 || is_all_black;
+                uint16_t out = c15_new_semi(q5[0], q5[1], q5[2], semi);
+
+                uint8_t editor_alpha = s->editor_alpha;                                           /* :1664-1669 */
+                if (editor_alpha == 0) { w0 += a0; w1 += a1; continue; }
+                size_t didx = (size_t)y * fb->width + x;
+                if (st->xray_mode) {                                                              /* :1671-1673 */
+                    set_pixel_xray_15(fb, (uint32_t)x, (uint32_t)y, out); fb->fragments++;
+                } else if (editor_alpha < 255) {                                                  /* :1674-1680 */
+                    if (st->use_zbuffer) {                                                        /* render.rs:595-628 */
+                        if (!(z >= fb->zbuffer[didx])) {
+                            if (!skip_z_write) fb->zbuffer[didx] = z;
+                            editor_alpha_store(fb, didx * 4, out, blend_mode, editor_alpha); fb->fragments++;
+                        }
+                    } else {
+                        editor_alpha_store(fb, didx * 4, out, blend_mode, editor_alpha); fb->fragments++;
+                    }
+                } else if (st->use_zbuffer) {                                                     /* :1681-1694 */
+                    if (z < fb->zbuffer[didx]) {
+                        if (!skip_z_write) fb->zbuffer[didx] = z;
+                        if ((out & 0x8000) && blend_mode != B32_BLEND_OPAQUE) set_pixel_blended_15(fb, (uint32_t)x, (uint32_t)y, out, blend_mode);
+                        else set_pixel_15(fb, (uint32_t)x, (uint32_t)y, out);
+                        fb->fragments++;
+                    }
+                } else {                                                                          /* :1695-1702 painter's */
+                    if ((out & 0x8000) && blend_mode != B32_BLEND_OPAQUE) set_pixel_blended_15(fb, (uint32_t)x, (uint32_t)y, out, blend_mode);
+                    else set_pixel_15(fb, (uint32_t)x, (uint32_t)y, out);
+                    fb->fragments++;
+                }
+            }
+            w0 += a0; w1 += a1;                                                                   /* :1706-1707 */
+        }
+        w0_row += b0; w1_row += b1;                                                               /* :1711-1712 */
+    }
+    return B32_OK;
+}
+
+/* ------------------------------------------------------------------ stable descending sort (slice::sort_by, render.rs:2527-2542) */
+static inline float center_z(const Surface* s) { return (s->v1.z + s->v2.z + s->v3.z) / 3.0f; }
+static void merge_sort_desc(uint32_t* idx, uint32_t* tmp, const float* key, uint32_t n) {
+    for (uint32_t width = 1; width < n; width *= 2) {
+        for (uint32_t lo = 0; lo < n; lo += 2 * width) {
+            uint32_t mid = lo + width < n ? lo + width : n;
+            uint32_t hi = lo + 2 * width < n ? lo + 2 * width : n;
+            uint32_t i = lo, j = mid, k = lo;
+            while (i < mid && j < hi) {
+                /* comparator(a,b) = b_key.partial_cmp(a_key): take right only when it is strictly "less", i.e. key[right] > key[left] */
+                if (key[idx[j]] > key[idx[i]]) tmp[k++] = idx[j++];
+                else tmp[k++] = idx[i++];
+            }
+            while (i < mid) tmp[k++] = idx[i++];
+            while (j < hi) tmp[k++] = idx[j++];
+        }
+        memcpy(idx, tmp, (size_t)n * sizeof(uint32_t));
+    }
+}
+
+/* Optional stage dump for parity tests (all arrays caller-allocated or NULL). */
+typedef struct B32OracleDump {
+    int32_t*  sx;          /* nv: screen x as i32 (fixed-point path) / truncated float otherwise */
+    int32_t*  sy;          /* nv */
+    float*    sz;          /* nv: screen z (render.rs:2345) */
+    uint32_t* draw_order;  /* nf capacity: face_idx in draw order */
+    uint32_t  n_drawn;
+    uint32_t  n_opaque;
+} B32OracleDump;
+
+/* Framebuffer::clear, render.rs:36-45 + Color::to_bytes types.rs:829-832 */
+EXPORT void b32o_fb_clear(uint8_t* pixels, float* zbuffer, uint32_t width, uint32_t height, uint8_t r, uint8_t g, uint8_t b, uint8_t blend) {
+    uint8_t a = blend == B32_BLEND_ERASE ? 0 : 255;
+    for (size_t i = 0; i < (size_t)width * height; ++i) {
+        pixels[i * 4] = r; pixels[i * 4 + 1] = g; pixels[i * 4 + 2] = b; pixels[i * 4 + 3] = a;
+        if (zbuffer) zbuffer[i] = 3.40282347e+38f;
+    }
+}
+
+/* render_mesh_15, render.rs:2302-2638 (wireframe phases :2574-2635 are out of scope -> B32_E_UNSUPPORTED) */
+EXPORT int b32o_render_mesh_15(uint8_t* fb_pixels, float* fb_zbuffer, uint32_t width, uint32_t height,
+                               const B32Vertex* vertices, uint32_t nv,
+                               const B32Face* faces, uint32_t nf,
+                               const B32Texture15* textures, uint32_t nt,
+                               const B32Camera* camera, const B32Settings* st, const B32Fog* fog,
+                               B32Timings* timings, B32OracleDump* dump) {
+    if (!fb_pixels || !camera || !st || (nv && !vertices) || (nf && !faces) || (nt && !textures)) return B32_E_ARG;
+    if (st->use_zbuffer && !fb_zbuffer) return B32_E_ARG;
+    if ((st->backface_cull && st->backface_wireframe) || st->wireframe_overlay) return B32_E_UNSUPPORTED;
+    if (st->shading != B32_SHADE_NONE)
+        for (uint32_t i = 0; i < st->n_lights; ++i)
+            if (st->lights[i].enabled && st->lights[i].type > B32_LIGHT_POINT) return B32_E_UNSUPPORTED;
+    FB fb = { fb_pixels, fb_zbuffer, width, height, 0 };
+    V3 cpos = v3p(camera->position), bx = v3p(camera->basis_x), by = v3p(camera->basis_y), bz = v3p(camera->basis_z);
+
+    /* TRANSFORM, :2313-2362 */
+    V3* cam_space = (V3*)malloc(sizeof(V3) * (nv ? nv : 1));
+    V3* projected = (V3*)malloc(sizeof(V3) * (nv ? nv : 1));
+    for (uint32_t i = 0; i < nv; ++i) {
+        V3 pos = v3p(vertices[i].pos);
+        V3 screen, cam_pos;
+        if (st->has_ortho) {                                                                      /* :2323-2328 */
+            cam_pos = perspective_transform(v3sub(pos, cpos), bx, by, bz);
+            screen = project_ortho(cam_pos, st->ortho_zoom, st->ortho_center_x, st->ortho_center_y, width, height);
+        } else if (st->use_fixed_point) {                                                         /* :2329-2345 */
+            int32_t sx, sy; float fd;
+            b32o_project_fixed(vertices[i].pos, camera->position, camera->basis_x, camera->basis_y, camera->basis_z, width, height, &sx, &sy, &fd);
+            cam_pos = perspective_transform(v3sub(pos, cpos), bx, by, bz);
+            screen = v3((float)sx, (float)sy, cam_pos.z + 5.0f);
+            if (dump && dump->sx) { dump->sx[i] = sx; dump->sy[i] = sy; }
+        } else {                                                                                  /* :2346-2352 */
+            cam_pos = perspective_transform(v3sub(pos, cpos), bx, by, bz);
+            screen = project_float(cam_pos, width, height);
+        }
+        if (dump && dump->sx && !(st->use_fixed_point && !st->has_ortho)) { dump->sx[i] = f2i32_sat(screen.x); dump->sy[i] = f2i32_sat(screen.y); }
+        if (dump && dump->sz) dump->sz[i] = screen.z;
+        cam_space[i] = cam_pos; projected[i] = screen;
+        /* cam_space_normals (:2357-2359) feed only Surface.vn*, which rasterize_triangle_15 never reads. */
+    }
+
+    /* CULL / SETUP, :2364-2516 */
+    Surface* surfaces = (Surface*)malloc(sizeof(Surface) * (nf ? nf : 1));
+    uint32_t ns = 0;
+    int rc = B32_OK;
+    for (uint32_t fi = 0; fi < nf; ++fi) {
+        const B32Face* f = &faces[fi];
+        if (f->v[0] >= nv || f->v[1] >= nv || f->v[2] >= nv) { rc = B32_E_INDEX; goto done; }    /* index panic :2375-2377 */
+        V3 cv1 = cam_space[f->v[0]], cv2 = cam_space[f->v[1]], cv3 = cam_space[f->v[2]];
+        if (!st->has_ortho) {                                                                     /* :2381-2385 NEAR_PLANE math.rs:155 */
+            if (cv1.z <= 0.1f || cv2.z <= 0.1f || cv3.z <= 0.1f) continue;
+        }
+        V3 v1 = projected[f->v[0]], v2 = projected[f->v[1]], v3_ = projected[f->v[2]];
+        float signed_area = (v2.x - v1.x) * (v3_.y - v1.y) - (v3_.x - v1.x) * (v2.y - v1.y);     /* :2393 */
+        int is_backface = signed_area <= 0.0f;
+        /* geometric normal (:2397-2399) only feeds Surface.normal, never read by the fill */
+        int has_transparency;                                                                     /* :2403-2415 */
+        {
+            int have_tex = f->texture_id != B32_NO_TEXTURE && f->texture_id < nt;
+            uint32_t tex_blend = have_tex ? textures[f->texture_id].blend_mode : B32_BLEND_OPAQUE;
+            if (have_tex && tex_blend != B32_BLEND_OPAQUE) has_transparency = 1;
+            else if (f->blend_mode != B32_BLEND_OPAQUE) has_transparency = 1;
+            else has_transparency = f->editor_alpha < 255;
+        }
+        Col c1 = { vertices[f->v[0]].r, vertices[f->v[0]].g, vertices[f->v[0]].b, vertices[f->v[0]].blend };
+        Col c2 = { vertices[f->v[1]].r, vertices[f->v[1]].g, vertices[f->v[1]].b, vertices[f->v[1]].blend };
+        Col c3 = { vertices[f->v[2]].r, vertices[f->v[2]].g, vertices[f->v[2]].b, vertices[f->v[2]].blend };
+        if (fog) {                                                                                /* :2419-2442 */
+            if (cv1.z > fog->cull_distance && cv2.z > fog->cull_distance && cv3.z > fog->cull_distance) continue;
+            Col fc = { fog->r, fog->g, fog->b, fog->blend };
+            c1 = apply_fog_to_color(c1, fc, calculate_fog_factor(cv1.z, fog->start, fog->falloff));
+            c2 = apply_fog_to_color(c2, fc, calculate_fog_factor(cv2.z, fog->start, fog->falloff));
+            c3 = apply_fog_to_color(c3, fc, calculate_fog_factor(cv3.z, fog->start, fog->falloff));
+        }
+        Surface s;
+        memset(&s, 0, sizeof s);
+        s.face_idx = fi; s.black_transparent = f->black_transparent; s.has_transparency = (uint8_t)has_transparency;
+        s.blend_mode = f->blend_mode; s.editor_alpha = f->editor_alpha;
+        const B32Vertex *A = &vertices[f->v[0]], *B = &vertices[f->v[1]], *C = &vertices[f->v[2]];
+        if (is_backface) {                                                                        /* :2445-2479 */
+            if (!(!st->backface_cull || st->xray_mode)) continue;
+            s.v1 = v1; s.v2 = v3_; s.v3 = v2;
+            s.w1 = v3p(A->pos); s.w2 = v3p(C->pos); s.w3 = v3p(B->pos);
+            s.wn1 = v3scale(v3p(A->normal), -1.0f); s.wn2 = v3scale(v3p(C->normal), -1.0f); s.wn3 = v3scale(v3p(B->normal), -1.0f);
+            memcpy(s.uv1, A->uv, 8); memcpy(s.uv2, C->uv, 8); memcpy(s.uv3, B->uv, 8);
+            s.vc1 = c1; s.vc2 = c3; s.vc3 = c2;
+        } else {                                                                                  /* :2481-2507 */
+            s.v1 = v1; s.v2 = v2; s.v3 = v3_;
+            s.w1 = v3p(A->pos); s.w2 = v3p(B->pos); s.w3 = v3p(C->pos);
+            s.wn1 = v3p(A->normal); s.wn2 = v3p(B->normal); s.wn3 = v3p(C->normal);
+            memcpy(s.uv1, A->uv, 8); memcpy(s.uv2, B->uv, 8); memcpy(s.uv3, C->uv, 8);
+            s.vc1 = c1; s.vc2 = c2; s.vc3 = c3;
+        }
+        surfaces[ns++] = s;
+    }
+
+    /* SORT, :2518-2545 */
+    {
+        uint32_t* order = (uint32_t*)malloc(sizeof(uint32_t) * (ns ? ns : 1));
+        uint32_t* tmp = (uint32_t*)malloc(sizeof(uint32_t) * (ns ? ns : 1));
+        float* key = (float*)malloc(sizeof(float) * (ns ? ns : 1));
+        uint32_t n_op = 0, n_tr = 0;
+        for (uint32_t i = 0; i < ns; ++i) { key[i] = center_z(&surfaces[i]); if (!surfaces[i].has_transparency) order[n_op++] = i; }
+        for (uint32_t i = 0; i < ns; ++i) if (surfaces[i].has_transparency) order[n_op + n_tr++] = i;
+        /* partial_cmp().unwrap() panics on NaN as soon as a comparison sees one (any list with >= 2 elements) */
+        int nan_tr = 0, nan_op = 0;
+        for (uint32_t i = 0; i < n_op; ++i) if (key[order[i]] != key[order[i]]) nan_op = 1;
+        for (uint32_t i = n_op; i < ns; ++i) if (key[order[i]] != key[order[i]]) nan_tr = 1;
+        if ((nan_tr && n_tr >= 2) || (!st->use_zbuffer && nan_op && n_op >= 2)) rc = B32_E_NAN_KEY;
+        if (!rc) {
+            merge_sort_desc(order + n_op, tmp, key, n_tr);                                        /* :2527-2532 */
+            if (!st->use_zbuffer) merge_sort_desc(order, tmp, key, n_op);                         /* :2535-2542 */
+            if (timings) timings->triangles_drawn = ns;
+            if (dump) { dump->n_drawn = ns; dump->n_opaque = n_op; if (dump->draw_order) for (uint32_t i = 0; i < ns; ++i) dump->draw_order[i] = surfaces[order[i]].face_idx; }
+            /* DRAW, :2547-2572 */
+            if (!st->wireframe_overlay) {
+                for (uint32_t i = 0; i < ns && !rc; ++i) {
+                    const Surface* s = &surfaces[order[i]];
+                    uint32_t tid = faces[s->face_idx].texture_id;
+                    const B32Texture15* tex = (tid != B32_NO_TEXTURE && tid < nt) ? &textures[tid] : NULL;  /* textures.get(id) :2554-2556 */
+                    rc = rasterize_triangle_15(&fb, s, tex, s->blend_mode, s->black_transparent, st, i >= n_op);
+                }
+            }
+        }
+        free(order); free(tmp); free(key);
+    }
+    if (timings) timings->fragments = fb.fragments;
+done:
+    free(surfaces); free(cam_space); free(projected);
+    return rc;
+}
+
+/* Reference unit-test helpers (math.rs:779-807) exposed so tests can replay them through this file. */
+EXPORT float b32o_vec3_dot(const float a[3], const float b[3]) { return v3dot(v3p(a), v3p(b)); }
+EXPORT void b32o_vec3_cross(const float a[3], const float b[3], float out[3]) {   /* math.rs:27-33 */
+    out[0] = a[1] * b[2] - a[2] * b[1]; out[1] = a[2] * b[0] - a[0] * b[2]; out[2] = a[0] * b[1] - a[1] * b[0];
+}
+EXPORT float b32o_fixed_to_f32(int32_t v) { return fixed_to_f32(v); }

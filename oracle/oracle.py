@@ -1,0 +1,121 @@
+"""ctypes wrapper of the CPU oracle (oracle/b32_oracle.c).
+
+TEST INFRASTRUCTURE: imported only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+import bonnie32_amd as b32
+from bonnie32_amd import abi, types as T
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_build", "libb32oracle.so")
+_lib = None
+
+
+class B32OracleDump(C.Structure):
+    _fields_ = [("sx", C.c_void_p), ("sy", C.c_void_p), ("sz", C.c_void_p), ("draw_order", C.c_void_p),
+                ("n_drawn", C.c_uint32), ("n_opaque", C.c_uint32)]
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "b32_oracle.c")
+    hdr = os.path.join(_HERE, "..", "include", "b32raster.h")
+    if (force or not os.path.exists(LIB_PATH)
+            or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(hdr))):
+        subprocess.run(["make", "-C", _HERE], check=True, capture_output=True)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(LIB_PATH)
+        P = C.c_void_p
+        L.b32o_unr_table.restype = C.c_uint8; L.b32o_unr_table.argtypes = [C.c_uint32]
+        L.b32o_fixed_from_f32.restype = C.c_int32; L.b32o_fixed_from_f32.argtypes = [C.c_float]
+        L.b32o_fixed_mul.restype = C.c_int32; L.b32o_fixed_mul.argtypes = [C.c_int32, C.c_int32]
+        L.b32o_fixed_div_unr.restype = C.c_int32; L.b32o_fixed_div_unr.argtypes = [C.c_int32, C.c_int32]
+        L.b32o_fixed_to_f32.restype = C.c_float; L.b32o_fixed_to_f32.argtypes = [C.c_int32]
+        L.b32o_project_fixed.restype = None
+        L.b32o_project_fixed.argtypes = [P, P, P, P, P, C.c_uint32, C.c_uint32, P, P, P]
+        L.b32o_color15_to_rgba.restype = None; L.b32o_color15_to_rgba.argtypes = [C.c_uint16, P]
+        L.b32o_texture15_sample.restype = C.c_uint16
+        L.b32o_texture15_sample.argtypes = [P, C.c_uint32, C.c_uint32, C.c_float, C.c_float]
+        L.b32o_expand_indexed.restype = None; L.b32o_expand_indexed.argtypes = [P, C.c_uint32, P, C.c_uint32, P]
+        L.b32o_blend_rgb555.restype = None
+        L.b32o_blend_rgb555.argtypes = [C.c_uint8] * 6 + [C.c_uint32, P]
+        L.b32o_dither_offset.restype = C.c_int32; L.b32o_dither_offset.argtypes = [C.c_uint32, C.c_uint32]
+        L.b32o_dither_and_quantize.restype = None
+        L.b32o_dither_and_quantize.argtypes = [C.c_uint8] * 3 + [C.c_uint32, C.c_uint32, P]
+        L.b32o_fb_clear.restype = None
+        L.b32o_fb_clear.argtypes = [P, P, C.c_uint32, C.c_uint32] + [C.c_uint8] * 4
+        L.b32o_render_mesh_15.restype = C.c_int
+        L.b32o_render_mesh_15.argtypes = [P, P, C.c_uint32, C.c_uint32, P, C.c_uint32, P, C.c_uint32, P, C.c_uint32,
+                                          P, P, P, P, P]
+        L.b32o_vec3_dot.restype = C.c_float; L.b32o_vec3_dot.argtypes = [P, P]
+        L.b32o_vec3_cross.restype = None; L.b32o_vec3_cross.argtypes = [P, P, P]
+        _lib = L
+    return _lib
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(np.float32(x)) for x in v])
+
+
+def project_fixed(world_pos, camera: T.Camera, width, height):
+    """fixed::project_fixed (fixed.rs:424-441) -> (sx, sy, depth_f32)."""
+    sx, sy, d = C.c_int32(), C.c_int32(), C.c_float()
+    lib().b32o_project_fixed(_f3(world_pos), _f3(camera.position), _f3(camera.basis_x), _f3(camera.basis_y),
+                             _f3(camera.basis_z), width, height, C.byref(sx), C.byref(sy), C.byref(d))
+    return sx.value, sy.value, d.value
+
+
+class Framebuffer:
+    """Framebuffer (render.rs:10-45) on the host, for the oracle."""
+
+    def __init__(self, width, height):
+        self.width, self.height = width, height
+        self.pixels = np.zeros(width * height * 4, np.uint8)
+        self.zbuffer = np.full(width * height, np.finfo(np.float32).max, np.float32)
+
+    def clear(self, color: T.Color):
+        lib().b32o_fb_clear(self.pixels.ctypes.data, self.zbuffer.ctypes.data, self.width, self.height,
+                            color.r, color.g, color.b, color.blend)
+
+    def image(self):
+        return self.pixels.reshape(self.height, self.width, 4)
+
+
+def render_mesh_15(fb: Framebuffer, vertices, faces, textures, camera: T.Camera, settings: T.RasterSettings,
+                   fog=None, dump=False):
+    """render_mesh_15 (render.rs:2302-2638) on the CPU. Returns (rc, RasterTimings[, dump dict])."""
+    vertices = np.ascontiguousarray(vertices, dtype=abi.VERTEX_DTYPE)
+    faces = np.ascontiguousarray(faces, dtype=abi.FACE_DTYPE)
+    tex_arr, _keep_t = T.pack_textures(textures)
+    cam = camera.pack()
+    st, _keep_l = settings.pack()
+    fg = T.pack_fog(fog)
+    tm = abi.B32Timings()
+    d = None
+    if dump:
+        d = B32OracleDump()
+        sx = np.zeros(max(len(vertices), 1), np.int32); sy = np.zeros_like(sx)
+        sz = np.zeros(max(len(vertices), 1), np.float32)
+        order = np.zeros(max(len(faces), 1), np.uint32)
+        d.sx, d.sy, d.sz, d.draw_order = sx.ctypes.data, sy.ctypes.data, sz.ctypes.data, order.ctypes.data
+    rc = lib().b32o_render_mesh_15(fb.pixels.ctypes.data, fb.zbuffer.ctypes.data, fb.width, fb.height,
+                                   vertices.ctypes.data if len(vertices) else None, len(vertices),
+                                   faces.ctypes.data if len(faces) else None, len(faces),
+                                   C.cast(tex_arr, C.c_void_p), len(textures),
+                                   C.byref(cam), C.byref(st), C.byref(fg) if fg is not None else None,
+                                   C.byref(tm), C.byref(d) if d is not None else None)
+    t = T.RasterTimings.from_c(tm)
+    if dump:
+        return rc, t, {"sx": sx[:len(vertices)], "sy": sy[:len(vertices)], "sz": sz[:len(vertices)],
+                       "draw_order": order[:d.n_drawn].copy(), "n_opaque": int(d.n_opaque)}
+    return rc, t
