@@ -1,0 +1,392 @@
+// b32_fill.hip — affine texture-mapped triangle fill with RGB555 dither (rasterize_triangle_15, render.rs:1440-1714).
+//
+// Parallel decomposition (MI355X-first, not the reference's per-triangle scanline loop):
+//   * one persistent 1024-thread workgroup per CU pulls 64x64 screen tiles from a device-side cursor;
+//   * per tile, the surfaces binned to it arrive in painter's order (b32_bin.hip).  The opaque pass of the reference
+//     (render.rs:2553-2559) only ever overwrites pixels (set_pixel_15), so its result per pixel is the LAST surface in
+//     painter's order whose fragment is not skipped.  Phase A therefore runs all opaque surfaces of the tile in parallel
+//     (one wave per surface, lanes over the surface's own 8x8 pixel blocks) and resolves visibility with an LDS
+//     atomicMax on the surface's position in the tile list — order-independent, deterministic, no overdraw shading;
+//   * phase B shades each covered pixel exactly once from its winning surface (colour pipeline render.rs:1613-1661)
+//     and stores RGBA8 (Color15::to_rgba) with row-coalesced writes;
+//   * surfaces of the transparent pass (render.rs:2563-2569) blend against the framebuffer, so they are walked strictly
+//     in order: each wave owns 4 rows of the tile (no two waves touch the same pixel, no atomics, no barriers between
+//     surfaces) and applies set_pixel_blended_15 / editor-alpha stores to the LDS-resident tile.
+// Surface records are fetched 64 at a time with per-lane 16-B loads and broadcast with v_readlane, so per-surface
+// parameters live in SGPRs while the lanes work on pixels.
+//
+// Bit-exactness: barycentrics use the reference's expression order; the edge functions are evaluated in closed form only
+// for surfaces k_setup proved exact (integer coordinates, every intermediate < 2^24), otherwise the incremental walk
+// (render.rs:1706-1712) is replayed literally.
+#include "b32_device.h"
+
+namespace b32 {
+
+constexpr int LDS_TILE_BYTES = TILE_H * TILE_STRIDE * 4;      // 18432
+constexpr int LDS_MISC_BYTES = 64;
+constexpr int LDS_TEX_OFFSET = LDS_TILE_BYTES + LDS_MISC_BYTES;
+
+__device__ __forceinline__ float bcf(float v, int t) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), t)); }
+__device__ __forceinline__ uint32_t bcu(uint32_t v, int t) { return (uint32_t)__builtin_amdgcn_readlane((int)v, t); }
+
+struct Tri {            // wave-uniform view of one SurfRec (+ its texture)
+    float x3, y3, a0, b0, a1, b1, inv_area;
+    float u1, u2, u3, v1, v2, v3;
+    float w0_start, w1_start;
+    uint32_t min_x, max_x, min_y, max_y, flags;
+    uint32_t tw, th, toff;
+};
+
+template <int TEXMODE>
+__device__ __forceinline__ uint32_t sample15(const Tri& t, const uint16_t* __restrict__ gtex, const uint16_t* ltex, float u, float v) {
+    // Texture15::sample, types.rs:671-681
+    if (t.tw == 0 || t.th == 0) return 0;
+    const float uw = rem_euclid1(u), vw = rem_euclid1(v);
+    const uint32_t tx = min(f2u_sat(uw * (float)t.tw), t.tw - 1);
+    const uint32_t ty = min(f2u_sat(vw * (float)t.th), t.th - 1);
+    if (TEXMODE == 1) return ltex[ty * t.tw + tx];
+    return gtex[t.toff + ty * t.tw + tx];
+}
+
+// Inside test + texel fetch + transparency rules (render.rs:1536-1607). Returns false when the fragment is not drawn.
+template <int TEXMODE>
+__device__ __forceinline__ bool cover(const Tri& t, float w0, float w1, const uint16_t* __restrict__ gtex, const uint16_t* ltex,
+                                      float& bcx, float& bcy, float& bcz, uint32_t& texel) {
+    bcx = w0 * t.inv_area;
+    bcy = w1 * t.inv_area;
+    bcz = 1.0f - bcx - bcy;
+    const float ERR = -0.0001f;
+    if (!(bcx >= ERR && bcy >= ERR && bcz >= ERR)) return false;
+    uint32_t c = 0x7FFF;                                         // Color15::WHITE, render.rs:1585
+    if ((t.flags & F_TEX_MASK) != F_TEX_NONE) {
+        const float u = bcx * t.u1 + bcy * t.u2 + bcz * t.u3;    // affine, render.rs:1565-1566
+        const float v = bcx * t.v1 + bcy * t.v2 + bcz * t.v3;
+        c = sample15<TEXMODE>(t, gtex, ltex, u, 1.0f - v);       // render.rs:1583
+    }
+    if (c == 0) {                                                // render.rs:1592-1602
+        if (t.flags & F_BLACK_TR) return false;
+        c = 0x8000;                                              // BLACK_DRAWABLE
+    } else if ((t.flags & F_BLACK_TR) && (c & 0x7FFF) == 0) {    // render.rs:1603-1608
+        return false;
+    }
+    texel = c;
+    return true;
+}
+
+// Colour pipeline (render.rs:1613-1661): modulate by interpolated vertex colour, shade, dither, quantize to RGB555.
+__device__ __forceinline__ uint32_t shade15(uint32_t texel, float bcx, float bcy, float bcz, uint32_t vc1, uint32_t vc2, uint32_t vc3,
+                                            uint32_t flags, int shading, const float* sh, uint32_t px, uint32_t py) {
+    uint32_t q[3];
+    const int off = dither_offset(px, py);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const uint32_t c5 = (texel >> (10 - 5 * i)) & 31;        // i=0 r, 1 g, 2 b
+        const uint32_t tex8 = expand5(c5);
+        const float f1 = (float)((vc1 >> (8 * i)) & 255), f2 = (float)((vc2 >> (8 * i)) & 255), f3 = (float)((vc3 >> (8 * i)) & 255);
+        const uint32_t vert = f2u8_sat(bcx * f1 + bcy * f2 + bcz * f3);              // :1618-1620
+        uint32_t m = min((tex8 * vert) / 128u, 255u);                                 // :1624-1626
+        if (shading != B32_SHADE_NONE) {                                              // :1629-1645 (x1.0 is exact when None)
+            const float s = shading == B32_SHADE_FLAT ? sh[i] : (bcx * sh[i] + bcy * sh[3 + i] + bcz * sh[6 + i]);
+            m = f2u8_sat(rmin((float)m * rclamp(s, 0.0f, 2.0f), 255.0f));
+        }
+        if (flags & F_DITHER) q[i] = (uint32_t)min(max(((int)m + off) >> 3, 0), 31); // dither_and_quantize :1173-1182
+        else q[i] = m >> 3;                                                           // :1653
+    }
+    const bool all_black = (q[0] | q[1] | q[2]) == 0;                                 // :1659-1661
+    return (q[0] << 10) | (q[1] << 5) | q[2] | (((texel & 0x8000) || all_black) ? 0x8000u : 0u);
+}
+
+// Pixel store of the transparent pass in painter's mode (render.rs:1674-1680, 1695-1702) on an RGBA8 word.
+__device__ __forceinline__ uint32_t store_blend(uint32_t back, uint32_t out15, uint32_t flags) {
+    const uint32_t mode = (flags >> F_BLEND_SHIFT) & 7u, alpha = flags >> F_ALPHA_SHIFT;
+    const uint32_t front = c15_to_rgba(out15);
+    const bool do_blend = (out15 & 0x8000) && mode != B32_BLEND_OPAQUE;
+    if (alpha < 255) {                                           // set_pixel_with_editor_alpha_15, render.rs:567-591
+        const uint32_t ps1 = do_blend ? blend_rgb555(front, back, mode) : front;
+        uint32_t o = 0xFF000000u;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const uint32_t p = (ps1 >> (8 * i)) & 255, b = (back >> (8 * i)) & 255;
+            o |= (((p * alpha + b * (255 - alpha)) & 0xFFFF) / 255u) << (8 * i);
+        }
+        return o;
+    }
+    if (do_blend) return blend_rgb555(front, back, mode) | 0xFF000000u;   // set_pixel_blended_15, render.rs:479-502
+    return front;                                                           // set_pixel_15, render.rs:445-454
+}
+
+// Replay of the reference's accumulated edge functions up to pixel (px,py) (render.rs:1527-1533, 1706-1712).
+__device__ __forceinline__ void replay_w(const Tri& t, uint32_t px, uint32_t py, float& w0, float& w1) {
+    float r0 = t.w0_start, r1 = t.w1_start;
+    for (uint32_t y = t.min_y; y < py; ++y) { r0 += t.b0; r1 += t.b1; }
+    for (uint32_t x = t.min_x; x < px; ++x) { r0 += t.a0; r1 += t.a1; }
+    w0 = r0; w1 = r1;
+}
+
+struct Batch {          // per-lane copy of one surface record (lane l <-> list entry chunk_start + l)
+    uint4 q0, q1, q2, q3, q4, q5;
+    uint32_t tw, th, toff;
+};
+
+template <int TEXMODE>
+__device__ __forceinline__ void load_batch(Batch& b, const FillArgs& a, uint32_t entry, bool live, const TexDesc& lds_desc) {
+    b.q0 = b.q1 = b.q2 = b.q3 = b.q4 = b.q5 = make_uint4(0, 0, 0, 0);
+    b.tw = b.th = b.toff = 0;
+    if (live) {
+        const uint32_t sid = a.pair_vals[entry];
+        const uint4* p = reinterpret_cast<const uint4*>(a.recs + sid);
+        b.q0 = p[0]; b.q1 = p[1]; b.q2 = p[2]; b.q3 = p[3]; b.q4 = p[4]; b.q5 = p[5];
+        const uint32_t tid = b.q3.w & F_TEX_MASK;
+        if (tid != F_TEX_NONE) {
+            if (TEXMODE == 1) { b.tw = lds_desc.width; b.th = lds_desc.height; b.toff = 0; }
+            else { const TexDesc d = a.tex[tid]; b.tw = d.width; b.th = d.height; b.toff = d.offset; }
+        }
+    }
+}
+__device__ __forceinline__ Tri tri_from_batch(const Batch& b, int t) {
+    Tri r;
+    r.x3 = bcf(__uint_as_float(b.q0.x), t); r.y3 = bcf(__uint_as_float(b.q0.y), t);
+    r.a0 = bcf(__uint_as_float(b.q0.z), t); r.b0 = bcf(__uint_as_float(b.q0.w), t);
+    r.a1 = bcf(__uint_as_float(b.q1.x), t); r.b1 = bcf(__uint_as_float(b.q1.y), t);
+    r.inv_area = bcf(__uint_as_float(b.q1.z), t);
+    const uint32_t bbx = bcu(b.q1.w, t), bby = bcu(b.q2.x, t);
+    r.min_x = bbx & 0xFFFF; r.max_x = bbx >> 16; r.min_y = bby & 0xFFFF; r.max_y = bby >> 16;
+    r.u1 = bcf(__uint_as_float(b.q2.y), t); r.u2 = bcf(__uint_as_float(b.q2.z), t); r.u3 = bcf(__uint_as_float(b.q2.w), t);
+    r.v1 = bcf(__uint_as_float(b.q3.x), t); r.v2 = bcf(__uint_as_float(b.q3.y), t); r.v3 = bcf(__uint_as_float(b.q3.z), t);
+    r.flags = bcu(b.q3.w, t);
+    r.w0_start = bcf(__uint_as_float(b.q4.w), t); r.w1_start = bcf(__uint_as_float(b.q5.x), t);
+    r.tw = bcu(b.tw, t); r.th = bcu(b.th, t); r.toff = bcu(b.toff, t);
+    return r;
+}
+__device__ __forceinline__ Tri tri_from_rec(const uint4 q0, const uint4 q1, const uint4 q2, const uint4 q3, const uint4 q4, const uint4 q5) {
+    Tri r;
+    r.x3 = __uint_as_float(q0.x); r.y3 = __uint_as_float(q0.y); r.a0 = __uint_as_float(q0.z); r.b0 = __uint_as_float(q0.w);
+    r.a1 = __uint_as_float(q1.x); r.b1 = __uint_as_float(q1.y); r.inv_area = __uint_as_float(q1.z);
+    r.min_x = q1.w & 0xFFFF; r.max_x = q1.w >> 16; r.min_y = q2.x & 0xFFFF; r.max_y = q2.x >> 16;
+    r.u1 = __uint_as_float(q2.y); r.u2 = __uint_as_float(q2.z); r.u3 = __uint_as_float(q2.w);
+    r.v1 = __uint_as_float(q3.x); r.v2 = __uint_as_float(q3.y); r.v3 = __uint_as_float(q3.z);
+    r.flags = q3.w;
+    r.w0_start = __uint_as_float(q4.w); r.w1_start = __uint_as_float(q5.x);
+    r.tw = r.th = r.toff = 0;
+    return r;
+}
+
+template <int TEXMODE>
+__global__ __launch_bounds__(FILL_THREADS) void k_fill(FillArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* tilebuf = reinterpret_cast<uint32_t*>(smem);
+    volatile uint32_t* misc = reinterpret_cast<volatile uint32_t*>(smem + LDS_TILE_BYTES);
+    const uint16_t* ltex = reinterpret_cast<const uint16_t*>(smem + LDS_TEX_OFFSET);
+
+    if (a.ctrl->abort) return;
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));   // wave-uniform => SGPR control flow
+    const FrameParams& fp = a.fp;
+    const uint32_t ntiles = fp.tiles_x * fp.tiles_y;
+    const int shading = fp.shading;
+
+    TexDesc lds_desc = { 0, 0, 0, 0 };
+    if (TEXMODE == 1) {     // stage texture 0 once per workgroup: 16-B coalesced loads -> LDS
+        lds_desc = a.tex[0];
+        const uint4* src = reinterpret_cast<const uint4*>(a.texels + lds_desc.offset);
+        uint4* dst = reinterpret_cast<uint4*>(smem + LDS_TEX_OFFSET);
+        const uint32_t nq = (a.lds_tex_texels + 7) / 8;
+        for (uint32_t i = tid; i < nq; i += FILL_THREADS) dst[i] = src[i];
+    }
+    unsigned long long frag_count = 0;
+
+    for (;;) {
+        if (tid == 0) misc[0] = atomicAdd(&a.ctrl->tile_cursor, 1u);
+        __syncthreads();
+        const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)misc[0]);
+        if (tile >= ntiles) break;
+        const uint32_t e0 = a.ranges[2 * tile], e1 = a.ranges[2 * tile + 1], e2 = a.ranges[2 * tile + 2];
+        if (e0 != e2) {
+            const uint32_t txi = tile % fp.tiles_x, tyi = tile / fp.tiles_x + fp.tile_y0;
+            const uint32_t x_lo = txi * TILE_W, x_hi = min(x_lo + TILE_W, fp.width);
+            const uint32_t ty_top = tyi * TILE_H;
+            const uint32_t y_lo = max(ty_top, fp.band_y0), y_hi = min(ty_top + TILE_H, fp.band_y1);
+            const bool has_tr = e1 != e2;
+
+            // ---- phase 0: clear the visibility buffer
+            for (uint32_t i = tid; i < TILE_H * TILE_STRIDE; i += FILL_THREADS) tilebuf[i] = 0;
+            __syncthreads();
+
+            // ---- phase A: opaque coverage, winner = max list position (LDS atomicMax)
+            const uint32_t n_op = e1 - e0;
+            if (n_op) {
+                uint32_t chunk = (n_op + FILL_WAVES - 1) / FILL_WAVES;
+                chunk = min(max(chunk, 1u), 64u);
+                for (uint32_t cs = wave * chunk; cs < n_op; cs += FILL_WAVES * chunk) {
+                    const uint32_t cnt = min(chunk, n_op - cs);
+                    Batch b;
+                    load_batch<TEXMODE>(b, a, e0 + cs + lane, lane < cnt, lds_desc);
+                    for (uint32_t t = 0; t < cnt; ++t) {
+                        const Tri tr = tri_from_batch(b, (int)t);
+                        const uint32_t cx0 = max(tr.min_x, x_lo), cx1 = min(tr.max_x, x_hi);
+                        const uint32_t cy0 = max(tr.min_y, y_lo), cy1 = min(tr.max_y, y_hi);
+                        if (cx0 >= cx1 || cy0 >= cy1) continue;
+                        const uint32_t li = cs + t + 1;
+                        if (!(tr.flags & F_SLOW)) {
+                            for (uint32_t by = cy0; by < cy1; by += 8)
+                                for (uint32_t bx = cx0; bx < cx1; bx += 8) {
+                                    const uint32_t px = bx + (lane & 7), py = by + (lane >> 3);
+                                    if (px < cx1 && py < cy1) {
+                                        const float dx = (float)px - tr.x3, dy = (float)py - tr.y3;
+                                        const float w0 = tr.a0 * dx + tr.b0 * dy, w1 = tr.a1 * dx + tr.b1 * dy;   // exact integers (k_setup guard)
+                                        float bx_, by_, bz_; uint32_t texel;
+                                        if (cover<TEXMODE>(tr, w0, w1, a.texels, ltex, bx_, by_, bz_, texel)) {
+                                            atomicMax(&tilebuf[(py - ty_top) * TILE_STRIDE + (px - x_lo)], li);
+                                            ++frag_count;
+                                        }
+                                    }
+                                }
+                        } else {
+                            for (uint32_t by = cy0; by < cy1; by += 64) {       // one lane per row, literal incremental walk
+                                const uint32_t py = by + lane;
+                                if (py < cy1) {
+                                    float w0, w1;
+                                    replay_w(tr, cx0, py, w0, w1);
+                                    for (uint32_t px = cx0; px < cx1; ++px) {
+                                        float bx_, by_, bz_; uint32_t texel;
+                                        if (cover<TEXMODE>(tr, w0, w1, a.texels, ltex, bx_, by_, bz_, texel)) {
+                                            atomicMax(&tilebuf[(py - ty_top) * TILE_STRIDE + (px - x_lo)], li);
+                                            ++frag_count;
+                                        }
+                                        w0 += tr.a0; w1 += tr.a1;
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+
+            // ---- phase B: shade every covered pixel once from its winning surface
+#pragma unroll 1
+            for (uint32_t k = 0; k < (TILE_W * TILE_H) / FILL_THREADS; ++k) {
+                const uint32_t p = tid + k * FILL_THREADS;
+                const uint32_t row = p >> 6, col = p & 63;
+                const uint32_t px = x_lo + col, py = ty_top + row;
+                const bool inb = px < x_hi && py >= y_lo && py < y_hi;
+                const uint32_t li = tilebuf[row * TILE_STRIDE + col];
+                uint32_t rgba = 0;
+                if (inb && li) {
+                    const uint32_t sid = a.pair_vals[e0 + li - 1];
+                    const uint4* rp = reinterpret_cast<const uint4*>(a.recs + sid);
+                    const uint4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3], q4 = rp[4], q5 = rp[5];
+                    Tri tr = tri_from_rec(q0, q1, q2, q3, q4, q5);
+                    const uint32_t txid = tr.flags & F_TEX_MASK;
+                    if (txid != F_TEX_NONE) {
+                        if (TEXMODE == 1) { tr.tw = lds_desc.width; tr.th = lds_desc.height; tr.toff = 0; }
+                        else { const TexDesc d = a.tex[txid]; tr.tw = d.width; tr.th = d.height; tr.toff = d.offset; }
+                    }
+                    float w0, w1;
+                    if (!(tr.flags & F_SLOW)) {
+                        const float dx = (float)px - tr.x3, dy = (float)py - tr.y3;
+                        w0 = tr.a0 * dx + tr.b0 * dy; w1 = tr.a1 * dx + tr.b1 * dy;
+                    } else replay_w(tr, px, py, w0, w1);
+                    float bcx, bcy, bcz; uint32_t texel = 0;
+                    cover<TEXMODE>(tr, w0, w1, a.texels, ltex, bcx, bcy, bcz, texel);      // true by construction
+                    const float* sh = shading != B32_SHADE_NONE ? a.shades + (size_t)sid * 9 : nullptr;
+                    float shv[9];
+                    if (shading != B32_SHADE_NONE) for (int j = 0; j < 9; ++j) shv[j] = sh[j];
+                    const uint32_t out15 = shade15(texel, bcx, bcy, bcz, q4.x, q4.y, q4.z, tr.flags, shading, shv, px, py);
+                    rgba = c15_to_rgba(out15);                                               // set_pixel_15
+                    if (!has_tr) a.fb[(size_t)py * fp.width + px] = rgba;
+                }
+                if (has_tr) {
+                    if (inb && !li) rgba = a.fb[(size_t)py * fp.width + px];
+                    tilebuf[row * TILE_STRIDE + col] = rgba;
+                }
+            }
+
+            // ---- phase C: transparent pass, strictly in painter's order; wave w owns tile rows [4w, 4w+4)
+            if (has_tr) {
+                __syncthreads();
+                const uint32_t n_tr = e2 - e1;
+                const uint32_t wy0 = max(ty_top + wave * 4, y_lo), wy1 = min(ty_top + wave * 4 + 4, y_hi);
+                for (uint32_t cs = 0; cs < n_tr; cs += 64) {
+                    const uint32_t cnt = min(64u, n_tr - cs);
+                    Batch b;
+                    load_batch<TEXMODE>(b, a, e1 + cs + lane, lane < cnt, lds_desc);
+                    const uint32_t my_sid = lane < cnt ? a.pair_vals[e1 + cs + lane] : 0;
+                    for (uint32_t t = 0; t < cnt; ++t) {
+                        const Tri tr = tri_from_batch(b, (int)t);
+                        const uint32_t cx0 = max(tr.min_x, x_lo), cx1 = min(tr.max_x, x_hi);
+                        const uint32_t cy0 = max(tr.min_y, wy0), cy1 = min(tr.max_y, wy1);
+                        if (cx0 >= cx1 || cy0 >= cy1) continue;
+                        if ((tr.flags >> F_ALPHA_SHIFT) == 0) continue;                      // editor_alpha == 0, render.rs:1664-1669
+                        const uint32_t vc1 = bcu(b.q4.x, (int)t), vc2 = bcu(b.q4.y, (int)t), vc3 = bcu(b.q4.z, (int)t);
+                        const uint32_t sid = bcu(my_sid, (int)t);
+                        float shv[9];
+                        if (shading != B32_SHADE_NONE) for (int j = 0; j < 9; ++j) shv[j] = a.shades[(size_t)sid * 9 + j];
+                        if (!(tr.flags & F_SLOW)) {
+                            for (uint32_t bx = cx0; bx < cx1; bx += 16) {
+                                const uint32_t px = bx + (lane & 15), py = cy0 + (lane >> 4);
+                                if (px < cx1 && py < cy1) {
+                                    const float dx = (float)px - tr.x3, dy = (float)py - tr.y3;
+                                    const float w0 = tr.a0 * dx + tr.b0 * dy, w1 = tr.a1 * dx + tr.b1 * dy;
+                                    float bcx, bcy, bcz; uint32_t texel;
+                                    if (cover<TEXMODE>(tr, w0, w1, a.texels, ltex, bcx, bcy, bcz, texel)) {
+                                        const uint32_t out15 = shade15(texel, bcx, bcy, bcz, vc1, vc2, vc3, tr.flags, shading, shv, px, py);
+                                        uint32_t* dst = &tilebuf[(py - ty_top) * TILE_STRIDE + (px - x_lo)];
+                                        *dst = store_blend(*dst, out15, tr.flags);
+                                        ++frag_count;
+                                    }
+                                }
+                            }
+                        } else {
+                            const uint32_t py = cy0 + lane;
+                            if (py < cy1) {
+                                float w0, w1;
+                                replay_w(tr, cx0, py, w0, w1);
+                                for (uint32_t px = cx0; px < cx1; ++px) {
+                                    float bcx, bcy, bcz; uint32_t texel;
+                                    if (cover<TEXMODE>(tr, w0, w1, a.texels, ltex, bcx, bcy, bcz, texel)) {
+                                        const uint32_t out15 = shade15(texel, bcx, bcy, bcz, vc1, vc2, vc3, tr.flags, shading, shv, px, py);
+                                        uint32_t* dst = &tilebuf[(py - ty_top) * TILE_STRIDE + (px - x_lo)];
+                                        *dst = store_blend(*dst, out15, tr.flags);
+                                        ++frag_count;
+                                    }
+                                    w0 += tr.a0; w1 += tr.a1;
+                                }
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+                // write the finished tile back, one 256-B row segment per wave instruction
+                for (uint32_t k = 0; k < (TILE_W * TILE_H) / FILL_THREADS; ++k) {
+                    const uint32_t p = tid + k * FILL_THREADS;
+                    const uint32_t row = p >> 6, col = p & 63;
+                    const uint32_t px = x_lo + col, py = ty_top + row;
+                    if (px < x_hi && py >= y_lo && py < y_hi) a.fb[(size_t)py * fp.width + px] = tilebuf[row * TILE_STRIDE + col];
+                }
+            }
+        }
+        __syncthreads();   // everyone is done with misc[0] / tilebuf before the next tile
+    }
+
+    // exact fragment-store count (Mpixels/s numerator)
+    for (int off = 32; off > 0; off >>= 1) frag_count += __shfl_down(frag_count, off);
+    if (lane == 0 && frag_count) atomicAdd(&a.ctrl->fragments, frag_count);
+}
+
+void launch_fill(hipStream_t s, const FillArgs& a, int n_cu) {
+    const uint32_t ntiles = a.fp.tiles_x * a.fp.tiles_y;
+    if (ntiles == 0) return;
+    uint32_t grid = min(ntiles, (uint32_t)n_cu);
+    if (a.lds_tex_texels) {
+        const size_t lds = LDS_TEX_OFFSET + (((size_t)a.lds_tex_texels * 2 + 15) & ~(size_t)15);
+        static bool attr_set = false;
+        if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fill<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+        hipLaunchKernelGGL(k_fill<1>, dim3(grid), dim3(FILL_THREADS), lds, s, a);
+    } else {
+        grid = min(ntiles, (uint32_t)n_cu * 2);      // 18.5 KB LDS, 16 waves per workgroup: two workgroups fit a CU
+        hipLaunchKernelGGL(k_fill<0>, dim3(grid), dim3(FILL_THREADS), LDS_TEX_OFFSET, s, a);
+    }
+}
+
+}  // namespace b32

@@ -1,0 +1,206 @@
+"""Host-side mirror of the reference rasterizer interface, running on the MI355X through the C ABI.
+
+Same names and argument meaning as the reference:
+    Framebuffer::{new, resize, clear}       src/rasterizer/render.rs:18-45
+    render_mesh_15(fb, vertices, faces, textures, camera, settings, fog) -> RasterTimings   render.rs:2302-2310
+Errors the reference turns into panics come back as B32Error (index out of range, NaN sort key).
+
+There is no CPU path here: if libb32raster.so or a HIP device is missing, construction raises.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+from . import rtypes as T
+
+
+class B32Error(RuntimeError):
+    def __init__(self, code, where=""):
+        self.code = code
+        msg = abi.load_library().b32_strerror(code).decode()
+        super().__init__(f"{where}: {msg} (code {code})" if where else f"{msg} (code {code})")
+
+
+def _chk(rc, where=""):
+    if rc != abi.B32_OK:
+        raise B32Error(rc, where)
+
+
+class Context:
+    """One b32_ctx: one GPU, one stream, one device-resident framebuffer and scene."""
+
+    def __init__(self, device=0):
+        self.lib = abi.load_library()
+        h = C.c_void_p()
+        _chk(self.lib.b32_create(device, C.byref(h)), "b32_create")
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.b32_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_ptr):
+        _chk(self.lib.b32_set_stream(self.h, stream_ptr), "b32_set_stream")
+
+    def synchronize(self):
+        _chk(self.lib.b32_synchronize(self.h), "b32_synchronize")
+
+    def set_profiling(self, level):
+        _chk(self.lib.b32_set_profiling(self.h, level), "b32_set_profiling")
+
+    def last_kernel_times(self):
+        names = (C.c_char_p * 8)()
+        ms = (C.c_float * 8)()
+        n = self.lib.b32_last_kernel_times(self.h, names, ms, 8)
+        return {names[i].decode(): float(ms[i]) for i in range(n)}
+
+    # ---- stage taps -----------------------------------------------------------------
+    def project_fixed_batch(self, pos, camera: T.Camera, width, height):
+        pos = np.ascontiguousarray(pos, dtype=np.float32).reshape(-1, 3)
+        n = len(pos)
+        sx = np.zeros(n, np.int32); sy = np.zeros(n, np.int32); z = np.zeros(n, np.float32)
+        cam = camera.pack()
+        _chk(self.lib.b32_project_fixed_batch(self.h, pos.ctypes.data, n, C.byref(cam), width, height,
+                                              sx.ctypes.data, sy.ctypes.data, z.ctypes.data), "project_fixed_batch")
+        return sx, sy, z
+
+    def selftest_f32(self, op, a, b, c):
+        a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
+        c = np.ascontiguousarray(c, np.float32)
+        out = np.zeros_like(a)
+        _chk(self.lib.b32_selftest_f32(self.h, op, a.ctypes.data, b.ctypes.data, c.ctypes.data, out.ctypes.data, a.size))
+        return out
+
+    def last_draw_order(self, cap):
+        buf = np.zeros(max(cap, 1), np.uint32)
+        n = C.c_uint32()
+        _chk(self.lib.b32_last_draw_order(self.h, buf.ctypes.data, cap, C.byref(n)), "last_draw_order")
+        return buf[:min(n.value, cap)].copy()
+
+
+class Framebuffer:
+    """Framebuffer (render.rs:10-45), device resident. `pixels` downloads the RGBA8 bytes."""
+
+    def __init__(self, width, height, ctx: Context = None, device=0):
+        self.ctx = ctx or Context(device)
+        self.width, self.height = 0, 0
+        self.resize(width, height)
+
+    @staticmethod
+    def new(width, height, ctx=None):
+        return Framebuffer(width, height, ctx)
+
+    def resize(self, width, height):
+        _chk(self.ctx.lib.b32_fb_resize(self.ctx.h, width, height), "fb_resize")
+        self.width, self.height = width, height
+
+    def bind_device(self, device_ptr, width, height):
+        """Draw into caller-owned device memory (e.g. torch uint8 tensor .data_ptr())."""
+        _chk(self.ctx.lib.b32_fb_bind_device(self.ctx.h, device_ptr, width, height), "fb_bind_device")
+        self.width, self.height = width, height
+
+    def set_band(self, y0, y1):
+        _chk(self.ctx.lib.b32_set_band(self.ctx.h, y0, y1), "set_band")
+
+    def clear(self, color: T.Color):
+        _chk(self.ctx.lib.b32_fb_clear(self.ctx.h, color.r, color.g, color.b, color.blend), "fb_clear")
+
+    def upload(self, pixels):
+        px = np.ascontiguousarray(pixels, dtype=np.uint8).reshape(-1)
+        assert px.size == self.width * self.height * 4
+        _chk(self.ctx.lib.b32_fb_upload(self.ctx.h, px.ctypes.data), "fb_upload")
+
+    @property
+    def pixels(self):
+        out = np.empty(self.width * self.height * 4, np.uint8)
+        _chk(self.ctx.lib.b32_fb_download(self.ctx.h, out.ctypes.data), "fb_download")
+        return out
+
+    def image(self):
+        return self.pixels.reshape(self.height, self.width, 4)
+
+
+def _geom(vertices, faces):
+    v = np.ascontiguousarray(vertices, dtype=abi.VERTEX_DTYPE)
+    f = np.ascontiguousarray(faces, dtype=abi.FACE_DTYPE)
+    return v, f
+
+
+def render_mesh_15(fb: Framebuffer, vertices, faces, textures, camera: T.Camera, settings: T.RasterSettings,
+                   fog=None) -> T.RasterTimings:
+    """render_mesh_15 (render.rs:2302-2310): host slices in, draws into the device framebuffer."""
+    v, f = _geom(vertices, faces)
+    tex_arr, _keep = T.pack_textures(textures)
+    cam = camera.pack()
+    st, _kl = settings.pack()
+    fg = T.pack_fog(fog)
+    tm = abi.B32Timings()
+    rc = fb.ctx.lib.b32_render_mesh_15(fb.ctx.h, v.ctypes.data if len(v) else None, len(v),
+                                       f.ctypes.data if len(f) else None, len(f),
+                                       C.cast(tex_arr, C.c_void_p), len(textures), C.byref(cam), C.byref(st),
+                                       C.byref(fg) if fg is not None else None, C.byref(tm))
+    _chk(rc, "render_mesh_15")
+    return T.RasterTimings.from_c(tm)
+
+
+# aliases named in BASELINE.json's north_star (the reference's real entry point is render_mesh_15)
+draw_mesh = render_mesh_15
+
+
+class ResidentScene:
+    """A mesh + textures kept in HBM across frames: upload once, draw many times."""
+
+    def __init__(self, fb: Framebuffer, vertices, faces, textures=None, indexed_textures=None):
+        self.fb = fb
+        self.ctx = fb.ctx
+        v, f = _geom(vertices, faces)
+        if indexed_textures is not None:
+            arr, keep = T.pack_indexed_textures(indexed_textures)
+            rc = self.ctx.lib.b32_scene_upload_indexed(self.ctx.h, v.ctypes.data if len(v) else None, len(v),
+                                                       f.ctypes.data if len(f) else None, len(f),
+                                                       C.cast(arr, C.c_void_p), len(indexed_textures))
+        else:
+            textures = textures or []
+            arr, keep = T.pack_textures(textures)
+            rc = self.ctx.lib.b32_scene_upload(self.ctx.h, v.ctypes.data if len(v) else None, len(v),
+                                               f.ctypes.data if len(f) else None, len(f),
+                                               C.cast(arr, C.c_void_p), len(textures))
+        _chk(rc, "scene_upload")
+        self.n_faces = len(f)
+        self._packed = None
+
+    def _pack(self, camera, settings, fog):
+        cam = camera.pack()
+        st, kl = settings.pack()
+        fg = T.pack_fog(fog)
+        self._packed = (cam, st, kl, fg)
+        return self._packed
+
+    def render(self, camera, settings, fog=None) -> T.RasterTimings:
+        cam, st, _kl, fg = self._pack(camera, settings, fog)
+        tm = abi.B32Timings()
+        _chk(self.ctx.lib.b32_render_scene_15(self.ctx.h, C.byref(cam), C.byref(st),
+                                              C.byref(fg) if fg is not None else None, C.byref(tm)), "render_scene_15")
+        return T.RasterTimings.from_c(tm)
+
+    def render_async(self, camera=None, settings=None, fog=None):
+        """Enqueue only. With no arguments, re-enqueues the last packed camera/settings (no Python packing cost)."""
+        if camera is not None:
+            self._pack(camera, settings, fog)
+        cam, st, _kl, fg = self._packed
+        _chk(self.ctx.lib.b32_render_scene_15_async(self.ctx.h, C.byref(cam), C.byref(st),
+                                                    C.byref(fg) if fg is not None else None), "render_scene_15_async")
+
+    def finish(self) -> T.RasterTimings:
+        tm = abi.B32Timings()
+        _chk(self.ctx.lib.b32_frame_finish(self.ctx.h, C.byref(tm)), "frame_finish")
+        return T.RasterTimings.from_c(tm)

@@ -17,7 +17,7 @@ from typing import List, Optional
 import numpy as np
 
 from . import abi
-from .types import (Camera, Color, IndexedTexture, Light, RasterSettings, Texture15, make_faces, make_vertices)
+from .rtypes import (Camera, Color, IndexedTexture, Light, RasterSettings, Texture15, make_faces, make_vertices)
 
 GAMMA = np.uint64(0x9E3779B97F4A7C15)
 BASE_SEED = 0xB0771E32
@@ -154,7 +154,7 @@ def make_scene(config="C1", n_tris=None, seed=None, variant="bench", width=None,
 def cube_scene(width=320, height=240):
     """The reference-authored fixture: create_test_cube (draw.rs:138-214) + Texture15::checkerboard
     (types.rs:702-711), camera pulled back along -z, Gouraud default light, painter's."""
-    from .types import create_test_cube
+    from .rtypes import create_test_cube
     v, f = create_test_cube()
     tex = Texture15.checkerboard(32, 32, 0x7FFF, 0x3DEF)
     s = RasterSettings.benchmark()

@@ -216,6 +216,10 @@ int b32_selftest_f32(b32_ctx* ctx, int op, const float* a, const float* b, const
 /* Per-kernel device time of the last finished frame (HIP events on the ctx stream), for bench.py.
  * names[i] points at static strings; returns the number of entries written (<= cap). */
 int b32_last_kernel_times(b32_ctx* ctx, const char** names, float* ms, uint32_t cap);
+/* HIP-event instrumentation of the frames enqueued from now on: 0 = none (default for the async path),
+ * 1 = events around the fill kernel, 2 = events around every phase. Averages over the frames between two
+ * b32_frame_finish calls (last 64 at most) are returned by b32_last_kernel_times / B32Timings. */
+int b32_set_profiling(b32_ctx* ctx, int level);
 
 #ifdef __cplusplus
 }

@@ -9,7 +9,7 @@ import subprocess
 import numpy as np
 
 import bonnie32_amd as b32
-from bonnie32_amd import abi, types as T
+from bonnie32_amd import abi, rtypes as T
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_build", "libb32oracle.so")

@@ -1,0 +1,29 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as O
+    O.lib()
+    return O
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx():
+    """A live b32 context. Fails (does not skip) when the HIP library or device is missing: GPU tests must
+    never pass on a fallback."""
+    import __graft_entry__ as g
+    g.build()
+    from bonnie32_amd import rasterizer as R
+    return R.Context(0)
