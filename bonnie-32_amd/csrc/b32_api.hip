@@ -47,7 +47,8 @@ struct b32_ctx {
     size_t cap_pairs = 0;
     uint32_t *pkeys[2] = { nullptr, nullptr }, *pvals[2] = { nullptr, nullptr };
     // sort scratch
-    uint32_t* block_hist = nullptr; uint32_t hist_blocks = 0;
+    uint32_t* block_hist = nullptr; uint32_t hist_blocks = 0; uint32_t* digit_total = nullptr;
+    uint32_t* partials = nullptr; uint32_t partial_blocks = 0;
     // tiles
     uint32_t* ranges = nullptr; size_t cap_ranges = 0;
     // control
@@ -120,7 +121,8 @@ int b32_create(int device, b32_ctx** out) {
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return B32_E_HIP; }
     c->stream = c->own_stream;
     if (hipMalloc(reinterpret_cast<void**>(&c->d_ctrl), sizeof(Ctrl)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&c->d_consts), 16 * sizeof(uint32_t)) != hipSuccess) { delete c; return B32_E_HIP; }
+        hipMalloc(reinterpret_cast<void**>(&c->d_consts), 16 * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&c->digit_total), 256 * sizeof(uint32_t)) != hipSuccess) { delete c; return B32_E_HIP; }
     *out = c;
     return B32_OK;
 }
@@ -131,7 +133,7 @@ void b32_destroy(b32_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = { c->fb_own, c->d_verts, c->d_faces, c->d_texels, c->d_tex, c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->recs,
                      c->shades, c->counts, c->block_sums, c->pkeys[0], c->pkeys[1], c->pvals[0], c->pvals[1], c->block_hist, c->ranges,
-                     c->d_ctrl, c->d_consts, c->d_lights };
+                     c->d_ctrl, c->d_consts, c->d_lights, c->digit_total, c->partials };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->ev_created) for (auto& fr : c->ev) for (auto& e : fr) if (e) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -239,6 +241,8 @@ static int upload_geometry(b32_ctx* c, const B32Vertex* v, uint32_t nv, const B3
         if ((rc = ensure_plain(c, c->recs, n))) return rc;
         if ((rc = ensure_plain(c, c->counts, n))) return rc;
         c->bin_blocks = (uint32_t)((n + 4095) / 4096);
+        c->partial_blocks = (uint32_t)((n + 255) / 256);
+        if ((rc = ensure_plain(c, c->partials, (size_t)c->partial_blocks * 8 + 8))) return rc;
         if ((rc = ensure_plain(c, c->block_sums, (size_t)c->bin_blocks + 1))) return rc;
         c->cap_work = n;
     }
@@ -393,12 +397,12 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
 
     HIPCHK(c, hipMemsetAsync(c->d_ctrl, 0, sizeof(Ctrl), s));
     if (prof_all) HIPCHK(c, hipEventRecord(ev[0], s));
-    launch_setup(s, fp, c->d_verts, c->d_faces, c->d_tex, c->d_lights, c->recs, c->shades, c->keys[0], c->d_ctrl);
-    launch_after_setup(s, c->d_ctrl);
+    launch_setup(s, fp, c->d_verts, c->d_faces, c->d_tex, c->d_lights, c->recs, c->shades, c->keys[0], c->partials);
+    launch_after_setup(s, c->d_ctrl, c->partials, (c->nf + 255) / 256);
     if (prof_all) HIPCHK(c, hipEventRecord(ev[1], s));
 
     // painter's order: 4 stable passes over the 32-bit key; pass 1 also compacts away culled faces
-    const SortScratch sc{ c->block_hist, c->hist_blocks };
+    const SortScratch sc{ c->block_hist, c->hist_blocks, c->digit_total };
     launch_radix_pass(s, c->keys[0], nullptr, c->keys[1], c->vals[1], c->d_consts, c->nf, 0, sc);
     launch_radix_pass(s, c->keys[1], c->vals[1], c->keys[0], c->vals[0], &c->d_ctrl->n_visible, c->nf, 8, sc);
     launch_radix_pass(s, c->keys[0], c->vals[0], c->keys[1], c->vals[1], &c->d_ctrl->n_visible, c->nf, 16, sc);
@@ -478,6 +482,7 @@ int b32_frame_finish(b32_ctx* c, B32Timings* out) {
         int rc;
         for (int i = 0; i < 2; ++i) { if ((rc = ensure_plain(c, c->pkeys[i], n))) return rc; if ((rc = ensure_plain(c, c->pvals[i], n))) return rc; }
         c->cap_pairs = n;
+        c->ev_frames = 0;                              // the aborted frame must not enter the phase averages
         if ((rc = enqueue_frame(c, &c->last_cam, &c->last_settings, c->last_has_fog ? &c->last_fog : nullptr))) return rc;
     }
     c->frame_pending = false;

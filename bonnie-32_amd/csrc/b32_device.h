@@ -145,6 +145,7 @@ __device__ __forceinline__ uint32_t blend_rgb555(uint32_t front, uint32_t back, 
 struct SortScratch {
     uint32_t* block_hist;   // [256][max_blocks] digit-major
     uint32_t  max_blocks;
+    uint32_t* digit_total;  // [256]
 };
 constexpr int SORT_THREADS = 256;
 constexpr int SORT_ITEMS = 16;
@@ -155,9 +156,12 @@ constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;   // 4096 keys per block
 void launch_radix_pass(hipStream_t s, const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
                        const uint32_t* n_dev, uint32_t n_cap, int shift, const SortScratch& sc);
 
+// k_setup publishes 5 counters per 256-face block (visible, transparent, nan_opaque, nan_transparent, bad_index) into
+// `partials[block*8 + k]`; k_after_setup reduces them into Ctrl.  (One same-address atomic per wave costs ~12 ns each and
+// serialises: 15.6 k waves = the whole kernel time at 1 M faces.)
 void launch_setup(hipStream_t s, const FrameParams& fp, const B32Vertex* verts, const B32Face* faces, const TexDesc* tex,
-                  const B32Light* lights, SurfRec* recs, float* shades, uint32_t* keys, Ctrl* ctrl);
-void launch_after_setup(hipStream_t s, Ctrl* ctrl);
+                  const B32Light* lights, SurfRec* recs, float* shades, uint32_t* keys, uint32_t* partials);
+void launch_after_setup(hipStream_t s, Ctrl* ctrl, const uint32_t* partials, uint32_t nblocks);
 void launch_project_fixed(hipStream_t s, const float* pos, uint32_t n, B32Camera cam, uint32_t w, uint32_t h,
                           int32_t* sx, int32_t* sy, float* z);
 void launch_selftest(hipStream_t s, int op, const float* a, const float* b, const float* c, float* out, uint32_t n);

@@ -371,7 +371,15 @@ __global__ __launch_bounds__(FILL_THREADS) void k_fill(FillArgs a) {
 
     // exact fragment-store count (Mpixels/s numerator)
     for (int off = 32; off > 0; off >>= 1) frag_count += __shfl_down(frag_count, off);
-    if (lane == 0 && frag_count) atomicAdd(&a.ctrl->fragments, frag_count);
+    unsigned long long* wf = reinterpret_cast<unsigned long long*>(smem);       // tilebuf is free now
+    __syncthreads();
+    if (lane == 0) wf[wave] = frag_count;
+    __syncthreads();
+    if (tid == 0) {                                                              // one same-address atomic per workgroup
+        unsigned long long t = 0;
+        for (int w = 0; w < FILL_WAVES; ++w) t += wf[w];
+        if (t) atomicAdd(&a.ctrl->fragments, t);
+    }
 }
 
 void launch_fill(hipStream_t s, const FillArgs& a, int n_cu) {

@@ -4,8 +4,8 @@
 // reduced to a 32-bit radix key by k_setup and only (key, surface id) pairs move.  Stability of every pass is what makes
 // equal keys keep face order, exactly like slice::sort_by.
 //
-// One pass = k_hist (per-block digit histogram, LDS atomics) -> k_scan (exclusive scan of the digit-major table, one
-// workgroup) -> k_scatter (per-wave match-any ranking with 8 ballots, no atomics, deterministic).
+// One pass = k_hist (per-block digit histogram, LDS atomics) -> k_scan_rows (one workgroup per digit scans its row of the
+// digit-major table) -> k_scatter (per-wave match-any ranking with 8 ballots, no atomics, deterministic).
 // The element count lives in device memory (it is produced by the previous kernel); grids are sized for the capacity
 // and surplus workgroups exit at once.
 #include "b32_device.h"
@@ -41,40 +41,56 @@ __global__ __launch_bounds__(SORT_THREADS) void k_hist(const uint32_t* __restric
     block_hist[threadIdx.x * max_blocks + blockIdx.x] = hist[threadIdx.x];
 }
 
-// Exclusive scan of block_hist[256][max_blocks] viewed as one array of length 256*nblocks_used (digit-major), in place.
-__global__ __launch_bounds__(1024) void k_scan(uint32_t* __restrict__ block_hist, uint32_t max_blocks, uint32_t nblocks) {
-    __shared__ uint32_t part[1024];
-    const uint32_t total = 256u * nblocks;
-    const uint32_t per = (total + 1023u) / 1024u;
-    const uint32_t lo = threadIdx.x * per, hi = min(lo + per, total);
-    uint32_t sum = 0;
-    for (uint32_t i = lo; i < hi; ++i) sum += block_hist[(i / nblocks) * max_blocks + (i % nblocks)];
-    part[threadIdx.x] = sum;
+// Row d of block_hist[256][max_blocks] (one workgroup per digit): exclusive scan over the blocks, in place, and the
+// row total into digit_total[d].  The scan across digits is folded into k_scatter (256 values, one per thread).
+__global__ __launch_bounds__(256) void k_scan_rows(uint32_t* __restrict__ block_hist, uint32_t max_blocks, uint32_t nblocks,
+                                                   uint32_t* __restrict__ digit_total) {
+    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t carry_s;
+    uint32_t* row = block_hist + (size_t)blockIdx.x * max_blocks;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
-    // Hillis-Steele inclusive scan over 1024 partials
-    for (uint32_t off = 1; off < 1024; off <<= 1) {
-        uint32_t v = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+    for (uint32_t base = 0; base < nblocks; base += 256) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < nblocks ? row[i] : 0;
+        uint32_t inc = v;
+        for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(inc, off); if (lane >= (uint32_t)off) inc += t; }
+        if (lane == 63) wsum[wave] = inc;
         __syncthreads();
-        part[threadIdx.x] += v;
+        uint32_t woff = carry_s;
+        for (uint32_t w = 0; w < wave; ++w) woff += wsum[w];
+        if (i < nblocks) row[i] = woff + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s += wsum[0] + wsum[1] + wsum[2] + wsum[3];
         __syncthreads();
     }
-    uint32_t run = part[threadIdx.x] - sum;
-    for (uint32_t i = lo; i < hi; ++i) {
-        uint32_t* p = &block_hist[(i / nblocks) * max_blocks + (i % nblocks)];
-        uint32_t v = *p; *p = run; run += v;
-    }
+    if (threadIdx.x == 0) digit_total[blockIdx.x] = carry_s;
 }
 
 __global__ __launch_bounds__(SORT_THREADS) void k_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                            uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                            const uint32_t* __restrict__ n_dev, int shift, int drop_invalid,
-                                                           const uint32_t* __restrict__ block_hist, uint32_t max_blocks) {
+                                                           const uint32_t* __restrict__ block_hist, uint32_t max_blocks,
+                                                           const uint32_t* __restrict__ digit_total) {
     __shared__ uint32_t wcnt[4][256];     // per-wave running digit counts, then exclusive prefix over waves
+    __shared__ uint32_t dbase[256];       // exclusive scan of the 256 digit totals
+    __shared__ uint32_t dws[4];
     const uint32_t n = *n_dev;
     const uint32_t base = blockIdx.x * SORT_TILE;
     if (base >= n) return;
     const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
     for (int w = 0; w < 4; ++w) wcnt[w][threadIdx.x] = 0;
+    {   // digit bases: exclusive scan of digit_total over the 256 threads
+        const uint32_t v = digit_total[threadIdx.x];
+        uint32_t inc = v;
+        for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(inc, off); if (lane >= (uint32_t)off) inc += t; }
+        if (lane == 63) dws[wave] = inc;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (uint32_t w = 0; w < wave; ++w) woff += dws[w];
+        dbase[threadIdx.x] = woff + inc - v;
+    }
     __syncthreads();
     const uint32_t wbase = base + wave * (SORT_ITEMS * 64);
     uint32_t key[SORT_ITEMS], val[SORT_ITEMS], rnk[SORT_ITEMS];
@@ -108,7 +124,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_scatter(const uint32_t* __rest
     __syncthreads();
     {   // thread d: exclusive prefix of digit d over the 4 waves + global base of (digit, block)
         const uint32_t d = threadIdx.x;
-        uint32_t run = block_hist[d * max_blocks + blockIdx.x];
+        uint32_t run = dbase[d] + block_hist[d * max_blocks + blockIdx.x];
         for (int w = 0; w < 4; ++w) { uint32_t c = wcnt[w][d]; wcnt[w][d] = run; run += c; }
     }
     __syncthreads();
@@ -129,9 +145,9 @@ void launch_radix_pass(hipStream_t s, const uint32_t* keys_in, const uint32_t* v
     const uint32_t nblocks = (n_cap + SORT_TILE - 1) / SORT_TILE;
     const int drop = vals_in == nullptr ? 1 : 0;
     hipLaunchKernelGGL(k_hist, dim3(nblocks), dim3(SORT_THREADS), 0, s, keys_in, n_dev, shift, drop, sc.block_hist, sc.max_blocks);
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, sc.block_hist, sc.max_blocks, nblocks);
+    hipLaunchKernelGGL(k_scan_rows, dim3(256), dim3(256), 0, s, sc.block_hist, sc.max_blocks, nblocks, sc.digit_total);
     hipLaunchKernelGGL(k_scatter, dim3(nblocks), dim3(SORT_THREADS), 0, s, keys_in, vals_in, keys_out, vals_out, n_dev, shift, drop,
-                       sc.block_hist, sc.max_blocks);
+                       sc.block_hist, sc.max_blocks, sc.digit_total);
 }
 
 }  // namespace b32

@@ -1,0 +1,50 @@
+"""Screen-band sharding of one frame across ranks and the gather of band rows.
+
+One process per GPU.  Rank r owns the contiguous rows [y0, y1) of the frame; transform/cull/setup run on every
+rank (inputs are replicated in each GPU's HBM), everything after is band-local; the only exchange step of the path
+is one gather of W*(y1-y0)*4 bytes per rank to rank 0 (RCCL over xGMI on GPUs; gloo in the CPU tests).
+The functions take any torch.distributed backend and any uint8 tensors, so the same code is covered by the
+world_size-2 gloo tests with the CPU oracle standing in for the band renderer.
+"""
+import torch
+import torch.distributed as dist
+
+
+def band_rows(height, world_size, rank):
+    """Rows [y0, y1) owned by `rank`: a balanced contiguous partition (sizes differ by at most one row)."""
+    base, extra = divmod(height, world_size)
+    y0 = rank * base + min(rank, extra)
+    y1 = y0 + base + (1 if rank < extra else 0)
+    return y0, y1
+
+
+def gather_bands(frame: torch.Tensor, width, height, world_size, rank, dst=0, group=None):
+    """Collect every rank's band rows into `frame` on rank `dst`.
+
+    frame: flat uint8 tensor of width*height*4 bytes on every rank; rank r has rendered rows band_rows(r) into it.
+    Equal bands use one gather straight into views of dst's frame; ragged bands are padded to the tallest band.
+    """
+    if world_size == 1:
+        return frame
+    row = width * 4
+    bands = [band_rows(height, world_size, r) for r in range(world_size)]
+    sizes = [(b[1] - b[0]) * row for b in bands]
+    y0, y1 = bands[rank]
+    mine = frame[y0 * row:y1 * row]
+    if len(set(sizes)) == 1:
+        out = [frame[b[0] * row:b[1] * row] for b in bands] if rank == dst else None
+        if rank == dst:
+            # gather forbids aliasing of input and output: stage dst's own band
+            out[dst] = torch.empty_like(mine)
+        dist.gather(mine, out, dst=dst, group=group)
+        return frame
+    mx = max(sizes)
+    send = torch.zeros(mx, dtype=frame.dtype, device=frame.device)
+    send[:mine.numel()] = mine
+    out = [torch.empty(mx, dtype=frame.dtype, device=frame.device) for _ in range(world_size)] if rank == dst else None
+    dist.gather(send, out, dst=dst, group=group)
+    if rank == dst:
+        for r, b in enumerate(bands):
+            if r != dst:
+                frame[b[0] * row:b[1] * row] = out[r][:sizes[r]]
+    return frame

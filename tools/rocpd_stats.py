@@ -1,0 +1,26 @@
+"""Summarise a rocprofv3 rocpd sqlite database (ROCm 7.2 default output) as a per-kernel stats table:
+calls, total / average / min / max duration, share of GPU kernel time.  Usage: rocpd_stats.py results.db [out.md]"""
+import sqlite3
+import sys
+
+
+def main():
+    db = sqlite3.connect(sys.argv[1])
+    cur = db.cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+    name_col = "name" if "name" in cols else ("kernel_name" if "kernel_name" in cols else cols[0])
+    q = f"select {name_col}, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) from kernels group by {name_col} order by 3 desc"
+    rows = list(cur.execute(q))
+    total = sum(r[2] for r in rows) or 1
+    lines = ["| kernel | calls | total ms | avg us | min us | max us | % |", "|---|---|---|---|---|---|---|"]
+    for n, c, s, a, mn, mx in rows:
+        short = n if len(n) < 90 else n[:87] + "..."
+        lines.append(f"| `{short}` | {c} | {s/1e6:.3f} | {a/1e3:.2f} | {mn/1e3:.2f} | {mx/1e3:.2f} | {100*s/total:.1f} |")
+    out = "\n".join(lines)
+    print(out)
+    if len(sys.argv) > 2:
+        open(sys.argv[2], "w").write(out + "\n")
+
+
+if __name__ == "__main__":
+    main()
