@@ -1,0 +1,381 @@
+"""np_model.py — second, independent restatement of bonnie-32's `render_mesh_15` in numpy float32 / int64.
+
+TEST INFRASTRUCTURE.  Purpose: the reference is Rust and cannot run here, and it holds no test that pins a pixel
+("parity unpinned").  This file is a second reading of the same Rust text, written in a different style
+from oracle/b32_oracle.c (whole-bbox vectorised per triangle, `np.add.accumulate` for the incremental edge walk,
+vectorised UNR division on int64 arrays, `argsort(kind="stable")` for the painter's order).  tests/ require the two
+restatements to agree bit-for-bit on whole frames; a misreading would have to be made identically in both to survive.
+
+Every function cites the reference file:line it follows (paths relative to /root/reference).
+Scope: perspective projection (fixed-point or float), painter's mode, affine textures, shading None/Flat/Gouraud with
+directional and point lights, fog, blend modes, editor alpha.
+"""
+import numpy as np
+
+f32 = np.float32
+I32_MIN, I32_MAX = -(2 ** 31), 2 ** 31 - 1
+
+
+# ---------------------------------------------------------------- Rust numeric-cast semantics on arrays
+def as_i32(x):
+    """`f32 as i32`: truncate, saturate, NaN -> 0."""
+    x = np.asarray(x, dtype=np.float32)
+    with np.errstate(invalid="ignore"):
+        t = np.trunc(x.astype(np.float64))
+    t = np.where(np.isnan(t), 0.0, t)
+    return np.clip(t, I32_MIN, I32_MAX).astype(np.int64)
+
+
+def as_usize(x):
+    x = np.asarray(x, dtype=np.float32)
+    t = np.trunc(x.astype(np.float64))
+    t = np.where(np.isnan(t), 0.0, t)
+    return np.clip(t, 0, 2.0 ** 63).astype(np.int64)
+
+
+def as_u8(x):
+    x = np.asarray(x, dtype=np.float32)
+    t = np.trunc(x.astype(np.float64))
+    t = np.where(np.isnan(t), 0.0, t)
+    return np.clip(t, 0, 255).astype(np.int64)
+
+
+def wrap32(x):
+    """two's-complement wrap of int64 values to i32 (release-mode / wrapping_* arithmetic)."""
+    return ((np.asarray(x, dtype=np.int64) + 2 ** 31) % 2 ** 32) - 2 ** 31
+
+
+# ---------------------------------------------------------------- fixed.rs
+UNR_TABLE = np.array([max(0, (0x40000 // (i + 0x100) + 1) // 2 - 0x101) for i in range(257)], dtype=np.int64)  # :20-31
+
+
+def fx_from_f32(x):                       # Fixed32::from_f32 :125-127
+    return as_i32(np.asarray(x, np.float32) * f32(4096.0))
+
+
+def fx_mul(a, b):                         # mul_fixed :161-165  (i64 product, arithmetic shift, truncating narrow)
+    return wrap32((np.asarray(a, np.int64) * np.asarray(b, np.int64)) >> 12)
+
+
+def fx_div_unr(n, d):                     # div_unr :178-230
+    n = np.asarray(n, np.int64); d = np.asarray(d, np.int64)
+    out = np.zeros(np.broadcast(n, d).shape, np.int64)
+    n, d = np.broadcast_arrays(n, d)
+    nz = d != 0
+    num = np.abs(n[nz]).astype(np.uint64)
+    den = np.abs(d[nz]).astype(np.uint64)
+    neg = (n[nz] < 0) != (d[nz] < 0)
+    bl = np.zeros(den.shape, np.int64)                  # bit length of den (1..32)
+    t = den.copy()
+    for s in (16, 8, 4, 2, 1):
+        m = t >= (np.uint64(1) << np.uint64(s))
+        bl += np.where(m, s, 0)
+        t = np.where(m, t >> np.uint64(s), t)
+    bl += (t > 0).astype(np.int64)
+    z = (32 - bl).astype(np.uint64)
+    d16 = ((den << z) >> np.uint64(16)).astype(np.int64)
+    idx = np.minimum((d16 - 0x7FC0) >> 7, 256)
+    u = UNR_TABLE[idx] + 0x101
+    nr1 = (0x2000080 - d16 * u) >> 8
+    nr2 = ((0x80 + nr1 * u) >> 8).astype(np.uint64)
+    raw = num * nr2                                     # < 2^64 for every i32 numerator
+    shift = (np.uint64(36) - z)
+    mag = (raw + (np.uint64(1) << (shift - np.uint64(1)))) >> shift
+    mag = np.minimum(mag, np.uint64(I32_MAX)).astype(np.int64)
+    out[nz] = np.where(neg, -mag, mag)
+    return out
+
+
+def project_fixed(pos, cam, width, height):
+    """fixed::project_fixed :424-441 -> (sx, sy) int64 arrays."""
+    p = [fx_from_f32(pos[:, i]) for i in range(3)]
+    c = [fx_from_f32(f32(cam.position[i])) for i in range(3)]
+    rel = [wrap32(p[i] - c[i]) for i in range(3)]                               # :370 (wrapping_sub :244-246)
+    def dot(b):
+        bb = [fx_from_f32(f32(b[i])) for i in range(3)]
+        return wrap32(wrap32(fx_mul(rel[0], bb[0]) + fx_mul(rel[1], bb[1])) + fx_mul(rel[2], bb[2]))   # :311-313
+    cx, cy, cz = dot(cam.basis_x), dot(cam.basis_y), dot(cam.basis_z)
+    distance, scale = fx_from_f32(f32(5.0)), fx_from_f32(f32(4.0))              # :396-397
+    vs = fx_from_f32(f32(f32(min(width, height)) / f32(2.0)) * f32(0.75))       # :398
+    half_w, half_h = wrap32((width // 2) << 12), wrap32((height // 2) << 12)   # :399-400
+    denom = wrap32(cz + distance)
+    absd = np.where(denom < 0, wrap32(-denom), denom)                           # i32::abs (wraps at MIN)
+    small = absd < 256                                                          # :406-408
+    safe = np.where(small, 4096, denom)
+    px = fx_div_unr(fx_mul(cx, scale), safe)
+    py = fx_div_unr(fx_mul(cy, scale), safe)
+    sx = wrap32(fx_mul(px, vs) + half_w) >> 12
+    sy = wrap32(fx_mul(py, vs) + half_h) >> 12
+    return np.where(small, half_w >> 12, sx), np.where(small, half_h >> 12, sy)
+
+
+# ---------------------------------------------------------------- math.rs
+def dot3(a, b):                            # Vec3::dot :23-25  (x*ox + y*oy) + z*oz, all f32
+    return (a[..., 0] * b[..., 0] + a[..., 1] * b[..., 1]) + a[..., 2] * b[..., 2]
+
+
+def normalize3(v):                         # :39-49
+    v = np.asarray(v, np.float32)
+    l = np.sqrt(dot3(v, v))
+    if l == 0:
+        return np.zeros(3, np.float32)
+    return (v / l).astype(np.float32)
+
+
+def rmin(a, b):
+    return np.fmin(a, b)                   # f32::min ignores NaN
+
+
+def rmax(a, b):
+    return np.fmax(a, b)
+
+
+# ---------------------------------------------------------------- colour helpers (render.rs / types.rs)
+DITHER = np.array([[-4, 0, -3, 1], [2, -2, 3, -1], [-3, 1, -4, 0], [3, -1, 2, -2]], np.int64)   # render.rs:1150-1155
+
+
+def expand5(v):                            # render.rs:1161-1163
+    return ((v << 3) | (v >> 2)) & 0xFF
+
+
+def blend555(front, back, mode):           # render.rs:1093-1145 on [...,3] uint arrays
+    f5, b5 = front >> 3, back >> 3
+    if mode == 1:
+        r = np.minimum((b5 + f5) // 2, 31)
+    elif mode == 2:
+        r = np.minimum(b5 + f5, 31)
+    elif mode == 3:
+        r = np.maximum(b5 - f5, 0)
+    elif mode == 4:
+        r = np.minimum(b5 + f5 // 4, 31)
+    elif mode == 5:
+        r = b5
+    else:
+        r = f5
+    return r << 3
+
+
+def shade_multi(normal, wpos, lights, ambient):
+    """shade_multi_light_color render.rs:1013-1071 for one vertex (f32 scalars)."""
+    t = np.array([ambient, ambient, ambient], np.float32)
+    for l in lights:
+        if not l.enabled:
+            continue
+        if l.light_type == 0:
+            neg = (np.asarray(l.direction, np.float32) * f32(-1.0)).astype(np.float32)
+            contrib = f32(rmax(dot3(normal, neg), f32(0.0)) * f32(l.intensity))
+        elif l.light_type == 1:
+            to_light = (np.asarray(l.position, np.float32) - wpos).astype(np.float32)
+            dist = np.sqrt(dot3(to_light, to_light))
+            if dist > f32(l.radius) or dist < f32(0.001):
+                contrib = f32(0.0)
+            else:
+                att = f32(1.0) - (dist / f32(l.radius))
+                ndl = rmax(dot3(normal, normalize3(to_light)), f32(0.0))
+                contrib = f32(f32(f32(ndl * f32(l.intensity)) * att) * att)
+        else:
+            raise NotImplementedError("spot lights use acos: outside the bit-exact contract")
+        col = np.array([l.color.r, l.color.g, l.color.b], np.float32) / f32(255.0)
+        t = (t + contrib * col).astype(np.float32)
+    return rmin(t, f32(1.0)).astype(np.float32)
+
+
+# ---------------------------------------------------------------- render_mesh_15, render.rs:2302-2572
+def render_mesh_15(pixels, width, height, vertices, faces, textures, camera, settings, fog=None):
+    """Draw into `pixels` (uint8 [H*W*4]); returns dict(triangles_drawn, fragments, draw_order, sx, sy)."""
+    img = pixels.reshape(height, width, 4)
+    pos = vertices["pos"].astype(np.float32)
+    nv = len(vertices)
+    cpos = np.asarray(camera.position, np.float32)
+    B = [np.asarray(b, np.float32) for b in (camera.basis_x, camera.basis_y, camera.basis_z)]
+    rel = (pos - cpos).astype(np.float32)
+    cam = np.stack([dot3(rel, B[0]), dot3(rel, B[1]), dot3(rel, B[2])], axis=1).astype(np.float32)   # math.rs:103-109
+    if settings.use_fixed_point:                                                                     # :2329-2345
+        sx, sy = project_fixed(pos, camera, width, height)
+        scr = np.stack([sx.astype(np.float32), sy.astype(np.float32), cam[:, 2] + f32(5.0)], axis=1)
+    else:                                                                                            # math.rs:117-136
+        vs = f32(f32(min(width, height)) / f32(2.0)) * f32(0.75)
+        denom = cam[:, 2] + f32(5.0)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            x = (cam[:, 0] * f32(4.0)) / denom * vs + f32(width) / f32(2.0)
+            y = (cam[:, 1] * f32(4.0)) / denom * vs + f32(height) / f32(2.0)
+        tiny = np.abs(denom) < f32(0.001)
+        scr = np.stack([np.where(tiny, f32(width) / f32(2.0), x), np.where(tiny, f32(height) / f32(2.0), y),
+                        np.where(tiny, cam[:, 2], denom)], axis=1).astype(np.float32)
+        sx = sy = None
+    if len(faces) and faces["v"].max() >= nv:
+        raise IndexError("vertex index out of range")                                                # :2375-2377
+
+    surfaces = []
+    for fi, face in enumerate(faces):
+        i0, i1, i2 = (int(k) for k in face["v"])
+        cz = cam[[i0, i1, i2], 2]
+        if (cz <= f32(0.1)).any():                                                                   # :2381-2385
+            continue
+        v1, v2, v3 = scr[i0], scr[i1], scr[i2]
+        signed_area = (v2[0] - v1[0]) * (v3[1] - v1[1]) - (v3[0] - v1[0]) * (v2[1] - v1[1])          # :2393
+        back = signed_area <= 0
+        tid = int(face["texture_id"])
+        tex = textures[tid] if tid < len(textures) else None                                         # textures.get(id)
+        transp = ((tex is not None and tex.blend_mode != 0) or face["blend_mode"] != 0 or face["editor_alpha"] < 255)
+        cols = [np.array([vertices[i]["r"], vertices[i]["g"], vertices[i]["b"], vertices[i]["blend"]], np.int64) for i in (i0, i1, i2)]
+        if fog is not None:                                                                          # :2419-2442
+            start, falloff, cull, fc = fog
+            if (cz > f32(cull)).all():
+                continue
+            fcol = np.array([fc.r, fc.g, fc.b, fc.blend], np.int64)
+            for k in range(3):
+                z = cz[k]
+                if z <= f32(start):
+                    fac = f32(0.0)
+                elif f32(falloff) <= 0:
+                    fac = f32(1.0)
+                else:
+                    fac = rmin((z - f32(start)) / f32(falloff), f32(1.0))
+                if fac <= 0:
+                    pass
+                elif fac >= 1:
+                    cols[k] = fcol.copy()
+                else:
+                    inv = f32(1.0) - fac
+                    rgb = as_u8(cols[k][:3].astype(np.float32) * inv + fcol[:3].astype(np.float32) * fac)
+                    cols[k] = np.array([rgb[0], rgb[1], rgb[2], 0], np.int64)
+        if back and settings.backface_cull:                                                          # :2445-2452
+            continue
+        order = (i0, i2, i1) if back else (i0, i1, i2)
+        corder = (0, 2, 1) if back else (0, 1, 2)
+        sgn = f32(-1.0) if back else f32(1.0)
+        surfaces.append(dict(
+            v=[scr[i] for i in order], w=[pos[i] for i in order],
+            wn=[(vertices["normal"][i].astype(np.float32) * sgn).astype(np.float32) if back else vertices["normal"][i].astype(np.float32) for i in order],
+            uv=[vertices["uv"][i].astype(np.float32) for i in order], vc=[cols[k] for k in corder],
+            face=fi, tex=tex, black_tr=bool(face["black_transparent"]), transp=bool(transp),
+            blend=int(tex.blend_mode if tex is not None else face["blend_mode"]), alpha=int(face["editor_alpha"])))
+
+    # sort, :2518-2545
+    key = np.array([f32(f32(s["v"][0][2] + s["v"][1][2]) + s["v"][2][2]) / f32(3.0) for s in surfaces], np.float32)
+    opaque = [i for i, s in enumerate(surfaces) if not s["transp"]]
+    transp = [i for i, s in enumerate(surfaces) if s["transp"]]
+    def painter(ids):
+        ids = np.array(ids, np.int64)
+        if len(ids) >= 2 and np.isnan(key[ids]).any():
+            raise FloatingPointError("NaN sort key")                                                 # unwrap panic :2531
+        return ids[np.argsort(-key[ids], kind="stable")] if len(ids) else ids
+    draw = list(painter(opaque)) + list(painter(transp))
+
+    fragments = 0
+    for si in draw:
+        fragments += _rasterize(img, width, height, surfaces[si], settings)
+    return dict(triangles_drawn=len(surfaces), fragments=fragments, draw_order=np.array([surfaces[i]["face"] for i in draw], np.uint32),
+                sx=sx, sy=sy, sz=scr[:, 2])
+
+
+def _rasterize(img, width, height, s, st):
+    """rasterize_triangle_15, render.rs:1440-1714, painter's mode, whole bbox at once."""
+    v1, v2, v3 = s["v"]
+    min_x = int(as_usize(rmax(rmin(rmin(v1[0], v2[0]), v3[0]), f32(0.0))))                            # :1455-1458
+    max_x = int(as_usize(rmin(rmax(rmax(v1[0], v2[0]), v3[0]) + f32(1.0), f32(width))))
+    min_y = int(as_usize(rmax(rmin(rmin(v1[1], v2[1]), v3[1]), f32(0.0))))
+    max_y = int(as_usize(rmin(rmax(rmax(v1[1], v2[1]), v3[1]) + f32(1.0), f32(height))))
+    if min_x >= max_x or min_y >= max_y:
+        return 0
+    area = (v2[1] - v3[1]) * (v1[0] - v3[0]) + (v3[0] - v2[0]) * (v1[1] - v3[1])                      # :1500
+    if abs(area) < f32(0.00001):
+        return 0
+    inv_area = f32(1.0) / area
+    a0, b0, a1, b1 = v2[1] - v3[1], v3[0] - v2[0], v3[1] - v1[1], v1[0] - v3[0]                       # :1507-1510
+    w0s = a0 * (f32(min_x) - v3[0]) + b0 * (f32(min_y) - v3[1])                                       # :1517-1518
+    w1s = a1 * (f32(min_x) - v3[0]) + b1 * (f32(min_y) - v3[1])
+    nx, ny = max_x - min_x, max_y - min_y
+    # incremental walk (:1706-1712) as sequential f32 accumulations: rows first, then along each row
+    def walk(start, row_step, col_step):
+        rows = np.add.accumulate(np.concatenate([[start], np.full(ny - 1, row_step, np.float32)]).astype(np.float32), dtype=np.float32)
+        grid = np.empty((ny, nx), np.float32)
+        grid[:, 0] = rows
+        if nx > 1:
+            grid[:, 1:] = col_step
+        return np.add.accumulate(grid, axis=1, dtype=np.float32)
+    w0, w1 = walk(w0s, b0, a0), walk(w1s, b1, a1)
+    bcx = (w0 * inv_area).astype(np.float32)
+    bcy = (w1 * inv_area).astype(np.float32)
+    bcz = ((f32(1.0) - bcx) - bcy).astype(np.float32)                                                 # :1538
+    E = f32(-0.0001)
+    inside = (bcx >= E) & (bcy >= E) & (bcz >= E)                                                     # :1542
+    uv = s["uv"]
+    tex = s["tex"]
+    if tex is not None:
+        u = ((bcx * uv[0][0] + bcy * uv[1][0]) + bcz * uv[2][0]).astype(np.float32)                   # :1565-1566
+        v = ((bcx * uv[0][1] + bcy * uv[1][1]) + bcz * uv[2][1]).astype(np.float32)
+        if tex.width == 0 or tex.height == 0 or tex.pixels.size == 0:
+            texel = np.zeros(u.shape, np.int64)
+        else:                                                                                         # types.rs:671-681
+            def wrapc(c, n):
+                r = np.fmod(c, f32(1.0)).astype(np.float32)
+                r = np.where(r < 0, (r + f32(1.0)).astype(np.float32), r)
+                return np.minimum(as_usize(r * f32(n)), n - 1)
+            tx = wrapc(u, tex.width)
+            ty = wrapc((f32(1.0) - v).astype(np.float32), tex.height)
+            texel = tex.pixels.astype(np.int64)[ty * tex.width + tx]
+    else:
+        texel = np.full(bcx.shape, 0x7FFF, np.int64)
+    black = (texel & 0x7FFF) == 0
+    if s["black_tr"]:
+        drawn = inside & ~black                                                                       # :1592-1608
+    else:
+        drawn = inside.copy()
+        texel = np.where(texel == 0, 0x8000, texel)
+    if s["alpha"] == 0:                                                                               # :1664-1669
+        return 0
+    ys, xs = np.nonzero(drawn)
+    if len(ys) == 0:
+        return 0
+    bx, by, bz, tx_ = bcx[ys, xs], bcy[ys, xs], bcz[ys, xs], texel[ys, xs]
+    px, py = xs + min_x, ys + min_y
+    chans = [(tx_ >> 10) & 31, (tx_ >> 5) & 31, tx_ & 31]
+    out5 = []
+    for i in range(3):
+        tex8 = expand5(chans[i])
+        vert = as_u8((bx * f32(s["vc"][0][i]) + by * f32(s["vc"][1][i])).astype(np.float32) + bz * f32(s["vc"][2][i]))   # :1618-1620
+        m = np.minimum((tex8 * vert) // 128, 255)                                                     # :1624-1626
+        if st.shading != 0:
+            if "_sh" not in s:
+                _prep_shades(s, st)
+            if st.shading == 1:
+                sv = np.full(bx.shape, s["_sh"][0][i], np.float32)
+            else:
+                sv = ((bx * s["_sh"][0][i] + by * s["_sh"][1][i]).astype(np.float32) + bz * s["_sh"][2][i]).astype(np.float32)
+            svc = np.where(sv < 0, f32(0.0), np.where(sv > 2, f32(2.0), sv)).astype(np.float32)      # clamp propagates NaN
+            m = as_u8(rmin((m.astype(np.float32) * svc).astype(np.float32), f32(255.0)))              # :1643-1645
+        out5.append(m)
+    vc = s["vc"]
+    needs_dither = st.dithering and (st.shading == 2 or tex is not None or not np.array_equal(vc[0], vc[1]) or not np.array_equal(vc[1], vc[2]))
+    if needs_dither:                                                                                  # :1173-1182
+        off = DITHER[py & 3, px & 3]
+        q = [np.clip((c + off) >> 3, 0, 31) for c in out5]
+    else:
+        q = [c >> 3 for c in out5]
+    all_black = (q[0] == 0) & (q[1] == 0) & (q[2] == 0)
+    semi = ((tx_ & 0x8000) != 0) | all_black                                                          # :1659-1661
+    front = np.stack([expand5(q[0]), expand5(q[1]), expand5(q[2])], axis=1)                           # Color15::r8 etc.
+    back = img[py, px, :3].astype(np.int64)
+    mode, alpha = s["blend"], s["alpha"]
+    do_blend = semi & (mode != 0)
+    ps1 = np.where(do_blend[:, None], blend555(front, back, mode), front)
+    if alpha < 255:                                                                                   # render.rs:567-591
+        res = (ps1 * alpha + back * (255 - alpha)) // 255
+    else:
+        res = ps1                                                                                     # :445-502
+    img[py, px, :3] = res.astype(np.uint8)
+    img[py, px, 3] = 255
+    return int(len(ys))
+
+
+def _prep_shades(s, st):
+    if st.shading == 1:                                                                               # :1466-1469
+        third = f32(1.0) / f32(3.0)
+        center = (((s["w"][0] + s["w"][1]).astype(np.float32) + s["w"][2]).astype(np.float32) * third).astype(np.float32)
+        n = normalize3((((s["wn"][0] + s["wn"][1]).astype(np.float32) + s["wn"][2]).astype(np.float32) * third).astype(np.float32))
+        sh = shade_multi(n, center, st.lights, f32(st.ambient))
+        s["_sh"] = [sh, sh, sh]
+    else:                                                                                             # :1475-1483
+        s["_sh"] = [shade_multi(s["wn"][k], s["w"][k], st.lights, f32(st.ambient)) for k in range(3)]

@@ -1,0 +1,73 @@
+"""Regenerates tests/golden/*.  Run from the repo root:  python tests/golden/make_golden.py
+
+The reference (Rust) cannot be built or run in this image, and its own tests pin no pixel, so these vectors are
+produced by the CPU oracle (oracle/b32_oracle.c) after it has been cross-checked against the independent numpy
+restatement (oracle/np_model.py).  They pin the oracle against regressions and travel to the GPU box as data.
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import bonnie32_amd as b32  # noqa: E402
+from bonnie32_amd import scenegen  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def fog_scene():
+    sc = scenegen.make_scene("C1", n_tris=3000, bbox_px=300.0, seed=77)
+    sc.fog = (1000.0, 3000.0, 5500.0, b32.Color(90, 100, 120))
+    sc.settings.shading = b32.abi.SHADE_FLAT
+    sc.settings.lights = [b32.Light.point((100.0, -50.0, 900.0), 2500.0, 1.5), b32.Light.directional((0.3, -1.0, 0.2), 0.5)]
+    sc.settings.backface_cull = False
+    return sc
+
+
+SCENES = {
+    "C1": lambda: scenegen.make_scene("C1"),
+    "C1:gouraud": lambda: scenegen.make_scene("C1", variant="gouraud"),
+    "C1:blend": lambda: scenegen.make_scene("C1", variant="blend"),
+    "C1:float": lambda: scenegen.make_scene("C1", variant="float"),
+    "cube": scenegen.cube_scene,
+    "fog-flat-point-nocull": fog_scene,
+    "C2": lambda: scenegen.make_scene("C2"),
+    "C2:blend": lambda: scenegen.make_scene("C2", variant="blend"),
+    "C3:100k": lambda: scenegen.make_scene("C3", n_tris=100_000),
+    "C5:20k": lambda: scenegen.make_scene("C5", n_tris=20_000),
+}
+
+
+def render(sc):
+    fb = O.Framebuffer(sc.width, sc.height)
+    fb.clear(sc.clear_color)
+    rc, tm, d = O.render_mesh_15(fb, sc.vertices, sc.faces, sc.textures, sc.camera, sc.settings, sc.fog, dump=True)
+    assert rc == 0
+    return fb, tm, d
+
+
+def main():
+    hashes = {}
+    for name, mk in SCENES.items():
+        sc = mk()
+        fb, tm, d = render(sc)
+        hashes[name] = {"sha256": hashlib.sha256(fb.pixels).hexdigest(), "triangles_drawn": tm.triangles_drawn,
+                        "fragments": tm.fragments, "width": sc.width, "height": sc.height,
+                        "draw_order_sha256": hashlib.sha256(d["draw_order"].tobytes()).hexdigest(),
+                        "scene_sha256": hashlib.sha256(sc.vertices.tobytes() + sc.faces.tobytes() + sc.textures[0].pixels.tobytes()).hexdigest()}
+        if name == "C1":
+            np.savez_compressed(os.path.join(OUT, "c1_frame.npz"), rgba=fb.pixels, sx=d["sx"], sy=d["sy"],
+                                sz_bits=d["sz"].view(np.uint32), draw_order=d["draw_order"])
+        if name == "cube":
+            np.savez_compressed(os.path.join(OUT, "cube_frame.npz"), rgba=fb.pixels, draw_order=d["draw_order"])
+        print(name, hashes[name]["sha256"][:16], tm.triangles_drawn, tm.fragments)
+    json.dump(hashes, open(os.path.join(OUT, "hashes.json"), "w"), indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()

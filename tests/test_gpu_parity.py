@@ -1,0 +1,207 @@
+"""Parity tests proper: the HIP path through the C ABI against the CPU oracle, bit-exact (integer/byte outputs and
+exact-order f32).  Every test needs a real MI355X and fails loudly if the HIP library or device is missing."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import bonnie32_amd as b32
+from bonnie32_amd import scenegen
+from tests.golden.make_golden import SCENES
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+HASHES = json.load(open(os.path.join(GOLD, "hashes.json")))
+
+
+def gpu_render(ctx, sc, resident=False, indexed=False, band=None):
+    from bonnie32_amd import rasterizer as R
+    fb = R.Framebuffer(sc.width, sc.height, ctx)
+    fb.clear(sc.clear_color)
+    if band:
+        fb.set_band(*band)
+    if resident:
+        rs = R.ResidentScene(fb, sc.vertices, sc.faces, None if indexed else sc.textures, sc.indexed_textures if indexed else None)
+        tm = rs.render(sc.camera, sc.settings, sc.fog)
+    else:
+        tm = R.render_mesh_15(fb, sc.vertices, sc.faces, sc.textures, sc.camera, sc.settings, sc.fog)
+    return fb.pixels, tm
+
+
+def cpu_render(oracle, sc):
+    fb = oracle.Framebuffer(sc.width, sc.height); fb.clear(sc.clear_color)
+    rc, tm, d = oracle.render_mesh_15(fb, sc.vertices, sc.faces, sc.textures, sc.camera, sc.settings, sc.fog, dump=True)
+    assert rc == 0
+    return fb.pixels, tm, d
+
+
+def test_device_f32_semantics(gpu_ctx):
+    """No FMA contraction, correctly rounded / and sqrt, denormals kept: the premises of bit-exactness."""
+    rng = np.random.default_rng(1)
+    a = (rng.standard_normal(1 << 16) * 1e3).astype(np.float32)
+    b = rng.standard_normal(1 << 16).astype(np.float32)
+    c = (rng.standard_normal(1 << 16) * 1e-3).astype(np.float32)
+    a[:8] = [1e-40, 3e-39, 1.0, 16777216.0, 1e38, -1e-45, 0.1, 3.0]
+    b[:8] = [0.5, 0.25, 3.0, 1.0, 10.0, 0.5, 0.2, 7.0]
+    with np.errstate(all="ignore"):
+        assert np.array_equal(gpu_ctx.selftest_f32(0, a, b, c), (a * b).astype(np.float32) + c)
+        assert np.array_equal(gpu_ctx.selftest_f32(1, a, b, c), a / b)
+        assert np.array_equal(gpu_ctx.selftest_f32(2, np.abs(a), b, c), np.sqrt(np.abs(a)))
+        assert np.array_equal(gpu_ctx.selftest_f32(3, a, b, c), (a + b) / c)
+
+
+def test_project_fixed_stage(gpu_ctx, oracle):
+    """fixed::project_fixed on the device vs the oracle, including saturating and wrapping inputs."""
+    rng = np.random.default_rng(7)
+    pos = (rng.standard_normal((20000, 3)) * np.array([3000, 3000, 4000])).astype(np.float32)
+    pos[:200] *= 1e4
+    pos[200:210] = [[3.0, 4.0, -5.0]] * 10
+    cam = b32.Camera(position=(12.5, -7.25, 3.0), basis_x=(0.8, 0.0, -0.6), basis_y=(0.0, 1.0, 0.0), basis_z=(0.6, 0.0, 0.8))
+    sx, sy, z = gpu_ctx.project_fixed_batch(pos, cam, 2560, 1920)
+    from oracle import np_model as M
+    ex, ey = M.project_fixed(pos, cam, 2560, 1920)
+    assert np.array_equal(sx, ex) and np.array_equal(sy, ey)
+    for i in range(0, 400):
+        assert oracle.project_fixed(pos[i], cam, 2560, 1920)[:2] == (sx[i], sy[i])
+
+
+@pytest.mark.parametrize("name", ["C1", "C1:gouraud", "C1:blend", "C1:float", "cube", "fog-flat-point-nocull", "C2", "C2:blend"])
+def test_frame_parity_small(gpu_ctx, oracle, name):
+    sc = SCENES[name]()
+    exp, etm, d = cpu_render(oracle, sc)
+    got, tm = gpu_render(gpu_ctx, sc)
+    assert np.array_equal(got, exp), f"{int((got != exp).sum())} bytes differ"
+    assert hashlib.sha256(got).hexdigest() == HASHES[name]["sha256"]
+    assert (tm.triangles_drawn, tm.fragments) == (etm.triangles_drawn, etm.fragments)
+    assert np.array_equal(gpu_ctx.last_draw_order(len(sc.faces)), d["draw_order"])
+
+
+def test_c1_against_committed_frame(gpu_ctx):
+    z = np.load(os.path.join(GOLD, "c1_frame.npz"))
+    got, tm = gpu_render(gpu_ctx, SCENES["C1"]())
+    assert np.array_equal(got, z["rgba"])
+    assert np.array_equal(gpu_ctx.last_draw_order(2000), z["draw_order"])
+
+
+@pytest.mark.parametrize("name", ["C3:100k", "C5:20k"])
+def test_frame_parity_large_frame(gpu_ctx, oracle, name):
+    """2560x1920 frames: resident scene, index atlas + CLUT expanded on the device, texture staged in LDS."""
+    sc = SCENES[name]()
+    got, tm = gpu_render(gpu_ctx, sc, resident=True, indexed=True)
+    assert hashlib.sha256(got).hexdigest() == HASHES[name]["sha256"]
+    assert (tm.triangles_drawn, tm.fragments) == (HASHES[name]["triangles_drawn"], HASHES[name]["fragments"])
+
+
+def test_full_size_c3_properties(gpu_ctx, oracle):
+    """BASELINE size (1M tris @ 2560x1920): exact parity against the oracle plus size-independent properties:
+    idempotence (same frame twice), band decomposition (union of band renders == whole frame), fragment count."""
+    sc = scenegen.make_scene("C3")
+    exp, etm, d = cpu_render(oracle, sc)
+    got, tm = gpu_render(gpu_ctx, sc, resident=True, indexed=True)
+    assert np.array_equal(got, exp)
+    assert (tm.triangles_drawn, tm.fragments) == (etm.triangles_drawn, etm.fragments)
+    assert np.array_equal(gpu_ctx.last_draw_order(len(sc.faces)), d["draw_order"])
+    z = d["sz"][sc.faces["v"][d["draw_order"]]]          # painter's order: key is non-increasing along the draw order
+    key = ((z[:, 0] + z[:, 1]) + z[:, 2]) / np.float32(3.0)
+    assert (np.diff(key) <= 0).all()
+    got2, _ = gpu_render(gpu_ctx, sc, resident=True, indexed=True)
+    assert np.array_equal(got2, got)
+    row = sc.width * 4
+    frags = 0
+    assembled = np.empty_like(got)
+    for y0, y1 in [(0, 700), (700, 701), (701, 1300), (1300, 1920)]:      # ragged, tile-unaligned bands
+        part, ptm = gpu_render(gpu_ctx, sc, resident=True, indexed=True, band=(y0, y1))
+        assembled[y0 * row:y1 * row] = part[y0 * row:y1 * row]
+        clear = np.tile(np.array([20, 22, 28, 255], np.uint8), sc.width)
+        assert np.array_equal(part[:y0 * row].reshape(-1, row), np.tile(clear, (y0, 1)))      # rows outside the band untouched
+        frags += ptm.fragments
+    assert np.array_equal(assembled, exp) and frags == etm.fragments
+
+
+def test_rmw_sequence_and_empty_mesh(gpu_ctx, oracle):
+    """Several render_mesh_15 calls onto one framebuffer (scene.rs:215/165), then an empty mesh."""
+    from bonnie32_amd import rasterizer as R
+    a = scenegen.make_scene("C1", seed=1); b = scenegen.make_scene("C1", variant="blend", seed=2)
+    ofb = oracle.Framebuffer(a.width, a.height); ofb.clear(a.clear_color)
+    fb = R.Framebuffer(a.width, a.height, gpu_ctx); fb.clear(a.clear_color)
+    for sc in (a, b, a):
+        oracle.render_mesh_15(ofb, sc.vertices, sc.faces, sc.textures, sc.camera, sc.settings)
+        R.render_mesh_15(fb, sc.vertices, sc.faces, sc.textures, sc.camera, sc.settings)
+    assert np.array_equal(fb.pixels, ofb.pixels)
+    tm = R.render_mesh_15(fb, b32.make_vertices(0), b32.make_faces(0), [], a.camera, a.settings)
+    assert tm.triangles_drawn == 0 and np.array_equal(fb.pixels, ofb.pixels)
+    # upload / download round trip and Framebuffer::resize zero-fill
+    fb.upload(ofb.pixels[::-1].copy()); assert np.array_equal(fb.pixels, ofb.pixels[::-1])
+    fb.resize(64, 48); assert not fb.pixels.any()
+
+
+def test_edge_cases(gpu_ctx, oracle):
+    """Off-screen / huge triangles (literal incremental-walk path), zero-area faces, untextured faces, out-of-range texture
+    id, black_transparent off, zero-size texture, texture wider than the LDS budget (global-memory sampling)."""
+    from bonnie32_amd import rasterizer as R
+    rng = np.random.default_rng(11)
+    n = 600
+    v = b32.make_vertices(3 * n); f = b32.make_faces(n, texture_id=0)
+    f["v"] = np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+    z = rng.uniform(1.0, 50.0, n).astype(np.float32)
+    for k in range(3):
+        v["pos"][k::3, 0] = rng.uniform(-200, 200, n) * (z / 8)
+        v["pos"][k::3, 1] = rng.uniform(-200, 200, n) * (z / 8)
+        v["pos"][k::3, 2] = z + rng.uniform(-0.5, 0.5, n)
+    v["pos"][0:30] *= np.float32(400.0)                     # coordinates far beyond 2^22 after projection
+    v["pos"][30:33] = v["pos"][33:36]                       # zero-area
+    v["uv"] = rng.uniform(-3, 3, (3 * n, 2)).astype(np.float32)
+    v["r"], v["g"], v["b"] = rng.integers(0, 256, (3, 3 * n), dtype=np.uint8)
+    f["texture_id"][::5] = b32.abi.NO_TEXTURE
+    f["texture_id"][1::7] = 9                                # out of range -> untextured (render.rs:2554-2556)
+    f["texture_id"][2::11] = 1                               # zero-size texture
+    f["black_transparent"][::3] = 0
+    tex = b32.Texture15(512, 300, rng.integers(0, 0x10000, 512 * 300).astype(np.uint16))
+    tex.pixels[::7] = 0; tex.pixels[3::13] = 0x8000
+    empty = b32.Texture15(0, 0, np.zeros(0, np.uint16))
+    st = b32.RasterSettings.benchmark(); st.backface_cull = False
+    for (w, h) in [(320, 240), (333, 197)]:
+        ofb = oracle.Framebuffer(w, h); ofb.clear(b32.Color(1, 2, 3))
+        rc, etm = oracle.render_mesh_15(ofb, v, f, [tex, empty], b32.Camera(), st)
+        assert rc == 0
+        fb = R.Framebuffer(w, h, gpu_ctx); fb.clear(b32.Color(1, 2, 3))
+        tm = R.render_mesh_15(fb, v, f, [tex, empty], b32.Camera(), st)
+        assert np.array_equal(fb.pixels, ofb.pixels)
+        assert (tm.triangles_drawn, tm.fragments) == (etm.triangles_drawn, etm.fragments)
+
+
+def test_painters_sort_ties_are_stable(gpu_ctx, oracle):
+    """C5-style scene: 64 discrete depths => massive key ties; equal keys must keep face order (stable sort_by)."""
+    sc = scenegen.make_scene("C5", n_tris=30_000, width=640, height=480, bbox_px=200.0)
+    exp, etm, d = cpu_render(oracle, sc)
+    got, tm = gpu_render(gpu_ctx, sc)
+    assert np.array_equal(gpu_ctx.last_draw_order(len(sc.faces)), d["draw_order"])
+    assert np.array_equal(got, exp)
+
+
+def test_error_behaviour(gpu_ctx, oracle):
+    """Reference panics become error codes; the framebuffer is left untouched (the reference panics before drawing)."""
+    from bonnie32_amd import rasterizer as R
+    sc = scenegen.make_scene("C1")
+    fb = R.Framebuffer(sc.width, sc.height, gpu_ctx); fb.clear(sc.clear_color)
+    before = fb.pixels
+    bad = sc.faces.copy(); bad["v"][17, 2] = len(sc.vertices)
+    with pytest.raises(R.B32Error) as e:
+        R.render_mesh_15(fb, sc.vertices, bad, sc.textures, sc.camera, sc.settings)
+    assert e.value.code == b32.abi.B32_E_INDEX and np.array_equal(fb.pixels, before)
+    vn = sc.vertices.copy(); vn["pos"][0, 2] = np.nan
+    assert oracle.render_mesh_15(oracle.Framebuffer(sc.width, sc.height), vn, sc.faces, sc.textures, sc.camera, sc.settings)[0] == b32.abi.B32_E_NAN_KEY
+    with pytest.raises(R.B32Error) as e:
+        R.render_mesh_15(fb, vn, sc.faces, sc.textures, sc.camera, sc.settings)
+    assert e.value.code == b32.abi.B32_E_NAN_KEY and np.array_equal(fb.pixels, before)
+    for st in (b32.RasterSettings(), b32.RasterSettings(use_zbuffer=True, backface_wireframe=False)):
+        with pytest.raises(R.B32Error) as e:
+            R.render_mesh_15(fb, sc.vertices, sc.faces, sc.textures, sc.camera, st)
+        assert e.value.code == b32.abi.B32_E_UNSUPPORTED
+
+
+def test_smoke_entry():
+    import __graft_entry__ as g
+    g.smoke()

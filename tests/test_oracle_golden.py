@@ -1,0 +1,73 @@
+"""The oracle against the committed golden vectors, and against the independent numpy restatement.  CPU only."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests.golden.make_golden import SCENES, render
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+HASHES = json.load(open(os.path.join(GOLD, "hashes.json")))
+FAST = ["C1", "C1:gouraud", "C1:blend", "C1:float", "cube", "fog-flat-point-nocull", "C2", "C2:blend", "C3:100k", "C5:20k"]
+
+
+@pytest.mark.parametrize("name", FAST)
+def test_oracle_matches_golden_hash(oracle, name):
+    sc = SCENES[name]()
+    g = HASHES[name]
+    scene_sha = hashlib.sha256(sc.vertices.tobytes() + sc.faces.tobytes() + sc.textures[0].pixels.tobytes()).hexdigest()
+    assert scene_sha == g["scene_sha256"], "scene generator is not deterministic"
+    fb, tm, d = render(sc)
+    assert hashlib.sha256(fb.pixels).hexdigest() == g["sha256"]
+    assert (tm.triangles_drawn, tm.fragments) == (g["triangles_drawn"], g["fragments"])
+    assert hashlib.sha256(d["draw_order"].tobytes()).hexdigest() == g["draw_order_sha256"]
+
+
+def test_c1_full_frame_fixture(oracle):
+    z = np.load(os.path.join(GOLD, "c1_frame.npz"))
+    fb, tm, d = render(SCENES["C1"]())
+    assert np.array_equal(fb.pixels, z["rgba"])
+    assert np.array_equal(d["sx"], z["sx"]) and np.array_equal(d["sy"], z["sy"])
+    assert np.array_equal(d["sz"].view(np.uint32), z["sz_bits"])
+    assert np.array_equal(d["draw_order"], z["draw_order"])
+
+
+def test_cube_fixture(oracle):
+    z = np.load(os.path.join(GOLD, "cube_frame.npz"))
+    fb, tm, d = render(SCENES["cube"]())
+    assert np.array_equal(fb.pixels, z["rgba"]) and np.array_equal(d["draw_order"], z["draw_order"])
+
+
+@pytest.mark.parametrize("name", ["C1", "C1:gouraud", "C1:blend", "C1:float", "cube", "fog-flat-point-nocull"])
+def test_two_restatements_agree(oracle, name):
+    """oracle/b32_oracle.c and oracle/np_model.py are two readings of the same Rust; whole frames must be identical."""
+    from oracle import np_model as M
+    sc = SCENES[name]()
+    fb, tm, d = render(sc)
+    px = np.zeros(sc.width * sc.height * 4, np.uint8)
+    px.reshape(-1, 4)[:] = [sc.clear_color.r, sc.clear_color.g, sc.clear_color.b, 255]
+    r = M.render_mesh_15(px, sc.width, sc.height, sc.vertices, sc.faces, sc.textures, sc.camera, sc.settings, sc.fog)
+    assert np.array_equal(px, fb.pixels)
+    assert np.array_equal(r["draw_order"], d["draw_order"])
+    assert (r["triangles_drawn"], r["fragments"]) == (tm.triangles_drawn, tm.fragments)
+    assert np.array_equal(r["sz"], d["sz"])
+    if r["sx"] is not None:
+        assert np.array_equal(r["sx"], d["sx"]) and np.array_equal(r["sy"], d["sy"])
+
+
+def test_rmw_two_meshes(oracle):
+    """render_mesh_15 is read-modify-write on fb (scene.rs:215 draws room after room onto the same framebuffer)."""
+    import bonnie32_amd as b32
+    from bonnie32_amd import scenegen
+    a = scenegen.make_scene("C1", seed=1); b = scenegen.make_scene("C1", variant="blend", seed=2)
+    fb = oracle.Framebuffer(a.width, a.height); fb.clear(a.clear_color)
+    oracle.render_mesh_15(fb, a.vertices, a.faces, a.textures, a.camera, a.settings)
+    first = fb.pixels.copy()
+    oracle.render_mesh_15(fb, b.vertices, b.faces, b.textures, b.camera, b.settings)
+    assert not np.array_equal(first, fb.pixels)
+    # empty mesh leaves the frame untouched
+    keep = fb.pixels.copy()
+    rc, tm = oracle.render_mesh_15(fb, b32.make_vertices(0), b32.make_faces(0), [], a.camera, a.settings)
+    assert rc == 0 and tm.triangles_drawn == 0 and np.array_equal(keep, fb.pixels)

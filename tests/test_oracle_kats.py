@@ -1,0 +1,157 @@
+"""Known-answer tests that pin the CPU oracle (oracle/b32_oracle.c) against the reference's OWN unit tests and the
+public specs its comments name.  Reference: /root/reference/src/rasterizer/{fixed.rs:473-549, math.rs:779-807,
+render.rs:1093-1182, types.rs:20-227}.  CPU only."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import bonnie32_amd as b32
+
+
+def fx(oracle, f):
+    return oracle.lib().b32o_fixed_from_f32(C.c_float(f))
+
+
+def to_f(oracle, v):
+    return oracle.lib().b32o_fixed_to_f32(v)
+
+
+def test_fixed32_precision(oracle):                      # fixed.rs:478-489 test_fixed32_precision
+    assert fx(oracle, 1.0) == 4096
+    assert fx(oracle, 0.5) == 2048
+    assert fx(oracle, 0.001) > 0
+
+
+def test_fixed32_mul(oracle):                            # fixed.rs:492-497
+    r = oracle.lib().b32o_fixed_mul(fx(oracle, 2.0), fx(oracle, 3.0))
+    assert abs(to_f(oracle, r) - 6.0) < 0.01
+
+
+def test_unr_division_has_error(oracle):                 # fixed.rs:500-510
+    r = oracle.lib().b32o_fixed_div_unr(fx(oracle, 10.0), fx(oracle, 3.0))
+    assert abs(to_f(oracle, r) - 10.0 / 3.0) < 0.1
+
+
+def test_unr_division_basic(oracle):                     # fixed.rs:513-531
+    L = oracle.lib()
+    assert abs(to_f(oracle, L.b32o_fixed_div_unr(fx(oracle, 10.0), fx(oracle, 2.0))) - 5.0) < 0.01
+    assert abs(to_f(oracle, L.b32o_fixed_div_unr(fx(oracle, -6.0), fx(oracle, 2.0))) + 3.0) < 0.01
+    assert abs(to_f(oracle, L.b32o_fixed_div_unr(fx(oracle, 7.5), fx(oracle, 1.0))) - 7.5) < 0.1
+
+
+def test_projection_outputs_integers(oracle):            # fixed.rs:534-548
+    x, y, _ = oracle.project_fixed((1.234, 2.567, 5.0), b32.Camera(), 320, 240)
+    assert -1000 < x < 1000 and -1000 < y < 1000
+
+
+def test_vec3_ops(oracle):                               # math.rs:784-799 (dot = 32, cross z = 1)
+    L = oracle.lib()
+    a = (C.c_float * 3)(1, 2, 3); b = (C.c_float * 3)(4, 5, 6)
+    assert L.b32o_vec3_dot(a, b) == 32.0
+    out = (C.c_float * 3)()
+    L.b32o_vec3_cross((C.c_float * 3)(1, 0, 0), (C.c_float * 3)(0, 1, 0), out)
+    assert list(out) == [0.0, 0.0, 1.0]
+
+
+def test_unr_table_matches_psx_spx(oracle):
+    """fixed.rs:18-19 names the psx-spx GTE table: first 16, last 5 and the checksum of the 257 entries."""
+    t = [oracle.lib().b32o_unr_table(i) for i in range(257)]
+    assert t[:16] == [0xFF, 0xFD, 0xFB, 0xF9, 0xF7, 0xF5, 0xF3, 0xF1, 0xEF, 0xEE, 0xEC, 0xEA, 0xE8, 0xE6, 0xE4, 0xE3]
+    assert t[-5:] == [1, 1, 0, 0, 0]
+    assert sum(t) == 25186
+    assert t == [max(0, (0x40000 // (i + 0x100) + 1) // 2 - 0x101) for i in range(257)]
+
+
+def test_div_unr_and_project_vectors(oracle):
+    """Integer answers derived independently during the survey with a scratch model."""
+    L = oracle.lib()
+    assert L.b32o_fixed_div_unr(40960, 12288) == 13653
+    assert L.b32o_fixed_div_unr(40960, 8192) == 20480
+    assert L.b32o_fixed_div_unr(-24576, 8192) == -12288
+    assert L.b32o_fixed_div_unr(30720, 4096) == 30720
+    assert L.b32o_fixed_div_unr(123, 0) == 0
+    assert oracle.project_fixed((1.234, 2.567, 5.0), b32.Camera(), 320, 240)[:2] == (204, 212)
+    assert oracle.project_fixed((1.234, 2.567, 5.0), b32.Camera(), 2560, 1920)[:2] == (1635, 1699)
+    assert oracle.project_fixed((-300.5, 120.25, 2000.0), b32.Camera(position=(10, 20, -30)), 320, 240)[:2] == (105, 137)
+    # near-zero denominator -> screen centre (fixed.rs:406-408)
+    assert oracle.project_fixed((3.0, 4.0, -5.0), b32.Camera(), 320, 240)[:2] == (160, 120)
+
+
+def test_project_fixed_matches_numpy_model(oracle):
+    from oracle import np_model as M
+    rng = np.random.default_rng(5)
+    pos = (rng.standard_normal((4000, 3)) * np.array([3000, 3000, 4000])).astype(np.float32)
+    pos[:50] *= 1e4                                       # saturating conversions / wrapping dot products
+    cam = b32.Camera(position=(12.5, -7.25, 3.0), basis_x=(0.8, 0.0, -0.6), basis_y=(0.0, 1.0, 0.0), basis_z=(0.6, 0.0, 0.8))
+    sx, sy = M.project_fixed(pos, cam, 640, 480)
+    for i in range(len(pos)):
+        x, y, _ = oracle.project_fixed(pos[i], cam, 640, 480)
+        assert (x, y) == (sx[i], sy[i]), i
+
+
+def test_dither_matrix_is_psx_spx(oracle):               # render.rs:1150-1155
+    m = [[oracle.lib().b32o_dither_offset(x, y) for x in range(4)] for y in range(4)]
+    assert m == [[-4, 0, -3, 1], [2, -2, 3, -1], [-3, 1, -4, 0], [3, -1, 2, -2]]
+    out = (C.c_uint8 * 3)()
+    oracle.lib().b32o_dither_and_quantize(0, 255, 130, 0, 0, out)      # offset -4: clamp low, (251>>3)=31, (126>>3)=15
+    assert list(out) == [0, 31, 15]
+    oracle.lib().b32o_dither_and_quantize(250, 5, 7, 2, 1, out)        # offset +3
+    assert list(out) == [31, 1, 1]
+
+
+@pytest.mark.parametrize("mode,expect", [(0, (16, 24, 248)), (1, (64, 64, 120)), (2, (136, 128, 248)),
+                                         (3, (104, 80, 0)), (4, (120, 104, 56)), (5, (120, 104, 0))])
+def test_blend_rgb555(oracle, mode, expect):             # render.rs:1093-1145: 5-bit maths, result << 3 (no bit replication)
+    out = (C.c_uint8 * 3)()
+    oracle.lib().b32o_blend_rgb555(20, 30, 250, 123, 110, 5, mode, out)
+    assert tuple(out) == expect
+
+
+def test_color15_to_rgba(oracle):                        # types.rs:220-226
+    out = (C.c_uint8 * 4)()
+    oracle.lib().b32o_color15_to_rgba(0x0000, out); assert list(out) == [0, 0, 0, 0]
+    oracle.lib().b32o_color15_to_rgba(0x7FFF, out); assert list(out) == [255, 255, 255, 255]
+    oracle.lib().b32o_color15_to_rgba(0x8000, out); assert list(out) == [0, 0, 0, 255]
+    oracle.lib().b32o_color15_to_rgba((1 << 10) | (2 << 5) | 31, out); assert list(out) == [8, 16, 255, 255]
+
+
+def test_texture_sample_wrapping(oracle):                # types.rs:671-681
+    px = np.arange(16, dtype=np.uint16) + 1
+    s = lambda u, v: oracle.lib().b32o_texture15_sample(px.ctypes.data, 4, 4, C.c_float(u), C.c_float(v))
+    assert s(0.0, 0.0) == 1 and s(0.99, 0.99) == 16
+    assert s(-0.25, 0.0) == 4                                   # rem_euclid: -0.25 -> 0.75
+    assert s(1.5, 2.25) == px[1 * 4 + 2]
+    assert s(-1e-10, 0.0) == 4                                  # rem_euclid gives exactly 1.0 -> clamped to width-1
+    assert s(float("nan"), 0.0) == 1                            # NaN as usize == 0
+    assert oracle.lib().b32o_texture15_sample(None, 0, 0, C.c_float(0.5), C.c_float(0.5)) == 0
+
+
+def test_indexed_expansion(oracle):                      # types.rs:390-397, mesh_editor.rs:669-682
+    idx = np.array([0, 1, 15, 16, 255], np.uint8)
+    clut = (np.arange(16) + 100).astype(np.uint16)
+    out = np.zeros(5, np.uint16)
+    oracle.lib().b32o_expand_indexed(idx.ctypes.data, 5, clut.ctypes.data, 16, out.ctypes.data)
+    assert list(out) == [100, 101, 115, 0, 0]
+    t = b32.IndexedTexture(5, 1, idx, clut).to_texture15()
+    assert list(t.pixels) == list(out)
+
+
+def test_error_codes(oracle):
+    sc_v = b32.make_vertices(3); sc_f = b32.make_faces(1)
+    sc_v["pos"] = [[0, 0, 10], [1, 0, 10], [0, 1, 10]]
+    sc_f["v"][0] = (0, 1, 7)
+    fb = oracle.Framebuffer(32, 32)
+    st = b32.RasterSettings.benchmark()
+    assert oracle.render_mesh_15(fb, sc_v, sc_f, [], b32.Camera(), st)[0] == b32.abi.B32_E_INDEX
+    sc_f["v"][0] = (0, 1, 2)
+    v2 = np.concatenate([sc_v, sc_v]); f2 = np.concatenate([sc_f, sc_f]); f2["v"][1] = (3, 4, 5)
+    v2["pos"][3:6] = [[0, 0, 20], [0, 1, 20], [1, 0, 20]]      # front-facing (y down)
+    v2["pos"][0:3] = [[0, 0, 10], [0, 1, 10], [1, 0, 10]]
+    v2["pos"][4, 2] = np.nan
+    st_nc = b32.RasterSettings.benchmark(); st_nc.backface_cull = False
+    assert oracle.render_mesh_15(fb, v2, f2, [], b32.Camera(), st_nc)[0] == b32.abi.B32_E_NAN_KEY
+    # a single surface never compares keys: no panic in the reference (sort_by on a 1-element slice)
+    assert oracle.render_mesh_15(fb, v2[3:6], sc_f, [], b32.Camera(), st_nc)[0] == 0
+    st2 = b32.RasterSettings()                                  # reference defaults: backface wireframe on -> out of scope
+    assert oracle.render_mesh_15(fb, sc_v, sc_f, [], b32.Camera(), st2)[0] == b32.abi.B32_E_UNSUPPORTED
