@@ -192,9 +192,10 @@ def test_error_behaviour(gpu_ctx, oracle):
         R.render_mesh_15(fb, sc.vertices, bad, sc.textures, sc.camera, sc.settings)
     assert e.value.code == b32.abi.B32_E_INDEX and np.array_equal(fb.pixels, before)
     vn = sc.vertices.copy(); vn["pos"][0, 2] = np.nan
-    assert oracle.render_mesh_15(oracle.Framebuffer(sc.width, sc.height), vn, sc.faces, sc.textures, sc.camera, sc.settings)[0] == b32.abi.B32_E_NAN_KEY
+    nc = b32.RasterSettings.benchmark(); nc.backface_cull = False      # keep the NaN face alive whatever its winding
+    assert oracle.render_mesh_15(oracle.Framebuffer(sc.width, sc.height), vn, sc.faces, sc.textures, sc.camera, nc)[0] == b32.abi.B32_E_NAN_KEY
     with pytest.raises(R.B32Error) as e:
-        R.render_mesh_15(fb, vn, sc.faces, sc.textures, sc.camera, sc.settings)
+        R.render_mesh_15(fb, vn, sc.faces, sc.textures, sc.camera, nc)
     assert e.value.code == b32.abi.B32_E_NAN_KEY and np.array_equal(fb.pixels, before)
     for st in (b32.RasterSettings(), b32.RasterSettings(use_zbuffer=True, backface_wireframe=False)):
         with pytest.raises(R.B32Error) as e:
