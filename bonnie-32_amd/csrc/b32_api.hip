@@ -37,6 +37,8 @@ struct b32_ctx {
     std::vector<TexDesc> h_tex;
     uint32_t nv = 0, nf = 0, nt = 0;
     bool have_scene = false;
+    bool cheap_ok = false;              // every texture has few skippable texels: CHEAP coverage + repair is profitable
+    int count_fragments = 1;            // 1: exact fragment-store count every frame (EXACT coverage)
 
     // per-face work buffers
     size_t cap_work = 0;
@@ -283,9 +285,13 @@ int b32_scene_upload(b32_ctx* c, const B32Vertex* v, uint32_t nv, const B32Face*
     size_t total = 0;
     int rc = layout_textures(c, nt, w.data(), h.data(), bl.data(), &total);
     if (rc) return rc;
+    c->cheap_ok = true;
     for (uint32_t i = 0; i < nt; ++i) {
         const size_t n = (size_t)w[i] * h[i];
         if (n) HIPCHK(c, hipMemcpyAsync(c->d_texels + c->h_tex[i].offset, tex[i].pixels, n * 2, hipMemcpyHostToDevice, c->stream));
+        size_t skippable = 0;                                               // texels the black_transparent rule can skip
+        for (size_t k = 0; k < n; ++k) skippable += (tex[i].pixels[k] & 0x7FFF) == 0;
+        if (n == 0 || skippable * 32 > n) c->cheap_ok = false;
     }
     if ((rc = upload_geometry(c, v, nv, f, nf))) return rc;
     c->have_scene = true;
@@ -304,9 +310,19 @@ int b32_scene_upload_indexed(b32_ctx* c, const B32Vertex* v, uint32_t nv, const 
     size_t total = 0;
     int rc = layout_textures(c, nt, w.data(), h.data(), bl.data(), &total);
     if (rc) return rc;
+    c->cheap_ok = true;
     for (uint32_t i = 0; i < nt; ++i) {
         const size_t n = (size_t)w[i] * h[i];
-        if (!n) continue;
+        if (!n) { c->cheap_ok = false; continue; }
+        {
+            size_t skippable = 0;
+            for (size_t k = 0; k < n; ++k) {
+                const uint32_t ix = tex[i].indices[k];
+                const uint16_t col = ix < tex[i].clut_len ? tex[i].clut[ix] : (uint16_t)0;
+                skippable += (col & 0x7FFF) == 0;
+            }
+            if (skippable * 32 > n) c->cheap_ok = false;
+        }
         uint8_t* d_idx = nullptr; uint16_t* d_clut = nullptr;
         HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d_idx), n));
         HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d_clut), (size_t)(tex[i].clut_len ? tex[i].clut_len : 1) * 2));
@@ -427,8 +443,9 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     fa.lds_tex_texels = 0;
     if (c->nt == 1) {
         const size_t n = (size_t)c->h_tex[0].width * c->h_tex[0].height;
-        if (n > 0 && n * 2 + 18496 + 16 <= 160 * 1024) fa.lds_tex_texels = (uint32_t)n;
+        if (n > 0 && n * 2 <= fill_lds_tex_budget()) fa.lds_tex_texels = (uint32_t)n;
     }
+    fa.exact_coverage = (c->count_fragments || !c->cheap_ok) ? 1u : 0u;
     launch_fill(s, fa, c->n_cu);
     if (prof_fill) { HIPCHK(c, hipEventRecord(ev[4], s)); c->ev_frames++; }
     HIPCHK(c, hipGetLastError());
@@ -587,6 +604,11 @@ int b32_last_kernel_times(b32_ctx* c, const char** names, float* ms, uint32_t ca
 }  // extern "C"
 
 // 0 = no events, 1 = events around k_fill, 2 = events around every phase.
+extern "C" int b32_set_fragment_counting(b32_ctx* c, int on) {
+    if (!c) return B32_E_ARG;
+    c->count_fragments = on ? 1 : 0;
+    return B32_OK;
+}
 extern "C" int b32_set_profiling(b32_ctx* c, int level) {
     if (!c) return B32_E_ARG;
     c->profile_level = level < 0 ? 0 : (level > 2 ? 2 : level);

@@ -183,7 +183,9 @@ struct FillArgs {
     uint32_t* fb;               // RGBA8 words, full frame
     Ctrl* ctrl;
     uint32_t lds_tex_texels;    // > 0: every face samples texture 0 and it is staged in LDS (width*height texels)
+    uint32_t exact_coverage;    // 1: phase A applies the full skip rule and counts fragment stores; 0: CHEAP coverage + repair
 };
 void launch_fill(hipStream_t s, const FillArgs& a, int n_cu);
+size_t fill_lds_tex_budget();   // bytes of LDS left for a staged texture
 
 }  // namespace b32

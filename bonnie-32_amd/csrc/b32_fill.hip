@@ -1,19 +1,27 @@
 // b32_fill.hip — affine texture-mapped triangle fill with RGB555 dither (rasterize_triangle_15, render.rs:1440-1714).
 //
 // Parallel decomposition (MI355X-first, not the reference's per-triangle scanline loop):
-//   * one persistent 1024-thread workgroup per CU pulls 64x64 screen tiles from a device-side cursor;
+//   * one persistent 1024-thread workgroup per CU pulls 64x64 screen tiles from a device-side cursor; the texture
+//     (<= 128 KB of Color15) is staged once per workgroup in LDS;
 //   * per tile, the surfaces binned to it arrive in painter's order (b32_bin.hip).  The opaque pass of the reference
 //     (render.rs:2553-2559) only ever overwrites pixels (set_pixel_15), so its result per pixel is the LAST surface in
 //     painter's order whose fragment is not skipped.  Phase A therefore runs all opaque surfaces of the tile in parallel
-//     (one wave per surface, lanes over the surface's own 8x8 pixel blocks) and resolves visibility with an LDS
-//     atomicMax on the surface's position in the tile list — order-independent, deterministic, no overdraw shading;
+//     (one wave per surface, lanes over the surface's own pixel blocks) and resolves visibility with an LDS atomicMax
+//     on the surface's position in the tile list — order-independent, deterministic, no overdraw shading.
+//       - EXACT coverage evaluates the whole skip rule per fragment (inside test + texel fetch + transparency,
+//         render.rs:1536-1607) and counts the reference's pixel stores exactly;
+//       - CHEAP coverage (textures with few skippable texels) evaluates only the inside test; the winner of a pixel is
+//         then the top covering surface.  Phase B detects the rare pixels whose winner's texel is skipped and phase B2
+//         repairs them: all 1024 threads scan the tile's surface list once against the short list of failed pixels and
+//         atomicMax the best surface *below* the failed one whose fragment is really drawn.  Result identical to EXACT.
 //   * phase B shades each covered pixel exactly once from its winning surface (colour pipeline render.rs:1613-1661)
 //     and stores RGBA8 (Color15::to_rgba) with row-coalesced writes;
 //   * surfaces of the transparent pass (render.rs:2563-2569) blend against the framebuffer, so they are walked strictly
 //     in order: each wave owns 4 rows of the tile (no two waves touch the same pixel, no atomics, no barriers between
 //     surfaces) and applies set_pixel_blended_15 / editor-alpha stores to the LDS-resident tile.
-// Surface records are fetched 64 at a time with per-lane 16-B loads and broadcast with v_readlane, so per-surface
-// parameters live in SGPRs while the lanes work on pixels.
+// Surface records are fetched up to 64 at a time with per-lane 16-B loads and broadcast with v_readlane, so per-surface
+// parameters live in SGPRs while the lanes work on pixels.  The 64 lanes of a wave cover an 8x8, 16x4 or 4x16 pixel
+// block, whichever needs the fewest blocks for the surface's (tile-clipped) bounding box.
 //
 // Bit-exactness: barycentrics use the reference's expression order; the edge functions are evaluated in closed form only
 // for surfaces k_setup proved exact (integer coordinates, every intermediate < 2^24), otherwise the incremental walk
@@ -22,14 +30,16 @@
 
 namespace b32 {
 
-constexpr int LDS_TILE_BYTES = TILE_H * TILE_STRIDE * 4;      // 18432
+constexpr int FAIL_CAP = 512;                                   // repair list of phase B2 (per tile)
+constexpr int LDS_TILE_BYTES = TILE_H * TILE_STRIDE * 4;        // 18432
 constexpr int LDS_MISC_BYTES = 64;
-constexpr int LDS_TEX_OFFSET = LDS_TILE_BYTES + LDS_MISC_BYTES;
+constexpr int LDS_FAIL_BYTES = FAIL_CAP * 12;                   // px | li | best
+constexpr int LDS_TEX_OFFSET = LDS_TILE_BYTES + LDS_MISC_BYTES + LDS_FAIL_BYTES;   // 24640
 
 __device__ __forceinline__ float bcf(float v, int t) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), t)); }
 __device__ __forceinline__ uint32_t bcu(uint32_t v, int t) { return (uint32_t)__builtin_amdgcn_readlane((int)v, t); }
 
-struct Tri {            // wave-uniform view of one SurfRec (+ its texture)
+struct Tri {            // one SurfRec (+ its texture), wave-uniform in phase A/C, per-lane in phase B
     float x3, y3, a0, b0, a1, b1, inv_area;
     float u1, u2, u3, v1, v2, v3;
     float w0_start, w1_start;
@@ -48,15 +58,18 @@ __device__ __forceinline__ uint32_t sample15(const Tri& t, const uint16_t* __res
     return gtex[t.toff + ty * t.tw + tx];
 }
 
-// Inside test + texel fetch + transparency rules (render.rs:1536-1607). Returns false when the fragment is not drawn.
-template <int TEXMODE>
-__device__ __forceinline__ bool cover(const Tri& t, float w0, float w1, const uint16_t* __restrict__ gtex, const uint16_t* ltex,
-                                      float& bcx, float& bcy, float& bcz, uint32_t& texel) {
-    bcx = w0 * t.inv_area;
+__device__ __forceinline__ bool inside_bc(const Tri& t, float w0, float w1, float& bcx, float& bcy, float& bcz) {
+    bcx = w0 * t.inv_area;                                       // render.rs:1536-1542
     bcy = w1 * t.inv_area;
     bcz = 1.0f - bcx - bcy;
     const float ERR = -0.0001f;
-    if (!(bcx >= ERR && bcy >= ERR && bcz >= ERR)) return false;
+    return bcx >= ERR && bcy >= ERR && bcz >= ERR;
+}
+
+// Texel fetch + transparency rules (render.rs:1563-1607). Returns false when the fragment is skipped.
+template <int TEXMODE>
+__device__ __forceinline__ bool texel_drawn(const Tri& t, float bcx, float bcy, float bcz, const uint16_t* __restrict__ gtex,
+                                            const uint16_t* ltex, uint32_t& texel) {
     uint32_t c = 0x7FFF;                                         // Color15::WHITE, render.rs:1585
     if ((t.flags & F_TEX_MASK) != F_TEX_NONE) {
         const float u = bcx * t.u1 + bcy * t.u2 + bcz * t.u3;    // affine, render.rs:1565-1566
@@ -122,6 +135,12 @@ __device__ __forceinline__ void replay_w(const Tri& t, uint32_t px, uint32_t py,
     for (uint32_t x = t.min_x; x < px; ++x) { r0 += t.a0; r1 += t.a1; }
     w0 = r0; w1 = r1;
 }
+__device__ __forceinline__ void edge_w(const Tri& t, uint32_t px, uint32_t py, float& w0, float& w1) {
+    if (!(t.flags & F_SLOW)) {                                   // exact integers (k_setup guard): closed form == accumulation
+        const float dx = (float)px - t.x3, dy = (float)py - t.y3;
+        w0 = t.a0 * dx + t.b0 * dy; w1 = t.a1 * dx + t.b1 * dy;
+    } else replay_w(t, px, py, w0, w1);
+}
 
 struct Batch {          // per-lane copy of one surface record (lane l <-> list entry chunk_start + l)
     uint4 q0, q1, q2, q3, q4, q5;
@@ -129,21 +148,27 @@ struct Batch {          // per-lane copy of one surface record (lane l <-> list 
 };
 
 template <int TEXMODE>
-__device__ __forceinline__ void load_batch(Batch& b, const FillArgs& a, uint32_t entry, bool live, const TexDesc& lds_desc) {
+__device__ __forceinline__ void load_batch(Batch& b, const FillArgs& a, uint32_t entry, bool live, const TexDesc& lds_desc, bool need_uv) {
     b.q0 = b.q1 = b.q2 = b.q3 = b.q4 = b.q5 = make_uint4(0, 0, 0, 0);
     b.tw = b.th = b.toff = 0;
     if (live) {
         const uint32_t sid = a.pair_vals[entry];
         const uint4* p = reinterpret_cast<const uint4*>(a.recs + sid);
-        b.q0 = p[0]; b.q1 = p[1]; b.q2 = p[2]; b.q3 = p[3]; b.q4 = p[4]; b.q5 = p[5];
-        const uint32_t tid = b.q3.w & F_TEX_MASK;
-        if (tid != F_TEX_NONE) {
-            if (TEXMODE == 1) { b.tw = lds_desc.width; b.th = lds_desc.height; b.toff = 0; }
-            else { const TexDesc d = a.tex[tid]; b.tw = d.width; b.th = d.height; b.toff = d.offset; }
+        b.q0 = p[0]; b.q1 = p[1]; b.q2 = p[2]; b.q3 = p[3];
+        if (need_uv) {
+            b.q4 = p[4]; b.q5 = p[5];
+            const uint32_t tid = b.q3.w & F_TEX_MASK;
+            if (tid != F_TEX_NONE) {
+                if (TEXMODE == 1) { b.tw = lds_desc.width; b.th = lds_desc.height; b.toff = 0; }
+                else { const TexDesc d = a.tex[tid]; b.tw = d.width; b.th = d.height; b.toff = d.offset; }
+            }
+        } else if (b.q3.w & F_SLOW) {
+            b.q4 = p[4]; b.q5 = p[5];
         }
     }
 }
-__device__ __forceinline__ Tri tri_from_batch(const Batch& b, int t) {
+// Wave-uniform view of lane t's record.  `full` = also UVs / texture (not needed by CHEAP coverage).
+__device__ __forceinline__ Tri tri_from_batch(const Batch& b, int t, bool full) {
     Tri r;
     r.x3 = bcf(__uint_as_float(b.q0.x), t); r.y3 = bcf(__uint_as_float(b.q0.y), t);
     r.a0 = bcf(__uint_as_float(b.q0.z), t); r.b0 = bcf(__uint_as_float(b.q0.w), t);
@@ -151,14 +176,21 @@ __device__ __forceinline__ Tri tri_from_batch(const Batch& b, int t) {
     r.inv_area = bcf(__uint_as_float(b.q1.z), t);
     const uint32_t bbx = bcu(b.q1.w, t), bby = bcu(b.q2.x, t);
     r.min_x = bbx & 0xFFFF; r.max_x = bbx >> 16; r.min_y = bby & 0xFFFF; r.max_y = bby >> 16;
-    r.u1 = bcf(__uint_as_float(b.q2.y), t); r.u2 = bcf(__uint_as_float(b.q2.z), t); r.u3 = bcf(__uint_as_float(b.q2.w), t);
-    r.v1 = bcf(__uint_as_float(b.q3.x), t); r.v2 = bcf(__uint_as_float(b.q3.y), t); r.v3 = bcf(__uint_as_float(b.q3.z), t);
     r.flags = bcu(b.q3.w, t);
-    r.w0_start = bcf(__uint_as_float(b.q4.w), t); r.w1_start = bcf(__uint_as_float(b.q5.x), t);
-    r.tw = bcu(b.tw, t); r.th = bcu(b.th, t); r.toff = bcu(b.toff, t);
+    r.u1 = r.u2 = r.u3 = r.v1 = r.v2 = r.v3 = 0.0f; r.tw = r.th = r.toff = 0; r.w0_start = r.w1_start = 0.0f;
+    if (full) {
+        r.u1 = bcf(__uint_as_float(b.q2.y), t); r.u2 = bcf(__uint_as_float(b.q2.z), t); r.u3 = bcf(__uint_as_float(b.q2.w), t);
+        r.v1 = bcf(__uint_as_float(b.q3.x), t); r.v2 = bcf(__uint_as_float(b.q3.y), t); r.v3 = bcf(__uint_as_float(b.q3.z), t);
+        r.tw = bcu(b.tw, t); r.th = bcu(b.th, t); r.toff = bcu(b.toff, t);
+    }
+    if (r.flags & F_SLOW) { r.w0_start = bcf(__uint_as_float(b.q4.w), t); r.w1_start = bcf(__uint_as_float(b.q5.x), t); }
     return r;
 }
-__device__ __forceinline__ Tri tri_from_rec(const uint4 q0, const uint4 q1, const uint4 q2, const uint4 q3, const uint4 q4, const uint4 q5) {
+template <int TEXMODE>
+__device__ __forceinline__ Tri tri_from_mem(const FillArgs& a, uint32_t sid, const TexDesc& lds_desc, uint4& q4) {
+    const uint4* rp = reinterpret_cast<const uint4*>(a.recs + sid);
+    const uint4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3], q5 = rp[5];
+    q4 = rp[4];
     Tri r;
     r.x3 = __uint_as_float(q0.x); r.y3 = __uint_as_float(q0.y); r.a0 = __uint_as_float(q0.z); r.b0 = __uint_as_float(q0.w);
     r.a1 = __uint_as_float(q1.x); r.b1 = __uint_as_float(q1.y); r.inv_area = __uint_as_float(q1.z);
@@ -168,14 +200,102 @@ __device__ __forceinline__ Tri tri_from_rec(const uint4 q0, const uint4 q1, cons
     r.flags = q3.w;
     r.w0_start = __uint_as_float(q4.w); r.w1_start = __uint_as_float(q5.x);
     r.tw = r.th = r.toff = 0;
+    const uint32_t txid = r.flags & F_TEX_MASK;
+    if (txid != F_TEX_NONE) {
+        if (TEXMODE == 1) { r.tw = lds_desc.width; r.th = lds_desc.height; }
+        else { const TexDesc d = a.tex[txid]; r.tw = d.width; r.th = d.height; r.toff = d.offset; }
+    }
     return r;
+}
+
+// Phase A for one surface: coverage of the (tile-clipped) bbox [cx0,cx1) x [cy0,cy1), winner value li.
+template <int TEXMODE, bool EXACT>
+__device__ __forceinline__ uint32_t cover_surface(const Tri& tr, uint32_t cx0, uint32_t cx1, uint32_t cy0, uint32_t cy1, uint32_t li,
+                                                  uint32_t* tilebuf, uint32_t x_lo, uint32_t ty_top, uint32_t lane,
+                                                  const uint16_t* __restrict__ gtex, const uint16_t* ltex) {
+    uint32_t drawn_count = 0;
+    if (!(tr.flags & F_SLOW)) {
+        // lane block shape: the one needing the fewest blocks (ties -> 8x8)
+        const uint32_t w = cx1 - cx0, h = cy1 - cy0;
+        const uint32_t n88 = ((w + 7) >> 3) * ((h + 7) >> 3), n164 = ((w + 15) >> 4) * ((h + 3) >> 2), n416 = ((w + 3) >> 2) * ((h + 15) >> 4);
+        uint32_t sh = 3;                                          // log2(block width)
+        if (n164 < n88 && n164 <= n416) sh = 4; else if (n416 < n88) sh = 2;
+        const uint32_t bw = 1u << sh, bh = 64u >> sh;
+        const uint32_t lx = lane & (bw - 1), ly = lane >> sh;
+        for (uint32_t by = cy0; by < cy1; by += bh) {
+            const uint32_t py = by + ly;
+            const float dy = (float)py - tr.y3;
+            const float r0 = tr.b0 * dy, r1 = tr.b1 * dy;
+            for (uint32_t bx = cx0; bx < cx1; bx += bw) {
+                const uint32_t px = bx + lx;
+                bool drawn = false;
+                if (px < cx1 && py < cy1) {
+                    const float dx = (float)px - tr.x3;
+                    const float w0 = tr.a0 * dx + r0, w1 = tr.a1 * dx + r1;          // exact integers (k_setup guard)
+                    float bcx, bcy, bcz;
+                    if (inside_bc(tr, w0, w1, bcx, bcy, bcz)) {
+                        uint32_t texel;
+                        drawn = EXACT ? texel_drawn<TEXMODE>(tr, bcx, bcy, bcz, gtex, ltex, texel) : true;
+                        if (drawn) atomicMax(&tilebuf[(py - ty_top) * TILE_STRIDE + (px - x_lo)], li);
+                    }
+                }
+                if (EXACT) drawn_count += (uint32_t)__popcll(__ballot(drawn));
+            }
+        }
+    } else {
+        for (uint32_t by = cy0; by < cy1; by += 64) {               // one lane per row, literal incremental walk
+            const uint32_t py = by + lane;
+            uint32_t mine = 0;
+            if (py < cy1) {
+                float w0, w1;
+                replay_w(tr, cx0, py, w0, w1);
+                for (uint32_t px = cx0; px < cx1; ++px) {
+                    float bcx, bcy, bcz;
+                    if (inside_bc(tr, w0, w1, bcx, bcy, bcz)) {
+                        uint32_t texel;
+                        const bool drawn = EXACT ? texel_drawn<TEXMODE>(tr, bcx, bcy, bcz, gtex, ltex, texel) : true;
+                        if (drawn) { atomicMax(&tilebuf[(py - ty_top) * TILE_STRIDE + (px - x_lo)], li); ++mine; }
+                    }
+                    w0 += tr.a0; w1 += tr.a1;
+                }
+            }
+            if (EXACT) for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
+            if (EXACT) drawn_count += (uint32_t)__builtin_amdgcn_readfirstlane((int)mine);
+        }
+    }
+    return drawn_count;
+}
+
+template <int TEXMODE, bool EXACT>
+__device__ __forceinline__ unsigned long long phase_a(const FillArgs& a, uint32_t e0, uint32_t n_op, uint32_t wave, uint32_t lane,
+                                                      const TexDesc& lds_desc, uint32_t* tilebuf, uint32_t x_lo, uint32_t x_hi,
+                                                      uint32_t y_lo, uint32_t y_hi, uint32_t ty_top, const uint16_t* ltex) {
+    unsigned long long frags = 0;
+    uint32_t chunk = (n_op + FILL_WAVES - 1) / FILL_WAVES;
+    chunk = min(max(chunk, 1u), 64u);
+    for (uint32_t cs = wave * chunk; cs < n_op; cs += FILL_WAVES * chunk) {
+        const uint32_t cnt = min(chunk, n_op - cs);
+        Batch b;
+        load_batch<TEXMODE>(b, a, e0 + cs + lane, lane < cnt, lds_desc, EXACT);
+        for (uint32_t t = 0; t < cnt; ++t) {
+            const Tri tr = tri_from_batch(b, (int)t, EXACT);
+            const uint32_t cx0 = max(tr.min_x, x_lo), cx1 = min(tr.max_x, x_hi);
+            const uint32_t cy0 = max(tr.min_y, y_lo), cy1 = min(tr.max_y, y_hi);
+            if (cx0 >= cx1 || cy0 >= cy1) continue;
+            frags += cover_surface<TEXMODE, EXACT>(tr, cx0, cx1, cy0, cy1, cs + t + 1, tilebuf, x_lo, ty_top, lane, a.texels, ltex);
+        }
+    }
+    return frags;
 }
 
 template <int TEXMODE>
 __global__ __launch_bounds__(FILL_THREADS) void k_fill(FillArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* tilebuf = reinterpret_cast<uint32_t*>(smem);
-    volatile uint32_t* misc = reinterpret_cast<volatile uint32_t*>(smem + LDS_TILE_BYTES);
+    volatile uint32_t* misc = reinterpret_cast<volatile uint32_t*>(smem + LDS_TILE_BYTES);   // [0] tile, [1] fail count
+    uint32_t* fail_px = reinterpret_cast<uint32_t*>(smem + LDS_TILE_BYTES + LDS_MISC_BYTES);
+    uint32_t* fail_li = fail_px + FAIL_CAP;
+    uint32_t* fail_best = fail_li + FAIL_CAP;
     const uint16_t* ltex = reinterpret_cast<const uint16_t*>(smem + LDS_TEX_OFFSET);
 
     if (a.ctrl->abort) return;
@@ -196,7 +316,7 @@ __global__ __launch_bounds__(FILL_THREADS) void k_fill(FillArgs a) {
     unsigned long long frag_count = 0;
 
     for (;;) {
-        if (tid == 0) misc[0] = atomicAdd(&a.ctrl->tile_cursor, 1u);
+        if (tid == 0) { misc[0] = atomicAdd(&a.ctrl->tile_cursor, 1u); misc[1] = 0; }
         __syncthreads();
         const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)misc[0]);
         if (tile >= ntiles) break;
@@ -207,99 +327,110 @@ __global__ __launch_bounds__(FILL_THREADS) void k_fill(FillArgs a) {
             const uint32_t ty_top = tyi * TILE_H;
             const uint32_t y_lo = max(ty_top, fp.band_y0), y_hi = min(ty_top + TILE_H, fp.band_y1);
             const bool has_tr = e1 != e2;
-
-            // ---- phase 0: clear the visibility buffer
-            for (uint32_t i = tid; i < TILE_H * TILE_STRIDE; i += FILL_THREADS) tilebuf[i] = 0;
-            __syncthreads();
-
-            // ---- phase A: opaque coverage, winner = max list position (LDS atomicMax)
             const uint32_t n_op = e1 - e0;
-            if (n_op) {
-                uint32_t chunk = (n_op + FILL_WAVES - 1) / FILL_WAVES;
-                chunk = min(max(chunk, 1u), 64u);
-                for (uint32_t cs = wave * chunk; cs < n_op; cs += FILL_WAVES * chunk) {
-                    const uint32_t cnt = min(chunk, n_op - cs);
-                    Batch b;
-                    load_batch<TEXMODE>(b, a, e0 + cs + lane, lane < cnt, lds_desc);
-                    for (uint32_t t = 0; t < cnt; ++t) {
-                        const Tri tr = tri_from_batch(b, (int)t);
-                        const uint32_t cx0 = max(tr.min_x, x_lo), cx1 = min(tr.max_x, x_hi);
-                        const uint32_t cy0 = max(tr.min_y, y_lo), cy1 = min(tr.max_y, y_hi);
-                        if (cx0 >= cx1 || cy0 >= cy1) continue;
-                        const uint32_t li = cs + t + 1;
-                        if (!(tr.flags & F_SLOW)) {
-                            for (uint32_t by = cy0; by < cy1; by += 8)
-                                for (uint32_t bx = cx0; bx < cx1; bx += 8) {
-                                    const uint32_t px = bx + (lane & 7), py = by + (lane >> 3);
-                                    if (px < cx1 && py < cy1) {
-                                        const float dx = (float)px - tr.x3, dy = (float)py - tr.y3;
-                                        const float w0 = tr.a0 * dx + tr.b0 * dy, w1 = tr.a1 * dx + tr.b1 * dy;   // exact integers (k_setup guard)
-                                        float bx_, by_, bz_; uint32_t texel;
-                                        if (cover<TEXMODE>(tr, w0, w1, a.texels, ltex, bx_, by_, bz_, texel)) {
-                                            atomicMax(&tilebuf[(py - ty_top) * TILE_STRIDE + (px - x_lo)], li);
-                                            ++frag_count;
-                                        }
-                                    }
-                                }
-                        } else {
-                            for (uint32_t by = cy0; by < cy1; by += 64) {       // one lane per row, literal incremental walk
-                                const uint32_t py = by + lane;
-                                if (py < cy1) {
-                                    float w0, w1;
-                                    replay_w(tr, cx0, py, w0, w1);
-                                    for (uint32_t px = cx0; px < cx1; ++px) {
-                                        float bx_, by_, bz_; uint32_t texel;
-                                        if (cover<TEXMODE>(tr, w0, w1, a.texels, ltex, bx_, by_, bz_, texel)) {
-                                            atomicMax(&tilebuf[(py - ty_top) * TILE_STRIDE + (px - x_lo)], li);
-                                            ++frag_count;
-                                        }
-                                        w0 += tr.a0; w1 += tr.a1;
-                                    }
-                                }
-                            }
+            bool exact = a.exact_coverage != 0;
+
+            for (int attempt = 0; attempt < 2; ++attempt) {
+                // ---- phase 0: clear the visibility buffer
+                for (uint32_t i = tid; i < TILE_H * TILE_STRIDE; i += FILL_THREADS) tilebuf[i] = 0;
+                __syncthreads();
+
+                // ---- phase A: opaque coverage, winner = max list position (LDS atomicMax)
+                if (n_op) {
+                    if (exact) frag_count += phase_a<TEXMODE, true>(a, e0, n_op, wave, lane, lds_desc, tilebuf, x_lo, x_hi, y_lo, y_hi, ty_top, ltex);
+                    else phase_a<TEXMODE, false>(a, e0, n_op, wave, lane, lds_desc, tilebuf, x_lo, x_hi, y_lo, y_hi, ty_top, ltex);
+                }
+                __syncthreads();
+
+                // ---- phase B: shade every covered pixel once from its winning surface
+#pragma unroll 1
+                for (uint32_t k = 0; k < (TILE_W * TILE_H) / FILL_THREADS; ++k) {
+                    const uint32_t p = tid + k * FILL_THREADS;
+                    const uint32_t row = p >> 6, col = p & 63;
+                    const uint32_t px = x_lo + col, py = ty_top + row;
+                    const bool inb = px < x_hi && py >= y_lo && py < y_hi;
+                    const uint32_t li = tilebuf[row * TILE_STRIDE + col];
+                    uint32_t rgba = 0;
+                    bool have = false;
+                    if (inb && li) {
+                        const uint32_t sid = a.pair_vals[e0 + li - 1];
+                        uint4 q4;
+                        const Tri tr = tri_from_mem<TEXMODE>(a, sid, lds_desc, q4);
+                        float w0, w1, bcx, bcy, bcz;
+                        edge_w(tr, px, py, w0, w1);
+                        inside_bc(tr, w0, w1, bcx, bcy, bcz);                                     // true by construction
+                        uint32_t texel = 0;
+                        if (texel_drawn<TEXMODE>(tr, bcx, bcy, bcz, a.texels, ltex, texel)) {
+                            float shv[9];
+                            if (shading != B32_SHADE_NONE) for (int j = 0; j < 9; ++j) shv[j] = a.shades[(size_t)sid * 9 + j];
+                            const uint32_t out15 = shade15(texel, bcx, bcy, bcz, q4.x, q4.y, q4.z, tr.flags, shading, shv, px, py);
+                            rgba = c15_to_rgba(out15);                                            // set_pixel_15
+                            have = true;
+                            if (!has_tr) a.fb[(size_t)py * fp.width + px] = rgba;
+                        } else {                                                                  // only reachable with CHEAP coverage
+                            const uint32_t slot = atomicAdd(const_cast<uint32_t*>(&misc[1]), 1u);
+                            if (slot < FAIL_CAP) { fail_px[slot] = p; fail_li[slot] = li; fail_best[slot] = 0; }
+                        }
+                    }
+                    if (has_tr) {
+                        if (inb && !have) rgba = a.fb[(size_t)py * fp.width + px];
+                        tilebuf[row * TILE_STRIDE + col] = rgba;
+                    }
+                }
+                if (exact) break;
+                __syncthreads();
+                const uint32_t n_fail = misc[1];
+                if (n_fail == 0) break;
+                if (n_fail > FAIL_CAP) {                       // too many skipped winners: redo this tile with EXACT coverage
+                    __syncthreads();
+                    if (tid == 0) misc[1] = 0;
+                    exact = true;
+                    __syncthreads();
+                    continue;
+                }
+                // ---- phase B2: repair pixels whose top surface was skipped: best drawn surface strictly below it
+                for (uint32_t e = tid; e < n_op; e += FILL_THREADS) {
+                    const uint32_t sid = a.pair_vals[e0 + e];
+                    const uint4* rp = reinterpret_cast<const uint4*>(a.recs + sid);
+                    const uint32_t bbx = rp[1].w, bby = rp[2].x;
+                    const uint32_t mnx = bbx & 0xFFFF, mxx = bbx >> 16, mny = bby & 0xFFFF, mxy = bby >> 16;
+                    bool loaded = false;
+                    Tri tr; uint4 q4;
+                    for (uint32_t f = 0; f < n_fail; ++f) {
+                        const uint32_t p = fail_px[f];
+                        const uint32_t px = x_lo + (p & 63), py = ty_top + (p >> 6);
+                        if (e + 1 < fail_li[f] && px >= mnx && px < mxx && py >= mny && py < mxy) {
+                            if (!loaded) { tr = tri_from_mem<TEXMODE>(a, sid, lds_desc, q4); loaded = true; }
+                            float w0, w1, bcx, bcy, bcz;
+                            edge_w(tr, px, py, w0, w1);
+                            uint32_t texel;
+                            if (inside_bc(tr, w0, w1, bcx, bcy, bcz) && texel_drawn<TEXMODE>(tr, bcx, bcy, bcz, a.texels, ltex, texel))
+                                atomicMax(&fail_best[f], e + 1);
                         }
                     }
                 }
-            }
-            __syncthreads();
-
-            // ---- phase B: shade every covered pixel once from its winning surface
-#pragma unroll 1
-            for (uint32_t k = 0; k < (TILE_W * TILE_H) / FILL_THREADS; ++k) {
-                const uint32_t p = tid + k * FILL_THREADS;
-                const uint32_t row = p >> 6, col = p & 63;
-                const uint32_t px = x_lo + col, py = ty_top + row;
-                const bool inb = px < x_hi && py >= y_lo && py < y_hi;
-                const uint32_t li = tilebuf[row * TILE_STRIDE + col];
-                uint32_t rgba = 0;
-                if (inb && li) {
-                    const uint32_t sid = a.pair_vals[e0 + li - 1];
-                    const uint4* rp = reinterpret_cast<const uint4*>(a.recs + sid);
-                    const uint4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3], q4 = rp[4], q5 = rp[5];
-                    Tri tr = tri_from_rec(q0, q1, q2, q3, q4, q5);
-                    const uint32_t txid = tr.flags & F_TEX_MASK;
-                    if (txid != F_TEX_NONE) {
-                        if (TEXMODE == 1) { tr.tw = lds_desc.width; tr.th = lds_desc.height; tr.toff = 0; }
-                        else { const TexDesc d = a.tex[txid]; tr.tw = d.width; tr.th = d.height; tr.toff = d.offset; }
+                __syncthreads();
+                if (tid < n_fail) {
+                    const uint32_t p = fail_px[tid], li = fail_best[tid];
+                    if (li) {
+                        const uint32_t row = p >> 6, col = p & 63;
+                        const uint32_t px = x_lo + col, py = ty_top + row;
+                        const uint32_t sid = a.pair_vals[e0 + li - 1];
+                        uint4 q4;
+                        const Tri tr = tri_from_mem<TEXMODE>(a, sid, lds_desc, q4);
+                        float w0, w1, bcx, bcy, bcz;
+                        edge_w(tr, px, py, w0, w1);
+                        inside_bc(tr, w0, w1, bcx, bcy, bcz);
+                        uint32_t texel = 0;
+                        texel_drawn<TEXMODE>(tr, bcx, bcy, bcz, a.texels, ltex, texel);
+                        float shv[9];
+                        if (shading != B32_SHADE_NONE) for (int j = 0; j < 9; ++j) shv[j] = a.shades[(size_t)sid * 9 + j];
+                        const uint32_t rgba = c15_to_rgba(shade15(texel, bcx, bcy, bcz, q4.x, q4.y, q4.z, tr.flags, shading, shv, px, py));
+                        if (has_tr) tilebuf[row * TILE_STRIDE + col] = rgba;
+                        else a.fb[(size_t)py * fp.width + px] = rgba;
                     }
-                    float w0, w1;
-                    if (!(tr.flags & F_SLOW)) {
-                        const float dx = (float)px - tr.x3, dy = (float)py - tr.y3;
-                        w0 = tr.a0 * dx + tr.b0 * dy; w1 = tr.a1 * dx + tr.b1 * dy;
-                    } else replay_w(tr, px, py, w0, w1);
-                    float bcx, bcy, bcz; uint32_t texel = 0;
-                    cover<TEXMODE>(tr, w0, w1, a.texels, ltex, bcx, bcy, bcz, texel);      // true by construction
-                    const float* sh = shading != B32_SHADE_NONE ? a.shades + (size_t)sid * 9 : nullptr;
-                    float shv[9];
-                    if (shading != B32_SHADE_NONE) for (int j = 0; j < 9; ++j) shv[j] = sh[j];
-                    const uint32_t out15 = shade15(texel, bcx, bcy, bcz, q4.x, q4.y, q4.z, tr.flags, shading, shv, px, py);
-                    rgba = c15_to_rgba(out15);                                               // set_pixel_15
-                    if (!has_tr) a.fb[(size_t)py * fp.width + px] = rgba;
                 }
-                if (has_tr) {
-                    if (inb && !li) rgba = a.fb[(size_t)py * fp.width + px];
-                    tilebuf[row * TILE_STRIDE + col] = rgba;
-                }
+                break;
             }
 
             // ---- phase C: transparent pass, strictly in painter's order; wave w owns tile rows [4w, 4w+4)
@@ -310,10 +441,10 @@ __global__ __launch_bounds__(FILL_THREADS) void k_fill(FillArgs a) {
                 for (uint32_t cs = 0; cs < n_tr; cs += 64) {
                     const uint32_t cnt = min(64u, n_tr - cs);
                     Batch b;
-                    load_batch<TEXMODE>(b, a, e1 + cs + lane, lane < cnt, lds_desc);
+                    load_batch<TEXMODE>(b, a, e1 + cs + lane, lane < cnt, lds_desc, true);
                     const uint32_t my_sid = lane < cnt ? a.pair_vals[e1 + cs + lane] : 0;
                     for (uint32_t t = 0; t < cnt; ++t) {
-                        const Tri tr = tri_from_batch(b, (int)t);
+                        const Tri tr = tri_from_batch(b, (int)t, true);
                         const uint32_t cx0 = max(tr.min_x, x_lo), cx1 = min(tr.max_x, x_hi);
                         const uint32_t cy0 = max(tr.min_y, wy0), cy1 = min(tr.max_y, wy1);
                         if (cx0 >= cx1 || cy0 >= cy1) continue;
@@ -325,34 +456,38 @@ __global__ __launch_bounds__(FILL_THREADS) void k_fill(FillArgs a) {
                         if (!(tr.flags & F_SLOW)) {
                             for (uint32_t bx = cx0; bx < cx1; bx += 16) {
                                 const uint32_t px = bx + (lane & 15), py = cy0 + (lane >> 4);
+                                bool drawn = false;
                                 if (px < cx1 && py < cy1) {
-                                    const float dx = (float)px - tr.x3, dy = (float)py - tr.y3;
-                                    const float w0 = tr.a0 * dx + tr.b0 * dy, w1 = tr.a1 * dx + tr.b1 * dy;
-                                    float bcx, bcy, bcz; uint32_t texel;
-                                    if (cover<TEXMODE>(tr, w0, w1, a.texels, ltex, bcx, bcy, bcz, texel)) {
+                                    float w0, w1, bcx, bcy, bcz; uint32_t texel;
+                                    edge_w(tr, px, py, w0, w1);
+                                    if (inside_bc(tr, w0, w1, bcx, bcy, bcz) && texel_drawn<TEXMODE>(tr, bcx, bcy, bcz, a.texels, ltex, texel)) {
                                         const uint32_t out15 = shade15(texel, bcx, bcy, bcz, vc1, vc2, vc3, tr.flags, shading, shv, px, py);
                                         uint32_t* dst = &tilebuf[(py - ty_top) * TILE_STRIDE + (px - x_lo)];
                                         *dst = store_blend(*dst, out15, tr.flags);
-                                        ++frag_count;
+                                        drawn = true;
                                     }
                                 }
+                                frag_count += (unsigned long long)__popcll(__ballot(drawn));
                             }
                         } else {
                             const uint32_t py = cy0 + lane;
+                            uint32_t mine = 0;
                             if (py < cy1) {
                                 float w0, w1;
                                 replay_w(tr, cx0, py, w0, w1);
                                 for (uint32_t px = cx0; px < cx1; ++px) {
                                     float bcx, bcy, bcz; uint32_t texel;
-                                    if (cover<TEXMODE>(tr, w0, w1, a.texels, ltex, bcx, bcy, bcz, texel)) {
+                                    if (inside_bc(tr, w0, w1, bcx, bcy, bcz) && texel_drawn<TEXMODE>(tr, bcx, bcy, bcz, a.texels, ltex, texel)) {
                                         const uint32_t out15 = shade15(texel, bcx, bcy, bcz, vc1, vc2, vc3, tr.flags, shading, shv, px, py);
                                         uint32_t* dst = &tilebuf[(py - ty_top) * TILE_STRIDE + (px - x_lo)];
                                         *dst = store_blend(*dst, out15, tr.flags);
-                                        ++frag_count;
+                                        ++mine;
                                     }
                                     w0 += tr.a0; w1 += tr.a1;
                                 }
                             }
+                            for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
+                            frag_count += (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)mine);
                         }
                     }
                 }
@@ -366,16 +501,15 @@ __global__ __launch_bounds__(FILL_THREADS) void k_fill(FillArgs a) {
                 }
             }
         }
-        __syncthreads();   // everyone is done with misc[0] / tilebuf before the next tile
+        __syncthreads();   // everyone is done with misc / tilebuf before the next tile
     }
 
-    // exact fragment-store count (Mpixels/s numerator)
-    for (int off = 32; off > 0; off >>= 1) frag_count += __shfl_down(frag_count, off);
+    // fragment-store count (wave-uniform per wave): one same-address atomic per workgroup
     unsigned long long* wf = reinterpret_cast<unsigned long long*>(smem);       // tilebuf is free now
     __syncthreads();
     if (lane == 0) wf[wave] = frag_count;
     __syncthreads();
-    if (tid == 0) {                                                              // one same-address atomic per workgroup
+    if (tid == 0) {
         unsigned long long t = 0;
         for (int w = 0; w < FILL_WAVES; ++w) t += wf[w];
         if (t) atomicAdd(&a.ctrl->fragments, t);
@@ -392,9 +526,11 @@ void launch_fill(hipStream_t s, const FillArgs& a, int n_cu) {
         if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fill<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
         hipLaunchKernelGGL(k_fill<1>, dim3(grid), dim3(FILL_THREADS), lds, s, a);
     } else {
-        grid = min(ntiles, (uint32_t)n_cu * 2);      // 18.5 KB LDS, 16 waves per workgroup: two workgroups fit a CU
+        grid = min(ntiles, (uint32_t)n_cu * 2);      // 24 KB LDS, 16 waves per workgroup: two workgroups fit a CU
         hipLaunchKernelGGL(k_fill<0>, dim3(grid), dim3(FILL_THREADS), LDS_TEX_OFFSET, s, a);
     }
 }
+
+size_t fill_lds_tex_budget() { return 160 * 1024 - LDS_TEX_OFFSET - 16; }
 
 }  // namespace b32

@@ -57,6 +57,9 @@ class Context:
     def set_profiling(self, level):
         _chk(self.lib.b32_set_profiling(self.h, level), "b32_set_profiling")
 
+    def set_fragment_counting(self, on):
+        _chk(self.lib.b32_set_fragment_counting(self.h, int(on)), "b32_set_fragment_counting")
+
     def last_kernel_times(self):
         names = (C.c_char_p * 8)()
         ms = (C.c_float * 8)()

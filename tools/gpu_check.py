@@ -33,14 +33,26 @@ def check(name, sc, resident=False, indexed=False):
         print(f"[{name}] GPU error {e} (oracle rc={rc})")
         return False
     t_gpu = time.time() - t0
+    kern_exact = ctx.last_kernel_times()
     got = fb.image(); exp = ofb.image()
+    # same frame with fragment counting off (CHEAP coverage + repair where eligible): identical pixels required
+    ctx.set_fragment_counting(0)
+    fb2 = R.Framebuffer(sc.width, sc.height, ctx); fb2.clear(sc.clear_color)
+    if resident:
+        rs2 = R.ResidentScene(fb2, sc.vertices, sc.faces, sc.textures if not indexed else None, sc.indexed_textures if indexed else None)
+        rs2.render(sc.camera, sc.settings, sc.fog)
+    else:
+        R.render_mesh_15(fb2, sc.vertices, sc.faces, sc.textures, sc.camera, sc.settings, sc.fog)
+    cheap_kern = ctx.last_kernel_times()
+    cheap_bad = int((fb2.image() != exp).any(axis=2).sum())
+    ctx.set_fragment_counting(1)
     diff = (got != exp).any(axis=2)
     order = ctx.last_draw_order(len(sc.faces))
     order_ok = np.array_equal(order, dump["draw_order"])
-    ok = (not diff.any()) and order_ok and t.triangles_drawn == ot.triangles_drawn and t.fragments == ot.fragments
+    ok = (not diff.any()) and order_ok and t.triangles_drawn == ot.triangles_drawn and t.fragments == ot.fragments and cheap_bad == 0
     print(f"[{name}] {'OK ' if ok else 'BAD'} px_mismatch={int(diff.sum())} order_ok={order_ok} drawn gpu/cpu={t.triangles_drawn}/{ot.triangles_drawn} "
           f"frags gpu/cpu={t.fragments}/{ot.fragments} cpu={t_cpu*1e3:.1f}ms gpu_call={t_gpu*1e3:.1f}ms "
-          f"timings={t.cull_ms:.3f}/{t.sort_ms:.3f}/{t.draw_ms:.3f} kern={ctx.last_kernel_times()}")
+          f"cheap_px_mismatch={cheap_bad} fill exact/cheap ms={kern_exact.get('fill', 0):.3f}/{cheap_kern.get('fill', 0):.3f}")
     if diff.any():
         ys, xs = np.nonzero(diff)
         for i in range(min(5, len(ys))):
