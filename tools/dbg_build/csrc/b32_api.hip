@@ -1,0 +1,619 @@
+// b32_api.hip — the C ABI of include/b32raster.h: context, device-resident framebuffer and scene, frame enqueue.
+//
+// Frame = memset(ctrl) -> k_setup -> k_after_setup -> 4 radix passes (painter's order) -> k_bin_count/scan/emit ->
+// radix passes on (tile,class) -> k_tile_ranges -> k_fill.  Everything is enqueued on one HIP stream without host
+// round trips; counts that decide later grid work (surfaces, pairs) stay in device memory.  The only host readback is
+// b32_frame_finish (error flags, triangles_drawn, fragment count, pair-capacity overflow -> grow and redraw).
+#include "b32_device.h"
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+using namespace b32;
+static unsigned long long* g_dbg_ptr = nullptr;
+extern "C" int b32_debug_read(unsigned long long* out, int n) { return (int)hipMemcpy(out, g_dbg_ptr, (size_t)n * 8, hipMemcpyDeviceToHost); }
+
+namespace {
+constexpr int EV_RING = 64;     // frames of per-phase events kept between two b32_frame_finish calls
+constexpr int EV_PER_FRAME = 5; // start | setup | sort | bin | fill
+}
+
+struct b32_ctx {
+    int device = 0;
+    int n_cu = 256;
+    int last_hip = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+
+    // framebuffer
+    uint32_t width = 0, height = 0;
+    uint32_t* fb_own = nullptr; size_t fb_own_px = 0;
+    uint32_t* fb = nullptr; bool fb_external = false;
+    uint32_t band_y0 = 0, band_y1 = 0; bool band_set = false;
+
+    // resident scene
+    B32Vertex* d_verts = nullptr; size_t cap_verts = 0;
+    B32Face* d_faces = nullptr; size_t cap_faces = 0;
+    uint16_t* d_texels = nullptr; size_t cap_texels = 0;
+    TexDesc* d_tex = nullptr; size_t cap_tex = 0;
+    std::vector<TexDesc> h_tex;
+    uint32_t nv = 0, nf = 0, nt = 0;
+    bool have_scene = false;
+    bool cheap_ok = false;              // every texture has few skippable texels: CHEAP coverage + repair is profitable
+    int count_fragments = 1;            // 1: exact fragment-store count every frame (EXACT coverage)
+
+    // per-face work buffers
+    size_t cap_work = 0;
+    uint32_t *keys[2] = { nullptr, nullptr }, *vals[2] = { nullptr, nullptr };
+    SurfRec* recs = nullptr; float* shades = nullptr; size_t cap_shades = 0;
+    uint32_t* counts = nullptr; uint32_t* block_sums = nullptr; uint32_t bin_blocks = 0;
+    // pairs
+    size_t cap_pairs = 0;
+    uint32_t *pkeys[2] = { nullptr, nullptr }, *pvals[2] = { nullptr, nullptr };
+    // sort scratch
+    uint32_t* block_hist = nullptr; uint32_t hist_blocks = 0; uint32_t* digit_total = nullptr;
+    uint32_t* partials = nullptr; uint32_t partial_blocks = 0;
+    // tiles
+    uint32_t* ranges = nullptr; size_t cap_ranges = 0;
+    // control
+    Ctrl* d_ctrl = nullptr; uint32_t* d_consts = nullptr; Ctrl h_ctrl{};
+    B32Light* d_lights = nullptr; size_t cap_lights = 0; std::vector<B32Light> h_lights;
+
+    // last enqueued frame (for redraw after a pair overflow)
+    bool frame_pending = false;
+    B32Camera last_cam{}; B32Settings last_settings{}; B32Fog last_fog{}; bool last_has_fog = false;
+    int last_pair_buf = 0;
+
+    // profiling
+    int profile_level = 0;
+    hipEvent_t ev[EV_RING][EV_PER_FRAME] = {};
+    bool ev_created = false;
+    uint32_t ev_frames = 0;             // frames recorded since the last finish
+    float phase_ms[4] = { 0, 0, 0, 0 }; // averages of the last finished batch
+    uint32_t phase_frames = 0;
+    int phase_level = 0;                // profiling level those averages were taken at
+    std::vector<B32Light> keep_lights;  // private copy of the last frame's lights (redraw after overflow)
+};
+
+#define HIPCHK(ctx, expr)                                                 \
+    do {                                                                  \
+        hipError_t _e = (expr);                                           \
+        if (_e != hipSuccess) { (ctx)->last_hip = (int)_e; return B32_E_HIP; } \
+    } while (0)
+
+template <typename T>
+static int ensure(b32_ctx* c, T*& p, size_t& cap, size_t need) {
+    if (need <= cap && p) return B32_OK;
+    if (p) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(p)); p = nullptr; cap = 0; }
+    size_t n = need + need / 4 + 16;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(T)));
+    cap = n;
+    return B32_OK;
+}
+template <typename T>
+static int ensure_plain(b32_ctx* c, T*& p, size_t count) {   // exact-size (re)allocation without capacity tracking
+    if (p) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(p)); p = nullptr; }
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T)));
+    return B32_OK;
+}
+
+extern "C" {
+
+const char* b32_strerror(int code) {
+    switch (code) {
+        case B32_OK: return "ok";
+        case B32_E_ARG: return "invalid argument";
+        case B32_E_INDEX: return "face references a vertex index out of range";
+        case B32_E_NAN_KEY: return "NaN painter's-sort key";
+        case B32_E_HIP: return "HIP runtime error";
+        case B32_E_UNSUPPORTED: return "setting outside the supported hot-path scope";
+        case B32_E_NO_DEVICE: return "no HIP device (the rasterizer has no CPU fallback)";
+        default: return "unknown error";
+    }
+}
+
+int b32_create(int device, b32_ctx** out) {
+    if (!out) return B32_E_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return B32_E_NO_DEVICE;
+    b32_ctx* c = new b32_ctx();
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess) { delete c; return B32_E_NO_DEVICE; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return B32_E_HIP; }
+    c->stream = c->own_stream;
+    if (hipMalloc(reinterpret_cast<void**>(&c->d_ctrl), sizeof(Ctrl)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&c->d_consts), 16 * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&c->digit_total), 256 * sizeof(uint32_t)) != hipSuccess) { delete c; return B32_E_HIP; }
+    *out = c;
+    return B32_OK;
+}
+
+void b32_destroy(b32_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    void* ptrs[] = { c->fb_own, c->d_verts, c->d_faces, c->d_texels, c->d_tex, c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->recs,
+                     c->shades, c->counts, c->block_sums, c->pkeys[0], c->pkeys[1], c->pvals[0], c->pvals[1], c->block_hist, c->ranges,
+                     c->d_ctrl, c->d_consts, c->d_lights, c->digit_total, c->partials };
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (c->ev_created) for (auto& fr : c->ev) for (auto& e : fr) if (e) (void)hipEventDestroy(e);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int b32_last_hip_error(const b32_ctx* c) { return c ? c->last_hip : 0; }
+
+int b32_set_stream(b32_ctx* c, void* s) {
+    if (!c) return B32_E_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->stream = s ? reinterpret_cast<hipStream_t>(s) : c->own_stream;
+    return B32_OK;
+}
+int b32_synchronize(b32_ctx* c) {
+    if (!c) return B32_E_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return B32_OK;
+}
+
+// ------------------------------------------------------------------ framebuffer
+static int fb_set_dims(b32_ctx* c, uint32_t w, uint32_t h) {
+    c->width = w; c->height = h;
+    if (!c->band_set) { c->band_y0 = 0; c->band_y1 = h; }
+    else { if (c->band_y1 > h) c->band_y1 = h; if (c->band_y0 > c->band_y1) c->band_y0 = c->band_y1; }
+    return B32_OK;
+}
+int b32_fb_resize(b32_ctx* c, uint32_t w, uint32_t h) {
+    if (!c || w == 0 || h == 0 || w > 16384 || h > 16384) return B32_E_ARG;
+    (void)hipSetDevice(c->device);
+    if (c->fb_external) { c->fb_external = false; c->fb = nullptr; c->width = c->height = 0; }
+    if (c->fb && c->width == w && c->height == h) return B32_OK;          // Framebuffer::resize: no-op on equal dims
+    const size_t px = (size_t)w * h;
+    if (px > c->fb_own_px || !c->fb_own) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->fb_own) HIPCHK(c, hipFree(c->fb_own));
+        c->fb_own = nullptr;
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->fb_own), px * 4));
+        c->fb_own_px = px;
+    }
+    c->fb = c->fb_own;
+    c->band_set = false;
+    fb_set_dims(c, w, h);
+    HIPCHK(c, hipMemsetAsync(c->fb, 0, px * 4, c->stream));                // vec![0; w*h*4], render.rs:18-33
+    return B32_OK;
+}
+int b32_fb_bind_device(b32_ctx* c, void* dptr, uint32_t w, uint32_t h) {
+    if (!c) return B32_E_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (!dptr) { c->fb_external = false; c->fb = nullptr; c->width = c->height = 0; return B32_OK; }
+    if (w == 0 || h == 0 || w > 16384 || h > 16384 || (reinterpret_cast<uintptr_t>(dptr) & 15)) return B32_E_ARG;
+    c->fb = reinterpret_cast<uint32_t*>(dptr); c->fb_external = true;
+    c->band_set = false;
+    return fb_set_dims(c, w, h);
+}
+int b32_fb_size(const b32_ctx* c, uint32_t* w, uint32_t* h) {
+    if (!c) return B32_E_ARG;
+    if (w) *w = c->width;
+    if (h) *h = c->height;
+    return B32_OK;
+}
+int b32_set_band(b32_ctx* c, uint32_t y0, uint32_t y1) {
+    if (!c || !c->fb || y0 > y1 || y1 > c->height) return B32_E_ARG;
+    c->band_y0 = y0; c->band_y1 = y1; c->band_set = !(y0 == 0 && y1 == c->height);
+    return B32_OK;
+}
+int b32_fb_clear(b32_ctx* c, uint8_t r, uint8_t g, uint8_t b, uint8_t blend) {
+    if (!c || !c->fb) return B32_E_ARG;
+    (void)hipSetDevice(c->device);
+    const uint32_t a = blend == B32_BLEND_ERASE ? 0u : 255u;               // Color::to_bytes, types.rs:829-832
+    const uint32_t rgba = r | (g << 8) | (b << 16) | (a << 24);
+    launch_clear(c->stream, c->fb, (size_t)c->width * c->height, rgba);
+    HIPCHK(c, hipGetLastError());
+    return B32_OK;
+}
+int b32_fb_upload(b32_ctx* c, const uint8_t* rgba) {
+    if (!c || !c->fb || !rgba) return B32_E_ARG;
+    (void)hipSetDevice(c->device);
+    HIPCHK(c, hipMemcpyAsync(c->fb, rgba, (size_t)c->width * c->height * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return B32_OK;
+}
+int b32_fb_download(b32_ctx* c, uint8_t* rgba) {
+    if (!c || !c->fb || !rgba) return B32_E_ARG;
+    (void)hipSetDevice(c->device);
+    HIPCHK(c, hipMemcpyAsync(rgba, c->fb, (size_t)c->width * c->height * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return B32_OK;
+}
+
+// ------------------------------------------------------------------ scene upload
+static int upload_geometry(b32_ctx* c, const B32Vertex* v, uint32_t nv, const B32Face* f, uint32_t nf) {
+    if ((nv && !v) || (nf && !f)) return B32_E_ARG;
+    int rc;
+    if ((rc = ensure(c, c->d_verts, c->cap_verts, (size_t)nv + 1))) return rc;
+    if ((rc = ensure(c, c->d_faces, c->cap_faces, (size_t)nf + 1))) return rc;
+    if (nv) HIPCHK(c, hipMemcpyAsync(c->d_verts, v, (size_t)nv * sizeof(B32Vertex), hipMemcpyHostToDevice, c->stream));
+    if (nf) HIPCHK(c, hipMemcpyAsync(c->d_faces, f, (size_t)nf * sizeof(B32Face), hipMemcpyHostToDevice, c->stream));
+    c->nv = nv; c->nf = nf;
+    // per-face work buffers
+    if ((size_t)nf + 1 > c->cap_work || !c->recs) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        const size_t n = (size_t)nf + nf / 4 + 16;
+        for (int i = 0; i < 2; ++i) { if ((rc = ensure_plain(c, c->keys[i], n))) return rc; if ((rc = ensure_plain(c, c->vals[i], n))) return rc; }
+        if ((rc = ensure_plain(c, c->recs, n))) return rc;
+        if ((rc = ensure_plain(c, c->counts, n))) return rc;
+        c->bin_blocks = (uint32_t)((n + 4095) / 4096);
+        c->partial_blocks = (uint32_t)((n + 255) / 256);
+        if ((rc = ensure_plain(c, c->partials, (size_t)c->partial_blocks * 8 + 8))) return rc;
+        if ((rc = ensure_plain(c, c->block_sums, (size_t)c->bin_blocks + 1))) return rc;
+        c->cap_work = n;
+    }
+    const uint32_t consts[4] = { nf, 0, 0, 0 };
+    HIPCHK(c, hipMemcpyAsync(c->d_consts, consts, sizeof(consts), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return B32_OK;
+}
+
+static int layout_textures(b32_ctx* c, uint32_t nt, const uint32_t* w, const uint32_t* h, const uint32_t* blend, size_t* total) {
+    if (nt > 4094) return B32_E_UNSUPPORTED;
+    c->h_tex.resize(nt);
+    size_t off = 0;
+    for (uint32_t i = 0; i < nt; ++i) {
+        if (w[i] > 65535 || h[i] > 65535) return B32_E_ARG;
+        c->h_tex[i] = { w[i], h[i], blend[i], (uint32_t)off };
+        off += ((size_t)w[i] * h[i] + 7) & ~(size_t)7;
+        if (off > 0x7FFFFFFFull) return B32_E_ARG;
+    }
+    *total = off + 8;
+    int rc;
+    if ((rc = ensure(c, c->d_texels, c->cap_texels, *total))) return rc;
+    if ((rc = ensure(c, c->d_tex, c->cap_tex, (size_t)nt + 1))) return rc;
+    if (nt) HIPCHK(c, hipMemcpyAsync(c->d_tex, c->h_tex.data(), nt * sizeof(TexDesc), hipMemcpyHostToDevice, c->stream));
+    c->nt = nt;
+    return B32_OK;
+}
+
+int b32_scene_upload(b32_ctx* c, const B32Vertex* v, uint32_t nv, const B32Face* f, uint32_t nf, const B32Texture15* tex, uint32_t nt) {
+    if (!c || (nt && !tex)) return B32_E_ARG;
+    (void)hipSetDevice(c->device);
+    c->have_scene = false;
+    std::vector<uint32_t> w(nt), h(nt), bl(nt);
+    for (uint32_t i = 0; i < nt; ++i) {
+        w[i] = tex[i].width; h[i] = tex[i].height; bl[i] = tex[i].blend_mode;
+        if (!tex[i].pixels) w[i] = h[i] = 0;                                // pixels.is_empty() -> sample() returns TRANSPARENT
+    }
+    size_t total = 0;
+    int rc = layout_textures(c, nt, w.data(), h.data(), bl.data(), &total);
+    if (rc) return rc;
+    c->cheap_ok = true;
+    for (uint32_t i = 0; i < nt; ++i) {
+        const size_t n = (size_t)w[i] * h[i];
+        if (n) HIPCHK(c, hipMemcpyAsync(c->d_texels + c->h_tex[i].offset, tex[i].pixels, n * 2, hipMemcpyHostToDevice, c->stream));
+        size_t skippable = 0;                                               // texels the black_transparent rule can skip
+        for (size_t k = 0; k < n; ++k) skippable += (tex[i].pixels[k] & 0x7FFF) == 0;
+        if (n == 0 || skippable * 32 > n) c->cheap_ok = false;
+    }
+    if ((rc = upload_geometry(c, v, nv, f, nf))) return rc;
+    c->have_scene = true;
+    return B32_OK;
+}
+
+int b32_scene_upload_indexed(b32_ctx* c, const B32Vertex* v, uint32_t nv, const B32Face* f, uint32_t nf, const B32IndexedTexture* tex, uint32_t nt) {
+    if (!c || (nt && !tex)) return B32_E_ARG;
+    (void)hipSetDevice(c->device);
+    c->have_scene = false;
+    std::vector<uint32_t> w(nt), h(nt), bl(nt);
+    for (uint32_t i = 0; i < nt; ++i) {
+        w[i] = tex[i].width; h[i] = tex[i].height; bl[i] = tex[i].blend_mode;
+        if (!tex[i].indices || !tex[i].clut) w[i] = h[i] = 0;
+    }
+    size_t total = 0;
+    int rc = layout_textures(c, nt, w.data(), h.data(), bl.data(), &total);
+    if (rc) return rc;
+    c->cheap_ok = true;
+    for (uint32_t i = 0; i < nt; ++i) {
+        const size_t n = (size_t)w[i] * h[i];
+        if (!n) { c->cheap_ok = false; continue; }
+        {
+            size_t skippable = 0;
+            for (size_t k = 0; k < n; ++k) {
+                const uint32_t ix = tex[i].indices[k];
+                const uint16_t col = ix < tex[i].clut_len ? tex[i].clut[ix] : (uint16_t)0;
+                skippable += (col & 0x7FFF) == 0;
+            }
+            if (skippable * 32 > n) c->cheap_ok = false;
+        }
+        uint8_t* d_idx = nullptr; uint16_t* d_clut = nullptr;
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d_idx), n));
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d_clut), (size_t)(tex[i].clut_len ? tex[i].clut_len : 1) * 2));
+        HIPCHK(c, hipMemcpyAsync(d_idx, tex[i].indices, n, hipMemcpyHostToDevice, c->stream));
+        if (tex[i].clut_len) HIPCHK(c, hipMemcpyAsync(d_clut, tex[i].clut, (size_t)tex[i].clut_len * 2, hipMemcpyHostToDevice, c->stream));
+        launch_expand_indexed(c->stream, d_idx, (uint32_t)n, d_clut, tex[i].clut_len, c->d_texels + c->h_tex[i].offset);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(d_idx); (void)hipFree(d_clut);
+    }
+    if ((rc = upload_geometry(c, v, nv, f, nf))) return rc;
+    c->have_scene = true;
+    return B32_OK;
+}
+
+// ------------------------------------------------------------------ frame
+static int validate_settings(const B32Settings* st) {
+    if (st->use_zbuffer || st->has_ortho || st->xray_mode || !st->affine_textures) return B32_E_UNSUPPORTED;
+    if ((st->backface_cull && st->backface_wireframe) || st->wireframe_overlay) return B32_E_UNSUPPORTED;      // wireframe phase
+    if (st->shading > B32_SHADE_GOURAUD) return B32_E_ARG;
+    if (st->n_lights && !st->lights) return B32_E_ARG;
+    if (st->shading != B32_SHADE_NONE)
+        for (uint32_t i = 0; i < st->n_lights; ++i)
+            if (st->lights[i].enabled && st->lights[i].type > B32_LIGHT_POINT) return B32_E_UNSUPPORTED;        // acos
+    return B32_OK;
+}
+
+static uint32_t bits_for(uint32_t n_keys) { uint32_t b = 1; while ((1ull << b) < n_keys) ++b; return b; }
+
+static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st, const B32Fog* fog) {
+    hipStream_t s = c->stream;
+    FrameParams fp{};
+    fp.cam = *cam;
+    fp.width = c->width; fp.height = c->height;
+    fp.band_y0 = c->band_y0; fp.band_y1 = c->band_y1;
+    fp.tiles_x = (c->width + TILE_W - 1) / TILE_W;
+    fp.tile_y0 = c->band_y0 / TILE_H;
+    fp.tiles_y = c->band_y1 > c->band_y0 ? (c->band_y1 + TILE_H - 1) / TILE_H - fp.tile_y0 : 0;
+    fp.nv = c->nv; fp.nf = c->nf; fp.nt = c->nt;
+    fp.n_lights = st->shading != B32_SHADE_NONE ? st->n_lights : 0;
+    fp.ambient = st->ambient;
+    fp.affine = st->affine_textures; fp.shading = st->shading; fp.backface_cull = st->backface_cull;
+    fp.dithering = st->dithering; fp.fixed_point = st->use_fixed_point; fp.has_fog = fog ? 1 : 0;
+    if (fog) fp.fog = *fog;
+    const uint32_t ntiles = fp.tiles_x * fp.tiles_y;
+    const uint32_t n_keys = 2 * ntiles;
+    int rc;
+
+    // lights (rarely change: synchronous refresh only when they differ from the device copy)
+    if (fp.n_lights) {
+        bool same = c->h_lights.size() == fp.n_lights && memcmp(c->h_lights.data(), st->lights, fp.n_lights * sizeof(B32Light)) == 0;
+        if (!same) {
+            if ((rc = ensure(c, c->d_lights, c->cap_lights, (size_t)fp.n_lights))) return rc;
+            HIPCHK(c, hipStreamSynchronize(s));
+            HIPCHK(c, hipMemcpy(c->d_lights, st->lights, fp.n_lights * sizeof(B32Light), hipMemcpyHostToDevice));
+            c->h_lights.assign(st->lights, st->lights + fp.n_lights);
+        }
+    }
+    if (fp.shading != B32_SHADE_NONE && (!c->shades || c->cap_shades < c->cap_work)) {
+        if (c->shades) { HIPCHK(c, hipStreamSynchronize(s)); HIPCHK(c, hipFree(c->shades)); c->shades = nullptr; }
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->shades), c->cap_work * 9 * sizeof(float)));
+        c->cap_shades = c->cap_work;
+    }
+    // pair buffers: start at 2 pairs per face + one per tile; b32_frame_finish grows them on overflow
+    if (c->cap_pairs == 0 || !c->pkeys[0]) {
+        const size_t n = (size_t)c->nf * 2 + ntiles + 1024;
+        for (int i = 0; i < 2; ++i) { if ((rc = ensure_plain(c, c->pkeys[i], n))) return rc; if ((rc = ensure_plain(c, c->pvals[i], n))) return rc; }
+        c->cap_pairs = n;
+    }
+    const uint32_t need_blocks = (uint32_t)((std::max(c->cap_pairs, c->cap_work) + SORT_TILE - 1) / SORT_TILE) + 1;
+    if (need_blocks > c->hist_blocks || !c->block_hist) {
+        if ((rc = ensure_plain(c, c->block_hist, (size_t)256 * need_blocks))) return rc;
+        c->hist_blocks = need_blocks;
+    }
+    if ((size_t)n_keys + 2 > c->cap_ranges || !c->ranges) {
+        if ((rc = ensure_plain(c, c->ranges, (size_t)n_keys + 64))) return rc;
+        c->cap_ranges = (size_t)n_keys + 64;
+    }
+
+    const bool prof_all = c->profile_level >= 2, prof_fill = c->profile_level >= 1;
+    hipEvent_t* ev = nullptr;
+    if (prof_fill) {
+        if (!c->ev_created) {
+            for (auto& fr : c->ev) for (auto& e : fr) HIPCHK(c, hipEventCreate(&e));
+            c->ev_created = true;
+        }
+        ev = c->ev[c->ev_frames % EV_RING];
+    }
+
+    HIPCHK(c, hipMemsetAsync(c->d_ctrl, 0, sizeof(Ctrl), s));
+    if (prof_all) HIPCHK(c, hipEventRecord(ev[0], s));
+    launch_setup(s, fp, c->d_verts, c->d_faces, c->d_tex, c->d_lights, c->recs, c->shades, c->keys[0], c->partials);
+    launch_after_setup(s, c->d_ctrl, c->partials, (c->nf + 255) / 256);
+    if (prof_all) HIPCHK(c, hipEventRecord(ev[1], s));
+
+    // painter's order: 4 stable passes over the 32-bit key; pass 1 also compacts away culled faces
+    const SortScratch sc{ c->block_hist, c->hist_blocks, c->digit_total };
+    launch_radix_pass(s, c->keys[0], nullptr, c->keys[1], c->vals[1], c->d_consts, c->nf, 0, sc);
+    launch_radix_pass(s, c->keys[1], c->vals[1], c->keys[0], c->vals[0], &c->d_ctrl->n_visible, c->nf, 8, sc);
+    launch_radix_pass(s, c->keys[0], c->vals[0], c->keys[1], c->vals[1], &c->d_ctrl->n_visible, c->nf, 16, sc);
+    launch_radix_pass(s, c->keys[1], c->vals[1], c->keys[0], c->vals[0], &c->d_ctrl->n_visible, c->nf, 24, sc);
+    if (prof_all) HIPCHK(c, hipEventRecord(ev[2], s));
+
+    // binning
+    launch_bin(s, fp, c->recs, c->vals[0], c->d_ctrl, c->counts, c->block_sums, c->bin_blocks, c->pkeys[0], c->pvals[0], (uint32_t)c->cap_pairs);
+    const uint32_t kb = bits_for(n_keys ? n_keys : 1);
+    int cur = 0;
+    for (uint32_t shift = 0; shift < kb; shift += 8) {
+        launch_radix_pass(s, c->pkeys[cur], c->pvals[cur], c->pkeys[cur ^ 1], c->pvals[cur ^ 1], &c->d_ctrl->n_pairs, (uint32_t)c->cap_pairs, (int)shift, sc);
+        cur ^= 1;
+    }
+    c->last_pair_buf = cur;
+    launch_tile_ranges(s, c->pkeys[cur], c->d_ctrl, (uint32_t)c->cap_pairs, c->ranges, n_keys);
+    if (prof_fill) HIPCHK(c, hipEventRecord(ev[3], s));
+
+    FillArgs fa{};
+    fa.fp = fp; fa.recs = c->recs; fa.shades = c->shades; fa.pair_vals = c->pvals[cur]; fa.ranges = c->ranges;
+    fa.tex = c->d_tex; fa.texels = c->d_texels; fa.fb = c->fb; fa.ctrl = c->d_ctrl;
+    fa.lds_tex_texels = 0;
+    if (c->nt == 1) {
+        const size_t n = (size_t)c->h_tex[0].width * c->h_tex[0].height;
+        if (n > 0 && n * 2 <= fill_lds_tex_budget()) fa.lds_tex_texels = (uint32_t)n;
+    }
+    static unsigned long long* g_dbg = nullptr; if (!g_dbg) { (void)hipMalloc(reinterpret_cast<void**>(&g_dbg), 512*16*8*8); } (void)hipMemsetAsync(g_dbg, 0, 512*16*8*8, s); fa.debug = g_dbg; g_dbg_ptr = g_dbg;
+    fa.exact_coverage = (c->count_fragments || !c->cheap_ok) ? 1u : 0u;
+    launch_fill(s, fa, c->n_cu);
+    if (prof_fill) { HIPCHK(c, hipEventRecord(ev[4], s)); c->ev_frames++; }
+    HIPCHK(c, hipGetLastError());
+    return B32_OK;
+}
+
+int b32_render_scene_15_async(b32_ctx* c, const B32Camera* cam, const B32Settings* st, const B32Fog* fog) {
+    if (!c || !cam || !st || !c->fb || !c->have_scene) return B32_E_ARG;
+    (void)hipSetDevice(c->device);
+    int rc = validate_settings(st);
+    if (rc) return rc;
+    c->last_cam = *cam; c->last_settings = *st; c->last_has_fog = fog != nullptr;
+    if (fog) c->last_fog = *fog;
+    // keep a private copy of the lights so a redraw after overflow does not dereference a dead caller pointer
+    c->keep_lights.assign(st->lights, st->lights + (st->lights ? st->n_lights : 0));
+    c->last_settings.lights = c->keep_lights.empty() ? nullptr : c->keep_lights.data();
+    rc = enqueue_frame(c, cam, &c->last_settings, fog);
+    if (rc == B32_OK) c->frame_pending = true;
+    return rc;
+}
+
+static void collect_events(b32_ctx* c) {
+    c->phase_frames = 0;
+    for (float& p : c->phase_ms) p = 0;
+    if (!c->ev_created || c->ev_frames == 0 || c->profile_level < 1) { c->ev_frames = 0; return; }
+    const uint32_t n = c->ev_frames < (uint32_t)EV_RING ? c->ev_frames : (uint32_t)EV_RING;
+    for (uint32_t i = 0; i < n; ++i) {
+        float ms = 0;
+        if (c->profile_level >= 2) {
+            for (int p = 0; p < 3; ++p) if (hipEventElapsedTime(&ms, c->ev[i][p], c->ev[i][p + 1]) == hipSuccess) c->phase_ms[p] += ms;
+        }
+        if (hipEventElapsedTime(&ms, c->ev[i][3], c->ev[i][4]) == hipSuccess) c->phase_ms[3] += ms;
+    }
+    for (float& p : c->phase_ms) p /= (float)n;
+    c->phase_frames = n;
+    c->phase_level = c->profile_level;
+    c->ev_frames = 0;
+}
+
+int b32_frame_finish(b32_ctx* c, B32Timings* out) {
+    if (!c) return B32_E_ARG;
+    (void)hipSetDevice(c->device);
+    if (out) memset(out, 0, sizeof(*out));
+    if (!c->frame_pending) { HIPCHK(c, hipStreamSynchronize(c->stream)); return B32_OK; }
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        HIPCHK(c, hipMemcpyAsync(&c->h_ctrl, c->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (!c->h_ctrl.pairs_overflow) break;
+        // the fill aborted before touching the framebuffer: grow the pair buffers and redraw the same frame
+        const size_t n = (size_t)c->h_ctrl.pairs_overflow + c->h_ctrl.pairs_overflow / 4 + 1024;
+        int rc;
+        for (int i = 0; i < 2; ++i) { if ((rc = ensure_plain(c, c->pkeys[i], n))) return rc; if ((rc = ensure_plain(c, c->pvals[i], n))) return rc; }
+        c->cap_pairs = n;
+        c->ev_frames = 0;                              // the aborted frame must not enter the phase averages
+        if ((rc = enqueue_frame(c, &c->last_cam, &c->last_settings, c->last_has_fog ? &c->last_fog : nullptr))) return rc;
+    }
+    c->frame_pending = false;
+    collect_events(c);
+    if (c->h_ctrl.pairs_overflow) return B32_E_HIP;
+    if (c->h_ctrl.err_index) return B32_E_INDEX;
+    if (c->h_ctrl.abort) return B32_E_NAN_KEY;
+    if (out) {
+        out->triangles_drawn = c->h_ctrl.n_visible;
+        out->fragments = c->h_ctrl.fragments;
+        if (c->phase_frames && c->phase_level >= 2) {
+            out->transform_ms = 0.0f;                 // fused into the per-face setup kernel
+            out->cull_ms = c->phase_ms[0];
+            out->sort_ms = c->phase_ms[1];
+            out->draw_ms = c->phase_ms[2] + c->phase_ms[3];
+        }
+    }
+    return B32_OK;
+}
+
+int b32_render_scene_15(b32_ctx* c, const B32Camera* cam, const B32Settings* st, const B32Fog* fog, B32Timings* out) {
+    if (!c) return B32_E_ARG;
+    const int saved = c->profile_level;
+    if (out) c->profile_level = 2;                    // RasterTimings wants every phase
+    int rc = b32_render_scene_15_async(c, cam, st, fog);
+    if (rc == B32_OK) rc = b32_frame_finish(c, out);
+    c->profile_level = saved;
+    return rc;
+}
+
+int b32_render_mesh_15(b32_ctx* c, const B32Vertex* v, uint32_t nv, const B32Face* f, uint32_t nf, const B32Texture15* tex, uint32_t nt,
+                       const B32Camera* cam, const B32Settings* st, const B32Fog* fog, B32Timings* out) {
+    if (!c || !cam || !st || !c->fb) return B32_E_ARG;
+    int rc = validate_settings(st);
+    if (rc) return rc;
+    if ((rc = b32_scene_upload(c, v, nv, f, nf, tex, nt))) return rc;
+    return b32_render_scene_15(c, cam, st, fog, out);
+}
+
+// ------------------------------------------------------------------ stage taps
+int b32_project_fixed_batch(b32_ctx* c, const float* pos, uint32_t n, const B32Camera* cam, uint32_t w, uint32_t h,
+                            int32_t* sx, int32_t* sy, float* z) {
+    if (!c || !cam || (n && (!pos || !sx || !sy || !z))) return B32_E_ARG;
+    if (!n) return B32_OK;
+    (void)hipSetDevice(c->device);
+    float* d_pos = nullptr; int32_t *d_sx = nullptr, *d_sy = nullptr; float* d_z = nullptr;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d_pos), (size_t)n * 12));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d_sx), (size_t)n * 4));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d_sy), (size_t)n * 4));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d_z), (size_t)n * 4));
+    HIPCHK(c, hipMemcpyAsync(d_pos, pos, (size_t)n * 12, hipMemcpyHostToDevice, c->stream));
+    launch_project_fixed(c->stream, d_pos, n, *cam, w, h, d_sx, d_sy, d_z);
+    HIPCHK(c, hipMemcpyAsync(sx, d_sx, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(sy, d_sy, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(z, d_z, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(d_pos); (void)hipFree(d_sx); (void)hipFree(d_sy); (void)hipFree(d_z);
+    return B32_OK;
+}
+
+int b32_last_draw_order(b32_ctx* c, uint32_t* face_idx, uint32_t cap, uint32_t* n) {
+    if (!c || !n || c->frame_pending) return B32_E_ARG;
+    (void)hipSetDevice(c->device);
+    const uint32_t cnt = c->h_ctrl.n_visible;
+    *n = cnt;
+    const uint32_t m = cnt < cap ? cnt : cap;
+    if (m && face_idx) {
+        HIPCHK(c, hipMemcpyAsync(face_idx, c->vals[0], (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return B32_OK;
+}
+
+int b32_selftest_f32(b32_ctx* c, int op, const float* a, const float* b, const float* cc, float* out, uint32_t n) {
+    if (!c || !a || !b || !cc || !out) return B32_E_ARG;
+    if (!n) return B32_OK;
+    (void)hipSetDevice(c->device);
+    float* d[4] = { nullptr, nullptr, nullptr, nullptr };
+    for (auto& p : d) HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p), (size_t)n * 4));
+    HIPCHK(c, hipMemcpyAsync(d[0], a, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d[1], b, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d[2], cc, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    launch_selftest(c->stream, op, d[0], d[1], d[2], d[3], n);
+    HIPCHK(c, hipMemcpyAsync(out, d[3], (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (auto& p : d) (void)hipFree(p);
+    return B32_OK;
+}
+
+int b32_last_kernel_times(b32_ctx* c, const char** names, float* ms, uint32_t cap) {
+    if (!c || !names || !ms) return 0;
+    static const char* const kNames[4] = { "setup", "sort", "bin", "fill" };
+    if (!c->phase_frames) return 0;
+    uint32_t k = 0;
+    for (int p = 0; p < 4 && k < cap; ++p) {
+        if (p < 3 && c->phase_level < 2) continue;
+        names[k] = kNames[p]; ms[k] = c->phase_ms[p]; ++k;
+    }
+    return (int)k;
+}
+
+}  // extern "C"
+
+// 0 = no events, 1 = events around k_fill, 2 = events around every phase.
+extern "C" int b32_set_fragment_counting(b32_ctx* c, int on) {
+    if (!c) return B32_E_ARG;
+    c->count_fragments = on ? 1 : 0;
+    return B32_OK;
+}
+extern "C" int b32_set_profiling(b32_ctx* c, int level) {
+    if (!c) return B32_E_ARG;
+    c->profile_level = level < 0 ? 0 : (level > 2 ? 2 : level);
+    return B32_OK;
+}

@@ -1,0 +1,156 @@
+// b32_bin.hip — screen-tile binning of the depth-sorted surface list.
+//
+// Input: order[r] = surface id of painter's rank r (r = 0 is drawn first).  Each surface is expanded into one pair per
+// 64x64 screen tile its (band-clipped) bounding box touches: key = (tile << 1) | class (class 1 = transparent pass,
+// render.rs:2522-2523), value = surface id.  Pairs are emitted in rank order with offsets from a prefix sum (no atomics,
+// deterministic), then the radix sort of b32_sort.hip groups them by key; because that sort is stable, every tile's list
+// stays in painter's order — the order the transparent pass must honour, and the order whose *last* opaque writer wins.
+#include "b32_device.h"
+
+namespace b32 {
+
+__device__ __forceinline__ bool tile_span(const SurfRec& r, const FrameParams& fp, uint32_t& tx0, uint32_t& tx1, uint32_t& ty0, uint32_t& ty1) {
+    if (r.flags & F_EMPTY) return false;
+    uint32_t min_x = r.bbx & 0xFFFF, max_x = r.bbx >> 16, min_y = r.bby & 0xFFFF, max_y = r.bby >> 16;
+    min_y = max(min_y, fp.band_y0); max_y = min(max_y, fp.band_y1);     // rows outside this GPU's band belong to another rank
+    if (min_x >= max_x || min_y >= max_y) return false;
+    tx0 = min_x / TILE_W; tx1 = (max_x - 1) / TILE_W;
+    ty0 = min_y / TILE_H; ty1 = (max_y - 1) / TILE_H;
+    return true;
+}
+
+constexpr int BIN_THREADS = 256;
+constexpr int BIN_ITEMS = 16;
+constexpr int BIN_TILE = BIN_THREADS * BIN_ITEMS;
+
+// counts[r] = number of tiles surface order[r] touches; block_sums[b] = sum over the block's 4096 ranks.
+__global__ __launch_bounds__(BIN_THREADS) void k_bin_count(FrameParams fp, const SurfRec* __restrict__ recs, const uint32_t* __restrict__ order,
+                                                            const Ctrl* __restrict__ ctrl, uint32_t* __restrict__ counts,
+                                                            uint32_t* __restrict__ block_sums) {
+    __shared__ uint32_t wsum[BIN_THREADS / 64];
+    const uint32_t n = ctrl->n_visible;
+    const uint32_t base = blockIdx.x * BIN_TILE;
+    uint32_t local = 0;
+    if (base < n) {
+#pragma unroll 4
+        for (int i = 0; i < BIN_ITEMS; ++i) {
+            const uint32_t r = base + i * BIN_THREADS + threadIdx.x;
+            if (r < n) {
+                const SurfRec& rec = recs[order[r]];
+                SurfRec q; q.bbx = rec.bbx; q.bby = rec.bby; q.flags = rec.flags;
+                uint32_t tx0, tx1, ty0, ty1, c = 0;
+                if (tile_span(q, fp, tx0, tx1, ty0, ty1)) c = (tx1 - tx0 + 1) * (ty1 - ty0 + 1);
+                counts[r] = c;
+                local += c;
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// Exclusive scan of block_sums (<= 1024 entries per pass of the loop) by one workgroup; publishes n_pairs and the overflow verdict.
+__global__ __launch_bounds__(1024) void k_bin_scan(uint32_t* __restrict__ block_sums, uint32_t nblocks, Ctrl* __restrict__ ctrl, uint32_t pair_cap) {
+    __shared__ uint32_t part[1024];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nblocks; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < nblocks ? block_sums[i] : 0;
+        part[threadIdx.x] = v;
+        __syncthreads();
+        for (uint32_t off = 1; off < 1024; off <<= 1) {
+            uint32_t t = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+            __syncthreads();
+            part[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < nblocks) block_sums[i] = carry + part[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry += part[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        ctrl->n_pairs = carry;
+        if (carry > pair_cap) { ctrl->pairs_overflow = carry; ctrl->abort = 1; ctrl->n_pairs = 0; }
+    }
+}
+
+// Emit the pairs of each rank at its prefix offset (block base + in-block exclusive scan of counts).
+__global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(FrameParams fp, const SurfRec* __restrict__ recs, const uint32_t* __restrict__ order,
+                                                           const Ctrl* __restrict__ ctrl, const uint32_t* __restrict__ counts,
+                                                           const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ pair_keys,
+                                                           uint32_t* __restrict__ pair_vals) {
+    __shared__ uint32_t wtot[BIN_THREADS / 64];
+    __shared__ uint32_t step_base;
+    const uint32_t n = ctrl->n_visible;
+    const uint32_t base = blockIdx.x * BIN_TILE;
+    if (base >= n || ctrl->abort) return;
+    const uint32_t n_opaque = ctrl->n_opaque;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) step_base = block_sums[blockIdx.x];
+    __syncthreads();
+    for (int i = 0; i < BIN_ITEMS; ++i) {
+        const uint32_t r = base + i * BIN_THREADS + threadIdx.x;
+        const uint32_t c = r < n ? counts[r] : 0;
+        // exclusive scan of c over the 256 threads of this step
+        uint32_t inc = c;
+        for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(inc, off); if (lane >= (uint32_t)off) inc += t; }
+        if (lane == 63) wtot[wave] = inc;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (uint32_t w = 0; w < wave; ++w) woff += wtot[w];
+        uint32_t pos = step_base + woff + inc - c;
+        if (c) {
+            const uint32_t sid = order[r];
+            const SurfRec& rec = recs[sid];
+            SurfRec q; q.bbx = rec.bbx; q.bby = rec.bby; q.flags = rec.flags;
+            uint32_t tx0, tx1, ty0, ty1;
+            tile_span(q, fp, tx0, tx1, ty0, ty1);
+            const uint32_t cls = r >= n_opaque ? 1u : 0u;
+            for (uint32_t ty = ty0; ty <= ty1; ++ty)
+                for (uint32_t tx = tx0; tx <= tx1; ++tx) {
+                    const uint32_t tile = (ty - fp.tile_y0) * fp.tiles_x + tx;
+                    pair_keys[pos] = (tile << 1) | cls;
+                    pair_vals[pos] = sid;
+                    ++pos;
+                }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) step_base += wtot[0] + wtot[1] + wtot[2] + wtot[3];
+        __syncthreads();
+    }
+}
+
+void launch_bin(hipStream_t s, const FrameParams& fp, const SurfRec* recs, const uint32_t* order, Ctrl* ctrl,
+                uint32_t* counts, uint32_t* block_sums, uint32_t max_blocks, uint32_t* pair_keys, uint32_t* pair_vals, uint32_t pair_cap) {
+    if (fp.nf == 0) return;
+    const uint32_t nblocks = min((fp.nf + BIN_TILE - 1) / BIN_TILE, max_blocks);
+    hipLaunchKernelGGL(k_bin_count, dim3(nblocks), dim3(BIN_THREADS), 0, s, fp, recs, order, ctrl, counts, block_sums);
+    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, s, block_sums, nblocks, ctrl, pair_cap);
+    hipLaunchKernelGGL(k_bin_emit, dim3(nblocks), dim3(BIN_THREADS), 0, s, fp, recs, order, ctrl, counts, block_sums, pair_keys, pair_vals);
+}
+
+// ranges[k] = first pair index whose key >= k, for k in 0..n_keys (n_keys = 2*ntiles); ranges[n_keys] = n_pairs.
+__global__ void k_tile_ranges(const uint32_t* __restrict__ pair_keys, const Ctrl* __restrict__ ctrl, uint32_t* __restrict__ ranges, uint32_t n_keys) {
+    const uint32_t n = ctrl->n_pairs;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += stride) {
+        // boundary between pair i-1 and pair i: every key in (prev, cur] starts at i
+        const uint32_t prev = i == 0 ? 0xFFFFFFFFu : pair_keys[i - 1];          // -1 as "before key 0"
+        const uint32_t cur = i == n ? n_keys : pair_keys[i];
+        uint32_t k0 = i == 0 ? 0u : prev + 1u;
+        for (uint32_t k = k0; k <= cur && k <= n_keys; ++k) ranges[k] = i;
+    }
+}
+void launch_tile_ranges(hipStream_t s, const uint32_t* pair_keys, const Ctrl* ctrl, uint32_t pair_cap, uint32_t* ranges, uint32_t n_keys) {
+    uint32_t blocks = (pair_cap + 1 + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(k_tile_ranges, dim3(blocks), dim3(256), 0, s, pair_keys, ctrl, ranges, n_keys);
+}
+
+}  // namespace b32

@@ -1,0 +1,192 @@
+// b32_device.h — shared declarations of the gfx950 rasterizer kernels.
+//
+// Compiled ONLY for gfx950 with -ffp-contract=off (Rust never fuses a*b+c) and HIP's default correctly-rounded
+// f32 divide / sqrt; f32 denormals are kept.  b32_selftest_f32 proves those three properties on the device
+// before any parity claim is trusted (tests/test_gpu_parity.py::test_device_f32_semantics).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../include/b32raster.h"
+
+namespace b32 {
+
+// ---------------------------------------------------------------- geometry constants
+constexpr int TILE_W = 64;          // screen tile owned by one workgroup pass of k_fill
+constexpr int TILE_H = 64;
+constexpr int TILE_STRIDE = 72;     // LDS row stride in dwords (64 + 8: an 8x8 lane block maps to 32 distinct banks per half-wave)
+constexpr int FILL_THREADS = 1024;  // 16 waves: 4 per SIMD
+constexpr int FILL_WAVES = FILL_THREADS / 64;
+constexpr uint32_t KEY_INVALID = 0xFFFFFFFFu;
+
+// ---------------------------------------------------------------- per-surface record written by k_setup (96 B = 6 x 16 B)
+// Edge coefficients follow rasterize_triangle_15 (render.rs:1500-1518) and are computed once per face with the
+// reference's f32 expression order; the fill evaluates w0/w1 in closed form only when `F_SLOW` is clear, i.e. when
+// k_setup proved every intermediate of the reference's incremental accumulation (render.rs:1706-1712) is an integer
+// of magnitude < 2^24, so that accumulate == closed form bit-for-bit.
+struct __attribute__((aligned(16))) SurfRec {
+    float x3, y3, a0, b0;
+    float a1, b1, inv_area; uint32_t bbx;      // bbx = min_x | max_x << 16 (max exclusive, render.rs:1455-1458)
+    uint32_t bby; float u1, u2, u3;
+    float v1, v2, v3; uint32_t flags;
+    uint32_t vc1, vc2, vc3; float w0_start;    // vc = r | g<<8 | b<<16 ; w*_start = render.rs:1517-1518
+    float w1_start; uint32_t face_idx; uint32_t pad0, pad1;
+};
+static_assert(sizeof(SurfRec) == 96, "SurfRec layout");
+
+// SurfRec.flags
+constexpr uint32_t F_TEX_MASK   = 0xFFFu;      // texture slot, 0xFFF = untextured (Color15::WHITE, render.rs:1585)
+constexpr uint32_t F_TEX_NONE   = 0xFFFu;
+constexpr uint32_t F_BLACK_TR   = 1u << 12;    // face.black_transparent
+constexpr uint32_t F_BLEND_SHIFT = 13;         // 3 bits: effective blend mode (texture's if bound, render.rs:1450-1452)
+constexpr uint32_t F_DITHER     = 1u << 16;    // needs_dither, render.rs:1487-1492
+constexpr uint32_t F_SLOW       = 1u << 17;    // replay the incremental edge walk literally
+constexpr uint32_t F_TRANSP     = 1u << 18;    // has_transparency, render.rs:2403-2415
+constexpr uint32_t F_EMPTY      = 1u << 19;    // bbox empty or |area| < 1e-5: counted in triangles_drawn, draws nothing
+constexpr uint32_t F_ALPHA_SHIFT = 24;         // editor_alpha
+
+struct TexDesc { uint32_t width, height, blend_mode, offset; };   // offset into the pooled u16 texel buffer
+
+// Device-side control block, zeroed at the start of every frame.
+struct Ctrl {
+    uint32_t n_visible;        // surfaces surviving cull (== triangles_drawn)
+    uint32_t n_transparent;
+    uint32_t nan_opaque, nan_transparent;
+    uint32_t err_index;        // a face referenced vertex >= nv
+    uint32_t abort;            // set => k_fill draws nothing (error, or pair capacity exceeded)
+    uint32_t n_opaque;
+    uint32_t n_pairs;          // (tile,class) x surface pairs emitted by binning
+    uint32_t pairs_overflow;
+    uint32_t tile_cursor;      // persistent-workgroup tile dispenser of k_fill
+    uint32_t nf;               // copy of the face count (first sort pass length)
+    uint32_t pad;
+    unsigned long long fragments;
+};
+
+// Everything k_setup / k_fill need about the frame, passed by value.
+struct FrameParams {
+    B32Camera cam;
+    uint32_t width, height;
+    uint32_t band_y0, band_y1;
+    uint32_t tiles_x, tiles_y, tile_y0;    // tile grid of the band: tiles_y rows starting at tile row tile_y0
+    uint32_t nv, nf, nt;
+    uint32_t n_lights;
+    float ambient;
+    uint8_t affine, shading, backface_cull, dithering, fixed_point, has_fog, pad0, pad1;
+    B32Fog fog;
+};
+
+// ---------------------------------------------------------------- Rust-semantics helpers (device)
+// `f as u32/usize` for the value ranges this path produces: NaN -> 0, negative -> 0, saturating.
+__device__ __forceinline__ uint32_t f2u_sat(float f) {
+    f = __builtin_fmaxf(f, 0.0f);                 // maxNum: NaN -> 0
+    f = __builtin_fminf(f, 4294967040.0f);
+    return (uint32_t)f;
+}
+__device__ __forceinline__ uint32_t f2u8_sat(float f) {
+    f = __builtin_fmaxf(f, 0.0f);
+    f = __builtin_fminf(f, 255.0f);
+    return (uint32_t)f;
+}
+__device__ __forceinline__ int32_t f2i32_sat(float f) {
+    if (f != f) return 0;
+    if (f >= 2147483648.0f) return INT32_MAX;
+    if (f <= -2147483648.0f) return INT32_MIN;
+    return (int32_t)f;
+}
+// f32::min / f32::max ignore NaN == IEEE minNum/maxNum == fminf/fmaxf.
+__device__ __forceinline__ float rmin(float a, float b) { return __builtin_fminf(a, b); }
+__device__ __forceinline__ float rmax(float a, float b) { return __builtin_fmaxf(a, b); }
+// f32::clamp propagates NaN.
+__device__ __forceinline__ float rclamp(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+// f32::rem_euclid(1.0): fmodf(x,1) == x - trunc(x) exactly; then +1.0 when negative (may round to 1.0).
+__device__ __forceinline__ float rem_euclid1(float x) {
+    float r = x - __builtin_truncf(x);
+    return r < 0.0f ? r + 1.0f : r;
+}
+
+// ---------------------------------------------------------------- colour helpers
+__device__ __forceinline__ uint32_t expand5(uint32_t v5) { return ((v5 << 3) | (v5 >> 2)) & 0xFF; }   // render.rs:1161-1163
+// Color15::to_rgba (types.rs:220-226) as a little-endian RGBA8 word
+__device__ __forceinline__ uint32_t c15_to_rgba(uint32_t c) {
+    if ((c & 0xFFFF) == 0) return 0;
+    return expand5((c >> 10) & 31) | (expand5((c >> 5) & 31) << 8) | (expand5(c & 31) << 16) | 0xFF000000u;
+}
+// PS1_DITHER_MATRIX (render.rs:1150-1155) packed as 16 signed nibbles, index = (y&3)*4 + (x&3)
+__device__ __forceinline__ int dither_offset(uint32_t x, uint32_t y) {
+    // rows: {-4,0,-3,1} {2,-2,3,-1} {-3,1,-4,0} {3,-1,2,-2}; nibble = value & 0xF
+    const unsigned long long M = 0xE2F3'0C1D'F3E2'1D0CULL;
+    uint32_t i = ((y & 3) << 2) | (x & 3);
+    int v = (int)((M >> (i * 4)) & 0xF);
+    return (v ^ 8) - 8;   // sign-extend 4 bits
+}
+// blend_rgb555 (render.rs:1093-1145) on RGBA8 words; returns r|g<<8|b<<16 (no alpha)
+__device__ __forceinline__ uint32_t blend_rgb555(uint32_t front, uint32_t back, uint32_t mode) {
+    uint32_t out = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        int f5 = (int)((front >> (8 * i + 3)) & 31);
+        int b5 = (int)((back >> (8 * i + 3)) & 31);
+        int r5;
+        switch (mode) {
+            default:
+            case B32_BLEND_OPAQUE:      r5 = f5; break;
+            case B32_BLEND_AVERAGE:     r5 = min((b5 + f5) / 2, 31); break;
+            case B32_BLEND_ADD:         r5 = min(b5 + f5, 31); break;
+            case B32_BLEND_SUBTRACT:    r5 = max(b5 - f5, 0); break;
+            case B32_BLEND_ADD_QUARTER: r5 = min(b5 + f5 / 4, 31); break;
+            case B32_BLEND_ERASE:       r5 = b5; break;
+        }
+        out |= (uint32_t)(r5 << 3) << (8 * i);
+    }
+    return out;
+}
+
+// ---------------------------------------------------------------- kernel launchers (defined in the .hip files)
+struct SortScratch {
+    uint32_t* block_hist;   // [256][max_blocks] digit-major
+    uint32_t  max_blocks;
+    uint32_t* digit_total;  // [256]
+};
+constexpr int SORT_THREADS = 256;
+constexpr int SORT_ITEMS = 16;
+constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;   // 4096 keys per block
+
+// One stable LSD pass on `shift`..shift+7. n is read from *n_dev (<= n_cap). If vals_in == nullptr the value of
+// element i is i and keys equal to KEY_INVALID are dropped (first pass over the face-order key array).
+void launch_radix_pass(hipStream_t s, const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
+                       const uint32_t* n_dev, uint32_t n_cap, int shift, const SortScratch& sc);
+
+// k_setup publishes 5 counters per 256-face block (visible, transparent, nan_opaque, nan_transparent, bad_index) into
+// `partials[block*8 + k]`; k_after_setup reduces them into Ctrl.  (One same-address atomic per wave costs ~12 ns each and
+// serialises: 15.6 k waves = the whole kernel time at 1 M faces.)
+void launch_setup(hipStream_t s, const FrameParams& fp, const B32Vertex* verts, const B32Face* faces, const TexDesc* tex,
+                  const B32Light* lights, SurfRec* recs, float* shades, uint32_t* keys, uint32_t* partials);
+void launch_after_setup(hipStream_t s, Ctrl* ctrl, const uint32_t* partials, uint32_t nblocks);
+void launch_project_fixed(hipStream_t s, const float* pos, uint32_t n, B32Camera cam, uint32_t w, uint32_t h,
+                          int32_t* sx, int32_t* sy, float* z);
+void launch_selftest(hipStream_t s, int op, const float* a, const float* b, const float* c, float* out, uint32_t n);
+void launch_clear(hipStream_t s, uint32_t* fb, size_t n_px, uint32_t rgba);
+void launch_expand_indexed(hipStream_t s, const uint8_t* idx, uint32_t n, const uint16_t* clut, uint32_t clut_len, uint16_t* out);
+
+void launch_bin(hipStream_t s, const FrameParams& fp, const SurfRec* recs, const uint32_t* order, Ctrl* ctrl,
+                uint32_t* counts, uint32_t* block_sums, uint32_t max_blocks, uint32_t* pair_keys, uint32_t* pair_vals, uint32_t pair_cap);
+void launch_tile_ranges(hipStream_t s, const uint32_t* pair_keys, const Ctrl* ctrl, uint32_t pair_cap, uint32_t* ranges, uint32_t n_keys);
+
+struct FillArgs {
+    FrameParams fp;
+    const SurfRec* recs;
+    const float* shades;        // [sid][9] or nullptr
+    const uint32_t* pair_vals;  // surface ids, grouped by (tile,class), rank order inside a group
+    const uint32_t* ranges;     // [2*ntiles + 1]
+    const TexDesc* tex;
+    const uint16_t* texels;
+    uint32_t* fb;               // RGBA8 words, full frame
+    Ctrl* ctrl;
+    uint32_t lds_tex_texels;    // > 0: every face samples texture 0 and it is staged in LDS (width*height texels)
+    unsigned long long* debug;
+    uint32_t exact_coverage;    // 1: phase A applies the full skip rule and counts fragment stores; 0: CHEAP coverage + repair
+};
+void launch_fill(hipStream_t s, const FillArgs& a, int n_cu);
+size_t fill_lds_tex_budget();   // bytes of LDS left for a staged texture
+
+}  // namespace b32

@@ -1,0 +1,390 @@
+// b32_setup.hip — per-face transform + snap + cull + triangle setup (one lane per face), plus small utility kernels.
+//
+// Reference stages folded into k_setup (all per face, so no per-vertex intermediate ever touches HBM):
+//   TRANSFORM  render.rs:2313-2362  -> fixed::project_fixed (fixed.rs:424-441) + float cam_pos (math.rs:103-109)
+//   CULL/SETUP render.rs:2364-2516  -> near reject, 2D backface, has_transparency, fog, Surface build
+//   per-triangle prologue of rasterize_triangle_15 (render.rs:1450-1518): bbox, area, edge coefficients, needs_dither,
+//   flat / Gouraud vertex shades (render.rs:1013-1071)
+//   painter's key (render.rs:2527-2541): (v1.z + v2.z + v3.z) / 3.0
+#include "b32_device.h"
+
+namespace b32 {
+
+// ---------------------------------------------------------------- fixed.rs on the device
+struct UnrTable { uint8_t v[257]; };
+static constexpr UnrTable make_unr() {          // UNR_TABLE, fixed.rs:20-31
+    UnrTable t{};
+    for (uint32_t i = 0; i < 257; ++i) {
+        uint32_t q = 262144u / (i + 256u);
+        int32_t val = (int32_t)((q + 1) / 2) - 257;
+        t.v[i] = val > 0 ? (uint8_t)val : 0;
+    }
+    return t;
+}
+__constant__ UnrTable g_unr = make_unr();
+
+__device__ __forceinline__ int32_t wadd(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
+__device__ __forceinline__ int32_t wsub(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
+__device__ __forceinline__ int32_t fx_from_f32(float f) { return f2i32_sat(f * 4096.0f); }           // fixed.rs:125-127
+__device__ __forceinline__ int32_t fx_mul(int32_t a, int32_t b) { return (int32_t)(((int64_t)a * (int64_t)b) >> 12); }  // :161-165
+__device__ int32_t fx_div_unr(int32_t self, int32_t divisor) {                                       // fixed.rs:178-230
+    if (divisor == 0) return 0;
+    bool neg = (self < 0) != (divisor < 0);
+    uint64_t num = (uint64_t)(self < 0 ? (0u - (uint32_t)self) : (uint32_t)self);
+    uint32_t den = divisor < 0 ? (0u - (uint32_t)divisor) : (uint32_t)divisor;
+    uint32_t z = (uint32_t)__builtin_clz(den);
+    uint64_t d16 = ((uint64_t)den << z) >> 16;
+    uint64_t ti = (d16 - 0x7FC0ull) >> 7;
+    if (ti > 256) ti = 256;
+    uint64_t u = (uint64_t)g_unr.v[ti] + 0x101;
+    uint64_t nr1 = (0x2000080ull - d16 * u) >> 8;
+    uint64_t nr2 = (0x80ull + nr1 * u) >> 8;
+    uint64_t raw = num * nr2;
+    uint32_t shift = 36u - z;                       // z in 0..31 -> shift in 5..36
+    uint64_t mag = (raw + (1ull << (shift - 1))) >> shift;
+    int32_t clamped = (int32_t)(mag < (uint64_t)INT32_MAX ? mag : (uint64_t)INT32_MAX);
+    return neg ? -clamped : clamped;
+}
+
+struct CamFx {          // loop-invariant conversions of transform_to_camera_space / project_to_screen
+    int32_t px, py, pz, bx[3], by[3], bz[3];
+    int32_t vs, half_w, half_h;
+};
+__device__ __forceinline__ CamFx make_camfx(const B32Camera& c, uint32_t width, uint32_t height) {
+    CamFx k;
+    k.px = fx_from_f32(c.position[0]); k.py = fx_from_f32(c.position[1]); k.pz = fx_from_f32(c.position[2]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { k.bx[i] = fx_from_f32(c.basis_x[i]); k.by[i] = fx_from_f32(c.basis_y[i]); k.bz[i] = fx_from_f32(c.basis_z[i]); }
+    uint32_t mn = width < height ? width : height;
+    k.vs = fx_from_f32(((float)mn / 2.0f) * 0.75f);                     // fixed.rs:398
+    k.half_w = (int32_t)((uint32_t)((int32_t)width / 2) << 12);         // fixed.rs:399-400
+    k.half_h = (int32_t)((uint32_t)((int32_t)height / 2) << 12);
+    return k;
+}
+// project_fixed, fixed.rs:424-441 (screen integers only; the fixed depth is discarded by render.rs:2331)
+__device__ __forceinline__ void project_fixed_dev(float x, float y, float z, const CamFx& k, int32_t& sx, int32_t& sy) {
+    int32_t rx = wsub(fx_from_f32(x), k.px), ry = wsub(fx_from_f32(y), k.py), rz = wsub(fx_from_f32(z), k.pz);
+    int32_t cx = wadd(wadd(fx_mul(rx, k.bx[0]), fx_mul(ry, k.bx[1])), fx_mul(rz, k.bx[2]));
+    int32_t cy = wadd(wadd(fx_mul(rx, k.by[0]), fx_mul(ry, k.by[1])), fx_mul(rz, k.by[2]));
+    int32_t cz = wadd(wadd(fx_mul(rx, k.bz[0]), fx_mul(ry, k.bz[1])), fx_mul(rz, k.bz[2]));
+    const int32_t distance = 20480, scale = 16384;                      // from_f32(5.0), from_f32(4.0)
+    int32_t denom = wadd(cz, distance);
+    int32_t adenom = denom < 0 ? (int32_t)(0u - (uint32_t)denom) : denom;   // i32::abs wraps at MIN in release
+    if (adenom < 256) { sx = k.half_w >> 12; sy = k.half_h >> 12; return; }
+    int32_t proj_x = fx_div_unr(fx_mul(cx, scale), denom);
+    int32_t proj_y = fx_div_unr(fx_mul(cy, scale), denom);
+    sx = wadd(fx_mul(proj_x, k.vs), k.half_w) >> 12;
+    sy = wadd(fx_mul(proj_y, k.vs), k.half_h) >> 12;
+}
+
+// ---------------------------------------------------------------- math.rs on the device
+struct V3 { float x, y, z; };
+__device__ __forceinline__ float dot3(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }   // (x*ox + y*oy) + z*oz
+__device__ __forceinline__ V3 sub3(V3 a, V3 b) { return { a.x - b.x, a.y - b.y, a.z - b.z }; }
+__device__ __forceinline__ V3 add3(V3 a, V3 b) { return { a.x + b.x, a.y + b.y, a.z + b.z }; }
+__device__ __forceinline__ V3 scale3(V3 a, float s) { return { a.x * s, a.y * s, a.z * s }; }
+__device__ __forceinline__ V3 normalize3(V3 a) {                                                   // math.rs:39-49
+    float l = __builtin_sqrtf(dot3(a, a));
+    if (l == 0.0f) return { 0.0f, 0.0f, 0.0f };
+    return { a.x / l, a.y / l, a.z / l };
+}
+__device__ __forceinline__ V3 ld3(const float* p) { return { p[0], p[1], p[2] }; }
+
+// shade_multi_light_color, render.rs:1013-1071 (spot lights are rejected on the host: acos is not bit-portable)
+__device__ void shade_multi(V3 normal, V3 world_pos, const B32Light* lights, uint32_t n_lights, float ambient, float out[3]) {
+    float tr = ambient, tg = ambient, tb = ambient;
+    for (uint32_t i = 0; i < n_lights; ++i) {
+        const B32Light& l = lights[i];
+        if (!l.enabled) continue;
+        float contribution;
+        if (l.type == B32_LIGHT_DIRECTIONAL) {
+            V3 neg_dir = scale3(ld3(l.direction), -1.0f);
+            contribution = rmax(dot3(normal, neg_dir), 0.0f) * l.intensity;
+        } else {
+            V3 to_light = sub3(ld3(l.position), world_pos);
+            float dist = __builtin_sqrtf(dot3(to_light, to_light));
+            if (dist > l.radius || dist < 0.001f) contribution = 0.0f;
+            else {
+                float attenuation = 1.0f - (dist / l.radius);
+                float n_dot_l = rmax(dot3(normal, normalize3(to_light)), 0.0f);
+                contribution = n_dot_l * l.intensity * attenuation * attenuation;
+            }
+        }
+        float lr = (float)l.r / 255.0f, lg = (float)l.g / 255.0f, lb = (float)l.b / 255.0f;
+        tr += contribution * lr; tg += contribution * lg; tb += contribution * lb;
+    }
+    out[0] = rmin(tr, 1.0f); out[1] = rmin(tg, 1.0f); out[2] = rmin(tb, 1.0f);
+}
+
+// fog, render.rs:2266-2293. Colours are r | g<<8 | b<<16 | blend<<24.
+__device__ __forceinline__ float fog_factor(float z, float start, float falloff) {
+    if (z <= start) return 0.0f;
+    if (falloff <= 0.0f) return 1.0f;
+    return rmin((z - start) / falloff, 1.0f);
+}
+__device__ __forceinline__ uint32_t fog_color(uint32_t c, uint32_t fogc, float f) {
+    if (f <= 0.0f) return c;
+    if (f >= 1.0f) return fogc;
+    float inv = 1.0f - f;
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        o |= f2u8_sat((float)((c >> (8 * i)) & 255) * inv + (float)((fogc >> (8 * i)) & 255) * f) << (8 * i);
+    return o;   // Color::new -> blend Opaque (0)
+}
+
+// ---------------------------------------------------------------- k_setup
+__global__ __launch_bounds__(256) void k_setup(FrameParams fp, const B32Vertex* __restrict__ verts, const B32Face* __restrict__ faces,
+                                               const TexDesc* __restrict__ tex, const B32Light* __restrict__ lights,
+                                               SurfRec* __restrict__ recs, float* __restrict__ shades, uint32_t* __restrict__ keys,
+                                               uint32_t* __restrict__ partials) {
+    __shared__ uint32_t wpart[4][5];
+    const uint32_t f = blockIdx.x * 256u + threadIdx.x;
+    bool visible = false, transparent = false, nan_key = false, bad_index = false;
+    uint32_t key = KEY_INVALID;
+    if (f < fp.nf) {
+        const uint32_t* fw = reinterpret_cast<const uint32_t*>(faces) + (size_t)f * 5;
+        uint32_t vi[3] = { fw[0], fw[1], fw[2] };
+        const uint32_t tid = fw[3], fb4 = fw[4];
+        const uint32_t black_tr = fb4 & 0xFF, face_blend = (fb4 >> 8) & 0xFF, editor_alpha = (fb4 >> 16) & 0xFF;
+        if (vi[0] >= fp.nv || vi[1] >= fp.nv || vi[2] >= fp.nv) {
+            bad_index = true;                                   // index panic, render.rs:2375-2377
+        } else {
+            const CamFx k = make_camfx(fp.cam, fp.width, fp.height);
+            const V3 cpos = ld3(fp.cam.position), bx = ld3(fp.cam.basis_x), by = ld3(fp.cam.basis_y), bz = ld3(fp.cam.basis_z);
+            V3 scr[3]; float camz[3]; V3 wpos[3]; float uvx[3], uvy[3]; uint32_t col[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const float* vp = reinterpret_cast<const float*>(verts) + (size_t)vi[j] * 9;
+                V3 pos = { vp[0], vp[1], vp[2] };
+                uvx[j] = vp[3]; uvy[j] = vp[4];
+                col[j] = reinterpret_cast<const uint32_t*>(vp)[8];
+                wpos[j] = pos;
+                V3 rel = sub3(pos, cpos);
+                V3 cp = { dot3(rel, bx), dot3(rel, by), dot3(rel, bz) };       // perspective_transform, math.rs:103-109
+                camz[j] = cp.z;
+                if (fp.fixed_point) {                                            // render.rs:2329-2345
+                    int32_t sx, sy;
+                    project_fixed_dev(pos.x, pos.y, pos.z, k, sx, sy);
+                    scr[j] = { (float)sx, (float)sy, cp.z + 5.0f };
+                } else {                                                         // project, math.rs:117-136
+                    uint32_t mn = fp.width < fp.height ? fp.width : fp.height;
+                    float vs = ((float)mn / 2.0f) * 0.75f;
+                    float denom = cp.z + 5.0f;
+                    if (__builtin_fabsf(denom) < 0.001f) scr[j] = { (float)fp.width / 2.0f, (float)fp.height / 2.0f, cp.z };
+                    else scr[j] = { (cp.x * 4.0f) / denom * vs + ((float)fp.width / 2.0f),
+                                    (cp.y * 4.0f) / denom * vs + ((float)fp.height / 2.0f), denom };
+                }
+            }
+            bool keep = !(camz[0] <= 0.1f || camz[1] <= 0.1f || camz[2] <= 0.1f);   // near plane, render.rs:2381-2385
+            float signed_area = (scr[1].x - scr[0].x) * (scr[2].y - scr[0].y) - (scr[2].x - scr[0].x) * (scr[1].y - scr[0].y);
+            bool backface = signed_area <= 0.0f;                                     // render.rs:2393-2394
+            if (backface && fp.backface_cull) keep = false;
+            const bool have_tex = tid != B32_NO_TEXTURE && tid < fp.nt;             // textures.get(id)
+            uint32_t tex_blend = B32_BLEND_OPAQUE;
+            if (keep && have_tex) tex_blend = tex[tid].blend_mode;
+            if (fp.has_fog && keep) {                                                // render.rs:2419-2442
+                if (camz[0] > fp.fog.cull_distance && camz[1] > fp.fog.cull_distance && camz[2] > fp.fog.cull_distance) keep = false;
+                else {
+                    uint32_t fogc = fp.fog.r | (fp.fog.g << 8) | (fp.fog.b << 16) | ((uint32_t)fp.fog.blend << 24);
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) col[j] = fog_color(col[j], fogc, fog_factor(camz[j], fp.fog.start, fp.fog.falloff));
+                }
+            }
+            if (keep) {
+                visible = true;
+                transparent = (have_tex && tex_blend != B32_BLEND_OPAQUE) || face_blend != B32_BLEND_OPAQUE || editor_alpha < 255;  // :2403-2415
+                // Surface build: rendered backfaces swap v2/v3 and every per-vertex attribute (render.rs:2453-2479)
+                const int i1 = 0, i2 = backface ? 2 : 1, i3 = backface ? 1 : 2;
+                const V3 v1 = scr[i1], v2 = scr[i2], v3 = scr[i3];
+                SurfRec r;
+                // bbox, render.rs:1455-1458
+                uint32_t min_x = f2u_sat(rmax(rmin(rmin(v1.x, v2.x), v3.x), 0.0f));
+                uint32_t max_x = f2u_sat(rmin(rmax(rmax(v1.x, v2.x), v3.x) + 1.0f, (float)fp.width));
+                uint32_t min_y = f2u_sat(rmax(rmin(rmin(v1.y, v2.y), v3.y), 0.0f));
+                uint32_t max_y = f2u_sat(rmin(rmax(rmax(v1.y, v2.y), v3.y) + 1.0f, (float)fp.height));
+                bool empty = min_x >= max_x || min_y >= max_y;
+                float area = (v2.y - v3.y) * (v1.x - v3.x) + (v3.x - v2.x) * (v1.y - v3.y);      // :1500
+                if (__builtin_fabsf(area) < 0.00001f) empty = true;                               // :1501-1503
+                if (empty) { min_x = max_x = min_y = max_y = 0; }
+                r.inv_area = 1.0f / area;
+                r.a0 = v2.y - v3.y; r.b0 = v3.x - v2.x; r.a1 = v3.y - v1.y; r.b1 = v1.x - v3.x;   // :1507-1510
+                r.x3 = v3.x; r.y3 = v3.y;
+                const float start_x = (float)min_x, start_y = (float)min_y;
+                r.w0_start = r.a0 * (start_x - v3.x) + r.b0 * (start_y - v3.y);                    // :1517
+                r.w1_start = r.a1 * (start_x - v3.x) + r.b1 * (start_y - v3.y);                    // :1518
+                r.bbx = min_x | (max_x << 16); r.bby = min_y | (max_y << 16);
+                r.u1 = uvx[i1]; r.u2 = uvx[i2]; r.u3 = uvx[i3];
+                r.v1 = uvy[i1]; r.v2 = uvy[i2]; r.v3 = uvy[i3];
+                r.vc1 = col[i1] & 0xFFFFFF; r.vc2 = col[i2] & 0xFFFFFF; r.vc3 = col[i3] & 0xFFFFFF;
+                r.face_idx = f; r.pad0 = 0; r.pad1 = 0;
+                // Closed-form eligibility: with integer vertices every value the reference's incremental walk ever holds
+                // is an exact integer when |w| < 2^24 over the bbox and both start products are < 2^24.
+                bool slow = !fp.fixed_point;
+                if (!slow && !empty) {
+                    const float lim = 4194304.0f;   // 2^22
+                    if (!(__builtin_fabsf(v1.x) <= lim && __builtin_fabsf(v1.y) <= lim && __builtin_fabsf(v2.x) <= lim &&
+                          __builtin_fabsf(v2.y) <= lim && __builtin_fabsf(v3.x) <= lim && __builtin_fabsf(v3.y) <= lim)) slow = true;
+                    else {
+                        const int64_t A0 = (int64_t)r.a0, B0 = (int64_t)r.b0, A1 = (int64_t)r.a1, B1 = (int64_t)r.b1;
+                        const int64_t X3 = (int64_t)v3.x, Y3 = (int64_t)v3.y;
+                        const int64_t dx[2] = { (int64_t)min_x - X3, (int64_t)max_x - 1 - X3 };
+                        const int64_t dy[2] = { (int64_t)min_y - Y3, (int64_t)max_y - 1 - Y3 };
+                        const int64_t L = 16777216;   // 2^24
+                        for (int a = 0; a < 2; ++a)
+                            for (int b = 0; b < 2; ++b) {
+                                int64_t p0 = A0 * dx[a], q0 = B0 * dy[b], p1 = A1 * dx[a], q1 = B1 * dy[b];
+                                if (llabs(p0) >= L || llabs(q0) >= L || llabs(p1) >= L || llabs(q1) >= L ||
+                                    llabs(p0 + q0) >= L || llabs(p1 + q1) >= L) slow = true;
+                            }
+                    }
+                }
+                const bool vc_diff = (col[i1] != col[i2]) || (col[i2] != col[i3]);                  // Color equality incl. blend, types.rs:719
+                const bool needs_dither = fp.dithering && (fp.shading == B32_SHADE_GOURAUD || have_tex || vc_diff);   // :1487-1492
+                const uint32_t eff_blend = have_tex ? tex_blend : face_blend;                       // :1450-1452
+                r.flags = (have_tex ? tid : F_TEX_NONE) | (black_tr ? F_BLACK_TR : 0) | (eff_blend << F_BLEND_SHIFT) |
+                          (needs_dither ? F_DITHER : 0) | (slow ? F_SLOW : 0) | (transparent ? F_TRANSP : 0) |
+                          (empty ? F_EMPTY : 0) | (editor_alpha << F_ALPHA_SHIFT);
+                recs[f] = r;
+                if (fp.shading != B32_SHADE_NONE) {
+                    V3 wn[3];
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const float* vp = reinterpret_cast<const float*>(verts) + (size_t)vi[j] * 9;
+                        wn[j] = { vp[5], vp[6], vp[7] };
+                        if (backface) wn[j] = scale3(wn[j], -1.0f);
+                    }
+                    float* sh = shades + (size_t)f * 9;
+                    if (fp.shading == B32_SHADE_FLAT) {                                             // :1466-1469
+                        V3 center = scale3(add3(add3(wpos[i1], wpos[i2]), wpos[i3]), 1.0f / 3.0f);
+                        V3 nrm = normalize3(scale3(add3(add3(wn[i1], wn[i2]), wn[i3]), 1.0f / 3.0f));
+                        float s[3]; shade_multi(nrm, center, lights, fp.n_lights, fp.ambient, s);
+                        for (int j = 0; j < 9; ++j) sh[j] = s[j % 3];
+                    } else {                                                                        // :1475-1483
+                        shade_multi(wn[i1], wpos[i1], lights, fp.n_lights, fp.ambient, sh);
+                        shade_multi(wn[i2], wpos[i2], lights, fp.n_lights, fp.ambient, sh + 3);
+                        shade_multi(wn[i3], wpos[i3], lights, fp.n_lights, fp.ambient, sh + 6);
+                    }
+                }
+                // painter's key, render.rs:2529-2531 / 2538-2540. Perspective keys are > 5 (cam z > 0.1), so the sign bit
+                // is free: bit 31 = transparent class, low 31 bits = 0x7FFFFFFF - bits(z) => ascending radix == descending z,
+                // stability of the LSD passes == stability of slice::sort_by.
+                float kz = (v1.z + v2.z + v3.z) / 3.0f;
+                if (kz != kz) { nan_key = true; kz = 0.0f; }
+                if (kz == 0.0f) kz = 0.0f;                    // -0.0 == +0.0 under partial_cmp
+                uint32_t zb = __float_as_uint(kz);
+                key = ((0x7FFFFFFFu - (zb & 0x7FFFFFFFu)) & 0x7FFFFFFFu) | (transparent ? 0x80000000u : 0u);
+                if (key == KEY_INVALID) key = 0xFFFFFFFEu;    // unreachable for z > 5; keeps the sentinel unique
+            }
+        }
+        keys[f] = key;
+    }
+    // frame counters: ballot per wave -> LDS -> one 5-word record per block (reduced by k_after_setup; no atomics)
+    const unsigned long long mv = __ballot(visible), mt = __ballot(transparent);
+    const unsigned long long mn_op = __ballot(nan_key && !transparent), mn_tr = __ballot(nan_key && transparent), mb = __ballot(bad_index);
+    const uint32_t wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        wpart[wv][0] = (uint32_t)__popcll(mv); wpart[wv][1] = (uint32_t)__popcll(mt);
+        wpart[wv][2] = (uint32_t)__popcll(mn_op); wpart[wv][3] = (uint32_t)__popcll(mn_tr); wpart[wv][4] = mb ? 1u : 0u;
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) partials[blockIdx.x * 8 + threadIdx.x] = wpart[0][threadIdx.x] + wpart[1][threadIdx.x] + wpart[2][threadIdx.x] + wpart[3][threadIdx.x];
+}
+
+// After k_setup: derive n_opaque and decide whether the frame may draw at all.  The reference panics before drawing
+// on an out-of-range vertex index (render.rs:2375) or when a sort comparison sees NaN (render.rs:2531, lists of >= 2).
+__global__ __launch_bounds__(1024) void k_after_setup(Ctrl* ctrl, const uint32_t* __restrict__ partials, uint32_t nblocks) {
+    __shared__ uint32_t red[16][5];
+    uint32_t acc[5] = { 0, 0, 0, 0, 0 };
+    for (uint32_t b = threadIdx.x; b < nblocks; b += 1024)
+        for (int k = 0; k < 5; ++k) acc[k] += partials[b * 8 + k];
+    for (int k = 0; k < 5; ++k)
+        for (int off = 32; off > 0; off >>= 1) acc[k] += __shfl_down(acc[k], off);
+    if ((threadIdx.x & 63) == 0) for (int k = 0; k < 5; ++k) red[threadIdx.x >> 6][k] = acc[k];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t[5] = { 0, 0, 0, 0, 0 };
+        for (int w = 0; w < 16; ++w) for (int k = 0; k < 5; ++k) t[k] += red[w][k];
+        const uint32_t n_op = t[0] - t[1];
+        ctrl->n_visible = t[0]; ctrl->n_transparent = t[1]; ctrl->nan_opaque = t[2]; ctrl->nan_transparent = t[3];
+        ctrl->err_index = t[4] ? 1u : 0u;
+        ctrl->n_opaque = n_op;
+        if (t[4]) ctrl->abort = 1;
+        if ((t[2] && n_op >= 2) || (t[3] && t[1] >= 2)) ctrl->abort = 1;
+    }
+}
+
+void launch_setup(hipStream_t s, const FrameParams& fp, const B32Vertex* verts, const B32Face* faces, const TexDesc* tex,
+                  const B32Light* lights, SurfRec* recs, float* shades, uint32_t* keys, uint32_t* partials) {
+    if (fp.nf == 0) return;
+    hipLaunchKernelGGL(k_setup, dim3((fp.nf + 255) / 256), dim3(256), 0, s, fp, verts, faces, tex, lights, recs, shades, keys, partials);
+}
+void launch_after_setup(hipStream_t s, Ctrl* ctrl, const uint32_t* partials, uint32_t nblocks) {
+    hipLaunchKernelGGL(k_after_setup, dim3(1), dim3(1024), 0, s, ctrl, partials, nblocks);
+}
+
+// ---------------------------------------------------------------- stage tap: project_fixed for n positions
+__global__ void k_project_fixed(const float* __restrict__ pos, uint32_t n, B32Camera cam, uint32_t w, uint32_t h,
+                                int32_t* __restrict__ sx, int32_t* __restrict__ sy, float* __restrict__ z) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    CamFx k = make_camfx(cam, w, h);
+    V3 p = { pos[3 * i], pos[3 * i + 1], pos[3 * i + 2] };
+    int32_t x, y;
+    project_fixed_dev(p.x, p.y, p.z, k, x, y);
+    V3 rel = sub3(p, ld3(cam.position));
+    sx[i] = x; sy[i] = y; z[i] = dot3(rel, ld3(cam.basis_z)) + 5.0f;     // render.rs:2343-2345
+}
+void launch_project_fixed(hipStream_t s, const float* pos, uint32_t n, B32Camera cam, uint32_t w, uint32_t h,
+                          int32_t* sx, int32_t* sy, float* z) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_project_fixed, dim3((n + 255) / 256), dim3(256), 0, s, pos, n, cam, w, h, sx, sy, z);
+}
+
+// ---------------------------------------------------------------- f32 semantics self-test
+__global__ void k_selftest(int op, const float* a, const float* b, const float* c, float* out, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float r;
+    switch (op) {
+        case 0: r = a[i] * b[i] + c[i]; break;          // must round twice (no FMA contraction)
+        case 1: r = a[i] / b[i]; break;                 // correctly rounded
+        case 2: r = __builtin_sqrtf(a[i]); break;       // correctly rounded
+        default: r = (a[i] + b[i]) / c[i]; break;
+    }
+    out[i] = r;
+}
+void launch_selftest(hipStream_t s, int op, const float* a, const float* b, const float* c, float* out, uint32_t n) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_selftest, dim3((n + 255) / 256), dim3(256), 0, s, op, a, b, c, out, n);
+}
+
+// ---------------------------------------------------------------- Framebuffer::clear (render.rs:36-45): 16-B coalesced stores
+__global__ void k_clear(uint32_t* __restrict__ fb, size_t n_px, uint32_t rgba) {
+    size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
+    for (; i + 3 < n_px; i += stride) *reinterpret_cast<uint4*>(fb + i) = make_uint4(rgba, rgba, rgba, rgba);
+    if (i < n_px) for (size_t j = i; j < n_px; ++j) fb[j] = rgba;
+}
+void launch_clear(hipStream_t s, uint32_t* fb, size_t n_px, uint32_t rgba) {
+    if (!n_px) return;
+    size_t quads = (n_px + 3) / 4;
+    uint32_t blocks = (uint32_t)((quads + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_clear, dim3(blocks), dim3(256), 0, s, fb, n_px, rgba);
+}
+
+// ---------------------------------------------------------------- Clut::lookup expansion (types.rs:390-397, mesh_editor.rs:669-682)
+__global__ void k_expand_indexed(const uint8_t* __restrict__ idx, uint32_t n, const uint16_t* __restrict__ clut, uint32_t clut_len,
+                                 uint16_t* __restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t k = idx[i];
+    out[i] = k < clut_len ? clut[k] : (uint16_t)0;
+}
+void launch_expand_indexed(hipStream_t s, const uint8_t* idx, uint32_t n, const uint16_t* clut, uint32_t clut_len, uint16_t* out) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_expand_indexed, dim3((n + 255) / 256), dim3(256), 0, s, idx, n, clut, clut_len, out);
+}
+
+}  // namespace b32

@@ -1,0 +1,232 @@
+/*
+ * b32raster.h — C ABI of the MI355X-native bonnie-32 rasterizer hot path.
+ *
+ * This is the drop-in boundary for the reference's `render_mesh_15`
+ * (reference: src/rasterizer/render.rs:2302-2310, re-exported at
+ * src/rasterizer/mod.rs:63) and the `Framebuffer` it draws into
+ * (render.rs:10-45).  The reference has no FFI seam today; these entry points
+ * are exactly what a Rust `extern "C"` block for that path would bind (see
+ * INTEGRATION.md for the Rust-side stub).
+ *
+ * Plain pointers and sizes only; no torch / HIP types in any signature
+ * (streams and device pointers travel as `void*`).
+ *
+ * The same POD structs are consumed by the CPU oracle (oracle/b32_oracle.c),
+ * which is test infrastructure and never linked into the product library.
+ */
+#ifndef B32RASTER_H
+#define B32RASTER_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes (reference behaviour in brackets) ---------------------- */
+#define B32_OK             0
+#define B32_E_ARG         -1  /* null pointer / zero-size framebuffer                      */
+#define B32_E_INDEX       -2  /* face.v* >= nv            [index panic, render.rs:2375-2377] */
+#define B32_E_NAN_KEY     -3  /* NaN painter's key        [unwrap panic, render.rs:2531]     */
+#define B32_E_HIP         -4  /* HIP runtime failure (b32_last_hip_error has the code)      */
+#define B32_E_UNSUPPORTED -5  /* setting outside SURVEY §8 scope (z-buffer, ortho, xray, wireframe, spot light) */
+#define B32_E_NO_DEVICE   -6  /* no gfx950 device / kernels missing: the product path never falls back to CPU   */
+
+/* ---- enums mirrored as integers ------------------------------------------ */
+/* BlendMode, types.rs:1380-1388 */
+#define B32_BLEND_OPAQUE      0
+#define B32_BLEND_AVERAGE     1
+#define B32_BLEND_ADD         2
+#define B32_BLEND_SUBTRACT    3
+#define B32_BLEND_ADD_QUARTER 4
+#define B32_BLEND_ERASE       5
+/* ShadingMode, types.rs:1289-1294 */
+#define B32_SHADE_NONE    0
+#define B32_SHADE_FLAT    1
+#define B32_SHADE_GOURAUD 2
+/* LightType, types.rs:1297-1304 */
+#define B32_LIGHT_DIRECTIONAL 0
+#define B32_LIGHT_POINT       1
+#define B32_LIGHT_SPOT        2   /* acos: not bit-portable -> B32_E_UNSUPPORTED */
+
+#define B32_NO_TEXTURE 0xFFFFFFFFu
+
+/* ---- POD mirrors of the reference API types ------------------------------ */
+
+/* Vertex, types.rs:947-959 (bone_index is editor-only and dropped). 36 B. */
+typedef struct B32Vertex {
+    float   pos[3];
+    float   uv[2];
+    float   normal[3];
+    uint8_t r, g, b, blend;      /* Color{r,g,b,blend}, types.rs:721-726 */
+} B32Vertex;
+
+/* Face, types.rs:984-1002. 20 B. texture_id: Option<usize> -> B32_NO_TEXTURE = None. */
+typedef struct B32Face {
+    uint32_t v[3];
+    uint32_t texture_id;
+    uint8_t  black_transparent;
+    uint8_t  blend_mode;
+    uint8_t  editor_alpha;
+    uint8_t  _pad;
+} B32Face;
+
+/* Texture15, types.rs:532-539. `pixels` is a HOST pointer to width*height Color15 (u16). */
+typedef struct B32Texture15 {
+    uint32_t        width, height;
+    uint32_t        blend_mode;
+    uint32_t        _pad;
+    const uint16_t* pixels;
+} B32Texture15;
+
+/* IndexedAtlas + Clut (modeler/mesh_editor.rs:594-682, types.rs:390-397): one byte per texel for
+ * both 4- and 8-bit depths; out-of-range index -> 0x0000.  Expanded with Clut::lookup semantics
+ * exactly as IndexedAtlas::to_texture15 does before the rasterizer sees it (scene.rs:164). */
+typedef struct B32IndexedTexture {
+    uint32_t        width, height;
+    uint32_t        blend_mode;
+    uint32_t        clut_len;     /* 16 or 256 */
+    const uint8_t*  indices;      /* HOST pointer, width*height */
+    const uint16_t* clut;         /* HOST pointer, clut_len Color15 */
+} B32IndexedTexture;
+
+/* Camera, camera.rs:9-18: basis vectors are inputs (sin/cos stay on the host). */
+typedef struct B32Camera {
+    float position[3];
+    float basis_x[3];
+    float basis_y[3];
+    float basis_z[3];
+} B32Camera;
+
+/* Light, types.rs:1306-1314 */
+typedef struct B32Light {
+    uint32_t type;
+    float    position[3];
+    float    direction[3];
+    float    radius;
+    float    angle;
+    float    intensity;
+    uint8_t  r, g, b, enabled;
+} B32Light;
+
+/* RasterSettings, types.rs:1392-1428 (low_resolution / stretch_to_fill are presentation-only). */
+typedef struct B32Settings {
+    uint8_t affine_textures;
+    uint8_t use_zbuffer;
+    uint8_t shading;
+    uint8_t backface_cull;
+    uint8_t backface_wireframe;
+    uint8_t dithering;
+    uint8_t wireframe_overlay;
+    uint8_t use_rgb555;
+    uint8_t use_fixed_point;
+    uint8_t xray_mode;
+    uint8_t has_ortho;           /* ortho_projection.is_some() */
+    uint8_t _pad;
+    float   ambient;
+    float   ortho_zoom, ortho_center_x, ortho_center_y;
+    uint32_t        n_lights;
+    const B32Light* lights;      /* HOST pointer */
+} B32Settings;
+
+/* fog: Option<(f32,f32,f32,Color)> of render_mesh_15 (render.rs:2309); NULL pointer = None. */
+typedef struct B32Fog {
+    float   start, falloff, cull_distance;
+    uint8_t r, g, b, blend;
+} B32Fog;
+
+/* RasterTimings, types.rs:1499-1514, plus the exact fragment-store count used for Mpixels/s. */
+typedef struct B32Timings {
+    float    transform_ms, fog_ms, cull_ms, sort_ms, draw_ms, wireframe_ms;
+    uint32_t triangles_drawn;    /* opaque.len()+transparent.len(), render.rs:2545 */
+    uint32_t _pad;
+    uint64_t fragments;          /* pixel stores reached in rasterize_triangle_15 (render.rs:1671-1702) */
+} B32Timings;
+
+typedef struct b32_ctx b32_ctx;
+
+/* ---- context -------------------------------------------------------------- */
+/* One ctx = one device = one caller thread at a time.  Fails with B32_E_NO_DEVICE when no HIP
+ * device is visible; there is no CPU fallback. */
+int         b32_create(int device, b32_ctx** out);
+void        b32_destroy(b32_ctx* ctx);
+const char* b32_strerror(int code);
+int         b32_last_hip_error(const b32_ctx* ctx);
+/* Run on a caller-owned hipStream_t (e.g. torch's current stream); NULL = the ctx's own stream. */
+int         b32_set_stream(b32_ctx* ctx, void* hip_stream);
+int         b32_synchronize(b32_ctx* ctx);
+
+/* ---- Framebuffer (render.rs:10-45) --------------------------------------- */
+int b32_fb_resize(b32_ctx* ctx, uint32_t width, uint32_t height);           /* Framebuffer::new/resize: zero-filled on change */
+int b32_fb_clear(b32_ctx* ctx, uint8_t r, uint8_t g, uint8_t b, uint8_t blend); /* Framebuffer::clear :36-45 */
+int b32_fb_upload(b32_ctx* ctx, const uint8_t* rgba);                        /* host fb.pixels -> device */
+int b32_fb_download(b32_ctx* ctx, uint8_t* rgba);                            /* device -> host fb.pixels */
+/* Draw into caller-owned DEVICE memory (width*height*4 B, e.g. a torch uint8 tensor) instead of the
+ * ctx-owned buffer; pass NULL to return to the ctx-owned buffer. */
+int b32_fb_bind_device(b32_ctx* ctx, void* device_rgba, uint32_t width, uint32_t height);
+int b32_fb_size(const b32_ctx* ctx, uint32_t* width, uint32_t* height);
+/* Multi-GPU screen-band sharding: only rows [y0,y1) are filled by this ctx (default = whole frame). */
+int b32_set_band(b32_ctx* ctx, uint32_t y0, uint32_t y1);
+
+/* ---- render_mesh_15 (render.rs:2302-2638) -------------------------------- */
+/* Drop-in form: host slices in, framebuffer stays device resident (read-modify-write). */
+int b32_render_mesh_15(b32_ctx* ctx,
+                       const B32Vertex* vertices, uint32_t nv,
+                       const B32Face* faces, uint32_t nf,
+                       const B32Texture15* textures, uint32_t nt,
+                       const B32Camera* camera, const B32Settings* settings,
+                       const B32Fog* fog /* nullable */,
+                       B32Timings* out /* nullable */);
+
+/* Resident form (scene.rs:112-261 step-before): upload a mesh once, draw it many times. */
+int b32_scene_upload(b32_ctx* ctx,
+                     const B32Vertex* vertices, uint32_t nv,
+                     const B32Face* faces, uint32_t nf,
+                     const B32Texture15* textures, uint32_t nt);
+/* Same, textures given as index atlas + CLUT; the expansion (Clut::lookup) runs on the device. */
+int b32_scene_upload_indexed(b32_ctx* ctx,
+                             const B32Vertex* vertices, uint32_t nv,
+                             const B32Face* faces, uint32_t nf,
+                             const B32IndexedTexture* textures, uint32_t nt);
+int b32_render_scene_15(b32_ctx* ctx,
+                        const B32Camera* camera, const B32Settings* settings,
+                        const B32Fog* fog /* nullable */,
+                        B32Timings* out /* nullable */);
+/* Asynchronous draw of the resident scene: enqueue only, no host sync, no timings. Errors and counters
+ * of the most recent frame are collected by b32_frame_finish (which synchronizes the stream). */
+int b32_render_scene_15_async(b32_ctx* ctx,
+                              const B32Camera* camera, const B32Settings* settings,
+                              const B32Fog* fog /* nullable */);
+int b32_frame_finish(b32_ctx* ctx, B32Timings* out /* nullable */);
+
+/* ---- stage taps (parity tests only; not on the frame path) ---------------- */
+/* fixed::project_fixed (fixed.rs:424-441) + float depth (render.rs:2331-2345) for n positions. */
+int b32_project_fixed_batch(b32_ctx* ctx, const float* pos_xyz, uint32_t n,
+                            const B32Camera* camera, uint32_t width, uint32_t height,
+                            int32_t* sx, int32_t* sy, float* z);
+/* Draw order of the last frame: face index of every surviving surface, in the order drawn
+ * (opaque sorted, then transparent sorted; render.rs:2518-2569). `cap` entries max; returns count via n. */
+int b32_last_draw_order(b32_ctx* ctx, uint32_t* face_idx, uint32_t cap, uint32_t* n);
+/* IEEE-754 f32 self-test of the device arithmetic the pipeline relies on (no FMA contraction,
+ * correctly rounded / and sqrt, denormals kept): evaluates op(a[i], b[i], c[i]) on the GPU.
+ * op: 0 a*b+c (two roundings), 1 a/b, 2 sqrt(a), 3 (a+b)/c. */
+int b32_selftest_f32(b32_ctx* ctx, int op, const float* a, const float* b, const float* c,
+                     float* out, uint32_t n);
+
+/* Per-kernel device time of the last finished frame (HIP events on the ctx stream), for bench.py.
+ * names[i] points at static strings; returns the number of entries written (<= cap). */
+int b32_last_kernel_times(b32_ctx* ctx, const char** names, float* ms, uint32_t cap);
+/* HIP-event instrumentation of the frames enqueued from now on: 0 = none (default for the async path),
+ * 1 = events around the fill kernel, 2 = events around every phase. Averages over the frames between two
+ * b32_frame_finish calls (last 64 at most) are returned by b32_last_kernel_times / B32Timings. */
+int b32_set_profiling(b32_ctx* ctx, int level);
+/* B32Timings.fragments (the reference's pixel-store count, render.rs:1671-1702) is instrumentation, not an output of
+ * render_mesh_15.  on = 1 (default): counted exactly every frame.  on = 0: B32Timings.fragments is only exact for
+ * frames whose textures force exact coverage; the fill may then resolve opaque visibility without fetching the texel
+ * of every overdrawn fragment (identical framebuffer, see b32_fill.hip). */
+int b32_set_fragment_counting(b32_ctx* ctx, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* B32RASTER_H */
