@@ -53,6 +53,7 @@ struct b32_ctx {
     uint32_t* partials = nullptr; uint32_t partial_blocks = 0;
     // tiles
     uint32_t* ranges = nullptr; size_t cap_ranges = 0;
+    uint2* vis = nullptr; size_t cap_vis = 0;
     // control
     Ctrl* d_ctrl = nullptr; uint32_t* d_consts = nullptr; Ctrl h_ctrl{};
     B32Light* d_lights = nullptr; size_t cap_lights = 0; std::vector<B32Light> h_lights;
@@ -135,7 +136,7 @@ void b32_destroy(b32_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = { c->fb_own, c->d_verts, c->d_faces, c->d_texels, c->d_tex, c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->recs,
                      c->shades, c->counts, c->block_sums, c->pkeys[0], c->pkeys[1], c->pvals[0], c->pvals[1], c->block_hist, c->ranges,
-                     c->d_ctrl, c->d_consts, c->d_lights, c->digit_total, c->partials };
+                     c->d_ctrl, c->d_consts, c->d_lights, c->digit_total, c->partials, c->vis };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->ev_created) for (auto& fr : c->ev) for (auto& e : fr) if (e) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -401,6 +402,11 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
         c->cap_ranges = (size_t)n_keys + 64;
     }
 
+    if ((size_t)c->width * c->height > c->cap_vis || !c->vis) {
+        if ((rc = ensure_plain(c, c->vis, (size_t)c->width * c->height + 64))) return rc;
+        c->cap_vis = (size_t)c->width * c->height;
+    }
+
     const bool prof_all = c->profile_level >= 2, prof_fill = c->profile_level >= 1;
     hipEvent_t* ev = nullptr;
     if (prof_fill) {
@@ -439,13 +445,15 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
 
     FillArgs fa{};
     fa.fp = fp; fa.recs = c->recs; fa.shades = c->shades; fa.pair_vals = c->pvals[cur]; fa.ranges = c->ranges;
-    fa.tex = c->d_tex; fa.texels = c->d_texels; fa.fb = c->fb; fa.ctrl = c->d_ctrl;
+    fa.tex = c->d_tex; fa.texels = c->d_texels; fa.fb = c->fb; fa.vis = c->vis; fa.ctrl = c->d_ctrl;
+    fa.tex0 = c->nt ? c->h_tex[0] : TexDesc{ 0, 0, 0, 0 };
     fa.lds_tex_texels = 0;
     if (c->nt == 1) {
         const size_t n = (size_t)c->h_tex[0].width * c->h_tex[0].height;
         if (n > 0 && n * 2 <= fill_lds_tex_budget()) fa.lds_tex_texels = (uint32_t)n;
     }
     fa.exact_coverage = (c->count_fragments || !c->cheap_ok) ? 1u : 0u;
+    if (!fa.exact_coverage) fa.lds_tex_texels = 0;      // CHEAP coverage: one texel fetch per output pixel, served by L1/L2
     launch_fill(s, fa, c->n_cu);
     if (prof_fill) { HIPCHK(c, hipEventRecord(ev[4], s)); c->ev_frames++; }
     HIPCHK(c, hipGetLastError());

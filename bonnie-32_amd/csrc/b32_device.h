@@ -181,6 +181,8 @@ struct FillArgs {
     const TexDesc* tex;
     const uint16_t* texels;
     uint32_t* fb;               // RGBA8 words, full frame
+    uint2* vis;                 // visibility buffer per pixel: x = winning tile-list position (1-based, 0 = uncovered), y = surface id
+    TexDesc tex0;               // descriptor of texture 0 (used when nt == 1: no per-pixel descriptor gather)
     Ctrl* ctrl;
     uint32_t lds_tex_texels;    // > 0: every face samples texture 0 and it is staged in LDS (width*height texels)
     uint32_t exact_coverage;    // 1: phase A applies the full skip rule and counts fragment stores; 0: CHEAP coverage + repair

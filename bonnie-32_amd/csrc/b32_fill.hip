@@ -1,41 +1,37 @@
-// b32_fill.hip — affine texture-mapped triangle fill with RGB555 dither (rasterize_triangle_15, render.rs:1440-1714).
+// b32_fill.hip — affine texture-mapped triangle fill with RGB555 dither (rasterize_triangle_15, render.rs:1440-1714)
+// as a visibility-buffer pipeline of three kernels (MI355X-first, not the reference's per-triangle scanline loop):
 //
-// Parallel decomposition (MI355X-first, not the reference's per-triangle scanline loop):
-//   * one persistent 1024-thread workgroup per CU pulls 64x64 screen tiles from a device-side cursor; the texture
-//     (<= 128 KB of Color15) is staged once per workgroup in LDS;
-//   * per tile, the surfaces binned to it arrive in painter's order (b32_bin.hip).  The opaque pass of the reference
-//     (render.rs:2553-2559) only ever overwrites pixels (set_pixel_15), so its result per pixel is the LAST surface in
-//     painter's order whose fragment is not skipped.  Phase A therefore runs all opaque surfaces of the tile in parallel
-//     (one wave per surface, lanes over the surface's own pixel blocks) and resolves visibility with an LDS atomicMax
-//     on the surface's position in the tile list — order-independent, deterministic, no overdraw shading.
-//       - EXACT coverage evaluates the whole skip rule per fragment (inside test + texel fetch + transparency,
-//         render.rs:1536-1607) and counts the reference's pixel stores exactly;
-//       - CHEAP coverage (textures with few skippable texels) evaluates only the inside test; the winner of a pixel is
-//         then the top covering surface.  Phase B detects the rare pixels whose winner's texel is skipped and phase B2
-//         repairs them: all 1024 threads scan the tile's surface list once against the short list of failed pixels and
-//         atomicMax the best surface *below* the failed one whose fragment is really drawn.  Result identical to EXACT.
-//   * phase B shades each covered pixel exactly once from its winning surface (colour pipeline render.rs:1613-1661)
-//     and stores RGBA8 (Color15::to_rgba) with row-coalesced writes;
-//   * surfaces of the transparent pass (render.rs:2563-2569) blend against the framebuffer, so they are walked strictly
-//     in order: each wave owns 4 rows of the tile (no two waves touch the same pixel, no atomics, no barriers between
-//     surfaces) and applies set_pixel_blended_15 / editor-alpha stores to the LDS-resident tile.
-// Surface records are fetched up to 64 at a time with per-lane 16-B loads and broadcast with v_readlane, so per-surface
-// parameters live in SGPRs while the lanes work on pixels.  The 64 lanes of a wave cover an 8x8, 16x4 or 4x16 pixel
-// block, whichever needs the fewest blocks for the surface's (tile-clipped) bounding box.
+//   k_cover  persistent workgroups pull 64x64 screen tiles from a device-side cursor.  The surfaces binned to a tile
+//            arrive in painter's order (b32_bin.hip).  The opaque pass of the reference (render.rs:2553-2559) only ever
+//            overwrites pixels (set_pixel_15), so its result per pixel is the LAST surface in painter's order whose
+//            fragment is not skipped: coverage of all opaque surfaces of the tile runs in parallel and visibility is an
+//            LDS atomicMax of the surface's position in the tile list (order-independent, deterministic, no overdraw
+//            shading).  The tile of winners is written, row-coalesced, to the u32 visibility buffer.
+//              EXACT coverage applies the whole skip rule per fragment (inside test + texel + transparency,
+//                    render.rs:1536-1607; texture staged in LDS) and counts the reference's pixel stores exactly;
+//              CHEAP coverage (textures with few skippable texels) applies only the inside test; the rare pixels whose
+//                    top surface turns out to be skipped are repaired by k_shade.
+//            Coverage is scheduled by ROW ITEMS (see phase_a_rows): every lane walks one row of one surface.
+//   k_shade  one lane per pixel, grid-stride, high occupancy: winner -> surface record -> barycentrics -> texel ->
+//            colour pipeline (render.rs:1613-1661) -> RGBA8 store (Color15::to_rgba), 256-B coalesced per wave.  If the
+//            winner's texel is skipped (CHEAP only) the wave scans the tile list downward, 64 entries at a time, for
+//            the highest surface below it whose fragment is really drawn — identical result to EXACT coverage.
+//   k_blend  surfaces of the transparent pass (render.rs:2563-2569) blend against the framebuffer, so they are walked
+//            strictly in order, per tile, on an LDS copy of the tile: each wave owns a band of rows (no two waves touch
+//            the same pixel, no atomics, no barriers between surfaces): set_pixel_blended_15 / editor-alpha stores.
 //
-// Bit-exactness: barycentrics use the reference's expression order; the edge functions are evaluated in closed form only
-// for surfaces k_setup proved exact (integer coordinates, every intermediate < 2^24), otherwise the incremental walk
-// (render.rs:1706-1712) is replayed literally.
+// Bit-exactness: barycentrics use the reference's expression order; the edge functions are evaluated from exact integers
+// only for surfaces k_setup proved exact (integer coordinates, every intermediate < 2^24), otherwise the incremental
+// walk (render.rs:1706-1712) is replayed literally.
 #include "b32_device.h"
+#include <cstdlib>
 
 namespace b32 {
 
-constexpr int FAIL_CAP = 512;                                   // repair list of phase B2 (per tile)
 constexpr int LDS_TILE_BYTES = TILE_H * TILE_STRIDE * 4;        // 18432
 constexpr int LDS_MISC_BYTES = 64;
-constexpr int LDS_FAIL_BYTES = FAIL_CAP * 12;                   // px | li | best
 constexpr int LDS_MARK_BYTES = FILL_WAVES * 64 * 4;             // row-start marks of the row-item scheduler
-constexpr int LDS_TEX_OFFSET = LDS_TILE_BYTES + LDS_MISC_BYTES + LDS_FAIL_BYTES + LDS_MARK_BYTES;   // 28736
+constexpr int LDS_TEX_OFFSET = LDS_TILE_BYTES + LDS_MISC_BYTES + LDS_MARK_BYTES;   // 22592
 
 __device__ __forceinline__ float bcf(float v, int t) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), t)); }
 __device__ __forceinline__ uint32_t bcu(uint32_t v, int t) { return (uint32_t)__builtin_amdgcn_readlane((int)v, t); }
@@ -305,7 +301,7 @@ __device__ __forceinline__ uint32_t cover_one(const Batch& b, int t, uint32_t li
 // incrementally exactly like the reference's inner loop (render.rs:1533-1707): start value = closed form at the row start
 // (exact integers under the k_setup guard), then w0 += a0, w1 += a1 per pixel.  Row lengths are far more uniform than
 // bbox areas, big surfaces fill whole rounds, and there is no per-surface scalar work.
-template <int TEXMODE, bool EXACT>
+template <int TEXMODE, bool EXACT, int NW>
 __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, uint32_t e0, uint32_t n_op, uint32_t lane, uint32_t wave,
                                                            volatile uint32_t* cursor, volatile uint32_t* wmark, const TexDesc& lds_desc,
                                                            uint32_t* tilebuf, uint32_t x_lo, uint32_t x_hi, uint32_t y_lo, uint32_t y_hi,
@@ -314,7 +310,7 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
     unsigned long long frags = 0;
     const float ERR = -0.0001f;
     // entries per grab: ~3 grabs per wave for balance, never more than the 64 lanes can hold
-    const uint32_t grab = min(64u, max(4u, (n_op + 3 * FILL_WAVES - 1) / (3 * FILL_WAVES)));
+    const uint32_t grab = min(64u, max(4u, (n_op + 3 * NW - 1) / (3 * NW)));
     for (;;) {
         uint32_t cs = 0;
         if (lane == 0) cs = atomicAdd(const_cast<uint32_t*>(cursor), grab);
@@ -399,15 +395,15 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
     return frags;
 }
 
-template <int TEXMODE>
-__global__ __launch_bounds__(FILL_THREADS) void k_fill(FillArgs a) {
+
+// ------------------------------------------------------------------------------------------------ k_cover
+template <int TEXMODE, bool EXACT, int NT>
+__global__ __launch_bounds__(NT) void k_cover(FillArgs a) {
+    constexpr int NW = NT / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* tilebuf = reinterpret_cast<uint32_t*>(smem);
-    volatile uint32_t* misc = reinterpret_cast<volatile uint32_t*>(smem + LDS_TILE_BYTES);   // [0] tile, [1] fail count, [2] list cursor, [3] next tile
-    uint32_t* fail_px = reinterpret_cast<uint32_t*>(smem + LDS_TILE_BYTES + LDS_MISC_BYTES);
-    uint32_t* fail_li = fail_px + FAIL_CAP;
-    uint32_t* fail_best = fail_li + FAIL_CAP;
-    uint32_t* wmarks = fail_best + FAIL_CAP;
+    volatile uint32_t* misc = reinterpret_cast<volatile uint32_t*>(smem + LDS_TILE_BYTES);   // [0] tile, [2] list cursor
+    uint32_t* wmarks = reinterpret_cast<uint32_t*>(smem + LDS_TILE_BYTES + LDS_MISC_BYTES);
     const uint16_t* ltex = reinterpret_cast<const uint16_t*>(smem + LDS_TEX_OFFSET);
 
     if (a.ctrl->abort) return;
@@ -415,7 +411,6 @@ __global__ __launch_bounds__(FILL_THREADS) void k_fill(FillArgs a) {
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));   // wave-uniform => SGPR control flow
     const FrameParams& fp = a.fp;
     const uint32_t ntiles = fp.tiles_x * fp.tiles_y;
-    const int shading = fp.shading;
 
     TexDesc lds_desc = { 0, 0, 0, 0 };
     if (TEXMODE == 1) {     // stage texture 0 once per workgroup: 16-B coalesced loads -> LDS
@@ -423,210 +418,234 @@ __global__ __launch_bounds__(FILL_THREADS) void k_fill(FillArgs a) {
         const uint4* src = reinterpret_cast<const uint4*>(a.texels + lds_desc.offset);
         uint4* dst = reinterpret_cast<uint4*>(smem + LDS_TEX_OFFSET);
         const uint32_t nq = (a.lds_tex_texels + 7) / 8;
-        for (uint32_t i = tid; i < nq; i += FILL_THREADS) dst[i] = src[i];
+        for (uint32_t i = tid; i < nq; i += NT) dst[i] = src[i];
     }
     unsigned long long frag_count = 0;
-
-    if (tid == 0) misc[3] = atomicAdd(&a.ctrl->tile_cursor, 1u);
+    uint32_t next_tile = 0;
+    if (tid == 0) next_tile = atomicAdd(&a.ctrl->tile_cursor, 1u);
     for (;;) {
-        if (tid == 0) { misc[0] = misc[3]; misc[1] = 0; }
+        if (tid == 0) { misc[0] = next_tile; misc[2] = 0; }
+        for (uint32_t i = tid; i < TILE_H * TILE_STRIDE; i += NT) tilebuf[i] = 0;
         __syncthreads();
         const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)misc[0]);
         if (tile >= ntiles) break;
-        if (tid == 0) misc[3] = atomicAdd(&a.ctrl->tile_cursor, 1u);      // prefetch the next tile index (latency hidden behind this tile)
-        const uint32_t e0 = a.ranges[2 * tile], e1 = a.ranges[2 * tile + 1], e2 = a.ranges[2 * tile + 2];
-        if (e0 != e2) {
-            const uint32_t txi = tile % fp.tiles_x, tyi = tile / fp.tiles_x + fp.tile_y0;
-            const uint32_t x_lo = txi * TILE_W, x_hi = min(x_lo + TILE_W, fp.width);
-            const uint32_t ty_top = tyi * TILE_H;
-            const uint32_t y_lo = max(ty_top, fp.band_y0), y_hi = min(ty_top + TILE_H, fp.band_y1);
-            const bool has_tr = e1 != e2;
-            const uint32_t n_op = e1 - e0;
-            bool exact = a.exact_coverage != 0;
-
-            for (int attempt = 0; attempt < 2; ++attempt) {
-                // ---- phase 0: clear the visibility buffer
-                for (uint32_t i = tid; i < TILE_H * TILE_STRIDE; i += FILL_THREADS) tilebuf[i] = 0;
-                if (tid == 0) misc[2] = 0;                     // list cursor of phase_a_cheap
-                __syncthreads();
-
-                // ---- phase A: opaque coverage, winner = max list position (LDS atomicMax)
-                if (n_op) {
-                    if (exact) frag_count += phase_a_rows<TEXMODE, true>(a, e0, n_op, lane, wave, &misc[2], wmarks + wave * 64, lds_desc, tilebuf, x_lo, x_hi, y_lo, y_hi, ty_top, ltex);
-                    else phase_a_rows<TEXMODE, false>(a, e0, n_op, lane, wave, &misc[2], wmarks + wave * 64, lds_desc, tilebuf, x_lo, x_hi, y_lo, y_hi, ty_top, ltex);
-                }
-                __syncthreads();
-
-                // ---- phase B: shade every covered pixel once from its winning surface
-#pragma unroll 1
-                for (uint32_t k = 0; k < (TILE_W * TILE_H) / FILL_THREADS; ++k) {
-                    const uint32_t p = tid + k * FILL_THREADS;
-                    const uint32_t row = p >> 6, col = p & 63;
-                    const uint32_t px = x_lo + col, py = ty_top + row;
-                    const bool inb = px < x_hi && py >= y_lo && py < y_hi;
-                    const uint32_t li = tilebuf[row * TILE_STRIDE + col];
-                    uint32_t rgba = 0;
-                    bool have = false;
-                    if (inb && li) {
-                        const uint32_t sid = a.pair_vals[e0 + li - 1];
-                        uint4 q4;
-                        const Tri tr = tri_from_mem<TEXMODE>(a, sid, lds_desc, q4);
-                        float w0, w1, bcx, bcy, bcz;
-                        edge_w(tr, px, py, w0, w1);
-                        inside_bc(tr, w0, w1, bcx, bcy, bcz);                                     // true by construction
-                        uint32_t texel = 0;
-                        if (texel_drawn<TEXMODE>(tr, bcx, bcy, bcz, a.texels, ltex, texel)) {
-                            float shv[9];
-                            if (shading != B32_SHADE_NONE) for (int j = 0; j < 9; ++j) shv[j] = a.shades[(size_t)sid * 9 + j];
-                            const uint32_t out15 = shade15(texel, bcx, bcy, bcz, q4.x, q4.y, q4.z, tr.flags, shading, shv, px, py);
-                            rgba = c15_to_rgba(out15);                                            // set_pixel_15
-                            have = true;
-                            if (!has_tr) a.fb[(size_t)py * fp.width + px] = rgba;
-                        } else {                                                                  // only reachable with CHEAP coverage
-                            const uint32_t slot = atomicAdd(const_cast<uint32_t*>(&misc[1]), 1u);
-                            if (slot < FAIL_CAP) { fail_px[slot] = p; fail_li[slot] = li; fail_best[slot] = 0; }
-                        }
-                    }
-                    if (has_tr) {
-                        if (inb && !have) rgba = a.fb[(size_t)py * fp.width + px];
-                        tilebuf[row * TILE_STRIDE + col] = rgba;
-                    }
-                }
-                if (exact) break;
-                __syncthreads();
-                const uint32_t n_fail = misc[1];
-                if (n_fail == 0) break;
-                if (n_fail > FAIL_CAP) {                       // too many skipped winners: redo this tile with EXACT coverage
-                    __syncthreads();
-                    if (tid == 0) misc[1] = 0;
-                    exact = true;
-                    __syncthreads();
-                    continue;
-                }
-                // ---- phase B2: repair pixels whose top surface was skipped: best drawn surface strictly below it
-                for (uint32_t e = tid; e < n_op; e += FILL_THREADS) {
-                    const uint32_t sid = a.pair_vals[e0 + e];
-                    const uint4* rp = reinterpret_cast<const uint4*>(a.recs + sid);
-                    const uint32_t bbx = rp[1].w, bby = rp[2].x;
-                    const uint32_t mnx = bbx & 0xFFFF, mxx = bbx >> 16, mny = bby & 0xFFFF, mxy = bby >> 16;
-                    bool loaded = false;
-                    Tri tr; uint4 q4;
-                    for (uint32_t f = 0; f < n_fail; ++f) {
-                        const uint32_t p = fail_px[f];
-                        const uint32_t px = x_lo + (p & 63), py = ty_top + (p >> 6);
-                        if (e + 1 < fail_li[f] && px >= mnx && px < mxx && py >= mny && py < mxy) {
-                            if (!loaded) { tr = tri_from_mem<TEXMODE>(a, sid, lds_desc, q4); loaded = true; }
-                            float w0, w1, bcx, bcy, bcz;
-                            edge_w(tr, px, py, w0, w1);
-                            uint32_t texel;
-                            if (inside_bc(tr, w0, w1, bcx, bcy, bcz) && texel_drawn<TEXMODE>(tr, bcx, bcy, bcz, a.texels, ltex, texel))
-                                atomicMax(&fail_best[f], e + 1);
-                        }
-                    }
-                }
-                __syncthreads();
-                if (tid < n_fail) {
-                    const uint32_t p = fail_px[tid], li = fail_best[tid];
-                    if (li) {
-                        const uint32_t row = p >> 6, col = p & 63;
-                        const uint32_t px = x_lo + col, py = ty_top + row;
-                        const uint32_t sid = a.pair_vals[e0 + li - 1];
-                        uint4 q4;
-                        const Tri tr = tri_from_mem<TEXMODE>(a, sid, lds_desc, q4);
-                        float w0, w1, bcx, bcy, bcz;
-                        edge_w(tr, px, py, w0, w1);
-                        inside_bc(tr, w0, w1, bcx, bcy, bcz);
-                        uint32_t texel = 0;
-                        texel_drawn<TEXMODE>(tr, bcx, bcy, bcz, a.texels, ltex, texel);
-                        float shv[9];
-                        if (shading != B32_SHADE_NONE) for (int j = 0; j < 9; ++j) shv[j] = a.shades[(size_t)sid * 9 + j];
-                        const uint32_t rgba = c15_to_rgba(shade15(texel, bcx, bcy, bcz, q4.x, q4.y, q4.z, tr.flags, shading, shv, px, py));
-                        if (has_tr) tilebuf[row * TILE_STRIDE + col] = rgba;
-                        else a.fb[(size_t)py * fp.width + px] = rgba;
-                    }
-                }
-                break;
-            }
-
-            // ---- phase C: transparent pass, strictly in painter's order; wave w owns tile rows [4w, 4w+4)
-            if (has_tr) {
-                __syncthreads();
-                const uint32_t n_tr = e2 - e1;
-                const uint32_t wy0 = max(ty_top + wave * 4, y_lo), wy1 = min(ty_top + wave * 4 + 4, y_hi);
-                for (uint32_t cs = 0; cs < n_tr; cs += 64) {
-                    const uint32_t cnt = min(64u, n_tr - cs);
-                    Batch b;
-                    load_batch<TEXMODE>(b, a, e1 + cs + lane, lane < cnt, lds_desc, true);
-                    const uint32_t my_sid = lane < cnt ? a.pair_vals[e1 + cs + lane] : 0;
-                    for (uint32_t t = 0; t < cnt; ++t) {
-                        const Tri tr = tri_from_batch(b, (int)t, true);
-                        const uint32_t cx0 = max(tr.min_x, x_lo), cx1 = min(tr.max_x, x_hi);
-                        const uint32_t cy0 = max(tr.min_y, wy0), cy1 = min(tr.max_y, wy1);
-                        if (cx0 >= cx1 || cy0 >= cy1) continue;
-                        if ((tr.flags >> F_ALPHA_SHIFT) == 0) continue;                      // editor_alpha == 0, render.rs:1664-1669
-                        const uint32_t vc1 = bcu(b.q4.x, (int)t), vc2 = bcu(b.q4.y, (int)t), vc3 = bcu(b.q4.z, (int)t);
-                        const uint32_t sid = bcu(my_sid, (int)t);
-                        float shv[9];
-                        if (shading != B32_SHADE_NONE) for (int j = 0; j < 9; ++j) shv[j] = a.shades[(size_t)sid * 9 + j];
-                        if (!(tr.flags & F_SLOW)) {
-                            for (uint32_t bx = cx0; bx < cx1; bx += 16) {
-                                const uint32_t px = bx + (lane & 15), py = cy0 + (lane >> 4);
-                                bool drawn = false;
-                                if (px < cx1 && py < cy1) {
-                                    float w0, w1, bcx, bcy, bcz; uint32_t texel;
-                                    edge_w(tr, px, py, w0, w1);
-                                    if (inside_bc(tr, w0, w1, bcx, bcy, bcz) && texel_drawn<TEXMODE>(tr, bcx, bcy, bcz, a.texels, ltex, texel)) {
-                                        const uint32_t out15 = shade15(texel, bcx, bcy, bcz, vc1, vc2, vc3, tr.flags, shading, shv, px, py);
-                                        uint32_t* dst = &tilebuf[(py - ty_top) * TILE_STRIDE + (px - x_lo)];
-                                        *dst = store_blend(*dst, out15, tr.flags);
-                                        drawn = true;
-                                    }
-                                }
-                                frag_count += (unsigned long long)__popcll(__ballot(drawn));
-                            }
-                        } else {
-                            const uint32_t py = cy0 + lane;
-                            uint32_t mine = 0;
-                            if (py < cy1) {
-                                float w0, w1;
-                                replay_w(tr, cx0, py, w0, w1);
-                                for (uint32_t px = cx0; px < cx1; ++px) {
-                                    float bcx, bcy, bcz; uint32_t texel;
-                                    if (inside_bc(tr, w0, w1, bcx, bcy, bcz) && texel_drawn<TEXMODE>(tr, bcx, bcy, bcz, a.texels, ltex, texel)) {
-                                        const uint32_t out15 = shade15(texel, bcx, bcy, bcz, vc1, vc2, vc3, tr.flags, shading, shv, px, py);
-                                        uint32_t* dst = &tilebuf[(py - ty_top) * TILE_STRIDE + (px - x_lo)];
-                                        *dst = store_blend(*dst, out15, tr.flags);
-                                        ++mine;
-                                    }
-                                    w0 += tr.a0; w1 += tr.a1;
-                                }
-                            }
-                            for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
-                            frag_count += (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)mine);
-                        }
-                    }
-                }
-                __syncthreads();
-                // write the finished tile back, one 256-B row segment per wave instruction
-                for (uint32_t k = 0; k < (TILE_W * TILE_H) / FILL_THREADS; ++k) {
-                    const uint32_t p = tid + k * FILL_THREADS;
-                    const uint32_t row = p >> 6, col = p & 63;
-                    const uint32_t px = x_lo + col, py = ty_top + row;
-                    if (px < x_hi && py >= y_lo && py < y_hi) a.fb[(size_t)py * fp.width + px] = tilebuf[row * TILE_STRIDE + col];
-                }
+        if (tid == 0) next_tile = atomicAdd(&a.ctrl->tile_cursor, 1u);    // prefetch the next tile index; consumed at the loop top
+        const uint32_t e0 = a.ranges[2 * tile], e1 = a.ranges[2 * tile + 1];
+        const uint32_t txi = tile % fp.tiles_x, tyi = tile / fp.tiles_x + fp.tile_y0;
+        const uint32_t x_lo = txi * TILE_W, x_hi = min(x_lo + TILE_W, fp.width);
+        const uint32_t ty_top = tyi * TILE_H;
+        const uint32_t y_lo = max(ty_top, fp.band_y0), y_hi = min(ty_top + TILE_H, fp.band_y1);
+        const uint32_t n_op = e1 - e0;
+        if (n_op) {
+            frag_count += phase_a_rows<TEXMODE, EXACT, NW>(a, e0, n_op, lane, wave, &misc[2], wmarks + wave * 64, lds_desc, tilebuf,
+                                                           x_lo, x_hi, y_lo, y_hi, ty_top, ltex);
+            __syncthreads();
+        }
+        // winners -> visibility buffer: one 256-B row segment per wave instruction (zeros for uncovered pixels)
+        for (uint32_t p = tid; p < TILE_W * TILE_H; p += NT) {
+            const uint32_t row = p >> 6, col = p & 63;
+            const uint32_t px = x_lo + col, py = ty_top + row;
+            if (px < x_hi && py >= y_lo && py < y_hi) {
+                const uint32_t li = tilebuf[row * TILE_STRIDE + col];
+                const uint32_t sid = li ? a.pair_vals[e0 + li - 1] : 0u;                // resolve the surface id here: one level
+                a.vis[(size_t)py * fp.width + px] = make_uint2(li, sid);                // less in k_shade's dependent gather chain
             }
         }
         __syncthreads();   // everyone is done with misc / tilebuf before the next tile
     }
+    if (EXACT) {           // fragment-store count (wave-uniform per wave): one same-address atomic per workgroup
+        unsigned long long* wf = reinterpret_cast<unsigned long long*>(smem);
+        __syncthreads();
+        if (lane == 0) wf[wave] = frag_count;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long t = 0;
+            for (int w = 0; w < NW; ++w) t += wf[w];
+            if (t) atomicAdd(&a.ctrl->fragments, t);
+        }
+    }
+}
 
-    // fragment-store count (wave-uniform per wave): one same-address atomic per workgroup
-    unsigned long long* wf = reinterpret_cast<unsigned long long*>(smem);       // tilebuf is free now
+// ------------------------------------------------------------------------------------------------ k_shade
+// Coverage test of list entry li at pixel (px,py): inside test + texel + transparency rule. Keeps what colouring needs.
+struct Hit { float bcx, bcy, bcz; uint32_t texel, vc1, vc2, vc3, flags, sid; };
+__device__ __forceinline__ bool hit_test(const FillArgs& a, uint32_t sid, uint32_t px, uint32_t py, Hit& h) {
+    const uint4* rp = reinterpret_cast<const uint4*>(a.recs + sid);
+    const uint4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3], q4 = rp[4];
+    Tri tr;
+    tr.x3 = __uint_as_float(q0.x); tr.y3 = __uint_as_float(q0.y); tr.a0 = __uint_as_float(q0.z); tr.b0 = __uint_as_float(q0.w);
+    tr.a1 = __uint_as_float(q1.x); tr.b1 = __uint_as_float(q1.y); tr.inv_area = __uint_as_float(q1.z);
+    tr.min_x = q1.w & 0xFFFF; tr.max_x = q1.w >> 16; tr.min_y = q2.x & 0xFFFF; tr.max_y = q2.x >> 16;
+    tr.u1 = __uint_as_float(q2.y); tr.u2 = __uint_as_float(q2.z); tr.u3 = __uint_as_float(q2.w);
+    tr.v1 = __uint_as_float(q3.x); tr.v2 = __uint_as_float(q3.y); tr.v3 = __uint_as_float(q3.z);
+    tr.flags = q3.w;
+    tr.w0_start = __uint_as_float(q4.w); tr.w1_start = 0.0f;
+    if (tr.flags & F_SLOW) tr.w1_start = __uint_as_float(rp[5].x);
+    tr.tw = tr.th = tr.toff = 0;
+    const uint32_t txid = tr.flags & F_TEX_MASK;
+    if (txid != F_TEX_NONE) {
+        if (a.fp.nt == 1) { tr.tw = a.tex0.width; tr.th = a.tex0.height; tr.toff = a.tex0.offset; }   // uniform: no descriptor gather
+        else { const TexDesc d = a.tex[txid]; tr.tw = d.width; tr.th = d.height; tr.toff = d.offset; }
+    }
+    float w0, w1;
+    edge_w(tr, px, py, w0, w1);
+    if (!inside_bc(tr, w0, w1, h.bcx, h.bcy, h.bcz)) return false;
+    h.texel = 0;
+    if (!texel_drawn<0>(tr, h.bcx, h.bcy, h.bcz, a.texels, nullptr, h.texel)) return false;
+    h.vc1 = q4.x; h.vc2 = q4.y; h.vc3 = q4.z; h.flags = tr.flags; h.sid = sid;
+    return true;
+}
+__device__ __forceinline__ uint32_t colour(const FillArgs& a, const Hit& h, int shading, uint32_t px, uint32_t py) {
+    float shv[9];
+    if (shading != B32_SHADE_NONE) for (int j = 0; j < 9; ++j) shv[j] = a.shades[(size_t)h.sid * 9 + j];
+    return c15_to_rgba(shade15(h.texel, h.bcx, h.bcy, h.bcz, h.vc1, h.vc2, h.vc3, h.flags, shading, shv, px, py));   // set_pixel_15
+}
+
+// grid = (ceil(W/256), band height); block = 256 threads = 4 waves = 4 consecutive 64-pixel row segments (a segment never
+// straddles a tile).
+__global__ __launch_bounds__(256) void k_shade(FillArgs a) {
+    if (a.ctrl->abort) return;
+    const FrameParams& fp = a.fp;
+    const uint32_t lane = threadIdx.x & 63;
+    const int shading = fp.shading;
+    const uint32_t W = fp.width;
+    const uint32_t py = fp.band_y0 + blockIdx.y, px = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t seg_x = (uint32_t)__builtin_amdgcn_readfirstlane((int)(px & ~63u));
+    if (seg_x >= W) return;
+    const bool inb = px < W;
+    const uint2 ve = inb ? a.vis[(size_t)py * W + px] : make_uint2(0u, 0u);
+    const uint32_t li = ve.x;
+    if (!__ballot(li != 0)) return;
+    const uint32_t tile = (py / TILE_H - fp.tile_y0) * fp.tiles_x + seg_x / TILE_W;      // same tile for the whole wave
+    const uint32_t e0 = a.ranges[2 * tile];
+    Hit h;
+    bool have = false, failed = false;
+    if (li) { have = hit_test(a, ve.y, px, py, h); failed = !have; }
+    // CHEAP coverage only: the top surface is skipped at this pixel -> highest surface below it whose fragment is drawn.
+    // The wave scans the tile list downward, 64 entries per step; only the cheap coverage test runs per candidate.
+    unsigned long long fm = __ballot(failed);
+    while (fm) {
+        const int fl = __builtin_ctzll(fm);
+        fm &= fm - 1;
+        const uint32_t fx = (uint32_t)__builtin_amdgcn_readlane((int)px, fl), fli = (uint32_t)__builtin_amdgcn_readlane((int)li, fl);
+        for (uint32_t top = fli - 1; top > 0; top = top > 64 ? top - 64 : 0) {            // list positions top-lane, descending
+            Hit c;
+            bool hit = false;
+            if (lane < top) {
+                const uint32_t cli = top - lane;
+                const uint32_t csid = a.pair_vals[e0 + cli - 1];
+                const uint4* rp = reinterpret_cast<const uint4*>(a.recs + csid);
+                const uint32_t bbx = rp[1].w, bby = rp[2].x;
+                if (fx >= (bbx & 0xFFFF) && fx < (bbx >> 16) && py >= (bby & 0xFFFF) && py < (bby >> 16)) hit = hit_test(a, csid, fx, py, c);
+            }
+            const unsigned long long hm = __ballot(hit);
+            if (hm) {                                                                     // lowest lane == highest list position
+                const int hl = __builtin_ctzll(hm);
+                // hand the winning candidate's data to the failed lane
+                const float bx_ = bcf(c.bcx, hl), by_ = bcf(c.bcy, hl), bz_ = bcf(c.bcz, hl);
+                const uint32_t t_ = bcu(c.texel, hl), v1_ = bcu(c.vc1, hl), v2_ = bcu(c.vc2, hl), v3_ = bcu(c.vc3, hl), f_ = bcu(c.flags, hl), s_ = bcu(c.sid, hl);
+                if ((int)lane == fl) { h.bcx = bx_; h.bcy = by_; h.bcz = bz_; h.texel = t_; h.vc1 = v1_; h.vc2 = v2_; h.vc3 = v3_; h.flags = f_; h.sid = s_; have = true; }
+                break;
+            }
+        }
+    }
+    if (have) a.fb[(size_t)py * W + px] = colour(a, h, shading, px, py);
+}
+
+// ------------------------------------------------------------------------------------------------ k_blend
+template <int NT>
+__global__ __launch_bounds__(NT) void k_blend(FillArgs a) {
+    constexpr int NW = NT / 64;
+    __shared__ uint32_t tilebuf[TILE_H * TILE_STRIDE];
+    __shared__ unsigned long long wf[NW];
+    if (a.ctrl->abort) return;
+    const FrameParams& fp = a.fp;
+    const uint32_t tile = blockIdx.x;
+    const uint32_t e1 = a.ranges[2 * tile + 1], e2 = a.ranges[2 * tile + 2];
+    if (e1 == e2) return;
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const int shading = fp.shading;
+    const uint32_t txi = tile % fp.tiles_x, tyi = tile / fp.tiles_x + fp.tile_y0;
+    const uint32_t x_lo = txi * TILE_W, x_hi = min(x_lo + TILE_W, fp.width);
+    const uint32_t ty_top = tyi * TILE_H;
+    const uint32_t y_lo = max(ty_top, fp.band_y0), y_hi = min(ty_top + TILE_H, fp.band_y1);
+    for (uint32_t p = tid; p < TILE_W * TILE_H; p += NT) {
+        const uint32_t row = p >> 6, col = p & 63;
+        const uint32_t px = x_lo + col, py = ty_top + row;
+        tilebuf[row * TILE_STRIDE + col] = (px < x_hi && py >= y_lo && py < y_hi) ? a.fb[(size_t)py * fp.width + px] : 0u;
+    }
     __syncthreads();
+    unsigned long long frag_count = 0;
+    const TexDesc none = { 0, 0, 0, 0 };
+    const uint32_t n_tr = e2 - e1;
+    constexpr uint32_t RPW = TILE_H / NW;          // tile rows owned by one wave
+    const uint32_t wy0 = max(ty_top + wave * RPW, y_lo), wy1 = min(ty_top + wave * RPW + RPW, y_hi);
+    for (uint32_t cs = 0; cs < n_tr; cs += 64) {
+        const uint32_t cnt = min(64u, n_tr - cs);
+        Batch b;
+        load_batch<0>(b, a, e1 + cs + lane, lane < cnt, none, true);
+        const uint32_t my_sid = lane < cnt ? a.pair_vals[e1 + cs + lane] : 0;
+        for (uint32_t t = 0; t < cnt; ++t) {
+            const Tri tr = tri_from_batch(b, (int)t, true);
+            const uint32_t cx0 = max(tr.min_x, x_lo), cx1 = min(tr.max_x, x_hi);
+            const uint32_t cy0 = max(tr.min_y, wy0), cy1 = min(tr.max_y, wy1);
+            if (cx0 >= cx1 || cy0 >= cy1) continue;
+            if ((tr.flags >> F_ALPHA_SHIFT) == 0) continue;                      // editor_alpha == 0, render.rs:1664-1669
+            const uint32_t vc1 = bcu(b.q4.x, (int)t), vc2 = bcu(b.q4.y, (int)t), vc3 = bcu(b.q4.z, (int)t);
+            const uint32_t sid = bcu(my_sid, (int)t);
+            float shv[9];
+            if (shading != B32_SHADE_NONE) for (int j = 0; j < 9; ++j) shv[j] = a.shades[(size_t)sid * 9 + j];
+            if (!(tr.flags & F_SLOW)) {
+                for (uint32_t by = cy0; by < cy1; by += 4)
+                    for (uint32_t bx = cx0; bx < cx1; bx += 16) {
+                        const uint32_t px = bx + (lane & 15), py = by + (lane >> 4);
+                        bool drawn = false;
+                        if (px < cx1 && py < cy1) {
+                            float w0, w1, bcx, bcy, bcz; uint32_t texel;
+                            edge_w(tr, px, py, w0, w1);
+                            if (inside_bc(tr, w0, w1, bcx, bcy, bcz) && texel_drawn<0>(tr, bcx, bcy, bcz, a.texels, nullptr, texel)) {
+                                const uint32_t out15 = shade15(texel, bcx, bcy, bcz, vc1, vc2, vc3, tr.flags, shading, shv, px, py);
+                                uint32_t* dst = &tilebuf[(py - ty_top) * TILE_STRIDE + (px - x_lo)];
+                                *dst = store_blend(*dst, out15, tr.flags);
+                                drawn = true;
+                            }
+                        }
+                        frag_count += (unsigned long long)__popcll(__ballot(drawn));
+                    }
+            } else {
+                const uint32_t py = cy0 + lane;            // RPW <= 64 rows
+                uint32_t mine = 0;
+                if (py < cy1) {
+                    float w0, w1;
+                    replay_w(tr, cx0, py, w0, w1);
+                    for (uint32_t px = cx0; px < cx1; ++px) {
+                        float bcx, bcy, bcz; uint32_t texel;
+                        if (inside_bc(tr, w0, w1, bcx, bcy, bcz) && texel_drawn<0>(tr, bcx, bcy, bcz, a.texels, nullptr, texel)) {
+                            const uint32_t out15 = shade15(texel, bcx, bcy, bcz, vc1, vc2, vc3, tr.flags, shading, shv, px, py);
+                            uint32_t* dst = &tilebuf[(py - ty_top) * TILE_STRIDE + (px - x_lo)];
+                            *dst = store_blend(*dst, out15, tr.flags);
+                            ++mine;
+                        }
+                        w0 += tr.a0; w1 += tr.a1;
+                    }
+                }
+                for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
+                frag_count += (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)mine);
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t p = tid; p < TILE_W * TILE_H; p += NT) {      // finished tile back, one 256-B row segment per wave instruction
+        const uint32_t row = p >> 6, col = p & 63;
+        const uint32_t px = x_lo + col, py = ty_top + row;
+        if (px < x_hi && py >= y_lo && py < y_hi) a.fb[(size_t)py * fp.width + px] = tilebuf[row * TILE_STRIDE + col];
+    }
     if (lane == 0) wf[wave] = frag_count;
     __syncthreads();
     if (tid == 0) {
         unsigned long long t = 0;
-        for (int w = 0; w < FILL_WAVES; ++w) t += wf[w];
+        for (int w = 0; w < NW; ++w) t += wf[w];
         if (t) atomicAdd(&a.ctrl->fragments, t);
     }
 }
@@ -634,16 +653,21 @@ __global__ __launch_bounds__(FILL_THREADS) void k_fill(FillArgs a) {
 void launch_fill(hipStream_t s, const FillArgs& a, int n_cu) {
     const uint32_t ntiles = a.fp.tiles_x * a.fp.tiles_y;
     if (ntiles == 0) return;
-    uint32_t grid = min(ntiles, (uint32_t)n_cu);
-    if (a.lds_tex_texels) {
-        const size_t lds = LDS_TEX_OFFSET + (((size_t)a.lds_tex_texels * 2 + 15) & ~(size_t)15);
-        static bool attr_set = false;
-        if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fill<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
-        hipLaunchKernelGGL(k_fill<1>, dim3(grid), dim3(FILL_THREADS), lds, s, a);
+    if (a.exact_coverage) {
+        if (a.lds_tex_texels) {     // texture sampled once per fragment: stage it in LDS, one 16-wave workgroup per CU
+            const size_t lds = LDS_TEX_OFFSET + (((size_t)a.lds_tex_texels * 2 + 15) & ~(size_t)15);
+            static bool attr_set = false;
+            if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<1, true, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+            hipLaunchKernelGGL((k_cover<1, true, 1024>), dim3(min(ntiles, (uint32_t)n_cu)), dim3(1024), lds, s, a);
+        } else {
+            hipLaunchKernelGGL((k_cover<0, true, 512>), dim3(min(ntiles, (uint32_t)n_cu * 2)), dim3(512), LDS_TEX_OFFSET, s, a);
+        }
     } else {
-        grid = min(ntiles, (uint32_t)n_cu * 2);      // 24 KB LDS, 16 waves per workgroup: two workgroups fit a CU
-        hipLaunchKernelGGL(k_fill<0>, dim3(grid), dim3(FILL_THREADS), LDS_TEX_OFFSET, s, a);
+        hipLaunchKernelGGL((k_cover<0, false, 512>), dim3(min(ntiles, (uint32_t)n_cu * 4)), dim3(512), LDS_TEX_OFFSET, s, a);
     }
+    const uint32_t band_h = a.fp.band_y1 - a.fp.band_y0;
+    if (band_h) hipLaunchKernelGGL(k_shade, dim3((a.fp.width + 255) / 256, band_h), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((k_blend<1024>), dim3(ntiles), dim3(1024), 0, s, a);
 }
 
 size_t fill_lds_tex_budget() { return 160 * 1024 - LDS_TEX_OFFSET - 16; }

@@ -34,7 +34,8 @@ constexpr int FAIL_CAP = 512;                                   // repair list o
 constexpr int LDS_TILE_BYTES = TILE_H * TILE_STRIDE * 4;        // 18432
 constexpr int LDS_MISC_BYTES = 64;
 constexpr int LDS_FAIL_BYTES = FAIL_CAP * 12;                   // px | li | best
-constexpr int LDS_TEX_OFFSET = LDS_TILE_BYTES + LDS_MISC_BYTES + LDS_FAIL_BYTES;   // 24640
+constexpr int LDS_MARK_BYTES = FILL_WAVES * 64 * 4;             // row-start marks of the row-item scheduler
+constexpr int LDS_TEX_OFFSET = LDS_TILE_BYTES + LDS_MISC_BYTES + LDS_FAIL_BYTES + LDS_MARK_BYTES;   // 28736
 
 __device__ __forceinline__ float bcf(float v, int t) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), t)); }
 __device__ __forceinline__ uint32_t bcu(uint32_t v, int t) { return (uint32_t)__builtin_amdgcn_readlane((int)v, t); }
@@ -266,25 +267,135 @@ __device__ __forceinline__ uint32_t cover_surface(const Tri& tr, uint32_t cx0, u
     return drawn_count;
 }
 
+// ---- wave-level helpers for the row-item scheduler
+__device__ __forceinline__ uint32_t dpp_max_scan(uint32_t v) {          // inclusive prefix max over the 64 lanes, identity 0
+#ifdef B32_NO_DPP
+    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(v, off); if (lane >= (uint32_t)off) v = max(v, t); }
+    return v;
+#endif
+    // Hillis-Steele inside each 16-lane row (row_shr 1,2,4,8), then row_bcast:15 / row_bcast:31 across rows.
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));
+    return v;
+}
+__device__ __forceinline__ uint32_t bperm(uint32_t src_lane, uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v); }
+__device__ __forceinline__ float bpermf(uint32_t src_lane, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), __float_as_int(v))); }
+
+// Phase A, EXACT coverage, wave-cooperative form (one wave per surface): used for F_SLOW surfaces and as reference path.
 template <int TEXMODE, bool EXACT>
-__device__ __forceinline__ unsigned long long phase_a(const FillArgs& a, uint32_t e0, uint32_t n_op, uint32_t wave, uint32_t lane,
-                                                      const TexDesc& lds_desc, uint32_t* tilebuf, uint32_t x_lo, uint32_t x_hi,
-                                                      uint32_t y_lo, uint32_t y_hi, uint32_t ty_top, const uint16_t* ltex) {
+__device__ __forceinline__ uint32_t cover_one(const Batch& b, int t, uint32_t li, uint32_t* tilebuf, uint32_t x_lo, uint32_t x_hi,
+                                              uint32_t y_lo, uint32_t y_hi, uint32_t ty_top, uint32_t lane,
+                                              const uint16_t* __restrict__ gtex, const uint16_t* ltex) {
+    const Tri tr = tri_from_batch(b, t, EXACT);
+    const uint32_t cx0 = max(tr.min_x, x_lo), cx1 = min(tr.max_x, x_hi);
+    const uint32_t cy0 = max(tr.min_y, y_lo), cy1 = min(tr.max_y, y_hi);
+    if (cx0 >= cx1 || cy0 >= cy1) return 0;
+    return cover_surface<TEXMODE, EXACT>(tr, cx0, cx1, cy0, cy1, li, tilebuf, x_lo, ty_top, lane, gtex, ltex);
+}
+
+// Phase A as a ROW-ITEM scheduler.  Waves grab 64 list entries at a time from an LDS cursor (load balance across the 16
+// waves).  Each lane first holds one surface; the work items of the batch are the rows of the tile-clipped bounding boxes
+// (exclusive prefix sum of the heights).  In rounds of 64 items every lane takes ONE ROW of some surface: the owner is
+// found with a scatter of row starts + DPP prefix-max, its parameters come over ds_bpermute, and the lane walks the row
+// incrementally exactly like the reference's inner loop (render.rs:1533-1707): start value = closed form at the row start
+// (exact integers under the k_setup guard), then w0 += a0, w1 += a1 per pixel.  Row lengths are far more uniform than
+// bbox areas, big surfaces fill whole rounds, and there is no per-surface scalar work.
+template <int TEXMODE, bool EXACT>
+__device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, uint32_t e0, uint32_t n_op, uint32_t lane, uint32_t wave,
+                                                           volatile uint32_t* cursor, volatile uint32_t* wmark, const TexDesc& lds_desc,
+                                                           uint32_t* tilebuf, uint32_t x_lo, uint32_t x_hi, uint32_t y_lo, uint32_t y_hi,
+                                                           uint32_t ty_top, const uint16_t* ltex) {
+    const uint16_t* __restrict__ gtex = a.texels;
     unsigned long long frags = 0;
-    uint32_t chunk = (n_op + FILL_WAVES - 1) / FILL_WAVES;
-    chunk = min(max(chunk, 1u), 64u);
-    for (uint32_t cs = wave * chunk; cs < n_op; cs += FILL_WAVES * chunk) {
-        const uint32_t cnt = min(chunk, n_op - cs);
+    const float ERR = -0.0001f;
+    // entries per grab: ~3 grabs per wave for balance, never more than the 64 lanes can hold
+    const uint32_t grab = min(64u, max(4u, (n_op + 3 * FILL_WAVES - 1) / (3 * FILL_WAVES)));
+    for (;;) {
+        uint32_t cs = 0;
+        if (lane == 0) cs = atomicAdd(const_cast<uint32_t*>(cursor), grab);
+        cs = (uint32_t)__builtin_amdgcn_readfirstlane((int)cs);
+        if (cs >= n_op) break;
+        const uint32_t e = cs + lane;
+        bool live = lane < grab && e < n_op;
         Batch b;
-        load_batch<TEXMODE>(b, a, e0 + cs + lane, lane < cnt, lds_desc, EXACT);
-        for (uint32_t t = 0; t < cnt; ++t) {
-            const Tri tr = tri_from_batch(b, (int)t, EXACT);
-            const uint32_t cx0 = max(tr.min_x, x_lo), cx1 = min(tr.max_x, x_hi);
-            const uint32_t cy0 = max(tr.min_y, y_lo), cy1 = min(tr.max_y, y_hi);
-            if (cx0 >= cx1 || cy0 >= cy1) continue;
-            frags += cover_surface<TEXMODE, EXACT>(tr, cx0, cx1, cy0, cy1, cs + t + 1, tilebuf, x_lo, ty_top, lane, a.texels, ltex);
+        load_batch<TEXMODE>(b, a, e0 + e, live, lds_desc, EXACT);
+        const uint32_t flags = b.q3.w;
+        const uint32_t cx0 = max(b.q1.w & 0xFFFF, x_lo), cx1 = min(b.q1.w >> 16, x_hi);
+        const uint32_t cy0 = max(b.q2.x & 0xFFFF, y_lo), cy1 = min(b.q2.x >> 16, y_hi);
+        live = live && cx0 < cx1 && cy0 < cy1;
+        const bool slow = live && (flags & F_SLOW);
+        const uint32_t h = (live && !slow) ? cy1 - cy0 : 0u;
+        // exclusive prefix sum of the row counts
+        uint32_t inc = h;
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(inc, off); if (lane >= (uint32_t)off) inc += t; }
+        const uint32_t R = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+        const uint32_t P = inc - h;
+        const float a0 = __uint_as_float(b.q0.z), b0 = __uint_as_float(b.q0.w), a1 = __uint_as_float(b.q1.x), b1 = __uint_as_float(b.q1.y);
+        const uint32_t box = (cx0 - x_lo) | ((cx1 - x_lo) << 8) | ((cy0 - ty_top) << 16);      // 7+7+6 bits
+        for (uint32_t k0 = 0; k0 < R; k0 += 64) {
+            // owner of item k0+lane: last surface s with h>0 and P[s] <= k
+            const unsigned long long before = __ballot(h > 0 && P <= k0);
+            const uint32_t carry = before ? 64u - (uint32_t)__builtin_clzll(before) : 0u;       // (index of that surface) + 1
+            // cross-lane exchange through LDS inside one wave: volatile accesses + wave barriers keep the three steps
+            // ordered (the hardware executes a wave's LDS operations in order)
+            wmark[lane] = 0;
+            __builtin_amdgcn_wave_barrier();
+            if (h > 0 && P > k0 && P < k0 + 64) wmark[P - k0] = lane + 1;
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t own = max(dpp_max_scan(wmark[lane]), carry);                          // >= 1 whenever the item exists
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t k = k0 + lane;
+            const bool valid = k < R;
+            const uint32_t s = valid ? own - 1 : lane;
+            const uint32_t sbox = bperm(s, box), sP = bperm(s, P);
+            const float sx3 = bpermf(s, __uint_as_float(b.q0.x)), sy3 = bpermf(s, __uint_as_float(b.q0.y));
+            const float sa0 = bpermf(s, a0), sb0 = bpermf(s, b0), sa1 = bpermf(s, a1), sb1 = bpermf(s, b1);
+            const float sinv = bpermf(s, __uint_as_float(b.q1.z));
+            Tri tr;                                                                              // per-lane view (EXACT only)
+            if (EXACT) {
+                tr.u1 = bpermf(s, __uint_as_float(b.q2.y)); tr.u2 = bpermf(s, __uint_as_float(b.q2.z)); tr.u3 = bpermf(s, __uint_as_float(b.q2.w));
+                tr.v1 = bpermf(s, __uint_as_float(b.q3.x)); tr.v2 = bpermf(s, __uint_as_float(b.q3.y)); tr.v3 = bpermf(s, __uint_as_float(b.q3.z));
+                tr.flags = bperm(s, flags);
+                tr.tw = bperm(s, b.tw); tr.th = bperm(s, b.th); tr.toff = bperm(s, b.toff);
+            }
+            const uint32_t rx0 = sbox & 0xFF, rx1 = (sbox >> 8) & 0xFF, ry = (sbox >> 16) + (k - sP);   // tile-local
+            const uint32_t n = valid ? rx1 - rx0 : 0u;
+            const float dx = (float)(rx0 + x_lo) - sx3, dy = (float)(ry + ty_top) - sy3;
+            float w0 = sa0 * dx + sb0 * dy, w1 = sa1 * dx + sb1 * dy;                            // exact integers
+            uint32_t addr = ry * TILE_STRIDE + rx0;
+            const uint32_t li = cs + s + 1;
+            uint32_t mine = 0;
+            for (uint32_t i = 0; __ballot(i < n); ++i) {
+                if (i < n) {
+                    const float bcx = w0 * sinv, bcy = w1 * sinv;
+                    const float bcz = 1.0f - bcx - bcy;
+                    if ((bcx >= ERR) & (bcy >= ERR) & (bcz >= ERR)) {
+                        bool drawn = true;
+                        if (EXACT) { uint32_t texel; drawn = texel_drawn<TEXMODE>(tr, bcx, bcy, bcz, gtex, ltex, texel); }
+                        if (drawn) { atomicMax(&tilebuf[addr], li); ++mine; }
+                    }
+                    ++addr; w0 += sa0; w1 += sa1;
+                }
+            }
+            if (EXACT) {
+                for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
+                frags += (uint32_t)__builtin_amdgcn_readfirstlane((int)mine);
+            }
+        }
+        // surfaces whose edge walk must be replayed literally: wave-cooperative slow path
+        unsigned long long sm = __ballot(slow);
+        while (sm) {
+            const int t = __builtin_ctzll(sm);
+            sm &= sm - 1;
+            frags += cover_one<TEXMODE, EXACT>(b, t, cs + (uint32_t)t + 1, tilebuf, x_lo, x_hi, y_lo, y_hi, ty_top, lane, gtex, ltex);
         }
     }
+    (void)wave;
     return frags;
 }
 
@@ -292,10 +403,11 @@ template <int TEXMODE>
 __global__ __launch_bounds__(FILL_THREADS) void k_fill(FillArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* tilebuf = reinterpret_cast<uint32_t*>(smem);
-    volatile uint32_t* misc = reinterpret_cast<volatile uint32_t*>(smem + LDS_TILE_BYTES);   // [0] tile, [1] fail count
+    volatile uint32_t* misc = reinterpret_cast<volatile uint32_t*>(smem + LDS_TILE_BYTES);   // [0] tile, [1] fail count, [2] list cursor, [3] next tile
     uint32_t* fail_px = reinterpret_cast<uint32_t*>(smem + LDS_TILE_BYTES + LDS_MISC_BYTES);
     uint32_t* fail_li = fail_px + FAIL_CAP;
     uint32_t* fail_best = fail_li + FAIL_CAP;
+    uint32_t* wmarks = fail_best + FAIL_CAP;
     const uint16_t* ltex = reinterpret_cast<const uint16_t*>(smem + LDS_TEX_OFFSET);
 
     if (a.ctrl->abort) return;
@@ -317,12 +429,14 @@ __global__ __launch_bounds__(FILL_THREADS) void k_fill(FillArgs a) {
     unsigned long long T[8] = {0,0,0,0,0,0,0,0}; unsigned long long t0 = __builtin_readcyclecounter(), t1;
 #define TICK(i) { t1 = __builtin_readcyclecounter(); T[i] += t1 - t0; t0 = t1; }
     __syncthreads(); TICK(0)
+    if (tid == 0) misc[3] = atomicAdd(&a.ctrl->tile_cursor, 1u);
     for (;;) {
-        if (tid == 0) { misc[0] = atomicAdd(&a.ctrl->tile_cursor, 1u); misc[1] = 0; }
+        if (tid == 0) { misc[0] = misc[3]; misc[1] = 0; }
         __syncthreads();
         const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)misc[0]);
         TICK(1)
         if (tile >= ntiles) break;
+        if (tid == 0) misc[3] = atomicAdd(&a.ctrl->tile_cursor, 1u);      // prefetch the next tile index (latency hidden behind this tile)
         const uint32_t e0 = a.ranges[2 * tile], e1 = a.ranges[2 * tile + 1], e2 = a.ranges[2 * tile + 2];
         if (e0 != e2) {
             const uint32_t txi = tile % fp.tiles_x, tyi = tile / fp.tiles_x + fp.tile_y0;
@@ -336,12 +450,13 @@ __global__ __launch_bounds__(FILL_THREADS) void k_fill(FillArgs a) {
             for (int attempt = 0; attempt < 2; ++attempt) {
                 // ---- phase 0: clear the visibility buffer
                 for (uint32_t i = tid; i < TILE_H * TILE_STRIDE; i += FILL_THREADS) tilebuf[i] = 0;
+                if (tid == 0) misc[2] = 0;
                 __syncthreads(); TICK(2)
 
                 // ---- phase A: opaque coverage, winner = max list position (LDS atomicMax)
                 if (n_op) {
-                    if (exact) frag_count += phase_a<TEXMODE, true>(a, e0, n_op, wave, lane, lds_desc, tilebuf, x_lo, x_hi, y_lo, y_hi, ty_top, ltex);
-                    else phase_a<TEXMODE, false>(a, e0, n_op, wave, lane, lds_desc, tilebuf, x_lo, x_hi, y_lo, y_hi, ty_top, ltex);
+                    if (exact) frag_count += phase_a_rows<TEXMODE, true>(a, e0, n_op, lane, wave, &misc[2], wmarks + wave * 64, lds_desc, tilebuf, x_lo, x_hi, y_lo, y_hi, ty_top, ltex);
+                    else phase_a_rows<TEXMODE, false>(a, e0, n_op, lane, wave, &misc[2], wmarks + wave * 64, lds_desc, tilebuf, x_lo, x_hi, y_lo, y_hi, ty_top, ltex);
                 }
                 TICK(3)
                 __syncthreads(); TICK(4)
