@@ -37,6 +37,7 @@ struct b32_ctx {
     std::vector<TexDesc> h_tex;
     uint32_t nv = 0, nf = 0, nt = 0;
     bool have_scene = false;
+    bool may_blend = true;              // some face / texture can produce a transparent-pass surface (render.rs:2403-2415)
     bool cheap_ok = false;              // every texture has few skippable texels: CHEAP coverage + repair is profitable
     int count_fragments = 1;            // 1: exact fragment-store count every frame (EXACT coverage)
 
@@ -125,7 +126,7 @@ int b32_create(int device, b32_ctx** out) {
     c->stream = c->own_stream;
     if (hipMalloc(reinterpret_cast<void**>(&c->d_ctrl), sizeof(Ctrl)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&c->d_consts), 16 * sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&c->digit_total), 256 * sizeof(uint32_t)) != hipSuccess) { delete c; return B32_E_HIP; }
+        hipMalloc(reinterpret_cast<void**>(&c->digit_total), 4096 * sizeof(uint32_t)) != hipSuccess) { delete c; return B32_E_HIP; }
     *out = c;
     return B32_OK;
 }
@@ -233,6 +234,11 @@ static int upload_geometry(b32_ctx* c, const B32Vertex* v, uint32_t nv, const B3
     int rc;
     if ((rc = ensure(c, c->d_verts, c->cap_verts, (size_t)nv + 1))) return rc;
     if ((rc = ensure(c, c->d_faces, c->cap_faces, (size_t)nf + 1))) return rc;
+    {   // can any face end up in the transparent pass? (face blend mode / editor alpha; texture blend modes are added by the callers)
+        bool mb = false;
+        for (uint32_t i = 0; i < nf && !mb; ++i) mb = f[i].blend_mode != B32_BLEND_OPAQUE || f[i].editor_alpha < 255;
+        c->may_blend = mb;
+    }
     if (nv) HIPCHK(c, hipMemcpyAsync(c->d_verts, v, (size_t)nv * sizeof(B32Vertex), hipMemcpyHostToDevice, c->stream));
     if (nf) HIPCHK(c, hipMemcpyAsync(c->d_faces, f, (size_t)nf * sizeof(B32Face), hipMemcpyHostToDevice, c->stream));
     c->nv = nv; c->nf = nf;
@@ -295,6 +301,7 @@ int b32_scene_upload(b32_ctx* c, const B32Vertex* v, uint32_t nv, const B32Face*
         if (n == 0 || skippable * 32 > n) c->cheap_ok = false;
     }
     if ((rc = upload_geometry(c, v, nv, f, nf))) return rc;
+    for (uint32_t i = 0; i < nt; ++i) if (bl[i] != B32_BLEND_OPAQUE) c->may_blend = true;
     c->have_scene = true;
     return B32_OK;
 }
@@ -334,6 +341,7 @@ int b32_scene_upload_indexed(b32_ctx* c, const B32Vertex* v, uint32_t nv, const 
         (void)hipFree(d_idx); (void)hipFree(d_clut);
     }
     if ((rc = upload_geometry(c, v, nv, f, nf))) return rc;
+    for (uint32_t i = 0; i < nt; ++i) if (bl[i] != B32_BLEND_OPAQUE) c->may_blend = true;
     c->have_scene = true;
     return B32_OK;
 }
@@ -394,7 +402,7 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     }
     const uint32_t need_blocks = (uint32_t)((std::max(c->cap_pairs, c->cap_work) + SORT_TILE - 1) / SORT_TILE) + 1;
     if (need_blocks > c->hist_blocks || !c->block_hist) {
-        if ((rc = ensure_plain(c, c->block_hist, (size_t)256 * need_blocks))) return rc;
+        if ((rc = ensure_plain(c, c->block_hist, (size_t)4096 * need_blocks))) return rc;
         c->hist_blocks = need_blocks;
     }
     if ((size_t)n_keys + 2 > c->cap_ranges || !c->ranges) {
@@ -417,30 +425,38 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
         ev = c->ev[c->ev_frames % EV_RING];
     }
 
-    HIPCHK(c, hipMemsetAsync(c->d_ctrl, 0, sizeof(Ctrl), s));
+    if (c->nf == 0) HIPCHK(c, hipMemsetAsync(c->d_ctrl, 0, sizeof(Ctrl), s));    // otherwise k_setup resets it
     if (prof_all) HIPCHK(c, hipEventRecord(ev[0], s));
-    launch_setup(s, fp, c->d_verts, c->d_faces, c->d_tex, c->d_lights, c->recs, c->shades, c->keys[0], c->partials);
-    launch_after_setup(s, c->d_ctrl, c->partials, (c->nf + 255) / 256);
+    launch_setup(s, fp, c->d_verts, c->d_faces, c->d_tex, c->d_lights, c->recs, c->shades, c->keys[0], c->partials, c->d_ctrl);
     if (prof_all) HIPCHK(c, hipEventRecord(ev[1], s));
 
-    // painter's order: 4 stable passes over the 32-bit key; pass 1 also compacts away culled faces
+    // painter's order: 4 stable passes over the 32-bit key; pass 1 also compacts away culled faces and its scan kernel
+    // reduces k_setup's counters into Ctrl (n_visible feeds the later passes).
     const SortScratch sc{ c->block_hist, c->hist_blocks, c->digit_total };
-    launch_radix_pass(s, c->keys[0], nullptr, c->keys[1], c->vals[1], c->d_consts, c->nf, 0, sc);
-    launch_radix_pass(s, c->keys[1], c->vals[1], c->keys[0], c->vals[0], &c->d_ctrl->n_visible, c->nf, 8, sc);
-    launch_radix_pass(s, c->keys[0], c->vals[0], c->keys[1], c->vals[1], &c->d_ctrl->n_visible, c->nf, 16, sc);
-    launch_radix_pass(s, c->keys[1], c->vals[1], c->keys[0], c->vals[0], &c->d_ctrl->n_visible, c->nf, 24, sc);
+    RadixExtra ex1; ex1.post_ctrl = c->d_ctrl; ex1.partials = c->partials; ex1.npart = (c->nf + 255) / 256;
+    launch_radix_pass(s, c->keys[0], nullptr, c->keys[1], c->vals[1], c->d_consts, c->nf, 0, 8, sc, ex1);
+    launch_radix_pass(s, c->keys[1], c->vals[1], c->keys[0], c->vals[0], &c->d_ctrl->n_visible, c->nf, 8, 8, sc);
+    launch_radix_pass(s, c->keys[0], c->vals[0], c->keys[1], c->vals[1], &c->d_ctrl->n_visible, c->nf, 16, 8, sc);
+    launch_radix_pass(s, c->keys[1], c->vals[1], c->keys[0], c->vals[0], &c->d_ctrl->n_visible, c->nf, 24, 8, sc);
+    uint32_t* const order = c->vals[0];
     if (prof_all) HIPCHK(c, hipEventRecord(ev[2], s));
 
     // binning
-    launch_bin(s, fp, c->recs, c->vals[0], c->d_ctrl, c->counts, c->block_sums, c->bin_blocks, c->pkeys[0], c->pvals[0], (uint32_t)c->cap_pairs);
+    launch_bin(s, fp, c->recs, order, c->d_ctrl, c->counts, c->block_sums, c->bin_blocks, c->pkeys[0], c->pvals[0], (uint32_t)c->cap_pairs);
     const uint32_t kb = bits_for(n_keys ? n_keys : 1);
     int cur = 0;
-    for (uint32_t shift = 0; shift < kb; shift += 8) {
-        launch_radix_pass(s, c->pkeys[cur], c->pvals[cur], c->pkeys[cur ^ 1], c->pvals[cur ^ 1], &c->d_ctrl->n_pairs, (uint32_t)c->cap_pairs, (int)shift, sc);
+    if (kb <= 8 || kb > 12) {
+        for (uint32_t shift = 0; shift < kb; shift += 8) {
+            launch_radix_pass(s, c->pkeys[cur], c->pvals[cur], c->pkeys[cur ^ 1], c->pvals[cur ^ 1], &c->d_ctrl->n_pairs, (uint32_t)c->cap_pairs, (int)shift, 8, sc);
+            cur ^= 1;
+        }
+        launch_tile_ranges(s, c->pkeys[cur], c->d_ctrl, (uint32_t)c->cap_pairs, c->ranges, n_keys);
+    } else {    // up to 2048 tiles: one pass groups every (tile, class) list and its digit bases are the list ranges
+        RadixExtra exr; exr.ranges_out = c->ranges; exr.n_ranges = n_keys + 1;
+        launch_radix_pass(s, c->pkeys[cur], c->pvals[cur], c->pkeys[cur ^ 1], c->pvals[cur ^ 1], &c->d_ctrl->n_pairs, (uint32_t)c->cap_pairs, 0, kb <= 11 ? 11 : 12, sc, exr);
         cur ^= 1;
     }
     c->last_pair_buf = cur;
-    launch_tile_ranges(s, c->pkeys[cur], c->d_ctrl, (uint32_t)c->cap_pairs, c->ranges, n_keys);
     if (prof_fill) HIPCHK(c, hipEventRecord(ev[3], s));
 
     FillArgs fa{};
@@ -454,6 +470,7 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     }
     fa.exact_coverage = (c->count_fragments || !c->cheap_ok) ? 1u : 0u;
     if (!fa.exact_coverage) fa.lds_tex_texels = 0;      // CHEAP coverage: one texel fetch per output pixel, served by L1/L2
+    fa.may_blend = c->may_blend ? 1u : 0u;
     launch_fill(s, fa, c->n_cu);
     if (prof_fill) { HIPCHK(c, hipEventRecord(ev[4], s)); c->ev_frames++; }
     HIPCHK(c, hipGetLastError());

@@ -15,7 +15,7 @@ __device__ __forceinline__ bool tile_span(const SurfRec& r, const FrameParams& f
     min_y = max(min_y, fp.band_y0); max_y = min(max_y, fp.band_y1);     // rows outside this GPU's band belong to another rank
     if (min_x >= max_x || min_y >= max_y) return false;
     tx0 = min_x / TILE_W; tx1 = (max_x - 1) / TILE_W;
-    ty0 = min_y / TILE_H; ty1 = (max_y - 1) / TILE_H;
+    ty0 = min_y / TILE_H - fp.tile_y0; ty1 = (max_y - 1) / TILE_H - fp.tile_y0;      // band-relative tile rows (fit 8 bits: <= 16384 px)
     return true;
 }
 
@@ -38,9 +38,9 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_count(FrameParams fp, const
             if (r < n) {
                 const SurfRec& rec = recs[order[r]];
                 SurfRec q; q.bbx = rec.bbx; q.bby = rec.bby; q.flags = rec.flags;
-                uint32_t tx0, tx1, ty0, ty1, c = 0;
+                uint32_t tx0 = 1, tx1 = 0, ty0 = 1, ty1 = 0, c = 0;
                 if (tile_span(q, fp, tx0, tx1, ty0, ty1)) c = (tx1 - tx0 + 1) * (ty1 - ty0 + 1);
-                counts[r] = c;
+                counts[r] = c ? (tx0 | (tx1 << 8) | (ty0 << 16) | (ty1 << 24)) : 0xFFFFFFFFu;   // packed tile span (<= 256 tiles per axis)
                 local += c;
             }
         }
@@ -51,51 +51,41 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_count(FrameParams fp, const
     if (threadIdx.x == 0) block_sums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
-// Exclusive scan of block_sums (<= 1024 entries per pass of the loop) by one workgroup; publishes n_pairs and the overflow verdict.
-__global__ __launch_bounds__(1024) void k_bin_scan(uint32_t* __restrict__ block_sums, uint32_t nblocks, Ctrl* __restrict__ ctrl, uint32_t pair_cap) {
-    __shared__ uint32_t part[1024];
-    __shared__ uint32_t carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < nblocks; base += 1024) {
-        const uint32_t i = base + threadIdx.x;
-        const uint32_t v = i < nblocks ? block_sums[i] : 0;
-        part[threadIdx.x] = v;
-        __syncthreads();
-        for (uint32_t off = 1; off < 1024; off <<= 1) {
-            uint32_t t = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
-            __syncthreads();
-            part[threadIdx.x] += t;
-            __syncthreads();
-        }
-        if (i < nblocks) block_sums[i] = carry + part[threadIdx.x] - v;
-        __syncthreads();
-        if (threadIdx.x == 0) carry += part[1023];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        ctrl->n_pairs = carry;
-        if (carry > pair_cap) { ctrl->pairs_overflow = carry; ctrl->abort = 1; ctrl->n_pairs = 0; }
-    }
-}
-
 // Emit the pairs of each rank at its prefix offset (block base + in-block exclusive scan of counts).
 __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(FrameParams fp, const SurfRec* __restrict__ recs, const uint32_t* __restrict__ order,
-                                                           const Ctrl* __restrict__ ctrl, const uint32_t* __restrict__ counts,
-                                                           const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ pair_keys,
-                                                           uint32_t* __restrict__ pair_vals) {
+                                                           Ctrl* __restrict__ ctrl, const uint32_t* __restrict__ counts,
+                                                           const uint32_t* __restrict__ block_sums, uint32_t nblocks, uint32_t pair_cap,
+                                                           uint32_t* __restrict__ pair_keys, uint32_t* __restrict__ pair_vals) {
     __shared__ uint32_t wtot[BIN_THREADS / 64];
-    __shared__ uint32_t step_base;
+    __shared__ uint32_t step_base, total_s;
     const uint32_t n = ctrl->n_visible;
     const uint32_t base = blockIdx.x * BIN_TILE;
-    if (base >= n || ctrl->abort) return;
-    const uint32_t n_opaque = ctrl->n_opaque;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) step_base = block_sums[blockIdx.x];
-    __syncthreads();
+    {   // every block derives its own base and the grand total from the (<= few hundred) block sums: no separate scan kernel
+        uint32_t before = 0, all = 0;
+        for (uint32_t i = threadIdx.x; i < nblocks; i += BIN_THREADS) { const uint32_t v = block_sums[i]; all += v; if (i < blockIdx.x) before += v; }
+        for (int off = 32; off > 0; off >>= 1) { before += __shfl_down(before, off); all += __shfl_down(all, off); }
+        if (lane == 0) { wtot[wave] = before; }
+        __syncthreads();
+        if (threadIdx.x == 0) step_base = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+        __syncthreads();
+        if (lane == 0) wtot[wave] = all;
+        __syncthreads();
+        if (threadIdx.x == 0) total_s = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+        __syncthreads();
+    }
+    const uint32_t total = total_s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (total > pair_cap) { ctrl->pairs_overflow = total; ctrl->abort = 1; ctrl->n_pairs = 0; }
+        else ctrl->n_pairs = total;
+    }
+    if (base >= n || total > pair_cap || ctrl->abort) return;
+    const uint32_t n_opaque = ctrl->n_opaque;
     for (int i = 0; i < BIN_ITEMS; ++i) {
         const uint32_t r = base + i * BIN_THREADS + threadIdx.x;
-        const uint32_t c = r < n ? counts[r] : 0;
+        const uint32_t span = r < n ? counts[r] : 0xFFFFFFFFu;
+        const uint32_t tx0 = span & 0xFF, tx1 = (span >> 8) & 0xFF, ty0 = (span >> 16) & 0xFF, ty1 = span >> 24;
+        const uint32_t c = span == 0xFFFFFFFFu ? 0u : (tx1 - tx0 + 1) * (ty1 - ty0 + 1);
         // exclusive scan of c over the 256 threads of this step
         uint32_t inc = c;
         for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(inc, off); if (lane >= (uint32_t)off) inc += t; }
@@ -106,14 +96,10 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(FrameParams fp, const 
         uint32_t pos = step_base + woff + inc - c;
         if (c) {
             const uint32_t sid = order[r];
-            const SurfRec& rec = recs[sid];
-            SurfRec q; q.bbx = rec.bbx; q.bby = rec.bby; q.flags = rec.flags;
-            uint32_t tx0, tx1, ty0, ty1;
-            tile_span(q, fp, tx0, tx1, ty0, ty1);
             const uint32_t cls = r >= n_opaque ? 1u : 0u;
             for (uint32_t ty = ty0; ty <= ty1; ++ty)
                 for (uint32_t tx = tx0; tx <= tx1; ++tx) {
-                    const uint32_t tile = (ty - fp.tile_y0) * fp.tiles_x + tx;
+                    const uint32_t tile = ty * fp.tiles_x + tx;
                     pair_keys[pos] = (tile << 1) | cls;
                     pair_vals[pos] = sid;
                     ++pos;
@@ -130,8 +116,7 @@ void launch_bin(hipStream_t s, const FrameParams& fp, const SurfRec* recs, const
     if (fp.nf == 0) return;
     const uint32_t nblocks = min((fp.nf + BIN_TILE - 1) / BIN_TILE, max_blocks);
     hipLaunchKernelGGL(k_bin_count, dim3(nblocks), dim3(BIN_THREADS), 0, s, fp, recs, order, ctrl, counts, block_sums);
-    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, s, block_sums, nblocks, ctrl, pair_cap);
-    hipLaunchKernelGGL(k_bin_emit, dim3(nblocks), dim3(BIN_THREADS), 0, s, fp, recs, order, ctrl, counts, block_sums, pair_keys, pair_vals);
+    hipLaunchKernelGGL(k_bin_emit, dim3(nblocks), dim3(BIN_THREADS), 0, s, fp, recs, order, ctrl, counts, block_sums, nblocks, pair_cap, pair_keys, pair_vals);
 }
 
 // ranges[k] = first pair index whose key >= k, for k in 0..n_keys (n_keys = 2*ntiles); ranges[n_keys] = n_pairs.

@@ -143,25 +143,28 @@ __device__ __forceinline__ uint32_t blend_rgb555(uint32_t front, uint32_t back, 
 
 // ---------------------------------------------------------------- kernel launchers (defined in the .hip files)
 struct SortScratch {
-    uint32_t* block_hist;   // [256][max_blocks] digit-major
+    uint32_t* block_hist;   // [4096][max_blocks] digit-major (rows used: 2^bits)
     uint32_t  max_blocks;
-    uint32_t* digit_total;  // [256]
+    uint32_t* digit_total;  // [4096]
 };
 constexpr int SORT_THREADS = 256;
 constexpr int SORT_ITEMS = 16;
 constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;   // 4096 keys per block
 
-// One stable LSD pass on `shift`..shift+7. n is read from *n_dev (<= n_cap). If vals_in == nullptr the value of
-// element i is i and keys equal to KEY_INVALID are dropped (first pass over the face-order key array).
+// One stable LSD pass on bits [shift, shift+bits), bits in {8, 11, 12}. n is read from *n_dev (<= n_cap). If vals_in == nullptr
+// the value of element i is i and keys equal to KEY_INVALID are dropped (first pass over the face-order key array).
+struct RadixExtra {            // optional jobs folded into a pass to save kernel launches
+    Ctrl* post_ctrl = nullptr; const uint32_t* partials = nullptr; uint32_t npart = 0;   // k_setup counter reduction (first depth pass)
+    uint32_t* ranges_out = nullptr; uint32_t n_ranges = 0;                               // tile-list ranges (single-pass tile sort)
+};
 void launch_radix_pass(hipStream_t s, const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
-                       const uint32_t* n_dev, uint32_t n_cap, int shift, const SortScratch& sc);
+                       const uint32_t* n_dev, uint32_t n_cap, int shift, int bits, const SortScratch& sc, const RadixExtra& ex = RadixExtra());
 
 // k_setup publishes 5 counters per 256-face block (visible, transparent, nan_opaque, nan_transparent, bad_index) into
 // `partials[block*8 + k]`; k_after_setup reduces them into Ctrl.  (One same-address atomic per wave costs ~12 ns each and
 // serialises: 15.6 k waves = the whole kernel time at 1 M faces.)
 void launch_setup(hipStream_t s, const FrameParams& fp, const B32Vertex* verts, const B32Face* faces, const TexDesc* tex,
-                  const B32Light* lights, SurfRec* recs, float* shades, uint32_t* keys, uint32_t* partials);
-void launch_after_setup(hipStream_t s, Ctrl* ctrl, const uint32_t* partials, uint32_t nblocks);
+                  const B32Light* lights, SurfRec* recs, float* shades, uint32_t* keys, uint32_t* partials, Ctrl* ctrl);
 void launch_project_fixed(hipStream_t s, const float* pos, uint32_t n, B32Camera cam, uint32_t w, uint32_t h,
                           int32_t* sx, int32_t* sy, float* z);
 void launch_selftest(hipStream_t s, int op, const float* a, const float* b, const float* c, float* out, uint32_t n);
@@ -185,6 +188,7 @@ struct FillArgs {
     TexDesc tex0;               // descriptor of texture 0 (used when nt == 1: no per-pixel descriptor gather)
     Ctrl* ctrl;
     uint32_t lds_tex_texels;    // > 0: every face samples texture 0 and it is staged in LDS (width*height texels)
+    uint32_t may_blend;         // 0: no face/texture can be in the transparent pass -> k_blend is not launched
     uint32_t exact_coverage;    // 1: phase A applies the full skip rule and counts fragment stores; 0: CHEAP coverage + repair
 };
 void launch_fill(hipStream_t s, const FillArgs& a, int n_cu);

@@ -667,7 +667,7 @@ void launch_fill(hipStream_t s, const FillArgs& a, int n_cu) {
     }
     const uint32_t band_h = a.fp.band_y1 - a.fp.band_y0;
     if (band_h) hipLaunchKernelGGL(k_shade, dim3((a.fp.width + 255) / 256, band_h), dim3(256), 0, s, a);
-    hipLaunchKernelGGL((k_blend<1024>), dim3(ntiles), dim3(1024), 0, s, a);
+    if (a.may_blend) hipLaunchKernelGGL((k_blend<1024>), dim3(ntiles), dim3(1024), 0, s, a);
 }
 
 size_t fill_lds_tex_budget() { return 160 * 1024 - LDS_TEX_OFFSET - 16; }

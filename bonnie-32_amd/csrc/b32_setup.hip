@@ -137,8 +137,9 @@ __device__ __forceinline__ uint32_t fog_color(uint32_t c, uint32_t fogc, float f
 __global__ __launch_bounds__(256) void k_setup(FrameParams fp, const B32Vertex* __restrict__ verts, const B32Face* __restrict__ faces,
                                                const TexDesc* __restrict__ tex, const B32Light* __restrict__ lights,
                                                SurfRec* __restrict__ recs, float* __restrict__ shades, uint32_t* __restrict__ keys,
-                                               uint32_t* __restrict__ partials) {
+                                               uint32_t* __restrict__ partials, Ctrl* __restrict__ ctrl) {
     __shared__ uint32_t wpart[4][5];
+    if (blockIdx.x == 0 && threadIdx.x < sizeof(Ctrl) / 4) reinterpret_cast<uint32_t*>(ctrl)[threadIdx.x] = 0;   // frame-start reset (no memset launch)
     const uint32_t f = blockIdx.x * 256u + threadIdx.x;
     bool visible = false, transparent = false, nan_key = false, bad_index = false;
     uint32_t key = KEY_INVALID;
@@ -291,36 +292,10 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp, const B32Vertex* 
     if (threadIdx.x < 5) partials[blockIdx.x * 8 + threadIdx.x] = wpart[0][threadIdx.x] + wpart[1][threadIdx.x] + wpart[2][threadIdx.x] + wpart[3][threadIdx.x];
 }
 
-// After k_setup: derive n_opaque and decide whether the frame may draw at all.  The reference panics before drawing
-// on an out-of-range vertex index (render.rs:2375) or when a sort comparison sees NaN (render.rs:2531, lists of >= 2).
-__global__ __launch_bounds__(1024) void k_after_setup(Ctrl* ctrl, const uint32_t* __restrict__ partials, uint32_t nblocks) {
-    __shared__ uint32_t red[16][5];
-    uint32_t acc[5] = { 0, 0, 0, 0, 0 };
-    for (uint32_t b = threadIdx.x; b < nblocks; b += 1024)
-        for (int k = 0; k < 5; ++k) acc[k] += partials[b * 8 + k];
-    for (int k = 0; k < 5; ++k)
-        for (int off = 32; off > 0; off >>= 1) acc[k] += __shfl_down(acc[k], off);
-    if ((threadIdx.x & 63) == 0) for (int k = 0; k < 5; ++k) red[threadIdx.x >> 6][k] = acc[k];
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t t[5] = { 0, 0, 0, 0, 0 };
-        for (int w = 0; w < 16; ++w) for (int k = 0; k < 5; ++k) t[k] += red[w][k];
-        const uint32_t n_op = t[0] - t[1];
-        ctrl->n_visible = t[0]; ctrl->n_transparent = t[1]; ctrl->nan_opaque = t[2]; ctrl->nan_transparent = t[3];
-        ctrl->err_index = t[4] ? 1u : 0u;
-        ctrl->n_opaque = n_op;
-        if (t[4]) ctrl->abort = 1;
-        if ((t[2] && n_op >= 2) || (t[3] && t[1] >= 2)) ctrl->abort = 1;
-    }
-}
-
 void launch_setup(hipStream_t s, const FrameParams& fp, const B32Vertex* verts, const B32Face* faces, const TexDesc* tex,
-                  const B32Light* lights, SurfRec* recs, float* shades, uint32_t* keys, uint32_t* partials) {
+                  const B32Light* lights, SurfRec* recs, float* shades, uint32_t* keys, uint32_t* partials, Ctrl* ctrl) {
     if (fp.nf == 0) return;
-    hipLaunchKernelGGL(k_setup, dim3((fp.nf + 255) / 256), dim3(256), 0, s, fp, verts, faces, tex, lights, recs, shades, keys, partials);
-}
-void launch_after_setup(hipStream_t s, Ctrl* ctrl, const uint32_t* partials, uint32_t nblocks) {
-    hipLaunchKernelGGL(k_after_setup, dim3(1), dim3(1024), 0, s, ctrl, partials, nblocks);
+    hipLaunchKernelGGL(k_setup, dim3((fp.nf + 255) / 256), dim3(256), 0, s, fp, verts, faces, tex, lights, recs, shades, keys, partials, ctrl);
 }
 
 // ---------------------------------------------------------------- stage tap: project_fixed for n positions

@@ -1,4 +1,4 @@
-// b32_sort.hip — stable LSD radix sort (8-bit digits) over (u32 key, u32 value) pairs, wave64-native.
+// b32_sort.hip — stable LSD radix sort (8-, 11- or 12-bit digits) over (u32 key, u32 value) pairs, wave64-native.
 //
 // Replaces the reference's `sort_by` merge sort of 208-byte Surface structs (render.rs:2527-2541): the painter's key is
 // reduced to a 32-bit radix key by k_setup and only (key, surface id) pairs move.  Stability of every pass is what makes
@@ -16,16 +16,19 @@ __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi
 
 // Each wave of a block owns a contiguous run of 16 x 64 elements, read 64 at a time (256-B coalesced loads), so that
 // "earlier element" == "earlier step, or same step and lower lane" inside a wave, and waves are ordered by index.
+// BITS = digit width (8, 11 or 12): NB = 2^BITS bins.
+template <int BITS>
 __global__ __launch_bounds__(SORT_THREADS) void k_hist(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ n_dev,
                                                         int shift, int drop_invalid, uint32_t* __restrict__ block_hist, uint32_t max_blocks) {
-    __shared__ uint32_t hist[256];
+    constexpr uint32_t NB = 1u << BITS;
+    __shared__ uint32_t hist[NB];
     const uint32_t n = *n_dev;
     const uint32_t base = blockIdx.x * SORT_TILE;
     if (base >= n) {   // still publish zeros so the scan sees a clean column
-        block_hist[threadIdx.x * max_blocks + blockIdx.x] = 0;
+        for (uint32_t d = threadIdx.x; d < NB; d += SORT_THREADS) block_hist[(size_t)d * max_blocks + blockIdx.x] = 0;
         return;
     }
-    hist[threadIdx.x] = 0;
+    for (uint32_t d = threadIdx.x; d < NB; d += SORT_THREADS) hist[d] = 0;
     __syncthreads();
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t wbase = base + wave * (SORT_ITEMS * 64);
@@ -34,18 +37,46 @@ __global__ __launch_bounds__(SORT_THREADS) void k_hist(const uint32_t* __restric
         uint32_t idx = wbase + i * 64 + lane;
         if (idx < n) {
             uint32_t k = keys[idx];
-            if (!(drop_invalid && k == KEY_INVALID)) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+            if (!(drop_invalid && k == KEY_INVALID)) atomicAdd(&hist[(k >> shift) & (NB - 1)], 1u);
         }
     }
     __syncthreads();
-    block_hist[threadIdx.x * max_blocks + blockIdx.x] = hist[threadIdx.x];
+    for (uint32_t d = threadIdx.x; d < NB; d += SORT_THREADS) block_hist[(size_t)d * max_blocks + blockIdx.x] = hist[d];
 }
 
-// Row d of block_hist[256][max_blocks] (one workgroup per digit): exclusive scan over the blocks, in place, and the
-// row total into digit_total[d].  The scan across digits is folded into k_scatter (256 values, one per thread).
+// Reduction of k_setup's per-block counters: derive n_opaque and decide whether the frame may draw at all.  The reference
+// panics before drawing on an out-of-range vertex index (render.rs:2375) or when a sort comparison sees NaN
+// (render.rs:2531, lists of >= 2 elements).  Called by one 256-thread block.
+__device__ void reduce_setup_partials(Ctrl* ctrl, const uint32_t* __restrict__ partials, uint32_t nblocks) {
+    __shared__ uint32_t red[4][5];
+    uint32_t acc[5] = { 0, 0, 0, 0, 0 };
+    for (uint32_t b = threadIdx.x; b < nblocks; b += 256)
+        for (int k = 0; k < 5; ++k) acc[k] += partials[b * 8 + k];
+    for (int k = 0; k < 5; ++k)
+        for (int off = 32; off > 0; off >>= 1) acc[k] += __shfl_down(acc[k], off);
+    if ((threadIdx.x & 63) == 0) for (int k = 0; k < 5; ++k) red[threadIdx.x >> 6][k] = acc[k];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t[5] = { 0, 0, 0, 0, 0 };
+        for (int w = 0; w < 4; ++w) for (int k = 0; k < 5; ++k) t[k] += red[w][k];
+        const uint32_t n_op = t[0] - t[1];
+        ctrl->n_visible = t[0]; ctrl->n_transparent = t[1]; ctrl->nan_opaque = t[2]; ctrl->nan_transparent = t[3];
+        ctrl->err_index = t[4] ? 1u : 0u;
+        ctrl->n_opaque = n_op;
+        if (t[4]) ctrl->abort = 1;
+        if ((t[2] && n_op >= 2) || (t[3] && t[1] >= 2)) ctrl->abort = 1;
+    }
+    __syncthreads();
+}
+
+// Row d of block_hist[NB][max_blocks] (one workgroup per digit): exclusive scan over the blocks, in place, and the
+// row total into digit_total[d].  The scan across digits is folded into k_scatter.
+// `post` (first depth pass only): block 0 also reduces k_setup's per-block counters into Ctrl (former k_after_setup).
 __global__ __launch_bounds__(256) void k_scan_rows(uint32_t* __restrict__ block_hist, uint32_t max_blocks, uint32_t nblocks,
-                                                   uint32_t* __restrict__ digit_total) {
+                                                   uint32_t* __restrict__ digit_total, Ctrl* __restrict__ post_ctrl,
+                                                   const uint32_t* __restrict__ partials, uint32_t npart) {
     __shared__ uint32_t wsum[4];
+    if (post_ctrl && blockIdx.x == 0) reduce_setup_partials(post_ctrl, partials, npart);
     __shared__ uint32_t carry_s;
     uint32_t* row = block_hist + (size_t)blockIdx.x * max_blocks;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -68,30 +99,45 @@ __global__ __launch_bounds__(256) void k_scan_rows(uint32_t* __restrict__ block_
     if (threadIdx.x == 0) digit_total[blockIdx.x] = carry_s;
 }
 
+template <int BITS>
 __global__ __launch_bounds__(SORT_THREADS) void k_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                            uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                            const uint32_t* __restrict__ n_dev, int shift, int drop_invalid,
                                                            const uint32_t* __restrict__ block_hist, uint32_t max_blocks,
-                                                           const uint32_t* __restrict__ digit_total) {
-    __shared__ uint32_t wcnt[4][256];     // per-wave running digit counts, then exclusive prefix over waves
-    __shared__ uint32_t dbase[256];       // exclusive scan of the 256 digit totals
+                                                           const uint32_t* __restrict__ digit_total, uint32_t* __restrict__ ranges_out,
+                                                           uint32_t n_ranges) {
+    constexpr uint32_t NB = 1u << BITS;
+    constexpr uint32_t PER = NB / SORT_THREADS;           // bins per thread in the prefix steps
+    __shared__ uint32_t wcnt[4][NB];      // per-wave running digit counts, then exclusive prefix over waves (+ global base)
     __shared__ uint32_t dws[4];
     const uint32_t n = *n_dev;
     const uint32_t base = blockIdx.x * SORT_TILE;
-    if (base >= n) return;
+    if (base >= n && !(ranges_out && blockIdx.x == 0)) return;
     const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
-    for (int w = 0; w < 4; ++w) wcnt[w][threadIdx.x] = 0;
-    {   // digit bases: exclusive scan of digit_total over the 256 threads
-        const uint32_t v = digit_total[threadIdx.x];
-        uint32_t inc = v;
+    for (int w = 0; w < 4; ++w) for (uint32_t d = threadIdx.x; d < NB; d += SORT_THREADS) wcnt[w][d] = 0;
+    // digit bases: exclusive scan of digit_total; thread t owns bins [t*PER, t*PER+PER)
+    uint32_t dbase[PER];
+    {
+        uint32_t tot[PER], sum = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < PER; ++j) { tot[j] = digit_total[threadIdx.x * PER + j]; sum += tot[j]; }
+        uint32_t inc = sum;
         for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(inc, off); if (lane >= (uint32_t)off) inc += t; }
         if (lane == 63) dws[wave] = inc;
         __syncthreads();
-        uint32_t woff = 0;
-        for (uint32_t w = 0; w < wave; ++w) woff += dws[w];
-        dbase[threadIdx.x] = woff + inc - v;
+        uint32_t run = inc - sum;
+        for (uint32_t w = 0; w < wave; ++w) run += dws[w];
+#pragma unroll
+        for (uint32_t j = 0; j < PER; ++j) { dbase[j] = run; run += tot[j]; }
+        // single-pass sort of (tile,class) keys: the digit bases ARE the list ranges (ranges[k] = first pair with key >= k)
+        if (ranges_out && blockIdx.x == 0) {
+#pragma unroll
+            for (uint32_t j = 0; j < PER; ++j) { const uint32_t d = threadIdx.x * PER + j; if (d < n_ranges) ranges_out[d] = dbase[j]; }
+            if (threadIdx.x == SORT_THREADS - 1 && n_ranges > NB) ranges_out[NB] = run;
+        }
     }
     __syncthreads();
+    if (base >= n) return;
     const uint32_t wbase = base + wave * (SORT_ITEMS * 64);
     uint32_t key[SORT_ITEMS], val[SORT_ITEMS], rnk[SORT_ITEMS];
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -103,11 +149,11 @@ __global__ __launch_bounds__(SORT_THREADS) void k_scatter(const uint32_t* __rest
         if (drop_invalid && k == KEY_INVALID) live = false;
         key[i] = k;
         val[i] = live ? (vals_in ? vals_in[idx] : idx) : 0u;
-        const uint32_t d = (k >> shift) & 255u;
-        // peers = live lanes of this wave holding the same digit (8 ballots)
+        const uint32_t d = (k >> shift) & (NB - 1);
+        // peers = live lanes of this wave holding the same digit (BITS ballots)
         unsigned long long peers = __ballot(live);
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
+        for (int b = 0; b < BITS; ++b) {
             const unsigned long long m = __ballot((d >> b) & 1u);
             peers &= ((d >> b) & 1u) ? m : ~m;
         }
@@ -122,16 +168,17 @@ __global__ __launch_bounds__(SORT_THREADS) void k_scatter(const uint32_t* __rest
         rnk[i] = live ? before : 0xFFFFFFFFu;
     }
     __syncthreads();
-    {   // thread d: exclusive prefix of digit d over the 4 waves + global base of (digit, block)
-        const uint32_t d = threadIdx.x;
-        uint32_t run = dbase[d] + block_hist[d * max_blocks + blockIdx.x];
+#pragma unroll
+    for (uint32_t j = 0; j < PER; ++j) {   // exclusive prefix of each owned digit over the 4 waves + global base of (digit, block)
+        const uint32_t d = threadIdx.x * PER + j;
+        uint32_t run = dbase[j] + block_hist[(size_t)d * max_blocks + blockIdx.x];
         for (int w = 0; w < 4; ++w) { uint32_t c = wcnt[w][d]; wcnt[w][d] = run; run += c; }
     }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < SORT_ITEMS; ++i) {
         if (rnk[i] != 0xFFFFFFFFu) {
-            const uint32_t d = (key[i] >> shift) & 255u;
+            const uint32_t d = (key[i] >> shift) & (NB - 1);
             const uint32_t pos = wcnt[wave][d] + rnk[i];
             keys_out[pos] = key[i];
             vals_out[pos] = val[i];
@@ -139,15 +186,24 @@ __global__ __launch_bounds__(SORT_THREADS) void k_scatter(const uint32_t* __rest
     }
 }
 
-void launch_radix_pass(hipStream_t s, const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
-                       const uint32_t* n_dev, uint32_t n_cap, int shift, const SortScratch& sc) {
-    if (n_cap == 0) return;
+template <int BITS>
+static void radix_pass_t(hipStream_t s, const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
+                         const uint32_t* n_dev, uint32_t n_cap, int shift, const SortScratch& sc, const RadixExtra& ex) {
     const uint32_t nblocks = (n_cap + SORT_TILE - 1) / SORT_TILE;
     const int drop = vals_in == nullptr ? 1 : 0;
-    hipLaunchKernelGGL(k_hist, dim3(nblocks), dim3(SORT_THREADS), 0, s, keys_in, n_dev, shift, drop, sc.block_hist, sc.max_blocks);
-    hipLaunchKernelGGL(k_scan_rows, dim3(256), dim3(256), 0, s, sc.block_hist, sc.max_blocks, nblocks, sc.digit_total);
-    hipLaunchKernelGGL(k_scatter, dim3(nblocks), dim3(SORT_THREADS), 0, s, keys_in, vals_in, keys_out, vals_out, n_dev, shift, drop,
-                       sc.block_hist, sc.max_blocks, sc.digit_total);
+    hipLaunchKernelGGL(k_hist<BITS>, dim3(nblocks), dim3(SORT_THREADS), 0, s, keys_in, n_dev, shift, drop, sc.block_hist, sc.max_blocks);
+    hipLaunchKernelGGL(k_scan_rows, dim3(1u << BITS), dim3(256), 0, s, sc.block_hist, sc.max_blocks, nblocks, sc.digit_total,
+                       ex.post_ctrl, ex.partials, ex.npart);
+    hipLaunchKernelGGL(k_scatter<BITS>, dim3(nblocks), dim3(SORT_THREADS), 0, s, keys_in, vals_in, keys_out, vals_out, n_dev, shift, drop,
+                       sc.block_hist, sc.max_blocks, sc.digit_total, ex.ranges_out, ex.n_ranges);
+}
+
+void launch_radix_pass(hipStream_t s, const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
+                       const uint32_t* n_dev, uint32_t n_cap, int shift, int bits, const SortScratch& sc, const RadixExtra& ex) {
+    if (n_cap == 0) return;
+    if (bits == 11) radix_pass_t<11>(s, keys_in, vals_in, keys_out, vals_out, n_dev, n_cap, shift, sc, ex);
+    else if (bits == 12) radix_pass_t<12>(s, keys_in, vals_in, keys_out, vals_out, n_dev, n_cap, shift, sc, ex);
+    else radix_pass_t<8>(s, keys_in, vals_in, keys_out, vals_out, n_dev, n_cap, shift, sc, ex);
 }
 
 }  // namespace b32
