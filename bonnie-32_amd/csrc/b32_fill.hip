@@ -31,7 +31,7 @@ namespace b32 {
 constexpr int LDS_TILE_BYTES = TILE_H * TILE_STRIDE * 4;        // 18432
 constexpr int LDS_MISC_BYTES = 64;
 constexpr int LDS_MARK_BYTES = FILL_WAVES * 64 * 4;             // row-start marks of the row-item scheduler
-constexpr int LDS_TEX_OFFSET = LDS_TILE_BYTES + LDS_MISC_BYTES + LDS_MARK_BYTES;   // 22592
+constexpr int LDS_TEX_OFFSET = 2 * LDS_TILE_BYTES + LDS_MISC_BYTES + LDS_MARK_BYTES;   // 41024: top + runner-up tile buffers
 
 __device__ __forceinline__ float bcf(float v, int t) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), t)); }
 __device__ __forceinline__ uint32_t bcu(uint32_t v, int t) { return (uint32_t)__builtin_amdgcn_readlane((int)v, t); }
@@ -233,7 +233,11 @@ __device__ __forceinline__ uint32_t cover_surface(const Tri& tr, uint32_t cx0, u
                     if (inside_bc(tr, w0, w1, bcx, bcy, bcz)) {
                         uint32_t texel;
                         drawn = EXACT ? texel_drawn<TEXMODE>(tr, bcx, bcy, bcz, gtex, ltex, texel) : true;
-                        if (drawn) atomicMax(&tilebuf[(py - ty_top) * TILE_STRIDE + (px - x_lo)], li);
+                        if (drawn) {
+                            uint32_t* t = &tilebuf[(py - ty_top) * TILE_STRIDE + (px - x_lo)];
+                            if (EXACT) atomicMax(t, li);
+                            else { const uint32_t old = atomicMax(t, li); atomicMax(t + TILE_H * TILE_STRIDE, min(old, li)); }
+                        }
                     }
                 }
                 if (EXACT) drawn_count += (uint32_t)__popcll(__ballot(drawn));
@@ -251,7 +255,12 @@ __device__ __forceinline__ uint32_t cover_surface(const Tri& tr, uint32_t cx0, u
                     if (inside_bc(tr, w0, w1, bcx, bcy, bcz)) {
                         uint32_t texel;
                         const bool drawn = EXACT ? texel_drawn<TEXMODE>(tr, bcx, bcy, bcz, gtex, ltex, texel) : true;
-                        if (drawn) { atomicMax(&tilebuf[(py - ty_top) * TILE_STRIDE + (px - x_lo)], li); ++mine; }
+                        if (drawn) {
+                            uint32_t* t = &tilebuf[(py - ty_top) * TILE_STRIDE + (px - x_lo)];
+                            if (EXACT) atomicMax(t, li);
+                            else { const uint32_t old = atomicMax(t, li); atomicMax(t + TILE_H * TILE_STRIDE, min(old, li)); }
+                            ++mine;
+                        }
                     }
                     w0 += tr.a0; w1 += tr.a1;
                 }
@@ -373,7 +382,15 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
                     if ((bcx >= ERR) & (bcy >= ERR) & (bcz >= ERR)) {
                         bool drawn = true;
                         if (EXACT) { uint32_t texel; drawn = texel_drawn<TEXMODE>(tr, bcx, bcy, bcz, gtex, ltex, texel); }
-                        if (drawn) { atomicMax(&tilebuf[addr], li); ++mine; }
+                        if (drawn) {
+                            if (EXACT) { atomicMax(&tilebuf[addr], li); ++mine; }
+                            else {
+                                // exact top-2 under any arrival order: whoever loses the max (the newcomer, or the value it displaced)
+                                // is a runner-up candidate; the final max is never displaced, every other value is pushed once.
+                                const uint32_t old = atomicMax(&tilebuf[addr], li);
+                                atomicMax(&tilebuf[addr + TILE_H * TILE_STRIDE], min(old, li));
+                            }
+                        }
                     }
                     ++addr; w0 += sa0; w1 += sa1;
                 }
@@ -402,8 +419,8 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a) {
     constexpr int NW = NT / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* tilebuf = reinterpret_cast<uint32_t*>(smem);
-    volatile uint32_t* misc = reinterpret_cast<volatile uint32_t*>(smem + LDS_TILE_BYTES);   // [0] tile, [2] list cursor
-    uint32_t* wmarks = reinterpret_cast<uint32_t*>(smem + LDS_TILE_BYTES + LDS_MISC_BYTES);
+    volatile uint32_t* misc = reinterpret_cast<volatile uint32_t*>(smem + 2 * LDS_TILE_BYTES);   // [0] tile, [2] list cursor
+    uint32_t* wmarks = reinterpret_cast<uint32_t*>(smem + 2 * LDS_TILE_BYTES + LDS_MISC_BYTES);
     const uint16_t* ltex = reinterpret_cast<const uint16_t*>(smem + LDS_TEX_OFFSET);
 
     if (a.ctrl->abort) return;
@@ -425,7 +442,7 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a) {
     if (tid == 0) next_tile = atomicAdd(&a.ctrl->tile_cursor, 1u);
     for (;;) {
         if (tid == 0) { misc[0] = next_tile; misc[2] = 0; }
-        for (uint32_t i = tid; i < TILE_H * TILE_STRIDE; i += NT) tilebuf[i] = 0;
+        for (uint32_t i = tid; i < (EXACT ? 1 : 2) * TILE_H * TILE_STRIDE; i += NT) tilebuf[i] = 0;
         __syncthreads();
         const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)misc[0]);
         if (tile >= ntiles) break;
@@ -448,7 +465,14 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a) {
             if (px < x_hi && py >= y_lo && py < y_hi) {
                 const uint32_t li = tilebuf[row * TILE_STRIDE + col];
                 const uint32_t sid = li ? a.pair_vals[e0 + li - 1] : 0u;                // resolve the surface id here: one level
-                a.vis[(size_t)py * fp.width + px] = make_uint2(li, sid);                // less in k_shade's dependent gather chain
+                // less in k_shade's dependent gather chain.  CHEAP coverage: the runner-up travels in the high half when the
+                // tile list is short enough (< 32768 entries); bit 31 marks a long list whose runner-up is unknown.
+                uint32_t packed = li;
+                if (!EXACT) {
+                    const uint32_t second = tilebuf[TILE_H * TILE_STRIDE + row * TILE_STRIDE + col];
+                    packed = n_op < 0x8000u ? (li | (second << 16)) : (li | 0x80000000u);     // bit 31 = long list, no runner-up
+                }
+                a.vis[(size_t)py * fp.width + px] = make_uint2(packed, sid);
             }
         }
         __syncthreads();   // everyone is done with misc / tilebuf before the next tile
@@ -514,21 +538,30 @@ __global__ __launch_bounds__(256) void k_shade(FillArgs a) {
     if (seg_x >= W) return;
     const bool inb = px < W;
     const uint2 ve = inb ? a.vis[(size_t)py * W + px] : make_uint2(0u, 0u);
-    const uint32_t li = ve.x;
-    if (!__ballot(li != 0)) return;
+    if (!__ballot(ve.x != 0)) return;
+    // decode (CHEAP coverage packs the runner-up list position in the high half, see k_cover)
+    const bool long_list = !a.exact_coverage && (ve.x >> 31);
+    const uint32_t li = a.exact_coverage ? ve.x : (long_list ? (ve.x & 0x7FFFFFFFu) : (ve.x & 0xFFFFu));
+    const uint32_t second = (a.exact_coverage || long_list) ? 0u : (ve.x >> 16);
     const uint32_t tile = (py / TILE_H - fp.tile_y0) * fp.tiles_x + seg_x / TILE_W;      // same tile for the whole wave
     const uint32_t e0 = a.ranges[2 * tile];
     Hit h;
-    bool have = false, failed = false;
-    if (li) { have = hit_test(a, ve.y, px, py, h); failed = !have; }
-    // CHEAP coverage only: the top surface is skipped at this pixel -> highest surface below it whose fragment is drawn.
-    // The wave scans the tile list downward, 64 entries per step; only the cheap coverage test runs per candidate.
-    unsigned long long fm = __ballot(failed);
+    bool have = false;
+    uint32_t scan_from = 0;                     // > 0: list positions <= scan_from still have to be searched
+    if (li && !(have = hit_test(a, ve.y, px, py, h))) {
+        // CHEAP coverage only: the top surface is skipped at this pixel -> highest surface below it whose fragment is drawn.
+        if (long_list) scan_from = li - 1;
+        else if (second) {                      // exact runner-up from k_cover: almost always the answer (else ~1/256 again)
+            if (!(have = hit_test(a, a.pair_vals[e0 + second - 1], px, py, h))) scan_from = second - 1;
+        }                                       // second == 0: no other surface covers the pixel, it keeps the framebuffer value
+    }
+    // rare: the wave scans the tile list downward, 64 entries per step; only the coverage test runs per candidate
+    unsigned long long fm = __ballot(scan_from != 0);
     while (fm) {
         const int fl = __builtin_ctzll(fm);
         fm &= fm - 1;
-        const uint32_t fx = (uint32_t)__builtin_amdgcn_readlane((int)px, fl), fli = (uint32_t)__builtin_amdgcn_readlane((int)li, fl);
-        for (uint32_t top = fli - 1; top > 0; top = top > 64 ? top - 64 : 0) {            // list positions top-lane, descending
+        const uint32_t fx = (uint32_t)__builtin_amdgcn_readlane((int)px, fl), ftop = (uint32_t)__builtin_amdgcn_readlane((int)scan_from, fl);
+        for (uint32_t top = ftop; top > 0; top = top > 64 ? top - 64 : 0) {               // list positions top-lane, descending
             Hit c;
             bool hit = false;
             if (lane < top) {
@@ -541,7 +574,6 @@ __global__ __launch_bounds__(256) void k_shade(FillArgs a) {
             const unsigned long long hm = __ballot(hit);
             if (hm) {                                                                     // lowest lane == highest list position
                 const int hl = __builtin_ctzll(hm);
-                // hand the winning candidate's data to the failed lane
                 const float bx_ = bcf(c.bcx, hl), by_ = bcf(c.bcy, hl), bz_ = bcf(c.bcz, hl);
                 const uint32_t t_ = bcu(c.texel, hl), v1_ = bcu(c.vc1, hl), v2_ = bcu(c.vc2, hl), v3_ = bcu(c.vc3, hl), f_ = bcu(c.flags, hl), s_ = bcu(c.sid, hl);
                 if ((int)lane == fl) { h.bcx = bx_; h.bcy = by_; h.bcz = bz_; h.texel = t_; h.vc1 = v1_; h.vc2 = v2_; h.vc3 = v3_; h.flags = f_; h.sid = s_; have = true; }
