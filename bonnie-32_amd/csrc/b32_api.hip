@@ -46,6 +46,9 @@ struct b32_ctx {
     uint32_t *keys[2] = { nullptr, nullptr }, *vals[2] = { nullptr, nullptr };
     SurfRec* recs = nullptr; float* shades = nullptr; size_t cap_shades = 0;
     uint32_t* counts = nullptr; uint32_t* block_sums = nullptr; uint32_t bin_blocks = 0;
+    uint32_t* spans = nullptr;
+    bool local_sort_ok = true;          // no tile list of this scene has exceeded the LDS sort capacity so far
+    bool last_local_sort = false;       // the last frame took the fast path (draw order not materialised)
     // pairs
     size_t cap_pairs = 0;
     uint32_t *pkeys[2] = { nullptr, nullptr }, *pvals[2] = { nullptr, nullptr };
@@ -137,7 +140,7 @@ void b32_destroy(b32_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = { c->fb_own, c->d_verts, c->d_faces, c->d_texels, c->d_tex, c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->recs,
                      c->shades, c->counts, c->block_sums, c->pkeys[0], c->pkeys[1], c->pvals[0], c->pvals[1], c->block_hist, c->ranges,
-                     c->d_ctrl, c->d_consts, c->d_lights, c->digit_total, c->partials, c->vis };
+                     c->d_ctrl, c->d_consts, c->d_lights, c->digit_total, c->partials, c->vis, c->spans };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->ev_created) for (auto& fr : c->ev) for (auto& e : fr) if (e) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -242,6 +245,7 @@ static int upload_geometry(b32_ctx* c, const B32Vertex* v, uint32_t nv, const B3
     if (nv) HIPCHK(c, hipMemcpyAsync(c->d_verts, v, (size_t)nv * sizeof(B32Vertex), hipMemcpyHostToDevice, c->stream));
     if (nf) HIPCHK(c, hipMemcpyAsync(c->d_faces, f, (size_t)nf * sizeof(B32Face), hipMemcpyHostToDevice, c->stream));
     c->nv = nv; c->nf = nf;
+    c->local_sort_ok = true;
     // per-face work buffers
     if ((size_t)nf + 1 > c->cap_work || !c->recs) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -249,6 +253,7 @@ static int upload_geometry(b32_ctx* c, const B32Vertex* v, uint32_t nv, const B3
         for (int i = 0; i < 2; ++i) { if ((rc = ensure_plain(c, c->keys[i], n))) return rc; if ((rc = ensure_plain(c, c->vals[i], n))) return rc; }
         if ((rc = ensure_plain(c, c->recs, n))) return rc;
         if ((rc = ensure_plain(c, c->counts, n))) return rc;
+        if ((rc = ensure_plain(c, c->spans, n))) return rc;
         c->bin_blocks = (uint32_t)((n + 4095) / 4096);
         c->partial_blocks = (uint32_t)((n + 255) / 256);
         if ((rc = ensure_plain(c, c->partials, (size_t)c->partial_blocks * 8 + 8))) return rc;
@@ -427,22 +432,29 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
 
     if (c->nf == 0) HIPCHK(c, hipMemsetAsync(c->d_ctrl, 0, sizeof(Ctrl), s));    // otherwise k_setup resets it
     if (prof_all) HIPCHK(c, hipEventRecord(ev[0], s));
-    launch_setup(s, fp, c->d_verts, c->d_faces, c->d_tex, c->d_lights, c->recs, c->shades, c->keys[0], c->partials, c->d_ctrl);
+    launch_setup(s, fp, c->d_verts, c->d_faces, c->d_tex, c->d_lights, c->recs, c->shades, c->keys[0], c->spans, c->partials, c->d_ctrl);
     if (prof_all) HIPCHK(c, hipEventRecord(ev[1], s));
 
-    // painter's order: 4 stable passes over the 32-bit key; pass 1 also compacts away culled faces and its scan kernel
-    // reduces k_setup's counters into Ctrl (n_visible feeds the later passes).
     const SortScratch sc{ c->block_hist, c->hist_blocks, c->digit_total };
-    RadixExtra ex1; ex1.post_ctrl = c->d_ctrl; ex1.partials = c->partials; ex1.npart = (c->nf + 255) / 256;
-    launch_radix_pass(s, c->keys[0], nullptr, c->keys[1], c->vals[1], c->d_consts, c->nf, 0, 8, sc, ex1);
-    launch_radix_pass(s, c->keys[1], c->vals[1], c->keys[0], c->vals[0], &c->d_ctrl->n_visible, c->nf, 8, 8, sc);
-    launch_radix_pass(s, c->keys[0], c->vals[0], c->keys[1], c->vals[1], &c->d_ctrl->n_visible, c->nf, 16, 8, sc);
-    launch_radix_pass(s, c->keys[1], c->vals[1], c->keys[0], c->vals[0], &c->d_ctrl->n_visible, c->nf, 24, 8, sc);
-    uint32_t* const order = c->vals[0];
-    if (prof_all) HIPCHK(c, hipEventRecord(ev[2], s));
-
-    // binning
-    launch_bin(s, fp, c->recs, order, c->d_ctrl, c->counts, c->block_sums, c->bin_blocks, c->pkeys[0], c->pvals[0], (uint32_t)c->cap_pairs);
+    const bool exact_cov = c->count_fragments || !c->cheap_ok;
+    const bool local_sort = !exact_cov && c->local_sort_ok;
+    c->last_local_sort = local_sort;
+    if (local_sort) {
+        // fast path: no global depth sort.  Pairs are emitted in face order from k_setup's spans; k_cover sorts every tile
+        // list by depth key in LDS (stable, so ties keep face order).
+        if (prof_all) HIPCHK(c, hipEventRecord(ev[2], s));
+        launch_bin_faces(s, fp, c->spans, c->keys[0], c->partials, c->d_ctrl, c->pkeys[0], c->pvals[0], (uint32_t)c->cap_pairs);
+    } else {
+        // painter's order: 4 stable passes over the 32-bit key; pass 1 also compacts away culled faces and its scan kernel
+        // reduces k_setup's counters into Ctrl (n_visible feeds the later passes).
+        RadixExtra ex1; ex1.post_ctrl = c->d_ctrl; ex1.partials = c->partials; ex1.npart = (c->nf + 255) / 256;
+        launch_radix_pass(s, c->keys[0], nullptr, c->keys[1], c->vals[1], c->d_consts, c->nf, 0, 8, sc, ex1);
+        launch_radix_pass(s, c->keys[1], c->vals[1], c->keys[0], c->vals[0], &c->d_ctrl->n_visible, c->nf, 8, 8, sc);
+        launch_radix_pass(s, c->keys[0], c->vals[0], c->keys[1], c->vals[1], &c->d_ctrl->n_visible, c->nf, 16, 8, sc);
+        launch_radix_pass(s, c->keys[1], c->vals[1], c->keys[0], c->vals[0], &c->d_ctrl->n_visible, c->nf, 24, 8, sc);
+        if (prof_all) HIPCHK(c, hipEventRecord(ev[2], s));
+        launch_bin(s, fp, c->recs, c->vals[0], c->d_ctrl, c->counts, c->block_sums, c->bin_blocks, c->pkeys[0], c->pvals[0], (uint32_t)c->cap_pairs);
+    }
     const uint32_t kb = bits_for(n_keys ? n_keys : 1);
     int cur = 0;
     if (kb <= 8 || kb > 12) {
@@ -461,6 +473,7 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
 
     FillArgs fa{};
     fa.fp = fp; fa.recs = c->recs; fa.shades = c->shades; fa.pair_vals = c->pvals[cur]; fa.ranges = c->ranges;
+    fa.keys = c->keys[0]; fa.local_sort = local_sort ? 1u : 0u;
     fa.tex = c->d_tex; fa.texels = c->d_texels; fa.fb = c->fb; fa.vis = c->vis; fa.ctrl = c->d_ctrl;
     fa.tex0 = c->nt ? c->h_tex[0] : TexDesc{ 0, 0, 0, 0 };
     fa.lds_tex_texels = 0;
@@ -468,7 +481,7 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
         const size_t n = (size_t)c->h_tex[0].width * c->h_tex[0].height;
         if (n > 0 && n * 2 <= fill_lds_tex_budget()) fa.lds_tex_texels = (uint32_t)n;
     }
-    fa.exact_coverage = (c->count_fragments || !c->cheap_ok) ? 1u : 0u;
+    fa.exact_coverage = exact_cov ? 1u : 0u;
     if (!fa.exact_coverage) fa.lds_tex_texels = 0;      // CHEAP coverage: one texel fetch per output pixel, served by L1/L2
     fa.may_blend = c->may_blend ? 1u : 0u;
     launch_fill(s, fa, c->n_cu);
@@ -515,9 +528,18 @@ int b32_frame_finish(b32_ctx* c, B32Timings* out) {
     (void)hipSetDevice(c->device);
     if (out) memset(out, 0, sizeof(*out));
     if (!c->frame_pending) { HIPCHK(c, hipStreamSynchronize(c->stream)); return B32_OK; }
-    for (int attempt = 0; attempt < 4; ++attempt) {
+    for (int attempt = 0; attempt < 5; ++attempt) {
         HIPCHK(c, hipMemcpyAsync(&c->h_ctrl, c->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->h_ctrl.need_global_sort && c->local_sort_ok) {
+            // a tile list was longer than the LDS sort handles: nothing was drawn; redraw this frame (and the following ones of
+            // this scene) with the global depth sort
+            c->local_sort_ok = false;
+            c->ev_frames = 0;
+            int rc;
+            if ((rc = enqueue_frame(c, &c->last_cam, &c->last_settings, c->last_has_fog ? &c->last_fog : nullptr))) return rc;
+            continue;
+        }
         if (!c->h_ctrl.pairs_overflow) break;
         // the fill aborted before touching the framebuffer: grow the pair buffers and redraw the same frame
         const size_t n = (size_t)c->h_ctrl.pairs_overflow + c->h_ctrl.pairs_overflow / 4 + 1024;
@@ -590,6 +612,15 @@ int b32_last_draw_order(b32_ctx* c, uint32_t* face_idx, uint32_t cap, uint32_t* 
     (void)hipSetDevice(c->device);
     const uint32_t cnt = c->h_ctrl.n_visible;
     *n = cnt;
+    if (c->last_local_sort && cnt) {     // the fast path never builds the global order: sort k_setup's keys now (tap only)
+        const SortScratch sc{ c->block_hist, c->hist_blocks, c->digit_total };
+        hipStream_t s = c->stream;
+        launch_radix_pass(s, c->keys[0], nullptr, c->keys[1], c->vals[1], c->d_consts, c->nf, 0, 8, sc);
+        launch_radix_pass(s, c->keys[1], c->vals[1], c->keys[0], c->vals[0], &c->d_ctrl->n_visible, c->nf, 8, 8, sc);
+        launch_radix_pass(s, c->keys[0], c->vals[0], c->keys[1], c->vals[1], &c->d_ctrl->n_visible, c->nf, 16, 8, sc);
+        launch_radix_pass(s, c->keys[1], c->vals[1], c->keys[0], c->vals[0], &c->d_ctrl->n_visible, c->nf, 24, 8, sc);
+        c->last_local_sort = false;
+    }
     const uint32_t m = cnt < cap ? cnt : cap;
     if (m && face_idx) {
         HIPCHK(c, hipMemcpyAsync(face_idx, c->vals[0], (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));

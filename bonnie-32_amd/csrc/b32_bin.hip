@@ -9,15 +9,6 @@
 
 namespace b32 {
 
-__device__ __forceinline__ bool tile_span(const SurfRec& r, const FrameParams& fp, uint32_t& tx0, uint32_t& tx1, uint32_t& ty0, uint32_t& ty1) {
-    if (r.flags & F_EMPTY) return false;
-    uint32_t min_x = r.bbx & 0xFFFF, max_x = r.bbx >> 16, min_y = r.bby & 0xFFFF, max_y = r.bby >> 16;
-    min_y = max(min_y, fp.band_y0); max_y = min(max_y, fp.band_y1);     // rows outside this GPU's band belong to another rank
-    if (min_x >= max_x || min_y >= max_y) return false;
-    tx0 = min_x / TILE_W; tx1 = (max_x - 1) / TILE_W;
-    ty0 = min_y / TILE_H - fp.tile_y0; ty1 = (max_y - 1) / TILE_H - fp.tile_y0;      // band-relative tile rows (fit 8 bits: <= 16384 px)
-    return true;
-}
 
 constexpr int BIN_THREADS = 256;
 constexpr int BIN_ITEMS = 16;
@@ -37,10 +28,8 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_count(FrameParams fp, const
             const uint32_t r = base + i * BIN_THREADS + threadIdx.x;
             if (r < n) {
                 const SurfRec& rec = recs[order[r]];
-                SurfRec q; q.bbx = rec.bbx; q.bby = rec.bby; q.flags = rec.flags;
-                uint32_t tx0 = 1, tx1 = 0, ty0 = 1, ty1 = 0, c = 0;
-                if (tile_span(q, fp, tx0, tx1, ty0, ty1)) c = (tx1 - tx0 + 1) * (ty1 - ty0 + 1);
-                counts[r] = c ? (tx0 | (tx1 << 8) | (ty0 << 16) | (ty1 << 24)) : 0xFFFFFFFFu;   // packed tile span (<= 256 tiles per axis)
+                uint32_t c = 0;
+                counts[r] = pack_tile_span(rec.bbx, rec.bby, rec.flags, fp, c);
                 local += c;
             }
         }
@@ -117,6 +106,80 @@ void launch_bin(hipStream_t s, const FrameParams& fp, const SurfRec* recs, const
     const uint32_t nblocks = min((fp.nf + BIN_TILE - 1) / BIN_TILE, max_blocks);
     hipLaunchKernelGGL(k_bin_count, dim3(nblocks), dim3(BIN_THREADS), 0, s, fp, recs, order, ctrl, counts, block_sums);
     hipLaunchKernelGGL(k_bin_emit, dim3(nblocks), dim3(BIN_THREADS), 0, s, fp, recs, order, ctrl, counts, block_sums, nblocks, pair_cap, pair_keys, pair_vals);
+}
+
+// ---- fast path ----------------------------------------------------------------------------------------------------
+// k_bin_emit_faces: one block per 4096 faces, pairs in FACE order from k_setup's packed spans (no record gather, no depth
+// sort needed first: k_cover sorts every tile list by depth key in LDS).  The prologue of every block derives its base
+// from k_setup's per-256-face pair counts; block 0 also reduces the frame counters into Ctrl.
+__global__ __launch_bounds__(BIN_THREADS) void k_bin_emit_faces(FrameParams fp, const uint32_t* __restrict__ spans, const uint32_t* __restrict__ keys,
+                                                                 const uint32_t* __restrict__ partials, uint32_t npart, Ctrl* __restrict__ ctrl,
+                                                                 uint32_t pair_cap, uint32_t* __restrict__ pair_keys, uint32_t* __restrict__ pair_vals) {
+    __shared__ uint32_t wtot[BIN_THREADS / 64];
+    __shared__ uint32_t red[BIN_THREADS / 64][8];
+    __shared__ uint32_t step_base, total_s;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t first_part = blockIdx.x * (BIN_TILE / 256);            // partial records (256 faces each) before this block
+    {
+        uint32_t acc[7] = { 0, 0, 0, 0, 0, 0, 0 };                         // 0..4 frame counters, 5 all pairs, 6 pairs before this block
+        for (uint32_t i = threadIdx.x; i < npart; i += BIN_THREADS) {
+            const uint32_t pc = partials[i * 8 + 5];
+            acc[5] += pc;
+            if (i < first_part) acc[6] += pc;
+            if (blockIdx.x == 0) for (int k = 0; k < 5; ++k) acc[k] += partials[i * 8 + k];
+        }
+        for (int k = 0; k < 7; ++k) for (int off = 32; off > 0; off >>= 1) acc[k] += __shfl_down(acc[k], off);
+        if (lane == 0) for (int k = 0; k < 7; ++k) red[wave][k] = acc[k];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t t[7];
+            for (int k = 0; k < 7; ++k) t[k] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+            step_base = t[6]; total_s = t[5];
+            if (blockIdx.x == 0) {     // frame counters (the reference panics before drawing on a bad index / NaN sort key)
+                const uint32_t n_op = t[0] - t[1];
+                ctrl->n_visible = t[0]; ctrl->n_transparent = t[1]; ctrl->nan_opaque = t[2]; ctrl->nan_transparent = t[3];
+                ctrl->err_index = t[4] ? 1u : 0u; ctrl->n_opaque = n_op;
+                if (t[4] || (t[2] && n_op >= 2) || (t[3] && t[1] >= 2)) ctrl->abort = 1;
+                if (t[5] > pair_cap) { ctrl->pairs_overflow = t[5]; ctrl->abort = 1; ctrl->n_pairs = 0; }
+                else ctrl->n_pairs = t[5];
+            }
+        }
+        __syncthreads();
+    }
+    if (total_s > pair_cap) return;
+    const uint32_t base = blockIdx.x * BIN_TILE;
+    for (int i = 0; i < BIN_ITEMS; ++i) {
+        const uint32_t f = base + i * BIN_THREADS + threadIdx.x;
+        const uint32_t span = f < fp.nf ? spans[f] : 0xFFFFFFFFu;
+        const uint32_t tx0 = span & 0xFF, tx1 = (span >> 8) & 0xFF, ty0 = (span >> 16) & 0xFF, ty1 = span >> 24;
+        const uint32_t c = span == 0xFFFFFFFFu ? 0u : (tx1 - tx0 + 1) * (ty1 - ty0 + 1);
+        uint32_t inc = c;
+        for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(inc, off); if (lane >= (uint32_t)off) inc += t; }
+        if (lane == 63) wtot[wave] = inc;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (uint32_t w = 0; w < wave; ++w) woff += wtot[w];
+        uint32_t pos = step_base + woff + inc - c;
+        if (c) {
+            const uint32_t cls = keys[f] >> 31;                                    // transparent pass, render.rs:2522-2523
+            for (uint32_t ty = ty0; ty <= ty1; ++ty)
+                for (uint32_t tx = tx0; tx <= tx1; ++tx) {
+                    pair_keys[pos] = ((ty * fp.tiles_x + tx) << 1) | cls;
+                    pair_vals[pos] = f;
+                    ++pos;
+                }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) step_base += wtot[0] + wtot[1] + wtot[2] + wtot[3];
+        __syncthreads();
+    }
+}
+void launch_bin_faces(hipStream_t s, const FrameParams& fp, const uint32_t* spans, const uint32_t* keys, const uint32_t* partials,
+                      Ctrl* ctrl, uint32_t* pair_keys, uint32_t* pair_vals, uint32_t pair_cap) {
+    if (fp.nf == 0) return;
+    const uint32_t nblocks = (fp.nf + BIN_TILE - 1) / BIN_TILE;
+    hipLaunchKernelGGL(k_bin_emit_faces, dim3(nblocks), dim3(BIN_THREADS), 0, s, fp, spans, keys, partials, (fp.nf + 255) / 256, ctrl, pair_cap,
+                       pair_keys, pair_vals);
 }
 
 // ranges[k] = first pair index whose key >= k, for k in 0..n_keys (n_keys = 2*ntiles); ranges[n_keys] = n_pairs.

@@ -58,9 +58,11 @@ struct Ctrl {
     uint32_t pairs_overflow;
     uint32_t tile_cursor;      // persistent-workgroup tile dispenser of k_fill
     uint32_t nf;               // copy of the face count (first sort pass length)
-    uint32_t pad;
+    uint32_t need_global_sort; // a tile list exceeded the LDS sort capacity: redraw with the global depth sort
     unsigned long long fragments;
 };
+
+constexpr uint32_t LOCAL_SORT_CAP = 2048;   // longest tile list the per-tile LDS radix sort handles
 
 // Everything k_setup / k_fill need about the frame, passed by value.
 struct FrameParams {
@@ -141,6 +143,20 @@ __device__ __forceinline__ uint32_t blend_rgb555(uint32_t front, uint32_t back, 
     return out;
 }
 
+// Tile span of a surface's (band-clipped) bounding box, packed tx0 | tx1<<8 | ty0<<16 | ty1<<24 with band-relative tile rows
+// (<= 256 tiles per axis: 16384 px); 0xFFFFFFFF = touches no tile of this band.
+__device__ __forceinline__ uint32_t pack_tile_span(uint32_t bbx, uint32_t bby, uint32_t flags, const FrameParams& fp, uint32_t& count) {
+    count = 0;
+    if (flags & F_EMPTY) return 0xFFFFFFFFu;
+    const uint32_t min_x = bbx & 0xFFFF, max_x = bbx >> 16;
+    const uint32_t min_y = max(bby & 0xFFFF, fp.band_y0), max_y = min(bby >> 16, fp.band_y1);   // other rows belong to another rank
+    if (min_x >= max_x || min_y >= max_y) return 0xFFFFFFFFu;
+    const uint32_t tx0 = min_x / TILE_W, tx1 = (max_x - 1) / TILE_W;
+    const uint32_t ty0 = min_y / TILE_H - fp.tile_y0, ty1 = (max_y - 1) / TILE_H - fp.tile_y0;
+    count = (tx1 - tx0 + 1) * (ty1 - ty0 + 1);
+    return tx0 | (tx1 << 8) | (ty0 << 16) | (ty1 << 24);
+}
+
 // ---------------------------------------------------------------- kernel launchers (defined in the .hip files)
 struct SortScratch {
     uint32_t* block_hist;   // [4096][max_blocks] digit-major (rows used: 2^bits)
@@ -164,7 +180,7 @@ void launch_radix_pass(hipStream_t s, const uint32_t* keys_in, const uint32_t* v
 // `partials[block*8 + k]`; k_after_setup reduces them into Ctrl.  (One same-address atomic per wave costs ~12 ns each and
 // serialises: 15.6 k waves = the whole kernel time at 1 M faces.)
 void launch_setup(hipStream_t s, const FrameParams& fp, const B32Vertex* verts, const B32Face* faces, const TexDesc* tex,
-                  const B32Light* lights, SurfRec* recs, float* shades, uint32_t* keys, uint32_t* partials, Ctrl* ctrl);
+                  const B32Light* lights, SurfRec* recs, float* shades, uint32_t* keys, uint32_t* spans, uint32_t* partials, Ctrl* ctrl);
 void launch_project_fixed(hipStream_t s, const float* pos, uint32_t n, B32Camera cam, uint32_t w, uint32_t h,
                           int32_t* sx, int32_t* sy, float* z);
 void launch_selftest(hipStream_t s, int op, const float* a, const float* b, const float* c, float* out, uint32_t n);
@@ -173,13 +189,18 @@ void launch_expand_indexed(hipStream_t s, const uint8_t* idx, uint32_t n, const 
 
 void launch_bin(hipStream_t s, const FrameParams& fp, const SurfRec* recs, const uint32_t* order, Ctrl* ctrl,
                 uint32_t* counts, uint32_t* block_sums, uint32_t max_blocks, uint32_t* pair_keys, uint32_t* pair_vals, uint32_t pair_cap);
+// Fast path: pairs straight from k_setup's per-face spans, in face order (the per-tile LDS sort of k_cover orders them).
+void launch_bin_faces(hipStream_t s, const FrameParams& fp, const uint32_t* spans, const uint32_t* keys, const uint32_t* partials,
+                      Ctrl* ctrl, uint32_t* pair_keys, uint32_t* pair_vals, uint32_t pair_cap);
 void launch_tile_ranges(hipStream_t s, const uint32_t* pair_keys, const Ctrl* ctrl, uint32_t pair_cap, uint32_t* ranges, uint32_t n_keys);
 
 struct FillArgs {
     FrameParams fp;
     const SurfRec* recs;
     const float* shades;        // [sid][9] or nullptr
-    const uint32_t* pair_vals;  // surface ids, grouped by (tile,class), rank order inside a group
+    uint32_t* pair_vals;        // surface ids, grouped by (tile,class); painter's order inside a group (after the tile-local sort)
+    const uint32_t* keys;       // face-order radix keys of k_setup (tile-local sort)
+    uint32_t local_sort;        // 1: lists arrive in face order and k_cover sorts each one in LDS
     const uint32_t* ranges;     // [2*ntiles + 1]
     const TexDesc* tex;
     const uint16_t* texels;

@@ -32,6 +32,8 @@ constexpr int LDS_TILE_BYTES = TILE_H * TILE_STRIDE * 4;        // 18432
 constexpr int LDS_MISC_BYTES = 64;
 constexpr int LDS_MARK_BYTES = FILL_WAVES * 64 * 4;             // row-start marks of the row-item scheduler
 constexpr int LDS_TEX_OFFSET = 2 * LDS_TILE_BYTES + LDS_MISC_BYTES + LDS_MARK_BYTES;   // 41024: top + runner-up tile buffers
+constexpr int LDS_SORT_CNT_BYTES = 8 * 256 * 4;                 // per-wave digit counters of the tile-local sort (8 waves)
+static_assert(4 * LOCAL_SORT_CAP * 4 <= 2 * LDS_TILE_BYTES, "the tile-local sort aliases the two tile buffers");
 
 __device__ __forceinline__ float bcf(float v, int t) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), t)); }
 __device__ __forceinline__ uint32_t bcu(uint32_t v, int t) { return (uint32_t)__builtin_amdgcn_readlane((int)v, t); }
@@ -413,6 +415,80 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
 }
 
 
+// ------------------------------------------------------------------------------------------------ tile-local depth sort
+// Stable LSD radix sort (4 x 8 bits) of one tile list (n <= LOCAL_SORT_CAP surface ids, keyed by k_setup's 32-bit painter's
+// key) entirely in LDS, by the NT threads of the workgroup; the sorted ids go back to the list in global memory.  This is the
+// reference's `sort_by` (render.rs:2527-2541) applied per tile: lists arrive in face order and every pass is stable, so equal
+// keys keep face order exactly like the global sort.  The four LDS arrays alias the (not yet used) tile buffers.
+template <int NT>
+__device__ void tile_local_sort(uint32_t* sort_area, uint32_t* wcnt, volatile uint32_t* dws, const uint32_t* __restrict__ keys,
+                                uint32_t* list, uint32_t n) {
+    constexpr int NW = NT / 64;
+    constexpr int STEPS = LOCAL_SORT_CAP / (NW * 64);
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t *ki = sort_area, *vi = sort_area + LOCAL_SORT_CAP, *ko = sort_area + 2 * LOCAL_SORT_CAP, *vo = sort_area + 3 * LOCAL_SORT_CAP;
+    for (uint32_t i = tid; i < n; i += NT) { const uint32_t sid = list[i]; ki[i] = keys[sid]; vi[i] = sid; }
+    __syncthreads();
+    const uint32_t per_wave = ((n + NW * 64 - 1) / (NW * 64)) * 64;      // contiguous run per wave: order = (wave, step, lane)
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = pass * 8;
+        for (uint32_t d = tid; d < NW * 256; d += NT) wcnt[d] = 0;
+        __syncthreads();
+        uint32_t key[STEPS], val[STEPS], rnk[STEPS];
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st) {
+            const uint32_t idx = wave * per_wave + st * 64 + lane;
+            const bool live = (uint32_t)(st * 64) < per_wave && idx < n;
+            const uint32_t k = live ? ki[idx] : 0u;
+            key[st] = k; val[st] = live ? vi[idx] : 0u;
+            const uint32_t d = (k >> shift) & 255u;
+            unsigned long long peers = __ballot(live);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const unsigned long long m = __ballot((d >> b) & 1u);
+                peers &= ((d >> b) & 1u) ? m : ~m;
+            }
+            uint32_t before = 0;
+            if (live) {
+                const uint32_t leader = (uint32_t)__builtin_ctzll(peers);
+                uint32_t old = 0;
+                if (lane == leader) { old = wcnt[wave * 256 + d]; wcnt[wave * 256 + d] = old + (uint32_t)__popcll(peers); }
+                old = __shfl(old, (int)leader);
+                before = old + (uint32_t)__popcll(peers & lt_mask);
+            }
+            rnk[st] = live ? before : 0xFFFFFFFFu;
+        }
+        __syncthreads();
+        if (tid < 256) {      // digit tid: total over waves, exclusive scan over digits, then per-wave bases
+            uint32_t tot = 0;
+            for (int w = 0; w < NW; ++w) tot += wcnt[w * 256 + tid];
+            uint32_t inc = tot;
+            for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(inc, off); if (lane >= (uint32_t)off) inc += t; }
+            if (lane == 63) dws[wave] = inc;
+            wcnt[NW * 256 + tid] = inc - tot;     // in-wave exclusive prefix; the cross-wave part follows the barrier
+        }
+        __syncthreads();
+        if (tid < 256) {
+            uint32_t run = wcnt[NW * 256 + tid];
+            for (uint32_t w = 0; w < wave; ++w) run += dws[w];
+            for (int w = 0; w < NW; ++w) { const uint32_t c = wcnt[w * 256 + tid]; wcnt[w * 256 + tid] = run; run += c; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st) {
+            if (rnk[st] != 0xFFFFFFFFu) {
+                const uint32_t pos = wcnt[wave * 256 + ((key[st] >> shift) & 255u)] + rnk[st];
+                ko[pos] = key[st]; vo[pos] = val[st];
+            }
+        }
+        __syncthreads();
+        uint32_t* t = ki; ki = ko; ko = t; t = vi; vi = vo; vo = t;
+    }
+    for (uint32_t i = tid; i < n; i += NT) list[i] = vi[i];
+    __syncthreads();
+}
+
 // ------------------------------------------------------------------------------------------------ k_cover
 template <int TEXMODE, bool EXACT, int NT>
 __global__ __launch_bounds__(NT) void k_cover(FillArgs a) {
@@ -422,6 +498,7 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a) {
     volatile uint32_t* misc = reinterpret_cast<volatile uint32_t*>(smem + 2 * LDS_TILE_BYTES);   // [0] tile, [2] list cursor
     uint32_t* wmarks = reinterpret_cast<uint32_t*>(smem + 2 * LDS_TILE_BYTES + LDS_MISC_BYTES);
     const uint16_t* ltex = reinterpret_cast<const uint16_t*>(smem + LDS_TEX_OFFSET);
+    uint32_t* sort_cnt = reinterpret_cast<uint32_t*>(smem + LDS_TEX_OFFSET);        // local sort only exists without an LDS texture
 
     if (a.ctrl->abort) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63;
@@ -442,12 +519,23 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a) {
     if (tid == 0) next_tile = atomicAdd(&a.ctrl->tile_cursor, 1u);
     for (;;) {
         if (tid == 0) { misc[0] = next_tile; misc[2] = 0; }
-        for (uint32_t i = tid; i < (EXACT ? 1 : 2) * TILE_H * TILE_STRIDE; i += NT) tilebuf[i] = 0;
         __syncthreads();
         const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)misc[0]);
         if (tile >= ntiles) break;
         if (tid == 0) next_tile = atomicAdd(&a.ctrl->tile_cursor, 1u);    // prefetch the next tile index; consumed at the loop top
         const uint32_t e0 = a.ranges[2 * tile], e1 = a.ranges[2 * tile + 1];
+        if (TEXMODE == 0 && a.local_sort) {      // lists arrive in face order: painter's order per tile, in LDS
+            const uint32_t e2 = a.ranges[2 * tile + 2];
+            if (e1 - e0 > LOCAL_SORT_CAP || e2 - e1 > LOCAL_SORT_CAP) {
+                if (tid == 0) atomicOr(&a.ctrl->need_global_sort, 1u);               // host redraws with the global depth sort
+                __syncthreads();
+                continue;
+            }
+            if (e1 - e0 > 1) tile_local_sort<NT>(tilebuf, sort_cnt, misc + 8, a.keys, a.pair_vals + e0, e1 - e0);
+            if (e2 - e1 > 1) tile_local_sort<NT>(tilebuf, sort_cnt, misc + 8, a.keys, a.pair_vals + e1, e2 - e1);
+        }
+        for (uint32_t i = tid; i < (EXACT ? 1 : 2) * TILE_H * TILE_STRIDE; i += NT) tilebuf[i] = 0;
+        __syncthreads();
         const uint32_t txi = tile % fp.tiles_x, tyi = tile / fp.tiles_x + fp.tile_y0;
         const uint32_t x_lo = txi * TILE_W, x_hi = min(x_lo + TILE_W, fp.width);
         const uint32_t ty_top = tyi * TILE_H;
@@ -528,7 +616,7 @@ __device__ __forceinline__ uint32_t colour(const FillArgs& a, const Hit& h, int 
 // grid = (ceil(W/256), band height); block = 256 threads = 4 waves = 4 consecutive 64-pixel row segments (a segment never
 // straddles a tile).
 __global__ __launch_bounds__(256) void k_shade(FillArgs a) {
-    if (a.ctrl->abort) return;
+    if (a.ctrl->abort || a.ctrl->need_global_sort) return;
     const FrameParams& fp = a.fp;
     const uint32_t lane = threadIdx.x & 63;
     const int shading = fp.shading;
@@ -590,7 +678,7 @@ __global__ __launch_bounds__(NT) void k_blend(FillArgs a) {
     constexpr int NW = NT / 64;
     __shared__ uint32_t tilebuf[TILE_H * TILE_STRIDE];
     __shared__ unsigned long long wf[NW];
-    if (a.ctrl->abort) return;
+    if (a.ctrl->abort || a.ctrl->need_global_sort) return;
     const FrameParams& fp = a.fp;
     const uint32_t tile = blockIdx.x;
     const uint32_t e1 = a.ranges[2 * tile + 1], e2 = a.ranges[2 * tile + 2];
@@ -695,7 +783,7 @@ void launch_fill(hipStream_t s, const FillArgs& a, int n_cu) {
             hipLaunchKernelGGL((k_cover<0, true, 512>), dim3(min(ntiles, (uint32_t)n_cu * 2)), dim3(512), LDS_TEX_OFFSET, s, a);
         }
     } else {
-        hipLaunchKernelGGL((k_cover<0, false, 512>), dim3(min(ntiles, (uint32_t)n_cu * 4)), dim3(512), LDS_TEX_OFFSET, s, a);
+        hipLaunchKernelGGL((k_cover<0, false, 512>), dim3(min(ntiles, (uint32_t)n_cu * 3)), dim3(512), LDS_TEX_OFFSET + LDS_SORT_CNT_BYTES + 2048, s, a);
     }
     const uint32_t band_h = a.fp.band_y1 - a.fp.band_y0;
     if (band_h) hipLaunchKernelGGL(k_shade, dim3((a.fp.width + 255) / 256, band_h), dim3(256), 0, s, a);

@@ -137,12 +137,12 @@ __device__ __forceinline__ uint32_t fog_color(uint32_t c, uint32_t fogc, float f
 __global__ __launch_bounds__(256) void k_setup(FrameParams fp, const B32Vertex* __restrict__ verts, const B32Face* __restrict__ faces,
                                                const TexDesc* __restrict__ tex, const B32Light* __restrict__ lights,
                                                SurfRec* __restrict__ recs, float* __restrict__ shades, uint32_t* __restrict__ keys,
-                                               uint32_t* __restrict__ partials, Ctrl* __restrict__ ctrl) {
-    __shared__ uint32_t wpart[4][5];
+                                               uint32_t* __restrict__ spans, uint32_t* __restrict__ partials, Ctrl* __restrict__ ctrl) {
+    __shared__ uint32_t wpart[4][6];
     if (blockIdx.x == 0 && threadIdx.x < sizeof(Ctrl) / 4) reinterpret_cast<uint32_t*>(ctrl)[threadIdx.x] = 0;   // frame-start reset (no memset launch)
     const uint32_t f = blockIdx.x * 256u + threadIdx.x;
     bool visible = false, transparent = false, nan_key = false, bad_index = false;
-    uint32_t key = KEY_INVALID;
+    uint32_t key = KEY_INVALID, span = 0xFFFFFFFFu, n_tiles = 0;
     if (f < fp.nf) {
         const uint32_t* fw = reinterpret_cast<const uint32_t*>(faces) + (size_t)f * 5;
         uint32_t vi[3] = { fw[0], fw[1], fw[2] };
@@ -247,6 +247,7 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp, const B32Vertex* 
                           (needs_dither ? F_DITHER : 0) | (slow ? F_SLOW : 0) | (transparent ? F_TRANSP : 0) |
                           (empty ? F_EMPTY : 0) | (editor_alpha << F_ALPHA_SHIFT);
                 recs[f] = r;
+                span = pack_tile_span(r.bbx, r.bby, r.flags, fp, n_tiles);
                 if (fp.shading != B32_SHADE_NONE) {
                     V3 wn[3];
 #pragma unroll
@@ -279,6 +280,7 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp, const B32Vertex* 
             }
         }
         keys[f] = key;
+        spans[f] = span;
     }
     // frame counters: ballot per wave -> LDS -> one 5-word record per block (reduced by k_after_setup; no atomics)
     const unsigned long long mv = __ballot(visible), mt = __ballot(transparent);
@@ -288,14 +290,16 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp, const B32Vertex* 
         wpart[wv][0] = (uint32_t)__popcll(mv); wpart[wv][1] = (uint32_t)__popcll(mt);
         wpart[wv][2] = (uint32_t)__popcll(mn_op); wpart[wv][3] = (uint32_t)__popcll(mn_tr); wpart[wv][4] = mb ? 1u : 0u;
     }
+    for (int off = 32; off > 0; off >>= 1) n_tiles += __shfl_down(n_tiles, off);      // (tile, surface) pairs of this block
+    if ((threadIdx.x & 63) == 0) wpart[wv][5] = n_tiles;
     __syncthreads();
-    if (threadIdx.x < 5) partials[blockIdx.x * 8 + threadIdx.x] = wpart[0][threadIdx.x] + wpart[1][threadIdx.x] + wpart[2][threadIdx.x] + wpart[3][threadIdx.x];
+    if (threadIdx.x < 6) partials[blockIdx.x * 8 + threadIdx.x] = wpart[0][threadIdx.x] + wpart[1][threadIdx.x] + wpart[2][threadIdx.x] + wpart[3][threadIdx.x];
 }
 
 void launch_setup(hipStream_t s, const FrameParams& fp, const B32Vertex* verts, const B32Face* faces, const TexDesc* tex,
-                  const B32Light* lights, SurfRec* recs, float* shades, uint32_t* keys, uint32_t* partials, Ctrl* ctrl) {
+                  const B32Light* lights, SurfRec* recs, float* shades, uint32_t* keys, uint32_t* spans, uint32_t* partials, Ctrl* ctrl) {
     if (fp.nf == 0) return;
-    hipLaunchKernelGGL(k_setup, dim3((fp.nf + 255) / 256), dim3(256), 0, s, fp, verts, faces, tex, lights, recs, shades, keys, partials, ctrl);
+    hipLaunchKernelGGL(k_setup, dim3((fp.nf + 255) / 256), dim3(256), 0, s, fp, verts, faces, tex, lights, recs, shades, keys, spans, partials, ctrl);
 }
 
 // ---------------------------------------------------------------- stage tap: project_fixed for n positions
