@@ -110,7 +110,7 @@ def main():
         torch.cuda.synchronize(dev)
     t1 = time.perf_counter()
     tm = rs.finish()
-    fill_ms = ctx.last_kernel_times().get("fill", None)
+    cover_ms = ctx.last_kernel_times().get("cover", None)     # HIP events around k_cover on the stream it runs on
     ctx.set_profiling(0)
 
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
@@ -133,25 +133,26 @@ def main():
     if rank == 0:
         mtri = NF / (ms_per_step * 1e-3) / 1e6
         mpix = fragments / (ms_per_step * 1e-3) / 1e6
-        # ALGORITHMIC bytes of the dominant kernel (k_fill), DESIGN.md §4: every output pixel read+written once (8 B),
-        # one 96-B surface record + 8-B (tile,surface) pair per binned surface, the texture once.
-        n_pairs_est = None
+        # ALGORITHMIC bytes.  Frame: SURVEY 8d B_alg.  Dominant kernel k_cover, per launch:
+        #   per (surface, tile) pair: 4 B surface id read + 4 B depth key gathered + 4 B sorted id written back
+        #                             + 64 B of the surface record (edge coefficients, bbox, flags)
+        #   per band pixel: 8 B visibility entry written
         tex_bytes = sum(t.width * t.height * 2 for t in sc.textures)
-        alg_frame = 36 * len(sc.vertices) + 20 * NF + 16 * tm.triangles_drawn + 8 * W * H + tex_bytes   # SURVEY §8d B_alg
+        alg_frame = 36 * len(sc.vertices) + 20 * NF + 16 * tm.triangles_drawn + 8 * W * H + tex_bytes   # SURVEY 8d B_alg
         roofline = None
-        if fill_ms:
-            alg_fill = 8 * W * (y1 - y0) + 96 * tm.triangles_drawn + tex_bytes
-            ach = alg_fill / (fill_ms * 1e-3) / 1e9
+        if cover_ms:
+            alg_cover = 76 * tm.tile_pairs + 8 * W * (y1 - y0)
+            ach = alg_cover / (cover_ms * 1e-3) / 1e9
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(tpath):
                 try:
-                    traffic = json.load(open(tpath)).get(f"{args.config}:k_fill")
+                    traffic = json.load(open(tpath)).get(f"{args.config}:k_cover")
                 except Exception:
                     traffic = None
-            roofline = {"kernel": "k_fill", "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            roofline = {"kernel": "k_cover", "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
-                        "kernel_ms": round(fill_ms, 4), "algorithmic_bytes": alg_fill,
+                        "kernel_ms": round(cover_ms, 4), "algorithmic_bytes": alg_cover, "units": {"tile_pairs": tm.tile_pairs, "pixels": W * (y1 - y0)},
                         "frame_algorithmic_bytes": alg_frame,
                         "frame_frac": round(alg_frame / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
         cpu = None

@@ -68,7 +68,7 @@ class B32Fog(C.Structure):
 class B32Timings(C.Structure):
     _fields_ = [("transform_ms", C.c_float), ("fog_ms", C.c_float), ("cull_ms", C.c_float), ("sort_ms", C.c_float),
                 ("draw_ms", C.c_float), ("wireframe_ms", C.c_float), ("triangles_drawn", C.c_uint32),
-                ("_pad", C.c_uint32), ("fragments", C.c_uint64)]
+                ("tile_pairs", C.c_uint32), ("fragments", C.c_uint64)]
 
 
 # Every symbol include/b32raster.h declares: (name, restype, argtypes)

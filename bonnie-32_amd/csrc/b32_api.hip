@@ -14,7 +14,7 @@ using namespace b32;
 
 namespace {
 constexpr int EV_RING = 64;     // frames of per-phase events kept between two b32_frame_finish calls
-constexpr int EV_PER_FRAME = 5; // start | setup | sort | bin | fill
+constexpr int EV_PER_FRAME = 6; // start | setup | sort | bin | cover | shade+blend
 }
 
 struct b32_ctx {
@@ -72,7 +72,7 @@ struct b32_ctx {
     hipEvent_t ev[EV_RING][EV_PER_FRAME] = {};
     bool ev_created = false;
     uint32_t ev_frames = 0;             // frames recorded since the last finish
-    float phase_ms[4] = { 0, 0, 0, 0 }; // averages of the last finished batch
+    float phase_ms[5] = { 0, 0, 0, 0, 0 }; // averages of the last finished batch: setup, sort, bin, cover, shade
     uint32_t phase_frames = 0;
     int phase_level = 0;                // profiling level those averages were taken at
     std::vector<B32Light> keep_lights;  // private copy of the last frame's lights (redraw after overflow)
@@ -484,8 +484,8 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     fa.exact_coverage = exact_cov ? 1u : 0u;
     if (!fa.exact_coverage) fa.lds_tex_texels = 0;      // CHEAP coverage: one texel fetch per output pixel, served by L1/L2
     fa.may_blend = c->may_blend ? 1u : 0u;
-    launch_fill(s, fa, c->n_cu);
-    if (prof_fill) { HIPCHK(c, hipEventRecord(ev[4], s)); c->ev_frames++; }
+    launch_fill(s, fa, c->n_cu, prof_fill ? ev[4] : nullptr);
+    if (prof_fill) { if (prof_all) HIPCHK(c, hipEventRecord(ev[5], s)); c->ev_frames++; }
     HIPCHK(c, hipGetLastError());
     return B32_OK;
 }
@@ -514,8 +514,9 @@ static void collect_events(b32_ctx* c) {
         float ms = 0;
         if (c->profile_level >= 2) {
             for (int p = 0; p < 3; ++p) if (hipEventElapsedTime(&ms, c->ev[i][p], c->ev[i][p + 1]) == hipSuccess) c->phase_ms[p] += ms;
+            if (hipEventElapsedTime(&ms, c->ev[i][4], c->ev[i][5]) == hipSuccess) c->phase_ms[4] += ms;
         }
-        if (hipEventElapsedTime(&ms, c->ev[i][3], c->ev[i][4]) == hipSuccess) c->phase_ms[3] += ms;
+        if (hipEventElapsedTime(&ms, c->ev[i][3], c->ev[i][4]) == hipSuccess) c->phase_ms[3] += ms;     // the coverage kernel alone
     }
     for (float& p : c->phase_ms) p /= (float)n;
     c->phase_frames = n;
@@ -557,11 +558,12 @@ int b32_frame_finish(b32_ctx* c, B32Timings* out) {
     if (out) {
         out->triangles_drawn = c->h_ctrl.n_visible;
         out->fragments = c->h_ctrl.fragments;
+        out->tile_pairs = c->h_ctrl.n_pairs;
         if (c->phase_frames && c->phase_level >= 2) {
             out->transform_ms = 0.0f;                 // fused into the per-face setup kernel
             out->cull_ms = c->phase_ms[0];
             out->sort_ms = c->phase_ms[1];
-            out->draw_ms = c->phase_ms[2] + c->phase_ms[3];
+            out->draw_ms = c->phase_ms[2] + c->phase_ms[3] + c->phase_ms[4];
         }
     }
     return B32_OK;
@@ -647,11 +649,11 @@ int b32_selftest_f32(b32_ctx* c, int op, const float* a, const float* b, const f
 
 int b32_last_kernel_times(b32_ctx* c, const char** names, float* ms, uint32_t cap) {
     if (!c || !names || !ms) return 0;
-    static const char* const kNames[4] = { "setup", "sort", "bin", "fill" };
+    static const char* const kNames[5] = { "setup", "sort", "bin", "cover", "shade" };
     if (!c->phase_frames) return 0;
     uint32_t k = 0;
-    for (int p = 0; p < 4 && k < cap; ++p) {
-        if (p < 3 && c->phase_level < 2) continue;
+    for (int p = 0; p < 5 && k < cap; ++p) {
+        if (p != 3 && c->phase_level < 2) continue;
         names[k] = kNames[p]; ms[k] = c->phase_ms[p]; ++k;
     }
     return (int)k;

@@ -212,7 +212,7 @@ struct FillArgs {
     uint32_t may_blend;         // 0: no face/texture can be in the transparent pass -> k_blend is not launched
     uint32_t exact_coverage;    // 1: phase A applies the full skip rule and counts fragment stores; 0: CHEAP coverage + repair
 };
-void launch_fill(hipStream_t s, const FillArgs& a, int n_cu);
+void launch_fill(hipStream_t s, const FillArgs& a, int n_cu, hipEvent_t after_cover = nullptr);   // k_cover [event] k_shade k_blend
 size_t fill_lds_tex_budget();   // bytes of LDS left for a staged texture
 
 }  // namespace b32

@@ -770,7 +770,7 @@ __global__ __launch_bounds__(NT) void k_blend(FillArgs a) {
     }
 }
 
-void launch_fill(hipStream_t s, const FillArgs& a, int n_cu) {
+void launch_fill(hipStream_t s, const FillArgs& a, int n_cu, hipEvent_t after_cover) {
     const uint32_t ntiles = a.fp.tiles_x * a.fp.tiles_y;
     if (ntiles == 0) return;
     if (a.exact_coverage) {
@@ -785,6 +785,7 @@ void launch_fill(hipStream_t s, const FillArgs& a, int n_cu) {
     } else {
         hipLaunchKernelGGL((k_cover<0, false, 512>), dim3(min(ntiles, (uint32_t)n_cu * 3)), dim3(512), LDS_TEX_OFFSET + LDS_SORT_CNT_BYTES + 2048, s, a);
     }
+    if (after_cover) (void)hipEventRecord(after_cover, s);
     const uint32_t band_h = a.fp.band_y1 - a.fp.band_y0;
     if (band_h) hipLaunchKernelGGL(k_shade, dim3((a.fp.width + 255) / 256, band_h), dim3(256), 0, s, a);
     if (a.may_blend) hipLaunchKernelGGL((k_blend<1024>), dim3(ntiles), dim3(1024), 0, s, a);

@@ -184,11 +184,12 @@ class RasterTimings:
     wireframe_ms: float = 0.0
     triangles_drawn: int = 0
     fragments: int = 0
+    tile_pairs: int = 0
 
     @staticmethod
     def from_c(t):
         return RasterTimings(t.transform_ms, t.fog_ms, t.cull_ms, t.sort_ms, t.draw_ms, t.wireframe_ms,
-                             int(t.triangles_drawn), int(t.fragments))
+                             int(t.triangles_drawn), int(t.fragments), int(t.tile_pairs))
 
 
 def make_vertices(n):

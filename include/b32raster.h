@@ -139,7 +139,7 @@ typedef struct B32Fog {
 typedef struct B32Timings {
     float    transform_ms, fog_ms, cull_ms, sort_ms, draw_ms, wireframe_ms;
     uint32_t triangles_drawn;    /* opaque.len()+transparent.len(), render.rs:2545 */
-    uint32_t _pad;
+    uint32_t tile_pairs;         /* (surface, 64x64 tile) pairs binned this frame (work unit of the coverage kernel) */
     uint64_t fragments;          /* pixel stores reached in rasterize_triangle_15 (render.rs:1671-1702) */
 } B32Timings;
 
@@ -217,7 +217,8 @@ int b32_selftest_f32(b32_ctx* ctx, int op, const float* a, const float* b, const
  * names[i] points at static strings; returns the number of entries written (<= cap). */
 int b32_last_kernel_times(b32_ctx* ctx, const char** names, float* ms, uint32_t cap);
 /* HIP-event instrumentation of the frames enqueued from now on: 0 = none (default for the async path),
- * 1 = events around the fill kernel, 2 = events around every phase. Averages over the frames between two
+ * 1 = events around the coverage kernel (the dominant one), 2 = events around every phase
+ * (setup, sort, bin, cover, shade). Averages over the frames between two
  * b32_frame_finish calls (last 64 at most) are returned by b32_last_kernel_times / B32Timings. */
 int b32_set_profiling(b32_ctx* ctx, int level);
 /* B32Timings.fragments (the reference's pixel-store count, render.rs:1671-1702) is instrumentation, not an output of

@@ -78,6 +78,60 @@ def test_frame_parity_small(gpu_ctx, oracle, name):
     assert np.array_equal(gpu_ctx.last_draw_order(len(sc.faces)), d["draw_order"])
 
 
+@pytest.fixture
+def fast_ctx(gpu_ctx):
+    """Fragment counting off: CHEAP coverage + runner-up repair + per-tile LDS depth sort where eligible."""
+    gpu_ctx.set_fragment_counting(0)
+    yield gpu_ctx
+    gpu_ctx.set_fragment_counting(1)
+
+
+@pytest.mark.parametrize("name", ["C1", "C1:gouraud", "C1:blend", "C1:float", "cube", "fog-flat-point-nocull", "C2", "C2:blend",
+                                  "C3:100k", "C5:20k"])
+def test_fast_path_frame_parity(fast_ctx, oracle, name):
+    """Same frames through the fast path (no global depth sort, inside-test-only coverage, top-2 visibility).  C2 has tile
+    lists longer than the LDS sort capacity, so it also exercises the automatic redraw with the global sort."""
+    sc = SCENES[name]()
+    exp, etm, d = cpu_render(oracle, sc)
+    for resident in (False, True):
+        got, tm = gpu_render(fast_ctx, sc, resident=resident, indexed=resident and bool(sc.indexed_textures))
+        assert np.array_equal(got, exp), f"{int((got != exp).sum())} bytes differ (resident={resident})"
+        assert tm.triangles_drawn == etm.triangles_drawn
+        assert np.array_equal(fast_ctx.last_draw_order(len(sc.faces)), d["draw_order"])      # lazily materialised global order
+
+
+def test_fast_path_long_lists_and_skipped_winners(fast_ctx, oracle):
+    """One 64x64 tile holding > 32768 surfaces (runner-up not representable -> list scan), with a texture where a third of
+    the texels are skippable on some faces and none on others (black_transparent off)."""
+    sc = scenegen.make_scene("C2", n_tris=90_000, width=64, height=64, bbox_px=30.0, seed=4242)
+    sc.faces["black_transparent"][::4] = 0
+    exp, etm, d = cpu_render(oracle, sc)
+    assert etm.triangles_drawn > 33000
+    got, tm = gpu_render(fast_ctx, sc, resident=True)
+    assert np.array_equal(got, exp)
+    # a texture with many skippable texels forces EXACT coverage even with counting off
+    sc2 = scenegen.make_scene("C1", seed=99)
+    sc2.textures[0].pixels[::3] = 0
+    exp2, etm2, _ = cpu_render(oracle, sc2)
+    got2, tm2 = gpu_render(fast_ctx, sc2)
+    assert np.array_equal(got2, exp2) and tm2.fragments == etm2.fragments
+
+
+def test_fast_path_full_size_c3(fast_ctx, oracle):
+    """Headline configuration through the fast path, bands included."""
+    sc = scenegen.make_scene("C3")
+    exp, etm, d = cpu_render(oracle, sc)
+    got, tm = gpu_render(fast_ctx, sc, resident=True, indexed=True)
+    assert np.array_equal(got, exp)
+    assert tm.triangles_drawn == etm.triangles_drawn and tm.tile_pairs > tm.triangles_drawn
+    row = sc.width * 4
+    assembled = np.empty_like(got)
+    for y0, y1 in [(0, 333), (333, 960), (960, 1920)]:
+        part, _ = gpu_render(fast_ctx, sc, resident=True, indexed=True, band=(y0, y1))
+        assembled[y0 * row:y1 * row] = part[y0 * row:y1 * row]
+    assert np.array_equal(assembled, exp)
+
+
 def test_c1_against_committed_frame(gpu_ctx):
     z = np.load(os.path.join(GOLD, "c1_frame.npz"))
     got, tm = gpu_render(gpu_ctx, SCENES["C1"]())
