@@ -47,6 +47,7 @@ struct b32_ctx {
     SurfRec* recs = nullptr; float* shades = nullptr; size_t cap_shades = 0;
     uint32_t* counts = nullptr; uint32_t* block_sums = nullptr; uint32_t bin_blocks = 0;
     uint32_t* spans = nullptr;
+    uint32_t* tile_mid = nullptr; size_t cap_tile_mid = 0;
     bool local_sort_ok = true;          // no tile list of this scene has exceeded the LDS sort capacity so far
     bool last_local_sort = false;       // the last frame took the fast path (draw order not materialised)
     // pairs
@@ -140,7 +141,7 @@ void b32_destroy(b32_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = { c->fb_own, c->d_verts, c->d_faces, c->d_texels, c->d_tex, c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->recs,
                      c->shades, c->counts, c->block_sums, c->pkeys[0], c->pkeys[1], c->pvals[0], c->pvals[1], c->block_hist, c->ranges,
-                     c->d_ctrl, c->d_consts, c->d_lights, c->digit_total, c->partials, c->vis, c->spans };
+                     c->d_ctrl, c->d_consts, c->d_lights, c->digit_total, c->partials, c->vis, c->spans, c->tile_mid };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->ev_created) for (auto& fr : c->ev) for (auto& e : fr) if (e) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -212,7 +213,8 @@ int b32_fb_clear(b32_ctx* c, uint8_t r, uint8_t g, uint8_t b, uint8_t blend) {
     (void)hipSetDevice(c->device);
     const uint32_t a = blend == B32_BLEND_ERASE ? 0u : 255u;               // Color::to_bytes, types.rs:829-832
     const uint32_t rgba = r | (g << 8) | (b << 16) | (a << 24);
-    launch_clear(c->stream, c->fb, (size_t)c->width * c->height, rgba);
+    // with a screen band set (multi-GPU sharding) only the rows this rank owns are cleared: the others belong to other ranks
+    launch_clear(c->stream, c->fb + (size_t)c->band_y0 * c->width, (size_t)c->width * (c->band_y1 - c->band_y0), rgba);
     HIPCHK(c, hipGetLastError());
     return B32_OK;
 }
@@ -415,6 +417,10 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
         c->cap_ranges = (size_t)n_keys + 64;
     }
 
+    if ((size_t)ntiles + 1 > c->cap_tile_mid || !c->tile_mid) {
+        if ((rc = ensure_plain(c, c->tile_mid, (size_t)ntiles + 64))) return rc;
+        c->cap_tile_mid = (size_t)ntiles + 64;
+    }
     if ((size_t)c->width * c->height > c->cap_vis || !c->vis) {
         if ((rc = ensure_plain(c, c->vis, (size_t)c->width * c->height + 64))) return rc;
         c->cap_vis = (size_t)c->width * c->height;
@@ -443,7 +449,7 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
         // fast path: no global depth sort.  Pairs are emitted in face order from k_setup's spans; k_cover sorts every tile
         // list by depth key in LDS (stable, so ties keep face order).
         if (prof_all) HIPCHK(c, hipEventRecord(ev[2], s));
-        launch_bin_faces(s, fp, c->spans, c->keys[0], c->partials, c->d_ctrl, c->pkeys[0], c->pvals[0], (uint32_t)c->cap_pairs);
+        launch_bin_faces(s, fp, c->spans, c->keys[0], c->partials, c->d_ctrl, c->pkeys[0], c->pvals[0], (uint32_t)c->cap_pairs, 0);
     } else {
         // painter's order: 4 stable passes over the 32-bit key; pass 1 also compacts away culled faces and its scan kernel
         // reduces k_setup's counters into Ctrl (n_visible feeds the later passes).
@@ -455,16 +461,17 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
         if (prof_all) HIPCHK(c, hipEventRecord(ev[2], s));
         launch_bin(s, fp, c->recs, c->vals[0], c->d_ctrl, c->counts, c->block_sums, c->bin_blocks, c->pkeys[0], c->pvals[0], (uint32_t)c->cap_pairs);
     }
-    const uint32_t kb = bits_for(n_keys ? n_keys : 1);
+    const uint32_t n_sort_keys = local_sort ? ntiles : n_keys;          // the fast path groups by tile only
+    const uint32_t kb = bits_for(n_sort_keys ? n_sort_keys : 1);
     int cur = 0;
     if (kb <= 8 || kb > 12) {
         for (uint32_t shift = 0; shift < kb; shift += 8) {
             launch_radix_pass(s, c->pkeys[cur], c->pvals[cur], c->pkeys[cur ^ 1], c->pvals[cur ^ 1], &c->d_ctrl->n_pairs, (uint32_t)c->cap_pairs, (int)shift, 8, sc);
             cur ^= 1;
         }
-        launch_tile_ranges(s, c->pkeys[cur], c->d_ctrl, (uint32_t)c->cap_pairs, c->ranges, n_keys);
+        launch_tile_ranges(s, c->pkeys[cur], c->d_ctrl, (uint32_t)c->cap_pairs, c->ranges, n_sort_keys);
     } else {    // up to 2048 tiles: one pass groups every (tile, class) list and its digit bases are the list ranges
-        RadixExtra exr; exr.ranges_out = c->ranges; exr.n_ranges = n_keys + 1;
+        RadixExtra exr; exr.ranges_out = c->ranges; exr.n_ranges = n_sort_keys + 1;
         launch_radix_pass(s, c->pkeys[cur], c->pvals[cur], c->pkeys[cur ^ 1], c->pvals[cur ^ 1], &c->d_ctrl->n_pairs, (uint32_t)c->cap_pairs, 0, kb <= 11 ? 11 : 12, sc, exr);
         cur ^= 1;
     }
@@ -473,7 +480,7 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
 
     FillArgs fa{};
     fa.fp = fp; fa.recs = c->recs; fa.shades = c->shades; fa.pair_vals = c->pvals[cur]; fa.ranges = c->ranges;
-    fa.keys = c->keys[0]; fa.local_sort = local_sort ? 1u : 0u;
+    fa.keys = c->keys[0]; fa.local_sort = local_sort ? 1u : 0u; fa.tile_keys_only = fa.local_sort; fa.tile_mid = c->tile_mid;
     fa.tex = c->d_tex; fa.texels = c->d_texels; fa.fb = c->fb; fa.vis = c->vis; fa.ctrl = c->d_ctrl;
     fa.tex0 = c->nt ? c->h_tex[0] : TexDesc{ 0, 0, 0, 0 };
     fa.lds_tex_texels = 0;

@@ -114,7 +114,8 @@ void launch_bin(hipStream_t s, const FrameParams& fp, const SurfRec* recs, const
 // from k_setup's per-256-face pair counts; block 0 also reduces the frame counters into Ctrl.
 __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit_faces(FrameParams fp, const uint32_t* __restrict__ spans, const uint32_t* __restrict__ keys,
                                                                  const uint32_t* __restrict__ partials, uint32_t npart, Ctrl* __restrict__ ctrl,
-                                                                 uint32_t pair_cap, uint32_t* __restrict__ pair_keys, uint32_t* __restrict__ pair_vals) {
+                                                                 uint32_t pair_cap, uint32_t* __restrict__ pair_keys, uint32_t* __restrict__ pair_vals,
+                                                                 int with_class) {
     __shared__ uint32_t wtot[BIN_THREADS / 64];
     __shared__ uint32_t red[BIN_THREADS / 64][8];
     __shared__ uint32_t step_base, total_s;
@@ -147,39 +148,51 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit_faces(FrameParams fp, 
         __syncthreads();
     }
     if (total_s > pair_cap) return;
-    const uint32_t base = blockIdx.x * BIN_TILE;
-    for (int i = 0; i < BIN_ITEMS; ++i) {
-        const uint32_t f = base + i * BIN_THREADS + threadIdx.x;
-        const uint32_t span = f < fp.nf ? spans[f] : 0xFFFFFFFFu;
-        const uint32_t tx0 = span & 0xFF, tx1 = (span >> 8) & 0xFF, ty0 = (span >> 16) & 0xFF, ty1 = span >> 24;
-        const uint32_t c = span == 0xFFFFFFFFu ? 0u : (tx1 - tx0 + 1) * (ty1 - ty0 + 1);
-        uint32_t inc = c;
-        for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(inc, off); if (lane >= (uint32_t)off) inc += t; }
-        if (lane == 63) wtot[wave] = inc;
-        __syncthreads();
-        uint32_t woff = 0;
-        for (uint32_t w = 0; w < wave; ++w) woff += wtot[w];
-        uint32_t pos = step_base + woff + inc - c;
-        if (c) {
-            const uint32_t cls = keys[f] >> 31;                                    // transparent pass, render.rs:2522-2523
+    // blocked arrangement: thread t owns the 16 consecutive faces base + 16 t .. +15, so positions are monotone in the face id
+    // (all the tile-local sort needs for stability) with one block-wide scan instead of one per step.
+    const uint32_t f0 = blockIdx.x * BIN_TILE + threadIdx.x * BIN_ITEMS;
+    uint32_t span[BIN_ITEMS];
+    uint32_t mine = 0;
+    if (f0 + BIN_ITEMS <= fp.nf) {
+        const uint4* sp = reinterpret_cast<const uint4*>(spans + f0);
+#pragma unroll
+        for (int q = 0; q < BIN_ITEMS / 4; ++q) { const uint4 v = sp[q]; span[4 * q] = v.x; span[4 * q + 1] = v.y; span[4 * q + 2] = v.z; span[4 * q + 3] = v.w; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < BIN_ITEMS; ++i) span[i] = f0 + i < fp.nf ? spans[f0 + i] : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int i = 0; i < BIN_ITEMS; ++i)
+        if (span[i] != 0xFFFFFFFFu) mine += (((span[i] >> 8) & 0xFF) - (span[i] & 0xFF) + 1) * ((span[i] >> 24) - ((span[i] >> 16) & 0xFF) + 1);
+    uint32_t inc = mine;
+    for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(inc, off); if (lane >= (uint32_t)off) inc += t; }
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    uint32_t pos = step_base + inc - mine;
+    for (uint32_t w = 0; w < wave; ++w) pos += wtot[w];
+    if (mine) {
+#pragma unroll 1
+        for (int i = 0; i < BIN_ITEMS; ++i) {
+            if (span[i] == 0xFFFFFFFFu) continue;
+            const uint32_t f = f0 + i;
+            const uint32_t tx0 = span[i] & 0xFF, tx1 = (span[i] >> 8) & 0xFF, ty0 = (span[i] >> 16) & 0xFF, ty1 = span[i] >> 24;
+            const uint32_t cls = with_class ? keys[f] >> 31 : 0u;                  // transparent pass, render.rs:2522-2523
             for (uint32_t ty = ty0; ty <= ty1; ++ty)
                 for (uint32_t tx = tx0; tx <= tx1; ++tx) {
-                    pair_keys[pos] = ((ty * fp.tiles_x + tx) << 1) | cls;
+                    const uint32_t tile = ty * fp.tiles_x + tx;
+                    pair_keys[pos] = with_class ? ((tile << 1) | cls) : tile;
                     pair_vals[pos] = f;
                     ++pos;
                 }
         }
-        __syncthreads();
-        if (threadIdx.x == 0) step_base += wtot[0] + wtot[1] + wtot[2] + wtot[3];
-        __syncthreads();
     }
 }
 void launch_bin_faces(hipStream_t s, const FrameParams& fp, const uint32_t* spans, const uint32_t* keys, const uint32_t* partials,
-                      Ctrl* ctrl, uint32_t* pair_keys, uint32_t* pair_vals, uint32_t pair_cap) {
+                      Ctrl* ctrl, uint32_t* pair_keys, uint32_t* pair_vals, uint32_t pair_cap, int with_class) {
     if (fp.nf == 0) return;
     const uint32_t nblocks = (fp.nf + BIN_TILE - 1) / BIN_TILE;
     hipLaunchKernelGGL(k_bin_emit_faces, dim3(nblocks), dim3(BIN_THREADS), 0, s, fp, spans, keys, partials, (fp.nf + 255) / 256, ctrl, pair_cap,
-                       pair_keys, pair_vals);
+                       pair_keys, pair_vals, with_class);
 }
 
 // ranges[k] = first pair index whose key >= k, for k in 0..n_keys (n_keys = 2*ntiles); ranges[n_keys] = n_pairs.

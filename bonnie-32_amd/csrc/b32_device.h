@@ -191,7 +191,7 @@ void launch_bin(hipStream_t s, const FrameParams& fp, const SurfRec* recs, const
                 uint32_t* counts, uint32_t* block_sums, uint32_t max_blocks, uint32_t* pair_keys, uint32_t* pair_vals, uint32_t pair_cap);
 // Fast path: pairs straight from k_setup's per-face spans, in face order (the per-tile LDS sort of k_cover orders them).
 void launch_bin_faces(hipStream_t s, const FrameParams& fp, const uint32_t* spans, const uint32_t* keys, const uint32_t* partials,
-                      Ctrl* ctrl, uint32_t* pair_keys, uint32_t* pair_vals, uint32_t pair_cap);
+                      Ctrl* ctrl, uint32_t* pair_keys, uint32_t* pair_vals, uint32_t pair_cap, int with_class);
 void launch_tile_ranges(hipStream_t s, const uint32_t* pair_keys, const Ctrl* ctrl, uint32_t pair_cap, uint32_t* ranges, uint32_t n_keys);
 
 struct FillArgs {
@@ -201,7 +201,9 @@ struct FillArgs {
     uint32_t* pair_vals;        // surface ids, grouped by (tile,class); painter's order inside a group (after the tile-local sort)
     const uint32_t* keys;       // face-order radix keys of k_setup (tile-local sort)
     uint32_t local_sort;        // 1: lists arrive in face order and k_cover sorts each one in LDS
-    const uint32_t* ranges;     // [2*ntiles + 1]
+    const uint32_t* ranges;     // list ranges: [2*ntiles + 1] keyed by (tile<<1|class), or [ntiles + 1] keyed by tile (fast path)
+    uint32_t* tile_mid;         // fast path: first transparent-pass entry of every tile list (written by k_cover)
+    uint32_t tile_keys_only;    // 1: ranges are per tile, the class boundary comes from the tile-local sort
     const TexDesc* tex;
     const uint16_t* texels;
     uint32_t* fb;               // RGBA8 words, full frame

@@ -422,12 +422,15 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
 // keys keep face order exactly like the global sort.  The four LDS arrays alias the (not yet used) tile buffers.
 template <int NT>
 __device__ void tile_local_sort(uint32_t* sort_area, uint32_t* wcnt, volatile uint32_t* dws, const uint32_t* __restrict__ keys,
-                                uint32_t* list, uint32_t n) {
+                                uint32_t* list, uint32_t n, volatile uint32_t* n_opaque_out) {
     constexpr int NW = NT / 64;
     constexpr int STEPS = LOCAL_SORT_CAP / (NW * 64);
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t *ki = sort_area, *vi = sort_area + LOCAL_SORT_CAP, *ko = sort_area + 2 * LOCAL_SORT_CAP, *vo = sort_area + 3 * LOCAL_SORT_CAP;
-    for (uint32_t i = tid; i < n; i += NT) { const uint32_t sid = list[i]; ki[i] = keys[sid]; vi[i] = sid; }
+    uint32_t my_opaque = 0;
+    for (uint32_t i = tid; i < n; i += NT) { const uint32_t sid = list[i]; const uint32_t k = keys[sid]; ki[i] = k; vi[i] = sid; my_opaque += (k >> 31) ^ 1u; }
+    for (int off = 32; off > 0; off >>= 1) my_opaque += __shfl_down(my_opaque, off);
+    if (lane == 0 && my_opaque) atomicAdd(const_cast<uint32_t*>(n_opaque_out), my_opaque);       // class boundary of the sorted list
     __syncthreads();
     const uint32_t per_wave = ((n + NW * 64 - 1) / (NW * 64)) * 64;      // contiguous run per wave: order = (wave, step, lane)
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -518,21 +521,27 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a) {
     uint32_t next_tile = 0;
     if (tid == 0) next_tile = atomicAdd(&a.ctrl->tile_cursor, 1u);
     for (;;) {
-        if (tid == 0) { misc[0] = next_tile; misc[2] = 0; }
+        if (tid == 0) { misc[0] = next_tile; misc[2] = 0; misc[4] = 0; }
         __syncthreads();
         const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)misc[0]);
         if (tile >= ntiles) break;
         if (tid == 0) next_tile = atomicAdd(&a.ctrl->tile_cursor, 1u);    // prefetch the next tile index; consumed at the loop top
-        const uint32_t e0 = a.ranges[2 * tile], e1 = a.ranges[2 * tile + 1];
-        if (TEXMODE == 0 && a.local_sort) {      // lists arrive in face order: painter's order per tile, in LDS
-            const uint32_t e2 = a.ranges[2 * tile + 2];
-            if (e1 - e0 > LOCAL_SORT_CAP || e2 - e1 > LOCAL_SORT_CAP) {
+        uint32_t e0, e1;
+        if (TEXMODE == 0 && a.local_sort) {      // lists arrive in face order, keyed by tile only: painter's order per tile, in LDS
+            e0 = a.ranges[tile];
+            const uint32_t e2 = a.ranges[tile + 1];
+            if (e2 - e0 > LOCAL_SORT_CAP) {
                 if (tid == 0) atomicOr(&a.ctrl->need_global_sort, 1u);               // host redraws with the global depth sort
                 __syncthreads();
                 continue;
             }
-            if (e1 - e0 > 1) tile_local_sort<NT>(tilebuf, sort_cnt, misc + 8, a.keys, a.pair_vals + e0, e1 - e0);
-            if (e2 - e1 > 1) tile_local_sort<NT>(tilebuf, sort_cnt, misc + 8, a.keys, a.pair_vals + e1, e2 - e1);
+            // one stable sort of the whole list: the class bit is the key's top bit, so the transparent pass ends up behind
+            // the opaque one, each in painter's order (render.rs:2522-2541)
+            if (e2 > e0) tile_local_sort<NT>(tilebuf, sort_cnt, misc + 8, a.keys, a.pair_vals + e0, e2 - e0, &misc[4]);
+            e1 = e0 + misc[4];
+            if (tid == 0) a.tile_mid[tile] = e1;
+        } else {
+            e0 = a.ranges[2 * tile]; e1 = a.ranges[2 * tile + 1];
         }
         for (uint32_t i = tid; i < (EXACT ? 1 : 2) * TILE_H * TILE_STRIDE; i += NT) tilebuf[i] = 0;
         __syncthreads();
@@ -632,7 +641,7 @@ __global__ __launch_bounds__(256) void k_shade(FillArgs a) {
     const uint32_t li = a.exact_coverage ? ve.x : (long_list ? (ve.x & 0x7FFFFFFFu) : (ve.x & 0xFFFFu));
     const uint32_t second = (a.exact_coverage || long_list) ? 0u : (ve.x >> 16);
     const uint32_t tile = (py / TILE_H - fp.tile_y0) * fp.tiles_x + seg_x / TILE_W;      // same tile for the whole wave
-    const uint32_t e0 = a.ranges[2 * tile];
+    const uint32_t e0 = a.tile_keys_only ? a.ranges[tile] : a.ranges[2 * tile];
     Hit h;
     bool have = false;
     uint32_t scan_from = 0;                     // > 0: list positions <= scan_from still have to be searched
@@ -681,7 +690,8 @@ __global__ __launch_bounds__(NT) void k_blend(FillArgs a) {
     if (a.ctrl->abort || a.ctrl->need_global_sort) return;
     const FrameParams& fp = a.fp;
     const uint32_t tile = blockIdx.x;
-    const uint32_t e1 = a.ranges[2 * tile + 1], e2 = a.ranges[2 * tile + 2];
+    const uint32_t e1 = a.tile_keys_only ? a.tile_mid[tile] : a.ranges[2 * tile + 1];
+    const uint32_t e2 = a.tile_keys_only ? a.ranges[tile + 1] : a.ranges[2 * tile + 2];
     if (e1 == e2) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));

@@ -158,7 +158,7 @@ int         b32_synchronize(b32_ctx* ctx);
 
 /* ---- Framebuffer (render.rs:10-45) --------------------------------------- */
 int b32_fb_resize(b32_ctx* ctx, uint32_t width, uint32_t height);           /* Framebuffer::new/resize: zero-filled on change */
-int b32_fb_clear(b32_ctx* ctx, uint8_t r, uint8_t g, uint8_t b, uint8_t blend); /* Framebuffer::clear :36-45 */
+int b32_fb_clear(b32_ctx* ctx, uint8_t r, uint8_t g, uint8_t b, uint8_t blend); /* Framebuffer::clear :36-45 (rows of the band only when b32_set_band is active) */
 int b32_fb_upload(b32_ctx* ctx, const uint8_t* rgba);                        /* host fb.pixels -> device */
 int b32_fb_download(b32_ctx* ctx, uint8_t* rgba);                            /* device -> host fb.pixels */
 /* Draw into caller-owned DEVICE memory (width*height*4 B, e.g. a torch uint8 tensor) instead of the
