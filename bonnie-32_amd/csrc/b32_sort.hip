@@ -24,10 +24,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_hist(const uint32_t* __restric
     __shared__ uint32_t hist[NB];
     const uint32_t n = *n_dev;
     const uint32_t base = blockIdx.x * SORT_TILE;
-    if (base >= n) {   // still publish zeros so the scan sees a clean column
-        for (uint32_t d = threadIdx.x; d < NB; d += SORT_THREADS) block_hist[(size_t)d * max_blocks + blockIdx.x] = 0;
-        return;
-    }
+    if (base >= n) return;   // the scan only looks at the ceil(n / SORT_TILE) blocks in use
     for (uint32_t d = threadIdx.x; d < NB; d += SORT_THREADS) hist[d] = 0;
     __syncthreads();
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -74,8 +71,9 @@ __device__ void reduce_setup_partials(Ctrl* ctrl, const uint32_t* __restrict__ p
 // `post` (first depth pass only): block 0 also reduces k_setup's per-block counters into Ctrl (former k_after_setup).
 __global__ __launch_bounds__(256) void k_scan_rows(uint32_t* __restrict__ block_hist, uint32_t max_blocks, uint32_t nblocks,
                                                    uint32_t* __restrict__ digit_total, Ctrl* __restrict__ post_ctrl,
-                                                   const uint32_t* __restrict__ partials, uint32_t npart) {
+                                                   const uint32_t* __restrict__ partials, uint32_t npart, const uint32_t* __restrict__ n_dev) {
     __shared__ uint32_t wsum[4];
+    nblocks = min(nblocks, (*n_dev + SORT_TILE - 1) / SORT_TILE);          // blocks actually in use (grids are sized for the capacity)
     if (post_ctrl && blockIdx.x == 0) reduce_setup_partials(post_ctrl, partials, npart);
     __shared__ uint32_t carry_s;
     uint32_t* row = block_hist + (size_t)blockIdx.x * max_blocks;
@@ -193,7 +191,7 @@ static void radix_pass_t(hipStream_t s, const uint32_t* keys_in, const uint32_t*
     const int drop = vals_in == nullptr ? 1 : 0;
     hipLaunchKernelGGL(k_hist<BITS>, dim3(nblocks), dim3(SORT_THREADS), 0, s, keys_in, n_dev, shift, drop, sc.block_hist, sc.max_blocks);
     hipLaunchKernelGGL(k_scan_rows, dim3(1u << BITS), dim3(256), 0, s, sc.block_hist, sc.max_blocks, nblocks, sc.digit_total,
-                       ex.post_ctrl, ex.partials, ex.npart);
+                       ex.post_ctrl, ex.partials, ex.npart, n_dev);
     hipLaunchKernelGGL(k_scatter<BITS>, dim3(nblocks), dim3(SORT_THREADS), 0, s, keys_in, vals_in, keys_out, vals_out, n_dev, shift, drop,
                        sc.block_hist, sc.max_blocks, sc.digit_total, ex.ranges_out, ex.n_ranges);
 }
