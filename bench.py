@@ -31,6 +31,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--check", action="store_true", help="also verify the final frame against the oracle (slow at C3)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (default). gloo = debug only: ranks may share one GPU, band rows are staged through the host")
     args = ap.parse_args()
 
     import numpy as np
@@ -44,11 +46,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the rasterizer has no CPU path")
+    if args.dist_backend == "gloo":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     import __graft_entry__ as g
     if rank == 0:
@@ -79,7 +86,13 @@ def main():
         else:
             rs.render_async()
         if world > 1:
-            parallel.gather_bands(frame, W, H, world, rank)
+            if args.dist_backend == "nccl":
+                parallel.gather_bands(frame, W, H, world, rank)
+            else:       # debug: same gather logic on a host copy
+                host = frame.cpu()
+                parallel.gather_bands(host, W, H, world, rank)
+                if rank == 0:
+                    frame.copy_(host)
 
     # warmup (also settles buffer capacities: finish() grows the pair buffers if the first frame overflowed them)
     step(first=True)
@@ -113,8 +126,9 @@ def main():
     cover_ms = ctx.last_kernel_times().get("cover", None)     # HIP events around k_cover on the stream it runs on
     ctx.set_profiling(0)
 
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
-    frags = torch.tensor([float(exact_fragments)], dtype=torch.float64, device=dev)
+    rdev = dev if args.dist_backend == "nccl" else torch.device("cpu")
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=rdev)
+    frags = torch.tensor([float(exact_fragments)], dtype=torch.float64, device=rdev)
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
         dist.all_reduce(frags, op=dist.ReduceOp.SUM)
@@ -170,9 +184,12 @@ def main():
             cpu = {"value": round(NF / per / 1e6, 4), "unit": "Mtriangles/s", "cores": 1, "kind": "port",
                    "mpixels_per_s": round(otm.fragments / per / 1e6, 3), "ms_per_frame": round(per * 1e3, 2),
                    "sample": f"{reps} full frames of the same {args.config} scene ({NF} tris @ {W}x{H}), oracle/b32_oracle.c, 1 thread"}
-            if args.check:
-                got = frame.cpu().numpy()
-                print("# parity vs oracle:", "bit-exact" if np.array_equal(got, ofb.pixels) else "MISMATCH", file=sys.stderr)
+        if args.check:
+            from oracle import oracle as O
+            cfb = O.Framebuffer(W, H); cfb.clear(sc.clear_color)
+            O.render_mesh_15(cfb, sc.vertices, sc.faces, sc.textures, sc.camera, sc.settings, sc.fog)
+            got = frame.cpu().numpy()
+            print("# parity vs oracle:", "bit-exact" if np.array_equal(got, cfb.pixels) else "MISMATCH", file=sys.stderr)
         line = {
             "metric": "Mtriangles/s + Mpixels/s, 1M-tri synthetic scene @ 2560x1920",
             "value": round(mtri, 3), "unit": "Mtriangles/s",
