@@ -355,7 +355,7 @@ int b32_scene_upload_indexed(b32_ctx* c, const B32Vertex* v, uint32_t nv, const 
 
 // ------------------------------------------------------------------ frame
 static int validate_settings(const B32Settings* st) {
-    if (st->use_zbuffer || st->has_ortho || st->xray_mode || !st->affine_textures) return B32_E_UNSUPPORTED;
+    if (st->use_zbuffer || st->has_ortho || st->xray_mode) return B32_E_UNSUPPORTED;
     if ((st->backface_cull && st->backface_wireframe) || st->wireframe_overlay) return B32_E_UNSUPPORTED;      // wireframe phase
     if (st->shading > B32_SHADE_GOURAUD) return B32_E_ARG;
     if (st->n_lights && !st->lights) return B32_E_ARG;

@@ -29,7 +29,7 @@ struct __attribute__((aligned(16))) SurfRec {
     uint32_t bby; float u1, u2, u3;
     float v1, v2, v3; uint32_t flags;
     uint32_t vc1, vc2, vc3; float w0_start;    // vc = r | g<<8 | b<<16 ; w*_start = render.rs:1517-1518
-    float w1_start; uint32_t face_idx; uint32_t pad0, pad1;
+    float w1_start; float iz1, iz2, iz3;       // 1.0 / v_i.z (render.rs:1546-1548): perspective-correct UVs, z-buffer depth
 };
 static_assert(sizeof(SurfRec) == 96, "SurfRec layout");
 

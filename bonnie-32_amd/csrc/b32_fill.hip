@@ -42,6 +42,7 @@ struct Tri {            // one SurfRec (+ its texture), wave-uniform in phase A/
     float x3, y3, a0, b0, a1, b1, inv_area;
     float u1, u2, u3, v1, v2, v3;
     float w0_start, w1_start;
+    float iz1, iz2, iz3;
     uint32_t min_x, max_x, min_y, max_y, flags;
     uint32_t tw, th, toff;
 };
@@ -68,11 +69,20 @@ __device__ __forceinline__ bool inside_bc(const Tri& t, float w0, float w1, floa
 // Texel fetch + transparency rules (render.rs:1563-1607). Returns false when the fragment is skipped.
 template <int TEXMODE>
 __device__ __forceinline__ bool texel_drawn(const Tri& t, float bcx, float bcy, float bcz, const uint16_t* __restrict__ gtex,
-                                            const uint16_t* ltex, uint32_t& texel) {
+                                            const uint16_t* ltex, uint32_t& texel, bool affine = true) {
     uint32_t c = 0x7FFF;                                         // Color15::WHITE, render.rs:1585
     if ((t.flags & F_TEX_MASK) != F_TEX_NONE) {
-        const float u = bcx * t.u1 + bcy * t.u2 + bcz * t.u3;    // affine, render.rs:1565-1566
-        const float v = bcx * t.v1 + bcy * t.v2 + bcz * t.v3;
+        float u, v;
+        if (affine) {
+            u = bcx * t.u1 + bcy * t.u2 + bcz * t.u3;            // affine, render.rs:1565-1566
+            v = bcx * t.v1 + bcy * t.v2 + bcz * t.v3;
+        } else {                                                 // perspective-correct, render.rs:1568-1579
+            const float inv_z = bcx * t.iz1 + bcy * t.iz2 + bcz * t.iz3;
+            const float u_over_z = bcx * t.u1 * t.iz1 + bcy * t.u2 * t.iz2 + bcz * t.u3 * t.iz3;
+            const float v_over_z = bcx * t.v1 * t.iz1 + bcy * t.v2 * t.iz2 + bcz * t.v3 * t.iz3;
+            u = u_over_z / inv_z;
+            v = v_over_z / inv_z;
+        }
         c = sample15<TEXMODE>(t, gtex, ltex, u, 1.0f - v);       // render.rs:1583
     }
     if (c == 0) {                                                // render.rs:1592-1602
@@ -183,6 +193,8 @@ __device__ __forceinline__ Tri tri_from_batch(const Batch& b, int t, bool full) 
         r.tw = bcu(b.tw, t); r.th = bcu(b.th, t); r.toff = bcu(b.toff, t);
     }
     if (r.flags & F_SLOW) { r.w0_start = bcf(__uint_as_float(b.q4.w), t); r.w1_start = bcf(__uint_as_float(b.q5.x), t); }
+    r.iz1 = r.iz2 = r.iz3 = 0.0f;
+    if (full) { r.iz1 = bcf(__uint_as_float(b.q5.y), t); r.iz2 = bcf(__uint_as_float(b.q5.z), t); r.iz3 = bcf(__uint_as_float(b.q5.w), t); }
     return r;
 }
 template <int TEXMODE>
@@ -198,6 +210,7 @@ __device__ __forceinline__ Tri tri_from_mem(const FillArgs& a, uint32_t sid, con
     r.v1 = __uint_as_float(q3.x); r.v2 = __uint_as_float(q3.y); r.v3 = __uint_as_float(q3.z);
     r.flags = q3.w;
     r.w0_start = __uint_as_float(q4.w); r.w1_start = __uint_as_float(q5.x);
+    r.iz1 = __uint_as_float(q5.y); r.iz2 = __uint_as_float(q5.z); r.iz3 = __uint_as_float(q5.w);
     r.tw = r.th = r.toff = 0;
     const uint32_t txid = r.flags & F_TEX_MASK;
     if (txid != F_TEX_NONE) {
@@ -211,7 +224,7 @@ __device__ __forceinline__ Tri tri_from_mem(const FillArgs& a, uint32_t sid, con
 template <int TEXMODE, bool EXACT>
 __device__ __forceinline__ uint32_t cover_surface(const Tri& tr, uint32_t cx0, uint32_t cx1, uint32_t cy0, uint32_t cy1, uint32_t li,
                                                   uint32_t* tilebuf, uint32_t x_lo, uint32_t ty_top, uint32_t lane,
-                                                  const uint16_t* __restrict__ gtex, const uint16_t* ltex) {
+                                                  const uint16_t* __restrict__ gtex, const uint16_t* ltex, bool affine) {
     uint32_t drawn_count = 0;
     if (!(tr.flags & F_SLOW)) {
         // lane block shape: the one needing the fewest blocks (ties -> 8x8)
@@ -234,7 +247,7 @@ __device__ __forceinline__ uint32_t cover_surface(const Tri& tr, uint32_t cx0, u
                     float bcx, bcy, bcz;
                     if (inside_bc(tr, w0, w1, bcx, bcy, bcz)) {
                         uint32_t texel;
-                        drawn = EXACT ? texel_drawn<TEXMODE>(tr, bcx, bcy, bcz, gtex, ltex, texel) : true;
+                        drawn = EXACT ? texel_drawn<TEXMODE>(tr, bcx, bcy, bcz, gtex, ltex, texel, affine) : true;
                         if (drawn) {
                             uint32_t* t = &tilebuf[(py - ty_top) * TILE_STRIDE + (px - x_lo)];
                             if (EXACT) atomicMax(t, li);
@@ -256,7 +269,7 @@ __device__ __forceinline__ uint32_t cover_surface(const Tri& tr, uint32_t cx0, u
                     float bcx, bcy, bcz;
                     if (inside_bc(tr, w0, w1, bcx, bcy, bcz)) {
                         uint32_t texel;
-                        const bool drawn = EXACT ? texel_drawn<TEXMODE>(tr, bcx, bcy, bcz, gtex, ltex, texel) : true;
+                        const bool drawn = EXACT ? texel_drawn<TEXMODE>(tr, bcx, bcy, bcz, gtex, ltex, texel, affine) : true;
                         if (drawn) {
                             uint32_t* t = &tilebuf[(py - ty_top) * TILE_STRIDE + (px - x_lo)];
                             if (EXACT) atomicMax(t, li);
@@ -297,12 +310,12 @@ __device__ __forceinline__ float bpermf(uint32_t src_lane, float v) { return __i
 template <int TEXMODE, bool EXACT>
 __device__ __forceinline__ uint32_t cover_one(const Batch& b, int t, uint32_t li, uint32_t* tilebuf, uint32_t x_lo, uint32_t x_hi,
                                               uint32_t y_lo, uint32_t y_hi, uint32_t ty_top, uint32_t lane,
-                                              const uint16_t* __restrict__ gtex, const uint16_t* ltex) {
+                                              const uint16_t* __restrict__ gtex, const uint16_t* ltex, bool affine) {
     const Tri tr = tri_from_batch(b, t, EXACT);
     const uint32_t cx0 = max(tr.min_x, x_lo), cx1 = min(tr.max_x, x_hi);
     const uint32_t cy0 = max(tr.min_y, y_lo), cy1 = min(tr.max_y, y_hi);
     if (cx0 >= cx1 || cy0 >= cy1) return 0;
-    return cover_surface<TEXMODE, EXACT>(tr, cx0, cx1, cy0, cy1, li, tilebuf, x_lo, ty_top, lane, gtex, ltex);
+    return cover_surface<TEXMODE, EXACT>(tr, cx0, cx1, cy0, cy1, li, tilebuf, x_lo, ty_top, lane, gtex, ltex, affine);
 }
 
 // Phase A as a ROW-ITEM scheduler.  Waves grab 64 list entries at a time from an LDS cursor (load balance across the 16
@@ -320,6 +333,7 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
     const uint16_t* __restrict__ gtex = a.texels;
     unsigned long long frags = 0;
     const float ERR = -0.0001f;
+    const bool affine = a.fp.affine != 0;
     // entries per grab: ~3 grabs per wave for balance, never more than the 64 lanes can hold
     const uint32_t grab = min(64u, max(4u, (n_op + 3 * NW - 1) / (3 * NW)));
     for (;;) {
@@ -369,6 +383,7 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
                 tr.v1 = bpermf(s, __uint_as_float(b.q3.x)); tr.v2 = bpermf(s, __uint_as_float(b.q3.y)); tr.v3 = bpermf(s, __uint_as_float(b.q3.z));
                 tr.flags = bperm(s, flags);
                 tr.tw = bperm(s, b.tw); tr.th = bperm(s, b.th); tr.toff = bperm(s, b.toff);
+                if (!affine) { tr.iz1 = bpermf(s, __uint_as_float(b.q5.y)); tr.iz2 = bpermf(s, __uint_as_float(b.q5.z)); tr.iz3 = bpermf(s, __uint_as_float(b.q5.w)); }
             }
             const uint32_t rx0 = sbox & 0xFF, rx1 = (sbox >> 8) & 0xFF, ry = (sbox >> 16) + (k - sP);   // tile-local
             const uint32_t n = valid ? rx1 - rx0 : 0u;
@@ -383,7 +398,7 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
                     const float bcz = 1.0f - bcx - bcy;
                     if ((bcx >= ERR) & (bcy >= ERR) & (bcz >= ERR)) {
                         bool drawn = true;
-                        if (EXACT) { uint32_t texel; drawn = texel_drawn<TEXMODE>(tr, bcx, bcy, bcz, gtex, ltex, texel); }
+                        if (EXACT) { uint32_t texel; drawn = texel_drawn<TEXMODE>(tr, bcx, bcy, bcz, gtex, ltex, texel, affine); }
                         if (drawn) {
                             if (EXACT) { atomicMax(&tilebuf[addr], li); ++mine; }
                             else {
@@ -407,7 +422,7 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
         while (sm) {
             const int t = __builtin_ctzll(sm);
             sm &= sm - 1;
-            frags += cover_one<TEXMODE, EXACT>(b, t, cs + (uint32_t)t + 1, tilebuf, x_lo, x_hi, y_lo, y_hi, ty_top, lane, gtex, ltex);
+            frags += cover_one<TEXMODE, EXACT>(b, t, cs + (uint32_t)t + 1, tilebuf, x_lo, x_hi, y_lo, y_hi, ty_top, lane, gtex, ltex, affine);
         }
     }
     (void)wave;
@@ -601,7 +616,9 @@ __device__ __forceinline__ bool hit_test(const FillArgs& a, uint32_t sid, uint32
     tr.v1 = __uint_as_float(q3.x); tr.v2 = __uint_as_float(q3.y); tr.v3 = __uint_as_float(q3.z);
     tr.flags = q3.w;
     tr.w0_start = __uint_as_float(q4.w); tr.w1_start = 0.0f;
-    if (tr.flags & F_SLOW) tr.w1_start = __uint_as_float(rp[5].x);
+    tr.iz1 = tr.iz2 = tr.iz3 = 0.0f;
+    const bool affine = a.fp.affine != 0;
+    if ((tr.flags & F_SLOW) || !affine) { const uint4 q5 = rp[5]; tr.w1_start = __uint_as_float(q5.x); tr.iz1 = __uint_as_float(q5.y); tr.iz2 = __uint_as_float(q5.z); tr.iz3 = __uint_as_float(q5.w); }
     tr.tw = tr.th = tr.toff = 0;
     const uint32_t txid = tr.flags & F_TEX_MASK;
     if (txid != F_TEX_NONE) {
@@ -612,7 +629,7 @@ __device__ __forceinline__ bool hit_test(const FillArgs& a, uint32_t sid, uint32
     edge_w(tr, px, py, w0, w1);
     if (!inside_bc(tr, w0, w1, h.bcx, h.bcy, h.bcz)) return false;
     h.texel = 0;
-    if (!texel_drawn<0>(tr, h.bcx, h.bcy, h.bcz, a.texels, nullptr, h.texel)) return false;
+    if (!texel_drawn<0>(tr, h.bcx, h.bcy, h.bcz, a.texels, nullptr, h.texel, affine)) return false;
     h.vc1 = q4.x; h.vc2 = q4.y; h.vc3 = q4.z; h.flags = tr.flags; h.sid = sid;
     return true;
 }
@@ -743,7 +760,7 @@ __global__ __launch_bounds__(NT) void k_blend(FillArgs a) {
                         if (px < cx1 && py < cy1) {
                             float w0, w1, bcx, bcy, bcz; uint32_t texel;
                             edge_w(tr, px, py, w0, w1);
-                            if (inside_bc(tr, w0, w1, bcx, bcy, bcz) && texel_drawn<0>(tr, bcx, bcy, bcz, a.texels, nullptr, texel)) {
+                            if (inside_bc(tr, w0, w1, bcx, bcy, bcz) && texel_drawn<0>(tr, bcx, bcy, bcz, a.texels, nullptr, texel, fp.affine != 0)) {
                                 const uint32_t out15 = shade15(texel, bcx, bcy, bcz, vc1, vc2, vc3, tr.flags, shading, shv, px, py);
                                 uint32_t* dst = &tilebuf[(py - ty_top) * TILE_STRIDE + (px - x_lo)];
                                 *dst = store_blend(*dst, out15, tr.flags);
@@ -760,7 +777,7 @@ __global__ __launch_bounds__(NT) void k_blend(FillArgs a) {
                     replay_w(tr, cx0, py, w0, w1);
                     for (uint32_t px = cx0; px < cx1; ++px) {
                         float bcx, bcy, bcz; uint32_t texel;
-                        if (inside_bc(tr, w0, w1, bcx, bcy, bcz) && texel_drawn<0>(tr, bcx, bcy, bcz, a.texels, nullptr, texel)) {
+                        if (inside_bc(tr, w0, w1, bcx, bcy, bcz) && texel_drawn<0>(tr, bcx, bcy, bcz, a.texels, nullptr, texel, fp.affine != 0)) {
                             const uint32_t out15 = shade15(texel, bcx, bcy, bcz, vc1, vc2, vc3, tr.flags, shading, shv, px, py);
                             uint32_t* dst = &tilebuf[(py - ty_top) * TILE_STRIDE + (px - x_lo)];
                             *dst = store_blend(*dst, out15, tr.flags);

@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp, const B32Vertex* 
                 r.u1 = uvx[i1]; r.u2 = uvx[i2]; r.u3 = uvx[i3];
                 r.v1 = uvy[i1]; r.v2 = uvy[i2]; r.v3 = uvy[i3];
                 r.vc1 = col[i1] & 0xFFFFFF; r.vc2 = col[i2] & 0xFFFFFF; r.vc3 = col[i3] & 0xFFFFFF;
-                r.face_idx = f; r.pad0 = 0; r.pad1 = 0;
+                r.iz1 = 1.0f / v1.z; r.iz2 = 1.0f / v2.z; r.iz3 = 1.0f / v3.z;                       // :1546-1548
                 // Closed-form eligibility: with integer vertices every value the reference's incremental walk ever holds
                 // is an exact integer when |w| < 2^24 over the bbox and both start products are < 2^24.
                 bool slow = !fp.fixed_point;

@@ -7,7 +7,7 @@ vectorised UNR division on int64 arrays, `argsort(kind="stable")` for the painte
 restatements to agree bit-for-bit on whole frames; a misreading would have to be made identically in both to survive.
 
 Every function cites the reference file:line it follows (paths relative to /root/reference).
-Scope: perspective projection (fixed-point or float), painter's mode, affine textures, shading None/Flat/Gouraud with
+Scope: perspective projection (fixed-point or float), painter's mode, affine and perspective-correct textures, shading None/Flat/Gouraud with
 directional and point lights, fog, blend modes, editor alpha.
 """
 import numpy as np
@@ -304,8 +304,20 @@ def _rasterize(img, width, height, s, st):
     uv = s["uv"]
     tex = s["tex"]
     if tex is not None:
-        u = ((bcx * uv[0][0] + bcy * uv[1][0]) + bcz * uv[2][0]).astype(np.float32)                   # :1565-1566
-        v = ((bcx * uv[0][1] + bcy * uv[1][1]) + bcz * uv[2][1]).astype(np.float32)
+        if st.affine_textures:
+            u = ((bcx * uv[0][0] + bcy * uv[1][0]) + bcz * uv[2][0]).astype(np.float32)               # :1565-1566
+            v = ((bcx * uv[0][1] + bcy * uv[1][1]) + bcz * uv[2][1]).astype(np.float32)
+        else:                                                                                         # :1546-1579
+            iz = [f32(1.0) / f32(vv[2]) for vv in (v1, v2, v3)]
+            inv_z = ((bcx * iz[0] + bcy * iz[1]).astype(np.float32) + bcz * iz[2]).astype(np.float32)
+            def over_z(c):
+                t0 = ((bcx * uv[0][c]).astype(np.float32) * iz[0]).astype(np.float32)
+                t1 = ((bcy * uv[1][c]).astype(np.float32) * iz[1]).astype(np.float32)
+                t2 = ((bcz * uv[2][c]).astype(np.float32) * iz[2]).astype(np.float32)
+                return ((t0 + t1).astype(np.float32) + t2).astype(np.float32)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                u = (over_z(0) / inv_z).astype(np.float32)
+                v = (over_z(1) / inv_z).astype(np.float32)
         if tex.width == 0 or tex.height == 0 or tex.pixels.size == 0:
             texel = np.zeros(u.shape, np.int64)
         else:                                                                                         # types.rs:671-681

@@ -29,7 +29,14 @@ def fog_scene():
     return sc
 
 
+def persp_scene():
+    sc = scenegen.make_scene("C1", seed=31, bbox_px=400.0)
+    sc.settings.affine_textures = False          # perspective-correct UVs (render.rs:1568-1579)
+    return sc
+
+
 SCENES = {
+    "C1:persp": persp_scene,
     "C1": lambda: scenegen.make_scene("C1"),
     "C1:gouraud": lambda: scenegen.make_scene("C1", variant="gouraud"),
     "C1:blend": lambda: scenegen.make_scene("C1", variant="blend"),

@@ -67,7 +67,7 @@ def test_project_fixed_stage(gpu_ctx, oracle):
         assert oracle.project_fixed(pos[i], cam, 2560, 1920)[:2] == (sx[i], sy[i])
 
 
-@pytest.mark.parametrize("name", ["C1", "C1:gouraud", "C1:blend", "C1:float", "cube", "fog-flat-point-nocull", "C2", "C2:blend"])
+@pytest.mark.parametrize("name", ["C1", "C1:gouraud", "C1:blend", "C1:float", "C1:persp", "cube", "fog-flat-point-nocull", "C2", "C2:blend"])
 def test_frame_parity_small(gpu_ctx, oracle, name):
     sc = SCENES[name]()
     exp, etm, d = cpu_render(oracle, sc)
@@ -86,7 +86,7 @@ def fast_ctx(gpu_ctx):
     gpu_ctx.set_fragment_counting(1)
 
 
-@pytest.mark.parametrize("name", ["C1", "C1:gouraud", "C1:blend", "C1:float", "cube", "fog-flat-point-nocull", "C2", "C2:blend",
+@pytest.mark.parametrize("name", ["C1", "C1:gouraud", "C1:blend", "C1:float", "C1:persp", "cube", "fog-flat-point-nocull", "C2", "C2:blend",
                                   "C3:100k", "C5:20k"])
 def test_fast_path_frame_parity(fast_ctx, oracle, name):
     """Same frames through the fast path (no global depth sort, inside-test-only coverage, top-2 visibility).  C2 has tile

@@ -10,7 +10,7 @@ from tests.golden.make_golden import SCENES, render
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 HASHES = json.load(open(os.path.join(GOLD, "hashes.json")))
-FAST = ["C1", "C1:gouraud", "C1:blend", "C1:float", "cube", "fog-flat-point-nocull", "C2", "C2:blend", "C3:100k", "C5:20k"]
+FAST = ["C1", "C1:gouraud", "C1:blend", "C1:float", "C1:persp", "cube", "fog-flat-point-nocull", "C2", "C2:blend", "C3:100k", "C5:20k"]
 
 
 @pytest.mark.parametrize("name", FAST)
@@ -40,7 +40,7 @@ def test_cube_fixture(oracle):
     assert np.array_equal(fb.pixels, z["rgba"]) and np.array_equal(d["draw_order"], z["draw_order"])
 
 
-@pytest.mark.parametrize("name", ["C1", "C1:gouraud", "C1:blend", "C1:float", "cube", "fog-flat-point-nocull"])
+@pytest.mark.parametrize("name", ["C1", "C1:gouraud", "C1:blend", "C1:float", "C1:persp", "cube", "fog-flat-point-nocull"])
 def test_two_restatements_agree(oracle, name):
     """oracle/b32_oracle.c and oracle/np_model.py are two readings of the same Rust; whole frames must be identical."""
     from oracle import np_model as M
