@@ -84,6 +84,8 @@ SYMBOLS = [
     ("b32_fb_clear", C.c_int, [_P, C.c_uint8, C.c_uint8, C.c_uint8, C.c_uint8]),
     ("b32_fb_upload", C.c_int, [_P, _P]),
     ("b32_fb_download", C.c_int, [_P, _P]),
+    ("b32_zbuffer_download", C.c_int, [_P, _P]),
+    ("b32_zbuffer_upload", C.c_int, [_P, _P]),
     ("b32_fb_bind_device", C.c_int, [_P, _P, C.c_uint32, C.c_uint32]),
     ("b32_fb_size", C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("b32_set_band", C.c_int, [_P, C.c_uint32, C.c_uint32]),

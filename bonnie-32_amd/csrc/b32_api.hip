@@ -28,6 +28,7 @@ struct b32_ctx {
     uint32_t* fb_own = nullptr; size_t fb_own_px = 0;
     uint32_t* fb = nullptr; bool fb_external = false;
     uint32_t band_y0 = 0, band_y1 = 0; bool band_set = false;
+    float* zbuf = nullptr; size_t cap_zbuf = 0; bool zbuf_valid = false;   // Framebuffer::zbuffer; !valid == every entry f32::MAX
 
     // resident scene
     B32Vertex* d_verts = nullptr; size_t cap_verts = 0;
@@ -141,7 +142,7 @@ void b32_destroy(b32_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = { c->fb_own, c->d_verts, c->d_faces, c->d_texels, c->d_tex, c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->recs,
                      c->shades, c->counts, c->block_sums, c->pkeys[0], c->pkeys[1], c->pvals[0], c->pvals[1], c->block_hist, c->ranges,
-                     c->d_ctrl, c->d_consts, c->d_lights, c->digit_total, c->partials, c->vis, c->spans, c->tile_mid };
+                     c->d_ctrl, c->d_consts, c->d_lights, c->digit_total, c->partials, c->vis, c->spans, c->tile_mid, c->zbuf };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->ev_created) for (auto& fr : c->ev) for (auto& e : fr) if (e) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -184,6 +185,7 @@ int b32_fb_resize(b32_ctx* c, uint32_t w, uint32_t h) {
     }
     c->fb = c->fb_own;
     c->band_set = false;
+    c->zbuf_valid = false;                                                  // vec![f32::MAX; w*h], render.rs:22,32
     fb_set_dims(c, w, h);
     HIPCHK(c, hipMemsetAsync(c->fb, 0, px * 4, c->stream));                // vec![0; w*h*4], render.rs:18-33
     return B32_OK;
@@ -195,6 +197,7 @@ int b32_fb_bind_device(b32_ctx* c, void* dptr, uint32_t w, uint32_t h) {
     if (w == 0 || h == 0 || w > 16384 || h > 16384 || (reinterpret_cast<uintptr_t>(dptr) & 15)) return B32_E_ARG;
     c->fb = reinterpret_cast<uint32_t*>(dptr); c->fb_external = true;
     c->band_set = false;
+    c->zbuf_valid = false;
     return fb_set_dims(c, w, h);
 }
 int b32_fb_size(const b32_ctx* c, uint32_t* w, uint32_t* h) {
@@ -215,6 +218,8 @@ int b32_fb_clear(b32_ctx* c, uint8_t r, uint8_t g, uint8_t b, uint8_t blend) {
     const uint32_t rgba = r | (g << 8) | (b << 16) | (a << 24);
     // with a screen band set (multi-GPU sharding) only the rows this rank owns are cleared: the others belong to other ranks
     launch_clear(c->stream, c->fb + (size_t)c->band_y0 * c->width, (size_t)c->width * (c->band_y1 - c->band_y0), rgba);
+    if (c->zbuf && c->zbuf_valid && (size_t)c->width * c->height <= c->cap_zbuf)        // self.zbuffer[i] = f32::MAX, render.rs:43
+        launch_clear(c->stream, reinterpret_cast<uint32_t*>(c->zbuf) + (size_t)c->band_y0 * c->width, (size_t)c->width * (c->band_y1 - c->band_y0), 0x7F7FFFFFu);
     HIPCHK(c, hipGetLastError());
     return B32_OK;
 }
@@ -223,6 +228,26 @@ int b32_fb_upload(b32_ctx* c, const uint8_t* rgba) {
     (void)hipSetDevice(c->device);
     HIPCHK(c, hipMemcpyAsync(c->fb, rgba, (size_t)c->width * c->height * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return B32_OK;
+}
+int b32_zbuffer_download(b32_ctx* c, float* z) {
+    if (!c || !c->fb || !z) return B32_E_ARG;
+    (void)hipSetDevice(c->device);
+    const size_t px = (size_t)c->width * c->height;
+    if (!c->zbuf || !c->zbuf_valid) { HIPCHK(c, hipStreamSynchronize(c->stream)); for (size_t i = 0; i < px; ++i) z[i] = 3.40282347e+38f; return B32_OK; }
+    HIPCHK(c, hipMemcpyAsync(z, c->zbuf, px * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return B32_OK;
+}
+int b32_zbuffer_upload(b32_ctx* c, const float* z) {
+    if (!c || !c->fb || !z) return B32_E_ARG;
+    (void)hipSetDevice(c->device);
+    const size_t px = (size_t)c->width * c->height;
+    int rc;
+    if (px > c->cap_zbuf || !c->zbuf) { if ((rc = ensure_plain(c, c->zbuf, px + 64))) return rc; c->cap_zbuf = px; }
+    HIPCHK(c, hipMemcpyAsync(c->zbuf, z, px * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->zbuf_valid = true;
     return B32_OK;
 }
 int b32_fb_download(b32_ctx* c, uint8_t* rgba) {
@@ -355,7 +380,7 @@ int b32_scene_upload_indexed(b32_ctx* c, const B32Vertex* v, uint32_t nv, const 
 
 // ------------------------------------------------------------------ frame
 static int validate_settings(const B32Settings* st) {
-    if (st->use_zbuffer || st->has_ortho || st->xray_mode) return B32_E_UNSUPPORTED;
+    if (st->has_ortho || st->xray_mode) return B32_E_UNSUPPORTED;
     if ((st->backface_cull && st->backface_wireframe) || st->wireframe_overlay) return B32_E_UNSUPPORTED;      // wireframe phase
     if (st->shading > B32_SHADE_GOURAUD) return B32_E_ARG;
     if (st->n_lights && !st->lights) return B32_E_ARG;
@@ -380,7 +405,7 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     fp.n_lights = st->shading != B32_SHADE_NONE ? st->n_lights : 0;
     fp.ambient = st->ambient;
     fp.affine = st->affine_textures; fp.shading = st->shading; fp.backface_cull = st->backface_cull;
-    fp.dithering = st->dithering; fp.fixed_point = st->use_fixed_point; fp.has_fog = fog ? 1 : 0;
+    fp.dithering = st->dithering; fp.fixed_point = st->use_fixed_point; fp.has_fog = fog ? 1 : 0; fp.zmode = st->use_zbuffer ? 1 : 0;
     if (fog) fp.fog = *fog;
     const uint32_t ntiles = fp.tiles_x * fp.tiles_y;
     const uint32_t n_keys = 2 * ntiles;
@@ -417,6 +442,11 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
         c->cap_ranges = (size_t)n_keys + 64;
     }
 
+    if (fp.zmode) {          // Framebuffer::zbuffer (render.rs:12): allocated on first use, f32::MAX until drawn into
+        const size_t px = (size_t)c->width * c->height;
+        if (px > c->cap_zbuf || !c->zbuf) { if ((rc = ensure_plain(c, c->zbuf, px + 64))) return rc; c->cap_zbuf = px; c->zbuf_valid = false; }
+        if (!c->zbuf_valid) { launch_clear(s, reinterpret_cast<uint32_t*>(c->zbuf), px, 0x7F7FFFFFu); c->zbuf_valid = true; }
+    }
     if ((size_t)ntiles + 1 > c->cap_tile_mid || !c->tile_mid) {
         if ((rc = ensure_plain(c, c->tile_mid, (size_t)ntiles + 64))) return rc;
         c->cap_tile_mid = (size_t)ntiles + 64;
@@ -442,7 +472,7 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     if (prof_all) HIPCHK(c, hipEventRecord(ev[1], s));
 
     const SortScratch sc{ c->block_hist, c->hist_blocks, c->digit_total };
-    const bool exact_cov = c->count_fragments || !c->cheap_ok;
+    const bool exact_cov = c->count_fragments || !c->cheap_ok || fp.zmode;   // z-buffer mode: depth + skip rule per fragment
     const bool local_sort = !exact_cov && c->local_sort_ok;
     c->last_local_sort = local_sort;
     if (local_sort) {
@@ -481,7 +511,7 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     FillArgs fa{};
     fa.fp = fp; fa.recs = c->recs; fa.shades = c->shades; fa.pair_vals = c->pvals[cur]; fa.ranges = c->ranges;
     fa.keys = c->keys[0]; fa.local_sort = local_sort ? 1u : 0u; fa.tile_keys_only = fa.local_sort; fa.tile_mid = c->tile_mid;
-    fa.tex = c->d_tex; fa.texels = c->d_texels; fa.fb = c->fb; fa.vis = c->vis; fa.ctrl = c->d_ctrl;
+    fa.tex = c->d_tex; fa.texels = c->d_texels; fa.fb = c->fb; fa.vis = c->vis; fa.zbuf = c->zbuf; fa.ctrl = c->d_ctrl;
     fa.tex0 = c->nt ? c->h_tex[0] : TexDesc{ 0, 0, 0, 0 };
     fa.lds_tex_texels = 0;
     if (c->nt == 1) {
@@ -564,7 +594,7 @@ int b32_frame_finish(b32_ctx* c, B32Timings* out) {
     if (c->h_ctrl.abort) return B32_E_NAN_KEY;
     if (out) {
         out->triangles_drawn = c->h_ctrl.n_visible;
-        out->fragments = c->h_ctrl.fragments;
+        out->fragments = c->last_settings.use_zbuffer ? 0 : c->h_ctrl.fragments;     // not defined in z-buffer mode (order dependent)
         out->tile_pairs = c->h_ctrl.n_pairs;
         if (c->phase_frames && c->phase_level >= 2) {
             out->transform_ms = 0.0f;                 // fused into the per-face setup kernel

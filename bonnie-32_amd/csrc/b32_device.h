@@ -73,7 +73,7 @@ struct FrameParams {
     uint32_t nv, nf, nt;
     uint32_t n_lights;
     float ambient;
-    uint8_t affine, shading, backface_cull, dithering, fixed_point, has_fog, pad0, pad1;
+    uint8_t affine, shading, backface_cull, dithering, fixed_point, has_fog, zmode, pad1;   // zmode = settings.use_zbuffer
     B32Fog fog;
 };
 
@@ -105,6 +105,10 @@ __device__ __forceinline__ float rem_euclid1(float x) {
     float r = x - __builtin_truncf(x);
     return r < 0.0f ? r + 1.0f : r;
 }
+
+// total order on non-NaN f32 as u32 (z-buffer keys for the 64-bit LDS atomicMin) and its inverse
+__device__ __forceinline__ uint32_t zsort_key(float z) { const uint32_t b = __float_as_uint(z); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+__device__ __forceinline__ float zsort_val(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k); }
 
 // ---------------------------------------------------------------- colour helpers
 __device__ __forceinline__ uint32_t expand5(uint32_t v5) { return ((v5 << 3) | (v5 >> 2)) & 0xFF; }   // render.rs:1161-1163
@@ -207,6 +211,7 @@ struct FillArgs {
     const TexDesc* tex;
     const uint16_t* texels;
     uint32_t* fb;               // RGBA8 words, full frame
+    float* zbuf;                // z-buffer mode: Framebuffer::zbuffer (f32 per pixel, read-modify-write across calls)
     uint2* vis;                 // visibility buffer per pixel: x = winning tile-list position (1-based, 0 = uncovered), y = surface id
     TexDesc tex0;               // descriptor of texture 0 (used when nt == 1: no per-pixel descriptor gather)
     Ctrl* ctrl;

@@ -220,8 +220,30 @@ __device__ __forceinline__ Tri tri_from_mem(const FillArgs& a, uint32_t sid, con
     return r;
 }
 
+// Records a drawn fragment of list entry li in the tile buffer(s).
+//   painter's EXACT: max list position.  painter's CHEAP: exact top-2 (see k_cover).  z-buffer: min of (depth key, list position)
+//   == the first surface in face order reaching the smallest depth, what the sequential `z < zbuffer` test leaves behind.
+template <bool EXACT, bool ZMODE>
+__device__ __forceinline__ void commit_fragment(uint32_t* tilebuf, uint32_t addr, uint32_t li, uint32_t zkey) {
+    if (ZMODE) atomicMin(reinterpret_cast<unsigned long long*>(tilebuf) + addr, ((unsigned long long)zkey << 32) | li);
+    else if (EXACT) atomicMax(&tilebuf[addr], li);
+    else {
+        // exact top-2 under any arrival order: whoever loses the max (the newcomer, or the value it displaced) is a runner-up
+        // candidate; the final max is never displaced, every other value is pushed exactly once.
+        const uint32_t old = atomicMax(&tilebuf[addr], li);
+        atomicMax(&tilebuf[addr + TILE_H * TILE_STRIDE], min(old, li));
+    }
+}
+// Depth of a fragment (render.rs:1546-1550) -> sortable key; false for NaN (never passes `z < zbuffer`).
+__device__ __forceinline__ bool frag_zkey(const Tri& t, float bcx, float bcy, float bcz, uint32_t& zkey) {
+    const float inv_z = bcx * t.iz1 + bcy * t.iz2 + bcz * t.iz3;
+    const float z = 1.0f / inv_z;
+    zkey = zsort_key(z);
+    return z == z;
+}
+
 // Phase A for one surface: coverage of the (tile-clipped) bbox [cx0,cx1) x [cy0,cy1), winner value li.
-template <int TEXMODE, bool EXACT>
+template <int TEXMODE, bool EXACT, bool ZMODE>
 __device__ __forceinline__ uint32_t cover_surface(const Tri& tr, uint32_t cx0, uint32_t cx1, uint32_t cy0, uint32_t cy1, uint32_t li,
                                                   uint32_t* tilebuf, uint32_t x_lo, uint32_t ty_top, uint32_t lane,
                                                   const uint16_t* __restrict__ gtex, const uint16_t* ltex, bool affine) {
@@ -247,12 +269,10 @@ __device__ __forceinline__ uint32_t cover_surface(const Tri& tr, uint32_t cx0, u
                     float bcx, bcy, bcz;
                     if (inside_bc(tr, w0, w1, bcx, bcy, bcz)) {
                         uint32_t texel;
-                        drawn = EXACT ? texel_drawn<TEXMODE>(tr, bcx, bcy, bcz, gtex, ltex, texel, affine) : true;
-                        if (drawn) {
-                            uint32_t* t = &tilebuf[(py - ty_top) * TILE_STRIDE + (px - x_lo)];
-                            if (EXACT) atomicMax(t, li);
-                            else { const uint32_t old = atomicMax(t, li); atomicMax(t + TILE_H * TILE_STRIDE, min(old, li)); }
-                        }
+                        uint32_t zkey = 0;
+                        drawn = ZMODE ? frag_zkey(tr, bcx, bcy, bcz, zkey) : true;
+                        if (drawn && EXACT) drawn = texel_drawn<TEXMODE>(tr, bcx, bcy, bcz, gtex, ltex, texel, affine);
+                        if (drawn) commit_fragment<EXACT, ZMODE>(tilebuf, (py - ty_top) * TILE_STRIDE + (px - x_lo), li, zkey);
                     }
                 }
                 if (EXACT) drawn_count += (uint32_t)__popcll(__ballot(drawn));
@@ -269,13 +289,10 @@ __device__ __forceinline__ uint32_t cover_surface(const Tri& tr, uint32_t cx0, u
                     float bcx, bcy, bcz;
                     if (inside_bc(tr, w0, w1, bcx, bcy, bcz)) {
                         uint32_t texel;
-                        const bool drawn = EXACT ? texel_drawn<TEXMODE>(tr, bcx, bcy, bcz, gtex, ltex, texel, affine) : true;
-                        if (drawn) {
-                            uint32_t* t = &tilebuf[(py - ty_top) * TILE_STRIDE + (px - x_lo)];
-                            if (EXACT) atomicMax(t, li);
-                            else { const uint32_t old = atomicMax(t, li); atomicMax(t + TILE_H * TILE_STRIDE, min(old, li)); }
-                            ++mine;
-                        }
+                        uint32_t zkey = 0;
+                        bool drawn = ZMODE ? frag_zkey(tr, bcx, bcy, bcz, zkey) : true;
+                        if (drawn && EXACT) drawn = texel_drawn<TEXMODE>(tr, bcx, bcy, bcz, gtex, ltex, texel, affine);
+                        if (drawn) { commit_fragment<EXACT, ZMODE>(tilebuf, (py - ty_top) * TILE_STRIDE + (px - x_lo), li, zkey); ++mine; }
                     }
                     w0 += tr.a0; w1 += tr.a1;
                 }
@@ -307,7 +324,7 @@ __device__ __forceinline__ uint32_t bperm(uint32_t src_lane, uint32_t v) { retur
 __device__ __forceinline__ float bpermf(uint32_t src_lane, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), __float_as_int(v))); }
 
 // Phase A, EXACT coverage, wave-cooperative form (one wave per surface): used for F_SLOW surfaces and as reference path.
-template <int TEXMODE, bool EXACT>
+template <int TEXMODE, bool EXACT, bool ZMODE>
 __device__ __forceinline__ uint32_t cover_one(const Batch& b, int t, uint32_t li, uint32_t* tilebuf, uint32_t x_lo, uint32_t x_hi,
                                               uint32_t y_lo, uint32_t y_hi, uint32_t ty_top, uint32_t lane,
                                               const uint16_t* __restrict__ gtex, const uint16_t* ltex, bool affine) {
@@ -315,7 +332,7 @@ __device__ __forceinline__ uint32_t cover_one(const Batch& b, int t, uint32_t li
     const uint32_t cx0 = max(tr.min_x, x_lo), cx1 = min(tr.max_x, x_hi);
     const uint32_t cy0 = max(tr.min_y, y_lo), cy1 = min(tr.max_y, y_hi);
     if (cx0 >= cx1 || cy0 >= cy1) return 0;
-    return cover_surface<TEXMODE, EXACT>(tr, cx0, cx1, cy0, cy1, li, tilebuf, x_lo, ty_top, lane, gtex, ltex, affine);
+    return cover_surface<TEXMODE, EXACT, ZMODE>(tr, cx0, cx1, cy0, cy1, li, tilebuf, x_lo, ty_top, lane, gtex, ltex, affine);
 }
 
 // Phase A as a ROW-ITEM scheduler.  Waves grab 64 list entries at a time from an LDS cursor (load balance across the 16
@@ -325,7 +342,7 @@ __device__ __forceinline__ uint32_t cover_one(const Batch& b, int t, uint32_t li
 // incrementally exactly like the reference's inner loop (render.rs:1533-1707): start value = closed form at the row start
 // (exact integers under the k_setup guard), then w0 += a0, w1 += a1 per pixel.  Row lengths are far more uniform than
 // bbox areas, big surfaces fill whole rounds, and there is no per-surface scalar work.
-template <int TEXMODE, bool EXACT, int NW>
+template <int TEXMODE, bool EXACT, int NW, bool ZMODE>
 __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, uint32_t e0, uint32_t n_op, uint32_t lane, uint32_t wave,
                                                            volatile uint32_t* cursor, volatile uint32_t* wmark, const TexDesc& lds_desc,
                                                            uint32_t* tilebuf, uint32_t x_lo, uint32_t x_hi, uint32_t y_lo, uint32_t y_hi,
@@ -383,7 +400,7 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
                 tr.v1 = bpermf(s, __uint_as_float(b.q3.x)); tr.v2 = bpermf(s, __uint_as_float(b.q3.y)); tr.v3 = bpermf(s, __uint_as_float(b.q3.z));
                 tr.flags = bperm(s, flags);
                 tr.tw = bperm(s, b.tw); tr.th = bperm(s, b.th); tr.toff = bperm(s, b.toff);
-                if (!affine) { tr.iz1 = bpermf(s, __uint_as_float(b.q5.y)); tr.iz2 = bpermf(s, __uint_as_float(b.q5.z)); tr.iz3 = bpermf(s, __uint_as_float(b.q5.w)); }
+                if (!affine || ZMODE) { tr.iz1 = bpermf(s, __uint_as_float(b.q5.y)); tr.iz2 = bpermf(s, __uint_as_float(b.q5.z)); tr.iz3 = bpermf(s, __uint_as_float(b.q5.w)); }
             }
             const uint32_t rx0 = sbox & 0xFF, rx1 = (sbox >> 8) & 0xFF, ry = (sbox >> 16) + (k - sP);   // tile-local
             const uint32_t n = valid ? rx1 - rx0 : 0u;
@@ -398,16 +415,10 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
                     const float bcz = 1.0f - bcx - bcy;
                     if ((bcx >= ERR) & (bcy >= ERR) & (bcz >= ERR)) {
                         bool drawn = true;
-                        if (EXACT) { uint32_t texel; drawn = texel_drawn<TEXMODE>(tr, bcx, bcy, bcz, gtex, ltex, texel, affine); }
-                        if (drawn) {
-                            if (EXACT) { atomicMax(&tilebuf[addr], li); ++mine; }
-                            else {
-                                // exact top-2 under any arrival order: whoever loses the max (the newcomer, or the value it displaced)
-                                // is a runner-up candidate; the final max is never displaced, every other value is pushed once.
-                                const uint32_t old = atomicMax(&tilebuf[addr], li);
-                                atomicMax(&tilebuf[addr + TILE_H * TILE_STRIDE], min(old, li));
-                            }
-                        }
+                        uint32_t zkey = 0;
+                        if (ZMODE) drawn = frag_zkey(tr, bcx, bcy, bcz, zkey);
+                        if (EXACT && drawn) { uint32_t texel; drawn = texel_drawn<TEXMODE>(tr, bcx, bcy, bcz, gtex, ltex, texel, affine); }
+                        if (drawn) { commit_fragment<EXACT, ZMODE>(tilebuf, addr, li, zkey); ++mine; }
                     }
                     ++addr; w0 += sa0; w1 += sa1;
                 }
@@ -422,7 +433,7 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
         while (sm) {
             const int t = __builtin_ctzll(sm);
             sm &= sm - 1;
-            frags += cover_one<TEXMODE, EXACT>(b, t, cs + (uint32_t)t + 1, tilebuf, x_lo, x_hi, y_lo, y_hi, ty_top, lane, gtex, ltex, affine);
+            frags += cover_one<TEXMODE, EXACT, ZMODE>(b, t, cs + (uint32_t)t + 1, tilebuf, x_lo, x_hi, y_lo, y_hi, ty_top, lane, gtex, ltex, affine);
         }
     }
     (void)wave;
@@ -508,7 +519,7 @@ __device__ void tile_local_sort(uint32_t* sort_area, uint32_t* wcnt, volatile ui
 }
 
 // ------------------------------------------------------------------------------------------------ k_cover
-template <int TEXMODE, bool EXACT, int NT>
+template <int TEXMODE, bool EXACT, int NT, bool ZMODE>
 __global__ __launch_bounds__(NT) void k_cover(FillArgs a) {
     constexpr int NW = NT / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -558,15 +569,25 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a) {
         } else {
             e0 = a.ranges[2 * tile]; e1 = a.ranges[2 * tile + 1];
         }
-        for (uint32_t i = tid; i < (EXACT ? 1 : 2) * TILE_H * TILE_STRIDE; i += NT) tilebuf[i] = 0;
-        __syncthreads();
         const uint32_t txi = tile % fp.tiles_x, tyi = tile / fp.tiles_x + fp.tile_y0;
         const uint32_t x_lo = txi * TILE_W, x_hi = min(x_lo + TILE_W, fp.width);
         const uint32_t ty_top = tyi * TILE_H;
         const uint32_t y_lo = max(ty_top, fp.band_y0), y_hi = min(ty_top + TILE_H, fp.band_y1);
+        if (ZMODE) {        // 64-bit entries (depth key << 32 | list position), seeded with the current z-buffer: a fragment wins
+            unsigned long long* t64 = reinterpret_cast<unsigned long long*>(tilebuf);       // only with a strictly smaller depth
+            for (uint32_t p = tid; p < TILE_W * TILE_H; p += NT) {
+                const uint32_t row = p >> 6, col = p & 63;
+                const uint32_t px = x_lo + col, py = ty_top + row;
+                const bool inb = px < x_hi && py >= y_lo && py < y_hi;
+                t64[row * TILE_STRIDE + col] = inb ? ((unsigned long long)zsort_key(a.zbuf[(size_t)py * fp.width + px]) << 32) : 0ull;
+            }
+        } else {
+            for (uint32_t i = tid; i < (EXACT ? 1 : 2) * TILE_H * TILE_STRIDE; i += NT) tilebuf[i] = 0;
+        }
+        __syncthreads();
         const uint32_t n_op = e1 - e0;
         if (n_op) {
-            frag_count += phase_a_rows<TEXMODE, EXACT, NW>(a, e0, n_op, lane, wave, &misc[2], wmarks + wave * 64, lds_desc, tilebuf,
+            frag_count += phase_a_rows<TEXMODE, EXACT, NW, ZMODE>(a, e0, n_op, lane, wave, &misc[2], wmarks + wave * 64, lds_desc, tilebuf,
                                                            x_lo, x_hi, y_lo, y_hi, ty_top, ltex);
             __syncthreads();
         }
@@ -575,7 +596,12 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a) {
             const uint32_t row = p >> 6, col = p & 63;
             const uint32_t px = x_lo + col, py = ty_top + row;
             if (px < x_hi && py >= y_lo && py < y_hi) {
-                const uint32_t li = tilebuf[row * TILE_STRIDE + col];
+                uint32_t li;
+                if (ZMODE) {
+                    const unsigned long long e = reinterpret_cast<const unsigned long long*>(tilebuf)[row * TILE_STRIDE + col];
+                    li = (uint32_t)e;
+                    if (li) a.zbuf[(size_t)py * fp.width + px] = zsort_val((uint32_t)(e >> 32));   // fb.zbuffer[idx] = z, render.rs:1686-1688
+                } else li = tilebuf[row * TILE_STRIDE + col];
                 const uint32_t sid = li ? a.pair_vals[e0 + li - 1] : 0u;                // resolve the surface id here: one level
                 // less in k_shade's dependent gather chain.  CHEAP coverage: the runner-up travels in the high half when the
                 // tile list is short enough (< 32768 entries); bit 31 marks a long list whose runner-up is unknown.
@@ -589,7 +615,8 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a) {
         }
         __syncthreads();   // everyone is done with misc / tilebuf before the next tile
     }
-    if (EXACT) {           // fragment-store count (wave-uniform per wave): one same-address atomic per workgroup
+    if (EXACT && !ZMODE) { // fragment-store count (wave-uniform per wave): one same-address atomic per workgroup
+                           // (not defined in z-buffer mode: which fragments pass `z < zbuffer` depends on the sequential order)
         unsigned long long* wf = reinterpret_cast<unsigned long long*>(smem);
         __syncthreads();
         if (lane == 0) wf[wave] = frag_count;
@@ -708,10 +735,20 @@ __global__ __launch_bounds__(256) void k_shade(FillArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ k_blend
+// Depth test of the transparent pass in z-buffer mode (no z write).  Editor-alpha stores reject on `z >= zbuffer`
+// (render.rs:595-605), plain stores draw on `z < zbuffer` (render.rs:1683); the two differ only for NaN depths.
+__device__ __forceinline__ bool ztest(const Tri& t, float bcx, float bcy, float bcz, int zmode, float zb) {
+    if (!zmode) return true;
+    const float inv_z = bcx * t.iz1 + bcy * t.iz2 + bcz * t.iz3;
+    const float z = 1.0f / inv_z;
+    return ((t.flags >> F_ALPHA_SHIFT) < 255) ? !(z >= zb) : (z < zb);
+}
+
 template <int NT>
 __global__ __launch_bounds__(NT) void k_blend(FillArgs a) {
     constexpr int NW = NT / 64;
     __shared__ uint32_t tilebuf[TILE_H * TILE_STRIDE];
+    __shared__ float tilez[TILE_H * TILE_STRIDE];      // z-buffer mode: depth of the tile (read only: the transparent pass never writes z)
     __shared__ unsigned long long wf[NW];
     if (a.ctrl->abort || a.ctrl->need_global_sort) return;
     const FrameParams& fp = a.fp;
@@ -729,7 +766,9 @@ __global__ __launch_bounds__(NT) void k_blend(FillArgs a) {
     for (uint32_t p = tid; p < TILE_W * TILE_H; p += NT) {
         const uint32_t row = p >> 6, col = p & 63;
         const uint32_t px = x_lo + col, py = ty_top + row;
-        tilebuf[row * TILE_STRIDE + col] = (px < x_hi && py >= y_lo && py < y_hi) ? a.fb[(size_t)py * fp.width + px] : 0u;
+        const bool inb = px < x_hi && py >= y_lo && py < y_hi;
+        tilebuf[row * TILE_STRIDE + col] = inb ? a.fb[(size_t)py * fp.width + px] : 0u;
+        if (fp.zmode) tilez[row * TILE_STRIDE + col] = inb ? a.zbuf[(size_t)py * fp.width + px] : 0.0f;
     }
     __syncthreads();
     unsigned long long frag_count = 0;
@@ -760,7 +799,8 @@ __global__ __launch_bounds__(NT) void k_blend(FillArgs a) {
                         if (px < cx1 && py < cy1) {
                             float w0, w1, bcx, bcy, bcz; uint32_t texel;
                             edge_w(tr, px, py, w0, w1);
-                            if (inside_bc(tr, w0, w1, bcx, bcy, bcz) && texel_drawn<0>(tr, bcx, bcy, bcz, a.texels, nullptr, texel, fp.affine != 0)) {
+                            if (inside_bc(tr, w0, w1, bcx, bcy, bcz) && ztest(tr, bcx, bcy, bcz, fp.zmode, tilez[(py - ty_top) * TILE_STRIDE + (px - x_lo)]) &&
+                                texel_drawn<0>(tr, bcx, bcy, bcz, a.texels, nullptr, texel, fp.affine != 0)) {
                                 const uint32_t out15 = shade15(texel, bcx, bcy, bcz, vc1, vc2, vc3, tr.flags, shading, shv, px, py);
                                 uint32_t* dst = &tilebuf[(py - ty_top) * TILE_STRIDE + (px - x_lo)];
                                 *dst = store_blend(*dst, out15, tr.flags);
@@ -777,7 +817,8 @@ __global__ __launch_bounds__(NT) void k_blend(FillArgs a) {
                     replay_w(tr, cx0, py, w0, w1);
                     for (uint32_t px = cx0; px < cx1; ++px) {
                         float bcx, bcy, bcz; uint32_t texel;
-                        if (inside_bc(tr, w0, w1, bcx, bcy, bcz) && texel_drawn<0>(tr, bcx, bcy, bcz, a.texels, nullptr, texel, fp.affine != 0)) {
+                        if (inside_bc(tr, w0, w1, bcx, bcy, bcz) && ztest(tr, bcx, bcy, bcz, fp.zmode, tilez[(py - ty_top) * TILE_STRIDE + (px - x_lo)]) &&
+                            texel_drawn<0>(tr, bcx, bcy, bcz, a.texels, nullptr, texel, fp.affine != 0)) {
                             const uint32_t out15 = shade15(texel, bcx, bcy, bcz, vc1, vc2, vc3, tr.flags, shading, shv, px, py);
                             uint32_t* dst = &tilebuf[(py - ty_top) * TILE_STRIDE + (px - x_lo)];
                             *dst = store_blend(*dst, out15, tr.flags);
@@ -809,17 +850,19 @@ __global__ __launch_bounds__(NT) void k_blend(FillArgs a) {
 void launch_fill(hipStream_t s, const FillArgs& a, int n_cu, hipEvent_t after_cover) {
     const uint32_t ntiles = a.fp.tiles_x * a.fp.tiles_y;
     if (ntiles == 0) return;
-    if (a.exact_coverage) {
+    if (a.fp.zmode) {
+        hipLaunchKernelGGL((k_cover<0, true, 512, true>), dim3(min(ntiles, (uint32_t)n_cu * 3)), dim3(512), LDS_TEX_OFFSET + LDS_SORT_CNT_BYTES + 2048, s, a);
+    } else if (a.exact_coverage) {
         if (a.lds_tex_texels) {     // texture sampled once per fragment: stage it in LDS, one 16-wave workgroup per CU
             const size_t lds = LDS_TEX_OFFSET + (((size_t)a.lds_tex_texels * 2 + 15) & ~(size_t)15);
             static bool attr_set = false;
-            if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<1, true, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
-            hipLaunchKernelGGL((k_cover<1, true, 1024>), dim3(min(ntiles, (uint32_t)n_cu)), dim3(1024), lds, s, a);
+            if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<1, true, 1024, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+            hipLaunchKernelGGL((k_cover<1, true, 1024, false>), dim3(min(ntiles, (uint32_t)n_cu)), dim3(1024), lds, s, a);
         } else {
-            hipLaunchKernelGGL((k_cover<0, true, 512>), dim3(min(ntiles, (uint32_t)n_cu * 2)), dim3(512), LDS_TEX_OFFSET, s, a);
+            hipLaunchKernelGGL((k_cover<0, true, 512, false>), dim3(min(ntiles, (uint32_t)n_cu * 2)), dim3(512), LDS_TEX_OFFSET, s, a);
         }
     } else {
-        hipLaunchKernelGGL((k_cover<0, false, 512>), dim3(min(ntiles, (uint32_t)n_cu * 3)), dim3(512), LDS_TEX_OFFSET + LDS_SORT_CNT_BYTES + 2048, s, a);
+        hipLaunchKernelGGL((k_cover<0, false, 512, false>), dim3(min(ntiles, (uint32_t)n_cu * 3)), dim3(512), LDS_TEX_OFFSET + LDS_SORT_CNT_BYTES + 2048, s, a);
     }
     if (after_cover) (void)hipEventRecord(after_cover, s);
     const uint32_t band_h = a.fp.band_y1 - a.fp.band_y0;

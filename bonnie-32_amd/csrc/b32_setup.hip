@@ -272,10 +272,14 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp, const B32Vertex* 
                 // is free: bit 31 = transparent class, low 31 bits = 0x7FFFFFFF - bits(z) => ascending radix == descending z,
                 // stability of the LSD passes == stability of slice::sort_by.
                 float kz = (v1.z + v2.z + v3.z) / 3.0f;
+                // z-buffer mode never sorts the opaque list (render.rs:2535): key 0 keeps it in face order through the stable
+                // passes, and a NaN key there is never compared
+                if (fp.zmode && !transparent) kz = 0.0f;
                 if (kz != kz) { nan_key = true; kz = 0.0f; }
                 if (kz == 0.0f) kz = 0.0f;                    // -0.0 == +0.0 under partial_cmp
                 uint32_t zb = __float_as_uint(kz);
                 key = ((0x7FFFFFFFu - (zb & 0x7FFFFFFFu)) & 0x7FFFFFFFu) | (transparent ? 0x80000000u : 0u);
+                if (fp.zmode && !transparent) key = 0;
                 if (key == KEY_INVALID) key = 0xFFFFFFFEu;    // unreachable for z > 5; keeps the sentinel unique
             }
         }

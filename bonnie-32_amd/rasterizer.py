@@ -128,6 +128,13 @@ class Framebuffer:
         _chk(self.ctx.lib.b32_fb_download(self.ctx.h, out.ctypes.data), "fb_download")
         return out
 
+    @property
+    def zbuffer(self):
+        """Framebuffer::zbuffer (render.rs:12): f32 per pixel, f32::MAX where nothing was drawn in z-buffer mode."""
+        out = np.empty(self.width * self.height, np.float32)
+        _chk(self.ctx.lib.b32_zbuffer_download(self.ctx.h, out.ctypes.data), "zbuffer_download")
+        return out
+
     def image(self):
         return self.pixels.reshape(self.height, self.width, 4)
 

@@ -29,7 +29,7 @@ extern "C" {
 #define B32_E_INDEX       -2  /* face.v* >= nv            [index panic, render.rs:2375-2377] */
 #define B32_E_NAN_KEY     -3  /* NaN painter's key        [unwrap panic, render.rs:2531]     */
 #define B32_E_HIP         -4  /* HIP runtime failure (b32_last_hip_error has the code)      */
-#define B32_E_UNSUPPORTED -5  /* setting outside SURVEY §8 scope (z-buffer, ortho, xray, wireframe, spot light) */
+#define B32_E_UNSUPPORTED -5  /* setting outside SURVEY §8 scope (ortho, xray, wireframe phases, spot light) */
 #define B32_E_NO_DEVICE   -6  /* no gfx950 device / kernels missing: the product path never falls back to CPU   */
 
 /* ---- enums mirrored as integers ------------------------------------------ */
@@ -161,6 +161,9 @@ int b32_fb_resize(b32_ctx* ctx, uint32_t width, uint32_t height);           /* F
 int b32_fb_clear(b32_ctx* ctx, uint8_t r, uint8_t g, uint8_t b, uint8_t blend); /* Framebuffer::clear :36-45 (rows of the band only when b32_set_band is active) */
 int b32_fb_upload(b32_ctx* ctx, const uint8_t* rgba);                        /* host fb.pixels -> device */
 int b32_fb_download(b32_ctx* ctx, uint8_t* rgba);                            /* device -> host fb.pixels */
+/* Framebuffer::zbuffer (render.rs:12), used when settings.use_zbuffer: f32 per pixel, f32::MAX after new/resize/clear. */
+int b32_zbuffer_download(b32_ctx* ctx, float* z);
+int b32_zbuffer_upload(b32_ctx* ctx, const float* z);
 /* Draw into caller-owned DEVICE memory (width*height*4 B, e.g. a torch uint8 tensor) instead of the
  * ctx-owned buffer; pass NULL to return to the ctx-owned buffer. */
 int b32_fb_bind_device(b32_ctx* ctx, void* device_rgba, uint32_t width, uint32_t height);

@@ -7,7 +7,7 @@ vectorised UNR division on int64 arrays, `argsort(kind="stable")` for the painte
 restatements to agree bit-for-bit on whole frames; a misreading would have to be made identically in both to survive.
 
 Every function cites the reference file:line it follows (paths relative to /root/reference).
-Scope: perspective projection (fixed-point or float), painter's mode, affine and perspective-correct textures, shading None/Flat/Gouraud with
+Scope: perspective projection (fixed-point or float), painter's and z-buffer mode, affine and perspective-correct textures, shading None/Flat/Gouraud with
 directional and point lights, fog, blend modes, editor alpha.
 """
 import numpy as np
@@ -181,9 +181,11 @@ def shade_multi(normal, wpos, lights, ambient):
 
 
 # ---------------------------------------------------------------- render_mesh_15, render.rs:2302-2572
-def render_mesh_15(pixels, width, height, vertices, faces, textures, camera, settings, fog=None):
-    """Draw into `pixels` (uint8 [H*W*4]); returns dict(triangles_drawn, fragments, draw_order, sx, sy)."""
+def render_mesh_15(pixels, width, height, vertices, faces, textures, camera, settings, fog=None, zbuffer=None):
+    """Draw into `pixels` (uint8 [H*W*4]) (and `zbuffer` f32 [H*W] when settings.use_zbuffer); returns dict(triangles_drawn,
+    fragments, draw_order, sx, sy)."""
     img = pixels.reshape(height, width, 4)
+    zb = zbuffer.reshape(height, width) if settings.use_zbuffer else None
     pos = vertices["pos"].astype(np.float32)
     nv = len(vertices)
     cpos = np.asarray(camera.position, np.float32)
@@ -261,17 +263,20 @@ def render_mesh_15(pixels, width, height, vertices, faces, textures, camera, set
         if len(ids) >= 2 and np.isnan(key[ids]).any():
             raise FloatingPointError("NaN sort key")                                                 # unwrap panic :2531
         return ids[np.argsort(-key[ids], kind="stable")] if len(ids) else ids
-    draw = list(painter(opaque)) + list(painter(transp))
+    # opaque surfaces are sorted only in painter's mode (render.rs:2535); the transparent pass always is
+    draw = (list(opaque) if settings.use_zbuffer else list(painter(opaque))) + list(painter(transp))
+    n_opaque = len(opaque)
 
     fragments = 0
-    for si in draw:
-        fragments += _rasterize(img, width, height, surfaces[si], settings)
+    for k, si in enumerate(draw):
+        fragments += _rasterize(img, width, height, surfaces[si], settings, zb, skip_z_write=k >= n_opaque)
     return dict(triangles_drawn=len(surfaces), fragments=fragments, draw_order=np.array([surfaces[i]["face"] for i in draw], np.uint32),
                 sx=sx, sy=sy, sz=scr[:, 2])
 
 
-def _rasterize(img, width, height, s, st):
-    """rasterize_triangle_15, render.rs:1440-1714, painter's mode, whole bbox at once."""
+def _rasterize(img, width, height, s, st, zb=None, skip_z_write=False):
+    """rasterize_triangle_15, render.rs:1440-1714, whole bbox at once (one triangle touches a pixel once, so the sequential
+    z-buffer semantics hold within the call)."""
     v1, v2, v3 = s["v"]
     min_x = int(as_usize(rmax(rmin(rmin(v1[0], v2[0]), v3[0]), f32(0.0))))                            # :1455-1458
     max_x = int(as_usize(rmin(rmax(rmax(v1[0], v2[0]), v3[0]) + f32(1.0), f32(width))))
@@ -301,6 +306,13 @@ def _rasterize(img, width, height, s, st):
     bcz = ((f32(1.0) - bcx) - bcy).astype(np.float32)                                                 # :1538
     E = f32(-0.0001)
     inside = (bcx >= E) & (bcy >= E) & (bcz >= E)                                                     # :1542
+    zgrid = None
+    if zb is not None:                                                                                # :1546-1560
+        izs = [f32(1.0) / f32(vv[2]) for vv in (v1, v2, v3)]
+        inv_zi = ((bcx * izs[0] + bcy * izs[1]).astype(np.float32) + bcz * izs[2]).astype(np.float32)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            zgrid = (f32(1.0) / inv_zi).astype(np.float32)
+            inside = inside & ~(zgrid >= zb[min_y:max_y, min_x:max_x])
     uv = s["uv"]
     tex = s["tex"]
     if tex is not None:
@@ -338,9 +350,14 @@ def _rasterize(img, width, height, s, st):
         texel = np.where(texel == 0, 0x8000, texel)
     if s["alpha"] == 0:                                                                               # :1664-1669
         return 0
+    if zb is not None and s["alpha"] == 255:                                                          # :1681-1683 `z < zbuffer`
+        with np.errstate(invalid="ignore"):
+            drawn = drawn & (zgrid < zb[min_y:max_y, min_x:max_x])
     ys, xs = np.nonzero(drawn)
     if len(ys) == 0:
         return 0
+    if zb is not None and not skip_z_write:                                                           # :1686-1688, render.rs:603-605
+        zb[ys + min_y, xs + min_x] = zgrid[ys, xs]
     bx, by, bz, tx_ = bcx[ys, xs], bcy[ys, xs], bcz[ys, xs], texel[ys, xs]
     px, py = xs + min_x, ys + min_y
     chans = [(tx_ >> 10) & 31, (tx_ >> 5) & 31, tx_ & 31]

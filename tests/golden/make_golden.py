@@ -35,8 +35,17 @@ def persp_scene():
     return sc
 
 
+def zbuf_scene(variant="bench", seed=17):
+    sc = scenegen.make_scene("C1", seed=seed, variant=variant, bbox_px=150.0)
+    sc.settings.use_zbuffer = True               # the reference's default / RasterSettings::game() (types.rs:1455-1495)
+    return sc
+
+
 SCENES = {
     "C1:persp": persp_scene,
+    "C1:zbuf": zbuf_scene,
+    "C1:zbuf-blend": lambda: zbuf_scene("blend", 19),
+    "C1:zbuf-gouraud": lambda: zbuf_scene("gouraud", 23),
     "C1": lambda: scenegen.make_scene("C1"),
     "C1:gouraud": lambda: scenegen.make_scene("C1", variant="gouraud"),
     "C1:blend": lambda: scenegen.make_scene("C1", variant="blend"),
@@ -63,7 +72,8 @@ def main():
     for name, mk in SCENES.items():
         sc = mk()
         fb, tm, d = render(sc)
-        hashes[name] = {"sha256": hashlib.sha256(fb.pixels).hexdigest(), "triangles_drawn": tm.triangles_drawn,
+        hashes[name] = {"sha256": hashlib.sha256(fb.pixels).hexdigest(), "zbuffer_sha256": hashlib.sha256(fb.zbuffer.tobytes()).hexdigest(),
+                        "triangles_drawn": tm.triangles_drawn,
                         "fragments": tm.fragments, "width": sc.width, "height": sc.height,
                         "draw_order_sha256": hashlib.sha256(d["draw_order"].tobytes()).hexdigest(),
                         "scene_sha256": hashlib.sha256(sc.vertices.tobytes() + sc.faces.tobytes() + sc.textures[0].pixels.tobytes()).hexdigest()}

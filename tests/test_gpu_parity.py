@@ -132,6 +132,58 @@ def test_fast_path_full_size_c3(fast_ctx, oracle):
     assert np.array_equal(assembled, exp)
 
 
+@pytest.mark.parametrize("name", ["C1:zbuf", "C1:zbuf-blend", "C1:zbuf-gouraud"])
+def test_zbuffer_mode_parity(gpu_ctx, oracle, name):
+    """use_zbuffer=true (the reference's default / RasterSettings::game()): framebuffer AND z-buffer bit-exact, opaque list
+    in face order, transparent pass depth-tested without z writes."""
+    from bonnie32_amd import rasterizer as R
+    sc = SCENES[name]()
+    ofb = oracle.Framebuffer(sc.width, sc.height); ofb.clear(sc.clear_color)
+    rc, etm, d = oracle.render_mesh_15(ofb, sc.vertices, sc.faces, sc.textures, sc.camera, sc.settings, sc.fog, dump=True)
+    assert rc == 0
+    assert hashlib.sha256(ofb.pixels).hexdigest() == HASHES[name]["sha256"]
+    for resident in (False, True):
+        fb = R.Framebuffer(sc.width, sc.height, gpu_ctx); fb.clear(sc.clear_color)
+        if resident:
+            tm = R.ResidentScene(fb, sc.vertices, sc.faces, sc.textures).render(sc.camera, sc.settings, sc.fog)
+        else:
+            tm = R.render_mesh_15(fb, sc.vertices, sc.faces, sc.textures, sc.camera, sc.settings, sc.fog)
+        assert np.array_equal(fb.pixels, ofb.pixels)
+        assert np.array_equal(fb.zbuffer.view(np.uint32), ofb.zbuffer.view(np.uint32))
+        assert tm.triangles_drawn == etm.triangles_drawn
+        assert np.array_equal(gpu_ctx.last_draw_order(len(sc.faces)), d["draw_order"])
+
+
+def test_zbuffer_persists_across_calls_and_clear_resets(gpu_ctx, oracle):
+    """fb.zbuffer is read-modify-write across render_mesh_15 calls (scene.rs:215/165) and Framebuffer::clear resets it."""
+    from bonnie32_amd import rasterizer as R
+    a = SCENES["C1:zbuf"](); b = SCENES["C1:zbuf-blend"](); c = scenegen.make_scene("C1", seed=5)    # c: painter's mode onto the same fb
+    ofb = oracle.Framebuffer(a.width, a.height); ofb.clear(a.clear_color)
+    fb = R.Framebuffer(a.width, a.height, gpu_ctx); fb.clear(a.clear_color)
+    assert np.all(fb.zbuffer == np.finfo(np.float32).max)
+    for sc in (a, b, c, a):
+        oracle.render_mesh_15(ofb, sc.vertices, sc.faces, sc.textures, sc.camera, sc.settings)
+        R.render_mesh_15(fb, sc.vertices, sc.faces, sc.textures, sc.camera, sc.settings)
+        assert np.array_equal(fb.pixels, ofb.pixels)
+        assert np.array_equal(fb.zbuffer.view(np.uint32), ofb.zbuffer.view(np.uint32))
+    ofb.clear(a.clear_color); fb.clear(a.clear_color)
+    assert np.array_equal(fb.zbuffer.view(np.uint32), ofb.zbuffer.view(np.uint32))
+    oracle.render_mesh_15(ofb, b.vertices, b.faces, b.textures, b.camera, b.settings)
+    R.render_mesh_15(fb, b.vertices, b.faces, b.textures, b.camera, b.settings)
+    assert np.array_equal(fb.pixels, ofb.pixels) and np.array_equal(fb.zbuffer.view(np.uint32), ofb.zbuffer.view(np.uint32))
+
+
+def test_zbuffer_mode_large_frame(gpu_ctx, oracle):
+    sc = scenegen.make_scene("C3", n_tris=150_000)
+    sc.settings.use_zbuffer = True
+    ofb = oracle.Framebuffer(sc.width, sc.height); ofb.clear(sc.clear_color)
+    rc, etm = oracle.render_mesh_15(ofb, sc.vertices, sc.faces, sc.textures, sc.camera, sc.settings)
+    from bonnie32_amd import rasterizer as R
+    fb = R.Framebuffer(sc.width, sc.height, gpu_ctx); fb.clear(sc.clear_color)
+    R.ResidentScene(fb, sc.vertices, sc.faces, indexed_textures=sc.indexed_textures).render(sc.camera, sc.settings)
+    assert np.array_equal(fb.pixels, ofb.pixels) and np.array_equal(fb.zbuffer.view(np.uint32), ofb.zbuffer.view(np.uint32))
+
+
 def test_c1_against_committed_frame(gpu_ctx):
     z = np.load(os.path.join(GOLD, "c1_frame.npz"))
     got, tm = gpu_render(gpu_ctx, SCENES["C1"]())
@@ -251,7 +303,8 @@ def test_error_behaviour(gpu_ctx, oracle):
     with pytest.raises(R.B32Error) as e:
         R.render_mesh_15(fb, vn, sc.faces, sc.textures, sc.camera, nc)
     assert e.value.code == b32.abi.B32_E_NAN_KEY and np.array_equal(fb.pixels, before)
-    for st in (b32.RasterSettings(), b32.RasterSettings(use_zbuffer=True, backface_wireframe=False)):
+    for st in (b32.RasterSettings(), b32.RasterSettings(xray_mode=True, backface_wireframe=False),
+               b32.RasterSettings(ortho_projection=(1.0, 0.0, 0.0), backface_wireframe=False)):
         with pytest.raises(R.B32Error) as e:
             R.render_mesh_15(fb, sc.vertices, sc.faces, sc.textures, sc.camera, st)
         assert e.value.code == b32.abi.B32_E_UNSUPPORTED

@@ -10,7 +10,7 @@ from tests.golden.make_golden import SCENES, render
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 HASHES = json.load(open(os.path.join(GOLD, "hashes.json")))
-FAST = ["C1", "C1:gouraud", "C1:blend", "C1:float", "C1:persp", "cube", "fog-flat-point-nocull", "C2", "C2:blend", "C3:100k", "C5:20k"]
+FAST = ["C1", "C1:zbuf", "C1:zbuf-blend", "C1:zbuf-gouraud", "C1:gouraud", "C1:blend", "C1:float", "C1:persp", "cube", "fog-flat-point-nocull", "C2", "C2:blend", "C3:100k", "C5:20k"]
 
 
 @pytest.mark.parametrize("name", FAST)
@@ -21,6 +21,7 @@ def test_oracle_matches_golden_hash(oracle, name):
     assert scene_sha == g["scene_sha256"], "scene generator is not deterministic"
     fb, tm, d = render(sc)
     assert hashlib.sha256(fb.pixels).hexdigest() == g["sha256"]
+    assert hashlib.sha256(fb.zbuffer.tobytes()).hexdigest() == g["zbuffer_sha256"]
     assert (tm.triangles_drawn, tm.fragments) == (g["triangles_drawn"], g["fragments"])
     assert hashlib.sha256(d["draw_order"].tobytes()).hexdigest() == g["draw_order_sha256"]
 
@@ -40,7 +41,8 @@ def test_cube_fixture(oracle):
     assert np.array_equal(fb.pixels, z["rgba"]) and np.array_equal(d["draw_order"], z["draw_order"])
 
 
-@pytest.mark.parametrize("name", ["C1", "C1:gouraud", "C1:blend", "C1:float", "C1:persp", "cube", "fog-flat-point-nocull"])
+@pytest.mark.parametrize("name", ["C1", "C1:gouraud", "C1:blend", "C1:float", "C1:persp", "cube", "fog-flat-point-nocull",
+                                  "C1:zbuf", "C1:zbuf-blend", "C1:zbuf-gouraud"])
 def test_two_restatements_agree(oracle, name):
     """oracle/b32_oracle.c and oracle/np_model.py are two readings of the same Rust; whole frames must be identical."""
     from oracle import np_model as M
@@ -48,8 +50,11 @@ def test_two_restatements_agree(oracle, name):
     fb, tm, d = render(sc)
     px = np.zeros(sc.width * sc.height * 4, np.uint8)
     px.reshape(-1, 4)[:] = [sc.clear_color.r, sc.clear_color.g, sc.clear_color.b, 255]
-    r = M.render_mesh_15(px, sc.width, sc.height, sc.vertices, sc.faces, sc.textures, sc.camera, sc.settings, sc.fog)
+    zb = np.full(sc.width * sc.height, np.finfo(np.float32).max, np.float32)
+    r = M.render_mesh_15(px, sc.width, sc.height, sc.vertices, sc.faces, sc.textures, sc.camera, sc.settings, sc.fog, zbuffer=zb)
     assert np.array_equal(px, fb.pixels)
+    if sc.settings.use_zbuffer:
+        assert np.array_equal(zb.view(np.uint32), fb.zbuffer.view(np.uint32))
     assert np.array_equal(r["draw_order"], d["draw_order"])
     assert (r["triangles_drawn"], r["fragments"]) == (tm.triangles_drawn, tm.fragments)
     assert np.array_equal(r["sz"], d["sz"])
