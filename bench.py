@@ -94,6 +94,7 @@ def main():
                 if rank == 0:
                     frame.copy_(host)
 
+    ctx.set_fragment_counting(1)          # warmup frames count the reference's pixel stores exactly (Mpixels/s numerator)
     # warmup (also settles buffer capacities: finish() grows the pair buffers if the first frame overflowed them)
     step(first=True)
     tm = rs.finish()

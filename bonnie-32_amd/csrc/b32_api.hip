@@ -40,7 +40,8 @@ struct b32_ctx {
     bool have_scene = false;
     bool may_blend = true;              // some face / texture can produce a transparent-pass surface (render.rs:2403-2415)
     bool cheap_ok = false;              // every texture has few skippable texels: CHEAP coverage + repair is profitable
-    int count_fragments = 1;            // 1: exact fragment-store count every frame (EXACT coverage)
+    int count_fragments = 0;            // 1: exact fragment-store count every frame (EXACT coverage); instrumentation, off by default
+    bool last_exact = false;            // the last frame ran EXACT coverage in painter's mode (B32Timings.fragments is exact)
 
     // per-face work buffers
     size_t cap_work = 0;
@@ -475,6 +476,7 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     const bool exact_cov = c->count_fragments || !c->cheap_ok || fp.zmode;   // z-buffer mode: depth + skip rule per fragment
     const bool local_sort = !exact_cov && c->local_sort_ok;
     c->last_local_sort = local_sort;
+    c->last_exact = exact_cov && !fp.zmode;
     if (local_sort) {
         // fast path: no global depth sort.  Pairs are emitted in face order from k_setup's spans; k_cover sorts every tile
         // list by depth key in LDS (stable, so ties keep face order).
@@ -594,7 +596,7 @@ int b32_frame_finish(b32_ctx* c, B32Timings* out) {
     if (c->h_ctrl.abort) return B32_E_NAN_KEY;
     if (out) {
         out->triangles_drawn = c->h_ctrl.n_visible;
-        out->fragments = c->last_settings.use_zbuffer ? 0 : c->h_ctrl.fragments;     // not defined in z-buffer mode (order dependent)
+        out->fragments = c->last_exact ? c->h_ctrl.fragments : 0;     // exact only with fragment counting on, painter's mode
         out->tile_pairs = c->h_ctrl.n_pairs;
         if (c->phase_frames && c->phase_level >= 2) {
             out->transform_ms = 0.0f;                 // fused into the per-face setup kernel

@@ -225,9 +225,9 @@ int b32_last_kernel_times(b32_ctx* ctx, const char** names, float* ms, uint32_t 
  * b32_frame_finish calls (last 64 at most) are returned by b32_last_kernel_times / B32Timings. */
 int b32_set_profiling(b32_ctx* ctx, int level);
 /* B32Timings.fragments (the reference's pixel-store count, render.rs:1671-1702) is instrumentation, not an output of
- * render_mesh_15.  on = 1 (default): counted exactly every frame.  on = 0: B32Timings.fragments is only exact for
- * frames whose textures force exact coverage; the fill may then resolve opaque visibility without fetching the texel
- * of every overdrawn fragment (identical framebuffer, see b32_fill.hip). */
+ * render_mesh_15.  on = 0 (default): not counted (B32Timings.fragments = 0 unless the textures force exact coverage); the fill
+ * may then resolve opaque visibility without fetching the texel of every overdrawn fragment and without a global depth
+ * sort (identical framebuffer, see b32_fill.hip).  on = 1: every fragment is evaluated and counted exactly (painter's mode). */
 int b32_set_fragment_counting(b32_ctx* ctx, int on);
 
 #ifdef __cplusplus

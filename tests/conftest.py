@@ -26,4 +26,6 @@ def gpu_ctx():
     import __graft_entry__ as g
     g.build()
     from bonnie32_amd import rasterizer as R
-    return R.Context(0)
+    ctx = R.Context(0)
+    ctx.set_fragment_counting(1)      # instrumented path: exact coverage + exact fragment-store counts (tests compare them)
+    return ctx

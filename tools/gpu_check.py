@@ -13,6 +13,7 @@ from bonnie32_amd import rasterizer as R, scenegen  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
 ctx = R.Context(0)
+ctx.set_fragment_counting(1)
 
 
 def check(name, sc, resident=False, indexed=False):
