@@ -60,7 +60,7 @@ struct b32_ctx {
     uint32_t* partials = nullptr; uint32_t partial_blocks = 0;
     // tiles
     uint32_t* ranges = nullptr; size_t cap_ranges = 0;
-    uint2* vis = nullptr; size_t cap_vis = 0;
+    uint32_t* vis = nullptr; size_t cap_vis = 0;
     // control
     Ctrl* d_ctrl = nullptr; uint32_t* d_consts = nullptr; Ctrl h_ctrl{};
     B32Light* d_lights = nullptr; size_t cap_lights = 0; std::vector<B32Light> h_lights;

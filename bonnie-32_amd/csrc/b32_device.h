@@ -212,7 +212,7 @@ struct FillArgs {
     const uint16_t* texels;
     uint32_t* fb;               // RGBA8 words, full frame
     float* zbuf;                // z-buffer mode: Framebuffer::zbuffer (f32 per pixel, read-modify-write across calls)
-    uint2* vis;                 // visibility buffer per pixel: x = winning tile-list position (1-based, 0 = uncovered), y = surface id
+    uint32_t* vis;              // visibility buffer per pixel: winning tile-list position (1-based, 0 = uncovered) [+ runner-up << 16]
     TexDesc tex0;               // descriptor of texture 0 (used when nt == 1: no per-pixel descriptor gather)
     Ctrl* ctrl;
     uint32_t lds_tex_texels;    // > 0: every face samples texture 0 and it is staged in LDS (width*height texels)

@@ -409,18 +409,36 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
             uint32_t addr = ry * TILE_STRIDE + rx0;
             const uint32_t li = cs + s + 1;
             uint32_t mine = 0;
-            for (uint32_t i = 0; __ballot(i < n); ++i) {
-                if (i < n) {
-                    const float bcx = w0 * sinv, bcy = w1 * sinv;
-                    const float bcz = 1.0f - bcx - bcy;
-                    if ((bcx >= ERR) & (bcy >= ERR) & (bcz >= ERR)) {
-                        bool drawn = true;
-                        uint32_t zkey = 0;
-                        if (ZMODE) drawn = frag_zkey(tr, bcx, bcy, bcz, zkey);
-                        if (EXACT && drawn) { uint32_t texel; drawn = texel_drawn<TEXMODE>(tr, bcx, bcy, bcz, gtex, ltex, texel, affine); }
-                        if (drawn) { commit_fragment<EXACT, ZMODE>(tilebuf, addr, li, zkey); ++mine; }
+            if (EXACT || ZMODE) {
+                for (uint32_t i = 0; __ballot(i < n); ++i) {
+                    if (i < n) {
+                        const float bcx = w0 * sinv, bcy = w1 * sinv;
+                        const float bcz = 1.0f - bcx - bcy;
+                        if ((bcx >= ERR) & (bcy >= ERR) & (bcz >= ERR)) {
+                            bool drawn = true;
+                            uint32_t zkey = 0;
+                            if (ZMODE) drawn = frag_zkey(tr, bcx, bcy, bcz, zkey);
+                            if (EXACT && drawn) { uint32_t texel; drawn = texel_drawn<TEXMODE>(tr, bcx, bcy, bcz, gtex, ltex, texel, affine); }
+                            if (drawn) { commit_fragment<EXACT, ZMODE>(tilebuf, addr, li, zkey); ++mine; }
+                        }
+                        ++addr; w0 += sa0; w1 += sa1;
                     }
-                    ++addr; w0 += sa0; w1 += sa1;
+                }
+            } else {
+                // CHEAP coverage: two pixels per trip, so the two returning LDS atomics are in flight together and the wave
+                // waits once per pair (the second value is the same sequential accumulation w + a the reference performs)
+                for (uint32_t i = 0; __ballot(i < n); i += 2) {
+                    const float w0b = w0 + sa0, w1b = w1 + sa1;
+                    const float ax = w0 * sinv, ay = w1 * sinv, bx = w0b * sinv, by = w1b * sinv;
+                    const float az = 1.0f - ax - ay, bz = 1.0f - bx - by;
+                    const bool ina = (i < n) & (ax >= ERR) & (ay >= ERR) & (az >= ERR);
+                    const bool inb = (i + 1 < n) & (bx >= ERR) & (by >= ERR) & (bz >= ERR);
+                    uint32_t olda = 0, oldb = 0;
+                    if (ina) olda = atomicMax(&tilebuf[addr], li);
+                    if (inb) oldb = atomicMax(&tilebuf[addr + 1], li);
+                    if (ina) atomicMax(&tilebuf[addr + TILE_H * TILE_STRIDE], min(olda, li));
+                    if (inb) atomicMax(&tilebuf[addr + 1 + TILE_H * TILE_STRIDE], min(oldb, li));
+                    addr += 2; w0 = w0b + sa0; w1 = w1b + sa1;
                 }
             }
             if (EXACT) {
@@ -602,15 +620,14 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a) {
                     li = (uint32_t)e;
                     if (li) a.zbuf[(size_t)py * fp.width + px] = zsort_val((uint32_t)(e >> 32));   // fb.zbuffer[idx] = z, render.rs:1686-1688
                 } else li = tilebuf[row * TILE_STRIDE + col];
-                const uint32_t sid = li ? a.pair_vals[e0 + li - 1] : 0u;                // resolve the surface id here: one level
-                // less in k_shade's dependent gather chain.  CHEAP coverage: the runner-up travels in the high half when the
-                // tile list is short enough (< 32768 entries); bit 31 marks a long list whose runner-up is unknown.
+                // CHEAP coverage: the runner-up travels in the high half when the tile list is short enough (< 32768 entries);
+                // bit 31 marks a long list whose runner-up is unknown.
                 uint32_t packed = li;
                 if (!EXACT) {
                     const uint32_t second = tilebuf[TILE_H * TILE_STRIDE + row * TILE_STRIDE + col];
                     packed = n_op < 0x8000u ? (li | (second << 16)) : (li | 0x80000000u);     // bit 31 = long list, no runner-up
                 }
-                a.vis[(size_t)py * fp.width + px] = make_uint2(packed, sid);
+                a.vis[(size_t)py * fp.width + px] = packed;
             }
         }
         __syncthreads();   // everyone is done with misc / tilebuf before the next tile
@@ -688,16 +705,16 @@ __global__ __launch_bounds__(256) void k_shade(FillArgs a) {
     for (uint32_t r = strip * 16 + wave; r < strip * 16 + 16; r += 4) {
     const uint32_t py = ty_top + r;
     if (py < fp.band_y0 || py >= fp.band_y1) continue;
-    const uint2 ve = inb ? a.vis[(size_t)py * W + px] : make_uint2(0u, 0u);
-    if (!__ballot(ve.x != 0)) continue;
+    const uint32_t ve = inb ? a.vis[(size_t)py * W + px] : 0u;
+    if (!__ballot(ve != 0)) continue;
     // decode (CHEAP coverage packs the runner-up list position in the high half, see k_cover)
-    const bool long_list = !a.exact_coverage && (ve.x >> 31);
-    const uint32_t li = a.exact_coverage ? ve.x : (long_list ? (ve.x & 0x7FFFFFFFu) : (ve.x & 0xFFFFu));
-    const uint32_t second = (a.exact_coverage || long_list) ? 0u : (ve.x >> 16);
+    const bool long_list = !a.exact_coverage && (ve >> 31);
+    const uint32_t li = a.exact_coverage ? ve : (long_list ? (ve & 0x7FFFFFFFu) : (ve & 0xFFFFu));
+    const uint32_t second = (a.exact_coverage || long_list) ? 0u : (ve >> 16);
     Hit h;
     bool have = false;
     uint32_t scan_from = 0;                     // > 0: list positions <= scan_from still have to be searched
-    if (li && !(have = hit_test(a, ve.y, px, py, h))) {
+    if (li && !(have = hit_test(a, a.pair_vals[e0 + li - 1], px, py, h))) {
         // CHEAP coverage only: the top surface is skipped at this pixel -> highest surface below it whose fragment is drawn.
         if (long_list) scan_from = li - 1;
         else if (second) {                      // exact runner-up from k_cover: almost always the answer (else ~1/256 again)
