@@ -61,6 +61,9 @@ struct b32_ctx {
     // tiles
     uint32_t* ranges = nullptr; size_t cap_ranges = 0;
     uint32_t* vis = nullptr; size_t cap_vis = 0;
+    // wireframe phases (allocated on first use)
+    WireTri* wire = nullptr; size_t cap_wire = 0;
+    uint32_t *wire_owner = nullptr, *wire_first = nullptr; size_t cap_wire_table = 0;
     // control
     Ctrl* d_ctrl = nullptr; uint32_t* d_consts = nullptr; Ctrl h_ctrl{};
     B32Light* d_lights = nullptr; size_t cap_lights = 0; std::vector<B32Light> h_lights;
@@ -143,7 +146,8 @@ void b32_destroy(b32_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = { c->fb_own, c->d_verts, c->d_faces, c->d_texels, c->d_tex, c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->recs,
                      c->shades, c->counts, c->block_sums, c->pkeys[0], c->pkeys[1], c->pvals[0], c->pvals[1], c->block_hist, c->ranges,
-                     c->d_ctrl, c->d_consts, c->d_lights, c->digit_total, c->partials, c->vis, c->spans, c->tile_mid, c->zbuf };
+                     c->d_ctrl, c->d_consts, c->d_lights, c->digit_total, c->partials, c->vis, c->spans, c->tile_mid, c->zbuf,
+                     c->wire, c->wire_owner, c->wire_first };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->ev_created) for (auto& fr : c->ev) for (auto& e : fr) if (e) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -381,8 +385,6 @@ int b32_scene_upload_indexed(b32_ctx* c, const B32Vertex* v, uint32_t nv, const 
 
 // ------------------------------------------------------------------ frame
 static int validate_settings(const B32Settings* st) {
-    if (st->has_ortho || st->xray_mode) return B32_E_UNSUPPORTED;
-    if ((st->backface_cull && st->backface_wireframe) || st->wireframe_overlay) return B32_E_UNSUPPORTED;      // wireframe phase
     if (st->shading > B32_SHADE_GOURAUD) return B32_E_ARG;
     if (st->n_lights && !st->lights) return B32_E_ARG;
     if (st->shading != B32_SHADE_NONE)
@@ -408,6 +410,11 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     fp.affine = st->affine_textures; fp.shading = st->shading; fp.backface_cull = st->backface_cull;
     fp.dithering = st->dithering; fp.fixed_point = st->use_fixed_point; fp.has_fog = fog ? 1 : 0; fp.zmode = st->use_zbuffer ? 1 : 0;
     if (fog) fp.fog = *fog;
+    fp.ortho = st->has_ortho ? 1 : 0; fp.xray = st->xray_mode ? 1 : 0;
+    fp.ortho_zoom = st->ortho_zoom; fp.ortho_cx = st->ortho_center_x; fp.ortho_cy = st->ortho_center_y;
+    const bool wire_back = st->backface_cull && st->backface_wireframe;      // render.rs:2577
+    const bool wire_front = st->wireframe_overlay != 0;                       // render.rs:2603 (an empty list draws nothing either way)
+    fp.wire_collect = (wire_back || wire_front) ? 1 : 0;
     const uint32_t ntiles = fp.tiles_x * fp.tiles_y;
     const uint32_t n_keys = 2 * ntiles;
     int rc;
@@ -457,6 +464,17 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
         c->cap_vis = (size_t)c->width * c->height;
     }
 
+    if (fp.wire_collect && c->nf) {
+        if ((size_t)c->nf > c->cap_wire || !c->wire) { if ((rc = ensure_plain(c, c->wire, (size_t)c->nf + 16))) return rc; c->cap_wire = c->nf; }
+        size_t slots = 1024;
+        while (slots < (size_t)c->nf * 6) slots <<= 1;                        // load factor <= 0.5 with all 3*nf edges distinct
+        if (wire_back && (slots > c->cap_wire_table || !c->wire_owner)) {
+            if ((rc = ensure_plain(c, c->wire_owner, slots))) return rc;
+            if ((rc = ensure_plain(c, c->wire_first, slots))) return rc;
+            c->cap_wire_table = slots;
+        }
+    }
+
     const bool prof_all = c->profile_level >= 2, prof_fill = c->profile_level >= 1;
     hipEvent_t* ev = nullptr;
     if (prof_fill) {
@@ -469,14 +487,15 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
 
     if (c->nf == 0) HIPCHK(c, hipMemsetAsync(c->d_ctrl, 0, sizeof(Ctrl), s));    // otherwise k_setup resets it
     if (prof_all) HIPCHK(c, hipEventRecord(ev[0], s));
-    launch_setup(s, fp, c->d_verts, c->d_faces, c->d_tex, c->d_lights, c->recs, c->shades, c->keys[0], c->spans, c->partials, c->d_ctrl);
+    launch_setup(s, fp, c->d_verts, c->d_faces, c->d_tex, c->d_lights, c->recs, c->shades, c->keys[0], c->spans, c->partials, c->d_ctrl, c->wire);
     if (prof_all) HIPCHK(c, hipEventRecord(ev[1], s));
 
     const SortScratch sc{ c->block_hist, c->hist_blocks, c->digit_total };
     const bool exact_cov = c->count_fragments || !c->cheap_ok || fp.zmode;   // z-buffer mode: depth + skip rule per fragment
-    const bool local_sort = !exact_cov && c->local_sort_ok;
+    // the fast path reads the class from bit 31 of the depth key and has no ordered opaque walk: not for ortho / x-ray frames
+    const bool local_sort = !exact_cov && c->local_sort_ok && !fp.ortho && !fp.xray;
     c->last_local_sort = local_sort;
-    c->last_exact = exact_cov && !fp.zmode;
+    c->last_exact = fp.xray ? true : (exact_cov && !fp.zmode);              // x-ray: every store goes through the counted ordered pass
     if (local_sort) {
         // fast path: no global depth sort.  Pairs are emitted in face order from k_setup's spans; k_cover sorts every tile
         // list by depth key in LDS (stable, so ties keep face order).
@@ -490,6 +509,11 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
         launch_radix_pass(s, c->keys[1], c->vals[1], c->keys[0], c->vals[0], &c->d_ctrl->n_visible, c->nf, 8, 8, sc);
         launch_radix_pass(s, c->keys[0], c->vals[0], c->keys[1], c->vals[1], &c->d_ctrl->n_visible, c->nf, 16, 8, sc);
         launch_radix_pass(s, c->keys[1], c->vals[1], c->keys[0], c->vals[0], &c->d_ctrl->n_visible, c->nf, 24, 8, sc);
+        if (fp.ortho) {      // 32-bit depth keys: the opaque/transparent partition is a fifth stable pass on the class
+            launch_class_keys(s, c->recs, c->vals[0], &c->d_ctrl->n_visible, c->nf, c->keys[0]);
+            launch_radix_pass(s, c->keys[0], c->vals[0], c->keys[1], c->vals[1], &c->d_ctrl->n_visible, c->nf, 0, 8, sc);
+            HIPCHK(c, hipMemcpyAsync(c->vals[0], c->vals[1], (size_t)c->nf * 4, hipMemcpyDeviceToDevice, s));
+        }
         if (prof_all) HIPCHK(c, hipEventRecord(ev[2], s));
         launch_bin(s, fp, c->recs, c->vals[0], c->d_ctrl, c->counts, c->block_sums, c->bin_blocks, c->pkeys[0], c->pvals[0], (uint32_t)c->cap_pairs);
     }
@@ -523,7 +547,16 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     fa.exact_coverage = exact_cov ? 1u : 0u;
     if (!fa.exact_coverage) fa.lds_tex_texels = 0;      // CHEAP coverage: one texel fetch per output pixel, served by L1/L2
     fa.may_blend = c->may_blend ? 1u : 0u;
+    fa.skip_solid = wire_front ? 1u : 0u;
     launch_fill(s, fa, c->n_cu, prof_fill ? ev[4] : nullptr);
+    if (fp.wire_collect && c->nf) {
+        WireArgs wa{};
+        wa.tris = c->wire; wa.nf = c->nf; wa.table_owner = c->wire_owner; wa.table_first = c->wire_first;
+        wa.table_mask = c->cap_wire_table ? (uint32_t)(c->cap_wire_table - 1) : 0;
+        wa.fb = c->fb; wa.zbuf = (c->zbuf && c->zbuf_valid) ? c->zbuf : nullptr;
+        wa.width = c->width; wa.height = c->height; wa.band_y0 = c->band_y0; wa.band_y1 = c->band_y1; wa.ctrl = c->d_ctrl;
+        launch_wire(s, wa, wire_back, wire_front);
+    }
     if (prof_fill) { if (prof_all) HIPCHK(c, hipEventRecord(ev[5], s)); c->ev_frames++; }
     HIPCHK(c, hipGetLastError());
     return B32_OK;
@@ -594,6 +627,7 @@ int b32_frame_finish(b32_ctx* c, B32Timings* out) {
     if (c->h_ctrl.pairs_overflow) return B32_E_HIP;
     if (c->h_ctrl.err_index) return B32_E_INDEX;
     if (c->h_ctrl.abort) return B32_E_NAN_KEY;
+    if (c->h_ctrl.wire_overflow) return B32_E_UNSUPPORTED;     // an edge >= 2^30 px long: i32 overflow in the reference's Bresenham
     if (out) {
         out->triangles_drawn = c->h_ctrl.n_visible;
         out->fragments = c->last_exact ? c->h_ctrl.fragments : 0;     // exact only with fragment counting on, painter's mode

@@ -59,6 +59,8 @@ struct Ctrl {
     uint32_t tile_cursor;      // persistent-workgroup tile dispenser of k_fill
     uint32_t nf;               // copy of the face count (first sort pass length)
     uint32_t need_global_sort; // a tile list exceeded the LDS sort capacity: redraw with the global depth sort
+    uint32_t wire_overflow;    // a wireframe edge is >= 2^30 pixels long: the reference's i32 Bresenham state overflows
+    uint32_t pad;
     unsigned long long fragments;
 };
 
@@ -74,8 +76,14 @@ struct FrameParams {
     uint32_t n_lights;
     float ambient;
     uint8_t affine, shading, backface_cull, dithering, fixed_point, has_fog, zmode, pad1;   // zmode = settings.use_zbuffer
+    uint8_t ortho, xray, wire_collect, pad2;   // ortho_projection.is_some(), xray_mode, any wireframe phase wants its triangles
+    float ortho_zoom, ortho_cx, ortho_cy;      // OrthoProjection (types.rs), math.rs:140-148
     B32Fog fog;
 };
+
+// Triangle of the wireframe phases (render.rs:2445-2449, 2509-2511, 2574-2635): screen coordinates `as i32`, depth as is.
+struct WireTri { int32_t x[3], y[3]; float z[3]; uint32_t kind; };   // kind: 0 none, 1 back-face, 2 front-face
+static_assert(sizeof(WireTri) == 40, "WireTri layout");
 
 // ---------------------------------------------------------------- Rust-semantics helpers (device)
 // `f as u32/usize` for the value ranges this path produces: NaN -> 0, negative -> 0, saturating.
@@ -184,7 +192,8 @@ void launch_radix_pass(hipStream_t s, const uint32_t* keys_in, const uint32_t* v
 // `partials[block*8 + k]`; k_after_setup reduces them into Ctrl.  (One same-address atomic per wave costs ~12 ns each and
 // serialises: 15.6 k waves = the whole kernel time at 1 M faces.)
 void launch_setup(hipStream_t s, const FrameParams& fp, const B32Vertex* verts, const B32Face* faces, const TexDesc* tex,
-                  const B32Light* lights, SurfRec* recs, float* shades, uint32_t* keys, uint32_t* spans, uint32_t* partials, Ctrl* ctrl);
+                  const B32Light* lights, SurfRec* recs, float* shades, uint32_t* keys, uint32_t* spans, uint32_t* partials, Ctrl* ctrl,
+                  WireTri* wire);
 void launch_project_fixed(hipStream_t s, const float* pos, uint32_t n, B32Camera cam, uint32_t w, uint32_t h,
                           int32_t* sx, int32_t* sy, float* z);
 void launch_selftest(hipStream_t s, int op, const float* a, const float* b, const float* c, float* out, uint32_t n);
@@ -196,6 +205,19 @@ void launch_bin(hipStream_t s, const FrameParams& fp, const SurfRec* recs, const
 // Fast path: pairs straight from k_setup's per-face spans, in face order (the per-tile LDS sort of k_cover orders them).
 void launch_bin_faces(hipStream_t s, const FrameParams& fp, const uint32_t* spans, const uint32_t* keys, const uint32_t* partials,
                       Ctrl* ctrl, uint32_t* pair_keys, uint32_t* pair_vals, uint32_t pair_cap, int with_class);
+// Orthographic depth keys use all 32 bits, so the opaque/transparent partition (render.rs:2522-2523) is one more stable pass
+// on a class key: keys_out[i] = transparent(recs[order[i]]) for i < *n_dev.
+void launch_class_keys(hipStream_t s, const SurfRec* recs, const uint32_t* order, const uint32_t* n_dev, uint32_t n_cap, uint32_t* keys_out);
+// Wireframe phases (render.rs:2574-2635).  kind 1: back-face edges, first occurrence per screen-space edge, depth-tested
+// (draw_line_3d, render.rs:757-817); kind 2: front-face overlay, no depth test (draw_line, render.rs:716-750).
+struct WireArgs {
+    const WireTri* tris; uint32_t nf;
+    uint32_t* table_owner; uint32_t* table_first; uint32_t table_mask;    // open-addressed edge table (power-of-two size)
+    uint32_t* fb; const float* zbuf;                                        // zbuf == nullptr: every depth is f32::MAX
+    uint32_t width, height, band_y0, band_y1;
+    Ctrl* ctrl;
+};
+void launch_wire(hipStream_t s, const WireArgs& a, bool back, bool front);
 void launch_tile_ranges(hipStream_t s, const uint32_t* pair_keys, const Ctrl* ctrl, uint32_t pair_cap, uint32_t* ranges, uint32_t n_keys);
 
 struct FillArgs {
@@ -218,6 +240,7 @@ struct FillArgs {
     uint32_t lds_tex_texels;    // > 0: every face samples texture 0 and it is staged in LDS (width*height texels)
     uint32_t may_blend;         // 0: no face/texture can be in the transparent pass -> k_blend is not launched
     uint32_t exact_coverage;    // 1: phase A applies the full skip rule and counts fragment stores; 0: CHEAP coverage + repair
+    uint32_t skip_solid;        // wireframe_overlay: surfaces are counted but not drawn (render.rs:2550)
 };
 void launch_fill(hipStream_t s, const FillArgs& a, int n_cu, hipEvent_t after_cover = nullptr);   // k_cover [event] k_shade k_blend
 size_t fill_lds_tex_budget();   // bytes of LDS left for a staged texture

@@ -119,9 +119,15 @@ __device__ __forceinline__ uint32_t shade15(uint32_t texel, float bcx, float bcy
 }
 
 // Pixel store of the transparent pass in painter's mode (render.rs:1674-1680, 1695-1702) on an RGBA8 word.
-__device__ __forceinline__ uint32_t store_blend(uint32_t back, uint32_t out15, uint32_t flags) {
+__device__ __forceinline__ uint32_t store_blend(uint32_t back, uint32_t out15, uint32_t flags, bool xray) {
     const uint32_t mode = (flags >> F_BLEND_SHIFT) & 7u, alpha = flags >> F_ALPHA_SHIFT;
     const uint32_t front = c15_to_rgba(out15);
+    if (xray) {                                                  // set_pixel_xray_15, render.rs:507-526: (front + back) / 2 per channel
+        uint32_t o = 0xFF000000u;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) o |= ((((front >> (8 * i)) & 255) + ((back >> (8 * i)) & 255)) >> 1) << (8 * i);
+        return o;
+    }
     const bool do_blend = (out15 & 0x8000) && mode != B32_BLEND_OPAQUE;
     if (alpha < 255) {                                           // set_pixel_with_editor_alpha_15, render.rs:567-591
         const uint32_t ps1 = do_blend ? blend_rgb555(front, back, mode) : front;
@@ -770,9 +776,12 @@ __global__ __launch_bounds__(NT) void k_blend(FillArgs a) {
     if (a.ctrl->abort || a.ctrl->need_global_sort) return;
     const FrameParams& fp = a.fp;
     const uint32_t tile = blockIdx.x;
-    const uint32_t e1 = a.tile_keys_only ? a.tile_mid[tile] : a.ranges[2 * tile + 1];
+    // x-ray: every surface blends (render.rs:1671-1673), so the ordered pass walks the opaque list too, then the transparent one
+    const bool xray = fp.xray != 0;
+    const uint32_t e1 = a.tile_keys_only ? a.tile_mid[tile] : a.ranges[2 * tile + (xray ? 0 : 1)];
     const uint32_t e2 = a.tile_keys_only ? a.ranges[tile + 1] : a.ranges[2 * tile + 2];
     if (e1 == e2) return;
+    const int zmode = (fp.zmode && !xray) ? 1 : 0;               // x-ray skips the depth test (render.rs:1553)
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const int shading = fp.shading;
@@ -785,7 +794,7 @@ __global__ __launch_bounds__(NT) void k_blend(FillArgs a) {
         const uint32_t px = x_lo + col, py = ty_top + row;
         const bool inb = px < x_hi && py >= y_lo && py < y_hi;
         tilebuf[row * TILE_STRIDE + col] = inb ? a.fb[(size_t)py * fp.width + px] : 0u;
-        if (fp.zmode) tilez[row * TILE_STRIDE + col] = inb ? a.zbuf[(size_t)py * fp.width + px] : 0.0f;
+        if (zmode) tilez[row * TILE_STRIDE + col] = inb ? a.zbuf[(size_t)py * fp.width + px] : 0.0f;
     }
     __syncthreads();
     unsigned long long frag_count = 0;
@@ -816,11 +825,11 @@ __global__ __launch_bounds__(NT) void k_blend(FillArgs a) {
                         if (px < cx1 && py < cy1) {
                             float w0, w1, bcx, bcy, bcz; uint32_t texel;
                             edge_w(tr, px, py, w0, w1);
-                            if (inside_bc(tr, w0, w1, bcx, bcy, bcz) && ztest(tr, bcx, bcy, bcz, fp.zmode, tilez[(py - ty_top) * TILE_STRIDE + (px - x_lo)]) &&
+                            if (inside_bc(tr, w0, w1, bcx, bcy, bcz) && ztest(tr, bcx, bcy, bcz, zmode, tilez[(py - ty_top) * TILE_STRIDE + (px - x_lo)]) &&
                                 texel_drawn<0>(tr, bcx, bcy, bcz, a.texels, nullptr, texel, fp.affine != 0)) {
                                 const uint32_t out15 = shade15(texel, bcx, bcy, bcz, vc1, vc2, vc3, tr.flags, shading, shv, px, py);
                                 uint32_t* dst = &tilebuf[(py - ty_top) * TILE_STRIDE + (px - x_lo)];
-                                *dst = store_blend(*dst, out15, tr.flags);
+                                *dst = store_blend(*dst, out15, tr.flags, xray);
                                 drawn = true;
                             }
                         }
@@ -834,11 +843,11 @@ __global__ __launch_bounds__(NT) void k_blend(FillArgs a) {
                     replay_w(tr, cx0, py, w0, w1);
                     for (uint32_t px = cx0; px < cx1; ++px) {
                         float bcx, bcy, bcz; uint32_t texel;
-                        if (inside_bc(tr, w0, w1, bcx, bcy, bcz) && ztest(tr, bcx, bcy, bcz, fp.zmode, tilez[(py - ty_top) * TILE_STRIDE + (px - x_lo)]) &&
+                        if (inside_bc(tr, w0, w1, bcx, bcy, bcz) && ztest(tr, bcx, bcy, bcz, zmode, tilez[(py - ty_top) * TILE_STRIDE + (px - x_lo)]) &&
                             texel_drawn<0>(tr, bcx, bcy, bcz, a.texels, nullptr, texel, fp.affine != 0)) {
                             const uint32_t out15 = shade15(texel, bcx, bcy, bcz, vc1, vc2, vc3, tr.flags, shading, shv, px, py);
                             uint32_t* dst = &tilebuf[(py - ty_top) * TILE_STRIDE + (px - x_lo)];
-                            *dst = store_blend(*dst, out15, tr.flags);
+                            *dst = store_blend(*dst, out15, tr.flags, xray);
                             ++mine;
                         }
                         w0 += tr.a0; w1 += tr.a1;
@@ -867,6 +876,12 @@ __global__ __launch_bounds__(NT) void k_blend(FillArgs a) {
 void launch_fill(hipStream_t s, const FillArgs& a, int n_cu, hipEvent_t after_cover) {
     const uint32_t ntiles = a.fp.tiles_x * a.fp.tiles_y;
     if (ntiles == 0) return;
+    if (a.skip_solid) { if (after_cover) (void)hipEventRecord(after_cover, s); return; }   // wireframe_overlay: nothing solid is drawn (render.rs:2550)
+    if (a.fp.xray) {                                             // no overwrite pass at all: everything goes through the ordered blend
+        if (after_cover) (void)hipEventRecord(after_cover, s);
+        hipLaunchKernelGGL((k_blend<1024>), dim3(ntiles), dim3(1024), 0, s, a);
+        return;
+    }
     if (a.fp.zmode) {
         hipLaunchKernelGGL((k_cover<0, true, 512, true>), dim3(min(ntiles, (uint32_t)n_cu * 3)), dim3(512), LDS_TEX_OFFSET + LDS_SORT_CNT_BYTES + 2048, s, a);
     } else if (a.exact_coverage) {

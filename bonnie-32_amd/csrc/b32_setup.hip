@@ -137,7 +137,8 @@ __device__ __forceinline__ uint32_t fog_color(uint32_t c, uint32_t fogc, float f
 __global__ __launch_bounds__(256) void k_setup(FrameParams fp, const B32Vertex* __restrict__ verts, const B32Face* __restrict__ faces,
                                                const TexDesc* __restrict__ tex, const B32Light* __restrict__ lights,
                                                SurfRec* __restrict__ recs, float* __restrict__ shades, uint32_t* __restrict__ keys,
-                                               uint32_t* __restrict__ spans, uint32_t* __restrict__ partials, Ctrl* __restrict__ ctrl) {
+                                               uint32_t* __restrict__ spans, uint32_t* __restrict__ partials, Ctrl* __restrict__ ctrl,
+                                               WireTri* __restrict__ wire) {
     __shared__ uint32_t wpart[4][6];
     if (blockIdx.x == 0 && threadIdx.x < sizeof(Ctrl) / 4) reinterpret_cast<uint32_t*>(ctrl)[threadIdx.x] = 0;   // frame-start reset (no memset launch)
     const uint32_t f = blockIdx.x * 256u + threadIdx.x;
@@ -164,7 +165,10 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp, const B32Vertex* 
                 V3 rel = sub3(pos, cpos);
                 V3 cp = { dot3(rel, bx), dot3(rel, by), dot3(rel, bz) };       // perspective_transform, math.rs:103-109
                 camz[j] = cp.z;
-                if (fp.fixed_point) {                                            // render.rs:2329-2345
+                if (fp.ortho) {                                                  // render.rs:2323-2328, project_ortho math.rs:140-148
+                    scr[j] = { (cp.x - fp.ortho_cx) * fp.ortho_zoom + ((float)fp.width / 2.0f),
+                               -(cp.y - fp.ortho_cy) * fp.ortho_zoom + ((float)fp.height / 2.0f), cp.z };
+                } else if (fp.fixed_point) {                                     // render.rs:2329-2345
                     int32_t sx, sy;
                     project_fixed_dev(pos.x, pos.y, pos.z, k, sx, sy);
                     scr[j] = { (float)sx, (float)sy, cp.z + 5.0f };
@@ -177,10 +181,9 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp, const B32Vertex* 
                                     (cp.y * 4.0f) / denom * vs + ((float)fp.height / 2.0f), denom };
                 }
             }
-            bool keep = !(camz[0] <= 0.1f || camz[1] <= 0.1f || camz[2] <= 0.1f);   // near plane, render.rs:2381-2385
+            bool keep = fp.ortho || !(camz[0] <= 0.1f || camz[1] <= 0.1f || camz[2] <= 0.1f);   // near plane, render.rs:2381-2385
             float signed_area = (scr[1].x - scr[0].x) * (scr[2].y - scr[0].y) - (scr[2].x - scr[0].x) * (scr[1].y - scr[0].y);
             bool backface = signed_area <= 0.0f;                                     // render.rs:2393-2394
-            if (backface && fp.backface_cull) keep = false;
             const bool have_tex = tid != B32_NO_TEXTURE && tid < fp.nt;             // textures.get(id)
             uint32_t tex_blend = B32_BLEND_OPAQUE;
             if (keep && have_tex) tex_blend = tex[tid].blend_mode;
@@ -192,6 +195,14 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp, const B32Vertex* 
                     for (int j = 0; j < 3; ++j) col[j] = fog_color(col[j], fogc, fog_factor(camz[j], fp.fog.start, fp.fog.falloff));
                 }
             }
+            if (fp.wire_collect) {                       // wireframe lists take the face before the solid decision (render.rs:2445-2449, 2509-2511)
+                WireTri wt;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { wt.x[j] = f2i32_sat(scr[j].x); wt.y[j] = f2i32_sat(scr[j].y); wt.z[j] = scr[j].z; }
+                wt.kind = !keep ? 0u : (backface ? (fp.xray ? 0u : 1u) : 2u);
+                wire[f] = wt;
+            }
+            if (backface && fp.backface_cull && !fp.xray) keep = false;              // render.rs:2451-2453
             if (keep) {
                 visible = true;
                 transparent = (have_tex && tex_blend != B32_BLEND_OPAQUE) || face_blend != B32_BLEND_OPAQUE || editor_alpha < 255;  // :2403-2415
@@ -221,7 +232,7 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp, const B32Vertex* 
                 r.iz1 = 1.0f / v1.z; r.iz2 = 1.0f / v2.z; r.iz3 = 1.0f / v3.z;                       // :1546-1548
                 // Closed-form eligibility: with integer vertices every value the reference's incremental walk ever holds
                 // is an exact integer when |w| < 2^24 over the bbox and both start products are < 2^24.
-                bool slow = !fp.fixed_point;
+                bool slow = !fp.fixed_point || fp.ortho;
                 if (!slow && !empty) {
                     const float lim = 4194304.0f;   // 2^22
                     if (!(__builtin_fabsf(v1.x) <= lim && __builtin_fabsf(v1.y) <= lim && __builtin_fabsf(v2.x) <= lim &&
@@ -279,12 +290,16 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp, const B32Vertex* 
                 if (kz == 0.0f) kz = 0.0f;                    // -0.0 == +0.0 under partial_cmp
                 uint32_t zb = __float_as_uint(kz);
                 key = ((0x7FFFFFFFu - (zb & 0x7FFFFFFFu)) & 0x7FFFFFFFu) | (transparent ? 0x80000000u : 0u);
+                // orthographic depths may be negative: all 32 bits order the depth (descending), the class partition is a pass of
+                // its own (launch_class_keys).  ~zsort_key(z) == 0xFFFFFFFF only for a NaN pattern, which was replaced above.
+                if (fp.ortho) key = ~zsort_key(kz);
                 if (fp.zmode && !transparent) key = 0;
                 if (key == KEY_INVALID) key = 0xFFFFFFFEu;    // unreachable for z > 5; keeps the sentinel unique
             }
         }
         keys[f] = key;
         spans[f] = span;
+        if (fp.wire_collect && bad_index) wire[f].kind = 0;
     }
     // frame counters: ballot per wave -> LDS -> one 5-word record per block (reduced by k_after_setup; no atomics)
     const unsigned long long mv = __ballot(visible), mt = __ballot(transparent);
@@ -301,9 +316,10 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp, const B32Vertex* 
 }
 
 void launch_setup(hipStream_t s, const FrameParams& fp, const B32Vertex* verts, const B32Face* faces, const TexDesc* tex,
-                  const B32Light* lights, SurfRec* recs, float* shades, uint32_t* keys, uint32_t* spans, uint32_t* partials, Ctrl* ctrl) {
+                  const B32Light* lights, SurfRec* recs, float* shades, uint32_t* keys, uint32_t* spans, uint32_t* partials, Ctrl* ctrl,
+                  WireTri* wire) {
     if (fp.nf == 0) return;
-    hipLaunchKernelGGL(k_setup, dim3((fp.nf + 255) / 256), dim3(256), 0, s, fp, verts, faces, tex, lights, recs, shades, keys, spans, partials, ctrl);
+    hipLaunchKernelGGL(k_setup, dim3((fp.nf + 255) / 256), dim3(256), 0, s, fp, verts, faces, tex, lights, recs, shades, keys, spans, partials, ctrl, wire);
 }
 
 // ---------------------------------------------------------------- stage tap: project_fixed for n positions

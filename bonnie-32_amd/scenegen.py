@@ -162,3 +162,54 @@ def cube_scene(width=320, height=240):
     s.lights = [Light.directional((-1.0, -1.0, -1.0), 0.7)]
     cam = Camera(position=(0.7, -0.9, -4.5))
     return Scene("cube", width, height, v, f, [tex], [], cam, s)
+
+
+def wire_grid_scene(back_first=True, width=320, height=240, n=9):
+    """Exercises the wireframe phases (render.rs:2574-2635) with the reference's default settings (z-buffer, Gouraud,
+    back-face wireframe).  Two back-facing grids with SHARED vertices (so most edges repeat inside a grid) sit at depths
+    1000 and 2000 on the same screen positions (so edges also repeat ACROSS the grids with different depths), and a
+    front-facing quad at depth 1500 covers the left half: which grid comes first in face order decides whose depths the
+    de-duplicated edges carry, i.e. whether they survive the `z < zbuffer` test over the quad."""
+    from .rtypes import make_vertices, make_faces
+    vs = (min(width, height) / 2.0) * 0.75
+
+    def grid(cz, jitter):
+        pts = []
+        for j in range(n):
+            for i in range(n):
+                px = 20.0 + i * (width - 40.0) / (n - 1)
+                py = 20.0 + j * (height - 40.0) / (n - 1)
+                z = cz + jitter * ((i * 7 + j * 13) % 5)
+                pts.append(((px - width / 2.0) / vs * (z + 5.0) / 4.0, (py - height / 2.0) / vs * (z + 5.0) / 4.0, z))
+        tris = []
+        for j in range(n - 1):
+            for i in range(n - 1):
+                a, b, c, d = j * n + i, j * n + i + 1, (j + 1) * n + i, (j + 1) * n + i + 1
+                tris += [(a, b, c), (b, d, c)]      # clockwise on screen (y down) -> signed area > 0?  fixed below by probing
+        return pts, tris
+
+    near, tn = grid(1000.0, 3.0)
+    far, tf = grid(2000.0, 0.0)
+    quad = [(-1.0, -1.0), (0.0, -1.0), (0.0, 1.0), (-1.0, 1.0)]
+    qz = 1500.0
+    qpts = [((qx * width / 2.0) / vs * (qz + 5.0) / 4.0, (qy * height / 2.0) / vs * (qz + 5.0) / 4.0, qz) for qx, qy in quad]
+    groups = [(far, tf), (near, tn)] if back_first else [(near, tn), (far, tf)]
+    pts, tris, base = [], [], 0
+    for g, t in groups:
+        pts += g
+        tris += [(a + base, c + base, b + base) for a, b, c in t]     # flipped winding: back-faces
+        base += len(g)
+    pts += qpts
+    tris += [(base, base + 1, base + 2), (base, base + 2, base + 3)]
+    v = make_vertices(len(pts))
+    v["pos"] = np.array(pts, np.float32)
+    v["uv"] = (v["pos"][:, :2] / 2000.0).astype(np.float32)
+    v["normal"] = (0.0, 0.0, -1.0)
+    v["r"], v["g"], v["b"], v["blend"] = 200, 180, 160, 0
+    f = make_faces(len(tris))
+    f["v"] = np.array(tris, np.uint32)
+    f["texture_id"] = 0
+    f["black_transparent"] = 1
+    f["editor_alpha"] = 255
+    tex = Texture15.checkerboard(32, 32, 0x7FFF, 0x3DEF)
+    return Scene("wire-grid", width, height, v, f, [tex], [], Camera(), RasterSettings())

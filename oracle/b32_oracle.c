@@ -512,6 +512,94 @@ static int rasterize_triangle_15(FB* fb, const Surface* s, const B32Texture15* t
     return B32_OK;
 }
 
+/* ------------------------------------------------------------------ lines of the wireframe phases */
+/* Framebuffer::set_pixel, render.rs:301-310 with Color::new(r,g,b) (blend Opaque -> alpha 255, types.rs:829-832) */
+static inline void set_pixel_rgb(FB* fb, int32_t x, int32_t y, uint8_t r, uint8_t g, uint8_t b) {
+    if ((uint32_t)x < fb->width && (uint32_t)y < fb->height) {
+        size_t idx = ((size_t)y * fb->width + (size_t)x) * 4;
+        fb->pixels[idx] = r; fb->pixels[idx + 1] = g; fb->pixels[idx + 2] = b; fb->pixels[idx + 3] = 255;
+    }
+}
+static inline int32_t i32_wadd(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
+static inline int32_t i32_wsub(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
+static inline int32_t i32_wabs(int32_t a) { return a < 0 ? (int32_t)(0u - (uint32_t)a) : a; }
+/* Lines whose Bresenham state would overflow i32 in the reference (debug builds panic, release builds wrap and spin):
+ * |dx| or |dy| >= 2^30 makes `2 * err` overflow.  Reported as B32_E_UNSUPPORTED by oracle and GPU alike. */
+static inline int line_overflows(int32_t x0, int32_t y0, int32_t x1, int32_t y1) {
+    int64_t adx = (int64_t)x1 - x0, ady = (int64_t)y1 - y0;
+    if (adx < 0) adx = -adx;
+    if (ady < 0) ady = -ady;
+    return adx >= ((int64_t)1 << 30) || ady >= ((int64_t)1 << 30);
+}
+/* Framebuffer::draw_line -> draw_line_blended(mode = Opaque), render.rs:716-750 */
+EXPORT int b32o_draw_line(uint8_t* pixels, uint32_t width, uint32_t height, int32_t x0, int32_t y0, int32_t x1, int32_t y1,
+                          uint8_t r, uint8_t g, uint8_t b) {
+    if (line_overflows(x0, y0, x1, y1)) return B32_E_UNSUPPORTED;
+    FB fb = { pixels, NULL, width, height, 0 };
+    int32_t dx = i32_wabs(i32_wsub(x1, x0)), dy = -i32_wabs(i32_wsub(y1, y0));
+    int32_t sx = x0 < x1 ? 1 : -1, sy = y0 < y1 ? 1 : -1;
+    int32_t err = i32_wadd(dx, dy), x = x0, y = y0;
+    for (;;) {
+        if (x >= 0 && x < (int32_t)width && y >= 0 && y < (int32_t)height) set_pixel_rgb(&fb, x, y, r, g, b);
+        if (x == x1 && y == y1) break;
+        int32_t e2 = 2 * err;
+        if (e2 >= dy) { err = i32_wadd(err, dy); x += sx; }
+        if (e2 <= dx) { err = i32_wadd(err, dx); y += sy; }
+    }
+    return B32_OK;
+}
+/* Framebuffer::draw_line_3d -> draw_line_3d_impl(allow_equal = false), render.rs:757-817.  zbuffer == NULL: every depth f32::MAX */
+EXPORT int b32o_draw_line_3d(uint8_t* pixels, const float* zbuffer, uint32_t width, uint32_t height,
+                             int32_t x0, int32_t y0, float z0, int32_t x1, int32_t y1, float z1, uint8_t r, uint8_t g, uint8_t b) {
+    if (line_overflows(x0, y0, x1, y1)) return B32_E_UNSUPPORTED;
+    FB fb = { pixels, NULL, width, height, 0 };
+    int32_t dx = i32_wabs(i32_wsub(x1, x0)), dy = -i32_wabs(i32_wsub(y1, y0));
+    int32_t sx = x0 < x1 ? 1 : -1, sy = y0 < y1 ? 1 : -1;
+    int32_t err = i32_wadd(dx, dy), x = x0, y = y0;
+    int32_t ndy = -dy;
+    int32_t m = ndy > 1 ? ndy : 1;
+    float total_steps = (float)(dx > m ? dx : m);                                                 /* dx.max((-dy).max(1)) as f32 */
+    float step = 0.0f;
+    for (;;) {
+        if (x >= 0 && x < (int32_t)width && y >= 0 && y < (int32_t)height) {
+            float t = step / total_steps;
+            float z = z0 + t * (z1 - z0);
+            size_t idx = (size_t)y * width + (size_t)x;
+            float zb = zbuffer ? zbuffer[idx] : 3.40282347e+38f;
+            if (z < zb) set_pixel_rgb(&fb, x, y, r, g, b);
+        }
+        if (x == x1 && y == y1) break;
+        int32_t e2 = 2 * err;
+        if (e2 >= dy) { err = i32_wadd(err, dy); x += sx; step += 1.0f; }
+        if (e2 <= dx) { err = i32_wadd(err, dx); y += sy; if (e2 < dy) step += 1.0f; }
+    }
+    return B32_OK;
+}
+typedef struct { int32_t x0, y0; float z0; int32_t x1, y1; float z1; } WireEdge;
+typedef struct { V3 v1, v2, v3; } WireTri;
+/* unique-edge list of a wireframe phase, render.rs:2578-2596 / 2604-2626: first occurrence wins, compared on screen integers only */
+static WireEdge* unique_edges(const WireTri* tris, uint32_t n, uint32_t* n_out) {
+    WireEdge* out = (WireEdge*)malloc(sizeof(WireEdge) * ((size_t)n * 3 + 1));
+    uint32_t cnt = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const V3 p[3] = { tris[i].v1, tris[i].v2, tris[i].v3 };
+        for (int j = 0; j < 3; ++j) {
+            const V3 a = p[j], b = p[(j + 1) % 3];
+            WireEdge e = { f2i32_sat(a.x), f2i32_sat(a.y), a.z, f2i32_sat(b.x), f2i32_sat(b.y), b.z };
+            if (!(e.x0 < e.x1 || (e.x0 == e.x1 && e.y0 < e.y1))) {                              /* (x0, y0) < (x1, y1) as tuples */
+                WireEdge t = { e.x1, e.y1, e.z1, e.x0, e.y0, e.z0 };
+                e = t;
+            }
+            int seen = 0;
+            for (uint32_t k = 0; k < cnt && !seen; ++k)
+                seen = out[k].x0 == e.x0 && out[k].y0 == e.y0 && out[k].x1 == e.x1 && out[k].y1 == e.y1;
+            if (!seen) out[cnt++] = e;
+        }
+    }
+    *n_out = cnt;
+    return out;
+}
+
 /* ------------------------------------------------------------------ stable descending sort (slice::sort_by, render.rs:2527-2542) */
 static inline float center_z(const Surface* s) { return (s->v1.z + s->v2.z + s->v3.z) / 3.0f; }
 static void merge_sort_desc(uint32_t* idx, uint32_t* tmp, const float* key, uint32_t n) {
@@ -551,7 +639,7 @@ EXPORT void b32o_fb_clear(uint8_t* pixels, float* zbuffer, uint32_t width, uint3
     }
 }
 
-/* render_mesh_15, render.rs:2302-2638 (wireframe phases :2574-2635 are out of scope -> B32_E_UNSUPPORTED) */
+/* render_mesh_15, render.rs:2302-2638 */
 EXPORT int b32o_render_mesh_15(uint8_t* fb_pixels, float* fb_zbuffer, uint32_t width, uint32_t height,
                                const B32Vertex* vertices, uint32_t nv,
                                const B32Face* faces, uint32_t nf,
@@ -560,7 +648,6 @@ EXPORT int b32o_render_mesh_15(uint8_t* fb_pixels, float* fb_zbuffer, uint32_t w
                                B32Timings* timings, B32OracleDump* dump) {
     if (!fb_pixels || !camera || !st || (nv && !vertices) || (nf && !faces) || (nt && !textures)) return B32_E_ARG;
     if (st->use_zbuffer && !fb_zbuffer) return B32_E_ARG;
-    if ((st->backface_cull && st->backface_wireframe) || st->wireframe_overlay) return B32_E_UNSUPPORTED;
     if (st->shading != B32_SHADE_NONE)
         for (uint32_t i = 0; i < st->n_lights; ++i)
             if (st->lights[i].enabled && st->lights[i].type > B32_LIGHT_POINT) return B32_E_UNSUPPORTED;
@@ -594,7 +681,9 @@ EXPORT int b32o_render_mesh_15(uint8_t* fb_pixels, float* fb_zbuffer, uint32_t w
 
     /* CULL / SETUP, :2364-2516 */
     Surface* surfaces = (Surface*)malloc(sizeof(Surface) * (nf ? nf : 1));
-    uint32_t ns = 0;
+    WireTri* backface_wireframes = (WireTri*)malloc(sizeof(WireTri) * (nf ? nf : 1));
+    WireTri* frontface_wireframes = (WireTri*)malloc(sizeof(WireTri) * (nf ? nf : 1));
+    uint32_t ns = 0, n_bw = 0, n_fw = 0;
     int rc = B32_OK;
     for (uint32_t fi = 0; fi < nf; ++fi) {
         const B32Face* f = &faces[fi];
@@ -631,6 +720,7 @@ EXPORT int b32o_render_mesh_15(uint8_t* fb_pixels, float* fb_zbuffer, uint32_t w
         s.blend_mode = f->blend_mode; s.editor_alpha = f->editor_alpha;
         const B32Vertex *A = &vertices[f->v[0]], *B = &vertices[f->v[1]], *C = &vertices[f->v[2]];
         if (is_backface) {                                                                        /* :2445-2479 */
+            if (!st->xray_mode) { WireTri w = { v1, v2, v3_ }; backface_wireframes[n_bw++] = w; }
             if (!(!st->backface_cull || st->xray_mode)) continue;
             s.v1 = v1; s.v2 = v3_; s.v3 = v2;
             s.w1 = v3p(A->pos); s.w2 = v3p(C->pos); s.w3 = v3p(B->pos);
@@ -643,6 +733,7 @@ EXPORT int b32o_render_mesh_15(uint8_t* fb_pixels, float* fb_zbuffer, uint32_t w
             s.wn1 = v3p(A->normal); s.wn2 = v3p(B->normal); s.wn3 = v3p(C->normal);
             memcpy(s.uv1, A->uv, 8); memcpy(s.uv2, B->uv, 8); memcpy(s.uv3, C->uv, 8);
             s.vc1 = c1; s.vc2 = c2; s.vc3 = c3;
+            if (st->wireframe_overlay) { WireTri w = { v1, v2, v3_ }; frontface_wireframes[n_fw++] = w; }   /* :2509-2511 */
         }
         surfaces[ns++] = s;
     }
@@ -678,8 +769,23 @@ EXPORT int b32o_render_mesh_15(uint8_t* fb_pixels, float* fb_zbuffer, uint32_t w
         free(order); free(tmp); free(key);
     }
     if (timings) timings->fragments = fb.fragments;
+    /* WIREFRAME, :2574-2635 */
+    if (!rc && st->backface_cull && st->backface_wireframe) {
+        uint32_t ne = 0;
+        WireEdge* ue = unique_edges(backface_wireframes, n_bw, &ne);
+        for (uint32_t i = 0; i < ne && !rc; ++i)
+            rc = b32o_draw_line_3d(fb.pixels, fb.zbuffer, width, height, ue[i].x0, ue[i].y0, ue[i].z0, ue[i].x1, ue[i].y1, ue[i].z1, 80, 80, 100);
+        free(ue);
+    }
+    if (!rc && st->wireframe_overlay && n_fw) {
+        uint32_t ne = 0;
+        WireEdge* ue = unique_edges(frontface_wireframes, n_fw, &ne);
+        for (uint32_t i = 0; i < ne && !rc; ++i)
+            rc = b32o_draw_line(fb.pixels, width, height, ue[i].x0, ue[i].y0, ue[i].x1, ue[i].y1, 200, 200, 220);
+        free(ue);
+    }
 done:
-    free(surfaces); free(cam_space); free(projected);
+    free(surfaces); free(cam_space); free(projected); free(backface_wireframes); free(frontface_wireframes);
     return rc;
 }
 

@@ -192,7 +192,14 @@ def render_mesh_15(pixels, width, height, vertices, faces, textures, camera, set
     B = [np.asarray(b, np.float32) for b in (camera.basis_x, camera.basis_y, camera.basis_z)]
     rel = (pos - cpos).astype(np.float32)
     cam = np.stack([dot3(rel, B[0]), dot3(rel, B[1]), dot3(rel, B[2])], axis=1).astype(np.float32)   # math.rs:103-109
-    if settings.use_fixed_point:                                                                     # :2329-2345
+    ortho = settings.ortho_projection
+    if ortho is not None:                                                                            # :2323-2328, math.rs:140-148
+        zoom, ocx, ocy = (f32(x) for x in ortho)
+        x = ((cam[:, 0] - ocx).astype(np.float32) * zoom).astype(np.float32) + f32(width) / f32(2.0)
+        y = ((-(cam[:, 1] - ocy)).astype(np.float32) * zoom).astype(np.float32) + f32(height) / f32(2.0)
+        scr = np.stack([x, y, cam[:, 2]], axis=1).astype(np.float32)
+        sx = sy = None
+    elif settings.use_fixed_point:                                                                   # :2329-2345
         sx, sy = project_fixed(pos, camera, width, height)
         scr = np.stack([sx.astype(np.float32), sy.astype(np.float32), cam[:, 2] + f32(5.0)], axis=1)
     else:                                                                                            # math.rs:117-136
@@ -209,10 +216,11 @@ def render_mesh_15(pixels, width, height, vertices, faces, textures, camera, set
         raise IndexError("vertex index out of range")                                                # :2375-2377
 
     surfaces = []
+    back_wires, front_wires = [], []
     for fi, face in enumerate(faces):
         i0, i1, i2 = (int(k) for k in face["v"])
         cz = cam[[i0, i1, i2], 2]
-        if (cz <= f32(0.1)).any():                                                                   # :2381-2385
+        if ortho is None and (cz <= f32(0.1)).any():                                                 # :2381-2385
             continue
         v1, v2, v3 = scr[i0], scr[i1], scr[i2]
         signed_area = (v2[0] - v1[0]) * (v3[1] - v1[1]) - (v3[0] - v1[0]) * (v2[1] - v1[1])          # :2393
@@ -242,7 +250,11 @@ def render_mesh_15(pixels, width, height, vertices, faces, textures, camera, set
                     inv = f32(1.0) - fac
                     rgb = as_u8(cols[k][:3].astype(np.float32) * inv + fcol[:3].astype(np.float32) * fac)
                     cols[k] = np.array([rgb[0], rgb[1], rgb[2], 0], np.int64)
-        if back and settings.backface_cull:                                                          # :2445-2452
+        if back and not settings.xray_mode:                                                          # :2445-2449
+            back_wires.append((v1, v2, v3))
+        if not back and settings.wireframe_overlay:                                                  # :2509-2511
+            front_wires.append((v1, v2, v3))
+        if back and settings.backface_cull and not settings.xray_mode:                               # :2451-2453
             continue
         order = (i0, i2, i1) if back else (i0, i1, i2)
         corder = (0, 2, 1) if back else (0, 1, 2)
@@ -268,10 +280,77 @@ def render_mesh_15(pixels, width, height, vertices, faces, textures, camera, set
     n_opaque = len(opaque)
 
     fragments = 0
-    for k, si in enumerate(draw):
-        fragments += _rasterize(img, width, height, surfaces[si], settings, zb, skip_z_write=k >= n_opaque)
+    if not settings.wireframe_overlay:                                                               # :2550
+        for k, si in enumerate(draw):
+            fragments += _rasterize(img, width, height, surfaces[si], settings, zb, skip_z_write=k >= n_opaque)
+    # wireframe phases, :2574-2635
+    zfull = zbuffer.reshape(height, width) if zbuffer is not None else None
+    if settings.backface_cull and settings.backface_wireframe:
+        for e in _unique_edges(back_wires):
+            draw_line(img, width, height, e, (80, 80, 100), zfull, depth_test=True)
+    if settings.wireframe_overlay and front_wires:
+        for e in _unique_edges(front_wires):
+            draw_line(img, width, height, e, (200, 200, 220), None, depth_test=False)
     return dict(triangles_drawn=len(surfaces), fragments=fragments, draw_order=np.array([surfaces[i]["face"] for i in draw], np.uint32),
                 sx=sx, sy=sy, sz=scr[:, 2])
+
+
+def _as_i32(x):
+    """Rust `f32 as i32`: truncating, saturating, NaN -> 0."""
+    x = float(x)
+    if x != x:
+        return 0
+    return int(max(-2147483648.0, min(2147483647.0, np.trunc(x))))
+
+
+def _unique_edges(tris):
+    """render.rs:2578-2596: edges as screen integers, direction-normalised, first occurrence kept (with its depths)."""
+    seen, out = set(), []
+    for tri in tris:
+        for j in range(3):
+            a, b = tri[j], tri[(j + 1) % 3]
+            e = (_as_i32(a[0]), _as_i32(a[1]), f32(a[2]), _as_i32(b[0]), _as_i32(b[1]), f32(b[2]))
+            if not ((e[0], e[1]) < (e[3], e[4])):
+                e = (e[3], e[4], e[5], e[0], e[1], e[2])
+            k = (e[0], e[1], e[3], e[4])
+            if k not in seen:
+                seen.add(k)
+                out.append(e)
+    return out
+
+
+def line_points(x0, y0, x1, y1):
+    """Pixels of the reference's Bresenham (render.rs:716-750 / 771-817) in closed form: the k-th plotted point, k = 0..N.
+    For an x-major line x advances every iteration and y has advanced floor((2*ady*k + adx) / (2*adx)) times (round half up),
+    symmetrically for y-major lines.  Independent of the literal loop in oracle/b32_oracle.c; tests compare the two."""
+    adx, ady = abs(x1 - x0), abs(y1 - y0)
+    sx, sy = (1 if x0 < x1 else -1), (1 if y0 < y1 else -1)
+    n = max(adx, ady)
+    k = np.arange(n + 1, dtype=np.int64)
+    if n == 0:
+        return np.array([x0], np.int64), np.array([y0], np.int64), k
+    if adx >= ady:
+        return x0 + sx * k, y0 + sy * ((2 * ady * k + adx) // (2 * adx)), k
+    return x0 + sx * ((2 * adx * k + ady) // (2 * ady)), y0 + sy * k, k
+
+
+def draw_line(img, width, height, e, rgb, zb, depth_test):
+    x0, y0, z0, x1, y1, z1 = e
+    if max(abs(x1 - x0), abs(y1 - y0)) >= 1 << 30:
+        raise OverflowError("Bresenham state overflows i32 in the reference")
+    xs, ys, k = line_points(x0, y0, x1, y1)
+    on = (xs >= 0) & (xs < width) & (ys >= 0) & (ys < height)
+    xs, ys, k = xs[on], ys[on], k[on]
+    if depth_test:
+        total = f32(max(abs(x1 - x0), max(abs(y1 - y0), 1)))
+        step = np.minimum(k, 1 << 24).astype(np.float32)                  # step += 1.0 saturates at 2^24 in f32
+        with np.errstate(invalid="ignore", over="ignore"):
+            t = (step / total).astype(np.float32)
+            z = (f32(z0) + (t * (f32(z1) - f32(z0))).astype(np.float32)).astype(np.float32)
+            cur = zb[ys, xs] if zb is not None else np.full(len(xs), np.finfo(np.float32).max, np.float32)
+            ok = z < cur
+        xs, ys = xs[ok], ys[ok]
+    img[ys, xs, 0], img[ys, xs, 1], img[ys, xs, 2], img[ys, xs, 3] = rgb[0], rgb[1], rgb[2], 255
 
 
 def _rasterize(img, width, height, s, st, zb=None, skip_z_write=False):
@@ -306,6 +385,8 @@ def _rasterize(img, width, height, s, st, zb=None, skip_z_write=False):
     bcz = ((f32(1.0) - bcx) - bcy).astype(np.float32)                                                 # :1538
     E = f32(-0.0001)
     inside = (bcx >= E) & (bcy >= E) & (bcz >= E)                                                     # :1542
+    if st.xray_mode:
+        zb = None                                                                                     # :1553: no depth test, no depth write
     zgrid = None
     if zb is not None:                                                                                # :1546-1560
         izs = [f32(1.0) / f32(vv[2]) for vv in (v1, v2, v3)]
@@ -390,7 +471,9 @@ def _rasterize(img, width, height, s, st, zb=None, skip_z_write=False):
     mode, alpha = s["blend"], s["alpha"]
     do_blend = semi & (mode != 0)
     ps1 = np.where(do_blend[:, None], blend555(front, back, mode), front)
-    if alpha < 255:                                                                                   # render.rs:567-591
+    if st.xray_mode:                                                                                  # render.rs:507-526
+        res = (front + back) // 2
+    elif alpha < 255:                                                                                 # render.rs:567-591
         res = (ps1 * alpha + back * (255 - alpha)) // 255
     else:
         res = ps1                                                                                     # :445-502

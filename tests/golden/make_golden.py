@@ -41,7 +41,49 @@ def zbuf_scene(variant="bench", seed=17):
     return sc
 
 
+def ortho_scene():
+    sc = scenegen.make_scene("C1", seed=41, variant="blend", bbox_px=900.0)
+    sc.camera.position = (30.0, -20.0, 3000.0)   # part of the scene ends up at negative camera depth: no near cull in ortho
+    sc.settings.ortho_projection = (0.05, 10.0, -15.0)
+    return sc
+
+
+def xray_scene(zbuf):
+    sc = scenegen.make_scene("C1", seed=43, variant="blend", bbox_px=200.0)
+    sc.settings.xray_mode = True
+    sc.settings.use_zbuffer = zbuf
+    return sc
+
+
+def default_settings_scene():
+    sc = scenegen.make_scene("C1", seed=47, variant="gouraud", bbox_px=200.0)
+    sc.settings = b32.RasterSettings()            # reference defaults: z-buffer, Gouraud + directional light, back-face wireframe
+    return sc
+
+
+def wire_painter_scene(overlay):
+    sc = scenegen.make_scene("C1", seed=53, bbox_px=300.0)
+    sc.settings.backface_wireframe = True
+    sc.settings.wireframe_overlay = overlay
+    return sc
+
+
+def cube_default_scene():
+    sc = scenegen.cube_scene()
+    sc.settings = b32.RasterSettings()            # far-side faces are back-faces: their wireframe must fail the depth test
+    return sc
+
+
 SCENES = {
+    "C1:ortho": ortho_scene,
+    "C1:xray": lambda: xray_scene(False),
+    "C1:xray-zbuf": lambda: xray_scene(True),
+    "C1:default-settings": default_settings_scene,
+    "C1:wire-painter": lambda: wire_painter_scene(False),
+    "C1:wire-overlay": lambda: wire_painter_scene(True),
+    "cube:default": cube_default_scene,
+    "wire-grid:far-first": lambda: scenegen.wire_grid_scene(True),
+    "wire-grid:near-first": lambda: scenegen.wire_grid_scene(False),
     "C1:persp": persp_scene,
     "C1:zbuf": zbuf_scene,
     "C1:zbuf-blend": lambda: zbuf_scene("blend", 19),

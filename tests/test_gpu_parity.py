@@ -303,13 +303,82 @@ def test_error_behaviour(gpu_ctx, oracle):
     with pytest.raises(R.B32Error) as e:
         R.render_mesh_15(fb, vn, sc.faces, sc.textures, sc.camera, nc)
     assert e.value.code == b32.abi.B32_E_NAN_KEY and np.array_equal(fb.pixels, before)
-    for st in (b32.RasterSettings(), b32.RasterSettings(xray_mode=True, backface_wireframe=False),
-               b32.RasterSettings(ortho_projection=(1.0, 0.0, 0.0), backface_wireframe=False)):
-        with pytest.raises(R.B32Error) as e:
-            R.render_mesh_15(fb, sc.vertices, sc.faces, sc.textures, sc.camera, st)
-        assert e.value.code == b32.abi.B32_E_UNSUPPORTED
+    st = b32.RasterSettings()                     # the only setting still refused: a spot light (acos is not bit-portable)
+    st.lights = [b32.Light(2, position=(0, 0, 0), direction=(0, 0, 1), radius=50.0, angle=0.5)]
+    with pytest.raises(R.B32Error) as e:
+        R.render_mesh_15(fb, sc.vertices, sc.faces, sc.textures, sc.camera, st)
+    assert e.value.code == b32.abi.B32_E_UNSUPPORTED and np.array_equal(fb.pixels, before)
 
 
 def test_smoke_entry():
     import __graft_entry__ as g
     g.smoke()
+
+
+NEW_MODES = ["C1:ortho", "C1:xray", "C1:xray-zbuf", "C1:default-settings", "C1:wire-painter", "C1:wire-overlay", "cube:default",
+             "wire-grid:far-first", "wire-grid:near-first"]
+
+
+@pytest.mark.parametrize("name", NEW_MODES)
+@pytest.mark.parametrize("counting", [1, 0])
+def test_editor_modes_parity(gpu_ctx, oracle, name, counting):
+    """Orthographic projection (math.rs:140-148), x-ray (render.rs:507-526, 1671-1673) and both wireframe phases
+    (render.rs:2574-2635) — the reference's default settings use the back-face wireframe with the z-buffer."""
+    sc = SCENES[name]()
+    fbo = oracle.Framebuffer(sc.width, sc.height); fbo.clear(sc.clear_color)
+    rc, etm, d = oracle.render_mesh_15(fbo, sc.vertices, sc.faces, sc.textures, sc.camera, sc.settings, sc.fog, dump=True)
+    assert rc == 0
+    gpu_ctx.set_fragment_counting(counting)
+    try:
+        from bonnie32_amd import rasterizer as R
+        fb = R.Framebuffer(sc.width, sc.height, gpu_ctx)
+        fb.clear(sc.clear_color)
+        tm = R.render_mesh_15(fb, sc.vertices, sc.faces, sc.textures, sc.camera, sc.settings, sc.fog)
+        got = fb.pixels
+        assert np.array_equal(got, fbo.pixels), f"{int((got != fbo.pixels).sum())} bytes differ"
+        assert hashlib.sha256(got).hexdigest() == HASHES[name]["sha256"]
+        assert tm.triangles_drawn == etm.triangles_drawn
+        if sc.settings.use_zbuffer:
+            assert np.array_equal(fb.zbuffer.view(np.uint32), fbo.zbuffer.view(np.uint32))
+        if sc.settings.xray_mode:
+            assert tm.fragments == etm.fragments
+        assert np.array_equal(gpu_ctx.last_draw_order(len(sc.faces)), d["draw_order"])
+    finally:
+        gpu_ctx.set_fragment_counting(1)
+
+
+def test_editor_modes_large_frame_bands(gpu_ctx, oracle):
+    """Default settings (z-buffer + Gouraud + back-face wireframe) at 1280x960 with 20 k triangles, drawn as three ragged
+    screen bands (multi-GPU sharding): long lines cross tiles and bands, dedup table sized for 60 k edges."""
+    sc = scenegen.make_scene("C3", n_tris=20_000, width=1280, height=960, bbox_px=2500.0, seed=99, variant="gouraud")
+    sc.settings = b32.RasterSettings()
+    fbo = oracle.Framebuffer(sc.width, sc.height); fbo.clear(sc.clear_color)
+    rc, etm = oracle.render_mesh_15(fbo, sc.vertices, sc.faces, sc.textures, sc.camera, sc.settings, sc.fog)
+    assert rc == 0
+    from bonnie32_amd import rasterizer as R
+    fb = R.Framebuffer(sc.width, sc.height, gpu_ctx)
+    rs = R.ResidentScene(fb, sc.vertices, sc.faces, sc.textures)
+    for band in ((0, 301), (301, 700), (700, 960)):
+        fb.set_band(*band)
+        fb.clear(sc.clear_color)
+        tm = rs.render(sc.camera, sc.settings, sc.fog)
+        assert tm.triangles_drawn == etm.triangles_drawn
+    fb.set_band(0, sc.height)
+    got = fb.pixels
+    assert np.array_equal(got, fbo.pixels), f"{int((got != fbo.pixels).sum())} bytes differ"
+    assert np.array_equal(fb.zbuffer.view(np.uint32), fbo.zbuffer.view(np.uint32))
+
+
+def test_wire_edge_overflow_is_refused(gpu_ctx, oracle):
+    """An edge >= 2^30 pixels long overflows the reference's i32 Bresenham state: both sides return B32_E_UNSUPPORTED."""
+    sc = scenegen.wire_grid_scene()
+    sc.settings.use_fixed_point = False
+    sc.vertices["pos"][0] = (-3.0e9, 0.0, 1000.0)            # float projection keeps the huge coordinate; `as i32` saturates
+    fbo = oracle.Framebuffer(sc.width, sc.height); fbo.clear(sc.clear_color)
+    rc, _ = oracle.render_mesh_15(fbo, sc.vertices, sc.faces, sc.textures, sc.camera, sc.settings, sc.fog)
+    assert rc == b32.abi.B32_E_UNSUPPORTED
+    from bonnie32_amd import rasterizer as R
+    fb = R.Framebuffer(sc.width, sc.height, gpu_ctx)
+    with pytest.raises(R.B32Error) as ei:
+        R.render_mesh_15(fb, sc.vertices, sc.faces, sc.textures, sc.camera, sc.settings, sc.fog)
+    assert ei.value.code == b32.abi.B32_E_UNSUPPORTED

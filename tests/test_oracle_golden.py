@@ -10,7 +10,9 @@ from tests.golden.make_golden import SCENES, render
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 HASHES = json.load(open(os.path.join(GOLD, "hashes.json")))
-FAST = ["C1", "C1:zbuf", "C1:zbuf-blend", "C1:zbuf-gouraud", "C1:gouraud", "C1:blend", "C1:float", "C1:persp", "cube", "fog-flat-point-nocull", "C2", "C2:blend", "C3:100k", "C5:20k"]
+NEW_MODES = ["C1:ortho", "C1:xray", "C1:xray-zbuf", "C1:default-settings", "C1:wire-painter", "C1:wire-overlay", "cube:default",
+             "wire-grid:far-first", "wire-grid:near-first"]
+FAST = NEW_MODES + ["C1", "C1:zbuf", "C1:zbuf-blend", "C1:zbuf-gouraud", "C1:gouraud", "C1:blend", "C1:float", "C1:persp", "cube", "fog-flat-point-nocull", "C2", "C2:blend", "C3:100k", "C5:20k"]
 
 
 @pytest.mark.parametrize("name", FAST)
@@ -42,7 +44,7 @@ def test_cube_fixture(oracle):
 
 
 @pytest.mark.parametrize("name", ["C1", "C1:gouraud", "C1:blend", "C1:float", "C1:persp", "cube", "fog-flat-point-nocull",
-                                  "C1:zbuf", "C1:zbuf-blend", "C1:zbuf-gouraud"])
+                                  "C1:zbuf", "C1:zbuf-blend", "C1:zbuf-gouraud"] + NEW_MODES)
 def test_two_restatements_agree(oracle, name):
     """oracle/b32_oracle.c and oracle/np_model.py are two readings of the same Rust; whole frames must be identical."""
     from oracle import np_model as M
@@ -60,6 +62,15 @@ def test_two_restatements_agree(oracle, name):
     assert np.array_equal(r["sz"], d["sz"])
     if r["sx"] is not None:
         assert np.array_equal(r["sx"], d["sx"]) and np.array_equal(r["sy"], d["sy"])
+
+
+def test_wire_grid_first_occurrence_decides(oracle):
+    """The de-duplicated back-face edges carry the depths of their first occurrence (render.rs:2589-2594): swapping which
+    grid comes first in face order changes what survives the depth test over the quad."""
+    a, _, _ = render(SCENES["wire-grid:far-first"]())
+    b, _, _ = render(SCENES["wire-grid:near-first"]())
+    wire = lambda fb: int(((fb.image()[:, :, :3] == (80, 80, 100)).all(axis=2)).sum())
+    assert wire(a) > 0 and wire(b) > wire(a)
 
 
 def test_rmw_two_meshes(oracle):

@@ -153,5 +153,40 @@ def test_error_codes(oracle):
     assert oracle.render_mesh_15(fb, v2, f2, [], b32.Camera(), st_nc)[0] == b32.abi.B32_E_NAN_KEY
     # a single surface never compares keys: no panic in the reference (sort_by on a 1-element slice)
     assert oracle.render_mesh_15(fb, v2[3:6], sc_f, [], b32.Camera(), st_nc)[0] == 0
-    st2 = b32.RasterSettings()                                  # reference defaults: backface wireframe on -> out of scope
-    assert oracle.render_mesh_15(fb, sc_v, sc_f, [], b32.Camera(), st2)[0] == b32.abi.B32_E_UNSUPPORTED
+    st2 = b32.RasterSettings()                                  # reference defaults (z-buffer, back-face wireframe) are in scope
+    assert oracle.render_mesh_15(fb, sc_v, sc_f, [], b32.Camera(), st2)[0] == 0
+    st2.lights = [b32.Light(b32.abi.LIGHT_SPOT if hasattr(b32.abi, "LIGHT_SPOT") else 2, position=(0, 0, 0), direction=(0, 0, 1), radius=50.0, angle=0.5)]
+    assert oracle.render_mesh_15(fb, sc_v, sc_f, [], b32.Camera(), st2)[0] == b32.abi.B32_E_UNSUPPORTED   # spot: acos
+
+
+def test_bresenham_closed_form_equals_literal_loop(oracle):
+    """The GPU (b32_wire.hip) and oracle/np_model.py use the closed form of the reference's Bresenham state
+    (render.rs:716-750); oracle/b32_oracle.c runs the loop literally.  Same pixels, and same per-pixel depths through
+    draw_line_3d (render.rs:771-817), on random lines including steep, flat, reversed, degenerate and off-screen ones."""
+    import ctypes as C
+    from oracle import np_model as M
+    L = oracle.lib()
+    L.b32o_draw_line.restype = C.c_int
+    L.b32o_draw_line.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32] + [C.c_int32] * 4 + [C.c_uint8] * 3
+    L.b32o_draw_line_3d.restype = C.c_int
+    L.b32o_draw_line_3d.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_float,
+                                    C.c_int32, C.c_int32, C.c_float] + [C.c_uint8] * 3
+    rng = np.random.default_rng(5)
+    W, H = 97, 61
+    zb = (rng.random(W * H) * 100).astype(np.float32)
+    for it in range(1500):
+        x0, y0, x1, y1 = [int(v) for v in rng.integers(-60, 160, 4)]
+        if it % 7 == 0: x1 = x0
+        if it % 11 == 0: y1 = y0
+        if it % 13 == 0: x1, y1 = x0 + (y1 - y0), y0 + (y1 - y0)      # exact diagonal
+        z0, z1 = np.float32(rng.random() * 100), np.float32(rng.random() * 100)
+        a = np.zeros(W * H * 4, np.uint8); b = np.zeros((H, W, 4), np.uint8)
+        assert L.b32o_draw_line(a.ctypes.data, W, H, x0, y0, x1, y1, 1, 2, 3) == 0
+        M.draw_line(b, W, H, (x0, y0, z0, x1, y1, z1), (1, 2, 3), None, False)
+        assert np.array_equal(a.reshape(H, W, 4), b), (x0, y0, x1, y1)
+        a[:] = 0; b[:] = 0
+        assert L.b32o_draw_line_3d(a.ctypes.data, zb.ctypes.data, W, H, x0, y0, z0, x1, y1, z1, 4, 5, 6) == 0
+        M.draw_line(b, W, H, (x0, y0, z0, x1, y1, z1), (4, 5, 6), zb.reshape(H, W), True)
+        assert np.array_equal(a.reshape(H, W, 4), b), (x0, y0, x1, y1)
+    # a line whose Bresenham state overflows i32 in the reference is refused, not walked
+    assert L.b32o_draw_line(a.ctypes.data, W, H, -(1 << 30), 0, 5, 5, 1, 2, 3) == b32.abi.B32_E_UNSUPPORTED
