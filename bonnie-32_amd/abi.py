@@ -35,6 +35,10 @@ class B32Texture15(C.Structure):
                 ("pixels", C.c_void_p)]
 
 
+class B32Texture(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("blend_mode", C.c_uint32), ("_pad", C.c_uint32), ("pixels", C.c_void_p)]
+
+
 class B32IndexedTexture(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("blend_mode", C.c_uint32), ("clut_len", C.c_uint32),
                 ("indices", C.c_void_p), ("clut", C.c_void_p)]
@@ -95,6 +99,10 @@ SYMBOLS = [
     ("b32_render_scene_15", C.c_int, [_P, _P, _P, _P, _P]),
     ("b32_render_scene_15_async", C.c_int, [_P, _P, _P, _P]),
     ("b32_frame_finish", C.c_int, [_P, _P]),
+    ("b32_render_mesh", C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint32, _P, C.c_uint32, _P, _P, _P]),
+    ("b32_scene_upload_rgba", C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint32, _P, C.c_uint32]),
+    ("b32_render_scene", C.c_int, [_P, _P, _P, _P]),
+    ("b32_render_scene_async", C.c_int, [_P, _P, _P]),
     ("b32_project_fixed_batch", C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint32, C.c_uint32, _P, _P, _P]),
     ("b32_last_draw_order", C.c_int, [_P, _P, C.c_uint32, C.POINTER(C.c_uint32)]),
     ("b32_selftest_f32", C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_uint32]),

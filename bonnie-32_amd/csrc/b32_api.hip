@@ -34,6 +34,9 @@ struct b32_ctx {
     B32Vertex* d_verts = nullptr; size_t cap_verts = 0;
     B32Face* d_faces = nullptr; size_t cap_faces = 0;
     uint16_t* d_texels = nullptr; size_t cap_texels = 0;
+    uint32_t* d_texels32 = nullptr; size_t cap_texels32 = 0;   // 8-bit-colour path: Color texels
+    bool fmt8 = false;                  // the resident scene was uploaded by b32_scene_upload_rgba (render_mesh path)
+    bool blend8 = false;                // 8-bit path: some texel blends or some face has editor_alpha < 255 -> ordered walk
     TexDesc* d_tex = nullptr; size_t cap_tex = 0;
     std::vector<TexDesc> h_tex;
     uint32_t nv = 0, nf = 0, nt = 0;
@@ -147,7 +150,7 @@ void b32_destroy(b32_ctx* c) {
     void* ptrs[] = { c->fb_own, c->d_verts, c->d_faces, c->d_texels, c->d_tex, c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->recs,
                      c->shades, c->counts, c->block_sums, c->pkeys[0], c->pkeys[1], c->pvals[0], c->pvals[1], c->block_hist, c->ranges,
                      c->d_ctrl, c->d_consts, c->d_lights, c->digit_total, c->partials, c->vis, c->spans, c->tile_mid, c->zbuf,
-                     c->wire, c->wire_owner, c->wire_first };
+                     c->wire, c->wire_owner, c->wire_first, c->d_texels32 };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->ev_created) for (auto& fr : c->ev) for (auto& e : fr) if (e) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -298,7 +301,7 @@ static int upload_geometry(b32_ctx* c, const B32Vertex* v, uint32_t nv, const B3
     return B32_OK;
 }
 
-static int layout_textures(b32_ctx* c, uint32_t nt, const uint32_t* w, const uint32_t* h, const uint32_t* blend, size_t* total) {
+static int layout_textures(b32_ctx* c, uint32_t nt, const uint32_t* w, const uint32_t* h, const uint32_t* blend, size_t* total, bool rgba = false) {
     if (nt > 4094) return B32_E_UNSUPPORTED;
     c->h_tex.resize(nt);
     size_t off = 0;
@@ -310,7 +313,8 @@ static int layout_textures(b32_ctx* c, uint32_t nt, const uint32_t* w, const uin
     }
     *total = off + 8;
     int rc;
-    if ((rc = ensure(c, c->d_texels, c->cap_texels, *total))) return rc;
+    if (rgba) { if ((rc = ensure(c, c->d_texels32, c->cap_texels32, *total))) return rc; }
+    else if ((rc = ensure(c, c->d_texels, c->cap_texels, *total))) return rc;
     if ((rc = ensure(c, c->d_tex, c->cap_tex, (size_t)nt + 1))) return rc;
     if (nt) HIPCHK(c, hipMemcpyAsync(c->d_tex, c->h_tex.data(), nt * sizeof(TexDesc), hipMemcpyHostToDevice, c->stream));
     c->nt = nt;
@@ -339,6 +343,42 @@ int b32_scene_upload(b32_ctx* c, const B32Vertex* v, uint32_t nv, const B32Face*
     }
     if ((rc = upload_geometry(c, v, nv, f, nf))) return rc;
     for (uint32_t i = 0; i < nt; ++i) if (bl[i] != B32_BLEND_OPAQUE) c->may_blend = true;
+    c->fmt8 = false;
+    c->have_scene = true;
+    return B32_OK;
+}
+
+int b32_scene_upload_rgba(b32_ctx* c, const B32Vertex* v, uint32_t nv, const B32Face* f, uint32_t nf, const B32Texture* tex, uint32_t nt) {
+    if (!c || (nt && !tex)) return B32_E_ARG;
+    (void)hipSetDevice(c->device);
+    c->have_scene = false;
+    std::vector<uint32_t> w(nt), h(nt), bl(nt);
+    for (uint32_t i = 0; i < nt; ++i) {
+        w[i] = tex[i].width; h[i] = tex[i].height; bl[i] = tex[i].blend_mode;
+        if (!tex[i].pixels) w[i] = h[i] = 0;                                // pixels.is_empty() -> Color::TRANSPARENT
+    }
+    size_t total = 0;
+    int rc = layout_textures(c, nt, w.data(), h.data(), bl.data(), &total, true);
+    if (rc) return rc;
+    c->cheap_ok = true;
+    bool blend_texels = false;
+    for (uint32_t i = 0; i < nt; ++i) {
+        const size_t n = (size_t)w[i] * h[i];
+        if (n) HIPCHK(c, hipMemcpyAsync(c->d_texels32 + c->h_tex[i].offset, tex[i].pixels, n * 4, hipMemcpyHostToDevice, c->stream));
+        size_t skippable = 0;                                               // Erase texels: the fragment is skipped (render.rs:1348)
+        for (size_t k = 0; k < n; ++k) {
+            const uint8_t b = tex[i].pixels[k * 4 + 3];
+            skippable += b == B32_BLEND_ERASE;
+            blend_texels |= b != B32_BLEND_OPAQUE && b != B32_BLEND_ERASE;
+        }
+        if (n == 0 || skippable * 32 > n) c->cheap_ok = false;
+    }
+    if ((rc = upload_geometry(c, v, nv, f, nf))) return rc;
+    bool alpha_faces = false;
+    for (uint32_t i = 0; i < nf && !alpha_faces; ++i) alpha_faces = f[i].editor_alpha < 255;
+    c->blend8 = blend_texels || alpha_faces;
+    c->may_blend = false;
+    c->fmt8 = true;
     c->have_scene = true;
     return B32_OK;
 }
@@ -379,6 +419,7 @@ int b32_scene_upload_indexed(b32_ctx* c, const B32Vertex* v, uint32_t nv, const 
     }
     if ((rc = upload_geometry(c, v, nv, f, nf))) return rc;
     for (uint32_t i = 0; i < nt; ++i) if (bl[i] != B32_BLEND_OPAQUE) c->may_blend = true;
+    c->fmt8 = false;
     c->have_scene = true;
     return B32_OK;
 }
@@ -410,6 +451,7 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     fp.affine = st->affine_textures; fp.shading = st->shading; fp.backface_cull = st->backface_cull;
     fp.dithering = st->dithering; fp.fixed_point = st->use_fixed_point; fp.has_fog = fog ? 1 : 0; fp.zmode = st->use_zbuffer ? 1 : 0;
     if (fog) fp.fog = *fog;
+    fp.fmt8 = c->fmt8 ? 1 : 0;
     fp.ortho = st->has_ortho ? 1 : 0; fp.xray = st->xray_mode ? 1 : 0;
     fp.ortho_zoom = st->ortho_zoom; fp.ortho_cx = st->ortho_center_x; fp.ortho_cy = st->ortho_center_y;
     const bool wire_back = st->backface_cull && st->backface_wireframe;      // render.rs:2577
@@ -493,9 +535,11 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     const SortScratch sc{ c->block_hist, c->hist_blocks, c->digit_total };
     const bool exact_cov = c->count_fragments || !c->cheap_ok || fp.zmode;   // z-buffer mode: depth + skip rule per fragment
     // the fast path reads the class from bit 31 of the depth key and has no ordered opaque walk: not for ortho / x-ray frames
-    const bool local_sort = !exact_cov && c->local_sort_ok && !fp.ortho && !fp.xray;
+    // ordered walk of whole tile lists instead of the overwrite pass: x-ray (RGB555), or the 8-bit path with blending texels / editor alpha
+    const bool ordered_all = c->fmt8 ? c->blend8 : (fp.xray != 0);
+    const bool local_sort = !exact_cov && c->local_sort_ok && !fp.ortho && !ordered_all;
     c->last_local_sort = local_sort;
-    c->last_exact = fp.xray ? true : (exact_cov && !fp.zmode);              // x-ray: every store goes through the counted ordered pass
+    c->last_exact = ordered_all ? true : (exact_cov && !fp.zmode);          // the ordered walk counts every store it performs
     if (local_sort) {
         // fast path: no global depth sort.  Pairs are emitted in face order from k_setup's spans; k_cover sorts every tile
         // list by depth key in LDS (stable, so ties keep face order).
@@ -548,6 +592,9 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     if (!fa.exact_coverage) fa.lds_tex_texels = 0;      // CHEAP coverage: one texel fetch per output pixel, served by L1/L2
     fa.may_blend = c->may_blend ? 1u : 0u;
     fa.skip_solid = wire_front ? 1u : 0u;
+    fa.texels32 = c->d_texels32;
+    fa.ordered_all = ordered_all ? 1u : 0u;
+    if (c->fmt8) fa.fp.xray = 0;                        // render_mesh: x-ray only changes culling; its stores keep their own depth tests
     launch_fill(s, fa, c->n_cu, prof_fill ? ev[4] : nullptr);
     if (fp.wire_collect && c->nf) {
         WireArgs wa{};
@@ -562,7 +609,16 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     return B32_OK;
 }
 
+static int render_scene_async_any(b32_ctx* c, const B32Camera* cam, const B32Settings* st, const B32Fog* fog);
 int b32_render_scene_15_async(b32_ctx* c, const B32Camera* cam, const B32Settings* st, const B32Fog* fog) {
+    if (!c || c->fmt8) return B32_E_ARG;                 // the resident scene holds Texture (8-bit) texels: use b32_render_scene
+    return render_scene_async_any(c, cam, st, fog);
+}
+int b32_render_scene_async(b32_ctx* c, const B32Camera* cam, const B32Settings* st) {
+    if (!c || !c->fmt8) return B32_E_ARG;
+    return render_scene_async_any(c, cam, st, nullptr);
+}
+static int render_scene_async_any(b32_ctx* c, const B32Camera* cam, const B32Settings* st, const B32Fog* fog) {
     if (!c || !cam || !st || !c->fb || !c->have_scene) return B32_E_ARG;
     (void)hipSetDevice(c->device);
     int rc = validate_settings(st);
@@ -650,6 +706,25 @@ int b32_render_scene_15(b32_ctx* c, const B32Camera* cam, const B32Settings* st,
     if (rc == B32_OK) rc = b32_frame_finish(c, out);
     c->profile_level = saved;
     return rc;
+}
+
+int b32_render_scene(b32_ctx* c, const B32Camera* cam, const B32Settings* st, B32Timings* out) {
+    if (!c) return B32_E_ARG;
+    const int saved = c->profile_level;
+    if (out) c->profile_level = 2;
+    int rc = b32_render_scene_async(c, cam, st);
+    if (rc == B32_OK) rc = b32_frame_finish(c, out);
+    c->profile_level = saved;
+    return rc;
+}
+
+int b32_render_mesh(b32_ctx* c, const B32Vertex* v, uint32_t nv, const B32Face* f, uint32_t nf, const B32Texture* tex, uint32_t nt,
+                    const B32Camera* cam, const B32Settings* st, B32Timings* out) {
+    if (!c || !cam || !st || !c->fb) return B32_E_ARG;
+    int rc = validate_settings(st);
+    if (rc) return rc;
+    if ((rc = b32_scene_upload_rgba(c, v, nv, f, nf, tex, nt))) return rc;
+    return b32_render_scene(c, cam, st, out);
 }
 
 int b32_render_mesh_15(b32_ctx* c, const B32Vertex* v, uint32_t nv, const B32Face* f, uint32_t nf, const B32Texture15* tex, uint32_t nt,

@@ -75,7 +75,7 @@ struct FrameParams {
     uint32_t nv, nf, nt;
     uint32_t n_lights;
     float ambient;
-    uint8_t affine, shading, backface_cull, dithering, fixed_point, has_fog, zmode, pad1;   // zmode = settings.use_zbuffer
+    uint8_t affine, shading, backface_cull, dithering, fixed_point, has_fog, zmode, fmt8;   // zmode = settings.use_zbuffer; fmt8 = render_mesh (8-bit colour)
     uint8_t ortho, xray, wire_collect, pad2;   // ortho_projection.is_some(), xray_mode, any wireframe phase wants its triangles
     float ortho_zoom, ortho_cx, ortho_cy;      // OrthoProjection (types.rs), math.rs:140-148
     B32Fog fog;
@@ -241,6 +241,8 @@ struct FillArgs {
     uint32_t may_blend;         // 0: no face/texture can be in the transparent pass -> k_blend is not launched
     uint32_t exact_coverage;    // 1: phase A applies the full skip rule and counts fragment stores; 0: CHEAP coverage + repair
     uint32_t skip_solid;        // wireframe_overlay: surfaces are counted but not drawn (render.rs:2550)
+    const uint32_t* texels32;   // 8-bit-colour path: pooled Color texels, r | g<<8 | b<<16 | blend<<24 (TexDesc.offset indexes this pool)
+    uint32_t ordered_all;       // 1: every surface may blend -> no overwrite pass, k_blend walks the whole tile list in order
 };
 void launch_fill(hipStream_t s, const FillArgs& a, int n_cu, hipEvent_t after_cover = nullptr);   // k_cover [event] k_shade k_blend
 size_t fill_lds_tex_budget();   // bytes of LDS left for a staged texture

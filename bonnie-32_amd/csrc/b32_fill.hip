@@ -66,11 +66,20 @@ __device__ __forceinline__ bool inside_bc(const Tri& t, float w0, float w1, floa
     return bcx >= ERR && bcy >= ERR && bcz >= ERR;
 }
 
-// Texel fetch + transparency rules (render.rs:1563-1607). Returns false when the fragment is skipped.
-template <int TEXMODE>
+// Texture::sample of the 8-bit-colour path (types.rs:1242-1253): Color texel r | g<<8 | b<<16 | blend<<24
+__device__ __forceinline__ uint32_t sample8(const Tri& t, const uint32_t* __restrict__ gtex, float u, float v) {
+    if (t.tw == 0 || t.th == 0) return (uint32_t)B32_BLEND_ERASE << 24;                 // Color::TRANSPARENT
+    const float uw = rem_euclid1(u), vw = rem_euclid1(v);
+    const uint32_t tx = min(f2u_sat(uw * (float)t.tw), t.tw - 1);
+    const uint32_t ty = min(f2u_sat(vw * (float)t.th), t.th - 1);
+    return gtex[t.toff + ty * t.tw + tx];
+}
+
+// Texel fetch + transparency rules (render.rs:1563-1607; 8-bit path render.rs:1322-1352). Returns false when the fragment is skipped.
+template <int TEXMODE, bool FMT8 = false>
 __device__ __forceinline__ bool texel_drawn(const Tri& t, float bcx, float bcy, float bcz, const uint16_t* __restrict__ gtex,
                                             const uint16_t* ltex, uint32_t& texel, bool affine = true) {
-    uint32_t c = 0x7FFF;                                         // Color15::WHITE, render.rs:1585
+    uint32_t c = FMT8 ? 0x00FFFFFFu : 0x7FFFu;                   // Color::WHITE (render.rs:1344) / Color15::WHITE (render.rs:1585)
     if ((t.flags & F_TEX_MASK) != F_TEX_NONE) {
         float u, v;
         if (affine) {
@@ -83,7 +92,12 @@ __device__ __forceinline__ bool texel_drawn(const Tri& t, float bcx, float bcy, 
             u = u_over_z / inv_z;
             v = v_over_z / inv_z;
         }
-        c = sample15<TEXMODE>(t, gtex, ltex, u, 1.0f - v);       // render.rs:1583
+        if (FMT8) c = sample8(t, reinterpret_cast<const uint32_t*>(gtex), u, 1.0f - v);   // render.rs:1342
+        else c = sample15<TEXMODE>(t, gtex, ltex, u, 1.0f - v);  // render.rs:1583
+    }
+    if (FMT8) {                                                  // color.is_transparent(), render.rs:1348-1352
+        texel = c;
+        return (c >> 24) != B32_BLEND_ERASE;
     }
     if (c == 0) {                                                // render.rs:1592-1602
         if (t.flags & F_BLACK_TR) return false;
@@ -141,6 +155,58 @@ __device__ __forceinline__ uint32_t store_blend(uint32_t back, uint32_t out15, u
     }
     if (do_blend) return blend_rgb555(front, back, mode) | 0xFF000000u;   // set_pixel_blended_15, render.rs:479-502
     return front;                                                           // set_pixel_15, render.rs:445-454
+}
+
+// 8-bit-colour pipeline (render.rs:1355-1387): modulate (types.rs:801-808), shade_color_rgb (render.rs:1074-1081, no clamp of
+// the shade), apply_dither (render.rs:1186-1197).  Returns r | g<<8 | b<<16 | blend<<24 (the texel's blend mode survives).
+__device__ __forceinline__ uint32_t shade8(uint32_t texel, float bcx, float bcy, float bcz, uint32_t vc1, uint32_t vc2, uint32_t vc3,
+                                           uint32_t flags, int shading, const float* sh, uint32_t px, uint32_t py) {
+    uint32_t out = texel & 0xFF000000u;
+    const int off = dither_offset(px, py);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const uint32_t t8 = (texel >> (8 * i)) & 255;
+        const float f1 = (float)((vc1 >> (8 * i)) & 255), f2 = (float)((vc2 >> (8 * i)) & 255), f3 = (float)((vc3 >> (8 * i)) & 255);
+        const uint32_t vert = f2u8_sat(bcx * f1 + bcy * f2 + bcz * f3);
+        uint32_t m = min((t8 * vert) / 128u, 255u);
+        if (shading != B32_SHADE_NONE) {
+            const float s = shading == B32_SHADE_FLAT ? sh[i] : (bcx * sh[i] + bcy * sh[3 + i] + bcz * sh[6 + i]);
+            m = f2u8_sat(rmin((float)m * s, 255.0f));
+        }
+        if (flags & F_DITHER) m = (uint32_t)min(max(((int)m + off) >> 3, 0), 31) << 3;
+        out |= m << (8 * i);
+    }
+    return out;
+}
+// Pixel store of the 8-bit path once the depth test (if any) has passed: Color::blend_with (types.rs:886-936) by the
+// colour's own blend mode, then the editor-alpha lerp in f32 (render.rs:356-366) -> RGBA8 word (Color::to_bytes).
+__device__ __forceinline__ uint32_t store8(uint32_t back, uint32_t color, uint32_t alpha) {
+    const uint32_t mode = color >> 24;
+    uint32_t ps1 = 0, a8 = 255;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int f = (int)((color >> (8 * i)) & 255), b = (int)((back >> (8 * i)) & 255);
+        int r;
+        switch (mode) {
+            default:
+            case B32_BLEND_OPAQUE:      r = f; break;
+            case B32_BLEND_AVERAGE:     r = (b + f) / 2; break;
+            case B32_BLEND_ADD:         r = min(b + f, 255); break;
+            case B32_BLEND_SUBTRACT:    r = max(b - f, 0); break;
+            case B32_BLEND_ADD_QUARTER: r = min(b + f / 4, 255); break;
+            case B32_BLEND_ERASE:       r = 0; a8 = 0; break;
+        }
+        ps1 |= (uint32_t)r << (8 * i);
+    }
+    if (alpha < 255) {
+        const float a = (float)alpha / 255.0f, inv_a = 1.0f - a;
+        uint32_t o = 0xFF000000u;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            o |= f2u8_sat((float)((ps1 >> (8 * i)) & 255) * a + (float)((back >> (8 * i)) & 255) * inv_a) << (8 * i);
+        return o;
+    }
+    return ps1 | (a8 << 24);
 }
 
 // Replay of the reference's accumulated edge functions up to pixel (px,py) (render.rs:1527-1533, 1706-1712).
@@ -249,7 +315,7 @@ __device__ __forceinline__ bool frag_zkey(const Tri& t, float bcx, float bcy, fl
 }
 
 // Phase A for one surface: coverage of the (tile-clipped) bbox [cx0,cx1) x [cy0,cy1), winner value li.
-template <int TEXMODE, bool EXACT, bool ZMODE>
+template <int TEXMODE, bool EXACT, bool ZMODE, bool FMT8>
 __device__ __forceinline__ uint32_t cover_surface(const Tri& tr, uint32_t cx0, uint32_t cx1, uint32_t cy0, uint32_t cy1, uint32_t li,
                                                   uint32_t* tilebuf, uint32_t x_lo, uint32_t ty_top, uint32_t lane,
                                                   const uint16_t* __restrict__ gtex, const uint16_t* ltex, bool affine) {
@@ -277,7 +343,7 @@ __device__ __forceinline__ uint32_t cover_surface(const Tri& tr, uint32_t cx0, u
                         uint32_t texel;
                         uint32_t zkey = 0;
                         drawn = ZMODE ? frag_zkey(tr, bcx, bcy, bcz, zkey) : true;
-                        if (drawn && EXACT) drawn = texel_drawn<TEXMODE>(tr, bcx, bcy, bcz, gtex, ltex, texel, affine);
+                        if (drawn && EXACT) drawn = texel_drawn<TEXMODE, FMT8>(tr, bcx, bcy, bcz, gtex, ltex, texel, affine);
                         if (drawn) commit_fragment<EXACT, ZMODE>(tilebuf, (py - ty_top) * TILE_STRIDE + (px - x_lo), li, zkey);
                     }
                 }
@@ -297,7 +363,7 @@ __device__ __forceinline__ uint32_t cover_surface(const Tri& tr, uint32_t cx0, u
                         uint32_t texel;
                         uint32_t zkey = 0;
                         bool drawn = ZMODE ? frag_zkey(tr, bcx, bcy, bcz, zkey) : true;
-                        if (drawn && EXACT) drawn = texel_drawn<TEXMODE>(tr, bcx, bcy, bcz, gtex, ltex, texel, affine);
+                        if (drawn && EXACT) drawn = texel_drawn<TEXMODE, FMT8>(tr, bcx, bcy, bcz, gtex, ltex, texel, affine);
                         if (drawn) { commit_fragment<EXACT, ZMODE>(tilebuf, (py - ty_top) * TILE_STRIDE + (px - x_lo), li, zkey); ++mine; }
                     }
                     w0 += tr.a0; w1 += tr.a1;
@@ -330,7 +396,7 @@ __device__ __forceinline__ uint32_t bperm(uint32_t src_lane, uint32_t v) { retur
 __device__ __forceinline__ float bpermf(uint32_t src_lane, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), __float_as_int(v))); }
 
 // Phase A, EXACT coverage, wave-cooperative form (one wave per surface): used for F_SLOW surfaces and as reference path.
-template <int TEXMODE, bool EXACT, bool ZMODE>
+template <int TEXMODE, bool EXACT, bool ZMODE, bool FMT8>
 __device__ __forceinline__ uint32_t cover_one(const Batch& b, int t, uint32_t li, uint32_t* tilebuf, uint32_t x_lo, uint32_t x_hi,
                                               uint32_t y_lo, uint32_t y_hi, uint32_t ty_top, uint32_t lane,
                                               const uint16_t* __restrict__ gtex, const uint16_t* ltex, bool affine) {
@@ -338,7 +404,7 @@ __device__ __forceinline__ uint32_t cover_one(const Batch& b, int t, uint32_t li
     const uint32_t cx0 = max(tr.min_x, x_lo), cx1 = min(tr.max_x, x_hi);
     const uint32_t cy0 = max(tr.min_y, y_lo), cy1 = min(tr.max_y, y_hi);
     if (cx0 >= cx1 || cy0 >= cy1) return 0;
-    return cover_surface<TEXMODE, EXACT, ZMODE>(tr, cx0, cx1, cy0, cy1, li, tilebuf, x_lo, ty_top, lane, gtex, ltex, affine);
+    return cover_surface<TEXMODE, EXACT, ZMODE, FMT8>(tr, cx0, cx1, cy0, cy1, li, tilebuf, x_lo, ty_top, lane, gtex, ltex, affine);
 }
 
 // Phase A as a ROW-ITEM scheduler.  Waves grab 64 list entries at a time from an LDS cursor (load balance across the 16
@@ -348,12 +414,12 @@ __device__ __forceinline__ uint32_t cover_one(const Batch& b, int t, uint32_t li
 // incrementally exactly like the reference's inner loop (render.rs:1533-1707): start value = closed form at the row start
 // (exact integers under the k_setup guard), then w0 += a0, w1 += a1 per pixel.  Row lengths are far more uniform than
 // bbox areas, big surfaces fill whole rounds, and there is no per-surface scalar work.
-template <int TEXMODE, bool EXACT, int NW, bool ZMODE>
+template <int TEXMODE, bool EXACT, int NW, bool ZMODE, bool FMT8>
 __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, uint32_t e0, uint32_t n_op, uint32_t lane, uint32_t wave,
                                                            volatile uint32_t* cursor, volatile uint32_t* wmark, const TexDesc& lds_desc,
                                                            uint32_t* tilebuf, uint32_t x_lo, uint32_t x_hi, uint32_t y_lo, uint32_t y_hi,
                                                            uint32_t ty_top, const uint16_t* ltex) {
-    const uint16_t* __restrict__ gtex = a.texels;
+    const uint16_t* __restrict__ gtex = FMT8 ? reinterpret_cast<const uint16_t*>(a.texels32) : a.texels;
     unsigned long long frags = 0;
     const float ERR = -0.0001f;
     const bool affine = a.fp.affine != 0;
@@ -424,7 +490,7 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
                             bool drawn = true;
                             uint32_t zkey = 0;
                             if (ZMODE) drawn = frag_zkey(tr, bcx, bcy, bcz, zkey);
-                            if (EXACT && drawn) { uint32_t texel; drawn = texel_drawn<TEXMODE>(tr, bcx, bcy, bcz, gtex, ltex, texel, affine); }
+                            if (EXACT && drawn) { uint32_t texel; drawn = texel_drawn<TEXMODE, FMT8>(tr, bcx, bcy, bcz, gtex, ltex, texel, affine); }
                             if (drawn) { commit_fragment<EXACT, ZMODE>(tilebuf, addr, li, zkey); ++mine; }
                         }
                         ++addr; w0 += sa0; w1 += sa1;
@@ -457,7 +523,7 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
         while (sm) {
             const int t = __builtin_ctzll(sm);
             sm &= sm - 1;
-            frags += cover_one<TEXMODE, EXACT, ZMODE>(b, t, cs + (uint32_t)t + 1, tilebuf, x_lo, x_hi, y_lo, y_hi, ty_top, lane, gtex, ltex, affine);
+            frags += cover_one<TEXMODE, EXACT, ZMODE, FMT8>(b, t, cs + (uint32_t)t + 1, tilebuf, x_lo, x_hi, y_lo, y_hi, ty_top, lane, gtex, ltex, affine);
         }
     }
     (void)wave;
@@ -543,7 +609,7 @@ __device__ void tile_local_sort(uint32_t* sort_area, uint32_t* wcnt, volatile ui
 }
 
 // ------------------------------------------------------------------------------------------------ k_cover
-template <int TEXMODE, bool EXACT, int NT, bool ZMODE>
+template <int TEXMODE, bool EXACT, int NT, bool ZMODE, bool FMT8 = false>
 __global__ __launch_bounds__(NT) void k_cover(FillArgs a) {
     constexpr int NW = NT / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -611,7 +677,7 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a) {
         __syncthreads();
         const uint32_t n_op = e1 - e0;
         if (n_op) {
-            frag_count += phase_a_rows<TEXMODE, EXACT, NW, ZMODE>(a, e0, n_op, lane, wave, &misc[2], wmarks + wave * 64, lds_desc, tilebuf,
+            frag_count += phase_a_rows<TEXMODE, EXACT, NW, ZMODE, FMT8>(a, e0, n_op, lane, wave, &misc[2], wmarks + wave * 64, lds_desc, tilebuf,
                                                            x_lo, x_hi, y_lo, y_hi, ty_top, ltex);
             __syncthreads();
         }
@@ -655,6 +721,7 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a) {
 // ------------------------------------------------------------------------------------------------ k_shade
 // Coverage test of list entry li at pixel (px,py): inside test + texel + transparency rule. Keeps what colouring needs.
 struct Hit { float bcx, bcy, bcz; uint32_t texel, vc1, vc2, vc3, flags, sid; };
+template <bool FMT8>
 __device__ __forceinline__ bool hit_test(const FillArgs& a, uint32_t sid, uint32_t px, uint32_t py, Hit& h) {
     const uint4* rp = reinterpret_cast<const uint4*>(a.recs + sid);
     const uint4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3], q4 = rp[4];
@@ -679,19 +746,23 @@ __device__ __forceinline__ bool hit_test(const FillArgs& a, uint32_t sid, uint32
     edge_w(tr, px, py, w0, w1);
     if (!inside_bc(tr, w0, w1, h.bcx, h.bcy, h.bcz)) return false;
     h.texel = 0;
-    if (!texel_drawn<0>(tr, h.bcx, h.bcy, h.bcz, a.texels, nullptr, h.texel, affine)) return false;
+    if (!texel_drawn<0, FMT8>(tr, h.bcx, h.bcy, h.bcz, FMT8 ? reinterpret_cast<const uint16_t*>(a.texels32) : a.texels, nullptr, h.texel, affine)) return false;
     h.vc1 = q4.x; h.vc2 = q4.y; h.vc3 = q4.z; h.flags = tr.flags; h.sid = sid;
     return true;
 }
+template <bool FMT8>
 __device__ __forceinline__ uint32_t colour(const FillArgs& a, const Hit& h, int shading, uint32_t px, uint32_t py) {
     float shv[9];
     if (shading != B32_SHADE_NONE) for (int j = 0; j < 9; ++j) shv[j] = a.shades[(size_t)h.sid * 9 + j];
+    // 8-bit path: the overwrite pass only runs when no texel blends and every editor alpha is 255 -> set_pixel (render.rs:301-310)
+    if (FMT8) return (shade8(h.texel, h.bcx, h.bcy, h.bcz, h.vc1, h.vc2, h.vc3, h.flags, shading, shv, px, py) & 0xFFFFFFu) | 0xFF000000u;
     return c15_to_rgba(shade15(h.texel, h.bcx, h.bcy, h.bcz, h.vc1, h.vc2, h.vc3, h.flags, shading, shv, px, py));   // set_pixel_15
 }
 
 // One 256-thread workgroup per 64x16 strip of a 64x64 tile; each wave shades a 64-pixel row segment at a time (256-B coalesced
 // visibility reads / framebuffer writes), 4 rows per wave, and the strips of a tile are placed on one XCD, so a surface record
 // is pulled through one L2 only (row-major traversal re-fetched every record once per row it covers: 145 MB instead of ~85 MB).
+template <bool FMT8>
 __global__ __launch_bounds__(256) void k_shade(FillArgs a) {
     if (a.ctrl->abort || a.ctrl->need_global_sort) return;
     const FrameParams& fp = a.fp;
@@ -720,11 +791,11 @@ __global__ __launch_bounds__(256) void k_shade(FillArgs a) {
     Hit h;
     bool have = false;
     uint32_t scan_from = 0;                     // > 0: list positions <= scan_from still have to be searched
-    if (li && !(have = hit_test(a, a.pair_vals[e0 + li - 1], px, py, h))) {
+    if (li && !(have = hit_test<FMT8>(a, a.pair_vals[e0 + li - 1], px, py, h))) {
         // CHEAP coverage only: the top surface is skipped at this pixel -> highest surface below it whose fragment is drawn.
         if (long_list) scan_from = li - 1;
         else if (second) {                      // exact runner-up from k_cover: almost always the answer (else ~1/256 again)
-            if (!(have = hit_test(a, a.pair_vals[e0 + second - 1], px, py, h))) scan_from = second - 1;
+            if (!(have = hit_test<FMT8>(a, a.pair_vals[e0 + second - 1], px, py, h))) scan_from = second - 1;
         }                                       // second == 0: no other surface covers the pixel, it keeps the framebuffer value
     }
     // rare: the wave scans the tile list downward, 64 entries per step; only the coverage test runs per candidate
@@ -741,7 +812,7 @@ __global__ __launch_bounds__(256) void k_shade(FillArgs a) {
                 const uint32_t csid = a.pair_vals[e0 + cli - 1];
                 const uint4* rp = reinterpret_cast<const uint4*>(a.recs + csid);
                 const uint32_t bbx = rp[1].w, bby = rp[2].x;
-                if (fx >= (bbx & 0xFFFF) && fx < (bbx >> 16) && py >= (bby & 0xFFFF) && py < (bby >> 16)) hit = hit_test(a, csid, fx, py, c);
+                if (fx >= (bbx & 0xFFFF) && fx < (bbx >> 16) && py >= (bby & 0xFFFF) && py < (bby >> 16)) hit = hit_test<FMT8>(a, csid, fx, py, c);
             }
             const unsigned long long hm = __ballot(hit);
             if (hm) {                                                                     // lowest lane == highest list position
@@ -753,7 +824,7 @@ __global__ __launch_bounds__(256) void k_shade(FillArgs a) {
             }
         }
     }
-    if (have) a.fb[(size_t)py * W + px] = colour(a, h, shading, px, py);
+    if (have) a.fb[(size_t)py * W + px] = colour<FMT8>(a, h, shading, px, py);
     }
 }
 
@@ -767,7 +838,38 @@ __device__ __forceinline__ bool ztest(const Tri& t, float bcx, float bcy, float 
     return ((t.flags >> F_ALPHA_SHIFT) < 255) ? !(z >= zb) : (z < zb);
 }
 
-template <int NT>
+// One fragment of the ordered pass at a pixel the inside test accepted.  Returns true when a pixel store happened.
+template <bool FMT8>
+__device__ __forceinline__ bool blend_fragment(const FillArgs& a, const Tri& tr, float bcx, float bcy, float bcz, uint32_t px, uint32_t py,
+                                               uint32_t vc1, uint32_t vc2, uint32_t vc3, int shading, const float* shv,
+                                               uint32_t* dst, float* zdst, int zmode, bool xray) {
+    const bool affine = a.fp.affine != 0;
+    uint32_t texel;
+    if (FMT8) {
+        // rasterize_triangle (render.rs:1302-1424): the early `z >= zbuffer` reject and the store's own test collapse into one
+        // test per store kind (they differ only for NaN depths); every store that passes also writes the depth.
+        const uint32_t alpha = tr.flags >> F_ALPHA_SHIFT;
+        float z = 0.0f;
+        if (zmode) {
+            const float inv_z = bcx * tr.iz1 + bcy * tr.iz2 + bcz * tr.iz3;
+            z = 1.0f / inv_z;
+            const float zb = *zdst;
+            if (alpha < 255 ? (z >= zb) : !(z < zb)) return false;               // render.rs:387 / :432, :1407
+        }
+        if (!texel_drawn<0, true>(tr, bcx, bcy, bcz, reinterpret_cast<const uint16_t*>(a.texels32), nullptr, texel, affine)) return false;
+        const uint32_t col = shade8(texel, bcx, bcy, bcz, vc1, vc2, vc3, tr.flags, shading, shv, px, py);
+        if (zmode) *zdst = z;
+        *dst = store8(*dst, col, alpha);
+        return true;
+    }
+    if (!ztest(tr, bcx, bcy, bcz, zmode, *zdst)) return false;
+    if (!texel_drawn<0>(tr, bcx, bcy, bcz, a.texels, nullptr, texel, affine)) return false;
+    const uint32_t out15 = shade15(texel, bcx, bcy, bcz, vc1, vc2, vc3, tr.flags, shading, shv, px, py);
+    *dst = store_blend(*dst, out15, tr.flags, xray);
+    return true;
+}
+
+template <int NT, bool FMT8>
 __global__ __launch_bounds__(NT) void k_blend(FillArgs a) {
     constexpr int NW = NT / 64;
     __shared__ uint32_t tilebuf[TILE_H * TILE_STRIDE];
@@ -777,8 +879,9 @@ __global__ __launch_bounds__(NT) void k_blend(FillArgs a) {
     const FrameParams& fp = a.fp;
     const uint32_t tile = blockIdx.x;
     // x-ray: every surface blends (render.rs:1671-1673), so the ordered pass walks the opaque list too, then the transparent one
+    // (8-bit path with blending texels / editor alpha: one list, same ordered walk, render.rs:2193-2202)
     const bool xray = fp.xray != 0;
-    const uint32_t e1 = a.tile_keys_only ? a.tile_mid[tile] : a.ranges[2 * tile + (xray ? 0 : 1)];
+    const uint32_t e1 = a.tile_keys_only ? a.tile_mid[tile] : a.ranges[2 * tile + (a.ordered_all ? 0 : 1)];
     const uint32_t e2 = a.tile_keys_only ? a.ranges[tile + 1] : a.ranges[2 * tile + 2];
     if (e1 == e2) return;
     const int zmode = (fp.zmode && !xray) ? 1 : 0;               // x-ray skips the depth test (render.rs:1553)
@@ -823,15 +926,11 @@ __global__ __launch_bounds__(NT) void k_blend(FillArgs a) {
                         const uint32_t px = bx + (lane & 15), py = by + (lane >> 4);
                         bool drawn = false;
                         if (px < cx1 && py < cy1) {
-                            float w0, w1, bcx, bcy, bcz; uint32_t texel;
+                            float w0, w1, bcx, bcy, bcz;
                             edge_w(tr, px, py, w0, w1);
-                            if (inside_bc(tr, w0, w1, bcx, bcy, bcz) && ztest(tr, bcx, bcy, bcz, zmode, tilez[(py - ty_top) * TILE_STRIDE + (px - x_lo)]) &&
-                                texel_drawn<0>(tr, bcx, bcy, bcz, a.texels, nullptr, texel, fp.affine != 0)) {
-                                const uint32_t out15 = shade15(texel, bcx, bcy, bcz, vc1, vc2, vc3, tr.flags, shading, shv, px, py);
-                                uint32_t* dst = &tilebuf[(py - ty_top) * TILE_STRIDE + (px - x_lo)];
-                                *dst = store_blend(*dst, out15, tr.flags, xray);
-                                drawn = true;
-                            }
+                            const uint32_t ti = (py - ty_top) * TILE_STRIDE + (px - x_lo);
+                            if (inside_bc(tr, w0, w1, bcx, bcy, bcz))
+                                drawn = blend_fragment<FMT8>(a, tr, bcx, bcy, bcz, px, py, vc1, vc2, vc3, shading, shv, &tilebuf[ti], &tilez[ti], zmode, xray);
                         }
                         frag_count += (unsigned long long)__popcll(__ballot(drawn));
                     }
@@ -842,14 +941,10 @@ __global__ __launch_bounds__(NT) void k_blend(FillArgs a) {
                     float w0, w1;
                     replay_w(tr, cx0, py, w0, w1);
                     for (uint32_t px = cx0; px < cx1; ++px) {
-                        float bcx, bcy, bcz; uint32_t texel;
-                        if (inside_bc(tr, w0, w1, bcx, bcy, bcz) && ztest(tr, bcx, bcy, bcz, zmode, tilez[(py - ty_top) * TILE_STRIDE + (px - x_lo)]) &&
-                            texel_drawn<0>(tr, bcx, bcy, bcz, a.texels, nullptr, texel, fp.affine != 0)) {
-                            const uint32_t out15 = shade15(texel, bcx, bcy, bcz, vc1, vc2, vc3, tr.flags, shading, shv, px, py);
-                            uint32_t* dst = &tilebuf[(py - ty_top) * TILE_STRIDE + (px - x_lo)];
-                            *dst = store_blend(*dst, out15, tr.flags, xray);
-                            ++mine;
-                        }
+                        float bcx, bcy, bcz;
+                        const uint32_t ti = (py - ty_top) * TILE_STRIDE + (px - x_lo);
+                        if (inside_bc(tr, w0, w1, bcx, bcy, bcz) &&
+                            blend_fragment<FMT8>(a, tr, bcx, bcy, bcz, px, py, vc1, vc2, vc3, shading, shv, &tilebuf[ti], &tilez[ti], zmode, xray)) ++mine;
                         w0 += tr.a0; w1 += tr.a1;
                     }
                 }
@@ -862,7 +957,10 @@ __global__ __launch_bounds__(NT) void k_blend(FillArgs a) {
     for (uint32_t p = tid; p < TILE_W * TILE_H; p += NT) {      // finished tile back, one 256-B row segment per wave instruction
         const uint32_t row = p >> 6, col = p & 63;
         const uint32_t px = x_lo + col, py = ty_top + row;
-        if (px < x_hi && py >= y_lo && py < y_hi) a.fb[(size_t)py * fp.width + px] = tilebuf[row * TILE_STRIDE + col];
+        if (px < x_hi && py >= y_lo && py < y_hi) {
+            a.fb[(size_t)py * fp.width + px] = tilebuf[row * TILE_STRIDE + col];
+            if (FMT8 && zmode) a.zbuf[(size_t)py * fp.width + px] = tilez[row * TILE_STRIDE + col];     // the 8-bit path writes depth on every store
+        }
     }
     if (lane == 0) wf[wave] = frag_count;
     __syncthreads();
@@ -877,29 +975,38 @@ void launch_fill(hipStream_t s, const FillArgs& a, int n_cu, hipEvent_t after_co
     const uint32_t ntiles = a.fp.tiles_x * a.fp.tiles_y;
     if (ntiles == 0) return;
     if (a.skip_solid) { if (after_cover) (void)hipEventRecord(after_cover, s); return; }   // wireframe_overlay: nothing solid is drawn (render.rs:2550)
-    if (a.fp.xray) {                                             // no overwrite pass at all: everything goes through the ordered blend
+    const bool f8 = a.fp.fmt8 != 0;
+    if (a.ordered_all) {                                         // no overwrite pass at all: everything goes through the ordered walk
         if (after_cover) (void)hipEventRecord(after_cover, s);
-        hipLaunchKernelGGL((k_blend<1024>), dim3(ntiles), dim3(1024), 0, s, a);
+        if (f8) hipLaunchKernelGGL((k_blend<1024, true>), dim3(ntiles), dim3(1024), 0, s, a);
+        else hipLaunchKernelGGL((k_blend<1024, false>), dim3(ntiles), dim3(1024), 0, s, a);
         return;
     }
+    const size_t lds_sort = LDS_TEX_OFFSET + LDS_SORT_CNT_BYTES + 2048;
     if (a.fp.zmode) {
-        hipLaunchKernelGGL((k_cover<0, true, 512, true>), dim3(min(ntiles, (uint32_t)n_cu * 3)), dim3(512), LDS_TEX_OFFSET + LDS_SORT_CNT_BYTES + 2048, s, a);
+        if (f8) hipLaunchKernelGGL((k_cover<0, true, 512, true, true>), dim3(min(ntiles, (uint32_t)n_cu * 3)), dim3(512), lds_sort, s, a);
+        else hipLaunchKernelGGL((k_cover<0, true, 512, true, false>), dim3(min(ntiles, (uint32_t)n_cu * 3)), dim3(512), lds_sort, s, a);
     } else if (a.exact_coverage) {
-        if (a.lds_tex_texels) {     // texture sampled once per fragment: stage it in LDS, one 16-wave workgroup per CU
+        if (f8) {
+            hipLaunchKernelGGL((k_cover<0, true, 512, false, true>), dim3(min(ntiles, (uint32_t)n_cu * 2)), dim3(512), LDS_TEX_OFFSET, s, a);
+        } else if (a.lds_tex_texels) {     // texture sampled once per fragment: stage it in LDS, one 16-wave workgroup per CU
             const size_t lds = LDS_TEX_OFFSET + (((size_t)a.lds_tex_texels * 2 + 15) & ~(size_t)15);
             static bool attr_set = false;
-            if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<1, true, 1024, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
-            hipLaunchKernelGGL((k_cover<1, true, 1024, false>), dim3(min(ntiles, (uint32_t)n_cu)), dim3(1024), lds, s, a);
+            if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<1, true, 1024, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+            hipLaunchKernelGGL((k_cover<1, true, 1024, false, false>), dim3(min(ntiles, (uint32_t)n_cu)), dim3(1024), lds, s, a);
         } else {
-            hipLaunchKernelGGL((k_cover<0, true, 512, false>), dim3(min(ntiles, (uint32_t)n_cu * 2)), dim3(512), LDS_TEX_OFFSET, s, a);
+            hipLaunchKernelGGL((k_cover<0, true, 512, false, false>), dim3(min(ntiles, (uint32_t)n_cu * 2)), dim3(512), LDS_TEX_OFFSET, s, a);
         }
-    } else {
-        hipLaunchKernelGGL((k_cover<0, false, 512, false>), dim3(min(ntiles, (uint32_t)n_cu * 3)), dim3(512), LDS_TEX_OFFSET + LDS_SORT_CNT_BYTES + 2048, s, a);
+    } else {    // CHEAP coverage never samples a texture: one kernel for both pixel formats
+        hipLaunchKernelGGL((k_cover<0, false, 512, false, false>), dim3(min(ntiles, (uint32_t)n_cu * 3)), dim3(512), lds_sort, s, a);
     }
     if (after_cover) (void)hipEventRecord(after_cover, s);
     const uint32_t band_h = a.fp.band_y1 - a.fp.band_y0;
-    if (band_h) hipLaunchKernelGGL(k_shade, dim3(((ntiles + 7) / 8) * 8 * 4), dim3(256), 0, s, a);
-    if (a.may_blend) hipLaunchKernelGGL((k_blend<1024>), dim3(ntiles), dim3(1024), 0, s, a);
+    if (band_h) {
+        if (f8) hipLaunchKernelGGL(k_shade<true>, dim3(((ntiles + 7) / 8) * 8 * 4), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(k_shade<false>, dim3(((ntiles + 7) / 8) * 8 * 4), dim3(256), 0, s, a);
+    }
+    if (a.may_blend && !f8) hipLaunchKernelGGL((k_blend<1024, false>), dim3(ntiles), dim3(1024), 0, s, a);
 }
 
 size_t fill_lds_tex_budget() { return 160 * 1024 - LDS_TEX_OFFSET - 16; }

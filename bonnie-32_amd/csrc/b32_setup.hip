@@ -206,6 +206,7 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp, const B32Vertex* 
             if (keep) {
                 visible = true;
                 transparent = (have_tex && tex_blend != B32_BLEND_OPAQUE) || face_blend != B32_BLEND_OPAQUE || editor_alpha < 255;  // :2403-2415
+                if (fp.fmt8) transparent = false;     // render_mesh computes has_transparency but never partitions (render.rs:2175-2184)
                 // Surface build: rendered backfaces swap v2/v3 and every per-vertex attribute (render.rs:2453-2479)
                 const int i1 = 0, i2 = backface ? 2 : 1, i3 = backface ? 1 : 2;
                 const V3 v1 = scr[i1], v2 = scr[i2], v3 = scr[i3];

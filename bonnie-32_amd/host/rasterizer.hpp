@@ -60,6 +60,9 @@ struct Face {
 // types.rs:532-539
 struct Texture15 { size_t width = 0, height = 0; std::vector<uint16_t> pixels; BlendMode blend_mode = BlendMode::Opaque; };
 
+// types.rs:1166-1176 — the 8-bit-colour path's texture: Color texels carry their own blend mode (Erase = transparent texel)
+struct Texture { size_t width = 0, height = 0; std::vector<Color> pixels; BlendMode blend_mode = BlendMode::Opaque; };
+
 // camera.rs:9-18 (basis vectors are inputs of the path)
 struct Camera { Vec3 position; Vec3 basis_x{ 1, 0, 0 }, basis_y{ 0, 1, 0 }, basis_z{ 0, 0, 1 }; };
 
@@ -145,6 +148,36 @@ inline RasterTimings render_mesh_15(Framebuffer& fb, const std::vector<Vertex>& 
     B32Timings tm{};
     check(b32_render_mesh_15(fb.ctx(), v.data(), (uint32_t)v.size(), f.data(), (uint32_t)f.size(), t.data(), (uint32_t)t.size(), &c, &s, fgp, &tm),
           "render_mesh_15");
+    return { tm.transform_ms, tm.fog_ms, tm.cull_ms, tm.sort_ms, tm.draw_ms, tm.wireframe_ms, tm.triangles_drawn, tm.fragments };
+}
+
+// render.rs:1971-1978 — the path taken when settings.use_rgb555 is false (scene.rs:163-169); no fog parameter
+inline RasterTimings render_mesh(Framebuffer& fb, const std::vector<Vertex>& vertices, const std::vector<Face>& faces,
+                                 const std::vector<Texture>& textures, const Camera& camera, const RasterSettings& settings) {
+    std::vector<B32Vertex> v; v.reserve(vertices.size());
+    for (const auto& x : vertices) v.push_back(detail::pack(x));
+    std::vector<B32Face> f; f.reserve(faces.size());
+    for (const auto& x : faces) f.push_back(detail::pack(x));
+    static_assert(sizeof(Color) == 4, "Color packs as r,g,b,blend bytes");
+    std::vector<B32Texture> t; t.reserve(textures.size());
+    for (const auto& x : textures)
+        t.push_back({ (uint32_t)x.width, (uint32_t)x.height, (uint32_t)x.blend_mode, 0,
+                      x.pixels.size() >= x.width * x.height && !x.pixels.empty() ? reinterpret_cast<const uint8_t*>(x.pixels.data()) : nullptr });
+    std::vector<B32Light> l;
+    for (const auto& x : settings.lights)
+        l.push_back({ x.type, { x.position.x, x.position.y, x.position.z }, { x.direction.x, x.direction.y, x.direction.z }, x.radius, x.angle,
+                      x.intensity, x.color.r, x.color.g, x.color.b, (uint8_t)x.enabled });
+    B32Camera c{ { camera.position.x, camera.position.y, camera.position.z }, { camera.basis_x.x, camera.basis_x.y, camera.basis_x.z },
+                 { camera.basis_y.x, camera.basis_y.y, camera.basis_y.z }, { camera.basis_z.x, camera.basis_z.y, camera.basis_z.z } };
+    B32Settings s{};
+    s.affine_textures = settings.affine_textures; s.use_zbuffer = settings.use_zbuffer; s.shading = (uint8_t)settings.shading;
+    s.backface_cull = settings.backface_cull; s.backface_wireframe = settings.backface_wireframe; s.dithering = settings.dithering;
+    s.wireframe_overlay = settings.wireframe_overlay; s.use_rgb555 = settings.use_rgb555; s.use_fixed_point = settings.use_fixed_point;
+    s.xray_mode = settings.xray_mode; s.has_ortho = settings.ortho_projection.has_value(); s.ambient = settings.ambient;
+    if (settings.ortho_projection) { s.ortho_zoom = settings.ortho_projection->x; s.ortho_center_x = settings.ortho_projection->y; s.ortho_center_y = settings.ortho_projection->z; }
+    s.n_lights = (uint32_t)l.size(); s.lights = l.empty() ? nullptr : l.data();
+    B32Timings tm{};
+    check(b32_render_mesh(fb.ctx(), v.data(), (uint32_t)v.size(), f.data(), (uint32_t)f.size(), t.data(), (uint32_t)t.size(), &c, &s, &tm), "render_mesh");
     return { tm.transform_ms, tm.fog_ms, tm.cull_ms, tm.sort_ms, tm.draw_ms, tm.wireframe_ms, tm.triangles_drawn, tm.fragments };
 }
 

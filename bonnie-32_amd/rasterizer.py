@@ -162,6 +162,21 @@ def render_mesh_15(fb: Framebuffer, vertices, faces, textures, camera: T.Camera,
     return T.RasterTimings.from_c(tm)
 
 
+def render_mesh(fb: Framebuffer, vertices, faces, textures, camera: T.Camera, settings: T.RasterSettings) -> T.RasterTimings:
+    """render_mesh (render.rs:1971-1978), the 8-bit-colour path every caller takes when `settings.use_rgb555` is false
+    (scene.rs:163-169).  `textures` are rtypes.Texture (Color texels with per-texel blend modes)."""
+    v, f = _geom(vertices, faces)
+    tex_arr, _keep = T.pack_textures8(textures)
+    cam = camera.pack()
+    st, _kl = settings.pack()
+    tm = abi.B32Timings()
+    rc = fb.ctx.lib.b32_render_mesh(fb.ctx.h, v.ctypes.data if len(v) else None, len(v),
+                                    f.ctypes.data if len(f) else None, len(f),
+                                    C.cast(tex_arr, C.c_void_p), len(textures), C.byref(cam), C.byref(st), C.byref(tm))
+    _chk(rc, "render_mesh")
+    return T.RasterTimings.from_c(tm)
+
+
 # aliases named in BASELINE.json's north_star (the reference's real entry point is render_mesh_15, SURVEY fact 3)
 draw_mesh = render_mesh_15
 
@@ -169,11 +184,17 @@ draw_mesh = render_mesh_15
 class ResidentScene:
     """A mesh + textures kept in HBM across frames: upload once, draw many times."""
 
-    def __init__(self, fb: Framebuffer, vertices, faces, textures=None, indexed_textures=None):
+    def __init__(self, fb: Framebuffer, vertices, faces, textures=None, indexed_textures=None, textures8=None):
         self.fb = fb
         self.ctx = fb.ctx
         v, f = _geom(vertices, faces)
-        if indexed_textures is not None:
+        self.fmt8 = textures8 is not None
+        if textures8 is not None:                       # the 8-bit-colour path (render_mesh)
+            arr, keep = T.pack_textures8(textures8)
+            rc = self.ctx.lib.b32_scene_upload_rgba(self.ctx.h, v.ctypes.data if len(v) else None, len(v),
+                                                    f.ctypes.data if len(f) else None, len(f),
+                                                    C.cast(arr, C.c_void_p), len(textures8))
+        elif indexed_textures is not None:
             arr, keep = T.pack_indexed_textures(indexed_textures)
             rc = self.ctx.lib.b32_scene_upload_indexed(self.ctx.h, v.ctypes.data if len(v) else None, len(v),
                                                        f.ctypes.data if len(f) else None, len(f),
@@ -198,8 +219,11 @@ class ResidentScene:
     def render(self, camera, settings, fog=None) -> T.RasterTimings:
         cam, st, _kl, fg = self._pack(camera, settings, fog)
         tm = abi.B32Timings()
-        _chk(self.ctx.lib.b32_render_scene_15(self.ctx.h, C.byref(cam), C.byref(st),
-                                              C.byref(fg) if fg is not None else None, C.byref(tm)), "render_scene_15")
+        if self.fmt8:
+            _chk(self.ctx.lib.b32_render_scene(self.ctx.h, C.byref(cam), C.byref(st), C.byref(tm)), "render_scene")
+        else:
+            _chk(self.ctx.lib.b32_render_scene_15(self.ctx.h, C.byref(cam), C.byref(st),
+                                                  C.byref(fg) if fg is not None else None, C.byref(tm)), "render_scene_15")
         return T.RasterTimings.from_c(tm)
 
     def render_async(self, camera=None, settings=None, fog=None):
@@ -207,6 +231,9 @@ class ResidentScene:
         if camera is not None:
             self._pack(camera, settings, fog)
         cam, st, _kl, fg = self._packed
+        if self.fmt8:
+            _chk(self.ctx.lib.b32_render_scene_async(self.ctx.h, C.byref(cam), C.byref(st)), "render_scene_async")
+            return
         _chk(self.ctx.lib.b32_render_scene_15_async(self.ctx.h, C.byref(cam), C.byref(st),
                                                     C.byref(fg) if fg is not None else None), "render_scene_15_async")
 

@@ -10,7 +10,7 @@ from typing import List, Optional, Tuple
 import numpy as np
 
 from . import abi
-from .abi import (OPAQUE, SHADE_GOURAUD, SHADE_NONE, LIGHT_DIRECTIONAL, LIGHT_POINT, LIGHT_SPOT,
+from .abi import (OPAQUE, ERASE, SHADE_GOURAUD, SHADE_NONE, LIGHT_DIRECTIONAL, LIGHT_POINT, LIGHT_SPOT,
                   VERTEX_DTYPE, FACE_DTYPE, NO_TEXTURE)
 
 
@@ -42,6 +42,38 @@ class Texture15:
         y, x = np.mgrid[0:height, 0:width]
         px = np.where(((x // 4) + (y // 4)) % 2 == 0, color1, color2).astype(np.uint16)
         return Texture15(width, height, px, OPAQUE, "checkerboard")
+
+
+@dataclass
+class Texture:
+    """types.rs:1166-1176 (8-bit-colour path): width*height Color values = (r, g, b, blend) bytes, row-major."""
+    width: int
+    height: int
+    pixels: np.ndarray  # uint8 [height*width, 4]
+    blend_mode: int = OPAQUE
+    name: str = ""
+
+    def __post_init__(self):
+        self.pixels = np.ascontiguousarray(self.pixels, dtype=np.uint8).reshape(-1, 4)
+        assert self.pixels.shape[0] == self.width * self.height
+
+    @staticmethod
+    def checkerboard(width, height, color1, color2):
+        """types.rs:1231-1240; colours are (r, g, b, blend) tuples."""
+        y, x = np.mgrid[0:height, 0:width]
+        m = (((x // 4) + (y // 4)) % 2 == 0)[..., None]
+        px = np.where(m, np.array(color1, np.uint8), np.array(color2, np.uint8)).astype(np.uint8)
+        return Texture(width, height, px, OPAQUE, "checkerboard")
+
+    @staticmethod
+    def from_texture15(t, stp_blend=OPAQUE):
+        """Test helper (not a reference function): RGB555 texels widened to Color; 0x0000 -> Erase (what Texture::from_bytes
+        makes of alpha 0, types.rs:1198-1223), STP-bit texels get `stp_blend` as their per-texel blend mode."""
+        c = t.pixels.astype(np.uint32)
+        def e(v5):
+            return ((v5 << 3) | (v5 >> 2)) & 0xFF
+        px = np.stack([e((c >> 10) & 31), e((c >> 5) & 31), e(c & 31), np.where(c == 0, ERASE, np.where(c & 0x8000, stp_blend, OPAQUE))], axis=1)
+        return Texture(t.width, t.height, px.astype(np.uint8), t.blend_mode, t.name)
 
 
 @dataclass
@@ -224,6 +256,16 @@ def pack_textures(textures):
     """[Texture15] -> (B32Texture15 array, keepalive)."""
     n = len(textures)
     arr = (abi.B32Texture15 * max(n, 1))()
+    for i, t in enumerate(textures):
+        arr[i].width, arr[i].height, arr[i].blend_mode = t.width, t.height, t.blend_mode
+        arr[i].pixels = t.pixels.ctypes.data if t.pixels.size else None
+    return arr, list(textures)
+
+
+def pack_textures8(textures):
+    """[Texture] -> (B32Texture array, keepalive)."""
+    n = len(textures)
+    arr = (abi.B32Texture * max(n, 1))()
     for i, t in enumerate(textures):
         arr[i].width, arr[i].height, arr[i].blend_mode = t.width, t.height, t.blend_mode
         arr[i].pixels = t.pixels.ctypes.data if t.pixels.size else None

@@ -79,6 +79,15 @@ typedef struct B32Texture15 {
     const uint16_t* pixels;
 } B32Texture15;
 
+/* Texture, types.rs:1166-1176 (the 8-bit-colour path): `pixels` is a HOST pointer to width*height Color values, 4 bytes
+ * each = r, g, b, blend (Color{r,g,b,blend: BlendMode}, types.rs:721-726; blend == B32_BLEND_ERASE is a transparent texel). */
+typedef struct B32Texture {
+    uint32_t       width, height;
+    uint32_t       blend_mode;
+    uint32_t       _pad;
+    const uint8_t* pixels;
+} B32Texture;
+
 /* IndexedAtlas + Clut (modeler/mesh_editor.rs:594-682, types.rs:390-397): one byte per texel for
  * both 4- and 8-bit depths; out-of-range index -> 0x0000.  Expanded with Clut::lookup semantics
  * exactly as IndexedAtlas::to_texture15 does before the rasterizer sees it (scene.rs:164). */
@@ -201,6 +210,24 @@ int b32_render_scene_15_async(b32_ctx* ctx,
                               const B32Camera* camera, const B32Settings* settings,
                               const B32Fog* fog /* nullable */);
 int b32_frame_finish(b32_ctx* ctx, B32Timings* out /* nullable */);
+
+/* ---- the 8-bit-colour path: render_mesh (render.rs:1971-2264) + rasterize_triangle (render.rs:1202-1433) ----
+ * What every caller of the reference runs when settings.use_rgb555 is false (scene.rs:163-169).  Same pipeline and settings
+ * as render_mesh_15 except: Texture texels are Color values with a per-texel blend mode, no fog, no opaque/transparent
+ * partition (one depth sort of all surfaces in painter's mode), every passing fragment writes depth in z-buffer mode. */
+int b32_render_mesh(b32_ctx* ctx,
+                    const B32Vertex* vertices, uint32_t nv,
+                    const B32Face* faces, uint32_t nf,
+                    const B32Texture* textures, uint32_t nt,
+                    const B32Camera* camera, const B32Settings* settings,
+                    B32Timings* out /* nullable */);
+int b32_scene_upload_rgba(b32_ctx* ctx,
+                          const B32Vertex* vertices, uint32_t nv,
+                          const B32Face* faces, uint32_t nf,
+                          const B32Texture* textures, uint32_t nt);
+/* Draws the scene uploaded by b32_scene_upload_rgba; finish with b32_frame_finish like the _15 form. */
+int b32_render_scene(b32_ctx* ctx, const B32Camera* camera, const B32Settings* settings, B32Timings* out /* nullable */);
+int b32_render_scene_async(b32_ctx* ctx, const B32Camera* camera, const B32Settings* settings);
 
 /* ---- stage taps (parity tests only; not on the frame path) ---------------- */
 /* fixed::project_fixed (fixed.rs:424-441) + float depth (render.rs:2331-2345) for n positions. */

@@ -512,6 +512,164 @@ static int rasterize_triangle_15(FB* fb, const Surface* s, const B32Texture15* t
     return B32_OK;
 }
 
+/* ------------------------------------------------------------------ the 8-bit-colour path */
+/* Texture::sample, types.rs:1242-1253 -> Color{r,g,b,blend}; zero-size / empty -> Color::TRANSPARENT (0,0,0,Erase) */
+static inline Col texture_sample8(const B32Texture* t, float u, float v) {
+    Col tr = { 0, 0, 0, B32_BLEND_ERASE };
+    if (t->width == 0 || t->height == 0 || !t->pixels) return tr;
+    float uw = rem_euclid1(u), vw = rem_euclid1(v);
+    uint64_t tx = f2usize_sat(uw * (float)t->width), ty = f2usize_sat(vw * (float)t->height);
+    if (tx > t->width - 1) tx = t->width - 1;
+    if (ty > t->height - 1) ty = t->height - 1;
+    const uint8_t* p = t->pixels + (ty * t->width + tx) * 4;
+    Col c = { p[0], p[1], p[2], p[3] };
+    return c;
+}
+/* Color::blend_with, types.rs:886-936, front.blend = mode (Color::blend :940-942). Returns the bytes Color::to_bytes would store. */
+static inline void color_blend_bytes(Col front, uint32_t mode, const uint8_t back[3], uint8_t out[4]) {
+    const uint8_t f[3] = { front.r, front.g, front.b };
+    out[3] = 255;
+    for (int i = 0; i < 3; ++i) {
+        switch (mode) {
+            default:
+            case B32_BLEND_OPAQUE:      out[i] = f[i]; break;
+            case B32_BLEND_AVERAGE:     out[i] = (uint8_t)(((uint16_t)back[i] + (uint16_t)f[i]) / 2); break;
+            case B32_BLEND_ADD:         { uint16_t v = (uint16_t)(back[i] + f[i]); out[i] = (uint8_t)(v > 255 ? 255 : v); } break;
+            case B32_BLEND_SUBTRACT:    { int16_t v = (int16_t)((int16_t)back[i] - (int16_t)f[i]); out[i] = (uint8_t)(v < 0 ? 0 : v); } break;
+            case B32_BLEND_ADD_QUARTER: { uint16_t v = (uint16_t)(back[i] + f[i] / 4); out[i] = (uint8_t)(v > 255 ? 255 : v); } break;
+            case B32_BLEND_ERASE:       out[i] = 0; out[3] = 0; break;                      /* Color::TRANSPARENT */
+        }
+    }
+}
+/* Framebuffer::set_pixel_blended, render.rs:313-334 */
+static inline void set_pixel_blended8(FB* fb, size_t idx, Col color, uint32_t mode) {
+    uint8_t out[4];
+    color_blend_bytes(color, mode, &fb->pixels[idx], out);
+    memcpy(&fb->pixels[idx], out, 4);
+}
+/* editor-alpha lerp of set_pixel_with_editor_alpha / set_pixel_with_depth_and_editor_alpha, render.rs:339-375, 378-427 */
+static inline void editor_alpha_store8(FB* fb, size_t idx, Col color, uint32_t mode, uint8_t editor_alpha) {
+    uint8_t back[3] = { fb->pixels[idx], fb->pixels[idx + 1], fb->pixels[idx + 2] };
+    uint8_t ps1[4];
+    color_blend_bytes(color, mode, back, ps1);
+    if (editor_alpha < 255) {
+        float a = (float)editor_alpha / 255.0f, inv_a = 1.0f - a;
+        for (int i = 0; i < 3; ++i) fb->pixels[idx + i] = f2u8_sat((float)ps1[i] * a + (float)back[i] * inv_a);
+        fb->pixels[idx + 3] = 255;                                                            /* Color::new -> Opaque */
+    } else memcpy(&fb->pixels[idx], ps1, 4);
+}
+/* apply_dither, render.rs:1186-1197 */
+static inline uint8_t dither8(uint8_t c, int32_t off) {
+    int32_t q = ((int32_t)c + off) >> 3;
+    q = q < 0 ? 0 : (q > 31 ? 31 : q);
+    return (uint8_t)(q << 3);
+}
+
+/* rasterize_triangle, render.rs:1202-1433 */
+static int rasterize_triangle8(FB* fb, const Surface* s, const B32Texture* texture, const B32Settings* st) {
+    uint64_t min_x = f2usize_sat(rmax(rmin(rmin(s->v1.x, s->v2.x), s->v3.x), 0.0f));           /* :1209-1212 */
+    uint64_t max_x = f2usize_sat(rmin(rmax(rmax(s->v1.x, s->v2.x), s->v3.x) + 1.0f, (float)fb->width));
+    uint64_t min_y = f2usize_sat(rmax(rmin(rmin(s->v1.y, s->v2.y), s->v3.y), 0.0f));
+    uint64_t max_y = f2usize_sat(rmin(rmax(rmax(s->v1.y, s->v2.y), s->v3.y) + 1.0f, (float)fb->height));
+    if (min_x >= max_x || min_y >= max_y) return B32_OK;
+    Shade flat_shade = { 1.0f, 1.0f, 1.0f };                                                     /* :1220-1226 */
+    if (st->shading == B32_SHADE_FLAT) {
+        V3 center_pos = v3scale(v3add(v3add(s->w1, s->w2), s->w3), 1.0f / 3.0f);
+        V3 world_normal = v3normalize(v3scale(v3add(v3add(s->wn1, s->wn2), s->wn3), 1.0f / 3.0f));
+        int rc = shade_multi_light_color(world_normal, center_pos, st->lights, st->n_lights, st->ambient, &flat_shade);
+        if (rc) return rc;
+    }
+    Shade gs1 = { 0, 0, 0 }, gs2 = { 0, 0, 0 }, gs3 = { 0, 0, 0 };                               /* :1229-1237 */
+    if (st->shading == B32_SHADE_GOURAUD) {
+        int rc = shade_multi_light_color(s->wn1, s->w1, st->lights, st->n_lights, st->ambient, &gs1);
+        if (!rc) rc = shade_multi_light_color(s->wn2, s->w2, st->lights, st->n_lights, st->ambient, &gs2);
+        if (!rc) rc = shade_multi_light_color(s->wn3, s->w3, st->lights, st->n_lights, st->ambient, &gs3);
+        if (rc) return rc;
+    }
+    int needs_dither = st->dithering && (st->shading == B32_SHADE_GOURAUD || texture != NULL       /* :1241-1246 */
+                                         || !col_eq(s->vc1, s->vc2) || !col_eq(s->vc2, s->vc3));
+    V3 v1 = s->v1, v2 = s->v2, v3_ = s->v3;
+    float area = (v2.y - v3_.y) * (v1.x - v3_.x) + (v3_.x - v2.x) * (v1.y - v3_.y);              /* :1257 */
+    if (fabsf(area) < 0.00001f) return B32_OK;
+    float inv_area = 1.0f / area;
+    float a0 = v2.y - v3_.y, b0 = v3_.x - v2.x, a1 = v3_.y - v1.y, b1 = v1.x - v3_.x;            /* :1264-1269 */
+    float start_x = (float)min_x, start_y = (float)min_y;
+    float w0_row = a0 * (start_x - v3_.x) + b0 * (start_y - v3_.y);                              /* :1277-1278 */
+    float w1_row = a1 * (start_x - v3_.x) + b1 * (start_y - v3_.y);
+    for (uint64_t y = min_y; y < max_y; ++y) {
+        float w0 = w0_row, w1 = w1_row;
+        for (uint64_t x = min_x; x < max_x; ++x) {
+            float bc_x = w0 * inv_area, bc_y = w1 * inv_area;
+            float bc_z = 1.0f - bc_x - bc_y;
+            const float ERR = -0.0001f;
+            if (bc_x >= ERR && bc_y >= ERR && bc_z >= ERR) {                                      /* :1302 */
+                float inv_z1 = 1.0f / v1.z, inv_z2 = 1.0f / v2.z, inv_z3 = 1.0f / v3_.z;         /* :1305-1309 */
+                float inv_z_interp = bc_x * inv_z1 + bc_y * inv_z2 + bc_z * inv_z3;
+                float z = 1.0f / inv_z_interp;
+                size_t didx = (size_t)y * fb->width + x;
+                if (st->use_zbuffer && !st->xray_mode) {                                          /* :1312-1319 */
+                    if (z >= fb->zbuffer[didx]) { w0 += a0; w1 += a1; continue; }
+                }
+                float u, v;
+                if (st->affine_textures) {                                                        /* :1322-1326 */
+                    u = bc_x * s->uv1[0] + bc_y * s->uv2[0] + bc_z * s->uv3[0];
+                    v = bc_x * s->uv1[1] + bc_y * s->uv2[1] + bc_z * s->uv3[1];
+                } else {                                                                          /* :1327-1338 */
+                    float u_over_z = bc_x * s->uv1[0] * inv_z1 + bc_y * s->uv2[0] * inv_z2 + bc_z * s->uv3[0] * inv_z3;
+                    float v_over_z = bc_x * s->uv1[1] * inv_z1 + bc_y * s->uv2[1] * inv_z2 + bc_z * s->uv3[1] * inv_z3;
+                    u = u_over_z / inv_z_interp;
+                    v = v_over_z / inv_z_interp;
+                }
+                Col color = { 255, 255, 255, B32_BLEND_OPAQUE };                                   /* Color::WHITE :1344 */
+                if (texture) color = texture_sample8(texture, u, 1.0f - v);                       /* :1342 */
+                if (color.blend == B32_BLEND_ERASE) { w0 += a0; w1 += a1; continue; }             /* is_transparent :1348-1352 */
+                uint8_t vr = f2u8_sat(bc_x * (float)s->vc1.r + bc_y * (float)s->vc2.r + bc_z * (float)s->vc3.r);   /* :1355-1360 */
+                uint8_t vg = f2u8_sat(bc_x * (float)s->vc1.g + bc_y * (float)s->vc2.g + bc_z * (float)s->vc3.g);
+                uint8_t vb = f2u8_sat(bc_x * (float)s->vc1.b + bc_y * (float)s->vc2.b + bc_z * (float)s->vc3.b);
+                uint16_t m;                                                                       /* Color::modulate types.rs:801-808 */
+                m = (uint16_t)(((uint16_t)color.r * (uint16_t)vr) / 128); color.r = (uint8_t)(m > 255 ? 255 : m);
+                m = (uint16_t)(((uint16_t)color.g * (uint16_t)vg) / 128); color.g = (uint8_t)(m > 255 ? 255 : m);
+                m = (uint16_t)(((uint16_t)color.b * (uint16_t)vb) / 128); color.b = (uint8_t)(m > 255 ? 255 : m);
+                float shade_r, shade_g, shade_b;                                                  /* :1366-1379 */
+                if (st->shading == B32_SHADE_NONE) { shade_r = shade_g = shade_b = 1.0f; }
+                else if (st->shading == B32_SHADE_FLAT) { shade_r = flat_shade.r; shade_g = flat_shade.g; shade_b = flat_shade.b; }
+                else {
+                    shade_r = bc_x * gs1.r + bc_y * gs2.r + bc_z * gs3.r;
+                    shade_g = bc_x * gs1.g + bc_y * gs2.g + bc_z * gs3.g;
+                    shade_b = bc_x * gs1.b + bc_y * gs2.b + bc_z * gs3.b;
+                }
+                color.r = f2u8_sat(rmin((float)color.r * shade_r, 255.0f));                        /* shade_color_rgb :1074-1081 */
+                color.g = f2u8_sat(rmin((float)color.g * shade_g, 255.0f));
+                color.b = f2u8_sat(rmin((float)color.b * shade_b, 255.0f));
+                if (needs_dither) {                                                               /* :1385-1387 */
+                    int32_t off = PS1_DITHER_MATRIX[y & 3][x & 3];
+                    color.r = dither8(color.r, off); color.g = dither8(color.g, off); color.b = dither8(color.b, off);
+                }
+                uint8_t editor_alpha = s->editor_alpha;                                           /* :1390-1396 */
+                if (editor_alpha == 0) { w0 += a0; w1 += a1; continue; }
+                uint8_t bytes[4] = { color.r, color.g, color.b, 255 };                            /* to_bytes: blend != Erase here */
+                if (st->use_zbuffer) {                                                            /* :1398-1412 */
+                    if (editor_alpha < 255) {                                                     /* render.rs:378-427 */
+                        if (!(z >= fb->zbuffer[didx])) { fb->zbuffer[didx] = z; editor_alpha_store8(fb, didx * 4, color, color.blend, editor_alpha); fb->fragments++; }
+                    } else if (color.blend == B32_BLEND_OPAQUE) {                                 /* set_pixel_with_depth :429-444 */
+                        if (z < fb->zbuffer[didx]) { fb->zbuffer[didx] = z; memcpy(&fb->pixels[didx * 4], bytes, 4); fb->fragments++; }
+                    } else if (z < fb->zbuffer[didx]) {                                           /* :1405-1411 */
+                        fb->zbuffer[didx] = z; set_pixel_blended8(fb, didx * 4, color, color.blend); fb->fragments++;
+                    }
+                } else {                                                                          /* :1413-1422 painter's */
+                    if (editor_alpha < 255) editor_alpha_store8(fb, didx * 4, color, color.blend, editor_alpha);
+                    else if (color.blend == B32_BLEND_OPAQUE) memcpy(&fb->pixels[didx * 4], bytes, 4);
+                    else set_pixel_blended8(fb, didx * 4, color, color.blend);
+                    fb->fragments++;
+                }
+            }
+            w0 += a0; w1 += a1;
+        }
+        w0_row += b0; w1_row += b1;
+    }
+    return B32_OK;
+}
+
 /* ------------------------------------------------------------------ lines of the wireframe phases */
 /* Framebuffer::set_pixel, render.rs:301-310 with Color::new(r,g,b) (blend Opaque -> alpha 255, types.rs:829-832) */
 static inline void set_pixel_rgb(FB* fb, int32_t x, int32_t y, uint8_t r, uint8_t g, uint8_t b) {
@@ -639,14 +797,16 @@ EXPORT void b32o_fb_clear(uint8_t* pixels, float* zbuffer, uint32_t width, uint3
     }
 }
 
-/* render_mesh_15, render.rs:2302-2638 */
-EXPORT int b32o_render_mesh_15(uint8_t* fb_pixels, float* fb_zbuffer, uint32_t width, uint32_t height,
-                               const B32Vertex* vertices, uint32_t nv,
-                               const B32Face* faces, uint32_t nf,
-                               const B32Texture15* textures, uint32_t nt,
-                               const B32Camera* camera, const B32Settings* st, const B32Fog* fog,
-                               B32Timings* timings, B32OracleDump* dump) {
-    if (!fb_pixels || !camera || !st || (nv && !vertices) || (nf && !faces) || (nt && !textures)) return B32_E_ARG;
+/* render_mesh_15, render.rs:2302-2638, and render_mesh (8-bit colour), render.rs:1971-2264: the two functions share their
+ * transform / cull / wireframe text almost verbatim; `textures8 != NULL` selects the 8-bit variant's differences (cited). */
+static int render_mesh_impl(uint8_t* fb_pixels, float* fb_zbuffer, uint32_t width, uint32_t height,
+                            const B32Vertex* vertices, uint32_t nv,
+                            const B32Face* faces, uint32_t nf,
+                            const B32Texture15* textures, const B32Texture* textures8, uint32_t nt,
+                            const B32Camera* camera, const B32Settings* st, const B32Fog* fog,
+                            B32Timings* timings, B32OracleDump* dump) {
+    const int fmt8 = textures8 != NULL;
+    if (!fb_pixels || !camera || !st || (nv && !vertices) || (nf && !faces) || (nt && !textures && !textures8)) return B32_E_ARG;
     if (st->use_zbuffer && !fb_zbuffer) return B32_E_ARG;
     if (st->shading != B32_SHADE_NONE)
         for (uint32_t i = 0; i < st->n_lights; ++i)
@@ -699,10 +859,11 @@ EXPORT int b32o_render_mesh_15(uint8_t* fb_pixels, float* fb_zbuffer, uint32_t w
         int has_transparency;                                                                     /* :2403-2415 */
         {
             int have_tex = f->texture_id != B32_NO_TEXTURE && f->texture_id < nt;
-            uint32_t tex_blend = have_tex ? textures[f->texture_id].blend_mode : B32_BLEND_OPAQUE;
+            uint32_t tex_blend = !have_tex ? B32_BLEND_OPAQUE : (fmt8 ? textures8[f->texture_id].blend_mode : textures[f->texture_id].blend_mode);
             if (have_tex && tex_blend != B32_BLEND_OPAQUE) has_transparency = 1;
-            else if (f->blend_mode != B32_BLEND_OPAQUE) has_transparency = 1;
+            else if (!fmt8 && f->blend_mode != B32_BLEND_OPAQUE) has_transparency = 1;            /* 8-bit: render.rs:2077-2081 ignores it */
             else has_transparency = f->editor_alpha < 255;
+            if (fmt8) has_transparency = 0;             /* computed but never used by render_mesh: one list, one sort (:2175-2184) */
         }
         Col c1 = { vertices[f->v[0]].r, vertices[f->v[0]].g, vertices[f->v[0]].b, vertices[f->v[0]].blend };
         Col c2 = { vertices[f->v[1]].r, vertices[f->v[1]].g, vertices[f->v[1]].b, vertices[f->v[1]].blend };
@@ -761,6 +922,11 @@ EXPORT int b32o_render_mesh_15(uint8_t* fb_pixels, float* fb_zbuffer, uint32_t w
                 for (uint32_t i = 0; i < ns && !rc; ++i) {
                     const Surface* s = &surfaces[order[i]];
                     uint32_t tid = faces[s->face_idx].texture_id;
+                    if (fmt8) {
+                        const B32Texture* tex8 = (tid != B32_NO_TEXTURE && tid < nt) ? &textures8[tid] : NULL;       /* :2196-2198 */
+                        rc = rasterize_triangle8(&fb, s, tex8, st);
+                        continue;
+                    }
                     const B32Texture15* tex = (tid != B32_NO_TEXTURE && tid < nt) ? &textures[tid] : NULL;  /* textures.get(id) :2554-2556 */
                     rc = rasterize_triangle_15(&fb, s, tex, s->blend_mode, s->black_transparent, st, i >= n_op);
                 }
@@ -787,6 +953,28 @@ EXPORT int b32o_render_mesh_15(uint8_t* fb_pixels, float* fb_zbuffer, uint32_t w
 done:
     free(surfaces); free(cam_space); free(projected); free(backface_wireframes); free(frontface_wireframes);
     return rc;
+}
+
+EXPORT int b32o_render_mesh_15(uint8_t* fb_pixels, float* fb_zbuffer, uint32_t width, uint32_t height,
+                               const B32Vertex* vertices, uint32_t nv, const B32Face* faces, uint32_t nf,
+                               const B32Texture15* textures, uint32_t nt,
+                               const B32Camera* camera, const B32Settings* st, const B32Fog* fog,
+                               B32Timings* timings, B32OracleDump* dump) {
+    if (nt && !textures) return B32_E_ARG;
+    static const B32Texture15 none15 = { 0, 0, 0, 0, NULL };
+    return render_mesh_impl(fb_pixels, fb_zbuffer, width, height, vertices, nv, faces, nf, textures ? textures : &none15, NULL, nt,
+                            camera, st, fog, timings, dump);
+}
+/* render_mesh, render.rs:1971-2264: no fog parameter */
+EXPORT int b32o_render_mesh(uint8_t* fb_pixels, float* fb_zbuffer, uint32_t width, uint32_t height,
+                            const B32Vertex* vertices, uint32_t nv, const B32Face* faces, uint32_t nf,
+                            const B32Texture* textures, uint32_t nt,
+                            const B32Camera* camera, const B32Settings* st,
+                            B32Timings* timings, B32OracleDump* dump) {
+    if (nt && !textures) return B32_E_ARG;
+    static const B32Texture none8 = { 0, 0, 0, 0, NULL };
+    return render_mesh_impl(fb_pixels, fb_zbuffer, width, height, vertices, nv, faces, nf, NULL, textures ? textures : &none8, nt,
+                            camera, st, NULL, timings, dump);
 }
 
 /* Reference unit-test helpers (math.rs:779-807) exposed so tests can replay them through this file. */

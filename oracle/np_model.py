@@ -181,7 +181,12 @@ def shade_multi(normal, wpos, lights, ambient):
 
 
 # ---------------------------------------------------------------- render_mesh_15, render.rs:2302-2572
-def render_mesh_15(pixels, width, height, vertices, faces, textures, camera, settings, fog=None, zbuffer=None):
+def render_mesh(pixels, width, height, vertices, faces, textures, camera, settings, zbuffer=None):
+    """render_mesh (render.rs:1971-2264): the 8-bit-colour path; `textures` are rtypes.Texture."""
+    return render_mesh_15(pixels, width, height, vertices, faces, textures, camera, settings, None, zbuffer, fmt8=True)
+
+
+def render_mesh_15(pixels, width, height, vertices, faces, textures, camera, settings, fog=None, zbuffer=None, fmt8=False):
     """Draw into `pixels` (uint8 [H*W*4]) (and `zbuffer` f32 [H*W] when settings.use_zbuffer); returns dict(triangles_drawn,
     fragments, draw_order, sx, sy)."""
     img = pixels.reshape(height, width, 4)
@@ -228,6 +233,8 @@ def render_mesh_15(pixels, width, height, vertices, faces, textures, camera, set
         tid = int(face["texture_id"])
         tex = textures[tid] if tid < len(textures) else None                                         # textures.get(id)
         transp = ((tex is not None and tex.blend_mode != 0) or face["blend_mode"] != 0 or face["editor_alpha"] < 255)
+        if fmt8:
+            transp = False                                # render_mesh computes the flag but never partitions (render.rs:2175-2184)
         cols = [np.array([vertices[i]["r"], vertices[i]["g"], vertices[i]["b"], vertices[i]["blend"]], np.int64) for i in (i0, i1, i2)]
         if fog is not None:                                                                          # :2419-2442
             start, falloff, cull, fc = fog
@@ -282,7 +289,10 @@ def render_mesh_15(pixels, width, height, vertices, faces, textures, camera, set
     fragments = 0
     if not settings.wireframe_overlay:                                                               # :2550
         for k, si in enumerate(draw):
-            fragments += _rasterize(img, width, height, surfaces[si], settings, zb, skip_z_write=k >= n_opaque)
+            if fmt8:
+                fragments += _rasterize8(img, width, height, surfaces[si], settings, zb)
+            else:
+                fragments += _rasterize(img, width, height, surfaces[si], settings, zb, skip_z_write=k >= n_opaque)
     # wireframe phases, :2574-2635
     zfull = zbuffer.reshape(height, width) if zbuffer is not None else None
     if settings.backface_cull and settings.backface_wireframe:
@@ -479,6 +489,140 @@ def _rasterize(img, width, height, s, st, zb=None, skip_z_write=False):
         res = ps1                                                                                     # :445-502
     img[py, px, :3] = res.astype(np.uint8)
     img[py, px, 3] = 255
+    return int(len(ys))
+
+
+def blend8(front, back, mode):
+    """Color::blend_with (types.rs:886-936) on int64 arrays [n,3]; mode scalar, not Erase/Opaque-specific shortcuts."""
+    if mode == 1:
+        return (back + front) // 2
+    if mode == 2:
+        return np.minimum(back + front, 255)
+    if mode == 3:
+        return np.maximum(back - front, 0)
+    if mode == 4:
+        return np.minimum(back + front // 4, 255)
+    if mode == 5:
+        return np.zeros_like(front)
+    return front
+
+
+def _rasterize8(img, width, height, s, st, zb=None):
+    """rasterize_triangle (render.rs:1202-1433), whole bbox at once."""
+    v1, v2, v3 = s["v"]
+    min_x = int(as_usize(rmax(rmin(rmin(v1[0], v2[0]), v3[0]), f32(0.0))))
+    max_x = int(as_usize(rmin(rmax(rmax(v1[0], v2[0]), v3[0]) + f32(1.0), f32(width))))
+    min_y = int(as_usize(rmax(rmin(rmin(v1[1], v2[1]), v3[1]), f32(0.0))))
+    max_y = int(as_usize(rmin(rmax(rmax(v1[1], v2[1]), v3[1]) + f32(1.0), f32(height))))
+    if min_x >= max_x or min_y >= max_y:
+        return 0
+    area = (v2[1] - v3[1]) * (v1[0] - v3[0]) + (v3[0] - v2[0]) * (v1[1] - v3[1])
+    if abs(area) < f32(0.00001):
+        return 0
+    inv_area = f32(1.0) / area
+    a0, b0, a1, b1 = v2[1] - v3[1], v3[0] - v2[0], v3[1] - v1[1], v1[0] - v3[0]
+    w0s = a0 * (f32(min_x) - v3[0]) + b0 * (f32(min_y) - v3[1])
+    w1s = a1 * (f32(min_x) - v3[0]) + b1 * (f32(min_y) - v3[1])
+    nx, ny = max_x - min_x, max_y - min_y
+
+    def walk(start, row_step, col_step):
+        rows = np.add.accumulate(np.concatenate([[start], np.full(ny - 1, row_step, np.float32)]).astype(np.float32), dtype=np.float32)
+        grid = np.empty((ny, nx), np.float32)
+        grid[:, 0] = rows
+        if nx > 1:
+            grid[:, 1:] = col_step
+        return np.add.accumulate(grid, axis=1, dtype=np.float32)
+    w0, w1 = walk(w0s, b0, a0), walk(w1s, b1, a1)
+    bcx = (w0 * inv_area).astype(np.float32)
+    bcy = (w1 * inv_area).astype(np.float32)
+    bcz = ((f32(1.0) - bcx) - bcy).astype(np.float32)
+    E = f32(-0.0001)
+    inside = (bcx >= E) & (bcy >= E) & (bcz >= E)
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        iz = [f32(1.0) / f32(vv[2]) for vv in (v1, v2, v3)]
+        inv_z = ((bcx * iz[0] + bcy * iz[1]).astype(np.float32) + bcz * iz[2]).astype(np.float32)
+        zgrid = (f32(1.0) / inv_z).astype(np.float32)
+        zsub = zb[min_y:max_y, min_x:max_x] if zb is not None else None
+        if zb is not None and not st.xray_mode:                                                       # :1312-1319
+            inside = inside & ~(zgrid >= zsub)
+    uv, tex = s["uv"], s["tex"]
+    if tex is not None:
+        if st.affine_textures:
+            u = ((bcx * uv[0][0] + bcy * uv[1][0]) + bcz * uv[2][0]).astype(np.float32)
+            v = ((bcx * uv[0][1] + bcy * uv[1][1]) + bcz * uv[2][1]).astype(np.float32)
+        else:
+            def over_z(c):
+                t0 = ((bcx * uv[0][c]).astype(np.float32) * iz[0]).astype(np.float32)
+                t1 = ((bcy * uv[1][c]).astype(np.float32) * iz[1]).astype(np.float32)
+                t2 = ((bcz * uv[2][c]).astype(np.float32) * iz[2]).astype(np.float32)
+                return ((t0 + t1).astype(np.float32) + t2).astype(np.float32)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                u = (over_z(0) / inv_z).astype(np.float32)
+                v = (over_z(1) / inv_z).astype(np.float32)
+        if tex.width == 0 or tex.height == 0 or tex.pixels.size == 0:
+            texel = np.zeros(u.shape + (4,), np.int64); texel[..., 3] = 5
+        else:
+            def wrapc(c, n):
+                r = np.fmod(c, f32(1.0)).astype(np.float32)
+                r = np.where(r < 0, (r + f32(1.0)).astype(np.float32), r)
+                return np.minimum(as_usize(r * f32(n)), n - 1)
+            tx = wrapc(u, tex.width)
+            ty = wrapc((f32(1.0) - v).astype(np.float32), tex.height)
+            texel = tex.pixels.astype(np.int64)[ty * tex.width + tx]
+    else:
+        texel = np.zeros(bcx.shape + (4,), np.int64); texel[..., :3] = 255                            # Color::WHITE
+    drawn = inside & (texel[..., 3] != 5)                                                             # is_transparent :1348
+    if s["alpha"] == 0:
+        return 0
+    alpha = s["alpha"]
+    if zb is not None:
+        with np.errstate(invalid="ignore"):
+            drawn = drawn & (~(zgrid >= zsub) if alpha < 255 else (zgrid < zsub))                    # render.rs:387 vs :432, :1407
+    ys, xs = np.nonzero(drawn)
+    if len(ys) == 0:
+        return 0
+    if zb is not None:
+        zb[ys + min_y, xs + min_x] = zgrid[ys, xs]                                                   # every passing fragment writes depth
+    bx, by, bz, tx_ = bcx[ys, xs], bcy[ys, xs], bcz[ys, xs], texel[ys, xs]
+    px, py = xs + min_x, ys + min_y
+    cols = []
+    for i in range(3):
+        vert = as_u8((bx * f32(s["vc"][0][i]) + by * f32(s["vc"][1][i])).astype(np.float32) + bz * f32(s["vc"][2][i]))
+        m = np.minimum((tx_[:, i] * vert) // 128, 255)                                                # modulate, types.rs:801-808
+        if st.shading != 0:
+            if "_sh" not in s:
+                _prep_shades(s, st)
+            if st.shading == 1:
+                sv = np.full(bx.shape, s["_sh"][0][i], np.float32)
+            else:
+                sv = ((bx * s["_sh"][0][i] + by * s["_sh"][1][i]).astype(np.float32) + bz * s["_sh"][2][i]).astype(np.float32)
+            m = as_u8(rmin((m.astype(np.float32) * sv).astype(np.float32), f32(255.0)))               # shade_color_rgb :1074-1081 (no clamp)
+        cols.append(m)
+    vc = s["vc"]
+    needs_dither = st.dithering and (st.shading == 2 or tex is not None or not np.array_equal(vc[0], vc[1]) or not np.array_equal(vc[1], vc[2]))
+    if needs_dither:                                                                                  # apply_dither :1186-1197
+        off = DITHER[py & 3, px & 3]
+        cols = [np.clip((c + off) >> 3, 0, 31) << 3 for c in cols]
+    front = np.stack(cols, axis=1).astype(np.int64)
+    back = img[py, px, :3].astype(np.int64)
+    mode = tx_[:, 3]
+    ps1 = front.copy()
+    a_out = np.full(len(ys), 255, np.int64)
+    for mval in (1, 2, 3, 4, 5):
+        sel = mode == mval
+        if sel.any():
+            ps1[sel] = blend8(front[sel], back[sel], mval)
+            if mval == 5:
+                a_out[sel] = 0
+    if alpha < 255:                                                                                   # render.rs:356-366
+        a = f32(alpha) / f32(255.0)
+        inv_a = f32(1.0) - a
+        res = as_u8((ps1.astype(np.float32) * a).astype(np.float32) + (back.astype(np.float32) * inv_a).astype(np.float32))
+        a_out[:] = 255
+    else:
+        res = ps1
+    img[py, px, :3] = res.astype(np.uint8)
+    img[py, px, 3] = a_out.astype(np.uint8)
     return int(len(ys))
 
 

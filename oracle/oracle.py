@@ -57,6 +57,8 @@ def lib():
         L.b32o_render_mesh_15.restype = C.c_int
         L.b32o_render_mesh_15.argtypes = [P, P, C.c_uint32, C.c_uint32, P, C.c_uint32, P, C.c_uint32, P, C.c_uint32,
                                           P, P, P, P, P]
+        L.b32o_render_mesh.restype = C.c_int
+        L.b32o_render_mesh.argtypes = [P, P, C.c_uint32, C.c_uint32, P, C.c_uint32, P, C.c_uint32, P, C.c_uint32, P, P, P, P]
         L.b32o_vec3_dot.restype = C.c_float; L.b32o_vec3_dot.argtypes = [P, P]
         L.b32o_vec3_cross.restype = None; L.b32o_vec3_cross.argtypes = [P, P, P]
         _lib = L
@@ -91,12 +93,17 @@ class Framebuffer:
         return self.pixels.reshape(self.height, self.width, 4)
 
 
+def render_mesh(fb: Framebuffer, vertices, faces, textures, camera: T.Camera, settings: T.RasterSettings, dump=False):
+    """render_mesh (render.rs:1971-2264), the 8-bit-colour path, on the CPU. `textures` are rtypes.Texture."""
+    return render_mesh_15(fb, vertices, faces, textures, camera, settings, None, dump, _fmt8=True)
+
+
 def render_mesh_15(fb: Framebuffer, vertices, faces, textures, camera: T.Camera, settings: T.RasterSettings,
-                   fog=None, dump=False):
+                   fog=None, dump=False, _fmt8=False):
     """render_mesh_15 (render.rs:2302-2638) on the CPU. Returns (rc, RasterTimings[, dump dict])."""
     vertices = np.ascontiguousarray(vertices, dtype=abi.VERTEX_DTYPE)
     faces = np.ascontiguousarray(faces, dtype=abi.FACE_DTYPE)
-    tex_arr, _keep_t = T.pack_textures(textures)
+    tex_arr, _keep_t = T.pack_textures8(textures) if _fmt8 else T.pack_textures(textures)
     cam = camera.pack()
     st, _keep_l = settings.pack()
     fg = T.pack_fog(fog)
@@ -108,12 +115,14 @@ def render_mesh_15(fb: Framebuffer, vertices, faces, textures, camera: T.Camera,
         sz = np.zeros(max(len(vertices), 1), np.float32)
         order = np.zeros(max(len(faces), 1), np.uint32)
         d.sx, d.sy, d.sz, d.draw_order = sx.ctypes.data, sy.ctypes.data, sz.ctypes.data, order.ctypes.data
-    rc = lib().b32o_render_mesh_15(fb.pixels.ctypes.data, fb.zbuffer.ctypes.data, fb.width, fb.height,
-                                   vertices.ctypes.data if len(vertices) else None, len(vertices),
-                                   faces.ctypes.data if len(faces) else None, len(faces),
-                                   C.cast(tex_arr, C.c_void_p), len(textures),
-                                   C.byref(cam), C.byref(st), C.byref(fg) if fg is not None else None,
-                                   C.byref(tm), C.byref(d) if d is not None else None)
+    common = (fb.pixels.ctypes.data, fb.zbuffer.ctypes.data, fb.width, fb.height,
+              vertices.ctypes.data if len(vertices) else None, len(vertices),
+              faces.ctypes.data if len(faces) else None, len(faces), C.cast(tex_arr, C.c_void_p), len(textures), C.byref(cam), C.byref(st))
+    tail = (C.byref(tm), C.byref(d) if d is not None else None)
+    if _fmt8:
+        rc = lib().b32o_render_mesh(*common, *tail)
+    else:
+        rc = lib().b32o_render_mesh_15(*common, C.byref(fg) if fg is not None else None, *tail)
     t = T.RasterTimings.from_c(tm)
     if dump:
         return rc, t, {"sx": sx[:len(vertices)], "sy": sy[:len(vertices)], "sz": sz[:len(vertices)],

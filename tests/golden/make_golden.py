@@ -101,6 +101,57 @@ SCENES = {
 }
 
 
+def rgba_scene(name="C1", stp_blend=0, seed=61, variant="bench", settings=None, alpha_every=0, bbox_px=200.0, **kw):
+    """A scenegen scene with its RGB555 atlas widened to the 8-bit path's Texture (per-texel blend modes on STP texels)."""
+    sc = scenegen.make_scene(name, seed=seed, variant=variant, bbox_px=bbox_px, **kw)
+    sc.textures8 = [b32.Texture.from_texture15(t, stp_blend) for t in sc.textures]
+    if stp_blend:                                  # mix all four PS1 modes over the STP texels, keyed by texel position
+        for t in sc.textures8:
+            stp = t.pixels[:, 3] == stp_blend
+            t.pixels[stp, 3] = 1 + (np.arange(len(t.pixels))[stp] % 4)
+    if settings is not None:
+        sc.settings = settings
+    if alpha_every:
+        sc.faces["editor_alpha"][::alpha_every] = 140
+        sc.faces["editor_alpha"][1::alpha_every * 3] = 0
+    sc.settings.use_rgb555 = False
+    return sc
+
+
+def cube8_scene():
+    sc = scenegen.cube_scene()
+    sc.textures8 = [b32.Texture.checkerboard(32, 32, (255, 255, 255, 0), (120, 120, 120, 0))]
+    sc.settings = b32.RasterSettings(use_rgb555=False)
+    return sc
+
+
+def zb_settings(**kw):
+    return b32.RasterSettings(use_rgb555=False, **kw)
+
+
+SCENES8 = {
+    "8:C1": lambda: rgba_scene(),
+    "8:C1-gouraud": lambda: rgba_scene(variant="gouraud", seed=62),
+    "8:C1-blend": lambda: rgba_scene(stp_blend=1, variant="blend", seed=63),
+    "8:C1-alpha": lambda: rgba_scene(stp_blend=1, variant="blend", seed=64, alpha_every=5),
+    "8:C1-default": lambda: rgba_scene(variant="gouraud", seed=65, settings=zb_settings()),
+    "8:C1-zbuf-blend-alpha": lambda: rgba_scene(stp_blend=1, variant="blend", seed=66, alpha_every=4, settings=zb_settings(backface_wireframe=False)),
+    "8:C1-persp-float": lambda: rgba_scene(variant="float", seed=67, settings=zb_settings(affine_textures=False, use_fixed_point=False, use_zbuffer=False, backface_wireframe=False, shading=1)),
+    "8:C1-xray-zbuf": lambda: rgba_scene(stp_blend=1, variant="blend", seed=68, settings=zb_settings(xray_mode=True)),
+    "8:C1-ortho-overlay": lambda: rgba_scene(seed=69, bbox_px=900.0, settings=zb_settings(ortho_projection=(0.05, 10.0, -15.0), wireframe_overlay=True)),
+    "8:cube": cube8_scene,
+    "8:C2": lambda: rgba_scene("C2", seed=70, bbox_px=None),
+}
+
+
+def render8(sc):
+    fb = O.Framebuffer(sc.width, sc.height)
+    fb.clear(sc.clear_color)
+    rc, tm, d = O.render_mesh(fb, sc.vertices, sc.faces, sc.textures8, sc.camera, sc.settings, dump=True)
+    assert rc == 0
+    return fb, tm, d
+
+
 def render(sc):
     fb = O.Framebuffer(sc.width, sc.height)
     fb.clear(sc.clear_color)
@@ -124,6 +175,14 @@ def main():
                                 sz_bits=d["sz"].view(np.uint32), draw_order=d["draw_order"])
         if name == "cube":
             np.savez_compressed(os.path.join(OUT, "cube_frame.npz"), rgba=fb.pixels, draw_order=d["draw_order"])
+        print(name, hashes[name]["sha256"][:16], tm.triangles_drawn, tm.fragments)
+    for name, mk in SCENES8.items():
+        sc = mk()
+        fb, tm, d = render8(sc)
+        hashes[name] = {"sha256": hashlib.sha256(fb.pixels).hexdigest(), "zbuffer_sha256": hashlib.sha256(fb.zbuffer.tobytes()).hexdigest(),
+                        "triangles_drawn": tm.triangles_drawn, "fragments": tm.fragments, "width": sc.width, "height": sc.height,
+                        "draw_order_sha256": hashlib.sha256(d["draw_order"].tobytes()).hexdigest(),
+                        "scene_sha256": hashlib.sha256(sc.vertices.tobytes() + sc.faces.tobytes() + sc.textures8[0].pixels.tobytes()).hexdigest()}
         print(name, hashes[name]["sha256"][:16], tm.triangles_drawn, tm.fragments)
     json.dump(hashes, open(os.path.join(OUT, "hashes.json"), "w"), indent=1, sort_keys=True)
 

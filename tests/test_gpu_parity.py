@@ -9,7 +9,7 @@ import pytest
 
 import bonnie32_amd as b32
 from bonnie32_amd import scenegen
-from tests.golden.make_golden import SCENES
+from tests.golden.make_golden import SCENES, SCENES8
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -382,3 +382,46 @@ def test_wire_edge_overflow_is_refused(gpu_ctx, oracle):
     with pytest.raises(R.B32Error) as ei:
         R.render_mesh_15(fb, sc.vertices, sc.faces, sc.textures, sc.camera, sc.settings, sc.fog)
     assert ei.value.code == b32.abi.B32_E_UNSUPPORTED
+
+
+@pytest.mark.parametrize("name", list(SCENES8))
+@pytest.mark.parametrize("counting", [1, 0])
+def test_8bit_path_parity(gpu_ctx, oracle, name, counting):
+    """render_mesh (render.rs:1971-2264) + rasterize_triangle (render.rs:1202-1433): the 8-bit-colour path, drop-in and
+    resident forms, with and without fragment counting (EXACT / CHEAP coverage where the overwrite pass applies)."""
+    sc = SCENES8[name]()
+    fbo = oracle.Framebuffer(sc.width, sc.height); fbo.clear(sc.clear_color)
+    rc, etm, d = oracle.render_mesh(fbo, sc.vertices, sc.faces, sc.textures8, sc.camera, sc.settings, dump=True)
+    assert rc == 0
+    from bonnie32_amd import rasterizer as R
+    gpu_ctx.set_fragment_counting(counting)
+    try:
+        for resident in (False, True):
+            fb = R.Framebuffer(sc.width, sc.height, gpu_ctx)
+            fb.clear(sc.clear_color)
+            if resident:
+                tm = R.ResidentScene(fb, sc.vertices, sc.faces, textures8=sc.textures8).render(sc.camera, sc.settings)
+            else:
+                tm = R.render_mesh(fb, sc.vertices, sc.faces, sc.textures8, sc.camera, sc.settings)
+            got = fb.pixels
+            assert np.array_equal(got, fbo.pixels), f"{int((got != fbo.pixels).sum())} bytes differ (resident={resident})"
+            assert hashlib.sha256(got).hexdigest() == HASHES[name]["sha256"]
+            assert tm.triangles_drawn == etm.triangles_drawn
+            if sc.settings.use_zbuffer:
+                assert np.array_equal(fb.zbuffer.view(np.uint32), fbo.zbuffer.view(np.uint32))
+            if tm.fragments:
+                assert tm.fragments == etm.fragments
+            assert np.array_equal(gpu_ctx.last_draw_order(len(sc.faces)), d["draw_order"])
+    finally:
+        gpu_ctx.set_fragment_counting(1)
+
+
+def test_8bit_scene_rejects_15bit_draw(gpu_ctx):
+    from bonnie32_amd import rasterizer as R
+    sc = SCENES8["8:cube"]()
+    fb = R.Framebuffer(sc.width, sc.height, gpu_ctx)
+    rs = R.ResidentScene(fb, sc.vertices, sc.faces, textures8=sc.textures8)
+    rs.fmt8 = False                     # force the RGB555 entry point on an 8-bit scene
+    with pytest.raises(R.B32Error) as e:
+        rs.render(sc.camera, sc.settings)
+    assert e.value.code == b32.abi.B32_E_ARG

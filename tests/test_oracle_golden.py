@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from tests.golden.make_golden import SCENES, render
+from tests.golden.make_golden import SCENES, SCENES8, render, render8
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 HASHES = json.load(open(os.path.join(GOLD, "hashes.json")))
@@ -62,6 +62,35 @@ def test_two_restatements_agree(oracle, name):
     assert np.array_equal(r["sz"], d["sz"])
     if r["sx"] is not None:
         assert np.array_equal(r["sx"], d["sx"]) and np.array_equal(r["sy"], d["sy"])
+
+
+@pytest.mark.parametrize("name", list(SCENES8))
+def test_oracle8_matches_golden_hash(oracle, name):
+    """The 8-bit-colour path (render_mesh, render.rs:1971-2264) of the oracle against its committed vectors."""
+    sc = SCENES8[name]()
+    g = HASHES[name]
+    assert hashlib.sha256(sc.vertices.tobytes() + sc.faces.tobytes() + sc.textures8[0].pixels.tobytes()).hexdigest() == g["scene_sha256"]
+    fb, tm, d = render8(sc)
+    assert hashlib.sha256(fb.pixels).hexdigest() == g["sha256"]
+    assert hashlib.sha256(fb.zbuffer.tobytes()).hexdigest() == g["zbuffer_sha256"]
+    assert (tm.triangles_drawn, tm.fragments) == (g["triangles_drawn"], g["fragments"])
+    assert hashlib.sha256(d["draw_order"].tobytes()).hexdigest() == g["draw_order_sha256"]
+
+
+@pytest.mark.parametrize("name", [n for n in SCENES8 if n != "8:C2"])
+def test_two_restatements_agree_8bit(oracle, name):
+    from oracle import np_model as M
+    sc = SCENES8[name]()
+    fb, tm, d = render8(sc)
+    px = np.zeros(sc.width * sc.height * 4, np.uint8)
+    px.reshape(-1, 4)[:] = [sc.clear_color.r, sc.clear_color.g, sc.clear_color.b, 255]
+    zb = np.full(sc.width * sc.height, np.finfo(np.float32).max, np.float32)
+    r = M.render_mesh(px, sc.width, sc.height, sc.vertices, sc.faces, sc.textures8, sc.camera, sc.settings, zbuffer=zb)
+    assert np.array_equal(px, fb.pixels)
+    if sc.settings.use_zbuffer:
+        assert np.array_equal(zb.view(np.uint32), fb.zbuffer.view(np.uint32))
+    assert np.array_equal(r["draw_order"], d["draw_order"])
+    assert (r["triangles_drawn"], r["fragments"]) == (tm.triangles_drawn, tm.fragments)
 
 
 def test_wire_grid_first_occurrence_decides(oracle):
