@@ -7,6 +7,7 @@
 #include "b32_device.h"
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -55,6 +56,7 @@ struct b32_ctx {
     uint32_t* tile_mid = nullptr; size_t cap_tile_mid = 0;
     bool local_sort_ok = true;          // no tile list of this scene has exceeded the LDS sort capacity so far
     bool last_local_sort = false;       // the last frame took the fast path (draw order not materialised)
+    bool no_prio64 = false;             // debug/experiment switch (B32_NO_PRIO64=1): keep the per-tile LDS sort
     // pairs
     size_t cap_pairs = 0;
     uint32_t *pkeys[2] = { nullptr, nullptr }, *pvals[2] = { nullptr, nullptr };
@@ -131,6 +133,7 @@ int b32_create(int device, b32_ctx** out) {
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return B32_E_NO_DEVICE;
     b32_ctx* c = new b32_ctx();
     c->device = device;
+    c->no_prio64 = getenv("B32_NO_PRIO64") != nullptr;
     if (hipSetDevice(device) != hipSuccess) { delete c; return B32_E_NO_DEVICE; }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -502,7 +505,7 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
         c->cap_tile_mid = (size_t)ntiles + 64;
     }
     if ((size_t)c->width * c->height > c->cap_vis || !c->vis) {
-        if ((rc = ensure_plain(c, c->vis, (size_t)c->width * c->height + 64))) return rc;
+        if ((rc = ensure_plain(c, c->vis, (size_t)c->width * c->height * 2 + 64))) return rc;    // two words per pixel (prio64 coverage)
         c->cap_vis = (size_t)c->width * c->height;
     }
 
@@ -594,6 +597,7 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     fa.skip_solid = wire_front ? 1u : 0u;
     fa.texels32 = c->d_texels32;
     fa.ordered_all = ordered_all ? 1u : 0u;
+    fa.prio64 = (local_sort && !c->may_blend && !c->no_prio64) ? 1u : 0u;   // no transparent pass -> no tile list order needed at all
     if (c->fmt8) fa.fp.xray = 0;                        // render_mesh: x-ray only changes culling; its stores keep their own depth tests
     launch_fill(s, fa, c->n_cu, prof_fill ? ev[4] : nullptr);
     if (fp.wire_collect && c->nf) {

@@ -243,6 +243,8 @@ struct FillArgs {
     uint32_t skip_solid;        // wireframe_overlay: surfaces are counted but not drawn (render.rs:2550)
     const uint32_t* texels32;   // 8-bit-colour path: pooled Color texels, r | g<<8 | b<<16 | blend<<24 (TexDesc.offset indexes this pool)
     uint32_t ordered_all;       // 1: every surface may blend -> no overwrite pass, k_blend walks the whole tile list in order
+    uint32_t prio64;            // 1: sort-free coverage -- visibility is a 64-bit max of (painter's key << 32 | face id); `vis` holds
+                                //    two words per pixel: winner face id + 1, runner-up face id + 1 (0 = none)
 };
 void launch_fill(hipStream_t s, const FillArgs& a, int n_cu, hipEvent_t after_cover = nullptr);   // k_cover [event] k_shade k_blend
 size_t fill_lds_tex_budget();   // bytes of LDS left for a staged texture

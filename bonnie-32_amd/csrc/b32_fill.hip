@@ -407,6 +407,32 @@ __device__ __forceinline__ uint32_t cover_one(const Batch& b, int t, uint32_t li
     return cover_surface<TEXMODE, EXACT, ZMODE, FMT8>(tr, cx0, cx1, cy0, cy1, li, tilebuf, x_lo, ty_top, lane, gtex, ltex, affine);
 }
 
+// P64 coverage of a surface whose edge walk must be replayed literally (F_SLOW): one lane per row.
+__device__ __forceinline__ void cover_slow64(const Tri& tr, unsigned long long P, uint32_t* tilebuf, uint32_t x_lo, uint32_t x_hi,
+                                             uint32_t y_lo, uint32_t y_hi, uint32_t ty_top, uint32_t lane) {
+    const uint32_t cx0 = max(tr.min_x, x_lo), cx1 = min(tr.max_x, x_hi);
+    const uint32_t cy0 = max(tr.min_y, y_lo), cy1 = min(tr.max_y, y_hi);
+    if (cx0 >= cx1 || cy0 >= cy1) return;
+    unsigned long long* top = reinterpret_cast<unsigned long long*>(tilebuf);
+    unsigned long long* sec = top + TILE_H * TILE_STRIDE;
+    for (uint32_t by = cy0; by < cy1; by += 64) {
+        const uint32_t py = by + lane;
+        if (py < cy1) {
+            float w0, w1;
+            replay_w(tr, cx0, py, w0, w1);
+            for (uint32_t px = cx0; px < cx1; ++px) {
+                float bcx, bcy, bcz;
+                if (inside_bc(tr, w0, w1, bcx, bcy, bcz)) {
+                    const uint32_t addr = (py - ty_top) * TILE_STRIDE + (px - x_lo);
+                    const unsigned long long old = atomicMax(&top[addr], P);
+                    atomicMax(&sec[addr], min(old, P));
+                }
+                w0 += tr.a0; w1 += tr.a1;
+            }
+        }
+    }
+}
+
 // Phase A as a ROW-ITEM scheduler.  Waves grab 64 list entries at a time from an LDS cursor (load balance across the 16
 // waves).  Each lane first holds one surface; the work items of the batch are the rows of the tile-clipped bounding boxes
 // (exclusive prefix sum of the heights).  In rounds of 64 items every lane takes ONE ROW of some surface: the owner is
@@ -414,7 +440,7 @@ __device__ __forceinline__ uint32_t cover_one(const Batch& b, int t, uint32_t li
 // incrementally exactly like the reference's inner loop (render.rs:1533-1707): start value = closed form at the row start
 // (exact integers under the k_setup guard), then w0 += a0, w1 += a1 per pixel.  Row lengths are far more uniform than
 // bbox areas, big surfaces fill whole rounds, and there is no per-surface scalar work.
-template <int TEXMODE, bool EXACT, int NW, bool ZMODE, bool FMT8>
+template <int TEXMODE, bool EXACT, int NW, bool ZMODE, bool FMT8, bool P64 = false>
 __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, uint32_t e0, uint32_t n_op, uint32_t lane, uint32_t wave,
                                                            volatile uint32_t* cursor, volatile uint32_t* wmark, const TexDesc& lds_desc,
                                                            uint32_t* tilebuf, uint32_t x_lo, uint32_t x_hi, uint32_t y_lo, uint32_t y_hi,
@@ -434,6 +460,8 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
         bool live = lane < grab && e < n_op;
         Batch b;
         load_batch<TEXMODE>(b, a, e0 + e, live, lds_desc, EXACT);
+        uint32_t my_sid = 0, my_key = 0;                       // P64: the surface's place in the global painter's order
+        if (P64 && live) { my_sid = a.pair_vals[e0 + e]; my_key = a.keys[my_sid]; }
         const uint32_t flags = b.q3.w;
         const uint32_t cx0 = max(b.q1.w & 0xFFFF, x_lo), cx1 = min(b.q1.w >> 16, x_hi);
         const uint32_t cy0 = max(b.q2.x & 0xFFFF, y_lo), cy1 = min(b.q2.x >> 16, y_hi);
@@ -496,6 +524,33 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
                         ++addr; w0 += sa0; w1 += sa1;
                     }
                 }
+            } else if (P64) {
+                // sort-free CHEAP coverage: the value is the surface's global painter's priority, so no tile list order is needed.
+                // Four pixels per trip: four returning LDS atomics in flight, one wait (w advances by the reference's own
+                // sequential accumulation w += a).
+                const unsigned long long P = ((unsigned long long)bperm(s, my_key) << 32) | bperm(s, my_sid);
+                unsigned long long* top = reinterpret_cast<unsigned long long*>(tilebuf);
+                unsigned long long* sec = top + TILE_H * TILE_STRIDE;
+                for (uint32_t i = 0; __ballot(i < n); i += 4) {
+                    float wa[4], wb[4];
+                    wa[0] = w0; wb[0] = w1;
+#pragma unroll
+                    for (int j = 1; j < 4; ++j) { wa[j] = wa[j - 1] + sa0; wb[j] = wb[j - 1] + sa1; }
+                    bool in[4];
+                    unsigned long long old[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float cx = wa[j] * sinv, cy = wb[j] * sinv;
+                        const float cz = 1.0f - cx - cy;
+                        in[j] = (i + j < n) & (cx >= ERR) & (cy >= ERR) & (cz >= ERR);
+                        old[j] = 0;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (in[j]) old[j] = atomicMax(&top[addr + j], P);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (in[j]) atomicMax(&sec[addr + j], min(old[j], P));
+                    addr += 4; w0 = wa[3] + sa0; w1 = wb[3] + sa1;
+                }
             } else {
                 // CHEAP coverage: two pixels per trip, so the two returning LDS atomics are in flight together and the wave
                 // waits once per pair (the second value is the same sequential accumulation w + a the reference performs)
@@ -523,6 +578,11 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
         while (sm) {
             const int t = __builtin_ctzll(sm);
             sm &= sm - 1;
+            if (P64) {
+                const unsigned long long P = ((unsigned long long)bcu(my_key, t) << 32) | bcu(my_sid, t);
+                cover_slow64(tri_from_batch(b, t, false), P, tilebuf, x_lo, x_hi, y_lo, y_hi, ty_top, lane);
+                continue;
+            }
             frags += cover_one<TEXMODE, EXACT, ZMODE, FMT8>(b, t, cs + (uint32_t)t + 1, tilebuf, x_lo, x_hi, y_lo, y_hi, ty_top, lane, gtex, ltex, affine);
         }
     }
@@ -609,13 +669,18 @@ __device__ void tile_local_sort(uint32_t* sort_area, uint32_t* wcnt, volatile ui
 }
 
 // ------------------------------------------------------------------------------------------------ k_cover
-template <int TEXMODE, bool EXACT, int NT, bool ZMODE, bool FMT8 = false>
+template <bool FMT8, int NT>
+__device__ __forceinline__ void shade_tile_p64(const FillArgs& a, const uint32_t* tilebuf, uint32_t e0, uint32_t e1, uint32_t x_lo, uint32_t x_hi,
+                                               uint32_t y_lo, uint32_t y_hi, uint32_t ty_top, uint32_t tid, uint32_t lane);
+
+template <int TEXMODE, bool EXACT, int NT, bool ZMODE, bool FMT8 = false, bool P64 = false>
 __global__ __launch_bounds__(NT) void k_cover(FillArgs a) {
     constexpr int NW = NT / 64;
+    constexpr int TB = (P64 ? 4 : 2) * LDS_TILE_BYTES;          // tile buffers: top + runner-up, 32- or 64-bit entries
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* tilebuf = reinterpret_cast<uint32_t*>(smem);
-    volatile uint32_t* misc = reinterpret_cast<volatile uint32_t*>(smem + 2 * LDS_TILE_BYTES);   // [0] tile, [2] list cursor
-    uint32_t* wmarks = reinterpret_cast<uint32_t*>(smem + 2 * LDS_TILE_BYTES + LDS_MISC_BYTES);
+    volatile uint32_t* misc = reinterpret_cast<volatile uint32_t*>(smem + TB);   // [0] tile, [2] list cursor
+    uint32_t* wmarks = reinterpret_cast<uint32_t*>(smem + TB + LDS_MISC_BYTES);
     const uint16_t* ltex = reinterpret_cast<const uint16_t*>(smem + LDS_TEX_OFFSET);
     uint32_t* sort_cnt = reinterpret_cast<uint32_t*>(smem + LDS_TEX_OFFSET);        // local sort only exists without an LDS texture
 
@@ -643,7 +708,9 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a) {
         if (tile >= ntiles) break;
         if (tid == 0) next_tile = atomicAdd(&a.ctrl->tile_cursor, 1u);    // prefetch the next tile index; consumed at the loop top
         uint32_t e0, e1;
-        if (TEXMODE == 0 && a.local_sort) {      // lists arrive in face order, keyed by tile only: painter's order per tile, in LDS
+        if (P64) {                               // lists in any order, keyed by tile only; the whole list is the opaque pass
+            e0 = a.ranges[tile]; e1 = a.ranges[tile + 1];
+        } else if (TEXMODE == 0 && a.local_sort) {      // lists arrive in face order, keyed by tile only: painter's order per tile, in LDS
             e0 = a.ranges[tile];
             const uint32_t e2 = a.ranges[tile + 1];
             if (e2 - e0 > LOCAL_SORT_CAP) {
@@ -672,14 +739,19 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a) {
                 t64[row * TILE_STRIDE + col] = inb ? ((unsigned long long)zsort_key(a.zbuf[(size_t)py * fp.width + px]) << 32) : 0ull;
             }
         } else {
-            for (uint32_t i = tid; i < (EXACT ? 1 : 2) * TILE_H * TILE_STRIDE; i += NT) tilebuf[i] = 0;
+            for (uint32_t i = tid; i < (P64 ? 4 : (EXACT ? 1 : 2)) * TILE_H * TILE_STRIDE; i += NT) tilebuf[i] = 0;
         }
         __syncthreads();
         const uint32_t n_op = e1 - e0;
         if (n_op) {
-            frag_count += phase_a_rows<TEXMODE, EXACT, NW, ZMODE, FMT8>(a, e0, n_op, lane, wave, &misc[2], wmarks + wave * 64, lds_desc, tilebuf,
+            frag_count += phase_a_rows<TEXMODE, EXACT, NW, ZMODE, FMT8, P64>(a, e0, n_op, lane, wave, &misc[2], wmarks + wave * 64, lds_desc, tilebuf,
                                                            x_lo, x_hi, y_lo, y_hi, ty_top, ltex);
             __syncthreads();
+        }
+        if (P64) {          // shade the tile straight from the LDS winners (no visibility buffer)
+            if (n_op) shade_tile_p64<FMT8, NT>(a, tilebuf, e0, e1, x_lo, x_hi, y_lo, y_hi, ty_top, tid, lane);
+            __syncthreads();
+            continue;
         }
         // winners -> visibility buffer: one 256-B row segment per wave instruction (zeros for uncovered pixels)
         for (uint32_t p = tid; p < TILE_W * TILE_H; p += NT) {
@@ -757,6 +829,152 @@ __device__ __forceinline__ uint32_t colour(const FillArgs& a, const Hit& h, int 
     // 8-bit path: the overwrite pass only runs when no texel blends and every editor alpha is 255 -> set_pixel (render.rs:301-310)
     if (FMT8) return (shade8(h.texel, h.bcx, h.bcy, h.bcz, h.vc1, h.vc2, h.vc3, h.flags, shading, shv, px, py) & 0xFFFFFFu) | 0xFF000000u;
     return c15_to_rgba(shade15(h.texel, h.bcx, h.bcy, h.bcz, h.vc1, h.vc2, h.vc3, h.flags, shading, shv, px, py));   // set_pixel_15
+}
+
+// ------------------------------------------------------------------------------------------------ fused shading (P64 fast path)
+// After the sort-free coverage of a tile the workgroup shades the tile straight from the LDS winners: no visibility buffer
+// round trip through HBM, and while one workgroup of a CU sits in the (memory-latency bound) shading phase the other one
+// runs its (LDS/VALU bound) coverage phase.  Each lane shades TWO pixels at a time: both record gathers are issued before
+// either is used, then both texel fetches, so two dependent load chains are in flight per lane.
+struct RecRegs { uint4 q0, q1, q2, q3, q4, q5; };
+__device__ __forceinline__ void rec_load(const FillArgs& a, uint32_t sid, bool need5, RecRegs& r) {
+    const uint4* rp = reinterpret_cast<const uint4*>(a.recs + sid);
+    r.q0 = rp[0]; r.q1 = rp[1]; r.q2 = rp[2]; r.q3 = rp[3]; r.q4 = rp[4];
+    r.q5 = make_uint4(0, 0, 0, 0);
+    if (need5) r.q5 = rp[5];
+}
+// inside test + texel address (index into the texel pool; -1 = untextured -> white, -2 = zero-size texture -> transparent)
+__device__ __forceinline__ bool hit_prepare(const FillArgs& a, const RecRegs& r, uint32_t px, uint32_t py, Hit& h, int& taddr) {
+    Tri tr;
+    tr.x3 = __uint_as_float(r.q0.x); tr.y3 = __uint_as_float(r.q0.y); tr.a0 = __uint_as_float(r.q0.z); tr.b0 = __uint_as_float(r.q0.w);
+    tr.a1 = __uint_as_float(r.q1.x); tr.b1 = __uint_as_float(r.q1.y); tr.inv_area = __uint_as_float(r.q1.z);
+    tr.min_x = r.q1.w & 0xFFFF; tr.max_x = r.q1.w >> 16; tr.min_y = r.q2.x & 0xFFFF; tr.max_y = r.q2.x >> 16;
+    tr.flags = r.q3.w;
+    tr.w0_start = __uint_as_float(r.q4.w); tr.w1_start = __uint_as_float(r.q5.x);
+    float w0, w1;
+    edge_w(tr, px, py, w0, w1);
+    taddr = -1;
+    if (!inside_bc(tr, w0, w1, h.bcx, h.bcy, h.bcz)) return false;
+    h.vc1 = r.q4.x; h.vc2 = r.q4.y; h.vc3 = r.q4.z; h.flags = tr.flags;
+    const uint32_t txid = tr.flags & F_TEX_MASK;
+    if (txid == F_TEX_NONE) return true;
+    TexDesc d;
+    if (a.fp.nt == 1) d = a.tex0; else d = a.tex[txid];
+    if (d.width == 0 || d.height == 0) { taddr = -2; return true; }
+    const float u1 = __uint_as_float(r.q2.y), u2 = __uint_as_float(r.q2.z), u3 = __uint_as_float(r.q2.w);
+    const float v1 = __uint_as_float(r.q3.x), v2 = __uint_as_float(r.q3.y), v3 = __uint_as_float(r.q3.z);
+    float u, v;
+    if (a.fp.affine) {
+        u = h.bcx * u1 + h.bcy * u2 + h.bcz * u3;                // render.rs:1565-1566
+        v = h.bcx * v1 + h.bcy * v2 + h.bcz * v3;
+    } else {                                                     // render.rs:1568-1579
+        const float iz1 = __uint_as_float(r.q5.y), iz2 = __uint_as_float(r.q5.z), iz3 = __uint_as_float(r.q5.w);
+        const float inv_z = h.bcx * iz1 + h.bcy * iz2 + h.bcz * iz3;
+        const float u_over_z = h.bcx * u1 * iz1 + h.bcy * u2 * iz2 + h.bcz * u3 * iz3;
+        const float v_over_z = h.bcx * v1 * iz1 + h.bcy * v2 * iz2 + h.bcz * v3 * iz3;
+        u = u_over_z / inv_z;
+        v = v_over_z / inv_z;
+    }
+    const float uw = rem_euclid1(u), vw = rem_euclid1(1.0f - v);                        // Texture15::sample, types.rs:671-681
+    const uint32_t tx = min(f2u_sat(uw * (float)d.width), d.width - 1);
+    const uint32_t ty = min(f2u_sat(vw * (float)d.height), d.height - 1);
+    taddr = (int)(d.offset + ty * d.width + tx);
+    return true;
+}
+// transparency rule on the fetched texel (render.rs:1591-1608 / 8-bit :1348-1352)
+template <bool FMT8>
+__device__ __forceinline__ bool hit_finish(uint32_t flags, int taddr, uint32_t fetched, uint32_t& texel) {
+    if (FMT8) {
+        const uint32_t c = taddr == -1 ? 0x00FFFFFFu : (taddr == -2 ? ((uint32_t)B32_BLEND_ERASE << 24) : fetched);
+        texel = c;
+        return (c >> 24) != B32_BLEND_ERASE;
+    }
+    uint32_t c = taddr == -1 ? 0x7FFFu : (taddr == -2 ? 0u : fetched);
+    if (c == 0) {
+        if (flags & F_BLACK_TR) return false;
+        c = 0x8000;
+    } else if ((flags & F_BLACK_TR) && (c & 0x7FFF) == 0) return false;
+    texel = c;
+    return true;
+}
+template <bool FMT8>
+__device__ __forceinline__ uint32_t fetch_texel(const FillArgs& a, int taddr) {
+    if (taddr < 0) return 0;
+    return FMT8 ? a.texels32[taddr] : (uint32_t)a.texels[taddr];
+}
+
+template <bool FMT8, int NT>
+__device__ __forceinline__ void shade_tile_p64(const FillArgs& a, const uint32_t* tilebuf, uint32_t e0, uint32_t e1, uint32_t x_lo, uint32_t x_hi,
+                                               uint32_t y_lo, uint32_t y_hi, uint32_t ty_top, uint32_t tid, uint32_t lane) {
+    const FrameParams& fp = a.fp;
+    const unsigned long long* top = reinterpret_cast<const unsigned long long*>(tilebuf);
+    const unsigned long long* sec = top + TILE_H * TILE_STRIDE;
+    const int shading = fp.shading;
+    const bool need5 = !fp.affine || !fp.fixed_point || fp.ortho;       // q5: literal-replay start value / 1/z terms
+    const uint32_t W = fp.width;
+    constexpr uint32_t ROWS_PER_STEP = NT / 64;
+    for (uint32_t r0 = 0; r0 < TILE_H; r0 += 2 * ROWS_PER_STEP) {
+        const uint32_t col = tid & 63;
+        const uint32_t rowA = r0 + (tid >> 6), rowB = rowA + ROWS_PER_STEP;
+        const uint32_t px = x_lo + col, pyA = ty_top + rowA, pyB = ty_top + rowB;
+        const bool inA = px < x_hi && pyA >= y_lo && pyA < y_hi, inB = px < x_hi && pyB >= y_lo && pyB < y_hi;
+        const unsigned long long tA = inA ? top[rowA * TILE_STRIDE + col] : 0ull, tB = inB ? top[rowB * TILE_STRIDE + col] : 0ull;
+        if (!__ballot(tA != 0 || tB != 0)) continue;
+        RecRegs ra, rb;
+        rec_load(a, tA ? (uint32_t)tA : 0u, need5, ra);           // surface 0's record is a harmless dummy for uncovered pixels
+        rec_load(a, tB ? (uint32_t)tB : 0u, need5, rb);
+        Hit hA, hB;
+        int taA = -1, taB = -1;
+        bool okA = tA != 0 && hit_prepare(a, ra, px, pyA, hA, taA);
+        bool okB = tB != 0 && hit_prepare(a, rb, px, pyB, hB, taB);
+        const uint32_t fA = fetch_texel<FMT8>(a, okA ? taA : -1), fB = fetch_texel<FMT8>(a, okB ? taB : -1);
+        hA.sid = (uint32_t)tA; hB.sid = (uint32_t)tB;
+        okA = okA && hit_finish<FMT8>(hA.flags, taA, fA, hA.texel);
+        okB = okB && hit_finish<FMT8>(hB.flags, taB, fB, hB.texel);
+        // skipped winner (rare): the exact runner-up from LDS, then (rarer) the best drawn surface below it from the list
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            const unsigned long long t = which ? tB : tA;
+            bool& ok = which ? okB : okA;
+            Hit& h = which ? hB : hA;
+            const uint32_t py = which ? pyB : pyA, row = which ? rowB : rowA;
+            unsigned long long limit = 0;
+            if (t != 0 && !ok) {
+                const unsigned long long t2 = sec[row * TILE_STRIDE + col];
+                if (t2) {
+                    ok = hit_test<FMT8>(a, (uint32_t)t2, px, py, h);
+                    if (!ok) limit = t2;
+                }
+            }
+            unsigned long long fm = __ballot(limit != 0);
+            while (fm) {
+                const int fl = __builtin_ctzll(fm);
+                fm &= fm - 1;
+                const uint32_t fx = (uint32_t)__builtin_amdgcn_readlane((int)px, fl), fy = (uint32_t)__builtin_amdgcn_readlane((int)py, fl);
+                const unsigned long long lim = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(limit >> 32), fl) << 32) |
+                                               (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)limit, fl);
+                unsigned long long best = 0;
+                for (uint32_t base = e0; base < e1; base += 64) {
+                    unsigned long long cand = 0;
+                    if (base + lane < e1) {
+                        const uint32_t csid = a.pair_vals[base + lane];
+                        const unsigned long long P = ((unsigned long long)a.keys[csid] << 32) | csid;
+                        if (P < lim && P > best) {
+                            const uint4* rp = reinterpret_cast<const uint4*>(a.recs + csid);
+                            const uint32_t bbx = rp[1].w, bby = rp[2].x;
+                            Hit c;
+                            if (fx >= (bbx & 0xFFFF) && fx < (bbx >> 16) && fy >= (bby & 0xFFFF) && fy < (bby >> 16) && hit_test<FMT8>(a, csid, fx, fy, c)) cand = P;
+                        }
+                    }
+                    for (int off = 32; off > 0; off >>= 1) { const unsigned long long o = __shfl_xor(cand, off); cand = o > cand ? o : cand; }
+                    best = cand > best ? cand : best;
+                }
+                if ((int)lane == fl && best) ok = hit_test<FMT8>(a, (uint32_t)best, px, py, h);
+            }
+        }
+        if (okA) a.fb[(size_t)pyA * W + px] = colour<FMT8>(a, hA, shading, px, pyA);
+        if (okB) a.fb[(size_t)pyB * W + px] = colour<FMT8>(a, hB, shading, px, pyB);
+    }
 }
 
 // One 256-thread workgroup per 64x16 strip of a 64x64 tile; each wave shades a 64-pixel row segment at a time (256-B coalesced
@@ -997,14 +1215,25 @@ void launch_fill(hipStream_t s, const FillArgs& a, int n_cu, hipEvent_t after_co
         } else {
             hipLaunchKernelGGL((k_cover<0, true, 512, false, false>), dim3(min(ntiles, (uint32_t)n_cu * 2)), dim3(512), LDS_TEX_OFFSET, s, a);
         }
+    } else if (a.prio64) {   // sort-free: 64-bit tile buffers (2 x 36 KB) -> two workgroups per CU
+        const size_t lds64 = 4 * LDS_TILE_BYTES + LDS_MISC_BYTES + LDS_MARK_BYTES;
+        static bool attr_set64 = false;
+        if (!attr_set64) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<0, false, 512, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
+        if (!attr_set64) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<0, false, 512, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
+        attr_set64 = true;
+        if (f8) hipLaunchKernelGGL((k_cover<0, false, 512, false, true, true>), dim3(min(ntiles, (uint32_t)n_cu * 2)), dim3(512), lds64, s, a);
+        else hipLaunchKernelGGL((k_cover<0, false, 512, false, false, true>), dim3(min(ntiles, (uint32_t)n_cu * 2)), dim3(512), lds64, s, a);
+        if (after_cover) (void)hipEventRecord(after_cover, s);
+        return;                                                  // coverage and shading are one kernel on this path
     } else {    // CHEAP coverage never samples a texture: one kernel for both pixel formats
         hipLaunchKernelGGL((k_cover<0, false, 512, false, false>), dim3(min(ntiles, (uint32_t)n_cu * 3)), dim3(512), lds_sort, s, a);
     }
     if (after_cover) (void)hipEventRecord(after_cover, s);
     const uint32_t band_h = a.fp.band_y1 - a.fp.band_y0;
     if (band_h) {
-        if (f8) hipLaunchKernelGGL(k_shade<true>, dim3(((ntiles + 7) / 8) * 8 * 4), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL(k_shade<false>, dim3(((ntiles + 7) / 8) * 8 * 4), dim3(256), 0, s, a);
+        const dim3 g(((ntiles + 7) / 8) * 8 * 4);
+        if (f8) hipLaunchKernelGGL((k_shade<true>), g, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((k_shade<false>), g, dim3(256), 0, s, a);
     }
     if (a.may_blend && !f8) hipLaunchKernelGGL((k_blend<1024, false>), dim3(ntiles), dim3(1024), 0, s, a);
 }

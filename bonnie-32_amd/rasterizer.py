@@ -97,6 +97,7 @@ class Framebuffer:
         self.ctx = ctx or Context(device)
         self.width, self.height = 0, 0
         self.resize(width, height)
+        self.set_band(0, height)          # a new Framebuffer owns all its rows (a band set earlier on this ctx does not carry over)
 
     @staticmethod
     def new(width, height, ctx=None):
