@@ -485,7 +485,8 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
         for (int i = 0; i < 2; ++i) { if ((rc = ensure_plain(c, c->pkeys[i], n))) return rc; if ((rc = ensure_plain(c, c->pvals[i], n))) return rc; }
         c->cap_pairs = n;
     }
-    const uint32_t need_blocks = (uint32_t)((std::max(c->cap_pairs, c->cap_work) + SORT_TILE - 1) / SORT_TILE) + 1;
+    const uint32_t need_blocks = std::max((uint32_t)((std::max(c->cap_pairs, c->cap_work) + SORT_TILE - 1) / SORT_TILE) + 1,
+                                          (uint32_t)(c->cap_work / 2048 + 2));          // span counting sort: 2048 faces per block
     if (need_blocks > c->hist_blocks || !c->block_hist) {
         if ((rc = ensure_plain(c, c->block_hist, (size_t)4096 * need_blocks))) return rc;
         c->hist_blocks = need_blocks;
@@ -543,6 +544,14 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     const bool local_sort = !exact_cov && c->local_sort_ok && !fp.ortho && !ordered_all;
     c->last_local_sort = local_sort;
     c->last_exact = ordered_all ? true : (exact_cov && !fp.zmode);          // the ordered walk counts every store it performs
+    const bool want_prio64 = local_sort && !c->may_blend && !c->no_prio64 && c->nf > 0;   // no transparent pass -> no tile list order needed
+    int cur = 0;
+    bool prio64 = false;
+    if (want_prio64) {
+        if (prof_all) HIPCHK(c, hipEventRecord(ev[2], s));
+        prio64 = launch_bin_spans(s, fp, c->spans, c->partials, c->d_ctrl, sc, (uint32_t)c->cap_pairs, c->ranges, c->pvals[0]);
+    }
+    if (!prio64) {
     if (local_sort) {
         // fast path: no global depth sort.  Pairs are emitted in face order from k_setup's spans; k_cover sorts every tile
         // list by depth key in LDS (stable, so ties keep face order).
@@ -566,7 +575,6 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     }
     const uint32_t n_sort_keys = local_sort ? ntiles : n_keys;          // the fast path groups by tile only
     const uint32_t kb = bits_for(n_sort_keys ? n_sort_keys : 1);
-    int cur = 0;
     if (kb <= 8 || kb > 12) {
         for (uint32_t shift = 0; shift < kb; shift += 8) {
             launch_radix_pass(s, c->pkeys[cur], c->pvals[cur], c->pkeys[cur ^ 1], c->pvals[cur ^ 1], &c->d_ctrl->n_pairs, (uint32_t)c->cap_pairs, (int)shift, 8, sc);
@@ -578,6 +586,7 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
         launch_radix_pass(s, c->pkeys[cur], c->pvals[cur], c->pkeys[cur ^ 1], c->pvals[cur ^ 1], &c->d_ctrl->n_pairs, (uint32_t)c->cap_pairs, 0, kb <= 11 ? 11 : 12, sc, exr);
         cur ^= 1;
     }
+    }   // !prio64
     c->last_pair_buf = cur;
     if (prof_fill) HIPCHK(c, hipEventRecord(ev[3], s));
 
@@ -597,7 +606,7 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     fa.skip_solid = wire_front ? 1u : 0u;
     fa.texels32 = c->d_texels32;
     fa.ordered_all = ordered_all ? 1u : 0u;
-    fa.prio64 = (local_sort && !c->may_blend && !c->no_prio64) ? 1u : 0u;   // no transparent pass -> no tile list order needed at all
+    fa.prio64 = prio64 ? 1u : 0u;
     if (c->fmt8) fa.fp.xray = 0;                        // render_mesh: x-ray only changes culling; its stores keep their own depth tests
     launch_fill(s, fa, c->n_cu, prof_fill ? ev[4] : nullptr);
     if (fp.wire_collect && c->nf) {

@@ -218,6 +218,10 @@ struct WireArgs {
     Ctrl* ctrl;
 };
 void launch_wire(hipStream_t s, const WireArgs& a, bool back, bool front);
+// Sort-free fast path: tile lists (unordered) by a counting sort straight from k_setup's spans; false = not applicable (too many
+// tiles for the LDS histogram), the caller takes the keyed radix path.
+bool launch_bin_spans(hipStream_t s, const FrameParams& fp, const uint32_t* spans, const uint32_t* partials, Ctrl* ctrl, const SortScratch& sc,
+                      uint32_t pair_cap, uint32_t* ranges, uint32_t* pair_vals);
 void launch_tile_ranges(hipStream_t s, const uint32_t* pair_keys, const Ctrl* ctrl, uint32_t pair_cap, uint32_t* ranges, uint32_t n_keys);
 
 struct FillArgs {

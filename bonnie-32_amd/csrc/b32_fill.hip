@@ -917,7 +917,7 @@ __device__ __forceinline__ void shade_tile_p64(const FillArgs& a, const uint32_t
         const uint32_t col = tid & 63;
         const uint32_t rowA = r0 + (tid >> 6), rowB = rowA + ROWS_PER_STEP;
         const uint32_t px = x_lo + col, pyA = ty_top + rowA, pyB = ty_top + rowB;
-        const bool inA = px < x_hi && pyA >= y_lo && pyA < y_hi, inB = px < x_hi && pyB >= y_lo && pyB < y_hi;
+        const bool inA = rowA < TILE_H && px < x_hi && pyA >= y_lo && pyA < y_hi, inB = rowB < TILE_H && px < x_hi && pyB >= y_lo && pyB < y_hi;
         const unsigned long long tA = inA ? top[rowA * TILE_STRIDE + col] : 0ull, tB = inB ? top[rowB * TILE_STRIDE + col] : 0ull;
         if (!__ballot(tA != 0 || tB != 0)) continue;
         RecRegs ra, rb;
@@ -1221,6 +1221,14 @@ void launch_fill(hipStream_t s, const FillArgs& a, int n_cu, hipEvent_t after_co
         if (!attr_set64) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<0, false, 512, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
         if (!attr_set64) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<0, false, 512, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
         attr_set64 = true;
+        static const int nt64 = getenv("B32_P64_NT") ? atoi(getenv("B32_P64_NT")) : 512;
+        if (!f8 && nt64 == 768) {
+            static bool ab = false; if (!ab) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<0, false, 768, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); ab = true; }
+            hipLaunchKernelGGL((k_cover<0, false, 768, false, false, true>), dim3(min(ntiles, (uint32_t)n_cu * 2)), dim3(768), lds64, s, a);
+        } else if (!f8 && nt64 == 1024) {
+            static bool ab = false; if (!ab) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<0, false, 1024, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); ab = true; }
+            hipLaunchKernelGGL((k_cover<0, false, 1024, false, false, true>), dim3(min(ntiles, (uint32_t)n_cu * 2)), dim3(1024), lds64, s, a);
+        } else
         if (f8) hipLaunchKernelGGL((k_cover<0, false, 512, false, true, true>), dim3(min(ntiles, (uint32_t)n_cu * 2)), dim3(512), lds64, s, a);
         else hipLaunchKernelGGL((k_cover<0, false, 512, false, false, true>), dim3(min(ntiles, (uint32_t)n_cu * 2)), dim3(512), lds64, s, a);
         if (after_cover) (void)hipEventRecord(after_cover, s);

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void k_scan_rows(uint32_t* __restrict__ block_
                                                    uint32_t* __restrict__ digit_total, Ctrl* __restrict__ post_ctrl,
                                                    const uint32_t* __restrict__ partials, uint32_t npart, const uint32_t* __restrict__ n_dev) {
     __shared__ uint32_t wsum[4];
-    nblocks = min(nblocks, (*n_dev + SORT_TILE - 1) / SORT_TILE);          // blocks actually in use (grids are sized for the capacity)
+    if (n_dev) nblocks = min(nblocks, (*n_dev + SORT_TILE - 1) / SORT_TILE);   // blocks actually in use (grids are sized for the capacity)
     if (post_ctrl && blockIdx.x == 0) reduce_setup_partials(post_ctrl, partials, npart);
     __shared__ uint32_t carry_s;
     uint32_t* row = block_hist + (size_t)blockIdx.x * max_blocks;
@@ -182,6 +182,90 @@ __global__ __launch_bounds__(SORT_THREADS) void k_scatter(const uint32_t* __rest
             vals_out[pos] = val[i];
         }
     }
+}
+
+// ---- sort-free fast path: tile lists by counting sort straight from k_setup's spans --------------------------------------
+// The max-of-priorities coverage needs no order inside a tile list, so the (tile, surface) pairs are never materialised with
+// keys and never ranked: k_count_spans histograms the tiles of 2048 faces in LDS (LDS atomics), k_scan_rows scans every tile's
+// row across the blocks, k_place_spans re-reads the spans and drops each surface id at base[tile]++ (LDS atomic cursor).
+constexpr uint32_t SPAN_BLOCK = 2048;           // faces per workgroup
+constexpr uint32_t SPAN_MAX_TILES = 4096;       // LDS histogram capacity
+
+__global__ __launch_bounds__(256) void k_count_spans(uint32_t nf, uint32_t ntiles, uint32_t tiles_x, const uint32_t* __restrict__ spans,
+                                                     uint32_t* __restrict__ block_hist, uint32_t max_blocks) {
+    __shared__ uint32_t hist[SPAN_MAX_TILES];
+    for (uint32_t t = threadIdx.x; t < ntiles; t += 256) hist[t] = 0;
+    __syncthreads();
+    const uint32_t f0 = blockIdx.x * SPAN_BLOCK;
+    for (uint32_t i = threadIdx.x; i < SPAN_BLOCK; i += 256) {
+        const uint32_t f = f0 + i;
+        const uint32_t span = f < nf ? spans[f] : 0xFFFFFFFFu;
+        if (span == 0xFFFFFFFFu) continue;
+        const uint32_t tx0 = span & 0xFF, tx1 = (span >> 8) & 0xFF, ty0 = (span >> 16) & 0xFF, ty1 = span >> 24;
+        for (uint32_t ty = ty0; ty <= ty1; ++ty)
+            for (uint32_t tx = tx0; tx <= tx1; ++tx) atomicAdd(&hist[ty * tiles_x + tx], 1u);
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < ntiles; t += 256) block_hist[(size_t)t * max_blocks + blockIdx.x] = hist[t];
+}
+
+__global__ __launch_bounds__(256) void k_place_spans(uint32_t nf, uint32_t ntiles, uint32_t tiles_x, const uint32_t* __restrict__ spans,
+                                                     const uint32_t* __restrict__ block_hist, uint32_t max_blocks,
+                                                     const uint32_t* __restrict__ digit_total, Ctrl* __restrict__ ctrl, uint32_t pair_cap,
+                                                     uint32_t* __restrict__ ranges, uint32_t* __restrict__ pair_vals) {
+    __shared__ uint32_t base[SPAN_MAX_TILES];
+    __shared__ uint32_t dws[4];
+    __shared__ uint32_t total_s;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // tile bases: exclusive scan of the row totals; thread t owns tiles [t*per, t*per + per)
+    const uint32_t per = (ntiles + 255) / 256;                           // <= 16
+    uint32_t tot[16], sum = 0;
+    for (uint32_t j = 0; j < per; ++j) { const uint32_t t = threadIdx.x * per + j; tot[j] = t < ntiles ? digit_total[t] : 0u; sum += tot[j]; }
+    uint32_t inc = sum;
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t v = __shfl_up(inc, off); if (lane >= (uint32_t)off) inc += v; }
+    if (lane == 63) dws[wave] = inc;
+    __syncthreads();
+    uint32_t run = inc - sum;
+    for (uint32_t w = 0; w < wave; ++w) run += dws[w];
+    if (threadIdx.x == 255) total_s = run + sum;
+    for (uint32_t j = 0; j < per; ++j) {
+        const uint32_t t = threadIdx.x * per + j;
+        if (t < ntiles) {
+            base[t] = run + block_hist[(size_t)t * max_blocks + blockIdx.x];
+            if (blockIdx.x == 0) ranges[t] = run;                        // list range of tile t = [ranges[t], ranges[t+1])
+        }
+        run += tot[j];
+    }
+    __syncthreads();
+    const uint32_t total = total_s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ranges[ntiles] = total;
+        if (total > pair_cap) { ctrl->pairs_overflow = total; ctrl->abort = 1; ctrl->n_pairs = 0; }
+        else ctrl->n_pairs = total;
+    }
+    if (total > pair_cap || ctrl->abort) return;
+    const uint32_t f0 = blockIdx.x * SPAN_BLOCK;
+    for (uint32_t i = threadIdx.x; i < SPAN_BLOCK; i += 256) {
+        const uint32_t f = f0 + i;
+        const uint32_t span = f < nf ? spans[f] : 0xFFFFFFFFu;
+        if (span == 0xFFFFFFFFu) continue;
+        const uint32_t tx0 = span & 0xFF, tx1 = (span >> 8) & 0xFF, ty0 = (span >> 16) & 0xFF, ty1 = span >> 24;
+        for (uint32_t ty = ty0; ty <= ty1; ++ty)
+            for (uint32_t tx = tx0; tx <= tx1; ++tx) pair_vals[atomicAdd(&base[ty * tiles_x + tx], 1u)] = f;
+    }
+}
+
+bool launch_bin_spans(hipStream_t s, const FrameParams& fp, const uint32_t* spans, const uint32_t* partials, Ctrl* ctrl, const SortScratch& sc,
+                      uint32_t pair_cap, uint32_t* ranges, uint32_t* pair_vals) {
+    const uint32_t ntiles = fp.tiles_x * fp.tiles_y;
+    const uint32_t nblocks = (fp.nf + SPAN_BLOCK - 1) / SPAN_BLOCK;
+    if (ntiles == 0 || ntiles > SPAN_MAX_TILES || nblocks > sc.max_blocks || fp.nf == 0) return false;
+    hipLaunchKernelGGL(k_count_spans, dim3(nblocks), dim3(256), 0, s, fp.nf, ntiles, fp.tiles_x, spans, sc.block_hist, sc.max_blocks);
+    hipLaunchKernelGGL(k_scan_rows, dim3(ntiles), dim3(256), 0, s, sc.block_hist, sc.max_blocks, nblocks, sc.digit_total,
+                       ctrl, partials, (fp.nf + 255) / 256, (const uint32_t*)nullptr);
+    hipLaunchKernelGGL(k_place_spans, dim3(nblocks), dim3(256), 0, s, fp.nf, ntiles, fp.tiles_x, spans, sc.block_hist, sc.max_blocks,
+                       sc.digit_total, ctrl, pair_cap, ranges, pair_vals);
+    return true;
 }
 
 template <int BITS>
