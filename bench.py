@@ -148,15 +148,16 @@ def main():
     if rank == 0:
         mtri = NF / (ms_per_step * 1e-3) / 1e6
         mpix = fragments / (ms_per_step * 1e-3) / 1e6
-        # ALGORITHMIC bytes.  Frame: SURVEY 8d B_alg.  Dominant kernel k_cover, per launch:
-        #   per (surface, tile) pair: 4 B surface id read + 4 B depth key gathered + 4 B sorted id written back
-        #                             + 64 B of the surface record (edge coefficients, bbox, flags)
-        #   per band pixel: 8 B visibility entry written
+        # ALGORITHMIC bytes.  Frame: SURVEY 8d B_alg.  Dominant kernel k_cover (coverage + shading of the
+        # default fast path), per launch, every input counted once:
+        #   per (surface, tile) pair: 4 B surface id + 4 B painter's key + 64 B of the surface record (edges, bbox, uv, flags)
+        #   per surface: 16 B more of its record for shading (vertex colours)
+        #   per band pixel: 4 B framebuffer write;  + the texture once
         tex_bytes = sum(t.width * t.height * 2 for t in sc.textures)
         alg_frame = 36 * len(sc.vertices) + 20 * NF + 16 * tm.triangles_drawn + 8 * W * H + tex_bytes   # SURVEY 8d B_alg
         roofline = None
         if cover_ms:
-            alg_cover = 76 * tm.tile_pairs + 8 * W * (y1 - y0)
+            alg_cover = 72 * tm.tile_pairs + 16 * tm.triangles_drawn + 4 * W * (y1 - y0) + tex_bytes
             ach = alg_cover / (cover_ms * 1e-3) / 1e9
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -167,7 +168,7 @@ def main():
                     traffic = None
             roofline = {"kernel": "k_cover", "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
-                        "kernel_ms": round(cover_ms, 4), "algorithmic_bytes": alg_cover, "units": {"tile_pairs": tm.tile_pairs, "pixels": W * (y1 - y0)},
+                        "kernel_ms": round(cover_ms, 4), "algorithmic_bytes": alg_cover, "units": {"tile_pairs": tm.tile_pairs, "surfaces": tm.triangles_drawn, "pixels": W * (y1 - y0)},
                         "frame_algorithmic_bytes": alg_frame,
                         "frame_frac": round(alg_frame / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
         cpu = None
