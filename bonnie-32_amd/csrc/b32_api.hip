@@ -537,14 +537,19 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     if (prof_all) HIPCHK(c, hipEventRecord(ev[1], s));
 
     const SortScratch sc{ c->block_hist, c->hist_blocks, c->digit_total };
-    const bool exact_cov = c->count_fragments || !c->cheap_ok || fp.zmode;   // z-buffer mode: depth + skip rule per fragment
+    // z-buffer frames without a transparent pass take the sort-free fused path too (depth is the priority); otherwise z-buffer
+    // mode applies depth + skip rule per fragment (EXACT coverage)
+    const bool spans_ok = ntiles > 0 && ntiles <= 4096 && (c->nf + 2047) / 2048 <= c->hist_blocks;   // launch_bin_spans applies
+    const bool zfast = spans_ok && fp.zmode && !c->count_fragments && c->cheap_ok && !c->may_blend && !c->no_prio64 && !fp.ortho && c->nf > 0 &&
+                       !(c->fmt8 && c->blend8);
+    const bool exact_cov = c->count_fragments || !c->cheap_ok || (fp.zmode && !zfast);
     // the fast path reads the class from bit 31 of the depth key and has no ordered opaque walk: not for ortho / x-ray frames
     // ordered walk of whole tile lists instead of the overwrite pass: x-ray (RGB555), or the 8-bit path with blending texels / editor alpha
     const bool ordered_all = c->fmt8 ? c->blend8 : (fp.xray != 0);
     const bool local_sort = !exact_cov && c->local_sort_ok && !fp.ortho && !ordered_all;
     c->last_local_sort = local_sort;
     c->last_exact = ordered_all ? true : (exact_cov && !fp.zmode);          // the ordered walk counts every store it performs
-    const bool want_prio64 = local_sort && !c->may_blend && !c->no_prio64 && c->nf > 0;   // no transparent pass -> no tile list order needed
+    const bool want_prio64 = (local_sort || zfast) && !c->may_blend && !c->no_prio64 && c->nf > 0;   // no transparent pass -> no tile list order needed
     int cur = 0;
     bool prio64 = false;
     if (want_prio64) {

@@ -408,6 +408,7 @@ __device__ __forceinline__ uint32_t cover_one(const Batch& b, int t, uint32_t li
 }
 
 // P64 coverage of a surface whose edge walk must be replayed literally (F_SLOW): one lane per row.
+template <bool ZMODE>
 __device__ __forceinline__ void cover_slow64(const Tri& tr, unsigned long long P, uint32_t* tilebuf, uint32_t x_lo, uint32_t x_hi,
                                              uint32_t y_lo, uint32_t y_hi, uint32_t ty_top, uint32_t lane) {
     const uint32_t cx0 = max(tr.min_x, x_lo), cx1 = min(tr.max_x, x_hi);
@@ -424,8 +425,13 @@ __device__ __forceinline__ void cover_slow64(const Tri& tr, unsigned long long P
                 float bcx, bcy, bcz;
                 if (inside_bc(tr, w0, w1, bcx, bcy, bcz)) {
                     const uint32_t addr = (py - ty_top) * TILE_STRIDE + (px - x_lo);
-                    const unsigned long long old = atomicMax(&top[addr], P);
-                    atomicMax(&sec[addr], min(old, P));
+                    unsigned long long Pf = P;
+                    bool ok = true;
+                    if (ZMODE) { uint32_t zkey; ok = frag_zkey(tr, bcx, bcy, bcz, zkey); Pf = ((unsigned long long)(~zkey) << 32) | (uint32_t)P; }
+                    if (ok) {
+                        const unsigned long long old = atomicMax(&top[addr], Pf);
+                        atomicMax(&sec[addr], min(old, Pf));
+                    }
                 }
                 w0 += tr.a0; w1 += tr.a1;
             }
@@ -459,9 +465,12 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
         const uint32_t e = cs + lane;
         bool live = lane < grab && e < n_op;
         Batch b;
-        load_batch<TEXMODE>(b, a, e0 + e, live, lds_desc, EXACT);
-        uint32_t my_sid = 0, my_key = 0;                       // P64: the surface's place in the global painter's order
-        if (P64 && live) { my_sid = a.pair_vals[e0 + e]; my_key = a.keys[my_sid]; }
+        load_batch<TEXMODE>(b, a, e0 + e, live, lds_desc, EXACT || (P64 && ZMODE));
+        // P64: the surface's place in the global painter's order; in z-buffer mode the high word is the fragment's depth and the
+        // low word 0xFFFFFFFE - face id (first in face order wins a depth tie, like the sequential `z < zbuffer` test; all ones is
+        // reserved for the z-buffer seed, which therefore wins every tie: `z < zbuffer` is strict)
+        uint32_t my_sid = 0, my_key = 0;
+        if (P64 && live) { my_sid = a.pair_vals[e0 + e]; my_key = ZMODE ? 0u : a.keys[my_sid]; if (ZMODE) my_sid = 0xFFFFFFFEu - my_sid; }
         const uint32_t flags = b.q3.w;
         const uint32_t cx0 = max(b.q1.w & 0xFFFF, x_lo), cx1 = min(b.q1.w >> 16, x_hi);
         const uint32_t cy0 = max(b.q2.x & 0xFFFF, y_lo), cy1 = min(b.q2.x >> 16, y_hi);
@@ -509,7 +518,7 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
             uint32_t addr = ry * TILE_STRIDE + rx0;
             const uint32_t li = cs + s + 1;
             uint32_t mine = 0;
-            if (EXACT || ZMODE) {
+            if (EXACT || (ZMODE && !P64)) {
                 for (uint32_t i = 0; __ballot(i < n); ++i) {
                     if (i < n) {
                         const float bcx = w0 * sinv, bcy = w1 * sinv;
@@ -531,24 +540,32 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
                 const unsigned long long P = ((unsigned long long)bperm(s, my_key) << 32) | bperm(s, my_sid);
                 unsigned long long* top = reinterpret_cast<unsigned long long*>(tilebuf);
                 unsigned long long* sec = top + TILE_H * TILE_STRIDE;
+                float z1 = 0.0f, z2 = 0.0f, z3 = 0.0f;
+                if (ZMODE) { z1 = bpermf(s, __uint_as_float(b.q5.y)); z2 = bpermf(s, __uint_as_float(b.q5.z)); z3 = bpermf(s, __uint_as_float(b.q5.w)); }
                 for (uint32_t i = 0; __ballot(i < n); i += 4) {
                     float wa[4], wb[4];
                     wa[0] = w0; wb[0] = w1;
 #pragma unroll
                     for (int j = 1; j < 4; ++j) { wa[j] = wa[j - 1] + sa0; wb[j] = wb[j - 1] + sa1; }
                     bool in[4];
-                    unsigned long long old[4];
+                    unsigned long long old[4], Pj[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float cx = wa[j] * sinv, cy = wb[j] * sinv;
                         const float cz = 1.0f - cx - cy;
                         in[j] = (i + j < n) & (cx >= ERR) & (cy >= ERR) & (cz >= ERR);
-                        old[j] = 0;
+                        old[j] = 0; Pj[j] = P;
+                        if (ZMODE) {                            // fragment depth (render.rs:1546-1550); NaN never passes `z < zbuffer`
+                            const float inv_z = cx * z1 + cy * z2 + cz * z3;
+                            const float z = 1.0f / inv_z;
+                            in[j] = in[j] & (z == z);
+                            Pj[j] = ((unsigned long long)(~zsort_key(z)) << 32) | (uint32_t)P;
+                        }
                     }
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) if (in[j]) old[j] = atomicMax(&top[addr + j], P);
+                    for (int j = 0; j < 4; ++j) if (in[j]) old[j] = atomicMax(&top[addr + j], Pj[j]);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) if (in[j]) atomicMax(&sec[addr + j], min(old[j], P));
+                    for (int j = 0; j < 4; ++j) if (in[j]) atomicMax(&sec[addr + j], min(old[j], Pj[j]));
                     addr += 4; w0 = wa[3] + sa0; w1 = wb[3] + sa1;
                 }
             } else {
@@ -580,7 +597,7 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
             sm &= sm - 1;
             if (P64) {
                 const unsigned long long P = ((unsigned long long)bcu(my_key, t) << 32) | bcu(my_sid, t);
-                cover_slow64(tri_from_batch(b, t, false), P, tilebuf, x_lo, x_hi, y_lo, y_hi, ty_top, lane);
+                cover_slow64<ZMODE>(tri_from_batch(b, t, ZMODE), P, tilebuf, x_lo, x_hi, y_lo, y_hi, ty_top, lane);
                 continue;
             }
             frags += cover_one<TEXMODE, EXACT, ZMODE, FMT8>(b, t, cs + (uint32_t)t + 1, tilebuf, x_lo, x_hi, y_lo, y_hi, ty_top, lane, gtex, ltex, affine);
@@ -669,7 +686,7 @@ __device__ void tile_local_sort(uint32_t* sort_area, uint32_t* wcnt, volatile ui
 }
 
 // ------------------------------------------------------------------------------------------------ k_cover
-template <bool FMT8, int NT>
+template <bool FMT8, int NT, bool ZMODE>
 __device__ __forceinline__ void shade_tile_p64(const FillArgs& a, const uint32_t* tilebuf, uint32_t e0, uint32_t e1, uint32_t x_lo, uint32_t x_hi,
                                                uint32_t y_lo, uint32_t y_hi, uint32_t ty_top, uint32_t tid, uint32_t lane);
 
@@ -730,7 +747,16 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a) {
         const uint32_t x_lo = txi * TILE_W, x_hi = min(x_lo + TILE_W, fp.width);
         const uint32_t ty_top = tyi * TILE_H;
         const uint32_t y_lo = max(ty_top, fp.band_y0), y_hi = min(ty_top + TILE_H, fp.band_y1);
-        if (ZMODE) {        // 64-bit entries (depth key << 32 | list position), seeded with the current z-buffer: a fragment wins
+        if (P64 && ZMODE) { // winners seeded with the current z-buffer: a fragment wins only with a strictly smaller depth (low word all ones)
+            unsigned long long* t64 = reinterpret_cast<unsigned long long*>(tilebuf);
+            for (uint32_t p = tid; p < TILE_W * TILE_H; p += NT) {
+                const uint32_t row = p >> 6, col = p & 63;
+                const uint32_t px = x_lo + col, py = ty_top + row;
+                const bool inb = px < x_hi && py >= y_lo && py < y_hi;
+                t64[row * TILE_STRIDE + col] = inb ? (((unsigned long long)(~zsort_key(a.zbuf[(size_t)py * fp.width + px])) << 32) | 0xFFFFFFFFull) : ~0ull;
+                t64[TILE_H * TILE_STRIDE + row * TILE_STRIDE + col] = 0ull;
+            }
+        } else if (ZMODE) { // 64-bit entries (depth key << 32 | list position), seeded with the current z-buffer: a fragment wins
             unsigned long long* t64 = reinterpret_cast<unsigned long long*>(tilebuf);       // only with a strictly smaller depth
             for (uint32_t p = tid; p < TILE_W * TILE_H; p += NT) {
                 const uint32_t row = p >> 6, col = p & 63;
@@ -749,7 +775,7 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a) {
             __syncthreads();
         }
         if (P64) {          // shade the tile straight from the LDS winners (no visibility buffer)
-            if (n_op) shade_tile_p64<FMT8, NT>(a, tilebuf, e0, e1, x_lo, x_hi, y_lo, y_hi, ty_top, tid, lane);
+            if (n_op) shade_tile_p64<FMT8, NT, ZMODE>(a, tilebuf, e0, e1, x_lo, x_hi, y_lo, y_hi, ty_top, tid, lane);
             __syncthreads();
             continue;
         }
@@ -903,7 +929,16 @@ __device__ __forceinline__ uint32_t fetch_texel(const FillArgs& a, int taddr) {
     return FMT8 ? a.texels32[taddr] : (uint32_t)a.texels[taddr];
 }
 
-template <bool FMT8, int NT>
+// depth of surface `sid` at the pixel whose barycentrics are in h (render.rs:1546-1550) as a z-buffer priority word
+__device__ __forceinline__ bool depth_prio(const FillArgs& a, uint32_t sid, const Hit& h, unsigned long long& P) {
+    const uint4 q5 = reinterpret_cast<const uint4*>(a.recs + sid)[5];
+    const float inv_z = h.bcx * __uint_as_float(q5.y) + h.bcy * __uint_as_float(q5.z) + h.bcz * __uint_as_float(q5.w);
+    const float z = 1.0f / inv_z;
+    P = ((unsigned long long)(~zsort_key(z)) << 32) | (0xFFFFFFFEu - sid);
+    return z == z;
+}
+
+template <bool FMT8, int NT, bool ZMODE>
 __device__ __forceinline__ void shade_tile_p64(const FillArgs& a, const uint32_t* tilebuf, uint32_t e0, uint32_t e1, uint32_t x_lo, uint32_t x_hi,
                                                uint32_t y_lo, uint32_t y_hi, uint32_t ty_top, uint32_t tid, uint32_t lane) {
     const FrameParams& fp = a.fp;
@@ -913,37 +948,43 @@ __device__ __forceinline__ void shade_tile_p64(const FillArgs& a, const uint32_t
     const bool need5 = !fp.affine || !fp.fixed_point || fp.ortho;       // q5: literal-replay start value / 1/z terms
     const uint32_t W = fp.width;
     constexpr uint32_t ROWS_PER_STEP = NT / 64;
+    // z-buffer mode: a winner exists when the low word is not the seed's all-ones; its face id is 0xFFFFFFFE - low word
+    auto covered = [](unsigned long long t) { return ZMODE ? ((uint32_t)t != 0xFFFFFFFFu) : (t != 0ull); };
+    auto sid_of = [](unsigned long long t) { return ZMODE ? 0xFFFFFFFEu - (uint32_t)t : (uint32_t)t; };
     for (uint32_t r0 = 0; r0 < TILE_H; r0 += 2 * ROWS_PER_STEP) {
         const uint32_t col = tid & 63;
         const uint32_t rowA = r0 + (tid >> 6), rowB = rowA + ROWS_PER_STEP;
         const uint32_t px = x_lo + col, pyA = ty_top + rowA, pyB = ty_top + rowB;
         const bool inA = rowA < TILE_H && px < x_hi && pyA >= y_lo && pyA < y_hi, inB = rowB < TILE_H && px < x_hi && pyB >= y_lo && pyB < y_hi;
-        const unsigned long long tA = inA ? top[rowA * TILE_STRIDE + col] : 0ull, tB = inB ? top[rowB * TILE_STRIDE + col] : 0ull;
-        if (!__ballot(tA != 0 || tB != 0)) continue;
+        unsigned long long tA = inA ? top[rowA * TILE_STRIDE + col] : (ZMODE ? ~0ull : 0ull), tB = inB ? top[rowB * TILE_STRIDE + col] : (ZMODE ? ~0ull : 0ull);
+        const bool cA = covered(tA), cB = covered(tB);
+        if (!__ballot(cA || cB)) continue;
         RecRegs ra, rb;
-        rec_load(a, tA ? (uint32_t)tA : 0u, need5, ra);           // surface 0's record is a harmless dummy for uncovered pixels
-        rec_load(a, tB ? (uint32_t)tB : 0u, need5, rb);
+        rec_load(a, cA ? sid_of(tA) : 0u, need5, ra);             // surface 0's record is a harmless dummy for uncovered pixels
+        rec_load(a, cB ? sid_of(tB) : 0u, need5, rb);
         Hit hA, hB;
         int taA = -1, taB = -1;
-        bool okA = tA != 0 && hit_prepare(a, ra, px, pyA, hA, taA);
-        bool okB = tB != 0 && hit_prepare(a, rb, px, pyB, hB, taB);
+        bool okA = cA && hit_prepare(a, ra, px, pyA, hA, taA);
+        bool okB = cB && hit_prepare(a, rb, px, pyB, hB, taB);
         const uint32_t fA = fetch_texel<FMT8>(a, okA ? taA : -1), fB = fetch_texel<FMT8>(a, okB ? taB : -1);
-        hA.sid = (uint32_t)tA; hB.sid = (uint32_t)tB;
+        hA.sid = sid_of(tA); hB.sid = sid_of(tB);
         okA = okA && hit_finish<FMT8>(hA.flags, taA, fA, hA.texel);
         okB = okB && hit_finish<FMT8>(hB.flags, taB, fB, hB.texel);
         // skipped winner (rare): the exact runner-up from LDS, then (rarer) the best drawn surface below it from the list
 #pragma unroll
         for (int which = 0; which < 2; ++which) {
-            const unsigned long long t = which ? tB : tA;
+            unsigned long long& t = which ? tB : tA;
+            const bool cov = which ? cB : cA;
             bool& ok = which ? okB : okA;
             Hit& h = which ? hB : hA;
             const uint32_t py = which ? pyB : pyA, row = which ? rowB : rowA;
-            unsigned long long limit = 0;
-            if (t != 0 && !ok) {
+            unsigned long long limit = 0, seed = 0;
+            if (cov && !ok) {
+                if (ZMODE) seed = ((unsigned long long)(~zsort_key(a.zbuf[(size_t)py * W + px])) << 32) | 0xFFFFFFFFull;
                 const unsigned long long t2 = sec[row * TILE_STRIDE + col];
-                if (t2) {
-                    ok = hit_test<FMT8>(a, (uint32_t)t2, px, py, h);
-                    if (!ok) limit = t2;
+                if (t2 > seed) {                                  // (z-buffer mode: the runner-up must itself beat the stored depth)
+                    ok = hit_test<FMT8>(a, sid_of(t2), px, py, h);
+                    if (ok) t = t2; else limit = t2;
                 }
             }
             unsigned long long fm = __ballot(limit != 0);
@@ -953,27 +994,31 @@ __device__ __forceinline__ void shade_tile_p64(const FillArgs& a, const uint32_t
                 const uint32_t fx = (uint32_t)__builtin_amdgcn_readlane((int)px, fl), fy = (uint32_t)__builtin_amdgcn_readlane((int)py, fl);
                 const unsigned long long lim = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(limit >> 32), fl) << 32) |
                                                (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)limit, fl);
+                const unsigned long long sd = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(seed >> 32), fl) << 32) |
+                                              (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)seed, fl);
                 unsigned long long best = 0;
                 for (uint32_t base = e0; base < e1; base += 64) {
                     unsigned long long cand = 0;
                     if (base + lane < e1) {
                         const uint32_t csid = a.pair_vals[base + lane];
-                        const unsigned long long P = ((unsigned long long)a.keys[csid] << 32) | csid;
-                        if (P < lim && P > best) {
-                            const uint4* rp = reinterpret_cast<const uint4*>(a.recs + csid);
-                            const uint32_t bbx = rp[1].w, bby = rp[2].x;
+                        const uint4* rp = reinterpret_cast<const uint4*>(a.recs + csid);
+                        const uint32_t bbx = rp[1].w, bby = rp[2].x;
+                        if (fx >= (bbx & 0xFFFF) && fx < (bbx >> 16) && fy >= (bby & 0xFFFF) && fy < (bby >> 16)) {
+                            unsigned long long P = ((unsigned long long)a.keys[csid] << 32) | csid;
                             Hit c;
-                            if (fx >= (bbx & 0xFFFF) && fx < (bbx >> 16) && fy >= (bby & 0xFFFF) && fy < (bby >> 16) && hit_test<FMT8>(a, csid, fx, fy, c)) cand = P;
+                            if (ZMODE) {
+                                if (hit_test<FMT8>(a, csid, fx, fy, c) && depth_prio(a, csid, c, P) && P < lim && P > sd) cand = P;
+                            } else if (P < lim && P > best && hit_test<FMT8>(a, csid, fx, fy, c)) cand = P;
                         }
                     }
                     for (int off = 32; off > 0; off >>= 1) { const unsigned long long o = __shfl_xor(cand, off); cand = o > cand ? o : cand; }
                     best = cand > best ? cand : best;
                 }
-                if ((int)lane == fl && best) ok = hit_test<FMT8>(a, (uint32_t)best, px, py, h);
+                if ((int)lane == fl && best) { ok = hit_test<FMT8>(a, sid_of(best), px, py, h); t = best; }
             }
         }
-        if (okA) a.fb[(size_t)pyA * W + px] = colour<FMT8>(a, hA, shading, px, pyA);
-        if (okB) a.fb[(size_t)pyB * W + px] = colour<FMT8>(a, hB, shading, px, pyB);
+        if (okA) { a.fb[(size_t)pyA * W + px] = colour<FMT8>(a, hA, shading, px, pyA); if (ZMODE) a.zbuf[(size_t)pyA * W + px] = zsort_val(~(uint32_t)(tA >> 32)); }
+        if (okB) { a.fb[(size_t)pyB * W + px] = colour<FMT8>(a, hB, shading, px, pyB); if (ZMODE) a.zbuf[(size_t)pyB * W + px] = zsort_val(~(uint32_t)(tB >> 32)); }
     }
 }
 
@@ -1201,7 +1246,37 @@ void launch_fill(hipStream_t s, const FillArgs& a, int n_cu, hipEvent_t after_co
         return;
     }
     const size_t lds_sort = LDS_TEX_OFFSET + LDS_SORT_CNT_BYTES + 2048;
-    if (a.fp.zmode) {
+    if (a.prio64) {   // sort-free: 64-bit tile buffers (2 x 36 KB) -> two workgroups per CU
+        const size_t lds64 = 4 * LDS_TILE_BYTES + LDS_MISC_BYTES + LDS_MARK_BYTES;
+        static bool attr_set64 = false;
+        if (!attr_set64) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<0, false, 512, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
+        if (!attr_set64) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<0, false, 512, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
+        attr_set64 = true;
+        if (a.fp.zmode) {       // z-buffer mode: same kernel, the priority's high word is the fragment depth
+            static bool az = false;
+            if (!az) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<0, false, 512, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<0, false, 512, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                az = true;
+            }
+            if (f8) hipLaunchKernelGGL((k_cover<0, false, 512, true, true, true>), dim3(min(ntiles, (uint32_t)n_cu * 2)), dim3(512), lds64, s, a);
+            else hipLaunchKernelGGL((k_cover<0, false, 512, true, false, true>), dim3(min(ntiles, (uint32_t)n_cu * 2)), dim3(512), lds64, s, a);
+            if (after_cover) (void)hipEventRecord(after_cover, s);
+            return;
+        }
+        static const int nt64 = getenv("B32_P64_NT") ? atoi(getenv("B32_P64_NT")) : 512;
+        if (!f8 && nt64 == 768) {
+            static bool ab = false; if (!ab) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<0, false, 768, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); ab = true; }
+            hipLaunchKernelGGL((k_cover<0, false, 768, false, false, true>), dim3(min(ntiles, (uint32_t)n_cu * 2)), dim3(768), lds64, s, a);
+        } else if (!f8 && nt64 == 1024) {
+            static bool ab = false; if (!ab) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<0, false, 1024, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); ab = true; }
+            hipLaunchKernelGGL((k_cover<0, false, 1024, false, false, true>), dim3(min(ntiles, (uint32_t)n_cu * 2)), dim3(1024), lds64, s, a);
+        } else
+        if (f8) hipLaunchKernelGGL((k_cover<0, false, 512, false, true, true>), dim3(min(ntiles, (uint32_t)n_cu * 2)), dim3(512), lds64, s, a);
+        else hipLaunchKernelGGL((k_cover<0, false, 512, false, false, true>), dim3(min(ntiles, (uint32_t)n_cu * 2)), dim3(512), lds64, s, a);
+        if (after_cover) (void)hipEventRecord(after_cover, s);
+        return;                                                  // coverage and shading are one kernel on this path
+    } else if (a.fp.zmode) {
         if (f8) hipLaunchKernelGGL((k_cover<0, true, 512, true, true>), dim3(min(ntiles, (uint32_t)n_cu * 3)), dim3(512), lds_sort, s, a);
         else hipLaunchKernelGGL((k_cover<0, true, 512, true, false>), dim3(min(ntiles, (uint32_t)n_cu * 3)), dim3(512), lds_sort, s, a);
     } else if (a.exact_coverage) {
@@ -1215,24 +1290,6 @@ void launch_fill(hipStream_t s, const FillArgs& a, int n_cu, hipEvent_t after_co
         } else {
             hipLaunchKernelGGL((k_cover<0, true, 512, false, false>), dim3(min(ntiles, (uint32_t)n_cu * 2)), dim3(512), LDS_TEX_OFFSET, s, a);
         }
-    } else if (a.prio64) {   // sort-free: 64-bit tile buffers (2 x 36 KB) -> two workgroups per CU
-        const size_t lds64 = 4 * LDS_TILE_BYTES + LDS_MISC_BYTES + LDS_MARK_BYTES;
-        static bool attr_set64 = false;
-        if (!attr_set64) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<0, false, 512, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
-        if (!attr_set64) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<0, false, 512, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
-        attr_set64 = true;
-        static const int nt64 = getenv("B32_P64_NT") ? atoi(getenv("B32_P64_NT")) : 512;
-        if (!f8 && nt64 == 768) {
-            static bool ab = false; if (!ab) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<0, false, 768, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); ab = true; }
-            hipLaunchKernelGGL((k_cover<0, false, 768, false, false, true>), dim3(min(ntiles, (uint32_t)n_cu * 2)), dim3(768), lds64, s, a);
-        } else if (!f8 && nt64 == 1024) {
-            static bool ab = false; if (!ab) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<0, false, 1024, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); ab = true; }
-            hipLaunchKernelGGL((k_cover<0, false, 1024, false, false, true>), dim3(min(ntiles, (uint32_t)n_cu * 2)), dim3(1024), lds64, s, a);
-        } else
-        if (f8) hipLaunchKernelGGL((k_cover<0, false, 512, false, true, true>), dim3(min(ntiles, (uint32_t)n_cu * 2)), dim3(512), lds64, s, a);
-        else hipLaunchKernelGGL((k_cover<0, false, 512, false, false, true>), dim3(min(ntiles, (uint32_t)n_cu * 2)), dim3(512), lds64, s, a);
-        if (after_cover) (void)hipEventRecord(after_cover, s);
-        return;                                                  // coverage and shading are one kernel on this path
     } else {    // CHEAP coverage never samples a texture: one kernel for both pixel formats
         hipLaunchKernelGGL((k_cover<0, false, 512, false, false>), dim3(min(ntiles, (uint32_t)n_cu * 3)), dim3(512), lds_sort, s, a);
     }

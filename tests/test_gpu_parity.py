@@ -425,3 +425,38 @@ def test_8bit_scene_rejects_15bit_draw(gpu_ctx):
     with pytest.raises(R.B32Error) as e:
         rs.render(sc.camera, sc.settings)
     assert e.value.code == b32.abi.B32_E_ARG
+
+
+@pytest.mark.parametrize("fmt8", [False, True])
+def test_zbuffer_fast_path(fast_ctx, oracle, fmt8):
+    """z-buffer mode without a transparent pass through the sort-free fused kernel (depth as the visibility priority):
+    two meshes drawn onto the same framebuffer (the second one is depth-tested against the first), Gouraud lighting,
+    a texture with skippable texels on faces that ignore / honour black_transparent, drawn as ragged bands."""
+    from bonnie32_amd import rasterizer as R
+    a = scenegen.make_scene("C3", n_tris=60_000, seed=5, variant="gouraud")
+    b = scenegen.make_scene("C3", n_tris=40_000, seed=6, variant="gouraud", bbox_px=2000.0)
+    for sc in (a, b):
+        sc.settings = b32.RasterSettings.game()
+        sc.settings.use_rgb555 = not fmt8
+        sc.faces["black_transparent"][::3] = 0
+    ofb = oracle.Framebuffer(a.width, a.height); ofb.clear(a.clear_color)
+    fb = R.Framebuffer(a.width, a.height, fast_ctx)
+    for band in ((0, 500), (500, 1301), (1301, 1920)):
+        fb.set_band(*band); fb.clear(a.clear_color)
+    for sc in (a, b):
+        if fmt8:
+            t8 = [b32.Texture.from_texture15(t) for t in sc.textures]
+            rc, etm = oracle.render_mesh(ofb, sc.vertices, sc.faces, t8, sc.camera, sc.settings)
+            rs = R.ResidentScene(fb, sc.vertices, sc.faces, textures8=t8)
+        else:
+            rc, etm = oracle.render_mesh_15(ofb, sc.vertices, sc.faces, sc.textures, sc.camera, sc.settings)
+            rs = R.ResidentScene(fb, sc.vertices, sc.faces, sc.textures)
+        assert rc == 0
+        for band in ((0, 500), (500, 1301), (1301, 1920)):
+            fb.set_band(*band)
+            tm = rs.render(sc.camera, sc.settings)
+            assert tm.triangles_drawn == etm.triangles_drawn
+    fb.set_band(0, a.height)
+    got = fb.pixels
+    assert np.array_equal(got, ofb.pixels), f"{int((got != ofb.pixels).sum())} bytes differ"
+    assert np.array_equal(fb.zbuffer.view(np.uint32), ofb.zbuffer.view(np.uint32))
