@@ -163,7 +163,7 @@ def main():
             tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(tpath):
                 try:
-                    traffic = json.load(open(tpath)).get(f"{args.config}:k_cover")
+                    traffic = json.load(open(tpath)).get(f"{args.config}:k_cover") if world == 1 else None   # measured for the whole frame on 1 GPU
                 except Exception:
                     traffic = None
             roofline = {"kernel": "k_cover", "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

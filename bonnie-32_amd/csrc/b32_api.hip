@@ -539,9 +539,10 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     const SortScratch sc{ c->block_hist, c->hist_blocks, c->digit_total };
     // z-buffer frames without a transparent pass take the sort-free fused path too (depth is the priority); otherwise z-buffer
     // mode applies depth + skip rule per fragment (EXACT coverage)
-    const bool spans_ok = ntiles > 0 && ntiles <= 4096 && (c->nf + 2047) / 2048 <= c->hist_blocks;   // launch_bin_spans applies
-    const bool zfast = spans_ok && fp.zmode && !c->count_fragments && c->cheap_ok && !c->may_blend && !c->no_prio64 && !fp.ortho && c->nf > 0 &&
-                       !(c->fmt8 && c->blend8);
+    // (a transparent pass rides along: its entries are split off at binning time and sorted per tile by k_blend)
+    const bool with_class = c->may_blend && !c->fmt8;
+    const bool spans_ok = !c->no_prio64 && c->local_sort_ok && bin_spans_applicable(fp, sc, with_class);
+    const bool zfast = spans_ok && fp.zmode && !c->count_fragments && c->cheap_ok && !fp.ortho && !(c->fmt8 && c->blend8) && !fp.xray;
     const bool exact_cov = c->count_fragments || !c->cheap_ok || (fp.zmode && !zfast);
     // the fast path reads the class from bit 31 of the depth key and has no ordered opaque walk: not for ortho / x-ray frames
     // ordered walk of whole tile lists instead of the overwrite pass: x-ray (RGB555), or the 8-bit path with blending texels / editor alpha
@@ -549,12 +550,13 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     const bool local_sort = !exact_cov && c->local_sort_ok && !fp.ortho && !ordered_all;
     c->last_local_sort = local_sort;
     c->last_exact = ordered_all ? true : (exact_cov && !fp.zmode);          // the ordered walk counts every store it performs
-    const bool want_prio64 = (local_sort || zfast) && !c->may_blend && !c->no_prio64 && c->nf > 0;   // no transparent pass -> no tile list order needed
+    const bool want_prio64 = (local_sort || zfast) && spans_ok;     // max-of-priorities coverage: no tile list order needed
     int cur = 0;
     bool prio64 = false;
     if (want_prio64) {
         if (prof_all) HIPCHK(c, hipEventRecord(ev[2], s));
-        prio64 = launch_bin_spans(s, fp, c->spans, c->partials, c->d_ctrl, sc, (uint32_t)c->cap_pairs, c->ranges, c->pvals[0]);
+        prio64 = launch_bin_spans(s, fp, c->spans, with_class ? c->keys[0] : nullptr, c->partials, c->d_ctrl, sc, (uint32_t)c->cap_pairs, c->ranges,
+                                  c->tile_mid, BLEND_SORT_CAP, c->pvals[0]);
     }
     if (!prio64) {
     if (local_sort) {
@@ -612,6 +614,7 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     fa.texels32 = c->d_texels32;
     fa.ordered_all = ordered_all ? 1u : 0u;
     fa.prio64 = prio64 ? 1u : 0u;
+    fa.gather_blend = (prio64 && with_class) ? 1u : 0u;
     if (c->fmt8) fa.fp.xray = 0;                        // render_mesh: x-ray only changes culling; its stores keep their own depth tests
     launch_fill(s, fa, c->n_cu, prof_fill ? ev[4] : nullptr);
     if (fp.wire_collect && c->nf) {

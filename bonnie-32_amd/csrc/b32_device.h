@@ -219,9 +219,12 @@ struct WireArgs {
 };
 void launch_wire(hipStream_t s, const WireArgs& a, bool back, bool front);
 // Sort-free fast path: tile lists (unordered) by a counting sort straight from k_setup's spans; false = not applicable (too many
-// tiles for the LDS histogram), the caller takes the keyed radix path.
-bool launch_bin_spans(hipStream_t s, const FrameParams& fp, const uint32_t* spans, const uint32_t* partials, Ctrl* ctrl, const SortScratch& sc,
-                      uint32_t pair_cap, uint32_t* ranges, uint32_t* pair_vals);
+// tiles for the LDS histogram), the caller takes the keyed radix path.  With `keys` the lists are split by class
+// ([opaque..., transparent...], boundary in tile_mid) and a transparent part longer than blend_cap raises need_global_sort.
+constexpr uint32_t BLEND_SORT_CAP = 2048;       // longest transparent tile list k_blend sorts in LDS (rank sort on 64-bit priorities)
+bool bin_spans_applicable(const FrameParams& fp, const SortScratch& sc, bool with_class);
+bool launch_bin_spans(hipStream_t s, const FrameParams& fp, const uint32_t* spans, const uint32_t* keys, const uint32_t* partials, Ctrl* ctrl,
+                      const SortScratch& sc, uint32_t pair_cap, uint32_t* ranges, uint32_t* tile_mid, uint32_t blend_cap, uint32_t* pair_vals);
 void launch_tile_ranges(hipStream_t s, const uint32_t* pair_keys, const Ctrl* ctrl, uint32_t pair_cap, uint32_t* ranges, uint32_t n_keys);
 
 struct FillArgs {
@@ -247,6 +250,7 @@ struct FillArgs {
     uint32_t skip_solid;        // wireframe_overlay: surfaces are counted but not drawn (render.rs:2550)
     const uint32_t* texels32;   // 8-bit-colour path: pooled Color texels, r | g<<8 | b<<16 | blend<<24 (TexDesc.offset indexes this pool)
     uint32_t ordered_all;       // 1: every surface may blend -> no overwrite pass, k_blend walks the whole tile list in order
+    uint32_t gather_blend;      // 1 (with prio64): k_blend sorts the transparent part of each (unordered) tile list itself
     uint32_t prio64;            // 1: sort-free coverage -- visibility is a 64-bit max of (painter's key << 32 | face id); `vis` holds
                                 //    two words per pixel: winner face id + 1, runner-up face id + 1 (0 = none)
 };

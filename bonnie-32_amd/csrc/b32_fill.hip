@@ -702,6 +702,7 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a) {
     uint32_t* sort_cnt = reinterpret_cast<uint32_t*>(smem + LDS_TEX_OFFSET);        // local sort only exists without an LDS texture
 
     if (a.ctrl->abort) return;
+    if (P64 && a.ctrl->need_global_sort) return;       // a transparent tile list is too long for k_blend's LDS sort: the host redraws
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));   // wave-uniform => SGPR control flow
     const FrameParams& fp = a.fp;
@@ -725,8 +726,8 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a) {
         if (tile >= ntiles) break;
         if (tid == 0) next_tile = atomicAdd(&a.ctrl->tile_cursor, 1u);    // prefetch the next tile index; consumed at the loop top
         uint32_t e0, e1;
-        if (P64) {                               // lists in any order, keyed by tile only; the whole list is the opaque pass
-            e0 = a.ranges[tile]; e1 = a.ranges[tile + 1];
+        if (P64) {                               // lists in any order, keyed by tile only; [e0, mid) is the opaque pass
+            e0 = a.ranges[tile]; e1 = a.gather_blend ? a.tile_mid[tile] : a.ranges[tile + 1];
         } else if (TEXMODE == 0 && a.local_sort) {      // lists arrive in face order, keyed by tile only: painter's order per tile, in LDS
             e0 = a.ranges[tile];
             const uint32_t e2 = a.ranges[tile + 1];
@@ -1132,12 +1133,13 @@ __device__ __forceinline__ bool blend_fragment(const FillArgs& a, const Tri& tr,
     return true;
 }
 
-template <int NT, bool FMT8>
+template <int NT, bool FMT8, bool GATHER = false>
 __global__ __launch_bounds__(NT) void k_blend(FillArgs a) {
     constexpr int NW = NT / 64;
     __shared__ uint32_t tilebuf[TILE_H * TILE_STRIDE];
     __shared__ float tilez[TILE_H * TILE_STRIDE];      // z-buffer mode: depth of the tile (read only: the transparent pass never writes z)
     __shared__ unsigned long long wf[NW];
+    __shared__ unsigned long long gprio[GATHER ? BLEND_SORT_CAP : 1];   // GATHER: painter's priorities of the tile's transparent entries
     if (a.ctrl->abort || a.ctrl->need_global_sort) return;
     const FrameParams& fp = a.fp;
     const uint32_t tile = blockIdx.x;
@@ -1147,6 +1149,20 @@ __global__ __launch_bounds__(NT) void k_blend(FillArgs a) {
     const uint32_t e1 = a.tile_keys_only ? a.tile_mid[tile] : a.ranges[2 * tile + (a.ordered_all ? 0 : 1)];
     const uint32_t e2 = a.tile_keys_only ? a.ranges[tile + 1] : a.ranges[2 * tile + 2];
     if (e1 == e2) return;
+    if (GATHER) {
+        // sort-free binning left the transparent entries [e1, e2) in arbitrary order: put them in painter's order (descending depth,
+        // ties in face order, render.rs:2527-2532) by ranking the 64-bit priorities (key << 32 | face id) -- all distinct -- in LDS
+        const uint32_t n = e2 - e1;                    // <= BLEND_SORT_CAP (k_place_spans raised need_global_sort otherwise)
+        for (uint32_t i = threadIdx.x; i < n; i += NT) { const uint32_t sid = a.pair_vals[e1 + i]; gprio[i] = ((unsigned long long)a.keys[sid] << 32) | sid; }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n; i += NT) {
+            const unsigned long long P = gprio[i];
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < n; ++j) rank += gprio[j] < P ? 1u : 0u;
+            a.pair_vals[e1 + rank] = (uint32_t)P;
+        }
+        __syncthreads();
+    }
     const int zmode = (fp.zmode && !xray) ? 1 : 0;               // x-ray skips the depth test (render.rs:1553)
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
@@ -1173,12 +1189,17 @@ __global__ __launch_bounds__(NT) void k_blend(FillArgs a) {
         Batch b;
         load_batch<0>(b, a, e1 + cs + lane, lane < cnt, none, true);
         const uint32_t my_sid = lane < cnt ? a.pair_vals[e1 + cs + lane] : 0;
-        for (uint32_t t = 0; t < cnt; ++t) {
+        // rows of this wave that each surface of the batch touches: most surfaces touch none of them, and the wave skips
+        // those without broadcasting their records (bit t of `mine` = surface t reaches rows [wy0, wy1) and columns of the tile)
+        const bool touches = lane < cnt && max(b.q2.x & 0xFFFF, wy0) < min(b.q2.x >> 16, wy1) && max(b.q1.w & 0xFFFF, x_lo) < min(b.q1.w >> 16, x_hi) &&
+                             (b.q3.w >> F_ALPHA_SHIFT) != 0;                     // editor_alpha == 0 draws nothing, render.rs:1664-1669
+        unsigned long long mine = __ballot(touches);
+        while (mine) {
+            const uint32_t t = (uint32_t)__builtin_ctzll(mine);
+            mine &= mine - 1;
             const Tri tr = tri_from_batch(b, (int)t, true);
             const uint32_t cx0 = max(tr.min_x, x_lo), cx1 = min(tr.max_x, x_hi);
             const uint32_t cy0 = max(tr.min_y, wy0), cy1 = min(tr.max_y, wy1);
-            if (cx0 >= cx1 || cy0 >= cy1) continue;
-            if ((tr.flags >> F_ALPHA_SHIFT) == 0) continue;                      // editor_alpha == 0, render.rs:1664-1669
             const uint32_t vc1 = bcu(b.q4.x, (int)t), vc2 = bcu(b.q4.y, (int)t), vc3 = bcu(b.q4.z, (int)t);
             const uint32_t sid = bcu(my_sid, (int)t);
             float shv[9];
@@ -1262,6 +1283,7 @@ void launch_fill(hipStream_t s, const FillArgs& a, int n_cu, hipEvent_t after_co
             if (f8) hipLaunchKernelGGL((k_cover<0, false, 512, true, true, true>), dim3(min(ntiles, (uint32_t)n_cu * 2)), dim3(512), lds64, s, a);
             else hipLaunchKernelGGL((k_cover<0, false, 512, true, false, true>), dim3(min(ntiles, (uint32_t)n_cu * 2)), dim3(512), lds64, s, a);
             if (after_cover) (void)hipEventRecord(after_cover, s);
+            if (a.gather_blend) hipLaunchKernelGGL((k_blend<1024, false, true>), dim3(ntiles), dim3(1024), 0, s, a);
             return;
         }
         static const int nt64 = getenv("B32_P64_NT") ? atoi(getenv("B32_P64_NT")) : 512;
@@ -1275,6 +1297,7 @@ void launch_fill(hipStream_t s, const FillArgs& a, int n_cu, hipEvent_t after_co
         if (f8) hipLaunchKernelGGL((k_cover<0, false, 512, false, true, true>), dim3(min(ntiles, (uint32_t)n_cu * 2)), dim3(512), lds64, s, a);
         else hipLaunchKernelGGL((k_cover<0, false, 512, false, false, true>), dim3(min(ntiles, (uint32_t)n_cu * 2)), dim3(512), lds64, s, a);
         if (after_cover) (void)hipEventRecord(after_cover, s);
+        if (a.gather_blend) hipLaunchKernelGGL((k_blend<1024, false, true>), dim3(ntiles), dim3(1024), 0, s, a);
         return;                                                  // coverage and shading are one kernel on this path
     } else if (a.fp.zmode) {
         if (f8) hipLaunchKernelGGL((k_cover<0, true, 512, true, true>), dim3(min(ntiles, (uint32_t)n_cu * 3)), dim3(512), lds_sort, s, a);

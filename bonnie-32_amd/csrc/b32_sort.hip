@@ -189,41 +189,55 @@ __global__ __launch_bounds__(SORT_THREADS) void k_scatter(const uint32_t* __rest
 // keys and never ranked: k_count_spans histograms the tiles of 2048 faces in LDS (LDS atomics), k_scan_rows scans every tile's
 // row across the blocks, k_place_spans re-reads the spans and drops each surface id at base[tile]++ (LDS atomic cursor).
 constexpr uint32_t SPAN_BLOCK = 2048;           // faces per workgroup
-constexpr uint32_t SPAN_MAX_TILES = 4096;       // LDS histogram capacity
+constexpr uint32_t SPAN_MAX_TILES = 4096;       // LDS histogram capacity (rows: tiles, or 2 x tiles with the class split)
 
+// With `keys` (scenes that can have a transparent pass) every tile gets two rows: opaque-class entries and transparent-class
+// entries (bit 31 of k_setup's key, render.rs:2522-2523); k_place_spans lays a tile's list out as [opaque..., transparent...] and
+// publishes the boundary in tile_mid, so k_cover takes the first part unordered and k_blend sorts only the second.
 __global__ __launch_bounds__(256) void k_count_spans(uint32_t nf, uint32_t ntiles, uint32_t tiles_x, const uint32_t* __restrict__ spans,
-                                                     uint32_t* __restrict__ block_hist, uint32_t max_blocks) {
+                                                     const uint32_t* __restrict__ keys, uint32_t* __restrict__ block_hist, uint32_t max_blocks) {
     __shared__ uint32_t hist[SPAN_MAX_TILES];
-    for (uint32_t t = threadIdx.x; t < ntiles; t += 256) hist[t] = 0;
+    const uint32_t nrows = keys ? 2 * ntiles : ntiles;
+    for (uint32_t t = threadIdx.x; t < nrows; t += 256) hist[t] = 0;
     __syncthreads();
     const uint32_t f0 = blockIdx.x * SPAN_BLOCK;
     for (uint32_t i = threadIdx.x; i < SPAN_BLOCK; i += 256) {
         const uint32_t f = f0 + i;
         const uint32_t span = f < nf ? spans[f] : 0xFFFFFFFFu;
         if (span == 0xFFFFFFFFu) continue;
+        const uint32_t row0 = (keys && (keys[f] >> 31)) ? ntiles : 0u;
         const uint32_t tx0 = span & 0xFF, tx1 = (span >> 8) & 0xFF, ty0 = (span >> 16) & 0xFF, ty1 = span >> 24;
         for (uint32_t ty = ty0; ty <= ty1; ++ty)
-            for (uint32_t tx = tx0; tx <= tx1; ++tx) atomicAdd(&hist[ty * tiles_x + tx], 1u);
+            for (uint32_t tx = tx0; tx <= tx1; ++tx) atomicAdd(&hist[row0 + ty * tiles_x + tx], 1u);
     }
     __syncthreads();
-    for (uint32_t t = threadIdx.x; t < ntiles; t += 256) block_hist[(size_t)t * max_blocks + blockIdx.x] = hist[t];
+    for (uint32_t t = threadIdx.x; t < nrows; t += 256) block_hist[(size_t)t * max_blocks + blockIdx.x] = hist[t];
 }
 
 __global__ __launch_bounds__(256) void k_place_spans(uint32_t nf, uint32_t ntiles, uint32_t tiles_x, const uint32_t* __restrict__ spans,
-                                                     const uint32_t* __restrict__ block_hist, uint32_t max_blocks,
+                                                     const uint32_t* __restrict__ keys, const uint32_t* __restrict__ block_hist, uint32_t max_blocks,
                                                      const uint32_t* __restrict__ digit_total, Ctrl* __restrict__ ctrl, uint32_t pair_cap,
-                                                     uint32_t* __restrict__ ranges, uint32_t* __restrict__ pair_vals) {
+                                                     uint32_t* __restrict__ ranges, uint32_t* __restrict__ tile_mid, uint32_t blend_cap,
+                                                     uint32_t* __restrict__ pair_vals) {
     __shared__ uint32_t base[SPAN_MAX_TILES];
-    __shared__ uint32_t dws[4];
+    __shared__ uint32_t dws[4], dmx[4];
     __shared__ uint32_t total_s;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // tile bases: exclusive scan of the row totals; thread t owns tiles [t*per, t*per + per)
     const uint32_t per = (ntiles + 255) / 256;                           // <= 16
-    uint32_t tot[16], sum = 0;
-    for (uint32_t j = 0; j < per; ++j) { const uint32_t t = threadIdx.x * per + j; tot[j] = t < ntiles ? digit_total[t] : 0u; sum += tot[j]; }
+    uint32_t tot[16], ttr[16], sum = 0, mx = 0;
+    for (uint32_t j = 0; j < per; ++j) {
+        const uint32_t t = threadIdx.x * per + j;
+        tot[j] = t < ntiles ? digit_total[t] : 0u;
+        ttr[j] = (keys && t < ntiles) ? digit_total[ntiles + t] : 0u;
+        sum += tot[j] + ttr[j];
+        mx = max(mx, ttr[j]);
+    }
     uint32_t inc = sum;
     for (int off = 1; off < 64; off <<= 1) { const uint32_t v = __shfl_up(inc, off); if (lane >= (uint32_t)off) inc += v; }
+    for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
     if (lane == 63) dws[wave] = inc;
+    if (lane == 0) dmx[wave] = mx;
     __syncthreads();
     uint32_t run = inc - sum;
     for (uint32_t w = 0; w < wave; ++w) run += dws[w];
@@ -232,39 +246,50 @@ __global__ __launch_bounds__(256) void k_place_spans(uint32_t nf, uint32_t ntile
         const uint32_t t = threadIdx.x * per + j;
         if (t < ntiles) {
             base[t] = run + block_hist[(size_t)t * max_blocks + blockIdx.x];
-            if (blockIdx.x == 0) ranges[t] = run;                        // list range of tile t = [ranges[t], ranges[t+1])
+            if (keys) base[ntiles + t] = run + tot[j] + block_hist[(size_t)(ntiles + t) * max_blocks + blockIdx.x];
+            if (blockIdx.x == 0) { ranges[t] = run; if (tile_mid) tile_mid[t] = run + tot[j]; }   // list of tile t = [ranges[t], ranges[t+1])
         }
-        run += tot[j];
+        run += tot[j] + ttr[j];
     }
     __syncthreads();
     const uint32_t total = total_s;
+    const uint32_t longest_tr = max(max(dmx[0], dmx[1]), max(dmx[2], dmx[3]));
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         ranges[ntiles] = total;
         if (total > pair_cap) { ctrl->pairs_overflow = total; ctrl->abort = 1; ctrl->n_pairs = 0; }
         else ctrl->n_pairs = total;
+        if (longest_tr > blend_cap) ctrl->need_global_sort = 1;          // k_blend's LDS sort cannot hold that list: nothing is drawn, the host redraws
     }
-    if (total > pair_cap || ctrl->abort) return;
+    if (total > pair_cap || longest_tr > blend_cap || ctrl->abort) return;
     const uint32_t f0 = blockIdx.x * SPAN_BLOCK;
     for (uint32_t i = threadIdx.x; i < SPAN_BLOCK; i += 256) {
         const uint32_t f = f0 + i;
         const uint32_t span = f < nf ? spans[f] : 0xFFFFFFFFu;
         if (span == 0xFFFFFFFFu) continue;
+        const uint32_t row0 = (keys && (keys[f] >> 31)) ? ntiles : 0u;
         const uint32_t tx0 = span & 0xFF, tx1 = (span >> 8) & 0xFF, ty0 = (span >> 16) & 0xFF, ty1 = span >> 24;
         for (uint32_t ty = ty0; ty <= ty1; ++ty)
-            for (uint32_t tx = tx0; tx <= tx1; ++tx) pair_vals[atomicAdd(&base[ty * tiles_x + tx], 1u)] = f;
+            for (uint32_t tx = tx0; tx <= tx1; ++tx) pair_vals[atomicAdd(&base[row0 + ty * tiles_x + tx], 1u)] = f;
     }
 }
 
-bool launch_bin_spans(hipStream_t s, const FrameParams& fp, const uint32_t* spans, const uint32_t* partials, Ctrl* ctrl, const SortScratch& sc,
-                      uint32_t pair_cap, uint32_t* ranges, uint32_t* pair_vals) {
+bool bin_spans_applicable(const FrameParams& fp, const SortScratch& sc, bool with_class) {
     const uint32_t ntiles = fp.tiles_x * fp.tiles_y;
     const uint32_t nblocks = (fp.nf + SPAN_BLOCK - 1) / SPAN_BLOCK;
-    if (ntiles == 0 || ntiles > SPAN_MAX_TILES || nblocks > sc.max_blocks || fp.nf == 0) return false;
-    hipLaunchKernelGGL(k_count_spans, dim3(nblocks), dim3(256), 0, s, fp.nf, ntiles, fp.tiles_x, spans, sc.block_hist, sc.max_blocks);
-    hipLaunchKernelGGL(k_scan_rows, dim3(ntiles), dim3(256), 0, s, sc.block_hist, sc.max_blocks, nblocks, sc.digit_total,
+    return ntiles > 0 && (with_class ? 2 : 1) * ntiles <= SPAN_MAX_TILES && nblocks <= sc.max_blocks && fp.nf > 0;
+}
+
+bool launch_bin_spans(hipStream_t s, const FrameParams& fp, const uint32_t* spans, const uint32_t* keys, const uint32_t* partials, Ctrl* ctrl,
+                      const SortScratch& sc, uint32_t pair_cap, uint32_t* ranges, uint32_t* tile_mid, uint32_t blend_cap, uint32_t* pair_vals) {
+    if (!bin_spans_applicable(fp, sc, keys != nullptr)) return false;
+    const uint32_t ntiles = fp.tiles_x * fp.tiles_y;
+    const uint32_t nblocks = (fp.nf + SPAN_BLOCK - 1) / SPAN_BLOCK;
+    const uint32_t nrows = keys ? 2 * ntiles : ntiles;
+    hipLaunchKernelGGL(k_count_spans, dim3(nblocks), dim3(256), 0, s, fp.nf, ntiles, fp.tiles_x, spans, keys, sc.block_hist, sc.max_blocks);
+    hipLaunchKernelGGL(k_scan_rows, dim3(nrows), dim3(256), 0, s, sc.block_hist, sc.max_blocks, nblocks, sc.digit_total,
                        ctrl, partials, (fp.nf + 255) / 256, (const uint32_t*)nullptr);
-    hipLaunchKernelGGL(k_place_spans, dim3(nblocks), dim3(256), 0, s, fp.nf, ntiles, fp.tiles_x, spans, sc.block_hist, sc.max_blocks,
-                       sc.digit_total, ctrl, pair_cap, ranges, pair_vals);
+    hipLaunchKernelGGL(k_place_spans, dim3(nblocks), dim3(256), 0, s, fp.nf, ntiles, fp.tiles_x, spans, keys, sc.block_hist, sc.max_blocks,
+                       sc.digit_total, ctrl, pair_cap, ranges, keys ? tile_mid : nullptr, blend_cap, pair_vals);
     return true;
 }
 

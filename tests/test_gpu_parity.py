@@ -460,3 +460,28 @@ def test_zbuffer_fast_path(fast_ctx, oracle, fmt8):
     got = fb.pixels
     assert np.array_equal(got, ofb.pixels), f"{int((got != ofb.pixels).sum())} bytes differ"
     assert np.array_equal(fb.zbuffer.view(np.uint32), ofb.zbuffer.view(np.uint32))
+
+
+def test_fast_path_transparent_lists(fast_ctx, oracle):
+    """Scenes with a transparent pass on the sort-free path: binning splits each tile list by class and k_blend ranks the
+    transparent part by 64-bit painter's priority in LDS (ties in depth -> face order).  The second scene has far more
+    transparent entries per tile than that sort holds, so the frame is redrawn through the general path (nothing of the
+    aborted attempt may have touched the framebuffer)."""
+    from bonnie32_amd import rasterizer as R
+    sc = scenegen.make_scene("C5", n_tris=30_000, variant="blend", seed=77)          # 64 depth levels: massive key ties
+    sc.faces["blend_mode"][::3] = b32.abi.ADD
+    exp, etm, d = cpu_render(oracle, sc)
+    for z in (False, True):
+        sc.settings.use_zbuffer = z
+        ofb = oracle.Framebuffer(sc.width, sc.height); ofb.clear(sc.clear_color)
+        rc, etm = oracle.render_mesh_15(ofb, sc.vertices, sc.faces, sc.textures, sc.camera, sc.settings)
+        got, tm = gpu_render(fast_ctx, sc, resident=True)
+        assert np.array_equal(got, ofb.pixels), f"{int((got != ofb.pixels).sum())} bytes differ (zbuffer={z})"
+        assert tm.triangles_drawn == etm.triangles_drawn
+    big = scenegen.make_scene("C2", n_tris=60_000, width=128, height=64, bbox_px=40.0, seed=78)
+    big.faces["blend_mode"][:] = b32.abi.AVERAGE
+    big.faces["blend_mode"][::2] = b32.abi.SUBTRACT
+    exp, etm, d = cpu_render(oracle, big)
+    got, tm = gpu_render(fast_ctx, big, resident=True)
+    assert np.array_equal(got, exp), f"{int((got != exp).sum())} bytes differ"
+    assert tm.triangles_drawn == etm.triangles_drawn > 2 * 2048 * 2

@@ -18,12 +18,18 @@ MODES = [
     ("z-buffer, no lights", b32.RasterSettings(shading=0, lights=[], backface_wireframe=False), False),
     ("RasterSettings::game()", b32.RasterSettings.game(), False),
     ("RasterSettings::default()", b32.RasterSettings(), False),
+    ("painter, 10 % faces in the transparent pass", b32.RasterSettings.benchmark(), "blend"),
+    ("game(), 10 % faces in the transparent pass", b32.RasterSettings(shading=0, lights=[], backface_wireframe=False), "blend"),
     ("8-bit painter", b32.RasterSettings(use_zbuffer=False, shading=0, lights=[], backface_wireframe=False, use_rgb555=False), True),
     ("8-bit game()", b32.RasterSettings(backface_wireframe=False, use_rgb555=False), True),
 ]
+blend = scenegen.make_scene("C3", n_tris=N, variant="blend")
 print("| settings | GPU ms/frame | Mtri/s | CPU oracle ms | bit-exact |")
 print("|---|---|---|---|---|")
 for name, st, f8 in MODES:
+    scene = base
+    if f8 == "blend":
+        scene, f8 = blend, False
     ofb = O.Framebuffer(base.width, base.height); ofb.clear(base.clear_color)
     t0 = time.perf_counter()
     skip_cpu = st.backface_cull and st.backface_wireframe and N > 100_000      # the reference's O(n^2) edge de-duplication: minutes on the CPU
@@ -32,11 +38,11 @@ for name, st, f8 in MODES:
     elif f8:
         rc, otm = O.render_mesh(ofb, base.vertices, base.faces, tex8, base.camera, st)
     else:
-        rc, otm = O.render_mesh_15(ofb, base.vertices, base.faces, base.textures, base.camera, st)
+        rc, otm = O.render_mesh_15(ofb, scene.vertices, scene.faces, scene.textures, scene.camera, st)
     tcpu = time.perf_counter() - t0
     assert rc == 0
     fb = R.Framebuffer(base.width, base.height, ctx)
-    rs = R.ResidentScene(fb, base.vertices, base.faces, textures8=tex8) if f8 else R.ResidentScene(fb, base.vertices, base.faces, base.textures)
+    rs = R.ResidentScene(fb, base.vertices, base.faces, textures8=tex8) if f8 else R.ResidentScene(fb, scene.vertices, scene.faces, scene.textures)
     fb.clear(base.clear_color); rs.render(base.camera, st)
     ok = skip_cpu or (np.array_equal(fb.pixels, ofb.pixels) and (not st.use_zbuffer or np.array_equal(fb.zbuffer.view(np.uint32), ofb.zbuffer.view(np.uint32))))
     for i in range(3):
