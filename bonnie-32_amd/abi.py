@@ -39,6 +39,9 @@ class B32Texture(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("blend_mode", C.c_uint32), ("_pad", C.c_uint32), ("pixels", C.c_void_p)]
 
 
+SKY_VERTEX_DTYPE = np.dtype([("pos", np.float32, 3), ("r", np.uint8), ("g", np.uint8), ("b", np.uint8), ("blend", np.uint8)])
+
+
 class B32IndexedTexture(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("blend_mode", C.c_uint32), ("clut_len", C.c_uint32),
                 ("indices", C.c_void_p), ("clut", C.c_void_p)]
@@ -99,6 +102,11 @@ SYMBOLS = [
     ("b32_render_scene_15", C.c_int, [_P, _P, _P, _P, _P]),
     ("b32_render_scene_15_async", C.c_int, [_P, _P, _P, _P]),
     ("b32_frame_finish", C.c_int, [_P, _P]),
+    ("b32_fb_clear_gradient", C.c_int, [_P] + [C.c_uint8] * 8),
+    ("b32_fb_clear_transparent", C.c_int, [_P]),
+    ("b32_render_skybox_mesh", C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint32, _P]),
+    ("b32_draw_star_diamonds", C.c_int, [_P, _P, _P, _P, C.c_uint32, C.c_float]),
+    ("b32_present_nearest", C.c_int, [_P, C.c_uint32, C.c_uint32, _P]),
     ("b32_render_mesh", C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint32, _P, C.c_uint32, _P, _P, _P]),
     ("b32_scene_upload_rgba", C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint32, _P, C.c_uint32]),
     ("b32_render_scene", C.c_int, [_P, _P, _P, _P]),

@@ -111,6 +111,16 @@ static int ensure_plain(b32_ctx* c, T*& p, size_t count) {   // exact-size (re)a
     return B32_OK;
 }
 
+// scratch upload helper for the small per-frame inputs of the sky / star / present calls
+template <typename T>
+static int to_device(b32_ctx* c, const T* host, size_t n, T** dev) {
+    *dev = nullptr;
+    if (!n) return B32_OK;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(dev), n * sizeof(T)));
+    HIPCHK(c, hipMemcpyAsync(*dev, host, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    return B32_OK;
+}
+
 extern "C" {
 
 const char* b32_strerror(int code) {
@@ -232,6 +242,57 @@ int b32_fb_clear(b32_ctx* c, uint8_t r, uint8_t g, uint8_t b, uint8_t blend) {
     if (c->zbuf && c->zbuf_valid && (size_t)c->width * c->height <= c->cap_zbuf)        // self.zbuffer[i] = f32::MAX, render.rs:43
         launch_clear(c->stream, reinterpret_cast<uint32_t*>(c->zbuf) + (size_t)c->band_y0 * c->width, (size_t)c->width * (c->band_y1 - c->band_y0), 0x7F7FFFFFu);
     HIPCHK(c, hipGetLastError());
+    return B32_OK;
+}
+int b32_fb_clear_gradient(b32_ctx* c, uint8_t r0, uint8_t g0, uint8_t b0, uint8_t blend0, uint8_t r1, uint8_t g1, uint8_t b1, uint8_t blend1) {
+    if (!c || !c->fb) return B32_E_ARG;
+    (void)hipSetDevice(c->device);
+    const bool z = c->zbuf && c->zbuf_valid && (size_t)c->width * c->height <= c->cap_zbuf;
+    launch_clear_gradient(c->stream, c->fb, z ? c->zbuf : nullptr, c->width, c->height, c->band_y0, c->band_y1,
+                          r0 | (g0 << 8) | (b0 << 16) | ((uint32_t)blend0 << 24), r1 | (g1 << 8) | (b1 << 16) | ((uint32_t)blend1 << 24));
+    HIPCHK(c, hipGetLastError());
+    return B32_OK;
+}
+int b32_fb_clear_transparent(b32_ctx* c) { return b32_fb_clear(c, 0, 0, 0, B32_BLEND_ERASE); }    // [0,0,0,0] + zbuffer = f32::MAX
+
+int b32_render_skybox_mesh(b32_ctx* c, const B32SkyVertex* v, uint32_t nv, const uint32_t* faces, uint32_t nf, const B32Camera* cam) {
+    if (!c || !c->fb || !cam || (nv && !v) || (nf && !faces)) return B32_E_ARG;
+    if (!nv || !nf) return B32_OK;
+    (void)hipSetDevice(c->device);
+    for (uint32_t i = 0; i < 3 * nf; ++i) if (faces[i] >= nv) return B32_E_INDEX;          // projected[face[k]] index panic
+    B32SkyVertex* dv = nullptr; uint32_t* df = nullptr; float2* dp = nullptr;
+    int rc;
+    if ((rc = to_device(c, v, (size_t)nv, &dv))) return rc;
+    if ((rc = to_device(c, faces, (size_t)nf * 3, &df))) return rc;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&dp), (size_t)nv * sizeof(float2)));
+    launch_sky(c->stream, dv, nv, df, nf, *cam, dp, c->fb, c->width, c->height, c->band_y0, c->band_y1);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(dv); (void)hipFree(df); (void)hipFree(dp);
+    return B32_OK;
+}
+int b32_draw_star_diamonds(b32_ctx* c, const int32_t* cx, const int32_t* cy, const uint8_t* rgb, uint32_t n, float size) {
+    if (!c || !c->fb || (n && (!cx || !cy || !rgb))) return B32_E_ARG;
+    if (!n) return B32_OK;
+    (void)hipSetDevice(c->device);
+    int32_t *dx = nullptr, *dy = nullptr; uint8_t* dc = nullptr;
+    int rc;
+    if ((rc = to_device(c, cx, (size_t)n, &dx))) return rc;
+    if ((rc = to_device(c, cy, (size_t)n, &dy))) return rc;
+    if ((rc = to_device(c, rgb, (size_t)n * 3, &dc))) return rc;
+    launch_stars(c->stream, dx, dy, dc, n, size, c->fb, c->width, c->height, c->band_y0, c->band_y1);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dc);
+    return B32_OK;
+}
+int b32_present_nearest(b32_ctx* c, uint32_t dw, uint32_t dh, uint8_t* out) {
+    if (!c || !c->fb || !out || !dw || !dh || dw > 32768 || dh > 32768) return B32_E_ARG;
+    (void)hipSetDevice(c->device);
+    uint32_t* dd = nullptr;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&dd), (size_t)dw * dh * 4));
+    launch_upscale_nearest(c->stream, c->fb, c->width, c->height, dd, dw, dh);
+    HIPCHK(c, hipMemcpyAsync(out, dd, (size_t)dw * dh * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(dd);
     return B32_OK;
 }
 int b32_fb_upload(b32_ctx* c, const uint8_t* rgba) {

@@ -227,6 +227,13 @@ bool launch_bin_spans(hipStream_t s, const FrameParams& fp, const uint32_t* span
                       const SortScratch& sc, uint32_t pair_cap, uint32_t* ranges, uint32_t* tile_mid, uint32_t blend_cap, uint32_t* pair_vals);
 void launch_tile_ranges(hipStream_t s, const uint32_t* pair_keys, const Ctrl* ctrl, uint32_t pair_cap, uint32_t* ranges, uint32_t n_keys);
 
+void launch_clear_gradient(hipStream_t s, uint32_t* fb, float* zbuf, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, uint32_t top, uint32_t bottom);
+void launch_sky(hipStream_t s, const B32SkyVertex* v, uint32_t nv, const uint32_t* faces, uint32_t nf, const B32Camera& cam, float2* proj,
+                uint32_t* fb, uint32_t width, uint32_t height, uint32_t band_y0, uint32_t band_y1);
+void launch_stars(hipStream_t s, const int32_t* cx, const int32_t* cy, const uint8_t* rgb, uint32_t n, float size, uint32_t* fb,
+                  uint32_t width, uint32_t height, uint32_t band_y0, uint32_t band_y1);
+void launch_upscale_nearest(hipStream_t s, const uint32_t* src, uint32_t sw, uint32_t sh, uint32_t* dst, uint32_t dw, uint32_t dh);
+
 struct FillArgs {
     FrameParams fp;
     const SurfRec* recs;

@@ -118,6 +118,35 @@ class Framebuffer:
     def clear(self, color: T.Color):
         _chk(self.ctx.lib.b32_fb_clear(self.ctx.h, color.r, color.g, color.b, color.blend), "fb_clear")
 
+    def clear_gradient(self, top: T.Color, bottom: T.Color):
+        """Framebuffer::clear_gradient (render.rs:58-77)"""
+        _chk(self.ctx.lib.b32_fb_clear_gradient(self.ctx.h, top.r, top.g, top.b, top.blend, bottom.r, bottom.g, bottom.b, bottom.blend), "fb_clear_gradient")
+
+    def clear_transparent(self):
+        """Framebuffer::clear_transparent (render.rs:47-56)"""
+        _chk(self.ctx.lib.b32_fb_clear_transparent(self.ctx.h), "fb_clear_transparent")
+
+    def render_skybox_mesh(self, vertices, faces, camera: T.Camera):
+        """Step 1 of Framebuffer::render_skybox (render.rs:81-134): `vertices` (abi.SKY_VERTEX_DTYPE) and `faces` ([n,3] u32) are
+        what Skybox::generate_mesh returned on the host."""
+        v = np.ascontiguousarray(vertices, dtype=abi.SKY_VERTEX_DTYPE)
+        f = np.ascontiguousarray(faces, dtype=np.uint32).reshape(-1, 3)
+        cam = camera.pack()
+        _chk(self.ctx.lib.b32_render_skybox_mesh(self.ctx.h, v.ctypes.data if len(v) else None, len(v),
+                                                 f.ctypes.data if len(f) else None, len(f), C.byref(cam)), "render_skybox_mesh")
+
+    def draw_star_diamonds(self, cx, cy, rgb, size):
+        """draw_star_diamond (render.rs:199-240) for every star, in order."""
+        cx = np.ascontiguousarray(cx, np.int32); cy = np.ascontiguousarray(cy, np.int32)
+        rgb = np.ascontiguousarray(rgb, np.uint8).reshape(-1, 3)
+        _chk(self.ctx.lib.b32_draw_star_diamonds(self.ctx.h, cx.ctypes.data, cy.ctypes.data, rgb.ctypes.data, len(cx), float(size)), "draw_star_diamonds")
+
+    def present_nearest(self, dst_w, dst_h):
+        """The presenter's nearest-neighbour upscale (game/renderer.rs:179-214) -> uint8 [dst_h, dst_w, 4]."""
+        out = np.empty((dst_h, dst_w, 4), np.uint8)
+        _chk(self.ctx.lib.b32_present_nearest(self.ctx.h, dst_w, dst_h, out.ctypes.data), "present_nearest")
+        return out
+
     def upload(self, pixels):
         px = np.ascontiguousarray(pixels, dtype=np.uint8).reshape(-1)
         assert px.size == self.width * self.height * 4

@@ -229,6 +229,25 @@ int b32_scene_upload_rgba(b32_ctx* ctx,
 int b32_render_scene(b32_ctx* ctx, const B32Camera* camera, const B32Settings* settings, B32Timings* out /* nullable */);
 int b32_render_scene_async(b32_ctx* ctx, const B32Camera* camera, const B32Settings* settings);
 
+/* ---- the steps around the mesh draw that the reference runs on the same framebuffer ----------
+ * so that a whole frame can stay device resident.  The procedural inputs that use sin/cos/powf (Skybox::generate_mesh,
+ * world/geometry.rs:529; star directions and twinkle, render.rs:166-196) are computed by the caller, like the camera basis. */
+typedef struct B32SkyVertex { float pos[3]; uint8_t r, g, b, blend; } B32SkyVertex;       /* SkyboxVertex{pos, color} */
+/* Framebuffer::clear_gradient, render.rs:58-77 (top at y = 0, bottom at y = height-1; also resets the z-buffer) */
+int b32_fb_clear_gradient(b32_ctx* ctx, uint8_t top_r, uint8_t top_g, uint8_t top_b, uint8_t top_blend,
+                          uint8_t bottom_r, uint8_t bottom_g, uint8_t bottom_b, uint8_t bottom_blend);
+/* Framebuffer::clear_transparent, render.rs:47-56 */
+int b32_fb_clear_transparent(b32_ctx* ctx);
+/* Step 1 of Framebuffer::render_skybox, render.rs:81-134: project (math.rs:117-136), cull and fill the vertex-coloured sphere with
+ * rasterize_skybox_triangle (render.rs:251-298).  `faces` = 3 vertex indices per face, drawn in order. */
+int b32_render_skybox_mesh(b32_ctx* ctx, const B32SkyVertex* vertices, uint32_t nv, const uint32_t* faces, uint32_t nf,
+                           const B32Camera* camera);
+/* draw_star_diamond, render.rs:199-240, for n stars in order: centre (cx, cy) = (screen.x as i32, screen.y as i32), colour rgb[3*i..]. */
+int b32_draw_star_diamonds(b32_ctx* ctx, const int32_t* cx, const int32_t* cy, const uint8_t* rgb, uint32_t n, float size);
+/* The presenter's upscale (game/renderer.rs:179-214: Texture2D::from_rgba8 + FilterMode::Nearest + dest_size): destination pixel
+ * (x, y) shows source texel floor((x + 0.5) * w / dst_w), floor((y + 0.5) * h / dst_h).  Writes dst_w*dst_h RGBA8 to host memory. */
+int b32_present_nearest(b32_ctx* ctx, uint32_t dst_w, uint32_t dst_h, uint8_t* rgba_out);
+
 /* ---- stage taps (parity tests only; not on the frame path) ---------------- */
 /* fixed::project_fixed (fixed.rs:424-441) + float depth (render.rs:2331-2345) for n positions. */
 int b32_project_fixed_batch(b32_ctx* ctx, const float* pos_xyz, uint32_t n,

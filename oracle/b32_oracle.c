@@ -977,6 +977,88 @@ EXPORT int b32o_render_mesh(uint8_t* fb_pixels, float* fb_zbuffer, uint32_t widt
                             camera, st, NULL, timings, dump);
 }
 
+/* ------------------------------------------------------------------ the steps around the mesh draw */
+/* Color::lerp, types.rs:812-821 + Framebuffer::clear_gradient, render.rs:58-77 */
+EXPORT void b32o_fb_clear_gradient(uint8_t* pixels, float* zbuffer, uint32_t width, uint32_t height, const uint8_t top[4], const uint8_t bottom[4]) {
+    for (uint32_t y = 0; y < height; ++y) {
+        float t = height > 1 ? (float)y / (float)(height - 1) : 0.0f;
+        float tc = rclamp(t, 0.0f, 1.0f), inv_t = 1.0f - tc;
+        uint8_t c[4];
+        for (int i = 0; i < 3; ++i) c[i] = f2u8_sat((float)top[i] * inv_t + (float)bottom[i] * tc);
+        c[3] = top[3] == B32_BLEND_ERASE ? 0 : 255;                                            /* blend: self.blend -> to_bytes */
+        for (uint32_t x = 0; x < width; ++x) {
+            size_t idx = ((size_t)y * width + x) * 4;
+            memcpy(&pixels[idx], c, 4);
+            if (zbuffer) zbuffer[(size_t)y * width + x] = 3.40282347e+38f;
+        }
+    }
+}
+/* rasterize_skybox_triangle, render.rs:251-298 */
+static void rasterize_skybox_triangle(uint8_t* pixels, uint32_t width, uint32_t height, const float p0[2], const float p1[2], const float p2[2],
+                                      const uint8_t* c0, const uint8_t* c1, const uint8_t* c2) {
+    uint64_t min_x = f2usize_sat(rmax(rmin(rmin(p0[0], p1[0]), p2[0]), 0.0f));
+    uint64_t max_x = f2usize_sat(rmin(rmax(rmax(p0[0], p1[0]), p2[0]), (float)width - 1.0f));
+    uint64_t min_y = f2usize_sat(rmax(rmin(rmin(p0[1], p1[1]), p2[1]), 0.0f));
+    uint64_t max_y = f2usize_sat(rmin(rmax(rmax(p0[1], p1[1]), p2[1]), (float)height - 1.0f));
+    if (min_x > max_x || min_y > max_y) return;
+    float denom = (p1[1] - p2[1]) * (p0[0] - p2[0]) + (p2[0] - p1[0]) * (p0[1] - p2[1]);
+    if (fabsf(denom) < 0.0001f) return;
+    float inv_denom = 1.0f / denom;
+    for (uint64_t y = min_y; y <= max_y; ++y)
+        for (uint64_t x = min_x; x <= max_x; ++x) {
+            float px = (float)x + 0.5f, py = (float)y + 0.5f;
+            float w0 = ((p1[1] - p2[1]) * (px - p2[0]) + (p2[0] - p1[0]) * (py - p2[1])) * inv_denom;
+            float w1 = ((p2[1] - p0[1]) * (px - p2[0]) + (p0[0] - p2[0]) * (py - p2[1])) * inv_denom;
+            float w2 = 1.0f - w0 - w1;
+            if (w0 >= 0.0f && w1 >= 0.0f && w2 >= 0.0f) {
+                size_t idx = ((size_t)y * width + x) * 4;
+                for (int i = 0; i < 3; ++i) pixels[idx + i] = f2u8_sat((float)c0[i] * w0 + (float)c1[i] * w1 + (float)c2[i] * w2);
+                pixels[idx + 3] = 255;
+            }
+        }
+}
+typedef struct { float pos[3]; uint8_t r, g, b, blend; } SkyVertex;
+/* step 1 of Framebuffer::render_skybox, render.rs:81-134 (the mesh itself comes from Skybox::generate_mesh on the host) */
+EXPORT int b32o_render_skybox_mesh(uint8_t* pixels, uint32_t width, uint32_t height, const SkyVertex* v, uint32_t nv,
+                                   const uint32_t* faces, uint32_t nf, const B32Camera* camera) {
+    V3 cpos = v3p(camera->position), bx = v3p(camera->basis_x), by = v3p(camera->basis_y), bz = v3p(camera->basis_z);
+    float* proj = (float*)malloc(sizeof(float) * 3 * (nv ? nv : 1));
+    for (uint32_t i = 0; i < nv; ++i) {
+        V3 cam_space = perspective_transform(v3sub(v3p(v[i].pos), cpos), bx, by, bz);
+        if (cam_space.z <= 0.1f) { proj[3 * i] = proj[3 * i + 1] = proj[3 * i + 2] = NAN; continue; }
+        V3 screen = project_float(cam_space, width, height);
+        proj[3 * i] = screen.x; proj[3 * i + 1] = screen.y; proj[3 * i + 2] = cam_space.z;
+    }
+    int rc = B32_OK;
+    for (uint32_t f = 0; f < nf && !rc; ++f) {
+        const uint32_t i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
+        if (i0 >= nv || i1 >= nv || i2 >= nv) { rc = B32_E_INDEX; break; }
+        const float *p0 = &proj[3 * i0], *p1 = &proj[3 * i1], *p2 = &proj[3 * i2];
+        if (p0[0] != p0[0] || p1[0] != p1[0] || p2[0] != p2[0]) continue;
+        float signed_area = (p1[0] - p0[0]) * (p2[1] - p0[1]) - (p2[0] - p0[0]) * (p1[1] - p0[1]);
+        if (signed_area >= 0.0f) continue;
+        rasterize_skybox_triangle(pixels, width, height, p0, p1, p2, &v[i0].r, &v[i1].r, &v[i2].r);
+    }
+    free(proj);
+    return rc;
+}
+/* draw_star_diamond + set_pixel_safe, render.rs:199-246 */
+EXPORT void b32o_draw_star_diamond(uint8_t* pixels, uint32_t width, uint32_t height, int32_t cx, int32_t cy, float size, const uint8_t rgb[3]) {
+    FB fb = { pixels, NULL, width, height, 0 };
+    int32_t s = f2i32_sat(rmax(size, 1.0f));
+    set_pixel_rgb(&fb, cx, cy, rgb[0], rgb[1], rgb[2]);
+    if (s >= 2) {
+        uint8_t d[3]; for (int i = 0; i < 3; ++i) d[i] = f2u8_sat((float)rgb[i] * 0.7f);
+        set_pixel_rgb(&fb, cx - 1, cy, d[0], d[1], d[2]); set_pixel_rgb(&fb, cx + 1, cy, d[0], d[1], d[2]);
+        set_pixel_rgb(&fb, cx, cy - 1, d[0], d[1], d[2]); set_pixel_rgb(&fb, cx, cy + 1, d[0], d[1], d[2]);
+    }
+    if (s >= 3) {
+        uint8_t d[3]; for (int i = 0; i < 3; ++i) d[i] = f2u8_sat((float)rgb[i] * 0.4f);
+        set_pixel_rgb(&fb, cx - 2, cy, d[0], d[1], d[2]); set_pixel_rgb(&fb, cx + 2, cy, d[0], d[1], d[2]);
+        set_pixel_rgb(&fb, cx, cy - 2, d[0], d[1], d[2]); set_pixel_rgb(&fb, cx, cy + 2, d[0], d[1], d[2]);
+    }
+}
+
 /* Reference unit-test helpers (math.rs:779-807) exposed so tests can replay them through this file. */
 EXPORT float b32o_vec3_dot(const float a[3], const float b[3]) { return v3dot(v3p(a), v3p(b)); }
 EXPORT void b32o_vec3_cross(const float a[3], const float b[3], float out[3]) {   /* math.rs:27-33 */

@@ -59,6 +59,11 @@ def lib():
                                           P, P, P, P, P]
         L.b32o_render_mesh.restype = C.c_int
         L.b32o_render_mesh.argtypes = [P, P, C.c_uint32, C.c_uint32, P, C.c_uint32, P, C.c_uint32, P, C.c_uint32, P, P, P, P]
+        L.b32o_fb_clear_gradient.restype = None; L.b32o_fb_clear_gradient.argtypes = [P, P, C.c_uint32, C.c_uint32, P, P]
+        L.b32o_render_skybox_mesh.restype = C.c_int
+        L.b32o_render_skybox_mesh.argtypes = [P, C.c_uint32, C.c_uint32, P, C.c_uint32, P, C.c_uint32, P]
+        L.b32o_draw_star_diamond.restype = None
+        L.b32o_draw_star_diamond.argtypes = [P, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_float, P]
         L.b32o_vec3_dot.restype = C.c_float; L.b32o_vec3_dot.argtypes = [P, P]
         L.b32o_vec3_cross.restype = None; L.b32o_vec3_cross.argtypes = [P, P, P]
         _lib = L
@@ -91,6 +96,21 @@ class Framebuffer:
 
     def image(self):
         return self.pixels.reshape(self.height, self.width, 4)
+
+    def clear_gradient(self, top: T.Color, bottom: T.Color):
+        t = (C.c_uint8 * 4)(top.r, top.g, top.b, top.blend); b = (C.c_uint8 * 4)(bottom.r, bottom.g, bottom.b, bottom.blend)
+        lib().b32o_fb_clear_gradient(self.pixels.ctypes.data, self.zbuffer.ctypes.data, self.width, self.height, t, b)
+
+    def render_skybox_mesh(self, vertices, faces, camera: T.Camera):
+        v = np.ascontiguousarray(vertices, dtype=abi.SKY_VERTEX_DTYPE)
+        f = np.ascontiguousarray(faces, dtype=np.uint32).reshape(-1, 3)
+        cam = camera.pack()
+        return lib().b32o_render_skybox_mesh(self.pixels.ctypes.data, self.width, self.height, v.ctypes.data, len(v), f.ctypes.data, len(f), C.byref(cam))
+
+    def draw_star_diamonds(self, cx, cy, rgb, size):
+        rgb = np.ascontiguousarray(rgb, np.uint8).reshape(-1, 3)
+        for i in range(len(cx)):
+            lib().b32o_draw_star_diamond(self.pixels.ctypes.data, self.width, self.height, int(cx[i]), int(cy[i]), float(size), rgb[i].ctypes.data)
 
 
 def render_mesh(fb: Framebuffer, vertices, faces, textures, camera: T.Camera, settings: T.RasterSettings, dump=False):
