@@ -239,16 +239,19 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp, const B32Vertex* 
                     if (!(__builtin_fabsf(v1.x) <= lim && __builtin_fabsf(v1.y) <= lim && __builtin_fabsf(v2.x) <= lim &&
                           __builtin_fabsf(v2.y) <= lim && __builtin_fabsf(v3.x) <= lim && __builtin_fabsf(v3.y) <= lim)) slow = true;
                     else {
-                        const int64_t A0 = (int64_t)r.a0, B0 = (int64_t)r.b0, A1 = (int64_t)r.a1, B1 = (int64_t)r.b1;
-                        const int64_t X3 = (int64_t)v3.x, Y3 = (int64_t)v3.y;
-                        const int64_t dx[2] = { (int64_t)min_x - X3, (int64_t)max_x - 1 - X3 };
-                        const int64_t dy[2] = { (int64_t)min_y - Y3, (int64_t)max_y - 1 - Y3 };
-                        const int64_t L = 16777216;   // 2^24
+                        // every operand is an integer-valued float below 2^23, so each product / sum below is exact whenever its
+                        // true value is below 2^24, and rounds to >= 2^24 otherwise (rounding is monotonic and 2^24 is
+                        // representable): the float comparisons decide exactly what 64-bit integer arithmetic would
+                        const float dxs[2] = { (float)min_x - v3.x, (float)(max_x - 1) - v3.x };
+                        const float dys[2] = { (float)min_y - v3.y, (float)(max_y - 1) - v3.y };
+                        const float L = 16777216.0f;   // 2^24
+#pragma unroll
                         for (int a = 0; a < 2; ++a)
+#pragma unroll
                             for (int b = 0; b < 2; ++b) {
-                                int64_t p0 = A0 * dx[a], q0 = B0 * dy[b], p1 = A1 * dx[a], q1 = B1 * dy[b];
-                                if (llabs(p0) >= L || llabs(q0) >= L || llabs(p1) >= L || llabs(q1) >= L ||
-                                    llabs(p0 + q0) >= L || llabs(p1 + q1) >= L) slow = true;
+                                const float p0 = r.a0 * dxs[a], q0 = r.b0 * dys[b], p1 = r.a1 * dxs[a], q1 = r.b1 * dys[b];
+                                if (!(__builtin_fabsf(p0) < L && __builtin_fabsf(q0) < L && __builtin_fabsf(p1) < L && __builtin_fabsf(q1) < L &&
+                                      __builtin_fabsf(p0 + q0) < L && __builtin_fabsf(p1 + q1) < L)) slow = true;
                             }
                     }
                 }
