@@ -515,6 +515,7 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     fp.affine = st->affine_textures; fp.shading = st->shading; fp.backface_cull = st->backface_cull;
     fp.dithering = st->dithering; fp.fixed_point = st->use_fixed_point; fp.has_fog = fog ? 1 : 0; fp.zmode = st->use_zbuffer ? 1 : 0;
     if (fog) fp.fog = *fog;
+    fp.camfx = make_camfx_any(*cam, c->width, c->height);
     fp.fmt8 = c->fmt8 ? 1 : 0;
     fp.ortho = st->has_ortho ? 1 : 0; fp.xray = st->xray_mode ? 1 : 0;
     fp.ortho_zoom = st->ortho_zoom; fp.ortho_cx = st->ortho_center_x; fp.ortho_cy = st->ortho_center_y;

@@ -66,6 +66,31 @@ struct Ctrl {
 
 constexpr uint32_t LOCAL_SORT_CAP = 2048;   // longest tile list the per-tile LDS radix sort handles
 
+// Loop-invariant conversions of transform_to_camera_space / project_to_screen (fixed.rs:362-400): the camera converted to 4.12
+// fixed point once per frame instead of once per vertex.  Plain IEEE f32 multiply + Rust's saturating `as i32`, identical on
+// host and device.
+struct CamFx {
+    int32_t px, py, pz, bx[3], by[3], bz[3];
+    int32_t vs, half_w, half_h;
+};
+__host__ __device__ inline int32_t fx_from_f32_any(float f) {                 // Fixed32::from_f32, fixed.rs:125-127
+    const float p = f * 4096.0f;
+    if (p != p) return 0;
+    if (p >= 2147483648.0f) return INT32_MAX;
+    if (p <= -2147483648.0f) return INT32_MIN;
+    return (int32_t)p;
+}
+__host__ __device__ inline CamFx make_camfx_any(const B32Camera& c, uint32_t width, uint32_t height) {
+    CamFx k;
+    k.px = fx_from_f32_any(c.position[0]); k.py = fx_from_f32_any(c.position[1]); k.pz = fx_from_f32_any(c.position[2]);
+    for (int i = 0; i < 3; ++i) { k.bx[i] = fx_from_f32_any(c.basis_x[i]); k.by[i] = fx_from_f32_any(c.basis_y[i]); k.bz[i] = fx_from_f32_any(c.basis_z[i]); }
+    const uint32_t mn = width < height ? width : height;
+    k.vs = fx_from_f32_any(((float)mn / 2.0f) * 0.75f);                       // fixed.rs:398
+    k.half_w = (int32_t)((uint32_t)((int32_t)width / 2) << 12);               // fixed.rs:399-400
+    k.half_h = (int32_t)((uint32_t)((int32_t)height / 2) << 12);
+    return k;
+}
+
 // Everything k_setup / k_fill need about the frame, passed by value.
 struct FrameParams {
     B32Camera cam;
@@ -79,6 +104,7 @@ struct FrameParams {
     uint8_t ortho, xray, wire_collect, pad2;   // ortho_projection.is_some(), xray_mode, any wireframe phase wants its triangles
     float ortho_zoom, ortho_cx, ortho_cy;      // OrthoProjection (types.rs), math.rs:140-148
     B32Fog fog;
+    CamFx camfx;
 };
 
 // Triangle of the wireframe phases (render.rs:2445-2449, 2509-2511, 2574-2635): screen coordinates `as i32`, depth as is.

@@ -27,40 +27,35 @@ __device__ __forceinline__ int32_t wadd(int32_t a, int32_t b) { return (int32_t)
 __device__ __forceinline__ int32_t wsub(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
 __device__ __forceinline__ int32_t fx_from_f32(float f) { return f2i32_sat(f * 4096.0f); }           // fixed.rs:125-127
 __device__ __forceinline__ int32_t fx_mul(int32_t a, int32_t b) { return (int32_t)(((int64_t)a * (int64_t)b) >> 12); }  // :161-165
-__device__ int32_t fx_div_unr(int32_t self, int32_t divisor) {                                       // fixed.rs:178-230
-    if (divisor == 0) return 0;
-    bool neg = (self < 0) != (divisor < 0);
-    uint64_t num = (uint64_t)(self < 0 ? (0u - (uint32_t)self) : (uint32_t)self);
-    uint32_t den = divisor < 0 ? (0u - (uint32_t)divisor) : (uint32_t)divisor;
-    uint32_t z = (uint32_t)__builtin_clz(den);
-    uint64_t d16 = ((uint64_t)den << z) >> 16;
+// Fixed32::div_unr, fixed.rs:178-230, split at the point where only the divisor has been used: project_to_screen divides x and
+// y by the same denominator (fixed.rs:411-412), so the table lookup and both Newton steps are done once per vertex.
+struct UnrRecip { uint64_t nr2; uint32_t shift; bool neg, zero; };
+__device__ __forceinline__ UnrRecip unr_recip(int32_t divisor) {
+    UnrRecip r;
+    r.zero = divisor == 0; r.neg = divisor < 0;
+    const uint32_t den = divisor < 0 ? (0u - (uint32_t)divisor) : (uint32_t)divisor;
+    const uint32_t z = (uint32_t)__builtin_clz(den | (r.zero ? 1u : 0u));
+    const uint64_t d16 = ((uint64_t)den << z) >> 16;
     uint64_t ti = (d16 - 0x7FC0ull) >> 7;
     if (ti > 256) ti = 256;
-    uint64_t u = (uint64_t)g_unr.v[ti] + 0x101;
-    uint64_t nr1 = (0x2000080ull - d16 * u) >> 8;
-    uint64_t nr2 = (0x80ull + nr1 * u) >> 8;
-    uint64_t raw = num * nr2;
-    uint32_t shift = 36u - z;                       // z in 0..31 -> shift in 5..36
-    uint64_t mag = (raw + (1ull << (shift - 1))) >> shift;
-    int32_t clamped = (int32_t)(mag < (uint64_t)INT32_MAX ? mag : (uint64_t)INT32_MAX);
+    const uint64_t u = (uint64_t)g_unr.v[ti] + 0x101;
+    const uint64_t nr1 = (0x2000080ull - d16 * u) >> 8;
+    r.nr2 = (0x80ull + nr1 * u) >> 8;
+    r.shift = 36u - z;                              // z in 0..31 -> shift in 5..36
+    return r;
+}
+__device__ __forceinline__ int32_t unr_apply(int32_t self, const UnrRecip& r) {
+    if (r.zero) return 0;
+    const bool neg = (self < 0) != r.neg;
+    const uint64_t num = (uint64_t)(self < 0 ? (0u - (uint32_t)self) : (uint32_t)self);
+    const uint64_t raw = num * r.nr2;
+    const uint64_t mag = (raw + (1ull << (r.shift - 1))) >> r.shift;
+    const int32_t clamped = (int32_t)(mag < (uint64_t)INT32_MAX ? mag : (uint64_t)INT32_MAX);
     return neg ? -clamped : clamped;
 }
+__device__ __forceinline__ int32_t fx_div_unr(int32_t self, int32_t divisor) { return unr_apply(self, unr_recip(divisor)); }
 
-struct CamFx {          // loop-invariant conversions of transform_to_camera_space / project_to_screen
-    int32_t px, py, pz, bx[3], by[3], bz[3];
-    int32_t vs, half_w, half_h;
-};
-__device__ __forceinline__ CamFx make_camfx(const B32Camera& c, uint32_t width, uint32_t height) {
-    CamFx k;
-    k.px = fx_from_f32(c.position[0]); k.py = fx_from_f32(c.position[1]); k.pz = fx_from_f32(c.position[2]);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { k.bx[i] = fx_from_f32(c.basis_x[i]); k.by[i] = fx_from_f32(c.basis_y[i]); k.bz[i] = fx_from_f32(c.basis_z[i]); }
-    uint32_t mn = width < height ? width : height;
-    k.vs = fx_from_f32(((float)mn / 2.0f) * 0.75f);                     // fixed.rs:398
-    k.half_w = (int32_t)((uint32_t)((int32_t)width / 2) << 12);         // fixed.rs:399-400
-    k.half_h = (int32_t)((uint32_t)((int32_t)height / 2) << 12);
-    return k;
-}
+__device__ __forceinline__ CamFx make_camfx(const B32Camera& c, uint32_t width, uint32_t height) { return make_camfx_any(c, width, height); }
 // project_fixed, fixed.rs:424-441 (screen integers only; the fixed depth is discarded by render.rs:2331)
 __device__ __forceinline__ void project_fixed_dev(float x, float y, float z, const CamFx& k, int32_t& sx, int32_t& sy) {
     int32_t rx = wsub(fx_from_f32(x), k.px), ry = wsub(fx_from_f32(y), k.py), rz = wsub(fx_from_f32(z), k.pz);
@@ -71,8 +66,9 @@ __device__ __forceinline__ void project_fixed_dev(float x, float y, float z, con
     int32_t denom = wadd(cz, distance);
     int32_t adenom = denom < 0 ? (int32_t)(0u - (uint32_t)denom) : denom;   // i32::abs wraps at MIN in release
     if (adenom < 256) { sx = k.half_w >> 12; sy = k.half_h >> 12; return; }
-    int32_t proj_x = fx_div_unr(fx_mul(cx, scale), denom);
-    int32_t proj_y = fx_div_unr(fx_mul(cy, scale), denom);
+    const UnrRecip rcp = unr_recip(denom);
+    int32_t proj_x = unr_apply(fx_mul(cx, scale), rcp);
+    int32_t proj_y = unr_apply(fx_mul(cy, scale), rcp);
     sx = wadd(fx_mul(proj_x, k.vs), k.half_w) >> 12;
     sy = wadd(fx_mul(proj_y, k.vs), k.half_h) >> 12;
 }
@@ -152,7 +148,7 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp, const B32Vertex* 
         if (vi[0] >= fp.nv || vi[1] >= fp.nv || vi[2] >= fp.nv) {
             bad_index = true;                                   // index panic, render.rs:2375-2377
         } else {
-            const CamFx k = make_camfx(fp.cam, fp.width, fp.height);
+            const CamFx& k = fp.camfx;              // loop-invariant fixed-point conversions, done once on the host
             const V3 cpos = ld3(fp.cam.position), bx = ld3(fp.cam.basis_x), by = ld3(fp.cam.basis_y), bz = ld3(fp.cam.basis_z);
             V3 scr[3]; float camz[3]; V3 wpos[3]; float uvx[3], uvy[3]; uint32_t col[3];
 #pragma unroll
