@@ -562,10 +562,15 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
                             Pj[j] = ((unsigned long long)(~zsort_key(z)) << 32) | (uint32_t)P;
                         }
                     }
+                    // one predicated block for the whole trip (a branch per atomic makes the compiler wait for each returning
+                    // atomic before it issues the next): pixels outside the triangle contribute priority 0, a no-op for both
+                    // maxima (min(old, 0) == 0)
+                    if (in[0] | in[1] | in[2] | in[3]) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) if (in[j]) old[j] = atomicMax(&top[addr + j], Pj[j]);
+                        for (int j = 0; j < 4; ++j) { if (!in[j]) Pj[j] = 0ull; old[j] = atomicMax(&top[addr + j], Pj[j]); }
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) if (in[j]) atomicMax(&sec[addr + j], min(old[j], Pj[j]));
+                        for (int j = 0; j < 4; ++j) atomicMax(&sec[addr + j], min(old[j], Pj[j]));
+                    }
                     addr += 4; w0 = wa[3] + sa0; w1 = wb[3] + sa1;
                 }
             } else {
