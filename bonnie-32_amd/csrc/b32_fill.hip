@@ -25,6 +25,9 @@
 // walk (render.rs:1706-1712) is replayed literally.
 #include "b32_device.h"
 #include <cstdlib>
+#ifndef B32_TRIP
+#define B32_TRIP 4
+#endif
 
 namespace b32 {
 
@@ -542,15 +545,16 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
                 unsigned long long* sec = top + TILE_H * TILE_STRIDE;
                 float z1 = 0.0f, z2 = 0.0f, z3 = 0.0f;
                 if (ZMODE) { z1 = bpermf(s, __uint_as_float(b.q5.y)); z2 = bpermf(s, __uint_as_float(b.q5.z)); z3 = bpermf(s, __uint_as_float(b.q5.w)); }
-                for (uint32_t i = 0; __ballot(i < n); i += 4) {
-                    float wa[4], wb[4];
+                constexpr int TRIP = B32_TRIP;
+                for (uint32_t i = 0; __ballot(i < n); i += TRIP) {
+                    float wa[TRIP], wb[TRIP];
                     wa[0] = w0; wb[0] = w1;
 #pragma unroll
-                    for (int j = 1; j < 4; ++j) { wa[j] = wa[j - 1] + sa0; wb[j] = wb[j - 1] + sa1; }
-                    bool in[4];
-                    unsigned long long old[4], Pj[4];
+                    for (int j = 1; j < TRIP; ++j) { wa[j] = wa[j - 1] + sa0; wb[j] = wb[j - 1] + sa1; }
+                    bool in[TRIP];
+                    unsigned long long old[TRIP], Pj[TRIP];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
+                    for (int j = 0; j < TRIP; ++j) {
                         const float cx = wa[j] * sinv, cy = wb[j] * sinv;
                         const float cz = 1.0f - cx - cy;
                         in[j] = (i + j < n) & (cx >= ERR) & (cy >= ERR) & (cz >= ERR);
@@ -565,13 +569,16 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
                     // one predicated block for the whole trip (a branch per atomic makes the compiler wait for each returning
                     // atomic before it issues the next): pixels outside the triangle contribute priority 0, a no-op for both
                     // maxima (min(old, 0) == 0)
-                    if (in[0] | in[1] | in[2] | in[3]) {
+                    bool any_in = false;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) { if (!in[j]) Pj[j] = 0ull; old[j] = atomicMax(&top[addr + j], Pj[j]); }
+                    for (int j = 0; j < TRIP; ++j) any_in |= in[j];
+                    if (any_in) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) atomicMax(&sec[addr + j], min(old[j], Pj[j]));
+                        for (int j = 0; j < TRIP; ++j) { if (!in[j]) Pj[j] = 0ull; old[j] = atomicMax(&top[addr + j], Pj[j]); }
+#pragma unroll
+                        for (int j = 0; j < TRIP; ++j) atomicMax(&sec[addr + j], min(old[j], Pj[j]));
                     }
-                    addr += 4; w0 = wa[3] + sa0; w1 = wb[3] + sa1;
+                    addr += TRIP; w0 = wa[TRIP - 1] + sa0; w1 = wb[TRIP - 1] + sa1;
                 }
             } else {
                 // CHEAP coverage: two pixels per trip, so the two returning LDS atomics are in flight together and the wave
