@@ -14,7 +14,7 @@ SOURCES = ["b32_api.hip", "b32_setup.hip", "b32_sort.hip", "b32_bin.hip", "b32_f
 OUT = os.path.join(CSRC, "libb32raster.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
          "-fno-gpu-flush-denormals-to-zero", "-fhip-fp32-correctly-rounded-divide-sqrt",
-         "-Wall", "-Wno-unused-function"]
+         "-Wall", "-Wno-unused-function"] + [f for f in os.environ.get("B32_EXTRA_FLAGS", "").split() if f]
 
 
 def hipcc():

@@ -28,6 +28,9 @@
 #ifndef B32_TRIP
 #define B32_TRIP 4
 #endif
+#ifndef B32_GRAB_DIV
+#define B32_GRAB_DIV 1          // list entries per grab ~ n / (B32_GRAB_DIV * waves); 1 measured best (130 us vs 134 at 3)
+#endif
 
 namespace b32 {
 
@@ -459,7 +462,7 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
     const float ERR = -0.0001f;
     const bool affine = a.fp.affine != 0;
     // entries per grab: ~3 grabs per wave for balance, never more than the 64 lanes can hold
-    const uint32_t grab = min(64u, max(4u, (n_op + 3 * NW - 1) / (3 * NW)));
+    const uint32_t grab = min(64u, max(4u, (n_op + B32_GRAB_DIV * NW - 1) / (B32_GRAB_DIV * NW)));
     for (;;) {
         uint32_t cs = 0;
         if (lane == 0) cs = atomicAdd(const_cast<uint32_t*>(cursor), grab);

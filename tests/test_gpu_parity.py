@@ -485,3 +485,26 @@ def test_fast_path_transparent_lists(fast_ctx, oracle):
     got, tm = gpu_render(fast_ctx, big, resident=True)
     assert np.array_equal(got, exp), f"{int((got != exp).sum())} bytes differ"
     assert tm.triangles_drawn == etm.triangles_drawn > 2 * 2048 * 2
+
+
+@pytest.mark.parametrize("counting", [0, 1])
+def test_more_tiles_than_the_span_histogram_holds(gpu_ctx, oracle, counting):
+    """4160x4160 = 4225 screen tiles: beyond the LDS histogram of the sort-free binning (4096) and beyond one 12-bit radix
+    pass, so the frame takes the keyed multi-pass tile sort + k_tile_ranges.  Also the blend variant (two classes per tile)."""
+    from bonnie32_amd import rasterizer as R
+    for variant in ("bench", "blend"):
+        sc = scenegen.make_scene("C1", n_tris=6000, width=4160, height=4160, bbox_px=30000.0, seed=91, variant=variant)
+        ofb = oracle.Framebuffer(sc.width, sc.height); ofb.clear(sc.clear_color)
+        rc, etm = oracle.render_mesh_15(ofb, sc.vertices, sc.faces, sc.textures, sc.camera, sc.settings)
+        assert rc == 0
+        gpu_ctx.set_fragment_counting(counting)
+        try:
+            fb = R.Framebuffer(sc.width, sc.height, gpu_ctx); fb.clear(sc.clear_color)
+            tm = R.ResidentScene(fb, sc.vertices, sc.faces, sc.textures).render(sc.camera, sc.settings)
+            got = fb.pixels
+            assert np.array_equal(got, ofb.pixels), f"{int((got != ofb.pixels).sum())} bytes differ ({variant})"
+            assert tm.triangles_drawn == etm.triangles_drawn
+            if counting:
+                assert tm.fragments == etm.fragments
+        finally:
+            gpu_ctx.set_fragment_counting(1)
