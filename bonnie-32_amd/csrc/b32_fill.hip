@@ -1148,13 +1148,30 @@ __device__ __forceinline__ bool blend_fragment(const FillArgs& a, const Tri& tr,
     return true;
 }
 
+// Fragment of the ordered pass, computed in phase 1 (order-free) and applied in phase 2 (in painter's order):
+//   RGB555 path: out15 | 1 << 16 when the fragment is drawn (inside, depth test against the read-only tile depth, texel rule)
+//   8-bit path : two words, colour r | g<<8 | b<<16 | blend<<24 | 1<<31 and the depth bits (its depth test needs the running depth)
+constexpr uint32_t FRAG_SLOTS = 4096;          // fragments per chunk (>= one full 64x64 surface): 16 KB of LDS (RGB555), 32 KB (8-bit)
+__host__ __device__ constexpr size_t blend_lds_bytes(bool fmt8, bool zmode) {
+    return (size_t)LDS_TILE_BYTES * (zmode ? 2 : 1) + (size_t)FRAG_SLOTS * (fmt8 ? 8 : 4) + 256 + 16 * 256 + 64 * 128;
+}
+
 template <int NT, bool FMT8, bool GATHER = false>
-__global__ __launch_bounds__(NT) void k_blend(FillArgs a) {
+__global__ __launch_bounds__(NT, 4) void k_blend(FillArgs a) {        // 4 waves per SIMD = two workgroups per CU: at most 128 VGPRs
     constexpr int NW = NT / 64;
-    __shared__ uint32_t tilebuf[TILE_H * TILE_STRIDE];
-    __shared__ float tilez[TILE_H * TILE_STRIDE];      // z-buffer mode: depth of the tile (read only: the transparent pass never writes z)
-    __shared__ unsigned long long wf[NW];
-    __shared__ unsigned long long gprio[GATHER ? BLEND_SORT_CAP : 1];   // GATHER: painter's priorities of the tile's transparent entries
+    constexpr uint32_t FCAP = FRAG_SLOTS;
+    // dynamic LDS (blend_lds_bytes): [wf 256 B][row-scheduler marks 256 B per wave][frag][tile colours][tile depths, z-buffer mode only]
+    extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
+    unsigned long long* wf = reinterpret_cast<unsigned long long*>(bsm);
+    volatile uint32_t* wmark = reinterpret_cast<volatile uint32_t*>(bsm + 256) + (threadIdx.x >> 6) * 64;
+    uint4* srec = reinterpret_cast<uint4*>(bsm + 256 + 16 * 256);           // the chunk's 64 surface records: 8 x 16 B each (q0..q5, texture, id)
+    uint32_t* frag = reinterpret_cast<uint32_t*>(bsm + 256 + 16 * 256 + 64 * 128);
+    static_assert(NW <= 16, "row-scheduler marks");
+    static_assert(NT == 512, "the chunk loader maps 8 threads to each of the 64 surfaces");
+    uint32_t* tilebuf = frag + FRAG_SLOTS * (FMT8 ? 2 : 1);
+    float* tilez = reinterpret_cast<float*>(tilebuf + TILE_H * TILE_STRIDE);   // (the RGB555 transparent pass never writes it)
+    static_assert(!GATHER || BLEND_SORT_CAP * 2 <= FRAG_SLOTS, "the priority sort aliases the fragment buffer");
+    static_assert(NW * 8 <= 256, "wf");
     if (a.ctrl->abort || a.ctrl->need_global_sort) return;
     const FrameParams& fp = a.fp;
     const uint32_t tile = blockIdx.x;
@@ -1167,6 +1184,7 @@ __global__ __launch_bounds__(NT) void k_blend(FillArgs a) {
     if (GATHER) {
         // sort-free binning left the transparent entries [e1, e2) in arbitrary order: put them in painter's order (descending depth,
         // ties in face order, render.rs:2527-2532) by ranking the 64-bit priorities (key << 32 | face id) -- all distinct -- in LDS
+        unsigned long long* gprio = reinterpret_cast<unsigned long long*>(frag);
         const uint32_t n = e2 - e1;                    // <= BLEND_SORT_CAP (k_place_spans raised need_global_sort otherwise)
         for (uint32_t i = threadIdx.x; i < n; i += NT) { const uint32_t sid = a.pair_vals[e1 + i]; gprio[i] = ((unsigned long long)a.keys[sid] << 32) | sid; }
         __syncthreads();
@@ -1182,6 +1200,7 @@ __global__ __launch_bounds__(NT) void k_blend(FillArgs a) {
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const int shading = fp.shading;
+    const bool affine = fp.affine != 0;
     const uint32_t txi = tile % fp.tiles_x, tyi = tile / fp.tiles_x + fp.tile_y0;
     const uint32_t x_lo = txi * TILE_W, x_hi = min(x_lo + TILE_W, fp.width);
     const uint32_t ty_top = tyi * TILE_H;
@@ -1197,62 +1216,219 @@ __global__ __launch_bounds__(NT) void k_blend(FillArgs a) {
     unsigned long long frag_count = 0;
     const TexDesc none = { 0, 0, 0, 0 };
     const uint32_t n_tr = e2 - e1;
-    constexpr uint32_t RPW = TILE_H / NW;          // tile rows owned by one wave
+    constexpr uint32_t RPW = TILE_H / NW;          // tile rows owned by one wave in phase 2
     const uint32_t wy0 = max(ty_top + wave * RPW, y_lo), wy1 = min(ty_top + wave * RPW + RPW, y_hi);
-    for (uint32_t cs = 0; cs < n_tr; cs += 64) {
+    // The walk is split so that only what MUST be ordered is ordered.  A chunk = consecutive list entries whose clipped bounding
+    // boxes fit the fragment buffer.  Phase 1 (no order): the waves take the chunk's surfaces round-robin and evaluate every
+    // pixel of their bounding boxes -- inside test, texel, colour pipeline -- into fixed slots (16 texel-latency chains in flight
+    // per workgroup instead of one per row owner).  Phase 2 (painter's order): each wave owns a band of tile rows and applies the
+    // chunk's fragments to its rows surface after surface: LDS reads and the blend, no global memory.
+    for (uint32_t cs = 0; cs < n_tr; ) {
         const uint32_t cnt = min(64u, n_tr - cs);
-        Batch b;
-        load_batch<0>(b, a, e1 + cs + lane, lane < cnt, none, true);
-        const uint32_t my_sid = lane < cnt ? a.pair_vals[e1 + cs + lane] : 0;
-        // rows of this wave that each surface of the batch touches: most surfaces touch none of them, and the wave skips
-        // those without broadcasting their records (bit t of `mine` = surface t reaches rows [wy0, wy1) and columns of the tile)
-        const bool touches = lane < cnt && max(b.q2.x & 0xFFFF, wy0) < min(b.q2.x >> 16, wy1) && max(b.q1.w & 0xFFFF, x_lo) < min(b.q1.w >> 16, x_hi) &&
-                             (b.q3.w >> F_ALPHA_SHIFT) != 0;                     // editor_alpha == 0 draws nothing, render.rs:1664-1669
-        unsigned long long mine = __ballot(touches);
+        {   // stage the chunk's records in LDS once per workgroup: 8 threads per surface, 16 B each
+            const uint32_t sfc = tid >> 3, part = tid & 7;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (sfc < cnt) {
+                const uint32_t sid = a.pair_vals[e1 + cs + sfc];
+                const uint4* rp = reinterpret_cast<const uint4*>(a.recs + sid);
+                if (part < 6) v = rp[part];
+                else if (part == 6) {
+                    const uint32_t txid = rp[3].w & F_TEX_MASK;
+                    TexDesc d = none;
+                    if (txid != F_TEX_NONE) d = a.tex[txid];
+                    v = make_uint4(d.width, d.height, d.offset, sid);
+                }
+            }
+            srec[sfc * 8 + part] = v;
+        }
+        __syncthreads();
+        // lane <-> surface view of the chunk (every wave computes the same prefix sums)
+        const uint4 mq1 = srec[lane * 8 + 1], mq2 = srec[lane * 8 + 2], mq3 = srec[lane * 8 + 3];
+        const uint32_t my_flags = mq3.w;
+        // clipped bounding box of lane's surface in this tile (band rows only); editor_alpha == 0 draws nothing (render.rs:1664-1669)
+        const uint32_t bx0 = max(mq1.w & 0xFFFF, x_lo), bx1 = min(mq1.w >> 16, x_hi);
+        const uint32_t by0 = max(mq2.x & 0xFFFF, y_lo), by1 = min(mq2.x >> 16, y_hi);
+        const bool live = lane < cnt && bx0 < bx1 && by0 < by1 && (my_flags >> F_ALPHA_SHIFT) != 0;
+        const uint32_t area = live ? (bx1 - bx0) * (by1 - by0) : 0u;
+        uint32_t inc = area;
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(inc, off); if (lane >= (uint32_t)off) inc += t; }
+        // entries of this chunk: the longest prefix whose fragments fit (every wave computes the same answer)
+        const unsigned long long fits = __ballot(lane < cnt && inc <= FCAP);
+        const uint32_t take = fits == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~fits);   // >= 1: a single clipped box has at most 4096 pixels
+        const uint32_t foff = inc - area;                                // fragment slot base of lane's surface
+
+        // ---- phase 1: fragments.  Same ROW-ITEM scheduling as the coverage kernel: the work items of the chunk are the rows of the
+        // clipped boxes; in rounds of 64 every lane takes one row of some surface (rounds are dealt to the waves round-robin),
+        // fetches that surface's parameters over ds_bpermute and walks the row, evaluating texel + colour pipeline per pixel.
+        const bool in_chunk = live && lane < take;
+        const bool slow = in_chunk && (my_flags & F_SLOW);
+        const uint32_t h = (in_chunk && !slow) ? by1 - by0 : 0u;
+        uint32_t hinc = h;
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(hinc, off); if (lane >= (uint32_t)off) hinc += t; }
+        const uint32_t R = (uint32_t)__builtin_amdgcn_readlane((int)hinc, 63);
+        const uint32_t P = hinc - h;
+        const uint32_t box = (bx0 - x_lo) | ((bx1 - x_lo) << 8) | ((by0 - ty_top) << 16);
+        for (uint32_t k0 = wave * 64; k0 < R; k0 += NW * 64) {
+            const unsigned long long before = __ballot(h > 0 && P <= k0);
+            const uint32_t carry = before ? 64u - (uint32_t)__builtin_clzll(before) : 0u;
+            wmark[lane] = 0;
+            __builtin_amdgcn_wave_barrier();
+            if (h > 0 && P > k0 && P < k0 + 64) wmark[P - k0] = lane + 1;
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t own = max(dpp_max_scan(wmark[lane]), carry);
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t k = k0 + lane;
+            const bool valid = k < R;
+            const uint32_t sl = valid ? own - 1 : lane;
+            Tri tr;
+            const uint32_t sbox = bperm(sl, box), sP = bperm(sl, P), sbase = bperm(sl, foff);
+            const uint4 r0 = srec[sl * 8], r1 = srec[sl * 8 + 1], r2 = srec[sl * 8 + 2], r3 = srec[sl * 8 + 3], r4 = srec[sl * 8 + 4], r6 = srec[sl * 8 + 6];
+            tr.x3 = __uint_as_float(r0.x); tr.y3 = __uint_as_float(r0.y); tr.a0 = __uint_as_float(r0.z); tr.b0 = __uint_as_float(r0.w);
+            tr.a1 = __uint_as_float(r1.x); tr.b1 = __uint_as_float(r1.y); tr.inv_area = __uint_as_float(r1.z);
+            tr.u1 = __uint_as_float(r2.y); tr.u2 = __uint_as_float(r2.z); tr.u3 = __uint_as_float(r2.w);
+            tr.v1 = __uint_as_float(r3.x); tr.v2 = __uint_as_float(r3.y); tr.v3 = __uint_as_float(r3.z);
+            tr.flags = r3.w;
+            tr.tw = r6.x; tr.th = r6.y; tr.toff = r6.z;
+            tr.iz1 = tr.iz2 = tr.iz3 = 0.0f;
+            if (!affine || zmode) { const uint4 r5 = srec[sl * 8 + 5]; tr.iz1 = __uint_as_float(r5.y); tr.iz2 = __uint_as_float(r5.z); tr.iz3 = __uint_as_float(r5.w); }
+            const uint32_t vc1 = r4.x, vc2 = r4.y, vc3 = r4.z;
+            float shv[9];
+            if (shading != B32_SHADE_NONE) {
+                const uint32_t ssid = r6.w;
+                for (int j = 0; j < 9; ++j) shv[j] = valid ? a.shades[(size_t)ssid * 9 + j] : 0.0f;
+            }
+            const uint32_t rx0 = sbox & 0xFF, rx1 = (sbox >> 8) & 0xFF, ry = (sbox >> 16) + (k - sP);       // tile-local
+            const uint32_t n = valid ? rx1 - rx0 : 0u;
+            const uint32_t py = ry + ty_top;
+            const float dx = (float)(rx0 + x_lo) - tr.x3, dy = (float)py - tr.y3;
+            float w0 = tr.a0 * dx + tr.b0 * dy, w1 = tr.a1 * dx + tr.b1 * dy;                              // exact integers (k_setup guard)
+            uint32_t slot = sbase + (k - sP) * (rx1 - rx0);
+            for (uint32_t i = 0; __ballot(i < n); ++i) {
+                if (i < n) {
+                    const uint32_t px = rx0 + x_lo + i;
+                    float bcx, bcy, bcz;
+                    uint32_t v0 = 0, v1 = 0;
+                    if (inside_bc(tr, w0, w1, bcx, bcy, bcz)) {
+                        uint32_t texel;
+                        if (FMT8) {
+                            if (texel_drawn<0, true>(tr, bcx, bcy, bcz, reinterpret_cast<const uint16_t*>(a.texels32), nullptr, texel, affine)) {
+                                v0 = shade8(texel, bcx, bcy, bcz, vc1, vc2, vc3, tr.flags, shading, shv, px, py) | 0x80000000u;
+                                const float inv_z = bcx * tr.iz1 + bcy * tr.iz2 + bcz * tr.iz3;
+                                v1 = __float_as_uint(1.0f / inv_z);
+                            }
+                        } else if (ztest(tr, bcx, bcy, bcz, zmode, zmode ? tilez[ry * TILE_STRIDE + rx0 + i] : 0.0f) &&
+                                   texel_drawn<0>(tr, bcx, bcy, bcz, a.texels, nullptr, texel, affine)) {
+                            v0 = shade15(texel, bcx, bcy, bcz, vc1, vc2, vc3, tr.flags, shading, shv, px, py) | 0x10000u;
+                        }
+                    }
+                    if (FMT8) { frag[2 * slot] = v0; frag[2 * slot + 1] = v1; } else frag[slot] = v0;
+                    ++slot; w0 += tr.a0; w1 += tr.a1;
+                }
+            }
+        }
+        // surfaces whose edge walk must be replayed literally: one wave each, one lane per row
+        {
+            unsigned long long sm = __ballot(slow);
+            uint32_t idx = 0;
+            while (sm) {
+                const int t = __builtin_ctzll(sm);
+                sm &= sm - 1;
+                if ((idx++ % NW) != wave) continue;
+                Tri tr;
+                {
+                    const uint4 r0 = srec[t * 8], r1 = srec[t * 8 + 1], r2 = srec[t * 8 + 2], r3 = srec[t * 8 + 3], r4 = srec[t * 8 + 4], r5 = srec[t * 8 + 5], r6 = srec[t * 8 + 6];
+                    tr.x3 = __uint_as_float(r0.x); tr.y3 = __uint_as_float(r0.y); tr.a0 = __uint_as_float(r0.z); tr.b0 = __uint_as_float(r0.w);
+                    tr.a1 = __uint_as_float(r1.x); tr.b1 = __uint_as_float(r1.y); tr.inv_area = __uint_as_float(r1.z);
+                    tr.min_x = r1.w & 0xFFFF; tr.max_x = r1.w >> 16; tr.min_y = r2.x & 0xFFFF; tr.max_y = r2.x >> 16;
+                    tr.u1 = __uint_as_float(r2.y); tr.u2 = __uint_as_float(r2.z); tr.u3 = __uint_as_float(r2.w);
+                    tr.v1 = __uint_as_float(r3.x); tr.v2 = __uint_as_float(r3.y); tr.v3 = __uint_as_float(r3.z);
+                    tr.flags = r3.w;
+                    tr.w0_start = __uint_as_float(r4.w); tr.w1_start = __uint_as_float(r5.x);
+                    tr.iz1 = __uint_as_float(r5.y); tr.iz2 = __uint_as_float(r5.z); tr.iz3 = __uint_as_float(r5.w);
+                    tr.tw = r6.x; tr.th = r6.y; tr.toff = r6.z;
+                }
+                const uint32_t cx0 = bcu(bx0, t), cx1 = bcu(bx1, t), cy0 = bcu(by0, t), cy1 = bcu(by1, t);
+                const uint32_t base = bcu(foff, t), bw = cx1 - cx0;
+                const uint32_t vc1 = srec[t * 8 + 4].x, vc2 = srec[t * 8 + 4].y, vc3 = srec[t * 8 + 4].z;
+                const uint32_t sid = srec[t * 8 + 6].w;
+                float shv[9];
+                if (shading != B32_SHADE_NONE) for (int j = 0; j < 9; ++j) shv[j] = a.shades[(size_t)sid * 9 + j];
+                for (uint32_t ry = cy0; ry < cy1; ry += 64) {
+                    const uint32_t py = ry + lane;
+                    if (py < cy1) {
+                        float w0, w1;
+                        replay_w(tr, cx0, py, w0, w1);
+                        for (uint32_t px = cx0; px < cx1; ++px) {
+                            const uint32_t slot = base + (py - cy0) * bw + (px - cx0);
+                            float bcx, bcy, bcz;
+                            uint32_t v0 = 0, v1 = 0;
+                            if (inside_bc(tr, w0, w1, bcx, bcy, bcz)) {
+                                uint32_t texel;
+                                if (FMT8) {
+                                    if (texel_drawn<0, true>(tr, bcx, bcy, bcz, reinterpret_cast<const uint16_t*>(a.texels32), nullptr, texel, affine)) {
+                                        v0 = shade8(texel, bcx, bcy, bcz, vc1, vc2, vc3, tr.flags, shading, shv, px, py) | 0x80000000u;
+                                        const float inv_z = bcx * tr.iz1 + bcy * tr.iz2 + bcz * tr.iz3;
+                                        v1 = __float_as_uint(1.0f / inv_z);
+                                    }
+                                } else if (ztest(tr, bcx, bcy, bcz, zmode, zmode ? tilez[(py - ty_top) * TILE_STRIDE + (px - x_lo)] : 0.0f) &&
+                                           texel_drawn<0>(tr, bcx, bcy, bcz, a.texels, nullptr, texel, affine)) {
+                                    v0 = shade15(texel, bcx, bcy, bcz, vc1, vc2, vc3, tr.flags, shading, shv, px, py) | 0x10000u;
+                                }
+                            }
+                            if (FMT8) { frag[2 * slot] = v0; frag[2 * slot + 1] = v1; } else frag[slot] = v0;
+                            w0 += tr.a0; w1 += tr.a1;
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- phase 2: apply, in order, to the rows this wave owns (lanes = columns of the surface's box)
+        unsigned long long mine = __ballot(live && lane < take && max(by0, wy0) < min(by1, wy1));
         while (mine) {
             const uint32_t t = (uint32_t)__builtin_ctzll(mine);
             mine &= mine - 1;
-            const Tri tr = tri_from_batch(b, (int)t, true);
-            const uint32_t cx0 = max(tr.min_x, x_lo), cx1 = min(tr.max_x, x_hi);
-            const uint32_t cy0 = max(tr.min_y, wy0), cy1 = min(tr.max_y, wy1);
-            const uint32_t vc1 = bcu(b.q4.x, (int)t), vc2 = bcu(b.q4.y, (int)t), vc3 = bcu(b.q4.z, (int)t);
-            const uint32_t sid = bcu(my_sid, (int)t);
-            float shv[9];
-            if (shading != B32_SHADE_NONE) for (int j = 0; j < 9; ++j) shv[j] = a.shades[(size_t)sid * 9 + j];
-            if (!(tr.flags & F_SLOW)) {
-                for (uint32_t by = cy0; by < cy1; by += 4)
-                    for (uint32_t bx = cx0; bx < cx1; bx += 16) {
-                        const uint32_t px = bx + (lane & 15), py = by + (lane >> 4);
-                        bool drawn = false;
-                        if (px < cx1 && py < cy1) {
-                            float w0, w1, bcx, bcy, bcz;
-                            edge_w(tr, px, py, w0, w1);
-                            const uint32_t ti = (py - ty_top) * TILE_STRIDE + (px - x_lo);
-                            if (inside_bc(tr, w0, w1, bcx, bcy, bcz))
-                                drawn = blend_fragment<FMT8>(a, tr, bcx, bcy, bcz, px, py, vc1, vc2, vc3, shading, shv, &tilebuf[ti], &tilez[ti], zmode, xray);
+            const uint32_t cx0 = bcu(bx0, (int)t), cx1 = bcu(bx1, (int)t), cy0 = bcu(by0, (int)t), cy1 = bcu(by1, (int)t);
+            const uint32_t base = bcu(foff, (int)t), bw = cx1 - cx0, flags = bcu(my_flags, (int)t);
+            const uint32_t r0 = max(cy0, wy0), r1 = min(cy1, wy1);
+            // lanes = (row, column) of the box, 64 / 2^k rows per step with 2^k >= box width: a small triangle is one step
+            const uint32_t sh = bw <= 1 ? 0u : 32u - (uint32_t)__builtin_clz(bw - 1);      // log2 of the padded width
+            const uint32_t col = lane & ((1u << sh) - 1u), sub = lane >> sh, rows_per_step = 64u >> sh;
+            const uint32_t px = cx0 + col;
+            uint32_t drawn = 0;
+            for (uint32_t rb = r0; rb < r1; rb += rows_per_step) {
+                const uint32_t py = rb + sub;
+                const bool on = col < bw && py < r1;
+                const uint32_t slot = base + (py - cy0) * bw + col;
+                const uint32_t ti = (py - ty_top) * TILE_STRIDE + (px - x_lo);
+                if (FMT8) {
+                    const uint32_t colr = on ? frag[2 * slot] : 0u;
+                    if (!__ballot(colr & 0x80000000u)) continue;
+                    if (colr & 0x80000000u) {
+                        // rasterize_triangle (render.rs:1302-1424): the early reject and the store's own test collapse into one test
+                        // per store kind (they differ only for NaN depths); every store that passes writes the depth
+                        const uint32_t alpha = flags >> F_ALPHA_SHIFT;
+                        bool pass = true;
+                        if (zmode) {
+                            const float z = __uint_as_float(frag[2 * slot + 1]), zb = tilez[ti];
+                            pass = alpha < 255 ? !(z >= zb) : (z < zb);                  // render.rs:387 / :432, :1407
+                            if (pass) tilez[ti] = z;
                         }
-                        frag_count += (unsigned long long)__popcll(__ballot(drawn));
+                        if (pass) { tilebuf[ti] = store8(tilebuf[ti], colr & 0x7FFFFFFFu, alpha); ++drawn; }
                     }
-            } else {
-                const uint32_t py = cy0 + lane;            // RPW <= 64 rows
-                uint32_t mine = 0;
-                if (py < cy1) {
-                    float w0, w1;
-                    replay_w(tr, cx0, py, w0, w1);
-                    for (uint32_t px = cx0; px < cx1; ++px) {
-                        float bcx, bcy, bcz;
-                        const uint32_t ti = (py - ty_top) * TILE_STRIDE + (px - x_lo);
-                        if (inside_bc(tr, w0, w1, bcx, bcy, bcz) &&
-                            blend_fragment<FMT8>(a, tr, bcx, bcy, bcz, px, py, vc1, vc2, vc3, shading, shv, &tilebuf[ti], &tilez[ti], zmode, xray)) ++mine;
-                        w0 += tr.a0; w1 += tr.a1;
-                    }
+                } else {
+                    const uint32_t v = on ? frag[slot] : 0u;
+                    if (!__ballot(v & 0x10000u)) continue;
+                    if (v & 0x10000u) { tilebuf[ti] = store_blend(tilebuf[ti], v & 0xFFFFu, flags, xray); ++drawn; }
                 }
-                for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
-                frag_count += (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)mine);
             }
+            for (int off = 32; off > 0; off >>= 1) drawn += __shfl_down(drawn, off);
+            frag_count += (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)drawn);
         }
+        __syncthreads();                                // the fragment buffer is reused by the next chunk
+        cs += take;
     }
-    __syncthreads();
     for (uint32_t p = tid; p < TILE_W * TILE_H; p += NT) {      // finished tile back, one 256-B row segment per wave instruction
         const uint32_t row = p >> 6, col = p & 63;
         const uint32_t px = x_lo + col, py = ty_top + row;
@@ -1270,6 +1446,16 @@ __global__ __launch_bounds__(NT) void k_blend(FillArgs a) {
     }
 }
 
+constexpr int BLEND_NT = 512;        // 8 waves: with ~80 VGPRs three workgroups fit a CU (the 1024-thread form only ever fit one)
+template <bool FMT8, bool GATHER>
+static void launch_blend(hipStream_t s, const FillArgs& a, uint32_t ntiles) {
+    const bool zmode = a.fp.zmode && !a.fp.xray;
+    const size_t lds = blend_lds_bytes(FMT8, zmode);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_blend<BLEND_NT, FMT8, GATHER>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    hipLaunchKernelGGL((k_blend<BLEND_NT, FMT8, GATHER>), dim3(ntiles), dim3(BLEND_NT), lds, s, a);
+}
+
 void launch_fill(hipStream_t s, const FillArgs& a, int n_cu, hipEvent_t after_cover) {
     const uint32_t ntiles = a.fp.tiles_x * a.fp.tiles_y;
     if (ntiles == 0) return;
@@ -1277,8 +1463,8 @@ void launch_fill(hipStream_t s, const FillArgs& a, int n_cu, hipEvent_t after_co
     const bool f8 = a.fp.fmt8 != 0;
     if (a.ordered_all) {                                         // no overwrite pass at all: everything goes through the ordered walk
         if (after_cover) (void)hipEventRecord(after_cover, s);
-        if (f8) hipLaunchKernelGGL((k_blend<1024, true>), dim3(ntiles), dim3(1024), 0, s, a);
-        else hipLaunchKernelGGL((k_blend<1024, false>), dim3(ntiles), dim3(1024), 0, s, a);
+        if (f8) launch_blend<true, false>(s, a, ntiles);
+        else launch_blend<false, false>(s, a, ntiles);
         return;
     }
     const size_t lds_sort = LDS_TEX_OFFSET + LDS_SORT_CNT_BYTES + 2048;
@@ -1298,7 +1484,7 @@ void launch_fill(hipStream_t s, const FillArgs& a, int n_cu, hipEvent_t after_co
             if (f8) hipLaunchKernelGGL((k_cover<0, false, 512, true, true, true>), dim3(min(ntiles, (uint32_t)n_cu * 2)), dim3(512), lds64, s, a);
             else hipLaunchKernelGGL((k_cover<0, false, 512, true, false, true>), dim3(min(ntiles, (uint32_t)n_cu * 2)), dim3(512), lds64, s, a);
             if (after_cover) (void)hipEventRecord(after_cover, s);
-            if (a.gather_blend) hipLaunchKernelGGL((k_blend<1024, false, true>), dim3(ntiles), dim3(1024), 0, s, a);
+            if (a.gather_blend) launch_blend<false, true>(s, a, ntiles);
             return;
         }
         static const int nt64 = getenv("B32_P64_NT") ? atoi(getenv("B32_P64_NT")) : 512;
@@ -1312,7 +1498,7 @@ void launch_fill(hipStream_t s, const FillArgs& a, int n_cu, hipEvent_t after_co
         if (f8) hipLaunchKernelGGL((k_cover<0, false, 512, false, true, true>), dim3(min(ntiles, (uint32_t)n_cu * 2)), dim3(512), lds64, s, a);
         else hipLaunchKernelGGL((k_cover<0, false, 512, false, false, true>), dim3(min(ntiles, (uint32_t)n_cu * 2)), dim3(512), lds64, s, a);
         if (after_cover) (void)hipEventRecord(after_cover, s);
-        if (a.gather_blend) hipLaunchKernelGGL((k_blend<1024, false, true>), dim3(ntiles), dim3(1024), 0, s, a);
+        if (a.gather_blend) launch_blend<false, true>(s, a, ntiles);
         return;                                                  // coverage and shading are one kernel on this path
     } else if (a.fp.zmode) {
         if (f8) hipLaunchKernelGGL((k_cover<0, true, 512, true, true>), dim3(min(ntiles, (uint32_t)n_cu * 3)), dim3(512), lds_sort, s, a);
@@ -1338,7 +1524,7 @@ void launch_fill(hipStream_t s, const FillArgs& a, int n_cu, hipEvent_t after_co
         if (f8) hipLaunchKernelGGL((k_shade<true>), g, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((k_shade<false>), g, dim3(256), 0, s, a);
     }
-    if (a.may_blend && !f8) hipLaunchKernelGGL((k_blend<1024, false>), dim3(ntiles), dim3(1024), 0, s, a);
+    if (a.may_blend && !f8) launch_blend<false, false>(s, a, ntiles);
 }
 
 size_t fill_lds_tex_budget() { return 160 * 1024 - LDS_TEX_OFFSET - 16; }
