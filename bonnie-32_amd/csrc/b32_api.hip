@@ -522,6 +522,7 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     const bool wire_back = st->backface_cull && st->backface_wireframe;      // render.rs:2577
     const bool wire_front = st->wireframe_overlay != 0;                       // render.rs:2603 (an empty list draws nothing either way)
     fp.wire_collect = (wire_back || wire_front) ? 1 : 0;
+    fp.band_only = 0;
     const uint32_t ntiles = fp.tiles_x * fp.tiles_y;
     const uint32_t n_keys = 2 * ntiles;
     int rc;
@@ -593,11 +594,6 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
         ev = c->ev[c->ev_frames % EV_RING];
     }
 
-    if (c->nf == 0) HIPCHK(c, hipMemsetAsync(c->d_ctrl, 0, sizeof(Ctrl), s));    // otherwise k_setup resets it
-    if (prof_all) HIPCHK(c, hipEventRecord(ev[0], s));
-    launch_setup(s, fp, c->d_verts, c->d_faces, c->d_tex, c->d_lights, c->recs, c->shades, c->keys[0], c->spans, c->partials, c->d_ctrl, c->wire);
-    if (prof_all) HIPCHK(c, hipEventRecord(ev[1], s));
-
     const SortScratch sc{ c->block_hist, c->hist_blocks, c->digit_total };
     // z-buffer frames without a transparent pass take the sort-free fused path too (depth is the priority); otherwise z-buffer
     // mode applies depth + skip rule per fragment (EXACT coverage)
@@ -613,6 +609,12 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     c->last_local_sort = local_sort;
     c->last_exact = ordered_all ? true : (exact_cov && !fp.zmode);          // the ordered walk counts every store it performs
     const bool want_prio64 = (local_sort || zfast) && spans_ok;     // max-of-priorities coverage: no tile list order needed
+    if (c->nf == 0) HIPCHK(c, hipMemsetAsync(c->d_ctrl, 0, sizeof(Ctrl), s));    // otherwise k_setup resets it
+    if (prof_all) HIPCHK(c, hipEventRecord(ev[0], s));
+    fp.band_only = (want_prio64 && c->band_set) ? 1 : 0;   // other ranks own the other rows: their surfaces' records are never read here
+    launch_setup(s, fp, c->d_verts, c->d_faces, c->d_tex, c->d_lights, c->recs, c->shades, c->keys[0], c->spans, c->partials, c->d_ctrl, c->wire);
+    if (prof_all) HIPCHK(c, hipEventRecord(ev[1], s));
+
     int cur = 0;
     bool prio64 = false;
     if (want_prio64) {

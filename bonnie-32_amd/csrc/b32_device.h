@@ -101,7 +101,8 @@ struct FrameParams {
     uint32_t n_lights;
     float ambient;
     uint8_t affine, shading, backface_cull, dithering, fixed_point, has_fog, zmode, fmt8;   // zmode = settings.use_zbuffer; fmt8 = render_mesh (8-bit colour)
-    uint8_t ortho, xray, wire_collect, pad2;   // ortho_projection.is_some(), xray_mode, any wireframe phase wants its triangles
+    uint8_t ortho, xray, wire_collect, band_only;   // ortho_projection.is_some(), xray_mode, any wireframe phase wants its triangles;
+                                                    // band_only: records of surfaces outside this rank's band are not needed (sort-free path)
     float ortho_zoom, ortho_cx, ortho_cy;      // OrthoProjection (types.rs), math.rs:140-148
     B32Fog fog;
     CamFx camfx;

@@ -257,9 +257,12 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp, const B32Vertex* 
                 r.flags = (have_tex ? tid : F_TEX_NONE) | (black_tr ? F_BLACK_TR : 0) | (eff_blend << F_BLEND_SHIFT) |
                           (needs_dither ? F_DITHER : 0) | (slow ? F_SLOW : 0) | (transparent ? F_TRANSP : 0) |
                           (empty ? F_EMPTY : 0) | (editor_alpha << F_ALPHA_SHIFT);
-                recs[f] = r;
                 span = pack_tile_span(r.bbx, r.bby, r.flags, fp, n_tiles);
-                if (fp.shading != B32_SHADE_NONE) {
+                // multi-GPU band sharding: every rank decides visibility for every face (triangles_drawn, painter's keys), but only the
+                // surfaces reaching its own rows are ever read again
+                const bool need_rec = !fp.band_only || n_tiles != 0;
+                if (need_rec) recs[f] = r;
+                if (need_rec && fp.shading != B32_SHADE_NONE) {
                     V3 wn[3];
 #pragma unroll
                     for (int j = 0; j < 3; ++j) {
