@@ -883,7 +883,7 @@ __device__ __forceinline__ void rec_load(const FillArgs& a, uint32_t sid, bool n
     const uint4* rp = reinterpret_cast<const uint4*>(a.recs + sid);
     r.q0 = rp[0]; r.q1 = rp[1]; r.q2 = rp[2]; r.q3 = rp[3]; r.q4 = rp[4];
     r.q5 = make_uint4(0, 0, 0, 0);
-    if (need5) r.q5 = rp[5];
+    if (need5 || (r.q3.w & F_SLOW)) r.q5 = rp[5];                // literal-replay start value w1_start lives in q5
 }
 // inside test + texel address (index into the texel pool; -1 = untextured -> white, -2 = zero-size texture -> transparent)
 __device__ __forceinline__ bool hit_prepare(const FillArgs& a, const RecRegs& r, uint32_t px, uint32_t py, Hit& h, int& taddr) {

@@ -535,3 +535,85 @@ def test_cpp_host_mirror_end_to_end(tmp_path):
     gold = np.load(os.path.join(GOLD, "cube_frame.npz"))["rgba"]
     assert np.array_equal(got, gold)
     assert "triangles_drawn 10" in r.stdout
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_hostile_geometry_every_path(gpu_ctx, oracle, seed):
+    """Adversarial inputs through every scheduling path (sort-free fused painter's / z-buffer, transparent pass, instrumented,
+    float projection, ortho): positions from 1e-3 to 1e30 and +-inf, coordinates that saturate the 4.12 conversion and the
+    `as i32` / `as usize` casts, degenerate and sliver triangles, huge on-screen triangles (every tile), wild UVs (1e9, inf,
+    NaN), vertices exactly on / behind the near plane.  NaN positions are excluded only where the reference itself panics
+    (NaN sort key).  Bit-exact framebuffers and depth buffers, no hang."""
+    from bonnie32_amd import rasterizer as R
+    rng = np.random.default_rng(seed)
+    n = 900
+    v = b32.make_vertices(3 * n); f = b32.make_faces(n, texture_id=0)
+    f["v"] = np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+    z = rng.uniform(0.5, 400.0, n).astype(np.float32)
+    scale = (10.0 ** rng.uniform(-1, 2.5, n)).astype(np.float32)
+    for k in range(3):
+        v["pos"][k::3, 0] = rng.normal(0, 1, n) * scale * (z / 4)
+        v["pos"][k::3, 1] = rng.normal(0, 1, n) * scale * (z / 4)
+        v["pos"][k::3, 2] = z * (1 + rng.normal(0, 0.2, n))
+    big = rng.choice(3 * n, 60, replace=False)
+    v["pos"][big[:20], 0] = (10.0 ** rng.uniform(5, 30, 20)) * rng.choice([-1, 1], 20)
+    v["pos"][big[20:30], 1] = np.inf
+    v["pos"][big[30:40], 1] = -np.inf
+    v["pos"][big[40:50], 2] = 10.0 ** rng.uniform(6, 30, 10)
+    v["pos"][big[50:60], 2] = rng.choice([0.1, 0.100001, 0.0999, -3.0, 0.0], 10)          # near plane (math.rs:155)
+    v["pos"][90:93] = v["pos"][93:96]                                                      # degenerate
+    v["pos"][96:99, :2] = [[-9000, -7000], [9000, -7000], [0, 9000]]; v["pos"][96:99, 2] = 40.0   # covers the whole screen
+    v["uv"] = rng.uniform(-3, 3, (3 * n, 2)).astype(np.float32)
+    v["uv"][rng.choice(3 * n, 40, replace=False)] = [1e9, -1e9]
+    v["uv"][rng.choice(3 * n, 10, replace=False), 0] = np.inf
+    v["uv"][rng.choice(3 * n, 10, replace=False), 1] = np.nan
+    v["r"], v["g"], v["b"] = rng.integers(0, 256, (3, 3 * n), dtype=np.uint8)
+    f["black_transparent"][::3] = 0
+    f["texture_id"][::9] = b32.abi.NO_TEXTURE
+    tex = b32.Texture15(64, 32, rng.integers(1, 0x8000, 64 * 32).astype(np.uint16))
+    tex.pixels[::97] = 0
+    blend_faces = f.copy(); blend_faces["blend_mode"][::6] = b32.abi.ADD; blend_faces["editor_alpha"][1::10] = 90
+    cam = b32.Camera(position=(3.0, -2.0, -1.0), basis_x=(0.8, 0.0, -0.6), basis_y=(0.0, 1.0, 0.0), basis_z=(0.6, 0.0, 0.8))
+    W, H = 400, 300
+    bench = b32.RasterSettings.benchmark
+    variants = [
+        ("painter", f, bench(), 0), ("painter-nocull", f, b32.RasterSettings(use_zbuffer=False, shading=0, lights=[], backface_wireframe=False, backface_cull=False), 0),
+        ("zbuffer-gouraud", f, b32.RasterSettings.game(), 0), ("transparent", blend_faces, bench(), 0),
+        ("transparent-z", blend_faces, b32.RasterSettings.game(), 0), ("instrumented", blend_faces, bench(), 1),
+        ("float", f, b32.RasterSettings(use_zbuffer=False, shading=0, lights=[], backface_wireframe=False, use_fixed_point=False), 0),
+        ("ortho", f, b32.RasterSettings(use_zbuffer=False, shading=0, lights=[], backface_wireframe=False, ortho_projection=(0.7, 1.0, -2.0)), 0),
+        ("default+wire", f, b32.RasterSettings(), 0),
+    ]
+    # the same geometry through the 8-bit-colour path: opaque/erase texels (overwrite pipeline) and blending texels (ordered walk)
+    tex8 = b32.Texture.from_texture15(tex)
+    tex8b = b32.Texture.from_texture15(tex); tex8b.pixels[::5, 3] = 1 + (np.arange(len(tex8b.pixels[::5])) % 4)
+    z8 = b32.RasterSettings(backface_wireframe=False, use_rgb555=False)
+    p8 = b32.RasterSettings(use_zbuffer=False, shading=0, lights=[], backface_wireframe=False, use_rgb555=False)
+    variants += [("8bit-painter", f, p8, 0, tex8), ("8bit-z-gouraud", f, z8, 0, tex8), ("8bit-blend-painter", blend_faces, p8, 0, tex8b),
+                 ("8bit-blend-z", blend_faces, z8, 0, tex8b), ("8bit-instrumented", f, p8, 1, tex8)]
+    for name, faces, st, counting, *t8 in variants:
+        ofb = oracle.Framebuffer(W, H); ofb.clear(b32.Color(9, 8, 7))
+        if t8:
+            rc, etm = oracle.render_mesh(ofb, v, faces, t8, cam, st)
+            gpu_draw = lambda fb: R.render_mesh(fb, v, faces, t8, cam, st)
+        else:
+            rc, etm = oracle.render_mesh_15(ofb, v, faces, [tex], cam, st)
+            gpu_draw = lambda fb: R.render_mesh_15(fb, v, faces, [tex], cam, st)
+        gpu_ctx.set_fragment_counting(counting)
+        try:
+            fb = R.Framebuffer(W, H, gpu_ctx); fb.clear(b32.Color(9, 8, 7))
+            if rc != 0:                                           # e.g. a wireframe edge longer than 2^30 px: both sides refuse
+                with pytest.raises(R.B32Error) as e:
+                    gpu_draw(fb)
+                assert e.value.code == rc, name
+                continue
+            tm = gpu_draw(fb)
+            got = fb.pixels
+            assert np.array_equal(got, ofb.pixels), f"{name}: {int((got != ofb.pixels).sum())} bytes differ"
+            assert tm.triangles_drawn == etm.triangles_drawn, name
+            if st.use_zbuffer:
+                assert np.array_equal(fb.zbuffer.view(np.uint32), ofb.zbuffer.view(np.uint32)), name
+            if counting:
+                assert tm.fragments == etm.fragments, name
+        finally:
+            gpu_ctx.set_fragment_counting(1)
