@@ -557,8 +557,8 @@ def test_hostile_geometry_every_path(gpu_ctx, oracle, seed):
         v["pos"][k::3, 2] = z * (1 + rng.normal(0, 0.2, n))
     big = rng.choice(3 * n, 60, replace=False)
     v["pos"][big[:20], 0] = (10.0 ** rng.uniform(5, 30, 20)) * rng.choice([-1, 1], 20)
-    v["pos"][big[20:30], 1] = np.inf
-    v["pos"][big[30:40], 1] = -np.inf
+    v["pos"][big[20:30], 1] = 3.0e38                       # (+-inf would give inf * 0 = NaN keys: checked separately below)
+    v["pos"][big[30:40], 1] = -3.0e38
     v["pos"][big[40:50], 2] = 10.0 ** rng.uniform(6, 30, 10)
     v["pos"][big[50:60], 2] = rng.choice([0.1, 0.100001, 0.0999, -3.0, 0.0], 10)          # near plane (math.rs:155)
     v["pos"][90:93] = v["pos"][93:96]                                                      # degenerate
@@ -591,6 +591,7 @@ def test_hostile_geometry_every_path(gpu_ctx, oracle, seed):
     p8 = b32.RasterSettings(use_zbuffer=False, shading=0, lights=[], backface_wireframe=False, use_rgb555=False)
     variants += [("8bit-painter", f, p8, 0, tex8), ("8bit-z-gouraud", f, z8, 0, tex8), ("8bit-blend-painter", blend_faces, p8, 0, tex8b),
                  ("8bit-blend-z", blend_faces, z8, 0, tex8b), ("8bit-instrumented", f, p8, 1, tex8)]
+    refused = 0
     for name, faces, st, counting, *t8 in variants:
         ofb = oracle.Framebuffer(W, H); ofb.clear(b32.Color(9, 8, 7))
         if t8:
@@ -606,6 +607,7 @@ def test_hostile_geometry_every_path(gpu_ctx, oracle, seed):
                 with pytest.raises(R.B32Error) as e:
                     gpu_draw(fb)
                 assert e.value.code == rc, name
+                refused += 1
                 continue
             tm = gpu_draw(fb)
             got = fb.pixels
@@ -617,3 +619,11 @@ def test_hostile_geometry_every_path(gpu_ctx, oracle, seed):
                 assert tm.fragments == etm.fragments, name
         finally:
             gpu_ctx.set_fragment_counting(1)
+    assert refused <= 2, "the scene is meant to be drawn, not refused"
+    # an infinite coordinate: inf * 0 = NaN camera depth -> NaN painter's key -> the reference panics; same verdict on both sides
+    vi = v.copy(); vi["pos"][96, 1] = np.inf          # a vertex of the screen-filling triangle (never near-culled)
+    nocull = b32.RasterSettings(use_zbuffer=False, shading=0, lights=[], backface_wireframe=False, backface_cull=False)
+    assert oracle.render_mesh_15(oracle.Framebuffer(W, H), vi, f, [tex], cam, nocull)[0] == b32.abi.B32_E_NAN_KEY
+    with pytest.raises(R.B32Error) as e:
+        R.render_mesh_15(R.Framebuffer(W, H, gpu_ctx), vi, f, [tex], cam, nocull)
+    assert e.value.code == b32.abi.B32_E_NAN_KEY

@@ -116,3 +116,58 @@ def test_rmw_two_meshes(oracle):
     keep = fb.pixels.copy()
     rc, tm = oracle.render_mesh_15(fb, b32.make_vertices(0), b32.make_faces(0), [], a.camera, a.settings)
     assert rc == 0 and tm.triangles_drawn == 0 and np.array_equal(keep, fb.pixels)
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_two_restatements_agree_on_hostile_geometry(oracle, seed):
+    """oracle/b32_oracle.c vs oracle/np_model.py on inputs at the edges of the Rust semantics both restate: saturating casts,
+    coordinates of 1e30 / +-inf, NaN and 1e9 UVs, degenerate and screen-filling triangles, near-plane vertices."""
+    import bonnie32_amd as b32
+    from oracle import np_model as M
+    rng = np.random.default_rng(seed)
+    n = 260
+    v = b32.make_vertices(3 * n); f = b32.make_faces(n, texture_id=0)
+    f["v"] = np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+    z = rng.uniform(0.5, 400.0, n).astype(np.float32)
+    scale = (10.0 ** rng.uniform(-1, 2.5, n)).astype(np.float32)
+    for k in range(3):
+        v["pos"][k::3, 0] = rng.normal(0, 1, n) * scale * (z / 4)
+        v["pos"][k::3, 1] = rng.normal(0, 1, n) * scale * (z / 4)
+        v["pos"][k::3, 2] = z * (1 + rng.normal(0, 0.2, n))
+    big = rng.choice(3 * n, 48, replace=False)
+    v["pos"][big[:16], 0] = (10.0 ** rng.uniform(5, 30, 16)) * rng.choice([-1, 1], 16)
+    v["pos"][big[16:24], 1] = np.inf
+    v["pos"][big[24:32], 1] = -np.inf
+    v["pos"][big[32:40], 2] = 10.0 ** rng.uniform(6, 30, 8)
+    v["pos"][big[40:48], 2] = rng.choice([0.1, 0.100001, 0.0999, -3.0, 0.0], 8)
+    v["pos"][30:33] = v["pos"][33:36]
+    v["pos"][36:39, :2] = [[-9000, -7000], [9000, -7000], [0, 9000]]; v["pos"][36:39, 2] = 40.0
+    v["uv"] = rng.uniform(-3, 3, (3 * n, 2)).astype(np.float32)
+    v["uv"][rng.choice(3 * n, 20, replace=False)] = [1e9, -1e9]
+    v["uv"][rng.choice(3 * n, 6, replace=False), 0] = np.inf
+    v["uv"][rng.choice(3 * n, 6, replace=False), 1] = np.nan
+    v["r"], v["g"], v["b"] = rng.integers(0, 256, (3, 3 * n), dtype=np.uint8)
+    f["black_transparent"][::3] = 0
+    f["blend_mode"][::6] = b32.abi.ADD; f["editor_alpha"][1::10] = 90
+    tex = b32.Texture15(64, 32, rng.integers(1, 0x8000, 64 * 32).astype(np.uint16)); tex.pixels[::97] = 0
+    cam = b32.Camera(position=(3.0, -2.0, -1.0), basis_x=(0.8, 0.0, -0.6), basis_y=(0.0, 1.0, 0.0), basis_z=(0.6, 0.0, 0.8))
+    W, H = 160, 120
+    # +-inf positions give inf * 0 = NaN camera coordinates -> NaN painter's key -> the reference panics: both restatements must say so
+    fbn = oracle.Framebuffer(W, H)
+    assert oracle.render_mesh_15(fbn, v, f, [tex], cam, b32.RasterSettings.benchmark())[0] == b32.abi.B32_E_NAN_KEY
+    with pytest.raises(FloatingPointError), np.errstate(all="ignore"):
+        M.render_mesh_15(np.zeros(W * H * 4, np.uint8), W, H, v, f, [tex], cam, b32.RasterSettings.benchmark())
+    v["pos"][np.isinf(v["pos"])] = 3.0e38
+    for st in (b32.RasterSettings.benchmark(), b32.RasterSettings.game(),
+               b32.RasterSettings(use_zbuffer=False, shading=0, lights=[], backface_wireframe=False, use_fixed_point=False, affine_textures=False)):
+        fb = oracle.Framebuffer(W, H); fb.clear(b32.Color(9, 8, 7))
+        rc, tm, d = oracle.render_mesh_15(fb, v, f, [tex], cam, st, dump=True)
+        assert rc == 0
+        px = np.zeros(W * H * 4, np.uint8); px.reshape(-1, 4)[:] = [9, 8, 7, 255]
+        zb = np.full(W * H, np.finfo(np.float32).max, np.float32)
+        with np.errstate(all="ignore"):
+            r = M.render_mesh_15(px, W, H, v, f, [tex], cam, st, zbuffer=zb)
+        assert np.array_equal(px, fb.pixels), f"{int((px != fb.pixels).sum())} bytes differ"
+        if st.use_zbuffer:
+            assert np.array_equal(zb.view(np.uint32), fb.zbuffer.view(np.uint32))
+        assert np.array_equal(r["draw_order"], d["draw_order"]) and r["triangles_drawn"] == tm.triangles_drawn and r["fragments"] == tm.fragments
