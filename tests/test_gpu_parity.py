@@ -627,3 +627,13 @@ def test_hostile_geometry_every_path(gpu_ctx, oracle, seed):
     with pytest.raises(R.B32Error) as e:
         R.render_mesh_15(R.Framebuffer(W, H, gpu_ctx), vi, f, [tex], cam, nocull)
     assert e.value.code == b32.abi.B32_E_NAN_KEY
+
+
+def test_four_million_triangles(fast_ctx, oracle):
+    """Four times the BASELINE triangle count (C4's whole-node load on one GPU): capacities grow on demand (pair buffers are
+    re-sized and the frame redrawn on overflow), ids and offsets stay within 32 bits, frame still bit-exact."""
+    sc = scenegen.make_scene("C3", n_tris=4_000_000, seed=123)
+    exp, etm, d = cpu_render(oracle, sc)
+    got, tm = gpu_render(fast_ctx, sc, resident=True)
+    assert np.array_equal(got, exp)
+    assert tm.triangles_drawn == etm.triangles_drawn == 1938655
