@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <vector>
 
@@ -71,6 +72,8 @@ struct b32_ctx {
     uint32_t *wire_owner = nullptr, *wire_first = nullptr; size_t cap_wire_table = 0;
     // control
     Ctrl* d_ctrl = nullptr; uint32_t* d_consts = nullptr; Ctrl h_ctrl{};
+    uint32_t h_consts[4] = { 0, 0, 0, 0 };   // staging for d_consts (outlives the async copy)
+    bool defer_upload_sync = false;            // drop-in calls: the frame's own synchronisation covers the uploads
     B32Light* d_lights = nullptr; size_t cap_lights = 0; std::vector<B32Light> h_lights;
 
     // last enqueued frame (for redraw after a pair overflow)
@@ -359,9 +362,11 @@ static int upload_geometry(b32_ctx* c, const B32Vertex* v, uint32_t nv, const B3
         if ((rc = ensure_plain(c, c->block_sums, (size_t)c->bin_blocks + 1))) return rc;
         c->cap_work = n;
     }
-    const uint32_t consts[4] = { nf, 0, 0, 0 };
-    HIPCHK(c, hipMemcpyAsync(c->d_consts, consts, sizeof(consts), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->h_consts[0] = nf;
+    HIPCHK(c, hipMemcpyAsync(c->d_consts, c->h_consts, sizeof(c->h_consts), hipMemcpyHostToDevice, c->stream));
+    // the caller may reuse its host buffers as soon as an upload call returns; the drop-in render calls return only after
+    // b32_frame_finish has synchronised the stream, so they skip this extra round trip
+    if (!c->defer_upload_sync) HIPCHK(c, hipStreamSynchronize(c->stream));
     return B32_OK;
 }
 
@@ -783,23 +788,27 @@ int b32_frame_finish(b32_ctx* c, B32Timings* out) {
     return B32_OK;
 }
 
+// RasterTimings of a synchronous call: the per-phase split comes from HIP events when b32_set_profiling(ctx, 2) is on; otherwise
+// (events cost ~40 us per small call) the wall time of the whole call is reported as draw_ms, like the reference's get_time() deltas.
+static void wall_timing(b32_ctx* c, B32Timings* out, std::chrono::steady_clock::time_point t0) {
+    if (!out || c->profile_level >= 2) return;
+    out->draw_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
 int b32_render_scene_15(b32_ctx* c, const B32Camera* cam, const B32Settings* st, const B32Fog* fog, B32Timings* out) {
     if (!c) return B32_E_ARG;
-    const int saved = c->profile_level;
-    if (out) c->profile_level = 2;                    // RasterTimings wants every phase
+    const auto t0 = std::chrono::steady_clock::now();
     int rc = b32_render_scene_15_async(c, cam, st, fog);
     if (rc == B32_OK) rc = b32_frame_finish(c, out);
-    c->profile_level = saved;
+    if (rc == B32_OK) wall_timing(c, out, t0);
     return rc;
 }
 
 int b32_render_scene(b32_ctx* c, const B32Camera* cam, const B32Settings* st, B32Timings* out) {
     if (!c) return B32_E_ARG;
-    const int saved = c->profile_level;
-    if (out) c->profile_level = 2;
+    const auto t0 = std::chrono::steady_clock::now();
     int rc = b32_render_scene_async(c, cam, st);
     if (rc == B32_OK) rc = b32_frame_finish(c, out);
-    c->profile_level = saved;
+    if (rc == B32_OK) wall_timing(c, out, t0);
     return rc;
 }
 
@@ -808,8 +817,13 @@ int b32_render_mesh(b32_ctx* c, const B32Vertex* v, uint32_t nv, const B32Face* 
     if (!c || !cam || !st || !c->fb) return B32_E_ARG;
     int rc = validate_settings(st);
     if (rc) return rc;
-    if ((rc = b32_scene_upload_rgba(c, v, nv, f, nf, tex, nt))) return rc;
-    return b32_render_scene(c, cam, st, out);
+    c->defer_upload_sync = true;
+    rc = b32_scene_upload_rgba(c, v, nv, f, nf, tex, nt);
+    c->defer_upload_sync = false;
+    if (rc) { (void)hipStreamSynchronize(c->stream); return rc; }
+    rc = b32_render_scene(c, cam, st, out);
+    if (rc != B32_OK) (void)hipStreamSynchronize(c->stream);      // the caller's buffers must be free of pending copies on every exit
+    return rc;
 }
 
 int b32_render_mesh_15(b32_ctx* c, const B32Vertex* v, uint32_t nv, const B32Face* f, uint32_t nf, const B32Texture15* tex, uint32_t nt,
@@ -817,8 +831,13 @@ int b32_render_mesh_15(b32_ctx* c, const B32Vertex* v, uint32_t nv, const B32Fac
     if (!c || !cam || !st || !c->fb) return B32_E_ARG;
     int rc = validate_settings(st);
     if (rc) return rc;
-    if ((rc = b32_scene_upload(c, v, nv, f, nf, tex, nt))) return rc;
-    return b32_render_scene_15(c, cam, st, fog, out);
+    c->defer_upload_sync = true;
+    rc = b32_scene_upload(c, v, nv, f, nf, tex, nt);
+    c->defer_upload_sync = false;
+    if (rc) { (void)hipStreamSynchronize(c->stream); return rc; }
+    rc = b32_render_scene_15(c, cam, st, fog, out);
+    if (rc != B32_OK) (void)hipStreamSynchronize(c->stream);      // the caller's buffers must be free of pending copies on every exit
+    return rc;
 }
 
 // ------------------------------------------------------------------ stage taps

@@ -273,6 +273,77 @@ __global__ __launch_bounds__(256) void k_place_spans(uint32_t nf, uint32_t ntile
     }
 }
 
+// Meshes of at most SPAN_BLOCK faces (what the reference's callers submit per room / asset part): count, scan and place in ONE
+// single-workgroup launch -- the block's own histogram is the whole histogram.
+__global__ __launch_bounds__(256) void k_bin_small(uint32_t nf, uint32_t ntiles, uint32_t tiles_x, const uint32_t* __restrict__ spans,
+                                                   const uint32_t* __restrict__ keys, const uint32_t* __restrict__ partials, uint32_t npart,
+                                                   Ctrl* __restrict__ ctrl, uint32_t pair_cap, uint32_t* __restrict__ ranges,
+                                                   uint32_t* __restrict__ tile_mid, uint32_t blend_cap, uint32_t* __restrict__ pair_vals) {
+    __shared__ uint32_t hist[SPAN_MAX_TILES];
+    __shared__ uint32_t dws[4], dmx[4];
+    __shared__ uint32_t total_s;
+    reduce_setup_partials(ctrl, partials, npart);              // frame counters / abort decision (ends with a barrier)
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t nrows = keys ? 2 * ntiles : ntiles;
+    for (uint32_t t = threadIdx.x; t < nrows; t += 256) hist[t] = 0;
+    __syncthreads();
+    for (uint32_t f = threadIdx.x; f < nf; f += 256) {
+        const uint32_t span = spans[f];
+        if (span == 0xFFFFFFFFu) continue;
+        const uint32_t row0 = (keys && (keys[f] >> 31)) ? ntiles : 0u;
+        const uint32_t tx0 = span & 0xFF, tx1 = (span >> 8) & 0xFF, ty0 = (span >> 16) & 0xFF, ty1 = span >> 24;
+        for (uint32_t ty = ty0; ty <= ty1; ++ty)
+            for (uint32_t tx = tx0; tx <= tx1; ++tx) atomicAdd(&hist[row0 + ty * tiles_x + tx], 1u);
+    }
+    __syncthreads();
+    const uint32_t per = (ntiles + 255) / 256;                           // <= 16
+    uint32_t tot[16], ttr[16], sum = 0, mx = 0;
+    for (uint32_t j = 0; j < per; ++j) {
+        const uint32_t t = threadIdx.x * per + j;
+        tot[j] = t < ntiles ? hist[t] : 0u;
+        ttr[j] = (keys && t < ntiles) ? hist[ntiles + t] : 0u;
+        sum += tot[j] + ttr[j];
+        mx = max(mx, ttr[j]);
+    }
+    uint32_t inc = sum;
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t v = __shfl_up(inc, off); if (lane >= (uint32_t)off) inc += v; }
+    for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
+    if (lane == 63) dws[wave] = inc;
+    if (lane == 0) dmx[wave] = mx;
+    __syncthreads();
+    uint32_t run = inc - sum;
+    for (uint32_t w = 0; w < wave; ++w) run += dws[w];
+    if (threadIdx.x == 255) total_s = run + sum;
+    for (uint32_t j = 0; j < per; ++j) {                                 // counts -> cursors (list layout [opaque..., transparent...])
+        const uint32_t t = threadIdx.x * per + j;
+        if (t < ntiles) {
+            hist[t] = run;
+            if (keys) hist[ntiles + t] = run + tot[j];
+            ranges[t] = run;
+            if (tile_mid) tile_mid[t] = run + tot[j];
+        }
+        run += tot[j] + ttr[j];
+    }
+    __syncthreads();
+    const uint32_t total = total_s;
+    const uint32_t longest_tr = max(max(dmx[0], dmx[1]), max(dmx[2], dmx[3]));
+    if (threadIdx.x == 0) {
+        ranges[ntiles] = total;
+        if (total > pair_cap) { ctrl->pairs_overflow = total; ctrl->abort = 1; ctrl->n_pairs = 0; }
+        else ctrl->n_pairs = total;
+        if (longest_tr > blend_cap) ctrl->need_global_sort = 1;
+    }
+    if (total > pair_cap || longest_tr > blend_cap || ctrl->abort) return;
+    for (uint32_t f = threadIdx.x; f < nf; f += 256) {
+        const uint32_t span = spans[f];
+        if (span == 0xFFFFFFFFu) continue;
+        const uint32_t row0 = (keys && (keys[f] >> 31)) ? ntiles : 0u;
+        const uint32_t tx0 = span & 0xFF, tx1 = (span >> 8) & 0xFF, ty0 = (span >> 16) & 0xFF, ty1 = span >> 24;
+        for (uint32_t ty = ty0; ty <= ty1; ++ty)
+            for (uint32_t tx = tx0; tx <= tx1; ++tx) pair_vals[atomicAdd(&hist[row0 + ty * tiles_x + tx], 1u)] = f;
+    }
+}
+
 bool bin_spans_applicable(const FrameParams& fp, const SortScratch& sc, bool with_class) {
     const uint32_t ntiles = fp.tiles_x * fp.tiles_y;
     const uint32_t nblocks = (fp.nf + SPAN_BLOCK - 1) / SPAN_BLOCK;
@@ -285,6 +356,11 @@ bool launch_bin_spans(hipStream_t s, const FrameParams& fp, const uint32_t* span
     const uint32_t ntiles = fp.tiles_x * fp.tiles_y;
     const uint32_t nblocks = (fp.nf + SPAN_BLOCK - 1) / SPAN_BLOCK;
     const uint32_t nrows = keys ? 2 * ntiles : ntiles;
+    if (nblocks == 1) {
+        hipLaunchKernelGGL(k_bin_small, dim3(1), dim3(256), 0, s, fp.nf, ntiles, fp.tiles_x, spans, keys, partials, (fp.nf + 255) / 256, ctrl, pair_cap,
+                           ranges, keys ? tile_mid : nullptr, blend_cap, pair_vals);
+        return true;
+    }
     hipLaunchKernelGGL(k_count_spans, dim3(nblocks), dim3(256), 0, s, fp.nf, ntiles, fp.tiles_x, spans, keys, sc.block_hist, sc.max_blocks);
     hipLaunchKernelGGL(k_scan_rows, dim3(nrows), dim3(256), 0, s, sc.block_hist, sc.max_blocks, nblocks, sc.digit_total,
                        ctrl, partials, (fp.nf + 255) / 256, (const uint32_t*)nullptr);
