@@ -605,15 +605,17 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     // (a transparent pass rides along: its entries are split off at binning time and sorted per tile by k_blend)
     const bool with_class = c->may_blend && !c->fmt8;
     const bool spans_ok = !c->no_prio64 && c->local_sort_ok && bin_spans_applicable(fp, sc, with_class);
-    const bool zfast = spans_ok && fp.zmode && !c->count_fragments && c->cheap_ok && !fp.ortho && !(c->fmt8 && c->blend8) && !fp.xray;
-    const bool exact_cov = c->count_fragments || !c->cheap_ok || (fp.zmode && !zfast);
-    // the fast path reads the class from bit 31 of the depth key and has no ordered opaque walk: not for ortho / x-ray frames
     // ordered walk of whole tile lists instead of the overwrite pass: x-ray (RGB555), or the 8-bit path with blending texels / editor alpha
     const bool ordered_all = c->fmt8 ? c->blend8 : (fp.xray != 0);
-    const bool local_sort = !exact_cov && c->local_sort_ok && !fp.ortho && !ordered_all;
-    c->last_local_sort = local_sort;
+    // sort-free path: painter's or z-buffer mode (orthographic keys use all 32 bits -> class pass -> general path)
+    const bool want_prio64 = spans_ok && !fp.ortho && !ordered_all;
+    // EXACT coverage = texel rule per fragment: exact store counting, textures with many skippable texels; the keyed z-buffer kernel
+    // is EXACT by construction
+    const bool exact_cov = c->count_fragments || !c->cheap_ok || (fp.zmode && !want_prio64);
+    // the sorted fast path reads the class from bit 31 of the depth key and has no ordered opaque walk: not for ortho / x-ray frames
+    const bool local_sort = !exact_cov && c->local_sort_ok && !fp.ortho && !ordered_all && !fp.zmode;
+    c->last_local_sort = local_sort || want_prio64;                         // the global draw order is not materialised
     c->last_exact = ordered_all ? true : (exact_cov && !fp.zmode);          // the ordered walk counts every store it performs
-    const bool want_prio64 = (local_sort || zfast) && spans_ok;     // max-of-priorities coverage: no tile list order needed
     if (c->nf == 0) HIPCHK(c, hipMemsetAsync(c->d_ctrl, 0, sizeof(Ctrl), s));    // otherwise k_setup resets it
     if (prof_all) HIPCHK(c, hipEventRecord(ev[0], s));
     fp.band_only = (want_prio64 && c->band_set) ? 1 : 0;   // other ranks own the other rows: their surfaces' records are never read here
@@ -668,7 +670,7 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
 
     FillArgs fa{};
     fa.fp = fp; fa.recs = c->recs; fa.shades = c->shades; fa.pair_vals = c->pvals[cur]; fa.ranges = c->ranges;
-    fa.keys = c->keys[0]; fa.local_sort = local_sort ? 1u : 0u; fa.tile_keys_only = fa.local_sort; fa.tile_mid = c->tile_mid;
+    fa.keys = c->keys[0]; fa.local_sort = local_sort ? 1u : 0u; fa.tile_keys_only = (local_sort || prio64) ? 1u : 0u; fa.tile_mid = c->tile_mid;
     fa.tex = c->d_tex; fa.texels = c->d_texels; fa.fb = c->fb; fa.vis = c->vis; fa.zbuf = c->zbuf; fa.ctrl = c->d_ctrl;
     fa.tex0 = c->nt ? c->h_tex[0] : TexDesc{ 0, 0, 0, 0 };
     fa.lds_tex_texels = 0;

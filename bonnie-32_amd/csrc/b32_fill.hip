@@ -414,12 +414,14 @@ __device__ __forceinline__ uint32_t cover_one(const Batch& b, int t, uint32_t li
 }
 
 // P64 coverage of a surface whose edge walk must be replayed literally (F_SLOW): one lane per row.
-template <bool ZMODE>
-__device__ __forceinline__ void cover_slow64(const Tri& tr, unsigned long long P, uint32_t* tilebuf, uint32_t x_lo, uint32_t x_hi,
-                                             uint32_t y_lo, uint32_t y_hi, uint32_t ty_top, uint32_t lane) {
+template <bool ZMODE, bool EXACT, bool FMT8>
+__device__ __forceinline__ uint32_t cover_slow64(const Tri& tr, unsigned long long P, uint32_t* tilebuf, uint32_t x_lo, uint32_t x_hi,
+                                                 uint32_t y_lo, uint32_t y_hi, uint32_t ty_top, uint32_t lane,
+                                                 const uint16_t* __restrict__ gtex, bool affine) {
     const uint32_t cx0 = max(tr.min_x, x_lo), cx1 = min(tr.max_x, x_hi);
     const uint32_t cy0 = max(tr.min_y, y_lo), cy1 = min(tr.max_y, y_hi);
-    if (cx0 >= cx1 || cy0 >= cy1) return;
+    if (cx0 >= cx1 || cy0 >= cy1) return 0;
+    uint32_t count = 0;
     unsigned long long* top = reinterpret_cast<unsigned long long*>(tilebuf);
     unsigned long long* sec = top + TILE_H * TILE_STRIDE;
     for (uint32_t by = cy0; by < cy1; by += 64) {
@@ -434,15 +436,19 @@ __device__ __forceinline__ void cover_slow64(const Tri& tr, unsigned long long P
                     unsigned long long Pf = P;
                     bool ok = true;
                     if (ZMODE) { uint32_t zkey; ok = frag_zkey(tr, bcx, bcy, bcz, zkey); Pf = ((unsigned long long)(~zkey) << 32) | (uint32_t)P; }
+                    if (EXACT && ok) { uint32_t texel; ok = texel_drawn<0, FMT8>(tr, bcx, bcy, bcz, gtex, nullptr, texel, affine); }
                     if (ok) {
                         const unsigned long long old = atomicMax(&top[addr], Pf);
-                        atomicMax(&sec[addr], min(old, Pf));
+                        if (!EXACT) atomicMax(&sec[addr], min(old, Pf));
+                        ++count;
                     }
                 }
                 w0 += tr.a0; w1 += tr.a1;
             }
         }
     }
+    for (int off = 32; off > 0; off >>= 1) count += __shfl_down(count, off);
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)count);
 }
 
 // Phase A as a ROW-ITEM scheduler.  Waves grab 64 list entries at a time from an LDS cursor (load balance across the 16
@@ -525,6 +531,9 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
             const uint32_t li = cs + s + 1;
             uint32_t mine = 0;
             if (EXACT || (ZMODE && !P64)) {
+                // (sort-free path with EXACT coverage: the fragment's global priority goes straight to the winners; every stored
+                // winner is a drawn fragment, so no runner-up is kept)
+                const unsigned long long P = P64 ? (((unsigned long long)bperm(s, my_key) << 32) | bperm(s, my_sid)) : 0ull;
                 for (uint32_t i = 0; __ballot(i < n); ++i) {
                     if (i < n) {
                         const float bcx = w0 * sinv, bcy = w1 * sinv;
@@ -534,7 +543,11 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
                             uint32_t zkey = 0;
                             if (ZMODE) drawn = frag_zkey(tr, bcx, bcy, bcz, zkey);
                             if (EXACT && drawn) { uint32_t texel; drawn = texel_drawn<TEXMODE, FMT8>(tr, bcx, bcy, bcz, gtex, ltex, texel, affine); }
-                            if (drawn) { commit_fragment<EXACT, ZMODE>(tilebuf, addr, li, zkey); ++mine; }
+                            if (drawn) {
+                                if (P64) atomicMax(reinterpret_cast<unsigned long long*>(tilebuf) + addr, ZMODE ? (((unsigned long long)(~zkey) << 32) | (uint32_t)P) : P);
+                                else commit_fragment<EXACT, ZMODE>(tilebuf, addr, li, zkey);
+                                ++mine;
+                            }
                         }
                         ++addr; w0 += sa0; w1 += sa1;
                     }
@@ -612,7 +625,8 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
             sm &= sm - 1;
             if (P64) {
                 const unsigned long long P = ((unsigned long long)bcu(my_key, t) << 32) | bcu(my_sid, t);
-                cover_slow64<ZMODE>(tri_from_batch(b, t, ZMODE), P, tilebuf, x_lo, x_hi, y_lo, y_hi, ty_top, lane);
+                const uint32_t cnt64 = cover_slow64<ZMODE, EXACT, FMT8>(tri_from_batch(b, t, ZMODE || EXACT), P, tilebuf, x_lo, x_hi, y_lo, y_hi, ty_top, lane, gtex, affine);
+                if (EXACT) frags += cnt64;
                 continue;
             }
             frags += cover_one<TEXMODE, EXACT, ZMODE, FMT8>(b, t, cs + (uint32_t)t + 1, tilebuf, x_lo, x_hi, y_lo, y_hi, ty_top, lane, gtex, ltex, affine);
@@ -1474,6 +1488,22 @@ void launch_fill(hipStream_t s, const FillArgs& a, int n_cu, hipEvent_t after_co
         if (!attr_set64) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<0, false, 512, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
         if (!attr_set64) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<0, false, 512, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
         attr_set64 = true;
+        if (a.exact_coverage) {   // texel rule per fragment (textures with many skippable texels, or exact store counting): still sort-free
+            static bool ae = false;
+            if (!ae) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<0, true, 512, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<0, true, 512, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<0, true, 512, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<0, true, 512, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                ae = true;
+            }
+            const dim3 g(min(ntiles, (uint32_t)n_cu * 2)), t(512);
+            if (a.fp.zmode) { if (f8) hipLaunchKernelGGL((k_cover<0, true, 512, true, true, true>), g, t, lds64, s, a); else hipLaunchKernelGGL((k_cover<0, true, 512, true, false, true>), g, t, lds64, s, a); }
+            else { if (f8) hipLaunchKernelGGL((k_cover<0, true, 512, false, true, true>), g, t, lds64, s, a); else hipLaunchKernelGGL((k_cover<0, true, 512, false, false, true>), g, t, lds64, s, a); }
+            if (after_cover) (void)hipEventRecord(after_cover, s);
+            if (a.gather_blend) launch_blend<false, true>(s, a, ntiles);
+            return;
+        }
         if (a.fp.zmode) {       // z-buffer mode: same kernel, the priority's high word is the fragment depth
             static bool az = false;
             if (!az) {

@@ -637,3 +637,44 @@ def test_four_million_triangles(fast_ctx, oracle):
     got, tm = gpu_render(fast_ctx, sc, resident=True)
     assert np.array_equal(got, exp)
     assert tm.triangles_drawn == etm.triangles_drawn == 1938655
+
+
+KEYED = ["C1", "C1:gouraud", "C1:blend", "C1:float", "C1:persp", "cube", "fog-flat-point-nocull", "C2", "C2:blend", "C1:zbuf", "C1:zbuf-blend",
+         "C1:zbuf-gouraud", "C3:100k", "C5:20k", "C1:default-settings", "C1:wire-painter"]
+
+
+@pytest.mark.parametrize("name", KEYED)
+@pytest.mark.parametrize("counting", [1, 0])
+def test_keyed_pipelines_parity(keyed_ctx, oracle, name, counting):
+    """The pipelines the sort-free path replaced (see conftest.keyed_ctx) against the oracle: still bit-exact, exact counts."""
+    sc = SCENES[name]()
+    fbo = oracle.Framebuffer(sc.width, sc.height); fbo.clear(sc.clear_color)
+    rc, etm, d = oracle.render_mesh_15(fbo, sc.vertices, sc.faces, sc.textures, sc.camera, sc.settings, sc.fog, dump=True)
+    assert rc == 0
+    from bonnie32_amd import rasterizer as R
+    keyed_ctx.set_fragment_counting(counting)
+    try:
+        fb = R.Framebuffer(sc.width, sc.height, keyed_ctx); fb.clear(sc.clear_color)
+        tm = R.ResidentScene(fb, sc.vertices, sc.faces, sc.textures).render(sc.camera, sc.settings, sc.fog)
+        got = fb.pixels
+        assert np.array_equal(got, fbo.pixels), f"{int((got != fbo.pixels).sum())} bytes differ"
+        assert tm.triangles_drawn == etm.triangles_drawn
+        if counting and not sc.settings.use_zbuffer:
+            assert tm.fragments == etm.fragments
+        if sc.settings.use_zbuffer:
+            assert np.array_equal(fb.zbuffer.view(np.uint32), fbo.zbuffer.view(np.uint32))
+        assert np.array_equal(keyed_ctx.last_draw_order(len(sc.faces)), d["draw_order"])
+    finally:
+        keyed_ctx.set_fragment_counting(1)
+
+
+def test_keyed_full_size_c3(keyed_ctx, oracle):
+    sc = scenegen.make_scene("C3")
+    exp, etm, d = cpu_render(oracle, sc)
+    for counting in (1, 0):
+        keyed_ctx.set_fragment_counting(counting)
+        got, tm = gpu_render(keyed_ctx, sc, resident=True, indexed=True)
+        assert np.array_equal(got, exp)
+        if counting:
+            assert tm.fragments == etm.fragments
+    keyed_ctx.set_fragment_counting(1)
