@@ -68,7 +68,9 @@ def main():
     W, H, NF = sc.width, sc.height, sc.n_tris
 
     ctx = R.Context(local_rank)
-    stream = torch.cuda.current_stream(dev)
+    # one explicit stream for everything of this rank: the rasterizer's kernels, torch's copies and the RCCL gather are ordered by it
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
     ctx.set_stream(stream.cuda_stream)
     frame = torch.zeros(W * H * 4, dtype=torch.uint8, device=dev)       # the Framebuffer's pixels, in HBM
     fb = R.Framebuffer.__new__(R.Framebuffer)
@@ -191,7 +193,12 @@ def main():
             cfb = O.Framebuffer(W, H); cfb.clear(sc.clear_color)
             O.render_mesh_15(cfb, sc.vertices, sc.faces, sc.textures, sc.camera, sc.settings, sc.fog)
             got = frame.cpu().numpy()
-            print("# parity vs oracle:", "bit-exact" if np.array_equal(got, cfb.pixels) else "MISMATCH", file=sys.stderr)
+            ok = np.array_equal(got, cfb.pixels)
+            print("# parity vs oracle:", "bit-exact" if ok else "MISMATCH", file=sys.stderr)
+            if not ok:
+                bad = (got.reshape(H, W, 4) != cfb.pixels.reshape(H, W, 4)).any(axis=2)
+                rows = np.nonzero(bad.any(axis=1))[0]
+                print(f"#   {int(bad.sum())} pixels differ, rows {rows.min()}..{rows.max()} ({len(rows)} rows)", file=sys.stderr)
         line = {
             "metric": "Mtriangles/s + Mpixels/s, 1M-tri synthetic scene @ 2560x1920",
             "value": round(mtri, 3), "unit": "Mtriangles/s",

@@ -49,7 +49,14 @@ class Context:
             pass
 
     def set_stream(self, stream_ptr):
-        _chk(self.lib.b32_set_stream(self.h, stream_ptr), "b32_set_stream")
+        """Run on a caller-owned hipStream_t.  torch reports its default stream as handle 0, which the C ABI reads as "the
+        context's own (non-blocking) stream" -- work enqueued there is NOT ordered with torch's default stream.  So 0 is mapped
+        to hipStreamLegacy (handle 1), the legacy default stream torch actually uses."""
+        HIP_STREAM_LEGACY = 1
+        _chk(self.lib.b32_set_stream(self.h, stream_ptr if stream_ptr else HIP_STREAM_LEGACY), "b32_set_stream")
+
+    def use_own_stream(self):
+        _chk(self.lib.b32_set_stream(self.h, None), "b32_set_stream")
 
     def synchronize(self):
         _chk(self.lib.b32_synchronize(self.h), "b32_synchronize")

@@ -678,3 +678,31 @@ def test_keyed_full_size_c3(keyed_ctx, oracle):
         if counting:
             assert tm.fragments == etm.fragments
     keyed_ctx.set_fragment_counting(1)
+
+
+def test_ordering_with_torch_streams(oracle):
+    """Frames enqueued asynchronously on torch's stream must be ordered with torch's own work on that stream (the RCCL gather
+    of bench.py reads the frame right after the fill): torch's default stream is handle 0, which b32_set_stream would read as
+    "the context's own stream" -- Context.set_stream maps it to hipStreamLegacy."""
+    import torch
+    from bonnie32_amd import rasterizer as R
+    sc = scenegen.make_scene("C3", n_tris=300_000)
+    exp, etm, d = cpu_render(oracle, sc)
+    dev = torch.device("cuda", 0)
+    for make in (lambda: torch.cuda.default_stream(dev), lambda: torch.cuda.Stream(device=dev)):
+        stream = make()
+        with torch.cuda.stream(stream):
+            ctx = R.Context(0)
+            ctx.set_stream(stream.cuda_stream)
+            frame = torch.zeros(sc.width * sc.height * 4, dtype=torch.uint8, device=dev)
+            fb = R.Framebuffer.__new__(R.Framebuffer); fb.ctx = ctx
+            fb.bind_device(frame.data_ptr(), sc.width, sc.height)
+            rs = R.ResidentScene(fb, sc.vertices, sc.faces, sc.textures)
+            rs.render(sc.camera, sc.settings)
+            for _ in range(6):
+                fb.clear(sc.clear_color)
+                rs.render_async()
+                got = frame.cpu().numpy()              # no b32 synchronisation in between: stream order alone must do
+                assert np.array_equal(got, exp)
+            rs.finish()
+            ctx.close()
