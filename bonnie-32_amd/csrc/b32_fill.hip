@@ -1470,6 +1470,20 @@ static void launch_blend(hipStream_t s, const FillArgs& a, uint32_t ntiles) {
     hipLaunchKernelGGL((k_blend<BLEND_NT, FMT8, GATHER>), dim3(ntiles), dim3(BLEND_NT), lds, s, a);
 }
 
+template <bool EXACT, bool ZMODE, bool FMT8>
+static void launch_p64(hipStream_t s, const FillArgs& a, uint32_t ntiles, int n_cu, bool wide) {
+    const size_t lds64 = 4 * LDS_TILE_BYTES + LDS_MISC_BYTES + LDS_MARK_BYTES;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<0, EXACT, 512, ZMODE, FMT8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<0, EXACT, 1024, ZMODE, FMT8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    const dim3 g(min(ntiles, (uint32_t)n_cu * 2));
+    if (wide) hipLaunchKernelGGL((k_cover<0, EXACT, 1024, ZMODE, FMT8, true>), g, dim3(1024), lds64, s, a);
+    else hipLaunchKernelGGL((k_cover<0, EXACT, 512, ZMODE, FMT8, true>), g, dim3(512), lds64, s, a);
+}
+
 void launch_fill(hipStream_t s, const FillArgs& a, int n_cu, hipEvent_t after_cover) {
     const uint32_t ntiles = a.fp.tiles_x * a.fp.tiles_y;
     if (ntiles == 0) return;
@@ -1482,54 +1496,24 @@ void launch_fill(hipStream_t s, const FillArgs& a, int n_cu, hipEvent_t after_co
         return;
     }
     const size_t lds_sort = LDS_TEX_OFFSET + LDS_SORT_CNT_BYTES + 2048;
-    if (a.prio64) {   // sort-free: 64-bit tile buffers (2 x 36 KB) -> two workgroups per CU
-        const size_t lds64 = 4 * LDS_TILE_BYTES + LDS_MISC_BYTES + LDS_MARK_BYTES;
-        static bool attr_set64 = false;
-        if (!attr_set64) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<0, false, 512, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
-        if (!attr_set64) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<0, false, 512, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
-        attr_set64 = true;
-        if (a.exact_coverage) {   // texel rule per fragment (textures with many skippable texels, or exact store counting): still sort-free
-            static bool ae = false;
-            if (!ae) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<0, true, 512, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<0, true, 512, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<0, true, 512, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<0, true, 512, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                ae = true;
-            }
-            const dim3 g(min(ntiles, (uint32_t)n_cu * 2)), t(512);
-            if (a.fp.zmode) { if (f8) hipLaunchKernelGGL((k_cover<0, true, 512, true, true, true>), g, t, lds64, s, a); else hipLaunchKernelGGL((k_cover<0, true, 512, true, false, true>), g, t, lds64, s, a); }
-            else { if (f8) hipLaunchKernelGGL((k_cover<0, true, 512, false, true, true>), g, t, lds64, s, a); else hipLaunchKernelGGL((k_cover<0, true, 512, false, false, true>), g, t, lds64, s, a); }
-            if (after_cover) (void)hipEventRecord(after_cover, s);
-            if (a.gather_blend) launch_blend<false, true>(s, a, ntiles);
-            return;
+    if (a.prio64) {   // sort-free fused kernel: coverage and shading are one launch; 64-bit tile buffers (2 x 36 KB)
+        // EXACT = texel rule per fragment (textures with many skippable texels, or exact store counting); z-buffer mode = the
+        // priority's high word is the fragment depth.  Few tiles (narrow multi-GPU bands, small frames): 16 waves per tile.
+        const bool wide = ntiles < 4u * (uint32_t)n_cu && !getenv("B32_P64_NT512");
+        const int sel = (a.exact_coverage ? 4 : 0) | (a.fp.zmode ? 2 : 0) | (f8 ? 1 : 0);
+        switch (sel) {
+            case 0: launch_p64<false, false, false>(s, a, ntiles, n_cu, wide); break;
+            case 1: launch_p64<false, false, true>(s, a, ntiles, n_cu, wide); break;
+            case 2: launch_p64<false, true, false>(s, a, ntiles, n_cu, wide); break;
+            case 3: launch_p64<false, true, true>(s, a, ntiles, n_cu, wide); break;
+            case 4: launch_p64<true, false, false>(s, a, ntiles, n_cu, wide); break;
+            case 5: launch_p64<true, false, true>(s, a, ntiles, n_cu, wide); break;
+            case 6: launch_p64<true, true, false>(s, a, ntiles, n_cu, wide); break;
+            default: launch_p64<true, true, true>(s, a, ntiles, n_cu, wide); break;
         }
-        if (a.fp.zmode) {       // z-buffer mode: same kernel, the priority's high word is the fragment depth
-            static bool az = false;
-            if (!az) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<0, false, 512, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<0, false, 512, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                az = true;
-            }
-            if (f8) hipLaunchKernelGGL((k_cover<0, false, 512, true, true, true>), dim3(min(ntiles, (uint32_t)n_cu * 2)), dim3(512), lds64, s, a);
-            else hipLaunchKernelGGL((k_cover<0, false, 512, true, false, true>), dim3(min(ntiles, (uint32_t)n_cu * 2)), dim3(512), lds64, s, a);
-            if (after_cover) (void)hipEventRecord(after_cover, s);
-            if (a.gather_blend) launch_blend<false, true>(s, a, ntiles);
-            return;
-        }
-        static const int nt64 = getenv("B32_P64_NT") ? atoi(getenv("B32_P64_NT")) : 512;
-        if (!f8 && nt64 == 768) {
-            static bool ab = false; if (!ab) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<0, false, 768, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); ab = true; }
-            hipLaunchKernelGGL((k_cover<0, false, 768, false, false, true>), dim3(min(ntiles, (uint32_t)n_cu * 2)), dim3(768), lds64, s, a);
-        } else if (!f8 && nt64 == 1024) {
-            static bool ab = false; if (!ab) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<0, false, 1024, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); ab = true; }
-            hipLaunchKernelGGL((k_cover<0, false, 1024, false, false, true>), dim3(min(ntiles, (uint32_t)n_cu * 2)), dim3(1024), lds64, s, a);
-        } else
-        if (f8) hipLaunchKernelGGL((k_cover<0, false, 512, false, true, true>), dim3(min(ntiles, (uint32_t)n_cu * 2)), dim3(512), lds64, s, a);
-        else hipLaunchKernelGGL((k_cover<0, false, 512, false, false, true>), dim3(min(ntiles, (uint32_t)n_cu * 2)), dim3(512), lds64, s, a);
         if (after_cover) (void)hipEventRecord(after_cover, s);
         if (a.gather_blend) launch_blend<false, true>(s, a, ntiles);
-        return;                                                  // coverage and shading are one kernel on this path
+        return;
     } else if (a.fp.zmode) {
         if (f8) hipLaunchKernelGGL((k_cover<0, true, 512, true, true>), dim3(min(ntiles, (uint32_t)n_cu * 3)), dim3(512), lds_sort, s, a);
         else hipLaunchKernelGGL((k_cover<0, true, 512, true, false>), dim3(min(ntiles, (uint32_t)n_cu * 3)), dim3(512), lds_sort, s, a);

@@ -1,0 +1,22 @@
+"""Per-rank compute time of the band-sharded frame (no gather): one GPU renders only the rows rank 0 would own at N ranks."""
+import sys, time
+sys.path.insert(0, ".")
+from bonnie32_amd import rasterizer as R, scenegen, parallel
+sc = scenegen.make_scene("C3")
+ctx = R.Context(0)
+fb = R.Framebuffer(sc.width, sc.height, ctx)
+rs = R.ResidentScene(fb, sc.vertices, sc.faces, indexed_textures=sc.indexed_textures)
+for N in (1, 2, 4, 8):
+    for r in sorted({0, N // 2}):
+        y0, y1 = parallel.band_rows(sc.height, N, r)
+        fb.set_band(y0, y1)
+        fb.clear(sc.clear_color); rs.render(sc.camera, sc.settings)
+        ctx.set_profiling(2)
+        for i in range(20):
+            fb.clear(sc.clear_color); rs.render_async()
+        rs.finish(); kt = ctx.last_kernel_times(); ctx.set_profiling(0)
+        n = 100; ctx.synchronize(); t0 = time.perf_counter()
+        for i in range(n):
+            fb.clear(sc.clear_color); rs.render_async()
+        rs.finish(); t = (time.perf_counter() - t0) / n
+        print(f"N={N} rank {r} rows [{y0},{y1}): {t*1e3:.3f} ms/frame  phases {kt}")
