@@ -512,6 +512,7 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     fp.width = c->width; fp.height = c->height;
     fp.band_y0 = c->band_y0; fp.band_y1 = c->band_y1;
     fp.tiles_x = (c->width + TILE_W - 1) / TILE_W;
+    fp.tile_h = TILE_H;
     fp.tile_y0 = c->band_y0 / TILE_H;
     fp.tiles_y = c->band_y1 > c->band_y0 ? (c->band_y1 + TILE_H - 1) / TILE_H - fp.tile_y0 : 0;
     fp.nv = c->nv; fp.nf = c->nf; fp.nt = c->nt;
@@ -528,8 +529,8 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     const bool wire_front = st->wireframe_overlay != 0;                       // render.rs:2603 (an empty list draws nothing either way)
     fp.wire_collect = (wire_back || wire_front) ? 1 : 0;
     fp.band_only = 0;
-    const uint32_t ntiles = fp.tiles_x * fp.tiles_y;
-    const uint32_t n_keys = 2 * ntiles;
+    uint32_t ntiles = fp.tiles_x * fp.tiles_y;
+    uint32_t n_keys = 2 * ntiles;
     int rc;
 
     // lights (rarely change: synchronous refresh only when they differ from the device copy)
@@ -559,9 +560,12 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
         if ((rc = ensure_plain(c, c->block_hist, (size_t)4096 * need_blocks))) return rc;
         c->hist_blocks = need_blocks;
     }
-    if ((size_t)n_keys + 2 > c->cap_ranges || !c->ranges) {
-        if ((rc = ensure_plain(c, c->ranges, (size_t)n_keys + 64))) return rc;
-        c->cap_ranges = (size_t)n_keys + 64;
+    {   // list ranges: 2 per 64x64 tile (tile, class); the sort-free path may cut tiles to a quarter of the height (4 x as many)
+        const size_t need = (size_t)4 * ntiles + 4 * fp.tiles_x + 2;
+        if (need > c->cap_ranges || !c->ranges) {
+            if ((rc = ensure_plain(c, c->ranges, need + 64))) return rc;
+            c->cap_ranges = need + 64;
+        }
     }
 
     if (fp.zmode) {          // Framebuffer::zbuffer (render.rs:12): allocated on first use, f32::MAX until drawn into
@@ -609,6 +613,20 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     const bool ordered_all = c->fmt8 ? c->blend8 : (fp.xray != 0);
     // sort-free path: painter's or z-buffer mode (orthographic keys use all 32 bits -> class pass -> general path)
     const bool want_prio64 = spans_ok && !fp.ortho && !ordered_all;
+    // too few 64x64 tiles to fill the GPU (narrow multi-GPU band, PS1-sized frame): tiles of 32 or 16 rows multiply the parallelism
+    // of the fused kernel.  Only the sort-free path without a transparent pass knows about them (k_blend / keyed kernels keep 64).
+    if (want_prio64 && !with_class && c->band_y1 > c->band_y0 && !getenv("B32_NO_HALF_TILES")) {
+        uint32_t th = TILE_H;
+        // 64 -> 32 rows below two tiles per CU, 32 -> 16 rows below one tile per CU (measured: a 240-row band of C3 prefers 320 tiles
+        // of 32 rows to 600 of 16; C2's 20 tiles prefer 80 of 16 rows)
+        while (th > 16 && fp.tiles_x * ((c->band_y1 + th - 1) / th - c->band_y0 / th) < (th == TILE_H ? 2u : 1u) * (uint32_t)c->n_cu &&
+               (c->band_y1 - c->band_y0) / (th / 2) + 2 <= 255 /* tile rows must fit the packed spans */) th /= 2;
+        fp.tile_h = th;
+        fp.tile_y0 = c->band_y0 / th;
+        fp.tiles_y = (c->band_y1 + th - 1) / th - fp.tile_y0;
+        ntiles = fp.tiles_x * fp.tiles_y;
+        n_keys = 2 * ntiles;
+    }
     // EXACT coverage = texel rule per fragment: exact store counting, textures with many skippable texels; the keyed z-buffer kernel
     // is EXACT by construction
     const bool exact_cov = c->count_fragments || !c->cheap_ok || (fp.zmode && !want_prio64);

@@ -97,6 +97,7 @@ struct FrameParams {
     uint32_t width, height;
     uint32_t band_y0, band_y1;
     uint32_t tiles_x, tiles_y, tile_y0;    // tile grid of the band: tiles_y rows starting at tile row tile_y0
+    uint32_t tile_h;                       // tile height of this frame: TILE_H, or TILE_H / 2 on the sort-free path when tiles are few
     uint32_t nv, nf, nt;
     uint32_t n_lights;
     float ambient;
@@ -191,7 +192,7 @@ __device__ __forceinline__ uint32_t pack_tile_span(uint32_t bbx, uint32_t bby, u
     const uint32_t min_y = max(bby & 0xFFFF, fp.band_y0), max_y = min(bby >> 16, fp.band_y1);   // other rows belong to another rank
     if (min_x >= max_x || min_y >= max_y) return 0xFFFFFFFFu;
     const uint32_t tx0 = min_x / TILE_W, tx1 = (max_x - 1) / TILE_W;
-    const uint32_t ty0 = min_y / TILE_H - fp.tile_y0, ty1 = (max_y - 1) / TILE_H - fp.tile_y0;
+    const uint32_t ty0 = min_y / fp.tile_h - fp.tile_y0, ty1 = (max_y - 1) / fp.tile_h - fp.tile_y0;
     count = (tx1 - tx0 + 1) * (ty1 - ty0 + 1);
     return tx0 | (tx1 << 8) | (ty0 << 16) | (ty1 << 24);
 }

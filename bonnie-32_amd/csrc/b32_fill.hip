@@ -717,7 +717,7 @@ __device__ void tile_local_sort(uint32_t* sort_area, uint32_t* wcnt, volatile ui
 // ------------------------------------------------------------------------------------------------ k_cover
 template <bool FMT8, int NT, bool ZMODE>
 __device__ __forceinline__ void shade_tile_p64(const FillArgs& a, const uint32_t* tilebuf, uint32_t e0, uint32_t e1, uint32_t x_lo, uint32_t x_hi,
-                                               uint32_t y_lo, uint32_t y_hi, uint32_t ty_top, uint32_t tid, uint32_t lane);
+                                               uint32_t y_lo, uint32_t y_hi, uint32_t ty_top, uint32_t tid, uint32_t lane, uint32_t TH);
 
 template <int TEXMODE, bool EXACT, int NT, bool ZMODE, bool FMT8 = false, bool P64 = false>
 __global__ __launch_bounds__(NT) void k_cover(FillArgs a) {
@@ -775,11 +775,14 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a) {
         }
         const uint32_t txi = tile % fp.tiles_x, tyi = tile / fp.tiles_x + fp.tile_y0;
         const uint32_t x_lo = txi * TILE_W, x_hi = min(x_lo + TILE_W, fp.width);
-        const uint32_t ty_top = tyi * TILE_H;
-        const uint32_t y_lo = max(ty_top, fp.band_y0), y_hi = min(ty_top + TILE_H, fp.band_y1);
+        // the sort-free path may run on half-height tiles (fp.tile_h = 32) when a frame or band has too few 64x64 tiles to fill the
+        // GPU; the LDS planes keep their full-tile layout, only the rows in use change
+        const uint32_t TH = P64 ? fp.tile_h : (uint32_t)TILE_H;
+        const uint32_t ty_top = tyi * TH;
+        const uint32_t y_lo = max(ty_top, fp.band_y0), y_hi = min(ty_top + TH, fp.band_y1);
         if (P64 && ZMODE) { // winners seeded with the current z-buffer: a fragment wins only with a strictly smaller depth (low word all ones)
             unsigned long long* t64 = reinterpret_cast<unsigned long long*>(tilebuf);
-            for (uint32_t p = tid; p < TILE_W * TILE_H; p += NT) {
+            for (uint32_t p = tid; p < TILE_W * TH; p += NT) {
                 const uint32_t row = p >> 6, col = p & 63;
                 const uint32_t px = x_lo + col, py = ty_top + row;
                 const bool inb = px < x_hi && py >= y_lo && py < y_hi;
@@ -795,6 +798,10 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a) {
                 t64[row * TILE_STRIDE + col] = inb ? ((unsigned long long)zsort_key(a.zbuf[(size_t)py * fp.width + px]) << 32) : 0ull;
             }
         } else {
+            if (P64 && TH < (uint32_t)TILE_H) {             // half-height tile: clear only the rows in use of both 64-bit planes
+                unsigned long long* t64 = reinterpret_cast<unsigned long long*>(tilebuf);
+                for (uint32_t i = tid; i < TH * TILE_STRIDE; i += NT) { t64[i] = 0ull; t64[TILE_H * TILE_STRIDE + i] = 0ull; }
+            } else
             for (uint32_t i = tid; i < (P64 ? 4 : (EXACT ? 1 : 2)) * TILE_H * TILE_STRIDE; i += NT) tilebuf[i] = 0;
         }
         __syncthreads();
@@ -805,7 +812,7 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a) {
             __syncthreads();
         }
         if (P64) {          // shade the tile straight from the LDS winners (no visibility buffer)
-            if (n_op) shade_tile_p64<FMT8, NT, ZMODE>(a, tilebuf, e0, e1, x_lo, x_hi, y_lo, y_hi, ty_top, tid, lane);
+            if (n_op) shade_tile_p64<FMT8, NT, ZMODE>(a, tilebuf, e0, e1, x_lo, x_hi, y_lo, y_hi, ty_top, tid, lane, TH);
             __syncthreads();
             continue;
         }
@@ -970,7 +977,7 @@ __device__ __forceinline__ bool depth_prio(const FillArgs& a, uint32_t sid, cons
 
 template <bool FMT8, int NT, bool ZMODE>
 __device__ __forceinline__ void shade_tile_p64(const FillArgs& a, const uint32_t* tilebuf, uint32_t e0, uint32_t e1, uint32_t x_lo, uint32_t x_hi,
-                                               uint32_t y_lo, uint32_t y_hi, uint32_t ty_top, uint32_t tid, uint32_t lane) {
+                                               uint32_t y_lo, uint32_t y_hi, uint32_t ty_top, uint32_t tid, uint32_t lane, uint32_t TH) {
     const FrameParams& fp = a.fp;
     const unsigned long long* top = reinterpret_cast<const unsigned long long*>(tilebuf);
     const unsigned long long* sec = top + TILE_H * TILE_STRIDE;
@@ -981,11 +988,11 @@ __device__ __forceinline__ void shade_tile_p64(const FillArgs& a, const uint32_t
     // z-buffer mode: a winner exists when the low word is not the seed's all-ones; its face id is 0xFFFFFFFE - low word
     auto covered = [](unsigned long long t) { return ZMODE ? ((uint32_t)t != 0xFFFFFFFFu) : (t != 0ull); };
     auto sid_of = [](unsigned long long t) { return ZMODE ? 0xFFFFFFFEu - (uint32_t)t : (uint32_t)t; };
-    for (uint32_t r0 = 0; r0 < TILE_H; r0 += 2 * ROWS_PER_STEP) {
+    for (uint32_t r0 = 0; r0 < TH; r0 += 2 * ROWS_PER_STEP) {
         const uint32_t col = tid & 63;
         const uint32_t rowA = r0 + (tid >> 6), rowB = rowA + ROWS_PER_STEP;
         const uint32_t px = x_lo + col, pyA = ty_top + rowA, pyB = ty_top + rowB;
-        const bool inA = rowA < TILE_H && px < x_hi && pyA >= y_lo && pyA < y_hi, inB = rowB < TILE_H && px < x_hi && pyB >= y_lo && pyB < y_hi;
+        const bool inA = rowA < TH && px < x_hi && pyA >= y_lo && pyA < y_hi, inB = rowB < TH && px < x_hi && pyB >= y_lo && pyB < y_hi;
         unsigned long long tA = inA ? top[rowA * TILE_STRIDE + col] : (ZMODE ? ~0ull : 0ull), tB = inB ? top[rowB * TILE_STRIDE + col] : (ZMODE ? ~0ull : 0ull);
         const bool cA = covered(tA), cB = covered(tB);
         if (!__ballot(cA || cB)) continue;
