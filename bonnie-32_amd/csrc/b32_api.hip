@@ -573,9 +573,12 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
         if (px > c->cap_zbuf || !c->zbuf) { if ((rc = ensure_plain(c, c->zbuf, px + 64))) return rc; c->cap_zbuf = px; c->zbuf_valid = false; }
         if (!c->zbuf_valid) { launch_clear(s, reinterpret_cast<uint32_t*>(c->zbuf), px, 0x7F7FFFFFu); c->zbuf_valid = true; }
     }
-    if ((size_t)ntiles + 1 > c->cap_tile_mid || !c->tile_mid) {
-        if ((rc = ensure_plain(c, c->tile_mid, (size_t)ntiles + 64))) return rc;
-        c->cap_tile_mid = (size_t)ntiles + 64;
+    {   // (cut tiles: up to 4 x as many)
+        const size_t need = (size_t)4 * ntiles + 4 * fp.tiles_x + 2;
+        if (need > c->cap_tile_mid || !c->tile_mid) {
+            if ((rc = ensure_plain(c, c->tile_mid, need + 64))) return rc;
+            c->cap_tile_mid = need + 64;
+        }
     }
     if ((size_t)c->width * c->height > c->cap_vis || !c->vis) {
         if ((rc = ensure_plain(c, c->vis, (size_t)c->width * c->height * 2 + 64))) return rc;    // two words per pixel (prio64 coverage)
@@ -614,8 +617,8 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     // sort-free path: painter's or z-buffer mode (orthographic keys use all 32 bits -> class pass -> general path)
     const bool want_prio64 = spans_ok && !fp.ortho && !ordered_all;
     // too few 64x64 tiles to fill the GPU (narrow multi-GPU band, PS1-sized frame): tiles of 32 or 16 rows multiply the parallelism
-    // of the fused kernel.  Only the sort-free path without a transparent pass knows about them (k_blend / keyed kernels keep 64).
-    if (want_prio64 && !with_class && c->band_y1 > c->band_y0 && !getenv("B32_NO_HALF_TILES")) {
+    // of the fused kernel.  Only the sort-free path knows about them (its k_blend included); the keyed kernels keep 64 rows.
+    if (want_prio64 && c->band_y1 > c->band_y0 && !getenv("B32_NO_HALF_TILES")) {
         uint32_t th = TILE_H;
         // 64 -> 32 rows below two tiles per CU, 32 -> 16 rows below one tile per CU (measured: a 240-row band of C3 prefers 320 tiles
         // of 32 rows to 600 of 16; C2's 20 tiles prefer 80 of 16 rows)

@@ -1224,9 +1224,10 @@ __global__ __launch_bounds__(NT, 4) void k_blend(FillArgs a) {        // 4 waves
     const bool affine = fp.affine != 0;
     const uint32_t txi = tile % fp.tiles_x, tyi = tile / fp.tiles_x + fp.tile_y0;
     const uint32_t x_lo = txi * TILE_W, x_hi = min(x_lo + TILE_W, fp.width);
-    const uint32_t ty_top = tyi * TILE_H;
-    const uint32_t y_lo = max(ty_top, fp.band_y0), y_hi = min(ty_top + TILE_H, fp.band_y1);
-    for (uint32_t p = tid; p < TILE_W * TILE_H; p += NT) {
+    const uint32_t TH = fp.tile_h;                  // 64, or 32 / 16 rows when the sort-free path runs on cut tiles (LDS layout unchanged)
+    const uint32_t ty_top = tyi * TH;
+    const uint32_t y_lo = max(ty_top, fp.band_y0), y_hi = min(ty_top + TH, fp.band_y1);
+    for (uint32_t p = tid; p < TILE_W * TH; p += NT) {
         const uint32_t row = p >> 6, col = p & 63;
         const uint32_t px = x_lo + col, py = ty_top + row;
         const bool inb = px < x_hi && py >= y_lo && py < y_hi;
@@ -1237,7 +1238,7 @@ __global__ __launch_bounds__(NT, 4) void k_blend(FillArgs a) {        // 4 waves
     unsigned long long frag_count = 0;
     const TexDesc none = { 0, 0, 0, 0 };
     const uint32_t n_tr = e2 - e1;
-    constexpr uint32_t RPW = TILE_H / NW;          // tile rows owned by one wave in phase 2
+    const uint32_t RPW = TH / NW;                   // tile rows owned by one wave in phase 2 (TH >= 16, NW = 8)
     const uint32_t wy0 = max(ty_top + wave * RPW, y_lo), wy1 = min(ty_top + wave * RPW + RPW, y_hi);
     // The walk is split so that only what MUST be ordered is ordered.  A chunk = consecutive list entries whose clipped bounding
     // boxes fit the fragment buffer.  Phase 1 (no order): the waves take the chunk's surfaces round-robin and evaluate every
@@ -1450,7 +1451,7 @@ __global__ __launch_bounds__(NT, 4) void k_blend(FillArgs a) {        // 4 waves
         __syncthreads();                                // the fragment buffer is reused by the next chunk
         cs += take;
     }
-    for (uint32_t p = tid; p < TILE_W * TILE_H; p += NT) {      // finished tile back, one 256-B row segment per wave instruction
+    for (uint32_t p = tid; p < TILE_W * TH; p += NT) {      // finished tile back, one 256-B row segment per wave instruction
         const uint32_t row = p >> 6, col = p & 63;
         const uint32_t px = x_lo + col, py = ty_top + row;
         if (px < x_hi && py >= y_lo && py < y_hi) {
