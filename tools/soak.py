@@ -1,0 +1,80 @@
+"""Randomised parity soak: random scenes x random settings (both pixel formats, every mode) GPU vs CPU oracle, bit-exact.
+usage: soak.py [seconds] [seed]"""
+import sys, time
+sys.path.insert(0, ".")
+import numpy as np
+import bonnie32_amd as b32
+from bonnie32_amd import rasterizer as R, scenegen, abi
+from oracle import oracle as O
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+ctx = R.Context(0)
+t_end = time.time() + budget
+n = fails = drawn = refused = 0
+while time.time() < t_end:
+    n += 1
+    cfg = rng.choice(["C1", "C2", "C5"])
+    W, H = [(320, 240), (333, 197), (640, 480), (64, 64), (1280, 720), (97, 801)][rng.integers(6)]
+    ntri = int(rng.choice([1, 7, 300, 2500, 20000]))
+    variant = rng.choice(["bench", "gouraud", "blend", "float"])
+    sc = scenegen.make_scene(cfg, n_tris=ntri, seed=int(rng.integers(1 << 30)), variant=variant, width=W, height=H,
+                             bbox_px=float(rng.choice([4.0, 60.0, 900.0, 20000.0])))
+    st = sc.settings
+    st.use_zbuffer = bool(rng.integers(2)); st.affine_textures = bool(rng.integers(4) > 0); st.dithering = bool(rng.integers(4) > 0)
+    st.backface_cull = bool(rng.integers(3) > 0)
+    st.backface_wireframe = bool(rng.integers(4) == 0) and ntri <= 2500
+    st.wireframe_overlay = bool(rng.integers(10) == 0) and ntri <= 2500
+    st.xray_mode = bool(rng.integers(8) == 0)
+    if rng.integers(6) == 0:
+        st.ortho_projection = (float(rng.choice([0.02, 0.1, 1.0])), float(rng.normal(0, 50)), float(rng.normal(0, 50)))
+        sc.camera.position = (0.0, 0.0, float(rng.choice([0.0, 2500.0])))
+    if rng.integers(3) == 0 and variant != "gouraud":
+        st.shading = int(rng.integers(1, 3))
+        st.lights = [b32.Light.directional((float(rng.normal()), float(rng.normal()), float(rng.normal()) + 0.1), float(rng.uniform(0.2, 1.5))),
+                     b32.Light.point((float(rng.normal(0, 500)), float(rng.normal(0, 500)), float(rng.uniform(300, 3000))), float(rng.uniform(500, 5000)), 1.2)][:int(rng.integers(1, 3))]
+        st.ambient = float(rng.uniform(0.0, 0.6))
+    fog = None
+    fmt8 = bool(rng.integers(3) == 0)
+    if not fmt8 and rng.integers(4) == 0:
+        fog = (float(rng.uniform(300, 2000)), float(rng.choice([0.0, 800.0, 3000.0])), float(rng.uniform(2000, 7000)), b32.Color(int(rng.integers(256)), 90, 120))
+    if rng.integers(4) == 0:
+        sc.faces["editor_alpha"][::int(rng.integers(2, 9))] = int(rng.choice([0, 1, 128, 254]))
+    if rng.integers(4) == 0:
+        sc.faces["black_transparent"][::3] = 0
+    counting = int(rng.integers(2))
+    ofb = O.Framebuffer(W, H); ofb.clear(sc.clear_color)
+    if fmt8:
+        st.use_rgb555 = False
+        stp = int(rng.choice([0, 1, 2, 3, 4]))
+        tex8 = [b32.Texture.from_texture15(t, stp) for t in sc.textures]
+        rc, otm = O.render_mesh(ofb, sc.vertices, sc.faces, tex8, sc.camera, st)
+    else:
+        rc, otm = O.render_mesh_15(ofb, sc.vertices, sc.faces, sc.textures, sc.camera, st, fog)
+    ctx.set_fragment_counting(counting)
+    fb = R.Framebuffer(W, H, ctx); fb.clear(sc.clear_color)
+    bands = [(0, H)] if rng.integers(3) else [(0, H // 3), (H // 3, H // 3 + 37), (H // 3 + 37, H)]
+    desc = f"#{n} {cfg} {W}x{H} tris={ntri} {variant} fmt8={fmt8} z={st.use_zbuffer} xray={st.xray_mode} ortho={st.ortho_projection is not None} wire={st.backface_wireframe}/{st.wireframe_overlay} shading={st.shading} fog={fog is not None} counting={counting} bands={len(bands)}"
+    try:
+        rs = R.ResidentScene(fb, sc.vertices, sc.faces, textures8=tex8) if fmt8 else R.ResidentScene(fb, sc.vertices, sc.faces, sc.textures)
+        grc = 0
+        for b0, b1 in bands:
+            fb.set_band(b0, b1)
+            if len(bands) > 1:
+                fb.clear(sc.clear_color)
+            tm = rs.render(sc.camera, st, None if fmt8 else fog)
+        fb.set_band(0, H)
+    except R.B32Error as e:
+        grc = e.code
+    ok = grc == rc
+    drawn += rc == 0; refused += rc != 0
+    if ok and rc == 0:
+        ok = np.array_equal(fb.pixels, ofb.pixels) and tm.triangles_drawn == otm.triangles_drawn
+        if ok and st.use_zbuffer:
+            ok = np.array_equal(fb.zbuffer.view(np.uint32), ofb.zbuffer.view(np.uint32))
+        if ok and tm.fragments and len(bands) == 1:
+            ok = tm.fragments == otm.fragments
+    if not ok:
+        fails += 1
+        print("FAIL", desc, "rc", rc, grc, flush=True)
+print(f"soak: {n} scenes ({drawn} drawn, {refused} refused by both sides), {fails} failures")
