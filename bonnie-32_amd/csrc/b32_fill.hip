@@ -28,6 +28,10 @@
 #ifndef B32_TRIP
 #define B32_TRIP 4
 #endif
+#ifndef B32_P64_STRIDE
+#define B32_P64_STRIDE 66        // row stride (u64 entries) of the 64-bit winner planes: 64 + 2, so the rows a surface touches at one
+                                 // column fall into different LDS banks (measured: 72 -> 133 us, 66 -> 128 us; must stay <= 72, the allocation)
+#endif
 #ifndef B32_GRAB_DIV
 #define B32_GRAB_DIV 1          // list entries per grab ~ n / (B32_GRAB_DIV * waves); 1 measured best (130 us vs 134 at 3)
 #endif
@@ -35,6 +39,8 @@
 namespace b32 {
 
 constexpr int LDS_TILE_BYTES = TILE_H * TILE_STRIDE * 4;        // 18432
+constexpr int STR64 = B32_P64_STRIDE;
+static_assert(STR64 >= 64 && STR64 <= TILE_STRIDE && (TILE_H - 1) * STR64 + 64 + 4 <= TILE_H * TILE_STRIDE, "64-bit planes must fit their allocation, trip overshoot included");
 constexpr int LDS_MISC_BYTES = 64;
 constexpr int LDS_MARK_BYTES = FILL_WAVES * 64 * 4;             // row-start marks of the row-item scheduler
 constexpr int LDS_TEX_OFFSET = 2 * LDS_TILE_BYTES + LDS_MISC_BYTES + LDS_MARK_BYTES;   // 41024: top + runner-up tile buffers
@@ -423,7 +429,7 @@ __device__ __forceinline__ uint32_t cover_slow64(const Tri& tr, unsigned long lo
     if (cx0 >= cx1 || cy0 >= cy1) return 0;
     uint32_t count = 0;
     unsigned long long* top = reinterpret_cast<unsigned long long*>(tilebuf);
-    unsigned long long* sec = top + TILE_H * TILE_STRIDE;
+    unsigned long long* sec = top + TILE_H * STR64;
     for (uint32_t by = cy0; by < cy1; by += 64) {
         const uint32_t py = by + lane;
         if (py < cy1) {
@@ -432,7 +438,7 @@ __device__ __forceinline__ uint32_t cover_slow64(const Tri& tr, unsigned long lo
             for (uint32_t px = cx0; px < cx1; ++px) {
                 float bcx, bcy, bcz;
                 if (inside_bc(tr, w0, w1, bcx, bcy, bcz)) {
-                    const uint32_t addr = (py - ty_top) * TILE_STRIDE + (px - x_lo);
+                    const uint32_t addr = (py - ty_top) * STR64 + (px - x_lo);
                     unsigned long long Pf = P;
                     bool ok = true;
                     if (ZMODE) { uint32_t zkey; ok = frag_zkey(tr, bcx, bcy, bcz, zkey); Pf = ((unsigned long long)(~zkey) << 32) | (uint32_t)P; }
@@ -527,7 +533,7 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
             const uint32_t n = valid ? rx1 - rx0 : 0u;
             const float dx = (float)(rx0 + x_lo) - sx3, dy = (float)(ry + ty_top) - sy3;
             float w0 = sa0 * dx + sb0 * dy, w1 = sa1 * dx + sb1 * dy;                            // exact integers
-            uint32_t addr = ry * TILE_STRIDE + rx0;
+            uint32_t addr = ry * (P64 ? STR64 : TILE_STRIDE) + rx0;
             const uint32_t li = cs + s + 1;
             uint32_t mine = 0;
             if (EXACT || (ZMODE && !P64)) {
@@ -558,7 +564,7 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
                 // sequential accumulation w += a).
                 const unsigned long long P = ((unsigned long long)bperm(s, my_key) << 32) | bperm(s, my_sid);
                 unsigned long long* top = reinterpret_cast<unsigned long long*>(tilebuf);
-                unsigned long long* sec = top + TILE_H * TILE_STRIDE;
+                unsigned long long* sec = top + TILE_H * STR64;
                 float z1 = 0.0f, z2 = 0.0f, z3 = 0.0f;
                 if (ZMODE) { z1 = bpermf(s, __uint_as_float(b.q5.y)); z2 = bpermf(s, __uint_as_float(b.q5.z)); z3 = bpermf(s, __uint_as_float(b.q5.w)); }
                 constexpr int TRIP = B32_TRIP;
@@ -786,8 +792,8 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a) {
                 const uint32_t row = p >> 6, col = p & 63;
                 const uint32_t px = x_lo + col, py = ty_top + row;
                 const bool inb = px < x_hi && py >= y_lo && py < y_hi;
-                t64[row * TILE_STRIDE + col] = inb ? (((unsigned long long)(~zsort_key(a.zbuf[(size_t)py * fp.width + px])) << 32) | 0xFFFFFFFFull) : ~0ull;
-                t64[TILE_H * TILE_STRIDE + row * TILE_STRIDE + col] = 0ull;
+                t64[row * STR64 + col] = inb ? (((unsigned long long)(~zsort_key(a.zbuf[(size_t)py * fp.width + px])) << 32) | 0xFFFFFFFFull) : ~0ull;
+                t64[TILE_H * STR64 + row * STR64 + col] = 0ull;
             }
         } else if (ZMODE) { // 64-bit entries (depth key << 32 | list position), seeded with the current z-buffer: a fragment wins
             unsigned long long* t64 = reinterpret_cast<unsigned long long*>(tilebuf);       // only with a strictly smaller depth
@@ -800,7 +806,7 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a) {
         } else {
             if (P64 && TH < (uint32_t)TILE_H) {             // half-height tile: clear only the rows in use of both 64-bit planes
                 unsigned long long* t64 = reinterpret_cast<unsigned long long*>(tilebuf);
-                for (uint32_t i = tid; i < TH * TILE_STRIDE; i += NT) { t64[i] = 0ull; t64[TILE_H * TILE_STRIDE + i] = 0ull; }
+                for (uint32_t i = tid; i < TH * STR64; i += NT) { t64[i] = 0ull; t64[TILE_H * STR64 + i] = 0ull; }
             } else
             for (uint32_t i = tid; i < (P64 ? 4 : (EXACT ? 1 : 2)) * TILE_H * TILE_STRIDE; i += NT) tilebuf[i] = 0;
         }
@@ -980,7 +986,7 @@ __device__ __forceinline__ void shade_tile_p64(const FillArgs& a, const uint32_t
                                                uint32_t y_lo, uint32_t y_hi, uint32_t ty_top, uint32_t tid, uint32_t lane, uint32_t TH) {
     const FrameParams& fp = a.fp;
     const unsigned long long* top = reinterpret_cast<const unsigned long long*>(tilebuf);
-    const unsigned long long* sec = top + TILE_H * TILE_STRIDE;
+    const unsigned long long* sec = top + TILE_H * STR64;
     const int shading = fp.shading;
     const bool need5 = !fp.affine || !fp.fixed_point || fp.ortho;       // q5: literal-replay start value / 1/z terms
     const uint32_t W = fp.width;
@@ -993,7 +999,7 @@ __device__ __forceinline__ void shade_tile_p64(const FillArgs& a, const uint32_t
         const uint32_t rowA = r0 + (tid >> 6), rowB = rowA + ROWS_PER_STEP;
         const uint32_t px = x_lo + col, pyA = ty_top + rowA, pyB = ty_top + rowB;
         const bool inA = rowA < TH && px < x_hi && pyA >= y_lo && pyA < y_hi, inB = rowB < TH && px < x_hi && pyB >= y_lo && pyB < y_hi;
-        unsigned long long tA = inA ? top[rowA * TILE_STRIDE + col] : (ZMODE ? ~0ull : 0ull), tB = inB ? top[rowB * TILE_STRIDE + col] : (ZMODE ? ~0ull : 0ull);
+        unsigned long long tA = inA ? top[rowA * STR64 + col] : (ZMODE ? ~0ull : 0ull), tB = inB ? top[rowB * STR64 + col] : (ZMODE ? ~0ull : 0ull);
         const bool cA = covered(tA), cB = covered(tB);
         if (!__ballot(cA || cB)) continue;
         RecRegs ra, rb;
@@ -1018,7 +1024,7 @@ __device__ __forceinline__ void shade_tile_p64(const FillArgs& a, const uint32_t
             unsigned long long limit = 0, seed = 0;
             if (cov && !ok) {
                 if (ZMODE) seed = ((unsigned long long)(~zsort_key(a.zbuf[(size_t)py * W + px])) << 32) | 0xFFFFFFFFull;
-                const unsigned long long t2 = sec[row * TILE_STRIDE + col];
+                const unsigned long long t2 = sec[row * STR64 + col];
                 if (t2 > seed) {                                  // (z-buffer mode: the runner-up must itself beat the stored depth)
                     ok = hit_test<FMT8>(a, sid_of(t2), px, py, h);
                     if (ok) t = t2; else limit = t2;
