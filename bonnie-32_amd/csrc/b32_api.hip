@@ -555,7 +555,7 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
         c->cap_pairs = n;
     }
     const uint32_t need_blocks = std::max((uint32_t)((std::max(c->cap_pairs, c->cap_work) + SORT_TILE - 1) / SORT_TILE) + 1,
-                                          (uint32_t)(c->cap_work / 2048 + 2));          // span counting sort: 2048 faces per block
+                                          (uint32_t)(c->cap_work / 1024 + 2));          // span counting sort: >= 1024 faces per block
     if (need_blocks > c->hist_blocks || !c->block_hist) {
         if ((rc = ensure_plain(c, c->block_hist, (size_t)4096 * need_blocks))) return rc;
         c->hist_blocks = need_blocks;

@@ -188,7 +188,10 @@ __global__ __launch_bounds__(SORT_THREADS) void k_scatter(const uint32_t* __rest
 // The max-of-priorities coverage needs no order inside a tile list, so the (tile, surface) pairs are never materialised with
 // keys and never ranked: k_count_spans histograms the tiles of 2048 faces in LDS (LDS atomics), k_scan_rows scans every tile's
 // row across the blocks, k_place_spans re-reads the spans and drops each surface id at base[tile]++ (LDS atomic cursor).
-constexpr uint32_t SPAN_BLOCK = 2048;           // faces per workgroup
+#ifndef B32_SPAN_BLOCK
+#define B32_SPAN_BLOCK 2048
+#endif
+constexpr uint32_t SPAN_BLOCK = B32_SPAN_BLOCK;           // faces per workgroup
 constexpr uint32_t SPAN_MAX_TILES = 4096;       // LDS histogram capacity (rows: tiles, or 2 x tiles with the class split)
 
 // With `keys` (scenes that can have a transparent pass) every tile gets two rows: opaque-class entries and transparent-class
