@@ -87,6 +87,28 @@ __device__ __forceinline__ uint32_t sample8(const Tri& t, const uint32_t* __rest
     return gtex[t.toff + ty * t.tw + tx];
 }
 
+// Texel address of a fragment (index into the texel pool): -1 = untextured (white), -2 = zero-size texture (transparent sample).
+// Same arithmetic as texel_drawn / Texture15::sample (types.rs:671-681); split off so that several fetches can be in flight.
+__device__ __forceinline__ int tri_texel_addr(const Tri& t, float bcx, float bcy, float bcz, bool affine) {
+    if ((t.flags & F_TEX_MASK) == F_TEX_NONE) return -1;
+    if (t.tw == 0 || t.th == 0) return -2;
+    float u, v;
+    if (affine) {
+        u = bcx * t.u1 + bcy * t.u2 + bcz * t.u3;
+        v = bcx * t.v1 + bcy * t.v2 + bcz * t.v3;
+    } else {
+        const float inv_z = bcx * t.iz1 + bcy * t.iz2 + bcz * t.iz3;
+        const float u_over_z = bcx * t.u1 * t.iz1 + bcy * t.u2 * t.iz2 + bcz * t.u3 * t.iz3;
+        const float v_over_z = bcx * t.v1 * t.iz1 + bcy * t.v2 * t.iz2 + bcz * t.v3 * t.iz3;
+        u = u_over_z / inv_z;
+        v = v_over_z / inv_z;
+    }
+    const float uw = rem_euclid1(u), vw = rem_euclid1(1.0f - v);
+    const uint32_t tx = min(f2u_sat(uw * (float)t.tw), t.tw - 1);
+    const uint32_t ty = min(f2u_sat(vw * (float)t.th), t.th - 1);
+    return (int)(t.toff + ty * t.tw + tx);
+}
+
 // Texel fetch + transparency rules (render.rs:1563-1607; 8-bit path render.rs:1322-1352). Returns false when the fragment is skipped.
 template <int TEXMODE, bool FMT8 = false>
 __device__ __forceinline__ bool texel_drawn(const Tri& t, float bcx, float bcy, float bcz, const uint16_t* __restrict__ gtex,
@@ -388,6 +410,9 @@ __device__ __forceinline__ uint32_t cover_surface(const Tri& tr, uint32_t cx0, u
     return drawn_count;
 }
 
+template <bool FMT8> __device__ __forceinline__ bool hit_finish(uint32_t flags, int taddr, uint32_t fetched, uint32_t& texel);
+template <bool FMT8> __device__ __forceinline__ uint32_t fetch_texel(const FillArgs& a, int taddr);
+
 // ---- wave-level helpers for the row-item scheduler
 __device__ __forceinline__ uint32_t dpp_max_scan(uint32_t v) {          // inclusive prefix max over the 64 lanes, identity 0
 #ifdef B32_NO_DPP
@@ -540,6 +565,44 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
                 // (sort-free path with EXACT coverage: the fragment's global priority goes straight to the winners; every stored
                 // winner is a drawn fragment, so no runner-up is kept)
                 const unsigned long long P = P64 ? (((unsigned long long)bperm(s, my_key) << 32) | bperm(s, my_sid)) : 0ull;
+                if (P64 && EXACT && TEXMODE == 0) {
+                    // four pixels per trip: the four texel fetches are issued together, then the skip rule, then the (non-returning)
+                    // atomics of the drawn fragments
+                    unsigned long long* top = reinterpret_cast<unsigned long long*>(tilebuf);
+                    for (uint32_t i = 0; __ballot(i < n); i += 4) {
+                        float wa[4], wb[4];
+                        wa[0] = w0; wb[0] = w1;
+#pragma unroll
+                        for (int j = 1; j < 4; ++j) { wa[j] = wa[j - 1] + sa0; wb[j] = wb[j - 1] + sa1; }
+                        bool in[4]; int ta[4]; uint32_t fe[4]; unsigned long long Pj[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float cx = wa[j] * sinv, cy = wb[j] * sinv;
+                            const float cz = 1.0f - cx - cy;
+                            in[j] = (i + j < n) & (cx >= ERR) & (cy >= ERR) & (cz >= ERR);
+                            Pj[j] = P; ta[j] = -1;
+                            if (in[j]) {
+                                if (ZMODE) { uint32_t zkey; in[j] = frag_zkey(tr, cx, cy, cz, zkey); Pj[j] = ((unsigned long long)(~zkey) << 32) | (uint32_t)P; }
+                                ta[j] = tri_texel_addr(tr, cx, cy, cz, affine);
+                            }
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) fe[j] = fetch_texel<FMT8>(a, in[j] ? ta[j] : -1);
+                        bool any = false;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            uint32_t texel;
+                            in[j] = in[j] && hit_finish<FMT8>(tr.flags, ta[j], fe[j], texel);
+                            any |= in[j];
+                            mine += in[j] ? 1u : 0u;
+                        }
+                        if (any) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) atomicMax(&top[addr + j], in[j] ? Pj[j] : 0ull);
+                        }
+                        addr += 4; w0 = wa[3] + sa0; w1 = wb[3] + sa1;
+                    }
+                } else
                 for (uint32_t i = 0; __ballot(i < n); ++i) {
                     if (i < n) {
                         const float bcx = w0 * sinv, bcy = w1 * sinv;
