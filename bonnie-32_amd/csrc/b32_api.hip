@@ -370,6 +370,9 @@ static int upload_geometry(b32_ctx* c, const B32Vertex* v, uint32_t nv, const B3
     return B32_OK;
 }
 
+// CHEAP coverage is worth it while skipped winners are rare: textures with at most 1/cheap_den() skippable texels
+static size_t cheap_den() { static const size_t d = getenv("B32_CHEAP_DEN") ? (size_t)atoi(getenv("B32_CHEAP_DEN")) : 32; return d ? d : 32; }
+
 static int layout_textures(b32_ctx* c, uint32_t nt, const uint32_t* w, const uint32_t* h, const uint32_t* blend, size_t* total, bool rgba = false) {
     if (nt > 4094) return B32_E_UNSUPPORTED;
     c->h_tex.resize(nt);
@@ -408,7 +411,7 @@ int b32_scene_upload(b32_ctx* c, const B32Vertex* v, uint32_t nv, const B32Face*
         if (n) HIPCHK(c, hipMemcpyAsync(c->d_texels + c->h_tex[i].offset, tex[i].pixels, n * 2, hipMemcpyHostToDevice, c->stream));
         size_t skippable = 0;                                               // texels the black_transparent rule can skip
         for (size_t k = 0; k < n; ++k) skippable += (tex[i].pixels[k] & 0x7FFF) == 0;
-        if (n == 0 || skippable * 32 > n) c->cheap_ok = false;
+        if (n == 0 || skippable * cheap_den() > n) c->cheap_ok = false;
     }
     if ((rc = upload_geometry(c, v, nv, f, nf))) return rc;
     for (uint32_t i = 0; i < nt; ++i) if (bl[i] != B32_BLEND_OPAQUE) c->may_blend = true;
@@ -440,7 +443,7 @@ int b32_scene_upload_rgba(b32_ctx* c, const B32Vertex* v, uint32_t nv, const B32
             skippable += b == B32_BLEND_ERASE;
             blend_texels |= b != B32_BLEND_OPAQUE && b != B32_BLEND_ERASE;
         }
-        if (n == 0 || skippable * 32 > n) c->cheap_ok = false;
+        if (n == 0 || skippable * cheap_den() > n) c->cheap_ok = false;
     }
     if ((rc = upload_geometry(c, v, nv, f, nf))) return rc;
     bool alpha_faces = false;
@@ -475,7 +478,7 @@ int b32_scene_upload_indexed(b32_ctx* c, const B32Vertex* v, uint32_t nv, const 
                 const uint16_t col = ix < tex[i].clut_len ? tex[i].clut[ix] : (uint16_t)0;
                 skippable += (col & 0x7FFF) == 0;
             }
-            if (skippable * 32 > n) c->cheap_ok = false;
+            if (skippable * cheap_den() > n) c->cheap_ok = false;
         }
         uint8_t* d_idx = nullptr; uint16_t* d_clut = nullptr;
         HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d_idx), n));
