@@ -143,7 +143,9 @@ __device__ __forceinline__ float rem_euclid1(float x) {
 }
 
 // total order on non-NaN f32 as u32 (z-buffer keys for the 64-bit LDS atomicMin) and its inverse
-__device__ __forceinline__ uint32_t zsort_key(float z) { const uint32_t b = __float_as_uint(z); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+// -0.0 and +0.0 get ONE key (the reference's `z < zbuffer` sees them as equal, so the first fragment in order keeps the pixel);
+// a stored depth that decodes to zero has its sign recomputed from the winning surface (exact_depth_at).
+__device__ __forceinline__ uint32_t zsort_key(float z) { const uint32_t b = z == 0.0f ? 0u : __float_as_uint(z); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
 __device__ __forceinline__ float zsort_val(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k); }
 
 // ---------------------------------------------------------------- colour helpers

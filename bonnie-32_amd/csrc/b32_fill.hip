@@ -348,6 +348,24 @@ __device__ __forceinline__ bool frag_zkey(const Tri& t, float bcx, float bcy, fl
     return z == z;
 }
 
+// Depth of surface `sid` at pixel (px, py) with its exact bits (only needed when the z-buffer key decoded to zero: the key does not
+// carry the sign of a zero depth).  Same arithmetic as the coverage: edge functions -> barycentrics -> 1 / (bc . 1/z).
+__device__ float exact_depth_at(const FillArgs& a, uint32_t sid, uint32_t px, uint32_t py) {
+    const uint4* rp = reinterpret_cast<const uint4*>(a.recs + sid);
+    const uint4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3], q4 = rp[4], q5 = rp[5];
+    Tri tr;
+    tr.x3 = __uint_as_float(q0.x); tr.y3 = __uint_as_float(q0.y); tr.a0 = __uint_as_float(q0.z); tr.b0 = __uint_as_float(q0.w);
+    tr.a1 = __uint_as_float(q1.x); tr.b1 = __uint_as_float(q1.y); tr.inv_area = __uint_as_float(q1.z);
+    tr.min_x = q1.w & 0xFFFF; tr.max_x = q1.w >> 16; tr.min_y = q2.x & 0xFFFF; tr.max_y = q2.x >> 16;
+    tr.flags = q3.w;
+    tr.w0_start = __uint_as_float(q4.w); tr.w1_start = __uint_as_float(q5.x);
+    float w0, w1, bcx, bcy, bcz;
+    edge_w(tr, px, py, w0, w1);
+    (void)inside_bc(tr, w0, w1, bcx, bcy, bcz);
+    const float inv_z = bcx * __uint_as_float(q5.y) + bcy * __uint_as_float(q5.z) + bcz * __uint_as_float(q5.w);
+    return 1.0f / inv_z;
+}
+
 // Phase A for one surface: coverage of the (tile-clipped) bbox [cx0,cx1) x [cy0,cy1), winner value li.
 template <int TEXMODE, bool EXACT, bool ZMODE, bool FMT8>
 __device__ __forceinline__ uint32_t cover_surface(const Tri& tr, uint32_t cx0, uint32_t cx1, uint32_t cy0, uint32_t cy1, uint32_t li,
@@ -894,7 +912,11 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a) {
                 if (ZMODE) {
                     const unsigned long long e = reinterpret_cast<const unsigned long long*>(tilebuf)[row * TILE_STRIDE + col];
                     li = (uint32_t)e;
-                    if (li) a.zbuf[(size_t)py * fp.width + px] = zsort_val((uint32_t)(e >> 32));   // fb.zbuffer[idx] = z, render.rs:1686-1688
+                    if (li) {                                                       // fb.zbuffer[idx] = z, render.rs:1686-1688
+                        float z = zsort_val((uint32_t)(e >> 32));
+                        if (z == 0.0f) z = exact_depth_at(a, a.pair_vals[e0 + li - 1], px, py);
+                        a.zbuf[(size_t)py * fp.width + px] = z;
+                    }
                 } else li = tilebuf[row * TILE_STRIDE + col];
                 // CHEAP coverage: the runner-up travels in the high half when the tile list is short enough (< 32768 entries);
                 // bit 31 marks a long list whose runner-up is unknown.
@@ -1123,8 +1145,14 @@ __device__ __forceinline__ void shade_tile_p64(const FillArgs& a, const uint32_t
                 if ((int)lane == fl && best) { ok = hit_test<FMT8>(a, sid_of(best), px, py, h); t = best; }
             }
         }
-        if (okA) { a.fb[(size_t)pyA * W + px] = colour<FMT8>(a, hA, shading, px, pyA); if (ZMODE) a.zbuf[(size_t)pyA * W + px] = zsort_val(~(uint32_t)(tA >> 32)); }
-        if (okB) { a.fb[(size_t)pyB * W + px] = colour<FMT8>(a, hB, shading, px, pyB); if (ZMODE) a.zbuf[(size_t)pyB * W + px] = zsort_val(~(uint32_t)(tB >> 32)); }
+        if (okA) {
+            a.fb[(size_t)pyA * W + px] = colour<FMT8>(a, hA, shading, px, pyA);
+            if (ZMODE) { float z = zsort_val(~(uint32_t)(tA >> 32)); if (z == 0.0f) z = exact_depth_at(a, hA.sid, px, pyA); a.zbuf[(size_t)pyA * W + px] = z; }
+        }
+        if (okB) {
+            a.fb[(size_t)pyB * W + px] = colour<FMT8>(a, hB, shading, px, pyB);
+            if (ZMODE) { float z = zsort_val(~(uint32_t)(tB >> 32)); if (z == 0.0f) z = exact_depth_at(a, hB.sid, px, pyB); a.zbuf[(size_t)pyB * W + px] = z; }
+        }
     }
 }
 

@@ -718,3 +718,9 @@ def test_randomised_mode_soak():
     last = r.stdout.strip().splitlines()[-1]
     assert last.startswith("soak:") and last.endswith(" 0 failures"), r.stdout[-3000:]
     assert int(last.split()[1]) > 50
+    # orthographic + z-buffer + hostile coordinates: depths of exactly -0.0 / +0.0 meet in one pixel (the reference's `z < zbuffer`
+    # sees them as equal, so one depth key for both, sign of the stored depth recomputed) -- found by this tool
+    env = dict(os.environ, SOAK_FORCE="orthoz")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak.py"), "15", "21"], capture_output=True, text=True, cwd=root, env=env)
+    last = r.stdout.strip().splitlines()[-1]
+    assert r.returncode == 0 and last.startswith("soak:") and last.endswith(" 0 failures"), r.stdout[-3000:] + r.stderr[-2000:]

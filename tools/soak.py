@@ -1,6 +1,6 @@
 """Randomised parity soak: random scenes x random settings (both pixel formats, every mode) GPU vs CPU oracle, bit-exact.
 usage: soak.py [seconds] [seed]"""
-import sys, time
+import os, sys, time
 sys.path.insert(0, ".")
 import numpy as np
 import bonnie32_amd as b32
@@ -17,16 +17,34 @@ while time.time() < t_end:
     cfg = rng.choice(["C1", "C2", "C5"])
     W, H = [(320, 240), (333, 197), (640, 480), (64, 64), (1280, 720), (97, 801)][rng.integers(6)]
     ntri = int(rng.choice([1, 7, 300, 2500, 20000]))
+    if os.environ.get("SOAK_FORCE"):                     # screen-filling triangles: keep the CPU oracle's work bounded
+        ntri = min(ntri, 300); W, H = min(W, 640), min(H, 480)
     variant = rng.choice(["bench", "gouraud", "blend", "float"])
     sc = scenegen.make_scene(cfg, n_tris=ntri, seed=int(rng.integers(1 << 30)), variant=variant, width=W, height=H,
                              bbox_px=float(rng.choice([4.0, 60.0, 900.0, 20000.0])))
+    force = os.environ.get("SOAK_FORCE", "")            # "orthoz": every scene hostile + orthographic + z-buffer (signed-zero depths)
+    hostile = bool(rng.integers(5) == 0 or force)
+    if hostile:                                           # hostile geometry: huge / degenerate / near-plane coordinates, wild UVs
+        v = sc.vertices
+        k = max(1, len(v) // 20)
+        idx = rng.choice(len(v), k, replace=False)
+        v["pos"][idx, int(rng.integers(3))] = (10.0 ** rng.uniform(3, 30, k)) * rng.choice([-1, 1], k)
+        idx = rng.choice(len(v), k, replace=False)
+        v["pos"][idx, 2] = rng.choice([0.1, 0.100001, 0.0999, -3.0, 0.0, 1e-3], k)
+        idx = rng.choice(len(v), k, replace=False)
+        v["uv"][idx] = rng.choice([1e9, -1e9, 0.0, 1.0, -1.0, 123456.789], (k, 2))
+        if len(v) >= 6:
+            v["pos"][0:3] = v["pos"][3:6]
     st = sc.settings
     st.use_zbuffer = bool(rng.integers(2)); st.affine_textures = bool(rng.integers(4) > 0); st.dithering = bool(rng.integers(4) > 0)
     st.backface_cull = bool(rng.integers(3) > 0)
-    st.backface_wireframe = bool(rng.integers(4) == 0) and ntri <= 2500
-    st.wireframe_overlay = bool(rng.integers(10) == 0) and ntri <= 2500
+    # (no wireframe on hostile coordinates: the oracle walks lines literally, 2^29 steps per edge would take minutes)
+    st.backface_wireframe = bool(rng.integers(4) == 0) and ntri <= 2500 and not hostile
+    st.wireframe_overlay = bool(rng.integers(10) == 0) and ntri <= 2500 and not hostile
     st.xray_mode = bool(rng.integers(8) == 0)
-    if rng.integers(6) == 0:
+    if force == "orthoz":
+        st.use_zbuffer = True; st.xray_mode = False
+    if rng.integers(6) == 0 or force == "orthoz":
         st.ortho_projection = (float(rng.choice([0.02, 0.1, 1.0])), float(rng.normal(0, 50)), float(rng.normal(0, 50)))
         sc.camera.position = (0.0, 0.0, float(rng.choice([0.0, 2500.0])))
     if rng.integers(3) == 0 and variant != "gouraud":
@@ -77,4 +95,14 @@ while time.time() < t_end:
     if not ok:
         fails += 1
         print("FAIL", desc, "rc", rc, grc, flush=True)
+        if rc == 0 and grc == 0:
+            got = fb.pixels.reshape(H, W, 4); exp = ofb.pixels.reshape(H, W, 4)
+            bad = (got != exp).any(axis=2)
+            zbad = (fb.zbuffer.view(np.uint32) != ofb.zbuffer.view(np.uint32)).reshape(H, W) if st.use_zbuffer else np.zeros((H, W), bool)
+            ys, xs = np.nonzero(bad | zbad)
+            print(f"   pixels {int(bad.sum())} zbuf {int(zbad.sum())} tris {tm.triangles_drawn}/{otm.triangles_drawn} first {list(zip(ys[:4].tolist(), xs[:4].tolist()))}", flush=True)
+            for y, x in list(zip(ys[:3].tolist(), xs[:3].tolist())):
+                print(f"   ({y},{x}) gpu {got[y, x].tolist()} z {fb.zbuffer.reshape(H, W)[y, x]!r}  cpu {exp[y, x].tolist()} z {ofb.zbuffer.reshape(H, W)[y, x]!r}", flush=True)
+        if os.environ.get("SOAK_STOP"):
+            break
 print(f"soak: {n} scenes ({drawn} drawn, {refused} refused by both sides), {fails} failures")
