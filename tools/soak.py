@@ -12,8 +12,42 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 ctx = R.Context(0)
 t_end = time.time() + budget
 n = fails = drawn = refused = 0
+
+def sky_case():
+    """clear_gradient + skybox sphere + star sprites + nearest upscale with a random camera orientation; returns ok."""
+    from tests.test_sky_present import sky_mesh
+    W, H = [(320, 240), (640, 480), (97, 333), (1000, 64)][rng.integers(4)]
+    q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+    if np.linalg.det(q) < 0:
+        q[:, 2] = -q[:, 2]
+    q = q.astype(np.float32)
+    pos = tuple(float(x) for x in rng.normal(0, 100, 3).astype(np.float32))
+    cam = b32.Camera(position=pos, basis_x=tuple(map(float, q[:, 0])), basis_y=tuple(map(float, q[:, 1])), basis_z=tuple(map(float, q[:, 2])))
+    verts, faces = sky_mesh(pos, int(rng.choice([8, 24, 48])), int(rng.choice([6, 16, 32])), seed=int(rng.integers(1 << 20)))
+    top = b32.Color(*[int(x) for x in rng.integers(0, 256, 3)]); bot = b32.Color(*[int(x) for x in rng.integers(0, 256, 3)])
+    k = int(rng.integers(0, 300))
+    cx = rng.integers(-4, W + 4, k); cy = rng.integers(-4, H + 4, k); rgb = rng.integers(0, 256, (k, 3)); size = float(rng.choice([0.5, 1.0, 2.0, 3.7]))
+    ofb = O.Framebuffer(W, H); ofb.clear_gradient(top, bot)
+    fb = R.Framebuffer(W, H, ctx); fb.clear_gradient(top, bot)
+    if ofb.render_skybox_mesh(verts, faces, cam) != 0:
+        return True
+    fb.render_skybox_mesh(verts, faces, cam)
+    if k:
+        ofb.draw_star_diamonds(cx, cy, rgb, size); fb.draw_star_diamonds(cx, cy, rgb, size)
+    ok = np.array_equal(fb.pixels, ofb.pixels)
+    dw, dh = int(rng.integers(1, 2000)), int(rng.integers(1, 1200))
+    out = fb.present_nearest(dw, dh)
+    sx = ((2 * np.arange(dw) + 1) * W) // (2 * dw); sy = ((2 * np.arange(dh) + 1) * H) // (2 * dh)
+    return ok and np.array_equal(out, ofb.image()[sy][:, sx])
+
 while time.time() < t_end:
     n += 1
+    if rng.integers(12) == 0:
+        drawn += 1
+        if not sky_case():
+            fails += 1
+            print(f"FAIL #{n} sky/gradient/stars/present", flush=True)
+        continue
     cfg = rng.choice(["C1", "C2", "C5"])
     W, H = [(320, 240), (333, 197), (640, 480), (64, 64), (1280, 720), (97, 801)][rng.integers(6)]
     ntri = int(rng.choice([1, 7, 300, 2500, 20000]))
@@ -92,6 +126,27 @@ while time.time() < t_end:
             ok = np.array_equal(fb.zbuffer.view(np.uint32), ofb.zbuffer.view(np.uint32))
         if ok and tm.fragments and len(bands) == 1:
             ok = tm.fragments == otm.fragments
+    if ok and rc == 0 and len(bands) == 1 and rng.integers(10) < 4:
+        # a second mesh on the same framebuffer through the drop-in call: read-modify-write of colours and of the persistent depth buffer
+        sc2 = scenegen.make_scene(str(rng.choice(["C1", "C2"])), n_tris=int(rng.choice([7, 300, 2500])), seed=int(rng.integers(1 << 30)),
+                                  variant=str(rng.choice(["bench", "blend", "gouraud"])), width=W, height=H, bbox_px=float(rng.choice([60.0, 900.0, 20000.0])))
+        st2 = sc2.settings
+        st2.use_zbuffer = bool(rng.integers(2)); st2.backface_cull = bool(rng.integers(2)); st2.use_rgb555 = not fmt8
+        desc += f" + mesh2 {sc2.name} z={st2.use_zbuffer}"
+        try:
+            if fmt8:
+                t2 = [b32.Texture.from_texture15(t, int(rng.choice([0, 1, 3]))) for t in sc2.textures]
+                rc2, otm2 = O.render_mesh(ofb, sc2.vertices, sc2.faces, t2, sc2.camera, st2)
+                tm2 = R.render_mesh(fb, sc2.vertices, sc2.faces, t2, sc2.camera, st2)
+            else:
+                rc2, otm2 = O.render_mesh_15(ofb, sc2.vertices, sc2.faces, sc2.textures, sc2.camera, st2)
+                tm2 = R.render_mesh_15(fb, sc2.vertices, sc2.faces, sc2.textures, sc2.camera, st2)
+            ok = rc2 == 0 and np.array_equal(fb.pixels, ofb.pixels) and tm2.triangles_drawn == otm2.triangles_drawn
+            if ok and (st.use_zbuffer or st2.use_zbuffer):
+                ok = np.array_equal(fb.zbuffer.view(np.uint32), ofb.zbuffer.view(np.uint32))
+            st = st2 if st2.use_zbuffer else st
+        except R.B32Error as e:
+            ok = False; grc = e.code
     if not ok:
         fails += 1
         print("FAIL", desc, "rc", rc, grc, flush=True)
