@@ -507,6 +507,41 @@ __device__ __forceinline__ uint32_t cover_slow64(const Tri& tr, unsigned long lo
 // incrementally exactly like the reference's inner loop (render.rs:1533-1707): start value = closed form at the row start
 // (exact integers under the k_setup guard), then w0 += a0, w1 += a1 per pixel.  Row lengths are far more uniform than
 // bbox areas, big surfaces fill whole rounds, and there is no per-surface scalar work.
+// Row trimming.  The inside test (render.rs:1536-1542) is evaluated on rounded floats, but a pixel can only pass it when three
+// linear conditions on the (exact, integer) edge values hold:
+//     bc_x = fl(w0 * inv_area) >= -1e-4            =>  s*w0 >= -T              (s = sign of inv_area, A = 1/|inv_area|,
+//     bc_y likewise                                 =>  s*w1 >= -T               T = 1.02e-4 * A: 2 % above what the rounding of the
+//     bc_z = fl(fl(1 - bc_x) - bc_y) >= -1e-4      =>  s*(w0 + w1) <= A + T     product and of A can move the threshold)
+// (for the third: bc_x and bc_y have passed, so both lie in [-1e-4, 1.0003] and the two subtractions are off by < 1.3e-7).
+// Every w is linear in x along the row, so the three conditions cut the clipped row [0, n) down to one interval [lo, hi);
+// pixels outside it are certain to fail, pixels inside still take the reference's own test.  The interval ends are computed with
+// an approximate reciprocal and widened by 0.01 px (its error over a 64-px row is < 2e-5 px).  Returns lo and shrinks n to
+// hi - lo.  Surfaces with A outside [0.5, 2^20) are left alone (w0 + w1 could round where it matters).
+#ifndef B32_ROW_TRIM
+#define B32_ROW_TRIM 1
+#endif
+__device__ __forceinline__ uint32_t row_trim(float w0, float w1, float a0, float a1, float inv_area, uint32_t& n) {
+    const float A = __builtin_amdgcn_rcpf(__builtin_fabsf(inv_area));
+    if (!((A >= 0.5f) & (A < 1048576.0f))) return 0u;
+    const float s = inv_area < 0.0f ? -1.0f : 1.0f;
+    const float T = 1.02e-4f * A;
+    const float E[3] = { s * w0 + T, s * w1 + T, (A + T) - s * (w0 + w1) };
+    const float G[3] = { s * a0, s * a1, -(s * a0 + s * a1) };
+    float flo = 0.0f, fhi = (float)n;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const float r = -E[j] * __builtin_amdgcn_rcpf(G[j]);
+        if (G[j] > 0.0f) flo = fmaxf(flo, ceilf(r - 0.01f));            // E + G x >= 0  <=>  x >= r
+        else if (G[j] < 0.0f) fhi = fminf(fhi, floorf(r + 0.01f) + 1.0f);   // x <= r
+        else if (E[j] < 0.0f) fhi = 0.0f;                                // constant along the row and failing
+    }
+    flo = fminf(flo, (float)n);
+    fhi = fmaxf(fhi, flo);
+    const uint32_t lo = (uint32_t)flo;
+    n = (uint32_t)fhi - lo;
+    return lo;
+}
+
 template <int TEXMODE, bool EXACT, int NW, bool ZMODE, bool FMT8, bool P64 = false>
 __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, uint32_t e0, uint32_t n_op, uint32_t lane, uint32_t wave,
                                                            volatile uint32_t* cursor, volatile uint32_t* wmark, const TexDesc& lds_desc,
@@ -572,10 +607,15 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
                 tr.tw = bperm(s, b.tw); tr.th = bperm(s, b.th); tr.toff = bperm(s, b.toff);
                 if (!affine || ZMODE) { tr.iz1 = bpermf(s, __uint_as_float(b.q5.y)); tr.iz2 = bpermf(s, __uint_as_float(b.q5.z)); tr.iz3 = bpermf(s, __uint_as_float(b.q5.w)); }
             }
-            const uint32_t rx0 = sbox & 0xFF, rx1 = (sbox >> 8) & 0xFF, ry = (sbox >> 16) + (k - sP);   // tile-local
-            const uint32_t n = valid ? rx1 - rx0 : 0u;
+            uint32_t rx0 = sbox & 0xFF;
+            const uint32_t rx1 = (sbox >> 8) & 0xFF, ry = (sbox >> 16) + (k - sP);              // tile-local
+            uint32_t n = valid ? rx1 - rx0 : 0u;
             const float dx = (float)(rx0 + x_lo) - sx3, dy = (float)(ry + ty_top) - sy3;
             float w0 = sa0 * dx + sb0 * dy, w1 = sa1 * dx + sb1 * dy;                            // exact integers
+            if (B32_ROW_TRIM) {
+                const uint32_t lo = row_trim(w0, w1, sa0, sa1, sinv, n);
+                rx0 += lo; w0 += sa0 * (float)lo; w1 += sa1 * (float)lo;                         // exact: the closed form at the new start
+            }
             uint32_t addr = ry * (P64 ? STR64 : TILE_STRIDE) + rx0;
             const uint32_t li = cs + s + 1;
             uint32_t mine = 0;
