@@ -873,14 +873,15 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a) {
         for (uint32_t i = tid; i < nq; i += NT) dst[i] = src[i];
     }
     unsigned long long frag_count = 0;
-    uint32_t next_tile = 0;
-    if (tid == 0) next_tile = atomicAdd(&a.ctrl->tile_cursor, 1u);
+    // the first tile of a workgroup is its own index (no atomic: 512 same-address atomics serialise at ~12 ns each), later ones come
+    // from the shared cursor
+    uint32_t next_tile = blockIdx.x;
     for (;;) {
         if (tid == 0) { misc[0] = next_tile; misc[2] = 0; misc[4] = 0; }
         __syncthreads();
         const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)misc[0]);
         if (tile >= ntiles) break;
-        if (tid == 0) next_tile = atomicAdd(&a.ctrl->tile_cursor, 1u);    // prefetch the next tile index; consumed at the loop top
+        if (tid == 0) next_tile = gridDim.x + atomicAdd(&a.ctrl->tile_cursor, 1u);    // prefetch the next tile index; consumed at the loop top
         uint32_t e0, e1;
         if (P64) {                               // lists in any order, keyed by tile only; [e0, mid) is the opaque pass
             e0 = a.ranges[tile]; e1 = a.gather_blend ? a.tile_mid[tile] : a.ranges[tile + 1];
