@@ -1463,8 +1463,18 @@ __global__ __launch_bounds__(NT, 4) void k_blend(FillArgs a) {        // 4 waves
             const float dx = (float)(rx0 + x_lo) - tr.x3, dy = (float)py - tr.y3;
             float w0 = tr.a0 * dx + tr.b0 * dy, w1 = tr.a1 * dx + tr.b1 * dy;                              // exact integers (k_setup guard)
             uint32_t slot = sbase + (k - sP) * (rx1 - rx0);
-            for (uint32_t i = 0; __ballot(i < n); ++i) {
-                if (i < n) {
+            // every pixel of the clipped box owns a slot; only the interval of the row that can pass the inside test (row_trim) takes
+            // the texel / colour pipeline, the rest of the row's slots are just zeroed
+            uint32_t i_lo = 0, i_n = n;
+            if (B32_ROW_TRIM) {
+                i_lo = row_trim(w0, w1, tr.a0, tr.a1, tr.inv_area, i_n);
+                for (uint32_t i = 0; __ballot(i < n); ++i)
+                    if (i < n && (i < i_lo || i >= i_lo + i_n)) { if (FMT8) { frag[2 * (slot + i)] = 0; frag[2 * (slot + i) + 1] = 0; } else frag[slot + i] = 0; }
+                w0 += tr.a0 * (float)i_lo; w1 += tr.a1 * (float)i_lo; slot += i_lo;
+            }
+            const uint32_t i_end = i_lo + i_n;
+            for (uint32_t i = i_lo; __ballot(i < i_end); ++i) {
+                if (i < i_end) {
                     const uint32_t px = rx0 + x_lo + i;
                     float bcx, bcy, bcz;
                     uint32_t v0 = 0, v1 = 0;
