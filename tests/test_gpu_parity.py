@@ -184,6 +184,26 @@ def test_zbuffer_mode_large_frame(gpu_ctx, oracle):
     assert np.array_equal(fb.pixels, ofb.pixels) and np.array_equal(fb.zbuffer.view(np.uint32), ofb.zbuffer.view(np.uint32))
 
 
+@pytest.mark.parametrize("bbox_px,n", [(3e3, 2000), (2e5, 300), (1.5e6, 80), (6e6, 30)])
+@pytest.mark.parametrize("zbuf", [False, True])
+def test_triangle_sizes_across_the_row_trim_thresholds(gpu_ctx, oracle, bbox_px, n, zbuf):
+    """Row trimming (b32_fill.hip: row_trim) changes regime with the triangle's doubled area A: integer-exact below ~4900, a widening
+    margin up to 2^20, switched off above.  Triangles from ~50 px to most of the 2560x1920 frame, EXACT and CHEAP coverage."""
+    sc = scenegen.make_scene("C3", n_tris=n, bbox_px=bbox_px, seed=int(bbox_px) % 9973)
+    sc.settings.use_zbuffer = zbuf
+    want, etm, _ = cpu_render(oracle, sc)
+    try:
+        for counting in (1, 0):
+            gpu_ctx.set_fragment_counting(counting)
+            got, tm = gpu_render(gpu_ctx, sc, resident=True, indexed=True)
+            assert np.array_equal(got, want)
+            assert tm.triangles_drawn == etm.triangles_drawn
+            if counting and not zbuf:
+                assert tm.fragments == etm.fragments
+    finally:
+        gpu_ctx.set_fragment_counting(1)
+
+
 def test_c1_against_committed_frame(gpu_ctx):
     z = np.load(os.path.join(GOLD, "c1_frame.npz"))
     got, tm = gpu_render(gpu_ctx, SCENES["C1"]())
