@@ -502,7 +502,7 @@ static int validate_settings(const B32Settings* st) {
     if (st->n_lights && !st->lights) return B32_E_ARG;
     if (st->shading != B32_SHADE_NONE)
         for (uint32_t i = 0; i < st->n_lights; ++i)
-            if (st->lights[i].enabled && st->lights[i].type > B32_LIGHT_POINT) return B32_E_UNSUPPORTED;        // acos
+            if (st->lights[i].enabled && st->lights[i].type > B32_LIGHT_SPOT) return B32_E_ARG;                 // not a LightType
     return B32_OK;
 }
 

@@ -86,7 +86,40 @@ __device__ __forceinline__ V3 normalize3(V3 a) {                                
 }
 __device__ __forceinline__ V3 ld3(const float* p) { return { p[0], p[1], p[2] }; }
 
-// shade_multi_light_color, render.rs:1013-1071 (spot lights are rejected on the host: acos is not bit-portable)
+// f32::acos of the spot-light cone test (render.rs:1047).  Rust's f32::acos is the target's libm acosf: on wasm32 (the console's
+// shipping target) the `libm` crate, a port of musl's src/math/acosf.c (FreeBSD msun e_acosf.c); on Linux glibc's, which differs
+// by up to 1 ulp -- the reference itself is not bit-portable here.  This is the published musl algorithm in plain f32 arithmetic
+// (< 1 ulp; pio2_hi = 0x3fc90fda, pio2_lo = 0x33a22168).
+__device__ __forceinline__ float acosf_R(float z) {
+    const float pS0 = 1.6666586697e-01f, pS1 = -4.2743422091e-02f, pS2 = -8.6563630030e-03f, qS1 = -7.0662963390e-01f;
+    const float p = z * (pS0 + z * (pS1 + z * pS2));
+    const float q = 1.0f + z * qS1;
+    return p / q;
+}
+__device__ float acosf_musl(float x) {
+    const float pio2_hi = 1.5707962513e+00f, pio2_lo = 7.5497894159e-08f;
+    const uint32_t hx = __float_as_uint(x), ix = hx & 0x7fffffffu;
+    if (ix >= 0x3f800000u) {
+        if (ix == 0x3f800000u) return (hx >> 31) ? 2.0f * pio2_hi : 0.0f;
+        return __uint_as_float(0x7fc00000u);          // 0/(x-x): only its NaN-ness is observable (comparison + min)
+    }
+    if (ix < 0x3f000000u) {
+        if (ix <= 0x32800000u) return pio2_hi;
+        return pio2_hi - (x - (pio2_lo - x * acosf_R(x * x)));
+    }
+    if (hx >> 31) {
+        const float z = (1.0f + x) * 0.5f, s = __builtin_sqrtf(z);
+        const float w = acosf_R(z) * s - pio2_lo;
+        return 2.0f * (pio2_hi - (s + w));
+    }
+    const float z = (1.0f - x) * 0.5f, s = __builtin_sqrtf(z);
+    const float df = __uint_as_float(__float_as_uint(s) & 0xfffff000u);
+    const float c = (z - df * df) / (s + df);
+    const float w = acosf_R(z) * s + c;
+    return 2.0f * (df + w);
+}
+
+// shade_multi_light_color, render.rs:1013-1071
 __device__ void shade_multi(V3 normal, V3 world_pos, const B32Light* lights, uint32_t n_lights, float ambient, float out[3]) {
     float tr = ambient, tg = ambient, tb = ambient;
     for (uint32_t i = 0; i < n_lights; ++i) {
@@ -96,7 +129,7 @@ __device__ void shade_multi(V3 normal, V3 world_pos, const B32Light* lights, uin
         if (l.type == B32_LIGHT_DIRECTIONAL) {
             V3 neg_dir = scale3(ld3(l.direction), -1.0f);
             contribution = rmax(dot3(normal, neg_dir), 0.0f) * l.intensity;
-        } else {
+        } else if (l.type == B32_LIGHT_POINT) {
             V3 to_light = sub3(ld3(l.position), world_pos);
             float dist = __builtin_sqrtf(dot3(to_light, to_light));
             if (dist > l.radius || dist < 0.001f) contribution = 0.0f;
@@ -104,6 +137,21 @@ __device__ void shade_multi(V3 normal, V3 world_pos, const B32Light* lights, uin
                 float attenuation = 1.0f - (dist / l.radius);
                 float n_dot_l = rmax(dot3(normal, normalize3(to_light)), 0.0f);
                 contribution = n_dot_l * l.intensity * attenuation * attenuation;
+            }
+        } else {                                       // Spot, render.rs:1038-1058
+            V3 to_light = sub3(ld3(l.position), world_pos);
+            float dist = __builtin_sqrtf(dot3(to_light, to_light));
+            if (dist > l.radius || dist < 0.001f) contribution = 0.0f;
+            else {
+                const V3 to_surface = normalize3(to_light);
+                const float spot_angle = acosf_musl(dot3(scale3(to_surface, -1.0f), ld3(l.direction)));
+                if (spot_angle > l.angle) contribution = 0.0f;
+                else {                                 // (a NaN angle lands here, as in the reference)
+                    float attenuation = 1.0f - (dist / l.radius);
+                    float edge_falloff = 1.0f - (spot_angle / l.angle);
+                    float n_dot_l = rmax(dot3(normal, to_surface), 0.0f);
+                    contribution = n_dot_l * l.intensity * attenuation * attenuation * edge_falloff;
+                }
             }
         }
         float lr = (float)l.r / 255.0f, lg = (float)l.g / 255.0f, lb = (float)l.b / 255.0f;

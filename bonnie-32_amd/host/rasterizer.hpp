@@ -13,6 +13,7 @@
 //
 // The Rust shim a maintainer would add to the reference is shown in INTEGRATION.md; it binds the same C symbols.
 #pragma once
+#include <cmath>
 #include <cstdint>
 #include <optional>
 #include <stdexcept>
@@ -70,6 +71,13 @@ struct Camera { Vec3 position; Vec3 basis_x{ 1, 0, 0 }, basis_y{ 0, 1, 0 }, basi
 struct Light {
     uint32_t type = B32_LIGHT_DIRECTIONAL; Vec3 position, direction; float radius = 0, angle = 0;
     Color color{ 255, 255, 255, BlendMode::Opaque }; float intensity = 1.0f; bool enabled = true;
+    // types.rs:1355-1369 (the direction is normalized at construction, math.rs:39-49)
+    static Light spot(Vec3 position, Vec3 direction, float angle, float radius, float intensity) {
+        Light l; l.type = B32_LIGHT_SPOT; l.position = position; l.angle = angle; l.radius = radius; l.intensity = intensity;
+        const float len = std::sqrt(direction.x * direction.x + direction.y * direction.y + direction.z * direction.z);
+        l.direction = len == 0.0f ? Vec3{ 0, 0, 0 } : Vec3{ direction.x / len, direction.y / len, direction.z / len };
+        return l;
+    }
 };
 
 // types.rs:1392-1428, defaults :1475-1495, game() :1455-1460

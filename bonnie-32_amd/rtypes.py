@@ -144,6 +144,12 @@ class Light:
         """types.rs:1329-1337"""
         return Light(LIGHT_POINT, position=tuple(position), radius=radius, intensity=intensity)
 
+    @staticmethod
+    def spot(position, direction, angle, radius, intensity):
+        """types.rs:1355-1369: the direction is normalized at construction."""
+        return Light(LIGHT_SPOT, position=tuple(position), direction=tuple(_normalize_f32(direction)), angle=angle, radius=radius,
+                     intensity=intensity)
+
 
 @dataclass
 class RasterSettings:

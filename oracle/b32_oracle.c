@@ -271,6 +271,45 @@ EXPORT void b32o_dither_and_quantize(uint8_t r8, uint8_t g8, uint8_t b8, uint32_
     }
 }
 
+/* ------------------------------------------------------------------ f32::acos (spot lights, render.rs:1047)
+ * Rust's f32::acos is the target's libm acosf: on wasm32 (the console's shipping target, the docs/ .wasm artefact) the `libm` crate, a port
+ * of musl's src/math/acosf.c (FreeBSD msun e_acosf.c); on Linux glibc's.  They agree to within 1 ulp, not bit for bit, so the
+ * reference itself is not bit-portable here.  This is the published musl / msun algorithm (plain f32 arithmetic, < 1 ulp), the
+ * same on the GPU (b32_setup.hip) and in oracle/np_model.py; constants as published (pio2_hi = 0x3fc90fda, pio2_lo = 0x33a22168). */
+static float acosf_R(float z) {
+    const float pS0 = 1.6666586697e-01f, pS1 = -4.2743422091e-02f, pS2 = -8.6563630030e-03f, qS1 = -7.0662963390e-01f;
+    float p = z * (pS0 + z * (pS1 + z * pS2));
+    float q = 1.0f + z * qS1;
+    return p / q;
+}
+EXPORT float b32o_acosf(float x) {
+    const float pio2_hi = 1.5707962513e+00f, pio2_lo = 7.5497894159e-08f;
+    uint32_t hx, ix;
+    memcpy(&hx, &x, 4);
+    ix = hx & 0x7fffffffu;
+    if (ix >= 0x3f800000u) {                          /* |x| >= 1 or NaN */
+        if (ix == 0x3f800000u) return (hx >> 31) ? 2.0f * pio2_hi : 0.0f;      /* (+ 0x1p-120 rounds away) */
+        return 0.0f / (x - x);
+    }
+    if (ix < 0x3f000000u) {                           /* |x| < 0.5 */
+        if (ix <= 0x32800000u) return pio2_hi;        /* |x| < 2^-26 */
+        return pio2_hi - (x - (pio2_lo - x * acosf_R(x * x)));
+    }
+    if (hx >> 31) {                                   /* x < -0.5 */
+        float z = (1.0f + x) * 0.5f, s = sqrtf(z);
+        float w = acosf_R(z) * s - pio2_lo;
+        return 2.0f * (pio2_hi - (s + w));
+    }
+    {                                                 /* x > 0.5 */
+        float z = (1.0f - x) * 0.5f, s = sqrtf(z), df, c, w;
+        uint32_t hs;
+        memcpy(&hs, &s, 4); hs &= 0xfffff000u; memcpy(&df, &hs, 4);
+        c = (z - df * df) / (s + df);
+        w = acosf_R(z) * s + c;
+        return 2.0f * (df + w);
+    }
+}
+
 /* ------------------------------------------------------------------ lighting, render.rs:1013-1071 */
 typedef struct { float r, g, b; } Shade;
 static int shade_multi_light_color(V3 normal, V3 world_pos, const B32Light* lights, uint32_t n_lights, float ambient, Shade* out) {
@@ -293,8 +332,26 @@ static int shade_multi_light_color(V3 normal, V3 world_pos, const B32Light* ligh
                 float n_dot_l = rmax(v3dot(normal, v3normalize(to_light)), 0.0f);
                 contribution = n_dot_l * l->intensity * attenuation * attenuation;
             }
+        } else if (l->type == B32_LIGHT_SPOT) {       /* Spot, render.rs:1038-1058 */
+            V3 to_light = v3sub(v3p(l->position), world_pos);
+            float dist = v3len(to_light);
+            if (dist > l->radius || dist < 0.001f) {
+                contribution = 0.0f;
+            } else {
+                V3 light_dir_to_surface = v3normalize(to_light);
+                V3 neg_light_dir = v3scale(light_dir_to_surface, -1.0f);
+                float spot_angle = b32o_acosf(v3dot(neg_light_dir, v3p(l->direction)));
+                if (spot_angle > l->angle) {
+                    contribution = 0.0f;
+                } else {                              /* (a NaN angle -- |dot| > 1 -- lands here, like in the reference) */
+                    float attenuation = 1.0f - (dist / l->radius);
+                    float edge_falloff = 1.0f - (spot_angle / l->angle);
+                    float n_dot_l = rmax(v3dot(normal, light_dir_to_surface), 0.0f);
+                    contribution = n_dot_l * l->intensity * attenuation * attenuation * edge_falloff;
+                }
+            }
         } else {
-            return B32_E_UNSUPPORTED; /* Spot uses acos (render.rs:1047): not bit-portable */
+            return B32_E_ARG;                         /* not a LightType */
         }
         float lr = (float)l->r / 255.0f, lg = (float)l->g / 255.0f, lb = (float)l->b / 255.0f;
         tr += contribution * lr; tg += contribution * lg; tb += contribution * lb;
@@ -810,7 +867,7 @@ static int render_mesh_impl(uint8_t* fb_pixels, float* fb_zbuffer, uint32_t widt
     if (st->use_zbuffer && !fb_zbuffer) return B32_E_ARG;
     if (st->shading != B32_SHADE_NONE)
         for (uint32_t i = 0; i < st->n_lights; ++i)
-            if (st->lights[i].enabled && st->lights[i].type > B32_LIGHT_POINT) return B32_E_UNSUPPORTED;
+            if (st->lights[i].enabled && st->lights[i].type > B32_LIGHT_SPOT) return B32_E_ARG;
     FB fb = { fb_pixels, fb_zbuffer, width, height, 0 };
     V3 cpos = v3p(camera->position), bx = v3p(camera->basis_x), by = v3p(camera->basis_y), bz = v3p(camera->basis_z);
 

@@ -155,6 +155,37 @@ def blend555(front, back, mode):           # render.rs:1093-1145 on [...,3] uint
     return r << 3
 
 
+def acosf(x):
+    """f32::acos as the `libm` crate / musl acosf.c computes it (see oracle/b32_oracle.c: b32o_acosf), scalar f32."""
+    x = f32(x)
+    pio2_hi, pio2_lo = f32(1.5707962513e+00), f32(7.5497894159e-08)
+    pS0, pS1, pS2, qS1 = f32(1.6666586697e-01), f32(-4.2743422091e-02), f32(-8.6563630030e-03), f32(-7.0662963390e-01)
+
+    def R(z):
+        p = f32(z * f32(pS0 + f32(z * f32(pS1 + f32(z * pS2)))))
+        q = f32(f32(1.0) + f32(z * qS1))
+        return f32(p / q)
+    hx = int(np.float32(x).view(np.uint32))
+    ix = hx & 0x7FFFFFFF
+    if ix >= 0x3F800000:
+        if ix == 0x3F800000:
+            return f32(f32(2.0) * pio2_hi) if hx >> 31 else f32(0.0)
+        return f32(np.nan)
+    if ix < 0x3F000000:
+        if ix <= 0x32800000:
+            return pio2_hi
+        return f32(pio2_hi - f32(x - f32(pio2_lo - f32(x * R(f32(x * x))))))
+    if hx >> 31:
+        z = f32(f32(f32(1.0) + x) * f32(0.5)); s = f32(np.sqrt(z))
+        w = f32(f32(R(z) * s) - pio2_lo)
+        return f32(f32(2.0) * f32(pio2_hi - f32(s + w)))
+    z = f32(f32(f32(1.0) - x) * f32(0.5)); s = f32(np.sqrt(z))
+    df = np.uint32(int(np.float32(s).view(np.uint32)) & 0xFFFFF000).view(np.float32)
+    c = f32(f32(z - f32(df * df)) / f32(s + df))
+    w = f32(f32(R(z) * s) + c)
+    return f32(f32(2.0) * f32(df + w))
+
+
 def shade_multi(normal, wpos, lights, ambient):
     """shade_multi_light_color render.rs:1013-1071 for one vertex (f32 scalars)."""
     t = np.array([ambient, ambient, ambient], np.float32)
@@ -173,8 +204,25 @@ def shade_multi(normal, wpos, lights, ambient):
                 att = f32(1.0) - (dist / f32(l.radius))
                 ndl = rmax(dot3(normal, normalize3(to_light)), f32(0.0))
                 contrib = f32(f32(f32(ndl * f32(l.intensity)) * att) * att)
+        elif l.light_type == 2:                                  # Spot, render.rs:1038-1058
+            to_light = (np.asarray(l.position, np.float32) - wpos).astype(np.float32)
+            dist = np.sqrt(dot3(to_light, to_light))
+            if dist > f32(l.radius) or dist < f32(0.001):
+                contrib = f32(0.0)
+            else:
+                to_surface = normalize3(to_light)
+                neg = (to_surface * f32(-1.0)).astype(np.float32)
+                with np.errstate(invalid="ignore"):
+                    spot_angle = acosf(dot3(neg, np.asarray(l.direction, np.float32)))
+                    if spot_angle > f32(l.angle):
+                        contrib = f32(0.0)
+                    else:                                        # (NaN angle lands here, as in the reference)
+                        att = f32(1.0) - (dist / f32(l.radius))
+                        edge = f32(1.0) - f32(spot_angle / f32(l.angle))
+                        ndl = rmax(dot3(normal, to_surface), f32(0.0))
+                        contrib = f32(f32(f32(f32(ndl * f32(l.intensity)) * att) * att) * edge)
         else:
-            raise NotImplementedError("spot lights use acos: outside the bit-exact contract")
+            raise ValueError("not a LightType")
         col = np.array([l.color.r, l.color.g, l.color.b], np.float32) / f32(255.0)
         t = (t + contrib * col).astype(np.float32)
     return rmin(t, f32(1.0)).astype(np.float32)

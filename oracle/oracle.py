@@ -64,6 +64,7 @@ def lib():
         L.b32o_render_skybox_mesh.argtypes = [P, C.c_uint32, C.c_uint32, P, C.c_uint32, P, C.c_uint32, P]
         L.b32o_draw_star_diamond.restype = None
         L.b32o_draw_star_diamond.argtypes = [P, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_float, P]
+        L.b32o_acosf.restype = C.c_float; L.b32o_acosf.argtypes = [C.c_float]
         L.b32o_vec3_dot.restype = C.c_float; L.b32o_vec3_dot.argtypes = [P, P]
         L.b32o_vec3_cross.restype = None; L.b32o_vec3_cross.argtypes = [P, P, P]
         _lib = L

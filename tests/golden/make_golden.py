@@ -29,6 +29,25 @@ def fog_scene():
     return sc
 
 
+def spot_lights():
+    """Spot lights (render.rs:1038-1058): one built like Light::spot (normalized direction), one with an over-long direction so that
+    |dot| > 1 makes acos NaN for surfaces near its axis (the reference then takes the lit branch with NaN -> min(NaN, 1) = 1)."""
+    return [b32.Light.spot((0.0, 0.0, -200.0), (0.1, -0.05, 1.0), 0.5, 7000.0, 1.6),
+            b32.Light(b32.abi.LIGHT_SPOT, position=(800.0, -300.0, 2500.0), direction=(-0.9, 0.2, 0.6), angle=1.2, radius=3000.0,
+                      color=b32.Color(255, 120, 60), intensity=1.0),
+            b32.Light.directional((0.2, 1.0, 0.3), 0.15)]
+
+
+def spot_scene(flat=False, zbuf=False):
+    sc = scenegen.make_scene("C1", n_tris=2500, variant="gouraud", seed=71, bbox_px=500.0)
+    sc.settings.lights = spot_lights()
+    sc.settings.ambient = 0.15
+    if flat:
+        sc.settings.shading = b32.abi.SHADE_FLAT
+    sc.settings.use_zbuffer = zbuf
+    return sc
+
+
 def persp_scene():
     sc = scenegen.make_scene("C1", seed=31, bbox_px=400.0)
     sc.settings.affine_textures = False          # perspective-correct UVs (render.rs:1568-1579)
@@ -84,6 +103,8 @@ SCENES = {
     "cube:default": cube_default_scene,
     "wire-grid:far-first": lambda: scenegen.wire_grid_scene(True),
     "wire-grid:near-first": lambda: scenegen.wire_grid_scene(False),
+    "C1:spot-gouraud": spot_scene,
+    "C1:spot-flat-zbuf": lambda: spot_scene(True, True),
     "C1:persp": persp_scene,
     "C1:zbuf": zbuf_scene,
     "C1:zbuf-blend": lambda: zbuf_scene("blend", 19),
@@ -139,6 +160,7 @@ SCENES8 = {
     "8:C1-persp-float": lambda: rgba_scene(variant="float", seed=67, settings=zb_settings(affine_textures=False, use_fixed_point=False, use_zbuffer=False, backface_wireframe=False, shading=1)),
     "8:C1-xray-zbuf": lambda: rgba_scene(stp_blend=1, variant="blend", seed=68, settings=zb_settings(xray_mode=True)),
     "8:C1-ortho-overlay": lambda: rgba_scene(seed=69, bbox_px=900.0, settings=zb_settings(ortho_projection=(0.05, 10.0, -15.0), wireframe_overlay=True)),
+    "8:C1-spot": lambda: rgba_scene(variant="gouraud", seed=72, settings=zb_settings(lights=spot_lights(), ambient=0.2, backface_wireframe=False)),
     "8:cube": cube8_scene,
     "8:C2": lambda: rgba_scene("C2", seed=70, bbox_px=None),
 }

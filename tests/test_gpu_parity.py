@@ -323,11 +323,12 @@ def test_error_behaviour(gpu_ctx, oracle):
     with pytest.raises(R.B32Error) as e:
         R.render_mesh_15(fb, vn, sc.faces, sc.textures, sc.camera, nc)
     assert e.value.code == b32.abi.B32_E_NAN_KEY and np.array_equal(fb.pixels, before)
-    st = b32.RasterSettings()                     # the only setting still refused: a spot light (acos is not bit-portable)
-    st.lights = [b32.Light(2, position=(0, 0, 0), direction=(0, 0, 1), radius=50.0, angle=0.5)]
+    st = b32.RasterSettings()                     # a light type outside LightType: refused by both sides, frame untouched
+    st.lights = [b32.Light(7, position=(0, 0, 0), direction=(0, 0, 1), radius=50.0, angle=0.5)]
+    assert oracle.render_mesh_15(oracle.Framebuffer(sc.width, sc.height), sc.vertices, sc.faces, sc.textures, sc.camera, st)[0] == b32.abi.B32_E_ARG
     with pytest.raises(R.B32Error) as e:
         R.render_mesh_15(fb, sc.vertices, sc.faces, sc.textures, sc.camera, st)
-    assert e.value.code == b32.abi.B32_E_UNSUPPORTED and np.array_equal(fb.pixels, before)
+    assert e.value.code == b32.abi.B32_E_ARG and np.array_equal(fb.pixels, before)
 
 
 def test_smoke_entry():
@@ -336,7 +337,7 @@ def test_smoke_entry():
 
 
 NEW_MODES = ["C1:ortho", "C1:xray", "C1:xray-zbuf", "C1:default-settings", "C1:wire-painter", "C1:wire-overlay", "cube:default",
-             "wire-grid:far-first", "wire-grid:near-first"]
+             "wire-grid:far-first", "wire-grid:near-first", "C1:spot-gouraud", "C1:spot-flat-zbuf"]
 
 
 @pytest.mark.parametrize("name", NEW_MODES)

@@ -155,8 +155,34 @@ def test_error_codes(oracle):
     assert oracle.render_mesh_15(fb, v2[3:6], sc_f, [], b32.Camera(), st_nc)[0] == 0
     st2 = b32.RasterSettings()                                  # reference defaults (z-buffer, back-face wireframe) are in scope
     assert oracle.render_mesh_15(fb, sc_v, sc_f, [], b32.Camera(), st2)[0] == 0
-    st2.lights = [b32.Light(b32.abi.LIGHT_SPOT if hasattr(b32.abi, "LIGHT_SPOT") else 2, position=(0, 0, 0), direction=(0, 0, 1), radius=50.0, angle=0.5)]
-    assert oracle.render_mesh_15(fb, sc_v, sc_f, [], b32.Camera(), st2)[0] == b32.abi.B32_E_UNSUPPORTED   # spot: acos
+    st2.lights = [b32.Light.spot((0, 0, 0), (0, 0, 1), 0.5, 50.0, 1.0)]
+    assert oracle.render_mesh_15(fb, sc_v, sc_f, [], b32.Camera(), st2)[0] == 0                            # spot lights are in scope
+    st2.lights = [b32.Light(7, position=(0, 0, 0), direction=(0, 0, 1), radius=50.0, angle=0.5)]
+    assert oracle.render_mesh_15(fb, sc_v, sc_f, [], b32.Camera(), st2)[0] == b32.abi.B32_E_ARG           # not a LightType
+
+
+def test_acosf_is_the_published_musl_algorithm(oracle):
+    """f32::acos of the spot-light cone test (render.rs:1047).  The oracle, oracle/np_model.py and the GPU all use the musl /
+    `libm`-crate acosf (what the reference's wasm32 build executes).  Known answers of that algorithm's special cases, agreement
+    of the two restatements bit for bit, and its published accuracy (< 1 ulp of the true value)."""
+    from oracle import np_model as M
+    L = oracle.lib()
+    bits = lambda f: int(np.float32(f).view(np.uint32))
+    assert bits(L.b32o_acosf(1.0)) == 0 and bits(L.b32o_acosf(-1.0)) == 0x40490FDA          # 0 and 2 * pio2_hi
+    assert bits(L.b32o_acosf(0.0)) == 0x3FC90FDA and bits(L.b32o_acosf(1e-9)) == 0x3FC90FDA  # pio2_hi below 2^-26
+    assert np.isnan(L.b32o_acosf(1.0000001)) and np.isnan(L.b32o_acosf(-2.0)) and np.isnan(L.b32o_acosf(float("nan")))
+    rng = np.random.default_rng(5)
+    xs = np.concatenate([rng.uniform(-1, 1, 3000), np.cos(rng.uniform(0, np.pi, 3000)), 1 - 10 ** rng.uniform(-8, 0, 1500),
+                         -1 + 10 ** rng.uniform(-8, 0, 1500), [0.5, -0.5, 0.49999997, -0.50000006]]).astype(np.float32)
+    xs = np.clip(xs, -1, 1)
+    worst = 0.0
+    for x in xs:
+        a = np.float32(L.b32o_acosf(float(x)))
+        b = M.acosf(x)
+        assert bits(a) == bits(b), (float(x), float(a), float(b))
+        true = np.arccos(np.float64(x))
+        worst = max(worst, abs(float(a) - true) / float(np.spacing(np.float32(true))))
+    assert worst < 1.0, worst
 
 
 def test_bresenham_closed_form_equals_literal_loop(oracle):

@@ -84,7 +84,14 @@ while time.time() < t_end:
     if rng.integers(3) == 0 and variant != "gouraud":
         st.shading = int(rng.integers(1, 3))
         st.lights = [b32.Light.directional((float(rng.normal()), float(rng.normal()), float(rng.normal()) + 0.1), float(rng.uniform(0.2, 1.5))),
-                     b32.Light.point((float(rng.normal(0, 500)), float(rng.normal(0, 500)), float(rng.uniform(300, 3000))), float(rng.uniform(500, 5000)), 1.2)][:int(rng.integers(1, 3))]
+                     b32.Light.point((float(rng.normal(0, 500)), float(rng.normal(0, 500)), float(rng.uniform(300, 3000))), float(rng.uniform(500, 5000)), 1.2),
+                     # spot light, direction normalized (Light::spot) or over-long (acos of |dot| > 1 is NaN: the reference's lit branch)
+                     (b32.Light.spot if rng.integers(2) else (lambda p, d, a, r, i: b32.Light(b32.abi.LIGHT_SPOT, position=p, direction=d, angle=a, radius=r, intensity=i)))(
+                         (float(rng.normal(0, 600)), float(rng.normal(0, 600)), float(rng.uniform(-300, 2500))),
+                         (float(rng.normal(0, 0.5)), float(rng.normal(0, 0.5)), float(rng.uniform(0.3, 1.2))),
+                         float(rng.uniform(0.05, 3.2)), float(rng.uniform(800, 8000)), float(rng.uniform(0.5, 2.0)))][:int(rng.integers(1, 4))]
+        if rng.integers(3) == 0:
+            st.lights = st.lights[::-1]
         st.ambient = float(rng.uniform(0.0, 0.6))
     fog = None
     fmt8 = bool(rng.integers(3) == 0)
