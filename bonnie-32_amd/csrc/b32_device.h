@@ -228,6 +228,10 @@ void launch_project_fixed(hipStream_t s, const float* pos, uint32_t n, B32Camera
                           int32_t* sx, int32_t* sy, float* z);
 void launch_selftest(hipStream_t s, int op, const float* a, const float* b, const float* c, float* out, uint32_t n);
 void launch_clear(hipStream_t s, uint32_t* fb, size_t n_px, uint32_t rgba);
+// staged upload of a drop-in call: up to 16 segments copied by ONE kernel from a pinned host arena (mapped into the device's address
+// space) to their device buffers -- every SDMA copy costs ~10 us of stream time, one kernel reading over PCIe ~5 us for all of them
+struct UploadSegs { void* dst[16]; uint32_t src_off[16]; uint32_t n16[16]; uint32_t count; };
+void launch_upload(hipStream_t s, const void* arena_dev, const UploadSegs& segs);
 void launch_expand_indexed(hipStream_t s, const uint8_t* idx, uint32_t n, const uint16_t* clut, uint32_t clut_len, uint16_t* out);
 
 void launch_bin(hipStream_t s, const FrameParams& fp, const SurfRec* recs, const uint32_t* order, Ctrl* ctrl,

@@ -424,6 +424,25 @@ void launch_clear(hipStream_t s, uint32_t* fb, size_t n_px, uint32_t rgba) {
     hipLaunchKernelGGL(k_clear, dim3(blocks), dim3(256), 0, s, fb, n_px, rgba);
 }
 
+// ---------------------------------------------------------------- staged upload (drop-in calls with small meshes)
+__global__ __launch_bounds__(256) void k_upload(const uint4* __restrict__ arena, UploadSegs segs) {
+    const uint32_t gtid = blockIdx.x * 256u + threadIdx.x, nthr = gridDim.x * 256u;
+    for (uint32_t k = 0; k < segs.count; ++k) {
+        const uint4* src = arena + (segs.src_off[k] >> 4);
+        uint4* dst = reinterpret_cast<uint4*>(segs.dst[k]);
+        for (uint32_t i = gtid; i < segs.n16[k]; i += nthr) dst[i] = src[i];
+    }
+}
+void launch_upload(hipStream_t s, const void* arena_dev, const UploadSegs& segs) {
+    if (!segs.count) return;
+    uint32_t total = 0;
+    for (uint32_t k = 0; k < segs.count; ++k) total += segs.n16[k];
+    uint32_t blocks = (total + 255) / 256;
+    if (blocks > 256) blocks = 256;
+    if (!blocks) return;
+    hipLaunchKernelGGL(k_upload, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const uint4*>(arena_dev), segs);
+}
+
 // ---------------------------------------------------------------- Clut::lookup expansion (types.rs:390-397, mesh_editor.rs:669-682)
 __global__ void k_expand_indexed(const uint8_t* __restrict__ idx, uint32_t n, const uint16_t* __restrict__ clut, uint32_t clut_len,
                                  uint16_t* __restrict__ out) {
