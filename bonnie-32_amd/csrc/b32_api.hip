@@ -60,6 +60,7 @@ struct b32_ctx {
     bool no_prio64 = false;             // debug/experiment switch (B32_NO_PRIO64=1): keep the per-tile LDS sort
     // pairs
     size_t cap_pairs = 0;
+    uint32_t* inline_lists = nullptr; size_t cap_inline = 0;      // small meshes: one list region per tile, filled inside k_cover
     uint32_t *pkeys[2] = { nullptr, nullptr }, *pvals[2] = { nullptr, nullptr };
     // sort scratch
     uint32_t* block_hist = nullptr; uint32_t hist_blocks = 0; uint32_t* digit_total = nullptr;
@@ -170,7 +171,7 @@ void b32_destroy(b32_ctx* c) {
     void* ptrs[] = { c->fb_own, c->d_verts, c->d_faces, c->d_texels, c->d_tex, c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->recs,
                      c->shades, c->counts, c->block_sums, c->pkeys[0], c->pkeys[1], c->pvals[0], c->pvals[1], c->block_hist, c->ranges,
                      c->d_ctrl, c->d_consts, c->d_lights, c->digit_total, c->partials, c->vis, c->spans, c->tile_mid, c->zbuf,
-                     c->wire, c->wire_owner, c->wire_first, c->d_texels32 };
+                     c->wire, c->wire_owner, c->wire_first, c->d_texels32, c->inline_lists };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->ev_created) for (auto& fr : c->ev) for (auto& e : fr) if (e) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -696,8 +697,19 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     if (prof_all) HIPCHK(c, hipEventRecord(ev[1], s));
 
     int cur = 0;
-    bool prio64 = false;
-    if (want_prio64) {
+    bool prio64 = false, inline_bin = false;
+    // small mesh without a transparent pass (what the reference's callers submit per room / asset part): no binning launch, the
+    // fused kernel's workgroups collect their own tile lists from the spans (needs one list region of nf entries per tile)
+    const uint32_t list_stride = (c->nf + 31u) & ~31u;
+    if (want_prio64 && !with_class && !wire_front && c->nf <= 2048 /* k_bin_small's range */ && !getenv("B32_NO_INLINE_BIN")) {
+        const size_t need = (size_t)ntiles * list_stride + 64;
+        if (need > c->cap_inline) {
+            if ((rc = ensure_plain(c, c->inline_lists, need + need / 2))) return rc;
+            c->cap_inline = need + need / 2;
+        }
+        if (prof_all) HIPCHK(c, hipEventRecord(ev[2], s));
+        prio64 = inline_bin = true;
+    } else if (want_prio64) {
         if (prof_all) HIPCHK(c, hipEventRecord(ev[2], s));
         prio64 = launch_bin_spans(s, fp, c->spans, with_class ? c->keys[0] : nullptr, c->partials, c->d_ctrl, sc, (uint32_t)c->cap_pairs, c->ranges,
                                   c->tile_mid, BLEND_SORT_CAP, c->pvals[0]);
@@ -758,6 +770,8 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     fa.texels32 = c->d_texels32;
     fa.ordered_all = ordered_all ? 1u : 0u;
     fa.prio64 = prio64 ? 1u : 0u;
+    fa.inline_bin = inline_bin ? 1u : 0u; fa.list_stride = list_stride; fa.spans = c->spans; fa.partials = c->partials;
+    if (inline_bin) fa.pair_vals = c->inline_lists;
     fa.gather_blend = (prio64 && with_class) ? 1u : 0u;
     if (c->fmt8) fa.fp.xray = 0;                        // render_mesh: x-ray only changes culling; its stores keep their own depth tests
     launch_fill(s, fa, c->n_cu, prof_fill ? ev[4] : nullptr);

@@ -857,12 +857,34 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a) {
     const uint16_t* ltex = reinterpret_cast<const uint16_t*>(smem + LDS_TEX_OFFSET);
     uint32_t* sort_cnt = reinterpret_cast<uint32_t*>(smem + LDS_TEX_OFFSET);        // local sort only exists without an LDS texture
 
-    if (a.ctrl->abort) return;
-    if (P64 && a.ctrl->need_global_sort) return;       // a transparent tile list is too long for k_blend's LDS sort: the host redraws
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));   // wave-uniform => SGPR control flow
     const FrameParams& fp = a.fp;
     const uint32_t ntiles = fp.tiles_x * fp.tiles_y;
+    if (P64 && a.inline_bin) {
+        // small mesh: there was no binning launch, so nobody has reduced k_setup's per-block counters yet.  Every workgroup derives
+        // the frame's abort decision from them (the reference panics before drawing on a bad vertex index, render.rs:2375, or when a
+        // sort comparison sees NaN, render.rs:2531); workgroup 0 publishes the counters in Ctrl for the host.
+        if (tid == 0) {
+            uint32_t t[5] = { 0, 0, 0, 0, 0 };
+            const uint32_t npart = (fp.nf + 255) / 256;
+            for (uint32_t b = 0; b < npart; ++b)
+                for (int k = 0; k < 5; ++k) t[k] += a.partials[b * 8 + k];
+            const uint32_t n_opq = t[0] - t[1];
+            const bool ab = t[4] != 0 || (t[2] && n_opq >= 2) || (t[3] && t[1] >= 2);
+            misc[6] = ab ? 1u : 0u;
+            if (blockIdx.x == 0) {
+                a.ctrl->n_visible = t[0]; a.ctrl->n_transparent = t[1]; a.ctrl->nan_opaque = t[2]; a.ctrl->nan_transparent = t[3];
+                a.ctrl->err_index = t[4] ? 1u : 0u; a.ctrl->n_opaque = n_opq;
+                if (ab) a.ctrl->abort = 1;
+            }
+        }
+        __syncthreads();
+        if (misc[6]) return;
+    } else {
+        if (a.ctrl->abort) return;
+        if (P64 && a.ctrl->need_global_sort) return;   // a transparent tile list is too long for k_blend's LDS sort: the host redraws
+    }
 
     TexDesc lds_desc = { 0, 0, 0, 0 };
     if (TEXMODE == 1) {     // stage texture 0 once per workgroup: 16-B coalesced loads -> LDS
@@ -883,7 +905,9 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a) {
         if (tile >= ntiles) break;
         if (tid == 0) next_tile = gridDim.x + atomicAdd(&a.ctrl->tile_cursor, 1u);    // prefetch the next tile index; consumed at the loop top
         uint32_t e0, e1;
-        if (P64) {                               // lists in any order, keyed by tile only; [e0, mid) is the opaque pass
+        if (P64 && a.inline_bin) {               // the list is collected below, into this tile's own region
+            e0 = e1 = tile * a.list_stride;
+        } else if (P64) {                        // lists in any order, keyed by tile only; [e0, mid) is the opaque pass
             e0 = a.ranges[tile]; e1 = a.gather_blend ? a.tile_mid[tile] : a.ranges[tile + 1];
         } else if (TEXMODE == 0 && a.local_sort) {      // lists arrive in face order, keyed by tile only: painter's order per tile, in LDS
             e0 = a.ranges[tile];
@@ -908,6 +932,23 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a) {
         const uint32_t TH = P64 ? fp.tile_h : (uint32_t)TILE_H;
         const uint32_t ty_top = tyi * TH;
         const uint32_t y_lo = max(ty_top, fp.band_y0), y_hi = min(ty_top + TH, fp.band_y1);
+        if (P64 && a.inline_bin) {
+            // the faces whose span reaches this tile, in any order (ballot compaction; misc[4] was zeroed with the tile index)
+            const uint32_t tyl = tile / fp.tiles_x;
+            for (uint32_t f0 = 0; f0 < fp.nf; f0 += NT) {
+                const uint32_t f = f0 + tid;
+                bool hit = false;
+                if (f < fp.nf) {
+                    const uint32_t span = a.spans[f];
+                    hit = span != 0xFFFFFFFFu && txi >= (span & 0xFF) && txi <= ((span >> 8) & 0xFF) && tyl >= ((span >> 16) & 0xFF) && tyl <= (span >> 24);
+                }
+                const unsigned long long m = __ballot(hit);
+                uint32_t base = 0;
+                if (lane == 0 && m) base = atomicAdd(const_cast<uint32_t*>(&misc[4]), (uint32_t)__builtin_popcountll(m));
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (hit) a.pair_vals[e0 + base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = f;
+            }
+        }
         if (P64 && ZMODE) { // winners seeded with the current z-buffer: a fragment wins only with a strictly smaller depth (low word all ones)
             unsigned long long* t64 = reinterpret_cast<unsigned long long*>(tilebuf);
             for (uint32_t p = tid; p < TILE_W * TH; p += NT) {
@@ -933,6 +974,10 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a) {
             for (uint32_t i = tid; i < (P64 ? 4 : (EXACT ? 1 : 2)) * TILE_H * TILE_STRIDE; i += NT) tilebuf[i] = 0;
         }
         __syncthreads();
+        if (P64 && a.inline_bin) {
+            e1 = e0 + misc[4];
+            if (tid == 0 && e1 != e0) atomicAdd(&a.ctrl->n_pairs, e1 - e0);
+        }
         const uint32_t n_op = e1 - e0;
         if (n_op) {
             frag_count += phase_a_rows<TEXMODE, EXACT, NW, ZMODE, FMT8, P64>(a, e0, n_op, lane, wave, &misc[2], wmarks + wave * 64, lds_desc, tilebuf,
