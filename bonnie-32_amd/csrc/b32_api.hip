@@ -698,10 +698,10 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
 
     int cur = 0;
     bool prio64 = false, inline_bin = false;
-    // small mesh without a transparent pass (what the reference's callers submit per room / asset part): no binning launch, the
+    // small mesh (what the reference's callers submit per room / asset part): no binning launch, the
     // fused kernel's workgroups collect their own tile lists from the spans (needs one list region of nf entries per tile)
     const uint32_t list_stride = (c->nf + 31u) & ~31u;
-    if (want_prio64 && !with_class && !wire_front && c->nf <= 2048 /* k_bin_small's range */ && !getenv("B32_NO_INLINE_BIN")) {
+    if (want_prio64 && !wire_front && c->nf <= 2048 /* k_bin_small's range */ && !getenv("B32_NO_INLINE_BIN")) {
         const size_t need = (size_t)ntiles * list_stride + 64;
         if (need > c->cap_inline) {
             if ((rc = ensure_plain(c, c->inline_lists, need + need / 2))) return rc;

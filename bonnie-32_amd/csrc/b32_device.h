@@ -292,7 +292,7 @@ struct FillArgs {
     const uint32_t* texels32;   // 8-bit-colour path: pooled Color texels, r | g<<8 | b<<16 | blend<<24 (TexDesc.offset indexes this pool)
     uint32_t ordered_all;       // 1: every surface may blend -> no overwrite pass, k_blend walks the whole tile list in order
     uint32_t gather_blend;      // 1 (with prio64): k_blend sorts the transparent part of each (unordered) tile list itself
-    // small meshes (at most SPAN_BLOCK faces, no transparent pass): no binning launch at all -- every workgroup of the fused kernel
+    // small meshes (at most 2048 faces): no binning launch at all -- every workgroup of the fused kernel
     // collects its tile's list from k_setup's spans itself, and reduces k_setup's counters (workgroup 0 publishes them in Ctrl)
     uint32_t inline_bin;        // 1: lists are built inside k_cover at pair_vals[tile * list_stride ...]
     uint32_t list_stride;       // entries per tile region (a multiple of 32: regions never share a cache line)

@@ -899,7 +899,7 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a) {
     // from the shared cursor
     uint32_t next_tile = blockIdx.x;
     for (;;) {
-        if (tid == 0) { misc[0] = next_tile; misc[2] = 0; misc[4] = 0; }
+        if (tid == 0) { misc[0] = next_tile; misc[2] = 0; misc[4] = 0; misc[5] = 0; }
         __syncthreads();
         const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)misc[0]);
         if (tile >= ntiles) break;
@@ -933,20 +933,27 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a) {
         const uint32_t ty_top = tyi * TH;
         const uint32_t y_lo = max(ty_top, fp.band_y0), y_hi = min(ty_top + TH, fp.band_y1);
         if (P64 && a.inline_bin) {
-            // the faces whose span reaches this tile, in any order (ballot compaction; misc[4] was zeroed with the tile index)
+            // the faces whose span reaches this tile, in any order (ballot compaction; misc[4..5] were zeroed with the tile index):
+            // the opaque pass grows from the front of the tile's region, the transparent pass (class = bit 31 of the depth key) from
+            // its back, so k_blend finds its entries in [tile_mid, region end)
             const uint32_t tyl = tile / fp.tiles_x;
+            const uint32_t r_end = e0 + a.list_stride;
             for (uint32_t f0 = 0; f0 < fp.nf; f0 += NT) {
                 const uint32_t f = f0 + tid;
-                bool hit = false;
+                bool hit = false, tr = false;
                 if (f < fp.nf) {
                     const uint32_t span = a.spans[f];
                     hit = span != 0xFFFFFFFFu && txi >= (span & 0xFF) && txi <= ((span >> 8) & 0xFF) && tyl >= ((span >> 16) & 0xFF) && tyl <= (span >> 24);
+                    if (hit && a.gather_blend) tr = (a.keys[f] >> 31) != 0;
                 }
-                const unsigned long long m = __ballot(hit);
-                uint32_t base = 0;
-                if (lane == 0 && m) base = atomicAdd(const_cast<uint32_t*>(&misc[4]), (uint32_t)__builtin_popcountll(m));
-                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                if (hit) a.pair_vals[e0 + base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = f;
+                const unsigned long long mo = __ballot(hit && !tr), mt = __ballot(hit && tr);
+                uint32_t bo = 0, bt = 0;
+                if (lane == 0 && mo) bo = atomicAdd(const_cast<uint32_t*>(&misc[4]), (uint32_t)__builtin_popcountll(mo));
+                if (lane == 0 && mt) bt = atomicAdd(const_cast<uint32_t*>(&misc[5]), (uint32_t)__builtin_popcountll(mt));
+                bo = (uint32_t)__builtin_amdgcn_readfirstlane((int)bo); bt = (uint32_t)__builtin_amdgcn_readfirstlane((int)bt);
+                const unsigned long long below = (1ull << lane) - 1ull;
+                if (hit && !tr) a.pair_vals[e0 + bo + (uint32_t)__builtin_popcountll(mo & below)] = f;
+                if (hit && tr) a.pair_vals[r_end - 1u - (bt + (uint32_t)__builtin_popcountll(mt & below))] = f;
             }
         }
         if (P64 && ZMODE) { // winners seeded with the current z-buffer: a fragment wins only with a strictly smaller depth (low word all ones)
@@ -976,7 +983,11 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a) {
         __syncthreads();
         if (P64 && a.inline_bin) {
             e1 = e0 + misc[4];
-            if (tid == 0 && e1 != e0) atomicAdd(&a.ctrl->n_pairs, e1 - e0);
+            const uint32_t n_tr = misc[5];
+            if (tid == 0) {
+                if (a.gather_blend) a.tile_mid[tile] = e0 + a.list_stride - n_tr;
+                if (e1 != e0 || n_tr) atomicAdd(&a.ctrl->n_pairs, e1 - e0 + n_tr);
+            }
         }
         const uint32_t n_op = e1 - e0;
         if (n_op) {
@@ -1383,7 +1394,7 @@ __global__ __launch_bounds__(NT, 4) void k_blend(FillArgs a) {        // 4 waves
     // (8-bit path with blending texels / editor alpha: one list, same ordered walk, render.rs:2193-2202)
     const bool xray = fp.xray != 0;
     const uint32_t e1 = a.tile_keys_only ? a.tile_mid[tile] : a.ranges[2 * tile + (a.ordered_all ? 0 : 1)];
-    const uint32_t e2 = a.tile_keys_only ? a.ranges[tile + 1] : a.ranges[2 * tile + 2];
+    const uint32_t e2 = a.inline_bin ? (tile + 1) * a.list_stride : (a.tile_keys_only ? a.ranges[tile + 1] : a.ranges[2 * tile + 2]);
     if (e1 == e2) return;
     if (GATHER) {
         // sort-free binning left the transparent entries [e1, e2) in arbitrary order: put them in painter's order (descending depth,
