@@ -102,6 +102,9 @@ SYMBOLS = [
     ("b32_render_scene_15", C.c_int, [_P, _P, _P, _P, _P]),
     ("b32_render_scene_15_async", C.c_int, [_P, _P, _P, _P]),
     ("b32_frame_finish", C.c_int, [_P, _P]),
+    ("b32_scene_create", C.c_int, [_P, C.POINTER(_P)]),
+    ("b32_scene_destroy", None, [_P, _P]),
+    ("b32_scene_swap", C.c_int, [_P, _P]),
     ("b32_fb_clear_gradient", C.c_int, [_P] + [C.c_uint8] * 8),
     ("b32_fb_clear_transparent", C.c_int, [_P]),
     ("b32_render_skybox_mesh", C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint32, _P]),

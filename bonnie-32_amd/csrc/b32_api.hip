@@ -83,6 +83,7 @@ struct b32_ctx {
 
     // last enqueued frame (for redraw after a pair overflow)
     bool frame_pending = false;
+    bool pending_may_redraw = false;    // the pending frame took a path that can overflow its buffers (not the small-mesh path)
     B32Camera last_cam{}; B32Settings last_settings{}; B32Fog last_fog{}; bool last_has_fog = false;
     int last_pair_buf = 0;
 
@@ -95,6 +96,19 @@ struct b32_ctx {
     uint32_t phase_frames = 0;
     int phase_level = 0;                // profiling level those averages were taken at
     std::vector<B32Light> keep_lights;  // private copy of the last frame's lights (redraw after overflow)
+};
+
+// A slot of b32_scene_swap: everything of b32_ctx that belongs to ONE uploaded scene.
+struct b32_scene {
+    B32Vertex* d_verts = nullptr; size_t cap_verts = 0;
+    B32Face* d_faces = nullptr; size_t cap_faces = 0;
+    uint16_t* d_texels = nullptr; size_t cap_texels = 0;
+    uint32_t* d_texels32 = nullptr; size_t cap_texels32 = 0;
+    TexDesc* d_tex = nullptr; size_t cap_tex = 0;
+    uint32_t* d_consts = nullptr;
+    std::vector<TexDesc> h_tex;
+    uint32_t nv = 0, nf = 0, nt = 0;
+    bool fmt8 = false, blend8 = false, have_scene = false, may_blend = true, cheap_ok = false, local_sort_ok = true;
 };
 
 #define HIPCHK(ctx, expr)                                                 \
@@ -160,6 +174,7 @@ int b32_create(int device, b32_ctx** out) {
     if (hipMalloc(reinterpret_cast<void**>(&c->d_ctrl), sizeof(Ctrl)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&c->d_consts), 16 * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&c->digit_total), 4096 * sizeof(uint32_t)) != hipSuccess) { delete c; return B32_E_HIP; }
+    if (hipMemset(c->d_ctrl, 0, sizeof(Ctrl)) != hipSuccess) { delete c; return B32_E_HIP; }     // (`sticky` is never reset by a frame)
     *out = c;
     return B32_OK;
 }
@@ -413,6 +428,7 @@ static int upload_geometry(b32_ctx* c, const B32Vertex* v, uint32_t nv, const B3
         c->cap_work = n;
     }
     c->h_consts[0] = nf;
+    if (!c->d_consts) HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_consts), 16 * sizeof(uint32_t)));   // (swapped away with a scene)
     if ((rc = h2d(c, c->d_consts, c->h_consts, sizeof(c->h_consts)))) return rc;
     // the caller may reuse its host buffers as soon as an upload call returns; the drop-in render calls return only after
     // b32_frame_finish has synchronised the stream, so they skip this extra round trip
@@ -690,7 +706,10 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     const bool local_sort = !exact_cov && c->local_sort_ok && !fp.ortho && !ordered_all && !fp.zmode;
     c->last_local_sort = local_sort || want_prio64;                         // the global draw order is not materialised
     c->last_exact = ordered_all ? true : (exact_cov && !fp.zmode);          // the ordered walk counts every store it performs
-    if (c->nf == 0) HIPCHK(c, hipMemsetAsync(c->d_ctrl, 0, sizeof(Ctrl), s));    // otherwise k_setup resets it
+    if (c->nf == 0) {                                                             // otherwise k_setup resets it (all but `sticky`)
+        HIPCHK(c, hipMemsetAsync(c->d_ctrl, 0, offsetof(Ctrl, sticky), s));
+        HIPCHK(c, hipMemsetAsync(&c->d_ctrl->fragments, 0, sizeof(unsigned long long), s));
+    }
     if (prof_all) HIPCHK(c, hipEventRecord(ev[0], s));
     fp.band_only = (want_prio64 && c->band_set) ? 1 : 0;   // other ranks own the other rows: their surfaces' records are never read here
     launch_setup(s, fp, c->d_verts, c->d_faces, c->d_tex, c->d_lights, c->recs, c->shades, c->keys[0], c->spans, c->partials, c->d_ctrl, c->wire);
@@ -701,7 +720,9 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     // small mesh (what the reference's callers submit per room / asset part): no binning launch, the
     // fused kernel's workgroups collect their own tile lists from the spans (needs one list region of nf entries per tile)
     const uint32_t list_stride = (c->nf + 31u) & ~31u;
-    if (want_prio64 && !wire_front && c->nf <= 2048 /* k_bin_small's range */ && !getenv("B32_NO_INLINE_BIN")) {
+    // (with a transparent pass only up to 2048 faces: no tile's transparent list can then exceed what k_blend sorts in LDS)
+    if (want_prio64 && !wire_front && c->nf <= (with_class ? 2048u : 8192u) && (size_t)ntiles * list_stride <= ((size_t)4 << 20) &&
+        !getenv("B32_NO_INLINE_BIN")) {
         const size_t need = (size_t)ntiles * list_stride + 64;
         if (need > c->cap_inline) {
             if ((rc = ensure_plain(c, c->inline_lists, need + need / 2))) return rc;
@@ -770,6 +791,7 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     fa.texels32 = c->d_texels32;
     fa.ordered_all = ordered_all ? 1u : 0u;
     fa.prio64 = prio64 ? 1u : 0u;
+    c->pending_may_redraw = !inline_bin;
     fa.inline_bin = inline_bin ? 1u : 0u; fa.list_stride = list_stride; fa.spans = c->spans; fa.partials = c->partials;
     if (inline_bin) fa.pair_vals = c->inline_lists;
     fa.gather_blend = (prio64 && with_class) ? 1u : 0u;
@@ -869,10 +891,12 @@ int b32_frame_finish(b32_ctx* c, B32Timings* out) {
     }
     c->frame_pending = false;
     collect_events(c);
+    const uint32_t sticky = c->h_ctrl.sticky;                  // errors of every frame enqueued since the last finish
+    if (sticky) HIPCHK(c, hipMemsetAsync(&c->d_ctrl->sticky, 0, sizeof(uint32_t), c->stream));
     if (c->h_ctrl.pairs_overflow) return B32_E_HIP;
-    if (c->h_ctrl.err_index) return B32_E_INDEX;
-    if (c->h_ctrl.abort) return B32_E_NAN_KEY;
-    if (c->h_ctrl.wire_overflow) return B32_E_UNSUPPORTED;     // an edge >= 2^30 px long: i32 overflow in the reference's Bresenham
+    if (c->h_ctrl.err_index || (sticky & 1u)) return B32_E_INDEX;
+    if (c->h_ctrl.abort || (sticky & 2u)) return B32_E_NAN_KEY;
+    if (c->h_ctrl.wire_overflow || (sticky & 4u)) return B32_E_UNSUPPORTED;     // an edge >= 2^30 px long: i32 overflow in the reference's Bresenham
     if (out) {
         out->triangles_drawn = c->h_ctrl.n_visible;
         out->fragments = c->last_exact ? c->h_ctrl.fragments : 0;     // exact only with fragment counting on, painter's mode
@@ -884,6 +908,38 @@ int b32_frame_finish(b32_ctx* c, B32Timings* out) {
             out->draw_ms = c->phase_ms[2] + c->phase_ms[3] + c->phase_ms[4];
         }
     }
+    return B32_OK;
+}
+
+// ------------------------------------------------------------------ scene slots (several resident scenes per context)
+int b32_scene_create(b32_ctx* c, b32_scene** out) {
+    if (!c || !out) return B32_E_ARG;
+    *out = new b32_scene();
+    return B32_OK;
+}
+void b32_scene_destroy(b32_ctx* c, b32_scene* sl) {
+    if (!c || !sl) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    void* ptrs[] = { sl->d_verts, sl->d_faces, sl->d_texels, sl->d_texels32, sl->d_tex, sl->d_consts };
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    delete sl;
+}
+int b32_scene_swap(b32_ctx* c, b32_scene* sl) {
+    if (!c || !sl) return B32_E_ARG;
+    // a pending frame of the outgoing scene that may have to be redrawn (pair overflow, long transparent lists) is settled first:
+    // the redraw needs that scene.  Frames of small meshes never redraw and stay in flight.
+    if (c->frame_pending && c->pending_may_redraw) { const int rc = b32_frame_finish(c, nullptr); if (rc) return rc; }
+    std::swap(c->d_verts, sl->d_verts); std::swap(c->cap_verts, sl->cap_verts);
+    std::swap(c->d_faces, sl->d_faces); std::swap(c->cap_faces, sl->cap_faces);
+    std::swap(c->d_texels, sl->d_texels); std::swap(c->cap_texels, sl->cap_texels);
+    std::swap(c->d_texels32, sl->d_texels32); std::swap(c->cap_texels32, sl->cap_texels32);
+    std::swap(c->d_tex, sl->d_tex); std::swap(c->cap_tex, sl->cap_tex);
+    std::swap(c->d_consts, sl->d_consts);
+    c->h_tex.swap(sl->h_tex);
+    std::swap(c->nv, sl->nv); std::swap(c->nf, sl->nf); std::swap(c->nt, sl->nt);
+    std::swap(c->fmt8, sl->fmt8); std::swap(c->blend8, sl->blend8); std::swap(c->have_scene, sl->have_scene);
+    std::swap(c->may_blend, sl->may_blend); std::swap(c->cheap_ok, sl->cheap_ok); std::swap(c->local_sort_ok, sl->local_sort_ok);
     return B32_OK;
 }
 

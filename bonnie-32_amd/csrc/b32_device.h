@@ -60,7 +60,8 @@ struct Ctrl {
     uint32_t nf;               // copy of the face count (first sort pass length)
     uint32_t need_global_sort; // a tile list exceeded the LDS sort capacity: redraw with the global depth sort
     uint32_t wire_overflow;    // a wireframe edge is >= 2^30 pixels long: the reference's i32 Bresenham state overflows
-    uint32_t pad;
+    uint32_t sticky;           // errors of every frame since the last b32_frame_finish (bit 0 vertex index, 1 NaN sort key, 2 wire edge):
+                               // NOT reset at frame start, so the meshes of a multi-scene frame can be enqueued without a sync each
     unsigned long long fragments;
 };
 

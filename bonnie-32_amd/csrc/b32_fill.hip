@@ -865,18 +865,21 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a) {
         // small mesh: there was no binning launch, so nobody has reduced k_setup's per-block counters yet.  Every workgroup derives
         // the frame's abort decision from them (the reference panics before drawing on a bad vertex index, render.rs:2375, or when a
         // sort comparison sees NaN, render.rs:2531); workgroup 0 publishes the counters in Ctrl for the host.
+        if (tid < 5) misc[8 + tid] = 0;
+        __syncthreads();
+        const uint32_t npart = (fp.nf + 255) / 256;
+        for (uint32_t b = tid; b < npart; b += NT)
+            for (int k = 0; k < 5; ++k) { const uint32_t v = a.partials[b * 8 + k]; if (v) atomicAdd(const_cast<uint32_t*>(&misc[8 + k]), v); }
+        __syncthreads();
         if (tid == 0) {
-            uint32_t t[5] = { 0, 0, 0, 0, 0 };
-            const uint32_t npart = (fp.nf + 255) / 256;
-            for (uint32_t b = 0; b < npart; ++b)
-                for (int k = 0; k < 5; ++k) t[k] += a.partials[b * 8 + k];
+            const uint32_t t[5] = { misc[8], misc[9], misc[10], misc[11], misc[12] };
             const uint32_t n_opq = t[0] - t[1];
             const bool ab = t[4] != 0 || (t[2] && n_opq >= 2) || (t[3] && t[1] >= 2);
             misc[6] = ab ? 1u : 0u;
             if (blockIdx.x == 0) {
                 a.ctrl->n_visible = t[0]; a.ctrl->n_transparent = t[1]; a.ctrl->nan_opaque = t[2]; a.ctrl->nan_transparent = t[3];
                 a.ctrl->err_index = t[4] ? 1u : 0u; a.ctrl->n_opaque = n_opq;
-                if (ab) a.ctrl->abort = 1;
+                if (ab) { a.ctrl->abort = 1; a.ctrl->sticky |= t[4] ? 1u : 2u; }
             }
         }
         __syncthreads();

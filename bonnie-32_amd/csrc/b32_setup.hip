@@ -184,7 +184,8 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp, const B32Vertex* 
                                                uint32_t* __restrict__ spans, uint32_t* __restrict__ partials, Ctrl* __restrict__ ctrl,
                                                WireTri* __restrict__ wire) {
     __shared__ uint32_t wpart[4][6];
-    if (blockIdx.x == 0 && threadIdx.x < sizeof(Ctrl) / 4) reinterpret_cast<uint32_t*>(ctrl)[threadIdx.x] = 0;   // frame-start reset (no memset launch)
+    if (blockIdx.x == 0 && threadIdx.x < sizeof(Ctrl) / 4 && threadIdx.x != offsetof(Ctrl, sticky) / 4)
+        reinterpret_cast<uint32_t*>(ctrl)[threadIdx.x] = 0;                                // frame-start reset (no memset launch)
     const uint32_t f = blockIdx.x * 256u + threadIdx.x;
     bool visible = false, transparent = false, nan_key = false, bad_index = false;
     uint32_t key = KEY_INVALID, span = 0xFFFFFFFFu, n_tiles = 0;

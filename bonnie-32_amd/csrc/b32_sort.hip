@@ -60,8 +60,8 @@ __device__ void reduce_setup_partials(Ctrl* ctrl, const uint32_t* __restrict__ p
         ctrl->n_visible = t[0]; ctrl->n_transparent = t[1]; ctrl->nan_opaque = t[2]; ctrl->nan_transparent = t[3];
         ctrl->err_index = t[4] ? 1u : 0u;
         ctrl->n_opaque = n_op;
-        if (t[4]) ctrl->abort = 1;
-        if ((t[2] && n_op >= 2) || (t[3] && t[1] >= 2)) ctrl->abort = 1;
+        if (t[4]) { ctrl->abort = 1; ctrl->sticky |= 1u; }
+        if ((t[2] && n_op >= 2) || (t[3] && t[1] >= 2)) { ctrl->abort = 1; ctrl->sticky |= 2u; }
     }
     __syncthreads();
 }

@@ -81,7 +81,7 @@ __global__ void k_wire_insert(WireArgs a) {
 // exactly 1.0 per iteration (saturating at 2^24 in f32).  tests/test_oracle_kats.py checks this against the literal loop.
 __device__ void draw_line_dev(const WireArgs& a, const Edge& e, bool depth_test, uint32_t rgba) {
     const long long adx = llabs((long long)e.x1 - e.x0), ady = llabs((long long)e.y1 - e.y0);
-    if (adx >= (1ll << 30) || ady >= (1ll << 30)) { atomicOr(&a.ctrl->wire_overflow, 1u); return; }   // 2*err overflows i32 in the reference
+    if (adx >= (1ll << 30) || ady >= (1ll << 30)) { atomicOr(&a.ctrl->wire_overflow, 1u); atomicOr(&a.ctrl->sticky, 4u); return; }   // 2*err overflows i32 in the reference
     const int sx = e.x0 < e.x1 ? 1 : -1, sy = e.y0 < e.y1 ? 1 : -1;
     const long long N = adx > ady ? adx : ady;
     const float total_steps = (float)(N > 1 ? N : 1);                   // dx.max((-dy).max(1)) as f32

@@ -245,6 +245,26 @@ class ResidentScene:
         _chk(rc, "scene_upload")
         self.n_faces = len(f)
         self._packed = None
+        self._slot = None
+
+    def detach(self):
+        """Move this scene into its own slot (b32_scene_swap) so that other scenes can be uploaded and drawn through the same context:
+        every later render*/render_async swaps it in, enqueues, and swaps it out again -- no upload, no host sync."""
+        if self._slot is None:
+            h = C.c_void_p()
+            _chk(self.ctx.lib.b32_scene_create(self.ctx.h, C.byref(h)), "scene_create")
+            self._slot = h
+            _chk(self.ctx.lib.b32_scene_swap(self.ctx.h, self._slot), "scene_swap")
+        return self
+
+    def _swap(self):
+        if self._slot is not None:
+            _chk(self.ctx.lib.b32_scene_swap(self.ctx.h, self._slot), "scene_swap")
+
+    def close(self):
+        if self._slot is not None:
+            self.ctx.lib.b32_scene_destroy(self.ctx.h, self._slot)
+            self._slot = None
 
     def _pack(self, camera, settings, fog):
         cam = camera.pack()
@@ -256,11 +276,15 @@ class ResidentScene:
     def render(self, camera, settings, fog=None) -> T.RasterTimings:
         cam, st, _kl, fg = self._pack(camera, settings, fog)
         tm = abi.B32Timings()
-        if self.fmt8:
-            _chk(self.ctx.lib.b32_render_scene(self.ctx.h, C.byref(cam), C.byref(st), C.byref(tm)), "render_scene")
-        else:
-            _chk(self.ctx.lib.b32_render_scene_15(self.ctx.h, C.byref(cam), C.byref(st),
-                                                  C.byref(fg) if fg is not None else None, C.byref(tm)), "render_scene_15")
+        self._swap()
+        try:
+            if self.fmt8:
+                _chk(self.ctx.lib.b32_render_scene(self.ctx.h, C.byref(cam), C.byref(st), C.byref(tm)), "render_scene")
+            else:
+                _chk(self.ctx.lib.b32_render_scene_15(self.ctx.h, C.byref(cam), C.byref(st),
+                                                      C.byref(fg) if fg is not None else None, C.byref(tm)), "render_scene_15")
+        finally:
+            self._swap()
         return T.RasterTimings.from_c(tm)
 
     def render_async(self, camera=None, settings=None, fog=None):
@@ -268,11 +292,15 @@ class ResidentScene:
         if camera is not None:
             self._pack(camera, settings, fog)
         cam, st, _kl, fg = self._packed
-        if self.fmt8:
-            _chk(self.ctx.lib.b32_render_scene_async(self.ctx.h, C.byref(cam), C.byref(st)), "render_scene_async")
-            return
-        _chk(self.ctx.lib.b32_render_scene_15_async(self.ctx.h, C.byref(cam), C.byref(st),
-                                                    C.byref(fg) if fg is not None else None), "render_scene_15_async")
+        self._swap()
+        try:
+            if self.fmt8:
+                _chk(self.ctx.lib.b32_render_scene_async(self.ctx.h, C.byref(cam), C.byref(st)), "render_scene_async")
+            else:
+                _chk(self.ctx.lib.b32_render_scene_15_async(self.ctx.h, C.byref(cam), C.byref(st),
+                                                            C.byref(fg) if fg is not None else None), "render_scene_15_async")
+        finally:
+            self._swap()
 
     def finish(self) -> T.RasterTimings:
         tm = abi.B32Timings()

@@ -212,6 +212,20 @@ int b32_render_scene_15_async(b32_ctx* ctx,
                               const B32Fog* fog /* nullable */);
 int b32_frame_finish(b32_ctx* ctx, B32Timings* out /* nullable */);
 
+/* Several resident scenes per context (scene.rs:112-261 draws room after room, asset part after asset part, onto one
+ * framebuffer every frame): a slot owns one uploaded scene's device buffers.  b32_scene_swap exchanges the context's current
+ * resident scene with the slot's content (either side may be empty), so
+ *     upload A; swap(sA);  upload B; swap(sB);                                 -- once
+ *     clear;  swap(sA); render_async; swap(sA);  swap(sB); render_async; swap(sB);  frame_finish      -- every frame
+ * draws both meshes with no upload and no host synchronisation between them.  Errors of ANY frame enqueued since the last
+ * b32_frame_finish are reported by it (B32_E_INDEX / B32_E_NAN_KEY / B32_E_UNSUPPORTED; as in the reference, the failing mesh
+ * draws nothing); its counters are those of the most recent frame.  A pending frame of a large scene (more than 8192 faces, or
+ * more than 2048 with a transparent pass: it may need a redraw with grown buffers) is finished by b32_scene_swap before the exchange. */
+typedef struct b32_scene b32_scene;
+int b32_scene_create(b32_ctx* ctx, b32_scene** out);
+void b32_scene_destroy(b32_ctx* ctx, b32_scene* slot);
+int b32_scene_swap(b32_ctx* ctx, b32_scene* slot);
+
 /* ---- the 8-bit-colour path: render_mesh (render.rs:1971-2264) + rasterize_triangle (render.rs:1202-1433) ----
  * What every caller of the reference runs when settings.use_rgb555 is false (scene.rs:163-169).  Same pipeline and settings
  * as render_mesh_15 except: Texture texels are Color values with a per-texel blend mode, no fog, no opaque/transparent

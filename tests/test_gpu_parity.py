@@ -729,6 +729,63 @@ def test_ordering_with_torch_streams(oracle):
             ctx.close()
 
 
+def test_scene_slots_multi_mesh_frame(gpu_ctx, oracle):
+    """Several resident scenes in one context (b32_scene_swap): a console-style frame -- clear, then room after room onto the same
+    framebuffer with persistent depth (scene.rs:112-261) -- enqueued without uploads or host syncs between the meshes, three frames
+    with a moving camera.  RGB555 and 8-bit scenes mixed, one mesh above the small-mesh limit (its pending frame is settled by the
+    swap), one with a transparent pass."""
+    from bonnie32_amd import rasterizer as R
+    specs = [("gouraud", 700, False), ("blend", 1500, False), ("gouraud", 5000, False), ("bench", 300, True), ("gouraud", 2048, False)]
+    meshes = []
+    for i, (variant, n, f8) in enumerate(specs):
+        sc = scenegen.make_scene("C1", n_tris=n, seed=900 + i, variant=variant, bbox_px=300.0)
+        sc.tex8 = [b32.Texture.from_texture15(t) for t in sc.textures] if f8 else None
+        meshes.append(sc)
+    st15 = b32.RasterSettings.game(); st15.lights = [b32.Light.directional((-1.0, -1.0, -1.0), 0.7), b32.Light.spot((0, 0, -100), (0, 0, 1), 0.6, 6000.0, 1.3)]
+    st8 = b32.RasterSettings.game(); st8.use_rgb555 = False
+    fog = (1500.0, 3000.0, 5800.0, b32.Color(40, 50, 70))
+    W, H = meshes[0].width, meshes[0].height
+    gpu_ctx.set_fragment_counting(0)
+    try:
+        fb = R.Framebuffer(W, H, gpu_ctx)
+        slots = [R.ResidentScene(fb, sc.vertices, sc.faces, None if sc.tex8 else sc.textures, textures8=sc.tex8).detach() for sc in meshes]
+        ofb = oracle.Framebuffer(W, H)
+        for frame in range(3):
+            cam = b32.Camera(); cam.position = (10.0 * frame, -5.0 * frame, 20.0 * frame)
+            ofb.clear(b32.Color(10, 10, 30)); fb.clear(b32.Color(10, 10, 30))
+            for sc, rs in zip(meshes, slots):
+                if sc.tex8:
+                    assert oracle.render_mesh(ofb, sc.vertices, sc.faces, sc.tex8, cam, st8)[0] == 0
+                    rs.render_async(cam, st8)
+                else:
+                    assert oracle.render_mesh_15(ofb, sc.vertices, sc.faces, sc.textures, cam, st15, fog)[0] == 0
+                    rs.render_async(cam, st15, fog)
+            slots[-1].finish()
+            assert np.array_equal(fb.pixels, ofb.pixels), f"frame {frame}"
+            assert np.array_equal(fb.zbuffer.view(np.uint32), ofb.zbuffer.view(np.uint32))
+        # an error in the middle of a frame is reported by the finish, the failing mesh draws nothing, the others are drawn
+        bad = meshes[1].faces.copy(); bad["v"][7, 1] = 10 ** 6
+        bad_rs = R.ResidentScene(fb, meshes[1].vertices, bad, meshes[1].textures).detach()
+        cam = b32.Camera()
+        ofb.clear(b32.Color(1, 2, 3)); fb.clear(b32.Color(1, 2, 3))
+        order = [(meshes[0], slots[0]), (None, bad_rs), (meshes[4], slots[4])]
+        for sc, rs in order:
+            if sc is None:
+                assert oracle.render_mesh_15(ofb, meshes[1].vertices, bad, meshes[1].textures, cam, st15, fog)[0] == b32.abi.B32_E_INDEX
+            else:
+                assert oracle.render_mesh_15(ofb, sc.vertices, sc.faces, sc.textures, cam, st15, fog)[0] == 0
+            rs.render_async(cam, st15, fog)
+        with pytest.raises(R.B32Error) as e:
+            slots[4].finish()
+        assert e.value.code == b32.abi.B32_E_INDEX
+        assert np.array_equal(fb.pixels, ofb.pixels)
+        slots[0].render_async(cam, st15, fog); slots[0].finish()          # the error does not stick beyond the finish that reported it
+        for rs in slots + [bad_rs]:
+            rs.close()
+    finally:
+        gpu_ctx.set_fragment_counting(1)
+
+
 def test_randomised_mode_soak():
     """tools/soak.py for 20 s: random scenes x random settings (both pixel formats, z-buffer, x-ray, ortho, wireframes, fog, lights,
     editor alpha, ragged bands, counting on/off), bit-exact against the oracle.  (Longer runs of the same tool while building found two real bugs -- a record word not loaded for literal-walk surfaces, signed-zero depths -- and then passed ~35 000 scenes over eight seeds.)"""

@@ -1,0 +1,64 @@
+"""A frame the way the console's render step issues it (scene.rs:112-261): Framebuffer::clear, then one render_mesh_15 call per room /
+asset part onto the same 320x240 framebuffer (z-buffer, Gouraud + lights, fog), through the DROP-IN call with host slices -- per-call
+upload, synchronous -- then the download of the 320x240 frame the presenter consumes.  GPU vs the CPU oracle, bit-exact check of the final frame."""
+import sys, time
+sys.path.insert(0, ".")
+import numpy as np
+import bonnie32_amd as b32
+from bonnie32_amd import rasterizer as R, scenegen
+from oracle import oracle as O
+
+n_meshes = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+rng = np.random.default_rng(2024)
+meshes = []
+for i in range(n_meshes):
+    sc = scenegen.make_scene("C1", n_tris=int(rng.integers(300, 3000)), seed=1000 + i, variant=("blend" if i % 4 == 3 else "gouraud"),
+                             bbox_px=float(rng.choice([150.0, 400.0, 900.0])))
+    meshes.append(sc)
+st = b32.RasterSettings.game()
+st.lights = [b32.Light.directional((-1.0, -1.0, -1.0), 0.7), b32.Light.point((0.0, -100.0, 1500.0), 3000.0, 1.2)]
+fog = (1500.0, 3000.0, 5800.0, b32.Color(40, 50, 70))
+W, H = meshes[0].width, meshes[0].height
+clear = b32.Color(10, 10, 30)
+
+ofb = O.Framebuffer(W, H)
+def cpu_frame():
+    ofb.clear(clear)
+    for sc in meshes:
+        rc, _ = O.render_mesh_15(ofb, sc.vertices, sc.faces, sc.textures, sc.camera, st, fog)
+        assert rc == 0
+cpu_frame(); t0 = time.perf_counter()
+for _ in range(5): cpu_frame()
+t_cpu = (time.perf_counter() - t0) / 5
+
+ctx = R.Context(0)
+fb = R.Framebuffer(W, H, ctx)
+def gpu_frame():
+    fb.clear(clear)
+    for sc in meshes:
+        R.render_mesh_15(fb, sc.vertices, sc.faces, sc.textures, sc.camera, st, fog)
+    return fb.pixels            # what the presenter hands to Texture2D::from_rgba8 (game/renderer.rs:179)
+for _ in range(3): gpu_frame()
+N = 50; t0 = time.perf_counter()
+for _ in range(N): gpu_frame()
+t_gpu = (time.perf_counter() - t0) / N
+# the same frame with the rooms resident (one scene slot each, b32_scene_swap): no upload, no host sync between the meshes
+slots = [R.ResidentScene(fb, sc.vertices, sc.faces, sc.textures).detach() for sc in meshes]
+def gpu_frame_resident(first=False):
+    fb.clear(clear)
+    for sc, rs in zip(meshes, slots):
+        if first: rs.render_async(sc.camera, st, fog)
+        else: rs.render_async()
+    slots[-1].finish()
+    return fb.pixels
+gpu_frame_resident(True); gpu_frame_resident()
+t0 = time.perf_counter()
+for _ in range(N): gpu_frame_resident()
+t_res = (time.perf_counter() - t0) / N
+ok_res = np.array_equal(fb.pixels, ofb.pixels) and np.array_equal(fb.zbuffer.view(np.uint32), ofb.zbuffer.view(np.uint32))
+gpu_frame()
+ok = np.array_equal(fb.pixels, ofb.pixels) and np.array_equal(fb.zbuffer.view(np.uint32), ofb.zbuffer.view(np.uint32))
+tris = sum(sc.n_tris for sc in meshes)
+print(f"console frame: {n_meshes} meshes, {tris} triangles, {W}x{H}, game() + point light + fog: CPU oracle {t_cpu*1e3:.2f} ms, "
+      f"GPU drop-in calls + frame download {t_gpu*1e3:.3f} ms ({t_cpu/t_gpu:.1f}x), {t_gpu/n_meshes*1e6:.0f} us per mesh, bit-exact: {ok}; "
+      f"rooms resident in scene slots {t_res*1e3:.3f} ms ({t_cpu/t_res:.1f}x), {t_res/n_meshes*1e6:.0f} us per mesh, bit-exact: {ok_res}")
