@@ -84,6 +84,7 @@ struct b32_ctx {
     // last enqueued frame (for redraw after a pair overflow)
     bool frame_pending = false;
     bool pending_may_redraw = false;    // the pending frame took a path that can overflow its buffers (not the small-mesh path)
+    int deferred_rc = 0;                // error of a frame that b32_scene_swap had to settle: reported by the next b32_frame_finish
     B32Camera last_cam{}; B32Settings last_settings{}; B32Fog last_fog{}; bool last_has_fog = false;
     int last_pair_buf = 0;
 
@@ -857,7 +858,11 @@ int b32_frame_finish(b32_ctx* c, B32Timings* out) {
     if (!c) return B32_E_ARG;
     (void)hipSetDevice(c->device);
     if (out) memset(out, 0, sizeof(*out));
-    if (!c->frame_pending) { HIPCHK(c, hipStreamSynchronize(c->stream)); return B32_OK; }
+    if (!c->frame_pending) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        const int d = c->deferred_rc; c->deferred_rc = 0;
+        return d;
+    }
     for (int attempt = 0; attempt < 5; ++attempt) {
         // the frame's counters come back through the pinned arena (one small kernel writing host memory) rather than an SDMA copy:
         // ~5 us of stream time less per synchronous frame
@@ -893,6 +898,7 @@ int b32_frame_finish(b32_ctx* c, B32Timings* out) {
     collect_events(c);
     const uint32_t sticky = c->h_ctrl.sticky;                  // errors of every frame enqueued since the last finish
     if (sticky) HIPCHK(c, hipMemsetAsync(&c->d_ctrl->sticky, 0, sizeof(uint32_t), c->stream));
+    if (c->deferred_rc) { const int d = c->deferred_rc; c->deferred_rc = 0; return d; }     // (an earlier mesh of this frame, settled by a swap)
     if (c->h_ctrl.pairs_overflow) return B32_E_HIP;
     if (c->h_ctrl.err_index || (sticky & 1u)) return B32_E_INDEX;
     if (c->h_ctrl.abort || (sticky & 2u)) return B32_E_NAN_KEY;
@@ -929,7 +935,12 @@ int b32_scene_swap(b32_ctx* c, b32_scene* sl) {
     if (!c || !sl) return B32_E_ARG;
     // a pending frame of the outgoing scene that may have to be redrawn (pair overflow, long transparent lists) is settled first:
     // the redraw needs that scene.  Frames of small meshes never redraw and stay in flight.
-    if (c->frame_pending && c->pending_may_redraw) { const int rc = b32_frame_finish(c, nullptr); if (rc) return rc; }
+    // Its error, if any, is the frame's error: kept for the b32_frame_finish that ends the frame (the exchange itself goes ahead).
+    if (c->frame_pending && c->pending_may_redraw) {
+        const int rc = b32_frame_finish(c, nullptr);
+        if (rc == B32_E_HIP || rc == B32_E_ARG) return rc;
+        if (rc && !c->deferred_rc) c->deferred_rc = rc;
+    }
     std::swap(c->d_verts, sl->d_verts); std::swap(c->cap_verts, sl->cap_verts);
     std::swap(c->d_faces, sl->d_faces); std::swap(c->cap_faces, sl->cap_faces);
     std::swap(c->d_texels, sl->d_texels); std::swap(c->cap_texels, sl->cap_texels);

@@ -220,7 +220,8 @@ int b32_frame_finish(b32_ctx* ctx, B32Timings* out /* nullable */);
  * draws both meshes with no upload and no host synchronisation between them.  Errors of ANY frame enqueued since the last
  * b32_frame_finish are reported by it (B32_E_INDEX / B32_E_NAN_KEY / B32_E_UNSUPPORTED; as in the reference, the failing mesh
  * draws nothing); its counters are those of the most recent frame.  A pending frame of a large scene (more than 8192 faces, or
- * more than 2048 with a transparent pass: it may need a redraw with grown buffers) is finished by b32_scene_swap before the exchange. */
+ * more than 2048 with a transparent pass: it may need a redraw with grown buffers) is finished by b32_scene_swap before the exchange; an error of that frame is kept and
+ * reported by the b32_frame_finish that ends the frame. */
 typedef struct b32_scene b32_scene;
 int b32_scene_create(b32_ctx* ctx, b32_scene** out);
 void b32_scene_destroy(b32_ctx* ctx, b32_scene* slot);

@@ -40,8 +40,63 @@ def sky_case():
     sx = ((2 * np.arange(dw) + 1) * W) // (2 * dw); sy = ((2 * np.arange(dh) + 1) * H) // (2 * dh)
     return ok and np.array_equal(out, ofb.image()[sy][:, sx])
 
+def slots_case():
+    """A multi-mesh frame through scene slots (b32_scene_swap): 2-5 meshes of random size (across the inline-binning limits) and
+    random per-mesh settings, RGB555 and 8-bit mixed, two frames with different cameras, persistent depth; sometimes a mesh with a
+    bad vertex index in the middle (the finish reports it, that mesh draws nothing)."""
+    W, H = [(320, 240), (333, 197), (640, 480), (64, 64)][rng.integers(4)]
+    k = int(rng.integers(2, 6))
+    items = []
+    for i in range(k):
+        ntri = int(rng.choice([5, 300, 2048, 2500, 8192, 9000]))
+        sc = scenegen.make_scene(str(rng.choice(["C1", "C2"])), n_tris=ntri, seed=int(rng.integers(1 << 30)), variant=str(rng.choice(["bench", "gouraud", "blend"])),
+                                 width=W, height=H, bbox_px=float(rng.choice([60.0, 900.0, 20000.0])))
+        st = sc.settings
+        st.use_zbuffer = bool(rng.integers(2)); st.backface_cull = bool(rng.integers(2)); st.affine_textures = bool(rng.integers(4))
+        f8 = bool(rng.integers(4) == 0)
+        st.use_rgb555 = not f8
+        tex8 = [b32.Texture.from_texture15(t, int(rng.choice([0, 1, 3]))) for t in sc.textures] if f8 else None
+        bad = bool(rng.integers(8) == 0)
+        faces = sc.faces.copy()
+        if bad:
+            faces["v"][int(rng.integers(len(faces))), int(rng.integers(3))] = len(sc.vertices) + 5
+        items.append((sc, st, tex8, faces, bad))
+    ctx.set_fragment_counting(int(rng.integers(2)))
+    fb = R.Framebuffer(W, H, ctx)
+    ofb = O.Framebuffer(W, H)
+    slots = [R.ResidentScene(fb, sc.vertices, faces, None if tex8 else sc.textures, textures8=tex8).detach() for sc, st, tex8, faces, bad in items]
+    ok = True
+    try:
+        for frame in range(2):
+            cam = b32.Camera(); cam.position = (float(rng.normal(0, 30)), float(rng.normal(0, 30)), float(rng.normal(0, 60)))
+            col = b32.Color(int(rng.integers(256)), int(rng.integers(256)), int(rng.integers(256)))
+            ofb.clear(col); fb.clear(col)
+            want_rc = 0
+            for (sc, st, tex8, faces, bad), rs in zip(items, slots):
+                rc = (O.render_mesh(ofb, sc.vertices, faces, tex8, cam, st) if tex8 else O.render_mesh_15(ofb, sc.vertices, faces, sc.textures, cam, st))[0]
+                if rc and not want_rc:
+                    want_rc = rc
+                rs.render_async(cam, st)
+            try:
+                slots[-1].finish(); got_rc = 0
+            except R.B32Error as e:
+                got_rc = e.code
+            ok = ok and (got_rc != 0) == (want_rc != 0) and np.array_equal(fb.pixels, ofb.pixels) and np.array_equal(fb.zbuffer.view(np.uint32), ofb.zbuffer.view(np.uint32))
+    finally:
+        for rs in slots:
+            rs.close()
+    if not ok:
+        print("   slots:", [(sc.name, st.use_zbuffer, tex8 is not None, bad) for sc, st, tex8, faces, bad in items], W, H, flush=True)
+    return ok
+
 while time.time() < t_end:
     n += 1
+    if rng.integers(10) == 0 and not os.environ.get("SOAK_FORCE"):
+        drawn += 1
+        if not slots_case():
+            fails += 1
+            print(f"FAIL #{n} scene slots", flush=True)
+        continue
     if rng.integers(12) == 0:
         drawn += 1
         if not sky_case():
