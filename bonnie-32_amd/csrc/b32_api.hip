@@ -134,15 +134,36 @@ static int ensure_plain(b32_ctx* c, T*& p, size_t count) {   // exact-size (re)a
     return B32_OK;
 }
 
-// scratch upload helper for the small per-frame inputs of the sky / star / present calls
-template <typename T>
-static int to_device(b32_ctx* c, const T* host, size_t n, T** dev) {
-    *dev = nullptr;
-    if (!n) return B32_OK;
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(dev), n * sizeof(T)));
-    HIPCHK(c, hipMemcpyAsync(*dev, host, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
-    return B32_OK;
-}
+// Scratch device allocations of ONE API call (sky / stars / present / taps): released on every exit path, error returns included,
+// after the stream has drained.
+struct Scratch {
+    b32_ctx* c;
+    std::vector<void*> ptrs;
+    explicit Scratch(b32_ctx* ctx) : c(ctx) {}
+    Scratch(const Scratch&) = delete;
+    Scratch& operator=(const Scratch&) = delete;
+    ~Scratch() {
+        if (ptrs.empty()) return;
+        (void)hipStreamSynchronize(c->stream);
+        for (void* q : ptrs) (void)hipFree(q);
+    }
+    template <typename T>
+    int alloc(T** out, size_t count) {
+        void* q = nullptr;
+        *out = nullptr;
+        HIPCHK(c, hipMalloc(&q, (count ? count : 1) * sizeof(T)));
+        ptrs.push_back(q);
+        *out = static_cast<T*>(q);
+        return B32_OK;
+    }
+    template <typename T>
+    int upload(const T* host, size_t n, T** dev) {       // scratch copy of a small per-call input
+        int rc = alloc(dev, n);
+        if (rc || !n) return rc;
+        HIPCHK(c, hipMemcpyAsync(*dev, host, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+        return B32_OK;
+    }
+};
 
 extern "C" {
 
@@ -286,13 +307,13 @@ int b32_render_skybox_mesh(b32_ctx* c, const B32SkyVertex* v, uint32_t nv, const
     (void)hipSetDevice(c->device);
     for (uint32_t i = 0; i < 3 * nf; ++i) if (faces[i] >= nv) return B32_E_INDEX;          // projected[face[k]] index panic
     B32SkyVertex* dv = nullptr; uint32_t* df = nullptr; float2* dp = nullptr;
+    Scratch tmp(c);
     int rc;
-    if ((rc = to_device(c, v, (size_t)nv, &dv))) return rc;
-    if ((rc = to_device(c, faces, (size_t)nf * 3, &df))) return rc;
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&dp), (size_t)nv * sizeof(float2)));
+    if ((rc = tmp.upload(v, (size_t)nv, &dv))) return rc;
+    if ((rc = tmp.upload(faces, (size_t)nf * 3, &df))) return rc;
+    if ((rc = tmp.alloc(&dp, (size_t)nv))) return rc;
     launch_sky(c->stream, dv, nv, df, nf, *cam, dp, c->fb, c->width, c->height, c->band_y0, c->band_y1);
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    (void)hipFree(dv); (void)hipFree(df); (void)hipFree(dp);
     return B32_OK;
 }
 int b32_draw_star_diamonds(b32_ctx* c, const int32_t* cx, const int32_t* cy, const uint8_t* rgb, uint32_t n, float size) {
@@ -300,24 +321,25 @@ int b32_draw_star_diamonds(b32_ctx* c, const int32_t* cx, const int32_t* cy, con
     if (!n) return B32_OK;
     (void)hipSetDevice(c->device);
     int32_t *dx = nullptr, *dy = nullptr; uint8_t* dc = nullptr;
+    Scratch tmp(c);
     int rc;
-    if ((rc = to_device(c, cx, (size_t)n, &dx))) return rc;
-    if ((rc = to_device(c, cy, (size_t)n, &dy))) return rc;
-    if ((rc = to_device(c, rgb, (size_t)n * 3, &dc))) return rc;
+    if ((rc = tmp.upload(cx, (size_t)n, &dx))) return rc;
+    if ((rc = tmp.upload(cy, (size_t)n, &dy))) return rc;
+    if ((rc = tmp.upload(rgb, (size_t)n * 3, &dc))) return rc;
     launch_stars(c->stream, dx, dy, dc, n, size, c->fb, c->width, c->height, c->band_y0, c->band_y1);
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dc);
     return B32_OK;
 }
 int b32_present_nearest(b32_ctx* c, uint32_t dw, uint32_t dh, uint8_t* out) {
     if (!c || !c->fb || !out || !dw || !dh || dw > 32768 || dh > 32768) return B32_E_ARG;
     (void)hipSetDevice(c->device);
     uint32_t* dd = nullptr;
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&dd), (size_t)dw * dh * 4));
+    Scratch tmp(c);
+    int rc;
+    if ((rc = tmp.alloc(&dd, (size_t)dw * dh))) return rc;
     launch_upscale_nearest(c->stream, c->fb, c->width, c->height, dd, dw, dh);
     HIPCHK(c, hipMemcpyAsync(out, dd, (size_t)dw * dh * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    (void)hipFree(dd);
     return B32_OK;
 }
 int b32_fb_upload(b32_ctx* c, const uint8_t* rgba) {
@@ -548,13 +570,11 @@ int b32_scene_upload_indexed(b32_ctx* c, const B32Vertex* v, uint32_t nv, const 
             if (skippable * cheap_den() > n) c->cheap_ok = false;
         }
         uint8_t* d_idx = nullptr; uint16_t* d_clut = nullptr;
-        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d_idx), n));
-        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d_clut), (size_t)(tex[i].clut_len ? tex[i].clut_len : 1) * 2));
-        HIPCHK(c, hipMemcpyAsync(d_idx, tex[i].indices, n, hipMemcpyHostToDevice, c->stream));
-        if (tex[i].clut_len) HIPCHK(c, hipMemcpyAsync(d_clut, tex[i].clut, (size_t)tex[i].clut_len * 2, hipMemcpyHostToDevice, c->stream));
+        Scratch tmp(c);
+        if ((rc = tmp.upload(tex[i].indices, n, &d_idx))) return rc;
+        if ((rc = tmp.upload(tex[i].clut, (size_t)tex[i].clut_len, &d_clut))) return rc;
         launch_expand_indexed(c->stream, d_idx, (uint32_t)n, d_clut, tex[i].clut_len, c->d_texels + c->h_tex[i].offset);
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        (void)hipFree(d_idx); (void)hipFree(d_clut);
     }
     if ((rc = upload_geometry(c, v, nv, f, nf))) return rc;
     for (uint32_t i = 0; i < nt; ++i) if (bl[i] != B32_BLEND_OPAQUE) c->may_blend = true;
@@ -688,7 +708,8 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     const bool want_prio64 = spans_ok && !fp.ortho && !ordered_all;
     // too few 64x64 tiles to fill the GPU (narrow multi-GPU band, PS1-sized frame): tiles of 32 or 16 rows multiply the parallelism
     // of the fused kernel.  Only the sort-free path knows about them (its k_blend included); the keyed kernels keep 64 rows.
-    if (want_prio64 && c->band_y1 > c->band_y0 && !getenv("B32_NO_HALF_TILES")) {
+    static const bool no_half_tiles = getenv("B32_NO_HALF_TILES") != nullptr, no_inline_bin = getenv("B32_NO_INLINE_BIN") != nullptr;   // experiment switches, read once
+    if (want_prio64 && c->band_y1 > c->band_y0 && !no_half_tiles) {
         uint32_t th = TILE_H;
         // 64 -> 32 rows below two tiles per CU, 32 -> 16 rows below one tile per CU (measured: a 240-row band of C3 prefers 320 tiles
         // of 32 rows to 600 of 16; C2's 20 tiles prefer 80 of 16 rows)
@@ -723,7 +744,7 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     const uint32_t list_stride = (c->nf + 31u) & ~31u;
     // (with a transparent pass only up to 2048 faces: no tile's transparent list can then exceed what k_blend sorts in LDS)
     if (want_prio64 && !wire_front && c->nf <= (with_class ? 2048u : 8192u) && (size_t)ntiles * list_stride <= ((size_t)4 << 20) &&
-        !getenv("B32_NO_INLINE_BIN")) {
+        !no_inline_bin) {
         const size_t need = (size_t)ntiles * list_stride + 64;
         if (need > c->cap_inline) {
             if ((rc = ensure_plain(c, c->inline_lists, need + need / 2))) return rc;
@@ -1017,17 +1038,17 @@ int b32_project_fixed_batch(b32_ctx* c, const float* pos, uint32_t n, const B32C
     if (!n) return B32_OK;
     (void)hipSetDevice(c->device);
     float* d_pos = nullptr; int32_t *d_sx = nullptr, *d_sy = nullptr; float* d_z = nullptr;
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d_pos), (size_t)n * 12));
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d_sx), (size_t)n * 4));
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d_sy), (size_t)n * 4));
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d_z), (size_t)n * 4));
-    HIPCHK(c, hipMemcpyAsync(d_pos, pos, (size_t)n * 12, hipMemcpyHostToDevice, c->stream));
+    Scratch tmp(c);
+    int rc;
+    if ((rc = tmp.upload(pos, (size_t)n * 3, &d_pos))) return rc;
+    if ((rc = tmp.alloc(&d_sx, (size_t)n))) return rc;
+    if ((rc = tmp.alloc(&d_sy, (size_t)n))) return rc;
+    if ((rc = tmp.alloc(&d_z, (size_t)n))) return rc;
     launch_project_fixed(c->stream, d_pos, n, *cam, w, h, d_sx, d_sy, d_z);
     HIPCHK(c, hipMemcpyAsync(sx, d_sx, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(sy, d_sy, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(z, d_z, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    (void)hipFree(d_pos); (void)hipFree(d_sx); (void)hipFree(d_sy); (void)hipFree(d_z);
     return B32_OK;
 }
 
@@ -1058,14 +1079,15 @@ int b32_selftest_f32(b32_ctx* c, int op, const float* a, const float* b, const f
     if (!n) return B32_OK;
     (void)hipSetDevice(c->device);
     float* d[4] = { nullptr, nullptr, nullptr, nullptr };
-    for (auto& p : d) HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p), (size_t)n * 4));
-    HIPCHK(c, hipMemcpyAsync(d[0], a, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(d[1], b, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(d[2], cc, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    Scratch tmp(c);
+    int rc;
+    if ((rc = tmp.upload(a, (size_t)n, &d[0]))) return rc;
+    if ((rc = tmp.upload(b, (size_t)n, &d[1]))) return rc;
+    if ((rc = tmp.upload(cc, (size_t)n, &d[2]))) return rc;
+    if ((rc = tmp.alloc(&d[3], (size_t)n))) return rc;
     launch_selftest(c->stream, op, d[0], d[1], d[2], d[3], n);
     HIPCHK(c, hipMemcpyAsync(out, d[3], (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (auto& p : d) (void)hipFree(p);
     return B32_OK;
 }
 

@@ -1676,23 +1676,32 @@ __global__ __launch_bounds__(NT, 4) void k_blend(FillArgs a) {        // 4 waves
 }
 
 constexpr int BLEND_NT = 512;        // 8 waves: with ~80 VGPRs three workgroups fit a CU (the 1024-thread form only ever fit one)
+// hipFuncSetAttribute is per device: remember, per kernel instantiation, on which devices the large-LDS opt-in has been made
+// (a process may own contexts on several GPUs)
+static bool first_launch_on_device(bool (&done)[64]) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+    if (done[dev]) return false;
+    done[dev] = true;
+    return true;
+}
+
 template <bool FMT8, bool GATHER>
 static void launch_blend(hipStream_t s, const FillArgs& a, uint32_t ntiles) {
     const bool zmode = a.fp.zmode && !a.fp.xray;
     const size_t lds = blend_lds_bytes(FMT8, zmode);
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_blend<BLEND_NT, FMT8, GATHER>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    static bool attr[64] = {};
+    if (first_launch_on_device(attr)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_blend<BLEND_NT, FMT8, GATHER>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL((k_blend<BLEND_NT, FMT8, GATHER>), dim3(ntiles), dim3(BLEND_NT), lds, s, a);
 }
 
 template <bool EXACT, bool ZMODE, bool FMT8>
 static void launch_p64(hipStream_t s, const FillArgs& a, uint32_t ntiles, int n_cu, bool wide) {
     const size_t lds64 = 4 * LDS_TILE_BYTES + LDS_MISC_BYTES + LDS_MARK_BYTES;
-    static bool attr = false;
-    if (!attr) {
+    static bool attr[64] = {};
+    if (first_launch_on_device(attr)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<0, EXACT, 512, ZMODE, FMT8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<0, EXACT, 1024, ZMODE, FMT8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
     }
     const dim3 g(min(ntiles, (uint32_t)n_cu * 2));
     if (wide) hipLaunchKernelGGL((k_cover<0, EXACT, 1024, ZMODE, FMT8, true>), g, dim3(1024), lds64, s, a);
@@ -1714,7 +1723,8 @@ void launch_fill(hipStream_t s, const FillArgs& a, int n_cu, hipEvent_t after_co
     if (a.prio64) {   // sort-free fused kernel: coverage and shading are one launch; 64-bit tile buffers (2 x 36 KB)
         // EXACT = texel rule per fragment (textures with many skippable texels, or exact store counting); z-buffer mode = the
         // priority's high word is the fragment depth.  Few tiles (narrow multi-GPU bands, small frames): 16 waves per tile.
-        const bool wide = ntiles < 4u * (uint32_t)n_cu && !getenv("B32_P64_NT512");
+        static const bool force_512 = getenv("B32_P64_NT512") != nullptr;          // experiment switch, read once
+        const bool wide = ntiles < 4u * (uint32_t)n_cu && !force_512;
         const int sel = (a.exact_coverage ? 4 : 0) | (a.fp.zmode ? 2 : 0) | (f8 ? 1 : 0);
         switch (sel) {
             case 0: launch_p64<false, false, false>(s, a, ntiles, n_cu, wide); break;
@@ -1737,8 +1747,8 @@ void launch_fill(hipStream_t s, const FillArgs& a, int n_cu, hipEvent_t after_co
             hipLaunchKernelGGL((k_cover<0, true, 512, false, true>), dim3(min(ntiles, (uint32_t)n_cu * 2)), dim3(512), LDS_TEX_OFFSET, s, a);
         } else if (a.lds_tex_texels) {     // texture sampled once per fragment: stage it in LDS, one 16-wave workgroup per CU
             const size_t lds = LDS_TEX_OFFSET + (((size_t)a.lds_tex_texels * 2 + 15) & ~(size_t)15);
-            static bool attr_set = false;
-            if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<1, true, 1024, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+            static bool attr_set[64] = {};
+            if (first_launch_on_device(attr_set)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<1, true, 1024, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             hipLaunchKernelGGL((k_cover<1, true, 1024, false, false>), dim3(min(ntiles, (uint32_t)n_cu)), dim3(1024), lds, s, a);
         } else {
             hipLaunchKernelGGL((k_cover<0, true, 512, false, false>), dim3(min(ntiles, (uint32_t)n_cu * 2)), dim3(512), LDS_TEX_OFFSET, s, a);
