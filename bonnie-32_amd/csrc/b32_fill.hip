@@ -75,7 +75,9 @@ __device__ __forceinline__ bool inside_bc(const Tri& t, float w0, float w1, floa
     bcy = w1 * t.inv_area;
     bcz = 1.0f - bcx - bcy;
     const float ERR = -0.0001f;
-    return bcx >= ERR && bcy >= ERR && bcz >= ERR;
+    // bcx >= ERR && bcy >= ERR && bcz >= ERR with one comparison less.  NaN-safe although fminf drops a NaN operand: a NaN (or an
+    // infinity of either sign) in bcx or bcy makes bcz NaN or -inf, and `bcz >= ERR` is then false like the original conjunction.
+    return (__builtin_fminf(bcx, bcy) >= ERR) & (bcz >= ERR);
 }
 
 // Texture::sample of the 8-bit-colour path (types.rs:1242-1253): Color texel r | g<<8 | b<<16 | blend<<24
@@ -637,7 +639,7 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
                         for (int j = 0; j < 4; ++j) {
                             const float cx = wa[j] * sinv, cy = wb[j] * sinv;
                             const float cz = 1.0f - cx - cy;
-                            in[j] = (i + j < n) & (cx >= ERR) & (cy >= ERR) & (cz >= ERR);
+                            in[j] = (i + j < n) & (__builtin_fminf(__builtin_fminf(cx, cy), cz) >= ERR);        // (see the CHEAP trip below)
                             Pj[j] = P; ta[j] = -1;
                             if (in[j]) {
                                 if (ZMODE) { uint32_t zkey; in[j] = frag_zkey(tr, cx, cy, cz, zkey); Pj[j] = ((unsigned long long)(~zkey) << 32) | (uint32_t)P; }
@@ -665,7 +667,7 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
                     if (i < n) {
                         const float bcx = w0 * sinv, bcy = w1 * sinv;
                         const float bcz = 1.0f - bcx - bcy;
-                        if ((bcx >= ERR) & (bcy >= ERR) & (bcz >= ERR)) {
+                        if (__builtin_fminf(__builtin_fminf(bcx, bcy), bcz) >= ERR) {
                             bool drawn = true;
                             uint32_t zkey = 0;
                             if (ZMODE) drawn = frag_zkey(tr, bcx, bcy, bcz, zkey);
@@ -700,7 +702,8 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
                     for (int j = 0; j < TRIP; ++j) {
                         const float cx = wa[j] * sinv, cy = wb[j] * sinv;
                         const float cz = 1.0f - cx - cy;
-                        in[j] = (i + j < n) & (cx >= ERR) & (cy >= ERR) & (cz >= ERR);
+                        // all three >= ERR  <=>  their minimum is (no NaN can occur here: w integers, inv_area finite and non-zero)
+                        in[j] = (i + j < n) & (__builtin_fminf(__builtin_fminf(cx, cy), cz) >= ERR);
                         old[j] = 0; Pj[j] = P;
                         if (ZMODE) {                            // fragment depth (render.rs:1546-1550); NaN never passes `z < zbuffer`
                             const float inv_z = cx * z1 + cy * z2 + cz * z3;
@@ -730,8 +733,8 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
                     const float w0b = w0 + sa0, w1b = w1 + sa1;
                     const float ax = w0 * sinv, ay = w1 * sinv, bx = w0b * sinv, by = w1b * sinv;
                     const float az = 1.0f - ax - ay, bz = 1.0f - bx - by;
-                    const bool ina = (i < n) & (ax >= ERR) & (ay >= ERR) & (az >= ERR);
-                    const bool inb = (i + 1 < n) & (bx >= ERR) & (by >= ERR) & (bz >= ERR);
+                    const bool ina = (i < n) & (__builtin_fminf(__builtin_fminf(ax, ay), az) >= ERR);
+                    const bool inb = (i + 1 < n) & (__builtin_fminf(__builtin_fminf(bx, by), bz) >= ERR);
                     uint32_t olda = 0, oldb = 0;
                     if (ina) olda = atomicMax(&tilebuf[addr], li);
                     if (inb) oldb = atomicMax(&tilebuf[addr + 1], li);
