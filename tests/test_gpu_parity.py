@@ -204,6 +204,74 @@ def test_triangle_sizes_across_the_row_trim_thresholds(gpu_ctx, oracle, bbox_px,
         gpu_ctx.set_fragment_counting(1)
 
 
+def needle_scene(n=160, seed=5):
+    """Needles millions of pixels long with their tip on the screen (the far end sits next to the camera plane, where the projection
+    blows up): doubled area up to 2^23, so the -1e-4 tolerance of the inside test (render.rs:1536-1542) is worth a few hundred edge
+    units, and the pixels straight BEYOND the tip -- outside the triangle's own bounding box -- still pass it.  The reference never
+    looks at them: its loops stop at the bounding box, which is therefore part of the semantics.  (Integer-snapped coordinates
+    below 2^22 with products below 2^24: these surfaces take the closed-form walk, not the literal replay.)"""
+    # (the 256-entry CLUT of C3 has too few black texels for EXACT coverage to be chosen: with fragment counting off this is CHEAP coverage)
+    sc = scenegen.make_scene("C3", n_tris=n, seed=seed, bbox_px=100.0, width=320, height=240)
+    rng = np.random.default_rng(seed)
+    W, H = sc.width, sc.height
+    vs = np.float32((np.float32(min(W, H)) / np.float32(2.0)) * np.float32(0.75))
+    pos = sc.vertices["pos"].reshape(n, 3, 3)
+    for i in range(n):
+        x0 = int(rng.integers(8, W - 8)); y0 = int(rng.integers(8, H - 8))
+        side = -1.0 if rng.integers(2) else 1.0                  # the far end lies to the left or to the right
+        zt = np.float32(rng.uniform(300, 3000)); zf = np.float32(0.2)
+        dy = sorted(int(v) for v in rng.choice(np.arange(-3, 4), 2, replace=False))
+        tip = [(x0 - W / 2) / vs * (zt + 5) / 4, (y0 - H / 2) / vs * (zt + 5) / 4, zt]
+        far = [[side * float(rng.uniform(3.0e4, 5.0e4)), (y0 + d - H / 2) / vs * (zf + 5) / 4, zf] for d in dy]
+        far[1][0] = far[0][0]
+        tri = np.array([tip, far[0], far[1]], np.float32)
+        pos[i] = tri[[0, 2, 1]] if rng.integers(2) else tri
+    sc.settings.backface_cull = False
+    return sc
+
+
+def test_bounding_box_is_part_of_the_inside_test(gpu_ctx, oracle):
+    """See needle_scene.  First the scene is checked to contain what it is for (pixels outside a triangle's box that would pass the
+    toleranced test), then GPU == oracle in CHEAP and EXACT coverage, painter's and z-buffer."""
+    sc = needle_scene()
+    want, etm, d = cpu_render(oracle, sc)
+    # count box-external pixels (up to 3 to the left / right, same rows) that pass bc >= -1e-4 for some drawn triangle
+    F = np.float32
+    sx, sy = d["sx"].astype(F), d["sy"].astype(F)
+    leaks = 0
+    for f in d["draw_order"][:150]:
+        i1, i2, i3 = sc.faces["v"][f]
+        x1, y1, x2, y2, x3, y3 = sx[i1], sy[i1], sx[i2], sy[i2], sx[i3], sy[i3]
+        area = F(F((y2 - y3) * (x1 - x3)) + F((x3 - x2) * (y1 - y3)))
+        if area < 0:                                             # rendered back-face: v2 / v3 swap (render.rs:2453-2479)
+            x2, y2, x3, y3 = x3, y3, x2, y2
+            area = F(F((y2 - y3) * (x1 - x3)) + F((x3 - x2) * (y1 - y3)))
+        if abs(area) < 1:
+            continue
+        inv = F(F(1.0) / area)
+        bx0, bx1 = int(max(min(x1, x2, x3), 0)), int(min(max(x1, x2, x3), sc.width - 1))
+        by0, by1 = max(int(min(y1, y2, y3)), 0), min(int(max(y1, y2, y3)), sc.height - 1)
+        ys = np.arange(by0, by1 + 1, dtype=np.float32)[:, None]
+        xs = np.concatenate([np.arange(bx0 - 3, bx0), np.arange(bx1 + 1, bx1 + 4)]).astype(np.float32)[None, :]
+        w0 = ((y2 - y3) * (xs - x3) + (x3 - x2) * (ys - y3)).astype(F)
+        w1 = ((y3 - y1) * (xs - x3) + (x1 - x3) * (ys - y3)).astype(F)
+        bx, by = (w0 * inv).astype(F), (w1 * inv).astype(F)
+        bz = ((F(1.0) - bx).astype(F) - by).astype(F)
+        leaks += int(((bx >= F(-0.0001)) & (by >= F(-0.0001)) & (bz >= F(-0.0001)) & (xs >= 0) & (xs < sc.width)).sum())
+    assert leaks > 50, leaks
+    for zbuf in (False, True):
+        sc.settings.use_zbuffer = zbuf
+        want, etm, _ = cpu_render(oracle, sc)
+        try:
+            for counting in (0, 1):
+                gpu_ctx.set_fragment_counting(counting)
+                for resident in (False, True):
+                    got, tm = gpu_render(gpu_ctx, sc, resident=resident)
+                    assert np.array_equal(got, want), (zbuf, counting, resident, int((got != want).sum()))
+        finally:
+            gpu_ctx.set_fragment_counting(1)
+
+
 def test_c1_against_committed_frame(gpu_ctx):
     z = np.load(os.path.join(GOLD, "c1_frame.npz"))
     got, tm = gpu_render(gpu_ctx, SCENES["C1"]())
