@@ -48,6 +48,32 @@ def spot_scene(flat=False, zbuf=False):
     return sc
 
 
+def needle_scene(n=160, seed=5):
+    """Needles millions of pixels long with their tip on the screen (the far end sits next to the camera plane, where the projection
+    blows up): doubled area up to 2^23, so the -1e-4 tolerance of the inside test (render.rs:1536-1542) is worth a few hundred edge
+    units, and the pixels straight BEYOND the tip -- outside the triangle's own bounding box -- still pass it.  The reference never
+    looks at them: its loops stop at the bounding box, which is therefore part of the semantics.  (Integer-snapped coordinates
+    below 2^22 with products below 2^24: these surfaces take the closed-form walk, not the literal replay.)"""
+    # (the 256-entry CLUT of C3 has too few black texels for EXACT coverage to be chosen: with fragment counting off this is CHEAP coverage)
+    sc = scenegen.make_scene("C3", n_tris=n, seed=seed, bbox_px=100.0, width=320, height=240)
+    rng = np.random.default_rng(seed)
+    W, H = sc.width, sc.height
+    vs = np.float32((np.float32(min(W, H)) / np.float32(2.0)) * np.float32(0.75))
+    pos = sc.vertices["pos"].reshape(n, 3, 3)
+    for i in range(n):
+        x0 = int(rng.integers(8, W - 8)); y0 = int(rng.integers(8, H - 8))
+        side = -1.0 if rng.integers(2) else 1.0                  # the far end lies to the left or to the right
+        zt = np.float32(rng.uniform(300, 3000)); zf = np.float32(0.2)
+        dy = sorted(int(v) for v in rng.choice(np.arange(-3, 4), 2, replace=False))
+        tip = [(x0 - W / 2) / vs * (zt + 5) / 4, (y0 - H / 2) / vs * (zt + 5) / 4, zt]
+        far = [[side * float(rng.uniform(3.0e4, 5.0e4)), (y0 + d - H / 2) / vs * (zf + 5) / 4, zf] for d in dy]
+        far[1][0] = far[0][0]
+        tri = np.array([tip, far[0], far[1]], np.float32)
+        pos[i] = tri[[0, 2, 1]] if rng.integers(2) else tri
+    sc.settings.backface_cull = False
+    return sc
+
+
 def persp_scene():
     sc = scenegen.make_scene("C1", seed=31, bbox_px=400.0)
     sc.settings.affine_textures = False          # perspective-correct UVs (render.rs:1568-1579)
@@ -105,6 +131,7 @@ SCENES = {
     "wire-grid:near-first": lambda: scenegen.wire_grid_scene(False),
     "C1:spot-gouraud": spot_scene,
     "C1:spot-flat-zbuf": lambda: spot_scene(True, True),
+    "needles": needle_scene,
     "C1:persp": persp_scene,
     "C1:zbuf": zbuf_scene,
     "C1:zbuf-blend": lambda: zbuf_scene("blend", 19),

@@ -12,7 +12,7 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden")
 HASHES = json.load(open(os.path.join(GOLD, "hashes.json")))
 NEW_MODES = ["C1:ortho", "C1:xray", "C1:xray-zbuf", "C1:default-settings", "C1:wire-painter", "C1:wire-overlay", "cube:default",
              "wire-grid:far-first", "wire-grid:near-first"]
-FAST = NEW_MODES + ["C1:spot-gouraud", "C1:spot-flat-zbuf", "C1", "C1:zbuf", "C1:zbuf-blend", "C1:zbuf-gouraud", "C1:gouraud", "C1:blend", "C1:float", "C1:persp", "cube", "fog-flat-point-nocull", "C2", "C2:blend", "C3:100k", "C5:20k"]
+FAST = NEW_MODES + ["C1:spot-gouraud", "C1:spot-flat-zbuf", "needles", "C1", "C1:zbuf", "C1:zbuf-blend", "C1:zbuf-gouraud", "C1:gouraud", "C1:blend", "C1:float", "C1:persp", "cube", "fog-flat-point-nocull", "C2", "C2:blend", "C3:100k", "C5:20k"]
 
 
 @pytest.mark.parametrize("name", FAST)
@@ -44,7 +44,7 @@ def test_cube_fixture(oracle):
 
 
 @pytest.mark.parametrize("name", ["C1", "C1:gouraud", "C1:blend", "C1:float", "C1:persp", "cube", "fog-flat-point-nocull",
-                                  "C1:zbuf", "C1:zbuf-blend", "C1:zbuf-gouraud", "C1:spot-gouraud", "C1:spot-flat-zbuf"] + NEW_MODES)
+                                  "C1:zbuf", "C1:zbuf-blend", "C1:zbuf-gouraud", "C1:spot-gouraud", "C1:spot-flat-zbuf", "needles"] + NEW_MODES)
 def test_two_restatements_agree(oracle, name):
     """oracle/b32_oracle.c and oracle/np_model.py are two readings of the same Rust; whole frames must be identical."""
     from oracle import np_model as M
