@@ -178,6 +178,10 @@ __device__ __forceinline__ uint32_t fog_color(uint32_t c, uint32_t fogc, float f
 }
 
 // ---------------------------------------------------------------- k_setup
+#ifndef B32_SETUP_FPT
+#define B32_SETUP_FPT 2
+#endif
+constexpr int SETUP_FPT = B32_SETUP_FPT;       // faces per thread
 __global__ __launch_bounds__(256) void k_setup(FrameParams fp, const B32Vertex* __restrict__ verts, const B32Face* __restrict__ faces,
                                                const TexDesc* __restrict__ tex, const B32Light* __restrict__ lights,
                                                SurfRec* __restrict__ recs, float* __restrict__ shades, uint32_t* __restrict__ keys,
@@ -186,26 +190,57 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp, const B32Vertex* 
     __shared__ uint32_t wpart[4][6];
     if (blockIdx.x == 0 && threadIdx.x < sizeof(Ctrl) / 4 && threadIdx.x != offsetof(Ctrl, sticky) / 4)
         reinterpret_cast<uint32_t*>(ctrl)[threadIdx.x] = 0;                                // frame-start reset (no memset launch)
-    const uint32_t f = blockIdx.x * 256u + threadIdx.x;
+    // Every thread owns SETUP_FPT faces, 256 apart (a workgroup covers SETUP_FPT groups of 256 consecutive faces).  All of their
+    // inputs -- the face words, then the three vertices each -- are requested before the first face is processed, so the second
+    // face's two dependent memory latencies pass behind the ~900 VALU instructions of the first.
+    struct FaceIn { uint32_t w[5]; float v[3][5]; uint32_t col[3]; bool live, bad; };
+    FaceIn fin[SETUP_FPT];
+#pragma unroll
+    for (int g = 0; g < SETUP_FPT; ++g) {
+        const uint32_t f = (blockIdx.x * SETUP_FPT + g) * 256u + threadIdx.x;
+        fin[g].live = f < fp.nf; fin[g].bad = false;
+        if (fin[g].live) {
+            const uint32_t* fw = reinterpret_cast<const uint32_t*>(faces) + (size_t)f * 5;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) fin[g].w[k] = fw[k];
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < SETUP_FPT; ++g) {
+        if (fin[g].live) {
+            fin[g].bad = fin[g].w[0] >= fp.nv || fin[g].w[1] >= fp.nv || fin[g].w[2] >= fp.nv;       // index panic, render.rs:2375-2377
+            if (!fin[g].bad) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const float* vp = reinterpret_cast<const float*>(verts) + (size_t)fin[g].w[j] * 9;
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) fin[g].v[j][k] = vp[k];
+                    fin[g].col[j] = reinterpret_cast<const uint32_t*>(vp)[8];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < SETUP_FPT; ++g) {
+    const uint32_t f = (blockIdx.x * SETUP_FPT + g) * 256u + threadIdx.x;
+    const FaceIn& in = fin[g];
     bool visible = false, transparent = false, nan_key = false, bad_index = false;
     uint32_t key = KEY_INVALID, span = 0xFFFFFFFFu, n_tiles = 0;
-    if (f < fp.nf) {
-        const uint32_t* fw = reinterpret_cast<const uint32_t*>(faces) + (size_t)f * 5;
-        uint32_t vi[3] = { fw[0], fw[1], fw[2] };
-        const uint32_t tid = fw[3], fb4 = fw[4];
+    if (in.live) {
+        uint32_t vi[3] = { in.w[0], in.w[1], in.w[2] };
+        const uint32_t tid = in.w[3], fb4 = in.w[4];
         const uint32_t black_tr = fb4 & 0xFF, face_blend = (fb4 >> 8) & 0xFF, editor_alpha = (fb4 >> 16) & 0xFF;
-        if (vi[0] >= fp.nv || vi[1] >= fp.nv || vi[2] >= fp.nv) {
-            bad_index = true;                                   // index panic, render.rs:2375-2377
+        if (in.bad) {
+            bad_index = true;
         } else {
             const CamFx& k = fp.camfx;              // loop-invariant fixed-point conversions, done once on the host
             const V3 cpos = ld3(fp.cam.position), bx = ld3(fp.cam.basis_x), by = ld3(fp.cam.basis_y), bz = ld3(fp.cam.basis_z);
             V3 scr[3]; float camz[3]; V3 wpos[3]; float uvx[3], uvy[3]; uint32_t col[3];
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                const float* vp = reinterpret_cast<const float*>(verts) + (size_t)vi[j] * 9;
-                V3 pos = { vp[0], vp[1], vp[2] };
-                uvx[j] = vp[3]; uvy[j] = vp[4];
-                col[j] = reinterpret_cast<const uint32_t*>(vp)[8];
+                V3 pos = { in.v[j][0], in.v[j][1], in.v[j][2] };
+                uvx[j] = in.v[j][3]; uvy[j] = in.v[j][4];
+                col[j] = in.col[j];
                 wpos[j] = pos;
                 V3 rel = sub3(pos, cpos);
                 V3 cp = { dot3(rel, bx), dot3(rel, by), dot3(rel, bz) };       // perspective_transform, math.rs:103-109
@@ -364,14 +399,18 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp, const B32Vertex* 
     for (int off = 32; off > 0; off >>= 1) n_tiles += __shfl_down(n_tiles, off);      // (tile, surface) pairs of this block
     if ((threadIdx.x & 63) == 0) wpart[wv][5] = n_tiles;
     __syncthreads();
-    if (threadIdx.x < 6) partials[blockIdx.x * 8 + threadIdx.x] = wpart[0][threadIdx.x] + wpart[1][threadIdx.x] + wpart[2][threadIdx.x] + wpart[3][threadIdx.x];
+    // (one record per group of 256 faces, as before: the consumers index them by face / 256)
+    const uint32_t grp = blockIdx.x * SETUP_FPT + g;
+    if (threadIdx.x < 6 && grp * 256u < fp.nf) partials[grp * 8 + threadIdx.x] = wpart[0][threadIdx.x] + wpart[1][threadIdx.x] + wpart[2][threadIdx.x] + wpart[3][threadIdx.x];
+    __syncthreads();
+    }   // SETUP_FPT faces per thread
 }
 
 void launch_setup(hipStream_t s, const FrameParams& fp, const B32Vertex* verts, const B32Face* faces, const TexDesc* tex,
                   const B32Light* lights, SurfRec* recs, float* shades, uint32_t* keys, uint32_t* spans, uint32_t* partials, Ctrl* ctrl,
                   WireTri* wire) {
     if (fp.nf == 0) return;
-    hipLaunchKernelGGL(k_setup, dim3((fp.nf + 255) / 256), dim3(256), 0, s, fp, verts, faces, tex, lights, recs, shades, keys, spans, partials, ctrl, wire);
+    hipLaunchKernelGGL(k_setup, dim3((fp.nf + 256 * SETUP_FPT - 1) / (256 * SETUP_FPT)), dim3(256), 0, s, fp, verts, faces, tex, lights, recs, shades, keys, spans, partials, ctrl, wire);
 }
 
 // ---------------------------------------------------------------- stage tap: project_fixed for n positions
