@@ -1,3 +1,5 @@
+"""hipMemcpyAsync host-to-device: enqueue cost and stream time per copy, pageable vs pinned source, small sizes (why the drop-in
+calls move their uploads with one copy kernel out of a pinned arena instead of five SDMA copies)."""
 import ctypes as C, time, numpy as np
 hip = C.CDLL("/opt/rocm/lib/libamdhip64.so")
 hip.hipSetDevice(0)
