@@ -178,10 +178,9 @@ __device__ __forceinline__ uint32_t fog_color(uint32_t c, uint32_t fogc, float f
 }
 
 // ---------------------------------------------------------------- k_setup
-#ifndef B32_SETUP_FPT
-#define B32_SETUP_FPT 2
-#endif
-constexpr int SETUP_FPT = B32_SETUP_FPT;       // faces per thread
+// SETUP_FPT = faces per thread: 2 for large meshes (memory latency of the second face hidden behind the first: 51 -> 47 us at 1 M
+// faces; 3 and 4 lose to register pressure), 1 for small ones (where the kernel's latency, not its throughput, is what a frame waits for)
+template <int SETUP_FPT>
 __global__ __launch_bounds__(256) void k_setup(FrameParams fp, const B32Vertex* __restrict__ verts, const B32Face* __restrict__ faces,
                                                const TexDesc* __restrict__ tex, const B32Light* __restrict__ lights,
                                                SurfRec* __restrict__ recs, float* __restrict__ shades, uint32_t* __restrict__ keys,
@@ -410,7 +409,8 @@ void launch_setup(hipStream_t s, const FrameParams& fp, const B32Vertex* verts, 
                   const B32Light* lights, SurfRec* recs, float* shades, uint32_t* keys, uint32_t* spans, uint32_t* partials, Ctrl* ctrl,
                   WireTri* wire) {
     if (fp.nf == 0) return;
-    hipLaunchKernelGGL(k_setup, dim3((fp.nf + 256 * SETUP_FPT - 1) / (256 * SETUP_FPT)), dim3(256), 0, s, fp, verts, faces, tex, lights, recs, shades, keys, spans, partials, ctrl, wire);
+    if (fp.nf >= 400000) hipLaunchKernelGGL(k_setup<2>, dim3((fp.nf + 511) / 512), dim3(256), 0, s, fp, verts, faces, tex, lights, recs, shades, keys, spans, partials, ctrl, wire);
+    else hipLaunchKernelGGL(k_setup<1>, dim3((fp.nf + 255) / 256), dim3(256), 0, s, fp, verts, faces, tex, lights, recs, shades, keys, spans, partials, ctrl, wire);
 }
 
 // ---------------------------------------------------------------- stage tap: project_fixed for n positions
