@@ -33,6 +33,11 @@ def main():
     ap.add_argument("--check", action="store_true", help="also verify the final frame against the oracle (slow at C3)")
     ap.add_argument("--weak-series", action="store_true",
                     help="also time the weak-scaling point of SURVEY 8e (N x 125 k tris on the same frame); always on for N > 1")
+    ap.add_argument("--sync-gather", action="store_true",
+                    help="N > 1: gather every frame before the next one starts (default: frames alternate between two framebuffers and the "
+                         "gather of one overlaps the rendering of the next, after a run-time self-check against the synchronous frame)")
+    ap.add_argument("--pipeline-debug", action="store_true",
+                    help="with --dist-backend gloo: run the overlapped-gather logic too (band rows staged through the host)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default). gloo = debug only: ranks may share one GPU, band rows are staged through the host")
     args = ap.parse_args()
@@ -116,18 +121,97 @@ def main():
     ctx.set_fragment_counting(0)          # instrumentation off for the timed region (identical framebuffer)
     step(); rs.finish()
 
+    # ---- N > 1: overlap the band gather with the next frame.  Frames alternate between two framebuffers (two contexts on the same
+    # stream, each with the scene resident); the gather of frame i is asynchronous (RCCL's own stream, started after frame i's kernels)
+    # and is only waited for when its buffer is about to be redrawn, two frames later.  Every frame is still cleared, rendered and
+    # gathered in full.  Guarded by a run-time self-check: pipelined frames must equal the synchronous frame on rank 0, on every
+    # rank's agreement, otherwise the synchronous path is timed.
+    sets = [(fb, rs, frame)]
+    pending = [None, None]
+    pipelined = False
+
+    def make_second_set():
+        ctx2 = R.Context(local_rank)
+        ctx2.set_stream(stream.cuda_stream)
+        frame2 = torch.zeros_like(frame)
+        fb2 = R.Framebuffer.__new__(R.Framebuffer)
+        fb2.ctx = ctx2
+        fb2.bind_device(frame2.data_ptr(), W, H)
+        fb2.set_band(y0, y1)
+        rs2 = R.ResidentScene(fb2, sc.vertices, sc.faces, indexed_textures=sc.indexed_textures)
+        return fb2, rs2, frame2
+
+    def pstep(i, ssets, scene, first=False):
+        k = i % len(ssets)
+        fbk, rsk, frk = ssets[k]
+        if pending[k] is not None:                      # this buffer's previous frame must have left before it is redrawn
+            pending[k][0].wait(); pending[k] = None
+        fbk.clear(scene.clear_color)
+        if first:
+            rsk.render_async(scene.camera, scene.settings, scene.fog)
+        else:
+            rsk.render_async()
+        if args.dist_backend == "nccl":
+            pending[k] = parallel.gather_bands_async(frk, W, H, world, rank)
+        else:               # debug: the same alternation and waits, rows staged through a host copy (gloo has no device gather)
+            host = frk.cpu()
+            work, keep = parallel.gather_bands_async(host, W, H, world, rank)
+
+            class _HostWait:
+                def wait(self, work=work, host=host, frk=frk):
+                    work.wait()
+                    if rank == 0:
+                        frk.copy_(host)
+            pending[k] = (_HostWait(), keep)
+
+    def pdrain():
+        for k in range(2):
+            if pending[k] is not None:
+                pending[k][0].wait(); pending[k] = None
+
+    if world > 1 and (args.dist_backend == "nccl" or args.pipeline_debug) and not args.sync_gather and H % world == 0:
+        ok = 1
+        try:
+            sets.append(make_second_set())
+            torch.cuda.synchronize(dev)
+            ref = frame.clone() if rank == 0 else None            # the synchronous frame (assembled by the last step())
+            for i in range(4):
+                pstep(i, sets, sc, first=(i < 2))
+            pdrain()
+            sets[0][1].finish(); sets[1][1].finish()
+            torch.cuda.synchronize(dev)
+            if rank == 0 and not (torch.equal(sets[0][2], ref) and torch.equal(sets[1][2], ref)):
+                ok = 0
+        except Exception as e:                                    # noqa: BLE001 -- any failure means: time the synchronous path
+            print(f"# rank {rank}: pipelined gather unavailable ({e!r}), timing the synchronous path", file=sys.stderr)
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev if args.dist_backend == "nccl" else torch.device("cpu"))
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        pipelined = bool(flag.item())
+        if not pipelined:
+            pending[0] = pending[1] = None
+            sets = sets[:1]
+            step(); rs.finish()
+
     # ---- timed region: exactly K steps, HIP events around the dominant kernel on the stream it runs on
     ctx.set_profiling(1)
     sync_all()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    if pipelined:
+        for i in range(args.steps):
+            pstep(i, sets, sc)
+        pdrain()
+    else:
+        for _ in range(args.steps):
+            step()
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
         torch.cuda.synchronize(dev)
     t1 = time.perf_counter()
     tm = rs.finish()
+    if pipelined:
+        sets[1][1].finish()
     cover_ms = ctx.last_kernel_times().get("cover", None)     # HIP events around k_cover on the stream it runs on
     ctx.set_profiling(0)
 
@@ -174,20 +258,35 @@ def main():
                     if rank == 0:
                         frame.copy_(host)
 
-        wstep(first=True); wrs.finish()
-        for _ in range(max(args.warmup - 1, 0)):
-            wstep()
-        wrs.finish()
+        wsets = [(fb, wrs, frame)]
+        if pipelined:       # the same overlap as the headline: the second framebuffer's context gets the weak scene too
+            wsets.append((sets[1][0], R.ResidentScene(sets[1][0], wsc.vertices, wsc.faces, indexed_textures=wsc.indexed_textures), sets[1][2]))
+            for i in range(2 + 2 * max(args.warmup - 1, 0)):
+                pstep(i, wsets, wsc, first=(i < 2))
+            pdrain()
+            wsets[0][1].finish(); wsets[1][1].finish()
+        else:
+            wstep(first=True); wrs.finish()
+            for _ in range(max(args.warmup - 1, 0)):
+                wstep()
+            wrs.finish()
         sync_all()
         w0 = time.perf_counter()
-        for _ in range(args.steps):
-            wstep()
+        if pipelined:
+            for i in range(args.steps):
+                pstep(i, wsets, wsc)
+            pdrain()
+        else:
+            for _ in range(args.steps):
+                wstep()
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize(dev)
         w1 = time.perf_counter()
         wrs.finish()
+        if pipelined:
+            wsets[1][1].finish()
         wel = torch.tensor([w1 - w0], dtype=torch.float64, device=rdev)
         if world > 1:
             dist.all_reduce(wel, op=dist.ReduceOp.MAX)
@@ -277,7 +376,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.config}: {NF} tris @ {W}x{H}, 256x256 8-bit atlas, affine+snap+RGB555 dither, painter's",
                        "triangles_drawn": tm.triangles_drawn, "fragments": fragments,
-                       "parallelism": f"screen bands x{world}" if world > 1 else "single GPU"},
+                       "parallelism": (f"screen bands x{world}, RCCL gather " + ("overlapped with the next frame (two framebuffers)" if pipelined else "after every frame")) if world > 1 else "single GPU"},
             "phases_ms": {k: round(v, 4) for k, v in phases.items()},
             "roofline": roofline,
             "cpu_baseline": cpu,

@@ -48,3 +48,25 @@ def gather_bands(frame: torch.Tensor, width, height, world_size, rank, dst=0, gr
             if r != dst:
                 frame[b[0] * row:b[1] * row] = out[r][:sizes[r]]
     return frame
+
+
+def gather_bands_async(frame: torch.Tensor, width, height, world_size, rank, dst=0, group=None):
+    """Non-blocking form of gather_bands for equal bands: returns (work, keepalive) -- `work.wait()` makes the current stream (or the
+    host, for CPU tensors) wait for the gather; `keepalive` must be held until then.  Returns None when there is nothing to do, and
+    raises ValueError for ragged bands (use gather_bands).  The collective starts after everything already enqueued on the current
+    stream, so a frame rendered on that stream is complete before its rows travel; the NEXT frame, rendered into another buffer, overlaps
+    with the transfer."""
+    if world_size == 1:
+        return None
+    row = width * 4
+    bands = [band_rows(height, world_size, r) for r in range(world_size)]
+    if len({(b[1] - b[0]) for b in bands}) != 1:
+        raise ValueError("gather_bands_async needs equal bands")
+    y0, y1 = bands[rank]
+    mine = frame[y0 * row:y1 * row]
+    out = None
+    if rank == dst:
+        out = [frame[b[0] * row:b[1] * row] for b in bands]
+        out[dst] = torch.empty_like(mine)          # gather forbids aliasing of input and output: stage dst's own band
+    work = dist.gather(mine, out, dst=dst, group=group, async_op=True)
+    return work, (mine, out)

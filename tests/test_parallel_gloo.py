@@ -31,6 +31,31 @@ def _worker(rank, world, port, height, out_path):
     parallel.gather_bands(frame, sc.width, sc.height, world, rank)
     if rank == 0:
         np.save(out_path, frame.numpy())
+    # ---- the overlapped form bench.py uses at N > 1: frames alternate between two buffers, the gather of one is only waited for when
+    # its buffer is about to be redrawn (two frames later); every assembled frame must equal the single-rank frame
+    W, H = sc.width, sc.height
+    if len({b[1] - b[0] for b in (parallel.band_rows(H, world, r) for r in range(world))}) == 1:
+        bufs = [torch.zeros(W * H * 4, dtype=torch.uint8), torch.zeros(W * H * 4, dtype=torch.uint8)]
+        pending = [None, None]
+
+        def settle(k):
+            if pending[k] is not None:
+                pending[k][0].wait(); pending[k] = None
+                if rank == 0:
+                    assert np.array_equal(bufs[k].numpy(), fb.pixels), "overlapped frame differs"
+        for i in range(5):
+            k = i % 2
+            settle(k)
+            bufs[k].fill_(7 + i)                                   # "clear": stale rows must not survive
+            bufs[k][y0 * row:y1 * row] = torch.from_numpy(fb.pixels[y0 * row:y1 * row].copy())
+            pending[k] = parallel.gather_bands_async(bufs[k], W, H, world, rank)
+        settle(0); settle(1)
+    else:
+        try:
+            parallel.gather_bands_async(torch.zeros(W * H * 4, dtype=torch.uint8), W, H, world, rank)
+            raise AssertionError("ragged bands must be refused")
+        except ValueError:
+            pass
     dist.barrier()
     dist.destroy_process_group()
 
