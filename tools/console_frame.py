@@ -56,9 +56,41 @@ t0 = time.perf_counter()
 for _ in range(N): gpu_frame_resident()
 t_res = (time.perf_counter() - t0) / N
 ok_res = np.array_equal(fb.pixels, ofb.pixels) and np.array_equal(fb.zbuffer.view(np.uint32), ofb.zbuffer.view(np.uint32))
+# runs of consecutive meshes WITHOUT a transparent pass merged into one resident mesh each: in z-buffer mode the result is identical
+# (the depth test is order-independent, ties go to the first face in order exactly like the sequential strict `z < zbuffer`); a mesh
+# with transparent faces must keep its place in the sequence (its blended pixels depend on what was drawn before it)
+def merge(run):
+    nv = 0; V = []; F = []; T = []
+    for sc in run:
+        f = sc.faces.copy(); f["v"] += nv
+        f["texture_id"] = np.where(f["texture_id"] == 0xFFFFFFFF, 0xFFFFFFFF, f["texture_id"] + len(T)).astype(np.uint32)
+        V.append(sc.vertices); F.append(f); T += list(sc.textures); nv += len(sc.vertices)
+    return np.concatenate(V), np.concatenate(F), T
+groups, run = [], []
+for sc in meshes:
+    if sc.name.split(":")[1] == "blend":
+        if run: groups.append(merge(run)); run = []
+        groups.append((sc.vertices, sc.faces, sc.textures))
+    else:
+        run.append(sc)
+if run: groups.append(merge(run))
+gslots = [R.ResidentScene(fb, v, f, t).detach() for v, f, t in groups]
+def gpu_frame_merged(first=False):
+    fb.clear(clear)
+    for rs in gslots:
+        if first: rs.render_async(meshes[0].camera, st, fog)
+        else: rs.render_async()
+    gslots[-1].finish()
+    return fb.pixels
+gpu_frame_merged(True); gpu_frame_merged()
+t0 = time.perf_counter()
+for _ in range(N): gpu_frame_merged()
+t_mrg = (time.perf_counter() - t0) / N
+ok_mrg = np.array_equal(fb.pixels, ofb.pixels) and np.array_equal(fb.zbuffer.view(np.uint32), ofb.zbuffer.view(np.uint32))
 gpu_frame()
 ok = np.array_equal(fb.pixels, ofb.pixels) and np.array_equal(fb.zbuffer.view(np.uint32), ofb.zbuffer.view(np.uint32))
 tris = sum(sc.n_tris for sc in meshes)
 print(f"console frame: {n_meshes} meshes, {tris} triangles, {W}x{H}, game() + point light + fog: CPU oracle {t_cpu*1e3:.2f} ms, "
       f"GPU drop-in calls + frame download {t_gpu*1e3:.3f} ms ({t_cpu/t_gpu:.1f}x), {t_gpu/n_meshes*1e6:.0f} us per mesh, bit-exact: {ok}; "
-      f"rooms resident in scene slots {t_res*1e3:.3f} ms ({t_cpu/t_res:.1f}x), {t_res/n_meshes*1e6:.0f} us per mesh, bit-exact: {ok_res}")
+      f"rooms resident in scene slots {t_res*1e3:.3f} ms ({t_cpu/t_res:.1f}x), {t_res/n_meshes*1e6:.0f} us per mesh, bit-exact: {ok_res}; "
+      f"opaque runs merged ({len(groups)} draws) {t_mrg*1e3:.3f} ms ({t_cpu/t_mrg:.1f}x), bit-exact: {ok_mrg}")
