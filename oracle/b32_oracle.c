@@ -27,6 +27,12 @@
 
 #define EXPORT __attribute__((visibility("default")))
 
+/* Row band of the all-cores CPU baseline (bench.py: N processes, each draws only its own rows of the same frame): triangle rows
+ * outside [g_band_y0, g_band_y1) keep the reference's row-to-row accumulation (w_row += b) but skip their pixels, so the rows that
+ * ARE drawn hold exactly the values of the full-frame walk.  Default: the whole frame. */
+static uint32_t g_band_y0 = 0, g_band_y1 = 0xFFFFFFFFu;
+EXPORT void b32o_set_row_band(uint32_t y0, uint32_t y1) { g_band_y0 = y0; g_band_y1 = y1; }
+
 /* ------------------------------------------------------------------ Rust cast / float helpers */
 static inline int32_t f2i32_sat(float f) {
     if (f != f) return 0;
@@ -475,9 +481,10 @@ static int rasterize_triangle_15(FB* fb, const Surface* s, const B32Texture15* t
     float w0_row = a0 * (start_x - v3_.x) + b0 * (start_y - v3_.y);                              /* :1517 */
     float w1_row = a1 * (start_x - v3_.x) + b1 * (start_y - v3_.y);                              /* :1518 */
 
+    if (max_y <= g_band_y0 || min_y >= g_band_y1) return B32_OK;      /* (all-cores baseline) no row of this triangle is ours */
     for (uint64_t y = min_y; y < max_y; ++y) {                                                   /* :1530 */
         float w0 = w0_row, w1 = w1_row;
-        for (uint64_t x = min_x; x < max_x; ++x) {
+        for (uint64_t x = (y >= g_band_y0 && y < g_band_y1) ? min_x : max_x; x < max_x; ++x) {
             float bc_x = w0 * inv_area;
             float bc_y = w1 * inv_area;
             float bc_z = 1.0f - bc_x - bc_y;
@@ -653,9 +660,10 @@ static int rasterize_triangle8(FB* fb, const Surface* s, const B32Texture* textu
     float start_x = (float)min_x, start_y = (float)min_y;
     float w0_row = a0 * (start_x - v3_.x) + b0 * (start_y - v3_.y);                              /* :1277-1278 */
     float w1_row = a1 * (start_x - v3_.x) + b1 * (start_y - v3_.y);
+    if (max_y <= g_band_y0 || min_y >= g_band_y1) return B32_OK;
     for (uint64_t y = min_y; y < max_y; ++y) {
         float w0 = w0_row, w1 = w1_row;
-        for (uint64_t x = min_x; x < max_x; ++x) {
+        for (uint64_t x = (y >= g_band_y0 && y < g_band_y1) ? min_x : max_x; x < max_x; ++x) {
             float bc_x = w0 * inv_area, bc_y = w1 * inv_area;
             float bc_z = 1.0f - bc_x - bc_y;
             const float ERR = -0.0001f;
@@ -730,7 +738,7 @@ static int rasterize_triangle8(FB* fb, const Surface* s, const B32Texture* textu
 /* ------------------------------------------------------------------ lines of the wireframe phases */
 /* Framebuffer::set_pixel, render.rs:301-310 with Color::new(r,g,b) (blend Opaque -> alpha 255, types.rs:829-832) */
 static inline void set_pixel_rgb(FB* fb, int32_t x, int32_t y, uint8_t r, uint8_t g, uint8_t b) {
-    if ((uint32_t)x < fb->width && (uint32_t)y < fb->height) {
+    if ((uint32_t)x < fb->width && (uint32_t)y < fb->height && (uint32_t)y >= g_band_y0 && (uint32_t)y < g_band_y1) {
         size_t idx = ((size_t)y * fb->width + (size_t)x) * 4;
         fb->pixels[idx] = r; fb->pixels[idx + 1] = g; fb->pixels[idx + 2] = b; fb->pixels[idx + 3] = 255;
     }

@@ -65,6 +65,7 @@ def lib():
         L.b32o_draw_star_diamond.restype = None
         L.b32o_draw_star_diamond.argtypes = [P, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_float, P]
         L.b32o_acosf.restype = C.c_float; L.b32o_acosf.argtypes = [C.c_float]
+        L.b32o_set_row_band.restype = None; L.b32o_set_row_band.argtypes = [C.c_uint32, C.c_uint32]
         L.b32o_vec3_dot.restype = C.c_float; L.b32o_vec3_dot.argtypes = [P, P]
         L.b32o_vec3_cross.restype = None; L.b32o_vec3_cross.argtypes = [P, P, P]
         _lib = L
@@ -149,3 +150,52 @@ def render_mesh_15(fb: Framebuffer, vertices, faces, textures, camera: T.Camera,
         return rc, t, {"sx": sx[:len(vertices)], "sy": sy[:len(vertices)], "sz": sz[:len(vertices)],
                        "draw_order": order[:d.n_drawn].copy(), "n_opaque": int(d.n_opaque)}
     return rc, t
+
+
+# ---------------------------------------------------------------- all-cores CPU baseline (bench.py)
+_pool_scene = None
+
+
+def _band_worker(args):
+    """One process of the all-cores baseline: draws the rows [y0, y1) of the shared scene into a private framebuffer."""
+    y0, y1, reps = args
+    sc = _pool_scene
+    L = lib()
+    fb = Framebuffer(sc.width, sc.height)
+    L.b32o_set_row_band(y0, y1)
+    import time
+    t = 0.0
+    for _ in range(reps):
+        fb.clear(sc.clear_color)
+        c0 = time.perf_counter()
+        rc, tm = render_mesh_15(fb, sc.vertices, sc.faces, sc.textures, sc.camera, sc.settings, sc.fog)
+        t += time.perf_counter() - c0
+    L.b32o_set_row_band(0, 0xFFFFFFFF)
+    row = sc.width * 4
+    return y0, y1, t / reps, rc, fb.pixels[y0 * row:y1 * row].copy()
+
+
+def render_all_cores(sc, n_procs, reps=1):
+    """The same frame drawn by n_procs processes, one row band each (transform, cull and sort replicated in every process -- the
+    reference rasterizer is single-threaded, this is the row-band-parallel "fair CPU" variant of SURVEY 8d).  Returns
+    (seconds per frame = the slowest band, assembled RGBA bytes).  Processes are forked: the scene is inherited, not pickled."""
+    import multiprocessing as mp
+    global _pool_scene
+    _pool_scene = sc
+    lib()
+    bands = []
+    base, extra = divmod(sc.height, n_procs)
+    y = 0
+    for r in range(n_procs):
+        h = base + (1 if r < extra else 0)
+        bands.append((y, y + h, reps)); y += h
+    with mp.get_context("fork").Pool(n_procs) as pool:
+        res = pool.map(_band_worker, bands, chunksize=1)
+    frame = np.zeros(sc.width * sc.height * 4, np.uint8)
+    row = sc.width * 4
+    worst = 0.0
+    for y0, y1, t, rc, px in res:
+        assert rc == 0
+        frame[y0 * row:y1 * row] = px
+        worst = max(worst, t)
+    return worst, frame

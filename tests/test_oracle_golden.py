@@ -171,3 +171,14 @@ def test_two_restatements_agree_on_hostile_geometry(oracle, seed):
         if st.use_zbuffer:
             assert np.array_equal(zb.view(np.uint32), fb.zbuffer.view(np.uint32))
         assert np.array_equal(r["draw_order"], d["draw_order"]) and r["triangles_drawn"] == tm.triangles_drawn and r["fragments"] == tm.fragments
+
+
+@pytest.mark.parametrize("name", ["C1", "C1:float", "C1:blend", "C1:zbuf-gouraud", "C1:wire-painter"])
+def test_all_cores_baseline_draws_the_same_frame(oracle, name):
+    """bench.py's all-cores CPU baseline: every process draws one row band of the frame (oracle.render_all_cores, b32o_set_row_band).
+    Skipped rows keep the reference's row-to-row accumulation, so the assembled frame equals the single-core frame -- also under
+    float projection, where the edge values are not integers and a restart per band would round differently."""
+    sc = SCENES[name]()
+    fb, tm, d = render(sc)
+    t, frame = oracle.render_all_cores(sc, 3, reps=1)
+    assert np.array_equal(frame, fb.pixels)
