@@ -463,7 +463,7 @@ static int upload_geometry(b32_ctx* c, const B32Vertex* v, uint32_t nv, const B3
 static size_t cheap_den() { static const size_t d = getenv("B32_CHEAP_DEN") ? (size_t)atoi(getenv("B32_CHEAP_DEN")) : 32; return d ? d : 32; }
 
 static int layout_textures(b32_ctx* c, uint32_t nt, const uint32_t* w, const uint32_t* h, const uint32_t* blend, size_t* total, bool rgba = false) {
-    if (nt > 4094) return B32_E_UNSUPPORTED;
+    if (nt > 65534) return B32_E_UNSUPPORTED;        // the surface record holds the texture slot in 16 bits
     c->h_tex.resize(nt);
     size_t off = 0;
     for (uint32_t i = 0; i < nt; ++i) {

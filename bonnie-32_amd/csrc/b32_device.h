@@ -34,14 +34,14 @@ struct __attribute__((aligned(16))) SurfRec {
 static_assert(sizeof(SurfRec) == 96, "SurfRec layout");
 
 // SurfRec.flags
-constexpr uint32_t F_TEX_MASK   = 0xFFFu;      // texture slot, 0xFFF = untextured (Color15::WHITE, render.rs:1585)
-constexpr uint32_t F_TEX_NONE   = 0xFFFu;
-constexpr uint32_t F_BLACK_TR   = 1u << 12;    // face.black_transparent
-constexpr uint32_t F_BLEND_SHIFT = 13;         // 3 bits: effective blend mode (texture's if bound, render.rs:1450-1452)
-constexpr uint32_t F_DITHER     = 1u << 16;    // needs_dither, render.rs:1487-1492
-constexpr uint32_t F_SLOW       = 1u << 17;    // replay the incremental edge walk literally
-constexpr uint32_t F_TRANSP     = 1u << 18;    // has_transparency, render.rs:2403-2415
-constexpr uint32_t F_EMPTY      = 1u << 19;    // bbox empty or |area| < 1e-5: counted in triangles_drawn, draws nothing
+constexpr uint32_t F_TEX_MASK   = 0xFFFFu;     // texture slot, 0xFFFF = untextured (Color15::WHITE, render.rs:1585): up to 65534 textures per call
+constexpr uint32_t F_TEX_NONE   = 0xFFFFu;
+constexpr uint32_t F_BLACK_TR   = 1u << 16;    // face.black_transparent
+constexpr uint32_t F_BLEND_SHIFT = 17;         // 3 bits: effective blend mode (texture's if bound, render.rs:1450-1452)
+constexpr uint32_t F_DITHER     = 1u << 20;    // needs_dither, render.rs:1487-1492
+constexpr uint32_t F_SLOW       = 1u << 21;    // replay the incremental edge walk literally
+constexpr uint32_t F_TRANSP     = 1u << 22;    // has_transparency, render.rs:2403-2415
+constexpr uint32_t F_EMPTY      = 1u << 23;    // bbox empty or |area| < 1e-5: counted in triangles_drawn, draws nothing
 constexpr uint32_t F_ALPHA_SHIFT = 24;         // editor_alpha
 
 struct TexDesc { uint32_t width, height, blend_mode, offset; };   // offset into the pooled u16 texel buffer

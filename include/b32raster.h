@@ -29,7 +29,7 @@ extern "C" {
 #define B32_E_INDEX       -2  /* face.v* >= nv            [index panic, render.rs:2375-2377] */
 #define B32_E_NAN_KEY     -3  /* NaN painter's key        [unwrap panic, render.rs:2531]     */
 #define B32_E_HIP         -4  /* HIP runtime failure (b32_last_hip_error has the code)      */
-#define B32_E_UNSUPPORTED -5  /* wireframe edge >= 2^30 px (i32 overflow in the reference); more than 4094 textures */
+#define B32_E_UNSUPPORTED -5  /* wireframe edge >= 2^30 px (i32 overflow in the reference); more than 65534 textures */
 #define B32_E_NO_DEVICE   -6  /* no gfx950 device / kernels missing: the product path never falls back to CPU   */
 
 /* ---- enums mirrored as integers ------------------------------------------ */

@@ -246,6 +246,37 @@ def test_bounding_box_is_part_of_the_inside_test(gpu_ctx, oracle):
             gpu_ctx.set_fragment_counting(1)
 
 
+def test_thousands_of_textures(gpu_ctx, oracle):
+    """One texture per face, 6 000 of them (the surface record keeps the slot in 16 bits: up to 65 534 textures per call), a few with a
+    texture blend mode, sizes 1x1 .. 8x5, plus ids past the end of the list (drawn untextured, like `textures.get(id)`)."""
+    n = 6000
+    sc = scenegen.make_scene("C1", n_tris=n, seed=77, bbox_px=120.0)
+    rng = np.random.default_rng(77)
+    texs = []
+    for i in range(n):
+        w, h = int(rng.integers(1, 9)), int(rng.integers(1, 6))
+        px = rng.integers(0, 0x10000, w * h).astype(np.uint16)
+        texs.append(b32.Texture15(w, h, px, int(b32.abi.ADD) if i % 97 == 0 else int(b32.abi.OPAQUE)))
+    sc.textures = texs
+    sc.faces["texture_id"] = np.arange(n, dtype=np.uint32)
+    sc.faces["texture_id"][::211] = n + 5                          # out of range: untextured
+    want, etm, _ = cpu_render(oracle, sc)
+    try:
+        for counting in (1, 0):
+            gpu_ctx.set_fragment_counting(counting)
+            for resident in (False, True):
+                got, tm = gpu_render(gpu_ctx, sc, resident=resident)
+                assert np.array_equal(got, want), (counting, resident, int((got != want).sum()))
+                assert tm.triangles_drawn == etm.triangles_drawn
+    finally:
+        gpu_ctx.set_fragment_counting(1)
+    from bonnie32_amd import rasterizer as R
+    fb = R.Framebuffer(sc.width, sc.height, gpu_ctx)
+    with pytest.raises(R.B32Error) as e:                           # 65 535 and more: refused, nothing drawn
+        R.render_mesh_15(fb, sc.vertices[:3], sc.faces[:1], [texs[0]] * 65535, sc.camera, sc.settings)
+    assert e.value.code == b32.abi.B32_E_UNSUPPORTED
+
+
 def test_c1_against_committed_frame(gpu_ctx):
     z = np.load(os.path.join(GOLD, "c1_frame.npz"))
     got, tm = gpu_render(gpu_ctx, SCENES["C1"]())
