@@ -33,7 +33,8 @@
                                  // column fall into different LDS banks (measured: 72 -> 133 us, 66 -> 128 us; must stay <= 72, the allocation)
 #endif
 #ifndef B32_GRAB_DIV
-#define B32_GRAB_DIV 1          // list entries per grab ~ n / (B32_GRAB_DIV * waves); 1 measured best (130 us vs 134 at 3)
+#define B32_GRAB_DIV 2          // list entries per grab ~ n / (B32_GRAB_DIV * waves).  Re-measured with the final kernel: C3 121 us at 1 and 2,
+                                // 126 at 3, 130 at 4; C5 (710 entries per tile) 290 us at 1, 257 at 2, 260 at 3, 262 at 4
 #endif
 
 namespace b32 {
