@@ -204,9 +204,15 @@ __global__ __launch_bounds__(256) void k_count_spans(uint32_t nf, uint32_t ntile
     for (uint32_t t = threadIdx.x; t < nrows; t += 256) hist[t] = 0;
     __syncthreads();
     const uint32_t f0 = blockIdx.x * SPAN_BLOCK;
-    for (uint32_t i = threadIdx.x; i < SPAN_BLOCK; i += 256) {
-        const uint32_t f = f0 + i;
-        const uint32_t span = f < nf ? spans[f] : 0xFFFFFFFFu;
+    // all of the thread's spans are requested before the first is used: one memory latency per workgroup instead of one per face
+    constexpr int PER_T = SPAN_BLOCK / 256;
+    uint32_t sp[PER_T];
+#pragma unroll
+    for (int k = 0; k < PER_T; ++k) { const uint32_t f = f0 + threadIdx.x + (uint32_t)k * 256u; sp[k] = f < nf ? spans[f] : 0xFFFFFFFFu; }
+#pragma unroll
+    for (int k = 0; k < PER_T; ++k) {
+        const uint32_t f = f0 + threadIdx.x + (uint32_t)k * 256u;
+        const uint32_t span = sp[k];
         if (span == 0xFFFFFFFFu) continue;
         const uint32_t row0 = (keys && (keys[f] >> 31)) ? ntiles : 0u;
         const uint32_t tx0 = span & 0xFF, tx1 = (span >> 8) & 0xFF, ty0 = (span >> 16) & 0xFF, ty1 = span >> 24;
@@ -265,9 +271,14 @@ __global__ __launch_bounds__(256) void k_place_spans(uint32_t nf, uint32_t ntile
     }
     if (total > pair_cap || longest_tr > blend_cap || ctrl->abort) return;
     const uint32_t f0 = blockIdx.x * SPAN_BLOCK;
-    for (uint32_t i = threadIdx.x; i < SPAN_BLOCK; i += 256) {
-        const uint32_t f = f0 + i;
-        const uint32_t span = f < nf ? spans[f] : 0xFFFFFFFFu;
+    constexpr int PER_T = SPAN_BLOCK / 256;
+    uint32_t sp[PER_T];
+#pragma unroll
+    for (int k = 0; k < PER_T; ++k) { const uint32_t f = f0 + threadIdx.x + (uint32_t)k * 256u; sp[k] = f < nf ? spans[f] : 0xFFFFFFFFu; }
+#pragma unroll
+    for (int k = 0; k < PER_T; ++k) {
+        const uint32_t f = f0 + threadIdx.x + (uint32_t)k * 256u;
+        const uint32_t span = sp[k];
         if (span == 0xFFFFFFFFu) continue;
         const uint32_t row0 = (keys && (keys[f] >> 31)) ? ntiles : 0u;
         const uint32_t tx0 = span & 0xFF, tx1 = (span >> 8) & 0xFF, ty0 = (span >> 16) & 0xFF, ty1 = span >> 24;
