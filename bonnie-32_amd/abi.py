@@ -118,6 +118,7 @@ SYMBOLS = [
     ("b32_last_draw_order", C.c_int, [_P, _P, C.c_uint32, C.POINTER(C.c_uint32)]),
     ("b32_selftest_f32", C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_uint32]),
     ("b32_last_kernel_times", C.c_int, [_P, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_uint32]),
+    ("b32_device_constants", C.c_int, [_P, C.POINTER(C.c_char_p), _P, _P, C.c_uint32, C.POINTER(C.c_uint32), _P, _P]),
     ("b32_set_profiling", C.c_int, [_P, C.c_int]),
     ("b32_set_fragment_counting", C.c_int, [_P, C.c_int]),
 ]

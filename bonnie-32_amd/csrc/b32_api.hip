@@ -1091,6 +1091,40 @@ int b32_selftest_f32(b32_ctx* c, int op, const float* a, const float* b, const f
     return B32_OK;
 }
 
+int b32_device_constants(b32_ctx* c, const char** names, uint32_t* bits, uint8_t* is_f32, uint32_t cap, uint32_t* count,
+                         uint8_t* unr_table257, int32_t* dither16) {
+    if (!c) return B32_E_ARG;
+    (void)hipSetDevice(c->device);
+    struct Entry { const char* name; uint8_t f; };
+#define B32_K_F 1
+#define B32_K_I 0
+#define B32_K_ENTRY(name, kind, v) { name, B32_K_##kind },
+    static const Entry kEntries[] = { B32_CONSTANTS(B32_K_ENTRY) };
+#undef B32_K_ENTRY
+#undef B32_K_F
+#undef B32_K_I
+    constexpr uint32_t N = sizeof(kEntries) / sizeof(kEntries[0]);
+    if (count) *count = N;
+    uint32_t* d_bits = nullptr; uint8_t* d_unr = nullptr; int32_t* d_dither = nullptr;
+    Scratch tmp(c);
+    int rc;
+    if ((rc = tmp.alloc(&d_bits, (size_t)N))) return rc;
+    if ((rc = tmp.alloc(&d_unr, (size_t)K::UNR_ENTRIES))) return rc;
+    if ((rc = tmp.alloc(&d_dither, (size_t)16))) return rc;
+    launch_constants(c->stream, d_bits, d_unr, d_dither);
+    std::vector<uint32_t> h(N);
+    HIPCHK(c, hipMemcpyAsync(h.data(), d_bits, N * 4, hipMemcpyDeviceToHost, c->stream));
+    if (unr_table257) HIPCHK(c, hipMemcpyAsync(unr_table257, d_unr, K::UNR_ENTRIES, hipMemcpyDeviceToHost, c->stream));
+    if (dither16) HIPCHK(c, hipMemcpyAsync(dither16, d_dither, 16 * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (uint32_t i = 0; i < N && i < cap; ++i) {
+        if (names) names[i] = kEntries[i].name;
+        if (bits) bits[i] = h[i];
+        if (is_f32) is_f32[i] = kEntries[i].f;
+    }
+    return B32_OK;
+}
+
 int b32_last_kernel_times(b32_ctx* c, const char** names, float* ms, uint32_t cap) {
     if (!c || !names || !ms) return 0;
     static const char* const kNames[5] = { "setup", "sort", "bin", "cover", "shade" };

@@ -18,6 +18,63 @@ constexpr int FILL_THREADS = 1024;  // 16 waves: 4 per SIMD
 constexpr int FILL_WAVES = FILL_THREADS / 64;
 constexpr uint32_t KEY_INVALID = 0xFFFFFFFFu;
 
+// ---------------------------------------------------------------- the reference's numeric literals, by name
+// Device code uses the algorithm's literals only through these names.  b32_device_constants() reads them back FROM DEVICE CODE
+// (k_constants in b32_setup.hip, with the UNR table and the dither matrix as the kernels see them) and
+// tests/test_gpu_parity.py::test_device_constants_are_the_reference_text compares every one with tests/golden/ref_constants.json,
+// which tests/golden/pin_constants.py derives from the reference's own text.  B32_CONSTANTS gives the fixture key of each.
+namespace K {
+constexpr int      FRAC_BITS = 12;                       // fixed.rs:110
+constexpr float    ONE_F = (float)(1 << FRAC_BITS);      // ONE_32 as f32, fixed.rs:111,126
+constexpr uint32_t UNR_ENTRIES = 257, UNR_INDEX_OFFSET = 256, UNR_NUMERATOR = 262144, UNR_ROUND_ADD = 1, UNR_ROUND_DIV = 2;   // fixed.rs:20-31
+constexpr int32_t  UNR_SUBTRACT = 257;
+constexpr uint32_t DIV_D16_SHIFT = 16, DIV_INDEX_SHIFT = 7, DIV_INDEX_MAX = 256, DIV_NR1_SHIFT = 8, DIV_NR2_SHIFT = 8, DIV_SHIFT_BASE = 36;   // fixed.rs:197-212
+constexpr uint64_t DIV_INDEX_BIAS = 0x7FC0, DIV_U_ADD = 0x101, DIV_NR1_CONST = 0x2000080, DIV_NR2_CONST = 0x80;
+constexpr float    PF_DISTANCE = 5.0f, PF_SCALE = 4.0f, PF_VIEWPORT_DIV = 2.0f, PF_VIEWPORT_FRAC = 0.75f;    // project_to_screen, fixed.rs:396-398
+constexpr int32_t  PF_DENOM_GUARD = 256;                 // fixed.rs:406
+constexpr float    P_DISTANCE = 5.0f, P_US_SUB = 1.0f, P_VIEWPORT_DIV = 2.0f, P_VIEWPORT_FRAC = 0.75f, P_DENOM_GUARD = 0.001f;   // project, math.rs:118-127
+constexpr float    NEAR_PLANE = 0.1f;                    // math.rs:155
+constexpr float    MESH_DISTANCE = 5.0f;                 // render.rs:2344
+constexpr float    AREA_EPS = 0.00001f, ERR = -0.0001f;  // render.rs:1501, 1541 (8-bit fill: 1258, 1302)
+constexpr uint32_t MOD_DIV = 128, MOD_MAX = 255;         // render.rs:1624
+constexpr float    SHADE_LO = 0.0f, SHADE_HI = 2.0f, SHADE_MAX = 255.0f;   // render.rs:1643
+constexpr int      DITHER_SHIFT = 3, DITHER_LO = 0, DITHER_HI = 31, NODITHER_SHIFT = 3;   // render.rs:1177, 1653
+constexpr int      DITHER8_EXPAND_SHIFT = 3;             // apply_dither, render.rs:1196
+constexpr uint32_t EXPAND5_SHL = 3, EXPAND5_SHR = 2;     // render.rs:1162
+constexpr int      BLEND_IN_SHIFT = 3, BLEND_AVG_DIV = 2, BLEND_HI = 31, BLEND_LO = 0, BLEND_QUARTER_DIV = 4, BLEND_OUT_SHIFT = 3;   // render.rs:1095-1144
+constexpr float    LIGHT_MIN_DIST = 0.001f, LIGHT_COLOR_DIV = 255.0f, LIGHT_TOTAL_MAX = 1.0f;   // render.rs:1030, 1062, 1070
+constexpr uint32_t C15_TRANSPARENT = 0x0000, C15_BLACK_DRAWABLE = 0x8000, C15_WHITE = 0x7FFF, C15_SEMI_BIT = 0x8000;   // types.rs:24-53
+constexpr uint32_t C15_R_SHIFT = 10, C15_G_SHIFT = 5, C15_CHANNEL_MAX = 31;                                             // types.rs:42-43
+}  // namespace K
+// X(fixture key, F = f32 / I = integer, value)
+#define B32_CONSTANTS(X)                                                                                                              \
+    X("fixed.frac_bits", I, K::FRAC_BITS)                                                                                             \
+    X("unr.entries", I, K::UNR_ENTRIES) X("unr.index_offset", I, K::UNR_INDEX_OFFSET) X("unr.numerator", I, K::UNR_NUMERATOR)         \
+    X("unr.round_add", I, K::UNR_ROUND_ADD) X("unr.round_div", I, K::UNR_ROUND_DIV) X("unr.subtract", I, K::UNR_SUBTRACT)             \
+    X("div_unr.d16_shift", I, K::DIV_D16_SHIFT) X("div_unr.index_bias", I, K::DIV_INDEX_BIAS) X("div_unr.index_shift", I, K::DIV_INDEX_SHIFT) \
+    X("div_unr.index_max", I, K::DIV_INDEX_MAX) X("div_unr.u_add", I, K::DIV_U_ADD) X("div_unr.nr1_const", I, K::DIV_NR1_CONST)       \
+    X("div_unr.nr1_shift", I, K::DIV_NR1_SHIFT) X("div_unr.nr2_const", I, K::DIV_NR2_CONST) X("div_unr.nr2_shift", I, K::DIV_NR2_SHIFT) \
+    X("div_unr.shift_base", I, K::DIV_SHIFT_BASE)                                                                                     \
+    X("project_fixed.distance", F, K::PF_DISTANCE) X("project_fixed.scale", F, K::PF_SCALE)                                           \
+    X("project_fixed.viewport_div", F, K::PF_VIEWPORT_DIV) X("project_fixed.viewport_frac", F, K::PF_VIEWPORT_FRAC)                   \
+    X("project_fixed.denom_guard", I, K::PF_DENOM_GUARD)                                                                              \
+    X("project.distance", F, K::P_DISTANCE) X("project.us_sub", F, K::P_US_SUB) X("project.viewport_div", F, K::P_VIEWPORT_DIV)       \
+    X("project.viewport_frac", F, K::P_VIEWPORT_FRAC) X("project.denom_guard", F, K::P_DENOM_GUARD)                                   \
+    X("near_plane", F, K::NEAR_PLANE) X("mesh.distance", F, K::MESH_DISTANCE)                                                         \
+    X("fill.area_eps", F, K::AREA_EPS) X("fill.err", F, K::ERR) X("fill8.area_eps", F, K::AREA_EPS) X("fill8.err", F, K::ERR)         \
+    X("fill.modulate_div", I, K::MOD_DIV) X("fill.modulate_max", I, K::MOD_MAX)                                                       \
+    X("fill.shade_clamp_lo", F, K::SHADE_LO) X("fill.shade_clamp_hi", F, K::SHADE_HI) X("fill.shade_max", F, K::SHADE_MAX)            \
+    X("fill.nodither_shift", I, K::NODITHER_SHIFT)                                                                                    \
+    X("dither.shift", I, K::DITHER_SHIFT) X("dither.clamp_lo", I, K::DITHER_LO) X("dither.clamp_hi", I, K::DITHER_HI)                 \
+    X("dither8.shift", I, K::DITHER_SHIFT) X("dither8.clamp_hi", I, K::DITHER_HI) X("dither8.expand_shift", I, K::DITHER8_EXPAND_SHIFT) \
+    X("expand5.shl", I, K::EXPAND5_SHL) X("expand5.shr", I, K::EXPAND5_SHR)                                                           \
+    X("blend555.in_shift", I, K::BLEND_IN_SHIFT) X("blend555.average_div", I, K::BLEND_AVG_DIV) X("blend555.clamp_hi", I, K::BLEND_HI) \
+    X("blend555.clamp_lo", I, K::BLEND_LO) X("blend555.quarter_div", I, K::BLEND_QUARTER_DIV) X("blend555.out_shift", I, K::BLEND_OUT_SHIFT) \
+    X("light.min_dist", F, K::LIGHT_MIN_DIST) X("light.color_div", F, K::LIGHT_COLOR_DIV) X("light.total_max", F, K::LIGHT_TOTAL_MAX) \
+    X("color15.transparent", I, K::C15_TRANSPARENT) X("color15.black_drawable", I, K::C15_BLACK_DRAWABLE) X("color15.white", I, K::C15_WHITE) \
+    X("color15.semi_bit", I, K::C15_SEMI_BIT) X("color15.r_shift", I, K::C15_R_SHIFT) X("color15.g_shift", I, K::C15_G_SHIFT)         \
+    X("color15.channel_max", I, K::C15_CHANNEL_MAX)
+
 // ---------------------------------------------------------------- per-surface record written by k_setup (96 B = 6 x 16 B)
 // Edge coefficients follow rasterize_triangle_15 (render.rs:1500-1518) and are computed once per face with the
 // reference's f32 expression order; the fill evaluates w0/w1 in closed form only when `F_SLOW` is clear, i.e. when
@@ -75,7 +132,7 @@ struct CamFx {
     int32_t vs, half_w, half_h;
 };
 __host__ __device__ inline int32_t fx_from_f32_any(float f) {                 // Fixed32::from_f32, fixed.rs:125-127
-    const float p = f * 4096.0f;
+    const float p = f * K::ONE_F;
     if (p != p) return 0;
     if (p >= 2147483648.0f) return INT32_MAX;
     if (p <= -2147483648.0f) return INT32_MIN;
@@ -86,9 +143,9 @@ __host__ __device__ inline CamFx make_camfx_any(const B32Camera& c, uint32_t wid
     k.px = fx_from_f32_any(c.position[0]); k.py = fx_from_f32_any(c.position[1]); k.pz = fx_from_f32_any(c.position[2]);
     for (int i = 0; i < 3; ++i) { k.bx[i] = fx_from_f32_any(c.basis_x[i]); k.by[i] = fx_from_f32_any(c.basis_y[i]); k.bz[i] = fx_from_f32_any(c.basis_z[i]); }
     const uint32_t mn = width < height ? width : height;
-    k.vs = fx_from_f32_any(((float)mn / 2.0f) * 0.75f);                       // fixed.rs:398
-    k.half_w = (int32_t)((uint32_t)((int32_t)width / 2) << 12);               // fixed.rs:399-400
-    k.half_h = (int32_t)((uint32_t)((int32_t)height / 2) << 12);
+    k.vs = fx_from_f32_any(((float)mn / K::PF_VIEWPORT_DIV) * K::PF_VIEWPORT_FRAC);      // fixed.rs:398
+    k.half_w = (int32_t)((uint32_t)((int32_t)width / 2) << K::FRAC_BITS);               // fixed.rs:399-400
+    k.half_h = (int32_t)((uint32_t)((int32_t)height / 2) << K::FRAC_BITS);
     return k;
 }
 
@@ -150,11 +207,12 @@ __device__ __forceinline__ uint32_t zsort_key(float z) { const uint32_t b = z ==
 __device__ __forceinline__ float zsort_val(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k); }
 
 // ---------------------------------------------------------------- colour helpers
-__device__ __forceinline__ uint32_t expand5(uint32_t v5) { return ((v5 << 3) | (v5 >> 2)) & 0xFF; }   // render.rs:1161-1163
+__device__ __forceinline__ uint32_t expand5(uint32_t v5) { return ((v5 << K::EXPAND5_SHL) | (v5 >> K::EXPAND5_SHR)) & 0xFF; }   // render.rs:1161-1163
 // Color15::to_rgba (types.rs:220-226) as a little-endian RGBA8 word
 __device__ __forceinline__ uint32_t c15_to_rgba(uint32_t c) {
-    if ((c & 0xFFFF) == 0) return 0;
-    return expand5((c >> 10) & 31) | (expand5((c >> 5) & 31) << 8) | (expand5(c & 31) << 16) | 0xFF000000u;
+    if ((c & 0xFFFF) == K::C15_TRANSPARENT) return 0;
+    return expand5((c >> K::C15_R_SHIFT) & K::C15_CHANNEL_MAX) | (expand5((c >> K::C15_G_SHIFT) & K::C15_CHANNEL_MAX) << 8) |
+           (expand5(c & K::C15_CHANNEL_MAX) << 16) | 0xFF000000u;
 }
 // PS1_DITHER_MATRIX (render.rs:1150-1155) packed as 16 signed nibbles, index = (y&3)*4 + (x&3)
 __device__ __forceinline__ int dither_offset(uint32_t x, uint32_t y) {
@@ -169,19 +227,19 @@ __device__ __forceinline__ uint32_t blend_rgb555(uint32_t front, uint32_t back, 
     uint32_t out = 0;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        int f5 = (int)((front >> (8 * i + 3)) & 31);
-        int b5 = (int)((back >> (8 * i + 3)) & 31);
+        int f5 = (int)(((front >> (8 * i)) & 255) >> K::BLEND_IN_SHIFT);
+        int b5 = (int)(((back >> (8 * i)) & 255) >> K::BLEND_IN_SHIFT);
         int r5;
         switch (mode) {
             default:
             case B32_BLEND_OPAQUE:      r5 = f5; break;
-            case B32_BLEND_AVERAGE:     r5 = min((b5 + f5) / 2, 31); break;
-            case B32_BLEND_ADD:         r5 = min(b5 + f5, 31); break;
-            case B32_BLEND_SUBTRACT:    r5 = max(b5 - f5, 0); break;
-            case B32_BLEND_ADD_QUARTER: r5 = min(b5 + f5 / 4, 31); break;
+            case B32_BLEND_AVERAGE:     r5 = min((b5 + f5) / K::BLEND_AVG_DIV, K::BLEND_HI); break;
+            case B32_BLEND_ADD:         r5 = min(b5 + f5, K::BLEND_HI); break;
+            case B32_BLEND_SUBTRACT:    r5 = max(b5 - f5, K::BLEND_LO); break;
+            case B32_BLEND_ADD_QUARTER: r5 = min(b5 + f5 / K::BLEND_QUARTER_DIV, K::BLEND_HI); break;
             case B32_BLEND_ERASE:       r5 = b5; break;
         }
-        out |= (uint32_t)(r5 << 3) << (8 * i);
+        out |= (uint32_t)(r5 << K::BLEND_OUT_SHIFT) << (8 * i);
     }
     return out;
 }
@@ -228,6 +286,9 @@ void launch_setup(hipStream_t s, const FrameParams& fp, const B32Vertex* verts, 
 void launch_project_fixed(hipStream_t s, const float* pos, uint32_t n, B32Camera cam, uint32_t w, uint32_t h,
                           int32_t* sx, int32_t* sy, float* z);
 void launch_selftest(hipStream_t s, int op, const float* a, const float* b, const float* c, float* out, uint32_t n);
+// test tap: constants of B32_CONSTANTS (one word each, f32 bits or the integer), UNR table (257 bytes) and dither offsets (16 words,
+// index (y & 3) * 4 + (x & 3)) as device code holds them
+void launch_constants(hipStream_t s, uint32_t* consts, uint8_t* unr, int32_t* dither);
 void launch_clear(hipStream_t s, uint32_t* fb, size_t n_px, uint32_t rgba);
 // staged upload of a drop-in call: up to 16 segments copied by ONE kernel from a pinned host arena (mapped into the device's address
 // space) to their device buffers -- every SDMA copy costs ~10 us of stream time, one kernel reading over PCIe ~5 us for all of them

@@ -75,7 +75,7 @@ __device__ __forceinline__ bool inside_bc(const Tri& t, float w0, float w1, floa
     bcx = w0 * t.inv_area;                                       // render.rs:1536-1542
     bcy = w1 * t.inv_area;
     bcz = 1.0f - bcx - bcy;
-    const float ERR = -0.0001f;
+    const float ERR = K::ERR;
     // bcx >= ERR && bcy >= ERR && bcz >= ERR with one comparison less.  NaN-safe although fminf drops a NaN operand: a NaN (or an
     // infinity of either sign) in bcx or bcy makes bcz NaN or -inf, and `bcz >= ERR` is then false like the original conjunction.
     return (__builtin_fminf(bcx, bcy) >= ERR) & (bcz >= ERR);
@@ -116,7 +116,7 @@ __device__ __forceinline__ int tri_texel_addr(const Tri& t, float bcx, float bcy
 template <int TEXMODE, bool FMT8 = false>
 __device__ __forceinline__ bool texel_drawn(const Tri& t, float bcx, float bcy, float bcz, const uint16_t* __restrict__ gtex,
                                             const uint16_t* ltex, uint32_t& texel, bool affine = true) {
-    uint32_t c = FMT8 ? 0x00FFFFFFu : 0x7FFFu;                   // Color::WHITE (render.rs:1344) / Color15::WHITE (render.rs:1585)
+    uint32_t c = FMT8 ? 0x00FFFFFFu : K::C15_WHITE;              // Color::WHITE (render.rs:1344) / Color15::WHITE (render.rs:1585)
     if ((t.flags & F_TEX_MASK) != F_TEX_NONE) {
         float u, v;
         if (affine) {
@@ -136,10 +136,10 @@ __device__ __forceinline__ bool texel_drawn(const Tri& t, float bcx, float bcy, 
         texel = c;
         return (c >> 24) != B32_BLEND_ERASE;
     }
-    if (c == 0) {                                                // render.rs:1592-1602
+    if (c == K::C15_TRANSPARENT) {                               // render.rs:1592-1602
         if (t.flags & F_BLACK_TR) return false;
-        c = 0x8000;                                              // BLACK_DRAWABLE
-    } else if ((t.flags & F_BLACK_TR) && (c & 0x7FFF) == 0) {    // render.rs:1603-1608
+        c = K::C15_BLACK_DRAWABLE;
+    } else if ((t.flags & F_BLACK_TR) && (c & ~K::C15_SEMI_BIT & 0xFFFFu) == 0) {    // is_black: r5 == g5 == b5 == 0, render.rs:1603-1608
         return false;
     }
     texel = c;
@@ -153,20 +153,20 @@ __device__ __forceinline__ uint32_t shade15(uint32_t texel, float bcx, float bcy
     const int off = dither_offset(px, py);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        const uint32_t c5 = (texel >> (10 - 5 * i)) & 31;        // i=0 r, 1 g, 2 b
+        const uint32_t c5 = (texel >> (i == 0 ? K::C15_R_SHIFT : (i == 1 ? K::C15_G_SHIFT : 0u))) & K::C15_CHANNEL_MAX;   // i=0 r, 1 g, 2 b
         const uint32_t tex8 = expand5(c5);
         const float f1 = (float)((vc1 >> (8 * i)) & 255), f2 = (float)((vc2 >> (8 * i)) & 255), f3 = (float)((vc3 >> (8 * i)) & 255);
         const uint32_t vert = f2u8_sat(bcx * f1 + bcy * f2 + bcz * f3);              // :1618-1620
-        uint32_t m = min((tex8 * vert) / 128u, 255u);                                 // :1624-1626
+        uint32_t m = min((tex8 * vert) / K::MOD_DIV, K::MOD_MAX);                     // :1624-1626
         if (shading != B32_SHADE_NONE) {                                              // :1629-1645 (x1.0 is exact when None)
             const float s = shading == B32_SHADE_FLAT ? sh[i] : (bcx * sh[i] + bcy * sh[3 + i] + bcz * sh[6 + i]);
-            m = f2u8_sat(rmin((float)m * rclamp(s, 0.0f, 2.0f), 255.0f));
+            m = f2u8_sat(rmin((float)m * rclamp(s, K::SHADE_LO, K::SHADE_HI), K::SHADE_MAX));
         }
-        if (flags & F_DITHER) q[i] = (uint32_t)min(max(((int)m + off) >> 3, 0), 31); // dither_and_quantize :1173-1182
-        else q[i] = m >> 3;                                                           // :1653
+        if (flags & F_DITHER) q[i] = (uint32_t)min(max(((int)m + off) >> K::DITHER_SHIFT, K::DITHER_LO), K::DITHER_HI); // dither_and_quantize :1173-1182
+        else q[i] = m >> K::NODITHER_SHIFT;                                           // :1653
     }
     const bool all_black = (q[0] | q[1] | q[2]) == 0;                                 // :1659-1661
-    return (q[0] << 10) | (q[1] << 5) | q[2] | (((texel & 0x8000) || all_black) ? 0x8000u : 0u);
+    return (q[0] << K::C15_R_SHIFT) | (q[1] << K::C15_G_SHIFT) | q[2] | (((texel & K::C15_SEMI_BIT) || all_black) ? K::C15_SEMI_BIT : 0u);
 }
 
 // Pixel store of the transparent pass in painter's mode (render.rs:1674-1680, 1695-1702) on an RGBA8 word.
@@ -179,7 +179,7 @@ __device__ __forceinline__ uint32_t store_blend(uint32_t back, uint32_t out15, u
         for (int i = 0; i < 3; ++i) o |= ((((front >> (8 * i)) & 255) + ((back >> (8 * i)) & 255)) >> 1) << (8 * i);
         return o;
     }
-    const bool do_blend = (out15 & 0x8000) && mode != B32_BLEND_OPAQUE;
+    const bool do_blend = (out15 & K::C15_SEMI_BIT) && mode != B32_BLEND_OPAQUE;
     if (alpha < 255) {                                           // set_pixel_with_editor_alpha_15, render.rs:567-591
         const uint32_t ps1 = do_blend ? blend_rgb555(front, back, mode) : front;
         uint32_t o = 0xFF000000u;
@@ -205,12 +205,12 @@ __device__ __forceinline__ uint32_t shade8(uint32_t texel, float bcx, float bcy,
         const uint32_t t8 = (texel >> (8 * i)) & 255;
         const float f1 = (float)((vc1 >> (8 * i)) & 255), f2 = (float)((vc2 >> (8 * i)) & 255), f3 = (float)((vc3 >> (8 * i)) & 255);
         const uint32_t vert = f2u8_sat(bcx * f1 + bcy * f2 + bcz * f3);
-        uint32_t m = min((t8 * vert) / 128u, 255u);
+        uint32_t m = min((t8 * vert) / K::MOD_DIV, K::MOD_MAX);
         if (shading != B32_SHADE_NONE) {
             const float s = shading == B32_SHADE_FLAT ? sh[i] : (bcx * sh[i] + bcy * sh[3 + i] + bcz * sh[6 + i]);
-            m = f2u8_sat(rmin((float)m * s, 255.0f));
+            m = f2u8_sat(rmin((float)m * s, K::SHADE_MAX));
         }
-        if (flags & F_DITHER) m = (uint32_t)min(max(((int)m + off) >> 3, 0), 31) << 3;
+        if (flags & F_DITHER) m = (uint32_t)min(max(((int)m + off) >> K::DITHER_SHIFT, K::DITHER_LO), K::DITHER_HI) << K::DITHER8_EXPAND_SHIFT;
         out |= m << (8 * i);
     }
     return out;
@@ -552,7 +552,7 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
                                                            uint32_t ty_top, const uint16_t* ltex) {
     const uint16_t* __restrict__ gtex = FMT8 ? reinterpret_cast<const uint16_t*>(a.texels32) : a.texels;
     unsigned long long frags = 0;
-    const float ERR = -0.0001f;
+    const float ERR = K::ERR;
     const bool affine = a.fp.affine != 0;
     // entries per grab: ~3 grabs per wave for balance, never more than the 64 lanes can hold
     const uint32_t grab = min(64u, max(4u, (n_op + B32_GRAB_DIV * NW - 1) / (B32_GRAB_DIV * NW)));
@@ -1147,11 +1147,11 @@ __device__ __forceinline__ bool hit_finish(uint32_t flags, int taddr, uint32_t f
         texel = c;
         return (c >> 24) != B32_BLEND_ERASE;
     }
-    uint32_t c = taddr == -1 ? 0x7FFFu : (taddr == -2 ? 0u : fetched);
-    if (c == 0) {
+    uint32_t c = taddr == -1 ? K::C15_WHITE : (taddr == -2 ? K::C15_TRANSPARENT : fetched);
+    if (c == K::C15_TRANSPARENT) {
         if (flags & F_BLACK_TR) return false;
-        c = 0x8000;
-    } else if ((flags & F_BLACK_TR) && (c & 0x7FFF) == 0) return false;
+        c = K::C15_BLACK_DRAWABLE;
+    } else if ((flags & F_BLACK_TR) && (c & ~K::C15_SEMI_BIT & 0xFFFFu) == 0) return false;
     texel = c;
     return true;
 }

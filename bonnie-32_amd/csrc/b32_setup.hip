@@ -11,12 +11,12 @@
 namespace b32 {
 
 // ---------------------------------------------------------------- fixed.rs on the device
-struct UnrTable { uint8_t v[257]; };
+struct UnrTable { uint8_t v[K::UNR_ENTRIES]; };
 static constexpr UnrTable make_unr() {          // UNR_TABLE, fixed.rs:20-31
     UnrTable t{};
-    for (uint32_t i = 0; i < 257; ++i) {
-        uint32_t q = 262144u / (i + 256u);
-        int32_t val = (int32_t)((q + 1) / 2) - 257;
+    for (uint32_t i = 0; i < K::UNR_ENTRIES; ++i) {
+        uint32_t q = K::UNR_NUMERATOR / (i + K::UNR_INDEX_OFFSET);
+        int32_t val = (int32_t)((q + K::UNR_ROUND_ADD) / K::UNR_ROUND_DIV) - K::UNR_SUBTRACT;
         t.v[i] = val > 0 ? (uint8_t)val : 0;
     }
     return t;
@@ -25,8 +25,8 @@ __constant__ UnrTable g_unr = make_unr();
 
 __device__ __forceinline__ int32_t wadd(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
 __device__ __forceinline__ int32_t wsub(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
-__device__ __forceinline__ int32_t fx_from_f32(float f) { return f2i32_sat(f * 4096.0f); }           // fixed.rs:125-127
-__device__ __forceinline__ int32_t fx_mul(int32_t a, int32_t b) { return (int32_t)(((int64_t)a * (int64_t)b) >> 12); }  // :161-165
+__device__ __forceinline__ int32_t fx_from_f32(float f) { return f2i32_sat(f * K::ONE_F); }           // fixed.rs:125-127
+__device__ __forceinline__ int32_t fx_mul(int32_t a, int32_t b) { return (int32_t)(((int64_t)a * (int64_t)b) >> K::FRAC_BITS); }  // :161-165
 // Fixed32::div_unr, fixed.rs:178-230, split at the point where only the divisor has been used: project_to_screen divides x and
 // y by the same denominator (fixed.rs:411-412), so the table lookup and both Newton steps are done once per vertex.
 struct UnrRecip { uint64_t nr2; uint32_t shift; bool neg, zero; };
@@ -35,13 +35,13 @@ __device__ __forceinline__ UnrRecip unr_recip(int32_t divisor) {
     r.zero = divisor == 0; r.neg = divisor < 0;
     const uint32_t den = divisor < 0 ? (0u - (uint32_t)divisor) : (uint32_t)divisor;
     const uint32_t z = (uint32_t)__builtin_clz(den | (r.zero ? 1u : 0u));
-    const uint64_t d16 = ((uint64_t)den << z) >> 16;
-    uint64_t ti = (d16 - 0x7FC0ull) >> 7;
-    if (ti > 256) ti = 256;
-    const uint64_t u = (uint64_t)g_unr.v[ti] + 0x101;
-    const uint64_t nr1 = (0x2000080ull - d16 * u) >> 8;
-    r.nr2 = (0x80ull + nr1 * u) >> 8;
-    r.shift = 36u - z;                              // z in 0..31 -> shift in 5..36
+    const uint64_t d16 = ((uint64_t)den << z) >> K::DIV_D16_SHIFT;
+    uint64_t ti = (d16 - K::DIV_INDEX_BIAS) >> K::DIV_INDEX_SHIFT;
+    if (ti > K::DIV_INDEX_MAX) ti = K::DIV_INDEX_MAX;
+    const uint64_t u = (uint64_t)g_unr.v[ti] + K::DIV_U_ADD;
+    const uint64_t nr1 = (K::DIV_NR1_CONST - d16 * u) >> K::DIV_NR1_SHIFT;
+    r.nr2 = (K::DIV_NR2_CONST + nr1 * u) >> K::DIV_NR2_SHIFT;
+    r.shift = K::DIV_SHIFT_BASE - z;                // z in 0..31 -> shift in 5..36
     return r;
 }
 __device__ __forceinline__ int32_t unr_apply(int32_t self, const UnrRecip& r) {
@@ -62,15 +62,15 @@ __device__ __forceinline__ void project_fixed_dev(float x, float y, float z, con
     int32_t cx = wadd(wadd(fx_mul(rx, k.bx[0]), fx_mul(ry, k.bx[1])), fx_mul(rz, k.bx[2]));
     int32_t cy = wadd(wadd(fx_mul(rx, k.by[0]), fx_mul(ry, k.by[1])), fx_mul(rz, k.by[2]));
     int32_t cz = wadd(wadd(fx_mul(rx, k.bz[0]), fx_mul(ry, k.bz[1])), fx_mul(rz, k.bz[2]));
-    const int32_t distance = 20480, scale = 16384;                      // from_f32(5.0), from_f32(4.0)
+    const int32_t distance = fx_from_f32_any(K::PF_DISTANCE), scale = fx_from_f32_any(K::PF_SCALE);   // 20480, 16384 (folded at compile time)
     int32_t denom = wadd(cz, distance);
     int32_t adenom = denom < 0 ? (int32_t)(0u - (uint32_t)denom) : denom;   // i32::abs wraps at MIN in release
-    if (adenom < 256) { sx = k.half_w >> 12; sy = k.half_h >> 12; return; }
+    if (adenom < K::PF_DENOM_GUARD) { sx = k.half_w >> K::FRAC_BITS; sy = k.half_h >> K::FRAC_BITS; return; }
     const UnrRecip rcp = unr_recip(denom);
     int32_t proj_x = unr_apply(fx_mul(cx, scale), rcp);
     int32_t proj_y = unr_apply(fx_mul(cy, scale), rcp);
-    sx = wadd(fx_mul(proj_x, k.vs), k.half_w) >> 12;
-    sy = wadd(fx_mul(proj_y, k.vs), k.half_h) >> 12;
+    sx = wadd(fx_mul(proj_x, k.vs), k.half_w) >> K::FRAC_BITS;
+    sy = wadd(fx_mul(proj_y, k.vs), k.half_h) >> K::FRAC_BITS;
 }
 
 // ---------------------------------------------------------------- math.rs on the device
@@ -132,7 +132,7 @@ __device__ void shade_multi(V3 normal, V3 world_pos, const B32Light* lights, uin
         } else if (l.type == B32_LIGHT_POINT) {
             V3 to_light = sub3(ld3(l.position), world_pos);
             float dist = __builtin_sqrtf(dot3(to_light, to_light));
-            if (dist > l.radius || dist < 0.001f) contribution = 0.0f;
+            if (dist > l.radius || dist < K::LIGHT_MIN_DIST) contribution = 0.0f;
             else {
                 float attenuation = 1.0f - (dist / l.radius);
                 float n_dot_l = rmax(dot3(normal, normalize3(to_light)), 0.0f);
@@ -141,7 +141,7 @@ __device__ void shade_multi(V3 normal, V3 world_pos, const B32Light* lights, uin
         } else {                                       // Spot, render.rs:1038-1058
             V3 to_light = sub3(ld3(l.position), world_pos);
             float dist = __builtin_sqrtf(dot3(to_light, to_light));
-            if (dist > l.radius || dist < 0.001f) contribution = 0.0f;
+            if (dist > l.radius || dist < K::LIGHT_MIN_DIST) contribution = 0.0f;
             else {
                 const V3 to_surface = normalize3(to_light);
                 const float spot_angle = acosf_musl(dot3(scale3(to_surface, -1.0f), ld3(l.direction)));
@@ -154,10 +154,10 @@ __device__ void shade_multi(V3 normal, V3 world_pos, const B32Light* lights, uin
                 }
             }
         }
-        float lr = (float)l.r / 255.0f, lg = (float)l.g / 255.0f, lb = (float)l.b / 255.0f;
+        float lr = (float)l.r / K::LIGHT_COLOR_DIV, lg = (float)l.g / K::LIGHT_COLOR_DIV, lb = (float)l.b / K::LIGHT_COLOR_DIV;
         tr += contribution * lr; tg += contribution * lg; tb += contribution * lb;
     }
-    out[0] = rmin(tr, 1.0f); out[1] = rmin(tg, 1.0f); out[2] = rmin(tb, 1.0f);
+    out[0] = rmin(tr, K::LIGHT_TOTAL_MAX); out[1] = rmin(tg, K::LIGHT_TOTAL_MAX); out[2] = rmin(tb, K::LIGHT_TOTAL_MAX);
 }
 
 // fog, render.rs:2266-2293. Colours are r | g<<8 | b<<16 | blend<<24.
@@ -250,17 +250,18 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp, const B32Vertex* 
                 } else if (fp.fixed_point) {                                     // render.rs:2329-2345
                     int32_t sx, sy;
                     project_fixed_dev(pos.x, pos.y, pos.z, k, sx, sy);
-                    scr[j] = { (float)sx, (float)sy, cp.z + 5.0f };
+                    scr[j] = { (float)sx, (float)sy, cp.z + K::MESH_DISTANCE };
                 } else {                                                         // project, math.rs:117-136
                     uint32_t mn = fp.width < fp.height ? fp.width : fp.height;
-                    float vs = ((float)mn / 2.0f) * 0.75f;
-                    float denom = cp.z + 5.0f;
-                    if (__builtin_fabsf(denom) < 0.001f) scr[j] = { (float)fp.width / 2.0f, (float)fp.height / 2.0f, cp.z };
-                    else scr[j] = { (cp.x * 4.0f) / denom * vs + ((float)fp.width / 2.0f),
-                                    (cp.y * 4.0f) / denom * vs + ((float)fp.height / 2.0f), denom };
+                    const float ud = K::P_DISTANCE, us = ud - K::P_US_SUB;                        // math.rs:121-122 (4.0, folded)
+                    float vs = ((float)mn / K::P_VIEWPORT_DIV) * K::P_VIEWPORT_FRAC;
+                    float denom = cp.z + ud;
+                    if (__builtin_fabsf(denom) < K::P_DENOM_GUARD) scr[j] = { (float)fp.width / 2.0f, (float)fp.height / 2.0f, cp.z };
+                    else scr[j] = { (cp.x * us) / denom * vs + ((float)fp.width / 2.0f),
+                                    (cp.y * us) / denom * vs + ((float)fp.height / 2.0f), denom };
                 }
             }
-            bool keep = fp.ortho || !(camz[0] <= 0.1f || camz[1] <= 0.1f || camz[2] <= 0.1f);   // near plane, render.rs:2381-2385
+            bool keep = fp.ortho || !(camz[0] <= K::NEAR_PLANE || camz[1] <= K::NEAR_PLANE || camz[2] <= K::NEAR_PLANE);   // render.rs:2381-2385
             float signed_area = (scr[1].x - scr[0].x) * (scr[2].y - scr[0].y) - (scr[2].x - scr[0].x) * (scr[1].y - scr[0].y);
             bool backface = signed_area <= 0.0f;                                     // render.rs:2393-2394
             const bool have_tex = tid != B32_NO_TEXTURE && tid < fp.nt;             // textures.get(id)
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp, const B32Vertex* 
                 uint32_t max_y = f2u_sat(rmin(rmax(rmax(v1.y, v2.y), v3.y) + 1.0f, (float)fp.height));
                 bool empty = min_x >= max_x || min_y >= max_y;
                 float area = (v2.y - v3.y) * (v1.x - v3.x) + (v3.x - v2.x) * (v1.y - v3.y);      // :1500
-                if (__builtin_fabsf(area) < 0.00001f) empty = true;                               // :1501-1503
+                if (__builtin_fabsf(area) < K::AREA_EPS) empty = true;                            // :1501-1503
                 if (empty) { min_x = max_x = min_y = max_y = 0; }
                 r.inv_area = 1.0f / area;
                 r.a0 = v2.y - v3.y; r.b0 = v3.x - v2.x; r.a1 = v3.y - v1.y; r.b1 = v1.x - v3.x;   // :1507-1510
@@ -423,12 +424,32 @@ __global__ void k_project_fixed(const float* __restrict__ pos, uint32_t n, B32Ca
     int32_t x, y;
     project_fixed_dev(p.x, p.y, p.z, k, x, y);
     V3 rel = sub3(p, ld3(cam.position));
-    sx[i] = x; sy[i] = y; z[i] = dot3(rel, ld3(cam.basis_z)) + 5.0f;     // render.rs:2343-2345
+    sx[i] = x; sy[i] = y; z[i] = dot3(rel, ld3(cam.basis_z)) + K::MESH_DISTANCE;     // render.rs:2343-2345
 }
 void launch_project_fixed(hipStream_t s, const float* pos, uint32_t n, B32Camera cam, uint32_t w, uint32_t h,
                           int32_t* sx, int32_t* sy, float* z) {
     if (!n) return;
     hipLaunchKernelGGL(k_project_fixed, dim3((n + 255) / 256), dim3(256), 0, s, pos, n, cam, w, h, sx, sy, z);
+}
+
+// ---------------------------------------------------------------- constants tap (see B32_CONSTANTS in b32_device.h)
+__global__ void k_constants(uint32_t* __restrict__ consts, uint8_t* __restrict__ unr, int32_t* __restrict__ dither) {
+    if (blockIdx.x != 0) return;
+    if (threadIdx.x == 0) {
+        uint32_t i = 0;
+#define B32_K_F(v) __float_as_uint((float)(v))
+#define B32_K_I(v) (uint32_t)(v)
+#define B32_K_STORE(name, kind, v) consts[i++] = B32_K_##kind(v);
+        B32_CONSTANTS(B32_K_STORE)
+#undef B32_K_STORE
+#undef B32_K_F
+#undef B32_K_I
+    }
+    for (uint32_t t = threadIdx.x; t < K::UNR_ENTRIES; t += blockDim.x) unr[t] = g_unr.v[t];
+    if (threadIdx.x < 16) dither[threadIdx.x] = dither_offset(threadIdx.x & 3, threadIdx.x >> 2);
+}
+void launch_constants(hipStream_t s, uint32_t* consts, uint8_t* unr, int32_t* dither) {
+    hipLaunchKernelGGL(k_constants, dim3(1), dim3(256), 0, s, consts, unr, dither);
 }
 
 // ---------------------------------------------------------------- f32 semantics self-test

@@ -83,6 +83,20 @@ class Context:
                                               sx.ctypes.data, sy.ctypes.data, z.ctypes.data), "project_fixed_batch")
         return sx, sy, z
 
+    def device_constants(self):
+        """({fixture key: value}, UNR table, 4x4 dither matrix [y & 3][x & 3]) read back from device code (b32_device_constants)."""
+        cap = 256
+        names = (C.c_char_p * cap)()
+        bits = np.zeros(cap, np.uint32); isf = np.zeros(cap, np.uint8)
+        n = C.c_uint32()
+        unr = np.zeros(257, np.uint8); dither = np.zeros(16, np.int32)
+        _chk(self.lib.b32_device_constants(self.h, names, bits.ctypes.data, isf.ctypes.data, cap, C.byref(n), unr.ctypes.data,
+                                           dither.ctypes.data), "b32_device_constants")
+        out = {}
+        for i in range(min(n.value, cap)):
+            out[names[i].decode()] = float(bits[i:i + 1].view(np.float32)[0]) if isf[i] else int(bits[i])
+        return out, unr, dither.reshape(4, 4)
+
     def selftest_f32(self, op, a, b, c):
         a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
         c = np.ascontiguousarray(c, np.float32)

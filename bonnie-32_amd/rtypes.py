@@ -93,7 +93,8 @@ class IndexedTexture:
         """IndexedAtlas::to_texture15 (mesh_editor.rs:669-682) with Clut::lookup (types.rs:390-397)."""
         idx = self.indices.astype(np.int64)
         ok = idx < self.clut.size
-        px = np.where(ok, self.clut[np.minimum(idx, self.clut.size - 1)], 0).astype(np.uint16)
+        lut = self.clut if self.clut.size else np.zeros(1, np.uint16)          # (an empty palette: every lookup is out of range)
+        px = np.where(ok, lut[np.minimum(idx, lut.size - 1)], 0).astype(np.uint16)
         return Texture15(self.width, self.height, px, self.blend_mode, name)
 
 

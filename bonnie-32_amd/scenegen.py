@@ -85,6 +85,11 @@ def make_scene(config="C1", n_tris=None, seed=None, variant="bench", width=None,
              "blend"  -> 10% of faces blend_mode=Average on an STP-bit CLUT + a second texture whose
                          blend_mode is Add (exercises the transparent partition and blend_rgb555)
              "float"  -> use_fixed_point=False (float projection, math.rs:117-136)
+             "blend5" -> every BlendMode of blend_rgb555 (render.rs:1093-1145) both ways it can reach a pixel store: five extra
+                         textures whose blend_mode is Average / Add / Subtract / AddQuarter / Erase over STP-bit CLUTs
+                         (render.rs:1450-1452: the texture's mode wins when one is bound), and untextured faces carrying the
+                         same five modes as the FACE blend mode with vertex colours dark enough that part of their pixels
+                         quantise to black, get bit 15 (render.rs:1659-1661) and are blended
     """
     cfg = dict(CONFIGS[config])
     if n_tris is not None:
@@ -142,6 +147,30 @@ def make_scene(config="C1", n_tris=None, seed=None, variant="bench", width=None,
         faces["texture_id"] = np.where((sel >= 0.10) & (sel < 0.15), 1, 0).astype(np.uint32)
         faces["black_transparent"] = np.where(sel > 0.9, 0, 1).astype(np.uint8)
         faces["editor_alpha"] = np.where((sel >= 0.15) & (sel < 0.18), 128, 255).astype(np.uint8)
+    elif variant == "blend5":
+        sel = uniform01(seed ^ 0xB1E4D, N)
+        modes = [abi.AVERAGE, abi.ADD, abi.SUBTRACT, abi.ADD_QUARTER, abi.ERASE]
+        tid = np.zeros(N, np.uint32)
+        fbm = np.full(N, abi.OPAQUE, np.uint8)
+        for k, m in enumerate(modes):
+            t = make_atlas(seed ^ (0x3333 + k), cfg["atlas"], cfg["clut"], stp=True)
+            t.blend_mode = m
+            indexed.append(t)
+            tid = np.where((sel >= 0.40 + 0.06 * k) & (sel < 0.46 + 0.06 * k), k + 1, tid).astype(np.uint32)
+            face_m = (sel >= 0.70 + 0.05 * k) & (sel < 0.75 + 0.05 * k)          # untextured, face blend mode m
+            tid = np.where(face_m, abi.NO_TEXTURE, tid).astype(np.uint32)
+            fbm = np.where(face_m, m, fbm).astype(np.uint8)
+        # textured faces with a face blend mode too (partition only: the bound texture's mode is the one applied)
+        fbm = np.where((sel >= 0.30) & (sel < 0.40), abi.ADD_QUARTER, fbm).astype(np.uint8)
+        faces["texture_id"] = tid
+        faces["blend_mode"] = fbm
+        faces["black_transparent"] = np.where(sel > 0.95, 0, 1).astype(np.uint8)
+        # a fifth of the blend-textured faces also carry an editor alpha (set_pixel_with_editor_alpha_15, render.rs:567-591)
+        faces["editor_alpha"] = np.where((sel >= 0.40) & (sel < 0.70) & (np.modf(sel * f32(997.0))[0] < 0.2), 100, 255).astype(np.uint8)
+        dark = np.repeat(tid == abi.NO_TEXTURE, 3)
+        dk = (splitmix64(seed ^ 0xDA4C, 9 * N) % np.uint64(12)).astype(np.uint8).reshape(3 * N, 3)
+        for c, name in enumerate(("r", "g", "b")):
+            verts[name] = np.where(dark, dk[:, c], verts[name]).astype(np.uint8)
     elif variant == "float":
         settings.use_fixed_point = False
     elif variant != "bench":

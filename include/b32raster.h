@@ -278,6 +278,14 @@ int b32_last_draw_order(b32_ctx* ctx, uint32_t* face_idx, uint32_t cap, uint32_t
 int b32_selftest_f32(b32_ctx* ctx, int op, const float* a, const float* b, const float* c,
                      float* out, uint32_t n);
 
+/* The numeric literals of the reference AS THE DEVICE CODE HOLDS THEM (a kernel writes them out): `count` named constants
+ * (names[i] = the key in tests/golden/ref_constants.json, which tests/golden/pin_constants.py derives from the reference text;
+ * bits[i] = the f32 bit pattern when is_f32[i], else the integer), the UNR_TABLE the projection kernel indexes (fixed.rs:20-31,
+ * 257 bytes) and PS1_DITHER_MATRIX as dither_offset() returns it, index (y & 3) * 4 + (x & 3) (render.rs:1150-1155).
+ * Any of the output pointers may be NULL; at most `cap` constants are written. */
+int b32_device_constants(b32_ctx* ctx, const char** names, uint32_t* bits, uint8_t* is_f32, uint32_t cap, uint32_t* count,
+                         uint8_t* unr_table257, int32_t* dither16);
+
 /* Per-kernel device time of the last finished frame (HIP events on the ctx stream), for bench.py.
  * names[i] points at static strings; returns the number of entries written (<= cap). */
 int b32_last_kernel_times(b32_ctx* ctx, const char** names, float* ms, uint32_t cap);

@@ -27,6 +27,122 @@
 
 #define EXPORT __attribute__((visibility("default")))
 
+/* ------------------------------------------------------------------ the reference's numeric literals, by name
+ * The code below uses the algorithm's literals only through these names; b32o_constant(key) hands each one back and
+ * tests/test_oracle_kats.py::test_oracle_constants_are_the_reference_text compares it with tests/golden/ref_constants.json, which
+ * tests/golden/pin_constants.py derives from the reference's own text (every row of K_TABLE gives the fixture key). */
+#define K_FRAC_BITS 12                   /* fixed.rs:110 */
+#define K_ONE_F ((float)(1 << K_FRAC_BITS))
+#define K_UNR_ENTRIES 257                /* fixed.rs:20-31 */
+#define K_UNR_INDEX_OFFSET 256
+#define K_UNR_NUMERATOR 262144u
+#define K_UNR_ROUND_ADD 1
+#define K_UNR_ROUND_DIV 2
+#define K_UNR_SUBTRACT 257
+#define K_DIV_D16_SHIFT 16               /* fixed.rs:197-212 */
+#define K_DIV_INDEX_BIAS 0x7FC0ull
+#define K_DIV_INDEX_SHIFT 7
+#define K_DIV_INDEX_MAX 256
+#define K_DIV_U_ADD 0x101
+#define K_DIV_NR1_CONST 0x2000080ull
+#define K_DIV_NR1_SHIFT 8
+#define K_DIV_NR2_CONST 0x80ull
+#define K_DIV_NR2_SHIFT 8
+#define K_DIV_SHIFT_BASE 36u
+#define K_PF_DISTANCE 5.0f               /* project_to_screen, fixed.rs:396-406 */
+#define K_PF_SCALE 4.0f
+#define K_PF_VIEWPORT_DIV 2.0f
+#define K_PF_VIEWPORT_FRAC 0.75f
+#define K_PF_DENOM_GUARD 256
+#define K_P_DISTANCE 5.0f                /* project, math.rs:118-127 */
+#define K_P_US_SUB 1.0f
+#define K_P_VIEWPORT_DIV 2.0f
+#define K_P_VIEWPORT_FRAC 0.75f
+#define K_P_DENOM_GUARD 0.001f
+#define K_NEAR_PLANE 0.1f                /* math.rs:155 */
+#define K_MESH_DISTANCE 5.0f             /* render.rs:2344 */
+#define K_AREA_EPS 0.00001f              /* render.rs:1501 */
+#define K_ERR (-0.0001f)                 /* render.rs:1541 */
+#define K_AREA_EPS8 0.00001f             /* render.rs:1258 (8-bit fill) */
+#define K_ERR8 (-0.0001f)                /* render.rs:1302 */
+#define K_MOD_DIV 128                    /* render.rs:1624 */
+#define K_MOD_MAX 255
+#define K_SHADE_LO 0.0f                  /* render.rs:1643 */
+#define K_SHADE_HI 2.0f
+#define K_SHADE_MAX 255.0f
+#define K_NODITHER_SHIFT 3               /* render.rs:1653 */
+#define K_DITHER_SHIFT 3                 /* render.rs:1177 */
+#define K_DITHER_LO 0
+#define K_DITHER_HI 31
+#define K_DITHER8_SHIFT 3                /* apply_dither, render.rs:1191-1196 */
+#define K_DITHER8_HI 31
+#define K_DITHER8_EXPAND_SHIFT 3
+#define K_EXPAND5_SHL 3                  /* render.rs:1162 */
+#define K_EXPAND5_SHR 2
+#define K_BLEND_IN_SHIFT 3               /* blend_rgb555, render.rs:1095-1144 */
+#define K_BLEND_AVG_DIV 2
+#define K_BLEND_HI 31
+#define K_BLEND_LO 0
+#define K_BLEND_QUARTER_DIV 4
+#define K_BLEND_OUT_SHIFT 3
+#define K_LIGHT_MIN_DIST 0.001f          /* render.rs:1030 */
+#define K_LIGHT_COLOR_DIV 255.0f         /* render.rs:1062 */
+#define K_LIGHT_TOTAL_MAX 1.0f           /* render.rs:1070 */
+#define K_C15_TRANSPARENT 0x0000         /* types.rs:24-53 */
+#define K_C15_BLACK_DRAWABLE 0x8000
+#define K_C15_WHITE 0x7FFF
+#define K_C15_SEMI_BIT 0x8000
+#define K_C15_R_SHIFT 10
+#define K_C15_G_SHIFT 5
+#define K_C15_CHANNEL_MAX 31
+#define K_TABLE(X) \
+    X("fixed.frac_bits", K_FRAC_BITS) \
+    X("unr.entries", K_UNR_ENTRIES) X("unr.index_offset", K_UNR_INDEX_OFFSET) X("unr.numerator", K_UNR_NUMERATOR) \
+    X("unr.round_add", K_UNR_ROUND_ADD) X("unr.round_div", K_UNR_ROUND_DIV) X("unr.subtract", K_UNR_SUBTRACT) \
+    X("div_unr.d16_shift", K_DIV_D16_SHIFT) X("div_unr.index_bias", K_DIV_INDEX_BIAS) X("div_unr.index_shift", K_DIV_INDEX_SHIFT) \
+    X("div_unr.index_max", K_DIV_INDEX_MAX) X("div_unr.u_add", K_DIV_U_ADD) X("div_unr.nr1_const", K_DIV_NR1_CONST) \
+    X("div_unr.nr1_shift", K_DIV_NR1_SHIFT) X("div_unr.nr2_const", K_DIV_NR2_CONST) X("div_unr.nr2_shift", K_DIV_NR2_SHIFT) \
+    X("div_unr.shift_base", K_DIV_SHIFT_BASE) \
+    X("project_fixed.distance", K_PF_DISTANCE) X("project_fixed.scale", K_PF_SCALE) X("project_fixed.viewport_div", K_PF_VIEWPORT_DIV) \
+    X("project_fixed.viewport_frac", K_PF_VIEWPORT_FRAC) X("project_fixed.denom_guard", K_PF_DENOM_GUARD) \
+    X("project.distance", K_P_DISTANCE) X("project.us_sub", K_P_US_SUB) X("project.viewport_div", K_P_VIEWPORT_DIV) \
+    X("project.viewport_frac", K_P_VIEWPORT_FRAC) X("project.denom_guard", K_P_DENOM_GUARD) \
+    X("near_plane", K_NEAR_PLANE) X("mesh.distance", K_MESH_DISTANCE) \
+    X("fill.area_eps", K_AREA_EPS) X("fill.err", K_ERR) X("fill8.area_eps", K_AREA_EPS8) X("fill8.err", K_ERR8) \
+    X("fill.modulate_div", K_MOD_DIV) X("fill.modulate_max", K_MOD_MAX) \
+    X("fill.shade_clamp_lo", K_SHADE_LO) X("fill.shade_clamp_hi", K_SHADE_HI) X("fill.shade_max", K_SHADE_MAX) \
+    X("fill.nodither_shift", K_NODITHER_SHIFT) \
+    X("dither.shift", K_DITHER_SHIFT) X("dither.clamp_lo", K_DITHER_LO) X("dither.clamp_hi", K_DITHER_HI) \
+    X("dither8.shift", K_DITHER8_SHIFT) X("dither8.clamp_hi", K_DITHER8_HI) X("dither8.expand_shift", K_DITHER8_EXPAND_SHIFT) \
+    X("expand5.shl", K_EXPAND5_SHL) X("expand5.shr", K_EXPAND5_SHR) \
+    X("blend555.in_shift", K_BLEND_IN_SHIFT) X("blend555.average_div", K_BLEND_AVG_DIV) X("blend555.clamp_hi", K_BLEND_HI) \
+    X("blend555.clamp_lo", K_BLEND_LO) X("blend555.quarter_div", K_BLEND_QUARTER_DIV) X("blend555.out_shift", K_BLEND_OUT_SHIFT) \
+    X("light.min_dist", K_LIGHT_MIN_DIST) X("light.color_div", K_LIGHT_COLOR_DIV) X("light.total_max", K_LIGHT_TOTAL_MAX) \
+    X("color15.transparent", K_C15_TRANSPARENT) X("color15.black_drawable", K_C15_BLACK_DRAWABLE) X("color15.white", K_C15_WHITE) \
+    X("color15.semi_bit", K_C15_SEMI_BIT) X("color15.r_shift", K_C15_R_SHIFT) X("color15.g_shift", K_C15_G_SHIFT) \
+    X("color15.channel_max", K_C15_CHANNEL_MAX)
+/* value of the named literal as a double (every literal here is exactly representable: f32 constants widen exactly); NaN = no such key */
+EXPORT double b32o_constant(const char* key) {
+#define K_ROW(name, v) if (strcmp(key, name) == 0) return (double)(v);
+    K_TABLE(K_ROW)
+#undef K_ROW
+    return NAN;
+}
+EXPORT uint32_t b32o_constant_count(void) {
+    uint32_t n = 0;
+#define K_ROW(name, v) ++n;
+    K_TABLE(K_ROW)
+#undef K_ROW
+    return n;
+}
+EXPORT const char* b32o_constant_name(uint32_t i) {
+    uint32_t n = 0;
+#define K_ROW(name, v) if (n++ == i) return name;
+    K_TABLE(K_ROW)
+#undef K_ROW
+    return 0;
+}
+
 /* Row band of the all-cores CPU baseline (bench.py: N processes, each draws only its own rows of the same frame): triangle rows
  * outside [g_band_y0, g_band_y1) keep the reference's row-to-row accumulation (w_row += b) but skip their pixels, so the rows that
  * ARE drawn hold exactly the values of the full-frame walk.  Default: the whole frame. */
@@ -82,10 +198,10 @@ static uint8_t g_unr[257];
 static int g_unr_ready = 0;
 static void unr_init(void) {
     if (g_unr_ready) return;
-    for (uint32_t i = 0; i < 257; ++i) {
-        uint32_t div = i + 256;
-        uint32_t quotient = 262144u / div;
-        int32_t val = (int32_t)((quotient + 1) / 2) - 257;
+    for (uint32_t i = 0; i < K_UNR_ENTRIES; ++i) {
+        uint32_t div = i + K_UNR_INDEX_OFFSET;
+        uint32_t quotient = K_UNR_NUMERATOR / div;
+        int32_t val = (int32_t)((quotient + K_UNR_ROUND_ADD) / K_UNR_ROUND_DIV) - K_UNR_SUBTRACT;
         g_unr[i] = val > 0 ? (uint8_t)val : 0;
     }
     g_unr_ready = 1;
@@ -93,14 +209,14 @@ static void unr_init(void) {
 EXPORT uint8_t b32o_unr_table(uint32_t i) { unr_init(); return g_unr[i <= 256 ? i : 256]; }
 
 /* Fixed32::from_f32, fixed.rs:125-127 */
-EXPORT int32_t b32o_fixed_from_f32(float f) { return f2i32_sat(f * 4096.0f); }
+EXPORT int32_t b32o_fixed_from_f32(float f) { return f2i32_sat(f * K_ONE_F); }
 /* Fixed32::from_int, fixed.rs:119-121 (release: shift wraps) */
-static inline int32_t fixed_from_int(int32_t n) { return (int32_t)((uint32_t)n << 12); }
+static inline int32_t fixed_from_int(int32_t n) { return (int32_t)((uint32_t)n << K_FRAC_BITS); }
 /* Fixed32::to_f32, fixed.rs:131-133 */
-static inline float fixed_to_f32(int32_t v) { return (float)v / 4096.0f; }
+static inline float fixed_to_f32(int32_t v) { return (float)v / K_ONE_F; }
 /* Fixed32::mul_fixed, fixed.rs:161-165 */
 EXPORT int32_t b32o_fixed_mul(int32_t a, int32_t b) {
-    int64_t r = ((int64_t)a * (int64_t)b) >> 12;
+    int64_t r = ((int64_t)a * (int64_t)b) >> K_FRAC_BITS;
     return (int32_t)r;
 }
 /* Fixed32::div_unr, fixed.rs:178-230 */
@@ -113,14 +229,14 @@ EXPORT int32_t b32o_fixed_div_unr(int32_t self, int32_t divisor) {
     if (den == 0) return 0;
     uint32_t z = (uint32_t)__builtin_clz(den);
     uint64_t d_norm = (uint64_t)den << z;
-    uint64_t d16 = d_norm >> 16;
-    uint64_t ti = (d16 - 0x7FC0ull) >> 7;                                             /* wrapping_sub */
-    if (ti > 256) ti = 256;
-    uint64_t u_val = (uint64_t)g_unr[ti] + 0x101;
-    uint64_t nr1 = (0x2000080ull - d16 * u_val) >> 8;
-    uint64_t nr2 = (0x80ull + nr1 * u_val) >> 8;
+    uint64_t d16 = d_norm >> K_DIV_D16_SHIFT;
+    uint64_t ti = (d16 - K_DIV_INDEX_BIAS) >> K_DIV_INDEX_SHIFT;                      /* wrapping_sub */
+    if (ti > K_DIV_INDEX_MAX) ti = K_DIV_INDEX_MAX;
+    uint64_t u_val = (uint64_t)g_unr[ti] + K_DIV_U_ADD;
+    uint64_t nr1 = (K_DIV_NR1_CONST - d16 * u_val) >> K_DIV_NR1_SHIFT;
+    uint64_t nr2 = (K_DIV_NR2_CONST + nr1 * u_val) >> K_DIV_NR2_SHIFT;
     uint64_t raw = num * nr2;
-    uint32_t shift = 36u - z;
+    uint32_t shift = K_DIV_SHIFT_BASE - z;
     uint64_t magnitude;
     if (shift < 64) {
         uint64_t rounding = shift > 0 ? (1ull << (shift - 1)) : 0;
@@ -152,24 +268,24 @@ EXPORT void b32o_project_fixed(const float world_pos[3], const float camera_pos[
     FixedVec3 bx = fv_from(basis_x), by = fv_from(basis_y), bz = fv_from(basis_z);
     FixedVec3 cam = { fv_dot(rel, bx), fv_dot(rel, by), fv_dot(rel, bz) };
 
-    int32_t distance = b32o_fixed_from_f32(5.0f);
-    int32_t scale = b32o_fixed_from_f32(4.0f);
+    int32_t distance = b32o_fixed_from_f32(K_PF_DISTANCE);
+    int32_t scale = b32o_fixed_from_f32(K_PF_SCALE);
     uint32_t mn = width < height ? width : height;
-    int32_t viewport_scale = b32o_fixed_from_f32(((float)mn / 2.0f) * 0.75f);
+    int32_t viewport_scale = b32o_fixed_from_f32(((float)mn / K_PF_VIEWPORT_DIV) * K_PF_VIEWPORT_FRAC);
     int32_t half_w = fixed_from_int((int32_t)width / 2);
     int32_t half_h = fixed_from_int((int32_t)height / 2);
     int32_t denom = wrap_add(cam.z, distance);
     /* i32::abs wraps for i32::MIN in release -> stays negative -> "< 256" is true */
     int32_t adenom = denom < 0 ? wrap_neg(denom) : denom;
-    if (adenom < 256) {
-        *sx = half_w >> 12; *sy = half_h >> 12; *depth = fixed_to_f32(cam.z);
+    if (adenom < K_PF_DENOM_GUARD) {
+        *sx = half_w >> K_FRAC_BITS; *sy = half_h >> K_FRAC_BITS; *depth = fixed_to_f32(cam.z);
         return;
     }
     int32_t proj_x = b32o_fixed_div_unr(b32o_fixed_mul(cam.x, scale), denom);
     int32_t proj_y = b32o_fixed_div_unr(b32o_fixed_mul(cam.y, scale), denom);
     int32_t screen_x = wrap_add(b32o_fixed_mul(proj_x, viewport_scale), half_w);
     int32_t screen_y = wrap_add(b32o_fixed_mul(proj_y, viewport_scale), half_h);
-    *sx = screen_x >> 12; *sy = screen_y >> 12; *depth = fixed_to_f32(cam.z);
+    *sx = screen_x >> K_FRAC_BITS; *sy = screen_y >> K_FRAC_BITS; *depth = fixed_to_f32(cam.z);
 }
 
 /* ------------------------------------------------------------------ math.rs */
@@ -193,12 +309,12 @@ static inline V3 perspective_transform(V3 v, V3 cx, V3 cy, V3 cz) {
 }
 /* project, math.rs:117-136 */
 static inline V3 project_float(V3 v, uint32_t width, uint32_t height) {
-    const float ud = 5.0f;
-    float us = ud - 1.0f;
+    const float ud = K_P_DISTANCE;
+    float us = ud - K_P_US_SUB;
     uint32_t mn = width < height ? width : height;
-    float vs = ((float)mn / 2.0f) * 0.75f;
+    float vs = ((float)mn / K_P_VIEWPORT_DIV) * K_P_VIEWPORT_FRAC;
     float denom = v.z + ud;
-    if (fabsf(denom) < 0.001f) return v3((float)width / 2.0f, (float)height / 2.0f, v.z);
+    if (fabsf(denom) < K_P_DENOM_GUARD) return v3((float)width / 2.0f, (float)height / 2.0f, v.z);
     return v3((v.x * us) / denom * vs + ((float)width / 2.0f),
               (v.y * us) / denom * vs + ((float)height / 2.0f),
               denom);
@@ -211,15 +327,16 @@ static inline V3 project_ortho(V3 v, float zoom, float cx, float cy, uint32_t wi
 }
 
 /* ------------------------------------------------------------------ types.rs Color15 / Texture15 */
-static inline uint8_t c15_r5(uint16_t c) { return (uint8_t)((c >> 10) & 0x1F); }   /* types.rs:119-121 */
-static inline uint8_t c15_g5(uint16_t c) { return (uint8_t)((c >> 5) & 0x1F); }    /* types.rs:125-127 */
+static inline uint8_t c15_r5(uint16_t c) { return (uint8_t)((c >> K_C15_R_SHIFT) & 0x1F); }   /* types.rs:119-121 */
+static inline uint8_t c15_g5(uint16_t c) { return (uint8_t)((c >> K_C15_G_SHIFT) & 0x1F); }    /* types.rs:125-127 */
 static inline uint8_t c15_b5(uint16_t c) { return (uint8_t)(c & 0x1F); }           /* types.rs:131-133 */
 /* expand_5_to_8, render.rs:1161-1163 == Color15::r8, types.rs:137-141 */
-static inline uint8_t expand_5_to_8(uint8_t v5) { return (uint8_t)((v5 << 3) | (v5 >> 2)); }
+static inline uint8_t expand_5_to_8(uint8_t v5) { return (uint8_t)((v5 << K_EXPAND5_SHL) | (v5 >> K_EXPAND5_SHR)); }
 /* Color15::new_semi, types.rs:41-56 */
 static inline uint16_t c15_new_semi(uint8_t r, uint8_t g, uint8_t b, int semi) {
-    uint16_t c = (uint16_t)(((uint16_t)(r > 31 ? 31 : r) << 10) | ((uint16_t)(g > 31 ? 31 : g) << 5) | (uint16_t)(b > 31 ? 31 : b));
-    if (semi) c |= 0x8000;
+    const uint8_t mx = K_C15_CHANNEL_MAX;
+    uint16_t c = (uint16_t)(((uint16_t)(r > mx ? mx : r) << K_C15_R_SHIFT) | ((uint16_t)(g > mx ? mx : g) << K_C15_G_SHIFT) | (uint16_t)(b > mx ? mx : b));
+    if (semi) c |= K_C15_SEMI_BIT;
     return c;
 }
 /* Color15::to_rgba, types.rs:220-226 */
@@ -243,20 +360,20 @@ EXPORT void b32o_expand_indexed(const uint8_t* indices, uint32_t n, const uint16
 /* ------------------------------------------------------------------ render.rs colour helpers */
 /* blend_rgb555, render.rs:1093-1145 */
 EXPORT void b32o_blend_rgb555(uint8_t fr, uint8_t fg, uint8_t fb, uint8_t br, uint8_t bg, uint8_t bb, uint32_t mode, uint8_t out[3]) {
-    uint8_t f5[3] = { (uint8_t)(fr >> 3), (uint8_t)(fg >> 3), (uint8_t)(fb >> 3) };
-    uint8_t b5[3] = { (uint8_t)(br >> 3), (uint8_t)(bg >> 3), (uint8_t)(bb >> 3) };
+    uint8_t f5[3] = { (uint8_t)(fr >> K_BLEND_IN_SHIFT), (uint8_t)(fg >> K_BLEND_IN_SHIFT), (uint8_t)(fb >> K_BLEND_IN_SHIFT) };
+    uint8_t b5[3] = { (uint8_t)(br >> K_BLEND_IN_SHIFT), (uint8_t)(bg >> K_BLEND_IN_SHIFT), (uint8_t)(bb >> K_BLEND_IN_SHIFT) };
     for (int i = 0; i < 3; ++i) {
         uint8_t r5;
         switch (mode) {
             default:
             case B32_BLEND_OPAQUE:      r5 = f5[i]; break;
-            case B32_BLEND_AVERAGE:     { uint16_t s = (uint16_t)((b5[i] + f5[i]) / 2); r5 = (uint8_t)(s > 31 ? 31 : s); } break;
+            case B32_BLEND_AVERAGE:     { uint16_t s = (uint16_t)((b5[i] + f5[i]) / K_BLEND_AVG_DIV); r5 = (uint8_t)(s > K_BLEND_HI ? K_BLEND_HI : s); } break;
             case B32_BLEND_ADD:         { uint16_t s = (uint16_t)(b5[i] + f5[i]); r5 = (uint8_t)(s > 31 ? 31 : s); } break;
             case B32_BLEND_SUBTRACT:    { int16_t s = (int16_t)(b5[i] - f5[i]); r5 = (uint8_t)(s < 0 ? 0 : s); } break;
-            case B32_BLEND_ADD_QUARTER: { uint16_t s = (uint16_t)(b5[i] + f5[i] / 4); r5 = (uint8_t)(s > 31 ? 31 : s); } break;
+            case B32_BLEND_ADD_QUARTER: { uint16_t s = (uint16_t)(b5[i] + f5[i] / K_BLEND_QUARTER_DIV); r5 = (uint8_t)(s > K_BLEND_HI ? K_BLEND_HI : s); } break;
             case B32_BLEND_ERASE:       r5 = b5[i]; break;
         }
-        out[i] = (uint8_t)(r5 << 3);
+        out[i] = (uint8_t)(r5 << K_BLEND_OUT_SHIFT);
     }
 }
 /* PS1_DITHER_MATRIX, render.rs:1150-1155 */
@@ -272,8 +389,8 @@ EXPORT void b32o_dither_and_quantize(uint8_t r8, uint8_t g8, uint8_t b8, uint32_
     int32_t off = PS1_DITHER_MATRIX[y & 3][x & 3];
     int32_t c[3] = { r8, g8, b8 };
     for (int i = 0; i < 3; ++i) {
-        int32_t q = (c[i] + off) >> 3;
-        out5[i] = (uint8_t)(q < 0 ? 0 : (q > 31 ? 31 : q));
+        int32_t q = (c[i] + off) >> K_DITHER_SHIFT;
+        out5[i] = (uint8_t)(q < K_DITHER_LO ? K_DITHER_LO : (q > K_DITHER_HI ? K_DITHER_HI : q));
     }
 }
 
@@ -331,7 +448,7 @@ static int shade_multi_light_color(V3 normal, V3 world_pos, const B32Light* ligh
         } else if (l->type == B32_LIGHT_POINT) {
             V3 to_light = v3sub(v3p(l->position), world_pos);
             float dist = v3len(to_light);
-            if (dist > l->radius || dist < 0.001f) {
+            if (dist > l->radius || dist < K_LIGHT_MIN_DIST) {
                 contribution = 0.0f;
             } else {
                 float attenuation = 1.0f - (dist / l->radius);
@@ -341,7 +458,7 @@ static int shade_multi_light_color(V3 normal, V3 world_pos, const B32Light* ligh
         } else if (l->type == B32_LIGHT_SPOT) {       /* Spot, render.rs:1038-1058 */
             V3 to_light = v3sub(v3p(l->position), world_pos);
             float dist = v3len(to_light);
-            if (dist > l->radius || dist < 0.001f) {
+            if (dist > l->radius || dist < K_LIGHT_MIN_DIST) {
                 contribution = 0.0f;
             } else {
                 V3 light_dir_to_surface = v3normalize(to_light);
@@ -359,10 +476,10 @@ static int shade_multi_light_color(V3 normal, V3 world_pos, const B32Light* ligh
         } else {
             return B32_E_ARG;                         /* not a LightType */
         }
-        float lr = (float)l->r / 255.0f, lg = (float)l->g / 255.0f, lb = (float)l->b / 255.0f;
+        float lr = (float)l->r / K_LIGHT_COLOR_DIV, lg = (float)l->g / K_LIGHT_COLOR_DIV, lb = (float)l->b / K_LIGHT_COLOR_DIV;
         tr += contribution * lr; tg += contribution * lg; tb += contribution * lb;
     }
-    out->r = rmin(tr, 1.0f); out->g = rmin(tg, 1.0f); out->b = rmin(tb, 1.0f);
+    out->r = rmin(tr, K_LIGHT_TOTAL_MAX); out->g = rmin(tg, K_LIGHT_TOTAL_MAX); out->b = rmin(tb, K_LIGHT_TOTAL_MAX);
     return B32_OK;
 }
 
@@ -474,7 +591,7 @@ static int rasterize_triangle_15(FB* fb, const Surface* s, const B32Texture15* t
 
     V3 v1 = s->v1, v2 = s->v2, v3_ = s->v3;
     float area = (v2.y - v3_.y) * (v1.x - v3_.x) + (v3_.x - v2.x) * (v1.y - v3_.y);              /* :1500 */
-    if (fabsf(area) < 0.00001f) return B32_OK;                                                   /* :1501-1503 */
+    if (fabsf(area) < K_AREA_EPS) return B32_OK;                                                 /* :1501-1503 */
     float inv_area = 1.0f / area;
     float a0 = v2.y - v3_.y, b0 = v3_.x - v2.x, a1 = v3_.y - v1.y, b1 = v1.x - v3_.x;            /* :1507-1510 */
     float start_x = (float)min_x, start_y = (float)min_y;
@@ -488,7 +605,7 @@ static int rasterize_triangle_15(FB* fb, const Surface* s, const B32Texture15* t
             float bc_x = w0 * inv_area;
             float bc_y = w1 * inv_area;
             float bc_z = 1.0f - bc_x - bc_y;
-            const float ERR = -0.0001f;
+            const float ERR = K_ERR;
             if (bc_x >= ERR && bc_y >= ERR && bc_z >= ERR) {                                      /* :1542 */
                 float inv_z1 = 1.0f / v1.z, inv_z2 = 1.0f / v2.z, inv_z3 = 1.0f / v3_.z;         /* :1546-1550 */
                 float inv_z_interp = bc_x * inv_z1 + bc_y * inv_z2 + bc_z * inv_z3;
@@ -508,10 +625,10 @@ static int rasterize_triangle_15(FB* fb, const Surface* s, const B32Texture15* t
                     v = v_over_z / inv_z_interp;
                 }
                 uint16_t color = texture ? b32o_texture15_sample(texture->pixels, texture->width, texture->height, u, 1.0f - v)
-                                         : (uint16_t)0x7FFF;                                      /* :1582-1586 */
+                                         : (uint16_t)K_C15_WHITE;                                 /* :1582-1586 */
                 int is_black = c15_r5(color) == 0 && c15_g5(color) == 0 && c15_b5(color) == 0;    /* :1591 */
-                if (color == 0) {                                                                 /* :1592-1602 */
-                    if (is_black && !black_transparent) color = 0x8000;
+                if (color == K_C15_TRANSPARENT) {                                                 /* :1592-1602 */
+                    if (is_black && !black_transparent) color = K_C15_BLACK_DRAWABLE;
                     else { w0 += a0; w1 += a1; continue; }
                 } else if (black_transparent && is_black) {                                       /* :1603-1608 */
                     w0 += a0; w1 += a1; continue;
@@ -521,9 +638,9 @@ static int rasterize_triangle_15(FB* fb, const Surface* s, const B32Texture15* t
                 uint8_t vertex_g = f2u8_sat(bc_x * (float)s->vc1.g + bc_y * (float)s->vc2.g + bc_z * (float)s->vc3.g);
                 uint8_t vertex_b = f2u8_sat(bc_x * (float)s->vc1.b + bc_y * (float)s->vc2.b + bc_z * (float)s->vc3.b);
                 uint32_t m;
-                m = ((uint32_t)tex_r8 * vertex_r) / 128; uint8_t mod_r8 = (uint8_t)(m > 255 ? 255 : m); /* :1624-1626 */
-                m = ((uint32_t)tex_g8 * vertex_g) / 128; uint8_t mod_g8 = (uint8_t)(m > 255 ? 255 : m);
-                m = ((uint32_t)tex_b8 * vertex_b) / 128; uint8_t mod_b8 = (uint8_t)(m > 255 ? 255 : m);
+                m = ((uint32_t)tex_r8 * vertex_r) / K_MOD_DIV; uint8_t mod_r8 = (uint8_t)(m > K_MOD_MAX ? K_MOD_MAX : m); /* :1624-1626 */
+                m = ((uint32_t)tex_g8 * vertex_g) / K_MOD_DIV; uint8_t mod_g8 = (uint8_t)(m > K_MOD_MAX ? K_MOD_MAX : m);
+                m = ((uint32_t)tex_b8 * vertex_b) / K_MOD_DIV; uint8_t mod_b8 = (uint8_t)(m > K_MOD_MAX ? K_MOD_MAX : m);
                 float shade_r, shade_g, shade_b;                                                  /* :1629-1640 */
                 if (st->shading == B32_SHADE_NONE) { shade_r = shade_g = shade_b = 1.0f; }
                 else if (st->shading == B32_SHADE_FLAT) { shade_r = flat_shade.r; shade_g = flat_shade.g; shade_b = flat_shade.b; }
@@ -532,14 +649,14 @@ static int rasterize_triangle_15(FB* fb, const Surface* s, const B32Texture15* t
                     shade_g = bc_x * gs1.g + bc_y * gs2.g + bc_z * gs3.g;
                     shade_b = bc_x * gs1.b + bc_y * gs2.b + bc_z * gs3.b;
                 }
-                uint8_t shaded_r8 = f2u8_sat(rmin((float)mod_r8 * rclamp(shade_r, 0.0f, 2.0f), 255.0f)); /* :1643-1645 */
-                uint8_t shaded_g8 = f2u8_sat(rmin((float)mod_g8 * rclamp(shade_g, 0.0f, 2.0f), 255.0f));
-                uint8_t shaded_b8 = f2u8_sat(rmin((float)mod_b8 * rclamp(shade_b, 0.0f, 2.0f), 255.0f));
+                uint8_t shaded_r8 = f2u8_sat(rmin((float)mod_r8 * rclamp(shade_r, K_SHADE_LO, K_SHADE_HI), K_SHADE_MAX)); /* :1643-1645 */
+                uint8_t shaded_g8 = f2u8_sat(rmin((float)mod_g8 * rclamp(shade_g, K_SHADE_LO, K_SHADE_HI), K_SHADE_MAX));
+                uint8_t shaded_b8 = f2u8_sat(rmin((float)mod_b8 * rclamp(shade_b, K_SHADE_LO, K_SHADE_HI), K_SHADE_MAX));
                 uint8_t q5[3];
                 if (needs_dither) b32o_dither_and_quantize(shaded_r8, shaded_g8, shaded_b8, (uint32_t)x, (uint32_t)y, q5); /* :1649-1654 */
-                else { q5[0] = shaded_r8 >> 3; q5[1] = shaded_g8 >> 3; q5[2] = shaded_b8 >> 3; }
+                else { q5[0] = shaded_r8 >> K_NODITHER_SHIFT; q5[1] = shaded_g8 >> K_NODITHER_SHIFT; q5[2] = shaded_b8 >> K_NODITHER_SHIFT; }
                 int is_all_black = q5[0] == 0 && q5[1] == 0 && q5[2] == 0;                        /* :1659-1661 */
-                int semi = (color & 0x8000) != 0 || is_all_black;
+                int semi = (color & K_C15_SEMI_BIT) != 0 || is_all_black;
                 uint16_t out = c15_new_semi(q5[0], q5[1], q5[2], semi);
 
                 uint8_t editor_alpha = s->editor_alpha;                                           /* :1664-1669 */
@@ -624,9 +741,9 @@ static inline void editor_alpha_store8(FB* fb, size_t idx, Col color, uint32_t m
 }
 /* apply_dither, render.rs:1186-1197 */
 static inline uint8_t dither8(uint8_t c, int32_t off) {
-    int32_t q = ((int32_t)c + off) >> 3;
-    q = q < 0 ? 0 : (q > 31 ? 31 : q);
-    return (uint8_t)(q << 3);
+    int32_t q = ((int32_t)c + off) >> K_DITHER8_SHIFT;
+    q = q < 0 ? 0 : (q > K_DITHER8_HI ? K_DITHER8_HI : q);
+    return (uint8_t)(q << K_DITHER8_EXPAND_SHIFT);
 }
 
 /* rasterize_triangle, render.rs:1202-1433 */
@@ -654,7 +771,7 @@ static int rasterize_triangle8(FB* fb, const Surface* s, const B32Texture* textu
                                          || !col_eq(s->vc1, s->vc2) || !col_eq(s->vc2, s->vc3));
     V3 v1 = s->v1, v2 = s->v2, v3_ = s->v3;
     float area = (v2.y - v3_.y) * (v1.x - v3_.x) + (v3_.x - v2.x) * (v1.y - v3_.y);              /* :1257 */
-    if (fabsf(area) < 0.00001f) return B32_OK;
+    if (fabsf(area) < K_AREA_EPS8) return B32_OK;
     float inv_area = 1.0f / area;
     float a0 = v2.y - v3_.y, b0 = v3_.x - v2.x, a1 = v3_.y - v1.y, b1 = v1.x - v3_.x;            /* :1264-1269 */
     float start_x = (float)min_x, start_y = (float)min_y;
@@ -666,7 +783,7 @@ static int rasterize_triangle8(FB* fb, const Surface* s, const B32Texture* textu
         for (uint64_t x = (y >= g_band_y0 && y < g_band_y1) ? min_x : max_x; x < max_x; ++x) {
             float bc_x = w0 * inv_area, bc_y = w1 * inv_area;
             float bc_z = 1.0f - bc_x - bc_y;
-            const float ERR = -0.0001f;
+            const float ERR = K_ERR8;
             if (bc_x >= ERR && bc_y >= ERR && bc_z >= ERR) {                                      /* :1302 */
                 float inv_z1 = 1.0f / v1.z, inv_z2 = 1.0f / v2.z, inv_z3 = 1.0f / v3_.z;         /* :1305-1309 */
                 float inv_z_interp = bc_x * inv_z1 + bc_y * inv_z2 + bc_z * inv_z3;
@@ -892,7 +1009,7 @@ static int render_mesh_impl(uint8_t* fb_pixels, float* fb_zbuffer, uint32_t widt
             int32_t sx, sy; float fd;
             b32o_project_fixed(vertices[i].pos, camera->position, camera->basis_x, camera->basis_y, camera->basis_z, width, height, &sx, &sy, &fd);
             cam_pos = perspective_transform(v3sub(pos, cpos), bx, by, bz);
-            screen = v3((float)sx, (float)sy, cam_pos.z + 5.0f);
+            screen = v3((float)sx, (float)sy, cam_pos.z + K_MESH_DISTANCE);
             if (dump && dump->sx) { dump->sx[i] = sx; dump->sy[i] = sy; }
         } else {                                                                                  /* :2346-2352 */
             cam_pos = perspective_transform(v3sub(pos, cpos), bx, by, bz);
@@ -915,7 +1032,7 @@ static int render_mesh_impl(uint8_t* fb_pixels, float* fb_zbuffer, uint32_t widt
         if (f->v[0] >= nv || f->v[1] >= nv || f->v[2] >= nv) { rc = B32_E_INDEX; goto done; }    /* index panic :2375-2377 */
         V3 cv1 = cam_space[f->v[0]], cv2 = cam_space[f->v[1]], cv3 = cam_space[f->v[2]];
         if (!st->has_ortho) {                                                                     /* :2381-2385 NEAR_PLANE math.rs:155 */
-            if (cv1.z <= 0.1f || cv2.z <= 0.1f || cv3.z <= 0.1f) continue;
+            if (cv1.z <= K_NEAR_PLANE || cv2.z <= K_NEAR_PLANE || cv3.z <= K_NEAR_PLANE) continue;
         }
         V3 v1 = projected[f->v[0]], v2 = projected[f->v[1]], v3_ = projected[f->v[2]];
         float signed_area = (v2.x - v1.x) * (v3_.y - v1.y) - (v3_.x - v1.x) * (v2.y - v1.y);     /* :2393 */

@@ -10,9 +10,24 @@ Every function cites the reference file:line it follows (paths relative to /root
 Scope: perspective projection (fixed-point or float), painter's and z-buffer mode, affine and perspective-correct textures, shading None/Flat/Gouraud with
 directional and point lights, fog, blend modes, editor alpha.
 """
+import json
+import os
+
 import numpy as np
 
 f32 = np.float32
+
+# Every numeric literal of the algorithm comes from tests/golden/ref_constants.json, which tests/golden/pin_constants.py derives from
+# the reference's own text (file:line recorded per entry): this restatement holds no hand-typed copy of them.
+_FIXTURE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "ref_constants.json")
+REF = {k: v["value"] for k, v in json.load(open(_FIXTURE)).items()}
+
+
+def K(name):
+    """literal `name` of the reference: f32 for float literals, int otherwise"""
+    v = REF[name]
+    return f32(v) if isinstance(v, float) else int(v)
+
 I32_MIN, I32_MAX = -(2 ** 31), 2 ** 31 - 1
 
 
@@ -46,15 +61,17 @@ def wrap32(x):
 
 
 # ---------------------------------------------------------------- fixed.rs
-UNR_TABLE = np.array([max(0, (0x40000 // (i + 0x100) + 1) // 2 - 0x101) for i in range(257)], dtype=np.int64)  # :20-31
+UNR_TABLE = np.array([max(0, (K("unr.numerator") // (i + K("unr.index_offset")) + K("unr.round_add")) // K("unr.round_div") - K("unr.subtract"))
+                      for i in range(K("unr.entries"))], dtype=np.int64)                                      # :20-31
+FRAC = K("fixed.frac_bits")
 
 
 def fx_from_f32(x):                       # Fixed32::from_f32 :125-127
-    return as_i32(np.asarray(x, np.float32) * f32(4096.0))
+    return as_i32(np.asarray(x, np.float32) * f32(1 << FRAC))
 
 
 def fx_mul(a, b):                         # mul_fixed :161-165  (i64 product, arithmetic shift, truncating narrow)
-    return wrap32((np.asarray(a, np.int64) * np.asarray(b, np.int64)) >> 12)
+    return wrap32((np.asarray(a, np.int64) * np.asarray(b, np.int64)) >> FRAC)
 
 
 def fx_div_unr(n, d):                     # div_unr :178-230
@@ -73,13 +90,13 @@ def fx_div_unr(n, d):                     # div_unr :178-230
         t = np.where(m, t >> np.uint64(s), t)
     bl += (t > 0).astype(np.int64)
     z = (32 - bl).astype(np.uint64)
-    d16 = ((den << z) >> np.uint64(16)).astype(np.int64)
-    idx = np.minimum((d16 - 0x7FC0) >> 7, 256)
-    u = UNR_TABLE[idx] + 0x101
-    nr1 = (0x2000080 - d16 * u) >> 8
-    nr2 = ((0x80 + nr1 * u) >> 8).astype(np.uint64)
+    d16 = ((den << z) >> np.uint64(K("div_unr.d16_shift"))).astype(np.int64)
+    idx = np.minimum((d16 - K("div_unr.index_bias")) >> K("div_unr.index_shift"), K("div_unr.index_max"))
+    u = UNR_TABLE[idx] + K("div_unr.u_add")
+    nr1 = (K("div_unr.nr1_const") - d16 * u) >> K("div_unr.nr1_shift")
+    nr2 = ((K("div_unr.nr2_const") + nr1 * u) >> K("div_unr.nr2_shift")).astype(np.uint64)
     raw = num * nr2                                     # < 2^64 for every i32 numerator
-    shift = (np.uint64(36) - z)
+    shift = (np.uint64(K("div_unr.shift_base")) - z)
     mag = (raw + (np.uint64(1) << (shift - np.uint64(1)))) >> shift
     mag = np.minimum(mag, np.uint64(I32_MAX)).astype(np.int64)
     out[nz] = np.where(neg, -mag, mag)
@@ -95,18 +112,18 @@ def project_fixed(pos, cam, width, height):
         bb = [fx_from_f32(f32(b[i])) for i in range(3)]
         return wrap32(wrap32(fx_mul(rel[0], bb[0]) + fx_mul(rel[1], bb[1])) + fx_mul(rel[2], bb[2]))   # :311-313
     cx, cy, cz = dot(cam.basis_x), dot(cam.basis_y), dot(cam.basis_z)
-    distance, scale = fx_from_f32(f32(5.0)), fx_from_f32(f32(4.0))              # :396-397
-    vs = fx_from_f32(f32(f32(min(width, height)) / f32(2.0)) * f32(0.75))       # :398
-    half_w, half_h = wrap32((width // 2) << 12), wrap32((height // 2) << 12)   # :399-400
+    distance, scale = fx_from_f32(K("project_fixed.distance")), fx_from_f32(K("project_fixed.scale"))              # :396-397
+    vs = fx_from_f32(f32(f32(min(width, height)) / K("project_fixed.viewport_div")) * K("project_fixed.viewport_frac"))   # :398
+    half_w, half_h = wrap32((width // 2) << FRAC), wrap32((height // 2) << FRAC)   # :399-400
     denom = wrap32(cz + distance)
     absd = np.where(denom < 0, wrap32(-denom), denom)                           # i32::abs (wraps at MIN)
-    small = absd < 256                                                          # :406-408
+    small = absd < K("project_fixed.denom_guard")                               # :406-408
     safe = np.where(small, 4096, denom)
     px = fx_div_unr(fx_mul(cx, scale), safe)
     py = fx_div_unr(fx_mul(cy, scale), safe)
-    sx = wrap32(fx_mul(px, vs) + half_w) >> 12
-    sy = wrap32(fx_mul(py, vs) + half_h) >> 12
-    return np.where(small, half_w >> 12, sx), np.where(small, half_h >> 12, sy)
+    sx = wrap32(fx_mul(px, vs) + half_w) >> FRAC
+    sy = wrap32(fx_mul(py, vs) + half_h) >> FRAC
+    return np.where(small, half_w >> FRAC, sx), np.where(small, half_h >> FRAC, sy)
 
 
 # ---------------------------------------------------------------- math.rs
@@ -131,28 +148,29 @@ def rmax(a, b):
 
 
 # ---------------------------------------------------------------- colour helpers (render.rs / types.rs)
-DITHER = np.array([[-4, 0, -3, 1], [2, -2, 3, -1], [-3, 1, -4, 0], [3, -1, 2, -2]], np.int64)   # render.rs:1150-1155
+DITHER = np.array(REF["dither.matrix"], np.int64)                                                # render.rs:1150-1155
 
 
 def expand5(v):                            # render.rs:1161-1163
-    return ((v << 3) | (v >> 2)) & 0xFF
+    return ((v << K("expand5.shl")) | (v >> K("expand5.shr"))) & 0xFF
 
 
 def blend555(front, back, mode):           # render.rs:1093-1145 on [...,3] uint arrays
-    f5, b5 = front >> 3, back >> 3
+    f5, b5 = front >> K("blend555.in_shift"), back >> K("blend555.in_shift")
+    hi = K("blend555.clamp_hi")
     if mode == 1:
-        r = np.minimum((b5 + f5) // 2, 31)
+        r = np.minimum((b5 + f5) // K("blend555.average_div"), hi)
     elif mode == 2:
-        r = np.minimum(b5 + f5, 31)
+        r = np.minimum(b5 + f5, hi)
     elif mode == 3:
-        r = np.maximum(b5 - f5, 0)
+        r = np.maximum(b5 - f5, K("blend555.clamp_lo"))
     elif mode == 4:
-        r = np.minimum(b5 + f5 // 4, 31)
+        r = np.minimum(b5 + f5 // K("blend555.quarter_div"), hi)
     elif mode == 5:
         r = b5
     else:
         r = f5
-    return r << 3
+    return r << K("blend555.out_shift")
 
 
 def acosf(x):
@@ -198,7 +216,7 @@ def shade_multi(normal, wpos, lights, ambient):
         elif l.light_type == 1:
             to_light = (np.asarray(l.position, np.float32) - wpos).astype(np.float32)
             dist = np.sqrt(dot3(to_light, to_light))
-            if dist > f32(l.radius) or dist < f32(0.001):
+            if dist > f32(l.radius) or dist < K("light.min_dist"):
                 contrib = f32(0.0)
             else:
                 att = f32(1.0) - (dist / f32(l.radius))
@@ -207,7 +225,7 @@ def shade_multi(normal, wpos, lights, ambient):
         elif l.light_type == 2:                                  # Spot, render.rs:1038-1058
             to_light = (np.asarray(l.position, np.float32) - wpos).astype(np.float32)
             dist = np.sqrt(dot3(to_light, to_light))
-            if dist > f32(l.radius) or dist < f32(0.001):
+            if dist > f32(l.radius) or dist < K("light.min_dist"):
                 contrib = f32(0.0)
             else:
                 to_surface = normalize3(to_light)
@@ -223,7 +241,7 @@ def shade_multi(normal, wpos, lights, ambient):
                         contrib = f32(f32(f32(f32(ndl * f32(l.intensity)) * att) * att) * edge)
         else:
             raise ValueError("not a LightType")
-        col = np.array([l.color.r, l.color.g, l.color.b], np.float32) / f32(255.0)
+        col = np.array([l.color.r, l.color.g, l.color.b], np.float32) / K("light.color_div")
         t = (t + contrib * col).astype(np.float32)
     return rmin(t, f32(1.0)).astype(np.float32)
 
@@ -254,14 +272,15 @@ def render_mesh_15(pixels, width, height, vertices, faces, textures, camera, set
         sx = sy = None
     elif settings.use_fixed_point:                                                                   # :2329-2345
         sx, sy = project_fixed(pos, camera, width, height)
-        scr = np.stack([sx.astype(np.float32), sy.astype(np.float32), cam[:, 2] + f32(5.0)], axis=1)
+        scr = np.stack([sx.astype(np.float32), sy.astype(np.float32), cam[:, 2] + K("mesh.distance")], axis=1)
     else:                                                                                            # math.rs:117-136
-        vs = f32(f32(min(width, height)) / f32(2.0)) * f32(0.75)
-        denom = cam[:, 2] + f32(5.0)
+        vs = f32(f32(min(width, height)) / K("project.viewport_div")) * K("project.viewport_frac")
+        denom = cam[:, 2] + K("project.distance")
+        us = f32(K("project.distance") - K("project.us_sub"))                                         # math.rs:121-122
         with np.errstate(divide="ignore", invalid="ignore"):
-            x = (cam[:, 0] * f32(4.0)) / denom * vs + f32(width) / f32(2.0)
-            y = (cam[:, 1] * f32(4.0)) / denom * vs + f32(height) / f32(2.0)
-        tiny = np.abs(denom) < f32(0.001)
+            x = (cam[:, 0] * us) / denom * vs + f32(width) / f32(2.0)
+            y = (cam[:, 1] * us) / denom * vs + f32(height) / f32(2.0)
+        tiny = np.abs(denom) < K("project.denom_guard")
         scr = np.stack([np.where(tiny, f32(width) / f32(2.0), x), np.where(tiny, f32(height) / f32(2.0), y),
                         np.where(tiny, cam[:, 2], denom)], axis=1).astype(np.float32)
         sx = sy = None
@@ -273,7 +292,7 @@ def render_mesh_15(pixels, width, height, vertices, faces, textures, camera, set
     for fi, face in enumerate(faces):
         i0, i1, i2 = (int(k) for k in face["v"])
         cz = cam[[i0, i1, i2], 2]
-        if ortho is None and (cz <= f32(0.1)).any():                                                 # :2381-2385
+        if ortho is None and (cz <= K("near_plane")).any():                                                 # :2381-2385
             continue
         v1, v2, v3 = scr[i0], scr[i1], scr[i2]
         signed_area = (v2[0] - v1[0]) * (v3[1] - v1[1]) - (v3[0] - v1[0]) * (v2[1] - v1[1])          # :2393
@@ -422,7 +441,7 @@ def _rasterize(img, width, height, s, st, zb=None, skip_z_write=False):
     if min_x >= max_x or min_y >= max_y:
         return 0
     area = (v2[1] - v3[1]) * (v1[0] - v3[0]) + (v3[0] - v2[0]) * (v1[1] - v3[1])                      # :1500
-    if abs(area) < f32(0.00001):
+    if abs(area) < K("fill.area_eps"):
         return 0
     inv_area = f32(1.0) / area
     a0, b0, a1, b1 = v2[1] - v3[1], v3[0] - v2[0], v3[1] - v1[1], v1[0] - v3[0]                       # :1507-1510
@@ -441,7 +460,7 @@ def _rasterize(img, width, height, s, st, zb=None, skip_z_write=False):
     bcx = (w0 * inv_area).astype(np.float32)
     bcy = (w1 * inv_area).astype(np.float32)
     bcz = ((f32(1.0) - bcx) - bcy).astype(np.float32)                                                 # :1538
-    E = f32(-0.0001)
+    E = K("fill.err")
     inside = (bcx >= E) & (bcy >= E) & (bcz >= E)                                                     # :1542
     if st.xray_mode:
         zb = None                                                                                     # :1553: no depth test, no depth write
@@ -480,13 +499,13 @@ def _rasterize(img, width, height, s, st, zb=None, skip_z_write=False):
             ty = wrapc((f32(1.0) - v).astype(np.float32), tex.height)
             texel = tex.pixels.astype(np.int64)[ty * tex.width + tx]
     else:
-        texel = np.full(bcx.shape, 0x7FFF, np.int64)
-    black = (texel & 0x7FFF) == 0
+        texel = np.full(bcx.shape, K("color15.white"), np.int64)
+    black = (texel & ~K("color15.semi_bit") & 0xFFFF) == 0
     if s["black_tr"]:
         drawn = inside & ~black                                                                       # :1592-1608
     else:
         drawn = inside.copy()
-        texel = np.where(texel == 0, 0x8000, texel)
+        texel = np.where(texel == K("color15.transparent"), K("color15.black_drawable"), texel)
     if s["alpha"] == 0:                                                                               # :1664-1669
         return 0
     if zb is not None and s["alpha"] == 255:                                                          # :1681-1683 `z < zbuffer`
@@ -504,7 +523,7 @@ def _rasterize(img, width, height, s, st, zb=None, skip_z_write=False):
     for i in range(3):
         tex8 = expand5(chans[i])
         vert = as_u8((bx * f32(s["vc"][0][i]) + by * f32(s["vc"][1][i])).astype(np.float32) + bz * f32(s["vc"][2][i]))   # :1618-1620
-        m = np.minimum((tex8 * vert) // 128, 255)                                                     # :1624-1626
+        m = np.minimum((tex8 * vert) // K("fill.modulate_div"), K("fill.modulate_max"))               # :1624-1626
         if st.shading != 0:
             if "_sh" not in s:
                 _prep_shades(s, st)
@@ -512,18 +531,19 @@ def _rasterize(img, width, height, s, st, zb=None, skip_z_write=False):
                 sv = np.full(bx.shape, s["_sh"][0][i], np.float32)
             else:
                 sv = ((bx * s["_sh"][0][i] + by * s["_sh"][1][i]).astype(np.float32) + bz * s["_sh"][2][i]).astype(np.float32)
-            svc = np.where(sv < 0, f32(0.0), np.where(sv > 2, f32(2.0), sv)).astype(np.float32)      # clamp propagates NaN
+            lo, hi = K("fill.shade_clamp_lo"), K("fill.shade_clamp_hi")
+            svc = np.where(sv < lo, lo, np.where(sv > hi, hi, sv)).astype(np.float32)                # clamp propagates NaN
             m = as_u8(rmin((m.astype(np.float32) * svc).astype(np.float32), f32(255.0)))              # :1643-1645
         out5.append(m)
     vc = s["vc"]
     needs_dither = st.dithering and (st.shading == 2 or tex is not None or not np.array_equal(vc[0], vc[1]) or not np.array_equal(vc[1], vc[2]))
     if needs_dither:                                                                                  # :1173-1182
         off = DITHER[py & 3, px & 3]
-        q = [np.clip((c + off) >> 3, 0, 31) for c in out5]
+        q = [np.clip((c + off) >> K("dither.shift"), K("dither.clamp_lo"), K("dither.clamp_hi")) for c in out5]
     else:
-        q = [c >> 3 for c in out5]
+        q = [c >> K("fill.nodither_shift") for c in out5]
     all_black = (q[0] == 0) & (q[1] == 0) & (q[2] == 0)
-    semi = ((tx_ & 0x8000) != 0) | all_black                                                          # :1659-1661
+    semi = ((tx_ & K("color15.semi_bit")) != 0) | all_black                                                          # :1659-1661
     front = np.stack([expand5(q[0]), expand5(q[1]), expand5(q[2])], axis=1)                           # Color15::r8 etc.
     back = img[py, px, :3].astype(np.int64)
     mode, alpha = s["blend"], s["alpha"]
@@ -565,7 +585,7 @@ def _rasterize8(img, width, height, s, st, zb=None):
     if min_x >= max_x or min_y >= max_y:
         return 0
     area = (v2[1] - v3[1]) * (v1[0] - v3[0]) + (v3[0] - v2[0]) * (v1[1] - v3[1])
-    if abs(area) < f32(0.00001):
+    if abs(area) < K("fill8.area_eps"):
         return 0
     inv_area = f32(1.0) / area
     a0, b0, a1, b1 = v2[1] - v3[1], v3[0] - v2[0], v3[1] - v1[1], v1[0] - v3[0]
@@ -584,7 +604,7 @@ def _rasterize8(img, width, height, s, st, zb=None):
     bcx = (w0 * inv_area).astype(np.float32)
     bcy = (w1 * inv_area).astype(np.float32)
     bcz = ((f32(1.0) - bcx) - bcy).astype(np.float32)
-    E = f32(-0.0001)
+    E = K("fill8.err")
     inside = (bcx >= E) & (bcy >= E) & (bcz >= E)
     with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
         iz = [f32(1.0) / f32(vv[2]) for vv in (v1, v2, v3)]
@@ -650,7 +670,7 @@ def _rasterize8(img, width, height, s, st, zb=None):
     needs_dither = st.dithering and (st.shading == 2 or tex is not None or not np.array_equal(vc[0], vc[1]) or not np.array_equal(vc[1], vc[2]))
     if needs_dither:                                                                                  # apply_dither :1186-1197
         off = DITHER[py & 3, px & 3]
-        cols = [np.clip((c + off) >> 3, 0, 31) << 3 for c in cols]
+        cols = [np.clip((c + off) >> K("dither8.shift"), 0, K("dither8.clamp_hi")) << K("dither8.expand_shift") for c in cols]
     front = np.stack(cols, axis=1).astype(np.int64)
     back = img[py, px, :3].astype(np.int64)
     mode = tx_[:, 3]

@@ -68,6 +68,9 @@ def lib():
         L.b32o_set_row_band.restype = None; L.b32o_set_row_band.argtypes = [C.c_uint32, C.c_uint32]
         L.b32o_vec3_dot.restype = C.c_float; L.b32o_vec3_dot.argtypes = [P, P]
         L.b32o_vec3_cross.restype = None; L.b32o_vec3_cross.argtypes = [P, P, P]
+        L.b32o_constant.restype = C.c_double; L.b32o_constant.argtypes = [C.c_char_p]
+        L.b32o_constant_count.restype = C.c_uint32; L.b32o_constant_count.argtypes = []
+        L.b32o_constant_name.restype = C.c_char_p; L.b32o_constant_name.argtypes = [C.c_uint32]
         _lib = L
     return _lib
 
@@ -82,6 +85,23 @@ def project_fixed(world_pos, camera: T.Camera, width, height):
     lib().b32o_project_fixed(_f3(world_pos), _f3(camera.position), _f3(camera.basis_x), _f3(camera.basis_y),
                              _f3(camera.basis_z), width, height, C.byref(sx), C.byref(sy), C.byref(d))
     return sx.value, sy.value, d.value
+
+
+def constants():
+    """{fixture key: value} of every named literal the C oracle computes with (b32o_constant)."""
+    L = lib()
+    names = [L.b32o_constant_name(i).decode() for i in range(L.b32o_constant_count())]
+    return {n: L.b32o_constant(n.encode()) for n in names}
+
+
+def expand_indexed(indices, clut):
+    """IndexedAtlas::to_texture15 texels (mesh_editor.rs:669-682) through Clut::lookup (types.rs:390-397): OOB index -> 0x0000."""
+    idx = np.ascontiguousarray(indices, np.uint8).reshape(-1)
+    cl = np.ascontiguousarray(clut, np.uint16).reshape(-1)
+    out = np.zeros(idx.size, np.uint16)
+    clp = cl if cl.size else np.zeros(1, np.uint16)
+    lib().b32o_expand_indexed(idx.ctypes.data, idx.size, clp.ctypes.data, cl.size, out.ctypes.data)
+    return out
 
 
 class Framebuffer:

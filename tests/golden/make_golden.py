@@ -86,6 +86,14 @@ def zbuf_scene(variant="bench", seed=17):
     return sc
 
 
+def blend5_scene(zbuf=False):
+    """All five PS1 blend modes (blend_rgb555, render.rs:1093-1145) as texture blend mode over STP texels and as face blend mode
+    of untextured faces, editor alpha on part of them (scenegen variant "blend5")."""
+    sc = scenegen.make_scene("C1", variant="blend5", seed=91, bbox_px=250.0)
+    sc.settings.use_zbuffer = zbuf
+    return sc
+
+
 def ortho_scene():
     sc = scenegen.make_scene("C1", seed=41, variant="blend", bbox_px=900.0)
     sc.camera.position = (30.0, -20.0, 3000.0)   # part of the scene ends up at negative camera depth: no near cull in ortho
@@ -136,6 +144,8 @@ SCENES = {
     "C1:zbuf": zbuf_scene,
     "C1:zbuf-blend": lambda: zbuf_scene("blend", 19),
     "C1:zbuf-gouraud": lambda: zbuf_scene("gouraud", 23),
+    "C1:blend5": blend5_scene,
+    "C1:zbuf-blend5": lambda: blend5_scene(True),
     "C1": lambda: scenegen.make_scene("C1"),
     "C1:gouraud": lambda: scenegen.make_scene("C1", variant="gouraud"),
     "C1:blend": lambda: scenegen.make_scene("C1", variant="blend"),
@@ -146,6 +156,8 @@ SCENES = {
     "C2:blend": lambda: scenegen.make_scene("C2", variant="blend"),
     "C3:100k": lambda: scenegen.make_scene("C3", n_tris=100_000),
     "C5:20k": lambda: scenegen.make_scene("C5", n_tris=20_000),
+    "C3": lambda: scenegen.make_scene("C3"),       # BASELINE configs[2] at full size (1 M triangles @ 2560x1920)
+    "C5": lambda: scenegen.make_scene("C5"),       # BASELINE configs[4] at full size (65.5 M fragments)
 }
 
 

@@ -52,6 +52,22 @@ def test_device_f32_semantics(gpu_ctx):
         assert np.array_equal(gpu_ctx.selftest_f32(3, a, b, c), (a + b) / c)
 
 
+def test_device_constants_are_the_reference_text(gpu_ctx):
+    """Every numeric literal of the algorithm as DEVICE code holds it (b32_device_constants: a kernel writes out the K:: names the
+    kernels compute with, the UNR table the projection indexes and the dither offsets the fill adds) equals the literal that
+    tests/golden/pin_constants.py found in the reference's text (tests/golden/ref_constants.json)."""
+    ref = json.load(open(os.path.join(GOLD, "ref_constants.json")))
+    got, unr, dither = gpu_ctx.device_constants()
+    scalar_keys = {k for k, e in ref.items() if not isinstance(e["value"], list)}
+    assert set(got) == scalar_keys, sorted(set(got) ^ scalar_keys)
+    for k in sorted(scalar_keys):
+        e = ref[k]
+        want = float(np.uint32(e["f32_bits"]).view(np.float32)) if isinstance(e["value"], float) else e["value"]
+        assert got[k] == want, (k, got[k], e)
+    assert unr.tolist() == ref["unr.table"]["value"]
+    assert dither.tolist() == ref["dither.matrix"]["value"]
+
+
 def test_project_fixed_stage(gpu_ctx, oracle):
     """fixed::project_fixed on the device vs the oracle, including saturating and wrapping inputs."""
     rng = np.random.default_rng(7)
@@ -67,7 +83,7 @@ def test_project_fixed_stage(gpu_ctx, oracle):
         assert oracle.project_fixed(pos[i], cam, 2560, 1920)[:2] == (sx[i], sy[i])
 
 
-@pytest.mark.parametrize("name", ["C1", "C1:gouraud", "C1:blend", "C1:float", "C1:persp", "cube", "fog-flat-point-nocull", "C2", "C2:blend"])
+@pytest.mark.parametrize("name", ["C1", "C1:gouraud", "C1:blend", "C1:blend5", "C1:float", "C1:persp", "cube", "fog-flat-point-nocull", "C2", "C2:blend"])
 def test_frame_parity_small(gpu_ctx, oracle, name):
     sc = SCENES[name]()
     exp, etm, d = cpu_render(oracle, sc)
@@ -86,7 +102,7 @@ def fast_ctx(gpu_ctx):
     gpu_ctx.set_fragment_counting(1)
 
 
-@pytest.mark.parametrize("name", ["C1", "C1:gouraud", "C1:blend", "C1:float", "C1:persp", "cube", "fog-flat-point-nocull", "C2", "C2:blend",
+@pytest.mark.parametrize("name", ["C1", "C1:gouraud", "C1:blend", "C1:blend5", "C1:float", "C1:persp", "cube", "fog-flat-point-nocull", "C2", "C2:blend",
                                   "C3:100k", "C5:20k"])
 def test_fast_path_frame_parity(fast_ctx, oracle, name):
     """Same frames through the fast path (no global depth sort, inside-test-only coverage, top-2 visibility).  C2 has tile
@@ -132,7 +148,7 @@ def test_fast_path_full_size_c3(fast_ctx, oracle):
     assert np.array_equal(assembled, exp)
 
 
-@pytest.mark.parametrize("name", ["C1:zbuf", "C1:zbuf-blend", "C1:zbuf-gouraud"])
+@pytest.mark.parametrize("name", ["C1:zbuf", "C1:zbuf-blend", "C1:zbuf-blend5", "C1:zbuf-gouraud"])
 def test_zbuffer_mode_parity(gpu_ctx, oracle, name):
     """use_zbuffer=true (the reference's default / RasterSettings::game()): framebuffer AND z-buffer bit-exact, opaque list
     in face order, transparent pass depth-tested without z writes."""
@@ -142,16 +158,20 @@ def test_zbuffer_mode_parity(gpu_ctx, oracle, name):
     rc, etm, d = oracle.render_mesh_15(ofb, sc.vertices, sc.faces, sc.textures, sc.camera, sc.settings, sc.fog, dump=True)
     assert rc == 0
     assert hashlib.sha256(ofb.pixels).hexdigest() == HASHES[name]["sha256"]
-    for resident in (False, True):
-        fb = R.Framebuffer(sc.width, sc.height, gpu_ctx); fb.clear(sc.clear_color)
-        if resident:
-            tm = R.ResidentScene(fb, sc.vertices, sc.faces, sc.textures).render(sc.camera, sc.settings, sc.fog)
-        else:
-            tm = R.render_mesh_15(fb, sc.vertices, sc.faces, sc.textures, sc.camera, sc.settings, sc.fog)
-        assert np.array_equal(fb.pixels, ofb.pixels)
-        assert np.array_equal(fb.zbuffer.view(np.uint32), ofb.zbuffer.view(np.uint32))
-        assert tm.triangles_drawn == etm.triangles_drawn
-        assert np.array_equal(gpu_ctx.last_draw_order(len(sc.faces)), d["draw_order"])
+    try:
+        for counting, resident in ((1, False), (1, True), (0, False), (0, True)):
+            gpu_ctx.set_fragment_counting(counting)
+            fb = R.Framebuffer(sc.width, sc.height, gpu_ctx); fb.clear(sc.clear_color)
+            if resident:
+                tm = R.ResidentScene(fb, sc.vertices, sc.faces, sc.textures).render(sc.camera, sc.settings, sc.fog)
+            else:
+                tm = R.render_mesh_15(fb, sc.vertices, sc.faces, sc.textures, sc.camera, sc.settings, sc.fog)
+            assert np.array_equal(fb.pixels, ofb.pixels), (counting, resident)
+            assert np.array_equal(fb.zbuffer.view(np.uint32), ofb.zbuffer.view(np.uint32))
+            assert tm.triangles_drawn == etm.triangles_drawn
+            assert np.array_equal(gpu_ctx.last_draw_order(len(sc.faces)), d["draw_order"])
+    finally:
+        gpu_ctx.set_fragment_counting(1)
 
 
 def test_zbuffer_persists_across_calls_and_clear_resets(gpu_ctx, oracle):
@@ -317,6 +337,62 @@ def test_full_size_c3_properties(gpu_ctx, oracle):
         assert np.array_equal(part[:y0 * row].reshape(-1, row), np.tile(clear, (y0, 1)))      # rows outside the band untouched
         frags += ptm.fragments
     assert np.array_equal(assembled, exp) and frags == etm.fragments
+
+
+def test_clut_indices_past_the_palette(gpu_ctx, oracle):
+    """Clut::lookup (types.rs:390-397) returns 0x0000 for an index past the palette: a 4-bit CLUT (16 entries) under an atlas whose
+    bytes run up to 255.  The device expansion of b32_scene_upload_indexed must give the texels of the oracle's expansion (and of
+    the host mirror's IndexedAtlas::to_texture15), i.e. transparent texels wherever the index is out of range."""
+    sc = scenegen.make_scene("C1", seed=123, bbox_px=300.0)
+    at = sc.indexed_textures[0]
+    assert at.clut.size == 16
+    at.indices[:] = (scenegen.splitmix64(555, at.indices.size) % np.uint64(40)).astype(np.uint8)     # 60 % of the texels out of range
+    at.indices[::97] = 255
+    want15 = oracle.expand_indexed(at.indices, at.clut)
+    assert np.array_equal(want15, at.to_texture15().pixels) and (want15 == 0).mean() > 0.5
+    sc.textures = [at.to_texture15()]
+    exp, etm, d = cpu_render(oracle, sc)
+    try:
+        for counting in (1, 0):
+            gpu_ctx.set_fragment_counting(counting)
+            got, tm = gpu_render(gpu_ctx, sc, resident=True, indexed=True)            # device-side CLUT expansion
+            assert np.array_equal(got, exp), f"{int((got != exp).sum())} bytes differ (counting={counting})"
+            assert tm.triangles_drawn == etm.triangles_drawn
+            if counting:
+                assert tm.fragments == etm.fragments
+            got, tm = gpu_render(gpu_ctx, sc, resident=True, indexed=False)           # pre-expanded Texture15
+            assert np.array_equal(got, exp)
+    finally:
+        gpu_ctx.set_fragment_counting(1)
+    # a zero-length palette: every texel transparent, only untextured / black_transparent-off pixels remain
+    at.clut = at.clut[:0]
+    sc.textures = [at.to_texture15()]
+    sc.faces["black_transparent"][::2] = 0
+    exp, etm, _ = cpu_render(oracle, sc)
+    got, tm = gpu_render(gpu_ctx, sc, resident=True, indexed=True)
+    assert np.array_equal(got, exp) and tm.fragments == etm.fragments
+
+
+def test_full_size_c5(gpu_ctx, oracle):
+    """BASELINE configs[4] at full size: 1 M triangles of ~400 px at 64 discrete depths (massive painter's-key ties, ~13x overdraw,
+    65 535 522 pixel stores).  Instrumented path (EXACT coverage, exact store count, draw order) and default path, against the
+    oracle run here and against the committed hash (tests/golden/hashes.json, written in the build container)."""
+    sc = scenegen.make_scene("C5")
+    g = HASHES["C5"]
+    exp, etm, d = cpu_render(oracle, sc)
+    assert hashlib.sha256(exp).hexdigest() == g["sha256"] and (etm.triangles_drawn, etm.fragments) == (g["triangles_drawn"], g["fragments"])
+    got, tm = gpu_render(gpu_ctx, sc, resident=True, indexed=True)
+    assert np.array_equal(got, exp), f"{int((got != exp).sum())} bytes differ"
+    assert hashlib.sha256(got).hexdigest() == g["sha256"]
+    assert (tm.triangles_drawn, tm.fragments) == (etm.triangles_drawn, etm.fragments) == (g["triangles_drawn"], 65535522)
+    order = gpu_ctx.last_draw_order(len(sc.faces))
+    assert np.array_equal(order, d["draw_order"]) and hashlib.sha256(order.tobytes()).hexdigest() == g["draw_order_sha256"]
+    gpu_ctx.set_fragment_counting(0)
+    try:
+        got, tm = gpu_render(gpu_ctx, sc, resident=True, indexed=True)          # the path bench.py times
+        assert hashlib.sha256(got).hexdigest() == g["sha256"] and tm.triangles_drawn == etm.triangles_drawn
+    finally:
+        gpu_ctx.set_fragment_counting(1)
 
 
 def test_rmw_sequence_and_empty_mesh(gpu_ctx, oracle):
@@ -733,7 +809,7 @@ def test_four_million_triangles(fast_ctx, oracle):
     assert tm.triangles_drawn == etm.triangles_drawn == 1938655
 
 
-KEYED = ["C1", "C1:gouraud", "C1:blend", "C1:float", "C1:persp", "cube", "fog-flat-point-nocull", "C2", "C2:blend", "C1:zbuf", "C1:zbuf-blend",
+KEYED = ["C1", "C1:gouraud", "C1:blend", "C1:blend5", "C1:zbuf-blend5", "C1:float", "C1:persp", "cube", "fog-flat-point-nocull", "C2", "C2:blend", "C1:zbuf", "C1:zbuf-blend",
          "C1:zbuf-gouraud", "C3:100k", "C5:20k", "C1:default-settings", "C1:wire-painter"]
 
 

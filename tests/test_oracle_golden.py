@@ -12,7 +12,7 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden")
 HASHES = json.load(open(os.path.join(GOLD, "hashes.json")))
 NEW_MODES = ["C1:ortho", "C1:xray", "C1:xray-zbuf", "C1:default-settings", "C1:wire-painter", "C1:wire-overlay", "cube:default",
              "wire-grid:far-first", "wire-grid:near-first"]
-FAST = NEW_MODES + ["C1:spot-gouraud", "C1:spot-flat-zbuf", "needles", "C1", "C1:zbuf", "C1:zbuf-blend", "C1:zbuf-gouraud", "C1:gouraud", "C1:blend", "C1:float", "C1:persp", "cube", "fog-flat-point-nocull", "C2", "C2:blend", "C3:100k", "C5:20k"]
+FAST = NEW_MODES + ["C1:spot-gouraud", "C1:spot-flat-zbuf", "needles", "C1", "C1:zbuf", "C1:zbuf-blend", "C1:zbuf-gouraud", "C1:blend5", "C1:zbuf-blend5", "C1:gouraud", "C1:blend", "C1:float", "C1:persp", "cube", "fog-flat-point-nocull", "C2", "C2:blend", "C3:100k", "C5:20k", "C3", "C5"]
 
 
 @pytest.mark.parametrize("name", FAST)
@@ -44,7 +44,7 @@ def test_cube_fixture(oracle):
 
 
 @pytest.mark.parametrize("name", ["C1", "C1:gouraud", "C1:blend", "C1:float", "C1:persp", "cube", "fog-flat-point-nocull",
-                                  "C1:zbuf", "C1:zbuf-blend", "C1:zbuf-gouraud", "C1:spot-gouraud", "C1:spot-flat-zbuf", "needles"] + NEW_MODES)
+                                  "C1:zbuf", "C1:zbuf-blend", "C1:zbuf-gouraud", "C1:blend5", "C1:zbuf-blend5", "C1:spot-gouraud", "C1:spot-flat-zbuf", "needles"] + NEW_MODES)
 def test_two_restatements_agree(oracle, name):
     """oracle/b32_oracle.c and oracle/np_model.py are two readings of the same Rust; whole frames must be identical."""
     from oracle import np_model as M
@@ -91,6 +91,27 @@ def test_two_restatements_agree_8bit(oracle, name):
         assert np.array_equal(zb.view(np.uint32), fb.zbuffer.view(np.uint32))
     assert np.array_equal(r["draw_order"], d["draw_order"])
     assert (r["triangles_drawn"], r["fragments"]) == (tm.triangles_drawn, tm.fragments)
+
+
+@pytest.mark.parametrize("zbuf", [False, True])
+def test_blend5_scene_reaches_every_blend_mode(oracle, zbuf):
+    """The blend5 scenes are only worth their name if every BlendMode really reaches a pixel store both ways (texture blend mode
+    over STP texels, face blend mode of untextured faces): switching any one of the ten to Opaque must change the frame."""
+    import bonnie32_amd as b32
+    base = SCENES["C1:zbuf-blend5" if zbuf else "C1:blend5"]()
+    ref, _, _ = render(base)
+    for k in range(1, 6):
+        sc = SCENES["C1:zbuf-blend5" if zbuf else "C1:blend5"]()
+        assert sc.textures[k].blend_mode == k
+        sc.textures[k].blend_mode = b32.abi.OPAQUE
+        fb, _, _ = render(sc)
+        assert not np.array_equal(fb.pixels, ref.pixels), f"texture blend mode {k} never reached a blended store"
+        sc = SCENES["C1:zbuf-blend5" if zbuf else "C1:blend5"]()
+        sel = (sc.faces["texture_id"] == b32.abi.NO_TEXTURE) & (sc.faces["blend_mode"] == k)
+        assert sel.sum() > 20
+        sc.faces["blend_mode"][sel] = b32.abi.OPAQUE
+        fb, _, _ = render(sc)
+        assert not np.array_equal(fb.pixels, ref.pixels), f"face blend mode {k} never reached a blended store"
 
 
 def test_wire_grid_first_occurrence_decides(oracle):

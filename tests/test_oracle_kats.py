@@ -216,3 +216,62 @@ def test_bresenham_closed_form_equals_literal_loop(oracle):
         assert np.array_equal(a.reshape(H, W, 4), b), (x0, y0, x1, y1)
     # a line whose Bresenham state overflows i32 in the reference is refused, not walked
     assert L.b32o_draw_line(a.ctypes.data, W, H, -(1 << 30), 0, 5, 5, 1, 2, 3) == b32.abi.B32_E_UNSUPPORTED
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Constants pinned to the reference's own text (tests/golden/pin_constants.py -> tests/golden/ref_constants.json)
+def _ref_constants():
+    import json
+    import os
+    return json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_constants.json")))
+
+
+def _expect(entry):
+    """the value a `const X: f32 = <literal>` / integer literal of the reference holds"""
+    v = entry["value"]
+    if isinstance(v, float):
+        assert int(np.float32(v).view(np.uint32)) == entry["f32_bits"]
+        return float(np.float32(v))
+    return v
+
+
+def test_fixture_is_current():
+    """Where the reference is present (the build container) the committed fixture must be exactly what the script derives from the
+    reference text today; on the GPU box (no /root/reference) only its shape is checked."""
+    import importlib.util
+    import os
+    ref = _ref_constants()
+    assert len(ref) >= 60 and all("source" in e and e["source"].startswith("src/rasterizer/") for e in ref.values())
+    spec = importlib.util.spec_from_file_location("pin_constants", os.path.join(os.path.dirname(__file__), "golden", "pin_constants.py"))
+    pin = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pin)
+    if not os.path.isdir(pin.SRC):
+        pytest.skip("reference text not on this box: the committed fixture is the pin")
+    assert pin.derive() == ref
+
+
+def test_oracle_constants_are_the_reference_text(oracle):
+    """Every named literal the C oracle computes with (b32o_constant: the K_* macros its code uses) equals the literal found in the
+    reference text; the UNR table it indexes and the dither matrix it adds are the ones the reference's generator / table give."""
+    ref = _ref_constants()
+    got = oracle.constants()
+    scalar_keys = {k for k, e in ref.items() if not isinstance(e["value"], list)}
+    assert set(got) == scalar_keys, (sorted(set(got) ^ scalar_keys))
+    for k in sorted(scalar_keys):
+        assert got[k] == _expect(ref[k]), (k, got[k], ref[k])
+    L = oracle.lib()
+    assert [L.b32o_unr_table(i) for i in range(257)] == ref["unr.table"]["value"]
+    assert [[L.b32o_dither_offset(x, y) for x in range(4)] for y in range(4)] == ref["dither.matrix"]["value"]
+    # the periodic extension the fill uses: [y & 3][x & 3]
+    assert L.b32o_dither_offset(6, 9) == ref["dither.matrix"]["value"][1][2]
+
+
+def test_np_model_constants_are_the_reference_text():
+    """oracle/np_model.py holds no literal of its own: it loads the fixture.  Spot-check that the loaded values are the ones in use."""
+    from oracle import np_model as M
+    ref = _ref_constants()
+    assert M.UNR_TABLE.tolist() == ref["unr.table"]["value"] and M.DITHER.tolist() == ref["dither.matrix"]["value"]
+    assert float(M.K("fill.err")) == float(np.float32(ref["fill.err"]["value"])) and M.K("div_unr.nr1_const") == 0x2000080
+    src = open(M.__file__).read()
+    for lit in ("0.0001", "0.00001", "0x7FC0", "0x2000080", "0x101", "262144", "0x40000"):
+        assert lit not in src, f"np_model.py still carries its own copy of {lit}"

@@ -49,7 +49,7 @@ def slots_case():
     items = []
     for i in range(k):
         ntri = int(rng.choice([5, 300, 2048, 2500, 8192, 9000]))
-        sc = scenegen.make_scene(str(rng.choice(["C1", "C2"])), n_tris=ntri, seed=int(rng.integers(1 << 30)), variant=str(rng.choice(["bench", "gouraud", "blend"])),
+        sc = scenegen.make_scene(str(rng.choice(["C1", "C2"])), n_tris=ntri, seed=int(rng.integers(1 << 30)), variant=str(rng.choice(["bench", "gouraud", "blend", "blend5"])),
                                  width=W, height=H, bbox_px=float(rng.choice([60.0, 900.0, 20000.0])))
         st = sc.settings
         st.use_zbuffer = bool(rng.integers(2)); st.backface_cull = bool(rng.integers(2)); st.affine_textures = bool(rng.integers(4))
@@ -108,7 +108,7 @@ while time.time() < t_end:
     ntri = int(rng.choice([1, 7, 300, 2500, 20000]))
     if os.environ.get("SOAK_FORCE"):                     # screen-filling triangles: keep the CPU oracle's work bounded
         ntri = min(ntri, 300); W, H = min(W, 640), min(H, 480)
-    variant = rng.choice(["bench", "gouraud", "blend", "float"])
+    variant = rng.choice(["bench", "gouraud", "blend", "blend5", "float"])        # blend5: all five blend_rgb555 modes, both as texture and as face mode
     sc = scenegen.make_scene(cfg, n_tris=ntri, seed=int(rng.integers(1 << 30)), variant=variant, width=W, height=H,
                              bbox_px=float(rng.choice([4.0, 60.0, 900.0, 20000.0])))
     force = os.environ.get("SOAK_FORCE", "")            # "orthoz": every scene hostile + orthographic + z-buffer (signed-zero depths)
