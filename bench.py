@@ -75,6 +75,8 @@ def main():
     W, H, NF = sc.width, sc.height, sc.n_tris
 
     ctx = R.Context(local_rank)
+    ctx.set_async_depth(1)      # frames back to back without a host synchronisation (static camera, capacities settled by the warm-up
+                                # frames); a frame dropped for lack of buffer space would be REPORTED by finish(), never silent
     # one explicit stream for everything of this rank: the rasterizer's kernels, torch's copies and the RCCL gather are ordered by it
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
@@ -132,6 +134,7 @@ def main():
 
     def make_second_set():
         ctx2 = R.Context(local_rank)
+        ctx2.set_async_depth(1)
         ctx2.set_stream(stream.cuda_stream)
         frame2 = torch.zeros_like(frame)
         fb2 = R.Framebuffer.__new__(R.Framebuffer)

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libb32raster.so")
 
 # ---- error codes -----------------------------------------------------------
-B32_OK, B32_E_ARG, B32_E_INDEX, B32_E_NAN_KEY, B32_E_HIP, B32_E_UNSUPPORTED, B32_E_NO_DEVICE = 0, -1, -2, -3, -4, -5, -6
+B32_OK, B32_E_ARG, B32_E_INDEX, B32_E_NAN_KEY, B32_E_HIP, B32_E_UNSUPPORTED, B32_E_NO_DEVICE, B32_E_FRAME_DROPPED = 0, -1, -2, -3, -4, -5, -6, -7
 NO_TEXTURE = 0xFFFFFFFF
 
 # BlendMode (types.rs:1380-1388)
@@ -88,6 +88,8 @@ SYMBOLS = [
     ("b32_set_stream", C.c_int, [_P, _P]),
     ("b32_synchronize", C.c_int, [_P]),
     ("b32_fb_resize", C.c_int, [_P, C.c_uint32, C.c_uint32]),
+    ("b32_fb_new", C.c_int, [_P, C.c_uint32, C.c_uint32]),
+    ("b32_set_async_depth", C.c_int, [_P, C.c_int]),
     ("b32_fb_clear", C.c_int, [_P, C.c_uint8, C.c_uint8, C.c_uint8, C.c_uint8]),
     ("b32_fb_upload", C.c_int, [_P, _P]),
     ("b32_fb_download", C.c_int, [_P, _P]),

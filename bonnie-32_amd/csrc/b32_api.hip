@@ -84,6 +84,8 @@ struct b32_ctx {
     // last enqueued frame (for redraw after a pair overflow)
     bool frame_pending = false;
     bool pending_may_redraw = false;    // the pending frame took a path that can overflow its buffers (not the small-mesh path)
+    bool deep_async = false;            // b32_set_async_depth(1): large-scene frames are enqueued back to back, a dropped one is reported
+    bool redrawing = false;             // enqueue_frame is repeating the pending frame (k_setup must not count it as lost)
     int deferred_rc = 0;                // error of a frame that b32_scene_swap had to settle: reported by the next b32_frame_finish
     B32Camera last_cam{}; B32Settings last_settings{}; B32Fog last_fog{}; bool last_has_fog = false;
     int last_pair_buf = 0;
@@ -176,6 +178,7 @@ const char* b32_strerror(int code) {
         case B32_E_HIP: return "HIP runtime error";
         case B32_E_UNSUPPORTED: return "setting outside the supported hot-path scope";
         case B32_E_NO_DEVICE: return "no HIP device (the rasterizer has no CPU fallback)";
+        case B32_E_FRAME_DROPPED: return "an earlier frame in flight ran out of buffer space and drew nothing (deep asynchronous mode)";
         default: return "unknown error";
     }
 }
@@ -218,8 +221,20 @@ void b32_destroy(b32_ctx* c) {
 
 int b32_last_hip_error(const b32_ctx* c) { return c ? c->last_hip : 0; }
 
+// A pending frame that may still need a redraw (pair overflow, long transparent lists) is settled before anything reads or rebinds
+// the framebuffer, so that no caller ever sees the cleared frame of an aborted attempt.  Its error, if any, is the frame's error: kept
+// for the b32_frame_finish that ends the frame.
+static int settle_pending(b32_ctx* c) {
+    if (!c->frame_pending || !c->pending_may_redraw) return B32_OK;
+    const int rc = b32_frame_finish(c, nullptr);
+    if (rc == B32_E_HIP || rc == B32_E_ARG) return rc;
+    if (rc && !c->deferred_rc) c->deferred_rc = rc;
+    return B32_OK;
+}
+
 int b32_set_stream(b32_ctx* c, void* s) {
     if (!c) return B32_E_ARG;
+    { const int rc = settle_pending(c); if (rc) return rc; }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->stream = s ? reinterpret_cast<hipStream_t>(s) : c->own_stream;
     return B32_OK;
@@ -237,11 +252,12 @@ static int fb_set_dims(b32_ctx* c, uint32_t w, uint32_t h) {
     else { if (c->band_y1 > h) c->band_y1 = h; if (c->band_y0 > c->band_y1) c->band_y0 = c->band_y1; }
     return B32_OK;
 }
-int b32_fb_resize(b32_ctx* c, uint32_t w, uint32_t h) {
+static int fb_resize_any(b32_ctx* c, uint32_t w, uint32_t h, bool always_new) {
     if (!c || w == 0 || h == 0 || w > 16384 || h > 16384) return B32_E_ARG;
     (void)hipSetDevice(c->device);
+    { const int rc = settle_pending(c); if (rc) return rc; }
     if (c->fb_external) { c->fb_external = false; c->fb = nullptr; c->width = c->height = 0; }
-    if (c->fb && c->width == w && c->height == h) return B32_OK;          // Framebuffer::resize: no-op on equal dims
+    if (!always_new && c->fb && c->width == w && c->height == h) return B32_OK;          // Framebuffer::resize: no-op on equal dims
     const size_t px = (size_t)w * h;
     if (px > c->fb_own_px || !c->fb_own) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -257,8 +273,11 @@ int b32_fb_resize(b32_ctx* c, uint32_t w, uint32_t h) {
     HIPCHK(c, hipMemsetAsync(c->fb, 0, px * 4, c->stream));                // vec![0; w*h*4], render.rs:18-33
     return B32_OK;
 }
+int b32_fb_resize(b32_ctx* c, uint32_t w, uint32_t h) { return fb_resize_any(c, w, h, false); }   // Framebuffer::resize, render.rs:27-34
+int b32_fb_new(b32_ctx* c, uint32_t w, uint32_t h) { return fb_resize_any(c, w, h, true); }       // Framebuffer::new, render.rs:18-25
 int b32_fb_bind_device(b32_ctx* c, void* dptr, uint32_t w, uint32_t h) {
     if (!c) return B32_E_ARG;
+    { const int rc = settle_pending(c); if (rc) return rc; }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (!dptr) { c->fb_external = false; c->fb = nullptr; c->width = c->height = 0; return B32_OK; }
     if (w == 0 || h == 0 || w > 16384 || h > 16384 || (reinterpret_cast<uintptr_t>(dptr) & 15)) return B32_E_ARG;
@@ -305,7 +324,7 @@ int b32_render_skybox_mesh(b32_ctx* c, const B32SkyVertex* v, uint32_t nv, const
     if (!c || !c->fb || !cam || (nv && !v) || (nf && !faces)) return B32_E_ARG;
     if (!nv || !nf) return B32_OK;
     (void)hipSetDevice(c->device);
-    for (uint32_t i = 0; i < 3 * nf; ++i) if (faces[i] >= nv) return B32_E_INDEX;          // projected[face[k]] index panic
+    for (size_t i = 0; i < (size_t)3 * nf; ++i) if (faces[i] >= nv) return B32_E_INDEX;    // projected[face[k]] index panic
     B32SkyVertex* dv = nullptr; uint32_t* df = nullptr; float2* dp = nullptr;
     Scratch tmp(c);
     int rc;
@@ -333,6 +352,7 @@ int b32_draw_star_diamonds(b32_ctx* c, const int32_t* cx, const int32_t* cy, con
 int b32_present_nearest(b32_ctx* c, uint32_t dw, uint32_t dh, uint8_t* out) {
     if (!c || !c->fb || !out || !dw || !dh || dw > 32768 || dh > 32768) return B32_E_ARG;
     (void)hipSetDevice(c->device);
+    { const int rc = settle_pending(c); if (rc) return rc; }
     uint32_t* dd = nullptr;
     Scratch tmp(c);
     int rc;
@@ -345,6 +365,7 @@ int b32_present_nearest(b32_ctx* c, uint32_t dw, uint32_t dh, uint8_t* out) {
 int b32_fb_upload(b32_ctx* c, const uint8_t* rgba) {
     if (!c || !c->fb || !rgba) return B32_E_ARG;
     (void)hipSetDevice(c->device);
+    { const int rc = settle_pending(c); if (rc) return rc; }
     HIPCHK(c, hipMemcpyAsync(c->fb, rgba, (size_t)c->width * c->height * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return B32_OK;
@@ -352,6 +373,7 @@ int b32_fb_upload(b32_ctx* c, const uint8_t* rgba) {
 int b32_zbuffer_download(b32_ctx* c, float* z) {
     if (!c || !c->fb || !z) return B32_E_ARG;
     (void)hipSetDevice(c->device);
+    { const int rc = settle_pending(c); if (rc) return rc; }
     const size_t px = (size_t)c->width * c->height;
     if (!c->zbuf || !c->zbuf_valid) { HIPCHK(c, hipStreamSynchronize(c->stream)); for (size_t i = 0; i < px; ++i) z[i] = 3.40282347e+38f; return B32_OK; }
     HIPCHK(c, hipMemcpyAsync(z, c->zbuf, px * 4, hipMemcpyDeviceToHost, c->stream));
@@ -361,6 +383,7 @@ int b32_zbuffer_download(b32_ctx* c, float* z) {
 int b32_zbuffer_upload(b32_ctx* c, const float* z) {
     if (!c || !c->fb || !z) return B32_E_ARG;
     (void)hipSetDevice(c->device);
+    { const int rc = settle_pending(c); if (rc) return rc; }
     const size_t px = (size_t)c->width * c->height;
     int rc;
     if (px > c->cap_zbuf || !c->zbuf) { if ((rc = ensure_plain(c, c->zbuf, px + 64))) return rc; c->cap_zbuf = px; }
@@ -372,6 +395,7 @@ int b32_zbuffer_upload(b32_ctx* c, const float* z) {
 int b32_fb_download(b32_ctx* c, uint8_t* rgba) {
     if (!c || !c->fb || !rgba) return B32_E_ARG;
     (void)hipSetDevice(c->device);
+    { const int rc = settle_pending(c); if (rc) return rc; }
     HIPCHK(c, hipMemcpyAsync(rgba, c->fb, (size_t)c->width * c->height * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return B32_OK;
@@ -623,8 +647,14 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     uint32_t n_keys = 2 * ntiles;
     int rc;
 
-    // lights (rarely change: synchronous refresh only when they differ from the device copy)
-    if (fp.n_lights) {
+    // lights: up to LIGHTS_INLINE travel by value in k_setup's arguments (a light change costs no copy and no synchronisation: the
+    // per-room light lists of a multi-mesh frame stay asynchronous); longer lists go through a device buffer, refreshed -- with a
+    // synchronisation -- only when they differ from the copy it holds
+    LightSet lset{};
+    if (fp.n_lights && fp.n_lights <= LIGHTS_INLINE) {
+        memcpy(lset.l, st->lights, fp.n_lights * sizeof(B32Light));
+        fp.lights_inline = 1;
+    } else if (fp.n_lights) {
         bool same = c->h_lights.size() == fp.n_lights && memcmp(c->h_lights.data(), st->lights, fp.n_lights * sizeof(B32Light)) == 0;
         if (!same) {
             if ((rc = ensure(c, c->d_lights, c->cap_lights, (size_t)fp.n_lights))) return rc;
@@ -734,7 +764,8 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     }
     if (prof_all) HIPCHK(c, hipEventRecord(ev[0], s));
     fp.band_only = (want_prio64 && c->band_set) ? 1 : 0;   // other ranks own the other rows: their surfaces' records are never read here
-    launch_setup(s, fp, c->d_verts, c->d_faces, c->d_tex, c->d_lights, c->recs, c->shades, c->keys[0], c->spans, c->partials, c->d_ctrl, c->wire);
+    fp.redraw = c->redrawing ? 1 : 0;
+    launch_setup(s, fp, c->d_verts, c->d_faces, c->d_tex, c->d_lights, lset, c->recs, c->shades, c->keys[0], c->spans, c->partials, c->d_ctrl, c->wire);
     if (prof_all) HIPCHK(c, hipEventRecord(ev[1], s));
 
     int cur = 0;
@@ -846,9 +877,11 @@ static int render_scene_async_any(b32_ctx* c, const B32Camera* cam, const B32Set
     (void)hipSetDevice(c->device);
     int rc = validate_settings(st);
     if (rc) return rc;
+    // keep a private copy of the lights so a redraw after overflow does not dereference a dead caller pointer
+    // (safe mode) a pending frame that may still need a redraw is settled before the next one overwrites its control block
+    if (!c->deep_async && (rc = settle_pending(c))) return rc;
     c->last_cam = *cam; c->last_settings = *st; c->last_has_fog = fog != nullptr;
     if (fog) c->last_fog = *fog;
-    // keep a private copy of the lights so a redraw after overflow does not dereference a dead caller pointer
     c->keep_lights.assign(st->lights, st->lights + (st->lights ? st->n_lights : 0));
     c->last_settings.lights = c->keep_lights.empty() ? nullptr : c->keep_lights.data();
     rc = enqueue_frame(c, cam, &c->last_settings, fog);
@@ -902,8 +935,10 @@ int b32_frame_finish(b32_ctx* c, B32Timings* out) {
             // this scene) with the global depth sort
             c->local_sort_ok = false;
             c->ev_frames = 0;
-            int rc;
-            if ((rc = enqueue_frame(c, &c->last_cam, &c->last_settings, c->last_has_fog ? &c->last_fog : nullptr))) return rc;
+            c->redrawing = true;
+            const int rc = enqueue_frame(c, &c->last_cam, &c->last_settings, c->last_has_fog ? &c->last_fog : nullptr);
+            c->redrawing = false;
+            if (rc) return rc;
             continue;
         }
         if (!c->h_ctrl.pairs_overflow) break;
@@ -913,7 +948,10 @@ int b32_frame_finish(b32_ctx* c, B32Timings* out) {
         for (int i = 0; i < 2; ++i) { if ((rc = ensure_plain(c, c->pkeys[i], n))) return rc; if ((rc = ensure_plain(c, c->pvals[i], n))) return rc; }
         c->cap_pairs = n;
         c->ev_frames = 0;                              // the aborted frame must not enter the phase averages
-        if ((rc = enqueue_frame(c, &c->last_cam, &c->last_settings, c->last_has_fog ? &c->last_fog : nullptr))) return rc;
+        c->redrawing = true;
+        rc = enqueue_frame(c, &c->last_cam, &c->last_settings, c->last_has_fog ? &c->last_fog : nullptr);
+        c->redrawing = false;
+        if (rc) return rc;
     }
     c->frame_pending = false;
     collect_events(c);
@@ -921,6 +959,7 @@ int b32_frame_finish(b32_ctx* c, B32Timings* out) {
     if (sticky) HIPCHK(c, hipMemsetAsync(&c->d_ctrl->sticky, 0, sizeof(uint32_t), c->stream));
     if (c->deferred_rc) { const int d = c->deferred_rc; c->deferred_rc = 0; return d; }     // (an earlier mesh of this frame, settled by a swap)
     if (c->h_ctrl.pairs_overflow) return B32_E_HIP;
+    if (sticky >> 8) return B32_E_FRAME_DROPPED;              // deep asynchronous mode: an earlier frame was lost (the last one is good)
     if (c->h_ctrl.err_index || (sticky & 1u)) return B32_E_INDEX;
     if (c->h_ctrl.abort || (sticky & 2u)) return B32_E_NAN_KEY;
     if (c->h_ctrl.wire_overflow || (sticky & 4u)) return B32_E_UNSUPPORTED;     // an edge >= 2^30 px long: i32 overflow in the reference's Bresenham
@@ -957,11 +996,7 @@ int b32_scene_swap(b32_ctx* c, b32_scene* sl) {
     // a pending frame of the outgoing scene that may have to be redrawn (pair overflow, long transparent lists) is settled first:
     // the redraw needs that scene.  Frames of small meshes never redraw and stay in flight.
     // Its error, if any, is the frame's error: kept for the b32_frame_finish that ends the frame (the exchange itself goes ahead).
-    if (c->frame_pending && c->pending_may_redraw) {
-        const int rc = b32_frame_finish(c, nullptr);
-        if (rc == B32_E_HIP || rc == B32_E_ARG) return rc;
-        if (rc && !c->deferred_rc) c->deferred_rc = rc;
-    }
+    { const int rc = settle_pending(c); if (rc) return rc; }
     std::swap(c->d_verts, sl->d_verts); std::swap(c->cap_verts, sl->cap_verts);
     std::swap(c->d_faces, sl->d_faces); std::swap(c->cap_faces, sl->cap_faces);
     std::swap(c->d_texels, sl->d_texels); std::swap(c->cap_texels, sl->cap_texels);
@@ -1143,6 +1178,12 @@ int b32_last_kernel_times(b32_ctx* c, const char** names, float* ms, uint32_t ca
 extern "C" int b32_set_fragment_counting(b32_ctx* c, int on) {
     if (!c) return B32_E_ARG;
     c->count_fragments = on ? 1 : 0;
+    return B32_OK;
+}
+extern "C" int b32_set_async_depth(b32_ctx* c, int deep) {
+    if (!c) return B32_E_ARG;
+    if (!deep) { const int rc = settle_pending(c); if (rc) return rc; }
+    c->deep_async = deep != 0;
     return B32_OK;
 }
 extern "C" int b32_set_profiling(b32_ctx* c, int level) {

@@ -118,7 +118,9 @@ struct Ctrl {
     uint32_t need_global_sort; // a tile list exceeded the LDS sort capacity: redraw with the global depth sort
     uint32_t wire_overflow;    // a wireframe edge is >= 2^30 pixels long: the reference's i32 Bresenham state overflows
     uint32_t sticky;           // errors of every frame since the last b32_frame_finish (bit 0 vertex index, 1 NaN sort key, 2 wire edge):
-                               // NOT reset at frame start, so the meshes of a multi-scene frame can be enqueued without a sync each
+                               // NOT reset at frame start, so the meshes of a multi-scene frame can be enqueued without a sync each.
+                               // Bits 8..31: frames that were dropped (pair overflow / need_global_sort) and then overwritten by a
+                               // later frame before the host could redraw them (counted by that later frame's k_setup)
     unsigned long long fragments;
 };
 
@@ -162,6 +164,8 @@ struct FrameParams {
     uint8_t affine, shading, backface_cull, dithering, fixed_point, has_fog, zmode, fmt8;   // zmode = settings.use_zbuffer; fmt8 = render_mesh (8-bit colour)
     uint8_t ortho, xray, wire_collect, band_only;   // ortho_projection.is_some(), xray_mode, any wireframe phase wants its triangles;
                                                     // band_only: records of surfaces outside this rank's band are not needed (sort-free path)
+    uint8_t redraw, lights_inline, _padb[2];        // redraw: the host is repeating a dropped frame (not a new one); lights_inline: the
+                                                    // lights travel in the kernel arguments (LightSet) instead of a device buffer
     float ortho_zoom, ortho_cx, ortho_cy;      // OrthoProjection (types.rs), math.rs:140-148
     B32Fog fog;
     CamFx camfx;
@@ -280,9 +284,12 @@ void launch_radix_pass(hipStream_t s, const uint32_t* keys_in, const uint32_t* v
 // k_setup publishes 5 counters per 256-face block (visible, transparent, nan_opaque, nan_transparent, bad_index) into
 // `partials[block*8 + k]`; k_after_setup reduces them into Ctrl.  (One same-address atomic per wave costs ~12 ns each and
 // serialises: 15.6 k waves = the whole kernel time at 1 M faces.)
+// up to LIGHTS_INLINE lights travel by value in the kernel arguments: a light change costs no copy and no synchronisation
+constexpr uint32_t LIGHTS_INLINE = 8;
+struct LightSet { B32Light l[LIGHTS_INLINE]; };
 void launch_setup(hipStream_t s, const FrameParams& fp, const B32Vertex* verts, const B32Face* faces, const TexDesc* tex,
-                  const B32Light* lights, SurfRec* recs, float* shades, uint32_t* keys, uint32_t* spans, uint32_t* partials, Ctrl* ctrl,
-                  WireTri* wire);
+                  const B32Light* lights, const LightSet& inline_lights, SurfRec* recs, float* shades, uint32_t* keys, uint32_t* spans,
+                  uint32_t* partials, Ctrl* ctrl, WireTri* wire);
 void launch_project_fixed(hipStream_t s, const float* pos, uint32_t n, B32Camera cam, uint32_t w, uint32_t h,
                           int32_t* sx, int32_t* sy, float* z);
 void launch_selftest(hipStream_t s, int op, const float* a, const float* b, const float* c, float* out, uint32_t n);

@@ -182,13 +182,20 @@ __device__ __forceinline__ uint32_t fog_color(uint32_t c, uint32_t fogc, float f
 // faces; 3 and 4 lose to register pressure), 1 for small ones (where the kernel's latency, not its throughput, is what a frame waits for)
 template <int SETUP_FPT>
 __global__ __launch_bounds__(256) void k_setup(FrameParams fp, const B32Vertex* __restrict__ verts, const B32Face* __restrict__ faces,
-                                               const TexDesc* __restrict__ tex, const B32Light* __restrict__ lights,
+                                               const TexDesc* __restrict__ tex, const B32Light* __restrict__ lights_mem, LightSet lset,
                                                SurfRec* __restrict__ recs, float* __restrict__ shades, uint32_t* __restrict__ keys,
                                                uint32_t* __restrict__ spans, uint32_t* __restrict__ partials, Ctrl* __restrict__ ctrl,
                                                WireTri* __restrict__ wire) {
     __shared__ uint32_t wpart[4][6];
-    if (blockIdx.x == 0 && threadIdx.x < sizeof(Ctrl) / 4 && threadIdx.x != offsetof(Ctrl, sticky) / 4)
-        reinterpret_cast<uint32_t*>(ctrl)[threadIdx.x] = 0;                                // frame-start reset (no memset launch)
+    const B32Light* lights = fp.lights_inline ? lset.l : lights_mem;
+    if (blockIdx.x == 0) {
+        // frame-start reset (no memset launch).  If the previous frame was dropped (pair overflow / long list: nothing drawn) and this
+        // is a NEW frame rather than the host's redraw of it, that frame is lost for good: count it, b32_frame_finish reports it
+        const bool lost = !fp.redraw && (ctrl->pairs_overflow || ctrl->need_global_sort);
+        __syncthreads();
+        if (threadIdx.x < sizeof(Ctrl) / 4 && threadIdx.x != offsetof(Ctrl, sticky) / 4) reinterpret_cast<uint32_t*>(ctrl)[threadIdx.x] = 0;
+        if (threadIdx.x == 0 && lost) ctrl->sticky += 0x100u;
+    }
     // Every thread owns SETUP_FPT faces, 256 apart (a workgroup covers SETUP_FPT groups of 256 consecutive faces).  All of their
     // inputs -- the face words, then the three vertices each -- are requested before the first face is processed, so the second
     // face's two dependent memory latencies pass behind the ~900 VALU instructions of the first.
@@ -407,11 +414,11 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp, const B32Vertex* 
 }
 
 void launch_setup(hipStream_t s, const FrameParams& fp, const B32Vertex* verts, const B32Face* faces, const TexDesc* tex,
-                  const B32Light* lights, SurfRec* recs, float* shades, uint32_t* keys, uint32_t* spans, uint32_t* partials, Ctrl* ctrl,
-                  WireTri* wire) {
+                  const B32Light* lights, const LightSet& ls, SurfRec* recs, float* shades, uint32_t* keys, uint32_t* spans, uint32_t* partials,
+                  Ctrl* ctrl, WireTri* wire) {
     if (fp.nf == 0) return;
-    if (fp.nf >= 400000) hipLaunchKernelGGL(k_setup<2>, dim3((fp.nf + 511) / 512), dim3(256), 0, s, fp, verts, faces, tex, lights, recs, shades, keys, spans, partials, ctrl, wire);
-    else hipLaunchKernelGGL(k_setup<1>, dim3((fp.nf + 255) / 256), dim3(256), 0, s, fp, verts, faces, tex, lights, recs, shades, keys, spans, partials, ctrl, wire);
+    if (fp.nf >= 400000) hipLaunchKernelGGL(k_setup<2>, dim3((fp.nf + 511) / 512), dim3(256), 0, s, fp, verts, faces, tex, lights, ls, recs, shades, keys, spans, partials, ctrl, wire);
+    else hipLaunchKernelGGL(k_setup<1>, dim3((fp.nf + 255) / 256), dim3(256), 0, s, fp, verts, faces, tex, lights, ls, recs, shades, keys, spans, partials, ctrl, wire);
 }
 
 // ---------------------------------------------------------------- stage tap: project_fixed for n positions

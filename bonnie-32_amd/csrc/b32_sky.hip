@@ -176,7 +176,8 @@ __global__ void k_stars(const int32_t* __restrict__ cx, const int32_t* __restric
     const bool on = k == 0 || (k < 5 ? s >= 2 : s >= 3);
     for (uint32_t i = 0; i < n; ++i) {
         if (!on) continue;
-        const int x = cx[i] + dx[k], y = cy[i] + dy[k];
+        // `cx - 1`, `cx + 2` ... on i32 (render.rs:219-236): a release build wraps (INT_MAX + 2 is negative -> set_pixel_safe rejects it)
+        const int x = (int)((uint32_t)cx[i] + (uint32_t)dx[k]), y = (int)((uint32_t)cy[i] + (uint32_t)dy[k]);
         if (x < 0 || y < 0 || x >= (int)width || y >= (int)height || (uint32_t)y < band_y0 || (uint32_t)y >= band_y1) continue;
         uint32_t o = 0xFF000000u;
         for (int ch = 0; ch < 3; ++ch) {

@@ -102,7 +102,10 @@ using Fog = std::optional<std::tuple<float, float, float, Color>>;   // render.r
 class Framebuffer {
 public:
     size_t width = 0, height = 0;
-    Framebuffer(size_t w, size_t h, int device = 0) { check(b32_create(device, &ctx_), "b32_create"); resize(w, h); }
+    Framebuffer(size_t w, size_t h, int device = 0) {                       // Framebuffer::new, render.rs:18-25
+        check(b32_create(device, &ctx_), "b32_create");
+        check(b32_fb_new(ctx_, (uint32_t)w, (uint32_t)h), "Framebuffer::new"); width = w; height = h;
+    }
     ~Framebuffer() { b32_destroy(ctx_); }
     Framebuffer(const Framebuffer&) = delete;
     Framebuffer& operator=(const Framebuffer&) = delete;

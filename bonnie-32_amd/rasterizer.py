@@ -64,6 +64,10 @@ class Context:
     def set_profiling(self, level):
         _chk(self.lib.b32_set_profiling(self.h, level), "b32_set_profiling")
 
+    def set_async_depth(self, deep):
+        """b32_set_async_depth: 0 = safe (default), 1 = large-scene frames back to back, a dropped one is reported by finish()."""
+        _chk(self.lib.b32_set_async_depth(self.h, int(deep)), "b32_set_async_depth")
+
     def set_fragment_counting(self, on):
         _chk(self.lib.b32_set_fragment_counting(self.h, int(on)), "b32_set_fragment_counting")
 
@@ -116,8 +120,9 @@ class Framebuffer:
 
     def __init__(self, width, height, ctx: Context = None, device=0):
         self.ctx = ctx or Context(device)
-        self.width, self.height = 0, 0
-        self.resize(width, height)
+        # Framebuffer::new (render.rs:18-25): zero pixels and an f32::MAX z-buffer even when the ctx already held a frame of this size
+        _chk(self.ctx.lib.b32_fb_new(self.ctx.h, width, height), "fb_new")
+        self.width, self.height = width, height
         self.set_band(0, height)          # a new Framebuffer owns all its rows (a band set earlier on this ctx does not carry over)
 
     @staticmethod

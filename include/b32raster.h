@@ -31,6 +31,9 @@ extern "C" {
 #define B32_E_HIP         -4  /* HIP runtime failure (b32_last_hip_error has the code)      */
 #define B32_E_UNSUPPORTED -5  /* wireframe edge >= 2^30 px (i32 overflow in the reference); more than 65534 textures */
 #define B32_E_NO_DEVICE   -6  /* no gfx950 device / kernels missing: the product path never falls back to CPU   */
+#define B32_E_FRAME_DROPPED -7 /* deep asynchronous mode only (b32_set_async_depth): an EARLIER frame in flight ran out of buffer
+                                  space and drew nothing (its framebuffer kept the cleared / previous contents); the most recent
+                                  frame has been redrawn correctly */
 
 /* ---- enums mirrored as integers ------------------------------------------ */
 /* BlendMode, types.rs:1380-1388 */
@@ -167,7 +170,8 @@ int         b32_set_stream(b32_ctx* ctx, void* hip_stream);
 int         b32_synchronize(b32_ctx* ctx);
 
 /* ---- Framebuffer (render.rs:10-45) --------------------------------------- */
-int b32_fb_resize(b32_ctx* ctx, uint32_t width, uint32_t height);           /* Framebuffer::new/resize: zero-filled on change */
+int b32_fb_resize(b32_ctx* ctx, uint32_t width, uint32_t height);           /* Framebuffer::resize :27-34: zero-filled on change, no-op on equal dimensions */
+int b32_fb_new(b32_ctx* ctx, uint32_t width, uint32_t height);              /* Framebuffer::new :18-25: ALWAYS zero pixels and an f32::MAX z-buffer */
 int b32_fb_clear(b32_ctx* ctx, uint8_t r, uint8_t g, uint8_t b, uint8_t blend); /* Framebuffer::clear :36-45 (rows of the band only when b32_set_band is active) */
 int b32_fb_upload(b32_ctx* ctx, const uint8_t* rgba);                        /* host fb.pixels -> device */
 int b32_fb_download(b32_ctx* ctx, uint8_t* rgba);                            /* device -> host fb.pixels */
@@ -211,6 +215,17 @@ int b32_render_scene_15_async(b32_ctx* ctx,
                               const B32Camera* camera, const B32Settings* settings,
                               const B32Fog* fog /* nullable */);
 int b32_frame_finish(b32_ctx* ctx, B32Timings* out /* nullable */);
+/* How many frames of a LARGE scene (more than 8192 faces, or more than 2048 with a transparent pass) may be in flight.  Such a
+ * frame can run out of pair-buffer space (or need the global depth sort); it then draws nothing and must be redrawn by the host.
+ *   deep = 0 (default): safe.  Enqueueing another frame, or any call that reads or rebinds the framebuffer (b32_fb_download,
+ *            b32_zbuffer_download, b32_fb_upload, b32_fb_bind_device, b32_set_stream, b32_present_nearest), first settles the pending
+ *            frame (one host synchronisation, redraw if needed): no frame is ever lost.
+ *   deep = 1: throughput.  Frames are enqueued back to back with no host synchronisation (bench.py, parallel.py: static camera,
+ *            capacities settled by a warm-up frame).  Only the most recent frame can be redrawn; if an earlier one was dropped,
+ *            b32_frame_finish reports B32_E_FRAME_DROPPED -- never silently.  Consumers outside the library that read the bound
+ *            framebuffer between two frames (an RCCL gather on the same stream) must accept that contract.
+ * Frames of small meshes never overflow and are always enqueued without synchronisation. */
+int b32_set_async_depth(b32_ctx* ctx, int deep);
 
 /* Several resident scenes per context (scene.rs:112-261 draws room after room, asset part after asset part, onto one
  * framebuffer every frame): a slot owns one uploaded scene's device buffers.  b32_scene_swap exchanges the context's current

@@ -1231,13 +1231,14 @@ EXPORT void b32o_draw_star_diamond(uint8_t* pixels, uint32_t width, uint32_t hei
     set_pixel_rgb(&fb, cx, cy, rgb[0], rgb[1], rgb[2]);
     if (s >= 2) {
         uint8_t d[3]; for (int i = 0; i < 3; ++i) d[i] = f2u8_sat((float)rgb[i] * 0.7f);
-        set_pixel_rgb(&fb, cx - 1, cy, d[0], d[1], d[2]); set_pixel_rgb(&fb, cx + 1, cy, d[0], d[1], d[2]);
-        set_pixel_rgb(&fb, cx, cy - 1, d[0], d[1], d[2]); set_pixel_rgb(&fb, cx, cy + 1, d[0], d[1], d[2]);
+        /* i32 `cx - 1` etc.: release builds wrap (render.rs:219-222) */
+        set_pixel_rgb(&fb, wrap_add(cx, -1), cy, d[0], d[1], d[2]); set_pixel_rgb(&fb, wrap_add(cx, 1), cy, d[0], d[1], d[2]);
+        set_pixel_rgb(&fb, cx, wrap_add(cy, -1), d[0], d[1], d[2]); set_pixel_rgb(&fb, cx, wrap_add(cy, 1), d[0], d[1], d[2]);
     }
     if (s >= 3) {
         uint8_t d[3]; for (int i = 0; i < 3; ++i) d[i] = f2u8_sat((float)rgb[i] * 0.4f);
-        set_pixel_rgb(&fb, cx - 2, cy, d[0], d[1], d[2]); set_pixel_rgb(&fb, cx + 2, cy, d[0], d[1], d[2]);
-        set_pixel_rgb(&fb, cx, cy - 2, d[0], d[1], d[2]); set_pixel_rgb(&fb, cx, cy + 2, d[0], d[1], d[2]);
+        set_pixel_rgb(&fb, wrap_add(cx, -2), cy, d[0], d[1], d[2]); set_pixel_rgb(&fb, wrap_add(cx, 2), cy, d[0], d[1], d[2]);
+        set_pixel_rgb(&fb, cx, wrap_add(cy, -2), d[0], d[1], d[2]); set_pixel_rgb(&fb, cx, wrap_add(cy, 2), d[0], d[1], d[2]);
     }
 }
 

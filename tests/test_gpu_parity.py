@@ -339,6 +339,97 @@ def test_full_size_c3_properties(gpu_ctx, oracle):
     assert np.array_equal(assembled, exp) and frags == etm.fragments
 
 
+def test_async_frames_are_never_silently_dropped(oracle):
+    """A large scene's frame can run out of pair-buffer space and then draws nothing until the host redraws it.  With frames enqueued
+    back to back and a camera that moves (far: tiny triangles -> few pairs; near: ~9 tiles per face -> overflow of the initial
+    buffers) the middle frame of  far, near, far  (no clear in between: read-modify-write) must not get lost:
+      safe mode (default): enqueueing the next frame settles the pending one -> the result equals the oracle's three draws;
+      deep mode (b32_set_async_depth(1)): no synchronisation between frames; the lost frame is REPORTED by b32_frame_finish
+      (B32_E_FRAME_DROPPED), the most recent frame is intact, and after that report the context works normally again."""
+    from bonnie32_amd import rasterizer as R
+    sc = scenegen.make_scene("C3", n_tris=20_000, width=640, height=480, bbox_px=3000.0, seed=321)
+    far = b32.Camera(position=(0.0, 0.0, -30000.0)); near = sc.camera
+    ofb = oracle.Framebuffer(sc.width, sc.height); ofb.clear(sc.clear_color)
+    for cam in (far, near, far):
+        assert oracle.render_mesh_15(ofb, sc.vertices, sc.faces, sc.textures, cam, sc.settings)[0] == 0
+    only_far = oracle.Framebuffer(sc.width, sc.height); only_far.clear(sc.clear_color)
+    for cam in (far, far):
+        oracle.render_mesh_15(only_far, sc.vertices, sc.faces, sc.textures, cam, sc.settings)
+    assert not np.array_equal(only_far.pixels, ofb.pixels)
+    # ---- safe mode, fresh context (pair buffers at their initial size)
+    ctx = R.Context(0)
+    fb = R.Framebuffer(sc.width, sc.height, ctx); fb.clear(sc.clear_color)
+    rs = R.ResidentScene(fb, sc.vertices, sc.faces, sc.textures)
+    for cam in (far, near, far):
+        rs.render_async(cam, sc.settings)
+    got = fb.pixels                                   # (the download settles the last frame too)
+    assert np.array_equal(got, ofb.pixels), f"{int((got != ofb.pixels).sum())} bytes differ"
+    tm = rs.finish()
+    # a download right after an overflowing frame shows the redrawn frame, never the cleared one
+    ctx2 = R.Context(0)
+    fb2 = R.Framebuffer(sc.width, sc.height, ctx2); fb2.clear(sc.clear_color)
+    rs2 = R.ResidentScene(fb2, sc.vertices, sc.faces, sc.textures)
+    rs2.render_async(near, sc.settings)
+    o2 = oracle.Framebuffer(sc.width, sc.height); o2.clear(sc.clear_color)
+    oracle.render_mesh_15(o2, sc.vertices, sc.faces, sc.textures, near, sc.settings)
+    assert np.array_equal(fb2.pixels, o2.pixels)
+    rs2.finish()
+    # ---- deep mode, fresh context
+    ctx3 = R.Context(0)
+    ctx3.set_async_depth(1)
+    fb3 = R.Framebuffer(sc.width, sc.height, ctx3); fb3.clear(sc.clear_color)
+    rs3 = R.ResidentScene(fb3, sc.vertices, sc.faces, sc.textures)
+    for cam in (far, near, far):
+        rs3.render_async(cam, sc.settings)
+    with pytest.raises(R.B32Error) as e:
+        rs3.finish()
+    assert e.value.code == b32.abi.B32_E_FRAME_DROPPED
+    assert np.array_equal(fb3.pixels, only_far.pixels)            # the lost frame drew nothing, the others are intact
+    fb3.clear(sc.clear_color)
+    rs3.render_async(near, sc.settings)
+    rs3.finish()                                                    # the most recent frame IS redrawn (buffers grown), no error left over
+    assert np.array_equal(fb3.pixels, o2.pixels)
+
+
+def test_framebuffer_new_on_a_reused_context(gpu_ctx, oracle):
+    """Framebuffer::new (render.rs:18-25) gives zero pixels and an f32::MAX z-buffer; Framebuffer::resize to the same size keeps
+    everything (render.rs:27-34).  A second Framebuffer of the same size on a reused context must not inherit the first one's frame."""
+    from bonnie32_amd import rasterizer as R
+    sc = SCENES["C1:zbuf"]()
+    fb = R.Framebuffer(sc.width, sc.height, gpu_ctx); fb.clear(sc.clear_color)
+    R.render_mesh_15(fb, sc.vertices, sc.faces, sc.textures, sc.camera, sc.settings)
+    drawn, zdrawn = fb.pixels, fb.zbuffer
+    assert drawn.any() and (zdrawn != np.finfo(np.float32).max).any()
+    fb.resize(sc.width, sc.height)                                   # same dimensions: no-op
+    assert np.array_equal(fb.pixels, drawn) and np.array_equal(fb.zbuffer, zdrawn)
+    fb2 = R.Framebuffer(sc.width, sc.height, gpu_ctx)                # new: zeroed, depth reset
+    assert not fb2.pixels.any() and np.all(fb2.zbuffer == np.finfo(np.float32).max)
+    ofb = oracle.Framebuffer(sc.width, sc.height)                    # (no clear: Framebuffer::new contents)
+    oracle.render_mesh_15(ofb, sc.vertices, sc.faces, sc.textures, sc.camera, sc.settings)
+    R.render_mesh_15(fb2, sc.vertices, sc.faces, sc.textures, sc.camera, sc.settings)
+    assert np.array_equal(fb2.pixels, ofb.pixels) and np.array_equal(fb2.zbuffer.view(np.uint32), ofb.zbuffer.view(np.uint32))
+
+
+def test_light_lists_change_between_async_frames(gpu_ctx, oracle):
+    """Per-room light lists (scene.rs draws room after room, each with its own lights): up to 8 lights travel in the kernel arguments,
+    longer lists through a device buffer; either way consecutive asynchronous frames with different lights must each use their own."""
+    from bonnie32_amd import rasterizer as R
+    sc = scenegen.make_scene("C1", variant="gouraud", seed=88, bbox_px=400.0)
+    sc.settings.use_zbuffer = True
+    mk = lambda k: [b32.Light.point((300.0 * i - 600.0, 100.0 * (i % 3), 1500.0 + 200.0 * i), 6000.0, 0.4 + 0.1 * i) for i in range(k)]
+    lists = [mk(1), mk(8), mk(9), mk(3), mk(12), mk(2)]
+    ofb = oracle.Framebuffer(sc.width, sc.height); ofb.clear(sc.clear_color)
+    fb = R.Framebuffer(sc.width, sc.height, gpu_ctx); fb.clear(sc.clear_color)
+    rs = R.ResidentScene(fb, sc.vertices, sc.faces, sc.textures)
+    for i, ls in enumerate(lists):
+        sc.settings.lights = ls
+        cam = b32.Camera(position=(10.0 * i, -5.0 * i, 30.0 * i))
+        assert oracle.render_mesh_15(ofb, sc.vertices, sc.faces, sc.textures, cam, sc.settings)[0] == 0
+        rs.render_async(cam, sc.settings)
+    rs.finish()
+    assert np.array_equal(fb.pixels, ofb.pixels) and np.array_equal(fb.zbuffer.view(np.uint32), ofb.zbuffer.view(np.uint32))
+
+
 def test_clut_indices_past_the_palette(gpu_ctx, oracle):
     """Clut::lookup (types.rs:390-397) returns 0x0000 for an index past the palette: a 4-bit CLUT (16 entries) under an atlas whose
     bytes run up to 255.  The device expansion of b32_scene_upload_indexed must give the texels of the oracle's expansion (and of

@@ -12,6 +12,7 @@ ofb = O.Framebuffer(W, H); ofb.clear(sc.clear_color)
 O.render_mesh_15(ofb, sc.vertices, sc.faces, sc.textures, sc.camera, sc.settings)
 dev = torch.device("cuda", 0); torch.cuda.set_device(0)
 ctx = R.Context(0)
+ctx.set_async_depth(1)      # timing loops: frames back to back (a dropped frame would be reported by finish())
 stream = torch.cuda.Stream(device=dev) if os.environ.get('OWN_TORCH_STREAM') else torch.cuda.current_stream(dev)
 torch.cuda.set_stream(stream)
 ctx.set_stream(stream.cuda_stream)

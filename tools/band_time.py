@@ -4,6 +4,7 @@ sys.path.insert(0, ".")
 from bonnie32_amd import rasterizer as R, scenegen, parallel
 sc = scenegen.make_scene("C3")
 ctx = R.Context(0)
+ctx.set_async_depth(1)      # timing loops: frames back to back (a dropped frame would be reported by finish())
 fb = R.Framebuffer(sc.width, sc.height, ctx)
 rs = R.ResidentScene(fb, sc.vertices, sc.faces, indexed_textures=sc.indexed_textures)
 for N in (1, 2, 4, 8):

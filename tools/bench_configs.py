@@ -9,6 +9,7 @@ from bonnie32_amd import rasterizer as R, scenegen
 from oracle import oracle as O
 
 ctx = R.Context(0)
+ctx.set_async_depth(1)      # timing loops: frames back to back (a dropped frame would be reported by finish())
 rows = []
 for cfg in ["C1", "C2", "C3", "C5"]:
     sc = scenegen.make_scene(cfg)

@@ -11,6 +11,7 @@ from oracle import oracle as O
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 ctx = R.Context(0)
+ctx.set_async_depth(1)      # timing loops: frames back to back (a dropped frame would be reported by finish())
 base = scenegen.make_scene("C3", n_tris=N, variant="gouraud")
 tex8 = [b32.Texture.from_texture15(t) for t in base.textures]
 MODES = [

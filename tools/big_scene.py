@@ -8,6 +8,7 @@ sc = scenegen.make_scene("C3", n_tris=N, seed=123)
 t0 = time.time(); ofb = O.Framebuffer(sc.width, sc.height); ofb.clear(sc.clear_color)
 rc, otm = O.render_mesh_15(ofb, sc.vertices, sc.faces, sc.textures, sc.camera, sc.settings); tc = time.time() - t0
 ctx = R.Context(0)
+ctx.set_async_depth(1)      # timing loops: frames back to back (a dropped frame would be reported by finish())
 fb = R.Framebuffer(sc.width, sc.height, ctx)
 rs = R.ResidentScene(fb, sc.vertices, sc.faces, sc.textures)
 for counting in (0, 1):

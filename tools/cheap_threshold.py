@@ -10,6 +10,7 @@ if len(sys.argv) > 1:
     t = sc.indexed_textures[0]
     t.indices = (t.indices % K).astype(np.uint8)          # index 0 -> CLUT entry 0 = transparent: 1/K of the texels
     ctx = R.Context(0)
+    ctx.set_async_depth(1)      # timing loops: frames back to back (a dropped frame would be reported by finish())
     fb = R.Framebuffer(sc.width, sc.height, ctx)
     rs = R.ResidentScene(fb, sc.vertices, sc.faces, indexed_textures=sc.indexed_textures)
     fb.clear(sc.clear_color); rs.render(sc.camera, sc.settings)

@@ -5,6 +5,7 @@ from bonnie32_amd import rasterizer as R, scenegen
 import bonnie32_amd as b32
 sc = scenegen.make_scene("C3")
 ctx = R.Context(0)
+ctx.set_async_depth(1)      # timing loops: frames back to back (a dropped frame would be reported by finish())
 fb = R.Framebuffer(sc.width, sc.height, ctx)
 rs = R.ResidentScene(fb, sc.vertices, sc.faces, indexed_textures=sc.indexed_textures)
 for name, st, counting in (("painter CHEAP", sc.settings, 0), ("painter EXACT", sc.settings, 1), ("z-buffer EXACT", b32.RasterSettings(shading=0, lights=[], backface_wireframe=False), 1)):

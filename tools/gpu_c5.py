@@ -12,6 +12,7 @@ ofb = O.Framebuffer(sc.width, sc.height); ofb.clear(sc.clear_color)
 t0 = time.time(); rc, otm, d = O.render_mesh_15(ofb, sc.vertices, sc.faces, sc.textures, sc.camera, sc.settings, dump=True); tc = time.time() - t0
 print(f"oracle {cfg}: {tc:.1f}s drawn={otm.triangles_drawn} frags={otm.fragments}")
 ctx = R.Context(0)
+ctx.set_async_depth(1)      # timing loops: frames back to back (a dropped frame would be reported by finish())
 fb = R.Framebuffer(sc.width, sc.height, ctx)
 rs = R.ResidentScene(fb, sc.vertices, sc.faces, indexed_textures=sc.indexed_textures)
 for mode in (1, 0):

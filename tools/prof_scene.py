@@ -9,6 +9,7 @@ sc = scenegen.make_scene(cfg, variant=variant)
 if len(sys.argv) > 3:
     sc.settings.use_zbuffer = True
 ctx = R.Context(0)
+ctx.set_async_depth(1)      # timing loops: frames back to back (a dropped frame would be reported by finish())
 fb = R.Framebuffer(sc.width, sc.height, ctx)
 rs = R.ResidentScene(fb, sc.vertices, sc.faces, sc.textures)
 for i in range(12):

@@ -5,6 +5,7 @@ import sys, time
 sys.path.insert(0, ".")
 from bonnie32_amd import rasterizer as R, scenegen, parallel
 ctx = R.Context(0)
+ctx.set_async_depth(1)      # timing loops: frames back to back (a dropped frame would be reported by finish())
 base = None
 for N in (1, 2, 4, 8):
     sc = scenegen.make_scene("C3", n_tris=125000 * N)
