@@ -2,14 +2,20 @@
 """bench.py — headline benchmark of the bonnie-32 rasterizer hot path on MI355X.
 
 One step = one whole frame of the hot path over a synthetic scene whose inputs are already resident in HBM:
-Framebuffer::clear + render_mesh_15 (vertex transform + snap, cull/setup, painter's sort, tile binning, textured
+Framebuffer::clear + render_mesh_15 (vertex transform + snap, cull/setup, painter's visibility, tile binning, textured
 RGB555-dither fill) and, for N > 1, the gather of the screen bands to rank 0.
 Workload at N = 1: BASELINE.json configs[2] "C3" — 2560x1920, 1M-triangle synthetic scene, 8-bit 256x256 atlas.
 
-Prints ONE JSON line on rank 0 (see the driver contract), with `roofline` (dominant kernel vs the 8 TB/s HBM peak)
-and `cpu_baseline` (the CPU oracle = C port of the reference, 1 thread, timed on this box's host cores).
+Prints ONE JSON line on rank 0 (see the driver contract), with
+  roofline       dominant kernel vs the 8 TB/s HBM peak (HIP events on the kernel's own stream, inside the timed region)
+  cpu_baseline   the CPU port of the reference (oracle/, release-profile build, 1 thread) timed on this box's host cores
+  cpu_all_cores  the same port threaded (transform split by vertex range, draw split by row band)
+  configs        (N = 1) the other BASELINE configs -- C1, C2, C5 -- each with ms/frame, Mtri/s, Mpix/s, frame-level roofline
+                 fraction and a framebuffer SHA-256 checked against tests/golden/hashes.json
+  protocol       SURVEY 8d extras: median of the per-step times, output-pixel rate, H2D of the scene, D2H of the frame
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -21,6 +27,16 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def csrc_digest():
+    """SHA-256 over the kernel sources: identifies the build a PMC measurement belongs to (profiles/pmc_traffic.json)."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "bonnie-32_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -29,6 +45,7 @@ def main():
     ap.add_argument("--config", default="C3", help="scene config of bonnie32_amd.scenegen (C1,C2,C3,C5)")
     ap.add_argument("--tris", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the C1 / C2 / C5 side measurements (profiling runs)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--check", action="store_true", help="also verify the final frame against the oracle (slow at C3)")
     ap.add_argument("--weak-series", action="store_true",
@@ -70,6 +87,7 @@ def main():
     if world > 1:
         dist.barrier()
     from bonnie32_amd import rasterizer as R, scenegen, parallel
+    HASHES = json.load(open(os.path.join(ROOT, "tests", "golden", "hashes.json")))
 
     sc = scenegen.make_scene(args.config, n_tris=args.tris)
     W, H, NF = sc.width, sc.height, sc.n_tris
@@ -87,8 +105,13 @@ def main():
     fb.bind_device(frame.data_ptr(), W, H)
     y0, y1 = parallel.band_rows(H, world, rank)
     fb.set_band(y0, y1)
-    # inputs resident in HBM before the timed region (index atlas + CLUT are expanded on the device)
+    # inputs resident in HBM before the timed region (index atlas + CLUT are expanded on the device); the upload is timed on its own
+    torch.cuda.synchronize(dev)
+    u0 = time.perf_counter()
     rs = R.ResidentScene(fb, sc.vertices, sc.faces, indexed_textures=sc.indexed_textures)
+    torch.cuda.synchronize(dev)
+    h2d_ms = (time.perf_counter() - u0) * 1e3
+    h2d_bytes = sc.vertices.nbytes + sc.faces.nbytes + sum(t.indices.nbytes + t.clut.nbytes for t in sc.indexed_textures)
 
     def step(first=False):
         fb.clear(sc.clear_color)
@@ -196,6 +219,25 @@ def main():
             sets = sets[:1]
             step(); rs.finish()
 
+    rdev = dev if args.dist_backend == "nccl" else torch.device("cpu")
+
+    def max_over_ranks(seconds):
+        t = torch.tensor([seconds], dtype=torch.float64, device=rdev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # ---- N > 1 only: the frame LATENCY beside the pipelined throughput -- K frames, each gathered before the next one starts
+    sync_ms = None
+    if pipelined:
+        sync_all()
+        s0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync_all()
+        sync_ms = max_over_ranks(time.perf_counter() - s0) / args.steps * 1e3
+        rs.finish()
+
     # ---- timed region: exactly K steps, HIP events around the dominant kernel on the stream it runs on
     ctx.set_profiling(1)
     sync_all()
@@ -218,15 +260,29 @@ def main():
     cover_ms = ctx.last_kernel_times().get("cover", None)     # HIP events around k_cover on the stream it runs on
     ctx.set_profiling(0)
 
-    rdev = dev if args.dist_backend == "nccl" else torch.device("cpu")
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=rdev)
     frags = torch.tensor([float(exact_fragments)], dtype=torch.float64, device=rdev)
     if world > 1:
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
         dist.all_reduce(frags, op=dist.ReduceOp.SUM)
-    elapsed = float(elapsed.item())
+    elapsed = max_over_ranks(t1 - t0)
     fragments = int(frags.item())
     ms_per_step = elapsed / args.steps * 1e3
+
+    # ---- SURVEY 8d protocol extras (untimed region): per-step device times -> median; D2H of the finished frame
+    per_step = []
+    if world == 1:
+        n_med = max(args.steps, 20)
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_med + 1)]
+        torch.cuda.synchronize(dev)
+        for i in range(n_med):
+            evs[i].record(stream)
+            step()
+        evs[n_med].record(stream)
+        rs.finish()
+        torch.cuda.synchronize(dev)
+        per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(n_med))
+    d0 = time.perf_counter()
+    final_host = fb.pixels if rank == 0 else None               # b32_fb_download: the presenter's copy (game/renderer.rs:179)
+    d2h_ms = (time.perf_counter() - d0) * 1e3
 
     # per-phase device times (separate untimed pass, events around every phase)
     ctx.set_profiling(2)
@@ -239,7 +295,7 @@ def main():
     # ---- weak-scaling point (north_star's >= 0.7 target): N x 125 k triangles on the same 2560x1920 frame, so every
     # rank's band keeps the fragments and binned triangles of the 1-GPU 125 k scene.  Reported beside the headline (which is the
     # fixed C3 scene, i.e. strong scaling, as `metric` states); raw times only, the driver derives efficiencies.
-    final_frame = frame.cpu().numpy() if (args.check and rank == 0) else None      # the C3 frame, before the weak series redraws
+    final_frame = final_host if (args.check and rank == 0) else None      # the C3 frame, before the weak series redraws
     weak = None
     if world > 1 or args.weak_series:
         per_gpu = 125000
@@ -290,10 +346,7 @@ def main():
         wrs.finish()
         if pipelined:
             wsets[1][1].finish()
-        wel = torch.tensor([w1 - w0], dtype=torch.float64, device=rdev)
-        if world > 1:
-            dist.all_reduce(wel, op=dist.ReduceOp.MAX)
-        w_ms = float(wel.item()) / args.steps * 1e3
+        w_ms = max_over_ranks(w1 - w0) / args.steps * 1e3
         # the 1-GPU point of the same series, on rank 0's GPU alone: 125 k triangles, whole frame, no gather
         one_ms = None
         if rank == 0:
@@ -317,6 +370,46 @@ def main():
                     "value": round(per_gpu * world / (w_ms * 1e-3) / 1e6, 3), "unit": "Mtriangles/s",
                     "one_gpu_ms_per_step": round(one_ms, 5), "one_gpu_value": round(per_gpu / (one_ms * 1e-3) / 1e6, 3)}
 
+    # ---- the other BASELINE configs on this GPU (N = 1): C1 and C2 (320x240) and C5 (heavy overdraw), same protocol, frames checked
+    # against the committed hashes
+    side = None
+    if world == 1 and rank == 0 and not args.no_configs and args.config == "C3" and args.tris is None:
+        side = {}
+        for name in ("C1", "C2", "C5"):
+            s2 = scenegen.make_scene(name)
+            c2 = R.Context(local_rank)
+            c2.set_async_depth(1)
+            c2.set_stream(stream.cuda_stream)
+            f2 = R.Framebuffer(s2.width, s2.height, c2)
+            r2 = R.ResidentScene(f2, s2.vertices, s2.faces, indexed_textures=s2.indexed_textures)
+            c2.set_fragment_counting(1)
+            f2.clear(s2.clear_color); r2.render_async(s2.camera, s2.settings, s2.fog)
+            tm2 = r2.finish()
+            c2.set_fragment_counting(0)
+            for _ in range(5):
+                f2.clear(s2.clear_color); r2.render_async()
+            r2.finish()
+            k2 = max(args.steps, 20) * (4 if name != "C5" else 1)
+            torch.cuda.synchronize(dev)
+            q0 = time.perf_counter()
+            for _ in range(k2):
+                f2.clear(s2.clear_color); r2.render_async()
+            torch.cuda.synchronize(dev)
+            ms2 = (time.perf_counter() - q0) / k2 * 1e3
+            r2.finish()
+            sha = hashlib.sha256(f2.pixels).hexdigest()
+            tex2 = sum(t.width * t.height * 2 for t in s2.textures)
+            alg2 = 36 * len(s2.vertices) + 20 * s2.n_tris + 16 * tm2.triangles_drawn + 8 * s2.width * s2.height + tex2
+            side[name] = {"workload": f"{s2.n_tris} tris @ {s2.width}x{s2.height}", "ms_per_frame": round(ms2, 5), "frames": k2,
+                          "mtriangles_per_s": round(s2.n_tris / (ms2 * 1e-3) / 1e6, 2),
+                          "mpixels_per_s": round(tm2.fragments / (ms2 * 1e-3) / 1e6, 2),
+                          "output_mpixels_per_s": round(s2.width * s2.height / (ms2 * 1e-3) / 1e6, 2),
+                          "triangles_drawn": tm2.triangles_drawn, "fragments": tm2.fragments,
+                          "frame_algorithmic_bytes": alg2, "frame_frac": round(alg2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                          "sha256": sha[:16], "bit_exact_vs_committed_hash": sha == HASHES[name]["sha256"] and
+                          (tm2.triangles_drawn, tm2.fragments) == (HASHES[name]["triangles_drawn"], HASHES[name]["fragments"])}
+            del r2, f2, c2
+
     if rank == 0:
         mtri = NF / (ms_per_step * 1e-3) / 1e6
         mpix = fragments / (ms_per_step * 1e-3) / 1e6
@@ -331,15 +424,24 @@ def main():
         if cover_ms:
             alg_cover = 72 * tm.tile_pairs + 16 * tm.triangles_drawn + 4 * W * (y1 - y0) + tex_bytes
             ach = alg_cover / (cover_ms * 1e-3) / 1e9
-            traffic = None
+            # HBM traffic of the dominant kernel: PMC counters need rocprofv3 around the process, so this is the per-launch figure of
+            # the committed PMC passes -- reported only when those passes were taken from THIS build of the kernels (digest over the
+            # kernel sources), null otherwise; `traffic_source` says which
+            traffic, tsrc = None, None
             tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(tpath):
+            if os.path.exists(tpath) and world == 1:
                 try:
-                    traffic = json.load(open(tpath)).get(f"{args.config}:k_cover") if world == 1 else None   # measured for the whole frame on 1 GPU
-                except Exception:
+                    tj = json.load(open(tpath))
+                    e = tj.get(f"{args.config}:k_cover")
+                    if isinstance(e, dict):
+                        same = e.get("csrc_digest") == csrc_digest()
+                        traffic = e.get("bytes") if same else None
+                        tsrc = {"file": e.get("file"), "csrc_digest": e.get("csrc_digest"), "this_build": csrc_digest(), "same_build": same,
+                                "measured_in_this_run": False, "stale_bytes": None if same else e.get("bytes")}
+                except Exception:                                   # noqa: BLE001
                     traffic = None
             roofline = {"kernel": "k_cover", "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+                        "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": tsrc,
                         "kernel_ms": round(cover_ms, 4), "algorithmic_bytes": alg_cover, "units": {"tile_pairs": tm.tile_pairs, "surfaces": tm.triangles_drawn, "pixels": W * (y1 - y0)},
                         "frame_algorithmic_bytes": alg_frame,
                         "frame_frac": round(alg_frame / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
@@ -352,29 +454,37 @@ def main():
             while t_cpu < args.cpu_seconds and reps < 50:
                 ofb.clear(sc.clear_color)
                 c0 = time.perf_counter()
-                rc, otm = O.render_mesh_15(ofb, sc.vertices, sc.faces, sc.textures, sc.camera, sc.settings, sc.fog)
+                rc, otm = O.render_mesh_15(ofb, sc.vertices, sc.faces, sc.textures, sc.camera, sc.settings, sc.fog, fast=True)
                 t_cpu += time.perf_counter() - c0
                 reps += 1
             per = t_cpu / reps
+            want = HASHES.get(args.config, {}).get("sha256") if args.tris is None else None
             cpu = {"value": round(NF / per / 1e6, 4), "unit": "Mtriangles/s", "cores": 1, "kind": "port",
                    "mpixels_per_s": round(otm.fragments / per / 1e6, 3), "ms_per_frame": round(per * 1e3, 2),
+                   "build": "gcc -O3 -flto -ffp-contract=off -msse2 (the reference's release profile, Cargo.toml:52-54; oracle/Makefile: libb32oracle_fast.so)",
+                   "frame_identical_to_checker_hash": (hashlib.sha256(ofb.pixels).hexdigest() == want) if want else None,
                    "sample": f"{reps} full frames of the same {args.config} scene ({NF} tris @ {W}x{H}), oracle/b32_oracle.c, 1 thread"}
-            # the "fair CPU" variant of SURVEY 8d beside it: the same port on all host cores, one row band per process (transform, cull
-            # and sort replicated in every process, like on the GPU ranks; the reference itself is single-threaded)
+            # the "fair CPU" variant of SURVEY 8d beside it: the same port threaded inside one process -- the per-vertex transform split
+            # by vertex range, cull / setup / sort once, the draw split by row band (the reference itself is single-threaded)
             try:
-                # (more processes are not always faster: on the GPU box 16 row bands take 342 ms, 32 take 783 -- the replicated part is
-                # memory-bound -- so a few counts are tried and the fastest is the baseline)
                 ncpu = os.cpu_count() or 1
                 best = None
-                for cand in sorted({max(1, min(c, ncpu, H)) for c in (8, 16, 32)}):
-                    t_c, frame_c = O.render_all_cores(sc, cand, reps=2)
-                    if best is None or t_c < best[0]:
-                        best = (t_c, frame_c, cand)
+                for cand in sorted({max(1, min(c, ncpu, H)) for c in (8, 16, 32, 64, 128)}):
+                    afb = O.Framebuffer(W, H)
+                    ts = []
+                    for _ in range(2):
+                        afb.clear(sc.clear_color)
+                        a0 = time.perf_counter()
+                        O.render_mesh_15(afb, sc.vertices, sc.faces, sc.textures, sc.camera, sc.settings, sc.fog, fast=True, threads=cand)
+                        ts.append(time.perf_counter() - a0)
+                    if best is None or min(ts) < best[0]:
+                        best = (min(ts), afb.pixels.copy(), cand)
                 t_all, frame_all, cores = best
                 cpu_all = {"value": round(NF / t_all / 1e6, 4), "unit": "Mtriangles/s", "cores": cores, "kind": "port",
                            "mpixels_per_s": round(otm.fragments / t_all / 1e6, 3), "ms_per_frame": round(t_all * 1e3, 2),
                            "identical_to_single_core_frame": bool(np.array_equal(frame_all, ofb.pixels)),
-                           "sample": f"2 frames of the same scene, {cores} processes x one row band each (slowest band; fastest of 8 / 16 / 32 processes on {ncpu} host CPUs), oracle/b32_oracle.c"}
+                           "sample": f"best of 2 frames of the same scene, {cores} threads in one process (transform split by vertex range, cull/setup/sort once, "
+                                     f"draw split by row band; fastest of 8..128 threads on {ncpu} host CPUs), oracle/b32_oracle.c release-profile build"}
             except Exception as e:                                  # noqa: BLE001 -- an extra, never a reason to lose the bench line
                 cpu_all = {"error": repr(e)}
         if args.check:
@@ -388,10 +498,13 @@ def main():
                 bad = (got.reshape(H, W, 4) != cfb.pixels.reshape(H, W, 4)).any(axis=2)
                 rows = np.nonzero(bad.any(axis=1))[0]
                 print(f"#   {int(bad.sum())} pixels differ, rows {rows.min()}..{rows.max()} ({len(rows)} rows)", file=sys.stderr)
+        sha = hashlib.sha256(final_host).hexdigest()
+        want = HASHES.get(args.config, {}).get("sha256") if args.tris is None else None
         line = {
             "metric": "Mtriangles/s + Mpixels/s, 1M-tri synthetic scene @ 2560x1920",
             "value": round(mtri, 3), "unit": "Mtriangles/s",
             "mpixels_per_s": round(mpix, 2),
+            "output_mpixels_per_s": round(W * H / (ms_per_step * 1e-3) / 1e6, 2),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 5), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32+i32 (exact-order f32 setup/barycentrics, integer snap and RGB555 colour tail)",
@@ -399,10 +512,18 @@ def main():
             "config": {"workload": f"{args.config}: {NF} tris @ {W}x{H}, 256x256 8-bit atlas, affine+snap+RGB555 dither, painter's",
                        "triangles_drawn": tm.triangles_drawn, "fragments": fragments,
                        "parallelism": (f"screen bands x{world}, RCCL gather " + ("overlapped with the next frame (two framebuffers)" if pipelined else "after every frame")) if world > 1 else "single GPU"},
+            "frame_sha256": sha[:16], "bit_exact_vs_committed_hash": (sha == want) if want else None,
+            "protocol": {"ms_per_step_median": round(per_step[len(per_step) // 2], 5) if per_step else None,
+                         "ms_per_step_min": round(per_step[0], 5) if per_step else None,
+                         "median_over": len(per_step), "median_note": "HIP events between consecutive steps on the frame's stream (separate pass)",
+                         "h2d_ms": round(h2d_ms, 3), "h2d_bytes": h2d_bytes, "d2h_ms": round(d2h_ms, 3), "d2h_bytes": W * H * 4,
+                         "sync_gather_ms_per_step": round(sync_ms, 5) if sync_ms is not None else None},
             "phases_ms": {k: round(v, 4) for k, v in phases.items()},
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
+        if side is not None:
+            line["configs"] = side
         if weak is not None:
             line["weak_series"] = weak
         if cpu_all is not None:

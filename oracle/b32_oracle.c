@@ -22,6 +22,7 @@
  */
 #include "../include/b32raster.h"
 #include <math.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -148,6 +149,11 @@ EXPORT const char* b32o_constant_name(uint32_t i) {
  * ARE drawn hold exactly the values of the full-frame walk.  Default: the whole frame. */
 static uint32_t g_band_y0 = 0, g_band_y1 = 0xFFFFFFFFu;
 EXPORT void b32o_set_row_band(uint32_t y0, uint32_t y1) { g_band_y0 = y0; g_band_y1 = y1; }
+/* Threads of the all-cores CPU baseline inside ONE process (bench.py cpu_all_cores): the per-vertex transform is split by vertex
+ * range, cull / setup / sort run once, and the draw phase gives every thread a band of rows (same mechanism as above, per thread), all
+ * threads walking the one sorted surface list.  1 = the reference's own single-threaded schedule (default, and what the checker uses). */
+static int g_threads = 1;
+EXPORT void b32o_set_threads(int n) { g_threads = n < 1 ? 1 : (n > 256 ? 256 : n); }
 
 /* ------------------------------------------------------------------ Rust cast / float helpers */
 static inline int32_t f2i32_sat(float f) {
@@ -519,6 +525,7 @@ typedef struct {
     float*   zbuffer;       /* may be NULL when !use_zbuffer */
     uint32_t width, height;
     uint64_t fragments;
+    uint32_t band_y0, band_y1;   /* rows this FB view draws (all-cores baseline); the whole frame by default */
 } FB;
 
 /* Framebuffer::set_pixel_15, render.rs:445-454 */
@@ -598,10 +605,10 @@ static int rasterize_triangle_15(FB* fb, const Surface* s, const B32Texture15* t
     float w0_row = a0 * (start_x - v3_.x) + b0 * (start_y - v3_.y);                              /* :1517 */
     float w1_row = a1 * (start_x - v3_.x) + b1 * (start_y - v3_.y);                              /* :1518 */
 
-    if (max_y <= g_band_y0 || min_y >= g_band_y1) return B32_OK;      /* (all-cores baseline) no row of this triangle is ours */
+    if (max_y <= fb->band_y0 || min_y >= fb->band_y1) return B32_OK;  /* (all-cores baseline) no row of this triangle is ours */
     for (uint64_t y = min_y; y < max_y; ++y) {                                                   /* :1530 */
         float w0 = w0_row, w1 = w1_row;
-        for (uint64_t x = (y >= g_band_y0 && y < g_band_y1) ? min_x : max_x; x < max_x; ++x) {
+        for (uint64_t x = (y >= fb->band_y0 && y < fb->band_y1) ? min_x : max_x; x < max_x; ++x) {
             float bc_x = w0 * inv_area;
             float bc_y = w1 * inv_area;
             float bc_z = 1.0f - bc_x - bc_y;
@@ -777,10 +784,10 @@ static int rasterize_triangle8(FB* fb, const Surface* s, const B32Texture* textu
     float start_x = (float)min_x, start_y = (float)min_y;
     float w0_row = a0 * (start_x - v3_.x) + b0 * (start_y - v3_.y);                              /* :1277-1278 */
     float w1_row = a1 * (start_x - v3_.x) + b1 * (start_y - v3_.y);
-    if (max_y <= g_band_y0 || min_y >= g_band_y1) return B32_OK;
+    if (max_y <= fb->band_y0 || min_y >= fb->band_y1) return B32_OK;
     for (uint64_t y = min_y; y < max_y; ++y) {
         float w0 = w0_row, w1 = w1_row;
-        for (uint64_t x = (y >= g_band_y0 && y < g_band_y1) ? min_x : max_x; x < max_x; ++x) {
+        for (uint64_t x = (y >= fb->band_y0 && y < fb->band_y1) ? min_x : max_x; x < max_x; ++x) {
             float bc_x = w0 * inv_area, bc_y = w1 * inv_area;
             float bc_z = 1.0f - bc_x - bc_y;
             const float ERR = K_ERR8;
@@ -855,7 +862,7 @@ static int rasterize_triangle8(FB* fb, const Surface* s, const B32Texture* textu
 /* ------------------------------------------------------------------ lines of the wireframe phases */
 /* Framebuffer::set_pixel, render.rs:301-310 with Color::new(r,g,b) (blend Opaque -> alpha 255, types.rs:829-832) */
 static inline void set_pixel_rgb(FB* fb, int32_t x, int32_t y, uint8_t r, uint8_t g, uint8_t b) {
-    if ((uint32_t)x < fb->width && (uint32_t)y < fb->height && (uint32_t)y >= g_band_y0 && (uint32_t)y < g_band_y1) {
+    if ((uint32_t)x < fb->width && (uint32_t)y < fb->height && (uint32_t)y >= fb->band_y0 && (uint32_t)y < fb->band_y1) {
         size_t idx = ((size_t)y * fb->width + (size_t)x) * 4;
         fb->pixels[idx] = r; fb->pixels[idx + 1] = g; fb->pixels[idx + 2] = b; fb->pixels[idx + 3] = 255;
     }
@@ -875,7 +882,7 @@ static inline int line_overflows(int32_t x0, int32_t y0, int32_t x1, int32_t y1)
 EXPORT int b32o_draw_line(uint8_t* pixels, uint32_t width, uint32_t height, int32_t x0, int32_t y0, int32_t x1, int32_t y1,
                           uint8_t r, uint8_t g, uint8_t b) {
     if (line_overflows(x0, y0, x1, y1)) return B32_E_UNSUPPORTED;
-    FB fb = { pixels, NULL, width, height, 0 };
+    FB fb = { pixels, NULL, width, height, 0, g_band_y0, g_band_y1 };
     int32_t dx = i32_wabs(i32_wsub(x1, x0)), dy = -i32_wabs(i32_wsub(y1, y0));
     int32_t sx = x0 < x1 ? 1 : -1, sy = y0 < y1 ? 1 : -1;
     int32_t err = i32_wadd(dx, dy), x = x0, y = y0;
@@ -892,7 +899,7 @@ EXPORT int b32o_draw_line(uint8_t* pixels, uint32_t width, uint32_t height, int3
 EXPORT int b32o_draw_line_3d(uint8_t* pixels, const float* zbuffer, uint32_t width, uint32_t height,
                              int32_t x0, int32_t y0, float z0, int32_t x1, int32_t y1, float z1, uint8_t r, uint8_t g, uint8_t b) {
     if (line_overflows(x0, y0, x1, y1)) return B32_E_UNSUPPORTED;
-    FB fb = { pixels, NULL, width, height, 0 };
+    FB fb = { pixels, NULL, width, height, 0, g_band_y0, g_band_y1 };
     int32_t dx = i32_wabs(i32_wsub(x1, x0)), dy = -i32_wabs(i32_wsub(y1, y0));
     int32_t sx = x0 < x1 ? 1 : -1, sy = y0 < y1 ? 1 : -1;
     int32_t err = i32_wadd(dx, dy), x = x0, y = y0;
@@ -981,25 +988,19 @@ EXPORT void b32o_fb_clear(uint8_t* pixels, float* zbuffer, uint32_t width, uint3
 
 /* render_mesh_15, render.rs:2302-2638, and render_mesh (8-bit colour), render.rs:1971-2264: the two functions share their
  * transform / cull / wireframe text almost verbatim; `textures8 != NULL` selects the 8-bit variant's differences (cited). */
-static int render_mesh_impl(uint8_t* fb_pixels, float* fb_zbuffer, uint32_t width, uint32_t height,
-                            const B32Vertex* vertices, uint32_t nv,
-                            const B32Face* faces, uint32_t nf,
-                            const B32Texture15* textures, const B32Texture* textures8, uint32_t nt,
-                            const B32Camera* camera, const B32Settings* st, const B32Fog* fog,
-                            B32Timings* timings, B32OracleDump* dump) {
-    const int fmt8 = textures8 != NULL;
-    if (!fb_pixels || !camera || !st || (nv && !vertices) || (nf && !faces) || (nt && !textures && !textures8)) return B32_E_ARG;
-    if (st->use_zbuffer && !fb_zbuffer) return B32_E_ARG;
-    if (st->shading != B32_SHADE_NONE)
-        for (uint32_t i = 0; i < st->n_lights; ++i)
-            if (st->lights[i].enabled && st->lights[i].type > B32_LIGHT_SPOT) return B32_E_ARG;
-    FB fb = { fb_pixels, fb_zbuffer, width, height, 0 };
+/* TRANSFORM of a vertex range, render.rs:2313-2362 (one job per thread of the all-cores baseline; the whole range otherwise) */
+typedef struct {
+    const B32Vertex* vertices; uint32_t i0, i1;
+    const B32Camera* camera; const B32Settings* st; uint32_t width, height;
+    V3* cam_space; V3* projected; B32OracleDump* dump;
+} TransformJob;
+static void* transform_range(void* arg) {
+    const TransformJob* j = (const TransformJob*)arg;
+    const B32Vertex* vertices = j->vertices; const B32Camera* camera = j->camera; const B32Settings* st = j->st;
+    const uint32_t width = j->width, height = j->height;
+    B32OracleDump* dump = j->dump;
     V3 cpos = v3p(camera->position), bx = v3p(camera->basis_x), by = v3p(camera->basis_y), bz = v3p(camera->basis_z);
-
-    /* TRANSFORM, :2313-2362 */
-    V3* cam_space = (V3*)malloc(sizeof(V3) * (nv ? nv : 1));
-    V3* projected = (V3*)malloc(sizeof(V3) * (nv ? nv : 1));
-    for (uint32_t i = 0; i < nv; ++i) {
+    for (uint32_t i = j->i0; i < j->i1; ++i) {
         V3 pos = v3p(vertices[i].pos);
         V3 screen, cam_pos;
         if (st->has_ortho) {                                                                      /* :2323-2328 */
@@ -1017,8 +1018,50 @@ static int render_mesh_impl(uint8_t* fb_pixels, float* fb_zbuffer, uint32_t widt
         }
         if (dump && dump->sx && !(st->use_fixed_point && !st->has_ortho)) { dump->sx[i] = f2i32_sat(screen.x); dump->sy[i] = f2i32_sat(screen.y); }
         if (dump && dump->sz) dump->sz[i] = screen.z;
-        cam_space[i] = cam_pos; projected[i] = screen;
+        j->cam_space[i] = cam_pos; j->projected[i] = screen;
         /* cam_space_normals (:2357-2359) feed only Surface.vn*, which rasterize_triangle_15 never reads. */
+    }
+    return NULL;
+}
+/* DRAW of the sorted list into one row band, render.rs:2547-2572 (one job per thread of the all-cores baseline) */
+struct Surface_;
+typedef struct {
+    FB fb; const void* surfaces; const uint32_t* order; uint32_t ns, n_op;
+    const B32Face* faces; const B32Texture15* textures; const B32Texture* textures8; uint32_t nt; const B32Settings* st; int rc;
+} DrawJob;
+static void* draw_range(void* arg);
+
+static int render_mesh_impl(uint8_t* fb_pixels, float* fb_zbuffer, uint32_t width, uint32_t height,
+                            const B32Vertex* vertices, uint32_t nv,
+                            const B32Face* faces, uint32_t nf,
+                            const B32Texture15* textures, const B32Texture* textures8, uint32_t nt,
+                            const B32Camera* camera, const B32Settings* st, const B32Fog* fog,
+                            B32Timings* timings, B32OracleDump* dump) {
+    const int fmt8 = textures8 != NULL;
+    if (!fb_pixels || !camera || !st || (nv && !vertices) || (nf && !faces) || (nt && !textures && !textures8)) return B32_E_ARG;
+    if (st->use_zbuffer && !fb_zbuffer) return B32_E_ARG;
+    if (st->shading != B32_SHADE_NONE)
+        for (uint32_t i = 0; i < st->n_lights; ++i)
+            if (st->lights[i].enabled && st->lights[i].type > B32_LIGHT_SPOT) return B32_E_ARG;
+    FB fb = { fb_pixels, fb_zbuffer, width, height, 0, g_band_y0, g_band_y1 };
+
+    /* TRANSFORM, :2313-2362 */
+    V3* cam_space = (V3*)malloc(sizeof(V3) * (nv ? nv : 1));
+    V3* projected = (V3*)malloc(sizeof(V3) * (nv ? nv : 1));
+    {
+        unr_init();                                           /* (before any thread touches the table) */
+        const uint32_t T = (g_threads > 1 && nv >= 4096) ? (uint32_t)g_threads : 1u;
+        TransformJob jobs[256]; pthread_t th[256];
+        for (uint32_t t = 0; t < T; ++t) {
+            TransformJob j = { vertices, (uint32_t)((uint64_t)nv * t / T), (uint32_t)((uint64_t)nv * (t + 1) / T), camera, st, width, height,
+                               cam_space, projected, dump };
+            jobs[t] = j;
+        }
+        if (T == 1) transform_range(&jobs[0]);
+        else {
+            for (uint32_t t = 0; t < T; ++t) pthread_create(&th[t], NULL, transform_range, &jobs[t]);
+            for (uint32_t t = 0; t < T; ++t) pthread_join(th[t], NULL);
+        }
     }
 
     /* CULL / SETUP, :2364-2516 */
@@ -1101,17 +1144,22 @@ static int render_mesh_impl(uint8_t* fb_pixels, float* fb_zbuffer, uint32_t widt
             if (dump) { dump->n_drawn = ns; dump->n_opaque = n_op; if (dump->draw_order) for (uint32_t i = 0; i < ns; ++i) dump->draw_order[i] = surfaces[order[i]].face_idx; }
             /* DRAW, :2547-2572 */
             if (!st->wireframe_overlay) {
-                for (uint32_t i = 0; i < ns && !rc; ++i) {
-                    const Surface* s = &surfaces[order[i]];
-                    uint32_t tid = faces[s->face_idx].texture_id;
-                    if (fmt8) {
-                        const B32Texture* tex8 = (tid != B32_NO_TEXTURE && tid < nt) ? &textures8[tid] : NULL;       /* :2196-2198 */
-                        rc = rasterize_triangle8(&fb, s, tex8, st);
-                        continue;
-                    }
-                    const B32Texture15* tex = (tid != B32_NO_TEXTURE && tid < nt) ? &textures[tid] : NULL;  /* textures.get(id) :2554-2556 */
-                    rc = rasterize_triangle_15(&fb, s, tex, s->blend_mode, s->black_transparent, st, i >= n_op);
+                const uint32_t by0 = fb.band_y0 < height ? fb.band_y0 : height, by1 = fb.band_y1 < height ? fb.band_y1 : height;
+                const uint32_t rows = by1 > by0 ? by1 - by0 : 0;
+                const uint32_t T = (g_threads > 1 && rows >= (uint32_t)g_threads && ns >= 64) ? (uint32_t)g_threads : 1u;
+                DrawJob jobs[256]; pthread_t th[256];
+                for (uint32_t t = 0; t < T; ++t) {
+                    DrawJob j = { fb, surfaces, order, ns, n_op, faces, textures, textures8, nt, st, B32_OK };
+                    j.fb.fragments = 0;
+                    if (T > 1) { j.fb.band_y0 = by0 + (uint32_t)((uint64_t)rows * t / T); j.fb.band_y1 = by0 + (uint32_t)((uint64_t)rows * (t + 1) / T); }
+                    jobs[t] = j;
                 }
+                if (T == 1) draw_range(&jobs[0]);
+                else {
+                    for (uint32_t t = 0; t < T; ++t) pthread_create(&th[t], NULL, draw_range, &jobs[t]);
+                    for (uint32_t t = 0; t < T; ++t) pthread_join(th[t], NULL);
+                }
+                for (uint32_t t = 0; t < T; ++t) { fb.fragments += jobs[t].fb.fragments; if (jobs[t].rc && !rc) rc = jobs[t].rc; }
             }
         }
         free(order); free(tmp); free(key);
@@ -1135,6 +1183,24 @@ static int render_mesh_impl(uint8_t* fb_pixels, float* fb_zbuffer, uint32_t widt
 done:
     free(surfaces); free(cam_space); free(projected); free(backface_wireframes); free(frontface_wireframes);
     return rc;
+}
+
+static void* draw_range(void* arg) {
+    DrawJob* j = (DrawJob*)arg;
+    const Surface* surfaces = (const Surface*)j->surfaces;
+    const int fmt8 = j->textures8 != NULL;
+    for (uint32_t i = 0; i < j->ns && !j->rc; ++i) {
+        const Surface* s = &surfaces[j->order[i]];
+        uint32_t tid = j->faces[s->face_idx].texture_id;
+        if (fmt8) {
+            const B32Texture* tex8 = (tid != B32_NO_TEXTURE && tid < j->nt) ? &j->textures8[tid] : NULL;       /* :2196-2198 */
+            j->rc = rasterize_triangle8(&j->fb, s, tex8, j->st);
+            continue;
+        }
+        const B32Texture15* tex = (tid != B32_NO_TEXTURE && tid < j->nt) ? &j->textures[tid] : NULL;  /* textures.get(id) :2554-2556 */
+        j->rc = rasterize_triangle_15(&j->fb, s, tex, s->blend_mode, s->black_transparent, j->st, i >= j->n_op);
+    }
+    return NULL;
 }
 
 EXPORT int b32o_render_mesh_15(uint8_t* fb_pixels, float* fb_zbuffer, uint32_t width, uint32_t height,
@@ -1226,7 +1292,7 @@ EXPORT int b32o_render_skybox_mesh(uint8_t* pixels, uint32_t width, uint32_t hei
 }
 /* draw_star_diamond + set_pixel_safe, render.rs:199-246 */
 EXPORT void b32o_draw_star_diamond(uint8_t* pixels, uint32_t width, uint32_t height, int32_t cx, int32_t cy, float size, const uint8_t rgb[3]) {
-    FB fb = { pixels, NULL, width, height, 0 };
+    FB fb = { pixels, NULL, width, height, 0, g_band_y0, g_band_y1 };
     int32_t s = f2i32_sat(rmax(size, 1.0f));
     set_pixel_rgb(&fb, cx, cy, rgb[0], rgb[1], rgb[2]);
     if (s >= 2) {

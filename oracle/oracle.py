@@ -13,7 +13,9 @@ from bonnie32_amd import abi, rtypes as T
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_build", "libb32oracle.so")
+FAST_PATH = os.path.join(_HERE, "_build", "libb32oracle_fast.so")     # bench.py's CPU baseline: the reference's release profile
 _lib = None
+_fast = None
 
 
 class B32OracleDump(C.Structure):
@@ -24,17 +26,16 @@ class B32OracleDump(C.Structure):
 def build(force=False):
     src = os.path.join(_HERE, "b32_oracle.c")
     hdr = os.path.join(_HERE, "..", "include", "b32raster.h")
-    if (force or not os.path.exists(LIB_PATH)
-            or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(hdr))):
-        subprocess.run(["make", "-C", _HERE], check=True, capture_output=True)
+    mk = os.path.join(_HERE, "Makefile")
+    newest = max(os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(mk))
+    if force or any(not os.path.exists(q) or os.path.getmtime(q) < newest for q in (LIB_PATH, FAST_PATH)):
+        subprocess.run(["make", "-C", _HERE] + (["-B"] if force else []), check=True, capture_output=True)
     return LIB_PATH
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        build()
-        L = C.CDLL(LIB_PATH)
+def _load(path):
+    if True:
+        L = C.CDLL(path)
         P = C.c_void_p
         L.b32o_unr_table.restype = C.c_uint8; L.b32o_unr_table.argtypes = [C.c_uint32]
         L.b32o_fixed_from_f32.restype = C.c_int32; L.b32o_fixed_from_f32.argtypes = [C.c_float]
@@ -71,8 +72,26 @@ def lib():
         L.b32o_constant.restype = C.c_double; L.b32o_constant.argtypes = [C.c_char_p]
         L.b32o_constant_count.restype = C.c_uint32; L.b32o_constant_count.argtypes = []
         L.b32o_constant_name.restype = C.c_char_p; L.b32o_constant_name.argtypes = [C.c_uint32]
-        _lib = L
+        L.b32o_set_threads.restype = None; L.b32o_set_threads.argtypes = [C.c_int]
+    return L
+
+
+def lib():
+    """the CHECKER build (strict IEEE flags): what every parity test compares against"""
+    global _lib
+    if _lib is None:
+        build()
+        _lib = _load(LIB_PATH)
     return _lib
+
+
+def fast_lib():
+    """the CPU-BASELINE build (the reference's release profile: -O3 -flto, x86-64 baseline); frames are asserted byte-identical"""
+    global _fast
+    if _fast is None:
+        build()
+        _fast = _load(FAST_PATH)
+    return _fast
 
 
 def _f3(v):
@@ -141,8 +160,11 @@ def render_mesh(fb: Framebuffer, vertices, faces, textures, camera: T.Camera, se
 
 
 def render_mesh_15(fb: Framebuffer, vertices, faces, textures, camera: T.Camera, settings: T.RasterSettings,
-                   fog=None, dump=False, _fmt8=False):
-    """render_mesh_15 (render.rs:2302-2638) on the CPU. Returns (rc, RasterTimings[, dump dict])."""
+                   fog=None, dump=False, _fmt8=False, fast=False, threads=1):
+    """render_mesh_15 (render.rs:2302-2638) on the CPU. Returns (rc, RasterTimings[, dump dict]).
+    fast: the baseline build (release profile) instead of the checker; threads > 1: the all-cores schedule (b32o_set_threads)."""
+    L = fast_lib() if fast else lib()
+    L.b32o_set_threads(int(threads))
     vertices = np.ascontiguousarray(vertices, dtype=abi.VERTEX_DTYPE)
     faces = np.ascontiguousarray(faces, dtype=abi.FACE_DTYPE)
     tex_arr, _keep_t = T.pack_textures8(textures) if _fmt8 else T.pack_textures(textures)
@@ -161,10 +183,13 @@ def render_mesh_15(fb: Framebuffer, vertices, faces, textures, camera: T.Camera,
               vertices.ctypes.data if len(vertices) else None, len(vertices),
               faces.ctypes.data if len(faces) else None, len(faces), C.cast(tex_arr, C.c_void_p), len(textures), C.byref(cam), C.byref(st))
     tail = (C.byref(tm), C.byref(d) if d is not None else None)
-    if _fmt8:
-        rc = lib().b32o_render_mesh(*common, *tail)
-    else:
-        rc = lib().b32o_render_mesh_15(*common, C.byref(fg) if fg is not None else None, *tail)
+    try:
+        if _fmt8:
+            rc = L.b32o_render_mesh(*common, *tail)
+        else:
+            rc = L.b32o_render_mesh_15(*common, C.byref(fg) if fg is not None else None, *tail)
+    finally:
+        L.b32o_set_threads(1)
     t = T.RasterTimings.from_c(tm)
     if dump:
         return rc, t, {"sx": sx[:len(vertices)], "sy": sy[:len(vertices)], "sz": sz[:len(vertices)],

@@ -1,0 +1,47 @@
+"""Derives profiles/pmc_traffic.json (read by bench.py into roofline.traffic) from the FETCH_SIZE / WRITE_SIZE passes of
+tools/pmc_passes.sh: per-launch HBM bytes of the dominant kernel, with the digest of the kernel sources the passes were taken from
+(bench.py reports the figure only for that very build).
+usage: pmc_traffic.py <pmcC.txt> <pmcD.txt> <config> <committed-file-name>
+
+Calibration (MI355X_MICROARCH.md, HBM section: FETCH_SIZE is uncalibrated for anything but wide streaming reads): in the same run
+k_setup reads every vertex and face exactly once -- 36 B x Nv + 20 B x Nf compulsory bytes -- so FETCH_SIZE(k_setup) / that count is
+this run's read factor; WRITE_SIZE(k_clear) / (4 B x pixels) is the write factor.  Both are applied to the dominant kernel."""
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import csrc_digest  # noqa: E402
+
+
+def read(path, counter):
+    out = {}
+    for ln in open(path):
+        m = re.match(r"(\S.*?)\s+" + counter + r"\s+([0-9.]+)\s+\(n=(\d+)\)", ln)
+        if m:
+            out[m.group(1).strip()] = (float(m.group(2)), int(m.group(3)))
+    return out
+
+
+def main():
+    fc, wc, config, fname = sys.argv[1:5]
+    nv, nf, px = (3_000_000, 1_000_000, 2560 * 1920) if config in ("C3", "C5") else (None, None, None)
+    F, Wt = read(fc, "FETCH_SIZE"), read(wc, "WRITE_SIZE")
+    cover = max((k for k in F if "k_cover" in k), key=lambda k: F[k][1])           # the instantiation launched most often = the timed one
+    setup = next(k for k in F if "k_setup" in k)
+    clear = next(k for k in Wt if "k_clear" in k)
+    rf = F[setup][0] * 1024 / (36 * nv + 20 * nf)
+    wf = Wt[clear][0] * 1024 / (4 * px)
+    by = F[cover][0] * 1024 / rf + Wt[cover][0] * 1024 / wf
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    cur = json.load(open(path)) if os.path.exists(path) else {}
+    cur[f"{config}:k_cover"] = {"bytes": int(by), "csrc_digest": csrc_digest(), "file": fname,
+                                "note": f"{cover}: FETCH_SIZE {F[cover][0]:.1f} KB / {rf:.3f} (k_setup calibration) + WRITE_SIZE {Wt[cover][0]:.1f} KB / {wf:.3f} (k_clear calibration)"}
+    json.dump(cur, open(path, "w"), indent=1)
+    print(json.dumps(cur[f"{config}:k_cover"]))
+
+
+if __name__ == "__main__":
+    main()
