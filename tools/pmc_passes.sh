@@ -12,8 +12,8 @@ timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmcC -o c -- $B > $O
 timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmcD -o d -- $B > $O/pmcD.log 2>&1
 timeout 200 rocprofv3 --kernel-trace --stats -d $O/kstats -o k -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-configs > $O/kstats.log 2>&1
 : > $R/gpurun_out/${TAG}_pmc.txt
-for p in A B C D; do f=$(ls $O/pmc$p/*/*.db 2>/dev/null | head -1); if [ -n "$f" ]; then echo "== pass $p" >> $R/gpurun_out/${TAG}_pmc.txt; python $R/tools/rocpd_pmc.py $f > $O/pmc$p.txt; cat $O/pmc$p.txt >> $R/gpurun_out/${TAG}_pmc.txt; fi; done
-f=$(ls $O/kstats/*/*.db 2>/dev/null | head -1); [ -n "$f" ] && python $R/tools/rocpd_stats.py $f > $R/gpurun_out/${TAG}_kstats.txt
+for p in A B C D; do f=$(find $O/pmc$p -name "*.db" 2>/dev/null | head -1); if [ -n "$f" ]; then echo "== pass $p" >> $R/gpurun_out/${TAG}_pmc.txt; python $R/tools/rocpd_pmc.py $f > $O/pmc$p.txt; cat $O/pmc$p.txt >> $R/gpurun_out/${TAG}_pmc.txt; fi; done
+f=$(find $O/kstats -name "*.db" 2>/dev/null | head -1); [ -n "$f" ] && python $R/tools/rocpd_stats.py $f > $R/gpurun_out/${TAG}_kstats.txt
 tail -1 $O/kstats.log > $R/gpurun_out/${TAG}_bench_under_rocprof.json
 python $R/tools/pmc_traffic.py $O/pmcC.txt $O/pmcD.txt C3 profiles/${TAG}_pmc.txt > $R/gpurun_out/${TAG}_traffic.json 2>&1 && cp $R/profiles/pmc_traffic.json $R/gpurun_out/${TAG}_pmc_traffic.json
 rm -rf $O/pmc?/ $O/kstats/     # the databases are large; the text summaries above are what is kept
