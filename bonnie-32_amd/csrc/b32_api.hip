@@ -51,7 +51,8 @@ struct b32_ctx {
     // per-face work buffers
     size_t cap_work = 0;
     uint32_t *keys[2] = { nullptr, nullptr }, *vals[2] = { nullptr, nullptr };
-    SurfRec* recs = nullptr; float* shades = nullptr; size_t cap_shades = 0;
+    CovRec* crecs = nullptr; ShadeRec* srecs = nullptr; AuxRec* xrecs = nullptr;      // per-face records (b32_device.h)
+    float* shades = nullptr; size_t cap_shades = 0;
     uint32_t* counts = nullptr; uint32_t* block_sums = nullptr; uint32_t bin_blocks = 0;
     uint32_t* spans = nullptr;
     uint32_t* tile_mid = nullptr; size_t cap_tile_mid = 0;
@@ -208,7 +209,7 @@ void b32_destroy(b32_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    void* ptrs[] = { c->fb_own, c->d_verts, c->d_faces, c->d_texels, c->d_tex, c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->recs,
+    void* ptrs[] = { c->fb_own, c->d_verts, c->d_faces, c->d_texels, c->d_tex, c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->crecs, c->srecs, c->xrecs,
                      c->shades, c->counts, c->block_sums, c->pkeys[0], c->pkeys[1], c->pvals[0], c->pvals[1], c->block_hist, c->ranges,
                      c->d_ctrl, c->d_consts, c->d_lights, c->digit_total, c->partials, c->vis, c->spans, c->tile_mid, c->zbuf,
                      c->wire, c->wire_owner, c->wire_first, c->d_texels32, c->inline_lists };
@@ -461,11 +462,13 @@ static int upload_geometry(b32_ctx* c, const B32Vertex* v, uint32_t nv, const B3
     c->nv = nv; c->nf = nf;
     c->local_sort_ok = true;
     // per-face work buffers
-    if ((size_t)nf + 1 > c->cap_work || !c->recs) {
+    if ((size_t)nf + 1 > c->cap_work || !c->crecs) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         const size_t n = (size_t)nf + nf / 4 + 16;
         for (int i = 0; i < 2; ++i) { if ((rc = ensure_plain(c, c->keys[i], n))) return rc; if ((rc = ensure_plain(c, c->vals[i], n))) return rc; }
-        if ((rc = ensure_plain(c, c->recs, n))) return rc;
+        if ((rc = ensure_plain(c, c->crecs, n))) return rc;
+        if ((rc = ensure_plain(c, c->srecs, n))) return rc;
+        if ((rc = ensure_plain(c, c->xrecs, n))) return rc;
         if ((rc = ensure_plain(c, c->counts, n))) return rc;
         if ((rc = ensure_plain(c, c->spans, n))) return rc;
         c->bin_blocks = (uint32_t)((n + 4095) / 4096);
@@ -765,7 +768,7 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     if (prof_all) HIPCHK(c, hipEventRecord(ev[0], s));
     fp.band_only = (want_prio64 && c->band_set) ? 1 : 0;   // other ranks own the other rows: their surfaces' records are never read here
     fp.redraw = c->redrawing ? 1 : 0;
-    launch_setup(s, fp, c->d_verts, c->d_faces, c->d_tex, c->d_lights, lset, c->recs, c->shades, c->keys[0], c->spans, c->partials, c->d_ctrl, c->wire);
+    launch_setup(s, fp, c->d_verts, c->d_faces, c->d_tex, c->d_lights, lset, RecArrays{ c->crecs, c->srecs, c->xrecs }, c->shades, c->keys[0], c->spans, c->partials, c->d_ctrl, c->wire);
     if (prof_all) HIPCHK(c, hipEventRecord(ev[1], s));
 
     int cur = 0;
@@ -803,12 +806,12 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
         launch_radix_pass(s, c->keys[0], c->vals[0], c->keys[1], c->vals[1], &c->d_ctrl->n_visible, c->nf, 16, 8, sc);
         launch_radix_pass(s, c->keys[1], c->vals[1], c->keys[0], c->vals[0], &c->d_ctrl->n_visible, c->nf, 24, 8, sc);
         if (fp.ortho) {      // 32-bit depth keys: the opaque/transparent partition is a fifth stable pass on the class
-            launch_class_keys(s, c->recs, c->vals[0], &c->d_ctrl->n_visible, c->nf, c->keys[0]);
+            launch_class_keys(s, c->crecs, c->vals[0], &c->d_ctrl->n_visible, c->nf, c->keys[0]);
             launch_radix_pass(s, c->keys[0], c->vals[0], c->keys[1], c->vals[1], &c->d_ctrl->n_visible, c->nf, 0, 8, sc);
             HIPCHK(c, hipMemcpyAsync(c->vals[0], c->vals[1], (size_t)c->nf * 4, hipMemcpyDeviceToDevice, s));
         }
         if (prof_all) HIPCHK(c, hipEventRecord(ev[2], s));
-        launch_bin(s, fp, c->recs, c->vals[0], c->d_ctrl, c->counts, c->block_sums, c->bin_blocks, c->pkeys[0], c->pvals[0], (uint32_t)c->cap_pairs);
+        launch_bin(s, fp, c->spans, c->vals[0], c->d_ctrl, c->counts, c->block_sums, c->bin_blocks, c->pkeys[0], c->pvals[0], (uint32_t)c->cap_pairs);
     }
     const uint32_t n_sort_keys = local_sort ? ntiles : n_keys;          // the fast path groups by tile only
     const uint32_t kb = bits_for(n_sort_keys ? n_sort_keys : 1);
@@ -828,7 +831,7 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     if (prof_fill) HIPCHK(c, hipEventRecord(ev[3], s));
 
     FillArgs fa{};
-    fa.fp = fp; fa.recs = c->recs; fa.shades = c->shades; fa.pair_vals = c->pvals[cur]; fa.ranges = c->ranges;
+    fa.fp = fp; fa.crecs = c->crecs; fa.srecs = c->srecs; fa.xrecs = c->xrecs; fa.shades = c->shades; fa.pair_vals = c->pvals[cur]; fa.ranges = c->ranges;
     fa.keys = c->keys[0]; fa.local_sort = local_sort ? 1u : 0u; fa.tile_keys_only = (local_sort || prio64) ? 1u : 0u; fa.tile_mid = c->tile_mid;
     fa.tex = c->d_tex; fa.texels = c->d_texels; fa.fb = c->fb; fa.vis = c->vis; fa.zbuf = c->zbuf; fa.ctrl = c->d_ctrl;
     fa.tex0 = c->nt ? c->h_tex[0] : TexDesc{ 0, 0, 0, 0 };

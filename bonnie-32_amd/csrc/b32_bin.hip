@@ -15,7 +15,7 @@ constexpr int BIN_ITEMS = 16;
 constexpr int BIN_TILE = BIN_THREADS * BIN_ITEMS;
 
 // counts[r] = number of tiles surface order[r] touches; block_sums[b] = sum over the block's 4096 ranks.
-__global__ __launch_bounds__(BIN_THREADS) void k_bin_count(FrameParams fp, const SurfRec* __restrict__ recs, const uint32_t* __restrict__ order,
+__global__ __launch_bounds__(BIN_THREADS) void k_bin_count(FrameParams fp, const uint32_t* __restrict__ spans, const uint32_t* __restrict__ order,
                                                             const Ctrl* __restrict__ ctrl, uint32_t* __restrict__ counts,
                                                             uint32_t* __restrict__ block_sums) {
     __shared__ uint32_t wsum[BIN_THREADS / 64];
@@ -27,10 +27,9 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_count(FrameParams fp, const
         for (int i = 0; i < BIN_ITEMS; ++i) {
             const uint32_t r = base + i * BIN_THREADS + threadIdx.x;
             if (r < n) {
-                const SurfRec& rec = recs[order[r]];
-                uint32_t c = 0;
-                counts[r] = pack_tile_span(rec.bbx, rec.bby, rec.flags, fp, c);
-                local += c;
+                const uint32_t span = spans[order[r]];          // k_setup's packed tile span of the surface (pack_tile_span)
+                counts[r] = span;
+                if (span != 0xFFFFFFFFu) local += (((span >> 8) & 0xFF) - (span & 0xFF) + 1) * ((span >> 24) - ((span >> 16) & 0xFF) + 1);
             }
         }
     }
@@ -41,7 +40,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_count(FrameParams fp, const
 }
 
 // Emit the pairs of each rank at its prefix offset (block base + in-block exclusive scan of counts).
-__global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(FrameParams fp, const SurfRec* __restrict__ recs, const uint32_t* __restrict__ order,
+__global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(FrameParams fp, const uint32_t* __restrict__ order,
                                                            Ctrl* __restrict__ ctrl, const uint32_t* __restrict__ counts,
                                                            const uint32_t* __restrict__ block_sums, uint32_t nblocks, uint32_t pair_cap,
                                                            uint32_t* __restrict__ pair_keys, uint32_t* __restrict__ pair_vals) {
@@ -100,12 +99,12 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(FrameParams fp, const 
     }
 }
 
-void launch_bin(hipStream_t s, const FrameParams& fp, const SurfRec* recs, const uint32_t* order, Ctrl* ctrl,
+void launch_bin(hipStream_t s, const FrameParams& fp, const uint32_t* spans, const uint32_t* order, Ctrl* ctrl,
                 uint32_t* counts, uint32_t* block_sums, uint32_t max_blocks, uint32_t* pair_keys, uint32_t* pair_vals, uint32_t pair_cap) {
     if (fp.nf == 0) return;
     const uint32_t nblocks = min((fp.nf + BIN_TILE - 1) / BIN_TILE, max_blocks);
-    hipLaunchKernelGGL(k_bin_count, dim3(nblocks), dim3(BIN_THREADS), 0, s, fp, recs, order, ctrl, counts, block_sums);
-    hipLaunchKernelGGL(k_bin_emit, dim3(nblocks), dim3(BIN_THREADS), 0, s, fp, recs, order, ctrl, counts, block_sums, nblocks, pair_cap, pair_keys, pair_vals);
+    hipLaunchKernelGGL(k_bin_count, dim3(nblocks), dim3(BIN_THREADS), 0, s, fp, spans, order, ctrl, counts, block_sums);
+    hipLaunchKernelGGL(k_bin_emit, dim3(nblocks), dim3(BIN_THREADS), 0, s, fp, order, ctrl, counts, block_sums, nblocks, pair_cap, pair_keys, pair_vals);
 }
 
 // ---- fast path ----------------------------------------------------------------------------------------------------

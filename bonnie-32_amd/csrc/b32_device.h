@@ -75,22 +75,67 @@ constexpr uint32_t C15_R_SHIFT = 10, C15_G_SHIFT = 5, C15_CHANNEL_MAX = 31;     
     X("color15.semi_bit", I, K::C15_SEMI_BIT) X("color15.r_shift", I, K::C15_R_SHIFT) X("color15.g_shift", I, K::C15_G_SHIFT)         \
     X("color15.channel_max", I, K::C15_CHANNEL_MAX)
 
-// ---------------------------------------------------------------- per-surface record written by k_setup (96 B = 6 x 16 B)
-// Edge coefficients follow rasterize_triangle_15 (render.rs:1500-1518) and are computed once per face with the
-// reference's f32 expression order; the fill evaluates w0/w1 in closed form only when `F_SLOW` is clear, i.e. when
-// k_setup proved every intermediate of the reference's incremental accumulation (render.rs:1706-1712) is an integer
-// of magnitude < 2^24, so that accumulate == closed form bit-for-bit.
-struct __attribute__((aligned(16))) SurfRec {
-    float x3, y3, a0, b0;
-    float a1, b1, inv_area; uint32_t bbx;      // bbx = min_x | max_x << 16 (max exclusive, render.rs:1455-1458)
-    uint32_t bby; float u1, u2, u3;
-    float v1, v2, v3; uint32_t flags;
-    uint32_t vc1, vc2, vc3; float w0_start;    // vc = r | g<<8 | b<<16 ; w*_start = render.rs:1517-1518
-    float w1_start; float iz1, iz2, iz3;       // 1.0 / v_i.z (render.rs:1546-1548): perspective-correct UVs, z-buffer depth
+// ---------------------------------------------------------------- per-surface records written by k_setup, indexed by face id
+// Three arrays, split by consumer so that every reader pulls whole, aligned 32-byte sectors of exactly what it needs:
+//   CovRec   32 B  coverage (the tile-list walk: one record per (surface, tile) pair): snapped screen vertices as 6 x i16, inv_area,
+//                  bounding box, painter's key, flags.  The edge coefficients a0 = y2 - y3, b0 = x3 - x2, a1 = y3 - y1, b1 = x1 - x3
+//                  (render.rs:1507-1510) are recomputed from the vertices in registers: the same f32 subtractions on the same operands.
+//   ShadeRec 64 B  shading (one record per run of winner pixels): f32 vertices, inv_area, UVs, vertex colours, texture slot and the
+//                  three flags the opaque colour pipeline reads.
+//   AuxRec   32 B  1 / v_i.z (perspective-correct UVs, z-buffer depth) and the start values of the literal edge walk: written and read
+//                  only in z-buffer mode, with perspective-correct textures, or for F_SLOW surfaces.
+// A surface whose vertices do not fit i16 (or are not integers: float projection, orthographic view) carries COV_WIDE in x1 and the
+// coverage reads its vertices from the ShadeRec instead.  The fill evaluates w0 / w1 in closed form only when F_SLOW is clear, i.e.
+// when k_setup proved every intermediate of the reference's incremental accumulation (render.rs:1706-1712) is an integer of magnitude
+// < 2^24, so that accumulate == closed form bit-for-bit.
+struct __attribute__((aligned(32))) CovRec {
+    uint32_t xy1, xy2, xy3;                    // x | y << 16, each an i16 (xy1's low half == COV_WIDE: see ShadeRec)
+    float inv_area;                            // 1.0 / area, render.rs:1504
+    uint32_t bbx, bby;                         // min | max << 16 (max exclusive, render.rs:1455-1458)
+    uint32_t key;                              // k_setup's painter's radix key (the same word as keys[face])
+    uint32_t flags;                            // F_* below
 };
-static_assert(sizeof(SurfRec) == 96, "SurfRec layout");
+static_assert(sizeof(CovRec) == 32, "CovRec layout");
+constexpr uint32_t COV_WIDE = 0x8000u;         // i16 -32768 in the x1 slot
+struct __attribute__((aligned(64))) ShadeRec {
+    float x1, y1, x2, y2;
+    float x3, y3, inv_area; uint32_t pk0;      // pk0 = vc1 | texture slot bits 0..7 << 24      (vc = r | g<<8 | b<<16)
+    float u1, u2, u3, v1;
+    float v2, v3; uint32_t pk1, pk2;           // pk1 = vc2 | texture slot bits 8..15 << 24;  pk2 = vc3 | SH_* << 24
+};
+static_assert(sizeof(ShadeRec) == 64, "ShadeRec layout");
+constexpr uint32_t SH_BLACK_TR = 1u, SH_DITHER = 2u, SH_SLOW = 4u;     // bits 24.. of ShadeRec.pk2
+struct __attribute__((aligned(32))) AuxRec {
+    float iz1, iz2, iz3, w0_start;             // 1.0 / v_i.z (render.rs:1546-1548); w*_start = render.rs:1517-1518
+    float w1_start; uint32_t _pad[3];
+};
+static_assert(sizeof(AuxRec) == 32, "AuxRec layout");
 
-// SurfRec.flags
+// The register view every consumer computes with: the six quads of the former 96-byte record, assembled from the compact records.
+//   q0 = x3, y3, a0, b0 | q1 = a1, b1, inv_area, bbx | q2 = bby, u1, u2, u3 | q3 = v1, v2, v3, flags | q4 = vc1, vc2, vc3, w0_start
+//   q5 = w1_start, iz1, iz2, iz3
+struct RecView { uint4 q0, q1, q2, q3, q4, q5; };
+__device__ __forceinline__ float i16lo(uint32_t w) { return (float)(int32_t)(int16_t)(w & 0xFFFFu); }
+__device__ __forceinline__ float i16hi(uint32_t w) { return (float)((int32_t)w >> 16); }
+// edge part (q0, q1.xyz) from the three screen vertices: the reference's own subtractions (render.rs:1507-1510)
+__device__ __forceinline__ void view_edges(RecView& r, float x1, float y1, float x2, float y2, float x3, float y3, float inv_area) {
+    r.q0 = make_uint4(__float_as_uint(x3), __float_as_uint(y3), __float_as_uint(y2 - y3), __float_as_uint(x3 - x2));
+    r.q1.x = __float_as_uint(y3 - y1); r.q1.y = __float_as_uint(x1 - x3); r.q1.z = __float_as_uint(inv_area);
+}
+// coverage part of the view from a CovRec (c0, c1 = its two quads); false = COV_WIDE (the caller takes the vertices from the ShadeRec)
+__device__ __forceinline__ bool view_from_cov(RecView& r, const uint4& c0, const uint4& c1) {
+    r.q1.w = c1.x; r.q2.x = c1.y; r.q3.w = c1.w;
+    if ((c0.x & 0xFFFFu) == COV_WIDE) return false;
+    view_edges(r, i16lo(c0.x), i16hi(c0.x), i16lo(c0.y), i16hi(c0.y), i16lo(c0.z), i16hi(c0.z), __uint_as_float(c0.w));
+    return true;
+}
+__device__ __forceinline__ void view_edges_from_shade(RecView& r, const uint4& s0, const uint4& s1) {
+    view_edges(r, __uint_as_float(s0.x), __uint_as_float(s0.y), __uint_as_float(s0.z), __uint_as_float(s0.w), __uint_as_float(s1.x),
+               __uint_as_float(s1.y), __uint_as_float(s1.z));
+}
+__device__ __forceinline__ uint32_t shade_tex_slot(const uint4& s1, const uint4& s3) { return (s1.w >> 24) | ((s3.z >> 24) << 8); }
+
+// CovRec.flags (the shading view rebuilds the bits it needs -- texture slot, F_BLACK_TR, F_DITHER, F_SLOW -- from the ShadeRec)
 constexpr uint32_t F_TEX_MASK   = 0xFFFFu;     // texture slot, 0xFFFF = untextured (Color15::WHITE, render.rs:1585): up to 65534 textures per call
 constexpr uint32_t F_TEX_NONE   = 0xFFFFu;
 constexpr uint32_t F_BLACK_TR   = 1u << 16;    // face.black_transparent
@@ -287,8 +332,9 @@ void launch_radix_pass(hipStream_t s, const uint32_t* keys_in, const uint32_t* v
 // up to LIGHTS_INLINE lights travel by value in the kernel arguments: a light change costs no copy and no synchronisation
 constexpr uint32_t LIGHTS_INLINE = 8;
 struct LightSet { B32Light l[LIGHTS_INLINE]; };
+struct RecArrays { CovRec* cov; ShadeRec* shade; AuxRec* aux; };
 void launch_setup(hipStream_t s, const FrameParams& fp, const B32Vertex* verts, const B32Face* faces, const TexDesc* tex,
-                  const B32Light* lights, const LightSet& inline_lights, SurfRec* recs, float* shades, uint32_t* keys, uint32_t* spans,
+                  const B32Light* lights, const LightSet& inline_lights, RecArrays recs, float* shades, uint32_t* keys, uint32_t* spans,
                   uint32_t* partials, Ctrl* ctrl, WireTri* wire);
 void launch_project_fixed(hipStream_t s, const float* pos, uint32_t n, B32Camera cam, uint32_t w, uint32_t h,
                           int32_t* sx, int32_t* sy, float* z);
@@ -303,14 +349,14 @@ struct UploadSegs { void* dst[16]; uint32_t src_off[16]; uint32_t n16[16]; uint3
 void launch_upload(hipStream_t s, const void* arena_dev, const UploadSegs& segs);
 void launch_expand_indexed(hipStream_t s, const uint8_t* idx, uint32_t n, const uint16_t* clut, uint32_t clut_len, uint16_t* out);
 
-void launch_bin(hipStream_t s, const FrameParams& fp, const SurfRec* recs, const uint32_t* order, Ctrl* ctrl,
+void launch_bin(hipStream_t s, const FrameParams& fp, const uint32_t* spans, const uint32_t* order, Ctrl* ctrl,
                 uint32_t* counts, uint32_t* block_sums, uint32_t max_blocks, uint32_t* pair_keys, uint32_t* pair_vals, uint32_t pair_cap);
 // Fast path: pairs straight from k_setup's per-face spans, in face order (the per-tile LDS sort of k_cover orders them).
 void launch_bin_faces(hipStream_t s, const FrameParams& fp, const uint32_t* spans, const uint32_t* keys, const uint32_t* partials,
                       Ctrl* ctrl, uint32_t* pair_keys, uint32_t* pair_vals, uint32_t pair_cap, int with_class);
 // Orthographic depth keys use all 32 bits, so the opaque/transparent partition (render.rs:2522-2523) is one more stable pass
 // on a class key: keys_out[i] = transparent(recs[order[i]]) for i < *n_dev.
-void launch_class_keys(hipStream_t s, const SurfRec* recs, const uint32_t* order, const uint32_t* n_dev, uint32_t n_cap, uint32_t* keys_out);
+void launch_class_keys(hipStream_t s, const CovRec* recs, const uint32_t* order, const uint32_t* n_dev, uint32_t n_cap, uint32_t* keys_out);
 // Wireframe phases (render.rs:2574-2635).  kind 1: back-face edges, first occurrence per screen-space edge, depth-tested
 // (draw_line_3d, render.rs:757-817); kind 2: front-face overlay, no depth test (draw_line, render.rs:716-750).
 struct WireArgs {
@@ -339,7 +385,9 @@ void launch_upscale_nearest(hipStream_t s, const uint32_t* src, uint32_t sw, uin
 
 struct FillArgs {
     FrameParams fp;
-    const SurfRec* recs;
+    const CovRec* crecs;        // coverage records, by face id
+    const ShadeRec* srecs;      // shading records
+    const AuxRec* xrecs;        // 1/z terms and literal-walk start values (z-buffer mode, perspective-correct UVs, F_SLOW surfaces)
     const float* shades;        // [sid][9] or nullptr
     uint32_t* pair_vals;        // surface ids, grouped by (tile,class); painter's order inside a group (after the tile-local sort)
     const uint32_t* keys;       // face-order radix keys of k_setup (tile-local sort)

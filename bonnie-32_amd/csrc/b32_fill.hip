@@ -265,24 +265,73 @@ struct Batch {          // per-lane copy of one surface record (lane l <-> list 
     uint32_t tw, th, toff;
 };
 
+// The surface's shading view (RecView quads q0..q4, q5 when asked for or when the surface is F_SLOW) from its ShadeRec, plus -- rare --
+// the AuxRec and, for F_SLOW surfaces, the bounding box of the CovRec (the literal edge walk starts at the box origin).  The flags word
+// is rebuilt for an opaque-pass surface: texture slot, F_BLACK_TR, F_DITHER, F_SLOW, editor alpha 255, blend mode Opaque.
+__device__ __forceinline__ void load_shade_view(const FillArgs& a, uint32_t sid, bool need5, RecView& r) {
+    const uint4* sp = reinterpret_cast<const uint4*>(a.srecs + sid);
+    const uint4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3];
+    view_edges_from_shade(r, s0, s1);
+    r.q1.w = 0; r.q2.x = 0;
+    r.q2.y = s2.x; r.q2.z = s2.y; r.q2.w = s2.z;
+    r.q3.x = s2.w; r.q3.y = s3.x; r.q3.z = s3.y;
+    const uint32_t sh = s3.w >> 24;
+    r.q3.w = shade_tex_slot(s1, s3) | ((sh & SH_BLACK_TR) ? F_BLACK_TR : 0u) | ((sh & SH_DITHER) ? F_DITHER : 0u) | ((sh & SH_SLOW) ? F_SLOW : 0u) |
+             (255u << F_ALPHA_SHIFT);
+    r.q4 = make_uint4(s1.w & 0xFFFFFFu, s3.z & 0xFFFFFFu, s3.w & 0xFFFFFFu, 0u);
+    r.q5 = make_uint4(0, 0, 0, 0);
+    if (need5 || (sh & SH_SLOW)) {
+        const uint4* xp = reinterpret_cast<const uint4*>(a.xrecs + sid);
+        const uint4 x0 = xp[0], x1 = xp[1];
+        r.q4.w = x0.w; r.q5 = make_uint4(x1.x, x0.x, x0.y, x0.z);
+    }
+    if (sh & SH_SLOW) { const uint4 c1 = reinterpret_cast<const uint4*>(a.crecs + sid)[1]; r.q1.w = c1.x; r.q2.x = c1.y; }
+}
+// Everything about a surface, with its true flags word (blend mode, editor alpha, class): the ordered pass and the list scans.
+__device__ __forceinline__ void load_full_view(const FillArgs& a, uint32_t sid, RecView& r) {
+    load_shade_view(a, sid, true, r);
+    const uint4 c1 = reinterpret_cast<const uint4*>(a.crecs + sid)[1];
+    r.q1.w = c1.x; r.q2.x = c1.y; r.q3.w = c1.w;
+}
+
+// Lane's list entry -> its coverage view (quads q0, q1, q2.x, q3.w), painter's key and face id.  need_uv: also the UVs and the texture
+// (EXACT coverage applies the texel rule); need_aux: also the 1/z terms (z-buffer depth, perspective-correct UVs).
 template <int TEXMODE>
-__device__ __forceinline__ void load_batch(Batch& b, const FillArgs& a, uint32_t entry, bool live, const TexDesc& lds_desc, bool need_uv) {
+__device__ __forceinline__ void load_batch(Batch& b, const FillArgs& a, uint32_t entry, bool live, const TexDesc& lds_desc, bool need_uv,
+                                           bool need_aux, uint32_t& sid_out, uint32_t& key_out) {
     b.q0 = b.q1 = b.q2 = b.q3 = b.q4 = b.q5 = make_uint4(0, 0, 0, 0);
     b.tw = b.th = b.toff = 0;
+    sid_out = 0; key_out = 0;
     if (live) {
         const uint32_t sid = a.pair_vals[entry];
-        const uint4* p = reinterpret_cast<const uint4*>(a.recs + sid);
-        b.q0 = p[0]; b.q1 = p[1]; b.q2 = p[2]; b.q3 = p[3];
-        if (need_uv) {
-            b.q4 = p[4]; b.q5 = p[5];
-            const uint32_t tid = b.q3.w & F_TEX_MASK;
-            if (tid != F_TEX_NONE) {
-                if (TEXMODE == 1) { b.tw = lds_desc.width; b.th = lds_desc.height; b.toff = 0; }
-                else { const TexDesc d = a.tex[tid]; b.tw = d.width; b.th = d.height; b.toff = d.offset; }
+        const uint4* cp = reinterpret_cast<const uint4*>(a.crecs + sid);
+        const uint4 c0 = cp[0], c1 = cp[1];
+        sid_out = sid; key_out = c1.z;
+        RecView v;
+        v.q0 = v.q1 = v.q2 = v.q3 = v.q4 = v.q5 = make_uint4(0, 0, 0, 0);
+        const bool narrow = view_from_cov(v, c0, c1);
+        if (!narrow || need_uv) {
+            const uint4* sp = reinterpret_cast<const uint4*>(a.srecs + sid);
+            const uint4 s0 = sp[0], s1 = sp[1];
+            if (!narrow) view_edges_from_shade(v, s0, s1);
+            if (need_uv) {
+                const uint4 s2 = sp[2], s3 = sp[3];
+                v.q2.y = s2.x; v.q2.z = s2.y; v.q2.w = s2.z;
+                v.q3.x = s2.w; v.q3.y = s3.x; v.q3.z = s3.y;
+                v.q4 = make_uint4(s1.w & 0xFFFFFFu, s3.z & 0xFFFFFFu, s3.w & 0xFFFFFFu, 0u);
+                const uint32_t tid = c1.w & F_TEX_MASK;
+                if (tid != F_TEX_NONE) {
+                    if (TEXMODE == 1) { b.tw = lds_desc.width; b.th = lds_desc.height; b.toff = 0; }
+                    else { const TexDesc d = a.tex[tid]; b.tw = d.width; b.th = d.height; b.toff = d.offset; }
+                }
             }
-        } else if (b.q3.w & F_SLOW) {
-            b.q4 = p[4]; b.q5 = p[5];
         }
+        if (need_aux || (c1.w & F_SLOW)) {
+            const uint4* xp = reinterpret_cast<const uint4*>(a.xrecs + sid);
+            const uint4 x0 = xp[0], x1 = xp[1];
+            v.q4.w = x0.w; v.q5 = make_uint4(x1.x, x0.x, x0.y, x0.z);
+        }
+        b.q0 = v.q0; b.q1 = v.q1; b.q2 = v.q2; b.q3 = v.q3; b.q4 = v.q4; b.q5 = v.q5;
     }
 }
 // Wave-uniform view of lane t's record.  `full` = also UVs / texture (not needed by CHEAP coverage).
@@ -306,29 +355,6 @@ __device__ __forceinline__ Tri tri_from_batch(const Batch& b, int t, bool full) 
     if (full) { r.iz1 = bcf(__uint_as_float(b.q5.y), t); r.iz2 = bcf(__uint_as_float(b.q5.z), t); r.iz3 = bcf(__uint_as_float(b.q5.w), t); }
     return r;
 }
-template <int TEXMODE>
-__device__ __forceinline__ Tri tri_from_mem(const FillArgs& a, uint32_t sid, const TexDesc& lds_desc, uint4& q4) {
-    const uint4* rp = reinterpret_cast<const uint4*>(a.recs + sid);
-    const uint4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3], q5 = rp[5];
-    q4 = rp[4];
-    Tri r;
-    r.x3 = __uint_as_float(q0.x); r.y3 = __uint_as_float(q0.y); r.a0 = __uint_as_float(q0.z); r.b0 = __uint_as_float(q0.w);
-    r.a1 = __uint_as_float(q1.x); r.b1 = __uint_as_float(q1.y); r.inv_area = __uint_as_float(q1.z);
-    r.min_x = q1.w & 0xFFFF; r.max_x = q1.w >> 16; r.min_y = q2.x & 0xFFFF; r.max_y = q2.x >> 16;
-    r.u1 = __uint_as_float(q2.y); r.u2 = __uint_as_float(q2.z); r.u3 = __uint_as_float(q2.w);
-    r.v1 = __uint_as_float(q3.x); r.v2 = __uint_as_float(q3.y); r.v3 = __uint_as_float(q3.z);
-    r.flags = q3.w;
-    r.w0_start = __uint_as_float(q4.w); r.w1_start = __uint_as_float(q5.x);
-    r.iz1 = __uint_as_float(q5.y); r.iz2 = __uint_as_float(q5.z); r.iz3 = __uint_as_float(q5.w);
-    r.tw = r.th = r.toff = 0;
-    const uint32_t txid = r.flags & F_TEX_MASK;
-    if (txid != F_TEX_NONE) {
-        if (TEXMODE == 1) { r.tw = lds_desc.width; r.th = lds_desc.height; }
-        else { const TexDesc d = a.tex[txid]; r.tw = d.width; r.th = d.height; r.toff = d.offset; }
-    }
-    return r;
-}
-
 // Records a drawn fragment of list entry li in the tile buffer(s).
 //   painter's EXACT: max list position.  painter's CHEAP: exact top-2 (see k_cover).  z-buffer: min of (depth key, list position)
 //   == the first surface in face order reaching the smallest depth, what the sequential `z < zbuffer` test leaves behind.
@@ -354,8 +380,9 @@ __device__ __forceinline__ bool frag_zkey(const Tri& t, float bcx, float bcy, fl
 // Depth of surface `sid` at pixel (px, py) with its exact bits (only needed when the z-buffer key decoded to zero: the key does not
 // carry the sign of a zero depth).  Same arithmetic as the coverage: edge functions -> barycentrics -> 1 / (bc . 1/z).
 __device__ float exact_depth_at(const FillArgs& a, uint32_t sid, uint32_t px, uint32_t py) {
-    const uint4* rp = reinterpret_cast<const uint4*>(a.recs + sid);
-    const uint4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3], q4 = rp[4], q5 = rp[5];
+    RecView rv;
+    load_full_view(a, sid, rv);
+    const uint4 q0 = rv.q0, q1 = rv.q1, q2 = rv.q2, q3 = rv.q3, q4 = rv.q4, q5 = rv.q5;
     Tri tr;
     tr.x3 = __uint_as_float(q0.x); tr.y3 = __uint_as_float(q0.y); tr.a0 = __uint_as_float(q0.z); tr.b0 = __uint_as_float(q0.w);
     tr.a1 = __uint_as_float(q1.x); tr.b1 = __uint_as_float(q1.y); tr.inv_area = __uint_as_float(q1.z);
@@ -564,12 +591,12 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
         const uint32_t e = cs + lane;
         bool live = lane < grab && e < n_op;
         Batch b;
-        load_batch<TEXMODE>(b, a, e0 + e, live, lds_desc, EXACT || (P64 && ZMODE));
         // P64: the surface's place in the global painter's order; in z-buffer mode the high word is the fragment's depth and the
         // low word 0xFFFFFFFE - face id (first in face order wins a depth tie, like the sequential `z < zbuffer` test; all ones is
         // reserved for the z-buffer seed, which therefore wins every tie: `z < zbuffer` is strict)
         uint32_t my_sid = 0, my_key = 0;
-        if (P64 && live) { my_sid = a.pair_vals[e0 + e]; my_key = ZMODE ? 0u : a.keys[my_sid]; if (ZMODE) my_sid = 0xFFFFFFFEu - my_sid; }
+        load_batch<TEXMODE>(b, a, e0 + e, live, lds_desc, EXACT, ZMODE || (EXACT && !affine), my_sid, my_key);
+        if (ZMODE) { my_key = 0u; my_sid = 0xFFFFFFFEu - my_sid; }
         const uint32_t flags = b.q3.w;
         const uint32_t cx0 = max(b.q1.w & 0xFFFF, x_lo), cx1 = min(b.q1.w >> 16, x_hi);
         const uint32_t cy0 = max(b.q2.x & 0xFFFF, y_lo), cy1 = min(b.q2.x >> 16, y_hi);
@@ -1053,8 +1080,10 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a) {
 struct Hit { float bcx, bcy, bcz; uint32_t texel, vc1, vc2, vc3, flags, sid; };
 template <bool FMT8>
 __device__ __forceinline__ bool hit_test(const FillArgs& a, uint32_t sid, uint32_t px, uint32_t py, Hit& h) {
-    const uint4* rp = reinterpret_cast<const uint4*>(a.recs + sid);
-    const uint4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3], q4 = rp[4];
+    const bool affine = a.fp.affine != 0;
+    RecView rv;
+    load_shade_view(a, sid, !affine, rv);
+    const uint4 q0 = rv.q0, q1 = rv.q1, q2 = rv.q2, q3 = rv.q3, q4 = rv.q4, q5 = rv.q5;
     Tri tr;
     tr.x3 = __uint_as_float(q0.x); tr.y3 = __uint_as_float(q0.y); tr.a0 = __uint_as_float(q0.z); tr.b0 = __uint_as_float(q0.w);
     tr.a1 = __uint_as_float(q1.x); tr.b1 = __uint_as_float(q1.y); tr.inv_area = __uint_as_float(q1.z);
@@ -1062,10 +1091,8 @@ __device__ __forceinline__ bool hit_test(const FillArgs& a, uint32_t sid, uint32
     tr.u1 = __uint_as_float(q2.y); tr.u2 = __uint_as_float(q2.z); tr.u3 = __uint_as_float(q2.w);
     tr.v1 = __uint_as_float(q3.x); tr.v2 = __uint_as_float(q3.y); tr.v3 = __uint_as_float(q3.z);
     tr.flags = q3.w;
-    tr.w0_start = __uint_as_float(q4.w); tr.w1_start = 0.0f;
-    tr.iz1 = tr.iz2 = tr.iz3 = 0.0f;
-    const bool affine = a.fp.affine != 0;
-    if ((tr.flags & F_SLOW) || !affine) { const uint4 q5 = rp[5]; tr.w1_start = __uint_as_float(q5.x); tr.iz1 = __uint_as_float(q5.y); tr.iz2 = __uint_as_float(q5.z); tr.iz3 = __uint_as_float(q5.w); }
+    tr.w0_start = __uint_as_float(q4.w); tr.w1_start = __uint_as_float(q5.x);
+    tr.iz1 = __uint_as_float(q5.y); tr.iz2 = __uint_as_float(q5.z); tr.iz3 = __uint_as_float(q5.w);
     tr.tw = tr.th = tr.toff = 0;
     const uint32_t txid = tr.flags & F_TEX_MASK;
     if (txid != F_TEX_NONE) {
@@ -1094,13 +1121,8 @@ __device__ __forceinline__ uint32_t colour(const FillArgs& a, const Hit& h, int 
 // round trip through HBM, and while one workgroup of a CU sits in the (memory-latency bound) shading phase the other one
 // runs its (LDS/VALU bound) coverage phase.  Each lane shades TWO pixels at a time: both record gathers are issued before
 // either is used, then both texel fetches, so two dependent load chains are in flight per lane.
-struct RecRegs { uint4 q0, q1, q2, q3, q4, q5; };
-__device__ __forceinline__ void rec_load(const FillArgs& a, uint32_t sid, bool need5, RecRegs& r) {
-    const uint4* rp = reinterpret_cast<const uint4*>(a.recs + sid);
-    r.q0 = rp[0]; r.q1 = rp[1]; r.q2 = rp[2]; r.q3 = rp[3]; r.q4 = rp[4];
-    r.q5 = make_uint4(0, 0, 0, 0);
-    if (need5 || (r.q3.w & F_SLOW)) r.q5 = rp[5];                // literal-replay start value w1_start lives in q5
-}
+using RecRegs = RecView;
+__device__ __forceinline__ void rec_load(const FillArgs& a, uint32_t sid, bool need5, RecRegs& r) { load_shade_view(a, sid, need5, r); }
 // inside test + texel address (index into the texel pool; -1 = untextured -> white, -2 = zero-size texture -> transparent)
 __device__ __forceinline__ bool hit_prepare(const FillArgs& a, const RecRegs& r, uint32_t px, uint32_t py, Hit& h, int& taddr) {
     Tri tr;
@@ -1163,8 +1185,8 @@ __device__ __forceinline__ uint32_t fetch_texel(const FillArgs& a, int taddr) {
 
 // depth of surface `sid` at the pixel whose barycentrics are in h (render.rs:1546-1550) as a z-buffer priority word
 __device__ __forceinline__ bool depth_prio(const FillArgs& a, uint32_t sid, const Hit& h, unsigned long long& P) {
-    const uint4 q5 = reinterpret_cast<const uint4*>(a.recs + sid)[5];
-    const float inv_z = h.bcx * __uint_as_float(q5.y) + h.bcy * __uint_as_float(q5.z) + h.bcz * __uint_as_float(q5.w);
+    const uint4 x0 = reinterpret_cast<const uint4*>(a.xrecs + sid)[0];             // iz1, iz2, iz3
+    const float inv_z = h.bcx * __uint_as_float(x0.x) + h.bcy * __uint_as_float(x0.y) + h.bcz * __uint_as_float(x0.z);
     const float z = 1.0f / inv_z;
     P = ((unsigned long long)(~zsort_key(z)) << 32) | (0xFFFFFFFEu - sid);
     return z == z;
@@ -1233,8 +1255,8 @@ __device__ __forceinline__ void shade_tile_p64(const FillArgs& a, const uint32_t
                     unsigned long long cand = 0;
                     if (base + lane < e1) {
                         const uint32_t csid = a.pair_vals[base + lane];
-                        const uint4* rp = reinterpret_cast<const uint4*>(a.recs + csid);
-                        const uint32_t bbx = rp[1].w, bby = rp[2].x;
+                        const uint4 cc1 = reinterpret_cast<const uint4*>(a.crecs + csid)[1];
+                        const uint32_t bbx = cc1.x, bby = cc1.y;
                         if (fx >= (bbx & 0xFFFF) && fx < (bbx >> 16) && fy >= (bby & 0xFFFF) && fy < (bby >> 16)) {
                             unsigned long long P = ((unsigned long long)a.keys[csid] << 32) | csid;
                             Hit c;
@@ -1311,8 +1333,8 @@ __global__ __launch_bounds__(256) void k_shade(FillArgs a) {
             if (lane < top) {
                 const uint32_t cli = top - lane;
                 const uint32_t csid = a.pair_vals[e0 + cli - 1];
-                const uint4* rp = reinterpret_cast<const uint4*>(a.recs + csid);
-                const uint32_t bbx = rp[1].w, bby = rp[2].x;
+                const uint4 cc1 = reinterpret_cast<const uint4*>(a.crecs + csid)[1];
+                const uint32_t bbx = cc1.x, bby = cc1.y;
                 if (fx >= (bbx & 0xFFFF) && fx < (bbx >> 16) && py >= (bby & 0xFFFF) && py < (bby >> 16)) hit = hit_test<FMT8>(a, csid, fx, py, c);
             }
             const unsigned long long hm = __ballot(hit);
@@ -1448,15 +1470,31 @@ __global__ __launch_bounds__(NT, 4) void k_blend(FillArgs a) {        // 4 waves
     // chunk's fragments to its rows surface after surface: LDS reads and the blend, no global memory.
     for (uint32_t cs = 0; cs < n_tr; ) {
         const uint32_t cnt = min(64u, n_tr - cs);
-        {   // stage the chunk's records in LDS once per workgroup: 8 threads per surface, 16 B each
+        {   // stage the chunk's records in LDS once per workgroup: 8 threads per surface; each assembles two quads of the surface's view
+            // (q0..q5, then the texture descriptor + face id, then a spare) from the compact records
             const uint32_t sfc = tid >> 3, part = tid & 7;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (sfc < cnt) {
                 const uint32_t sid = a.pair_vals[e1 + cs + sfc];
-                const uint4* rp = reinterpret_cast<const uint4*>(a.recs + sid);
-                if (part < 6) v = rp[part];
+                const uint4* cp = reinterpret_cast<const uint4*>(a.crecs + sid);
+                const uint4* sp = reinterpret_cast<const uint4*>(a.srecs + sid);
+                const uint4* xp = reinterpret_cast<const uint4*>(a.xrecs + sid);
+                const uint4 c1 = cp[1];
+                const bool aux = !affine || zmode || (c1.w & F_SLOW);
+                if (part < 2) {                              // q0, q1: edges from the vertices + bbx
+                    const uint4 s0 = sp[0], s1 = sp[1];
+                    RecView rv;
+                    view_edges_from_shade(rv, s0, s1);
+                    rv.q1.w = c1.x;
+                    v = part == 0 ? rv.q0 : rv.q1;
+                } else if (part == 2) { const uint4 s2 = sp[2]; v = make_uint4(c1.y, s2.x, s2.y, s2.z); }            // bby, u1, u2, u3
+                else if (part == 3) { const uint4 s2 = sp[2], s3 = sp[3]; v = make_uint4(s2.w, s3.x, s3.y, c1.w); }  // v1, v2, v3, flags
+                else if (part == 4) {
+                    const uint4 s1 = sp[1], s3 = sp[3];
+                    v = make_uint4(s1.w & 0xFFFFFFu, s3.z & 0xFFFFFFu, s3.w & 0xFFFFFFu, aux ? xp[0].w : 0u);        // vc1, vc2, vc3, w0_start
+                } else if (part == 5) { if (aux) { const uint4 x0 = xp[0], x1 = xp[1]; v = make_uint4(x1.x, x0.x, x0.y, x0.z); } }   // w1_start, iz1..3
                 else if (part == 6) {
-                    const uint32_t txid = rp[3].w & F_TEX_MASK;
+                    const uint32_t txid = c1.w & F_TEX_MASK;
                     TexDesc d = none;
                     if (txid != F_TEX_NONE) d = a.tex[txid];
                     v = make_uint4(d.width, d.height, d.offset, sid);

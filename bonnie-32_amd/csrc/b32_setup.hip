@@ -183,7 +183,7 @@ __device__ __forceinline__ uint32_t fog_color(uint32_t c, uint32_t fogc, float f
 template <int SETUP_FPT>
 __global__ __launch_bounds__(256) void k_setup(FrameParams fp, const B32Vertex* __restrict__ verts, const B32Face* __restrict__ faces,
                                                const TexDesc* __restrict__ tex, const B32Light* __restrict__ lights_mem, LightSet lset,
-                                               SurfRec* __restrict__ recs, float* __restrict__ shades, uint32_t* __restrict__ keys,
+                                               RecArrays recs, float* __restrict__ shades, uint32_t* __restrict__ keys,
                                                uint32_t* __restrict__ spans, uint32_t* __restrict__ partials, Ctrl* __restrict__ ctrl,
                                                WireTri* __restrict__ wire) {
     __shared__ uint32_t wpart[4][6];
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp, const B32Vertex* 
                 // Surface build: rendered backfaces swap v2/v3 and every per-vertex attribute (render.rs:2453-2479)
                 const int i1 = 0, i2 = backface ? 2 : 1, i3 = backface ? 1 : 2;
                 const V3 v1 = scr[i1], v2 = scr[i2], v3 = scr[i3];
-                SurfRec r;
+                struct { float inv_area, a0, b0, a1, b1, w0_start, w1_start; uint32_t bbx, bby, flags; } r;
                 // bbox, render.rs:1455-1458
                 uint32_t min_x = f2u_sat(rmax(rmin(rmin(v1.x, v2.x), v3.x), 0.0f));
                 uint32_t max_x = f2u_sat(rmin(rmax(rmax(v1.x, v2.x), v3.x) + 1.0f, (float)fp.width));
@@ -309,15 +309,10 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp, const B32Vertex* 
                 if (empty) { min_x = max_x = min_y = max_y = 0; }
                 r.inv_area = 1.0f / area;
                 r.a0 = v2.y - v3.y; r.b0 = v3.x - v2.x; r.a1 = v3.y - v1.y; r.b1 = v1.x - v3.x;   // :1507-1510
-                r.x3 = v3.x; r.y3 = v3.y;
                 const float start_x = (float)min_x, start_y = (float)min_y;
                 r.w0_start = r.a0 * (start_x - v3.x) + r.b0 * (start_y - v3.y);                    // :1517
                 r.w1_start = r.a1 * (start_x - v3.x) + r.b1 * (start_y - v3.y);                    // :1518
                 r.bbx = min_x | (max_x << 16); r.bby = min_y | (max_y << 16);
-                r.u1 = uvx[i1]; r.u2 = uvx[i2]; r.u3 = uvx[i3];
-                r.v1 = uvy[i1]; r.v2 = uvy[i2]; r.v3 = uvy[i3];
-                r.vc1 = col[i1] & 0xFFFFFF; r.vc2 = col[i2] & 0xFFFFFF; r.vc3 = col[i3] & 0xFFFFFF;
-                r.iz1 = 1.0f / v1.z; r.iz2 = 1.0f / v2.z; r.iz3 = 1.0f / v3.z;                       // :1546-1548
                 // Closed-form eligibility: with integer vertices every value the reference's incremental walk ever holds
                 // is an exact integer when |w| < 2^24 over the bbox and both start products are < 2^24.
                 bool slow = !fp.fixed_point || fp.ortho;
@@ -352,7 +347,6 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp, const B32Vertex* 
                 // multi-GPU band sharding: every rank decides visibility for every face (triangles_drawn, painter's keys), but only the
                 // surfaces reaching its own rows are ever read again
                 const bool need_rec = !fp.band_only || n_tiles != 0;
-                if (need_rec) recs[f] = r;
                 if (need_rec && fp.shading != B32_SHADE_NONE) {
                     V3 wn[3];
 #pragma unroll
@@ -389,6 +383,33 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp, const B32Vertex* 
                 if (fp.ortho) key = ~zsort_key(kz);
                 if (fp.zmode && !transparent) key = 0;
                 if (key == KEY_INVALID) key = 0xFFFFFFFEu;    // unreachable for z > 5; keeps the sentinel unique
+                if (need_rec) {
+                    // vertices as i16 when all six are integers within range (fixed-point snap, on or near the screen)
+                    const float lim16 = 32767.0f;
+                    const bool fits = __builtin_fabsf(v1.x) <= lim16 && __builtin_fabsf(v1.y) <= lim16 && __builtin_fabsf(v2.x) <= lim16 &&
+                                      __builtin_fabsf(v2.y) <= lim16 && __builtin_fabsf(v3.x) <= lim16 && __builtin_fabsf(v3.y) <= lim16 &&
+                                      v1.x == __builtin_truncf(v1.x) && v1.y == __builtin_truncf(v1.y) && v2.x == __builtin_truncf(v2.x) &&
+                                      v2.y == __builtin_truncf(v2.y) && v3.x == __builtin_truncf(v3.x) && v3.y == __builtin_truncf(v3.y);
+                    auto pk16 = [](float x, float y) { return ((uint32_t)(int32_t)x & 0xFFFFu) | ((uint32_t)(int32_t)y << 16); };
+                    uint4 c0, c1;
+                    c0.x = fits ? pk16(v1.x, v1.y) : COV_WIDE; c0.y = fits ? pk16(v2.x, v2.y) : 0u; c0.z = fits ? pk16(v3.x, v3.y) : 0u;
+                    c0.w = __float_as_uint(r.inv_area);
+                    c1 = make_uint4(r.bbx, r.bby, key, r.flags);
+                    uint4* cp = reinterpret_cast<uint4*>(recs.cov + f);
+                    cp[0] = c0; cp[1] = c1;
+                    const uint32_t slot = have_tex ? tid : F_TEX_NONE;
+                    const uint32_t sh = (black_tr ? SH_BLACK_TR : 0u) | (needs_dither ? SH_DITHER : 0u) | (slow ? SH_SLOW : 0u);
+                    uint4* sp = reinterpret_cast<uint4*>(recs.shade + f);
+                    sp[0] = make_uint4(__float_as_uint(v1.x), __float_as_uint(v1.y), __float_as_uint(v2.x), __float_as_uint(v2.y));
+                    sp[1] = make_uint4(__float_as_uint(v3.x), __float_as_uint(v3.y), __float_as_uint(r.inv_area), (col[i1] & 0xFFFFFFu) | ((slot & 0xFFu) << 24));
+                    sp[2] = make_uint4(__float_as_uint(uvx[i1]), __float_as_uint(uvx[i2]), __float_as_uint(uvx[i3]), __float_as_uint(uvy[i1]));
+                    sp[3] = make_uint4(__float_as_uint(uvy[i2]), __float_as_uint(uvy[i3]), (col[i2] & 0xFFFFFFu) | ((slot >> 8) << 24), (col[i3] & 0xFFFFFFu) | (sh << 24));
+                    if (fp.zmode || !fp.affine || slow) {
+                        uint4* xp = reinterpret_cast<uint4*>(recs.aux + f);
+                        xp[0] = make_uint4(__float_as_uint(1.0f / v1.z), __float_as_uint(1.0f / v2.z), __float_as_uint(1.0f / v3.z), __float_as_uint(r.w0_start));   // :1546-1548
+                        xp[1] = make_uint4(__float_as_uint(r.w1_start), 0u, 0u, 0u);
+                    }
+                }
             }
         }
         keys[f] = key;
@@ -414,7 +435,7 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp, const B32Vertex* 
 }
 
 void launch_setup(hipStream_t s, const FrameParams& fp, const B32Vertex* verts, const B32Face* faces, const TexDesc* tex,
-                  const B32Light* lights, const LightSet& ls, SurfRec* recs, float* shades, uint32_t* keys, uint32_t* spans, uint32_t* partials,
+                  const B32Light* lights, const LightSet& ls, RecArrays recs, float* shades, uint32_t* keys, uint32_t* spans, uint32_t* partials,
                   Ctrl* ctrl, WireTri* wire) {
     if (fp.nf == 0) return;
     if (fp.nf >= 400000) hipLaunchKernelGGL(k_setup<2>, dim3((fp.nf + 511) / 512), dim3(256), 0, s, fp, verts, faces, tex, lights, ls, recs, shades, keys, spans, partials, ctrl, wire);

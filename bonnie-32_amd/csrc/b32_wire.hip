@@ -15,13 +15,13 @@
 
 namespace b32 {
 
-__global__ void k_class_keys(const SurfRec* __restrict__ recs, const uint32_t* __restrict__ order, const uint32_t* __restrict__ n_dev,
+__global__ void k_class_keys(const CovRec* __restrict__ recs, const uint32_t* __restrict__ order, const uint32_t* __restrict__ n_dev,
                              uint32_t n_cap, uint32_t* __restrict__ keys_out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n = min(*n_dev, n_cap);
     if (i < n) keys_out[i] = (recs[order[i]].flags & F_TRANSP) ? 1u : 0u;
 }
-void launch_class_keys(hipStream_t s, const SurfRec* recs, const uint32_t* order, const uint32_t* n_dev, uint32_t n_cap, uint32_t* keys_out) {
+void launch_class_keys(hipStream_t s, const CovRec* recs, const uint32_t* order, const uint32_t* n_dev, uint32_t n_cap, uint32_t* keys_out) {
     if (!n_cap) return;
     hipLaunchKernelGGL(k_class_keys, dim3((n_cap + 255) / 256), dim3(256), 0, s, recs, order, n_dev, n_cap, keys_out);
 }
