@@ -133,7 +133,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("B32_LIB") or LIB_PATH          # B32_LIB: an experiment build (tools/exp_variants.py); never set by the product
     if not os.path.exists(p):
         raise RuntimeError(
             f"{p} is missing: build the HIP library first (python -c 'import __graft_entry__ as g; g.build()'). "

@@ -30,10 +30,11 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    if not force and not needs_build():
+def build(force=False, verbose=False, out=None, extra=()):
+    """out / extra: an experiment build with more -D flags into another file (tools/exp_variants.py)"""
+    if out is None and not force and not needs_build():
         return OUT
-    cmd = [hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT]
+    cmd = [hipcc()] + FLAGS + list(extra) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out or OUT]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or r.returncode:
         print(" ".join(cmd))
@@ -41,7 +42,7 @@ def build(force=False, verbose=False):
         print(r.stderr)
     if r.returncode:
         raise RuntimeError("hipcc failed")
-    return OUT
+    return out or OUT
 
 
 if __name__ == "__main__":

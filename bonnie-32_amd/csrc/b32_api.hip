@@ -630,8 +630,8 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     fp.band_y0 = c->band_y0; fp.band_y1 = c->band_y1;
     fp.tiles_x = (c->width + TILE_W - 1) / TILE_W;
     fp.tile_h = TILE_H;
-    fp.tile_y0 = c->band_y0 / TILE_H;
-    fp.tiles_y = c->band_y1 > c->band_y0 ? (c->band_y1 + TILE_H - 1) / TILE_H - fp.tile_y0 : 0;
+    fp.tile_yb = (c->band_y0 / TILE_H) * TILE_H;
+    fp.tiles_y = c->band_y1 > c->band_y0 ? (c->band_y1 - fp.tile_yb + TILE_H - 1) / TILE_H : 0;
     fp.nv = c->nv; fp.nf = c->nf; fp.nt = c->nt;
     fp.n_lights = st->shading != B32_SHADE_NONE ? st->n_lights : 0;
     fp.ambient = st->ambient;
@@ -749,8 +749,8 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
         while (th > 16 && fp.tiles_x * ((c->band_y1 + th - 1) / th - c->band_y0 / th) < (th == TILE_H ? 2u : 1u) * (uint32_t)c->n_cu &&
                (c->band_y1 - c->band_y0) / (th / 2) + 2 <= 255 /* tile rows must fit the packed spans */) th /= 2;
         fp.tile_h = th;
-        fp.tile_y0 = c->band_y0 / th;
-        fp.tiles_y = (c->band_y1 + th - 1) / th - fp.tile_y0;
+        fp.tile_yb = (c->band_y0 / th) * th;
+        fp.tiles_y = (c->band_y1 - fp.tile_yb + th - 1) / th;
         ntiles = fp.tiles_x * fp.tiles_y;
         n_keys = 2 * ntiles;
     }

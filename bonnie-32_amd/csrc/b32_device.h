@@ -201,8 +201,9 @@ struct FrameParams {
     B32Camera cam;
     uint32_t width, height;
     uint32_t band_y0, band_y1;
-    uint32_t tiles_x, tiles_y, tile_y0;    // tile grid of the band: tiles_y rows starting at tile row tile_y0
-    uint32_t tile_h;                       // tile height of this frame: TILE_H, or TILE_H / 2 on the sort-free path when tiles are few
+    uint32_t tiles_x, tiles_y;             // tile grid of the band: tiles_y tile rows
+    uint32_t tile_yb;                      // y of the first tile row (a multiple of tile_h at or above band_y0)
+    uint32_t tile_h;                       // height of the tile rows: TILE_H, or TILE_H / 2, / 4 on the sort-free path when tiles are few
     uint32_t nv, nf, nt;
     uint32_t n_lights;
     float ambient;
@@ -293,6 +294,11 @@ __device__ __forceinline__ uint32_t blend_rgb555(uint32_t front, uint32_t back, 
     return out;
 }
 
+// tile row of screen row y (y >= fp.tile_yb) and its inverse: top screen row and height of tile row `row`
+__host__ __device__ __forceinline__ uint32_t tile_row_of(const FrameParams& fp, uint32_t y) { return (y - fp.tile_yb) / fp.tile_h; }
+__host__ __device__ __forceinline__ void tile_row_geom(const FrameParams& fp, uint32_t row, uint32_t& top, uint32_t& th) {
+    th = fp.tile_h; top = fp.tile_yb + row * th;
+}
 // Tile span of a surface's (band-clipped) bounding box, packed tx0 | tx1<<8 | ty0<<16 | ty1<<24 with band-relative tile rows
 // (<= 256 tiles per axis: 16384 px); 0xFFFFFFFF = touches no tile of this band.
 __device__ __forceinline__ uint32_t pack_tile_span(uint32_t bbx, uint32_t bby, uint32_t flags, const FrameParams& fp, uint32_t& count) {
@@ -302,7 +308,7 @@ __device__ __forceinline__ uint32_t pack_tile_span(uint32_t bbx, uint32_t bby, u
     const uint32_t min_y = max(bby & 0xFFFF, fp.band_y0), max_y = min(bby >> 16, fp.band_y1);   // other rows belong to another rank
     if (min_x >= max_x || min_y >= max_y) return 0xFFFFFFFFu;
     const uint32_t tx0 = min_x / TILE_W, tx1 = (max_x - 1) / TILE_W;
-    const uint32_t ty0 = min_y / fp.tile_h - fp.tile_y0, ty1 = (max_y - 1) / fp.tile_h - fp.tile_y0;
+    const uint32_t ty0 = tile_row_of(fp, min_y), ty1 = tile_row_of(fp, max_y - 1);
     count = (tx1 - tx0 + 1) * (ty1 - ty0 + 1);
     return tx0 | (tx1 << 8) | (ty0 << 16) | (ty1 << 24);
 }
@@ -417,6 +423,9 @@ struct FillArgs {
     const uint32_t* partials;   // k_setup's per-block counters
     uint32_t prio64;            // 1: sort-free coverage -- visibility is a 64-bit max of (painter's key << 32 | face id); `vis` holds
                                 //    two words per pixel: winner face id + 1, runner-up face id + 1 (0 = none)
+#ifdef B32_TIMELINE
+    unsigned long long* dbg;    // experiment builds only: [0] = entry counter, then 4 words per tile (wg << 32 | tile, t_start, t_covered, t_shaded)
+#endif
 };
 void launch_fill(hipStream_t s, const FillArgs& a, int n_cu, hipEvent_t after_cover = nullptr);   // k_cover [event] k_shade k_blend
 size_t fill_lds_tex_budget();   // bytes of LDS left for a staged texture

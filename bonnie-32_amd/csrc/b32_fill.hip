@@ -937,7 +937,11 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a) {
         __syncthreads();
         const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)misc[0]);
         if (tile >= ntiles) break;
-        if (tid == 0) next_tile = gridDim.x + atomicAdd(&a.ctrl->tile_cursor, 1u);    // prefetch the next tile index; consumed at the loop top
+        // The next tile is taken from the shared cursor as LATE as its latency can still hide: after this tile's coverage, before its
+        // shading (P64), so that the last tiles of the queue go to the workgroups that really are about to be free (taking it at the top
+        // of the tile, one whole tile ahead, made the last round of the queue a static assignment: tools/timeline.py).
+        const bool fetch_late = P64;
+        if (!fetch_late && tid == 0) next_tile = gridDim.x + atomicAdd(&a.ctrl->tile_cursor, 1u);
         uint32_t e0, e1;
         if (P64 && a.inline_bin) {               // the list is collected below, into this tile's own region
             e0 = e1 = tile * a.list_stride;
@@ -959,12 +963,12 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a) {
         } else {
             e0 = a.ranges[2 * tile]; e1 = a.ranges[2 * tile + 1];
         }
-        const uint32_t txi = tile % fp.tiles_x, tyi = tile / fp.tiles_x + fp.tile_y0;
+        const uint32_t txi = tile % fp.tiles_x;
         const uint32_t x_lo = txi * TILE_W, x_hi = min(x_lo + TILE_W, fp.width);
-        // the sort-free path may run on half-height tiles (fp.tile_h = 32) when a frame or band has too few 64x64 tiles to fill the
-        // GPU; the LDS planes keep their full-tile layout, only the rows in use change
-        const uint32_t TH = P64 ? fp.tile_h : (uint32_t)TILE_H;
-        const uint32_t ty_top = tyi * TH;
+        // the sort-free path may run on cut tiles (32 or 16 rows: too few 64x64 tiles to fill the GPU); the LDS planes keep their
+        // full-tile layout, only the rows in use change
+        uint32_t TH, ty_top;
+        tile_row_geom(fp, tile / fp.tiles_x, ty_top, TH);
         const uint32_t y_lo = max(ty_top, fp.band_y0), y_hi = min(ty_top + TH, fp.band_y1);
         if (P64 && a.inline_bin) {
             // the faces whose span reaches this tile, in any order (ballot compaction; misc[4..5] were zeroed with the tile index):
@@ -1024,14 +1028,27 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a) {
             }
         }
         const uint32_t n_op = e1 - e0;
+#ifdef B32_TIMELINE
+        const unsigned long long tl0 = wall_clock64();
+#endif
         if (n_op) {
             frag_count += phase_a_rows<TEXMODE, EXACT, NW, ZMODE, FMT8, P64>(a, e0, n_op, lane, wave, &misc[2], wmarks + wave * 64, lds_desc, tilebuf,
                                                            x_lo, x_hi, y_lo, y_hi, ty_top, ltex);
             __syncthreads();
         }
         if (P64) {          // shade the tile straight from the LDS winners (no visibility buffer)
+            if (tid == 0) next_tile = gridDim.x + atomicAdd(&a.ctrl->tile_cursor, 1u);
+#ifdef B32_TIMELINE
+            const unsigned long long tl1 = wall_clock64();
+#endif
             if (n_op) shade_tile_p64<FMT8, NT, ZMODE>(a, tilebuf, e0, e1, x_lo, x_hi, y_lo, y_hi, ty_top, tid, lane, TH);
             __syncthreads();
+#ifdef B32_TIMELINE
+            if (tid == 0 && a.dbg) {
+                const unsigned long long k = atomicAdd(a.dbg, 1ull);
+                if (k < 8192) { unsigned long long* e = a.dbg + 1 + 4 * k; e[0] = ((unsigned long long)blockIdx.x << 32) | tile | ((unsigned long long)n_op << 48); e[1] = tl0; e[2] = tl1; e[3] = wall_clock64(); }
+            }
+#endif
             continue;
         }
         // winners -> visibility buffer: one 256-B row segment per wave instruction (zeros for uncovered pixels)
@@ -1298,7 +1315,7 @@ __global__ __launch_bounds__(256) void k_shade(FillArgs a) {
     const uint32_t tile = (g >> 2) * 8 + (blockIdx.x & 7), strip = g & 3;
     if (tile >= fp.tiles_x * fp.tiles_y) return;
     const uint32_t seg_x = (tile % fp.tiles_x) * TILE_W;
-    const uint32_t ty_top = (tile / fp.tiles_x + fp.tile_y0) * TILE_H;
+    const uint32_t ty_top = fp.tile_yb + (tile / fp.tiles_x) * TILE_H;       // (the keyed pipelines never cut or grade their tiles)
     const uint32_t e0 = a.tile_keys_only ? a.ranges[tile] : a.ranges[2 * tile];
     const uint32_t px = seg_x + lane;
     const bool inb = px < W;
@@ -1445,10 +1462,10 @@ __global__ __launch_bounds__(NT, 4) void k_blend(FillArgs a) {        // 4 waves
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const int shading = fp.shading;
     const bool affine = fp.affine != 0;
-    const uint32_t txi = tile % fp.tiles_x, tyi = tile / fp.tiles_x + fp.tile_y0;
+    const uint32_t txi = tile % fp.tiles_x;
     const uint32_t x_lo = txi * TILE_W, x_hi = min(x_lo + TILE_W, fp.width);
-    const uint32_t TH = fp.tile_h;                  // 64, or 32 / 16 rows when the sort-free path runs on cut tiles (LDS layout unchanged)
-    const uint32_t ty_top = tyi * TH;
+    uint32_t TH, ty_top;                            // 64, or 32 / 16 rows when the sort-free path runs on cut tiles (LDS layout unchanged)
+    tile_row_geom(fp, tile / fp.tiles_x, ty_top, TH);
     const uint32_t y_lo = max(ty_top, fp.band_y0), y_hi = min(ty_top + TH, fp.band_y1);
     for (uint32_t p = tid; p < TILE_W * TH; p += NT) {
         const uint32_t row = p >> 6, col = p & 63;
@@ -1461,7 +1478,7 @@ __global__ __launch_bounds__(NT, 4) void k_blend(FillArgs a) {        // 4 waves
     unsigned long long frag_count = 0;
     const TexDesc none = { 0, 0, 0, 0 };
     const uint32_t n_tr = e2 - e1;
-    const uint32_t RPW = TH / NW;                   // tile rows owned by one wave in phase 2 (TH >= 16, NW = 8)
+    const uint32_t RPW = (TH + NW - 1) / NW;        // tile rows owned by one wave in phase 2 (TH >= 16, NW = 8; any height up to 64)
     const uint32_t wy0 = max(ty_top + wave * RPW, y_lo), wy1 = min(ty_top + wave * RPW + RPW, y_hi);
     // The walk is split so that only what MUST be ordered is ordered.  A chunk = consecutive list entries whose clipped bounding
     // boxes fit the fragment buffer.  Phase 1 (no order): the waves take the chunk's surfaces round-robin and evaluate every
@@ -1737,6 +1754,15 @@ static void launch_blend(hipStream_t s, const FillArgs& a, uint32_t ntiles) {
     hipLaunchKernelGGL((k_blend<BLEND_NT, FMT8, GATHER>), dim3(ntiles), dim3(BLEND_NT), lds, s, a);
 }
 
+#ifdef B32_TIMELINE
+static unsigned long long* g_timeline = nullptr;
+extern "C" int b32_debug_timeline(unsigned long long* out, unsigned cap_words) {       // experiment builds only
+    if (!g_timeline) return 0;
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(out, g_timeline, (size_t)cap_words * 8, hipMemcpyDeviceToHost);
+    return 1;
+}
+#endif
 template <bool EXACT, bool ZMODE, bool FMT8>
 static void launch_p64(hipStream_t s, const FillArgs& a, uint32_t ntiles, int n_cu, bool wide) {
     const size_t lds64 = 4 * LDS_TILE_BYTES + LDS_MISC_BYTES + LDS_MARK_BYTES;
@@ -1746,6 +1772,15 @@ static void launch_p64(hipStream_t s, const FillArgs& a, uint32_t ntiles, int n_
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<0, EXACT, 1024, ZMODE, FMT8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
     const dim3 g(min(ntiles, (uint32_t)n_cu * 2));
+#ifdef B32_TIMELINE
+    {
+        static unsigned long long* dbg = nullptr;
+        if (!dbg) (void)hipMalloc(reinterpret_cast<void**>(&dbg), (1 + 4 * 8192) * 8);
+        (void)hipMemsetAsync(dbg, 0, 8, s);
+        const_cast<FillArgs&>(a).dbg = dbg;
+        g_timeline = dbg;
+    }
+#endif
     if (wide) hipLaunchKernelGGL((k_cover<0, EXACT, 1024, ZMODE, FMT8, true>), g, dim3(1024), lds64, s, a);
     else hipLaunchKernelGGL((k_cover<0, EXACT, 512, ZMODE, FMT8, true>), g, dim3(512), lds64, s, a);
 }
