@@ -45,6 +45,7 @@ struct b32_ctx {
     bool have_scene = false;
     bool may_blend = true;              // some face / texture can produce a transparent-pass surface (render.rs:2403-2415)
     bool cheap_ok = false;              // every texture has few skippable texels: CHEAP coverage + repair is profitable
+    bool tex_blend_any = false;         // some texture of the resident scene has a blend mode other than Opaque
     int count_fragments = 0;            // 1: exact fragment-store count every frame (EXACT coverage); instrumentation, off by default
     bool last_exact = false;            // the last frame ran EXACT coverage in painter's mode (B32Timings.fragments is exact)
 
@@ -112,7 +113,7 @@ struct b32_scene {
     uint32_t* d_consts = nullptr;
     std::vector<TexDesc> h_tex;
     uint32_t nv = 0, nf = 0, nt = 0;
-    bool fmt8 = false, blend8 = false, have_scene = false, may_blend = true, cheap_ok = false, local_sort_ok = true;
+    bool fmt8 = false, blend8 = false, have_scene = false, may_blend = true, cheap_ok = false, local_sort_ok = true, tex_blend_any = false;
 };
 
 #define HIPCHK(ctx, expr)                                                 \
@@ -492,9 +493,11 @@ static size_t cheap_den() { static const size_t d = getenv("B32_CHEAP_DEN") ? (s
 static int layout_textures(b32_ctx* c, uint32_t nt, const uint32_t* w, const uint32_t* h, const uint32_t* blend, size_t* total, bool rgba = false) {
     if (nt > 65534) return B32_E_UNSUPPORTED;        // the surface record holds the texture slot in 16 bits
     c->h_tex.resize(nt);
+    c->tex_blend_any = false;
     size_t off = 0;
     for (uint32_t i = 0; i < nt; ++i) {
         if (w[i] > 65535 || h[i] > 65535) return B32_E_ARG;
+        if (blend[i] != B32_BLEND_OPAQUE) c->tex_blend_any = true;
         c->h_tex[i] = { w[i], h[i], blend[i], (uint32_t)off };
         off += ((size_t)w[i] * h[i] + 7) & ~(size_t)7;
         if (off > 0x7FFFFFFFull) return B32_E_ARG;
@@ -768,7 +771,8 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     if (prof_all) HIPCHK(c, hipEventRecord(ev[0], s));
     fp.band_only = (want_prio64 && c->band_set) ? 1 : 0;   // other ranks own the other rows: their surfaces' records are never read here
     fp.redraw = c->redrawing ? 1 : 0;
-    launch_setup(s, fp, c->d_verts, c->d_faces, c->d_tex, c->d_lights, lset, RecArrays{ c->crecs, c->srecs, c->xrecs }, c->shades, c->keys[0], c->spans, c->partials, c->d_ctrl, c->wire);
+    fp.tex_blend_any = c->tex_blend_any ? 1 : 0;
+    launch_setup(s, fp, c->d_verts, c->d_faces, c->d_tex, c->d_lights, lset, RecArrays{ c->crecs, c->srecs, c->xrecs }, c->shades, c->keys[0], c->spans, c->partials, c->d_ctrl, c->wire, c->n_cu);
     if (prof_all) HIPCHK(c, hipEventRecord(ev[1], s));
 
     int cur = 0;
@@ -1010,6 +1014,7 @@ int b32_scene_swap(b32_ctx* c, b32_scene* sl) {
     std::swap(c->nv, sl->nv); std::swap(c->nf, sl->nf); std::swap(c->nt, sl->nt);
     std::swap(c->fmt8, sl->fmt8); std::swap(c->blend8, sl->blend8); std::swap(c->have_scene, sl->have_scene);
     std::swap(c->may_blend, sl->may_blend); std::swap(c->cheap_ok, sl->cheap_ok); std::swap(c->local_sort_ok, sl->local_sort_ok);
+    std::swap(c->tex_blend_any, sl->tex_blend_any);
     return B32_OK;
 }
 

@@ -210,7 +210,7 @@ struct FrameParams {
     uint8_t affine, shading, backface_cull, dithering, fixed_point, has_fog, zmode, fmt8;   // zmode = settings.use_zbuffer; fmt8 = render_mesh (8-bit colour)
     uint8_t ortho, xray, wire_collect, band_only;   // ortho_projection.is_some(), xray_mode, any wireframe phase wants its triangles;
                                                     // band_only: records of surfaces outside this rank's band are not needed (sort-free path)
-    uint8_t redraw, lights_inline, _padb[2];        // redraw: the host is repeating a dropped frame (not a new one); lights_inline: the
+    uint8_t redraw, lights_inline, tex_blend_any, _padb;   // tex_blend_any: some texture's blend mode is not Opaque (else k_setup never reads the descriptors)        // redraw: the host is repeating a dropped frame (not a new one); lights_inline: the
                                                     // lights travel in the kernel arguments (LightSet) instead of a device buffer
     float ortho_zoom, ortho_cx, ortho_cy;      // OrthoProjection (types.rs), math.rs:140-148
     B32Fog fog;
@@ -341,7 +341,7 @@ struct LightSet { B32Light l[LIGHTS_INLINE]; };
 struct RecArrays { CovRec* cov; ShadeRec* shade; AuxRec* aux; };
 void launch_setup(hipStream_t s, const FrameParams& fp, const B32Vertex* verts, const B32Face* faces, const TexDesc* tex,
                   const B32Light* lights, const LightSet& inline_lights, RecArrays recs, float* shades, uint32_t* keys, uint32_t* spans,
-                  uint32_t* partials, Ctrl* ctrl, WireTri* wire);
+                  uint32_t* partials, Ctrl* ctrl, WireTri* wire, int n_cu);
 void launch_project_fixed(hipStream_t s, const float* pos, uint32_t n, B32Camera cam, uint32_t w, uint32_t h,
                           int32_t* sx, int32_t* sy, float* z);
 void launch_selftest(hipStream_t s, int op, const float* a, const float* b, const float* c, float* out, uint32_t n);

@@ -30,17 +30,19 @@ __device__ __forceinline__ int32_t fx_mul(int32_t a, int32_t b) { return (int32_
 // Fixed32::div_unr, fixed.rs:178-230, split at the point where only the divisor has been used: project_to_screen divides x and
 // y by the same denominator (fixed.rs:411-412), so the table lookup and both Newton steps are done once per vertex.
 struct UnrRecip { uint64_t nr2; uint32_t shift; bool neg, zero; };
-__device__ __forceinline__ UnrRecip unr_recip(int32_t divisor) {
+__device__ __forceinline__ UnrRecip unr_recip(int32_t divisor, const uint8_t* __restrict__ table) {
     UnrRecip r;
     r.zero = divisor == 0; r.neg = divisor < 0;
     const uint32_t den = divisor < 0 ? (0u - (uint32_t)divisor) : (uint32_t)divisor;
     const uint32_t z = (uint32_t)__builtin_clz(den | (r.zero ? 1u : 0u));
-    const uint64_t d16 = ((uint64_t)den << z) >> K::DIV_D16_SHIFT;
-    uint64_t ti = (d16 - K::DIV_INDEX_BIAS) >> K::DIV_INDEX_SHIFT;
+    const uint32_t d16 = (den << z) >> K::DIV_D16_SHIFT;              // den << z has its top bit at bit 31 (0 for a zero divisor): 32 bits hold it
+    uint32_t ti = (d16 - (uint32_t)K::DIV_INDEX_BIAS) >> K::DIV_INDEX_SHIFT;   // (wraps to a huge value for d16 = 0, like the u64 wrapping_sub)
     if (ti > K::DIV_INDEX_MAX) ti = K::DIV_INDEX_MAX;
-    const uint64_t u = (uint64_t)g_unr.v[ti] + K::DIV_U_ADD;
-    const uint64_t nr1 = (K::DIV_NR1_CONST - d16 * u) >> K::DIV_NR1_SHIFT;
-    r.nr2 = (K::DIV_NR2_CONST + nr1 * u) >> K::DIV_NR2_SHIFT;
+    // d16 < 2^16, u <= 0xFF + 0x101 = 2^9: both Newton products are below 2^26 -- 32-bit arithmetic gives the u64 results of the
+    // reference (its wrapping_sub / wrapping_mul never wrap for these ranges: 0x2000080 - d16 * u >= 0x2000080 - 0xFFFF * 0x200 > 0)
+    const uint32_t u = (uint32_t)table[ti] + (uint32_t)K::DIV_U_ADD;
+    const uint32_t nr1 = ((uint32_t)K::DIV_NR1_CONST - d16 * u) >> K::DIV_NR1_SHIFT;
+    r.nr2 = (uint64_t)(((uint32_t)K::DIV_NR2_CONST + nr1 * u) >> K::DIV_NR2_SHIFT);
     r.shift = K::DIV_SHIFT_BASE - z;                // z in 0..31 -> shift in 5..36
     return r;
 }
@@ -53,11 +55,12 @@ __device__ __forceinline__ int32_t unr_apply(int32_t self, const UnrRecip& r) {
     const int32_t clamped = (int32_t)(mag < (uint64_t)INT32_MAX ? mag : (uint64_t)INT32_MAX);
     return neg ? -clamped : clamped;
 }
-__device__ __forceinline__ int32_t fx_div_unr(int32_t self, int32_t divisor) { return unr_apply(self, unr_recip(divisor)); }
+__device__ __forceinline__ int32_t fx_div_unr(int32_t self, int32_t divisor) { return unr_apply(self, unr_recip(divisor, g_unr.v)); }
 
 __device__ __forceinline__ CamFx make_camfx(const B32Camera& c, uint32_t width, uint32_t height) { return make_camfx_any(c, width, height); }
 // project_fixed, fixed.rs:424-441 (screen integers only; the fixed depth is discarded by render.rs:2331)
-__device__ __forceinline__ void project_fixed_dev(float x, float y, float z, const CamFx& k, int32_t& sx, int32_t& sy) {
+__device__ __forceinline__ void project_fixed_dev(float x, float y, float z, const CamFx& k, int32_t& sx, int32_t& sy,
+                                                  const uint8_t* __restrict__ unr_table = g_unr.v) {
     int32_t rx = wsub(fx_from_f32(x), k.px), ry = wsub(fx_from_f32(y), k.py), rz = wsub(fx_from_f32(z), k.pz);
     int32_t cx = wadd(wadd(fx_mul(rx, k.bx[0]), fx_mul(ry, k.bx[1])), fx_mul(rz, k.bx[2]));
     int32_t cy = wadd(wadd(fx_mul(rx, k.by[0]), fx_mul(ry, k.by[1])), fx_mul(rz, k.by[2]));
@@ -66,7 +69,7 @@ __device__ __forceinline__ void project_fixed_dev(float x, float y, float z, con
     int32_t denom = wadd(cz, distance);
     int32_t adenom = denom < 0 ? (int32_t)(0u - (uint32_t)denom) : denom;   // i32::abs wraps at MIN in release
     if (adenom < K::PF_DENOM_GUARD) { sx = k.half_w >> K::FRAC_BITS; sy = k.half_h >> K::FRAC_BITS; return; }
-    const UnrRecip rcp = unr_recip(denom);
+    const UnrRecip rcp = unr_recip(denom, unr_table);
     int32_t proj_x = unr_apply(fx_mul(cx, scale), rcp);
     int32_t proj_y = unr_apply(fx_mul(cy, scale), rcp);
     sx = wadd(fx_mul(proj_x, k.vs), k.half_w) >> K::FRAC_BITS;
@@ -178,15 +181,23 @@ __device__ __forceinline__ uint32_t fog_color(uint32_t c, uint32_t fogc, float f
 }
 
 // ---------------------------------------------------------------- k_setup
-// SETUP_FPT = faces per thread: 2 for large meshes (memory latency of the second face hidden behind the first: 51 -> 47 us at 1 M
-// faces; 3 and 4 lose to register pressure), 1 for small ones (where the kernel's latency, not its throughput, is what a frame waits for)
-template <int SETUP_FPT>
-__global__ __launch_bounds__(256) void k_setup(FrameParams fp, const B32Vertex* __restrict__ verts, const B32Face* __restrict__ faces,
+// SETUP_FPT = faces per thread (1 everywhere today: registers, i.e. waves per SIMD, are worth more than loads issued ahead)
+// PLAIN = the frame uses none of the optional stages (fixed-point snap, perspective, no fog, no lighting, no wireframe lists, no x-ray,
+// RGB555): those branches are compiled out -- fewer live scalars, less code in the instruction cache, no exec-mask juggling around them
+template <int SETUP_FPT, bool PLAIN>
+__global__ __launch_bounds__(256) void k_setup(FrameParams fp_in, const B32Vertex* __restrict__ verts, const B32Face* __restrict__ faces,
                                                const TexDesc* __restrict__ tex, const B32Light* __restrict__ lights_mem, LightSet lset,
                                                RecArrays recs, float* __restrict__ shades, uint32_t* __restrict__ keys,
                                                uint32_t* __restrict__ spans, uint32_t* __restrict__ partials, Ctrl* __restrict__ ctrl,
                                                WireTri* __restrict__ wire) {
+    FrameParams fp_plain = fp_in;                 // (dead code unless PLAIN)
+    if (PLAIN) { fp_plain.ortho = 0; fp_plain.fixed_point = 1; fp_plain.has_fog = 0; fp_plain.wire_collect = 0; fp_plain.shading = B32_SHADE_NONE;
+                 fp_plain.xray = 0; fp_plain.fmt8 = 0; fp_plain.n_lights = 0; }
+    const FrameParams& fp = PLAIN ? fp_plain : fp_in;
     __shared__ uint32_t wpart[4][6];
+    __shared__ uint8_t unr_lds[K::UNR_ENTRIES + 3];          // UNR_TABLE in LDS: its lookup sits in every vertex's dependent chain
+    for (uint32_t i = threadIdx.x; i < K::UNR_ENTRIES; i += 256) unr_lds[i] = g_unr.v[i];
+    __syncthreads();
     const B32Light* lights = fp.lights_inline ? lset.l : lights_mem;
     if (blockIdx.x == 0) {
         // frame-start reset (no memset launch).  If the previous frame was dropped (pair overflow / long list: nothing drawn) and this
@@ -256,7 +267,7 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp, const B32Vertex* 
                                -(cp.y - fp.ortho_cy) * fp.ortho_zoom + ((float)fp.height / 2.0f), cp.z };
                 } else if (fp.fixed_point) {                                     // render.rs:2329-2345
                     int32_t sx, sy;
-                    project_fixed_dev(pos.x, pos.y, pos.z, k, sx, sy);
+                    project_fixed_dev(pos.x, pos.y, pos.z, k, sx, sy, unr_lds);
                     scr[j] = { (float)sx, (float)sy, cp.z + K::MESH_DISTANCE };
                 } else {                                                         // project, math.rs:117-136
                     uint32_t mn = fp.width < fp.height ? fp.width : fp.height;
@@ -273,7 +284,7 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp, const B32Vertex* 
             bool backface = signed_area <= 0.0f;                                     // render.rs:2393-2394
             const bool have_tex = tid != B32_NO_TEXTURE && tid < fp.nt;             // textures.get(id)
             uint32_t tex_blend = B32_BLEND_OPAQUE;
-            if (keep && have_tex) tex_blend = tex[tid].blend_mode;
+            if (fp.tex_blend_any && keep && have_tex) tex_blend = tex[tid].blend_mode;     // (all Opaque: no descriptor gather in the chain)
             if (fp.has_fog && keep) {                                                // render.rs:2419-2442
                 if (camz[0] > fp.fog.cull_distance && camz[1] > fp.fog.cull_distance && camz[2] > fp.fog.cull_distance) keep = false;
                 else {
@@ -307,20 +318,35 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp, const B32Vertex* 
                 float area = (v2.y - v3.y) * (v1.x - v3.x) + (v3.x - v2.x) * (v1.y - v3.y);      // :1500
                 if (__builtin_fabsf(area) < K::AREA_EPS) empty = true;                            // :1501-1503
                 if (empty) { min_x = max_x = min_y = max_y = 0; }
+                r.bbx = min_x | (max_x << 16); r.bby = min_y | (max_y << 16);
+                span = pack_tile_span(r.bbx, r.bby, empty ? F_EMPTY : 0u, fp, n_tiles);
+                // multi-GPU band sharding: every rank decides visibility for every face (triangles_drawn, painter's keys), but only the
+                // surfaces reaching its own rows are ever read again: the triangle prologue, the exactness guard, the lighting and the
+                // record build are skipped for all the others
+                const bool need_rec = !fp.band_only || n_tiles != 0;
+                bool slow = !fp.fixed_point || fp.ortho;
+                bool needs_dither = false;
+                r.inv_area = 0.0f; r.w0_start = r.w1_start = 0.0f; r.flags = 0;
+                if (need_rec) {
                 r.inv_area = 1.0f / area;
                 r.a0 = v2.y - v3.y; r.b0 = v3.x - v2.x; r.a1 = v3.y - v1.y; r.b1 = v1.x - v3.x;   // :1507-1510
                 const float start_x = (float)min_x, start_y = (float)min_y;
                 r.w0_start = r.a0 * (start_x - v3.x) + r.b0 * (start_y - v3.y);                    // :1517
                 r.w1_start = r.a1 * (start_x - v3.x) + r.b1 * (start_y - v3.y);                    // :1518
-                r.bbx = min_x | (max_x << 16); r.bby = min_y | (max_y << 16);
                 // Closed-form eligibility: with integer vertices every value the reference's incremental walk ever holds
                 // is an exact integer when |w| < 2^24 over the bbox and both start products are < 2^24.
-                bool slow = !fp.fixed_point || fp.ortho;
                 if (!slow && !empty) {
                     const float lim = 4194304.0f;   // 2^22
-                    if (!(__builtin_fabsf(v1.x) <= lim && __builtin_fabsf(v1.y) <= lim && __builtin_fabsf(v2.x) <= lim &&
-                          __builtin_fabsf(v2.y) <= lim && __builtin_fabsf(v3.x) <= lim && __builtin_fabsf(v3.y) <= lim)) slow = true;
-                    else {
+                    const float cmax = rmax(rmax(rmax(__builtin_fabsf(v1.x), __builtin_fabsf(v1.y)), rmax(__builtin_fabsf(v2.x), __builtin_fabsf(v2.y))),
+                                            rmax(__builtin_fabsf(v3.x), __builtin_fabsf(v3.y)));
+                    // quick acceptance (nearly every triangle): every edge coefficient is at most amax, every offset from v3 to a
+                    // corner of the clipped box at most dmax (integers below 2^23), so every product is at most amax * dmax and every
+                    // sum of two at most twice that; the float product rounds monotonically and 2^24 is representable
+                    const float amax = rmax(rmax(__builtin_fabsf(r.a0), __builtin_fabsf(r.b0)), rmax(__builtin_fabsf(r.a1), __builtin_fabsf(r.b1)));
+                    const float dmax = rmax(rmax(__builtin_fabsf((float)min_x - v3.x), __builtin_fabsf((float)(max_x - 1) - v3.x)),
+                                            rmax(__builtin_fabsf((float)min_y - v3.y), __builtin_fabsf((float)(max_y - 1) - v3.y)));
+                    if (!(cmax <= lim)) slow = true;
+                    else if (!(2.0f * (amax * dmax) < 16777216.0f)) {
                         // every operand is an integer-valued float below 2^23, so each product / sum below is exact whenever its
                         // true value is below 2^24, and rounds to >= 2^24 otherwise (rounding is monotonic and 2^24 is
                         // representable): the float comparisons decide exactly what 64-bit integer arithmetic would
@@ -338,15 +364,12 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp, const B32Vertex* 
                     }
                 }
                 const bool vc_diff = (col[i1] != col[i2]) || (col[i2] != col[i3]);                  // Color equality incl. blend, types.rs:719
-                const bool needs_dither = fp.dithering && (fp.shading == B32_SHADE_GOURAUD || have_tex || vc_diff);   // :1487-1492
+                needs_dither = fp.dithering && (fp.shading == B32_SHADE_GOURAUD || have_tex || vc_diff);   // :1487-1492
                 const uint32_t eff_blend = have_tex ? tex_blend : face_blend;                       // :1450-1452
                 r.flags = (have_tex ? tid : F_TEX_NONE) | (black_tr ? F_BLACK_TR : 0) | (eff_blend << F_BLEND_SHIFT) |
                           (needs_dither ? F_DITHER : 0) | (slow ? F_SLOW : 0) | (transparent ? F_TRANSP : 0) |
                           (empty ? F_EMPTY : 0) | (editor_alpha << F_ALPHA_SHIFT);
-                span = pack_tile_span(r.bbx, r.bby, r.flags, fp, n_tiles);
-                // multi-GPU band sharding: every rank decides visibility for every face (triangles_drawn, painter's keys), but only the
-                // surfaces reaching its own rows are ever read again
-                const bool need_rec = !fp.band_only || n_tiles != 0;
+                }   // need_rec
                 if (need_rec && fp.shading != B32_SHADE_NONE) {
                     V3 wn[3];
 #pragma unroll
@@ -384,12 +407,11 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp, const B32Vertex* 
                 if (fp.zmode && !transparent) key = 0;
                 if (key == KEY_INVALID) key = 0xFFFFFFFEu;    // unreachable for z > 5; keeps the sentinel unique
                 if (need_rec) {
-                    // vertices as i16 when all six are integers within range (fixed-point snap, on or near the screen)
-                    const float lim16 = 32767.0f;
-                    const bool fits = __builtin_fabsf(v1.x) <= lim16 && __builtin_fabsf(v1.y) <= lim16 && __builtin_fabsf(v2.x) <= lim16 &&
-                                      __builtin_fabsf(v2.y) <= lim16 && __builtin_fabsf(v3.x) <= lim16 && __builtin_fabsf(v3.y) <= lim16 &&
-                                      v1.x == __builtin_truncf(v1.x) && v1.y == __builtin_truncf(v1.y) && v2.x == __builtin_truncf(v2.x) &&
-                                      v2.y == __builtin_truncf(v2.y) && v3.x == __builtin_truncf(v3.x) && v3.y == __builtin_truncf(v3.y);
+                    // vertices as i16 when all six are integers within range: the fixed-point snap yields integers (project_fixed), and
+                    // F_SLOW surfaces always take the wide form
+                    const float cmax16 = rmax(rmax(rmax(__builtin_fabsf(v1.x), __builtin_fabsf(v1.y)), rmax(__builtin_fabsf(v2.x), __builtin_fabsf(v2.y))),
+                                              rmax(__builtin_fabsf(v3.x), __builtin_fabsf(v3.y)));
+                    const bool fits = !slow && cmax16 <= 32767.0f;
                     auto pk16 = [](float x, float y) { return ((uint32_t)(int32_t)x & 0xFFFFu) | ((uint32_t)(int32_t)y << 16); };
                     uint4 c0, c1;
                     c0.x = fits ? pk16(v1.x, v1.y) : COV_WIDE; c0.y = fits ? pk16(v2.x, v2.y) : 0u; c0.z = fits ? pk16(v3.x, v3.y) : 0u;
@@ -436,10 +458,15 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp, const B32Vertex* 
 
 void launch_setup(hipStream_t s, const FrameParams& fp, const B32Vertex* verts, const B32Face* faces, const TexDesc* tex,
                   const B32Light* lights, const LightSet& ls, RecArrays recs, float* shades, uint32_t* keys, uint32_t* spans, uint32_t* partials,
-                  Ctrl* ctrl, WireTri* wire) {
+                  Ctrl* ctrl, WireTri* wire, int n_cu) {
+    (void)n_cu;
     if (fp.nf == 0) return;
-    if (fp.nf >= 400000) hipLaunchKernelGGL(k_setup<2>, dim3((fp.nf + 511) / 512), dim3(256), 0, s, fp, verts, faces, tex, lights, ls, recs, shades, keys, spans, partials, ctrl, wire);
-    else hipLaunchKernelGGL(k_setup<1>, dim3((fp.nf + 255) / 256), dim3(256), 0, s, fp, verts, faces, tex, lights, ls, recs, shades, keys, spans, partials, ctrl, wire);
+    const bool plain = fp.fixed_point && !fp.ortho && !fp.has_fog && !fp.wire_collect && fp.shading == B32_SHADE_NONE && !fp.xray && !fp.fmt8;
+    // one face per thread: 52 VGPRs in the plain form = 8 waves per SIMD (two faces per thread with their loads issued up front: 73 VGPRs,
+    // 43 us instead of 39 at 1 M faces; three: 49 us)
+    const dim3 g1((fp.nf + 255) / 256);
+    if (plain) hipLaunchKernelGGL((k_setup<1, true>), g1, dim3(256), 0, s, fp, verts, faces, tex, lights, ls, recs, shades, keys, spans, partials, ctrl, wire);
+    else hipLaunchKernelGGL((k_setup<1, false>), g1, dim3(256), 0, s, fp, verts, faces, tex, lights, ls, recs, shades, keys, spans, partials, ctrl, wire);
 }
 
 // ---------------------------------------------------------------- stage tap: project_fixed for n positions
