@@ -74,7 +74,7 @@ struct b32_ctx {
     WireTri* wire = nullptr; size_t cap_wire = 0;
     uint32_t *wire_owner = nullptr, *wire_first = nullptr; size_t cap_wire_table = 0;
     // control
-    Ctrl* d_ctrl = nullptr; uint32_t* d_consts = nullptr; Ctrl h_ctrl{};
+    Ctrl* d_ctrl = nullptr; uint32_t* d_consts = nullptr; Ctrl h_ctrl{}; Stamps h_stamps{};   // (d_ctrl: Ctrl followed by Stamps)
     uint32_t h_consts[4] = { 0, 0, 0, 0 };   // staging for d_consts (outlives the async copy)
     bool defer_upload_sync = false;            // drop-in calls: the frame's own synchronisation covers the uploads
     // staged upload of the drop-in calls (see UploadSegs): the caller's slices are packed into a pinned arena on the host and one
@@ -198,10 +198,10 @@ int b32_create(int device, b32_ctx** out) {
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return B32_E_HIP; }
     c->stream = c->own_stream;
-    if (hipMalloc(reinterpret_cast<void**>(&c->d_ctrl), sizeof(Ctrl)) != hipSuccess ||
+    if (hipMalloc(reinterpret_cast<void**>(&c->d_ctrl), sizeof(Ctrl) + sizeof(Stamps)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&c->d_consts), 16 * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&c->digit_total), 4096 * sizeof(uint32_t)) != hipSuccess) { delete c; return B32_E_HIP; }
-    if (hipMemset(c->d_ctrl, 0, sizeof(Ctrl)) != hipSuccess) { delete c; return B32_E_HIP; }     // (`sticky` is never reset by a frame)
+    if (hipMemset(c->d_ctrl, 0, sizeof(Ctrl) + sizeof(Stamps)) != hipSuccess) { delete c; return B32_E_HIP; }     // (`sticky` is never reset by a frame)
     *out = c;
     return B32_OK;
 }
@@ -421,8 +421,8 @@ static int h2d(b32_ctx* c, void* dst, const void* src, size_t bytes) {
     HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
     return B32_OK;
 }
-constexpr size_t STAGE_BYTES = (size_t)1 << 20, STAGE_CTRL_OFF = STAGE_BYTES - 64;    // the last 64 B receive the frame's Ctrl
-static_assert(sizeof(Ctrl) == 64, "Ctrl is read back through a 64-byte slot of the pinned arena");
+constexpr size_t STAGE_BYTES = (size_t)1 << 20, STAGE_CTRL_OFF = STAGE_BYTES - 128;   // the last 128 B receive the frame's Ctrl + Stamps
+static_assert(sizeof(Ctrl) == 64 && sizeof(Stamps) == 64, "Ctrl and Stamps are read back through a 128-byte slot of the pinned arena");
 static bool stage_ensure(b32_ctx* c) {
     if (!c->stage_host && !c->stage_failed) {
         void* h = nullptr;
@@ -928,14 +928,16 @@ int b32_frame_finish(b32_ctx* c, B32Timings* out) {
         // the frame's counters come back through the pinned arena (one small kernel writing host memory) rather than an SDMA copy:
         // ~5 us of stream time less per synchronous frame
         if (stage_ensure(c)) {
-            UploadSegs out_seg{};
-            out_seg.count = 1; out_seg.dst[0] = static_cast<unsigned char*>(c->stage_dev) + STAGE_CTRL_OFF; out_seg.src_off[0] = 0; out_seg.n16[0] = sizeof(Ctrl) / 16;
-            launch_upload(c->stream, c->d_ctrl, out_seg);
+            launch_ctrl_out(c->stream, c->d_ctrl, static_cast<unsigned char*>(c->stage_dev) + STAGE_CTRL_OFF);
             HIPCHK(c, hipStreamSynchronize(c->stream));
             std::memcpy(&c->h_ctrl, c->stage_host + STAGE_CTRL_OFF, sizeof(Ctrl));
+            std::memcpy(&c->h_stamps, c->stage_host + STAGE_CTRL_OFF + sizeof(Ctrl), sizeof(Stamps));
         } else {
-            HIPCHK(c, hipMemcpyAsync(&c->h_ctrl, c->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, c->stream));
+            unsigned char tmp[sizeof(Ctrl) + sizeof(Stamps)];
+            HIPCHK(c, hipMemcpyAsync(tmp, c->d_ctrl, sizeof(tmp), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
+            std::memcpy(&c->h_ctrl, tmp, sizeof(Ctrl)); std::memcpy(&c->h_stamps, tmp + sizeof(Ctrl), sizeof(Stamps));
+            c->h_stamps.t[ST_END] = 0;
         }
         if (c->h_ctrl.need_global_sort && c->local_sort_ok) {
             // a tile list was longer than the LDS sort handles: nothing was drawn; redraw this frame (and the following ones of
@@ -974,8 +976,21 @@ int b32_frame_finish(b32_ctx* c, B32Timings* out) {
         out->triangles_drawn = c->h_ctrl.n_visible;
         out->fragments = c->last_exact ? c->h_ctrl.fragments : 0;     // exact only with fragment counting on, painter's mode
         out->tile_pairs = c->h_ctrl.n_pairs;
+        // RasterTimings phases of the most recent frame from the device-side phase clock (10 ns ticks): the reference's TRANSFORM, FOG and
+        // CULL / SETUP stages are ONE fused kernel here (reported as cull_ms, transform_ms = fog_ms = 0), its sort is the tile binning,
+        // its draw loop the fill kernels, its wireframe phase the line kernels.  With b32_set_profiling(2) the HIP-event averages over
+        // the finished batch of frames take their place.
+        const unsigned long long* t = c->h_stamps.t;
+        const unsigned long long t_end = t[ST_END] ? t[ST_END] : 0ull;
+        if (c->nf && t[ST_SETUP] && t[ST_FILL] >= t[ST_SETUP]) {
+            const unsigned long long t_bin = t[ST_BIN] ? t[ST_BIN] : t[ST_FILL];
+            const unsigned long long t_fill_end = t[ST_WIRE] ? t[ST_WIRE] : t_end;
+            out->cull_ms = (float)(t_bin - t[ST_SETUP]) * 1e-5f;
+            out->sort_ms = (float)(t[ST_FILL] - t_bin) * 1e-5f;
+            if (t_fill_end >= t[ST_FILL]) out->draw_ms = (float)(t_fill_end - t[ST_FILL]) * 1e-5f;
+            if (t[ST_WIRE] && t_end >= t[ST_WIRE]) out->wireframe_ms = (float)(t_end - t[ST_WIRE]) * 1e-5f;
+        }
         if (c->phase_frames && c->phase_level >= 2) {
-            out->transform_ms = 0.0f;                 // fused into the per-face setup kernel
             out->cull_ms = c->phase_ms[0];
             out->sort_ms = c->phase_ms[1];
             out->draw_ms = c->phase_ms[2] + c->phase_ms[3] + c->phase_ms[4];
@@ -1018,10 +1033,10 @@ int b32_scene_swap(b32_ctx* c, b32_scene* sl) {
     return B32_OK;
 }
 
-// RasterTimings of a synchronous call: the per-phase split comes from HIP events when b32_set_profiling(ctx, 2) is on; otherwise
-// (events cost ~40 us per small call) the wall time of the whole call is reported as draw_ms, like the reference's get_time() deltas.
+// RasterTimings of a synchronous call: the per-phase split comes from the device-side phase clock (b32_frame_finish); the wall time of
+// the whole call is reported as draw_ms only for an empty mesh, where no kernel ran.
 static void wall_timing(b32_ctx* c, B32Timings* out, std::chrono::steady_clock::time_point t0) {
-    if (!out || c->profile_level >= 2) return;
+    if (!out || c->profile_level >= 2 || out->draw_ms > 0.0f || out->cull_ms > 0.0f) return;      // (the device phase clock filled them)
     out->draw_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 int b32_render_scene_15(b32_ctx* c, const B32Camera* cam, const B32Settings* st, const B32Fog* fog, B32Timings* out) {

@@ -118,6 +118,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit_faces(FrameParams fp, 
     __shared__ uint32_t wtot[BIN_THREADS / 64];
     __shared__ uint32_t red[BIN_THREADS / 64][8];
     __shared__ uint32_t step_base, total_s;
+    phase_stamp(ctrl, ST_BIN);
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t first_part = blockIdx.x * (BIN_TILE / 256);            // partial records (256 faces each) before this block
     {

@@ -169,6 +169,18 @@ struct Ctrl {
     unsigned long long fragments;
 };
 
+// Device-side phase clock: 100 MHz wall-clock stamps (10 ns) taken by the first thread of the first kernel of every phase, in the 64
+// bytes right behind Ctrl (one allocation).  They cost one store per kernel and no launch, so RasterTimings' phases are filled on every
+// synchronous call (render.rs:2362, 2515-2516, 2544, 2572 always fill them), not only under b32_set_profiling.
+struct Stamps { unsigned long long t[8]; };
+enum { ST_SETUP = 0, ST_BIN = 1, ST_FILL = 2, ST_WIRE = 3, ST_END = 4 };
+__device__ __forceinline__ void phase_stamp(Ctrl* ctrl, int k) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        unsigned long long* t = reinterpret_cast<Stamps*>(ctrl + 1)->t;
+        if (!t[k]) t[k] = wall_clock64();
+    }
+}
+
 constexpr uint32_t LOCAL_SORT_CAP = 2048;   // longest tile list the per-tile LDS radix sort handles
 
 // Loop-invariant conversions of transform_to_camera_space / project_to_screen (fixed.rs:362-400): the camera converted to 4.12
@@ -326,7 +338,7 @@ constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;   // 4096 keys per block
 // One stable LSD pass on bits [shift, shift+bits), bits in {8, 11, 12}. n is read from *n_dev (<= n_cap). If vals_in == nullptr
 // the value of element i is i and keys equal to KEY_INVALID are dropped (first pass over the face-order key array).
 struct RadixExtra {            // optional jobs folded into a pass to save kernel launches
-    Ctrl* post_ctrl = nullptr; const uint32_t* partials = nullptr; uint32_t npart = 0;   // k_setup counter reduction (first depth pass)
+    Ctrl* post_ctrl = nullptr; const uint32_t* partials = nullptr; uint32_t npart = 0;   // k_setup counter reduction (first depth pass; also stamps ST_BIN)
     uint32_t* ranges_out = nullptr; uint32_t n_ranges = 0;                               // tile-list ranges (single-pass tile sort)
 };
 void launch_radix_pass(hipStream_t s, const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
@@ -353,6 +365,7 @@ void launch_clear(hipStream_t s, uint32_t* fb, size_t n_px, uint32_t rgba);
 // space) to their device buffers -- every SDMA copy costs ~10 us of stream time, one kernel reading over PCIe ~5 us for all of them
 struct UploadSegs { void* dst[16]; uint32_t src_off[16]; uint32_t n16[16]; uint32_t count; };
 void launch_upload(hipStream_t s, const void* arena_dev, const UploadSegs& segs);
+void launch_ctrl_out(hipStream_t s, Ctrl* ctrl, void* dst128);      // end-of-frame stamp + Ctrl and Stamps (128 B) to a host-visible slot
 void launch_expand_indexed(hipStream_t s, const uint8_t* idx, uint32_t n, const uint16_t* clut, uint32_t clut_len, uint16_t* out);
 
 void launch_bin(hipStream_t s, const FrameParams& fp, const uint32_t* spans, const uint32_t* order, Ctrl* ctrl,

@@ -892,6 +892,7 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a) {
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));   // wave-uniform => SGPR control flow
     const FrameParams& fp = a.fp;
     const uint32_t ntiles = fp.tiles_x * fp.tiles_y;
+    phase_stamp(a.ctrl, ST_FILL);
     if (P64 && a.inline_bin) {
         // small mesh: there was no binning launch, so nobody has reduced k_setup's per-block counters yet.  Every workgroup derives
         // the frame's abort decision from them (the reference panics before drawing on a bad vertex index, render.rs:2375, or when a

@@ -206,6 +206,7 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp_in, const B32Verte
         __syncthreads();
         if (threadIdx.x < sizeof(Ctrl) / 4 && threadIdx.x != offsetof(Ctrl, sticky) / 4) reinterpret_cast<uint32_t*>(ctrl)[threadIdx.x] = 0;
         if (threadIdx.x == 0 && lost) ctrl->sticky += 0x100u;
+        if (threadIdx.x == 0) { Stamps* st = reinterpret_cast<Stamps*>(ctrl + 1); for (int k = 1; k < 8; ++k) st->t[k] = 0; st->t[ST_SETUP] = wall_clock64(); }
     }
     // Every thread owns SETUP_FPT faces, 256 apart (a workgroup covers SETUP_FPT groups of 256 consecutive faces).  All of their
     // inputs -- the face words, then the three vertices each -- are requested before the first face is processed, so the second
@@ -548,6 +549,14 @@ __global__ __launch_bounds__(256) void k_upload(const uint4* __restrict__ arena,
         uint4* dst = reinterpret_cast<uint4*>(segs.dst[k]);
         for (uint32_t i = gtid; i < segs.n16[k]; i += nthr) dst[i] = src[i];
     }
+}
+__global__ void k_ctrl_out(Ctrl* __restrict__ ctrl, uint4* __restrict__ dst) {
+    if (threadIdx.x == 0) { unsigned long long* t = reinterpret_cast<Stamps*>(ctrl + 1)->t; if (!t[ST_END]) t[ST_END] = wall_clock64(); }
+    __syncthreads();
+    if (threadIdx.x < (sizeof(Ctrl) + sizeof(Stamps)) / 16) dst[threadIdx.x] = reinterpret_cast<const uint4*>(ctrl)[threadIdx.x];
+}
+void launch_ctrl_out(hipStream_t s, Ctrl* ctrl, void* dst128) {
+    hipLaunchKernelGGL(k_ctrl_out, dim3(1), dim3(64), 0, s, ctrl, reinterpret_cast<uint4*>(dst128));
 }
 void launch_upload(hipStream_t s, const void* arena_dev, const UploadSegs& segs) {
     if (!segs.count) return;

@@ -19,9 +19,11 @@ __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi
 // BITS = digit width (8, 11 or 12): NB = 2^BITS bins.
 template <int BITS>
 __global__ __launch_bounds__(SORT_THREADS) void k_hist(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ n_dev,
-                                                        int shift, int drop_invalid, uint32_t* __restrict__ block_hist, uint32_t max_blocks) {
+                                                        int shift, int drop_invalid, uint32_t* __restrict__ block_hist, uint32_t max_blocks,
+                                                        Ctrl* __restrict__ stamp_ctrl) {
     constexpr uint32_t NB = 1u << BITS;
     __shared__ uint32_t hist[NB];
+    if (stamp_ctrl) phase_stamp(stamp_ctrl, ST_BIN);
     const uint32_t n = *n_dev;
     const uint32_t base = blockIdx.x * SORT_TILE;
     if (base >= n) return;   // the scan only looks at the ceil(n / SORT_TILE) blocks in use
@@ -198,8 +200,10 @@ constexpr uint32_t SPAN_MAX_TILES = 4096;       // LDS histogram capacity (rows:
 // entries (bit 31 of k_setup's key, render.rs:2522-2523); k_place_spans lays a tile's list out as [opaque..., transparent...] and
 // publishes the boundary in tile_mid, so k_cover takes the first part unordered and k_blend sorts only the second.
 __global__ __launch_bounds__(256) void k_count_spans(uint32_t nf, uint32_t ntiles, uint32_t tiles_x, const uint32_t* __restrict__ spans,
-                                                     const uint32_t* __restrict__ keys, uint32_t* __restrict__ block_hist, uint32_t max_blocks) {
+                                                     const uint32_t* __restrict__ keys, uint32_t* __restrict__ block_hist, uint32_t max_blocks,
+                                                     Ctrl* __restrict__ ctrl) {
     __shared__ uint32_t hist[SPAN_MAX_TILES];
+    phase_stamp(ctrl, ST_BIN);
     const uint32_t nrows = keys ? 2 * ntiles : ntiles;
     for (uint32_t t = threadIdx.x; t < nrows; t += 256) hist[t] = 0;
     __syncthreads();
@@ -296,6 +300,7 @@ __global__ __launch_bounds__(256) void k_bin_small(uint32_t nf, uint32_t ntiles,
     __shared__ uint32_t hist[SPAN_MAX_TILES];
     __shared__ uint32_t dws[4], dmx[4];
     __shared__ uint32_t total_s;
+    phase_stamp(ctrl, ST_BIN);
     reduce_setup_partials(ctrl, partials, npart);              // frame counters / abort decision (ends with a barrier)
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t nrows = keys ? 2 * ntiles : ntiles;
@@ -375,7 +380,7 @@ bool launch_bin_spans(hipStream_t s, const FrameParams& fp, const uint32_t* span
                            ranges, keys ? tile_mid : nullptr, blend_cap, pair_vals);
         return true;
     }
-    hipLaunchKernelGGL(k_count_spans, dim3(nblocks), dim3(256), 0, s, fp.nf, ntiles, fp.tiles_x, spans, keys, sc.block_hist, sc.max_blocks);
+    hipLaunchKernelGGL(k_count_spans, dim3(nblocks), dim3(256), 0, s, fp.nf, ntiles, fp.tiles_x, spans, keys, sc.block_hist, sc.max_blocks, ctrl);
     hipLaunchKernelGGL(k_scan_rows, dim3(nrows), dim3(256), 0, s, sc.block_hist, sc.max_blocks, nblocks, sc.digit_total,
                        ctrl, partials, (fp.nf + 255) / 256, (const uint32_t*)nullptr);
     hipLaunchKernelGGL(k_place_spans, dim3(nblocks), dim3(256), 0, s, fp.nf, ntiles, fp.tiles_x, spans, keys, sc.block_hist, sc.max_blocks,
@@ -388,7 +393,7 @@ static void radix_pass_t(hipStream_t s, const uint32_t* keys_in, const uint32_t*
                          const uint32_t* n_dev, uint32_t n_cap, int shift, const SortScratch& sc, const RadixExtra& ex) {
     const uint32_t nblocks = (n_cap + SORT_TILE - 1) / SORT_TILE;
     const int drop = vals_in == nullptr ? 1 : 0;
-    hipLaunchKernelGGL(k_hist<BITS>, dim3(nblocks), dim3(SORT_THREADS), 0, s, keys_in, n_dev, shift, drop, sc.block_hist, sc.max_blocks);
+    hipLaunchKernelGGL(k_hist<BITS>, dim3(nblocks), dim3(SORT_THREADS), 0, s, keys_in, n_dev, shift, drop, sc.block_hist, sc.max_blocks, ex.post_ctrl);
     hipLaunchKernelGGL(k_scan_rows, dim3(1u << BITS), dim3(256), 0, s, sc.block_hist, sc.max_blocks, nblocks, sc.digit_total,
                        ex.post_ctrl, ex.partials, ex.npart, n_dev);
     hipLaunchKernelGGL(k_scatter<BITS>, dim3(nblocks), dim3(SORT_THREADS), 0, s, keys_in, vals_in, keys_out, vals_out, n_dev, shift, drop,

@@ -64,6 +64,7 @@ __device__ __forceinline__ uint32_t wire_slot(const WireArgs& a, const Edge& e, 
 }
 
 __global__ void k_wire_insert(WireArgs a) {
+    phase_stamp(a.ctrl, ST_WIRE);
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= a.nf * 3) return;
     const uint32_t f = id / 3;
@@ -118,6 +119,7 @@ __device__ void draw_line_dev(const WireArgs& a, const Edge& e, bool depth_test,
 
 template <int KIND>
 __global__ void k_wire_draw(WireArgs a) {
+    phase_stamp(a.ctrl, ST_WIRE);
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= a.nf * 3 || a.ctrl->abort) return;
     const uint32_t f = id / 3;

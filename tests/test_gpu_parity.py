@@ -410,6 +410,28 @@ def test_framebuffer_new_on_a_reused_context(gpu_ctx, oracle):
     assert np.array_equal(fb2.pixels, ofb.pixels) and np.array_equal(fb2.zbuffer.view(np.uint32), ofb.zbuffer.view(np.uint32))
 
 
+def test_raster_timings_are_filled_on_every_synchronous_call(gpu_ctx):
+    """RasterTimings (types.rs:1499-1514): the reference fills every phase on every call (render.rs:2362, 2515-2516, 2544, 2572).  Here the
+    phases come from the device-side phase clock with no profiling switched on: cull (the fused transform + cull + setup kernel), sort
+    (the tile binning), draw (the fill kernels), wireframe (the line kernels); their sum cannot exceed the wall time of the call."""
+    import time
+    from bonnie32_amd import rasterizer as R
+    gpu_ctx.set_profiling(0)
+    for sc, wire in ((scenegen.make_scene("C3", n_tris=200_000), False), (SCENES["C1:default-settings"](), True), (SCENES["C1"](), False)):
+        fb = R.Framebuffer(sc.width, sc.height, gpu_ctx); fb.clear(sc.clear_color)
+        R.render_mesh_15(fb, sc.vertices, sc.faces, sc.textures, sc.camera, sc.settings)          # warm-up (allocations)
+        t0 = time.perf_counter()
+        tm = R.render_mesh_15(fb, sc.vertices, sc.faces, sc.textures, sc.camera, sc.settings)
+        wall = (time.perf_counter() - t0) * 1e3
+        assert tm.cull_ms > 0 and tm.draw_ms > 0, tm
+        assert (tm.wireframe_ms > 0) == wire, tm
+        assert tm.sort_ms >= 0 and tm.cull_ms + tm.sort_ms + tm.draw_ms + tm.wireframe_ms <= wall, (tm, wall)
+        if len(sc.faces) > 100_000:
+            assert tm.sort_ms > 0 and tm.cull_ms > 0.005 and tm.draw_ms > 0.01, tm               # a 200 k-triangle frame: tens of microseconds each
+    tm = R.render_mesh_15(fb, b32.make_vertices(0), b32.make_faces(0), [], sc.camera, sc.settings)   # empty mesh: no kernel ran
+    assert tm.triangles_drawn == 0 and tm.cull_ms == 0
+
+
 def test_light_lists_change_between_async_frames(gpu_ctx, oracle):
     """Per-room light lists (scene.rs draws room after room, each with its own lights): up to 8 lights travel in the kernel arguments,
     longer lists through a device buffer; either way consecutive asynchronous frames with different lights must each use their own."""
