@@ -14,7 +14,7 @@ Layout:
 from . import abi, rtypes  # noqa: F401
 from . import rtypes as types  # noqa: F401  (alias: mirrors the reference module name src/rasterizer/types.rs)
 from .rtypes import (Camera, Color, IndexedTexture, Light, RasterSettings, RasterTimings, Texture, Texture15,  # noqa: F401
-                    create_test_cube, make_faces, make_vertices)
+                    make_faces, make_vertices)
 
 __all__ = ["abi", "types", "Camera", "Color", "IndexedTexture", "Light", "RasterSettings", "RasterTimings",
-           "Texture", "Texture15", "create_test_cube", "make_faces", "make_vertices"]
+           "Texture", "Texture15", "make_faces", "make_vertices"]

@@ -46,6 +46,12 @@ struct b32_ctx {
     bool may_blend = true;              // some face / texture can produce a transparent-pass surface (render.rs:2403-2415)
     bool cheap_ok = false;              // every texture has few skippable texels: CHEAP coverage + repair is profitable
     bool tex_blend_any = false;         // some texture of the resident scene has a blend mode other than Opaque
+    // Texture cache of the drop-in calls ("texture upload may be cached by (ptr,len,hash) but must be semantically per-call"):
+    // what the texel pool currently holds -- per texture the caller's pointer, its dimensions, blend mode and a 64-bit hash of its
+    // content.  A call that passes the same set again (the reference's callers pass the same Texture15 slice every frame) skips the
+    // texel copies and the skippable-texel count; any change of pointer, size or content re-uploads.
+    struct TexSig { const void* ptr; uint32_t w, h, blend; uint64_t hash; };
+    std::vector<TexSig> tex_sig; bool tex_sig_valid = false; bool tex_sig_rgba = false;
     int count_fragments = 0;            // 1: exact fragment-store count every frame (EXACT coverage); instrumentation, off by default
     bool last_exact = false;            // the last frame ran EXACT coverage in painter's mode (B32Timings.fragments is exact)
 
@@ -114,6 +120,7 @@ struct b32_scene {
     std::vector<TexDesc> h_tex;
     uint32_t nv = 0, nf = 0, nt = 0;
     bool fmt8 = false, blend8 = false, have_scene = false, may_blend = true, cheap_ok = false, local_sort_ok = true, tex_blend_any = false;
+    std::vector<b32_ctx::TexSig> tex_sig; bool tex_sig_valid = false, tex_sig_rgba = false;
 };
 
 #define HIPCHK(ctx, expr)                                                 \
@@ -512,6 +519,25 @@ static int layout_textures(b32_ctx* c, uint32_t nt, const uint32_t* w, const uin
     return B32_OK;
 }
 
+// 64-bit content hash, four independent lanes of 8-byte words (about memcpy speed; the tail bytes go through a padded word)
+static uint64_t hash_bytes(const void* data, size_t n) {
+    const unsigned char* p = static_cast<const unsigned char*>(data);
+    const uint64_t K1 = 0x9E3779B185EBCA87ull, K2 = 0xC2B2AE3D27D4EB4Full;
+    uint64_t h[4] = { K1 ^ n, K2 + n, K1 * 3 + n, K2 * 5 ^ n };
+    auto round = [&](uint64_t acc, uint64_t x) { acc += x * K2; acc = (acc << 31) | (acc >> 33); return acc * K1; };
+    size_t i = 0;
+    for (; i + 32 <= n; i += 32) {
+        uint64_t w[4];
+        std::memcpy(w, p + i, 32);
+        h[0] = round(h[0], w[0]); h[1] = round(h[1], w[1]); h[2] = round(h[2], w[2]); h[3] = round(h[3], w[3]);
+    }
+    uint64_t tail[4] = { 0, 0, 0, 0 };
+    if (i < n) { std::memcpy(tail, p + i, n - i); for (int k = 0; k < 4; ++k) h[k] = round(h[k], tail[k]); }
+    uint64_t r = ((h[0] << 1) | (h[0] >> 63)) ^ ((h[1] << 7) | (h[1] >> 57)) ^ ((h[2] << 12) | (h[2] >> 52)) ^ ((h[3] << 18) | (h[3] >> 46));
+    r ^= r >> 33; r *= K2; r ^= r >> 29; r *= K1; r ^= r >> 32;
+    return r;
+}
+
 int b32_scene_upload(b32_ctx* c, const B32Vertex* v, uint32_t nv, const B32Face* f, uint32_t nf, const B32Texture15* tex, uint32_t nt) {
     if (!c || (nt && !tex)) return B32_E_ARG;
     (void)hipSetDevice(c->device);
@@ -521,16 +547,30 @@ int b32_scene_upload(b32_ctx* c, const B32Vertex* v, uint32_t nv, const B32Face*
         w[i] = tex[i].width; h[i] = tex[i].height; bl[i] = tex[i].blend_mode;
         if (!tex[i].pixels) w[i] = h[i] = 0;                                // pixels.is_empty() -> sample() returns TRANSPARENT
     }
-    size_t total = 0;
-    int rc = layout_textures(c, nt, w.data(), h.data(), bl.data(), &total);
-    if (rc) return rc;
-    c->cheap_ok = true;
-    for (uint32_t i = 0; i < nt; ++i) {
-        const size_t n = (size_t)w[i] * h[i];
-        if ((rc = h2d(c, c->d_texels + c->h_tex[i].offset, tex[i].pixels, n * 2))) return rc;
-        size_t skippable = 0;                                               // texels the black_transparent rule can skip
-        for (size_t k = 0; k < n; ++k) skippable += (tex[i].pixels[k] & 0x7FFF) == 0;
-        if (n == 0 || skippable * cheap_den() > n) c->cheap_ok = false;
+    // texture cache: the same set as the pool holds (pointer, size, blend mode, content hash of every texture)?
+    std::vector<b32_ctx::TexSig> sig(nt);
+    for (uint32_t i = 0; i < nt; ++i) sig[i] = { tex[i].pixels, w[i], h[i], bl[i], hash_bytes(tex[i].pixels, (size_t)w[i] * h[i] * 2) };
+    bool hit = c->tex_sig_valid && !c->tex_sig_rgba && c->tex_sig.size() == nt && c->nt == nt && c->d_texels && c->d_tex;
+    for (uint32_t i = 0; hit && i < nt; ++i) {
+        const b32_ctx::TexSig& o = c->tex_sig[i];
+        hit = o.ptr == sig[i].ptr && o.w == sig[i].w && o.h == sig[i].h && o.blend == sig[i].blend && o.hash == sig[i].hash;
+    }
+    int rc;
+    if (!hit) {
+        c->tex_sig_valid = false;
+        size_t total = 0;
+        rc = layout_textures(c, nt, w.data(), h.data(), bl.data(), &total);
+        if (rc) return rc;
+        c->cheap_ok = true;
+        for (uint32_t i = 0; i < nt; ++i) {
+            const size_t n = (size_t)w[i] * h[i];
+            if ((rc = h2d(c, c->d_texels + c->h_tex[i].offset, tex[i].pixels, n * 2))) return rc;
+            size_t skippable = 0;                                               // texels the black_transparent rule can skip
+            const uint16_t* px = tex[i].pixels;
+            for (size_t k = 0; k < n; ++k) skippable += (px[k] & 0x7FFF) == 0;
+            if (n == 0 || skippable * cheap_den() > n) c->cheap_ok = false;
+        }
+        c->tex_sig.swap(sig); c->tex_sig_valid = true; c->tex_sig_rgba = false;
     }
     if ((rc = upload_geometry(c, v, nv, f, nf))) return rc;
     for (uint32_t i = 0; i < nt; ++i) if (bl[i] != B32_BLEND_OPAQUE) c->may_blend = true;
@@ -549,6 +589,7 @@ int b32_scene_upload_rgba(b32_ctx* c, const B32Vertex* v, uint32_t nv, const B32
         if (!tex[i].pixels) w[i] = h[i] = 0;                                // pixels.is_empty() -> Color::TRANSPARENT
     }
     size_t total = 0;
+    c->tex_sig_valid = false;                                               // (the pool is rewritten below)
     int rc = layout_textures(c, nt, w.data(), h.data(), bl.data(), &total, true);
     if (rc) return rc;
     c->cheap_ok = true;
@@ -584,27 +625,25 @@ int b32_scene_upload_indexed(b32_ctx* c, const B32Vertex* v, uint32_t nv, const 
         if (!tex[i].indices || !tex[i].clut) w[i] = h[i] = 0;
     }
     size_t total = 0;
+    c->tex_sig_valid = false;                                               // (the pool is rewritten below)
     int rc = layout_textures(c, nt, w.data(), h.data(), bl.data(), &total);
     if (rc) return rc;
     c->cheap_ok = true;
     for (uint32_t i = 0; i < nt; ++i) {
         const size_t n = (size_t)w[i] * h[i];
         if (!n) { c->cheap_ok = false; continue; }
-        {
-            size_t skippable = 0;
-            for (size_t k = 0; k < n; ++k) {
-                const uint32_t ix = tex[i].indices[k];
-                const uint16_t col = ix < tex[i].clut_len ? tex[i].clut[ix] : (uint16_t)0;
-                skippable += (col & 0x7FFF) == 0;
-            }
-            if (skippable * cheap_den() > n) c->cheap_ok = false;
-        }
-        uint8_t* d_idx = nullptr; uint16_t* d_clut = nullptr;
+        // the expansion kernel also counts the texels the black_transparent rule can skip (no walk over the texels on the host)
+        uint8_t* d_idx = nullptr; uint16_t* d_clut = nullptr; uint32_t* d_cnt = nullptr;
         Scratch tmp(c);
         if ((rc = tmp.upload(tex[i].indices, n, &d_idx))) return rc;
         if ((rc = tmp.upload(tex[i].clut, (size_t)tex[i].clut_len, &d_clut))) return rc;
-        launch_expand_indexed(c->stream, d_idx, (uint32_t)n, d_clut, tex[i].clut_len, c->d_texels + c->h_tex[i].offset);
+        if ((rc = tmp.alloc(&d_cnt, 1))) return rc;
+        HIPCHK(c, hipMemsetAsync(d_cnt, 0, 4, c->stream));
+        launch_expand_indexed(c->stream, d_idx, (uint32_t)n, d_clut, tex[i].clut_len, c->d_texels + c->h_tex[i].offset, d_cnt);
+        uint32_t skippable = 0;
+        HIPCHK(c, hipMemcpyAsync(&skippable, d_cnt, 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        if ((size_t)skippable * cheap_den() > n) c->cheap_ok = false;
     }
     if ((rc = upload_geometry(c, v, nv, f, nf))) return rc;
     for (uint32_t i = 0; i < nt; ++i) if (bl[i] != B32_BLEND_OPAQUE) c->may_blend = true;
@@ -1030,6 +1069,7 @@ int b32_scene_swap(b32_ctx* c, b32_scene* sl) {
     std::swap(c->fmt8, sl->fmt8); std::swap(c->blend8, sl->blend8); std::swap(c->have_scene, sl->have_scene);
     std::swap(c->may_blend, sl->may_blend); std::swap(c->cheap_ok, sl->cheap_ok); std::swap(c->local_sort_ok, sl->local_sort_ok);
     std::swap(c->tex_blend_any, sl->tex_blend_any);
+    c->tex_sig.swap(sl->tex_sig); std::swap(c->tex_sig_valid, sl->tex_sig_valid); std::swap(c->tex_sig_rgba, sl->tex_sig_rgba);
     return B32_OK;
 }
 

@@ -366,7 +366,8 @@ void launch_clear(hipStream_t s, uint32_t* fb, size_t n_px, uint32_t rgba);
 struct UploadSegs { void* dst[16]; uint32_t src_off[16]; uint32_t n16[16]; uint32_t count; };
 void launch_upload(hipStream_t s, const void* arena_dev, const UploadSegs& segs);
 void launch_ctrl_out(hipStream_t s, Ctrl* ctrl, void* dst128);      // end-of-frame stamp + Ctrl and Stamps (128 B) to a host-visible slot
-void launch_expand_indexed(hipStream_t s, const uint8_t* idx, uint32_t n, const uint16_t* clut, uint32_t clut_len, uint16_t* out);
+// Clut::lookup expansion; *skippable (may be null) += texels with r5 = g5 = b5 = 0, i.e. the ones the black_transparent rule can skip
+void launch_expand_indexed(hipStream_t s, const uint8_t* idx, uint32_t n, const uint16_t* clut, uint32_t clut_len, uint16_t* out, uint32_t* skippable);
 
 void launch_bin(hipStream_t s, const FrameParams& fp, const uint32_t* spans, const uint32_t* order, Ctrl* ctrl,
                 uint32_t* counts, uint32_t* block_sums, uint32_t max_blocks, uint32_t* pair_keys, uint32_t* pair_vals, uint32_t pair_cap);

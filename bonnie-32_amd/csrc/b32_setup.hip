@@ -570,15 +570,21 @@ void launch_upload(hipStream_t s, const void* arena_dev, const UploadSegs& segs)
 
 // ---------------------------------------------------------------- Clut::lookup expansion (types.rs:390-397, mesh_editor.rs:669-682)
 __global__ void k_expand_indexed(const uint8_t* __restrict__ idx, uint32_t n, const uint16_t* __restrict__ clut, uint32_t clut_len,
-                                 uint16_t* __restrict__ out) {
+                                 uint16_t* __restrict__ out, uint32_t* __restrict__ skippable) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint32_t k = idx[i];
-    out[i] = k < clut_len ? clut[k] : (uint16_t)0;
+    bool skip = false;
+    if (i < n) {
+        uint32_t k = idx[i];
+        const uint16_t col = k < clut_len ? clut[k] : (uint16_t)0;
+        out[i] = col;
+        skip = (col & ~K::C15_SEMI_BIT & 0xFFFFu) == 0;
+    }
+    const unsigned long long m = __ballot(skip);
+    if (skippable && m && (threadIdx.x & 63) == 0) atomicAdd(skippable, (uint32_t)__popcll(m));
 }
-void launch_expand_indexed(hipStream_t s, const uint8_t* idx, uint32_t n, const uint16_t* clut, uint32_t clut_len, uint16_t* out) {
+void launch_expand_indexed(hipStream_t s, const uint8_t* idx, uint32_t n, const uint16_t* clut, uint32_t clut_len, uint16_t* out, uint32_t* skippable) {
     if (!n) return;
-    hipLaunchKernelGGL(k_expand_indexed, dim3((n + 255) / 256), dim3(256), 0, s, idx, n, clut, clut_len, out);
+    hipLaunchKernelGGL(k_expand_indexed, dim3((n + 255) / 256), dim3(256), 0, s, idx, n, clut, clut_len, out, skippable);
 }
 
 }  // namespace b32

@@ -287,28 +287,3 @@ def pack_indexed_textures(textures):
         arr[i].indices = t.indices.ctypes.data
         arr[i].clut = t.clut.ctypes.data
     return arr, list(textures)
-
-
-def create_test_cube():
-    """rasterizer/draw.rs:138-214: the reference's own fixture mesh (24 vertices, 12 faces, texture 0)."""
-    positions = np.array([
-        [-1, -1, 1], [1, -1, 1], [1, 1, 1], [-1, 1, 1],
-        [-1, -1, -1], [-1, 1, -1], [1, 1, -1], [1, -1, -1],
-        [-1, 1, -1], [-1, 1, 1], [1, 1, 1], [1, 1, -1],
-        [-1, -1, -1], [1, -1, -1], [1, -1, 1], [-1, -1, 1],
-        [1, -1, -1], [1, 1, -1], [1, 1, 1], [1, -1, 1],
-        [-1, -1, -1], [-1, -1, 1], [-1, 1, 1], [-1, 1, -1]], dtype=np.float32)
-    normals = np.array([[0, 0, 1], [0, 0, -1], [0, 1, 0], [0, -1, 0], [1, 0, 0], [-1, 0, 0]], dtype=np.float32)
-    uvs = np.array([[0, 0], [1, 0], [1, 1], [0, 1]], dtype=np.float32)
-    v = make_vertices(24)
-    f = make_faces(12, texture_id=0)
-    for face_idx in range(6):
-        for i in range(4):
-            k = face_idx * 4 + i
-            v["pos"][k] = positions[k]
-            v["uv"][k] = uvs[i]
-            v["normal"][k] = normals[face_idx]
-        b = face_idx * 4
-        f["v"][face_idx * 2] = (b, b + 1, b + 2)
-        f["v"][face_idx * 2 + 1] = (b, b + 2, b + 3)
-    return v, f

@@ -180,19 +180,6 @@ def make_scene(config="C1", n_tris=None, seed=None, variant="bench", width=None,
     return Scene(f"{config}:{variant}:{N}", W, H, verts, faces, textures, indexed, Camera(), settings)
 
 
-def cube_scene(width=320, height=240):
-    """The reference-authored fixture: create_test_cube (draw.rs:138-214) + Texture15::checkerboard
-    (types.rs:702-711), camera pulled back along -z, Gouraud default light, painter's."""
-    from .rtypes import create_test_cube
-    v, f = create_test_cube()
-    tex = Texture15.checkerboard(32, 32, 0x7FFF, 0x3DEF)
-    s = RasterSettings.benchmark()
-    s.shading = abi.SHADE_GOURAUD
-    s.lights = [Light.directional((-1.0, -1.0, -1.0), 0.7)]
-    cam = Camera(position=(0.7, -0.9, -4.5))
-    return Scene("cube", width, height, v, f, [tex], [], cam, s)
-
-
 def wire_grid_scene(back_first=True, width=320, height=240, n=9):
     """Exercises the wireframe phases (render.rs:2574-2635) with the reference's default settings (z-buffer, Gouraud,
     back-face wireframe).  Two back-facing grids with SHARED vertices (so most edges repeat inside a grid) sit at depths

@@ -16,6 +16,7 @@ sys.path.insert(0, ROOT)
 import bonnie32_amd as b32  # noqa: E402
 from bonnie32_amd import scenegen  # noqa: E402
 from oracle import oracle as O  # noqa: E402
+from tests.golden.ref_fixtures import cube_scene  # noqa: E402
 
 OUT = os.path.dirname(os.path.abspath(__file__))
 
@@ -122,7 +123,7 @@ def wire_painter_scene(overlay):
 
 
 def cube_default_scene():
-    sc = scenegen.cube_scene()
+    sc = cube_scene()
     sc.settings = b32.RasterSettings()            # far-side faces are back-faces: their wireframe must fail the depth test
     return sc
 
@@ -150,7 +151,7 @@ SCENES = {
     "C1:gouraud": lambda: scenegen.make_scene("C1", variant="gouraud"),
     "C1:blend": lambda: scenegen.make_scene("C1", variant="blend"),
     "C1:float": lambda: scenegen.make_scene("C1", variant="float"),
-    "cube": scenegen.cube_scene,
+    "cube": cube_scene,
     "fog-flat-point-nocull": fog_scene,
     "C2": lambda: scenegen.make_scene("C2"),
     "C2:blend": lambda: scenegen.make_scene("C2", variant="blend"),
@@ -179,7 +180,7 @@ def rgba_scene(name="C1", stp_blend=0, seed=61, variant="bench", settings=None, 
 
 
 def cube8_scene():
-    sc = scenegen.cube_scene()
+    sc = cube_scene()
     sc.textures8 = [b32.Texture.checkerboard(32, 32, (255, 255, 255, 0), (120, 120, 120, 0))]
     sc.settings = b32.RasterSettings(use_rgb555=False)
     return sc

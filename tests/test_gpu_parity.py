@@ -410,6 +410,38 @@ def test_framebuffer_new_on_a_reused_context(gpu_ctx, oracle):
     assert np.array_equal(fb2.pixels, ofb.pixels) and np.array_equal(fb2.zbuffer.view(np.uint32), ofb.zbuffer.view(np.uint32))
 
 
+def test_texture_cache_is_semantically_per_call(gpu_ctx, oracle):
+    """The drop-in call caches the uploaded textures by (pointer, size, blend mode, content hash): passing the same slice again skips
+    the texel copies, but the call must behave as if it uploaded every time -- a texel changed IN PLACE (same pointer), a changed
+    blend mode, another texture set and a return to the first one must all show up in the next frame."""
+    from bonnie32_amd import rasterizer as R
+    sc = scenegen.make_scene("C3", n_tris=3000, width=320, height=240, bbox_px=300.0, seed=808)      # 256x256 atlas
+    other = scenegen.make_scene("C1", n_tris=3000, bbox_px=300.0, seed=809)                           # 64x64 atlas, other content
+
+    def both(textures):
+        ofb = oracle.Framebuffer(sc.width, sc.height); ofb.clear(sc.clear_color)
+        assert oracle.render_mesh_15(ofb, sc.vertices, sc.faces, textures, sc.camera, sc.settings)[0] == 0
+        fb = R.Framebuffer(sc.width, sc.height, gpu_ctx); fb.clear(sc.clear_color)
+        R.render_mesh_15(fb, sc.vertices, sc.faces, textures, sc.camera, sc.settings)
+        got = fb.pixels
+        assert np.array_equal(got, ofb.pixels), f"{int((got != ofb.pixels).sum())} bytes differ"
+        return got
+    a = both(sc.textures)
+    assert np.array_equal(both(sc.textures), a)                     # second call: cache hit
+    sc.textures[0].pixels[1000:30000] ^= 0x1234                     # same pointer, new content
+    b = both(sc.textures)
+    assert not np.array_equal(a, b)
+    sc.textures[0].pixels[-1] ^= 1                                  # the very last texel (the hash's tail path)
+    both(sc.textures)
+    sc.textures[0].blend_mode = b32.abi.AVERAGE                     # same texels, other blend mode
+    c_ = both(sc.textures)
+    sc.textures[0].blend_mode = b32.abi.OPAQUE
+    both(other.textures)                                            # another set in between
+    assert np.array_equal(both(sc.textures), both(sc.textures))
+    keep = [b32.Texture15(t.width, t.height, t.pixels.copy(), t.blend_mode) for t in sc.textures]     # same content at another address
+    both(keep)
+
+
 def test_raster_timings_are_filled_on_every_synchronous_call(gpu_ctx):
     """RasterTimings (types.rs:1499-1514): the reference fills every phase on every call (render.rs:2362, 2515-2516, 2544, 2572).  Here the
     phases come from the device-side phase clock with no profiling switched on: cull (the fused transform + cull + setup kernel), sort
@@ -799,7 +831,8 @@ def test_cpp_host_mirror_end_to_end(tmp_path):
     the reference-authored cube fixture must come out byte-identical to the committed golden frame."""
     import struct, subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    sc = scenegen.cube_scene()
+    from tests.golden.ref_fixtures import cube_scene
+    sc = cube_scene()
     exe = tmp_path / "mesh_harness"
     lib_dir = os.path.join(root, "bonnie-32_amd", "csrc")
     subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(root, "bonnie-32_amd", "host"), "-I", os.path.join(root, "include"),

@@ -33,7 +33,8 @@ def test_reference_defaults_mirrored():
     d = s.lights[0].direction                     # Light::directional normalizes (types.rs:1318-1326)
     assert abs(d[0] + 0.57735026) < 1e-7 and s.lights[0].intensity == 0.7
     assert b32.RasterSettings.game().backface_wireframe is False      # types.rs:1455-1460
-    v, f = b32.create_test_cube()                 # draw.rs:138-214
+    from tests.golden.ref_fixtures import create_test_cube
+    v, f = create_test_cube()                 # draw.rs:138-214
     assert len(v) == 24 and len(f) == 12 and (v["r"] == 128).all() and (f["texture_id"] == 0).all()
     assert tuple(f["v"][1]) == (0, 2, 3)
     t = b32.Texture15.checkerboard(8, 8, 1, 2)    # types.rs:702-711

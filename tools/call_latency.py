@@ -5,8 +5,8 @@ import numpy as np
 from bonnie32_amd import rasterizer as R, scenegen
 import bonnie32_amd as b32
 ctx = R.Context(0)
-for cfg, n in (("C1", 2000), ("C1", 200), ("C2", 20000)):
-    sc = scenegen.make_scene(cfg, n_tris=n)
+for cfg, n in (("C1", 2000), ("C1", 200), ("C3", 2000), ("C3", 200), ("C2", 20000)):      # C1 / C2: 64x64 texture; C3: 256x256 (128 KB)
+    sc = scenegen.make_scene(cfg, n_tris=n, width=320, height=240, bbox_px=64.0 if cfg != "C2" else None)
     fb = R.Framebuffer(sc.width, sc.height, ctx)
     for st_name, st in (("painter", sc.settings), ("game()", b32.RasterSettings.game())):
         for i in range(5):

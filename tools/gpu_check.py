@@ -87,7 +87,7 @@ print("project_fixed", np.array_equal(sx[:5000], exp[:, 0]), np.array_equal(sy[:
 
 results = []
 results.append(check("C1", scenegen.make_scene("C1")))
-results.append(check("cube", scenegen.cube_scene()))
+results.append(check("cube", __import__("tests.golden.ref_fixtures", fromlist=["cube_scene"]).cube_scene()))
 results.append(check("C1-resident-indexed", scenegen.make_scene("C1"), resident=True, indexed=True))
 results.append(check("C1-gouraud", scenegen.make_scene("C1", variant="gouraud")))
 results.append(check("C1-blend", scenegen.make_scene("C1", variant="blend")))
