@@ -41,6 +41,8 @@ struct b32_ctx {
     bool blend8 = false;                // 8-bit path: some texel blends or some face has editor_alpha < 255 -> ordered walk
     TexDesc* d_tex = nullptr; size_t cap_tex = 0;
     std::vector<TexDesc> h_tex;
+    uint32_t* d_texmask = nullptr; size_t cap_texmask = 0;       // skip mask of the texel pool (FillArgs.texmask), rebuilt when the pool changes
+    uint32_t pool_texels = 0; bool mask_dirty = true;
     uint32_t nv = 0, nf = 0, nt = 0;
     bool have_scene = false;
     bool may_blend = true;              // some face / texture can produce a transparent-pass surface (render.rs:2403-2415)
@@ -117,6 +119,7 @@ struct b32_scene {
     uint32_t* d_texels32 = nullptr; size_t cap_texels32 = 0;
     TexDesc* d_tex = nullptr; size_t cap_tex = 0;
     uint32_t* d_consts = nullptr;
+    uint32_t* d_texmask = nullptr; size_t cap_texmask = 0; uint32_t pool_texels = 0; bool mask_dirty = true;
     std::vector<TexDesc> h_tex;
     uint32_t nv = 0, nf = 0, nt = 0;
     bool fmt8 = false, blend8 = false, have_scene = false, may_blend = true, cheap_ok = false, local_sort_ok = true, tex_blend_any = false;
@@ -220,7 +223,7 @@ void b32_destroy(b32_ctx* c) {
     void* ptrs[] = { c->fb_own, c->d_verts, c->d_faces, c->d_texels, c->d_tex, c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->crecs, c->srecs, c->xrecs,
                      c->shades, c->counts, c->block_sums, c->pkeys[0], c->pkeys[1], c->pvals[0], c->pvals[1], c->block_hist, c->ranges,
                      c->d_ctrl, c->d_consts, c->d_lights, c->digit_total, c->partials, c->vis, c->spans, c->tile_mid, c->zbuf,
-                     c->wire, c->wire_owner, c->wire_first, c->d_texels32, c->inline_lists };
+                     c->wire, c->wire_owner, c->wire_first, c->d_texels32, c->inline_lists, c->d_texmask };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->ev_created) for (auto& fr : c->ev) for (auto& e : fr) if (e) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -494,8 +497,10 @@ static int upload_geometry(b32_ctx* c, const B32Vertex* v, uint32_t nv, const B3
     return B32_OK;
 }
 
-// CHEAP coverage is worth it while skipped winners are rare: textures with at most 1/cheap_den() skippable texels
-static size_t cheap_den() { static const size_t d = getenv("B32_CHEAP_DEN") ? (size_t)atoi(getenv("B32_CHEAP_DEN")) : 32; return d ? d : 32; }
+// CHEAP coverage is worth it while skipped winners are rare: textures with at most 1/cheap_den() skippable texels.  Measured on the C3
+// geometry with 1 transparent CLUT entry out of K (tools/cheap_threshold.py): EXACT coverage (skip mask in LDS) 0.233 ms whatever the
+// texture; CHEAP 0.19 ms at K = 256, 0.220 at 64, 0.246 at 32, 0.307 at 16, 0.46 at 8.  (B32_CHEAP_DEN: that tool's switch.)
+static size_t cheap_den() { static const size_t d = getenv("B32_CHEAP_DEN") ? (size_t)atoi(getenv("B32_CHEAP_DEN")) : 64; return d ? d : 64; }
 
 static int layout_textures(b32_ctx* c, uint32_t nt, const uint32_t* w, const uint32_t* h, const uint32_t* blend, size_t* total, bool rgba = false) {
     if (nt > 65534) return B32_E_UNSUPPORTED;        // the surface record holds the texture slot in 16 bits
@@ -510,7 +515,9 @@ static int layout_textures(b32_ctx* c, uint32_t nt, const uint32_t* w, const uin
         if (off > 0x7FFFFFFFull) return B32_E_ARG;
     }
     *total = off + 8;
+    c->pool_texels = (uint32_t)off; c->mask_dirty = true;
     int rc;
+    if ((rc = ensure(c, c->d_texmask, c->cap_texmask, off / 32 + 4))) return rc;
     if (rgba) { if ((rc = ensure(c, c->d_texels32, c->cap_texels32, *total))) return rc; }
     else if ((rc = ensure(c, c->d_texels, c->cap_texels, *total))) return rc;
     if ((rc = ensure(c, c->d_tex, c->cap_tex, (size_t)nt + 1))) return rc;
@@ -733,6 +740,10 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
         }
     }
 
+    if (c->mask_dirty && c->pool_texels) {      // (after the drop-in call's staged copy kernel on the same stream: the texels are there)
+        launch_build_mask(s, c->fmt8 ? nullptr : c->d_texels, c->fmt8 ? c->d_texels32 : nullptr, c->pool_texels, c->d_texmask);
+        c->mask_dirty = false;
+    }
     if (fp.zmode) {          // Framebuffer::zbuffer (render.rs:12): allocated on first use, f32::MAX until drawn into
         const size_t px = (size_t)c->width * c->height;
         if (px > c->cap_zbuf || !c->zbuf) { if ((rc = ensure_plain(c, c->zbuf, px + 64))) return rc; c->cap_zbuf = px; c->zbuf_valid = false; }
@@ -890,6 +901,8 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     fa.texels32 = c->d_texels32;
     fa.ordered_all = ordered_all ? 1u : 0u;
     fa.prio64 = prio64 ? 1u : 0u;
+    fa.texmask = c->d_texmask;
+    { const uint32_t words = c->pool_texels / 32 + 2; fa.mask_lds_words = (c->pool_texels && words <= MASK_LDS_MAX_WORDS) ? words : 0u; }
     c->pending_may_redraw = !inline_bin;
     fa.inline_bin = inline_bin ? 1u : 0u; fa.list_stride = list_stride; fa.spans = c->spans; fa.partials = c->partials;
     if (inline_bin) fa.pair_vals = c->inline_lists;
@@ -1048,7 +1061,7 @@ void b32_scene_destroy(b32_ctx* c, b32_scene* sl) {
     if (!c || !sl) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    void* ptrs[] = { sl->d_verts, sl->d_faces, sl->d_texels, sl->d_texels32, sl->d_tex, sl->d_consts };
+    void* ptrs[] = { sl->d_verts, sl->d_faces, sl->d_texels, sl->d_texels32, sl->d_tex, sl->d_consts, sl->d_texmask };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete sl;
 }
@@ -1064,6 +1077,8 @@ int b32_scene_swap(b32_ctx* c, b32_scene* sl) {
     std::swap(c->d_texels32, sl->d_texels32); std::swap(c->cap_texels32, sl->cap_texels32);
     std::swap(c->d_tex, sl->d_tex); std::swap(c->cap_tex, sl->cap_tex);
     std::swap(c->d_consts, sl->d_consts);
+    std::swap(c->d_texmask, sl->d_texmask); std::swap(c->cap_texmask, sl->cap_texmask); std::swap(c->pool_texels, sl->pool_texels);
+    std::swap(c->mask_dirty, sl->mask_dirty);
     c->h_tex.swap(sl->h_tex);
     std::swap(c->nv, sl->nv); std::swap(c->nf, sl->nf); std::swap(c->nt, sl->nt);
     std::swap(c->fmt8, sl->fmt8); std::swap(c->blend8, sl->blend8); std::swap(c->have_scene, sl->have_scene);

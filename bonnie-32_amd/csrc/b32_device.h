@@ -360,6 +360,9 @@ void launch_selftest(hipStream_t s, int op, const float* a, const float* b, cons
 // test tap: constants of B32_CONSTANTS (one word each, f32 bits or the integer), UNR table (257 bytes) and dither offsets (16 words,
 // index (y & 3) * 4 + (x & 3)) as device code holds them
 void launch_constants(hipStream_t s, uint32_t* consts, uint8_t* unr, int32_t* dither);
+// skip mask of the texel pool (see FillArgs.texmask): n texels, 16-bit Color15 or 32-bit Color
+void launch_build_mask(hipStream_t s, const uint16_t* texels15, const uint32_t* texels32, uint32_t n, uint32_t* mask);
+constexpr uint32_t MASK_LDS_MAX_WORDS = 9216;      // 36 KB: the runner-up plane of the fused kernel, unused by EXACT coverage
 void launch_clear(hipStream_t s, uint32_t* fb, size_t n_px, uint32_t rgba);
 // staged upload of a drop-in call: up to 16 segments copied by ONE kernel from a pinned host arena (mapped into the device's address
 // space) to their device buffers -- every SDMA copy costs ~10 us of stream time, one kernel reading over PCIe ~5 us for all of them
@@ -435,6 +438,12 @@ struct FillArgs {
     uint32_t list_stride;       // entries per tile region (a multiple of 32: regions never share a cache line)
     const uint32_t* spans;      // k_setup's packed tile span per face
     const uint32_t* partials;   // k_setup's per-block counters
+    // Skip mask: one bit per texel of the pool, set when the texel can be skipped by the transparency rule -- r5 = g5 = b5 = 0 (RGB555:
+    // skipped when the face has black_transparent, render.rs:1591-1608) or blend == Erase (8-bit path, render.rs:1348-1352).  EXACT
+    // coverage on the sort-free path decides every fragment from this bit instead of fetching the texel: 1/16 of the bytes, and it fits
+    // LDS (mask_lds_words > 0: the first that many words are staged in the unused runner-up plane; a 256x256 texture is 8 KB).
+    const uint32_t* texmask;
+    uint32_t mask_lds_words;
     uint32_t prio64;            // 1: sort-free coverage -- visibility is a 64-bit max of (painter's key << 32 | face id); `vis` holds
                                 //    two words per pixel: winner face id + 1, runner-up face id + 1 (0 = none)
 #ifdef B32_TIMELINE

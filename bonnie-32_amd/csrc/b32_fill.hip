@@ -654,15 +654,18 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
                 // winner is a drawn fragment, so no runner-up is kept)
                 const unsigned long long P = P64 ? (((unsigned long long)bperm(s, my_key) << 32) | bperm(s, my_sid)) : 0ull;
                 if (P64 && EXACT && TEXMODE == 0) {
-                    // four pixels per trip: the four texel fetches are issued together, then the skip rule, then the (non-returning)
-                    // atomics of the drawn fragments
+                    // four pixels per trip: the four texel addresses, their bits of the skip mask (LDS when the pool's mask fits, else
+                    // global: 1/16 of the texels' bytes) -- no texel is fetched during coverage -- then the (non-returning) atomics of the
+                    // drawn fragments
                     unsigned long long* top = reinterpret_cast<unsigned long long*>(tilebuf);
+                    const uint32_t* mask_l = reinterpret_cast<const uint32_t*>(ltex);           // LDS copy of the mask (k_cover stages it)
+                    const bool mask_in_lds = a.mask_lds_words != 0;
                     for (uint32_t i = 0; __ballot(i < n); i += 4) {
                         float wa[4], wb[4];
                         wa[0] = w0; wb[0] = w1;
 #pragma unroll
                         for (int j = 1; j < 4; ++j) { wa[j] = wa[j - 1] + sa0; wb[j] = wb[j - 1] + sa1; }
-                        bool in[4]; int ta[4]; uint32_t fe[4]; unsigned long long Pj[4];
+                        bool in[4]; int ta[4]; unsigned long long Pj[4];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const float cx = wa[j] * sinv, cy = wb[j] * sinv;
@@ -674,13 +677,18 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
                                 ta[j] = tri_texel_addr(tr, cx, cy, cz, affine);
                             }
                         }
+                        uint32_t mw[4];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) fe[j] = fetch_texel<FMT8>(a, in[j] ? ta[j] : -1);
+                        for (int j = 0; j < 4; ++j) {
+                            mw[j] = 0;
+                            if (in[j] && ta[j] >= 0) mw[j] = mask_in_lds ? mask_l[(uint32_t)ta[j] >> 5] : a.texmask[(uint32_t)ta[j] >> 5];
+                        }
                         bool any = false;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            uint32_t texel;
-                            in[j] = in[j] && hit_finish<FMT8>(tr.flags, ta[j], fe[j], texel);
+                            // skippable texel: the mask bit; a zero-size texture samples TRANSPARENT (-2), no texture samples WHITE (-1)
+                            const bool blk = ta[j] == -2 ? true : (ta[j] >= 0 && ((mw[j] >> ((uint32_t)ta[j] & 31u)) & 1u));
+                            in[j] = in[j] && !(FMT8 ? blk : (blk && (tr.flags & F_BLACK_TR)));       // render.rs:1591-1608 / 8-bit :1348-1352
                             any |= in[j];
                             mine += in[j] ? 1u : 0u;
                         }
@@ -885,7 +893,7 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a) {
     uint32_t* tilebuf = reinterpret_cast<uint32_t*>(smem);
     volatile uint32_t* misc = reinterpret_cast<volatile uint32_t*>(smem + TB);   // [0] tile, [2] list cursor
     uint32_t* wmarks = reinterpret_cast<uint32_t*>(smem + TB + LDS_MISC_BYTES);
-    const uint16_t* ltex = reinterpret_cast<const uint16_t*>(smem + LDS_TEX_OFFSET);
+    const uint16_t* ltex = reinterpret_cast<const uint16_t*>(smem + LDS_TEX_OFFSET);    // LDS texture (TEXMODE 1) or LDS skip mask (P64 EXACT)
     uint32_t* sort_cnt = reinterpret_cast<uint32_t*>(smem + LDS_TEX_OFFSET);        // local sort only exists without an LDS texture
 
     const uint32_t tid = threadIdx.x, lane = tid & 63;
@@ -928,6 +936,11 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a) {
         uint4* dst = reinterpret_cast<uint4*>(smem + LDS_TEX_OFFSET);
         const uint32_t nq = (a.lds_tex_texels + 7) / 8;
         for (uint32_t i = tid; i < nq; i += NT) dst[i] = src[i];
+    }
+    if (P64 && EXACT && a.mask_lds_words) {     // the pool's skip mask into the (unused) runner-up plane, once per workgroup
+        uint32_t* ml = tilebuf + 2 * TILE_H * TILE_STRIDE;
+        for (uint32_t i = tid; i < a.mask_lds_words; i += NT) ml[i] = a.texmask[i];
+        ltex = reinterpret_cast<const uint16_t*>(ml);
     }
     unsigned long long frag_count = 0;
     // the first tile of a workgroup is its own index (no atomic: 512 same-address atomics serialise at ~12 ns each), later ones come
@@ -1002,7 +1015,7 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a) {
                 const uint32_t px = x_lo + col, py = ty_top + row;
                 const bool inb = px < x_hi && py >= y_lo && py < y_hi;
                 t64[row * STR64 + col] = inb ? (((unsigned long long)(~zsort_key(a.zbuf[(size_t)py * fp.width + px])) << 32) | 0xFFFFFFFFull) : ~0ull;
-                t64[TILE_H * STR64 + row * STR64 + col] = 0ull;
+                if (!EXACT) t64[TILE_H * STR64 + row * STR64 + col] = 0ull;          // (EXACT keeps no runner-up: that plane holds the skip mask)
             }
         } else if (ZMODE) { // 64-bit entries (depth key << 32 | list position), seeded with the current z-buffer: a fragment wins
             unsigned long long* t64 = reinterpret_cast<unsigned long long*>(tilebuf);       // only with a strictly smaller depth
@@ -1015,9 +1028,9 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a) {
         } else {
             if (P64 && TH < (uint32_t)TILE_H) {             // half-height tile: clear only the rows in use of both 64-bit planes
                 unsigned long long* t64 = reinterpret_cast<unsigned long long*>(tilebuf);
-                for (uint32_t i = tid; i < TH * STR64; i += NT) { t64[i] = 0ull; t64[TILE_H * STR64 + i] = 0ull; }
+                for (uint32_t i = tid; i < TH * STR64; i += NT) { t64[i] = 0ull; if (!EXACT) t64[TILE_H * STR64 + i] = 0ull; }
             } else
-            for (uint32_t i = tid; i < (P64 ? 4 : (EXACT ? 1 : 2)) * TILE_H * TILE_STRIDE; i += NT) tilebuf[i] = 0;
+            for (uint32_t i = tid; i < (P64 ? (EXACT ? 2 : 4) : (EXACT ? 1 : 2)) * TILE_H * TILE_STRIDE; i += NT) tilebuf[i] = 0;
         }
         __syncthreads();
         if (P64 && a.inline_bin) {

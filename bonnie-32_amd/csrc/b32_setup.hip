@@ -488,6 +488,19 @@ void launch_project_fixed(hipStream_t s, const float* pos, uint32_t n, B32Camera
     hipLaunchKernelGGL(k_project_fixed, dim3((n + 255) / 256), dim3(256), 0, s, pos, n, cam, w, h, sx, sy, z);
 }
 
+// ---------------------------------------------------------------- skip mask of the texel pool
+__global__ void k_build_mask(const uint16_t* __restrict__ t15, const uint32_t* __restrict__ t32, uint32_t n, uint32_t* __restrict__ mask) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool bit = false;
+    if (i < n) bit = t32 ? ((t32[i] >> 24) == B32_BLEND_ERASE) : ((t15[i] & ~K::C15_SEMI_BIT & 0xFFFFu) == 0);
+    const unsigned long long m = __ballot(bit);
+    if ((threadIdx.x & 63) == 0 && i < n) { mask[i >> 5] = (uint32_t)m; mask[(i >> 5) + 1] = (uint32_t)(m >> 32); }
+}
+void launch_build_mask(hipStream_t s, const uint16_t* texels15, const uint32_t* texels32, uint32_t n, uint32_t* mask) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_build_mask, dim3((n + 255) / 256), dim3(256), 0, s, texels15, texels32, n, mask);
+}
+
 // ---------------------------------------------------------------- constants tap (see B32_CONSTANTS in b32_device.h)
 __global__ void k_constants(uint32_t* __restrict__ consts, uint8_t* __restrict__ unr, int32_t* __restrict__ dither) {
     if (blockIdx.x != 0) return;
