@@ -90,6 +90,7 @@ SYMBOLS = [
     ("b32_fb_resize", C.c_int, [_P, C.c_uint32, C.c_uint32]),
     ("b32_fb_new", C.c_int, [_P, C.c_uint32, C.c_uint32]),
     ("b32_set_async_depth", C.c_int, [_P, C.c_int]),
+    ("b32_route_count", C.c_ulonglong, [_P, C.c_int]),
     ("b32_fb_clear", C.c_int, [_P, C.c_uint8, C.c_uint8, C.c_uint8, C.c_uint8]),
     ("b32_fb_upload", C.c_int, [_P, _P]),
     ("b32_fb_download", C.c_int, [_P, _P]),

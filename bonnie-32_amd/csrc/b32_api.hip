@@ -71,6 +71,16 @@ struct b32_ctx {
     // pairs
     size_t cap_pairs = 0;
     uint32_t* inline_lists = nullptr; size_t cap_inline = 0;      // small meshes: one list region per tile, filled inside k_cover
+    // direct binning (DirectBin, b32_device.h): k_setup appends to fixed tile regions; the regions grow when a frame overflowed one
+    uint32_t* direct_lists = nullptr; size_t cap_direct = 0;
+    uint32_t* tile_fill = nullptr; size_t cap_tile_fill = 0;      // FILL_PAD words per tile, zero between frames
+    // (per scene, swapped with the scene slots:)
+    uint32_t direct_cap_opaque = 0;                               // opaque entries per tile region (0: sized from the mesh on first use)
+    uint32_t direct_ntiles = 0;                                   // the tile grid that size belongs to (another grid: sized again)
+    bool direct_ok = true;                                        // false: the regions would not fit (one tile's list too long) -> counting sort
+    bool last_direct = false;
+    uint32_t epoch = 0;
+    unsigned long long routes[8] = {};                            // b32_route_count
     uint32_t *pkeys[2] = { nullptr, nullptr }, *pvals[2] = { nullptr, nullptr };
     // sort scratch
     uint32_t* block_hist = nullptr; uint32_t hist_blocks = 0; uint32_t* digit_total = nullptr;
@@ -123,6 +133,7 @@ struct b32_scene {
     std::vector<TexDesc> h_tex;
     uint32_t nv = 0, nf = 0, nt = 0;
     bool fmt8 = false, blend8 = false, have_scene = false, may_blend = true, cheap_ok = false, local_sort_ok = true, tex_blend_any = false;
+    uint32_t direct_cap_opaque = 0, direct_ntiles = 0; bool direct_ok = true;
     std::vector<b32_ctx::TexSig> tex_sig; bool tex_sig_valid = false, tex_sig_rgba = false;
 };
 
@@ -208,10 +219,10 @@ int b32_create(int device, b32_ctx** out) {
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return B32_E_HIP; }
     c->stream = c->own_stream;
-    if (hipMalloc(reinterpret_cast<void**>(&c->d_ctrl), sizeof(Ctrl) + sizeof(Stamps)) != hipSuccess ||
+    if (hipMalloc(reinterpret_cast<void**>(&c->d_ctrl), sizeof(Ctrl) + sizeof(Stamps) + sizeof(Events)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&c->d_consts), 16 * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&c->digit_total), 4096 * sizeof(uint32_t)) != hipSuccess) { delete c; return B32_E_HIP; }
-    if (hipMemset(c->d_ctrl, 0, sizeof(Ctrl) + sizeof(Stamps)) != hipSuccess) { delete c; return B32_E_HIP; }     // (`sticky` is never reset by a frame)
+    if (hipMemset(c->d_ctrl, 0, sizeof(Ctrl) + sizeof(Stamps) + sizeof(Events)) != hipSuccess) { delete c; return B32_E_HIP; }     // (`sticky` is never reset by a frame)
     *out = c;
     return B32_OK;
 }
@@ -223,7 +234,7 @@ void b32_destroy(b32_ctx* c) {
     void* ptrs[] = { c->fb_own, c->d_verts, c->d_faces, c->d_texels, c->d_tex, c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->crecs, c->srecs, c->xrecs,
                      c->shades, c->counts, c->block_sums, c->pkeys[0], c->pkeys[1], c->pvals[0], c->pvals[1], c->block_hist, c->ranges,
                      c->d_ctrl, c->d_consts, c->d_lights, c->digit_total, c->partials, c->vis, c->spans, c->tile_mid, c->zbuf,
-                     c->wire, c->wire_owner, c->wire_first, c->d_texels32, c->inline_lists, c->d_texmask };
+                     c->wire, c->wire_owner, c->wire_first, c->d_texels32, c->inline_lists, c->d_texmask, c->direct_lists, c->tile_fill };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->ev_created) for (auto& fr : c->ev) for (auto& e : fr) if (e) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -470,6 +481,9 @@ static int upload_geometry(b32_ctx* c, const B32Vertex* v, uint32_t nv, const B3
     }
     if ((rc = h2d(c, c->d_verts, v, (size_t)nv * sizeof(B32Vertex)))) return rc;
     if ((rc = h2d(c, c->d_faces, f, (size_t)nf * sizeof(B32Face)))) return rc;
+    // a mesh of another size: tile regions sized afresh (the per-frame drop-in call uploads the same mesh again and again: what an
+    // overflowing frame taught the context stays)
+    if (c->nf != nf) { c->direct_cap_opaque = 0; c->direct_ntiles = 0; c->direct_ok = true; }
     c->nv = nv; c->nf = nf;
     c->local_sort_ok = true;
     // per-face work buffers
@@ -822,17 +836,51 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     fp.band_only = (want_prio64 && c->band_set) ? 1 : 0;   // other ranks own the other rows: their surfaces' records are never read here
     fp.redraw = c->redrawing ? 1 : 0;
     fp.tex_blend_any = c->tex_blend_any ? 1 : 0;
-    launch_setup(s, fp, c->d_verts, c->d_faces, c->d_tex, c->d_lights, lset, RecArrays{ c->crecs, c->srecs, c->xrecs }, c->shades, c->keys[0], c->spans, c->partials, c->d_ctrl, c->wire, c->n_cu);
-    if (prof_all) HIPCHK(c, hipEventRecord(ev[1], s));
-
     int cur = 0;
-    bool prio64 = false, inline_bin = false;
+    bool prio64 = false, inline_bin = false, direct_bin = false;
     // small mesh (what the reference's callers submit per room / asset part): no binning launch, the
     // fused kernel's workgroups collect their own tile lists from the spans (needs one list region of nf entries per tile)
-    const uint32_t list_stride = (c->nf + 31u) & ~31u;
+    uint32_t list_stride = (c->nf + 31u) & ~31u;
     // (with a transparent pass only up to 2048 faces: no tile's transparent list can then exceed what k_blend sorts in LDS)
-    if (want_prio64 && !wire_front && c->nf <= (with_class ? 2048u : 8192u) && (size_t)ntiles * list_stride <= ((size_t)4 << 20) &&
-        !no_inline_bin) {
+    const bool want_inline = want_prio64 && !wire_front && c->nf <= (with_class ? 2048u : 8192u) && (size_t)ntiles * list_stride <= ((size_t)4 << 20) &&
+                             !no_inline_bin;
+    // larger meshes: no binning launch either -- k_setup appends every surviving face to fixed-size tile regions (DirectBin)
+    static const bool no_direct_bin = getenv("B32_NO_DIRECT_BIN") != nullptr;                   // experiment switch, read once
+    DirectBin db{};
+    if (c->direct_ntiles != ntiles) { c->direct_ntiles = ntiles; c->direct_cap_opaque = 0; c->direct_ok = true; }   // another tile grid (resize, band)
+    if (want_prio64 && !want_inline && !wire_front && c->direct_ok && !no_direct_bin && ntiles) {
+        // first guess: three times the mean list of a mesh whose every face is drawn and touches one tile; a frame that overflows
+        // reports its longest list and is redrawn with regions a quarter above it (b32_frame_finish)
+        if (!c->direct_cap_opaque) c->direct_cap_opaque = std::max<uint32_t>(512u, (uint32_t)std::min<uint64_t>((uint64_t)3 * c->nf / ntiles + 64, 1u << 24));
+        const uint32_t cap_o = (c->direct_cap_opaque + 31u) & ~31u;
+        const uint32_t region = cap_o + (with_class ? BLEND_SORT_CAP : 0u);
+        const size_t need = (size_t)ntiles * region + 64;
+        if (need <= ((size_t)1 << 28)) {                            // 1 GB of list space at most; beyond that the compact counting sort
+            if (need > c->cap_direct || !c->direct_lists) {
+                if ((rc = ensure_plain(c, c->direct_lists, need + need / 8))) return rc;
+                c->cap_direct = need + need / 8;
+            }
+            const size_t need_fill = (size_t)ntiles * FILL_PAD + 64;
+            if (need_fill > c->cap_tile_fill || !c->tile_fill) {
+                if ((rc = ensure_plain(c, c->tile_fill, need_fill * 2))) return rc;
+                c->cap_tile_fill = need_fill * 2;
+                HIPCHK(c, hipMemsetAsync(c->tile_fill, 0, c->cap_tile_fill * sizeof(uint32_t), s));   // zero from here on: k_cover re-zeroes what k_setup counted
+            }
+            if (++c->epoch == 0) c->epoch = 1;
+            db.fill = c->tile_fill; db.lists = c->direct_lists; db.region = region; db.cap_opaque = cap_o;
+            db.cap_transparent = with_class ? BLEND_SORT_CAP : 0u; db.with_class = with_class ? 1u : 0u; db.epoch = c->epoch;
+            direct_bin = true;
+            list_stride = region;
+        } else c->direct_ok = false;
+    }
+    c->last_direct = direct_bin;
+    launch_setup(s, fp, c->d_verts, c->d_faces, c->d_tex, c->d_lights, lset, RecArrays{ c->crecs, c->srecs, c->xrecs }, db, c->shades, c->keys[0], c->spans, c->partials, c->d_ctrl, c->wire, c->n_cu);
+    if (prof_all) HIPCHK(c, hipEventRecord(ev[1], s));
+
+    if (direct_bin) {
+        if (prof_all) HIPCHK(c, hipEventRecord(ev[2], s));
+        prio64 = true;
+    } else if (want_inline) {
         const size_t need = (size_t)ntiles * list_stride + 64;
         if (need > c->cap_inline) {
             if ((rc = ensure_plain(c, c->inline_lists, need + need / 2))) return rc;
@@ -882,6 +930,7 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     }
     }   // !prio64
     c->last_pair_buf = cur;
+    c->routes[direct_bin ? 0 : inline_bin ? 1 : prio64 ? 2 : 3]++;
     if (prof_fill) HIPCHK(c, hipEventRecord(ev[3], s));
 
     FillArgs fa{};
@@ -906,6 +955,8 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     c->pending_may_redraw = !inline_bin;
     fa.inline_bin = inline_bin ? 1u : 0u; fa.list_stride = list_stride; fa.spans = c->spans; fa.partials = c->partials;
     if (inline_bin) fa.pair_vals = c->inline_lists;
+    fa.direct_bin = direct_bin ? 1u : 0u; fa.tile_fill = c->tile_fill; fa.epoch = c->epoch;
+    if (direct_bin) fa.pair_vals = c->direct_lists;
     fa.gather_blend = (prio64 && with_class) ? 1u : 0u;
     if (c->fmt8) fa.fp.xray = 0;                        // render_mesh: x-ray only changes culling; its stores keep their own depth tests
     launch_fill(s, fa, c->n_cu, prof_fill ? ev[4] : nullptr);
@@ -991,10 +1042,23 @@ int b32_frame_finish(b32_ctx* c, B32Timings* out) {
             std::memcpy(&c->h_ctrl, tmp, sizeof(Ctrl)); std::memcpy(&c->h_stamps, tmp + sizeof(Ctrl), sizeof(Stamps));
             c->h_stamps.t[ST_END] = 0;
         }
-        if (c->h_ctrl.need_global_sort && c->local_sort_ok) {
+        if ((c->h_ctrl.need_global_sort & 2u) && c->last_direct) {
+            // direct binning: a tile region was too small and nothing was drawn; redraw this frame with regions a quarter above the
+            // longest list it reported (enqueue_frame falls back to the compact counting sort if those would not fit)
+            c->direct_cap_opaque = c->h_ctrl.list_demand + c->h_ctrl.list_demand / 4 + 64;
+            c->routes[4]++;
+            c->ev_frames = 0;
+            c->redrawing = true;
+            const int rc = enqueue_frame(c, &c->last_cam, &c->last_settings, c->last_has_fog ? &c->last_fog : nullptr);
+            c->redrawing = false;
+            if (rc) return rc;
+            continue;
+        }
+        if ((c->h_ctrl.need_global_sort & 1u) && c->local_sort_ok) {
             // a tile list was longer than the LDS sort handles: nothing was drawn; redraw this frame (and the following ones of
             // this scene) with the global depth sort
             c->local_sort_ok = false;
+            c->routes[5]++;
             c->ev_frames = 0;
             c->redrawing = true;
             const int rc = enqueue_frame(c, &c->last_cam, &c->last_settings, c->last_has_fog ? &c->last_fog : nullptr);
@@ -1008,6 +1072,7 @@ int b32_frame_finish(b32_ctx* c, B32Timings* out) {
         int rc;
         for (int i = 0; i < 2; ++i) { if ((rc = ensure_plain(c, c->pkeys[i], n))) return rc; if ((rc = ensure_plain(c, c->pvals[i], n))) return rc; }
         c->cap_pairs = n;
+        c->routes[6]++;
         c->ev_frames = 0;                              // the aborted frame must not enter the phase averages
         c->redrawing = true;
         rc = enqueue_frame(c, &c->last_cam, &c->last_settings, c->last_has_fog ? &c->last_fog : nullptr);
@@ -1084,6 +1149,7 @@ int b32_scene_swap(b32_ctx* c, b32_scene* sl) {
     std::swap(c->fmt8, sl->fmt8); std::swap(c->blend8, sl->blend8); std::swap(c->have_scene, sl->have_scene);
     std::swap(c->may_blend, sl->may_blend); std::swap(c->cheap_ok, sl->cheap_ok); std::swap(c->local_sort_ok, sl->local_sort_ok);
     std::swap(c->tex_blend_any, sl->tex_blend_any);
+    std::swap(c->direct_cap_opaque, sl->direct_cap_opaque); std::swap(c->direct_ntiles, sl->direct_ntiles); std::swap(c->direct_ok, sl->direct_ok);
     c->tex_sig.swap(sl->tex_sig); std::swap(c->tex_sig_valid, sl->tex_sig_valid); std::swap(c->tex_sig_rgba, sl->tex_sig_rgba);
     return B32_OK;
 }
@@ -1257,6 +1323,9 @@ extern "C" int b32_set_fragment_counting(b32_ctx* c, int on) {
     if (!c) return B32_E_ARG;
     c->count_fragments = on ? 1 : 0;
     return B32_OK;
+}
+extern "C" unsigned long long b32_route_count(const b32_ctx* c, int which) {
+    return (c && which >= 0 && which < 8) ? c->routes[which] : 0ull;
 }
 extern "C" int b32_set_async_depth(b32_ctx* c, int deep) {
     if (!c) return B32_E_ARG;

@@ -159,8 +159,9 @@ struct Ctrl {
     uint32_t n_pairs;          // (tile,class) x surface pairs emitted by binning
     uint32_t pairs_overflow;
     uint32_t tile_cursor;      // persistent-workgroup tile dispenser of k_fill
-    uint32_t nf;               // copy of the face count (first sort pass length)
-    uint32_t need_global_sort; // a tile list exceeded the LDS sort capacity: redraw with the global depth sort
+    uint32_t list_demand;      // direct binning, when a tile region overflowed: the longest opaque tile list of the frame (the host sizes the regions from it)
+    uint32_t need_global_sort; // bit 0: a tile list exceeded the LDS sort capacity: redraw with the global depth sort;
+                               // bit 1: a tile region of the direct binning overflowed: redraw with larger regions (nothing was drawn either way)
     uint32_t wire_overflow;    // a wireframe edge is >= 2^30 pixels long: the reference's i32 Bresenham state overflows
     uint32_t sticky;           // errors of every frame since the last b32_frame_finish (bit 0 vertex index, 1 NaN sort key, 2 wire edge):
                                // NOT reset at frame start, so the meshes of a multi-scene frame can be enqueued without a sync each.
@@ -173,6 +174,10 @@ struct Ctrl {
 // bytes right behind Ctrl (one allocation).  They cost one store per kernel and no launch, so RasterTimings' phases are filled on every
 // synchronous call (render.rs:2362, 2515-2516, 2544, 2572 always fill them), not only under b32_set_profiling.
 struct Stamps { unsigned long long t[8]; };
+// Rare events of k_setup under direct binning, behind Stamps: each word holds the EPOCH (frame number, never 0) of the last frame the
+// event happened in, so nothing has to be reset between frames and k_setup's own frame-start reset of Ctrl cannot race with them.
+struct Events { uint32_t bad_index, nan_opaque, nan_transparent, overflow, long_transparent, _pad[3]; };
+__device__ __forceinline__ Events* events_of(Ctrl* ctrl) { return reinterpret_cast<Events*>(reinterpret_cast<unsigned char*>(ctrl) + 128); }
 enum { ST_SETUP = 0, ST_BIN = 1, ST_FILL = 2, ST_WIRE = 3, ST_END = 4 };
 __device__ __forceinline__ void phase_stamp(Ctrl* ctrl, int k) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -351,8 +356,25 @@ void launch_radix_pass(hipStream_t s, const uint32_t* keys_in, const uint32_t* v
 constexpr uint32_t LIGHTS_INLINE = 8;
 struct LightSet { B32Light l[LIGHTS_INLINE]; };
 struct RecArrays { CovRec* cov; ShadeRec* shade; AuxRec* aux; };
+// Direct binning (sort-free path, meshes too large for the in-kernel collection): k_setup itself appends every surviving face to the
+// lists of the tiles its span touches -- one returning atomic per (tile, face) pair on the tile's fill counter, whose latency passes
+// behind the record build -- so the frame has no binning launch at all.  Every tile owns a fixed region of `region` entries:
+// opaque-class entries grow from its front (at most cap_opaque), transparent-class entries from its back (at most cap_transparent);
+// a face that finds a region full raises Events::overflow and the frame is redrawn with larger regions.  The counters (one 128-byte
+// line per tile: word 0 opaque, word 1 transparent) are zero between frames: k_cover zeroes a tile's pair when it takes the tile.
+#ifndef B32_FILL_PAD
+#define B32_FILL_PAD 32
+#endif
+constexpr uint32_t FILL_PAD = B32_FILL_PAD;     // words per tile counter line
+struct DirectBin {
+    uint32_t* fill;             // nullptr: off
+    uint32_t* lists;
+    uint32_t region, cap_opaque, cap_transparent;
+    uint32_t with_class;        // 1: faces of the transparent pass (render.rs:2522-2523) go to the back of the region
+    uint32_t epoch;
+};
 void launch_setup(hipStream_t s, const FrameParams& fp, const B32Vertex* verts, const B32Face* faces, const TexDesc* tex,
-                  const B32Light* lights, const LightSet& inline_lights, RecArrays recs, float* shades, uint32_t* keys, uint32_t* spans,
+                  const B32Light* lights, const LightSet& inline_lights, RecArrays recs, const DirectBin& direct, float* shades, uint32_t* keys, uint32_t* spans,
                   uint32_t* partials, Ctrl* ctrl, WireTri* wire, int n_cu);
 void launch_project_fixed(hipStream_t s, const float* pos, uint32_t n, B32Camera cam, uint32_t w, uint32_t h,
                           int32_t* sx, int32_t* sy, float* z);
@@ -435,6 +457,9 @@ struct FillArgs {
     // small meshes (at most 2048 faces): no binning launch at all -- every workgroup of the fused kernel
     // collects its tile's list from k_setup's spans itself, and reduces k_setup's counters (workgroup 0 publishes them in Ctrl)
     uint32_t inline_bin;        // 1: lists are built inside k_cover at pair_vals[tile * list_stride ...]
+    uint32_t direct_bin;        // 1: lists were built by k_setup (DirectBin) at pair_vals[tile * list_stride ...], counts in tile_fill
+    uint32_t* tile_fill;        // DirectBin::fill
+    uint32_t epoch;             // DirectBin::epoch
     uint32_t list_stride;       // entries per tile region (a multiple of 32: regions never share a cache line)
     const uint32_t* spans;      // k_setup's packed tile span per face
     const uint32_t* partials;   // k_setup's per-block counters

@@ -910,12 +910,23 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a_in) {
     const FrameParams& fp = a.fp;
     const uint32_t ntiles = fp.tiles_x * fp.tiles_y;
     phase_stamp(a.ctrl, ST_FILL);
-    if (P64 && a.inline_bin) {
-        // small mesh: there was no binning launch, so nobody has reduced k_setup's per-block counters yet.  Every workgroup derives
-        // the frame's abort decision from them (the reference panics before drawing on a bad vertex index, render.rs:2375, or when a
-        // sort comparison sees NaN, render.rs:2531); workgroup 0 publishes the counters in Ctrl for the host.
+    if (P64 && (a.inline_bin || a.direct_bin)) {
+        // there was no binning launch, so nobody has reduced k_setup's per-block counters yet.  Small mesh (inline_bin): every workgroup
+        // derives the frame's abort decision from them (the reference panics before drawing on a bad vertex index, render.rs:2375, or
+        // when a sort comparison sees NaN, render.rs:2531); workgroup 0 publishes the counters in Ctrl for the host.  Direct binning:
+        // k_setup left the epoch of this frame in Events when it met one of those, and only then does every workgroup pay for the
+        // reduction; otherwise workgroup 0 alone does it, for the host's counters.
+        bool reduce = a.inline_bin || blockIdx.x == 0;
+        uint32_t redraw = 0;
+        if (a.direct_bin) {
+            const Events* ev = events_of(a.ctrl);
+            reduce = reduce || ev->bad_index == a.epoch || ev->nan_opaque == a.epoch || ev->nan_transparent == a.epoch;
+            redraw = (ev->overflow == a.epoch ? 2u : 0u) | (ev->long_transparent == a.epoch ? 1u : 0u);
+        }
         if (tid < 5) misc[8 + tid] = 0;
+        if (tid == 0) misc[6] = 0;
         __syncthreads();
+        if (reduce) {
         const uint32_t npart = (fp.nf + 255) / 256;
         for (uint32_t b = tid; b < npart; b += NT)
             for (int k = 0; k < 5; ++k) { const uint32_t v = a.partials[b * 8 + k]; if (v) atomicAdd(const_cast<uint32_t*>(&misc[8 + k]), v); }
@@ -932,7 +943,21 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a_in) {
             }
         }
         __syncthreads();
-        if (misc[6]) return;
+        }   // reduce
+        if (misc[6] || redraw) {
+            // nothing is drawn.  Direct binning: a region overflowed (the host redraws with larger regions: the longest list goes
+            // back in Ctrl) or a transparent list is too long for k_blend's LDS sort (the host redraws with the global sort); either
+            // way the fill counters are left zero for the next frame, as k_setup expects them.
+            if (a.direct_bin) {
+                for (uint32_t t = blockIdx.x * NT + tid; t < ntiles; t += gridDim.x * NT) {
+                    uint32_t* fl = a.tile_fill + (size_t)t * FILL_PAD;
+                    if (redraw & 2u) atomicMax(&a.ctrl->list_demand, fl[0]);
+                    fl[0] = 0; fl[1] = 0;
+                }
+                if (blockIdx.x == 0 && tid == 0 && !misc[6]) a.ctrl->need_global_sort = redraw;
+            }
+            return;
+        }
     } else {
         if (a.ctrl->abort) return;
         if (P64 && a.ctrl->need_global_sort) return;   // a transparent tile list is too long for k_blend's LDS sort: the host redraws
@@ -968,6 +993,14 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a_in) {
         uint32_t e0, e1;
         if (P64 && a.inline_bin) {               // the list is collected below, into this tile's own region
             e0 = e1 = tile * a.list_stride;
+        } else if (P64 && a.direct_bin) {        // k_setup built the lists: opaque pass at the front of the region, transparent at its back
+            const uint32_t* fl = a.tile_fill + (size_t)tile * FILL_PAD;
+            const uint32_t n_o = fl[0], n_t = fl[1];
+            e0 = tile * a.list_stride; e1 = e0 + n_o;
+            if (tid == 0) {
+                if (a.gather_blend) a.tile_mid[tile] = e0 + a.list_stride - n_t;
+                if (n_o | n_t) atomicAdd(&a.ctrl->n_pairs, n_o + n_t);
+            }
         } else if (P64) {                        // lists in any order, keyed by tile only; [e0, mid) is the opaque pass
             e0 = a.ranges[tile]; e1 = a.gather_blend ? a.tile_mid[tile] : a.ranges[tile + 1];
         } else if (TEXMODE == 0 && a.local_sort) {      // lists arrive in face order, keyed by tile only: painter's order per tile, in LDS
@@ -1042,6 +1075,10 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a_in) {
             for (uint32_t i = tid; i < (P64 ? (EXACT ? 2 : 4) : (EXACT ? 1 : 2)) * TILE_H * TILE_STRIDE; i += NT) tilebuf[i] = 0;
         }
         __syncthreads();
+        if (P64 && a.direct_bin && tid == 0) {   // (everyone has read them) zero again for the next frame's k_setup
+            uint32_t* fl = a.tile_fill + (size_t)tile * FILL_PAD;
+            fl[0] = 0; fl[1] = 0;
+        }
         if (P64 && a.inline_bin) {
             e1 = e0 + misc[4];
             const uint32_t n_tr = misc[5];
@@ -1463,7 +1500,7 @@ __global__ __launch_bounds__(NT, 4) void k_blend(FillArgs a) {        // 4 waves
     // (8-bit path with blending texels / editor alpha: one list, same ordered walk, render.rs:2193-2202)
     const bool xray = fp.xray != 0;
     const uint32_t e1 = a.tile_keys_only ? a.tile_mid[tile] : a.ranges[2 * tile + (a.ordered_all ? 0 : 1)];
-    const uint32_t e2 = a.inline_bin ? (tile + 1) * a.list_stride : (a.tile_keys_only ? a.ranges[tile + 1] : a.ranges[2 * tile + 2]);
+    const uint32_t e2 = (a.inline_bin || a.direct_bin) ? (tile + 1) * a.list_stride : (a.tile_keys_only ? a.ranges[tile + 1] : a.ranges[2 * tile + 2]);
     if (e1 == e2) return;
     if (GATHER) {
         // sort-free binning left the transparent entries [e1, e2) in arbitrary order: put them in painter's order (descending depth,

@@ -187,7 +187,7 @@ __device__ __forceinline__ uint32_t fog_color(uint32_t c, uint32_t fogc, float f
 template <int SETUP_FPT, bool PLAIN>
 __global__ __launch_bounds__(256) void k_setup(FrameParams fp_in, const B32Vertex* __restrict__ verts, const B32Face* __restrict__ faces,
                                                const TexDesc* __restrict__ tex, const B32Light* __restrict__ lights_mem, LightSet lset,
-                                               RecArrays recs, float* __restrict__ shades, uint32_t* __restrict__ keys,
+                                               RecArrays recs, DirectBin db, float* __restrict__ shades, uint32_t* __restrict__ keys,
                                                uint32_t* __restrict__ spans, uint32_t* __restrict__ partials, Ctrl* __restrict__ ctrl,
                                                WireTri* __restrict__ wire) {
     FrameParams fp_plain = fp_in;                 // (dead code unless PLAIN)
@@ -244,6 +244,7 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp_in, const B32Verte
     const FaceIn& in = fin[g];
     bool visible = false, transparent = false, nan_key = false, bad_index = false;
     uint32_t key = KEY_INVALID, span = 0xFFFFFFFFu, n_tiles = 0;
+    uint32_t db_pos = 0; bool db_cls = false;
     if (in.live) {
         uint32_t vi[3] = { in.w[0], in.w[1], in.w[2] };
         const uint32_t tid = in.w[3], fb4 = in.w[4];
@@ -321,6 +322,15 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp_in, const B32Verte
                 if (empty) { min_x = max_x = min_y = max_y = 0; }
                 r.bbx = min_x | (max_x << 16); r.bby = min_y | (max_y << 16);
                 span = pack_tile_span(r.bbx, r.bby, empty ? F_EMPTY : 0u, fp, n_tiles);
+                if (db.fill && n_tiles) {     // direct binning: the list slot in the first tile is requested now, used after the record build
+                    db_cls = db.with_class && transparent;
+                    const uint32_t t0 = ((span >> 16) & 0xFF) * fp.tiles_x + (span & 0xFF);
+#ifdef B32_EXP_WGATOMIC
+                    db_pos = __hip_atomic_fetch_add(db.fill + (size_t)t0 * FILL_PAD + (db_cls ? 1u : 0u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+                    db_pos = atomicAdd(db.fill + (size_t)t0 * FILL_PAD + (db_cls ? 1u : 0u), 1u);
+#endif
+                }
                 // multi-GPU band sharding: every rank decides visibility for every face (triangles_drawn, painter's keys), but only the
                 // surfaces reaching its own rows are ever read again: the triangle prologue, the exactness guard, the lighting and the
                 // record build are skipped for all the others
@@ -433,6 +443,24 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp_in, const B32Verte
                         xp[1] = make_uint4(__float_as_uint(r.w1_start), 0u, 0u, 0u);
                     }
                 }
+                if (db.fill && n_tiles) {     // the face id into the list of every tile of the span (any order inside a list)
+                    const uint32_t cap = db_cls ? db.cap_transparent : db.cap_opaque;
+                    const uint32_t tx0 = span & 0xFF, tx1 = (span >> 8) & 0xFF, ty0 = (span >> 16) & 0xFF, ty1 = span >> 24;
+                    bool over = false;
+                    for (uint32_t ty = ty0; ty <= ty1; ++ty)
+                        for (uint32_t tx = tx0; tx <= tx1; ++tx) {
+                            const uint32_t tile = ty * fp.tiles_x + tx;
+                            uint32_t pos = db_pos;
+#ifdef B32_EXP_WGATOMIC
+                            if (ty != ty0 || tx != tx0) pos = __hip_atomic_fetch_add(db.fill + (size_t)tile * FILL_PAD + (db_cls ? 1u : 0u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+                            if (ty != ty0 || tx != tx0) pos = atomicAdd(db.fill + (size_t)tile * FILL_PAD + (db_cls ? 1u : 0u), 1u);
+#endif
+                            if (pos < cap) db.lists[(size_t)tile * db.region + (db_cls ? db.region - 1u - pos : pos)] = f;
+                            else over = true;
+                        }
+                    if (over) { Events* ev = events_of(ctrl); if (db_cls) ev->long_transparent = db.epoch; else ev->overflow = db.epoch; }
+                }
             }
         }
         keys[f] = key;
@@ -446,6 +474,12 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp_in, const B32Verte
     if ((threadIdx.x & 63) == 0) {
         wpart[wv][0] = (uint32_t)__popcll(mv); wpart[wv][1] = (uint32_t)__popcll(mt);
         wpart[wv][2] = (uint32_t)__popcll(mn_op); wpart[wv][3] = (uint32_t)__popcll(mn_tr); wpart[wv][4] = mb ? 1u : 0u;
+        if (db.fill && (mn_op | mn_tr | mb)) {   // direct binning: nobody reduces the counters before the fill, which only does so after one of these
+            Events* ev = events_of(ctrl);
+            if (mb) ev->bad_index = db.epoch;
+            if (mn_op) ev->nan_opaque = db.epoch;
+            if (mn_tr) ev->nan_transparent = db.epoch;
+        }
     }
     for (int off = 32; off > 0; off >>= 1) n_tiles += __shfl_down(n_tiles, off);      // (tile, surface) pairs of this block
     if ((threadIdx.x & 63) == 0) wpart[wv][5] = n_tiles;
@@ -458,7 +492,7 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp_in, const B32Verte
 }
 
 void launch_setup(hipStream_t s, const FrameParams& fp, const B32Vertex* verts, const B32Face* faces, const TexDesc* tex,
-                  const B32Light* lights, const LightSet& ls, RecArrays recs, float* shades, uint32_t* keys, uint32_t* spans, uint32_t* partials,
+                  const B32Light* lights, const LightSet& ls, RecArrays recs, const DirectBin& db, float* shades, uint32_t* keys, uint32_t* spans, uint32_t* partials,
                   Ctrl* ctrl, WireTri* wire, int n_cu) {
     (void)n_cu;
     if (fp.nf == 0) return;
@@ -466,8 +500,8 @@ void launch_setup(hipStream_t s, const FrameParams& fp, const B32Vertex* verts, 
     // one face per thread: 52 VGPRs in the plain form = 8 waves per SIMD (two faces per thread with their loads issued up front: 73 VGPRs,
     // 43 us instead of 39 at 1 M faces; three: 49 us)
     const dim3 g1((fp.nf + 255) / 256);
-    if (plain) hipLaunchKernelGGL((k_setup<1, true>), g1, dim3(256), 0, s, fp, verts, faces, tex, lights, ls, recs, shades, keys, spans, partials, ctrl, wire);
-    else hipLaunchKernelGGL((k_setup<1, false>), g1, dim3(256), 0, s, fp, verts, faces, tex, lights, ls, recs, shades, keys, spans, partials, ctrl, wire);
+    if (plain) hipLaunchKernelGGL((k_setup<1, true>), g1, dim3(256), 0, s, fp, verts, faces, tex, lights, ls, recs, db, shades, keys, spans, partials, ctrl, wire);
+    else hipLaunchKernelGGL((k_setup<1, false>), g1, dim3(256), 0, s, fp, verts, faces, tex, lights, ls, recs, db, shades, keys, spans, partials, ctrl, wire);
 }
 
 // ---------------------------------------------------------------- stage tap: project_fixed for n positions

@@ -68,6 +68,12 @@ class Context:
         """b32_set_async_depth: 0 = safe (default), 1 = large-scene frames back to back, a dropped one is reported by finish()."""
         _chk(self.lib.b32_set_async_depth(self.h, int(deep)), "b32_set_async_depth")
 
+    ROUTES = ("direct_bin", "inline_bin", "counting_sort", "keyed", "redraw_region", "redraw_global_sort", "redraw_pairs")
+
+    def route_counts(self):
+        """b32_route_count: how many frames of this context took each internal route (tests assert the targeted one ran)."""
+        return {n: int(self.lib.b32_route_count(self.h, i)) for i, n in enumerate(self.ROUTES)}
+
     def set_fragment_counting(self, on):
         _chk(self.lib.b32_set_fragment_counting(self.h, int(on)), "b32_set_fragment_counting")
 

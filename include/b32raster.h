@@ -216,7 +216,9 @@ int b32_render_scene_15_async(b32_ctx* ctx,
                               const B32Fog* fog /* nullable */);
 int b32_frame_finish(b32_ctx* ctx, B32Timings* out /* nullable */);
 /* How many frames of a LARGE scene (more than 8192 faces, or more than 2048 with a transparent pass) may be in flight.  Such a
- * frame can run out of pair-buffer space (or need the global depth sort); it then draws nothing and must be redrawn by the host.
+ * frame can run out of tile-list space (the setup kernel bins it into fixed tile regions sized from the mesh; a region overflows when
+ * far more of the mesh lands in one screen tile than the mean) or need the global depth sort; it then draws nothing and must be
+ * redrawn by the host.
  *   deep = 0 (default): safe.  Enqueueing another frame, or any call that reads or rebinds the framebuffer (b32_fb_download,
  *            b32_zbuffer_download, b32_fb_upload, b32_fb_bind_device, b32_set_stream, b32_present_nearest), first settles the pending
  *            frame (one host synchronisation, redraw if needed): no frame is ever lost.
@@ -226,6 +228,12 @@ int b32_frame_finish(b32_ctx* ctx, B32Timings* out /* nullable */);
  *            framebuffer between two frames (an RCCL gather on the same stream) must accept that contract.
  * Frames of small meshes never overflow and are always enqueued without synchronisation. */
 int b32_set_async_depth(b32_ctx* ctx, int deep);
+/* Which internal route the frames of this context took since it was created (tests assert that the route they target really ran;
+ * no reference counterpart).  which: 0 frames binned by the setup kernel into fixed tile regions (large meshes), 1 frames whose tile
+ * lists were collected inside the fill kernel (small meshes), 2 frames binned by the counting-sort launches, 3 frames through the
+ * keyed pipeline (global depth sort), 4 frames redrawn because a tile region overflowed, 5 frames redrawn through the global depth
+ * sort, 6 frames redrawn after a pair-buffer overflow.  Unknown `which` or null ctx: 0. */
+unsigned long long b32_route_count(const b32_ctx* ctx, int which);
 
 /* Several resident scenes per context (scene.rs:112-261 draws room after room, asset part after asset part, onto one
  * framebuffer every frame): a slot owns one uploaded scene's device buffers.  b32_scene_swap exchanges the context's current

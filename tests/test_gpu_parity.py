@@ -340,27 +340,28 @@ def test_full_size_c3_properties(gpu_ctx, oracle):
 
 
 def test_async_frames_are_never_silently_dropped(oracle):
-    """A large scene's frame can run out of pair-buffer space and then draws nothing until the host redraws it.  With frames enqueued
-    back to back and a camera that moves (far: tiny triangles -> few pairs; near: ~9 tiles per face -> overflow of the initial
-    buffers) the middle frame of  far, near, far  (no clear in between: read-modify-write) must not get lost:
+    """A large scene's frame can run out of tile-list space (direct binning: fixed tile regions sized from the mesh) and then draws
+    nothing until the host redraws it.  With frames enqueued back to back and a camera that moves (near: 58 000 surfaces spread over
+    300 tiles; far: 11 600 surfaces inside eight tiles -> their regions overflow at the initial size) the middle frame of
+    near, far, near  (no clear in between: read-modify-write) must not get lost:
       safe mode (default): enqueueing the next frame settles the pending one -> the result equals the oracle's three draws;
       deep mode (b32_set_async_depth(1)): no synchronisation between frames; the lost frame is REPORTED by b32_frame_finish
       (B32_E_FRAME_DROPPED), the most recent frame is intact, and after that report the context works normally again."""
     from bonnie32_amd import rasterizer as R
-    sc = scenegen.make_scene("C3", n_tris=20_000, width=640, height=480, bbox_px=3000.0, seed=321)
-    far = b32.Camera(position=(0.0, 0.0, -30000.0)); near = sc.camera
+    sc = scenegen.make_scene("C3", n_tris=120_000, width=640, height=480, bbox_px=60.0, seed=321)
+    far = b32.Camera(position=(0.0, 0.0, -45000.0)); near = sc.camera
     ofb = oracle.Framebuffer(sc.width, sc.height); ofb.clear(sc.clear_color)
-    for cam in (far, near, far):
+    for cam in (near, far, near):
         assert oracle.render_mesh_15(ofb, sc.vertices, sc.faces, sc.textures, cam, sc.settings)[0] == 0
-    only_far = oracle.Framebuffer(sc.width, sc.height); only_far.clear(sc.clear_color)
-    for cam in (far, far):
-        oracle.render_mesh_15(only_far, sc.vertices, sc.faces, sc.textures, cam, sc.settings)
-    assert not np.array_equal(only_far.pixels, ofb.pixels)
-    # ---- safe mode, fresh context (pair buffers at their initial size)
+    only_near = oracle.Framebuffer(sc.width, sc.height); only_near.clear(sc.clear_color)
+    for cam in (near, near):
+        oracle.render_mesh_15(only_near, sc.vertices, sc.faces, sc.textures, cam, sc.settings)
+    assert not np.array_equal(only_near.pixels, ofb.pixels)
+    # ---- safe mode, fresh context (tile regions at their initial size)
     ctx = R.Context(0)
     fb = R.Framebuffer(sc.width, sc.height, ctx); fb.clear(sc.clear_color)
     rs = R.ResidentScene(fb, sc.vertices, sc.faces, sc.textures)
-    for cam in (far, near, far):
+    for cam in (near, far, near):
         rs.render_async(cam, sc.settings)
     got = fb.pixels                                   # (the download settles the last frame too)
     assert np.array_equal(got, ofb.pixels), f"{int((got != ofb.pixels).sum())} bytes differ"
@@ -369,9 +370,9 @@ def test_async_frames_are_never_silently_dropped(oracle):
     ctx2 = R.Context(0)
     fb2 = R.Framebuffer(sc.width, sc.height, ctx2); fb2.clear(sc.clear_color)
     rs2 = R.ResidentScene(fb2, sc.vertices, sc.faces, sc.textures)
-    rs2.render_async(near, sc.settings)
+    rs2.render_async(far, sc.settings)
     o2 = oracle.Framebuffer(sc.width, sc.height); o2.clear(sc.clear_color)
-    oracle.render_mesh_15(o2, sc.vertices, sc.faces, sc.textures, near, sc.settings)
+    oracle.render_mesh_15(o2, sc.vertices, sc.faces, sc.textures, far, sc.settings)
     assert np.array_equal(fb2.pixels, o2.pixels)
     rs2.finish()
     # ---- deep mode, fresh context
@@ -379,15 +380,15 @@ def test_async_frames_are_never_silently_dropped(oracle):
     ctx3.set_async_depth(1)
     fb3 = R.Framebuffer(sc.width, sc.height, ctx3); fb3.clear(sc.clear_color)
     rs3 = R.ResidentScene(fb3, sc.vertices, sc.faces, sc.textures)
-    for cam in (far, near, far):
+    for cam in (near, far, near):
         rs3.render_async(cam, sc.settings)
     with pytest.raises(R.B32Error) as e:
         rs3.finish()
     assert e.value.code == b32.abi.B32_E_FRAME_DROPPED
-    assert np.array_equal(fb3.pixels, only_far.pixels)            # the lost frame drew nothing, the others are intact
+    assert np.array_equal(fb3.pixels, only_near.pixels)           # the lost frame drew nothing, the others are intact
     fb3.clear(sc.clear_color)
-    rs3.render_async(near, sc.settings)
-    rs3.finish()                                                    # the most recent frame IS redrawn (buffers grown), no error left over
+    rs3.render_async(far, sc.settings)
+    rs3.finish()                                                    # the most recent frame IS redrawn (regions grown), no error left over
     assert np.array_equal(fb3.pixels, o2.pixels)
 
 
@@ -445,7 +446,7 @@ def test_texture_cache_is_semantically_per_call(gpu_ctx, oracle):
 def test_raster_timings_are_filled_on_every_synchronous_call(gpu_ctx):
     """RasterTimings (types.rs:1499-1514): the reference fills every phase on every call (render.rs:2362, 2515-2516, 2544, 2572).  Here the
     phases come from the device-side phase clock with no profiling switched on: cull (the fused transform + cull + setup kernel), sort
-    (the tile binning), draw (the fill kernels), wireframe (the line kernels); their sum cannot exceed the wall time of the call."""
+    (the tile binning when it is a launch of its own; large meshes are binned by the setup kernel), draw (the fill kernels), wireframe (the line kernels); their sum cannot exceed the wall time of the call."""
     import time
     from bonnie32_amd import rasterizer as R
     gpu_ctx.set_profiling(0)
@@ -459,7 +460,8 @@ def test_raster_timings_are_filled_on_every_synchronous_call(gpu_ctx):
         assert (tm.wireframe_ms > 0) == wire, tm
         assert tm.sort_ms >= 0 and tm.cull_ms + tm.sort_ms + tm.draw_ms + tm.wireframe_ms <= wall, (tm, wall)
         if len(sc.faces) > 100_000:
-            assert tm.sort_ms > 0 and tm.cull_ms > 0.005 and tm.draw_ms > 0.01, tm               # a 200 k-triangle frame: tens of microseconds each
+            # a 200 k-triangle frame: tens of microseconds each (sort_ms is 0 when k_setup binned the faces itself: no binning launch)
+            assert tm.cull_ms > 0.005 and tm.draw_ms > 0.01, tm
     tm = R.render_mesh_15(fb, b32.make_vertices(0), b32.make_faces(0), [], sc.camera, sc.settings)   # empty mesh: no kernel ran
     assert tm.triangles_drawn == 0 and tm.cull_ms == 0
 
@@ -800,6 +802,28 @@ def test_fast_path_transparent_lists(fast_ctx, oracle):
     got, tm = gpu_render(fast_ctx, big, resident=True)
     assert np.array_equal(got, exp), f"{int((got != exp).sum())} bytes differ"
     assert tm.triangles_drawn == etm.triangles_drawn > 2 * 2048 * 2
+
+
+def test_direct_binning_region_overflow_and_regrowth(fast_ctx, oracle):
+    """Meshes above the in-kernel list collection are binned by k_setup itself into fixed tile regions sized from the mesh (three times
+    the mean list, at least 512 entries).  Two thirds of this mesh sit in the four centre tiles of a 300-tile frame, so the first attempt
+    overflows a region: nothing may be drawn by it, the frame is redrawn with regions sized from the longest list it reported, and the
+    following frames (same context, the other variant with a transparent pass) run with the grown regions."""
+    from bonnie32_amd import rasterizer as R
+    for variant in ("bench", "blend"):
+        sc = scenegen.make_scene("C1", n_tris=30_000, width=1280, height=960, bbox_px=300.0, seed=515, variant=variant)
+        sc.vertices["pos"][: 60_000, :2] *= np.float32(0.15)        # (three vertices per face: the first 20 000 faces)
+        exp, etm, d = cpu_render(oracle, sc)
+        for rep in range(2):
+            before = fast_ctx.route_counts()
+            got, tm = gpu_render(fast_ctx, sc, resident=True)
+            after = fast_ctx.route_counts()
+            assert np.array_equal(got, exp), f"{int((got != exp).sum())} bytes differ ({variant}, attempt {rep})"
+            assert tm.triangles_drawn == etm.triangles_drawn and tm.tile_pairs >= tm.triangles_drawn > 10_000
+            redrawn = after["redraw_region"] - before["redraw_region"]
+            assert after["direct_bin"] - before["direct_bin"] == 1 + redrawn and after["counting_sort"] == before["counting_sort"]
+            if variant == "bench":
+                assert redrawn == (1 if rep == 0 else 0)            # the first frame on this context overflows, the regions stay grown
 
 
 @pytest.mark.parametrize("counting", [0, 1])
