@@ -477,6 +477,15 @@ __device__ __forceinline__ uint32_t dpp_max_scan(uint32_t v) {          // inclu
     v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));
     return v;
 }
+__device__ __forceinline__ uint32_t dpp_add_scan(uint32_t v) {          // inclusive prefix sum over the 64 lanes
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return v;
+}
 __device__ __forceinline__ uint32_t bperm(uint32_t src_lane, uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v); }
 __device__ __forceinline__ float bpermf(uint32_t src_lane, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), __float_as_int(v))); }
 
@@ -559,11 +568,12 @@ __device__ __forceinline__ uint32_t row_trim(float w0, float w1, float a0, float
     const float G[3] = { s * a0, s * a1, -(s * a0 + s * a1) };
     float flo = 0.0f, fhi = (float)n;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
+    for (int j = 0; j < 3; ++j) {       // (selects, not branches: every lane of the wave walks a different surface)
         const float r = -E[j] * __builtin_amdgcn_rcpf(G[j]);
-        if (G[j] > 0.0f) flo = fmaxf(flo, ceilf(r - 0.01f));            // E + G x >= 0  <=>  x >= r
-        else if (G[j] < 0.0f) fhi = fminf(fhi, floorf(r + 0.01f) + 1.0f);   // x <= r
-        else if (E[j] < 0.0f) fhi = 0.0f;                                // constant along the row and failing
+        const float lo_c = fmaxf(flo, ceilf(r - 0.01f));                    // E + G x >= 0  <=>  x >= r   (G > 0)
+        const float hi_c = fminf(fhi, floorf(r + 0.01f) + 1.0f);            //                    x <= r   (G < 0)
+        flo = G[j] > 0.0f ? lo_c : flo;
+        fhi = G[j] < 0.0f ? hi_c : (((G[j] == 0.0f) & (E[j] < 0.0f)) ? 0.0f : fhi);   // G == 0: constant along the row; failing -> empty
     }
     flo = fminf(flo, (float)n);
     fhi = fmaxf(fhi, flo);
@@ -572,9 +582,52 @@ __device__ __forceinline__ uint32_t row_trim(float w0, float w1, float a0, float
     return lo;
 }
 
+// One trip of the sort-free CHEAP coverage: TRIP consecutive pixels of a row starting at LDS entry `addr` with edge values (w0, w1),
+// `left` of them inside the clipped row.  The value is the surface's global painter's priority P (z-buffer mode: the fragment's
+// depth in the high word), so no tile list order is needed; TRIP returning LDS atomics are in flight together and the wave waits
+// once (w advances by the reference's own sequential accumulation w += a, render.rs:1706-1707).
+template <bool ZMODE>
+__device__ __forceinline__ void cheap_trip(unsigned long long* top, unsigned long long* sec, uint32_t& addr, float& w0, float& w1, float sa0, float sa1,
+                                           float sinv, uint32_t left, unsigned long long P, float z1, float z2, float z3) {
+    constexpr int TRIP = B32_TRIP;
+    const float ERR = K::ERR;
+    float wa[TRIP], wb[TRIP];
+    wa[0] = w0; wb[0] = w1;
+#pragma unroll
+    for (int j = 1; j < TRIP; ++j) { wa[j] = wa[j - 1] + sa0; wb[j] = wb[j - 1] + sa1; }
+    bool in[TRIP];
+    unsigned long long old[TRIP], Pj[TRIP];
+#pragma unroll
+    for (int j = 0; j < TRIP; ++j) {
+        const float cx = wa[j] * sinv, cy = wb[j] * sinv;
+        const float cz = 1.0f - cx - cy;
+        // all three >= ERR  <=>  their minimum is (no NaN can occur here: w integers, inv_area finite and non-zero)
+        in[j] = ((uint32_t)j < left) & (__builtin_fminf(__builtin_fminf(cx, cy), cz) >= ERR);
+        old[j] = 0; Pj[j] = P;
+        if (ZMODE) {                            // fragment depth (render.rs:1546-1550); NaN never passes `z < zbuffer`
+            const float inv_z = cx * z1 + cy * z2 + cz * z3;
+            const float z = 1.0f / inv_z;
+            in[j] = in[j] & (z == z);
+            Pj[j] = ((unsigned long long)(~zsort_key(z)) << 32) | (uint32_t)P;
+        }
+    }
+    // one predicated block for the whole trip (a branch per atomic makes the compiler wait for each returning atomic before it
+    // issues the next): pixels outside the triangle contribute priority 0, a no-op for both maxima (min(old, 0) == 0)
+    bool any_in = false;
+#pragma unroll
+    for (int j = 0; j < TRIP; ++j) any_in |= in[j];
+    if (any_in) {
+#pragma unroll
+        for (int j = 0; j < TRIP; ++j) { if (!in[j]) Pj[j] = 0ull; old[j] = atomicMax(&top[addr + j], Pj[j]); }
+#pragma unroll
+        for (int j = 0; j < TRIP; ++j) atomicMax(&sec[addr + j], min(old[j], Pj[j]));
+    }
+    addr += TRIP; w0 = wa[TRIP - 1] + sa0; w1 = wb[TRIP - 1] + sa1;
+}
+
 template <int TEXMODE, bool EXACT, int NW, bool ZMODE, bool FMT8, bool P64 = false>
 __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, uint32_t e0, uint32_t n_op, uint32_t lane, uint32_t wave,
-                                                           volatile uint32_t* cursor, volatile uint32_t* wmark, const TexDesc& lds_desc,
+                                                           uint32_t* cursor, uint32_t* wmark, const TexDesc& lds_desc,
                                                            uint32_t* tilebuf, uint32_t x_lo, uint32_t x_hi, uint32_t y_lo, uint32_t y_hi,
                                                            uint32_t ty_top, const uint16_t* ltex) {
     const uint16_t* __restrict__ gtex = FMT8 ? reinterpret_cast<const uint16_t*>(a.texels32) : a.texels;
@@ -585,7 +638,7 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
     const uint32_t grab = min(64u, max(4u, (n_op + B32_GRAB_DIV * NW - 1) / (B32_GRAB_DIV * NW)));
     for (;;) {
         uint32_t cs = 0;
-        if (lane == 0) cs = atomicAdd(const_cast<uint32_t*>(cursor), grab);
+        if (lane == 0) cs = atomicAdd(cursor, grab);
         cs = (uint32_t)__builtin_amdgcn_readfirstlane((int)cs);
         if (cs >= n_op) break;
         const uint32_t e = cs + lane;
@@ -604,8 +657,7 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
         const bool slow = live && (flags & F_SLOW);
         const uint32_t h = (live && !slow) ? cy1 - cy0 : 0u;
         // exclusive prefix sum of the row counts
-        uint32_t inc = h;
-        for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(inc, off); if (lane >= (uint32_t)off) inc += t; }
+        const uint32_t inc = dpp_add_scan(h);
         const uint32_t R = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
         const uint32_t P = inc - h;
         const float a0 = __uint_as_float(b.q0.z), b0 = __uint_as_float(b.q0.w), a1 = __uint_as_float(b.q1.x), b1 = __uint_as_float(b.q1.y);
@@ -614,14 +666,12 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
             // owner of item k0+lane: last surface s with h>0 and P[s] <= k
             const unsigned long long before = __ballot(h > 0 && P <= k0);
             const uint32_t carry = before ? 64u - (uint32_t)__builtin_clzll(before) : 0u;       // (index of that surface) + 1
-            // cross-lane exchange through LDS inside one wave: volatile accesses + wave barriers keep the three steps
-            // ordered (the hardware executes a wave's LDS operations in order)
-            wmark[lane] = 0;
-            __builtin_amdgcn_wave_barrier();
-            if (h > 0 && P > k0 && P < k0 + 64) wmark[P - k0] = lane + 1;
-            __builtin_amdgcn_wave_barrier();
-            const uint32_t own = max(dpp_max_scan(wmark[lane]), carry);                          // >= 1 whenever the item exists
-            __builtin_amdgcn_wave_barrier();
+            // every surface that starts inside this round drops (its lane + 1) at the lane of its first item: a forward permute
+            // (ds_permute_b32: no memory involved; the starts are distinct and > k0, so lane 0 is never a target and takes the zeros
+            // of all the other lanes; lanes nobody writes read 0)
+            const bool starts = h > 0 && P > k0 && P < k0 + 64;
+            const uint32_t mark = (uint32_t)__builtin_amdgcn_ds_permute((int)((starts ? P - k0 : 0u) << 2), (int)(starts ? lane + 1 : 0u));
+            const uint32_t own = max(dpp_max_scan(mark), carry);                                 // >= 1 whenever the item exists
             const uint32_t k = k0 + lane;
             const bool valid = k < R;
             const uint32_t s = valid ? own - 1 : lane;
@@ -726,42 +776,8 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
                 unsigned long long* sec = top + TILE_H * STR64;
                 float z1 = 0.0f, z2 = 0.0f, z3 = 0.0f;
                 if (ZMODE) { z1 = bpermf(s, __uint_as_float(b.q5.y)); z2 = bpermf(s, __uint_as_float(b.q5.z)); z3 = bpermf(s, __uint_as_float(b.q5.w)); }
-                constexpr int TRIP = B32_TRIP;
-                for (uint32_t i = 0; __ballot(i < n); i += TRIP) {
-                    float wa[TRIP], wb[TRIP];
-                    wa[0] = w0; wb[0] = w1;
-#pragma unroll
-                    for (int j = 1; j < TRIP; ++j) { wa[j] = wa[j - 1] + sa0; wb[j] = wb[j - 1] + sa1; }
-                    bool in[TRIP];
-                    unsigned long long old[TRIP], Pj[TRIP];
-#pragma unroll
-                    for (int j = 0; j < TRIP; ++j) {
-                        const float cx = wa[j] * sinv, cy = wb[j] * sinv;
-                        const float cz = 1.0f - cx - cy;
-                        // all three >= ERR  <=>  their minimum is (no NaN can occur here: w integers, inv_area finite and non-zero)
-                        in[j] = (i + j < n) & (__builtin_fminf(__builtin_fminf(cx, cy), cz) >= ERR);
-                        old[j] = 0; Pj[j] = P;
-                        if (ZMODE) {                            // fragment depth (render.rs:1546-1550); NaN never passes `z < zbuffer`
-                            const float inv_z = cx * z1 + cy * z2 + cz * z3;
-                            const float z = 1.0f / inv_z;
-                            in[j] = in[j] & (z == z);
-                            Pj[j] = ((unsigned long long)(~zsort_key(z)) << 32) | (uint32_t)P;
-                        }
-                    }
-                    // one predicated block for the whole trip (a branch per atomic makes the compiler wait for each returning
-                    // atomic before it issues the next): pixels outside the triangle contribute priority 0, a no-op for both
-                    // maxima (min(old, 0) == 0)
-                    bool any_in = false;
-#pragma unroll
-                    for (int j = 0; j < TRIP; ++j) any_in |= in[j];
-                    if (any_in) {
-#pragma unroll
-                        for (int j = 0; j < TRIP; ++j) { if (!in[j]) Pj[j] = 0ull; old[j] = atomicMax(&top[addr + j], Pj[j]); }
-#pragma unroll
-                        for (int j = 0; j < TRIP; ++j) atomicMax(&sec[addr + j], min(old[j], Pj[j]));
-                    }
-                    addr += TRIP; w0 = wa[TRIP - 1] + sa0; w1 = wb[TRIP - 1] + sa1;
-                }
+                for (uint32_t i = 0; __ballot(i < n); i += B32_TRIP)
+                    cheap_trip<ZMODE>(top, sec, addr, w0, w1, sa0, sa1, sinv, i < n ? n - i : 0u, P, z1, z2, z3);
             } else {
                 // CHEAP coverage: two pixels per trip, so the two returning LDS atomics are in flight together and the wave
                 // waits once per pair (the second value is the same sequential accumulation w + a the reference performs)
@@ -798,7 +814,7 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
             frags += cover_one<TEXMODE, EXACT, ZMODE, FMT8>(b, t, cs + (uint32_t)t + 1, tilebuf, x_lo, x_hi, y_lo, y_hi, ty_top, lane, gtex, ltex, affine);
         }
     }
-    (void)wave;
+    (void)wave; (void)wmark;        // (the row starts travel by ds_permute now: the per-wave mark area in LDS is unused)
     return frags;
 }
 
@@ -809,8 +825,8 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
 // reference's `sort_by` (render.rs:2527-2541) applied per tile: lists arrive in face order and every pass is stable, so equal
 // keys keep face order exactly like the global sort.  The four LDS arrays alias the (not yet used) tile buffers.
 template <int NT>
-__device__ void tile_local_sort(uint32_t* sort_area, uint32_t* wcnt, volatile uint32_t* dws, const uint32_t* __restrict__ keys,
-                                uint32_t* list, uint32_t n, volatile uint32_t* n_opaque_out) {
+__device__ void tile_local_sort(uint32_t* sort_area, uint32_t* wcnt, uint32_t* dws, const uint32_t* __restrict__ keys,
+                                uint32_t* list, uint32_t n, uint32_t* n_opaque_out) {
     constexpr int NW = NT / 64;
     constexpr int STEPS = LOCAL_SORT_CAP / (NW * 64);
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -818,7 +834,7 @@ __device__ void tile_local_sort(uint32_t* sort_area, uint32_t* wcnt, volatile ui
     uint32_t my_opaque = 0;
     for (uint32_t i = tid; i < n; i += NT) { const uint32_t sid = list[i]; const uint32_t k = keys[sid]; ki[i] = k; vi[i] = sid; my_opaque += (k >> 31) ^ 1u; }
     for (int off = 32; off > 0; off >>= 1) my_opaque += __shfl_down(my_opaque, off);
-    if (lane == 0 && my_opaque) atomicAdd(const_cast<uint32_t*>(n_opaque_out), my_opaque);       // class boundary of the sorted list
+    if (lane == 0 && my_opaque) atomicAdd(n_opaque_out, my_opaque);       // class boundary of the sorted list
     __syncthreads();
     const uint32_t per_wave = ((n + NW * 64 - 1) / (NW * 64)) * 64;      // contiguous run per wave: order = (wave, step, lane)
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -900,7 +916,9 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a_in) {
     constexpr int TB = (P64 ? 4 : 2) * LDS_TILE_BYTES;          // tile buffers: top + runner-up, 32- or 64-bit entries
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* tilebuf = reinterpret_cast<uint32_t*>(smem);
-    volatile uint32_t* misc = reinterpret_cast<volatile uint32_t*>(smem + TB);   // [0] tile, [2] list cursor
+    // (plain LDS pointers: every cross-wave value below is read after a __syncthreads() that follows its write; `volatile` would turn
+    // these into FLAT accesses with a full vmcnt wait each)
+    uint32_t* misc = reinterpret_cast<uint32_t*>(smem + TB);   // [0] tile, [2] list cursor
     uint32_t* wmarks = reinterpret_cast<uint32_t*>(smem + TB + LDS_MISC_BYTES);
     const uint16_t* ltex = reinterpret_cast<const uint16_t*>(smem + LDS_TEX_OFFSET);    // LDS texture (TEXMODE 1) or LDS skip mask (P64 EXACT)
     uint32_t* sort_cnt = reinterpret_cast<uint32_t*>(smem + LDS_TEX_OFFSET);        // local sort only exists without an LDS texture
@@ -929,7 +947,7 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a_in) {
         if (reduce) {
         const uint32_t npart = (fp.nf + 255) / 256;
         for (uint32_t b = tid; b < npart; b += NT)
-            for (int k = 0; k < 5; ++k) { const uint32_t v = a.partials[b * 8 + k]; if (v) atomicAdd(const_cast<uint32_t*>(&misc[8 + k]), v); }
+            for (int k = 0; k < 5; ++k) { const uint32_t v = a.partials[b * 8 + k]; if (v) atomicAdd((&misc[8 + k]), v); }
         __syncthreads();
         if (tid == 0) {
             const uint32_t t[5] = { misc[8], misc[9], misc[10], misc[11], misc[12] };
@@ -1042,8 +1060,8 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a_in) {
                 }
                 const unsigned long long mo = __ballot(hit && !tr), mt = __ballot(hit && tr);
                 uint32_t bo = 0, bt = 0;
-                if (lane == 0 && mo) bo = atomicAdd(const_cast<uint32_t*>(&misc[4]), (uint32_t)__builtin_popcountll(mo));
-                if (lane == 0 && mt) bt = atomicAdd(const_cast<uint32_t*>(&misc[5]), (uint32_t)__builtin_popcountll(mt));
+                if (lane == 0 && mo) bo = atomicAdd((&misc[4]), (uint32_t)__builtin_popcountll(mo));
+                if (lane == 0 && mt) bt = atomicAdd((&misc[5]), (uint32_t)__builtin_popcountll(mt));
                 bo = (uint32_t)__builtin_amdgcn_readfirstlane((int)bo); bt = (uint32_t)__builtin_amdgcn_readfirstlane((int)bt);
                 const unsigned long long below = (1ull << lane) - 1ull;
                 if (hit && !tr) a.pair_vals[e0 + bo + (uint32_t)__builtin_popcountll(mo & below)] = f;
@@ -1335,7 +1353,7 @@ __device__ __forceinline__ void shade_tile_p64(const FillArgs& a, const uint32_t
                         const uint4 cc1 = reinterpret_cast<const uint4*>(a.crecs + csid)[1];
                         const uint32_t bbx = cc1.x, bby = cc1.y;
                         if (fx >= (bbx & 0xFFFF) && fx < (bbx >> 16) && fy >= (bby & 0xFFFF) && fy < (bby >> 16)) {
-                            unsigned long long P = ((unsigned long long)a.keys[csid] << 32) | csid;
+                            unsigned long long P = ((unsigned long long)cc1.z << 32) | csid;
                             Hit c;
                             if (ZMODE) {
                                 if (hit_test<FMT8>(a, csid, fx, fy, c) && depth_prio(a, csid, c, P) && P < lim && P > sd) cand = P;
@@ -1484,7 +1502,6 @@ __global__ __launch_bounds__(NT, 4) void k_blend(FillArgs a) {        // 4 waves
     // dynamic LDS (blend_lds_bytes): [wf 256 B][row-scheduler marks 256 B per wave][frag][tile colours][tile depths, z-buffer mode only]
     extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
     unsigned long long* wf = reinterpret_cast<unsigned long long*>(bsm);
-    volatile uint32_t* wmark = reinterpret_cast<volatile uint32_t*>(bsm + 256) + (threadIdx.x >> 6) * 64;
     uint4* srec = reinterpret_cast<uint4*>(bsm + 256 + 16 * 256);           // the chunk's 64 surface records: 8 x 16 B each (q0..q5, texture, id)
     uint32_t* frag = reinterpret_cast<uint32_t*>(bsm + 256 + 16 * 256 + 64 * 128);
     static_assert(NW <= 16, "row-scheduler marks");
@@ -1588,8 +1605,7 @@ __global__ __launch_bounds__(NT, 4) void k_blend(FillArgs a) {        // 4 waves
         const uint32_t by0 = max(mq2.x & 0xFFFF, y_lo), by1 = min(mq2.x >> 16, y_hi);
         const bool live = lane < cnt && bx0 < bx1 && by0 < by1 && (my_flags >> F_ALPHA_SHIFT) != 0;
         const uint32_t area = live ? (bx1 - bx0) * (by1 - by0) : 0u;
-        uint32_t inc = area;
-        for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(inc, off); if (lane >= (uint32_t)off) inc += t; }
+        const uint32_t inc = dpp_add_scan(area);
         // entries of this chunk: the longest prefix whose fragments fit (every wave computes the same answer)
         const unsigned long long fits = __ballot(lane < cnt && inc <= FCAP);
         const uint32_t take = fits == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~fits);   // >= 1: a single clipped box has at most 4096 pixels
@@ -1601,20 +1617,16 @@ __global__ __launch_bounds__(NT, 4) void k_blend(FillArgs a) {        // 4 waves
         const bool in_chunk = live && lane < take;
         const bool slow = in_chunk && (my_flags & F_SLOW);
         const uint32_t h = (in_chunk && !slow) ? by1 - by0 : 0u;
-        uint32_t hinc = h;
-        for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(hinc, off); if (lane >= (uint32_t)off) hinc += t; }
+        const uint32_t hinc = dpp_add_scan(h);
         const uint32_t R = (uint32_t)__builtin_amdgcn_readlane((int)hinc, 63);
         const uint32_t P = hinc - h;
         const uint32_t box = (bx0 - x_lo) | ((bx1 - x_lo) << 8) | ((by0 - ty_top) << 16);
         for (uint32_t k0 = wave * 64; k0 < R; k0 += NW * 64) {
             const unsigned long long before = __ballot(h > 0 && P <= k0);
             const uint32_t carry = before ? 64u - (uint32_t)__builtin_clzll(before) : 0u;
-            wmark[lane] = 0;
-            __builtin_amdgcn_wave_barrier();
-            if (h > 0 && P > k0 && P < k0 + 64) wmark[P - k0] = lane + 1;
-            __builtin_amdgcn_wave_barrier();
-            const uint32_t own = max(dpp_max_scan(wmark[lane]), carry);
-            __builtin_amdgcn_wave_barrier();
+            const bool starts = h > 0 && P > k0 && P < k0 + 64;       // forward permute of the row starts (see phase_a_rows)
+            const uint32_t mark = (uint32_t)__builtin_amdgcn_ds_permute((int)((starts ? P - k0 : 0u) << 2), (int)(starts ? lane + 1 : 0u));
+            const uint32_t own = max(dpp_max_scan(mark), carry);
             const uint32_t k = k0 + lane;
             const bool valid = k < R;
             const uint32_t sl = valid ? own - 1 : lane;

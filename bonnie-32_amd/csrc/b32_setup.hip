@@ -325,11 +325,7 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp_in, const B32Verte
                 if (db.fill && n_tiles) {     // direct binning: the list slot in the first tile is requested now, used after the record build
                     db_cls = db.with_class && transparent;
                     const uint32_t t0 = ((span >> 16) & 0xFF) * fp.tiles_x + (span & 0xFF);
-#ifdef B32_EXP_WGATOMIC
-                    db_pos = __hip_atomic_fetch_add(db.fill + (size_t)t0 * FILL_PAD + (db_cls ? 1u : 0u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#else
                     db_pos = atomicAdd(db.fill + (size_t)t0 * FILL_PAD + (db_cls ? 1u : 0u), 1u);
-#endif
                 }
                 // multi-GPU band sharding: every rank decides visibility for every face (triangles_drawn, painter's keys), but only the
                 // surfaces reaching its own rows are ever read again: the triangle prologue, the exactness guard, the lighting and the
@@ -451,11 +447,7 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp_in, const B32Verte
                         for (uint32_t tx = tx0; tx <= tx1; ++tx) {
                             const uint32_t tile = ty * fp.tiles_x + tx;
                             uint32_t pos = db_pos;
-#ifdef B32_EXP_WGATOMIC
-                            if (ty != ty0 || tx != tx0) pos = __hip_atomic_fetch_add(db.fill + (size_t)tile * FILL_PAD + (db_cls ? 1u : 0u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#else
                             if (ty != ty0 || tx != tx0) pos = atomicAdd(db.fill + (size_t)tile * FILL_PAD + (db_cls ? 1u : 0u), 1u);
-#endif
                             if (pos < cap) db.lists[(size_t)tile * db.region + (db_cls ? db.region - 1u - pos : pos)] = f;
                             else over = true;
                         }
