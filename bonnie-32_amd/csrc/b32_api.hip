@@ -74,6 +74,8 @@ struct b32_ctx {
     // direct binning (DirectBin, b32_device.h): k_setup appends to fixed tile regions; the regions grow when a frame overflowed one
     uint32_t* direct_lists = nullptr; size_t cap_direct = 0;
     uint32_t* tile_fill = nullptr; size_t cap_tile_fill = 0;      // FILL_PAD words per tile, zero between frames
+    // packed positions for band-sharded frames (k_pack_positions): built on the second such frame of an uploaded mesh
+    float* d_pos12 = nullptr; size_t cap_pos12 = 0; bool pos_valid = false; uint32_t band_frames = 0;
     // (per scene, swapped with the scene slots:)
     uint32_t direct_cap_opaque = 0;                               // opaque entries per tile region (0: sized from the mesh on first use)
     uint32_t direct_ntiles = 0;                                   // the tile grid that size belongs to (another grid: sized again)
@@ -134,6 +136,7 @@ struct b32_scene {
     uint32_t nv = 0, nf = 0, nt = 0;
     bool fmt8 = false, blend8 = false, have_scene = false, may_blend = true, cheap_ok = false, local_sort_ok = true, tex_blend_any = false;
     uint32_t direct_cap_opaque = 0, direct_ntiles = 0; bool direct_ok = true;
+    float* d_pos12 = nullptr; size_t cap_pos12 = 0; bool pos_valid = false; uint32_t band_frames = 0;
     std::vector<b32_ctx::TexSig> tex_sig; bool tex_sig_valid = false, tex_sig_rgba = false;
 };
 
@@ -234,7 +237,7 @@ void b32_destroy(b32_ctx* c) {
     void* ptrs[] = { c->fb_own, c->d_verts, c->d_faces, c->d_texels, c->d_tex, c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->crecs, c->srecs, c->xrecs,
                      c->shades, c->counts, c->block_sums, c->pkeys[0], c->pkeys[1], c->pvals[0], c->pvals[1], c->block_hist, c->ranges,
                      c->d_ctrl, c->d_consts, c->d_lights, c->digit_total, c->partials, c->vis, c->spans, c->tile_mid, c->zbuf,
-                     c->wire, c->wire_owner, c->wire_first, c->d_texels32, c->inline_lists, c->d_texmask, c->direct_lists, c->tile_fill };
+                     c->wire, c->wire_owner, c->wire_first, c->d_texels32, c->inline_lists, c->d_texmask, c->direct_lists, c->tile_fill, c->d_pos12 };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->ev_created) for (auto& fr : c->ev) for (auto& e : fr) if (e) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -486,6 +489,7 @@ static int upload_geometry(b32_ctx* c, const B32Vertex* v, uint32_t nv, const B3
     if (c->nf != nf) { c->direct_cap_opaque = 0; c->direct_ntiles = 0; c->direct_ok = true; }
     c->nv = nv; c->nf = nf;
     c->local_sort_ok = true;
+    c->pos_valid = false; c->band_frames = 0;
     // per-face work buffers
     if ((size_t)nf + 1 > c->cap_work || !c->crecs) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -874,7 +878,22 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
         } else c->direct_ok = false;
     }
     c->last_direct = direct_bin;
-    launch_setup(s, fp, c->d_verts, c->d_faces, c->d_tex, c->d_lights, lset, RecArrays{ c->crecs, c->srecs, c->xrecs }, db, c->shades, c->keys[0], c->spans, c->partials, c->d_ctrl, c->wire, c->n_cu);
+    // band-sharded frames of a mesh that stays (second such frame on): k_setup culls and bins every face from packed positions and reads
+    // whole vertices only for the faces that reach this rank's rows
+    const float* pos12 = nullptr;
+    if (fp.band_only && c->nv && 2 * (c->band_y1 - c->band_y0) <= c->height) {       // (a band of most of the frame: nearly every face needs its whole vertices)
+        if (!c->pos_valid && c->band_frames >= 1) {
+            if ((size_t)c->nv * 3 > c->cap_pos12 || !c->d_pos12) {
+                if ((rc = ensure_plain(c, c->d_pos12, (size_t)c->nv * 3 + 16))) return rc;
+                c->cap_pos12 = (size_t)c->nv * 3;
+            }
+            launch_pack_positions(s, c->d_verts, c->nv, c->d_pos12);
+            c->pos_valid = true;
+        }
+        c->band_frames++;
+        if (c->pos_valid) pos12 = c->d_pos12;
+    }
+    launch_setup(s, fp, c->d_verts, c->d_faces, c->d_tex, c->d_lights, lset, RecArrays{ c->crecs, c->srecs, c->xrecs }, db, c->shades, c->keys[0], c->spans, c->partials, c->d_ctrl, c->wire, c->n_cu, pos12);
     if (prof_all) HIPCHK(c, hipEventRecord(ev[1], s));
 
     if (direct_bin) {
@@ -1126,7 +1145,7 @@ void b32_scene_destroy(b32_ctx* c, b32_scene* sl) {
     if (!c || !sl) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    void* ptrs[] = { sl->d_verts, sl->d_faces, sl->d_texels, sl->d_texels32, sl->d_tex, sl->d_consts, sl->d_texmask };
+    void* ptrs[] = { sl->d_verts, sl->d_faces, sl->d_texels, sl->d_texels32, sl->d_tex, sl->d_consts, sl->d_texmask, sl->d_pos12 };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete sl;
 }
@@ -1150,6 +1169,7 @@ int b32_scene_swap(b32_ctx* c, b32_scene* sl) {
     std::swap(c->may_blend, sl->may_blend); std::swap(c->cheap_ok, sl->cheap_ok); std::swap(c->local_sort_ok, sl->local_sort_ok);
     std::swap(c->tex_blend_any, sl->tex_blend_any);
     std::swap(c->direct_cap_opaque, sl->direct_cap_opaque); std::swap(c->direct_ntiles, sl->direct_ntiles); std::swap(c->direct_ok, sl->direct_ok);
+    std::swap(c->d_pos12, sl->d_pos12); std::swap(c->cap_pos12, sl->cap_pos12); std::swap(c->pos_valid, sl->pos_valid); std::swap(c->band_frames, sl->band_frames);
     c->tex_sig.swap(sl->tex_sig); std::swap(c->tex_sig_valid, sl->tex_sig_valid); std::swap(c->tex_sig_rgba, sl->tex_sig_rgba);
     return B32_OK;
 }

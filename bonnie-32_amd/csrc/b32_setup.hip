@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp_in, const B32Verte
                                                const TexDesc* __restrict__ tex, const B32Light* __restrict__ lights_mem, LightSet lset,
                                                RecArrays recs, DirectBin db, float* __restrict__ shades, uint32_t* __restrict__ keys,
                                                uint32_t* __restrict__ spans, uint32_t* __restrict__ partials, Ctrl* __restrict__ ctrl,
-                                               WireTri* __restrict__ wire) {
+                                               WireTri* __restrict__ wire, const float* __restrict__ pos12) {
     FrameParams fp_plain = fp_in;                 // (dead code unless PLAIN)
     if (PLAIN) { fp_plain.ortho = 0; fp_plain.fixed_point = 1; fp_plain.has_fog = 0; fp_plain.wire_collect = 0; fp_plain.shading = B32_SHADE_NONE;
                  fp_plain.xray = 0; fp_plain.fmt8 = 0; fp_plain.n_lights = 0; }
@@ -230,6 +230,12 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp_in, const B32Verte
             if (!fin[g].bad) {
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
+                    if (pos12) {      // band-sharded frame: positions only (12 B instead of a 36-B vertex); the rest once the face is known to reach the band
+                        const float* pp = pos12 + (size_t)fin[g].w[j] * 3;
+                        fin[g].v[j][0] = pp[0]; fin[g].v[j][1] = pp[1]; fin[g].v[j][2] = pp[2];
+                        fin[g].v[j][3] = fin[g].v[j][4] = 0.0f; fin[g].col[j] = 0;
+                        continue;
+                    }
                     const float* vp = reinterpret_cast<const float*>(verts) + (size_t)fin[g].w[j] * 9;
 #pragma unroll
                     for (int k = 0; k < 5; ++k) fin[g].v[j][k] = vp[k];
@@ -287,14 +293,8 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp_in, const B32Verte
             const bool have_tex = tid != B32_NO_TEXTURE && tid < fp.nt;             // textures.get(id)
             uint32_t tex_blend = B32_BLEND_OPAQUE;
             if (fp.tex_blend_any && keep && have_tex) tex_blend = tex[tid].blend_mode;     // (all Opaque: no descriptor gather in the chain)
-            if (fp.has_fog && keep) {                                                // render.rs:2419-2442
-                if (camz[0] > fp.fog.cull_distance && camz[1] > fp.fog.cull_distance && camz[2] > fp.fog.cull_distance) keep = false;
-                else {
-                    uint32_t fogc = fp.fog.r | (fp.fog.g << 8) | (fp.fog.b << 16) | ((uint32_t)fp.fog.blend << 24);
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) col[j] = fog_color(col[j], fogc, fog_factor(camz[j], fp.fog.start, fp.fog.falloff));
-                }
-            }
+            // fog, render.rs:2419-2442: the distance cull here, the colours further down (only surfaces whose record is built need them)
+            if (fp.has_fog && keep && camz[0] > fp.fog.cull_distance && camz[1] > fp.fog.cull_distance && camz[2] > fp.fog.cull_distance) keep = false;
             if (fp.wire_collect) {                       // wireframe lists take the face before the solid decision (render.rs:2445-2449, 2509-2511)
                 WireTri wt;
 #pragma unroll
@@ -335,6 +335,18 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp_in, const B32Verte
                 bool needs_dither = false;
                 r.inv_area = 0.0f; r.w0_start = r.w1_start = 0.0f; r.flags = 0;
                 if (need_rec) {
+                if (pos12) {          // (band-sharded frame) the face reaches this rank's rows: now its UVs and vertex colours
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const float* vp = reinterpret_cast<const float*>(verts) + (size_t)vi[j] * 9;
+                        uvx[j] = vp[3]; uvy[j] = vp[4]; col[j] = reinterpret_cast<const uint32_t*>(vp)[8];
+                    }
+                }
+                if (fp.has_fog) {
+                    const uint32_t fogc = fp.fog.r | (fp.fog.g << 8) | (fp.fog.b << 16) | ((uint32_t)fp.fog.blend << 24);
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) col[j] = fog_color(col[j], fogc, fog_factor(camz[j], fp.fog.start, fp.fog.falloff));
+                }
                 r.inv_area = 1.0f / area;
                 r.a0 = v2.y - v3.y; r.b0 = v3.x - v2.x; r.a1 = v3.y - v1.y; r.b1 = v1.x - v3.x;   // :1507-1510
                 const float start_x = (float)min_x, start_y = (float)min_y;
@@ -485,15 +497,15 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp_in, const B32Verte
 
 void launch_setup(hipStream_t s, const FrameParams& fp, const B32Vertex* verts, const B32Face* faces, const TexDesc* tex,
                   const B32Light* lights, const LightSet& ls, RecArrays recs, const DirectBin& db, float* shades, uint32_t* keys, uint32_t* spans, uint32_t* partials,
-                  Ctrl* ctrl, WireTri* wire, int n_cu) {
+                  Ctrl* ctrl, WireTri* wire, int n_cu, const float* pos12) {
     (void)n_cu;
     if (fp.nf == 0) return;
     const bool plain = fp.fixed_point && !fp.ortho && !fp.has_fog && !fp.wire_collect && fp.shading == B32_SHADE_NONE && !fp.xray && !fp.fmt8;
     // one face per thread: 52 VGPRs in the plain form = 8 waves per SIMD (two faces per thread with their loads issued up front: 73 VGPRs,
     // 43 us instead of 39 at 1 M faces; three: 49 us)
     const dim3 g1((fp.nf + 255) / 256);
-    if (plain) hipLaunchKernelGGL((k_setup<1, true>), g1, dim3(256), 0, s, fp, verts, faces, tex, lights, ls, recs, db, shades, keys, spans, partials, ctrl, wire);
-    else hipLaunchKernelGGL((k_setup<1, false>), g1, dim3(256), 0, s, fp, verts, faces, tex, lights, ls, recs, db, shades, keys, spans, partials, ctrl, wire);
+    if (plain) hipLaunchKernelGGL((k_setup<1, true>), g1, dim3(256), 0, s, fp, verts, faces, tex, lights, ls, recs, db, shades, keys, spans, partials, ctrl, wire, pos12);
+    else hipLaunchKernelGGL((k_setup<1, false>), g1, dim3(256), 0, s, fp, verts, faces, tex, lights, ls, recs, db, shades, keys, spans, partials, ctrl, wire, pos12);
 }
 
 // ---------------------------------------------------------------- stage tap: project_fixed for n positions
@@ -588,6 +600,17 @@ __global__ __launch_bounds__(256) void k_upload(const uint4* __restrict__ arena,
         uint4* dst = reinterpret_cast<uint4*>(segs.dst[k]);
         for (uint32_t i = gtid; i < segs.n16[k]; i += nthr) dst[i] = src[i];
     }
+}
+// Packed vertex positions (12 bytes each) of a resident scene, for the band-sharded frames' k_setup: every rank culls and bins ALL the
+// faces, but reads a whole 36-byte vertex only for those that reach its own rows.
+__global__ void k_pack_positions(const B32Vertex* __restrict__ verts, uint32_t nv, float* __restrict__ pos12) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nv) return;
+    const float* vp = reinterpret_cast<const float*>(verts) + (size_t)i * 9;
+    pos12[3 * (size_t)i] = vp[0]; pos12[3 * (size_t)i + 1] = vp[1]; pos12[3 * (size_t)i + 2] = vp[2];
+}
+void launch_pack_positions(hipStream_t s, const B32Vertex* verts, uint32_t nv, float* pos12) {
+    if (nv) hipLaunchKernelGGL(k_pack_positions, dim3((nv + 255) / 256), dim3(256), 0, s, verts, nv, pos12);
 }
 __global__ void k_ctrl_out(Ctrl* __restrict__ ctrl, uint4* __restrict__ dst) {
     if (threadIdx.x == 0) { unsigned long long* t = reinterpret_cast<Stamps*>(ctrl + 1)->t; if (!t[ST_END]) t[ST_END] = wall_clock64(); }

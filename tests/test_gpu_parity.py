@@ -779,6 +779,33 @@ def test_zbuffer_fast_path(fast_ctx, oracle, fmt8):
     assert np.array_equal(fb.zbuffer.view(np.uint32), ofb.zbuffer.view(np.uint32))
 
 
+@pytest.mark.parametrize("kind", ["bench", "fog-flat", "blend"])
+def test_band_frames_of_a_resident_scene_use_packed_positions(fast_ctx, oracle, kind):
+    """Multi-GPU band sharding: every rank culls and bins ALL the faces of the resident scene.  From the second band frame of an uploaded
+    mesh on, k_setup does that from packed 12-byte positions and reads the whole vertex (UVs, colours; fog is applied to the colours
+    after that) only for faces that reach the band.  Ragged bands rendered three times each (first: whole vertices; then: packed
+    positions) must assemble to the oracle's frame, with the oracle's triangle count on every band."""
+    from bonnie32_amd import rasterizer as R
+    sc = scenegen.make_scene("C3", n_tris=60_000, seed=808, variant="blend" if kind == "blend" else "bench", width=1280, height=960, bbox_px=700.0)
+    if kind == "fog-flat":
+        sc.fog = (1000.0, 3000.0, 5500.0, b32.Color(90, 100, 120))
+        sc.settings.shading = b32.abi.SHADE_FLAT
+        sc.settings.lights = [b32.Light.point((100.0, -50.0, 900.0), 2500.0, 1.5), b32.Light.directional((0.3, -1.0, 0.2), 0.5)]
+        sc.settings.backface_cull = False
+    exp, etm, d = cpu_render(oracle, sc)
+    fb = R.Framebuffer(sc.width, sc.height, fast_ctx)
+    rs = R.ResidentScene(fb, sc.vertices, sc.faces, sc.textures)
+    bands = ((0, 333), (333, 334), (334, 800), (800, 960))
+    for rep in range(3):
+        for band in bands:
+            fb.set_band(*band); fb.clear(sc.clear_color)
+            tm = rs.render(sc.camera, sc.settings, sc.fog)
+            assert tm.triangles_drawn == etm.triangles_drawn
+        fb.set_band(0, sc.height)
+        got = fb.pixels
+        assert np.array_equal(got, exp), f"{int((got != exp).sum())} bytes differ ({kind}, repetition {rep})"
+
+
 def test_fast_path_transparent_lists(fast_ctx, oracle):
     """Scenes with a transparent pass on the sort-free path: binning splits each tile list by class and k_blend ranks the
     transparent part by 64-bit painter's priority in LDS (ties in depth -> face order).  The second scene has far more
