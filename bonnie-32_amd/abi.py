@@ -91,6 +91,8 @@ SYMBOLS = [
     ("b32_fb_new", C.c_int, [_P, C.c_uint32, C.c_uint32]),
     ("b32_set_async_depth", C.c_int, [_P, C.c_int]),
     ("b32_route_count", C.c_ulonglong, [_P, C.c_int]),
+    ("b32_set_routes", C.c_int, [_P, C.c_uint32]),
+    ("b32_set_cheap_threshold", C.c_int, [_P, C.c_uint32]),
     ("b32_fb_clear", C.c_int, [_P, C.c_uint8, C.c_uint8, C.c_uint8, C.c_uint8]),
     ("b32_fb_upload", C.c_int, [_P, _P]),
     ("b32_fb_download", C.c_int, [_P, _P]),
@@ -123,6 +125,7 @@ SYMBOLS = [
     ("b32_last_kernel_times", C.c_int, [_P, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_uint32]),
     ("b32_device_constants", C.c_int, [_P, C.POINTER(C.c_char_p), _P, _P, C.c_uint32, C.POINTER(C.c_uint32), _P, _P]),
     ("b32_set_profiling", C.c_int, [_P, C.c_int]),
+    ("b32_set_profiling_stride", C.c_int, [_P, C.c_uint32]),
     ("b32_set_fragment_counting", C.c_int, [_P, C.c_int]),
 ]
 

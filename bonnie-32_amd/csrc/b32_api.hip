@@ -7,7 +7,6 @@
 #include "b32_device.h"
 #include <algorithm>
 #include <cstdio>
-#include <cstdlib>
 #include <chrono>
 #include <cstring>
 #include <vector>
@@ -67,7 +66,8 @@ struct b32_ctx {
     uint32_t* tile_mid = nullptr; size_t cap_tile_mid = 0;
     bool local_sort_ok = true;          // no tile list of this scene has exceeded the LDS sort capacity so far
     bool last_local_sort = false;       // the last frame took the fast path (draw order not materialised)
-    bool no_prio64 = false;             // debug/experiment switch (B32_NO_PRIO64=1): keep the per-tile LDS sort
+    uint32_t route_off = 0;             // b32_set_routes: B32_ROUTE_* bits switched off (tests keep the older pipelines covered with it)
+    uint32_t cheap_den = 64;            // b32_set_cheap_threshold
     // pairs
     size_t cap_pairs = 0;
     uint32_t* inline_lists = nullptr; size_t cap_inline = 0;      // small meshes: one list region per tile, filled inside k_cover
@@ -114,6 +114,7 @@ struct b32_ctx {
 
     // profiling
     int profile_level = 0;
+    uint32_t prof_stride = 1, prof_seq = 0;      // b32_set_profiling_stride: events on every prof_stride-th frame only
     hipEvent_t ev[EV_RING][EV_PER_FRAME] = {};
     bool ev_created = false;
     uint32_t ev_frames = 0;             // frames recorded since the last finish
@@ -216,7 +217,6 @@ int b32_create(int device, b32_ctx** out) {
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return B32_E_NO_DEVICE;
     b32_ctx* c = new b32_ctx();
     c->device = device;
-    c->no_prio64 = getenv("B32_NO_PRIO64") != nullptr;
     if (hipSetDevice(device) != hipSuccess) { delete c; return B32_E_NO_DEVICE; }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -515,10 +515,9 @@ static int upload_geometry(b32_ctx* c, const B32Vertex* v, uint32_t nv, const B3
     return B32_OK;
 }
 
-// CHEAP coverage is worth it while skipped winners are rare: textures with at most 1/cheap_den() skippable texels.  Measured on the C3
+// CHEAP coverage is worth it while skipped winners are rare: textures with at most 1/cheap_den skippable texels (b32_set_cheap_threshold).  Measured on the C3
 // geometry with 1 transparent CLUT entry out of K (tools/cheap_threshold.py): EXACT coverage (skip mask in LDS) 0.233 ms whatever the
-// texture; CHEAP 0.19 ms at K = 256, 0.220 at 64, 0.246 at 32, 0.307 at 16, 0.46 at 8.  (B32_CHEAP_DEN: that tool's switch.)
-static size_t cheap_den() { static const size_t d = getenv("B32_CHEAP_DEN") ? (size_t)atoi(getenv("B32_CHEAP_DEN")) : 64; return d ? d : 64; }
+// texture; CHEAP 0.19 ms at K = 256, 0.220 at 64, 0.246 at 32, 0.307 at 16, 0.46 at 8.  (b32_set_cheap_threshold: that tool's switch.)
 
 static int layout_textures(b32_ctx* c, uint32_t nt, const uint32_t* w, const uint32_t* h, const uint32_t* blend, size_t* total, bool rgba = false) {
     if (nt > 65534) return B32_E_UNSUPPORTED;        // the surface record holds the texture slot in 16 bits
@@ -593,7 +592,7 @@ int b32_scene_upload(b32_ctx* c, const B32Vertex* v, uint32_t nv, const B32Face*
             size_t skippable = 0;                                               // texels the black_transparent rule can skip
             const uint16_t* px = tex[i].pixels;
             for (size_t k = 0; k < n; ++k) skippable += (px[k] & 0x7FFF) == 0;
-            if (n == 0 || skippable * cheap_den() > n) c->cheap_ok = false;
+            if (n == 0 || skippable * c->cheap_den > n) c->cheap_ok = false;
         }
         c->tex_sig.swap(sig); c->tex_sig_valid = true; c->tex_sig_rgba = false;
     }
@@ -628,7 +627,7 @@ int b32_scene_upload_rgba(b32_ctx* c, const B32Vertex* v, uint32_t nv, const B32
             skippable += b == B32_BLEND_ERASE;
             blend_texels |= b != B32_BLEND_OPAQUE && b != B32_BLEND_ERASE;
         }
-        if (n == 0 || skippable * cheap_den() > n) c->cheap_ok = false;
+        if (n == 0 || skippable * c->cheap_den > n) c->cheap_ok = false;
     }
     if ((rc = upload_geometry(c, v, nv, f, nf))) return rc;
     bool alpha_faces = false;
@@ -668,7 +667,7 @@ int b32_scene_upload_indexed(b32_ctx* c, const B32Vertex* v, uint32_t nv, const 
         uint32_t skippable = 0;
         HIPCHK(c, hipMemcpyAsync(&skippable, d_cnt, 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        if ((size_t)skippable * cheap_den() > n) c->cheap_ok = false;
+        if ((size_t)skippable * c->cheap_den > n) c->cheap_ok = false;
     }
     if ((rc = upload_geometry(c, v, nv, f, nf))) return rc;
     for (uint32_t i = 0; i < nt; ++i) if (bl[i] != B32_BLEND_OPAQUE) c->may_blend = true;
@@ -790,7 +789,8 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
         }
     }
 
-    const bool prof_all = c->profile_level >= 2, prof_fill = c->profile_level >= 1;
+    const bool prof_sample = c->profile_level >= 1 && (c->prof_seq++ % c->prof_stride) == 0;
+    const bool prof_all = prof_sample && c->profile_level >= 2, prof_fill = prof_sample;
     hipEvent_t* ev = nullptr;
     if (prof_fill) {
         if (!c->ev_created) {
@@ -805,14 +805,14 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     // mode applies depth + skip rule per fragment (EXACT coverage)
     // (a transparent pass rides along: its entries are split off at binning time and sorted per tile by k_blend)
     const bool with_class = c->may_blend && !c->fmt8;
-    const bool spans_ok = !c->no_prio64 && c->local_sort_ok && bin_spans_applicable(fp, sc, with_class);
+    const bool spans_ok = !(c->route_off & B32_ROUTE_SORT_FREE) && c->local_sort_ok && bin_spans_applicable(fp, sc, with_class);
     // ordered walk of whole tile lists instead of the overwrite pass: x-ray (RGB555), or the 8-bit path with blending texels / editor alpha
     const bool ordered_all = c->fmt8 ? c->blend8 : (fp.xray != 0);
     // sort-free path: painter's or z-buffer mode (orthographic keys use all 32 bits -> class pass -> general path)
     const bool want_prio64 = spans_ok && !fp.ortho && !ordered_all;
     // too few 64x64 tiles to fill the GPU (narrow multi-GPU band, PS1-sized frame): tiles of 32 or 16 rows multiply the parallelism
     // of the fused kernel.  Only the sort-free path knows about them (its k_blend included); the keyed kernels keep 64 rows.
-    static const bool no_half_tiles = getenv("B32_NO_HALF_TILES") != nullptr, no_inline_bin = getenv("B32_NO_INLINE_BIN") != nullptr;   // experiment switches, read once
+    const bool no_half_tiles = (c->route_off & B32_ROUTE_CUT_TILES) != 0, no_inline_bin = (c->route_off & B32_ROUTE_INLINE_BIN) != 0;
     if (want_prio64 && c->band_y1 > c->band_y0 && !no_half_tiles) {
         uint32_t th = TILE_H;
         // 64 -> 32 rows below two tiles per CU, 32 -> 16 rows below one tile per CU (measured: a 240-row band of C3 prefers 320 tiles
@@ -849,7 +849,7 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     const bool want_inline = want_prio64 && !wire_front && c->nf <= (with_class ? 2048u : 8192u) && (size_t)ntiles * list_stride <= ((size_t)4 << 20) &&
                              !no_inline_bin;
     // larger meshes: no binning launch either -- k_setup appends every surviving face to fixed-size tile regions (DirectBin)
-    static const bool no_direct_bin = getenv("B32_NO_DIRECT_BIN") != nullptr;                   // experiment switch, read once
+    const bool no_direct_bin = (c->route_off & B32_ROUTE_DIRECT_BIN) != 0;
     DirectBin db{};
     if (c->direct_ntiles != ntiles) { c->direct_ntiles = ntiles; c->direct_cap_opaque = 0; c->direct_ok = true; }   // another tile grid (resize, band)
     if (want_prio64 && !want_inline && !wire_front && c->direct_ok && !no_direct_bin && ntiles) {
@@ -969,6 +969,7 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     fa.texels32 = c->d_texels32;
     fa.ordered_all = ordered_all ? 1u : 0u;
     fa.prio64 = prio64 ? 1u : 0u;
+    fa.narrow_only = (c->route_off & B32_ROUTE_WIDE_GROUPS) ? 1u : 0u;
     fa.texmask = c->d_texmask;
     { const uint32_t words = c->pool_texels / 32 + 2; fa.mask_lds_words = (c->pool_texels && words <= MASK_LDS_MAX_WORDS) ? words : 0u; }
     c->pending_may_redraw = !inline_bin;
@@ -1356,5 +1357,24 @@ extern "C" int b32_set_async_depth(b32_ctx* c, int deep) {
 extern "C" int b32_set_profiling(b32_ctx* c, int level) {
     if (!c) return B32_E_ARG;
     c->profile_level = level < 0 ? 0 : (level > 2 ? 2 : level);
+    c->prof_seq = 0;
+    return B32_OK;
+}
+extern "C" int b32_set_routes(b32_ctx* c, uint32_t off_mask) {
+    if (!c) return B32_E_ARG;
+    const int rc = settle_pending(c);
+    if (rc) return rc;
+    c->route_off = off_mask;
+    return B32_OK;
+}
+extern "C" int b32_set_cheap_threshold(b32_ctx* c, uint32_t den) {
+    if (!c || den == 0) return B32_E_ARG;
+    c->cheap_den = den;          // (applies to the textures uploaded from now on)
+    return B32_OK;
+}
+extern "C" int b32_set_profiling_stride(b32_ctx* c, uint32_t every) {
+    if (!c) return B32_E_ARG;
+    c->prof_stride = every ? every : 1u;
+    c->prof_seq = 0;
     return B32_OK;
 }

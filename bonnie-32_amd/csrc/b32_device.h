@@ -470,6 +470,7 @@ struct FillArgs {
     // LDS (mask_lds_words > 0: the first that many words are staged in the unused runner-up plane; a 256x256 texture is 8 KB).
     const uint32_t* texmask;
     uint32_t mask_lds_words;
+    uint32_t narrow_only;       // 1: never the 16-wave workgroups of the fused kernel (b32_set_routes)
     uint32_t prio64;            // 1: sort-free coverage -- visibility is a 64-bit max of (painter's key << 32 | face id); `vis` holds
                                 //    two words per pixel: winner face id + 1, runner-up face id + 1 (0 = none)
 #ifdef B32_TIMELINE

@@ -24,7 +24,6 @@
 // only for surfaces k_setup proved exact (integer coordinates, every intermediate < 2^24), otherwise the incremental
 // walk (render.rs:1706-1712) is replayed literally.
 #include "b32_device.h"
-#include <cstdlib>
 #ifndef B32_TRIP
 #define B32_TRIP 4
 #endif
@@ -463,11 +462,6 @@ template <bool FMT8> __device__ __forceinline__ uint32_t fetch_texel(const FillA
 
 // ---- wave-level helpers for the row-item scheduler
 __device__ __forceinline__ uint32_t dpp_max_scan(uint32_t v) {          // inclusive prefix max over the 64 lanes, identity 0
-#ifdef B32_NO_DPP
-    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(v, off); if (lane >= (uint32_t)off) v = max(v, t); }
-    return v;
-#endif
     // Hillis-Steele inside each 16-lane row (row_shr 1,2,4,8), then row_bcast:15 / row_bcast:31 across rows.
     v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));
     v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));
@@ -1878,8 +1872,7 @@ void launch_fill(hipStream_t s, const FillArgs& a, int n_cu, hipEvent_t after_co
     if (a.prio64) {   // sort-free fused kernel: coverage and shading are one launch; 64-bit tile buffers (2 x 36 KB)
         // EXACT = texel rule per fragment (textures with many skippable texels, or exact store counting); z-buffer mode = the
         // priority's high word is the fragment depth.  Few tiles (narrow multi-GPU bands, small frames): 16 waves per tile.
-        static const bool force_512 = getenv("B32_P64_NT512") != nullptr;          // experiment switch, read once
-        const bool wide = ntiles < 4u * (uint32_t)n_cu && !force_512;
+        const bool wide = ntiles < 4u * (uint32_t)n_cu && !a.narrow_only;
         const int sel = (a.exact_coverage ? 4 : 0) | (a.fp.zmode ? 2 : 0) | (f8 ? 1 : 0);
         switch (sel) {
             case 0: launch_p64<false, false, false>(s, a, ntiles, n_cu, wide); break;

@@ -228,14 +228,16 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp_in, const B32Verte
         if (fin[g].live) {
             fin[g].bad = fin[g].w[0] >= fp.nv || fin[g].w[1] >= fp.nv || fin[g].w[2] >= fp.nv;       // index panic, render.rs:2375-2377
             if (!fin[g].bad) {
+                if (pos12) {          // band-sharded frame: positions only (12 B instead of a 36-B vertex); the rest once the face is known to reach the band
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    if (pos12) {      // band-sharded frame: positions only (12 B instead of a 36-B vertex); the rest once the face is known to reach the band
+                    for (int j = 0; j < 3; ++j) {
                         const float* pp = pos12 + (size_t)fin[g].w[j] * 3;
                         fin[g].v[j][0] = pp[0]; fin[g].v[j][1] = pp[1]; fin[g].v[j][2] = pp[2];
                         fin[g].v[j][3] = fin[g].v[j][4] = 0.0f; fin[g].col[j] = 0;
-                        continue;
                     }
+                } else                // (one branch around all three vertices: every load of a path is issued before the first is used)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
                     const float* vp = reinterpret_cast<const float*>(verts) + (size_t)fin[g].w[j] * 9;
 #pragma unroll
                     for (int k = 0; k < 5; ++k) fin[g].v[j][k] = vp[k];

@@ -64,11 +64,25 @@ class Context:
     def set_profiling(self, level):
         _chk(self.lib.b32_set_profiling(self.h, level), "b32_set_profiling")
 
+    def set_profiling_stride(self, every):
+        """b32_set_profiling_stride: HIP events on every `every`-th frame only (an event pair per frame costs the stream microseconds)."""
+        _chk(self.lib.b32_set_profiling_stride(self.h, int(every)), "b32_set_profiling_stride")
+
     def set_async_depth(self, deep):
         """b32_set_async_depth: 0 = safe (default), 1 = large-scene frames back to back, a dropped one is reported by finish()."""
         _chk(self.lib.b32_set_async_depth(self.h, int(deep)), "b32_set_async_depth")
 
     ROUTES = ("direct_bin", "inline_bin", "counting_sort", "keyed", "redraw_region", "redraw_global_sort", "redraw_pairs")
+
+    ROUTE_SORT_FREE, ROUTE_CUT_TILES, ROUTE_INLINE_BIN, ROUTE_DIRECT_BIN, ROUTE_WIDE_GROUPS = 1, 2, 4, 8, 16
+
+    def set_routes(self, off_mask):
+        """b32_set_routes: switch internal routes off (ROUTE_* bits); results are identical on every route."""
+        _chk(self.lib.b32_set_routes(self.h, int(off_mask)), "b32_set_routes")
+
+    def set_cheap_threshold(self, den):
+        """b32_set_cheap_threshold: CHEAP coverage while every texture has at most 1/den skippable texels (default 64)."""
+        _chk(self.lib.b32_set_cheap_threshold(self.h, int(den)), "b32_set_cheap_threshold")
 
     def route_counts(self):
         """b32_route_count: how many frames of this context took each internal route (tests assert the targeted one ran)."""

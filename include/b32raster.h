@@ -234,6 +234,17 @@ int b32_set_async_depth(b32_ctx* ctx, int deep);
  * keyed pipeline (global depth sort), 4 frames redrawn because a tile region overflowed, 5 frames redrawn through the global depth
  * sort, 6 frames redrawn after a pair-buffer overflow.  Unknown `which` or null ctx: 0. */
 unsigned long long b32_route_count(const b32_ctx* ctx, int which);
+/* Switch internal routes OFF for the frames enqueued from now on (no reference counterpart: the results are identical on every route;
+ * the tests use it to keep the older pipelines covered, the timing tools to compare routes).  off_mask = 0 restores the default. */
+#define B32_ROUTE_SORT_FREE   1u   /* the fused sort-free kernel -> keyed pipelines (global painter's sort / per-tile LDS sort)    */
+#define B32_ROUTE_CUT_TILES   2u   /* tiles of 32 / 16 rows when a frame has few 64x64 tiles                                      */
+#define B32_ROUTE_INLINE_BIN  4u   /* small meshes: tile lists collected inside the fill kernel -> binning launches                */
+#define B32_ROUTE_DIRECT_BIN  8u   /* large meshes: binning inside the setup kernel -> counting-sort launches                      */
+#define B32_ROUTE_WIDE_GROUPS 16u  /* 16-wave workgroups of the fused kernel when tiles are few -> always 8 waves                  */
+int b32_set_routes(b32_ctx* ctx, uint32_t off_mask);
+/* CHEAP coverage (inside test only, texel rule applied to the winner) is used while every texture has at most 1/den skippable texels
+ * (default 64); applies to textures uploaded after the call.  den = 0: B32_E_ARG. */
+int b32_set_cheap_threshold(b32_ctx* ctx, uint32_t den);
 
 /* Several resident scenes per context (scene.rs:112-261 draws room after room, asset part after asset part, onto one
  * framebuffer every frame): a slot owns one uploaded scene's device buffers.  b32_scene_swap exchanges the context's current
@@ -317,6 +328,9 @@ int b32_last_kernel_times(b32_ctx* ctx, const char** names, float* ms, uint32_t 
  * (setup, sort, bin, cover, shade). Averages over the frames between two
  * b32_frame_finish calls (last 64 at most) are returned by b32_last_kernel_times / B32Timings. */
 int b32_set_profiling(b32_ctx* ctx, int level);
+/* Instrument only every `every`-th frame (default 1: each one).  An event pair around a kernel costs the stream a few microseconds
+ * per frame (the kernels of consecutive frames no longer run back to back); bench.py samples every 8th frame of its timed region. */
+int b32_set_profiling_stride(b32_ctx* ctx, uint32_t every);
 /* B32Timings.fragments (the reference's pixel-store count, render.rs:1671-1702) is instrumentation, not an output of
  * render_mesh_15.  on = 0 (default): not counted (B32Timings.fragments = 0 unless the textures force exact coverage); the fill
  * may then resolve opaque visibility without fetching the texel of every overdrawn fragment and without a global depth

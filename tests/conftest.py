@@ -33,16 +33,13 @@ def gpu_ctx():
 
 @pytest.fixture(scope="session")
 def keyed_ctx():
-    """A context with the sort-free path switched off (B32_NO_PRIO64 is read when the context is created): frames take the keyed
+    """A context with the sort-free path switched off (b32_set_routes): frames take the keyed
     pipelines -- global painter's sort + EXACT coverage with fragment counting on, per-tile LDS sort + visibility buffer with it
     off, the keyed z-buffer kernel in z-buffer mode -- so those stay covered although the default path no longer needs them."""
     import __graft_entry__ as g
     g.build()
     from bonnie32_amd import rasterizer as R
-    os.environ["B32_NO_PRIO64"] = "1"
-    try:
-        ctx = R.Context(0)
-    finally:
-        del os.environ["B32_NO_PRIO64"]
+    ctx = R.Context(0)
+    ctx.set_routes(R.Context.ROUTE_SORT_FREE)
     ctx.set_fragment_counting(1)
     return ctx

@@ -831,6 +831,35 @@ def test_fast_path_transparent_lists(fast_ctx, oracle):
     assert tm.triangles_drawn == etm.triangles_drawn > 2 * 2048 * 2
 
 
+@pytest.mark.parametrize("name", ["C3:100k", "C1:blend5", "C2:blend"])
+def test_every_route_of_the_sort_free_path_gives_the_same_frame(fast_ctx, oracle, name):
+    """b32_set_routes switches internal routes off one at a time: binning inside k_setup (large meshes) -> counting-sort launches, list
+    collection inside the fill kernel (small meshes) -> binning launch, cut tiles -> 64-row tiles, 16-wave workgroups -> 8 waves, the
+    whole sort-free path -> keyed pipelines.  Every combination must give the oracle's frame, and b32_route_count must show the route
+    that was asked for."""
+    from bonnie32_amd import rasterizer as R
+    C = R.Context
+    sc = SCENES[name]()
+    exp, etm, d = cpu_render(oracle, sc)
+    try:
+        for off in (0, C.ROUTE_DIRECT_BIN, C.ROUTE_INLINE_BIN, C.ROUTE_DIRECT_BIN | C.ROUTE_INLINE_BIN, C.ROUTE_CUT_TILES, C.ROUTE_WIDE_GROUPS,
+                    C.ROUTE_CUT_TILES | C.ROUTE_WIDE_GROUPS | C.ROUTE_DIRECT_BIN, C.ROUTE_SORT_FREE):
+            fast_ctx.set_routes(off)
+            before = fast_ctx.route_counts()
+            got, tm = gpu_render(fast_ctx, sc, resident=True)
+            after = fast_ctx.route_counts()
+            assert np.array_equal(got, exp), f"{int((got != exp).sum())} bytes differ (routes off: {off})"
+            assert tm.triangles_drawn == etm.triangles_drawn
+            if off & C.ROUTE_DIRECT_BIN:
+                assert after["direct_bin"] == before["direct_bin"]
+            if off & C.ROUTE_INLINE_BIN:
+                assert after["inline_bin"] == before["inline_bin"]
+            if off & C.ROUTE_SORT_FREE:
+                assert after["keyed"] > before["keyed"] and after["direct_bin"] == before["direct_bin"] and after["inline_bin"] == before["inline_bin"]
+    finally:
+        fast_ctx.set_routes(0)
+
+
 def test_direct_binning_region_overflow_and_regrowth(fast_ctx, oracle):
     """Meshes above the in-kernel list collection are binned by k_setup itself into fixed tile regions sized from the mesh (three times
     the mean list, at least 512 entries).  Two thirds of this mesh sit in the four centre tiles of a 300-tile frame, so the first attempt

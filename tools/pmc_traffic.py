@@ -27,7 +27,8 @@ def read(path, counter):
 
 def main():
     fc, wc, config, fname = sys.argv[1:5]
-    nv, nf, px = (3_000_000, 1_000_000, 2560 * 1920) if config in ("C3", "C5") else (None, None, None)
+    nv, nf, px = {"C3": (3_000_000, 1_000_000, 2560 * 1920), "C5": (3_000_000, 1_000_000, 2560 * 1920), "C2": (300_000, 100_000, 320 * 240),
+                  "C1": (6_000, 2_000, 320 * 240)}[config]
     F, Wt = read(fc, "FETCH_SIZE"), read(wc, "WRITE_SIZE")
     cover = max((k for k in F if "k_cover" in k), key=lambda k: F[k][1])           # the instantiation launched most often = the timed one
     setup = next(k for k in F if "k_setup" in k)
