@@ -17,7 +17,7 @@ for cfg in ["C1", "C2", "C3", "C5"]:
     reps, tcpu = 0, 0.0
     while tcpu < 4.0 and reps < 20:
         ofb.clear(sc.clear_color); t0 = time.perf_counter()
-        rc, otm = O.render_mesh_15(ofb, sc.vertices, sc.faces, sc.textures, sc.camera, sc.settings); tcpu += time.perf_counter() - t0; reps += 1
+        rc, otm = O.render_mesh_15(ofb, sc.vertices, sc.faces, sc.textures, sc.camera, sc.settings, fast=True); tcpu += time.perf_counter() - t0; reps += 1
     tcpu /= reps
     fb = R.Framebuffer(sc.width, sc.height, ctx)
     rs = R.ResidentScene(fb, sc.vertices, sc.faces, indexed_textures=sc.indexed_textures)
