@@ -62,3 +62,12 @@ print("slowest tiles: (tile, wg, start us, cover us, shade us, entries)")
 for i in slow:
     print("   ", int(tile[i]), int(wg[i]), round(t0[i] * tick, 1), round((t1[i] - t0[i]) * tick, 1), round((t2[i] - t1[i]) * tick, 1), int(nop[i]))
 # same-CU partner: workgroups b and b + 256 share a CU if dispatch is breadth-first
+# ---- gaps between consecutive tiles of one workgroup (shaded stamp of tile k -> coverage start of tile k + 1): the per-tile fixed cost
+gaps = []
+for w, v in per_wg.items():
+    v = sorted(v)
+    gaps += [v[i + 1][0] - v[i][1] for i in range(len(v) - 1)]
+first = [min(a for a, b in v) for v in per_wg.values()]
+if gaps:
+    g = np.array(gaps) * tick
+    print(f"gap between a workgroup's tiles: mean {g.mean():.2f} us, median {np.median(g):.2f}, p90 {np.percentile(g, 90):.2f}; first tile starts {np.mean(first) * tick:.2f} us after the earliest")
