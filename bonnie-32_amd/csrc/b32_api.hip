@@ -82,6 +82,9 @@ struct b32_ctx {
     bool direct_ok = true;                                        // false: the regions would not fit (one tile's list too long) -> counting sort
     bool last_direct = false;
     uint32_t epoch = 0;
+    // Framebuffer::clear deferred (b32_fb_clear): applied by the next frame's fused kernel when that frame takes the sort-free path in
+    // painter's mode on the same band, else by a clear launch before whatever touches the framebuffer next (flush_clear)
+    bool clear_pending = false; uint32_t clear_rgba = 0, clear_y0 = 0, clear_y1 = 0;
     unsigned long long routes[8] = {};                            // b32_route_count
     uint32_t *pkeys[2] = { nullptr, nullptr }, *pvals[2] = { nullptr, nullptr };
     // sort scratch
@@ -258,15 +261,29 @@ static int settle_pending(b32_ctx* c) {
     return B32_OK;
 }
 
+// The deferred Framebuffer::clear as launches of its own: before anything but the sort-free frame reads or writes the framebuffer.
+static int flush_clear(b32_ctx* c) {
+    if (!c->clear_pending) return B32_OK;
+    c->clear_pending = false;
+    if (!c->fb || c->clear_y1 <= c->clear_y0) return B32_OK;
+    launch_clear(c->stream, c->fb + (size_t)c->clear_y0 * c->width, (size_t)c->width * (c->clear_y1 - c->clear_y0), c->clear_rgba);
+    if (c->zbuf && c->zbuf_valid && (size_t)c->width * c->height <= c->cap_zbuf)        // self.zbuffer[i] = f32::MAX, render.rs:43
+        launch_clear(c->stream, reinterpret_cast<uint32_t*>(c->zbuf) + (size_t)c->clear_y0 * c->width, (size_t)c->width * (c->clear_y1 - c->clear_y0), 0x7F7FFFFFu);
+    HIPCHK(c, hipGetLastError());
+    return B32_OK;
+}
+
 int b32_set_stream(b32_ctx* c, void* s) {
     if (!c) return B32_E_ARG;
     { const int rc = settle_pending(c); if (rc) return rc; }
+    { const int rc = flush_clear(c); if (rc) return rc; }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->stream = s ? reinterpret_cast<hipStream_t>(s) : c->own_stream;
     return B32_OK;
 }
 int b32_synchronize(b32_ctx* c) {
     if (!c) return B32_E_ARG;
+    { const int rc = flush_clear(c); if (rc) return rc; }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return B32_OK;
 }
@@ -282,6 +299,7 @@ static int fb_resize_any(b32_ctx* c, uint32_t w, uint32_t h, bool always_new) {
     if (!c || w == 0 || h == 0 || w > 16384 || h > 16384) return B32_E_ARG;
     (void)hipSetDevice(c->device);
     { const int rc = settle_pending(c); if (rc) return rc; }
+    { const int rcf = flush_clear(c); if (rcf) return rcf; }
     if (c->fb_external) { c->fb_external = false; c->fb = nullptr; c->width = c->height = 0; }
     if (!always_new && c->fb && c->width == w && c->height == h) return B32_OK;          // Framebuffer::resize: no-op on equal dims
     const size_t px = (size_t)w * h;
@@ -304,6 +322,7 @@ int b32_fb_new(b32_ctx* c, uint32_t w, uint32_t h) { return fb_resize_any(c, w, 
 int b32_fb_bind_device(b32_ctx* c, void* dptr, uint32_t w, uint32_t h) {
     if (!c) return B32_E_ARG;
     { const int rc = settle_pending(c); if (rc) return rc; }
+    { const int rcf = flush_clear(c); if (rcf) return rcf; }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (!dptr) { c->fb_external = false; c->fb = nullptr; c->width = c->height = 0; return B32_OK; }
     if (w == 0 || h == 0 || w > 16384 || h > 16384 || (reinterpret_cast<uintptr_t>(dptr) & 15)) return B32_E_ARG;
@@ -320,24 +339,33 @@ int b32_fb_size(const b32_ctx* c, uint32_t* w, uint32_t* h) {
 }
 int b32_set_band(b32_ctx* c, uint32_t y0, uint32_t y1) {
     if (!c || !c->fb || y0 > y1 || y1 > c->height) return B32_E_ARG;
+    { const int rcf = flush_clear(c); if (rcf) return rcf; }          // (a deferred clear belongs to the rows of the band it was issued for)
     c->band_y0 = y0; c->band_y1 = y1; c->band_set = !(y0 == 0 && y1 == c->height);
     return B32_OK;
 }
+// (safe mode) a pending large-scene frame that may still need a redraw is settled before anything else WRITES the framebuffer too:
+// redrawn after a clear or a sky pass it would put its pixels on top of them
+static int settle_before_write(b32_ctx* c) { return c->deep_async ? B32_OK : settle_pending(c); }
+
 int b32_fb_clear(b32_ctx* c, uint8_t r, uint8_t g, uint8_t b, uint8_t blend) {
     if (!c || !c->fb) return B32_E_ARG;
     (void)hipSetDevice(c->device);
+    { const int rc = settle_before_write(c); if (rc) return rc; }
     const uint32_t a = blend == B32_BLEND_ERASE ? 0u : 255u;               // Color::to_bytes, types.rs:829-832
     const uint32_t rgba = r | (g << 8) | (b << 16) | (a << 24);
-    // with a screen band set (multi-GPU sharding) only the rows this rank owns are cleared: the others belong to other ranks
-    launch_clear(c->stream, c->fb + (size_t)c->band_y0 * c->width, (size_t)c->width * (c->band_y1 - c->band_y0), rgba);
-    if (c->zbuf && c->zbuf_valid && (size_t)c->width * c->height <= c->cap_zbuf)        // self.zbuffer[i] = f32::MAX, render.rs:43
-        launch_clear(c->stream, reinterpret_cast<uint32_t*>(c->zbuf) + (size_t)c->band_y0 * c->width, (size_t)c->width * (c->band_y1 - c->band_y0), 0x7F7FFFFFu);
-    HIPCHK(c, hipGetLastError());
+    // with a screen band set (multi-GPU sharding) only the rows this rank owns are cleared: the others belong to other ranks.
+    // The clear is DEFERRED: the frame that follows folds it into its fused kernel (no clear launch, uncovered pixels written once);
+    // anything else that touches the framebuffer first turns it into the launches it replaces (flush_clear).  An earlier deferred
+    // clear of the same rows is dead (fully overwritten); of other rows, it is flushed.
+    if (c->clear_pending && (c->clear_y0 != c->band_y0 || c->clear_y1 != c->band_y1)) { const int rc = flush_clear(c); if (rc) return rc; }
+    c->clear_pending = true; c->clear_rgba = rgba; c->clear_y0 = c->band_y0; c->clear_y1 = c->band_y1;
     return B32_OK;
 }
 int b32_fb_clear_gradient(b32_ctx* c, uint8_t r0, uint8_t g0, uint8_t b0, uint8_t blend0, uint8_t r1, uint8_t g1, uint8_t b1, uint8_t blend1) {
     if (!c || !c->fb) return B32_E_ARG;
     (void)hipSetDevice(c->device);
+    { const int rc = settle_before_write(c); if (rc) return rc; }
+    { const int rcf = flush_clear(c); if (rcf) return rcf; }
     const bool z = c->zbuf && c->zbuf_valid && (size_t)c->width * c->height <= c->cap_zbuf;
     launch_clear_gradient(c->stream, c->fb, z ? c->zbuf : nullptr, c->width, c->height, c->band_y0, c->band_y1,
                           r0 | (g0 << 8) | (b0 << 16) | ((uint32_t)blend0 << 24), r1 | (g1 << 8) | (b1 << 16) | ((uint32_t)blend1 << 24));
@@ -350,6 +378,8 @@ int b32_render_skybox_mesh(b32_ctx* c, const B32SkyVertex* v, uint32_t nv, const
     if (!c || !c->fb || !cam || (nv && !v) || (nf && !faces)) return B32_E_ARG;
     if (!nv || !nf) return B32_OK;
     (void)hipSetDevice(c->device);
+    { const int rcs = settle_before_write(c); if (rcs) return rcs; }
+    { const int rcf = flush_clear(c); if (rcf) return rcf; }
     for (size_t i = 0; i < (size_t)3 * nf; ++i) if (faces[i] >= nv) return B32_E_INDEX;    // projected[face[k]] index panic
     B32SkyVertex* dv = nullptr; uint32_t* df = nullptr; float2* dp = nullptr;
     Scratch tmp(c);
@@ -365,6 +395,8 @@ int b32_draw_star_diamonds(b32_ctx* c, const int32_t* cx, const int32_t* cy, con
     if (!c || !c->fb || (n && (!cx || !cy || !rgb))) return B32_E_ARG;
     if (!n) return B32_OK;
     (void)hipSetDevice(c->device);
+    { const int rcs = settle_before_write(c); if (rcs) return rcs; }
+    { const int rcf = flush_clear(c); if (rcf) return rcf; }
     int32_t *dx = nullptr, *dy = nullptr; uint8_t* dc = nullptr;
     Scratch tmp(c);
     int rc;
@@ -379,6 +411,7 @@ int b32_present_nearest(b32_ctx* c, uint32_t dw, uint32_t dh, uint8_t* out) {
     if (!c || !c->fb || !out || !dw || !dh || dw > 32768 || dh > 32768) return B32_E_ARG;
     (void)hipSetDevice(c->device);
     { const int rc = settle_pending(c); if (rc) return rc; }
+    { const int rcf = flush_clear(c); if (rcf) return rcf; }
     uint32_t* dd = nullptr;
     Scratch tmp(c);
     int rc;
@@ -392,6 +425,7 @@ int b32_fb_upload(b32_ctx* c, const uint8_t* rgba) {
     if (!c || !c->fb || !rgba) return B32_E_ARG;
     (void)hipSetDevice(c->device);
     { const int rc = settle_pending(c); if (rc) return rc; }
+    { const int rcf = flush_clear(c); if (rcf) return rcf; }
     HIPCHK(c, hipMemcpyAsync(c->fb, rgba, (size_t)c->width * c->height * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return B32_OK;
@@ -400,6 +434,7 @@ int b32_zbuffer_download(b32_ctx* c, float* z) {
     if (!c || !c->fb || !z) return B32_E_ARG;
     (void)hipSetDevice(c->device);
     { const int rc = settle_pending(c); if (rc) return rc; }
+    { const int rcf = flush_clear(c); if (rcf) return rcf; }
     const size_t px = (size_t)c->width * c->height;
     if (!c->zbuf || !c->zbuf_valid) { HIPCHK(c, hipStreamSynchronize(c->stream)); for (size_t i = 0; i < px; ++i) z[i] = 3.40282347e+38f; return B32_OK; }
     HIPCHK(c, hipMemcpyAsync(z, c->zbuf, px * 4, hipMemcpyDeviceToHost, c->stream));
@@ -410,6 +445,7 @@ int b32_zbuffer_upload(b32_ctx* c, const float* z) {
     if (!c || !c->fb || !z) return B32_E_ARG;
     (void)hipSetDevice(c->device);
     { const int rc = settle_pending(c); if (rc) return rc; }
+    { const int rcf = flush_clear(c); if (rcf) return rcf; }
     const size_t px = (size_t)c->width * c->height;
     int rc;
     if (px > c->cap_zbuf || !c->zbuf) { if ((rc = ensure_plain(c, c->zbuf, px + 64))) return rc; c->cap_zbuf = px; }
@@ -422,6 +458,7 @@ int b32_fb_download(b32_ctx* c, uint8_t* rgba) {
     if (!c || !c->fb || !rgba) return B32_E_ARG;
     (void)hipSetDevice(c->device);
     { const int rc = settle_pending(c); if (rc) return rc; }
+    { const int rcf = flush_clear(c); if (rcf) return rcf; }
     HIPCHK(c, hipMemcpyAsync(rgba, c->fb, (size_t)c->width * c->height * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return B32_OK;
@@ -979,6 +1016,14 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     if (direct_bin) fa.pair_vals = c->direct_lists;
     fa.gather_blend = (prio64 && with_class) ? 1u : 0u;
     if (c->fmt8) fa.fp.xray = 0;                        // render_mesh: x-ray only changes culling; its stores keep their own depth tests
+    // a deferred Framebuffer::clear: folded into this frame's fused kernel when that kernel is the one that runs, the frame has no
+    // depth buffer to reset and the clear was issued for this very band; else the clear launches go first
+    if (c->clear_pending) {
+        const bool has_z = c->zbuf && c->zbuf_valid;
+        if (prio64 && !wire_front && !ordered_all && !has_z && c->nf && ntiles && c->clear_y0 == c->band_y0 && c->clear_y1 == c->band_y1) {
+            fa.clear_on = 1; fa.clear_rgba = c->clear_rgba; c->clear_pending = false;
+        } else if ((rc = flush_clear(c))) return rc;
+    }
     launch_fill(s, fa, c->n_cu, prof_fill ? ev[4] : nullptr);
     if (fp.wire_collect && c->nf) {
         WireArgs wa{};
@@ -1042,6 +1087,7 @@ int b32_frame_finish(b32_ctx* c, B32Timings* out) {
     if (!c) return B32_E_ARG;
     (void)hipSetDevice(c->device);
     if (out) memset(out, 0, sizeof(*out));
+    { const int rcf = flush_clear(c); if (rcf) return rcf; }              // (a clear issued after the frame's draw)
     if (!c->frame_pending) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         const int d = c->deferred_rc; c->deferred_rc = 0;

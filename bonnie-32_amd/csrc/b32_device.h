@@ -470,6 +470,9 @@ struct FillArgs {
     // LDS (mask_lds_words > 0: the first that many words are staged in the unused runner-up plane; a 256x256 texture is 8 KB).
     const uint32_t* texmask;
     uint32_t mask_lds_words;
+    // Framebuffer::clear folded into the frame (b32_fb_clear defers itself; the sort-free fused kernel writes the clear colour to every
+    // pixel of the band nobody draws, so the frame has no clear launch and uncovered pixels are written once, not twice)
+    uint32_t clear_on, clear_rgba;
     uint32_t narrow_only;       // 1: never the 16-wave workgroups of the fused kernel (b32_set_routes)
     uint32_t prio64;            // 1: sort-free coverage -- visibility is a 64-bit max of (painter's key << 32 | face id); `vis` holds
                                 //    two words per pixel: winner face id + 1, runner-up face id + 1 (0 = none)

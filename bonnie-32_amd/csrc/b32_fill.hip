@@ -895,6 +895,16 @@ template <bool FMT8, int NT, bool ZMODE>
 __device__ __forceinline__ void shade_tile_p64(const FillArgs& a, const uint32_t* tilebuf, uint32_t e0, uint32_t e1, uint32_t x_lo, uint32_t x_hi,
                                                uint32_t y_lo, uint32_t y_hi, uint32_t ty_top, uint32_t tid, uint32_t lane, uint32_t TH);
 
+// Framebuffer::clear folded into the frame (FillArgs::clear_on): a frame that draws nothing (abort, redraw by the host) still owes the
+// caller the clear it took over from b32_fb_clear -- all the workgroups fill the band together.
+template <int NT>
+__device__ __forceinline__ void clear_band(const FillArgs& a) {
+    const FrameParams& fp = a.fp;
+    uint32_t* row0 = a.fb + (size_t)fp.band_y0 * fp.width;
+    const size_t n = (size_t)fp.width * (fp.band_y1 - fp.band_y0);
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) row0[i] = a.clear_rgba;
+}
+
 // PLAIN: the configuration BASELINE.json's metric is quoted on, with its run-time switches turned into constants -- affine UVs, no
 // shading pass, fixed-point snapping, perspective camera, one texture, lists from the binning launch, no transparent pass.  The
 // compiler then drops the other branches of coverage and shading from this instantiation (102 -> 94 VGPRs, 45 -> 13 spilled SGPRs).
@@ -968,11 +978,14 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a_in) {
                 }
                 if (blockIdx.x == 0 && tid == 0 && !misc[6]) a.ctrl->need_global_sort = redraw;
             }
+            if (a.clear_on) clear_band<NT>(a);
             return;
         }
     } else {
-        if (a.ctrl->abort) return;
-        if (P64 && a.ctrl->need_global_sort) return;   // a transparent tile list is too long for k_blend's LDS sort: the host redraws
+        if (a.ctrl->abort || (P64 && a.ctrl->need_global_sort)) {   // (a transparent tile list too long for k_blend's LDS sort: the host redraws)
+            if (P64 && a.clear_on) clear_band<NT>(a);
+            return;
+        }
     }
 
     TexDesc lds_desc = { 0, 0, 0, 0 };
@@ -1114,6 +1127,12 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a_in) {
             const unsigned long long tl1 = wall_clock64();
 #endif
             if (n_op) shade_tile_p64<FMT8, NT, ZMODE>(a, tilebuf, e0, e1, x_lo, x_hi, y_lo, y_hi, ty_top, tid, lane, TH);
+            else if (a.clear_on) {      // nothing reaches this tile: it still gets the frame's clear colour
+                for (uint32_t p = tid; p < TILE_W * TH; p += NT) {
+                    const uint32_t px = x_lo + (p & 63), py = ty_top + (p >> 6);
+                    if (px < x_hi && py >= y_lo && py < y_hi) a.fb[(size_t)py * fp.width + px] = a.clear_rgba;
+                }
+            }
             __syncthreads();
 #ifdef B32_TIMELINE
             if (tid == 0 && a.dbg) {
@@ -1301,7 +1320,10 @@ __device__ __forceinline__ void shade_tile_p64(const FillArgs& a, const uint32_t
         const bool inA = rowA < TH && px < x_hi && pyA >= y_lo && pyA < y_hi, inB = rowB < TH && px < x_hi && pyB >= y_lo && pyB < y_hi;
         unsigned long long tA = inA ? top[rowA * STR64 + col] : (ZMODE ? ~0ull : 0ull), tB = inB ? top[rowB * STR64 + col] : (ZMODE ? ~0ull : 0ull);
         const bool cA = covered(tA), cB = covered(tB);
-        if (!__ballot(cA || cB)) continue;
+        if (!__ballot(cA || cB)) {
+            if (a.clear_on) { if (inA) a.fb[(size_t)pyA * W + px] = a.clear_rgba; if (inB) a.fb[(size_t)pyB * W + px] = a.clear_rgba; }
+            continue;
+        }
         RecRegs ra, rb;
         rec_load(a, cA ? sid_of(tA) : 0u, need5, ra);             // surface 0's record is a harmless dummy for uncovered pixels
         rec_load(a, cB ? sid_of(tB) : 0u, need5, rb);
@@ -1360,6 +1382,8 @@ __device__ __forceinline__ void shade_tile_p64(const FillArgs& a, const uint32_t
                 if ((int)lane == fl && best) { ok = hit_test<FMT8>(a, sid_of(best), px, py, h); t = best; }
             }
         }
+        // (Framebuffer::clear folded into the frame: pixels nobody draws get the clear colour here)
+        if (a.clear_on) { if (inA && !okA) a.fb[(size_t)pyA * W + px] = a.clear_rgba; if (inB && !okB) a.fb[(size_t)pyB * W + px] = a.clear_rgba; }
         if (okA) {
             a.fb[(size_t)pyA * W + px] = colour<FMT8>(a, hA, shading, px, pyA);
             if (ZMODE) { float z = zsort_val(~(uint32_t)(tA >> 32)); if (z == 0.0f) z = exact_depth_at(a, hA.sid, px, pyA); a.zbuf[(size_t)pyA * W + px] = z; }

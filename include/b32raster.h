@@ -172,7 +172,13 @@ int         b32_synchronize(b32_ctx* ctx);
 /* ---- Framebuffer (render.rs:10-45) --------------------------------------- */
 int b32_fb_resize(b32_ctx* ctx, uint32_t width, uint32_t height);           /* Framebuffer::resize :27-34: zero-filled on change, no-op on equal dimensions */
 int b32_fb_new(b32_ctx* ctx, uint32_t width, uint32_t height);              /* Framebuffer::new :18-25: ALWAYS zero pixels and an f32::MAX z-buffer */
-int b32_fb_clear(b32_ctx* ctx, uint8_t r, uint8_t g, uint8_t b, uint8_t blend); /* Framebuffer::clear :36-45 (rows of the band only when b32_set_band is active) */
+/* Framebuffer::clear :36-45 (rows of the band only when b32_set_band is active).  The clear is deferred inside the library: the draw
+ * that follows folds it into its fused kernel when it can (painter's mode, no depth buffer allocated, same band) -- the frame then has
+ * no clear launch and pixels nobody draws are written once -- and every other call that reads or writes the framebuffer, changes the
+ * band, the binding or the stream, b32_synchronize and b32_frame_finish first turn it into the launches it stands for.  Through this
+ * API the deferral is unobservable; code that reads a caller-bound device buffer (b32_fb_bind_device) DIRECTLY sees the clear after
+ * the next draw, b32_synchronize or b32_frame_finish, in stream order. */
+int b32_fb_clear(b32_ctx* ctx, uint8_t r, uint8_t g, uint8_t b, uint8_t blend);
 int b32_fb_upload(b32_ctx* ctx, const uint8_t* rgba);                        /* host fb.pixels -> device */
 int b32_fb_download(b32_ctx* ctx, uint8_t* rgba);                            /* device -> host fb.pixels */
 /* Framebuffer::zbuffer (render.rs:12), used when settings.use_zbuffer: f32 per pixel, f32::MAX after new/resize/clear. */
@@ -219,9 +225,10 @@ int b32_frame_finish(b32_ctx* ctx, B32Timings* out /* nullable */);
  * frame can run out of tile-list space (the setup kernel bins it into fixed tile regions sized from the mesh; a region overflows when
  * far more of the mesh lands in one screen tile than the mean) or need the global depth sort; it then draws nothing and must be
  * redrawn by the host.
- *   deep = 0 (default): safe.  Enqueueing another frame, or any call that reads or rebinds the framebuffer (b32_fb_download,
- *            b32_zbuffer_download, b32_fb_upload, b32_fb_bind_device, b32_set_stream, b32_present_nearest), first settles the pending
- *            frame (one host synchronisation, redraw if needed): no frame is ever lost.
+ *   deep = 0 (default): safe.  Enqueueing another frame, or any call that reads, writes or rebinds the framebuffer (b32_fb_download,
+ *            b32_zbuffer_download, b32_fb_upload, b32_fb_clear*, b32_render_skybox_mesh, b32_draw_star_diamonds, b32_fb_bind_device,
+ *            b32_set_stream, b32_present_nearest), first settles the pending frame (one host synchronisation, redraw if needed): no
+ *            frame is ever lost, and none is redrawn on top of a later clear.
  *   deep = 1: throughput.  Frames are enqueued back to back with no host synchronisation (bench.py, parallel.py: static camera,
  *            capacities settled by a warm-up frame).  Only the most recent frame can be redrawn; if an earlier one was dropped,
  *            b32_frame_finish reports B32_E_FRAME_DROPPED -- never silently.  Consumers outside the library that read the bound

@@ -375,6 +375,18 @@ def test_async_frames_are_never_silently_dropped(oracle):
     oracle.render_mesh_15(o2, sc.vertices, sc.faces, sc.textures, far, sc.settings)
     assert np.array_equal(fb2.pixels, o2.pixels)
     rs2.finish()
+    # a clear between two frames: the overflowing frame must be redrawn BEFORE the clear, not on top of it
+    ctx4 = R.Context(0)
+    fb4 = R.Framebuffer(sc.width, sc.height, ctx4); fb4.clear(sc.clear_color)
+    rs4 = R.ResidentScene(fb4, sc.vertices, sc.faces, sc.textures)
+    rs4.render_async(far, sc.settings)
+    fb4.clear(sc.clear_color)
+    far_shifted = b32.Camera(position=(3000.0, 0.0, -45000.0))          # the far view again, elsewhere on screen
+    rs4.render_async(far_shifted, sc.settings)
+    o4 = oracle.Framebuffer(sc.width, sc.height); o4.clear(sc.clear_color)
+    oracle.render_mesh_15(o4, sc.vertices, sc.faces, sc.textures, far_shifted, sc.settings)
+    assert np.array_equal(fb4.pixels, o4.pixels)
+    rs4.finish()
     # ---- deep mode, fresh context
     ctx3 = R.Context(0)
     ctx3.set_async_depth(1)
@@ -390,6 +402,60 @@ def test_async_frames_are_never_silently_dropped(oracle):
     rs3.render_async(far, sc.settings)
     rs3.finish()                                                    # the most recent frame IS redrawn (regions grown), no error left over
     assert np.array_equal(fb3.pixels, o2.pixels)
+
+
+def test_deferred_clear_is_never_observable(fast_ctx, oracle):
+    """b32_fb_clear defers itself so that the frame that follows can fold it into its fused kernel (no clear launch).  Whatever else
+    touches the framebuffer first must see the cleared frame: a download with no draw in between, a second clear with another
+    colour, a band change, a sky pass, a z-buffer frame (depth reset too), a frame that draws nothing (empty mesh), tiles no
+    surface reaches, and a bound device tensor read after b32_synchronize."""
+    import torch
+    from bonnie32_amd import rasterizer as R
+    sc = scenegen.make_scene("C3", n_tris=20_000, width=640, height=480, bbox_px=200.0, seed=12)
+    sc.vertices["pos"][:, :2] *= np.float32(0.5)                      # the mesh covers the middle of the frame only: whole tiles stay empty
+    red, blue = b32.Color(200, 10, 10), b32.Color(10, 10, 200)
+    fb = R.Framebuffer(sc.width, sc.height, fast_ctx)
+    ofb = oracle.Framebuffer(sc.width, sc.height)
+    # clear, nothing else, download
+    fb.clear(red); ofb.clear(red)
+    assert np.array_equal(fb.pixels, ofb.pixels)
+    # two clears, then a frame (folded), then the same again on top without a clear (read-modify-write)
+    rs = R.ResidentScene(fb, sc.vertices, sc.faces, sc.textures)
+    fb.clear(red); fb.clear(blue); ofb.clear(blue)
+    for _ in range(2):
+        rs.render(sc.camera, sc.settings)
+        oracle.render_mesh_15(ofb, sc.vertices, sc.faces, sc.textures, sc.camera, sc.settings)
+        assert np.array_equal(fb.pixels, ofb.pixels)
+    assert (ofb.pixels.reshape(-1, 4)[:, :3] == np.array([10, 10, 200], np.uint8)).all(axis=1).sum() > 100_000      # empty tiles really exist
+    # clear of one band, band changed before the draw
+    fb.set_band(100, 300); fb.clear(red); fb.set_band(0, sc.height)
+    ofb.pixels.reshape(sc.height, -1)[100:300] = np.tile(np.array([200, 10, 10, 255], np.uint8), sc.width)
+    rs.render(sc.camera, sc.settings)
+    oracle.render_mesh_15(ofb, sc.vertices, sc.faces, sc.textures, sc.camera, sc.settings)
+    assert np.array_equal(fb.pixels, ofb.pixels)
+    # clear, then an empty mesh (no kernel runs), then a z-buffer frame after another clear (the depth buffer is reset as well)
+    fb.clear(blue); ofb.clear(blue)
+    R.render_mesh_15(fb, b32.make_vertices(0), b32.make_faces(0), [], sc.camera, sc.settings)
+    assert np.array_equal(fb.pixels, ofb.pixels)
+    rs = R.ResidentScene(fb, sc.vertices, sc.faces, sc.textures)      # (the drop-in call replaced the context's resident mesh)
+    zs = b32.RasterSettings.game()
+    for _ in range(2):
+        fb.clear(red); ofb.clear(red)
+        rs.render(sc.camera, zs)
+        oracle.render_mesh_15(ofb, sc.vertices, sc.faces, sc.textures, sc.camera, zs)
+        got = fb.pixels
+        assert np.array_equal(got, ofb.pixels), f"{int((got != ofb.pixels).sum())} bytes differ (z-buffer frame)"
+        assert np.array_equal(fb.zbuffer.view(np.uint32), ofb.zbuffer.view(np.uint32))
+    # a bound device tensor: the clear is in the tensor after b32_synchronize
+    dev = torch.device("cuda", 0)
+    ctx = R.Context(0)
+    frame = torch.zeros(sc.width * sc.height * 4, dtype=torch.uint8, device=dev)
+    fb2 = R.Framebuffer.__new__(R.Framebuffer); fb2.ctx = ctx
+    fb2.bind_device(frame.data_ptr(), sc.width, sc.height)
+    fb2.clear(red); ctx.synchronize(); torch.cuda.synchronize(dev)
+    o2 = oracle.Framebuffer(sc.width, sc.height); o2.clear(red)
+    assert np.array_equal(frame.cpu().numpy(), o2.pixels)
+    ctx.close()
 
 
 def test_framebuffer_new_on_a_reused_context(gpu_ctx, oracle):
