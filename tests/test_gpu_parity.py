@@ -926,6 +926,33 @@ def test_every_route_of_the_sort_free_path_gives_the_same_frame(fast_ctx, oracle
         fast_ctx.set_routes(0)
 
 
+@pytest.mark.parametrize("variant", ["bench", "blend"])
+def test_direct_binning_of_a_spatially_ordered_mesh(fast_ctx, oracle, variant):
+    """A real mesh is spatially ordered: the faces of one wave of k_setup mostly land in the same tile, and the list append groups them
+    (one atomic per group of lanes asking for the same counter, base + rank for its members).  The synthetic scenes are spatially
+    random and form almost no groups, so this one is sorted by screen tile (and, second pass, by scanline) first; large triangles
+    make multi-tile spans whose later tiles are grouped too."""
+    from bonnie32_amd import rasterizer as R
+    sc = scenegen.make_scene("C3", n_tris=120_000, width=1280, height=960, bbox_px=900.0, seed=4711, variant=variant)
+    c = sc.vertices["pos"].reshape(-1, 3, 3).mean(axis=1)
+    k = (c[:, 2] + 5.0) / 4.0
+    vs = min(sc.width, sc.height) / 2 * 0.75
+    px = c[:, 0] / k * vs + sc.width / 2; py = c[:, 1] / k * vs + sc.height / 2
+    for order in (np.lexsort((px // 64, py // 64)), np.lexsort((px, py // 8))):
+        v = sc.vertices.reshape(-1, 3)[order].reshape(-1).copy()
+        f = sc.faces[order].copy(); f["v"] = np.arange(3 * len(order), dtype=np.uint32).reshape(-1, 3)
+        ofb = oracle.Framebuffer(sc.width, sc.height); ofb.clear(sc.clear_color)
+        rc, etm = oracle.render_mesh_15(ofb, v, f, sc.textures, sc.camera, sc.settings)
+        assert rc == 0
+        fb = R.Framebuffer(sc.width, sc.height, fast_ctx); fb.clear(sc.clear_color)
+        before = fast_ctx.route_counts()
+        tm = R.ResidentScene(fb, v, f, sc.textures).render(sc.camera, sc.settings)
+        assert fast_ctx.route_counts()["direct_bin"] > before["direct_bin"]
+        got = fb.pixels
+        assert np.array_equal(got, ofb.pixels), f"{int((got != ofb.pixels).sum())} bytes differ"
+        assert tm.triangles_drawn == etm.triangles_drawn and tm.tile_pairs > tm.triangles_drawn
+
+
 def test_direct_binning_region_overflow_and_regrowth(fast_ctx, oracle):
     """Meshes above the in-kernel list collection are binned by k_setup itself into fixed tile regions sized from the mesh (three times
     the mean list, at least 512 entries).  Two thirds of this mesh sit in the four centre tiles of a 300-tile frame, so the first attempt
