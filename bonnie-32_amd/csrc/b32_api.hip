@@ -725,8 +725,22 @@ static int validate_settings(const B32Settings* st) {
 
 static uint32_t bits_for(uint32_t n_keys) { uint32_t b = 1; while ((1ull << b) < n_keys) ++b; return b; }
 
-static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st, const B32Fog* fog) {
-    hipStream_t s = c->stream;
+// ------------------------------------------------------------------ one frame = the pieces below, in order (enqueue_frame)
+// Which pipeline a frame takes.  Every route produces the same framebuffer (tests run every scene through several of them).
+struct Route {
+    bool with_class = false;     // the scene can have a transparent pass: tile lists are split by class
+    bool ordered_all = false;    // ordered walk of whole tile lists instead of the overwrite pass (x-ray; 8-bit path with blending texels)
+    bool want_prio64 = false;    // sort-free fused path (painter's or z-buffer mode)
+    bool exact_cov = false;      // EXACT coverage: texel rule per fragment (exact store counting, textures with many skippable texels)
+    bool local_sort = false;     // keyed fast path: per-tile LDS sort instead of the global painter's sort
+    bool want_inline = false;    // small mesh: the fused kernel's workgroups collect their own tile lists
+    bool direct_bin = false;     // large mesh: k_setup appends to fixed tile regions (DirectBin)
+    bool inline_bin = false, prio64 = false;     // what was finally launched
+    uint32_t list_stride = 0;    // entries per tile region (inline / direct binning)
+    DirectBin db{};
+};
+
+static FrameParams frame_params(const b32_ctx* c, const B32Camera* cam, const B32Settings* st, const B32Fog* fog, bool wire_any) {
     FrameParams fp{};
     fp.cam = *cam;
     fp.width = c->width; fp.height = c->height;
@@ -745,18 +759,18 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     fp.fmt8 = c->fmt8 ? 1 : 0;
     fp.ortho = st->has_ortho ? 1 : 0; fp.xray = st->xray_mode ? 1 : 0;
     fp.ortho_zoom = st->ortho_zoom; fp.ortho_cx = st->ortho_center_x; fp.ortho_cy = st->ortho_center_y;
-    const bool wire_back = st->backface_cull && st->backface_wireframe;      // render.rs:2577
-    const bool wire_front = st->wireframe_overlay != 0;                       // render.rs:2603 (an empty list draws nothing either way)
-    fp.wire_collect = (wire_back || wire_front) ? 1 : 0;
+    fp.wire_collect = wire_any ? 1 : 0;
     fp.band_only = 0;
-    uint32_t ntiles = fp.tiles_x * fp.tiles_y;
-    uint32_t n_keys = 2 * ntiles;
-    int rc;
+    fp.redraw = c->redrawing ? 1 : 0;
+    fp.tex_blend_any = c->tex_blend_any ? 1 : 0;
+    return fp;
+}
 
-    // lights: up to LIGHTS_INLINE travel by value in k_setup's arguments (a light change costs no copy and no synchronisation: the
-    // per-room light lists of a multi-mesh frame stay asynchronous); longer lists go through a device buffer, refreshed -- with a
-    // synchronisation -- only when they differ from the copy it holds
-    LightSet lset{};
+// lights: up to LIGHTS_INLINE travel by value in k_setup's arguments (a light change costs no copy and no synchronisation: the
+// per-room light lists of a multi-mesh frame stay asynchronous); longer lists go through a device buffer, refreshed -- with a
+// synchronisation -- only when they differ from the copy it holds
+static int frame_lights(b32_ctx* c, const B32Settings* st, FrameParams& fp, LightSet& lset) {
+    int rc;
     if (fp.n_lights && fp.n_lights <= LIGHTS_INLINE) {
         memcpy(lset.l, st->lights, fp.n_lights * sizeof(B32Light));
         fp.lights_inline = 1;
@@ -764,16 +778,25 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
         bool same = c->h_lights.size() == fp.n_lights && memcmp(c->h_lights.data(), st->lights, fp.n_lights * sizeof(B32Light)) == 0;
         if (!same) {
             if ((rc = ensure(c, c->d_lights, c->cap_lights, (size_t)fp.n_lights))) return rc;
-            HIPCHK(c, hipStreamSynchronize(s));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
             HIPCHK(c, hipMemcpy(c->d_lights, st->lights, fp.n_lights * sizeof(B32Light), hipMemcpyHostToDevice));
             c->h_lights.assign(st->lights, st->lights + fp.n_lights);
         }
     }
     if (fp.shading != B32_SHADE_NONE && (!c->shades || c->cap_shades < c->cap_work)) {
-        if (c->shades) { HIPCHK(c, hipStreamSynchronize(s)); HIPCHK(c, hipFree(c->shades)); c->shades = nullptr; }
+        if (c->shades) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(c->shades)); c->shades = nullptr; }
         HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->shades), c->cap_work * 9 * sizeof(float)));
         c->cap_shades = c->cap_work;
     }
+    return B32_OK;
+}
+
+// work buffers every route may need, sized for the uncut 64x64 tile grid (the sort-free path may cut tiles to a quarter of the height:
+// 4 x as many list ranges)
+static int frame_buffers(b32_ctx* c, const FrameParams& fp, bool wire_back) {
+    hipStream_t s = c->stream;
+    const uint32_t ntiles = fp.tiles_x * fp.tiles_y;
+    int rc;
     // pair buffers: start at 2 pairs per face + one per tile; b32_frame_finish grows them on overflow
     if (c->cap_pairs == 0 || !c->pkeys[0]) {
         const size_t n = (size_t)c->nf * 2 + ntiles + 1024;
@@ -786,14 +809,15 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
         if ((rc = ensure_plain(c, c->block_hist, (size_t)4096 * need_blocks))) return rc;
         c->hist_blocks = need_blocks;
     }
-    {   // list ranges: 2 per 64x64 tile (tile, class); the sort-free path may cut tiles to a quarter of the height (4 x as many)
-        const size_t need = (size_t)4 * ntiles + 4 * fp.tiles_x + 2;
-        if (need > c->cap_ranges || !c->ranges) {
-            if ((rc = ensure_plain(c, c->ranges, need + 64))) return rc;
-            c->cap_ranges = need + 64;
-        }
+    const size_t need_ranges = (size_t)4 * ntiles + 4 * fp.tiles_x + 2;      // list ranges: 2 per tile (tile, class), x 4 for cut tiles
+    if (need_ranges > c->cap_ranges || !c->ranges) {
+        if ((rc = ensure_plain(c, c->ranges, need_ranges + 64))) return rc;
+        c->cap_ranges = need_ranges + 64;
     }
-
+    if (need_ranges > c->cap_tile_mid || !c->tile_mid) {
+        if ((rc = ensure_plain(c, c->tile_mid, need_ranges + 64))) return rc;
+        c->cap_tile_mid = need_ranges + 64;
+    }
     if (c->mask_dirty && c->pool_texels) {      // (after the drop-in call's staged copy kernel on the same stream: the texels are there)
         launch_build_mask(s, c->fmt8 ? nullptr : c->d_texels, c->fmt8 ? c->d_texels32 : nullptr, c->pool_texels, c->d_texmask);
         c->mask_dirty = false;
@@ -803,18 +827,10 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
         if (px > c->cap_zbuf || !c->zbuf) { if ((rc = ensure_plain(c, c->zbuf, px + 64))) return rc; c->cap_zbuf = px; c->zbuf_valid = false; }
         if (!c->zbuf_valid) { launch_clear(s, reinterpret_cast<uint32_t*>(c->zbuf), px, 0x7F7FFFFFu); c->zbuf_valid = true; }
     }
-    {   // (cut tiles: up to 4 x as many)
-        const size_t need = (size_t)4 * ntiles + 4 * fp.tiles_x + 2;
-        if (need > c->cap_tile_mid || !c->tile_mid) {
-            if ((rc = ensure_plain(c, c->tile_mid, need + 64))) return rc;
-            c->cap_tile_mid = need + 64;
-        }
-    }
     if ((size_t)c->width * c->height > c->cap_vis || !c->vis) {
         if ((rc = ensure_plain(c, c->vis, (size_t)c->width * c->height * 2 + 64))) return rc;    // two words per pixel (prio64 coverage)
         c->cap_vis = (size_t)c->width * c->height;
     }
-
     if (fp.wire_collect && c->nf) {
         if ((size_t)c->nf > c->cap_wire || !c->wire) { if ((rc = ensure_plain(c, c->wire, (size_t)c->nf + 16))) return rc; c->cap_wire = c->nf; }
         size_t slots = 1024;
@@ -825,32 +841,23 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
             c->cap_wire_table = slots;
         }
     }
+    return B32_OK;
+}
 
-    const bool prof_sample = c->profile_level >= 1 && (c->prof_seq++ % c->prof_stride) == 0;
-    const bool prof_all = prof_sample && c->profile_level >= 2, prof_fill = prof_sample;
-    hipEvent_t* ev = nullptr;
-    if (prof_fill) {
-        if (!c->ev_created) {
-            for (auto& fr : c->ev) for (auto& e : fr) HIPCHK(c, hipEventCreate(&e));
-            c->ev_created = true;
-        }
-        ev = c->ev[c->ev_frames % EV_RING];
-    }
-
-    const SortScratch sc{ c->block_hist, c->hist_blocks, c->digit_total };
+// Route selection.  May cut the tile grid (fp.tile_h / tile_yb / tiles_y) and prepares the direct binning's regions.
+static int plan_route(b32_ctx* c, FrameParams& fp, const SortScratch& sc, bool wire_front, Route& r) {
+    int rc;
     // z-buffer frames without a transparent pass take the sort-free fused path too (depth is the priority); otherwise z-buffer
     // mode applies depth + skip rule per fragment (EXACT coverage)
     // (a transparent pass rides along: its entries are split off at binning time and sorted per tile by k_blend)
-    const bool with_class = c->may_blend && !c->fmt8;
-    const bool spans_ok = !(c->route_off & B32_ROUTE_SORT_FREE) && c->local_sort_ok && bin_spans_applicable(fp, sc, with_class);
-    // ordered walk of whole tile lists instead of the overwrite pass: x-ray (RGB555), or the 8-bit path with blending texels / editor alpha
-    const bool ordered_all = c->fmt8 ? c->blend8 : (fp.xray != 0);
+    r.with_class = c->may_blend && !c->fmt8;
+    const bool spans_ok = !(c->route_off & B32_ROUTE_SORT_FREE) && c->local_sort_ok && bin_spans_applicable(fp, sc, r.with_class);
+    r.ordered_all = c->fmt8 ? c->blend8 : (fp.xray != 0);
     // sort-free path: painter's or z-buffer mode (orthographic keys use all 32 bits -> class pass -> general path)
-    const bool want_prio64 = spans_ok && !fp.ortho && !ordered_all;
+    r.want_prio64 = spans_ok && !fp.ortho && !r.ordered_all;
     // too few 64x64 tiles to fill the GPU (narrow multi-GPU band, PS1-sized frame): tiles of 32 or 16 rows multiply the parallelism
     // of the fused kernel.  Only the sort-free path knows about them (its k_blend included); the keyed kernels keep 64 rows.
-    const bool no_half_tiles = (c->route_off & B32_ROUTE_CUT_TILES) != 0, no_inline_bin = (c->route_off & B32_ROUTE_INLINE_BIN) != 0;
-    if (want_prio64 && c->band_y1 > c->band_y0 && !no_half_tiles) {
+    if (r.want_prio64 && c->band_y1 > c->band_y0 && !(c->route_off & B32_ROUTE_CUT_TILES)) {
         uint32_t th = TILE_H;
         // 64 -> 32 rows below two tiles per CU, 32 -> 16 rows below one tile per CU (measured: a 240-row band of C3 prefers 320 tiles
         // of 32 rows to 600 of 16; C2's 20 tiles prefer 80 of 16 rows)
@@ -859,42 +866,28 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
         fp.tile_h = th;
         fp.tile_yb = (c->band_y0 / th) * th;
         fp.tiles_y = (c->band_y1 - fp.tile_yb + th - 1) / th;
-        ntiles = fp.tiles_x * fp.tiles_y;
-        n_keys = 2 * ntiles;
     }
+    const uint32_t ntiles = fp.tiles_x * fp.tiles_y;
     // EXACT coverage = texel rule per fragment: exact store counting, textures with many skippable texels; the keyed z-buffer kernel
     // is EXACT by construction
-    const bool exact_cov = c->count_fragments || !c->cheap_ok || (fp.zmode && !want_prio64);
+    r.exact_cov = c->count_fragments || !c->cheap_ok || (fp.zmode && !r.want_prio64);
     // the sorted fast path reads the class from bit 31 of the depth key and has no ordered opaque walk: not for ortho / x-ray frames
-    const bool local_sort = !exact_cov && c->local_sort_ok && !fp.ortho && !ordered_all && !fp.zmode;
-    c->last_local_sort = local_sort || want_prio64;                         // the global draw order is not materialised
-    c->last_exact = ordered_all ? true : (exact_cov && !fp.zmode);          // the ordered walk counts every store it performs
-    if (c->nf == 0) {                                                             // otherwise k_setup resets it (all but `sticky`)
-        HIPCHK(c, hipMemsetAsync(c->d_ctrl, 0, offsetof(Ctrl, sticky), s));
-        HIPCHK(c, hipMemsetAsync(&c->d_ctrl->fragments, 0, sizeof(unsigned long long), s));
-    }
-    if (prof_all) HIPCHK(c, hipEventRecord(ev[0], s));
-    fp.band_only = (want_prio64 && c->band_set) ? 1 : 0;   // other ranks own the other rows: their surfaces' records are never read here
-    fp.redraw = c->redrawing ? 1 : 0;
-    fp.tex_blend_any = c->tex_blend_any ? 1 : 0;
-    int cur = 0;
-    bool prio64 = false, inline_bin = false, direct_bin = false;
+    r.local_sort = !r.exact_cov && c->local_sort_ok && !fp.ortho && !r.ordered_all && !fp.zmode;
+    fp.band_only = (r.want_prio64 && c->band_set) ? 1 : 0;   // other ranks own the other rows: their surfaces' records are never read here
     // small mesh (what the reference's callers submit per room / asset part): no binning launch, the
     // fused kernel's workgroups collect their own tile lists from the spans (needs one list region of nf entries per tile)
-    uint32_t list_stride = (c->nf + 31u) & ~31u;
     // (with a transparent pass only up to 2048 faces: no tile's transparent list can then exceed what k_blend sorts in LDS)
-    const bool want_inline = want_prio64 && !wire_front && c->nf <= (with_class ? 2048u : 8192u) && (size_t)ntiles * list_stride <= ((size_t)4 << 20) &&
-                             !no_inline_bin;
+    r.list_stride = (c->nf + 31u) & ~31u;
+    r.want_inline = r.want_prio64 && !wire_front && c->nf <= (r.with_class ? 2048u : 8192u) && (size_t)ntiles * r.list_stride <= ((size_t)4 << 20) &&
+                    !(c->route_off & B32_ROUTE_INLINE_BIN);
     // larger meshes: no binning launch either -- k_setup appends every surviving face to fixed-size tile regions (DirectBin)
-    const bool no_direct_bin = (c->route_off & B32_ROUTE_DIRECT_BIN) != 0;
-    DirectBin db{};
     if (c->direct_ntiles != ntiles) { c->direct_ntiles = ntiles; c->direct_cap_opaque = 0; c->direct_ok = true; }   // another tile grid (resize, band)
-    if (want_prio64 && !want_inline && !wire_front && c->direct_ok && !no_direct_bin && ntiles) {
+    if (r.want_prio64 && !r.want_inline && !wire_front && c->direct_ok && !(c->route_off & B32_ROUTE_DIRECT_BIN) && ntiles) {
         // first guess: three times the mean list of a mesh whose every face is drawn and touches one tile; a frame that overflows
         // reports its longest list and is redrawn with regions a quarter above it (b32_frame_finish)
         if (!c->direct_cap_opaque) c->direct_cap_opaque = std::max<uint32_t>(512u, (uint32_t)std::min<uint64_t>((uint64_t)3 * c->nf / ntiles + 64, 1u << 24));
         const uint32_t cap_o = (c->direct_cap_opaque + 31u) & ~31u;
-        const uint32_t region = cap_o + (with_class ? BLEND_SORT_CAP : 0u);
+        const uint32_t region = cap_o + (r.with_class ? BLEND_SORT_CAP : 0u);
         const size_t need = (size_t)ntiles * region + 64;
         if (need <= ((size_t)1 << 28)) {                            // 1 GB of list space at most; beyond that the compact counting sort
             if (need > c->cap_direct || !c->direct_lists) {
@@ -905,55 +898,48 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
             if (need_fill > c->cap_tile_fill || !c->tile_fill) {
                 if ((rc = ensure_plain(c, c->tile_fill, need_fill * 2))) return rc;
                 c->cap_tile_fill = need_fill * 2;
-                HIPCHK(c, hipMemsetAsync(c->tile_fill, 0, c->cap_tile_fill * sizeof(uint32_t), s));   // zero from here on: k_cover re-zeroes what k_setup counted
+                HIPCHK(c, hipMemsetAsync(c->tile_fill, 0, c->cap_tile_fill * sizeof(uint32_t), c->stream));   // zero from here on: k_cover re-zeroes what k_setup counted
             }
             if (++c->epoch == 0) c->epoch = 1;
-            db.fill = c->tile_fill; db.lists = c->direct_lists; db.region = region; db.cap_opaque = cap_o;
-            db.cap_transparent = with_class ? BLEND_SORT_CAP : 0u; db.with_class = with_class ? 1u : 0u; db.epoch = c->epoch;
-            direct_bin = true;
-            list_stride = region;
+            r.db.fill = c->tile_fill; r.db.lists = c->direct_lists; r.db.region = region; r.db.cap_opaque = cap_o;
+            r.db.cap_transparent = r.with_class ? BLEND_SORT_CAP : 0u; r.db.with_class = r.with_class ? 1u : 0u; r.db.epoch = c->epoch;
+            r.direct_bin = true;
+            r.list_stride = region;
         } else c->direct_ok = false;
     }
-    c->last_direct = direct_bin;
-    // band-sharded frames of a mesh that stays (second such frame on): k_setup culls and bins every face from packed positions and reads
-    // whole vertices only for the faces that reach this rank's rows
-    const float* pos12 = nullptr;
+    return B32_OK;
+}
+
+// band-sharded frames of a mesh that stays (second such frame on): k_setup culls and bins every face from packed positions and reads
+// whole vertices only for the faces that reach this rank's rows
+static int frame_positions(b32_ctx* c, const FrameParams& fp, const float*& pos12) {
+    int rc;
+    pos12 = nullptr;
     if (fp.band_only && c->nv && 2 * (c->band_y1 - c->band_y0) <= c->height) {       // (a band of most of the frame: nearly every face needs its whole vertices)
         if (!c->pos_valid && c->band_frames >= 1) {
             if ((size_t)c->nv * 3 > c->cap_pos12 || !c->d_pos12) {
                 if ((rc = ensure_plain(c, c->d_pos12, (size_t)c->nv * 3 + 16))) return rc;
                 c->cap_pos12 = (size_t)c->nv * 3;
             }
-            launch_pack_positions(s, c->d_verts, c->nv, c->d_pos12);
+            launch_pack_positions(c->stream, c->d_verts, c->nv, c->d_pos12);
             c->pos_valid = true;
         }
         c->band_frames++;
         if (c->pos_valid) pos12 = c->d_pos12;
     }
-    launch_setup(s, fp, c->d_verts, c->d_faces, c->d_tex, c->d_lights, lset, RecArrays{ c->crecs, c->srecs, c->xrecs }, db, c->shades, c->keys[0], c->spans, c->partials, c->d_ctrl, c->wire, c->n_cu, pos12);
-    if (prof_all) HIPCHK(c, hipEventRecord(ev[1], s));
+    return B32_OK;
+}
 
-    if (direct_bin) {
-        if (prof_all) HIPCHK(c, hipEventRecord(ev[2], s));
-        prio64 = true;
-    } else if (want_inline) {
-        const size_t need = (size_t)ntiles * list_stride + 64;
-        if (need > c->cap_inline) {
-            if ((rc = ensure_plain(c, c->inline_lists, need + need / 2))) return rc;
-            c->cap_inline = need + need / 2;
-        }
-        if (prof_all) HIPCHK(c, hipEventRecord(ev[2], s));
-        prio64 = inline_bin = true;
-    } else if (want_prio64) {
-        if (prof_all) HIPCHK(c, hipEventRecord(ev[2], s));
-        prio64 = launch_bin_spans(s, fp, c->spans, with_class ? c->keys[0] : nullptr, c->partials, c->d_ctrl, sc, (uint32_t)c->cap_pairs, c->ranges,
-                                  c->tile_mid, BLEND_SORT_CAP, c->pvals[0]);
-    }
-    if (!prio64) {
-    if (local_sort) {
+// The keyed pipelines (no sort-free path for this frame): pairs keyed by (tile, class), grouped by radix passes; returns the pair buffer
+// that holds the grouped lists.  ev_bin: event to record when the binning proper starts (profiling level 2), or nullptr.
+static int bin_keyed(b32_ctx* c, const FrameParams& fp, const Route& r, const SortScratch& sc, hipEvent_t ev_bin, int& cur) {
+    hipStream_t s = c->stream;
+    const uint32_t ntiles = fp.tiles_x * fp.tiles_y;
+    cur = 0;
+    if (r.local_sort) {
         // fast path: no global depth sort.  Pairs are emitted in face order from k_setup's spans; k_cover sorts every tile
         // list by depth key in LDS (stable, so ties keep face order).
-        if (prof_all) HIPCHK(c, hipEventRecord(ev[2], s));
+        if (ev_bin) HIPCHK(c, hipEventRecord(ev_bin, s));
         launch_bin_faces(s, fp, c->spans, c->keys[0], c->partials, c->d_ctrl, c->pkeys[0], c->pvals[0], (uint32_t)c->cap_pairs, 0);
     } else {
         // painter's order: 4 stable passes over the 32-bit key; pass 1 also compacts away culled faces and its scan kernel
@@ -968,10 +954,10 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
             launch_radix_pass(s, c->keys[0], c->vals[0], c->keys[1], c->vals[1], &c->d_ctrl->n_visible, c->nf, 0, 8, sc);
             HIPCHK(c, hipMemcpyAsync(c->vals[0], c->vals[1], (size_t)c->nf * 4, hipMemcpyDeviceToDevice, s));
         }
-        if (prof_all) HIPCHK(c, hipEventRecord(ev[2], s));
+        if (ev_bin) HIPCHK(c, hipEventRecord(ev_bin, s));
         launch_bin(s, fp, c->spans, c->vals[0], c->d_ctrl, c->counts, c->block_sums, c->bin_blocks, c->pkeys[0], c->pvals[0], (uint32_t)c->cap_pairs);
     }
-    const uint32_t n_sort_keys = local_sort ? ntiles : n_keys;          // the fast path groups by tile only
+    const uint32_t n_sort_keys = r.local_sort ? ntiles : 2 * ntiles;          // the fast path groups by tile only
     const uint32_t kb = bits_for(n_sort_keys ? n_sort_keys : 1);
     if (kb <= 8 || kb > 12) {
         for (uint32_t shift = 0; shift < kb; shift += 8) {
@@ -984,47 +970,115 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
         launch_radix_pass(s, c->pkeys[cur], c->pvals[cur], c->pkeys[cur ^ 1], c->pvals[cur ^ 1], &c->d_ctrl->n_pairs, (uint32_t)c->cap_pairs, 0, kb <= 11 ? 11 : 12, sc, exr);
         cur ^= 1;
     }
-    }   // !prio64
-    c->last_pair_buf = cur;
-    c->routes[direct_bin ? 0 : inline_bin ? 1 : prio64 ? 2 : 3]++;
-    if (prof_fill) HIPCHK(c, hipEventRecord(ev[3], s));
+    return B32_OK;
+}
 
+static FillArgs fill_args(const b32_ctx* c, const FrameParams& fp, const Route& r, int cur, bool wire_front) {
     FillArgs fa{};
     fa.fp = fp; fa.crecs = c->crecs; fa.srecs = c->srecs; fa.xrecs = c->xrecs; fa.shades = c->shades; fa.pair_vals = c->pvals[cur]; fa.ranges = c->ranges;
-    fa.keys = c->keys[0]; fa.local_sort = local_sort ? 1u : 0u; fa.tile_keys_only = (local_sort || prio64) ? 1u : 0u; fa.tile_mid = c->tile_mid;
+    fa.keys = c->keys[0]; fa.local_sort = r.local_sort ? 1u : 0u; fa.tile_keys_only = (r.local_sort || r.prio64) ? 1u : 0u; fa.tile_mid = c->tile_mid;
     fa.tex = c->d_tex; fa.texels = c->d_texels; fa.fb = c->fb; fa.vis = c->vis; fa.zbuf = c->zbuf; fa.ctrl = c->d_ctrl;
     fa.tex0 = c->nt ? c->h_tex[0] : TexDesc{ 0, 0, 0, 0 };
     fa.lds_tex_texels = 0;
-    if (c->nt == 1) {
+    if (c->nt == 1 && r.exact_cov) {                     // (CHEAP coverage: one texel fetch per output pixel, served by L1/L2)
         const size_t n = (size_t)c->h_tex[0].width * c->h_tex[0].height;
         if (n > 0 && n * 2 <= fill_lds_tex_budget()) fa.lds_tex_texels = (uint32_t)n;
     }
-    fa.exact_coverage = exact_cov ? 1u : 0u;
-    if (!fa.exact_coverage) fa.lds_tex_texels = 0;      // CHEAP coverage: one texel fetch per output pixel, served by L1/L2
+    fa.exact_coverage = r.exact_cov ? 1u : 0u;
     fa.may_blend = c->may_blend ? 1u : 0u;
     fa.skip_solid = wire_front ? 1u : 0u;
     fa.texels32 = c->d_texels32;
-    fa.ordered_all = ordered_all ? 1u : 0u;
-    fa.prio64 = prio64 ? 1u : 0u;
+    fa.ordered_all = r.ordered_all ? 1u : 0u;
+    fa.prio64 = r.prio64 ? 1u : 0u;
     fa.narrow_only = (c->route_off & B32_ROUTE_WIDE_GROUPS) ? 1u : 0u;
     fa.texmask = c->d_texmask;
     { const uint32_t words = c->pool_texels / 32 + 2; fa.mask_lds_words = (c->pool_texels && words <= MASK_LDS_MAX_WORDS) ? words : 0u; }
-    c->pending_may_redraw = !inline_bin;
-    fa.inline_bin = inline_bin ? 1u : 0u; fa.list_stride = list_stride; fa.spans = c->spans; fa.partials = c->partials;
-    if (inline_bin) fa.pair_vals = c->inline_lists;
-    fa.direct_bin = direct_bin ? 1u : 0u; fa.tile_fill = c->tile_fill; fa.epoch = c->epoch;
-    if (direct_bin) fa.pair_vals = c->direct_lists;
-    fa.gather_blend = (prio64 && with_class) ? 1u : 0u;
+    fa.inline_bin = r.inline_bin ? 1u : 0u; fa.list_stride = r.list_stride; fa.spans = c->spans; fa.partials = c->partials;
+    if (r.inline_bin) fa.pair_vals = c->inline_lists;
+    fa.direct_bin = r.direct_bin ? 1u : 0u; fa.tile_fill = c->tile_fill; fa.epoch = c->epoch;
+    if (r.direct_bin) fa.pair_vals = c->direct_lists;
+    fa.gather_blend = (r.prio64 && r.with_class) ? 1u : 0u;
     if (c->fmt8) fa.fp.xray = 0;                        // render_mesh: x-ray only changes culling; its stores keep their own depth tests
+    return fa;
+}
+
+static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st, const B32Fog* fog) {
+    hipStream_t s = c->stream;
+    const bool wire_back = st->backface_cull && st->backface_wireframe;      // render.rs:2577
+    const bool wire_front = st->wireframe_overlay != 0;                       // render.rs:2603 (an empty list draws nothing either way)
+    FrameParams fp = frame_params(c, cam, st, fog, wire_back || wire_front);
+    LightSet lset{};
+    int rc;
+    if ((rc = frame_lights(c, st, fp, lset))) return rc;
+    if ((rc = frame_buffers(c, fp, wire_back))) return rc;
+
+    const bool prof_sample = c->profile_level >= 1 && (c->prof_seq++ % c->prof_stride) == 0;
+    const bool prof_all = prof_sample && c->profile_level >= 2, prof_fill = prof_sample;
+    hipEvent_t* ev = nullptr;
+    if (prof_fill) {
+        if (!c->ev_created) {
+            for (auto& fr : c->ev) for (auto& e : fr) HIPCHK(c, hipEventCreate(&e));
+            c->ev_created = true;
+        }
+        ev = c->ev[c->ev_frames % EV_RING];
+    }
+
+    const SortScratch sc{ c->block_hist, c->hist_blocks, c->digit_total };
+    Route r;
+    if ((rc = plan_route(c, fp, sc, wire_front, r))) return rc;
+    const uint32_t ntiles = fp.tiles_x * fp.tiles_y;
+    c->last_local_sort = r.local_sort || r.want_prio64;                         // the global draw order is not materialised
+    c->last_exact = r.ordered_all ? true : (r.exact_cov && !fp.zmode);          // the ordered walk counts every store it performs
+    c->last_direct = r.direct_bin;
+    if (c->nf == 0) {                                                             // otherwise k_setup resets it (all but `sticky`)
+        HIPCHK(c, hipMemsetAsync(c->d_ctrl, 0, offsetof(Ctrl, sticky), s));
+        HIPCHK(c, hipMemsetAsync(&c->d_ctrl->fragments, 0, sizeof(unsigned long long), s));
+    }
+    const float* pos12 = nullptr;
+    if ((rc = frame_positions(c, fp, pos12))) return rc;
+
+    // ---- transform, cull, setup (+ tile binning of large meshes)
+    if (prof_all) HIPCHK(c, hipEventRecord(ev[0], s));
+    launch_setup(s, fp, c->d_verts, c->d_faces, c->d_tex, c->d_lights, lset, RecArrays{ c->crecs, c->srecs, c->xrecs }, r.db, c->shades, c->keys[0], c->spans, c->partials, c->d_ctrl, c->wire, c->n_cu, pos12);
+    if (prof_all) HIPCHK(c, hipEventRecord(ev[1], s));
+
+    // ---- tile lists
+    int cur = 0;
+    if (r.direct_bin) {
+        if (prof_all) HIPCHK(c, hipEventRecord(ev[2], s));
+        r.prio64 = true;
+    } else if (r.want_inline) {
+        const size_t need = (size_t)ntiles * r.list_stride + 64;
+        if (need > c->cap_inline) {
+            if ((rc = ensure_plain(c, c->inline_lists, need + need / 2))) return rc;
+            c->cap_inline = need + need / 2;
+        }
+        if (prof_all) HIPCHK(c, hipEventRecord(ev[2], s));
+        r.prio64 = r.inline_bin = true;
+    } else if (r.want_prio64) {
+        if (prof_all) HIPCHK(c, hipEventRecord(ev[2], s));
+        r.prio64 = launch_bin_spans(s, fp, c->spans, r.with_class ? c->keys[0] : nullptr, c->partials, c->d_ctrl, sc, (uint32_t)c->cap_pairs, c->ranges,
+                                    c->tile_mid, BLEND_SORT_CAP, c->pvals[0]);
+    }
+    if (!r.prio64 && (rc = bin_keyed(c, fp, r, sc, prof_all ? ev[2] : nullptr, cur))) return rc;
+    c->last_pair_buf = cur;
+    c->routes[r.direct_bin ? 0 : r.inline_bin ? 1 : r.prio64 ? 2 : 3]++;
+    c->pending_may_redraw = !r.inline_bin;
+    if (prof_fill) HIPCHK(c, hipEventRecord(ev[3], s));
+
+    // ---- coverage, shading, transparent pass
+    FillArgs fa = fill_args(c, fp, r, cur, wire_front);
     // a deferred Framebuffer::clear: folded into this frame's fused kernel when that kernel is the one that runs, the frame has no
     // depth buffer to reset and the clear was issued for this very band; else the clear launches go first
     if (c->clear_pending) {
         const bool has_z = c->zbuf && c->zbuf_valid;
-        if (prio64 && !wire_front && !ordered_all && !has_z && c->nf && ntiles && c->clear_y0 == c->band_y0 && c->clear_y1 == c->band_y1) {
+        if (r.prio64 && !wire_front && !r.ordered_all && !has_z && c->nf && ntiles && c->clear_y0 == c->band_y0 && c->clear_y1 == c->band_y1) {
             fa.clear_on = 1; fa.clear_rgba = c->clear_rgba; c->clear_pending = false;
         } else if ((rc = flush_clear(c))) return rc;
     }
     launch_fill(s, fa, c->n_cu, prof_fill ? ev[4] : nullptr);
+
+    // ---- wireframe phases
     if (fp.wire_collect && c->nf) {
         WireArgs wa{};
         wa.tris = c->wire; wa.nf = c->nf; wa.table_owner = c->wire_owner; wa.table_first = c->wire_first;
