@@ -656,6 +656,32 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
         const uint32_t P = inc - h;
         const float a0 = __uint_as_float(b.q0.z), b0 = __uint_as_float(b.q0.w), a1 = __uint_as_float(b.q1.x), b1 = __uint_as_float(b.q1.y);
         const uint32_t box = (cx0 - x_lo) | ((cx1 - x_lo) << 8) | ((cy0 - ty_top) << 16);      // 7+7+6 bits
+        // CHEAP sort-free coverage: every lane of a round makes ONE trip; what is left of the rows that need more (a fifth of them need a
+        // second trip, 3 % a third, but a round used to last as long as its longest row: three trips for an average need of 1.2) is queued
+        // -- one packed word per row remainder, the queue is a register: lane i holds entry i -- and worked off 64 at a time in rounds of
+        // their own, whose lanes are all busy.  The remainders refer to lanes of THIS batch (parameters come over ds_bpermute again), so
+        // the queue is drained before the next batch is loaded.
+        uint32_t lq = 0, lqn = 0;                       // leftover queue and its length (wave-uniform)
+        auto drain = [&]() {
+            const bool valid = lane < lqn;
+            const uint32_t s = valid ? (lq & 63u) : lane;
+            const uint32_t ry = (lq >> 6) & 63u, rx = (lq >> 12) & 127u;
+            const uint32_t n = valid ? (lq >> 19) : 0u;
+            const float sx3 = bpermf(s, __uint_as_float(b.q0.x)), sy3 = bpermf(s, __uint_as_float(b.q0.y));
+            const float sa0 = bpermf(s, a0), sb0 = bpermf(s, b0), sa1 = bpermf(s, a1), sb1 = bpermf(s, b1);
+            const float sinv = bpermf(s, __uint_as_float(b.q1.z));
+            const unsigned long long P = ((unsigned long long)bperm(s, my_key) << 32) | bperm(s, my_sid);
+            float z1 = 0.0f, z2 = 0.0f, z3 = 0.0f;
+            if (ZMODE) { z1 = bpermf(s, __uint_as_float(b.q5.y)); z2 = bpermf(s, __uint_as_float(b.q5.z)); z3 = bpermf(s, __uint_as_float(b.q5.w)); }
+            const float dx = (float)(rx + x_lo) - sx3, dy = (float)(ry + ty_top) - sy3;
+            float w0 = sa0 * dx + sb0 * dy, w1 = sa1 * dx + sb1 * dy;            // exact integers: the value the row's own walk would have reached
+            uint32_t addr = ry * STR64 + rx;
+            unsigned long long* top = reinterpret_cast<unsigned long long*>(tilebuf);
+            unsigned long long* sec = top + TILE_H * STR64;
+            for (uint32_t i = 0; __ballot(i < n); i += B32_TRIP)
+                cheap_trip<ZMODE>(top, sec, addr, w0, w1, sa0, sa1, sinv, i < n ? n - i : 0u, P, z1, z2, z3);
+            lqn = 0;
+        };
         for (uint32_t k0 = 0; k0 < R; k0 += 64) {
             // owner of item k0+lane: last surface s with h>0 and P[s] <= k
             const unsigned long long before = __ballot(h > 0 && P <= k0);
@@ -770,8 +796,20 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
                 unsigned long long* sec = top + TILE_H * STR64;
                 float z1 = 0.0f, z2 = 0.0f, z3 = 0.0f;
                 if (ZMODE) { z1 = bpermf(s, __uint_as_float(b.q5.y)); z2 = bpermf(s, __uint_as_float(b.q5.z)); z3 = bpermf(s, __uint_as_float(b.q5.w)); }
-                for (uint32_t i = 0; __ballot(i < n); i += B32_TRIP)
-                    cheap_trip<ZMODE>(top, sec, addr, w0, w1, sa0, sa1, sinv, i < n ? n - i : 0u, P, z1, z2, z3);
+                cheap_trip<ZMODE>(top, sec, addr, w0, w1, sa0, sa1, sinv, n, P, z1, z2, z3);          // (addr, w0, w1 now stand at pixel TRIP of the row)
+                const bool more = n > (uint32_t)B32_TRIP;
+                const unsigned long long mm = __ballot(more);
+                if (mm) {
+                    const uint32_t cnt = (uint32_t)__builtin_popcountll(mm);
+                    if (lqn + cnt > 64u) drain();
+                    // forward permute into the queue's free lanes [lqn, lqn + cnt); the lanes with nothing to push aim at the first lane
+                    // behind them (lane 0 when that is 64: then every lane pushes or lqn + cnt == 64 and lane 0 is not taken from `got`)
+                    const uint32_t entry = s | (ry << 6) | ((rx0 + (uint32_t)B32_TRIP) << 12) | ((n - (uint32_t)B32_TRIP) << 19);
+                    const uint32_t dst = more ? lqn + (uint32_t)__builtin_popcountll(mm & ((1ull << lane) - 1ull)) : ((lqn + cnt) & 63u);
+                    const uint32_t got = (uint32_t)__builtin_amdgcn_ds_permute((int)(dst << 2), (int)(more ? entry : 0u));
+                    if (lane >= lqn && lane < lqn + cnt) lq = got;
+                    lqn += cnt;
+                }
             } else {
                 // CHEAP coverage: two pixels per trip, so the two returning LDS atomics are in flight together and the wave
                 // waits once per pair (the second value is the same sequential accumulation w + a the reference performs)
@@ -794,6 +832,7 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
                 frags += (uint32_t)__builtin_amdgcn_readfirstlane((int)mine);
             }
         }
+        if (P64 && !EXACT && lqn) drain();             // (the row remainders of this batch: its registers are about to be reloaded)
         // surfaces whose edge walk must be replayed literally: wave-cooperative slow path
         unsigned long long sm = __ballot(slow);
         while (sm) {
