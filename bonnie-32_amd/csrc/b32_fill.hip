@@ -934,6 +934,38 @@ template <bool FMT8, int NT, bool ZMODE>
 __device__ __forceinline__ void shade_tile_p64(const FillArgs& a, const uint32_t* tilebuf, uint32_t e0, uint32_t e1, uint32_t x_lo, uint32_t x_hi,
                                                uint32_t y_lo, uint32_t y_hi, uint32_t ty_top, uint32_t tid, uint32_t lane, uint32_t TH);
 
+// k_setup's per-block counters (visible, transparent, NaN keys per class, bad vertex index) -> the frame's abort decision in misc[6]
+// (the reference panics before drawing on a bad vertex index, render.rs:2375, or when a sort comparison sees NaN, render.rs:2531);
+// workgroup 0 publishes the sums in Ctrl for the host.  Per-thread sums, a wave reduction, then one LDS atomic per wave and counter.
+template <int NT>
+__device__ __forceinline__ void reduce_setup_counters(const FillArgs& a, uint32_t* misc, uint32_t tid, uint32_t lane) {
+    if (tid < 5) misc[8 + tid] = 0;
+    __syncthreads();
+    const uint32_t npart = (a.fp.nf + 255) / 256;
+    uint32_t acc[5] = { 0, 0, 0, 0, 0 };
+    for (uint32_t b = tid; b < npart; b += NT)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) acc[k] += a.partials[b * 8 + k];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        for (int off = 32; off > 0; off >>= 1) acc[k] += __shfl_down(acc[k], off);
+        if (lane == 0 && acc[k]) atomicAdd(&misc[8 + k], acc[k]);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t t[5] = { misc[8], misc[9], misc[10], misc[11], misc[12] };
+        const uint32_t n_opq = t[0] - t[1];
+        const bool ab = t[4] != 0 || (t[2] && n_opq >= 2) || (t[3] && t[1] >= 2);
+        misc[6] = ab ? 1u : 0u;
+        if (blockIdx.x == 0) {
+            a.ctrl->n_visible = t[0]; a.ctrl->n_transparent = t[1]; a.ctrl->nan_opaque = t[2]; a.ctrl->nan_transparent = t[3];
+            a.ctrl->err_index = t[4] ? 1u : 0u; a.ctrl->n_opaque = n_opq;
+            if (ab) { a.ctrl->abort = 1; a.ctrl->sticky |= t[4] ? 1u : 2u; }
+        }
+    }
+    __syncthreads();
+}
+
 // Framebuffer::clear folded into the frame (FillArgs::clear_on): a frame that draws nothing (abort, redraw by the host) still owes the
 // caller the clear it took over from b32_fb_clear -- all the workgroups fill the band together.
 template <int NT>
@@ -971,40 +1003,27 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a_in) {
     const FrameParams& fp = a.fp;
     const uint32_t ntiles = fp.tiles_x * fp.tiles_y;
     phase_stamp(a.ctrl, ST_FILL);
+    bool reduce_late = false;
     if (P64 && (a.inline_bin || a.direct_bin)) {
         // there was no binning launch, so nobody has reduced k_setup's per-block counters yet.  Small mesh (inline_bin): every workgroup
         // derives the frame's abort decision from them (the reference panics before drawing on a bad vertex index, render.rs:2375, or
         // when a sort comparison sees NaN, render.rs:2531); workgroup 0 publishes the counters in Ctrl for the host.  Direct binning:
         // k_setup left the epoch of this frame in Events when it met one of those, and only then does every workgroup pay for the
         // reduction; otherwise workgroup 0 alone does it, for the host's counters.
-        bool reduce = a.inline_bin || blockIdx.x == 0;
+        bool reduce = a.inline_bin != 0;
         uint32_t redraw = 0;
         if (a.direct_bin) {
             const Events* ev = events_of(a.ctrl);
-            reduce = reduce || ev->bad_index == a.epoch || ev->nan_opaque == a.epoch || ev->nan_transparent == a.epoch;
+            reduce = ev->bad_index == a.epoch || ev->nan_opaque == a.epoch || ev->nan_transparent == a.epoch;
             redraw = (ev->overflow == a.epoch ? 2u : 0u) | (ev->long_transparent == a.epoch ? 1u : 0u);
+            // (no such event: the frame is not aborted, and workgroup 0 reduces the counters for the host AFTER its tiles -- with a
+            // million faces the reduction takes microseconds, and in a narrow band every workgroup has one tile: it was the kernel's
+            // critical path)
+            reduce_late = !reduce && blockIdx.x == 0;
         }
-        if (tid < 5) misc[8 + tid] = 0;
         if (tid == 0) misc[6] = 0;
         __syncthreads();
-        if (reduce) {
-        const uint32_t npart = (fp.nf + 255) / 256;
-        for (uint32_t b = tid; b < npart; b += NT)
-            for (int k = 0; k < 5; ++k) { const uint32_t v = a.partials[b * 8 + k]; if (v) atomicAdd((&misc[8 + k]), v); }
-        __syncthreads();
-        if (tid == 0) {
-            const uint32_t t[5] = { misc[8], misc[9], misc[10], misc[11], misc[12] };
-            const uint32_t n_opq = t[0] - t[1];
-            const bool ab = t[4] != 0 || (t[2] && n_opq >= 2) || (t[3] && t[1] >= 2);
-            misc[6] = ab ? 1u : 0u;
-            if (blockIdx.x == 0) {
-                a.ctrl->n_visible = t[0]; a.ctrl->n_transparent = t[1]; a.ctrl->nan_opaque = t[2]; a.ctrl->nan_transparent = t[3];
-                a.ctrl->err_index = t[4] ? 1u : 0u; a.ctrl->n_opaque = n_opq;
-                if (ab) { a.ctrl->abort = 1; a.ctrl->sticky |= t[4] ? 1u : 2u; }
-            }
-        }
-        __syncthreads();
-        }   // reduce
+        if (reduce) reduce_setup_counters<NT>(a, misc, tid, lane);
         if (misc[6] || redraw) {
             // nothing is drawn.  Direct binning: a region overflowed (the host redraws with larger regions: the longest list goes
             // back in Ctrl) or a transparent list is too long for k_blend's LDS sort (the host redraws with the global sort); either
@@ -1208,6 +1227,7 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a_in) {
         }
         __syncthreads();   // everyone is done with misc / tilebuf before the next tile
     }
+    if (P64 && reduce_late) { __syncthreads(); reduce_setup_counters<NT>(a, misc, tid, lane); }
     if (EXACT && !ZMODE) { // fragment-store count (wave-uniform per wave): one same-address atomic per workgroup
                            // (not defined in z-buffer mode: which fragments pass `z < zbuffer` depends on the sequential order)
         unsigned long long* wf = reinterpret_cast<unsigned long long*>(smem);
