@@ -31,10 +31,6 @@
 #define B32_P64_STRIDE 66        // row stride (u64 entries) of the 64-bit winner planes: 64 + 2, so the rows a surface touches at one
                                  // column fall into different LDS banks (measured: 72 -> 133 us, 66 -> 128 us; must stay <= 72, the allocation)
 #endif
-#ifndef B32_GRAB_DIV
-#define B32_GRAB_DIV 2          // list entries per grab ~ n / (B32_GRAB_DIV * waves).  Re-measured with the final kernel: C3 121 us at 1 and 2,
-                                // 126 at 3, 130 at 4; C5 (710 entries per tile) 290 us at 1, 257 at 2, 260 at 3, 262 at 4
-#endif
 
 namespace b32 {
 
@@ -628,8 +624,10 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
     unsigned long long frags = 0;
     const float ERR = K::ERR;
     const bool affine = a.fp.affine != 0;
-    // entries per grab: ~3 grabs per wave for balance, never more than the 64 lanes can hold
-    const uint32_t grab = min(64u, max(4u, (n_op + B32_GRAB_DIV * NW - 1) / (B32_GRAB_DIV * NW)));
+    // entries per grab: the fewest rounds of grabs that give every wave the same number of them -- m grabs per wave, each of
+    // ceil(n / (NW m)) <= 64 entries (500 entries, 8 waves: one grab of 63 each; 700: two of 44; a fixed divisor of 2 gave 32 / 44)
+    const uint32_t grab_m = max(1u, (n_op + NW * 64u - 1u) / (NW * 64u));
+    const uint32_t grab = min(64u, max(4u, (n_op + NW * grab_m - 1u) / (NW * grab_m)));
     for (;;) {
         uint32_t cs = 0;
         if (lane == 0) cs = atomicAdd(cursor, grab);
