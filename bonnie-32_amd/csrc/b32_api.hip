@@ -63,6 +63,7 @@ struct b32_ctx {
     float* shades = nullptr; size_t cap_shades = 0;
     uint32_t* counts = nullptr; uint32_t* block_sums = nullptr; uint32_t bin_blocks = 0;
     uint32_t* spans = nullptr;
+    uint32_t* face_of = nullptr;        // record slot -> face id (k_setup packs each wave's survivors to the front of its 64 slots)
     uint32_t* tile_mid = nullptr; size_t cap_tile_mid = 0;
     bool local_sort_ok = true;          // no tile list of this scene has exceeded the LDS sort capacity so far
     bool last_local_sort = false;       // the last frame took the fast path (draw order not materialised)
@@ -74,7 +75,8 @@ struct b32_ctx {
     // direct binning (DirectBin, b32_device.h): k_setup appends to fixed tile regions; the regions grow when a frame overflowed one
     uint32_t* direct_lists = nullptr; size_t cap_direct = 0;
     uint32_t* tile_fill = nullptr; size_t cap_tile_fill = 0;      // FILL_PAD words per tile, zero between frames
-    // packed positions for band-sharded frames (k_pack_positions): built on the second such frame of an uploaded mesh
+    // packed vertex streams of a resident mesh (k_pack_streams: nv positions of 12 B, then nv (u, v, rgba) of 12 B): built on the second
+    // frame of an uploaded mesh too large for the in-kernel list collection
     float* d_pos12 = nullptr; size_t cap_pos12 = 0; bool pos_valid = false; uint32_t band_frames = 0;
     // (per scene, swapped with the scene slots:)
     uint32_t direct_cap_opaque = 0;                               // opaque entries per tile region (0: sized from the mesh on first use)
@@ -240,7 +242,7 @@ void b32_destroy(b32_ctx* c) {
     void* ptrs[] = { c->fb_own, c->d_verts, c->d_faces, c->d_texels, c->d_tex, c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->crecs, c->srecs, c->xrecs,
                      c->shades, c->counts, c->block_sums, c->pkeys[0], c->pkeys[1], c->pvals[0], c->pvals[1], c->block_hist, c->ranges,
                      c->d_ctrl, c->d_consts, c->d_lights, c->digit_total, c->partials, c->vis, c->spans, c->tile_mid, c->zbuf,
-                     c->wire, c->wire_owner, c->wire_first, c->d_texels32, c->inline_lists, c->d_texmask, c->direct_lists, c->tile_fill, c->d_pos12 };
+                     c->wire, c->wire_owner, c->wire_first, c->d_texels32, c->inline_lists, c->d_texmask, c->direct_lists, c->tile_fill, c->d_pos12, c->face_of };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->ev_created) for (auto& fr : c->ev) for (auto& e : fr) if (e) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -537,6 +539,7 @@ static int upload_geometry(b32_ctx* c, const B32Vertex* v, uint32_t nv, const B3
         if ((rc = ensure_plain(c, c->xrecs, n))) return rc;
         if ((rc = ensure_plain(c, c->counts, n))) return rc;
         if ((rc = ensure_plain(c, c->spans, n))) return rc;
+        if ((rc = ensure_plain(c, c->face_of, n))) return rc;
         c->bin_blocks = (uint32_t)((n + 4095) / 4096);
         c->partial_blocks = (uint32_t)((n + 255) / 256);
         if ((rc = ensure_plain(c, c->partials, (size_t)c->partial_blocks * 8 + 8))) return rc;
@@ -910,22 +913,23 @@ static int plan_route(b32_ctx* c, FrameParams& fp, const SortScratch& sc, bool w
     return B32_OK;
 }
 
-// band-sharded frames of a mesh that stays (second such frame on): k_setup culls and bins every face from packed positions and reads
-// whole vertices only for the faces that reach this rank's rows
-static int frame_positions(b32_ctx* c, const FrameParams& fp, const float*& pos12) {
+// frames of a mesh that stays (second frame on) and is too large for the in-kernel list collection: k_setup culls and bins every face
+// from packed positions and reads the packed (u, v, rgba) only of the faces it draws (on a band-sharded frame: that reach this rank's rows)
+static int frame_positions(b32_ctx* c, const FrameParams& fp, const float*& pos12, const float*& attr12) {
     int rc;
-    pos12 = nullptr;
-    if (fp.band_only && c->nv && 2 * (c->band_y1 - c->band_y0) <= c->height) {       // (a band of most of the frame: nearly every face needs its whole vertices)
+    pos12 = attr12 = nullptr;
+    (void)fp;
+    if (c->nv && c->nf > 8192u && !(c->route_off & B32_ROUTE_PACKED_STREAMS)) {
         if (!c->pos_valid && c->band_frames >= 1) {
-            if ((size_t)c->nv * 3 > c->cap_pos12 || !c->d_pos12) {
-                if ((rc = ensure_plain(c, c->d_pos12, (size_t)c->nv * 3 + 16))) return rc;
-                c->cap_pos12 = (size_t)c->nv * 3;
+            if ((size_t)c->nv * 6 > c->cap_pos12 || !c->d_pos12) {
+                if ((rc = ensure_plain(c, c->d_pos12, (size_t)c->nv * 6 + 16))) return rc;
+                c->cap_pos12 = (size_t)c->nv * 6;
             }
-            launch_pack_positions(c->stream, c->d_verts, c->nv, c->d_pos12);
+            launch_pack_streams(c->stream, c->d_verts, c->nv, c->d_pos12, c->d_pos12 + (size_t)c->nv * 3);
             c->pos_valid = true;
         }
         c->band_frames++;
-        if (c->pos_valid) pos12 = c->d_pos12;
+        if (c->pos_valid) { pos12 = c->d_pos12; attr12 = c->d_pos12 + (size_t)c->nv * 3; }
     }
     return B32_OK;
 }
@@ -1034,12 +1038,13 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
         HIPCHK(c, hipMemsetAsync(c->d_ctrl, 0, offsetof(Ctrl, sticky), s));
         HIPCHK(c, hipMemsetAsync(&c->d_ctrl->fragments, 0, sizeof(unsigned long long), s));
     }
-    const float* pos12 = nullptr;
-    if ((rc = frame_positions(c, fp, pos12))) return rc;
+    const float *pos12 = nullptr, *attr12 = nullptr;
+    if ((rc = frame_positions(c, fp, pos12, attr12))) return rc;
 
     // ---- transform, cull, setup (+ tile binning of large meshes)
     if (prof_all) HIPCHK(c, hipEventRecord(ev[0], s));
-    launch_setup(s, fp, c->d_verts, c->d_faces, c->d_tex, c->d_lights, lset, RecArrays{ c->crecs, c->srecs, c->xrecs }, r.db, c->shades, c->keys[0], c->spans, c->partials, c->d_ctrl, c->wire, c->n_cu, pos12);
+    launch_setup(s, fp, c->d_verts, c->d_faces, c->d_tex, c->d_lights, lset, RecArrays{ c->crecs, c->srecs, c->xrecs }, r.db, c->shades, c->keys[0],
+                 r.direct_bin ? nullptr : c->spans /* (direct binning: nobody reads the spans) */, c->partials, c->d_ctrl, c->wire, c->n_cu, pos12, attr12, c->face_of);
     if (prof_all) HIPCHK(c, hipEventRecord(ev[1], s));
 
     // ---- tile lists
@@ -1368,8 +1373,12 @@ int b32_last_draw_order(b32_ctx* c, uint32_t* face_idx, uint32_t cap, uint32_t* 
     }
     const uint32_t m = cnt < cap ? cnt : cap;
     if (m && face_idx) {
+        // the device works on record slots (k_setup packs each wave's survivors to the front of its 64 slots): back to face ids
+        std::vector<uint32_t> fo(c->nf);
         HIPCHK(c, hipMemcpyAsync(face_idx, c->vals[0], (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(fo.data(), c->face_of, (size_t)c->nf * 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (uint32_t i = 0; i < m; ++i) face_idx[i] = face_idx[i] < c->nf ? fo[face_idx[i]] : 0xFFFFFFFFu;
     }
     return B32_OK;
 }

@@ -218,7 +218,8 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp_in, const B32Verte
                                                const TexDesc* __restrict__ tex, const B32Light* __restrict__ lights_mem, LightSet lset,
                                                RecArrays recs, DirectBin db, float* __restrict__ shades, uint32_t* __restrict__ keys,
                                                uint32_t* __restrict__ spans, uint32_t* __restrict__ partials, Ctrl* __restrict__ ctrl,
-                                               WireTri* __restrict__ wire, const float* __restrict__ pos12) {
+                                               WireTri* __restrict__ wire, const float* __restrict__ pos12, const float* __restrict__ attr12,
+                                               uint32_t* __restrict__ face_of) {
     FrameParams fp_plain = fp_in;                 // (dead code unless PLAIN)
     if (PLAIN) { fp_plain.ortho = 0; fp_plain.fixed_point = 1; fp_plain.has_fog = 0; fp_plain.wire_collect = 0; fp_plain.shading = B32_SHADE_NONE;
                  fp_plain.xray = 0; fp_plain.fmt8 = 0; fp_plain.n_lights = 0; }
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp_in, const B32Verte
         if (fin[g].live) {
             fin[g].bad = fin[g].w[0] >= fp.nv || fin[g].w[1] >= fp.nv || fin[g].w[2] >= fp.nv;       // index panic, render.rs:2375-2377
             if (!fin[g].bad) {
-                if (pos12) {          // band-sharded frame: positions only (12 B instead of a 36-B vertex); the rest once the face is known to reach the band
+                if (pos12) {          // packed streams of a resident mesh: positions only (12 B instead of a 36-B vertex); the rest once the face is known to be drawn
 #pragma unroll
                     for (int j = 0; j < 3; ++j) {
                         const float* pp = pos12 + (size_t)fin[g].w[j] * 3;
@@ -336,6 +337,12 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp_in, const B32Verte
             if (backface && fp.backface_cull && !fp.xray) keep = false;              // render.rs:2451-2453
             if (keep) {
                 visible = true;
+                // Record slot: the survivors of a wave's 64 faces are packed to the front of the wave's 64 slots (slot = first face id of
+                // the wave + rank among its survivors), so the records of a half-culled mesh fill whole cache lines instead of every other
+                // 32 / 64 bytes.  Slots are monotone in the face id, so everything downstream (tile lists, the priority's low word, the
+                // stable sorts) keeps face order; only b32_last_draw_order maps back (face_of).  (The ballot runs inside the branch: it
+                // sees exactly the lanes that got here.)
+                const uint32_t rslot = (f & ~63u) + (uint32_t)__builtin_popcountll(__ballot(true) & ((1ull << (threadIdx.x & 63u)) - 1ull));
                 transparent = (have_tex && tex_blend != B32_BLEND_OPAQUE) || face_blend != B32_BLEND_OPAQUE || editor_alpha < 255;  // :2403-2415
                 if (fp.fmt8) transparent = false;     // render_mesh computes has_transparency but never partitions (render.rs:2175-2184)
                 // Surface build: rendered backfaces swap v2/v3 and every per-vertex attribute (render.rs:2453-2479)
@@ -366,11 +373,11 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp_in, const B32Verte
                 bool needs_dither = false;
                 r.inv_area = 0.0f; r.w0_start = r.w1_start = 0.0f; r.flags = 0;
                 if (need_rec) {
-                if (pos12) {          // (band-sharded frame) the face reaches this rank's rows: now its UVs and vertex colours
+                if (pos12) {          // packed streams: the survivor's UVs and vertex colours only now (12 B per vertex, culled faces never fetch them)
 #pragma unroll
                     for (int j = 0; j < 3; ++j) {
-                        const float* vp = reinterpret_cast<const float*>(verts) + (size_t)vi[j] * 9;
-                        uvx[j] = vp[3]; uvy[j] = vp[4]; col[j] = reinterpret_cast<const uint32_t*>(vp)[8];
+                        const float* ap = attr12 + (size_t)vi[j] * 3;
+                        uvx[j] = ap[0]; uvy[j] = ap[1]; col[j] = reinterpret_cast<const uint32_t*>(ap)[2];
                     }
                 }
                 if (fp.has_fog) {
@@ -428,7 +435,7 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp_in, const B32Verte
                         wn[j] = { vp[5], vp[6], vp[7] };
                         if (backface) wn[j] = scale3(wn[j], -1.0f);
                     }
-                    float* sh = shades + (size_t)f * 9;
+                    float* sh = shades + (size_t)rslot * 9;
                     if (fp.shading == B32_SHADE_FLAT) {                                             // :1466-1469
                         V3 center = scale3(add3(add3(wpos[i1], wpos[i2]), wpos[i3]), 1.0f / 3.0f);
                         V3 nrm = normalize3(scale3(add3(add3(wn[i1], wn[i2]), wn[i3]), 1.0f / 3.0f));
@@ -467,17 +474,17 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp_in, const B32Verte
                     c0.x = fits ? pk16(v1.x, v1.y) : COV_WIDE; c0.y = fits ? pk16(v2.x, v2.y) : 0u; c0.z = fits ? pk16(v3.x, v3.y) : 0u;
                     c0.w = __float_as_uint(r.inv_area);
                     c1 = make_uint4(r.bbx, r.bby, key, r.flags);
-                    uint4* cp = reinterpret_cast<uint4*>(recs.cov + f);
+                    uint4* cp = reinterpret_cast<uint4*>(recs.cov + rslot);
                     cp[0] = c0; cp[1] = c1;
                     const uint32_t slot = have_tex ? tid : F_TEX_NONE;
-                    const uint32_t sh = (black_tr ? SH_BLACK_TR : 0u) | (needs_dither ? SH_DITHER : 0u) | (slow ? SH_SLOW : 0u);
-                    uint4* sp = reinterpret_cast<uint4*>(recs.shade + f);
+                    const uint32_t shf = (black_tr ? SH_BLACK_TR : 0u) | (needs_dither ? SH_DITHER : 0u) | (slow ? SH_SLOW : 0u);
+                    uint4* sp = reinterpret_cast<uint4*>(recs.shade + rslot);
                     sp[0] = make_uint4(__float_as_uint(v1.x), __float_as_uint(v1.y), __float_as_uint(v2.x), __float_as_uint(v2.y));
                     sp[1] = make_uint4(__float_as_uint(v3.x), __float_as_uint(v3.y), __float_as_uint(r.inv_area), (col[i1] & 0xFFFFFFu) | ((slot & 0xFFu) << 24));
                     sp[2] = make_uint4(__float_as_uint(uvx[i1]), __float_as_uint(uvx[i2]), __float_as_uint(uvx[i3]), __float_as_uint(uvy[i1]));
-                    sp[3] = make_uint4(__float_as_uint(uvy[i2]), __float_as_uint(uvy[i3]), (col[i2] & 0xFFFFFFu) | ((slot >> 8) << 24), (col[i3] & 0xFFFFFFu) | (sh << 24));
+                    sp[3] = make_uint4(__float_as_uint(uvy[i2]), __float_as_uint(uvy[i3]), (col[i2] & 0xFFFFFFu) | ((slot >> 8) << 24), (col[i3] & 0xFFFFFFu) | (shf << 24));
                     if (fp.zmode || !fp.affine || slow) {
-                        uint4* xp = reinterpret_cast<uint4*>(recs.aux + f);
+                        uint4* xp = reinterpret_cast<uint4*>(recs.aux + rslot);
                         xp[0] = make_uint4(__float_as_uint(1.0f / v1.z), __float_as_uint(1.0f / v2.z), __float_as_uint(1.0f / v3.z), __float_as_uint(r.w0_start));   // :1546-1548
                         xp[1] = make_uint4(__float_as_uint(r.w1_start), 0u, 0u, 0u);
                     }
@@ -495,7 +502,7 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp_in, const B32Verte
                         if (k) agg_issue(db.fill, tile * FILL_PAD + (db_cls ? 1u : 0u), act, threadIdx.x & 63u, g);
                         const uint32_t pos = agg_position(g);
                         if (act) {
-                            if (pos < cap) db.lists[(size_t)tile * db.region + (db_cls ? db.region - 1u - pos : pos)] = f;
+                            if (pos < cap) db.lists[(size_t)tile * db.region + (db_cls ? db.region - 1u - pos : pos)] = rslot;
                             else over = true;
                             if (++tx > tx1) { tx = tx0; ++ty; }
                         }
@@ -504,12 +511,20 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp_in, const B32Verte
                 }
             }
         }
-        keys[f] = key;
-        spans[f] = span;
         if (fp.wire_collect && bad_index) wire[f].kind = 0;
     }
     // frame counters: ballot per wave -> LDS -> one 5-word record per block (reduced by k_after_setup; no atomics)
     const unsigned long long mv = __ballot(visible), mt = __ballot(transparent);
+    {   // painter's key and tile span per SLOT (see `slot` above): survivors at the front of the wave's 64 slots, KEY_INVALID behind them
+        const uint32_t lane = threadIdx.x & 63u, nvis = (uint32_t)__popcll(mv), wbase = f - lane;
+        if (visible) {
+            const uint32_t slot = wbase + (uint32_t)__popcll(mv & ((1ull << lane) - 1ull));
+            keys[slot] = key;
+            if (spans) spans[slot] = span;
+            if (face_of) face_of[slot] = f;
+        }
+        if (in.live && lane >= nvis) { keys[wbase + lane] = KEY_INVALID; if (spans) spans[wbase + lane] = 0xFFFFFFFFu; }
+    }
     const unsigned long long mn_op = __ballot(nan_key && !transparent), mn_tr = __ballot(nan_key && transparent), mb = __ballot(bad_index);
     const uint32_t wv = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
@@ -534,15 +549,15 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp_in, const B32Verte
 
 void launch_setup(hipStream_t s, const FrameParams& fp, const B32Vertex* verts, const B32Face* faces, const TexDesc* tex,
                   const B32Light* lights, const LightSet& ls, RecArrays recs, const DirectBin& db, float* shades, uint32_t* keys, uint32_t* spans, uint32_t* partials,
-                  Ctrl* ctrl, WireTri* wire, int n_cu, const float* pos12) {
+                  Ctrl* ctrl, WireTri* wire, int n_cu, const float* pos12, const float* attr12, uint32_t* face_of) {
     (void)n_cu;
     if (fp.nf == 0) return;
     const bool plain = fp.fixed_point && !fp.ortho && !fp.has_fog && !fp.wire_collect && fp.shading == B32_SHADE_NONE && !fp.xray && !fp.fmt8;
     // one face per thread: 52 VGPRs in the plain form = 8 waves per SIMD (two faces per thread with their loads issued up front: 73 VGPRs,
     // 43 us instead of 39 at 1 M faces; three: 49 us)
     const dim3 g1((fp.nf + 255) / 256);
-    if (plain) hipLaunchKernelGGL((k_setup<1, true>), g1, dim3(256), 0, s, fp, verts, faces, tex, lights, ls, recs, db, shades, keys, spans, partials, ctrl, wire, pos12);
-    else hipLaunchKernelGGL((k_setup<1, false>), g1, dim3(256), 0, s, fp, verts, faces, tex, lights, ls, recs, db, shades, keys, spans, partials, ctrl, wire, pos12);
+    if (plain) hipLaunchKernelGGL((k_setup<1, true>), g1, dim3(256), 0, s, fp, verts, faces, tex, lights, ls, recs, db, shades, keys, spans, partials, ctrl, wire, pos12, attr12, face_of);
+    else hipLaunchKernelGGL((k_setup<1, false>), g1, dim3(256), 0, s, fp, verts, faces, tex, lights, ls, recs, db, shades, keys, spans, partials, ctrl, wire, pos12, attr12, face_of);
 }
 
 // ---------------------------------------------------------------- stage tap: project_fixed for n positions
@@ -638,16 +653,18 @@ __global__ __launch_bounds__(256) void k_upload(const uint4* __restrict__ arena,
         for (uint32_t i = gtid; i < segs.n16[k]; i += nthr) dst[i] = src[i];
     }
 }
-// Packed vertex positions (12 bytes each) of a resident scene, for the band-sharded frames' k_setup: every rank culls and bins ALL the
-// faces, but reads a whole 36-byte vertex only for those that reach its own rows.
-__global__ void k_pack_positions(const B32Vertex* __restrict__ verts, uint32_t nv, float* __restrict__ pos12) {
+// Packed vertex streams of a resident scene (structure of arrays, built once from the uploaded B32Vertex array): positions, 12 bytes
+// each, which k_setup reads for EVERY face, and (u, v, rgba), 12 bytes each, which it reads only for the faces that survive the cull
+// (and, on a band-sharded frame, reach this rank's rows).  The 12 bytes of normal stay in the B32Vertex array (lit frames only).
+__global__ void k_pack_streams(const B32Vertex* __restrict__ verts, uint32_t nv, float* __restrict__ pos12, float* __restrict__ attr12) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nv) return;
     const float* vp = reinterpret_cast<const float*>(verts) + (size_t)i * 9;
     pos12[3 * (size_t)i] = vp[0]; pos12[3 * (size_t)i + 1] = vp[1]; pos12[3 * (size_t)i + 2] = vp[2];
+    attr12[3 * (size_t)i] = vp[3]; attr12[3 * (size_t)i + 1] = vp[4]; attr12[3 * (size_t)i + 2] = vp[8];      // u, v, rgba (bit copy)
 }
-void launch_pack_positions(hipStream_t s, const B32Vertex* verts, uint32_t nv, float* pos12) {
-    if (nv) hipLaunchKernelGGL(k_pack_positions, dim3((nv + 255) / 256), dim3(256), 0, s, verts, nv, pos12);
+void launch_pack_streams(hipStream_t s, const B32Vertex* verts, uint32_t nv, float* pos12, float* attr12) {
+    if (nv) hipLaunchKernelGGL(k_pack_streams, dim3((nv + 255) / 256), dim3(256), 0, s, verts, nv, pos12, attr12);
 }
 __global__ void k_ctrl_out(Ctrl* __restrict__ ctrl, uint4* __restrict__ dst) {
     if (threadIdx.x == 0) { unsigned long long* t = reinterpret_cast<Stamps*>(ctrl + 1)->t; if (!t[ST_END]) t[ST_END] = wall_clock64(); }

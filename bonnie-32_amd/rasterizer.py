@@ -74,7 +74,7 @@ class Context:
 
     ROUTES = ("direct_bin", "inline_bin", "counting_sort", "keyed", "redraw_region", "redraw_global_sort", "redraw_pairs")
 
-    ROUTE_SORT_FREE, ROUTE_CUT_TILES, ROUTE_INLINE_BIN, ROUTE_DIRECT_BIN, ROUTE_WIDE_GROUPS = 1, 2, 4, 8, 16
+    ROUTE_SORT_FREE, ROUTE_CUT_TILES, ROUTE_INLINE_BIN, ROUTE_DIRECT_BIN, ROUTE_WIDE_GROUPS, ROUTE_PACKED_STREAMS, ROUTE_PIPELINE = 1, 2, 4, 8, 16, 32, 64
 
     def set_routes(self, off_mask):
         """b32_set_routes: switch internal routes off (ROUTE_* bits); results are identical on every route."""

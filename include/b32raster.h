@@ -248,6 +248,8 @@ unsigned long long b32_route_count(const b32_ctx* ctx, int which);
 #define B32_ROUTE_INLINE_BIN  4u   /* small meshes: tile lists collected inside the fill kernel -> binning launches                */
 #define B32_ROUTE_DIRECT_BIN  8u   /* large meshes: binning inside the setup kernel -> counting-sort launches                      */
 #define B32_ROUTE_WIDE_GROUPS 16u  /* 16-wave workgroups of the fused kernel when tiles are few -> always 8 waves                  */
+#define B32_ROUTE_PACKED_STREAMS 32u /* resident large meshes: packed position / attribute streams for the setup kernel -> B32Vertex array */
+#define B32_ROUTE_PIPELINE    64u  /* setup kernel of the next frame on a second stream beside the fill of the current one -> one stream */
 int b32_set_routes(b32_ctx* ctx, uint32_t off_mask);
 /* CHEAP coverage (inside test only, texel rule applied to the winner) is used while every texture has at most 1/den skippable texels
  * (default 64); applies to textures uploaded after the call.  den = 0: B32_E_ARG. */
