@@ -126,6 +126,7 @@ SYMBOLS = [
     ("b32_device_constants", C.c_int, [_P, C.POINTER(C.c_char_p), _P, _P, C.c_uint32, C.POINTER(C.c_uint32), _P, _P]),
     ("b32_set_profiling", C.c_int, [_P, C.c_int]),
     ("b32_set_profiling_stride", C.c_int, [_P, C.c_uint32]),
+    ("b32_set_pipeline_gate", C.c_int, [_P, C.c_uint32]),
     ("b32_set_fragment_counting", C.c_int, [_P, C.c_int]),
 ]
 

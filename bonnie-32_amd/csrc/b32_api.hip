@@ -18,11 +18,34 @@ constexpr int EV_RING = 64;     // frames of per-phase events kept between two b
 constexpr int EV_PER_FRAME = 6; // start | setup | sort | bin | cover | shade+blend
 }
 
+// Everything k_setup WRITES for one frame and the fill kernels read: a context owns two of these so that the setup kernel of frame
+// i + 1 can run on a second stream beside the fill of frame i (see pipeline_begin).  The context's own members of the same names are
+// the set of the frame being enqueued; `alt` holds the other one (swap_sets).
+struct FrameSet {
+    uint32_t* keys0 = nullptr; CovRec* crecs = nullptr; ShadeRec* srecs = nullptr; AuxRec* xrecs = nullptr;
+    uint32_t* spans = nullptr; uint32_t* face_of = nullptr; uint32_t* partials = nullptr; size_t cap_work = 0;
+    float* shades = nullptr; size_t cap_shades = 0;
+    uint32_t* direct_lists = nullptr; size_t cap_direct = 0;
+    uint32_t* tile_fill = nullptr; size_t cap_tile_fill = 0;
+    Ctrl* d_ctrl = nullptr;
+    hipEvent_t ev_setup = nullptr, ev_done = nullptr;      // k_setup finished (side stream) / last fill reading this set finished (main stream)
+    bool in_flight = false;                                  // a frame was enqueued on this set since the last b32_frame_finish
+};
+
 struct b32_ctx {
     int device = 0;
     int n_cu = 256;
     int last_hip = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    // two frames in flight: the setup kernel of the next frame on `side` beside the fill of the current one on `stream`
+    hipStream_t side = nullptr; hipEvent_t ev_main = nullptr;
+    FrameSet alt;                        // the other frame set (allocated on first use)
+    hipEvent_t ev_setup = nullptr, ev_done = nullptr; bool set_in_flight = false;     // (members of the current set, see FrameSet)
+    bool side_dirty = true;              // something k_setup reads was written on `stream` since the side stream last waited for it
+    uint32_t gate_permille = 300;        // b32_set_pipeline_gate: hold the next setup kernel until that share of the previous fill's tiles has started
+    uint32_t last_cover_tiles = 0, last_cover_groups = 0;   // tile count / workgroups of the previous frame's fused kernel (0: it had none)
+    bool pipelined = false;              // the frame being enqueued runs its k_setup on the side stream
+    unsigned long long pipelined_frames = 0;
 
     // framebuffer
     uint32_t width = 0, height = 0;
@@ -52,7 +75,7 @@ struct b32_ctx {
     // content.  A call that passes the same set again (the reference's callers pass the same Texture15 slice every frame) skips the
     // texel copies and the skippable-texel count; any change of pointer, size or content re-uploads.
     struct TexSig { const void* ptr; uint32_t w, h, blend; uint64_t hash; };
-    std::vector<TexSig> tex_sig; bool tex_sig_valid = false; bool tex_sig_rgba = false;
+    std::vector<TexSig> tex_sig; bool tex_sig_valid = false;
     int count_fragments = 0;            // 1: exact fragment-store count every frame (EXACT coverage); instrumentation, off by default
     bool last_exact = false;            // the last frame ran EXACT coverage in painter's mode (B32Timings.fragments is exact)
 
@@ -143,7 +166,7 @@ struct b32_scene {
     bool fmt8 = false, blend8 = false, have_scene = false, may_blend = true, cheap_ok = false, local_sort_ok = true, tex_blend_any = false;
     uint32_t direct_cap_opaque = 0, direct_ntiles = 0; bool direct_ok = true;
     float* d_pos12 = nullptr; size_t cap_pos12 = 0; bool pos_valid = false; uint32_t band_frames = 0;
-    std::vector<b32_ctx::TexSig> tex_sig; bool tex_sig_valid = false, tex_sig_rgba = false;
+    std::vector<b32_ctx::TexSig> tex_sig; bool tex_sig_valid = false;
 };
 
 #define HIPCHK(ctx, expr)                                                 \
@@ -155,6 +178,7 @@ struct b32_scene {
 template <typename T>
 static int ensure(b32_ctx* c, T*& p, size_t& cap, size_t need) {
     if (need <= cap && p) return B32_OK;
+    c->side_dirty = true;
     if (p) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(p)); p = nullptr; cap = 0; }
     size_t n = need + need / 4 + 16;
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(T)));
@@ -163,8 +187,70 @@ static int ensure(b32_ctx* c, T*& p, size_t& cap, size_t need) {
 }
 template <typename T>
 static int ensure_plain(b32_ctx* c, T*& p, size_t count) {   // exact-size (re)allocation without capacity tracking
+    c->side_dirty = true;
     if (p) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(p)); p = nullptr; }
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T)));
+    return B32_OK;
+}
+
+
+// ------------------------------------------------------------------ two frames in flight
+// The fused fill kernel leaves most CUs idle in its last fifth (the tile queue's tail), and k_setup of the NEXT frame needs nothing
+// from it: with two frame sets (everything k_setup writes, FrameSet) the setup kernel of frame i + 1 runs on a second stream beside the
+// fill of frame i.  Orders kept by events: setup(i) -> fill(i) (ev_setup), fill(i) -> setup(i + 2) on the same set (ev_done), and
+// anything enqueued on the main stream that k_setup reads (uploads, packed streams, light lists, list-space memsets) -> the next
+// setup (ev_main, only when `side_dirty`).  The main stream always waits for the frame's setup before enqueue_frame returns, so a
+// synchronisation of the main stream still covers everything this context has in flight.
+static void swap_sets(b32_ctx* c) {
+    FrameSet& a = c->alt;
+    std::swap(c->keys[0], a.keys0); std::swap(c->crecs, a.crecs); std::swap(c->srecs, a.srecs); std::swap(c->xrecs, a.xrecs);
+    std::swap(c->spans, a.spans); std::swap(c->face_of, a.face_of); std::swap(c->partials, a.partials);
+    std::swap(c->shades, a.shades); std::swap(c->cap_shades, a.cap_shades);
+    std::swap(c->direct_lists, a.direct_lists); std::swap(c->cap_direct, a.cap_direct);
+    std::swap(c->tile_fill, a.tile_fill); std::swap(c->cap_tile_fill, a.cap_tile_fill);
+    std::swap(c->d_ctrl, a.d_ctrl);
+    std::swap(c->ev_setup, a.ev_setup); std::swap(c->ev_done, a.ev_done); std::swap(c->set_in_flight, a.in_flight);
+}
+static void free_alt(b32_ctx* c) {          // (the caller has drained both streams)
+    FrameSet& a = c->alt;
+    void* ptrs[] = { a.keys0, a.crecs, a.srecs, a.xrecs, a.spans, a.face_of, a.partials, a.shades, a.direct_lists, a.tile_fill };
+    for (void* q : ptrs) if (q) (void)hipFree(q);
+    a.keys0 = nullptr; a.crecs = nullptr; a.srecs = nullptr; a.xrecs = nullptr; a.spans = nullptr; a.face_of = nullptr; a.partials = nullptr;
+    a.shades = nullptr; a.cap_shades = 0; a.direct_lists = nullptr; a.cap_direct = 0; a.tile_fill = nullptr; a.cap_tile_fill = 0; a.cap_work = 0;
+}
+// side stream, events and the second set's per-face buffers (sized like the current set's)
+static int pipeline_ensure(b32_ctx* c) {
+    if (!c->side) {
+        // lowest priority: while the fill kernel has workgroups to place, they go first; the setup kernel takes what is left
+        int prio_least = 0, prio_greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+        HIPCHK(c, hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, prio_least));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_setup, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&c->alt.ev_setup, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&c->alt.ev_done, hipEventDisableTiming));
+    }
+    FrameSet& a = c->alt;
+    if (!a.d_ctrl) {
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&a.d_ctrl), sizeof(Ctrl) + sizeof(Stamps) + sizeof(Events)));
+        HIPCHK(c, hipMemsetAsync(a.d_ctrl, 0, sizeof(Ctrl) + sizeof(Stamps) + sizeof(Events), c->stream));
+        c->side_dirty = true;
+    }
+    if (a.cap_work < c->cap_work || !a.crecs) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        free_alt(c);
+        const size_t n = c->cap_work;
+        int rc;
+        if ((rc = ensure_plain(c, a.keys0, n))) return rc;
+        if ((rc = ensure_plain(c, a.crecs, n))) return rc;
+        if ((rc = ensure_plain(c, a.srecs, n))) return rc;
+        if ((rc = ensure_plain(c, a.xrecs, n))) return rc;
+        if ((rc = ensure_plain(c, a.spans, n))) return rc;
+        if ((rc = ensure_plain(c, a.face_of, n))) return rc;
+        if ((rc = ensure_plain(c, a.partials, (size_t)((n + 255) / 256) * 8 + 8))) return rc;
+        a.cap_work = n;
+    }
     return B32_OK;
 }
 
@@ -244,6 +330,11 @@ void b32_destroy(b32_ctx* c) {
                      c->d_ctrl, c->d_consts, c->d_lights, c->digit_total, c->partials, c->vis, c->spans, c->tile_mid, c->zbuf,
                      c->wire, c->wire_owner, c->wire_first, c->d_texels32, c->inline_lists, c->d_texmask, c->direct_lists, c->tile_fill, c->d_pos12, c->face_of };
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (c->side) (void)hipStreamSynchronize(c->side);
+    free_alt(c);
+    if (c->alt.d_ctrl) (void)hipFree(c->alt.d_ctrl);
+    for (hipEvent_t e : { c->ev_main, c->ev_setup, c->ev_done, c->alt.ev_setup, c->alt.ev_done }) if (e) (void)hipEventDestroy(e);
+    if (c->side) (void)hipStreamDestroy(c->side);
     if (c->ev_created) for (auto& fr : c->ev) for (auto& e : fr) if (e) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->stage_host) (void)hipHostFree(c->stage_host);
@@ -281,6 +372,7 @@ int b32_set_stream(b32_ctx* c, void* s) {
     { const int rc = flush_clear(c); if (rc) return rc; }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->stream = s ? reinterpret_cast<hipStream_t>(s) : c->own_stream;
+    c->side_dirty = true;
     return B32_OK;
 }
 int b32_synchronize(b32_ctx* c) {
@@ -341,6 +433,7 @@ int b32_fb_size(const b32_ctx* c, uint32_t* w, uint32_t* h) {
 }
 int b32_set_band(b32_ctx* c, uint32_t y0, uint32_t y1) {
     if (!c || !c->fb || y0 > y1 || y1 > c->height) return B32_E_ARG;
+    { const int rcs = settle_pending(c); if (rcs) return rcs; }       // (a redraw of the pending frame belongs to the band it was enqueued for)
     { const int rcf = flush_clear(c); if (rcf) return rcf; }          // (a deferred clear belongs to the rows of the band it was issued for)
     c->band_y0 = y0; c->band_y1 = y1; c->band_set = !(y0 == 0 && y1 == c->height);
     return B32_OK;
@@ -473,6 +566,7 @@ int b32_fb_download(b32_ctx* c, uint8_t* rgba) {
 // offsets are multiples of 16 B).
 static int h2d(b32_ctx* c, void* dst, const void* src, size_t bytes) {
     if (!bytes) return B32_OK;
+    c->side_dirty = true;
     const size_t padded = (bytes + 15) & ~(size_t)15;
     if (c->stage_active && c->stage_segs.count < 16 && c->stage_used + padded <= c->stage_cap && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
         std::memcpy(c->stage_host + c->stage_used, src, bytes);
@@ -605,6 +699,9 @@ static uint64_t hash_bytes(const void* data, size_t n) {
 int b32_scene_upload(b32_ctx* c, const B32Vertex* v, uint32_t nv, const B32Face* f, uint32_t nf, const B32Texture15* tex, uint32_t nt) {
     if (!c || (nt && !tex)) return B32_E_ARG;
     (void)hipSetDevice(c->device);
+    // a pending frame that may still be redrawn (overflowed tile regions / pair buffers) is drawn from the RESIDENT scene: settle it
+    // before that scene is replaced, or the redraw would draw the new mesh in its place (and the new mesh twice)
+    { const int rcs = settle_pending(c); if (rcs) return rcs; }
     c->have_scene = false;
     std::vector<uint32_t> w(nt), h(nt), bl(nt);
     for (uint32_t i = 0; i < nt; ++i) {
@@ -614,7 +711,7 @@ int b32_scene_upload(b32_ctx* c, const B32Vertex* v, uint32_t nv, const B32Face*
     // texture cache: the same set as the pool holds (pointer, size, blend mode, content hash of every texture)?
     std::vector<b32_ctx::TexSig> sig(nt);
     for (uint32_t i = 0; i < nt; ++i) sig[i] = { tex[i].pixels, w[i], h[i], bl[i], hash_bytes(tex[i].pixels, (size_t)w[i] * h[i] * 2) };
-    bool hit = c->tex_sig_valid && !c->tex_sig_rgba && c->tex_sig.size() == nt && c->nt == nt && c->d_texels && c->d_tex;
+    bool hit = c->tex_sig_valid && !(c->route_off & B32_ROUTE_TEX_CACHE) && c->tex_sig.size() == nt && c->nt == nt && c->d_texels && c->d_tex;
     for (uint32_t i = 0; hit && i < nt; ++i) {
         const b32_ctx::TexSig& o = c->tex_sig[i];
         hit = o.ptr == sig[i].ptr && o.w == sig[i].w && o.h == sig[i].h && o.blend == sig[i].blend && o.hash == sig[i].hash;
@@ -634,7 +731,7 @@ int b32_scene_upload(b32_ctx* c, const B32Vertex* v, uint32_t nv, const B32Face*
             for (size_t k = 0; k < n; ++k) skippable += (px[k] & 0x7FFF) == 0;
             if (n == 0 || skippable * c->cheap_den > n) c->cheap_ok = false;
         }
-        c->tex_sig.swap(sig); c->tex_sig_valid = true; c->tex_sig_rgba = false;
+        c->tex_sig.swap(sig); c->tex_sig_valid = true;
     }
     if ((rc = upload_geometry(c, v, nv, f, nf))) return rc;
     for (uint32_t i = 0; i < nt; ++i) if (bl[i] != B32_BLEND_OPAQUE) c->may_blend = true;
@@ -646,6 +743,9 @@ int b32_scene_upload(b32_ctx* c, const B32Vertex* v, uint32_t nv, const B32Face*
 int b32_scene_upload_rgba(b32_ctx* c, const B32Vertex* v, uint32_t nv, const B32Face* f, uint32_t nf, const B32Texture* tex, uint32_t nt) {
     if (!c || (nt && !tex)) return B32_E_ARG;
     (void)hipSetDevice(c->device);
+    // a pending frame that may still be redrawn (overflowed tile regions / pair buffers) is drawn from the RESIDENT scene: settle it
+    // before that scene is replaced, or the redraw would draw the new mesh in its place (and the new mesh twice)
+    { const int rcs = settle_pending(c); if (rcs) return rcs; }
     c->have_scene = false;
     std::vector<uint32_t> w(nt), h(nt), bl(nt);
     for (uint32_t i = 0; i < nt; ++i) {
@@ -682,6 +782,9 @@ int b32_scene_upload_rgba(b32_ctx* c, const B32Vertex* v, uint32_t nv, const B32
 int b32_scene_upload_indexed(b32_ctx* c, const B32Vertex* v, uint32_t nv, const B32Face* f, uint32_t nf, const B32IndexedTexture* tex, uint32_t nt) {
     if (!c || (nt && !tex)) return B32_E_ARG;
     (void)hipSetDevice(c->device);
+    // a pending frame that may still be redrawn (overflowed tile regions / pair buffers) is drawn from the RESIDENT scene: settle it
+    // before that scene is replaced, or the redraw would draw the new mesh in its place (and the new mesh twice)
+    { const int rcs = settle_pending(c); if (rcs) return rcs; }
     c->have_scene = false;
     std::vector<uint32_t> w(nt), h(nt), bl(nt);
     for (uint32_t i = 0; i < nt; ++i) {
@@ -783,6 +886,7 @@ static int frame_lights(b32_ctx* c, const B32Settings* st, FrameParams& fp, Ligh
             if ((rc = ensure(c, c->d_lights, c->cap_lights, (size_t)fp.n_lights))) return rc;
             HIPCHK(c, hipStreamSynchronize(c->stream));
             HIPCHK(c, hipMemcpy(c->d_lights, st->lights, fp.n_lights * sizeof(B32Light), hipMemcpyHostToDevice));
+            c->side_dirty = true;
             c->h_lights.assign(st->lights, st->lights + fp.n_lights);
         }
     }
@@ -902,6 +1006,7 @@ static int plan_route(b32_ctx* c, FrameParams& fp, const SortScratch& sc, bool w
                 if ((rc = ensure_plain(c, c->tile_fill, need_fill * 2))) return rc;
                 c->cap_tile_fill = need_fill * 2;
                 HIPCHK(c, hipMemsetAsync(c->tile_fill, 0, c->cap_tile_fill * sizeof(uint32_t), c->stream));   // zero from here on: k_cover re-zeroes what k_setup counted
+                c->side_dirty = true;
             }
             if (++c->epoch == 0) c->epoch = 1;
             r.db.fill = c->tile_fill; r.db.lists = c->direct_lists; r.db.region = region; r.db.cap_opaque = cap_o;
@@ -926,7 +1031,7 @@ static int frame_positions(b32_ctx* c, const FrameParams& fp, const float*& pos1
                 c->cap_pos12 = (size_t)c->nv * 6;
             }
             launch_pack_streams(c->stream, c->d_verts, c->nv, c->d_pos12, c->d_pos12 + (size_t)c->nv * 3);
-            c->pos_valid = true;
+            c->pos_valid = true; c->side_dirty = true;
         }
         c->band_frames++;
         if (c->pos_valid) { pos12 = c->d_pos12; attr12 = c->d_pos12 + (size_t)c->nv * 3; }
@@ -1013,11 +1118,18 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     FrameParams fp = frame_params(c, cam, st, fog, wire_back || wire_front);
     LightSet lset{};
     int rc;
-    if ((rc = frame_lights(c, st, fp, lset))) return rc;
-    if ((rc = frame_buffers(c, fp, wire_back))) return rc;
-
     const bool prof_sample = c->profile_level >= 1 && (c->prof_seq++ % c->prof_stride) == 0;
     const bool prof_all = prof_sample && c->profile_level >= 2, prof_fill = prof_sample;
+    // Two frames in flight: when an earlier frame of this context is still pending, this frame takes the OTHER frame set and (if it
+    // ends up on a sort-free route without a binning launch) its setup kernel runs on the side stream, beside that frame's fill.
+    c->pipelined = false;
+    if (c->frame_pending && !c->redrawing && !fp.wire_collect && !prof_all && c->nf && !(c->route_off & B32_ROUTE_PIPELINE)) {
+        if ((rc = pipeline_ensure(c))) return rc;
+        swap_sets(c);
+        c->pipelined = true;
+    }
+    if ((rc = frame_lights(c, st, fp, lset))) return rc;
+    if ((rc = frame_buffers(c, fp, wire_back))) return rc;
     hipEvent_t* ev = nullptr;
     if (prof_fill) {
         if (!c->ev_created) {
@@ -1030,6 +1142,7 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     const SortScratch sc{ c->block_hist, c->hist_blocks, c->digit_total };
     Route r;
     if ((rc = plan_route(c, fp, sc, wire_front, r))) return rc;
+    if (c->pipelined && !(r.direct_bin || r.want_inline)) c->pipelined = false;     // (binning launches follow k_setup: one stream)
     const uint32_t ntiles = fp.tiles_x * fp.tiles_y;
     c->last_local_sort = r.local_sort || r.want_prio64;                         // the global draw order is not materialised
     c->last_exact = r.ordered_all ? true : (r.exact_cov && !fp.zmode);          // the ordered walk counts every store it performs
@@ -1042,9 +1155,30 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     if ((rc = frame_positions(c, fp, pos12, attr12))) return rc;
 
     // ---- transform, cull, setup (+ tile binning of large meshes)
+    hipStream_t ss = s;
+    if (c->pipelined) {
+        if (c->side_dirty) { HIPCHK(c, hipEventRecord(c->ev_main, s)); HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_main, 0)); c->side_dirty = false; }
+        HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_done, 0));     // the last fill that read this set (two frames ago)
+        ss = c->side;
+        c->pipelined_frames++;
+        if (c->gate_permille && c->last_cover_tiles && c->alt.d_ctrl) {
+            // The fused kernel's workgroups take their next tile from the cursor after the coverage of the current one: the cursor
+            // passes tiles - groups when the last tile is handed out, and every fetch beyond that is a workgroup that found the queue
+            // empty and has only the shading of its last tile left, i.e. is about to free its place on a CU.
+            const uint32_t groups = c->last_cover_groups, tiles = c->last_cover_tiles;
+            const uint32_t need = (tiles > groups ? tiles - groups : 0u) + (uint32_t)((uint64_t)(c->gate_permille - 1u) * groups / 1000u);
+            if (need) launch_gate(ss, c->alt.d_ctrl, need, 30000u /* 300 us */);
+        }
+    }
     if (prof_all) HIPCHK(c, hipEventRecord(ev[0], s));
-    launch_setup(s, fp, c->d_verts, c->d_faces, c->d_tex, c->d_lights, lset, RecArrays{ c->crecs, c->srecs, c->xrecs }, r.db, c->shades, c->keys[0],
+    launch_setup(ss, fp, c->d_verts, c->d_faces, c->d_tex, c->d_lights, lset, RecArrays{ c->crecs, c->srecs, c->xrecs }, r.db, c->shades, c->keys[0],
                  r.direct_bin ? nullptr : c->spans /* (direct binning: nobody reads the spans) */, c->partials, c->d_ctrl, c->wire, c->n_cu, pos12, attr12, c->face_of);
+    if (c->pipelined) {
+        hipError_t e1 = hipEventRecord(c->ev_setup, c->side);
+        if (e1 == hipSuccess) e1 = hipStreamWaitEvent(s, c->ev_setup, 0);
+        if (e1 != hipSuccess) { (void)hipStreamSynchronize(c->side); c->last_hip = (int)e1; return B32_E_HIP; }
+    }
+    c->set_in_flight = true;
     if (prof_all) HIPCHK(c, hipEventRecord(ev[1], s));
 
     // ---- tile lists
@@ -1093,6 +1227,9 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
         launch_wire(s, wa, wire_back, wire_front);
     }
     if (prof_fill) { if (prof_all) HIPCHK(c, hipEventRecord(ev[5], s)); c->ev_frames++; }
+    if (c->side) HIPCHK(c, hipEventRecord(c->ev_done, s));         // (the next setup kernel that writes this set waits for it)
+    c->last_cover_tiles = (r.prio64 && !wire_front && !r.ordered_all) ? ntiles : 0u;
+    c->last_cover_groups = std::min<uint32_t>(ntiles, (uint32_t)c->n_cu * 2u);
     HIPCHK(c, hipGetLastError());
     return B32_OK;
 }
@@ -1146,7 +1283,16 @@ int b32_frame_finish(b32_ctx* c, B32Timings* out) {
     if (!c) return B32_E_ARG;
     (void)hipSetDevice(c->device);
     if (out) memset(out, 0, sizeof(*out));
-    { const int rcf = flush_clear(c); if (rcf) return rcf; }              // (a clear issued after the frame's draw)
+    // A clear issued after the frame's draw (deep mode: safe mode settled the frame before it recorded the clear) stays deferred until
+    // the frame has been settled: a redraw below must land UNDER that clear, not on top of it, and must not fold it either.
+    const bool later_clear = c->frame_pending && c->clear_pending;
+    const uint32_t lc_rgba = c->clear_rgba, lc_y0 = c->clear_y0, lc_y1 = c->clear_y1;
+    if (later_clear) c->clear_pending = false;
+    struct ClearAfter {      // re-arms and flushes the later clear on every exit path
+        b32_ctx* c; bool on; uint32_t rgba, y0, y1;
+        ~ClearAfter() { if (on) { c->clear_pending = true; c->clear_rgba = rgba; c->clear_y0 = y0; c->clear_y1 = y1; (void)flush_clear(c); (void)hipStreamSynchronize(c->stream); } }
+    } clear_after{ c, later_clear, lc_rgba, lc_y0, lc_y1 };
+    if (!later_clear) { const int rcf = flush_clear(c); if (rcf) return rcf; }
     if (!c->frame_pending) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         const int d = c->deferred_rc; c->deferred_rc = 0;
@@ -1205,9 +1351,25 @@ int b32_frame_finish(b32_ctx* c, B32Timings* out) {
         if (rc) return rc;
     }
     c->frame_pending = false;
+    c->set_in_flight = false;
     collect_events(c);
-    const uint32_t sticky = c->h_ctrl.sticky;                  // errors of every frame enqueued since the last finish
+    uint32_t sticky = c->h_ctrl.sticky;                        // errors of every frame enqueued since the last finish
     if (sticky) HIPCHK(c, hipMemsetAsync(&c->d_ctrl->sticky, 0, sizeof(uint32_t), c->stream));
+    if (c->alt.in_flight && c->alt.d_ctrl) {
+        // two frames in flight: the frames of the other set since the last finish -- their sticky errors, and its last frame, which no
+        // later k_setup of that set has looked at: dropped (it ran out of list space and drew nothing) means lost
+        Ctrl other;
+        HIPCHK(c, hipMemcpy(&other, c->alt.d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost));      // (the main stream has drained)
+        c->alt.in_flight = false;
+        uint32_t st2 = other.sticky;
+        if (other.pairs_overflow || other.need_global_sort) st2 += 0x100u;
+        if (other.sticky) HIPCHK(c, hipMemsetAsync(&c->alt.d_ctrl->sticky, 0, sizeof(uint32_t), c->stream));
+        if (other.pairs_overflow || other.need_global_sort) {      // (not again at the next finish)
+            HIPCHK(c, hipMemsetAsync(&c->alt.d_ctrl->pairs_overflow, 0, sizeof(uint32_t), c->stream));
+            HIPCHK(c, hipMemsetAsync(&c->alt.d_ctrl->need_global_sort, 0, sizeof(uint32_t), c->stream));
+        }
+        sticky = (sticky | (st2 & 0xFFu)) + (st2 & ~0xFFu);
+    }
     if (c->deferred_rc) { const int d = c->deferred_rc; c->deferred_rc = 0; return d; }     // (an earlier mesh of this frame, settled by a swap)
     if (c->h_ctrl.pairs_overflow) return B32_E_HIP;
     if (sticky >> 8) return B32_E_FRAME_DROPPED;              // deep asynchronous mode: an earlier frame was lost (the last one is good)
@@ -1276,7 +1438,7 @@ int b32_scene_swap(b32_ctx* c, b32_scene* sl) {
     std::swap(c->tex_blend_any, sl->tex_blend_any);
     std::swap(c->direct_cap_opaque, sl->direct_cap_opaque); std::swap(c->direct_ntiles, sl->direct_ntiles); std::swap(c->direct_ok, sl->direct_ok);
     std::swap(c->d_pos12, sl->d_pos12); std::swap(c->cap_pos12, sl->cap_pos12); std::swap(c->pos_valid, sl->pos_valid); std::swap(c->band_frames, sl->band_frames);
-    c->tex_sig.swap(sl->tex_sig); std::swap(c->tex_sig_valid, sl->tex_sig_valid); std::swap(c->tex_sig_rgba, sl->tex_sig_rgba);
+    c->tex_sig.swap(sl->tex_sig); std::swap(c->tex_sig_valid, sl->tex_sig_valid);
     return B32_OK;
 }
 
@@ -1455,6 +1617,7 @@ extern "C" int b32_set_fragment_counting(b32_ctx* c, int on) {
     return B32_OK;
 }
 extern "C" unsigned long long b32_route_count(const b32_ctx* c, int which) {
+    if (c && which == 7) return c->pipelined_frames;
     return (c && which >= 0 && which < 8) ? c->routes[which] : 0ull;
 }
 extern "C" int b32_set_async_depth(b32_ctx* c, int deep) {
@@ -1478,7 +1641,13 @@ extern "C" int b32_set_routes(b32_ctx* c, uint32_t off_mask) {
 }
 extern "C" int b32_set_cheap_threshold(b32_ctx* c, uint32_t den) {
     if (!c || den == 0) return B32_E_ARG;
-    c->cheap_den = den;          // (applies to the textures uploaded from now on)
+    c->cheap_den = den;          // (applies to the textures uploaded from now on:
+    c->tex_sig_valid = false;    //  the next upload re-counts the skippable texels even if the pool already holds the same textures)
+    return B32_OK;
+}
+extern "C" int b32_set_pipeline_gate(b32_ctx* c, uint32_t permille) {
+    if (!c || permille > 1000u) return B32_E_ARG;
+    c->gate_permille = permille;
     return B32_OK;
 }
 extern "C" int b32_set_profiling_stride(b32_ctx* c, uint32_t every) {

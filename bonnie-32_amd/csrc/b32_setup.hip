@@ -560,6 +560,21 @@ void launch_setup(hipStream_t s, const FrameParams& fp, const B32Vertex* verts, 
     else hipLaunchKernelGGL((k_setup<1, false>), g1, dim3(256), 0, s, fp, verts, faces, tex, lights, ls, recs, db, shades, keys, spans, partials, ctrl, wire, pos12, attr12, face_of);
 }
 
+// ---------------------------------------------------------------- gate of a pipelined setup kernel (two frames in flight)
+// One wave on the side stream, in front of the next frame's k_setup: it returns once the fill kernel of the frame before has handed
+// out `need` tiles from its cursor -- so that the setup kernel runs in that kernel's thinning tail instead of beside its busy start --
+// or after `patience` ticks of the 100 MHz wall clock (a fill that aborted, or was no tile kernel at all, never moves its cursor).
+__global__ void k_gate(const Ctrl* __restrict__ prev, uint32_t need, uint32_t patience) {
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(&prev->tile_cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+        if (wall_clock64() - t0 > patience) break;
+        __builtin_amdgcn_s_sleep(64);
+    }
+}
+void launch_gate(hipStream_t s, const Ctrl* prev, uint32_t need, uint32_t patience) {
+    hipLaunchKernelGGL(k_gate, dim3(1), dim3(1), 0, s, prev, need, patience);
+}
+
 // ---------------------------------------------------------------- stage tap: project_fixed for n positions
 __global__ void k_project_fixed(const float* __restrict__ pos, uint32_t n, B32Camera cam, uint32_t w, uint32_t h,
                                 int32_t* __restrict__ sx, int32_t* __restrict__ sy, float* __restrict__ z) {

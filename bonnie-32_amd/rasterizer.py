@@ -72,9 +72,13 @@ class Context:
         """b32_set_async_depth: 0 = safe (default), 1 = large-scene frames back to back, a dropped one is reported by finish()."""
         _chk(self.lib.b32_set_async_depth(self.h, int(deep)), "b32_set_async_depth")
 
-    ROUTES = ("direct_bin", "inline_bin", "counting_sort", "keyed", "redraw_region", "redraw_global_sort", "redraw_pairs")
+    ROUTES = ("direct_bin", "inline_bin", "counting_sort", "keyed", "redraw_region", "redraw_global_sort", "redraw_pairs", "pipelined")
 
-    ROUTE_SORT_FREE, ROUTE_CUT_TILES, ROUTE_INLINE_BIN, ROUTE_DIRECT_BIN, ROUTE_WIDE_GROUPS, ROUTE_PACKED_STREAMS, ROUTE_PIPELINE = 1, 2, 4, 8, 16, 32, 64
+    ROUTE_SORT_FREE, ROUTE_CUT_TILES, ROUTE_INLINE_BIN, ROUTE_DIRECT_BIN, ROUTE_WIDE_GROUPS, ROUTE_PACKED_STREAMS, ROUTE_PIPELINE, ROUTE_TEX_CACHE = 1, 2, 4, 8, 16, 32, 64, 128
+
+    def set_pipeline_gate(self, permille):
+        """b32_set_pipeline_gate: hold a pipelined setup kernel until that share of the previous fill's tiles has started."""
+        _chk(self.lib.b32_set_pipeline_gate(self.h, int(permille)), "b32_set_pipeline_gate")
 
     def set_routes(self, off_mask):
         """b32_set_routes: switch internal routes off (ROUTE_* bits); results are identical on every route."""

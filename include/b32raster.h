@@ -192,7 +192,10 @@ int b32_fb_size(const b32_ctx* ctx, uint32_t* width, uint32_t* height);
 int b32_set_band(b32_ctx* ctx, uint32_t y0, uint32_t y1);
 
 /* ---- render_mesh_15 (render.rs:2302-2638) -------------------------------- */
-/* Drop-in form: host slices in, framebuffer stays device resident (read-modify-write). */
+/* Drop-in form: host slices in, framebuffer stays device resident (read-modify-write).
+ * Texture cache: the texel pool of the previous call is reused when every texture has the same host pointer, dimensions, blend mode and
+ * 64-bit content hash (the texels are re-hashed on every call, so an in-place edit is seen); an edit that collides in the hash (2^-64
+ * per edit, non-cryptographic) would draw stale texels -- b32_set_routes(B32_ROUTE_TEX_CACHE) uploads the texels on every call. */
 int b32_render_mesh_15(b32_ctx* ctx,
                        const B32Vertex* vertices, uint32_t nv,
                        const B32Face* faces, uint32_t nf,
@@ -227,19 +230,21 @@ int b32_frame_finish(b32_ctx* ctx, B32Timings* out /* nullable */);
  * redrawn by the host.
  *   deep = 0 (default): safe.  Enqueueing another frame, or any call that reads, writes or rebinds the framebuffer (b32_fb_download,
  *            b32_zbuffer_download, b32_fb_upload, b32_fb_clear*, b32_render_skybox_mesh, b32_draw_star_diamonds, b32_fb_bind_device,
- *            b32_set_stream, b32_present_nearest), first settles the pending frame (one host synchronisation, redraw if needed): no
+ *            b32_set_stream, b32_present_nearest, b32_scene_upload*, b32_scene_swap, b32_set_band), first settles the pending frame (one host synchronisation, redraw if needed): no
  *            frame is ever lost, and none is redrawn on top of a later clear.
- *   deep = 1: throughput.  Frames are enqueued back to back with no host synchronisation (bench.py, parallel.py: static camera,
- *            capacities settled by a warm-up frame).  Only the most recent frame can be redrawn; if an earlier one was dropped,
+ *   deep = 1: throughput.  Frames are enqueued back to back with no host synchronisation (bench.py and the tools that call
+ *            b32_set_async_depth(ctx, 1): static camera, capacities settled by a warm-up frame).  Only the most recent frame can be redrawn; if an earlier one was dropped,
  *            b32_frame_finish reports B32_E_FRAME_DROPPED -- never silently.  Consumers outside the library that read the bound
- *            framebuffer between two frames (an RCCL gather on the same stream) must accept that contract.
+ *            framebuffer between two frames (an RCCL gather on the same stream) must accept that contract.  A b32_fb_clear issued
+ *            after a draw is applied after that draw even when b32_frame_finish has to redraw it.
  * Frames of small meshes never overflow and are always enqueued without synchronisation. */
 int b32_set_async_depth(b32_ctx* ctx, int deep);
 /* Which internal route the frames of this context took since it was created (tests assert that the route they target really ran;
  * no reference counterpart).  which: 0 frames binned by the setup kernel into fixed tile regions (large meshes), 1 frames whose tile
  * lists were collected inside the fill kernel (small meshes), 2 frames binned by the counting-sort launches, 3 frames through the
  * keyed pipeline (global depth sort), 4 frames redrawn because a tile region overflowed, 5 frames redrawn through the global depth
- * sort, 6 frames redrawn after a pair-buffer overflow.  Unknown `which` or null ctx: 0. */
+ * sort, 6 frames redrawn after a pair-buffer overflow, 7 frames whose setup kernel ran on the second stream beside the previous frame's
+ * fill (two frames in flight).  Unknown `which` or null ctx: 0. */
 unsigned long long b32_route_count(const b32_ctx* ctx, int which);
 /* Switch internal routes OFF for the frames enqueued from now on (no reference counterpart: the results are identical on every route;
  * the tests use it to keep the older pipelines covered, the timing tools to compare routes).  off_mask = 0 restores the default. */
@@ -249,6 +254,7 @@ unsigned long long b32_route_count(const b32_ctx* ctx, int which);
 #define B32_ROUTE_DIRECT_BIN  8u   /* large meshes: binning inside the setup kernel -> counting-sort launches                      */
 #define B32_ROUTE_WIDE_GROUPS 16u  /* 16-wave workgroups of the fused kernel when tiles are few -> always 8 waves                  */
 #define B32_ROUTE_PACKED_STREAMS 32u /* resident large meshes: packed position / attribute streams for the setup kernel -> B32Vertex array */
+#define B32_ROUTE_TEX_CACHE   128u /* drop-in calls: texture cache by (pointer, size, blend mode, 64-bit content hash) -> texels uploaded on every call */
 #define B32_ROUTE_PIPELINE    64u  /* setup kernel of the next frame on a second stream beside the fill of the current one -> one stream */
 int b32_set_routes(b32_ctx* ctx, uint32_t off_mask);
 /* CHEAP coverage (inside test only, texel rule applied to the winner) is used while every texture has at most 1/den skippable texels
@@ -340,6 +346,13 @@ int b32_set_profiling(b32_ctx* ctx, int level);
 /* Instrument only every `every`-th frame (default 1: each one).  An event pair around a kernel costs the stream a few microseconds
  * per frame (the kernels of consecutive frames no longer run back to back); bench.py samples every 8th frame of its timed region. */
 int b32_set_profiling_stride(b32_ctx* ctx, uint32_t every);
+/* Two frames in flight (no reference counterpart; see B32_ROUTE_PIPELINE): when a frame is enqueued while an earlier one is still
+ * pending, its setup kernel runs on a second, low-priority stream of the context beside the earlier frame's fill kernel, on a second
+ * set of per-face buffers.  permille > 0 holds that setup kernel back until the earlier fill has handed out its last tile and
+ * (permille - 1) / 1000 of its workgroups have found the tile queue empty (they are about to leave their CUs), so that the setup kernel
+ * runs in the fill's thinning tail instead of beside its busy start; 0 = no hold.  Results are identical either way.
+ * permille > 1000: B32_E_ARG. */
+int b32_set_pipeline_gate(b32_ctx* ctx, uint32_t permille);
 /* B32Timings.fragments (the reference's pixel-store count, render.rs:1671-1702) is instrumentation, not an output of
  * render_mesh_15.  on = 0 (default): not counted (B32Timings.fragments = 0 unless the textures force exact coverage); the fill
  * may then resolve opaque visibility without fetching the texel of every overdrawn fragment and without a global depth

@@ -404,6 +404,120 @@ def test_async_frames_are_never_silently_dropped(oracle):
     assert np.array_equal(fb3.pixels, o2.pixels)
 
 
+@pytest.mark.parametrize("gate,routes_off", [(300, 0), (0, 0), (1000, 0), (300, 64)])
+def test_two_frames_in_flight(oracle, gate, routes_off):
+    """Frames enqueued back to back run their setup kernel on the context's second stream, on the other frame set, beside the previous
+    frame's fill (B32_ROUTE_PIPELINE, b32_set_pipeline_gate).  Six frames of a large mesh (direct binning) with a moving camera in
+    z-buffer mode without a clear in between -- colour AND depth accumulate, so every frame must have been drawn from its own records,
+    in order -- then painter's frames with a clear each; and the same with small meshes (in-kernel list collection) in safe mode."""
+    from bonnie32_amd import rasterizer as R
+    for n_tris, deep in ((60_000, 1), (1500, 0)):
+        sc = scenegen.make_scene("C3", n_tris=n_tris, width=640, height=480, bbox_px=120.0, seed=77 + n_tris, variant="gouraud")
+        sc.settings.use_zbuffer = True
+        cams = [b32.Camera(position=(40.0 * i, -25.0 * i, -300.0 * i)) for i in range(6)]
+        ofb = oracle.Framebuffer(sc.width, sc.height); ofb.clear(sc.clear_color)
+        for cam in cams:
+            assert oracle.render_mesh_15(ofb, sc.vertices, sc.faces, sc.textures, cam, sc.settings)[0] == 0
+        ctx = R.Context(0)
+        ctx.set_async_depth(deep); ctx.set_pipeline_gate(gate); ctx.set_routes(routes_off)
+        fb = R.Framebuffer(sc.width, sc.height, ctx); fb.clear(sc.clear_color)
+        rs = R.ResidentScene(fb, sc.vertices, sc.faces, sc.textures)
+        rs.render_async(cams[0], sc.settings); rs.finish()            # (deep mode: list regions settled by a first synchronous frame)
+        for cam in cams[1:]:
+            rs.render_async(cam, sc.settings)
+        tm = rs.finish()
+        assert ctx.route_counts()["pipelined"] == (0 if routes_off else 4)
+        assert np.array_equal(fb.pixels, ofb.pixels) and np.array_equal(fb.zbuffer.view(np.uint32), ofb.zbuffer.view(np.uint32))
+        # painter's mode, a (folded) clear before every frame: the last camera's frame is what stays
+        sc.settings.use_zbuffer = False
+        o2 = oracle.Framebuffer(sc.width, sc.height); o2.clear(sc.clear_color)
+        rc, otm, dump = oracle.render_mesh_15(o2, sc.vertices, sc.faces, sc.textures, cams[-1], sc.settings, None, dump=True)
+        fb2 = R.Framebuffer(sc.width, sc.height, ctx)
+        rs2 = R.ResidentScene(fb2, sc.vertices, sc.faces, sc.textures)
+        for cam in cams:
+            fb2.clear(sc.clear_color); rs2.render_async(cam, sc.settings)
+        tm = rs2.finish()
+        assert tm.triangles_drawn == otm.triangles_drawn and np.array_equal(fb2.pixels, o2.pixels)
+        assert np.array_equal(ctx.last_draw_order(len(sc.faces)), dump["draw_order"])
+        ctx.close()
+
+
+def test_pending_frame_is_settled_before_its_scene_is_replaced(oracle):
+    """Safe mode never loses a frame: a large mesh's frame whose tile regions overflowed is redrawn by the host from the RESIDENT scene, so
+    it has to be settled before b32_scene_upload* / b32_set_band change what such a redraw would draw (found by the round-2 review: frame
+    A was lost and mesh B -- with a transparent pass -- was drawn, and blended, twice)."""
+    from bonnie32_amd import rasterizer as R
+    a = scenegen.make_scene("C3", n_tris=120_000, width=640, height=480, bbox_px=60.0, seed=321)
+    far = b32.Camera(position=(0.0, 0.0, -45000.0))                 # 11 600 surfaces inside eight tiles: their regions overflow at the initial size
+    b = scenegen.make_scene("C3", n_tris=30_000, width=640, height=480, bbox_px=90.0, seed=99, variant="blend")
+    ofb = oracle.Framebuffer(a.width, a.height); ofb.clear(a.clear_color)
+    assert oracle.render_mesh_15(ofb, a.vertices, a.faces, a.textures, far, a.settings)[0] == 0
+    assert oracle.render_mesh_15(ofb, b.vertices, b.faces, b.textures, b.camera, b.settings)[0] == 0
+    for how in ("upload", "indexed", "band"):
+        ctx = R.Context(0)
+        fb = R.Framebuffer(a.width, a.height, ctx); fb.clear(a.clear_color)
+        rs = R.ResidentScene(fb, a.vertices, a.faces, a.textures)
+        rs.render_async(far, a.settings)                             # overflows; pending, not yet redrawn
+        if how == "band":
+            fb.set_band(0, a.height)                                 # (any band change settles the frame for the band it was enqueued with)
+            assert ctx.route_counts()["redraw_region"] == 1
+            rs.finish()
+            want = oracle.Framebuffer(a.width, a.height); want.clear(a.clear_color)
+            oracle.render_mesh_15(want, a.vertices, a.faces, a.textures, far, a.settings)
+            assert np.array_equal(fb.pixels, want.pixels)
+            ctx.close()
+            continue
+        rs2 = R.ResidentScene(fb, b.vertices, b.faces, b.textures) if how == "upload" else \
+            R.ResidentScene(fb, b.vertices, b.faces, indexed_textures=b.indexed_textures)
+        assert ctx.route_counts()["redraw_region"] == 1              # frame A was redrawn when mesh B was uploaded
+        rs2.render_async(b.camera, b.settings)
+        rs2.finish()
+        got = fb.pixels
+        assert np.array_equal(got, ofb.pixels), f"{int((got != ofb.pixels).sum())} bytes differ ({how})"
+        ctx.close()
+
+
+def test_clear_after_a_dropped_frame_in_deep_mode(oracle):
+    """Deep asynchronous mode: draw (overflows, draws nothing yet) -> b32_fb_clear -> b32_frame_finish.  The redraw of the frame belongs
+    BEFORE the clear that was issued after it: the framebuffer ends up cleared, not with the frame on top of the clear."""
+    from bonnie32_amd import rasterizer as R
+    a = scenegen.make_scene("C3", n_tris=120_000, width=640, height=480, bbox_px=60.0, seed=321)
+    far = b32.Camera(position=(0.0, 0.0, -45000.0))
+    red = b32.Color(200, 10, 10)
+    ctx = R.Context(0); ctx.set_async_depth(1)
+    fb = R.Framebuffer(a.width, a.height, ctx); fb.clear(a.clear_color)
+    rs = R.ResidentScene(fb, a.vertices, a.faces, a.textures)
+    rs.render_async(far, a.settings)
+    fb.clear(red)
+    rs.finish()
+    assert ctx.route_counts()["redraw_region"] == 1
+    want = oracle.Framebuffer(a.width, a.height); want.clear(red)
+    assert np.array_equal(fb.pixels, want.pixels)
+    # and the usual order afterwards: clear, draw
+    fb.clear(a.clear_color); rs.render_async(far, a.settings); rs.finish()
+    want.clear(a.clear_color); oracle.render_mesh_15(want, a.vertices, a.faces, a.textures, far, a.settings)
+    assert np.array_equal(fb.pixels, want.pixels)
+    ctx.close()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_band_ranks_share_one_gpu(world):
+    """BASELINE config C4's data path with real processes: `world` ranks (torch.distributed.run, gloo) share GPU 0, each binds the HIP
+    context to its band of the 2560x1920 frame, renders C3 at 100 k triangles and the full 1 M-triangle C3, and the rows are gathered
+    by bonnie32_amd.parallel.gather_bands and by the pipelined two-framebuffer flow of bench.py (gather_bands_async); rank 0 compares
+    every assembled frame with the CPU oracle's (tests/band_worker.py).  What this cannot cover is the RCCL transport itself (one GPU
+    per rank)."""
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "tests", "band_worker.py")], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "BAND_WORKER_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
 def test_deferred_clear_is_never_observable(fast_ctx, oracle):
     """b32_fb_clear defers itself so that the frame that follows can fold it into its fused kernel (no clear launch).  Whatever else
     touches the framebuffer first must see the cleared frame: a download with no draw in between, a second clear with another

@@ -24,6 +24,10 @@ def one():
     for cfg, n in (("C3", 200), ("C5", 100)):
         sc = scenegen.make_scene(cfg)
         ctx = R.Context(0); ctx.set_async_depth(1)
+        if os.environ.get("EXP_GATE"):
+            ctx.set_pipeline_gate(int(os.environ["EXP_GATE"]))
+        if os.environ.get("EXP_ROUTES"):
+            ctx.set_routes(int(os.environ["EXP_ROUTES"]))          # e.g. base@EXP_ROUTES=64: the product build without two frames in flight
         fb = R.Framebuffer(sc.width, sc.height, ctx)
         rs = R.ResidentScene(fb, sc.vertices, sc.faces, indexed_textures=sc.indexed_textures)
         def fin():
@@ -48,7 +52,7 @@ def one():
         except Exception as e:                       # (experiment builds that break the frame on purpose still report their kernel times)
             out.setdefault("errors", []).append(str(e)[:60])
         kt = ctx.last_kernel_times(); ctx.set_profiling(0)
-        out[cfg] = {"ms": round(best * 1e3, 4), "ok": ok, **{k: round(v * 1e3, 1) for k, v in kt.items()}}
+        out[cfg] = {"ms": round(best * 1e3, 4), "ok": ok, "pipelined": ctx.route_counts().get("pipelined"), **{k: round(v * 1e3, 1) for k, v in kt.items()}}
     print(json.dumps(out))
 
 
