@@ -49,6 +49,9 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="skip the C1 / C2 / C5 side measurements (profiling runs)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--check", action="store_true", help="also verify the final frame against the oracle (slow at C3)")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="one stream only: no setup kernel of the next frame beside the fill of the current one (b32_set_routes B32_ROUTE_PIPELINE; "
+                         "profiling runs that want kernel durations without overlap)")
     ap.add_argument("--weak-series", action="store_true",
                     help="also time the weak-scaling point of SURVEY 8e (N x 125 k tris on the same frame); always on for N > 1")
     ap.add_argument("--sync-gather", action="store_true",
@@ -96,6 +99,8 @@ def main():
     ctx = R.Context(local_rank)
     ctx.set_async_depth(1)      # frames back to back without a host synchronisation (static camera, capacities settled by the warm-up
                                 # frames); a frame dropped for lack of buffer space would be REPORTED by finish(), never silent
+    if args.no_pipeline:
+        ctx.set_routes(R.Context.ROUTE_PIPELINE)
     # one explicit stream for everything of this rank: the rasterizer's kernels, torch's copies and the RCCL gather are ordered by it
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
@@ -261,9 +266,10 @@ def main():
     tm = rs.finish()
     if pipelined:
         sets[1][1].finish()
-    cover_ms = ctx.last_kernel_times().get("cover", None)     # HIP events around k_cover on the stream it runs on
+    cover_ms_timed = ctx.last_kernel_times().get("cover", None)     # HIP events around k_cover on the stream it runs on (overlapped frames)
     ctx.set_profiling(0)
     ctx.set_profiling_stride(1)
+    pipelined_frames = ctx.route_counts().get("pipelined", 0)
 
     frags = torch.tensor([float(exact_fragments)], dtype=torch.float64, device=rdev)
     if world > 1:
@@ -289,13 +295,53 @@ def main():
     final_host = fb.pixels if rank == 0 else None               # b32_fb_download: the presenter's copy (game/renderer.rs:179)
     d2h_ms = (time.perf_counter() - d0) * 1e3
 
-    # per-phase device times (separate untimed pass, events around every phase)
-    ctx.set_profiling(2)
-    for _ in range(10):
-        step()
-    rs.finish()
-    phases = ctx.last_kernel_times()
-    ctx.set_profiling(0)
+    # ---- kernel durations WITHOUT overlap (untimed passes, one stream): in the timed region the next frame's setup kernel runs beside
+    # the fill kernel, so an event pair around the fill there measures a shared GPU.  (a) events around the fill kernel of every frame,
+    # >= 20 samples; (b) events around every phase; an empty phase ("sort": nothing is launched between its two events on the default
+    # path) is what an event pair itself costs.
+    cover_ms, cover_samples, phases = None, 0, {}
+    if world == 1:
+        ctx.set_routes(R.Context.ROUTE_PIPELINE)
+        n_iso = min(max(args.steps, 24), 60)
+        ctx.set_profiling(1)
+        for _ in range(n_iso):
+            step()
+        rs.finish()
+        cover_ms = ctx.last_kernel_times().get("cover", None); cover_samples = n_iso
+        ctx.set_profiling(2)
+        for _ in range(20):
+            step()
+        rs.finish()
+        phases = ctx.last_kernel_times()
+        ctx.set_profiling(0)
+        # single-frame latency: every frame finished (host round trip) before the next is enqueued
+        torch.cuda.synchronize(dev)
+        l0 = time.perf_counter()
+        for _ in range(max(args.steps, 20)):
+            step(); rs.finish()
+        latency_ms = (time.perf_counter() - l0) / max(args.steps, 20) * 1e3
+        # throughput of the same loop on one stream (no two frames in flight), and in the library's default SAFE mode
+        # (b32_set_async_depth(0): a large scene's pending frame is settled -- one host synchronisation -- before the next is enqueued)
+        torch.cuda.synchronize(dev)
+        q0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize(dev)
+        one_stream_ms = (time.perf_counter() - q0) / args.steps * 1e3
+        rs.finish()
+        ctx.set_routes(R.Context.ROUTE_PIPELINE if args.no_pipeline else 0)
+        ctx.set_async_depth(0)
+        torch.cuda.synchronize(dev)
+        q0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize(dev)
+        safe_ms = (time.perf_counter() - q0) / args.steps * 1e3
+        rs.finish()
+        ctx.set_async_depth(1)
+    else:
+        cover_ms, cover_samples = cover_ms_timed, (args.steps + EVENT_STRIDE - 1) // EVENT_STRIDE
+        latency_ms = one_stream_ms = safe_ms = None
 
     # ---- weak-scaling point (north_star's >= 0.7 target): N x 125 k triangles on the same 2560x1920 frame, so every
     # rank's band keeps the fragments and binned triangles of the 1-GPU 125 k scene.  Reported beside the headline (which is the
@@ -432,24 +478,56 @@ def main():
             # HBM traffic of the dominant kernel: PMC counters need rocprofv3 around the process, so this is the per-launch figure of
             # the committed PMC passes -- reported only when those passes were taken from THIS build of the kernels (digest over the
             # kernel sources), null otherwise; `traffic_source` says which
-            traffic, tsrc = None, None
+            tj = {}
             tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(tpath) and world == 1:
                 try:
                     tj = json.load(open(tpath))
-                    e = tj.get(f"{args.config}:k_cover")
-                    if isinstance(e, dict):
-                        same = e.get("csrc_digest") == csrc_digest()
-                        traffic = e.get("bytes") if same else None
-                        tsrc = {"file": e.get("file"), "csrc_digest": e.get("csrc_digest"), "this_build": csrc_digest(), "same_build": same,
-                                "measured_in_this_run": False, "stale_bytes": None if same else e.get("bytes")}
                 except Exception:                                   # noqa: BLE001
-                    traffic = None
+                    tj = {}
+
+            def pmc_entry(kernel):
+                e = tj.get(f"{args.config}:{kernel}")
+                if not isinstance(e, dict):
+                    return None, None, None
+                same = e.get("csrc_digest") == csrc_digest()
+                src = {"file": e.get("file"), "csrc_digest": e.get("csrc_digest"), "this_build": csrc_digest(), "same_build": same,
+                       "measured_in_this_run": False, "stale_bytes": None if same else e.get("bytes")}
+                return (e.get("bytes") if same else None), src, (e if same else None)
+            traffic, tsrc, ecov = pmc_entry("k_cover")
+            # the kernel's REAL bound beside the contractual HBM fraction: VALU issue.  wave_instr = SQ_INSTS_VALU of the committed PMC pass
+            # (same build only); a wave64 VALU instruction occupies its SIMD for 4 cycles, 4 SIMDs x n_cu CUs issue in parallel.
+            valu = None
+            if ecov and ecov.get("valu_wave_instr"):
+                n_simd = 4 * torch.cuda.get_device_properties(dev).multi_processor_count
+                clk = ecov.get("shader_clock_ghz", 2.4)
+                issue_us = ecov["valu_wave_instr"] / n_simd * 4 / (clk * 1e3)
+                valu = {"wave_instr": ecov["valu_wave_instr"], "simds": n_simd, "cycles_per_wave_instr": 4, "clock_ghz": clk,
+                        "issue_peak_us": round(issue_us, 2), "frac": round(issue_us / (cover_ms * 1e3), 4),
+                        "lds_bank_conflict_cycles": ecov.get("lds_bank_conflict"), "wait_any_share": ecov.get("wait_any_share")}
             roofline = {"kernel": "k_cover", "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": tsrc,
-                        "kernel_ms": round(cover_ms, 4), "kernel_ms_samples": (args.steps + EVENT_STRIDE - 1) // EVENT_STRIDE, "algorithmic_bytes": alg_cover, "units": {"tile_pairs": tm.tile_pairs, "surfaces": tm.triangles_drawn, "pixels": W * (y1 - y0)},
+                        "kernel_ms": round(cover_ms, 4), "kernel_ms_samples": cover_samples,
+                        "kernel_ms_note": "HIP events around the kernel on its own stream, every frame of an untimed pass on ONE stream (no other kernel beside it)" if world == 1 else "timed region",
+                        "kernel_ms_timed_region": round(cover_ms_timed, 4) if cover_ms_timed else None,
+                        "kernel_ms_timed_region_samples": (args.steps + EVENT_STRIDE - 1) // EVENT_STRIDE,
+                        "kernel_ms_timed_region_note": "same events on every 8th step of the timed region, where the next frame's setup kernel runs beside this kernel",
+                        "event_pair_overhead_ms": round(phases.get("sort", 0.0), 4) if phases else None,
+                        "algorithmic_bytes": alg_cover, "units": {"tile_pairs": tm.tile_pairs, "surfaces": tm.triangles_drawn, "pixels": W * (y1 - y0)},
+                        "valu": valu,
                         "frame_algorithmic_bytes": alg_frame,
                         "frame_frac": round(alg_frame / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+            # second kernel of the frame, the one nearest the HBM roofline: k_setup.  Algorithmic bytes per launch:
+            # 20 B face + 36 B of packed positions per face, 36 B of packed (u, v, rgba) + 96 B of records + 4 B face id per surviving
+            # face, 4 B painter's key per face slot, 4 B per (surface, tile) pair appended to a tile list
+            if phases.get("setup"):
+                alg_setup = (20 + 36 + 4) * NF + (36 + 96 + 4) * tm.triangles_drawn + 4 * tm.tile_pairs
+                s_ms = phases["setup"]
+                s_traffic, s_src, _ = pmc_entry("k_setup")
+                roofline["setup"] = {"kernel": "k_setup", "bound": "hbm", "achieved": round(alg_setup / (s_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
+                                     "unit": "GB/s", "frac": round(alg_setup / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": s_traffic,
+                                     "traffic_source": s_src, "kernel_ms": round(s_ms, 4), "kernel_ms_samples": 20, "algorithmic_bytes": alg_setup,
+                                     "traffic_frac_of_peak": round(s_traffic / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if s_traffic else None}
         cpu = None
         cpu_all = None
         if world == 1 and not args.no_cpu_baseline:
@@ -522,7 +600,14 @@ def main():
                          "ms_per_step_min": round(per_step[0], 5) if per_step else None,
                          "median_over": len(per_step), "median_note": "HIP events between consecutive steps on the frame's stream (separate pass)",
                          "h2d_ms": round(h2d_ms, 3), "h2d_bytes": h2d_bytes, "d2h_ms": round(d2h_ms, 3), "d2h_bytes": W * H * 4,
-                         "sync_gather_ms_per_step": round(sync_ms, 5) if sync_ms is not None else None},
+                         "sync_gather_ms_per_step": round(sync_ms, 5) if sync_ms is not None else None,
+                         "async_depth": 1, "frames_in_flight": 1 if args.no_pipeline else 2, "pipelined_frames_in_timed_region": pipelined_frames,
+                         "async_note": "timed region: b32_set_async_depth(1), frames enqueued back to back; the setup kernel of frame i+1 runs on the "
+                                       "library's second stream beside the fill of frame i (two frame sets); every frame is cleared, set up and drawn in full",
+                         "frame_latency_ms": round(latency_ms, 5) if latency_ms else None,
+                         "ms_per_step_one_stream": round(one_stream_ms, 5) if one_stream_ms else None,
+                         "ms_per_step_safe_mode": round(safe_ms, 5) if safe_ms else None,
+                         "safe_mode_note": "b32_set_async_depth(0), the library default: a large scene's pending frame is settled (host synchronisation) before the next is enqueued"},
             "phases_ms": {k: round(v, 4) for k, v in phases.items()},
             "roofline": roofline,
             "cpu_baseline": cpu,

@@ -72,6 +72,11 @@ class B32Fog(C.Structure):
                 ("r", C.c_uint8), ("g", C.c_uint8), ("b", C.c_uint8), ("blend", C.c_uint8)]
 
 
+class B32MeshParams(C.Structure):
+    _fields_ = [("ambient", C.c_float), ("backface_cull", C.c_uint8), ("backface_wireframe", C.c_uint8), ("has_fog", C.c_uint8),
+                ("_pad", C.c_uint8), ("fog", B32Fog)]
+
+
 class B32Timings(C.Structure):
     _fields_ = [("transform_ms", C.c_float), ("fog_ms", C.c_float), ("cull_ms", C.c_float), ("sort_ms", C.c_float),
                 ("draw_ms", C.c_float), ("wireframe_ms", C.c_float), ("triangles_drawn", C.c_uint32),
@@ -110,6 +115,10 @@ SYMBOLS = [
     ("b32_scene_create", C.c_int, [_P, C.POINTER(_P)]),
     ("b32_scene_destroy", None, [_P, _P]),
     ("b32_scene_swap", C.c_int, [_P, _P]),
+    ("b32_frame_begin", C.c_int, [_P, _P, _P]),
+    ("b32_frame_add_scene", C.c_int, [_P, _P, _P]),
+    ("b32_frame_end", C.c_int, [_P]),
+    ("b32_batch_count", C.c_ulonglong, [_P, C.c_int]),
     ("b32_fb_clear_gradient", C.c_int, [_P] + [C.c_uint8] * 8),
     ("b32_fb_clear_transparent", C.c_int, [_P]),
     ("b32_render_skybox_mesh", C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint32, _P]),

@@ -67,9 +67,11 @@ struct b32_ctx {
     uint32_t pool_texels = 0; bool mask_dirty = true;
     uint32_t nv = 0, nf = 0, nt = 0;
     bool have_scene = false;
+    unsigned long long gen = 0;         // identity of the resident scene's content (every upload gets a new number; swapped with the slots)
     bool may_blend = true;              // some face / texture can produce a transparent-pass surface (render.rs:2403-2415)
     bool cheap_ok = false;              // every texture has few skippable texels: CHEAP coverage + repair is profitable
     bool tex_blend_any = false;         // some texture of the resident scene has a blend mode other than Opaque
+    uint32_t blend_faces = 0;           // faces that their own blend mode / editor alpha or their texture's blend mode puts in the transparent pass
     // Texture cache of the drop-in calls ("texture upload may be cached by (ptr,len,hash) but must be semantically per-call"):
     // what the texel pool currently holds -- per texture the caller's pointer, its dimensions, blend mode and a 64-bit hash of its
     // content.  A call that passes the same set again (the reference's callers pass the same Texture15 slice every frame) skips the
@@ -131,6 +133,14 @@ struct b32_ctx {
     bool stage_active = false, stage_failed = false; UploadSegs stage_segs{};
     B32Light* d_lights = nullptr; size_t cap_lights = 0; std::vector<B32Light> h_lights;
 
+    // batched frame (b32_frame_begin / _add_scene / _end): per-mesh rows of the frame being enqueued (kept for a redraw), the recording
+    // between begin and end, and the merged meshes built so far (reused while their members' contents stay the same)
+    bool frame_batched = false; MeshTable frame_table{};
+    struct BatchEntry { b32_scene* slot; MeshRow row; bool wire; };
+    struct MergedRun { std::vector<b32_scene*> members; std::vector<unsigned long long> gens; b32_scene* merged = nullptr; unsigned long long used = 0; };
+    bool batch_open = false; B32Camera batch_cam{}; B32Settings batch_st{}; std::vector<B32Light> batch_lights; std::vector<BatchEntry> batch;
+    std::vector<MergedRun> merged_runs; unsigned long long batch_clock = 0, gen_counter = 0;
+    unsigned long long batch_stats[4] = {};      // merged draws, sequential draws, merged meshes built, frames
     // last enqueued frame (for redraw after a pair overflow)
     bool frame_pending = false;
     bool pending_may_redraw = false;    // the pending frame took a path that can overflow its buffers (not the small-mesh path)
@@ -163,6 +173,8 @@ struct b32_scene {
     uint32_t* d_texmask = nullptr; size_t cap_texmask = 0; uint32_t pool_texels = 0; bool mask_dirty = true;
     std::vector<TexDesc> h_tex;
     uint32_t nv = 0, nf = 0, nt = 0;
+    unsigned long long gen = 0;
+    uint32_t blend_faces = 0;
     bool fmt8 = false, blend8 = false, have_scene = false, may_blend = true, cheap_ok = false, local_sort_ok = true, tex_blend_any = false;
     uint32_t direct_cap_opaque = 0, direct_ntiles = 0; bool direct_ok = true;
     float* d_pos12 = nullptr; size_t cap_pos12 = 0; bool pos_valid = false; uint32_t band_frames = 0;
@@ -331,6 +343,9 @@ void b32_destroy(b32_ctx* c) {
                      c->wire, c->wire_owner, c->wire_first, c->d_texels32, c->inline_lists, c->d_texmask, c->direct_lists, c->tile_fill, c->d_pos12, c->face_of };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->side) (void)hipStreamSynchronize(c->side);
+    for (auto& r : c->merged_runs) if (r.merged) { void* mp[] = { r.merged->d_verts, r.merged->d_faces, r.merged->d_texels, r.merged->d_texels32, r.merged->d_tex,
+                                                                    r.merged->d_consts, r.merged->d_texmask, r.merged->d_pos12 };
+                                                   for (void* q : mp) if (q) (void)hipFree(q); delete r.merged; }
     free_alt(c);
     if (c->alt.d_ctrl) (void)hipFree(c->alt.d_ctrl);
     for (hipEvent_t e : { c->ev_main, c->ev_setup, c->ev_done, c->alt.ev_setup, c->alt.ev_done }) if (e) (void)hipEventDestroy(e);
@@ -605,25 +620,9 @@ static void stage_flush(b32_ctx* c) {        // enqueue the one copy kernel (ord
     c->stage_active = false; c->stage_segs.count = 0; c->stage_used = 0;
 }
 
-static int upload_geometry(b32_ctx* c, const B32Vertex* v, uint32_t nv, const B32Face* f, uint32_t nf) {
-    if ((nv && !v) || (nf && !f)) return B32_E_ARG;
+// per-face work buffers of the current frame set for a mesh of nf faces
+static int ensure_work(b32_ctx* c, uint32_t nf) {
     int rc;
-    if ((rc = ensure(c, c->d_verts, c->cap_verts, (size_t)nv + 1))) return rc;
-    if ((rc = ensure(c, c->d_faces, c->cap_faces, (size_t)nf + 1))) return rc;
-    {   // can any face end up in the transparent pass? (face blend mode / editor alpha; texture blend modes are added by the callers)
-        bool mb = false;
-        for (uint32_t i = 0; i < nf && !mb; ++i) mb = f[i].blend_mode != B32_BLEND_OPAQUE || f[i].editor_alpha < 255;
-        c->may_blend = mb;
-    }
-    if ((rc = h2d(c, c->d_verts, v, (size_t)nv * sizeof(B32Vertex)))) return rc;
-    if ((rc = h2d(c, c->d_faces, f, (size_t)nf * sizeof(B32Face)))) return rc;
-    // a mesh of another size: tile regions sized afresh (the per-frame drop-in call uploads the same mesh again and again: what an
-    // overflowing frame taught the context stays)
-    if (c->nf != nf) { c->direct_cap_opaque = 0; c->direct_ntiles = 0; c->direct_ok = true; }
-    c->nv = nv; c->nf = nf;
-    c->local_sort_ok = true;
-    c->pos_valid = false; c->band_frames = 0;
-    // per-face work buffers
     if ((size_t)nf + 1 > c->cap_work || !c->crecs) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         const size_t n = (size_t)nf + nf / 4 + 16;
@@ -640,6 +639,35 @@ static int upload_geometry(b32_ctx* c, const B32Vertex* v, uint32_t nv, const B3
         if ((rc = ensure_plain(c, c->block_sums, (size_t)c->bin_blocks + 1))) return rc;
         c->cap_work = n;
     }
+    return B32_OK;
+}
+
+static int upload_geometry(b32_ctx* c, const B32Vertex* v, uint32_t nv, const B32Face* f, uint32_t nf) {
+    if ((nv && !v) || (nf && !f)) return B32_E_ARG;
+    int rc;
+    if ((rc = ensure(c, c->d_verts, c->cap_verts, (size_t)nv + 1))) return rc;
+    if ((rc = ensure(c, c->d_faces, c->cap_faces, (size_t)nf + 1))) return rc;
+    {   // can any face end up in the transparent pass? (face blend mode / editor alpha; texture blend modes are added by the callers)
+        uint32_t nb = 0;
+        uint32_t nbt = 0;                    // ... counting the faces a texture's blend mode puts there too (render.rs:2403-2415)
+        for (uint32_t i = 0; i < nf; ++i) {
+            const bool own = f[i].blend_mode != B32_BLEND_OPAQUE || f[i].editor_alpha < 255;
+            const uint32_t t = f[i].texture_id;
+            nb += own ? 1u : 0u;
+            nbt += (own || (t != B32_NO_TEXTURE && t < c->nt && t < c->h_tex.size() && c->h_tex[t].blend_mode != B32_BLEND_OPAQUE)) ? 1u : 0u;
+        }
+        c->may_blend = nb != 0; c->blend_faces = nbt;
+    }
+    if ((rc = h2d(c, c->d_verts, v, (size_t)nv * sizeof(B32Vertex)))) return rc;
+    if ((rc = h2d(c, c->d_faces, f, (size_t)nf * sizeof(B32Face)))) return rc;
+    // a mesh of another size: tile regions sized afresh (the per-frame drop-in call uploads the same mesh again and again: what an
+    // overflowing frame taught the context stays)
+    if (c->nf != nf) { c->direct_cap_opaque = 0; c->direct_ntiles = 0; c->direct_ok = true; }
+    c->nv = nv; c->nf = nf;
+    c->local_sort_ok = true;
+    c->pos_valid = false; c->band_frames = 0;
+    if ((rc = ensure_work(c, nf))) return rc;
+    c->gen = ++c->gen_counter;
     c->h_consts[0] = nf;
     if (!c->d_consts) HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_consts), 16 * sizeof(uint32_t)));   // (swapped away with a scene)
     if ((rc = h2d(c, c->d_consts, c->h_consts, sizeof(c->h_consts)))) return rc;
@@ -869,6 +897,7 @@ static FrameParams frame_params(const b32_ctx* c, const B32Camera* cam, const B3
     fp.band_only = 0;
     fp.redraw = c->redrawing ? 1 : 0;
     fp.tex_blend_any = c->tex_blend_any ? 1 : 0;
+    fp.batched = c->frame_batched ? 1 : 0;
     return fp;
 }
 
@@ -993,6 +1022,9 @@ static int plan_route(b32_ctx* c, FrameParams& fp, const SortScratch& sc, bool w
         // first guess: three times the mean list of a mesh whose every face is drawn and touches one tile; a frame that overflows
         // reports its longest list and is redrawn with regions a quarter above it (b32_frame_finish)
         if (!c->direct_cap_opaque) c->direct_cap_opaque = std::max<uint32_t>(512u, (uint32_t)std::min<uint64_t>((uint64_t)3 * c->nf / ntiles + 64, 1u << 24));
+        // a mesh of moderate size gets regions that hold ALL its faces (at most 32 MB of list space): such a frame can never overflow a
+        // region, needs no redraw, and may stay in flight across scene swaps and further frames like a small mesh's
+        if (c->nf <= 65536u && (uint64_t)ntiles * (c->nf + (r.with_class ? BLEND_SORT_CAP : 0u)) <= (8u << 20)) c->direct_cap_opaque = std::max(c->direct_cap_opaque, c->nf);
         const uint32_t cap_o = (c->direct_cap_opaque + 31u) & ~31u;
         const uint32_t region = cap_o + (r.with_class ? BLEND_SORT_CAP : 0u);
         const size_t need = (size_t)ntiles * region + 64;
@@ -1120,10 +1152,10 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     int rc;
     const bool prof_sample = c->profile_level >= 1 && (c->prof_seq++ % c->prof_stride) == 0;
     const bool prof_all = prof_sample && c->profile_level >= 2, prof_fill = prof_sample;
-    // Two frames in flight: when an earlier frame of this context is still pending, this frame takes the OTHER frame set and (if it
-    // ends up on a sort-free route without a binning launch) its setup kernel runs on the side stream, beside that frame's fill.
+    // Two frames in flight: when an earlier frame of this context is still pending, this frame of a large mesh takes the OTHER frame set
+    // and (if it ends up on the direct-binning route) its setup kernel runs on the side stream, beside that frame's fill.
     c->pipelined = false;
-    if (c->frame_pending && !c->redrawing && !fp.wire_collect && !prof_all && c->nf && !(c->route_off & B32_ROUTE_PIPELINE)) {
+    if (c->frame_pending && !c->redrawing && !fp.wire_collect && !prof_all && c->nf > 2048u && !(c->route_off & B32_ROUTE_PIPELINE)) {
         if ((rc = pipeline_ensure(c))) return rc;
         swap_sets(c);
         c->pipelined = true;
@@ -1142,7 +1174,9 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     const SortScratch sc{ c->block_hist, c->hist_blocks, c->digit_total };
     Route r;
     if ((rc = plan_route(c, fp, sc, wire_front, r))) return rc;
-    if (c->pipelined && !(r.direct_bin || r.want_inline)) c->pipelined = false;     // (binning launches follow k_setup: one stream)
+    // (only large meshes: the frames of small ones are launch-latency bound and the cross-stream events cost them more than the overlap
+    // returns -- a 12-room console frame 0.72 ms against 0.65; keyed routes have binning launches behind k_setup: one stream)
+    if (c->pipelined && !r.direct_bin) c->pipelined = false;
     const uint32_t ntiles = fp.tiles_x * fp.tiles_y;
     c->last_local_sort = r.local_sort || r.want_prio64;                         // the global draw order is not materialised
     c->last_exact = r.ordered_all ? true : (r.exact_cov && !fp.zmode);          // the ordered walk counts every store it performs
@@ -1171,7 +1205,7 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
         }
     }
     if (prof_all) HIPCHK(c, hipEventRecord(ev[0], s));
-    launch_setup(ss, fp, c->d_verts, c->d_faces, c->d_tex, c->d_lights, lset, RecArrays{ c->crecs, c->srecs, c->xrecs }, r.db, c->shades, c->keys[0],
+    launch_setup(ss, fp, c->d_verts, c->d_faces, c->d_tex, c->d_lights, lset, c->frame_table, RecArrays{ c->crecs, c->srecs, c->xrecs }, r.db, c->shades, c->keys[0],
                  r.direct_bin ? nullptr : c->spans /* (direct binning: nobody reads the spans) */, c->partials, c->d_ctrl, c->wire, c->n_cu, pos12, attr12, c->face_of);
     if (c->pipelined) {
         hipError_t e1 = hipEventRecord(c->ev_setup, c->side);
@@ -1202,7 +1236,10 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     if (!r.prio64 && (rc = bin_keyed(c, fp, r, sc, prof_all ? ev[2] : nullptr, cur))) return rc;
     c->last_pair_buf = cur;
     c->routes[r.direct_bin ? 0 : r.inline_bin ? 1 : r.prio64 ? 2 : 3]++;
-    c->pending_may_redraw = !r.inline_bin;
+    // (direct binning with regions that hold the whole mesh, and no more faces that can be transparent than k_blend sorts per tile:
+    // nothing can overflow)
+    const bool direct_safe = r.direct_bin && r.db.cap_opaque >= c->nf && (!r.with_class || c->blend_faces <= BLEND_SORT_CAP);
+    c->pending_may_redraw = !(r.inline_bin || direct_safe);
     if (prof_fill) HIPCHK(c, hipEventRecord(ev[3], s));
 
     // ---- coverage, shading, transparent pass
@@ -1237,10 +1274,12 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
 static int render_scene_async_any(b32_ctx* c, const B32Camera* cam, const B32Settings* st, const B32Fog* fog);
 int b32_render_scene_15_async(b32_ctx* c, const B32Camera* cam, const B32Settings* st, const B32Fog* fog) {
     if (!c || c->fmt8) return B32_E_ARG;                 // the resident scene holds Texture (8-bit) texels: use b32_render_scene
+    c->frame_batched = false;
     return render_scene_async_any(c, cam, st, fog);
 }
 int b32_render_scene_async(b32_ctx* c, const B32Camera* cam, const B32Settings* st) {
     if (!c || !c->fmt8) return B32_E_ARG;
+    c->frame_batched = false;
     return render_scene_async_any(c, cam, st, nullptr);
 }
 static int render_scene_async_any(b32_ctx* c, const B32Camera* cam, const B32Settings* st, const B32Fog* fog) {
@@ -1433,7 +1472,7 @@ int b32_scene_swap(b32_ctx* c, b32_scene* sl) {
     std::swap(c->mask_dirty, sl->mask_dirty);
     c->h_tex.swap(sl->h_tex);
     std::swap(c->nv, sl->nv); std::swap(c->nf, sl->nf); std::swap(c->nt, sl->nt);
-    std::swap(c->fmt8, sl->fmt8); std::swap(c->blend8, sl->blend8); std::swap(c->have_scene, sl->have_scene);
+    std::swap(c->fmt8, sl->fmt8); std::swap(c->blend8, sl->blend8); std::swap(c->have_scene, sl->have_scene); std::swap(c->gen, sl->gen); std::swap(c->blend_faces, sl->blend_faces);
     std::swap(c->may_blend, sl->may_blend); std::swap(c->cheap_ok, sl->cheap_ok); std::swap(c->local_sort_ok, sl->local_sort_ok);
     std::swap(c->tex_blend_any, sl->tex_blend_any);
     std::swap(c->direct_cap_opaque, sl->direct_cap_opaque); std::swap(c->direct_ntiles, sl->direct_ntiles); std::swap(c->direct_ok, sl->direct_ok);
@@ -1441,6 +1480,167 @@ int b32_scene_swap(b32_ctx* c, b32_scene* sl) {
     c->tex_sig.swap(sl->tex_sig); std::swap(c->tex_sig_valid, sl->tex_sig_valid);
     return B32_OK;
 }
+
+
+// ------------------------------------------------------------------ batched frame (several meshes, one setup + fill pair)
+// scene.rs:112-261 draws a frame as one render_mesh_15 call per room and per asset part onto the same framebuffer: at 320x240 that is a
+// chain of launch-latency bound kernel pairs (~50 us per mesh).  b32_frame_begin / b32_frame_add_scene / b32_frame_end take the same
+// sequence of calls -- resident meshes in scene slots, one camera and base settings per frame, ambient / fog / backface_cull per mesh as
+// the reference's callers vary them -- and draw every RUN of meshes that commutes as ONE merged mesh:
+//   * z-buffer mode (RasterSettings::game() and the reference default): opaque fragments are depth-tested, so their order does not
+//     matter, and a depth tie goes to the earlier face exactly like the sequential strict `z < zbuffer` (the priority's low word is
+//     the record slot, monotone in mesh order then face order);
+//   * a mesh with a transparent pass blends against what was drawn before it, so it ENDS its run: its opaque faces join the merged
+//     opaque pass, its transparent faces are the run's transparent pass (all earlier opaque faces are in place by then, as in the
+//     sequential calls);
+//   * painter's mode, the 8-bit-colour path, x-ray, orthographic views and the wireframe phases are drawn mesh by mesh as before.
+// The merged mesh (vertices, faces with the member number in their spare byte, texel pool, texture descriptors) is built on the device
+// from the slots and kept while the members' contents stay the same.
+static void release_scene_buffers(b32_scene* sl) {
+    void* ptrs[] = { sl->d_verts, sl->d_faces, sl->d_texels, sl->d_texels32, sl->d_tex, sl->d_consts, sl->d_texmask, sl->d_pos12 };
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+}
+static int build_merged(b32_ctx* c, const b32_ctx::BatchEntry* e, uint32_t n, b32_scene* m) {
+    uint64_t nv = 0, nf = 0, nt = 0, pool = 0;
+    for (uint32_t j = 0; j < n; ++j) { const b32_scene* sl = e[j].slot; nv += sl->nv; nf += sl->nf; nt += sl->nt; pool += sl->pool_texels; }
+    if (nv >= 0x7FFFFFFFull || nf >= 0x7FFFFFFFull || nt > 65534 || pool > 0x7FFFFFFFull) return B32_E_UNSUPPORTED;
+    int rc;
+    if ((rc = ensure(c, m->d_verts, m->cap_verts, (size_t)nv + 1))) return rc;
+    if ((rc = ensure(c, m->d_faces, m->cap_faces, (size_t)nf + 1))) return rc;
+    if ((rc = ensure(c, m->d_texels, m->cap_texels, (size_t)pool + 8))) return rc;
+    if ((rc = ensure(c, m->d_tex, m->cap_tex, (size_t)nt + 1))) return rc;
+    if ((rc = ensure(c, m->d_texmask, m->cap_texmask, (size_t)pool / 32 + 4))) return rc;
+    if (!m->d_consts) HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&m->d_consts), 16 * sizeof(uint32_t)));
+    m->h_tex.clear();
+    uint32_t vb = 0, fb = 0, tb = 0, pb = 0;
+    m->may_blend = false; m->cheap_ok = true; m->tex_blend_any = false; m->blend_faces = 0;
+    for (uint32_t j = 0; j < n; ++j) {
+        const b32_scene* sl = e[j].slot;
+        launch_merge_mesh(c->stream, sl->d_verts, sl->nv, sl->d_faces, sl->nf, sl->nt, m->d_verts, m->d_faces + fb, vb, tb, j);
+        if (sl->pool_texels) HIPCHK(c, hipMemcpyAsync(m->d_texels + pb, sl->d_texels, (size_t)sl->pool_texels * 2, hipMemcpyDeviceToDevice, c->stream));
+        launch_offset_tex(c->stream, sl->d_tex, sl->nt, m->d_tex + tb, pb);
+        for (const TexDesc& d : sl->h_tex) m->h_tex.push_back({ d.width, d.height, d.blend_mode, d.offset + pb });
+        m->may_blend |= sl->may_blend; m->cheap_ok &= sl->cheap_ok; m->tex_blend_any |= sl->tex_blend_any;
+        m->blend_faces += sl->blend_faces;
+        vb += sl->nv; fb += sl->nf; tb += sl->nt; pb += sl->pool_texels;
+    }
+    const uint32_t consts[4] = { (uint32_t)nf, 0, 0, 0 };
+    HIPCHK(c, hipMemcpyAsync(m->d_consts, consts, sizeof(consts), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));          // (`consts` is on the stack; a merged mesh is built once and reused)
+    HIPCHK(c, hipGetLastError());
+    m->nv = (uint32_t)nv; m->nf = (uint32_t)nf; m->nt = (uint32_t)nt; m->pool_texels = (uint32_t)pool; m->mask_dirty = true;
+    m->fmt8 = false; m->blend8 = false; m->have_scene = true; m->local_sort_ok = true;
+    m->direct_cap_opaque = 0; m->direct_ntiles = 0; m->direct_ok = true; m->pos_valid = false; m->band_frames = 0;
+    m->tex_sig_valid = false; m->gen = ++c->gen_counter;
+    c->side_dirty = true;
+    return B32_OK;
+}
+// the merged mesh of a run: from the cache when the same slots with the same contents were merged before
+static int merged_for(b32_ctx* c, const b32_ctx::BatchEntry* e, uint32_t n, b32_scene** out) {
+    ++c->batch_clock;
+    for (auto& r : c->merged_runs) {
+        if (r.members.size() != n) continue;
+        bool same = true;
+        for (uint32_t j = 0; same && j < n; ++j) same = r.members[j] == e[j].slot && r.gens[j] == e[j].slot->gen;
+        if (same) { r.used = c->batch_clock; *out = r.merged; return B32_OK; }
+    }
+    b32_ctx::MergedRun* slot = nullptr;
+    if (c->merged_runs.size() >= 64) {                   // bounded cache: the least recently used merged mesh makes room
+        slot = &c->merged_runs[0];
+        for (auto& r : c->merged_runs) if (r.used < slot->used) slot = &r;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    } else { c->merged_runs.emplace_back(); slot = &c->merged_runs.back(); slot->merged = new b32_scene(); }
+    slot->members.clear(); slot->gens.clear();
+    const int rc = build_merged(c, e, n, slot->merged);
+    if (rc) return rc;
+    for (uint32_t j = 0; j < n; ++j) { slot->members.push_back(e[j].slot); slot->gens.push_back(e[j].slot->gen); }
+    slot->used = c->batch_clock;
+    c->batch_stats[2]++;
+    *out = slot->merged;
+    return B32_OK;
+}
+
+int b32_frame_begin(b32_ctx* c, const B32Camera* cam, const B32Settings* st) {
+    if (!c || !cam || !st || !c->fb) return B32_E_ARG;
+    const int rc = validate_settings(st);
+    if (rc) return rc;
+    c->batch_cam = *cam; c->batch_st = *st;
+    c->batch_lights.assign(st->lights, st->lights + (st->lights ? st->n_lights : 0));
+    c->batch_st.lights = nullptr;                         // (patched to the private copy when the frame is enqueued)
+    c->batch.clear();
+    c->batch_open = true;
+    return B32_OK;
+}
+int b32_frame_add_scene(b32_ctx* c, b32_scene* sl, const B32MeshParams* p) {
+    if (!c || !sl || !c->batch_open) return B32_E_ARG;
+    b32_ctx::BatchEntry e{};
+    e.slot = sl;
+    e.row.ambient = p ? p->ambient : c->batch_st.ambient;
+    const bool cull = p ? p->backface_cull != 0 : c->batch_st.backface_cull != 0;
+    const bool fogged = p && p->has_fog;
+    e.row.flags = (cull ? 1u : 0u) | (fogged ? 2u : 0u);
+    if (fogged) e.row.fog = p->fog;
+    e.wire = (p ? p->backface_wireframe != 0 : c->batch_st.backface_wireframe != 0) && cull;       // render.rs:2577
+    c->batch.push_back(e);
+    return B32_OK;
+}
+int b32_frame_end(b32_ctx* c) {
+    if (!c || !c->batch_open) return B32_E_ARG;
+    c->batch_open = false;
+    (void)hipSetDevice(c->device);
+    B32Settings base = c->batch_st;
+    base.lights = c->batch_lights.empty() ? nullptr : c->batch_lights.data();
+    base.n_lights = (uint32_t)c->batch_lights.size();
+    const bool can_merge = base.use_zbuffer && base.use_rgb555 && !base.xray_mode && !base.has_ortho && !base.wireframe_overlay &&
+                           !(c->route_off & B32_ROUTE_BATCH);
+    c->batch_stats[3]++;
+    const size_t n = c->batch.size();
+    int rc = B32_OK;
+    auto draw_one = [&](const b32_ctx::BatchEntry& e) -> int {      // the mesh on its own, exactly like a b32_render_scene_15_async call
+        B32Settings st = base;
+        st.ambient = e.row.ambient; st.backface_cull = (e.row.flags & 1u) ? 1 : 0; st.backface_wireframe = e.wire ? 1 : 0;
+        int r = b32_scene_swap(c, e.slot);
+        if (r) return r;
+        if (!c->have_scene) r = B32_E_ARG;
+        else if (c->fmt8) { c->frame_batched = false; r = render_scene_async_any(c, &c->batch_cam, &st, nullptr); }
+        else { c->frame_batched = false; r = render_scene_async_any(c, &c->batch_cam, &st, (e.row.flags & 2u) ? &e.row.fog : nullptr); }
+        const int r2 = b32_scene_swap(c, e.slot);
+        c->batch_stats[1]++;
+        return r ? r : r2;
+    };
+    size_t i = 0;
+    while (i < n && rc == B32_OK) {
+        // the run starting at mesh i: meshes that commute, ended by (and including) the first one with a transparent pass
+        size_t k = i;
+        if (can_merge) {
+            while (k < n && k - i < BATCH_MESHES) {
+                const b32_scene* sl = c->batch[k].slot;
+                if (!sl->have_scene || sl->fmt8 || c->batch[k].wire || !sl->nf) break;
+                ++k;
+                if (sl->may_blend) break;
+            }
+        }
+        if (k - i < 2) { rc = draw_one(c->batch[i]); ++i; continue; }
+        b32_scene* m = nullptr;
+        if ((rc = merged_for(c, &c->batch[i], (uint32_t)(k - i), &m))) break;
+        if ((rc = b32_scene_swap(c, m))) break;
+        rc = ensure_work(c, c->nf);
+        if (rc == B32_OK) {
+            bool any_fog = false;
+            for (size_t j = i; j < k; ++j) { c->frame_table.m[j - i] = c->batch[j].row; any_fog |= (c->batch[j].row.flags & 2u) != 0; }
+            c->frame_batched = true;
+            B32Fog f0{};                                    // (fp.has_fog switches the fog code on; the rows decide per mesh)
+            rc = render_scene_async_any(c, &c->batch_cam, &base, any_fog ? &f0 : nullptr);
+            c->batch_stats[0]++;
+        }
+        const int r2 = b32_scene_swap(c, m);
+        if (rc == B32_OK) rc = r2;
+        i = k;
+    }
+    c->batch.clear();
+    return rc;
+}
+unsigned long long b32_batch_count(const b32_ctx* c, int which) { return (c && which >= 0 && which < 4) ? c->batch_stats[which] : 0ull; }
 
 // RasterTimings of a synchronous call: the per-phase split comes from the device-side phase clock (b32_frame_finish); the wall time of
 // the whole call is reported as draw_ms only for an empty mesh, where no kernel ran.

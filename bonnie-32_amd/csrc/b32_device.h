@@ -227,7 +227,7 @@ struct FrameParams {
     uint8_t affine, shading, backface_cull, dithering, fixed_point, has_fog, zmode, fmt8;   // zmode = settings.use_zbuffer; fmt8 = render_mesh (8-bit colour)
     uint8_t ortho, xray, wire_collect, band_only;   // ortho_projection.is_some(), xray_mode, any wireframe phase wants its triangles;
                                                     // band_only: records of surfaces outside this rank's band are not needed (sort-free path)
-    uint8_t redraw, lights_inline, tex_blend_any, _padb;   // tex_blend_any: some texture's blend mode is not Opaque (else k_setup never reads the descriptors)        // redraw: the host is repeating a dropped frame (not a new one); lights_inline: the
+    uint8_t redraw, lights_inline, tex_blend_any, batched;   // batched: per-mesh ambient / fog / backface_cull from the MeshTable   // tex_blend_any: some texture's blend mode is not Opaque (else k_setup never reads the descriptors)        // redraw: the host is repeating a dropped frame (not a new one); lights_inline: the
                                                     // lights travel in the kernel arguments (LightSet) instead of a device buffer
     float ortho_zoom, ortho_cx, ortho_cy;      // OrthoProjection (types.rs), math.rs:140-148
     B32Fog fog;
@@ -355,6 +355,13 @@ void launch_radix_pass(hipStream_t s, const uint32_t* keys_in, const uint32_t* v
 // up to LIGHTS_INLINE lights travel by value in the kernel arguments: a light change costs no copy and no synchronisation
 constexpr uint32_t LIGHTS_INLINE = 8;
 struct LightSet { B32Light l[LIGHTS_INLINE]; };
+// Batched frame (b32_frame_begin / _add_scene / _end): several meshes merged into one resident mesh, drawn by ONE k_setup + fill pair.
+// What the reference's callers vary from mesh to mesh (scene.rs:112-261: per-room ambient and fog, per-part double_sided) travels in
+// this table, indexed by the mesh number k_merge_mesh left in the spare byte of every merged face; everything else (camera, lights,
+// the other settings) is the frame's.
+constexpr uint32_t BATCH_MESHES = 32;
+struct MeshRow { float ambient; uint32_t flags; B32Fog fog; };       // flags: bit 0 backface_cull, bit 1 fog is Some
+struct MeshTable { MeshRow m[BATCH_MESHES]; };
 struct RecArrays { CovRec* cov; ShadeRec* shade; AuxRec* aux; };
 // Direct binning (sort-free path, meshes too large for the in-kernel collection): k_setup itself appends every surviving face to the
 // lists of the tiles its span touches -- one returning atomic per (tile, face) pair on the tile's fill counter, whose latency passes
@@ -373,8 +380,11 @@ struct DirectBin {
     uint32_t with_class;        // 1: faces of the transparent pass (render.rs:2522-2523) go to the back of the region
     uint32_t epoch;
 };
+void launch_merge_mesh(hipStream_t s, const B32Vertex* sv, uint32_t nv, const B32Face* sf, uint32_t nf, uint32_t nt, B32Vertex* dv, B32Face* df,
+                       uint32_t vbase, uint32_t tbase, uint32_t mesh);
+void launch_offset_tex(hipStream_t s, const TexDesc* src, uint32_t nt, TexDesc* dst, uint32_t texel_base);
 void launch_setup(hipStream_t s, const FrameParams& fp, const B32Vertex* verts, const B32Face* faces, const TexDesc* tex,
-                  const B32Light* lights, const LightSet& inline_lights, RecArrays recs, const DirectBin& direct, float* shades, uint32_t* keys, uint32_t* spans,
+                  const B32Light* lights, const LightSet& inline_lights, const MeshTable& mesh_table, RecArrays recs, const DirectBin& direct, float* shades, uint32_t* keys, uint32_t* spans,
                   uint32_t* partials, Ctrl* ctrl, WireTri* wire, int n_cu, const float* pos12, const float* attr12, uint32_t* face_of);
 void launch_gate(hipStream_t s, const Ctrl* prev, uint32_t need, uint32_t patience_ticks);
 void launch_pack_streams(hipStream_t s, const B32Vertex* verts, uint32_t nv, float* pos12, float* attr12);

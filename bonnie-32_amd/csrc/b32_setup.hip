@@ -215,14 +215,14 @@ __device__ __forceinline__ uint32_t agg_position(const AggSlot& g) {
 // RGB555): those branches are compiled out -- fewer live scalars, less code in the instruction cache, no exec-mask juggling around them
 template <int SETUP_FPT, bool PLAIN>
 __global__ __launch_bounds__(256) void k_setup(FrameParams fp_in, const B32Vertex* __restrict__ verts, const B32Face* __restrict__ faces,
-                                               const TexDesc* __restrict__ tex, const B32Light* __restrict__ lights_mem, LightSet lset,
+                                               const TexDesc* __restrict__ tex, const B32Light* __restrict__ lights_mem, LightSet lset, MeshTable mtab,
                                                RecArrays recs, DirectBin db, float* __restrict__ shades, uint32_t* __restrict__ keys,
                                                uint32_t* __restrict__ spans, uint32_t* __restrict__ partials, Ctrl* __restrict__ ctrl,
                                                WireTri* __restrict__ wire, const float* __restrict__ pos12, const float* __restrict__ attr12,
                                                uint32_t* __restrict__ face_of) {
     FrameParams fp_plain = fp_in;                 // (dead code unless PLAIN)
     if (PLAIN) { fp_plain.ortho = 0; fp_plain.fixed_point = 1; fp_plain.has_fog = 0; fp_plain.wire_collect = 0; fp_plain.shading = B32_SHADE_NONE;
-                 fp_plain.xray = 0; fp_plain.fmt8 = 0; fp_plain.n_lights = 0; }
+                 fp_plain.xray = 0; fp_plain.fmt8 = 0; fp_plain.n_lights = 0; fp_plain.batched = 0; }
     const FrameParams& fp = PLAIN ? fp_plain : fp_in;
     __shared__ uint32_t wpart[4][6];
     __shared__ uint8_t unr_lds[K::UNR_ENTRIES + 3];          // UNR_TABLE in LDS: its lookup sits in every vertex's dependent chain
@@ -287,6 +287,12 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp_in, const B32Verte
         uint32_t vi[3] = { in.w[0], in.w[1], in.w[2] };
         const uint32_t tid = in.w[3], fb4 = in.w[4];
         const uint32_t black_tr = fb4 & 0xFF, face_blend = (fb4 >> 8) & 0xFF, editor_alpha = (fb4 >> 16) & 0xFF;
+        // per-mesh parameters of a batched frame (mesh number in the face's spare byte), else the frame's
+        float m_ambient = fp.ambient; bool m_cull = fp.backface_cull != 0, m_has_fog = fp.has_fog != 0; B32Fog m_fog = fp.fog;
+        if (fp.batched) {
+            const MeshRow& mr = mtab.m[(fb4 >> 24) & (BATCH_MESHES - 1u)];
+            m_ambient = mr.ambient; m_cull = (mr.flags & 1u) != 0; m_has_fog = (mr.flags & 2u) != 0; m_fog = mr.fog;
+        }
         if (in.bad) {
             bad_index = true;
         } else {
@@ -326,7 +332,7 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp_in, const B32Verte
             uint32_t tex_blend = B32_BLEND_OPAQUE;
             if (fp.tex_blend_any && keep && have_tex) tex_blend = tex[tid].blend_mode;     // (all Opaque: no descriptor gather in the chain)
             // fog, render.rs:2419-2442: the distance cull here, the colours further down (only surfaces whose record is built need them)
-            if (fp.has_fog && keep && camz[0] > fp.fog.cull_distance && camz[1] > fp.fog.cull_distance && camz[2] > fp.fog.cull_distance) keep = false;
+            if (fp.has_fog && m_has_fog && keep && camz[0] > m_fog.cull_distance && camz[1] > m_fog.cull_distance && camz[2] > m_fog.cull_distance) keep = false;
             if (fp.wire_collect) {                       // wireframe lists take the face before the solid decision (render.rs:2445-2449, 2509-2511)
                 WireTri wt;
 #pragma unroll
@@ -334,7 +340,7 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp_in, const B32Verte
                 wt.kind = !keep ? 0u : (backface ? (fp.xray ? 0u : 1u) : 2u);
                 wire[f] = wt;
             }
-            if (backface && fp.backface_cull && !fp.xray) keep = false;              // render.rs:2451-2453
+            if (backface && m_cull && !fp.xray) keep = false;              // render.rs:2451-2453
             if (keep) {
                 visible = true;
                 // Record slot: the survivors of a wave's 64 faces are packed to the front of the wave's 64 slots (slot = first face id of
@@ -380,10 +386,10 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp_in, const B32Verte
                         uvx[j] = ap[0]; uvy[j] = ap[1]; col[j] = reinterpret_cast<const uint32_t*>(ap)[2];
                     }
                 }
-                if (fp.has_fog) {
-                    const uint32_t fogc = fp.fog.r | (fp.fog.g << 8) | (fp.fog.b << 16) | ((uint32_t)fp.fog.blend << 24);
+                if (fp.has_fog && m_has_fog) {
+                    const uint32_t fogc = m_fog.r | (m_fog.g << 8) | (m_fog.b << 16) | ((uint32_t)m_fog.blend << 24);
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) col[j] = fog_color(col[j], fogc, fog_factor(camz[j], fp.fog.start, fp.fog.falloff));
+                    for (int j = 0; j < 3; ++j) col[j] = fog_color(col[j], fogc, fog_factor(camz[j], m_fog.start, m_fog.falloff));
                 }
                 r.inv_area = 1.0f / area;
                 r.a0 = v2.y - v3.y; r.b0 = v3.x - v2.x; r.a1 = v3.y - v1.y; r.b1 = v1.x - v3.x;   // :1507-1510
@@ -439,12 +445,12 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp_in, const B32Verte
                     if (fp.shading == B32_SHADE_FLAT) {                                             // :1466-1469
                         V3 center = scale3(add3(add3(wpos[i1], wpos[i2]), wpos[i3]), 1.0f / 3.0f);
                         V3 nrm = normalize3(scale3(add3(add3(wn[i1], wn[i2]), wn[i3]), 1.0f / 3.0f));
-                        float s[3]; shade_multi(nrm, center, lights, fp.n_lights, fp.ambient, s);
+                        float s[3]; shade_multi(nrm, center, lights, fp.n_lights, m_ambient, s);
                         for (int j = 0; j < 9; ++j) sh[j] = s[j % 3];
                     } else {                                                                        // :1475-1483
-                        shade_multi(wn[i1], wpos[i1], lights, fp.n_lights, fp.ambient, sh);
-                        shade_multi(wn[i2], wpos[i2], lights, fp.n_lights, fp.ambient, sh + 3);
-                        shade_multi(wn[i3], wpos[i3], lights, fp.n_lights, fp.ambient, sh + 6);
+                        shade_multi(wn[i1], wpos[i1], lights, fp.n_lights, m_ambient, sh);
+                        shade_multi(wn[i2], wpos[i2], lights, fp.n_lights, m_ambient, sh + 3);
+                        shade_multi(wn[i3], wpos[i3], lights, fp.n_lights, m_ambient, sh + 6);
                     }
                 }
                 // painter's key, render.rs:2529-2531 / 2538-2540. Perspective keys are > 5 (cam z > 0.1), so the sign bit
@@ -548,16 +554,52 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp_in, const B32Verte
 }
 
 void launch_setup(hipStream_t s, const FrameParams& fp, const B32Vertex* verts, const B32Face* faces, const TexDesc* tex,
-                  const B32Light* lights, const LightSet& ls, RecArrays recs, const DirectBin& db, float* shades, uint32_t* keys, uint32_t* spans, uint32_t* partials,
+                  const B32Light* lights, const LightSet& ls, const MeshTable& mt, RecArrays recs, const DirectBin& db, float* shades, uint32_t* keys, uint32_t* spans, uint32_t* partials,
                   Ctrl* ctrl, WireTri* wire, int n_cu, const float* pos12, const float* attr12, uint32_t* face_of) {
     (void)n_cu;
     if (fp.nf == 0) return;
-    const bool plain = fp.fixed_point && !fp.ortho && !fp.has_fog && !fp.wire_collect && fp.shading == B32_SHADE_NONE && !fp.xray && !fp.fmt8;
+    const bool plain = fp.fixed_point && !fp.ortho && !fp.has_fog && !fp.wire_collect && fp.shading == B32_SHADE_NONE && !fp.xray && !fp.fmt8 && !fp.batched;
     // one face per thread: 52 VGPRs in the plain form = 8 waves per SIMD (two faces per thread with their loads issued up front: 73 VGPRs,
     // 43 us instead of 39 at 1 M faces; three: 49 us)
     const dim3 g1((fp.nf + 255) / 256);
-    if (plain) hipLaunchKernelGGL((k_setup<1, true>), g1, dim3(256), 0, s, fp, verts, faces, tex, lights, ls, recs, db, shades, keys, spans, partials, ctrl, wire, pos12, attr12, face_of);
-    else hipLaunchKernelGGL((k_setup<1, false>), g1, dim3(256), 0, s, fp, verts, faces, tex, lights, ls, recs, db, shades, keys, spans, partials, ctrl, wire, pos12, attr12, face_of);
+    if (plain) hipLaunchKernelGGL((k_setup<1, true>), g1, dim3(256), 0, s, fp, verts, faces, tex, lights, ls, mt, recs, db, shades, keys, spans, partials, ctrl, wire, pos12, attr12, face_of);
+    else hipLaunchKernelGGL((k_setup<1, false>), g1, dim3(256), 0, s, fp, verts, faces, tex, lights, ls, mt, recs, db, shades, keys, spans, partials, ctrl, wire, pos12, attr12, face_of);
+}
+
+// ---------------------------------------------------------------- merged mesh of a batched frame
+// One member mesh into the merged vertex / face arrays: vertex indices and texture ids move by the member's bases, and the member's
+// number goes into the face's spare byte (k_setup's MeshTable index).  What the reference decides per call keeps its meaning: a vertex
+// index past the member's OWN vertex count stays out of range (index panic, render.rs:2375), a texture id past its OWN texture count
+// stays None (textures.get(id), render.rs:2554).
+__global__ void k_merge_mesh(const B32Vertex* __restrict__ sv, uint32_t nv, const B32Face* __restrict__ sf, uint32_t nf, uint32_t nt,
+                             B32Vertex* __restrict__ dv, B32Face* __restrict__ df, uint32_t vbase, uint32_t tbase, uint32_t mesh) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nv) {
+        const uint32_t* s = reinterpret_cast<const uint32_t*>(sv) + (size_t)i * 9;
+        uint32_t* d = reinterpret_cast<uint32_t*>(dv) + (size_t)(vbase + i) * 9;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) d[k] = s[k];
+    }
+    if (i < nf) {
+        const uint32_t* s = reinterpret_cast<const uint32_t*>(sf) + (size_t)i * 5;
+        uint32_t* d = reinterpret_cast<uint32_t*>(df) + (size_t)i * 5;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) d[k] = s[k] < nv ? s[k] + vbase : 0xFFFFFFFFu;
+        d[3] = (s[3] != B32_NO_TEXTURE && s[3] < nt) ? s[3] + tbase : B32_NO_TEXTURE;
+        d[4] = (s[4] & 0x00FFFFFFu) | (mesh << 24);
+    }
+}
+void launch_merge_mesh(hipStream_t s, const B32Vertex* sv, uint32_t nv, const B32Face* sf, uint32_t nf, uint32_t nt, B32Vertex* dv, B32Face* df,
+                       uint32_t vbase, uint32_t tbase, uint32_t mesh) {
+    const uint32_t n = nv > nf ? nv : nf;
+    if (n) hipLaunchKernelGGL(k_merge_mesh, dim3((n + 255) / 256), dim3(256), 0, s, sv, nv, sf, nf, nt, dv, df, vbase, tbase, mesh);
+}
+__global__ void k_offset_tex(const TexDesc* __restrict__ src, uint32_t nt, TexDesc* __restrict__ dst, uint32_t texel_base) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nt) { TexDesc d = src[i]; d.offset += texel_base; dst[i] = d; }
+}
+void launch_offset_tex(hipStream_t s, const TexDesc* src, uint32_t nt, TexDesc* dst, uint32_t texel_base) {
+    if (nt) hipLaunchKernelGGL(k_offset_tex, dim3((nt + 255) / 256), dim3(256), 0, s, src, nt, dst, texel_base);
 }
 
 // ---------------------------------------------------------------- gate of a pipelined setup kernel (two frames in flight)

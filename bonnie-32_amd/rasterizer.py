@@ -74,7 +74,41 @@ class Context:
 
     ROUTES = ("direct_bin", "inline_bin", "counting_sort", "keyed", "redraw_region", "redraw_global_sort", "redraw_pairs", "pipelined")
 
-    ROUTE_SORT_FREE, ROUTE_CUT_TILES, ROUTE_INLINE_BIN, ROUTE_DIRECT_BIN, ROUTE_WIDE_GROUPS, ROUTE_PACKED_STREAMS, ROUTE_PIPELINE, ROUTE_TEX_CACHE = 1, 2, 4, 8, 16, 32, 64, 128
+    ROUTE_SORT_FREE, ROUTE_CUT_TILES, ROUTE_INLINE_BIN, ROUTE_DIRECT_BIN, ROUTE_WIDE_GROUPS, ROUTE_PACKED_STREAMS, ROUTE_PIPELINE, ROUTE_TEX_CACHE, ROUTE_BATCH = 1, 2, 4, 8, 16, 32, 64, 128, 256
+
+    # ---- a frame of several meshes (scene.rs:112-261): b32_frame_begin / _add_scene / _end
+    def frame_begin(self, camera, settings):
+        """One camera, base settings and light list for the frame; the meshes follow with frame_add (resident scenes in slots)."""
+        cam = camera.pack()
+        st, keep = settings.pack()
+        self._frame_keep = (cam, st, keep)
+        _chk(self.lib.b32_frame_begin(self.h, C.byref(cam), C.byref(st)), "b32_frame_begin")
+
+    def frame_add(self, scene, ambient=None, backface_cull=None, backface_wireframe=None, fog=None):
+        """Append a detached ResidentScene with its per-mesh parameters (None: the base settings' value; fog None: no fog)."""
+        st = self._frame_keep[1]
+        p = abi.B32MeshParams()
+        p.ambient = float(st.ambient if ambient is None else ambient)
+        p.backface_cull = int(st.backface_cull if backface_cull is None else bool(backface_cull))
+        p.backface_wireframe = int(st.backface_wireframe if backface_wireframe is None else bool(backface_wireframe))
+        fg = T.pack_fog(fog)
+        p.has_fog = 0 if fg is None else 1
+        if fg is not None:
+            p.fog = fg
+        scene.detach()
+        _chk(self.lib.b32_frame_add_scene(self.h, scene._slot, C.byref(p)), "b32_frame_add_scene")
+
+    def frame_end(self):
+        _chk(self.lib.b32_frame_end(self.h), "b32_frame_end")
+
+    def finish(self) -> T.RasterTimings:
+        """b32_frame_finish of whatever this context has in flight."""
+        tm = abi.B32Timings()
+        _chk(self.lib.b32_frame_finish(self.h, C.byref(tm)), "b32_frame_finish")
+        return T.RasterTimings.from_c(tm)
+
+    def batch_counts(self):
+        return {n: int(self.lib.b32_batch_count(self.h, i)) for i, n in enumerate(("merged_draws", "single_draws", "merged_built", "frames"))}
 
     def set_pipeline_gate(self, permille):
         """b32_set_pipeline_gate: hold a pipelined setup kernel until that share of the previous fill's tiles has started."""

@@ -255,6 +255,7 @@ unsigned long long b32_route_count(const b32_ctx* ctx, int which);
 #define B32_ROUTE_WIDE_GROUPS 16u  /* 16-wave workgroups of the fused kernel when tiles are few -> always 8 waves                  */
 #define B32_ROUTE_PACKED_STREAMS 32u /* resident large meshes: packed position / attribute streams for the setup kernel -> B32Vertex array */
 #define B32_ROUTE_TEX_CACHE   128u /* drop-in calls: texture cache by (pointer, size, blend mode, 64-bit content hash) -> texels uploaded on every call */
+#define B32_ROUTE_BATCH       256u /* b32_frame_end: runs of commuting meshes drawn as one merged mesh -> one draw per mesh           */
 #define B32_ROUTE_PIPELINE    64u  /* setup kernel of the next frame on a second stream beside the fill of the current one -> one stream */
 int b32_set_routes(b32_ctx* ctx, uint32_t off_mask);
 /* CHEAP coverage (inside test only, texel rule applied to the winner) is used while every texture has at most 1/den skippable texels
@@ -275,6 +276,32 @@ typedef struct b32_scene b32_scene;
 int b32_scene_create(b32_ctx* ctx, b32_scene** out);
 void b32_scene_destroy(b32_ctx* ctx, b32_scene* slot);
 int b32_scene_swap(b32_ctx* ctx, b32_scene* slot);
+
+/* ---- a frame of several meshes (scene.rs:112-261) -------------------------------------------------------------------------------
+ * The console's render step is one render_mesh_15 call per room and per asset part onto the same framebuffer, with ONE camera and
+ * light list per frame and per-mesh ambient, fog (per room, scene.rs:189-205) and backface culling (per part: double_sided,
+ * scene.rs:133-137).  These three calls take that sequence -- the meshes resident in scene slots -- and produce the framebuffer (and
+ * depth buffer) the sequential calls produce, bit for bit, but draw every run of meshes whose draws commute as ONE merged mesh (one
+ * setup + fill kernel pair instead of one per mesh; a 12-room 320x240 frame is launch-latency bound otherwise):
+ *   z-buffer mode with RGB555 output: runs of meshes, each run ended by the first mesh that has a transparent pass (semi-transparent
+ *   faces blend against what was drawn before them, so that mesh keeps its place); painter's mode, the 8-bit-colour path, x-ray,
+ *   orthographic views and wireframe phases: mesh by mesh, exactly as b32_render_scene_15_async would.
+ * b32_frame_begin copies camera, settings and lights; b32_frame_add_scene appends a slot (which must HOLD its scene: not swapped into
+ * the context) with its per-mesh parameters (NULL: the base settings' ambient and backface flags, no fog); b32_frame_end enqueues the
+ * frame; b32_frame_finish reports errors as for any asynchronous frame.  Difference to the sequential calls in the ERROR case only: a
+ * vertex index out of range or a NaN sort key in one mesh of a merged run (the reference panics there) leaves the whole run undrawn.
+ * At most 32 meshes are merged into one draw; longer runs are split.  Merged meshes are cached per context while the member slots'
+ * contents stay the same (any b32_scene_upload* into a member rebuilds). */
+typedef struct B32MeshParams {
+    float   ambient;
+    uint8_t backface_cull, backface_wireframe, has_fog, _pad;
+    B32Fog  fog;
+} B32MeshParams;
+int b32_frame_begin(b32_ctx* ctx, const B32Camera* camera, const B32Settings* base_settings);
+int b32_frame_add_scene(b32_ctx* ctx, b32_scene* slot, const B32MeshParams* params /* nullable */);
+int b32_frame_end(b32_ctx* ctx);
+/* which: 0 merged draws, 1 mesh-by-mesh draws, 2 merged meshes built, 3 frames ended -- since the context was created (tests). */
+unsigned long long b32_batch_count(const b32_ctx* ctx, int which);
 
 /* ---- the 8-bit-colour path: render_mesh (render.rs:1971-2264) + rasterize_triangle (render.rs:1202-1433) ----
  * What every caller of the reference runs when settings.use_rgb555 is false (scene.rs:163-169).  Same pipeline and settings

@@ -1,5 +1,6 @@
 """Parity tests proper: the HIP path through the C ABI against the CPU oracle, bit-exact (integer/byte outputs and
 exact-order f32).  Every test needs a real MI355X and fails loudly if the HIP library or device is missing."""
+import copy
 import hashlib
 import json
 import os
@@ -409,7 +410,7 @@ def test_two_frames_in_flight(oracle, gate, routes_off):
     """Frames enqueued back to back run their setup kernel on the context's second stream, on the other frame set, beside the previous
     frame's fill (B32_ROUTE_PIPELINE, b32_set_pipeline_gate).  Six frames of a large mesh (direct binning) with a moving camera in
     z-buffer mode without a clear in between -- colour AND depth accumulate, so every frame must have been drawn from its own records,
-    in order -- then painter's frames with a clear each; and the same with small meshes (in-kernel list collection) in safe mode."""
+    in order -- then painter's frames with a clear each; and the same calls with a small mesh (whose frames stay on one stream)."""
     from bonnie32_amd import rasterizer as R
     for n_tris, deep in ((60_000, 1), (1500, 0)):
         sc = scenegen.make_scene("C3", n_tris=n_tris, width=640, height=480, bbox_px=120.0, seed=77 + n_tris, variant="gouraud")
@@ -426,7 +427,7 @@ def test_two_frames_in_flight(oracle, gate, routes_off):
         for cam in cams[1:]:
             rs.render_async(cam, sc.settings)
         tm = rs.finish()
-        assert ctx.route_counts()["pipelined"] == (0 if routes_off else 4)
+        assert ctx.route_counts()["pipelined"] == (0 if (routes_off or n_tris < 8192) else 4)
         assert np.array_equal(fb.pixels, ofb.pixels) and np.array_equal(fb.zbuffer.view(np.uint32), ofb.zbuffer.view(np.uint32))
         # painter's mode, a (folded) clear before every frame: the last camera's frame is what stays
         sc.settings.use_zbuffer = False
@@ -516,6 +517,86 @@ def test_band_ranks_share_one_gpu(world):
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(root, "tests", "band_worker.py")], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0 and "BAND_WORKER_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+def _console_meshes(n_meshes, seed0, blend_every=4):
+    rng = np.random.default_rng(seed0)
+    meshes = []
+    for i in range(n_meshes):
+        variant = "blend" if (blend_every and i % blend_every == blend_every - 1) else "gouraud"
+        meshes.append(scenegen.make_scene("C1", n_tris=int(rng.integers(200, 2500)), seed=seed0 + i, variant=variant,
+                                          bbox_px=float(rng.choice([150.0, 400.0, 900.0]))))
+    return meshes
+
+
+@pytest.mark.parametrize("zbuffer,counting", [(True, 0), (True, 1), (False, 0)])
+def test_batched_frame_equals_sequential_calls(oracle, zbuffer, counting):
+    """b32_frame_begin / _add_scene / _end: a console frame (scene.rs:112-261: clear, then one render_mesh_15 per room / asset part onto
+    the same framebuffer, one camera and light list, per-mesh ambient, fog and backface culling) drawn as merged runs must leave the
+    framebuffer AND the depth buffer of the oracle's sequential calls.  14 meshes, every fourth with a transparent pass (it ends its
+    run), two of them double-sided (backface_cull off), three fog settings, ambients differing per room; z-buffer mode merges, painter's
+    mode (order matters for every pixel) falls back to one draw per mesh through the same entry points; then the same frame again (merged
+    meshes come from the cache), with one mesh re-uploaded (its run is rebuilt), and with batching switched off."""
+    from bonnie32_amd import rasterizer as R
+    meshes = _console_meshes(14, 4200)
+    st = b32.RasterSettings.game()
+    st.use_zbuffer = zbuffer
+    st.lights = [b32.Light.directional((-1.0, -1.0, -1.0), 0.7), b32.Light.point((0.0, -100.0, 1500.0), 3000.0, 1.2)]
+    fogs = [None, (1500.0, 3000.0, 5800.0, b32.Color(40, 50, 70)), (800.0, 2500.0, 5000.0, b32.Color(90, 20, 20))]
+    per = [dict(ambient=0.2 + 0.05 * (i % 5), backface_cull=(i % 5 != 2), fog=fogs[i % 3]) for i in range(len(meshes))]
+    cam = b32.Camera(position=(15.0, -10.0, -40.0))
+    W, H = meshes[0].width, meshes[0].height
+    clear = b32.Color(10, 10, 30)
+
+    def cpu_frame(ms):
+        ofb = oracle.Framebuffer(W, H); ofb.clear(clear)
+        drawn = 0
+        for sc, p in zip(ms, per):
+            s2 = copy.copy(st); s2.ambient = p["ambient"]; s2.backface_cull = p["backface_cull"]
+            rc, tm = oracle.render_mesh_15(ofb, sc.vertices, sc.faces, sc.textures, cam, s2, p["fog"])
+            assert rc == 0
+            drawn += tm.triangles_drawn
+        return ofb, drawn
+    ofb, drawn = cpu_frame(meshes)
+    ctx = R.Context(0)
+    ctx.set_fragment_counting(counting)
+    fb = R.Framebuffer(W, H, ctx)
+    slots = [R.ResidentScene(fb, sc.vertices, sc.faces, sc.textures).detach() for sc in meshes]
+
+    def gpu_frame():
+        fb.clear(clear)
+        ctx.frame_begin(cam, st)
+        for rs, p in zip(slots, per):
+            ctx.frame_add(rs, **p)
+        ctx.frame_end()
+        return ctx.finish()
+    for rep in range(2):
+        gpu_frame()
+        got = fb.pixels
+        assert np.array_equal(got, ofb.pixels), f"{int((got != ofb.pixels).sum())} bytes differ (rep {rep})"
+        if zbuffer:
+            assert np.array_equal(fb.zbuffer.view(np.uint32), ofb.zbuffer.view(np.uint32))
+    bc = ctx.batch_counts()
+    if zbuffer:
+        assert bc["merged_draws"] == 2 * 4 and bc["single_draws"] == 0 and bc["merged_built"] == 4, bc      # runs [0..3] [4..7] [8..11] [12, 13], built once
+    else:
+        assert bc["merged_draws"] == 0 and bc["single_draws"] == 2 * 14, bc
+    # one mesh replaced: its run is rebuilt, the others are reused
+    meshes2 = list(meshes)
+    meshes2[5] = scenegen.make_scene("C1", n_tris=900, seed=777, variant="gouraud", bbox_px=500.0)
+    slots[5].close()
+    slots[5] = R.ResidentScene(fb, meshes2[5].vertices, meshes2[5].faces, meshes2[5].textures).detach()
+    ofb2, _ = cpu_frame(meshes2)
+    gpu_frame()
+    assert np.array_equal(fb.pixels, ofb2.pixels)
+    if zbuffer:
+        assert np.array_equal(fb.zbuffer.view(np.uint32), ofb2.zbuffer.view(np.uint32))
+        assert ctx.batch_counts()["merged_built"] == 5
+    # batching off: the same entry points, one draw per mesh
+    ctx.set_routes(R.Context.ROUTE_BATCH)
+    gpu_frame()
+    assert np.array_equal(fb.pixels, ofb2.pixels)
+    ctx.close()
 
 
 def test_deferred_clear_is_never_observable(fast_ctx, oracle):

@@ -1,7 +1,7 @@
 """A frame the way the console's render step issues it (scene.rs:112-261): Framebuffer::clear, then one render_mesh_15 call per room /
 asset part onto the same 320x240 framebuffer (z-buffer, Gouraud + lights, fog), through the DROP-IN call with host slices -- per-call
 upload, synchronous -- then the download of the 320x240 frame the presenter consumes.  GPU vs the CPU oracle, bit-exact check of the final frame."""
-import sys, time
+import os, sys, time
 sys.path.insert(0, ".")
 import numpy as np
 import bonnie32_amd as b32
@@ -32,6 +32,8 @@ for _ in range(5): cpu_frame()
 t_cpu = (time.perf_counter() - t0) / 5
 
 ctx = R.Context(0)
+if os.environ.get("EXP_ROUTES"):
+    ctx.set_routes(int(os.environ["EXP_ROUTES"]))
 fb = R.Framebuffer(W, H, ctx)
 def gpu_frame():
     fb.clear(clear)
@@ -87,10 +89,37 @@ t0 = time.perf_counter()
 for _ in range(N): gpu_frame_merged()
 t_mrg = (time.perf_counter() - t0) / N
 ok_mrg = np.array_equal(fb.pixels, ofb.pixels) and np.array_equal(fb.zbuffer.view(np.uint32), ofb.zbuffer.view(np.uint32))
+# the library's own batching (b32_frame_begin / _add_scene / _end): the same sequence of meshes, runs that commute drawn as one merged mesh
+def gpu_frame_batched():
+    fb.clear(clear)
+    ctx.frame_begin(meshes[0].camera, st)
+    for rs in slots:
+        ctx.frame_add(rs, fog=fog)
+    ctx.frame_end()
+    ctx.finish()
+    return fb.pixels
+gpu_frame_batched(); gpu_frame_batched()
+t0 = time.perf_counter()
+for _ in range(N): gpu_frame_batched()
+t_bat = (time.perf_counter() - t0) / N
+ok_bat = np.array_equal(fb.pixels, ofb.pixels) and np.array_equal(fb.zbuffer.view(np.uint32), ofb.zbuffer.view(np.uint32))
+bc = ctx.batch_counts()
+# without the download of the frame (a presenter on the device: b32_present_nearest / a bound tensor)
+def gpu_frame_batched_nodl():
+    fb.clear(clear)
+    ctx.frame_begin(meshes[0].camera, st)
+    for rs in slots:
+        ctx.frame_add(rs, fog=fog)
+    ctx.frame_end()
+    ctx.finish()
+t0 = time.perf_counter()
+for _ in range(N): gpu_frame_batched_nodl()
+t_bat2 = (time.perf_counter() - t0) / N
 gpu_frame()
 ok = np.array_equal(fb.pixels, ofb.pixels) and np.array_equal(fb.zbuffer.view(np.uint32), ofb.zbuffer.view(np.uint32))
 tris = sum(sc.n_tris for sc in meshes)
 print(f"console frame: {n_meshes} meshes, {tris} triangles, {W}x{H}, game() + point light + fog: CPU oracle {t_cpu*1e3:.2f} ms, "
       f"GPU drop-in calls + frame download {t_gpu*1e3:.3f} ms ({t_cpu/t_gpu:.1f}x), {t_gpu/n_meshes*1e6:.0f} us per mesh, bit-exact: {ok}; "
       f"rooms resident in scene slots {t_res*1e3:.3f} ms ({t_cpu/t_res:.1f}x), {t_res/n_meshes*1e6:.0f} us per mesh, bit-exact: {ok_res}; "
-      f"opaque runs merged ({len(groups)} draws) {t_mrg*1e3:.3f} ms ({t_cpu/t_mrg:.1f}x), bit-exact: {ok_mrg}")
+      f"opaque runs merged ({len(groups)} draws) {t_mrg*1e3:.3f} ms ({t_cpu/t_mrg:.1f}x), bit-exact: {ok_mrg}; "
+      f"b32_frame_begin/add_scene/end ({bc['merged_draws'] // (N + 2)} merged draws per frame) {t_bat*1e3:.3f} ms with the frame download, {t_bat2*1e3:.3f} ms without ({t_cpu/t_bat2:.1f}x), bit-exact: {ok_bat}")
