@@ -1176,8 +1176,11 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     if ((rc = plan_route(c, fp, sc, wire_front, r))) return rc;
     // (only large meshes: the frames of small ones are launch-latency bound and the cross-stream events cost them more than the overlap
     // returns -- a 12-room console frame 0.72 ms against 0.65; keyed routes have binning launches behind k_setup: one stream)
-    if (c->pipelined && !r.direct_bin) c->pipelined = false;
     const uint32_t ntiles = fp.tiles_x * fp.tiles_y;
+    // ... and a frame whose fused kernel has no more tiles than workgroup slots has no tail to fill: the cross-stream waits (~10 us
+    // between two kernels) then cost more than the overlap returns (C2, 100 k triangles at 320x240: 0.052 against 0.048 ms).  The merged
+    // runs of a batched frame are the exception: their kernels leave most of the GPU idle anyway (75 tiles for 256 CUs).
+    if (c->pipelined && !(r.direct_bin && (ntiles > 2u * (uint32_t)c->n_cu || c->frame_batched))) c->pipelined = false;
     c->last_local_sort = r.local_sort || r.want_prio64;                         // the global draw order is not materialised
     c->last_exact = r.ordered_all ? true : (r.exact_cov && !fp.zmode);          // the ordered walk counts every store it performs
     c->last_direct = r.direct_bin;

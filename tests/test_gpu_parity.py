@@ -413,7 +413,8 @@ def test_two_frames_in_flight(oracle, gate, routes_off):
     in order -- then painter's frames with a clear each; and the same calls with a small mesh (whose frames stay on one stream)."""
     from bonnie32_amd import rasterizer as R
     for n_tris, deep in ((60_000, 1), (1500, 0)):
-        sc = scenegen.make_scene("C3", n_tris=n_tris, width=640, height=480, bbox_px=120.0, seed=77 + n_tris, variant="gouraud")
+        big = n_tris > 8192          # (two frames in flight need a frame with more tiles than workgroup slots: 690 tiles of 64x64)
+        sc = scenegen.make_scene("C3", n_tris=n_tris, width=1920 if big else 640, height=1440 if big else 480, bbox_px=120.0, seed=77 + n_tris, variant="gouraud")
         sc.settings.use_zbuffer = True
         cams = [b32.Camera(position=(40.0 * i, -25.0 * i, -300.0 * i)) for i in range(6)]
         ofb = oracle.Framebuffer(sc.width, sc.height); ofb.clear(sc.clear_color)
