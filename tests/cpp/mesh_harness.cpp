@@ -1,67 +1,35 @@
-// Drives the C++ host mirror of the reference interface (bonnie-32_amd/host/rasterizer.hpp) end to end:
-//   mesh_harness <scene.bin> <out.rgba>
-// scene.bin (written by tests/test_gpu_parity.py): u32 w, h, nv, nf, tw, th, shading, n_lights; f32 cam position[3];
-// f32 light dir[3], intensity, ambient; clear rgb u8[4]; nv x {pos[3] uv[2] normal[3] rgba[4]} ; nf x {v0 v1 v2 tex u32, bt blend alpha pad u8};
-// tw*th u16 texels.  The harness builds reference-shaped objects (b32::Vertex, b32::Face, b32::Texture15, ...), calls
-// Framebuffer::clear + render_mesh_15 and dumps fb.pixels().
+// Drives the C++ host mirror of the reference interface (bonnie-32_amd/host/rasterizer.hpp) end to end FROM A FILE:
+//   mesh_harness <scene.b32scene> <out.rgba> [out.zbuffer]
+// The .b32scene file (bonnie-32_amd/scenefile.py; host/scenefile.hpp) holds everything one render_mesh_15 / render_mesh call takes --
+// vertices, faces, textures, camera, every RasterSettings field, lights, fog -- and the framebuffer it draws into.  The harness builds
+// the reference-shaped objects (b32::Vertex, b32::Face, b32::Texture15 / b32::Texture, b32::RasterSettings, ...), calls
+// Framebuffer::new + Framebuffer::clear + render_mesh_15 (or render_mesh for an 8-bit-colour file) through the C ABI on the GPU and
+// dumps fb.pixels (and the depth buffer).  The same file is what tests/rust/pin_oracle feeds to the reference itself.
 #include <cstdio>
-#include <cstring>
 #include <fstream>
-#include <iostream>
 #include <vector>
 
-#include "rasterizer.hpp"
-
-template <typename T> static T rd(std::ifstream& f) { T v; f.read(reinterpret_cast<char*>(&v), sizeof(T)); return v; }
+#include "scenefile.hpp"
 
 int main(int argc, char** argv) {
     if (argc < 3) return 2;
-    std::ifstream f(argv[1], std::ios::binary);
-    if (!f) return 3;
-    const uint32_t w = rd<uint32_t>(f), h = rd<uint32_t>(f), nv = rd<uint32_t>(f), nf = rd<uint32_t>(f), tw = rd<uint32_t>(f), th = rd<uint32_t>(f);
-    const uint32_t shading = rd<uint32_t>(f), n_lights = rd<uint32_t>(f);
-    b32::Camera cam;
-    cam.position = { rd<float>(f), rd<float>(f), rd<float>(f) };
-    b32::Light light;
-    light.type = B32_LIGHT_DIRECTIONAL;
-    light.direction = { rd<float>(f), rd<float>(f), rd<float>(f) };
-    light.intensity = rd<float>(f);
-    const float ambient = rd<float>(f);
-    uint8_t clear[4]; f.read(reinterpret_cast<char*>(clear), 4);
-    std::vector<b32::Vertex> verts(nv);
-    for (auto& v : verts) {
-        v.pos = { rd<float>(f), rd<float>(f), rd<float>(f) };
-        v.uv = { rd<float>(f), rd<float>(f) };
-        v.normal = { rd<float>(f), rd<float>(f), rd<float>(f) };
-        uint8_t c[4]; f.read(reinterpret_cast<char*>(c), 4);
-        v.color = { c[0], c[1], c[2], (b32::BlendMode)c[3] };
-    }
-    std::vector<b32::Face> faces(nf);
-    for (auto& fc : faces) {
-        const uint32_t v0 = rd<uint32_t>(f), v1 = rd<uint32_t>(f), v2 = rd<uint32_t>(f), tex = rd<uint32_t>(f);
-        uint8_t c[4]; f.read(reinterpret_cast<char*>(c), 4);
-        fc.v0 = v0; fc.v1 = v1; fc.v2 = v2;
-        if (tex != B32_NO_TEXTURE) fc.texture_id = tex;
-        fc.black_transparent = c[0] != 0; fc.blend_mode = (b32::BlendMode)c[1]; fc.editor_alpha = c[2];
-    }
-    b32::Texture15 tex;
-    tex.width = tw; tex.height = th; tex.pixels.resize((size_t)tw * th);
-    f.read(reinterpret_cast<char*>(tex.pixels.data()), (std::streamsize)tex.pixels.size() * 2);
-    if (!f) return 4;
-
-    b32::RasterSettings st = b32::RasterSettings::game();
-    st.use_zbuffer = false;                                      // the fixture is the painter's-mode cube
-    st.shading = (b32::ShadingMode)shading;
-    st.ambient = ambient;
-    if (n_lights) st.lights.push_back(light);
     try {
-        b32::Framebuffer fb(w, h);
-        fb.clear({ clear[0], clear[1], clear[2], b32::BlendMode::Opaque });
-        const b32::RasterTimings tm = b32::render_mesh_15(fb, verts, faces, { tex }, cam, st);
+        const b32::SceneFile sc = b32::read_scene(argv[1]);
+        b32::Framebuffer fb(sc.width, sc.height);
+        fb.clear(sc.clear);
+        const b32::RasterTimings tm = sc.fmt8 ? b32::render_mesh(fb, sc.vertices, sc.faces, sc.textures8, sc.camera, sc.settings)
+                                              : b32::render_mesh_15(fb, sc.vertices, sc.faces, sc.textures, sc.camera, sc.settings, sc.fog);
         const std::vector<uint8_t> px = fb.pixels();
         std::ofstream o(argv[2], std::ios::binary);
         o.write(reinterpret_cast<const char*>(px.data()), (std::streamsize)px.size());
+        if (argc > 3) {
+            std::vector<float> z((size_t)sc.width * sc.height);
+            b32::check(b32_zbuffer_download(fb.ctx(), z.data()), "zbuffer");
+            std::ofstream oz(argv[3], std::ios::binary);
+            oz.write(reinterpret_cast<const char*>(z.data()), (std::streamsize)(z.size() * 4));
+        }
         std::printf("triangles_drawn %u\n", tm.triangles_drawn);
+        if (sc.has_expect) std::printf("expect_triangles_drawn %u\n", sc.expect_triangles);
     } catch (const b32::Error& e) {
         std::fprintf(stderr, "b32::Error %d: %s\n", e.code, e.what());
         return 10;

@@ -1194,32 +1194,36 @@ def test_more_tiles_than_the_span_histogram_holds(gpu_ctx, oracle, counting):
             gpu_ctx.set_fragment_counting(1)
 
 
-def test_cpp_host_mirror_end_to_end(tmp_path):
-    """The C++ mirror of the reference interface (host/rasterizer.hpp: b32::Framebuffer, b32::render_mesh_15 with
-    reference-shaped Vertex / Face / Texture15 / RasterSettings) compiled with g++, linked against the C ABI, run on the GPU:
-    the reference-authored cube fixture must come out byte-identical to the committed golden frame."""
-    import struct, subprocess
+def test_cpp_host_mirror_renders_scene_files(tmp_path):
+    """The C++ mirror of the reference interface (host/rasterizer.hpp: b32::Framebuffer, b32::render_mesh_15 / render_mesh with
+    reference-shaped Vertex / Face / Texture15 / RasterSettings / Light / fog) compiled with g++, linked against the C ABI and run on the
+    GPU FROM `.b32scene` FILES (host/scenefile.hpp): every golden scene but the 1 M-triangle ones -- all the settings, light kinds, fog,
+    orthographic views, both pixel formats -- must come out with the frame and depth-buffer hashes of tests/golden/hashes.json.  This is
+    the proof that the file format is complete: the same files are what tests/rust/pin_oracle hands to the reference."""
+    import subprocess
+    from bonnie32_amd import scenefile
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    from tests.golden.ref_fixtures import cube_scene
-    sc = cube_scene()
     exe = tmp_path / "mesh_harness"
     lib_dir = os.path.join(root, "bonnie-32_amd", "csrc")
     subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(root, "bonnie-32_amd", "host"), "-I", os.path.join(root, "include"),
                     os.path.join(root, "tests", "cpp", "mesh_harness.cpp"), "-o", str(exe), "-L", lib_dir, "-lb32raster",
                     f"-Wl,-rpath,{lib_dir}"], check=True)
-    L = sc.settings.lights[0]
-    blob = struct.pack("<8I", sc.width, sc.height, len(sc.vertices), len(sc.faces), sc.textures[0].width, sc.textures[0].height,
-                       sc.settings.shading, 1)
-    blob += struct.pack("<3f", *sc.camera.position) + struct.pack("<3f", *L.direction) + struct.pack("<2f", L.intensity, sc.settings.ambient)
-    blob += bytes([sc.clear_color.r, sc.clear_color.g, sc.clear_color.b, 0])
-    blob += sc.vertices.tobytes() + sc.faces.tobytes() + sc.textures[0].pixels.tobytes()
-    (tmp_path / "scene.bin").write_bytes(blob)
-    r = subprocess.run([str(exe), str(tmp_path / "scene.bin"), str(tmp_path / "out.rgba")], capture_output=True, text=True)
+    H = json.load(open(os.path.join(GOLD, "hashes.json")))
+    names = [n for n in list(SCENES) + list(SCENES8) if n not in ("C3", "C5")]
+    for name in names:
+        sc = (SCENES.get(name) or SCENES8[name])()
+        path = str(tmp_path / "s.b32scene")
+        scenefile.write_scene(path, sc, expect=H[name])
+        r = subprocess.run([str(exe), path, str(tmp_path / "out.rgba"), str(tmp_path / "out.z")], capture_output=True, text=True)
+        assert r.returncode == 0, (name, r.stderr)
+        assert hashlib.sha256((tmp_path / "out.rgba").read_bytes()).hexdigest() == H[name]["sha256"], name
+        assert hashlib.sha256((tmp_path / "out.z").read_bytes()).hexdigest() == H[name]["zbuffer_sha256"], name
+        assert f"triangles_drawn {H[name]['triangles_drawn']}" in r.stdout, name
+    # the committed sample file (reference-authored cube: draw.rs:138-214, types.rs:702-711)
+    r = subprocess.run([str(exe), os.path.join(GOLD, "scenes", "cube.b32scene"), str(tmp_path / "out.rgba")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     got = np.frombuffer((tmp_path / "out.rgba").read_bytes(), np.uint8)
-    gold = np.load(os.path.join(GOLD, "cube_frame.npz"))["rgba"]
-    assert np.array_equal(got, gold)
-    assert "triangles_drawn 10" in r.stdout
+    assert np.array_equal(got, np.load(os.path.join(GOLD, "cube_frame.npz"))["rgba"]) and "triangles_drawn 10" in r.stdout
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3])
