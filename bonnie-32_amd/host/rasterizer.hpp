@@ -128,6 +128,42 @@ inline B32Face pack(const Face& f) {
     const uint32_t tex = f.texture_id ? (*f.texture_id >= 0xFFFFFFFFull ? 0xFFFFFFFEu : (uint32_t)*f.texture_id) : B32_NO_TEXTURE;
     return { { ix(f.v0), ix(f.v1), ix(f.v2) }, tex, (uint8_t)f.black_transparent, (uint8_t)f.blend_mode, f.editor_alpha, 0 };
 }
+// Camera (camera.rs:9-18) -> B32Camera: position and the three basis vectors (rotation_x / rotation_y only feed Camera::update_basis)
+inline B32Camera pack(const Camera& c) {
+    return { { c.position.x, c.position.y, c.position.z }, { c.basis_x.x, c.basis_x.y, c.basis_x.z },
+             { c.basis_y.x, c.basis_y.y, c.basis_y.z }, { c.basis_z.x, c.basis_z.y, c.basis_z.z } };
+}
+// Light (types.rs:1297-1314): LightType::Directional{direction} / Point{position, radius} / Spot{position, direction, angle, radius}
+// flattened; the fields a kind does not have stay zero
+inline B32Light pack(const Light& x) {
+    return { x.type, { x.position.x, x.position.y, x.position.z }, { x.direction.x, x.direction.y, x.direction.z }, x.radius, x.angle,
+             x.intensity, x.color.r, x.color.g, x.color.b, (uint8_t)x.enabled };
+}
+// RasterSettings (types.rs:1392-1428) -> B32Settings; `lights` must outlive the call (the struct points into it).
+// ShadingMode None / Flat / Gouraud = 0 / 1 / 2 (types.rs:1289-1293); Option<OrthoProjection> -> has_ortho + three floats (types.rs:1432-1438);
+// low_resolution and stretch_to_fill are presentation-only and not part of the C struct.
+inline B32Settings pack(const RasterSettings& settings, const std::vector<B32Light>& lights) {
+    B32Settings s{};
+    s.affine_textures = settings.affine_textures; s.use_zbuffer = settings.use_zbuffer; s.shading = (uint8_t)settings.shading;
+    s.backface_cull = settings.backface_cull; s.backface_wireframe = settings.backface_wireframe; s.dithering = settings.dithering;
+    s.wireframe_overlay = settings.wireframe_overlay; s.use_rgb555 = settings.use_rgb555; s.use_fixed_point = settings.use_fixed_point;
+    s.xray_mode = settings.xray_mode; s.has_ortho = settings.ortho_projection.has_value(); s.ambient = settings.ambient;
+    if (settings.ortho_projection) { s.ortho_zoom = settings.ortho_projection->x; s.ortho_center_x = settings.ortho_projection->y; s.ortho_center_y = settings.ortho_projection->z; }
+    s.n_lights = (uint32_t)lights.size(); s.lights = lights.empty() ? nullptr : lights.data();
+    return s;
+}
+inline std::vector<B32Light> pack(const std::vector<Light>& lights) {
+    std::vector<B32Light> l; l.reserve(lights.size());
+    for (const auto& x : lights) l.push_back(pack(x));
+    return l;
+}
+// fog: Option<(f32, f32, f32, Color)> (render.rs:2309) -> nullable B32Fog*
+inline bool pack(const Fog& fog, B32Fog& out) {
+    if (!fog) return false;
+    const auto& [st, fo, cu, col] = *fog;
+    out = { st, fo, cu, col.r, col.g, col.b, (uint8_t)col.blend };
+    return true;
+}
 }  // namespace detail
 
 // render.rs:2302-2310
@@ -141,21 +177,11 @@ inline RasterTimings render_mesh_15(Framebuffer& fb, const std::vector<Vertex>& 
     std::vector<B32Texture15> t; t.reserve(textures.size());
     for (const auto& x : textures)
         t.push_back({ (uint32_t)x.width, (uint32_t)x.height, (uint32_t)x.blend_mode, 0, x.pixels.size() >= x.width * x.height ? x.pixels.data() : nullptr });
-    std::vector<B32Light> l;
-    for (const auto& x : settings.lights)
-        l.push_back({ x.type, { x.position.x, x.position.y, x.position.z }, { x.direction.x, x.direction.y, x.direction.z }, x.radius, x.angle,
-                      x.intensity, x.color.r, x.color.g, x.color.b, (uint8_t)x.enabled });
-    B32Camera c{ { camera.position.x, camera.position.y, camera.position.z }, { camera.basis_x.x, camera.basis_x.y, camera.basis_x.z },
-                 { camera.basis_y.x, camera.basis_y.y, camera.basis_y.z }, { camera.basis_z.x, camera.basis_z.y, camera.basis_z.z } };
-    B32Settings s{};
-    s.affine_textures = settings.affine_textures; s.use_zbuffer = settings.use_zbuffer; s.shading = (uint8_t)settings.shading;
-    s.backface_cull = settings.backface_cull; s.backface_wireframe = settings.backface_wireframe; s.dithering = settings.dithering;
-    s.wireframe_overlay = settings.wireframe_overlay; s.use_rgb555 = settings.use_rgb555; s.use_fixed_point = settings.use_fixed_point;
-    s.xray_mode = settings.xray_mode; s.has_ortho = settings.ortho_projection.has_value(); s.ambient = settings.ambient;
-    if (settings.ortho_projection) { s.ortho_zoom = settings.ortho_projection->x; s.ortho_center_x = settings.ortho_projection->y; s.ortho_center_y = settings.ortho_projection->z; }
-    s.n_lights = (uint32_t)l.size(); s.lights = l.empty() ? nullptr : l.data();
-    B32Fog fg{}; const B32Fog* fgp = nullptr;
-    if (fog) { const auto& [st, fo, cu, col] = *fog; fg = { st, fo, cu, col.r, col.g, col.b, (uint8_t)col.blend }; fgp = &fg; }
+    const std::vector<B32Light> l = detail::pack(settings.lights);
+    const B32Camera c = detail::pack(camera);
+    const B32Settings s = detail::pack(settings, l);
+    B32Fog fg{};
+    const B32Fog* fgp = detail::pack(fog, fg) ? &fg : nullptr;
     B32Timings tm{};
     check(b32_render_mesh_15(fb.ctx(), v.data(), (uint32_t)v.size(), f.data(), (uint32_t)f.size(), t.data(), (uint32_t)t.size(), &c, &s, fgp, &tm),
           "render_mesh_15");
@@ -174,19 +200,9 @@ inline RasterTimings render_mesh(Framebuffer& fb, const std::vector<Vertex>& ver
     for (const auto& x : textures)
         t.push_back({ (uint32_t)x.width, (uint32_t)x.height, (uint32_t)x.blend_mode, 0,
                       x.pixels.size() >= x.width * x.height && !x.pixels.empty() ? reinterpret_cast<const uint8_t*>(x.pixels.data()) : nullptr });
-    std::vector<B32Light> l;
-    for (const auto& x : settings.lights)
-        l.push_back({ x.type, { x.position.x, x.position.y, x.position.z }, { x.direction.x, x.direction.y, x.direction.z }, x.radius, x.angle,
-                      x.intensity, x.color.r, x.color.g, x.color.b, (uint8_t)x.enabled });
-    B32Camera c{ { camera.position.x, camera.position.y, camera.position.z }, { camera.basis_x.x, camera.basis_x.y, camera.basis_x.z },
-                 { camera.basis_y.x, camera.basis_y.y, camera.basis_y.z }, { camera.basis_z.x, camera.basis_z.y, camera.basis_z.z } };
-    B32Settings s{};
-    s.affine_textures = settings.affine_textures; s.use_zbuffer = settings.use_zbuffer; s.shading = (uint8_t)settings.shading;
-    s.backface_cull = settings.backface_cull; s.backface_wireframe = settings.backface_wireframe; s.dithering = settings.dithering;
-    s.wireframe_overlay = settings.wireframe_overlay; s.use_rgb555 = settings.use_rgb555; s.use_fixed_point = settings.use_fixed_point;
-    s.xray_mode = settings.xray_mode; s.has_ortho = settings.ortho_projection.has_value(); s.ambient = settings.ambient;
-    if (settings.ortho_projection) { s.ortho_zoom = settings.ortho_projection->x; s.ortho_center_x = settings.ortho_projection->y; s.ortho_center_y = settings.ortho_projection->z; }
-    s.n_lights = (uint32_t)l.size(); s.lights = l.empty() ? nullptr : l.data();
+    const std::vector<B32Light> l = detail::pack(settings.lights);
+    const B32Camera c = detail::pack(camera);
+    const B32Settings s = detail::pack(settings, l);
     B32Timings tm{};
     check(b32_render_mesh(fb.ctx(), v.data(), (uint32_t)v.size(), f.data(), (uint32_t)f.size(), t.data(), (uint32_t)t.size(), &c, &s, &tm), "render_mesh");
     return { tm.transform_ms, tm.fog_ms, tm.cull_ms, tm.sort_ms, tm.draw_ms, tm.wireframe_ms, tm.triangles_drawn, tm.fragments };
