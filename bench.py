@@ -548,7 +548,8 @@ def main():
                    "frame_identical_to_checker_hash": (hashlib.sha256(ofb.pixels).hexdigest() == want) if want else None,
                    "sample": f"{reps} full frames of the same {args.config} scene ({NF} tris @ {W}x{H}), oracle/b32_oracle.c, 1 thread"}
             # the "fair CPU" variant of SURVEY 8d beside it: the same port threaded inside one process -- the per-vertex transform split
-            # by vertex range, cull / setup / sort once, the draw split by row band (the reference itself is single-threaded)
+            # by vertex range, cull / setup split by face range with ordered concatenation, a parallel stable merge sort, the draw split
+            # by row band (the reference itself is single-threaded); frame asserted identical to the single-core one
             try:
                 ncpu = os.cpu_count() or 1
                 best = None
@@ -566,8 +567,10 @@ def main():
                 cpu_all = {"value": round(NF / t_all / 1e6, 4), "unit": "Mtriangles/s", "cores": cores, "kind": "port",
                            "mpixels_per_s": round(otm.fragments / t_all / 1e6, 3), "ms_per_frame": round(t_all * 1e3, 2),
                            "identical_to_single_core_frame": bool(np.array_equal(frame_all, ofb.pixels)),
-                           "sample": f"best of 2 frames of the same scene, {cores} threads in one process (transform split by vertex range, cull/setup/sort once, "
-                                     f"draw split by row band; fastest of 8..128 threads on {ncpu} host CPUs), oracle/b32_oracle.c release-profile build"}
+                           "speedup_vs_one_core": round(per / t_all, 2),
+                           "sample": f"best of 2 frames of the same scene, {cores} threads in one process (transform by vertex range, cull/setup by face range with "
+                                     f"ordered concatenation, parallel stable merge sort, draw by row band; fastest of 8..128 threads on {ncpu} host CPUs), "
+                                     f"oracle/b32_oracle.c release-profile build"}
             except Exception as e:                                  # noqa: BLE001 -- an extra, never a reason to lose the bench line
                 cpu_all = {"error": repr(e)}
         if args.check:

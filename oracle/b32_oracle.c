@@ -967,6 +967,41 @@ static void merge_sort_desc(uint32_t* idx, uint32_t* tmp, const float* key, uint
     }
 }
 
+/* The same stable sort for the all-cores baseline: T contiguous chunks sorted by T threads, then adjacent chunks merged pairwise, level by
+ * level (a tie takes the LEFT element, like the merge above: chunks are adjacent ranges of the original order, so stability -- ties keep
+ * face order -- is preserved).  The result is identical to merge_sort_desc's: a stable sort has exactly one output. */
+typedef struct { uint32_t* idx; uint32_t* tmp; const float* key; uint32_t lo, mid, hi; int sort_only; } SortJob;
+static void* sort_job(void* arg) {
+    SortJob* j = (SortJob*)arg;
+    if (j->sort_only) { merge_sort_desc(j->idx + j->lo, j->tmp + j->lo, j->key, j->hi - j->lo); return NULL; }
+    uint32_t i = j->lo, r = j->mid, k = j->lo;
+    const uint32_t* idx = j->idx; uint32_t* tmp = j->tmp; const float* key = j->key;
+    while (i < j->mid && r < j->hi) { if (key[idx[r]] > key[idx[i]]) tmp[k++] = idx[r++]; else tmp[k++] = idx[i++]; }
+    while (i < j->mid) tmp[k++] = idx[i++];
+    while (r < j->hi) tmp[k++] = idx[r++];
+    memcpy(j->idx + j->lo, tmp + j->lo, (size_t)(j->hi - j->lo) * sizeof(uint32_t));
+    return NULL;
+}
+static void merge_sort_desc_mt(uint32_t* idx, uint32_t* tmp, const float* key, uint32_t n, uint32_t threads) {
+    uint32_t T = 1;
+    while (T * 2 <= threads && T * 2 <= 64 && n / (T * 2) >= 4096) T *= 2;
+    if (T == 1) { merge_sort_desc(idx, tmp, key, n); return; }
+    SortJob jobs[64]; pthread_t th[64];
+    uint32_t bound[65];
+    for (uint32_t t = 0; t <= T; ++t) bound[t] = (uint32_t)((uint64_t)n * t / T);
+    for (uint32_t t = 0; t < T; ++t) { SortJob j = { idx, tmp, key, bound[t], 0, bound[t + 1], 1 }; jobs[t] = j; pthread_create(&th[t], NULL, sort_job, &jobs[t]); }
+    for (uint32_t t = 0; t < T; ++t) pthread_join(th[t], NULL);
+    for (uint32_t span = 1; span < T; span *= 2) {
+        uint32_t m = 0;
+        for (uint32_t t = 0; t + span < T; t += 2 * span) {
+            const uint32_t hi_t = t + 2 * span < T ? t + 2 * span : T;
+            SortJob j = { idx, tmp, key, bound[t], bound[t + span], bound[hi_t], 0 }; jobs[m] = j;
+            pthread_create(&th[m], NULL, sort_job, &jobs[m]); ++m;
+        }
+        for (uint32_t t = 0; t < m; ++t) pthread_join(th[t], NULL);
+    }
+}
+
 /* Optional stage dump for parity tests (all arrays caller-allocated or NULL). */
 typedef struct B32OracleDump {
     int32_t*  sx;          /* nv: screen x as i32 (fixed-point path) / truncated float otherwise */
@@ -1031,48 +1066,23 @@ typedef struct {
 } DrawJob;
 static void* draw_range(void* arg);
 
-static int render_mesh_impl(uint8_t* fb_pixels, float* fb_zbuffer, uint32_t width, uint32_t height,
-                            const B32Vertex* vertices, uint32_t nv,
-                            const B32Face* faces, uint32_t nf,
-                            const B32Texture15* textures, const B32Texture* textures8, uint32_t nt,
-                            const B32Camera* camera, const B32Settings* st, const B32Fog* fog,
-                            B32Timings* timings, B32OracleDump* dump) {
+/* CULL / SETUP of a face range, render.rs:2364-2516 (one job per thread of the all-cores baseline, each into buffers of its own that are
+ * concatenated in range order afterwards -- the reference's single loop produces the surfaces in face order; the whole range otherwise) */
+typedef struct {
+    const B32Vertex* vertices; uint32_t nv; const B32Face* faces; uint32_t f0, f1;
+    const B32Texture15* textures; const B32Texture* textures8; uint32_t nt; const B32Settings* st; const B32Fog* fog;
+    const V3* cam_space; const V3* projected;
+    Surface* out; WireTri* bw; WireTri* fw; uint32_t ns, n_bw, n_fw; int rc;
+} CullJob;
+static void* cull_range(void* arg) {
+    CullJob* j = (CullJob*)arg;
+    const B32Vertex* vertices = j->vertices; const uint32_t nv = j->nv; const B32Face* faces = j->faces;
+    const B32Texture15* textures = j->textures; const B32Texture* textures8 = j->textures8; const uint32_t nt = j->nt;
+    const B32Settings* st = j->st; const B32Fog* fog = j->fog; const V3* cam_space = j->cam_space; const V3* projected = j->projected;
     const int fmt8 = textures8 != NULL;
-    if (!fb_pixels || !camera || !st || (nv && !vertices) || (nf && !faces) || (nt && !textures && !textures8)) return B32_E_ARG;
-    if (st->use_zbuffer && !fb_zbuffer) return B32_E_ARG;
-    if (st->shading != B32_SHADE_NONE)
-        for (uint32_t i = 0; i < st->n_lights; ++i)
-            if (st->lights[i].enabled && st->lights[i].type > B32_LIGHT_SPOT) return B32_E_ARG;
-    FB fb = { fb_pixels, fb_zbuffer, width, height, 0, g_band_y0, g_band_y1 };
-
-    /* TRANSFORM, :2313-2362 */
-    V3* cam_space = (V3*)malloc(sizeof(V3) * (nv ? nv : 1));
-    V3* projected = (V3*)malloc(sizeof(V3) * (nv ? nv : 1));
-    {
-        unr_init();                                           /* (before any thread touches the table) */
-        const uint32_t T = (g_threads > 1 && nv >= 4096) ? (uint32_t)g_threads : 1u;
-        TransformJob jobs[256]; pthread_t th[256];
-        for (uint32_t t = 0; t < T; ++t) {
-            TransformJob j = { vertices, (uint32_t)((uint64_t)nv * t / T), (uint32_t)((uint64_t)nv * (t + 1) / T), camera, st, width, height,
-                               cam_space, projected, dump };
-            jobs[t] = j;
-        }
-        if (T == 1) transform_range(&jobs[0]);
-        else {
-            for (uint32_t t = 0; t < T; ++t) pthread_create(&th[t], NULL, transform_range, &jobs[t]);
-            for (uint32_t t = 0; t < T; ++t) pthread_join(th[t], NULL);
-        }
-    }
-
-    /* CULL / SETUP, :2364-2516 */
-    Surface* surfaces = (Surface*)malloc(sizeof(Surface) * (nf ? nf : 1));
-    WireTri* backface_wireframes = (WireTri*)malloc(sizeof(WireTri) * (nf ? nf : 1));
-    WireTri* frontface_wireframes = (WireTri*)malloc(sizeof(WireTri) * (nf ? nf : 1));
-    uint32_t ns = 0, n_bw = 0, n_fw = 0;
-    int rc = B32_OK;
-    for (uint32_t fi = 0; fi < nf; ++fi) {
+    for (uint32_t fi = j->f0; fi < j->f1; ++fi) {
         const B32Face* f = &faces[fi];
-        if (f->v[0] >= nv || f->v[1] >= nv || f->v[2] >= nv) { rc = B32_E_INDEX; goto done; }    /* index panic :2375-2377 */
+        if (f->v[0] >= nv || f->v[1] >= nv || f->v[2] >= nv) { j->rc = B32_E_INDEX; break; }    /* index panic :2375-2377 */
         V3 cv1 = cam_space[f->v[0]], cv2 = cam_space[f->v[1]], cv3 = cam_space[f->v[2]];
         if (!st->has_ortho) {                                                                     /* :2381-2385 NEAR_PLANE math.rs:155 */
             if (cv1.z <= K_NEAR_PLANE || cv2.z <= K_NEAR_PLANE || cv3.z <= K_NEAR_PLANE) continue;
@@ -1106,7 +1116,7 @@ static int render_mesh_impl(uint8_t* fb_pixels, float* fb_zbuffer, uint32_t widt
         s.blend_mode = f->blend_mode; s.editor_alpha = f->editor_alpha;
         const B32Vertex *A = &vertices[f->v[0]], *B = &vertices[f->v[1]], *C = &vertices[f->v[2]];
         if (is_backface) {                                                                        /* :2445-2479 */
-            if (!st->xray_mode) { WireTri w = { v1, v2, v3_ }; backface_wireframes[n_bw++] = w; }
+            if (!st->xray_mode) { WireTri w = { v1, v2, v3_ }; j->bw[j->n_bw++] = w; }
             if (!(!st->backface_cull || st->xray_mode)) continue;
             s.v1 = v1; s.v2 = v3_; s.v3 = v2;
             s.w1 = v3p(A->pos); s.w2 = v3p(C->pos); s.w3 = v3p(B->pos);
@@ -1119,9 +1129,88 @@ static int render_mesh_impl(uint8_t* fb_pixels, float* fb_zbuffer, uint32_t widt
             s.wn1 = v3p(A->normal); s.wn2 = v3p(B->normal); s.wn3 = v3p(C->normal);
             memcpy(s.uv1, A->uv, 8); memcpy(s.uv2, B->uv, 8); memcpy(s.uv3, C->uv, 8);
             s.vc1 = c1; s.vc2 = c2; s.vc3 = c3;
-            if (st->wireframe_overlay) { WireTri w = { v1, v2, v3_ }; frontface_wireframes[n_fw++] = w; }   /* :2509-2511 */
+            if (st->wireframe_overlay) { WireTri w = { v1, v2, v3_ }; j->fw[j->n_fw++] = w; }   /* :2509-2511 */
         }
-        surfaces[ns++] = s;
+        j->out[j->ns++] = s;
+    }
+
+    return NULL;
+}
+typedef struct { void* dst; const void* src; size_t n; } CopyJob;
+static void* copy_job(void* arg) { const CopyJob* c = (const CopyJob*)arg; if (c->n) memcpy(c->dst, c->src, c->n); return NULL; }
+
+static int render_mesh_impl(uint8_t* fb_pixels, float* fb_zbuffer, uint32_t width, uint32_t height,
+                            const B32Vertex* vertices, uint32_t nv,
+                            const B32Face* faces, uint32_t nf,
+                            const B32Texture15* textures, const B32Texture* textures8, uint32_t nt,
+                            const B32Camera* camera, const B32Settings* st, const B32Fog* fog,
+                            B32Timings* timings, B32OracleDump* dump) {
+    if (!fb_pixels || !camera || !st || (nv && !vertices) || (nf && !faces) || (nt && !textures && !textures8)) return B32_E_ARG;
+    if (st->use_zbuffer && !fb_zbuffer) return B32_E_ARG;
+    if (st->shading != B32_SHADE_NONE)
+        for (uint32_t i = 0; i < st->n_lights; ++i)
+            if (st->lights[i].enabled && st->lights[i].type > B32_LIGHT_SPOT) return B32_E_ARG;
+    FB fb = { fb_pixels, fb_zbuffer, width, height, 0, g_band_y0, g_band_y1 };
+
+    /* TRANSFORM, :2313-2362 */
+    V3* cam_space = (V3*)malloc(sizeof(V3) * (nv ? nv : 1));
+    V3* projected = (V3*)malloc(sizeof(V3) * (nv ? nv : 1));
+    {
+        unr_init();                                           /* (before any thread touches the table) */
+        const uint32_t T = (g_threads > 1 && nv >= 4096) ? (uint32_t)g_threads : 1u;
+        TransformJob jobs[256]; pthread_t th[256];
+        for (uint32_t t = 0; t < T; ++t) {
+            TransformJob j = { vertices, (uint32_t)((uint64_t)nv * t / T), (uint32_t)((uint64_t)nv * (t + 1) / T), camera, st, width, height,
+                               cam_space, projected, dump };
+            jobs[t] = j;
+        }
+        if (T == 1) transform_range(&jobs[0]);
+        else {
+            for (uint32_t t = 0; t < T; ++t) pthread_create(&th[t], NULL, transform_range, &jobs[t]);
+            for (uint32_t t = 0; t < T; ++t) pthread_join(th[t], NULL);
+        }
+    }
+
+    /* CULL / SETUP, :2364-2516 */
+    Surface* surfaces = (Surface*)malloc(sizeof(Surface) * (nf ? nf : 1));
+    WireTri* backface_wireframes = (WireTri*)malloc(sizeof(WireTri) * (nf ? nf : 1));
+    WireTri* frontface_wireframes = (WireTri*)malloc(sizeof(WireTri) * (nf ? nf : 1));
+    uint32_t ns = 0, n_bw = 0, n_fw = 0;
+    int rc = B32_OK;
+    {
+        const uint32_t T = (g_threads > 1 && nf >= 8192) ? (uint32_t)(g_threads > 64 ? 64 : g_threads) : 1u;
+        CullJob jobs[64]; pthread_t th[64];
+        for (uint32_t t = 0; t < T; ++t) {
+            CullJob j = { vertices, nv, faces, (uint32_t)((uint64_t)nf * t / T), (uint32_t)((uint64_t)nf * (t + 1) / T), textures, textures8, nt, st, fog,
+                          cam_space, projected, surfaces, backface_wireframes, frontface_wireframes, 0, 0, 0, B32_OK };
+            if (T > 1) {
+                const size_t cnt = (size_t)(j.f1 - j.f0) + 1;
+                j.out = (Surface*)malloc(sizeof(Surface) * cnt); j.bw = (WireTri*)malloc(sizeof(WireTri) * cnt); j.fw = (WireTri*)malloc(sizeof(WireTri) * cnt);
+            }
+            jobs[t] = j;
+        }
+        if (T == 1) cull_range(&jobs[0]);
+        else {
+            for (uint32_t t = 0; t < T; ++t) pthread_create(&th[t], NULL, cull_range, &jobs[t]);
+            for (uint32_t t = 0; t < T; ++t) pthread_join(th[t], NULL);
+        }
+        for (uint32_t t = 0; t < T && !rc; ++t) rc = jobs[t].rc;           /* (the first failing range in face order, like the sequential loop) */
+        if (T == 1) { ns = jobs[0].ns; n_bw = jobs[0].n_bw; n_fw = jobs[0].n_fw; }
+        else {
+            CopyJob cj[64];
+            for (uint32_t t = 0; t < T; ++t) {      /* ordered concatenation, copied by the same threads */
+                if (!rc) {
+                    memcpy(backface_wireframes + n_bw, jobs[t].bw, sizeof(WireTri) * jobs[t].n_bw);
+                    memcpy(frontface_wireframes + n_fw, jobs[t].fw, sizeof(WireTri) * jobs[t].n_fw);
+                }
+                CopyJob c = { surfaces + ns, jobs[t].out, rc ? 0 : sizeof(Surface) * (size_t)jobs[t].ns }; cj[t] = c;
+                ns += jobs[t].ns; n_bw += jobs[t].n_bw; n_fw += jobs[t].n_fw;
+            }
+            for (uint32_t t = 0; t < T; ++t) pthread_create(&th[t], NULL, copy_job, &cj[t]);
+            for (uint32_t t = 0; t < T; ++t) pthread_join(th[t], NULL);
+            for (uint32_t t = 0; t < T; ++t) { free(jobs[t].out); free(jobs[t].bw); free(jobs[t].fw); }
+        }
+        if (rc) goto done;
     }
 
     /* SORT, :2518-2545 */
@@ -1138,8 +1227,8 @@ static int render_mesh_impl(uint8_t* fb_pixels, float* fb_zbuffer, uint32_t widt
         for (uint32_t i = n_op; i < ns; ++i) if (key[order[i]] != key[order[i]]) nan_tr = 1;
         if ((nan_tr && n_tr >= 2) || (!st->use_zbuffer && nan_op && n_op >= 2)) rc = B32_E_NAN_KEY;
         if (!rc) {
-            merge_sort_desc(order + n_op, tmp, key, n_tr);                                        /* :2527-2532 */
-            if (!st->use_zbuffer) merge_sort_desc(order, tmp, key, n_op);                         /* :2535-2542 */
+            merge_sort_desc_mt(order + n_op, tmp + n_op, key, n_tr, (uint32_t)g_threads);         /* :2527-2532 */
+            if (!st->use_zbuffer) merge_sort_desc_mt(order, tmp, key, n_op, (uint32_t)g_threads); /* :2535-2542 */
             if (timings) timings->triangles_drawn = ns;
             if (dump) { dump->n_drawn = ns; dump->n_opaque = n_op; if (dump->draw_order) for (uint32_t i = 0; i < ns; ++i) dump->draw_order[i] = surfaces[order[i]].face_idx; }
             /* DRAW, :2547-2572 */

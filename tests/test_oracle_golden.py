@@ -203,3 +203,33 @@ def test_all_cores_baseline_draws_the_same_frame(oracle, name):
     fb, tm, d = render(sc)
     t, frame = oracle.render_all_cores(sc, 3, reps=1)
     assert np.array_equal(frame, fb.pixels)
+
+
+@pytest.mark.parametrize("variant,zbuf", [("bench", False), ("blend", False), ("gouraud", True), ("blend", True)])
+def test_all_cores_schedule_equals_the_single_thread(oracle, variant, zbuf):
+    """bench.py's `cpu_all_cores` baseline runs the same port with pthreads: transform split by vertex range, cull / setup split by face
+    range with ordered concatenation, parallel stable merge sort, draw split by row band.  Frame, depth buffer, draw order, triangle
+    and fragment counts must equal the single-threaded schedule (the reference's own), for thread counts that do and do not divide
+    the work evenly -- and an out-of-range vertex index in a late face range must still be the index panic."""
+    import bonnie32_amd as b32
+    from bonnie32_amd import scenegen
+    O = oracle
+    sc = scenegen.make_scene("C3", n_tris=40_000, width=640, height=480, bbox_px=90.0, seed=4242, variant=variant)
+    sc.settings.use_zbuffer = zbuf
+    ref = None
+    for threads in (1, 3, 8, 64):
+        fb = O.Framebuffer(sc.width, sc.height); fb.clear(sc.clear_color)
+        rc, tm, d = O.render_mesh_15(fb, sc.vertices, sc.faces, sc.textures, sc.camera, sc.settings, sc.fog, dump=True, threads=threads)
+        assert rc == 0
+        got = (fb.pixels.copy(), fb.zbuffer.copy(), d["draw_order"].copy(), tm.triangles_drawn, tm.fragments)
+        if ref is None:
+            ref = got
+        else:
+            assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1].view(np.uint32), ref[1].view(np.uint32)), threads
+            assert np.array_equal(got[2], ref[2]) and got[3:] == ref[3:], threads
+    bad = sc.faces.copy()
+    bad["v"][35_000, 1] = len(sc.vertices) + 7
+    fb = O.Framebuffer(sc.width, sc.height); fb.clear(sc.clear_color)
+    before = fb.pixels.copy()
+    rc, tm = O.render_mesh_15(fb, sc.vertices, bad, sc.textures, sc.camera, sc.settings, sc.fog, threads=8)
+    assert rc == b32.abi.B32_E_INDEX and np.array_equal(fb.pixels, before)
