@@ -12,6 +12,9 @@
 #include <vector>
 
 using namespace b32;
+#ifndef B32_MIN_TILE_H
+#define B32_MIN_TILE_H 8
+#endif
 
 namespace {
 constexpr int EV_RING = 64;     // frames of per-phase events kept between two b32_frame_finish calls
@@ -995,9 +998,9 @@ static int plan_route(b32_ctx* c, FrameParams& fp, const SortScratch& sc, bool w
     // of the fused kernel.  Only the sort-free path knows about them (its k_blend included); the keyed kernels keep 64 rows.
     if (r.want_prio64 && c->band_y1 > c->band_y0 && !(c->route_off & B32_ROUTE_CUT_TILES)) {
         uint32_t th = TILE_H;
-        // 64 -> 32 rows below two tiles per CU, 32 -> 16 rows below one tile per CU (measured: a 240-row band of C3 prefers 320 tiles
-        // of 32 rows to 600 of 16; C2's 20 tiles prefer 80 of 16 rows)
-        while (th > 16 && fp.tiles_x * ((c->band_y1 + th - 1) / th - c->band_y0 / th) < (th == TILE_H ? 2u : 1u) * (uint32_t)c->n_cu &&
+        // 64 -> 32 rows below two tiles per CU, 32 -> 16 -> 8 rows below one tile per CU (measured: a 240-row band of C3 prefers 320 tiles
+        // of 32 rows to 600 of 16; C2's 20 tiles prefer 150 of 8 rows -- 0.039 ms against 0.051 with 75 of 16 rows, 0.049 with 300 of 4)
+        while (th > (uint32_t)B32_MIN_TILE_H && fp.tiles_x * ((c->band_y1 + th - 1) / th - c->band_y0 / th) < (th == TILE_H ? 2u : 1u) * (uint32_t)c->n_cu &&
                (c->band_y1 - c->band_y0) / (th / 2) + 2 <= 255 /* tile rows must fit the packed spans */) th /= 2;
         fp.tile_h = th;
         fp.tile_yb = (c->band_y0 / th) * th;

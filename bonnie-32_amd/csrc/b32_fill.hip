@@ -1565,7 +1565,7 @@ __device__ __forceinline__ bool blend_fragment(const FillArgs& a, const Tri& tr,
 // Fragment of the ordered pass, computed in phase 1 (order-free) and applied in phase 2 (in painter's order):
 //   RGB555 path: out15 | 1 << 16 when the fragment is drawn (inside, depth test against the read-only tile depth, texel rule)
 //   8-bit path : two words, colour r | g<<8 | b<<16 | blend<<24 | 1<<31 and the depth bits (its depth test needs the running depth)
-constexpr uint32_t FRAG_SLOTS = 4096;          // fragments per chunk (>= one full 64x64 surface): 16 KB of LDS (RGB555), 32 KB (8-bit)
+constexpr uint32_t FRAG_SLOTS = 4096;          // fragment buffer: 4096 words = 8192 fragments of 16 bits (RGB555, 16 KB of LDS), or 4096 fragments of two words (8-bit path, 32 KB)
 __host__ __device__ constexpr size_t blend_lds_bytes(bool fmt8, bool zmode) {
     return (size_t)LDS_TILE_BYTES * (zmode ? 2 : 1) + (size_t)FRAG_SLOTS * (fmt8 ? 8 : 4) + 256 + 16 * 256 + 64 * 128;
 }
@@ -1573,7 +1573,9 @@ __host__ __device__ constexpr size_t blend_lds_bytes(bool fmt8, bool zmode) {
 template <int NT, bool FMT8, bool GATHER = false>
 __global__ __launch_bounds__(NT, 4) void k_blend(FillArgs a) {        // 4 waves per SIMD = two workgroups per CU: at most 128 VGPRs
     constexpr int NW = NT / 64;
-    constexpr uint32_t FCAP = FRAG_SLOTS;
+    // fragment slots per chunk: the RGB555 path keeps a fragment in 16 bits (a drawn fragment's Color15 is never 0x0000: all-black sets
+    // bit 15, render.rs:1659-1661): 8192 in its 16 KB; the 8-bit path in two words: 4096 in 32 KB.  Either holds a whole 64x64 box.
+    constexpr uint32_t FCAP = FMT8 ? FRAG_SLOTS : FRAG_SLOTS * 2;
     // dynamic LDS (blend_lds_bytes): [wf 256 B][row-scheduler marks 256 B per wave][frag][tile colours][tile depths, z-buffer mode only]
     extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
     unsigned long long* wf = reinterpret_cast<unsigned long long*>(bsm);
@@ -1581,6 +1583,7 @@ __global__ __launch_bounds__(NT, 4) void k_blend(FillArgs a) {        // 4 waves
     uint32_t* frag = reinterpret_cast<uint32_t*>(bsm + 256 + 16 * 256 + 64 * 128);
     static_assert(NW <= 16, "row-scheduler marks");
     static_assert(NT == 512, "the chunk loader maps 8 threads to each of the 64 surfaces");
+    uint16_t* frag16 = reinterpret_cast<uint16_t*>(frag);
     uint32_t* tilebuf = frag + FRAG_SLOTS * (FMT8 ? 2 : 1);
     float* tilez = reinterpret_cast<float*>(tilebuf + TILE_H * TILE_STRIDE);   // (the RGB555 transparent pass never writes it)
     static_assert(!GATHER || BLEND_SORT_CAP * 2 <= FRAG_SLOTS, "the priority sort aliases the fragment buffer");
@@ -1637,9 +1640,9 @@ __global__ __launch_bounds__(NT, 4) void k_blend(FillArgs a) {        // 4 waves
     // pixel of their bounding boxes -- inside test, texel, colour pipeline -- into fixed slots (16 texel-latency chains in flight
     // per workgroup instead of one per row owner).  Phase 2 (painter's order): each wave owns a band of tile rows and applies the
     // chunk's fragments to its rows surface after surface: LDS reads and the blend, no global memory.
-    for (uint32_t cs = 0; cs < n_tr; ) {
+    for (uint32_t cs = 0; cs < n_tr; cs += 64) {
         const uint32_t cnt = min(64u, n_tr - cs);
-        {   // stage the chunk's records in LDS once per workgroup: 8 threads per surface; each assembles two quads of the surface's view
+        {   // stage the batch's records in LDS once per workgroup: 8 threads per surface; each assembles two quads of the surface's view
             // (q0..q5, then the texture descriptor + face id, then a spare) from the compact records
             const uint32_t sfc = tid >> 3, part = tid & 7;
             uint4 v = make_uint4(0, 0, 0, 0);
@@ -1679,17 +1682,27 @@ __global__ __launch_bounds__(NT, 4) void k_blend(FillArgs a) {        // 4 waves
         const uint32_t bx0 = max(mq1.w & 0xFFFF, x_lo), bx1 = min(mq1.w >> 16, x_hi);
         const uint32_t by0 = max(mq2.x & 0xFFFF, y_lo), by1 = min(mq2.x >> 16, y_hi);
         const bool live = lane < cnt && bx0 < bx1 && by0 < by1 && (my_flags >> F_ALPHA_SHIFT) != 0;
-        const uint32_t area = live ? (bx1 - bx0) * (by1 - by0) : 0u;
+        const uint32_t area_all = live ? (bx1 - bx0) * (by1 - by0) : 0u;
+        // The batch's 64 records are staged ONCE; its surfaces are then worked off in chunks of as many consecutive ones as fit the
+        // fragment buffer (a chunk used to restage 64 records to use the two or three that fit: ~20 chunks of a C3 tile, most waves idle
+        // in each).  `done` = surfaces of the batch already applied.
+        for (uint32_t done = 0; done < cnt; ) {
+        const uint32_t area = lane >= done ? area_all : 0u;
         const uint32_t inc = dpp_add_scan(area);
-        // entries of this chunk: the longest prefix whose fragments fit (every wave computes the same answer)
-        const unsigned long long fits = __ballot(lane < cnt && inc <= FCAP);
-        const uint32_t take = fits == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~fits);   // >= 1: a single clipped box has at most 4096 pixels
+        // entries of this chunk: the longest run from `done` whose fragments fit (every wave computes the same answer; a whole 64x64 box
+        // fits on its own, so the run is never empty)
+        const unsigned long long nofit = __ballot(lane >= done && !(lane < cnt && inc <= FCAP));
+        const uint32_t take = nofit ? (uint32_t)__builtin_ctzll(nofit) : 64u;           // exclusive end of the chunk (lane index)
         const uint32_t foff = inc - area;                                // fragment slot base of lane's surface
+        const uint32_t used = (uint32_t)__builtin_amdgcn_readlane((int)inc, (int)(take - 1));
+        // the chunk's slots start out as "not drawn": one cooperative pass instead of a zero-fill loop per row
+        for (uint32_t i = tid; i < (FMT8 ? used * 2 : (used + 1) / 2); i += NT) frag[i] = 0;
+        __syncthreads();
 
         // ---- phase 1: fragments.  Same ROW-ITEM scheduling as the coverage kernel: the work items of the chunk are the rows of the
         // clipped boxes; in rounds of 64 every lane takes one row of some surface (rounds are dealt to the waves round-robin),
         // fetches that surface's parameters over ds_bpermute and walks the row, evaluating texel + colour pipeline per pixel.
-        const bool in_chunk = live && lane < take;
+        const bool in_chunk = live && lane >= done && lane < take;
         const bool slow = in_chunk && (my_flags & F_SLOW);
         const uint32_t h = (in_chunk && !slow) ? by1 - by0 : 0u;
         const uint32_t hinc = dpp_add_scan(h);
@@ -1728,13 +1741,11 @@ __global__ __launch_bounds__(NT, 4) void k_blend(FillArgs a) {        // 4 waves
             const float dx = (float)(rx0 + x_lo) - tr.x3, dy = (float)py - tr.y3;
             float w0 = tr.a0 * dx + tr.b0 * dy, w1 = tr.a1 * dx + tr.b1 * dy;                              // exact integers (k_setup guard)
             uint32_t slot = sbase + (k - sP) * (rx1 - rx0);
-            // every pixel of the clipped box owns a slot; only the interval of the row that can pass the inside test (row_trim) takes
-            // the texel / colour pipeline, the rest of the row's slots are just zeroed
+            // every pixel of the clipped box owns a slot (zeroed with the chunk); only the interval of the row that can pass the inside
+            // test (row_trim) takes the texel / colour pipeline, and only drawn fragments are written
             uint32_t i_lo = 0, i_n = n;
             if (B32_ROW_TRIM) {
                 i_lo = row_trim(w0, w1, tr.a0, tr.a1, tr.inv_area, i_n);
-                for (uint32_t i = 0; __ballot(i < n); ++i)
-                    if (i < n && (i < i_lo || i >= i_lo + i_n)) { if (FMT8) { frag[2 * (slot + i)] = 0; frag[2 * (slot + i) + 1] = 0; } else frag[slot + i] = 0; }
                 w0 += tr.a0 * (float)i_lo; w1 += tr.a1 * (float)i_lo; slot += i_lo;
             }
             const uint32_t i_end = i_lo + i_n;
@@ -1753,10 +1764,10 @@ __global__ __launch_bounds__(NT, 4) void k_blend(FillArgs a) {        // 4 waves
                             }
                         } else if (ztest(tr, bcx, bcy, bcz, zmode, zmode ? tilez[ry * TILE_STRIDE + rx0 + i] : 0.0f) &&
                                    texel_drawn<0>(tr, bcx, bcy, bcz, a.texels, nullptr, texel, affine)) {
-                            v0 = shade15(texel, bcx, bcy, bcz, vc1, vc2, vc3, tr.flags, shading, shv, px, py) | 0x10000u;
+                            v0 = shade15(texel, bcx, bcy, bcz, vc1, vc2, vc3, tr.flags, shading, shv, px, py);      // (never 0: all-black sets bit 15)
                         }
                     }
-                    if (FMT8) { frag[2 * slot] = v0; frag[2 * slot + 1] = v1; } else frag[slot] = v0;
+                    if (v0) { if (FMT8) { frag[2 * slot] = v0; frag[2 * slot + 1] = v1; } else frag16[slot] = (uint16_t)v0; }
                     ++slot; w0 += tr.a0; w1 += tr.a1;
                 }
             }
@@ -1807,10 +1818,10 @@ __global__ __launch_bounds__(NT, 4) void k_blend(FillArgs a) {        // 4 waves
                                     }
                                 } else if (ztest(tr, bcx, bcy, bcz, zmode, zmode ? tilez[(py - ty_top) * TILE_STRIDE + (px - x_lo)] : 0.0f) &&
                                            texel_drawn<0>(tr, bcx, bcy, bcz, a.texels, nullptr, texel, affine)) {
-                                    v0 = shade15(texel, bcx, bcy, bcz, vc1, vc2, vc3, tr.flags, shading, shv, px, py) | 0x10000u;
+                                    v0 = shade15(texel, bcx, bcy, bcz, vc1, vc2, vc3, tr.flags, shading, shv, px, py);
                                 }
                             }
-                            if (FMT8) { frag[2 * slot] = v0; frag[2 * slot + 1] = v1; } else frag[slot] = v0;
+                            if (v0) { if (FMT8) { frag[2 * slot] = v0; frag[2 * slot + 1] = v1; } else frag16[slot] = (uint16_t)v0; }
                             w0 += tr.a0; w1 += tr.a1;
                         }
                     }
@@ -1820,7 +1831,7 @@ __global__ __launch_bounds__(NT, 4) void k_blend(FillArgs a) {        // 4 waves
         __syncthreads();
 
         // ---- phase 2: apply, in order, to the rows this wave owns (lanes = columns of the surface's box)
-        unsigned long long mine = __ballot(live && lane < take && max(by0, wy0) < min(by1, wy1));
+        unsigned long long mine = __ballot(in_chunk && max(by0, wy0) < min(by1, wy1));
         while (mine) {
             const uint32_t t = (uint32_t)__builtin_ctzll(mine);
             mine &= mine - 1;
@@ -1853,16 +1864,17 @@ __global__ __launch_bounds__(NT, 4) void k_blend(FillArgs a) {        // 4 waves
                         if (pass) { tilebuf[ti] = store8(tilebuf[ti], colr & 0x7FFFFFFFu, alpha); ++drawn; }
                     }
                 } else {
-                    const uint32_t v = on ? frag[slot] : 0u;
-                    if (!__ballot(v & 0x10000u)) continue;
-                    if (v & 0x10000u) { tilebuf[ti] = store_blend(tilebuf[ti], v & 0xFFFFu, flags, xray); ++drawn; }
+                    const uint32_t v = on ? (uint32_t)frag16[slot] : 0u;
+                    if (!__ballot(v != 0u)) continue;
+                    if (v) { tilebuf[ti] = store_blend(tilebuf[ti], v, flags, xray); ++drawn; }
                 }
             }
             for (int off = 32; off > 0; off >>= 1) drawn += __shfl_down(drawn, off);
             frag_count += (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)drawn);
         }
         __syncthreads();                                // the fragment buffer is reused by the next chunk
-        cs += take;
+        done = take;
+        }   // chunks of the batch
     }
     for (uint32_t p = tid; p < TILE_W * TH; p += NT) {      // finished tile back, one 256-B row segment per wave instruction
         const uint32_t row = p >> 6, col = p & 63;
