@@ -1253,9 +1253,11 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     // a deferred Framebuffer::clear: folded into this frame's fused kernel when that kernel is the one that runs, the frame has no
     // depth buffer to reset and the clear was issued for this very band; else the clear launches go first
     if (c->clear_pending) {
+        // (a frame with a depth buffer to reset: only in z-buffer mode, where the fused kernel owns the depth buffer too -- it seeds its
+        // winners with f32::MAX instead of reading the buffer and writes f32::MAX where nothing is drawn)
         const bool has_z = c->zbuf && c->zbuf_valid;
-        if (r.prio64 && !wire_front && !r.ordered_all && !has_z && c->nf && ntiles && c->clear_y0 == c->band_y0 && c->clear_y1 == c->band_y1) {
-            fa.clear_on = 1; fa.clear_rgba = c->clear_rgba; c->clear_pending = false;
+        if (r.prio64 && !wire_front && !r.ordered_all && (!has_z || fp.zmode) && c->nf && ntiles && c->clear_y0 == c->band_y0 && c->clear_y1 == c->band_y1) {
+            fa.clear_on = 1; fa.clear_rgba = c->clear_rgba; fa.clear_depth = (has_z && fp.zmode) ? 1u : 0u; c->clear_pending = false;
         } else if ((rc = flush_clear(c))) return rc;
     }
     launch_fill(s, fa, c->n_cu, prof_fill ? ev[4] : nullptr);

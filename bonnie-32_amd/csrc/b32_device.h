@@ -484,6 +484,7 @@ struct FillArgs {
     // Framebuffer::clear folded into the frame (b32_fb_clear defers itself; the sort-free fused kernel writes the clear colour to every
     // pixel of the band nobody draws, so the frame has no clear launch and uncovered pixels are written once, not twice)
     uint32_t clear_on, clear_rgba;
+    uint32_t clear_depth;       // with clear_on in z-buffer mode: the clear resets the depth buffer too (every depth f32::MAX, render.rs:43)
     uint32_t narrow_only;       // 1: never the 16-wave workgroups of the fused kernel (b32_set_routes)
     uint32_t prio64;            // 1: sort-free coverage -- visibility is a 64-bit max of (painter's key << 32 | face id); `vis` holds
                                 //    two words per pixel: winner face id + 1, runner-up face id + 1 (0 = none)

@@ -972,6 +972,10 @@ __device__ __forceinline__ void clear_band(const FillArgs& a) {
     uint32_t* row0 = a.fb + (size_t)fp.band_y0 * fp.width;
     const size_t n = (size_t)fp.width * (fp.band_y1 - fp.band_y0);
     for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) row0[i] = a.clear_rgba;
+    if (a.clear_depth) {        // (z-buffer mode: Framebuffer::clear resets the depth buffer too, render.rs:43)
+        float* z0 = a.zbuf + (size_t)fp.band_y0 * fp.width;
+        for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) z0[i] = __uint_as_float(0x7F7FFFFFu);
+    }
 }
 
 // PLAIN: the configuration BASELINE.json's metric is quoted on, with its run-time switches turned into constants -- affine UVs, no
@@ -1137,7 +1141,9 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a_in) {
                 const uint32_t row = p >> 6, col = p & 63;
                 const uint32_t px = x_lo + col, py = ty_top + row;
                 const bool inb = px < x_hi && py >= y_lo && py < y_hi;
-                t64[row * STR64 + col] = inb ? (((unsigned long long)(~zsort_key(a.zbuf[(size_t)py * fp.width + px])) << 32) | 0xFFFFFFFFull) : ~0ull;
+                // (a folded Framebuffer::clear: every depth is f32::MAX, nothing is read)
+                const float zseed = a.clear_depth ? __uint_as_float(0x7F7FFFFFu) : (inb ? a.zbuf[(size_t)py * fp.width + px] : 0.0f);
+                t64[row * STR64 + col] = inb ? (((unsigned long long)(~zsort_key(zseed)) << 32) | 0xFFFFFFFFull) : ~0ull;
                 if (!EXACT) t64[TILE_H * STR64 + row * STR64 + col] = 0ull;          // (EXACT keeps no runner-up: that plane holds the skip mask)
             }
         } else if (ZMODE) { // 64-bit entries (depth key << 32 | list position), seeded with the current z-buffer: a fragment wins
@@ -1186,7 +1192,7 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a_in) {
             else if (a.clear_on) {      // nothing reaches this tile: it still gets the frame's clear colour
                 for (uint32_t p = tid; p < TILE_W * TH; p += NT) {
                     const uint32_t px = x_lo + (p & 63), py = ty_top + (p >> 6);
-                    if (px < x_hi && py >= y_lo && py < y_hi) a.fb[(size_t)py * fp.width + px] = a.clear_rgba;
+                    if (px < x_hi && py >= y_lo && py < y_hi) { a.fb[(size_t)py * fp.width + px] = a.clear_rgba; if (a.clear_depth) a.zbuf[(size_t)py * fp.width + px] = __uint_as_float(0x7F7FFFFFu); }
                 }
             }
             __syncthreads();
@@ -1379,6 +1385,7 @@ __device__ __forceinline__ void shade_tile_p64(const FillArgs& a, const uint32_t
         const bool cA = covered(tA), cB = covered(tB);
         if (!__ballot(cA || cB)) {
             if (a.clear_on) { if (inA) a.fb[(size_t)pyA * W + px] = a.clear_rgba; if (inB) a.fb[(size_t)pyB * W + px] = a.clear_rgba; }
+            if (ZMODE && a.clear_depth) { if (inA) a.zbuf[(size_t)pyA * W + px] = __uint_as_float(0x7F7FFFFFu); if (inB) a.zbuf[(size_t)pyB * W + px] = __uint_as_float(0x7F7FFFFFu); }
             continue;
         }
         RecRegs ra, rb;
@@ -1402,7 +1409,7 @@ __device__ __forceinline__ void shade_tile_p64(const FillArgs& a, const uint32_t
             const uint32_t py = which ? pyB : pyA, row = which ? rowB : rowA;
             unsigned long long limit = 0, seed = 0;
             if (cov && !ok) {
-                if (ZMODE) seed = ((unsigned long long)(~zsort_key(a.zbuf[(size_t)py * W + px])) << 32) | 0xFFFFFFFFull;
+                if (ZMODE) seed = ((unsigned long long)(~zsort_key(a.clear_depth ? __uint_as_float(0x7F7FFFFFu) : a.zbuf[(size_t)py * W + px])) << 32) | 0xFFFFFFFFull;
                 const unsigned long long t2 = sec[row * STR64 + col];
                 if (t2 > seed) {                                  // (z-buffer mode: the runner-up must itself beat the stored depth)
                     ok = hit_test<FMT8>(a, sid_of(t2), px, py, h);
@@ -1441,6 +1448,7 @@ __device__ __forceinline__ void shade_tile_p64(const FillArgs& a, const uint32_t
         }
         // (Framebuffer::clear folded into the frame: pixels nobody draws get the clear colour here)
         if (a.clear_on) { if (inA && !okA) a.fb[(size_t)pyA * W + px] = a.clear_rgba; if (inB && !okB) a.fb[(size_t)pyB * W + px] = a.clear_rgba; }
+        if (ZMODE && a.clear_depth) { if (inA && !okA) a.zbuf[(size_t)pyA * W + px] = __uint_as_float(0x7F7FFFFFu); if (inB && !okB) a.zbuf[(size_t)pyB * W + px] = __uint_as_float(0x7F7FFFFFu); }
         if (okA) {
             a.fb[(size_t)pyA * W + px] = colour<FMT8>(a, hA, shading, px, pyA);
             if (ZMODE) { float z = zsort_val(~(uint32_t)(tA >> 32)); if (z == 0.0f) z = exact_depth_at(a, hA.sid, px, pyA); a.zbuf[(size_t)pyA * W + px] = z; }
