@@ -1638,7 +1638,9 @@ int b32_frame_end(b32_ctx* c) {
             for (size_t j = i; j < k; ++j) { c->frame_table.m[j - i] = c->batch[j].row; any_fog |= (c->batch[j].row.flags & 2u) != 0; }
             c->frame_batched = true;
             B32Fog f0{};                                    // (fp.has_fog switches the fog code on; the rows decide per mesh)
-            rc = render_scene_async_any(c, &c->batch_cam, &base, any_fog ? &f0 : nullptr);
+            B32Settings mst = base;                         // (members of a run never have a wireframe phase: see the run split above;
+            mst.backface_wireframe = 0;                     //  the base's flag must not give the merged mesh one -- found by the soak)
+            rc = render_scene_async_any(c, &c->batch_cam, &mst, any_fog ? &f0 : nullptr);
             c->batch_stats[0]++;
         }
         const int r2 = b32_scene_swap(c, m);

@@ -845,7 +845,7 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
             frags += cover_one<TEXMODE, EXACT, ZMODE, FMT8>(b, t, cs + (uint32_t)t + 1, tilebuf, x_lo, x_hi, y_lo, y_hi, ty_top, lane, gtex, ltex, affine);
         }
     }
-    (void)wave; (void)wmark;        // (the row starts travel by ds_permute now: the per-wave mark area in LDS is unused)
+    (void)wave; (void)wmark;        // (the row starts travel by ds_permute now; the per-wave mark area holds the shading phase's repair queues)
     return frags;
 }
 
@@ -930,7 +930,7 @@ __device__ void tile_local_sort(uint32_t* sort_area, uint32_t* wcnt, uint32_t* d
 // ------------------------------------------------------------------------------------------------ k_cover
 template <bool FMT8, int NT, bool ZMODE>
 __device__ __forceinline__ void shade_tile_p64(const FillArgs& a, const uint32_t* tilebuf, uint32_t e0, uint32_t e1, uint32_t x_lo, uint32_t x_hi,
-                                               uint32_t y_lo, uint32_t y_hi, uint32_t ty_top, uint32_t tid, uint32_t lane, uint32_t TH);
+                                               uint32_t y_lo, uint32_t y_hi, uint32_t ty_top, uint32_t tid, uint32_t lane, uint32_t TH, uint32_t* rq);
 
 // k_setup's per-block counters (visible, transparent, NaN keys per class, bad vertex index) -> the frame's abort decision in misc[6]
 // (the reference panics before drawing on a bad vertex index, render.rs:2375, or when a sort comparison sees NaN, render.rs:2531);
@@ -1188,7 +1188,7 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a_in) {
 #ifdef B32_TIMELINE
             const unsigned long long tl1 = wall_clock64();
 #endif
-            if (n_op) shade_tile_p64<FMT8, NT, ZMODE>(a, tilebuf, e0, e1, x_lo, x_hi, y_lo, y_hi, ty_top, tid, lane, TH);
+            if (n_op) shade_tile_p64<FMT8, NT, ZMODE>(a, tilebuf, e0, e1, x_lo, x_hi, y_lo, y_hi, ty_top, tid, lane, TH, wmarks + wave * 64);
             else if (a.clear_on) {      // nothing reaches this tile: it still gets the frame's clear colour
                 for (uint32_t p = tid; p < TILE_W * TH; p += NT) {
                     const uint32_t px = x_lo + (p & 63), py = ty_top + (p >> 6);
@@ -1363,9 +1363,61 @@ __device__ __forceinline__ bool depth_prio(const FillArgs& a, uint32_t sid, cons
     return z == z;
 }
 
+// A pixel whose winner turned out to be skipped by the texel rule (CHEAP coverage only tested the triangle): the exact runner-up from
+// LDS, then (rarer) the best drawn surface below it from the tile list.  Every lane of the wave must call this together (the list scan
+// is a wave-level loop over the lanes that need it); `need` = this lane has such a pixel.  On return ok / h / t describe what the
+// pixel finally shows (ok false: nothing drawn, the pixel keeps the framebuffer's / the folded clear's value).
+template <bool FMT8, bool ZMODE>
+__device__ __forceinline__ void repair_pixel(const FillArgs& a, const unsigned long long* sec, bool need, uint32_t row, uint32_t col, uint32_t px, uint32_t py,
+                                             uint32_t e0, uint32_t e1, uint32_t lane, bool& ok, Hit& h, unsigned long long& t) {
+    const uint32_t W = a.fp.width;
+    auto sid_of = [](unsigned long long v) { return ZMODE ? 0xFFFFFFFEu - (uint32_t)v : (uint32_t)v; };
+    unsigned long long limit = 0, seed = 0;
+    if (need) {
+        if (ZMODE) seed = ((unsigned long long)(~zsort_key(a.clear_depth ? __uint_as_float(0x7F7FFFFFu) : a.zbuf[(size_t)py * W + px])) << 32) | 0xFFFFFFFFull;
+        const unsigned long long t2 = sec[row * STR64 + col];
+        if (t2 > seed) {                                  // (z-buffer mode: the runner-up must itself beat the stored depth)
+            ok = hit_test<FMT8>(a, sid_of(t2), px, py, h);
+            if (ok) t = t2; else limit = t2;
+        }
+    }
+    unsigned long long fm = __ballot(limit != 0);
+    while (fm) {
+        const int fl = __builtin_ctzll(fm);
+        fm &= fm - 1;
+        const uint32_t fx = (uint32_t)__builtin_amdgcn_readlane((int)px, fl), fy = (uint32_t)__builtin_amdgcn_readlane((int)py, fl);
+        const unsigned long long lim = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(limit >> 32), fl) << 32) |
+                                       (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)limit, fl);
+        const unsigned long long sd = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(seed >> 32), fl) << 32) |
+                                      (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)seed, fl);
+        unsigned long long best = 0;
+        for (uint32_t base = e0; base < e1; base += 64) {
+            unsigned long long cand = 0;
+            if (base + lane < e1) {
+                const uint32_t csid = a.pair_vals[base + lane];
+                const uint4 cc1 = reinterpret_cast<const uint4*>(a.crecs + csid)[1];
+                const uint32_t bbx = cc1.x, bby = cc1.y;
+                if (fx >= (bbx & 0xFFFF) && fx < (bbx >> 16) && fy >= (bby & 0xFFFF) && fy < (bby >> 16)) {
+                    unsigned long long P = ((unsigned long long)cc1.z << 32) | csid;
+                    Hit c;
+                    if (ZMODE) {
+                        if (hit_test<FMT8>(a, csid, fx, fy, c) && depth_prio(a, csid, c, P) && P < lim && P > sd) cand = P;
+                    } else if (P < lim && P > best && hit_test<FMT8>(a, csid, fx, fy, c)) cand = P;
+                }
+            }
+            for (int off = 32; off > 0; off >>= 1) { const unsigned long long o = __shfl_xor(cand, off); cand = o > cand ? o : cand; }
+            best = cand > best ? cand : best;
+        }
+        if ((int)lane == fl && best) { ok = hit_test<FMT8>(a, sid_of(best), px, py, h); t = best; }
+    }
+}
+
+// wq: this WAVE's repair queue (64 words of LDS, entry i = row << 6 | col): pixels whose winner was skipped are NOT repaired where they
+// are found -- one lane of the wave shading a whole runner-up, behind a record gather and a texel fetch of its own, in two steps out
+// of five on the benchmark scene -- but collected and repaired together: when 64 have gathered, and behind the tile's last row.
 template <bool FMT8, int NT, bool ZMODE>
 __device__ __forceinline__ void shade_tile_p64(const FillArgs& a, const uint32_t* tilebuf, uint32_t e0, uint32_t e1, uint32_t x_lo, uint32_t x_hi,
-                                               uint32_t y_lo, uint32_t y_hi, uint32_t ty_top, uint32_t tid, uint32_t lane, uint32_t TH) {
+                                               uint32_t y_lo, uint32_t y_hi, uint32_t ty_top, uint32_t tid, uint32_t lane, uint32_t TH, uint32_t* wq) {
     const FrameParams& fp = a.fp;
     const unsigned long long* top = reinterpret_cast<const unsigned long long*>(tilebuf);
     const unsigned long long* sec = top + TILE_H * STR64;
@@ -1376,6 +1428,27 @@ __device__ __forceinline__ void shade_tile_p64(const FillArgs& a, const uint32_t
     // z-buffer mode: a winner exists when the low word is not the seed's all-ones; its face id is 0xFFFFFFFE - low word
     auto covered = [](unsigned long long t) { return ZMODE ? ((uint32_t)t != 0xFFFFFFFFu) : (t != 0ull); };
     auto sid_of = [](unsigned long long t) { return ZMODE ? 0xFFFFFFFEu - (uint32_t)t : (uint32_t)t; };
+    auto put = [&](uint32_t px, uint32_t py, bool ok, const Hit& h, unsigned long long t, bool in) {
+        if (ok) {
+            a.fb[(size_t)py * W + px] = colour<FMT8>(a, h, shading, px, py);
+            if (ZMODE) { float z = zsort_val(~(uint32_t)(t >> 32)); if (z == 0.0f) z = exact_depth_at(a, h.sid, px, py); a.zbuf[(size_t)py * W + px] = z; }
+        } else if (in) {          // (Framebuffer::clear folded into the frame: pixels nobody draws get the clear colour, and depth, here)
+            if (a.clear_on) a.fb[(size_t)py * W + px] = a.clear_rgba;
+            if (ZMODE && a.clear_depth) a.zbuf[(size_t)py * W + px] = __uint_as_float(0x7F7FFFFFu);
+        }
+    };
+    uint32_t lqn = 0;                                   // entries in this wave's queue (wave-uniform)
+    auto drain = [&]() {
+        const bool act = lane < lqn;
+        const uint32_t e = act ? wq[lane] : 0u;
+        const uint32_t row = e >> 6, col = e & 63u, px = x_lo + col, py = ty_top + row;
+        bool ok = false; Hit h; h.sid = 0;
+        unsigned long long t = 0;
+        repair_pixel<FMT8, ZMODE>(a, sec, act, row, col, px, py, e0, e1, lane, ok, h, t);
+        if (act) put(px, py, ok, h, t, true);
+        lqn = 0;
+    };
+    const unsigned long long below = (1ull << lane) - 1ull;
     for (uint32_t r0 = 0; r0 < TH; r0 += 2 * ROWS_PER_STEP) {
         const uint32_t col = tid & 63;
         const uint32_t rowA = r0 + (tid >> 6), rowB = rowA + ROWS_PER_STEP;
@@ -1383,81 +1456,39 @@ __device__ __forceinline__ void shade_tile_p64(const FillArgs& a, const uint32_t
         const bool inA = rowA < TH && px < x_hi && pyA >= y_lo && pyA < y_hi, inB = rowB < TH && px < x_hi && pyB >= y_lo && pyB < y_hi;
         unsigned long long tA = inA ? top[rowA * STR64 + col] : (ZMODE ? ~0ull : 0ull), tB = inB ? top[rowB * STR64 + col] : (ZMODE ? ~0ull : 0ull);
         const bool cA = covered(tA), cB = covered(tB);
-        if (!__ballot(cA || cB)) {
-            if (a.clear_on) { if (inA) a.fb[(size_t)pyA * W + px] = a.clear_rgba; if (inB) a.fb[(size_t)pyB * W + px] = a.clear_rgba; }
-            if (ZMODE && a.clear_depth) { if (inA) a.zbuf[(size_t)pyA * W + px] = __uint_as_float(0x7F7FFFFFu); if (inB) a.zbuf[(size_t)pyB * W + px] = __uint_as_float(0x7F7FFFFFu); }
-            continue;
+        unsigned long long mA = 0, mB = 0;
+        {
+            Hit hA, hB;
+            hA.sid = hB.sid = 0;
+            if (!__ballot(cA || cB)) { put(px, pyA, false, hA, tA, inA); put(px, pyB, false, hB, tB, inB); continue; }
+            RecRegs ra, rb;
+            rec_load(a, cA ? sid_of(tA) : 0u, need5, ra);             // surface 0's record is a harmless dummy for uncovered pixels
+            rec_load(a, cB ? sid_of(tB) : 0u, need5, rb);
+            int taA = -1, taB = -1;
+            bool okA = cA && hit_prepare(a, ra, px, pyA, hA, taA);
+            bool okB = cB && hit_prepare(a, rb, px, pyB, hB, taB);
+            const uint32_t fA = fetch_texel<FMT8>(a, okA ? taA : -1), fB = fetch_texel<FMT8>(a, okB ? taB : -1);
+            hA.sid = sid_of(tA); hB.sid = sid_of(tB);
+            okA = okA && hit_finish<FMT8>(hA.flags, taA, fA, hA.texel);
+            okB = okB && hit_finish<FMT8>(hB.flags, taB, fB, hB.texel);
+            // (a covered pixel whose winner is skipped waits in the queue; everything else is final)
+            mA = __ballot(cA && !okA); mB = __ballot(cB && !okB);
+            if (!(cA && !okA)) put(px, pyA, okA, hA, tA, inA);
+            if (!(cB && !okB)) put(px, pyB, okB, hB, tB, inB);
         }
-        RecRegs ra, rb;
-        rec_load(a, cA ? sid_of(tA) : 0u, need5, ra);             // surface 0's record is a harmless dummy for uncovered pixels
-        rec_load(a, cB ? sid_of(tB) : 0u, need5, rb);
-        Hit hA, hB;
-        int taA = -1, taB = -1;
-        bool okA = cA && hit_prepare(a, ra, px, pyA, hA, taA);
-        bool okB = cB && hit_prepare(a, rb, px, pyB, hB, taB);
-        const uint32_t fA = fetch_texel<FMT8>(a, okA ? taA : -1), fB = fetch_texel<FMT8>(a, okB ? taB : -1);
-        hA.sid = sid_of(tA); hB.sid = sid_of(tB);
-        okA = okA && hit_finish<FMT8>(hA.flags, taA, fA, hA.texel);
-        okB = okB && hit_finish<FMT8>(hB.flags, taB, fB, hB.texel);
-        // skipped winner (rare): the exact runner-up from LDS, then (rarer) the best drawn surface below it from the list
+        if (mA | mB) {
 #pragma unroll
-        for (int which = 0; which < 2; ++which) {
-            unsigned long long& t = which ? tB : tA;
-            const bool cov = which ? cB : cA;
-            bool& ok = which ? okB : okA;
-            Hit& h = which ? hB : hA;
-            const uint32_t py = which ? pyB : pyA, row = which ? rowB : rowA;
-            unsigned long long limit = 0, seed = 0;
-            if (cov && !ok) {
-                if (ZMODE) seed = ((unsigned long long)(~zsort_key(a.clear_depth ? __uint_as_float(0x7F7FFFFFu) : a.zbuf[(size_t)py * W + px])) << 32) | 0xFFFFFFFFull;
-                const unsigned long long t2 = sec[row * STR64 + col];
-                if (t2 > seed) {                                  // (z-buffer mode: the runner-up must itself beat the stored depth)
-                    ok = hit_test<FMT8>(a, sid_of(t2), px, py, h);
-                    if (ok) t = t2; else limit = t2;
-                }
+            for (int which = 0; which < 2; ++which) {
+                const unsigned long long m = which ? mB : mA;
+                if (!m) continue;
+                const uint32_t n = (uint32_t)__builtin_popcountll(m);
+                if (lqn + n > 64u) drain();
+                if ((m >> lane) & 1ull) wq[lqn + (uint32_t)__builtin_popcountll(m & below)] = ((which ? rowB : rowA) << 6) | col;
+                lqn += n;
             }
-            unsigned long long fm = __ballot(limit != 0);
-            while (fm) {
-                const int fl = __builtin_ctzll(fm);
-                fm &= fm - 1;
-                const uint32_t fx = (uint32_t)__builtin_amdgcn_readlane((int)px, fl), fy = (uint32_t)__builtin_amdgcn_readlane((int)py, fl);
-                const unsigned long long lim = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(limit >> 32), fl) << 32) |
-                                               (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)limit, fl);
-                const unsigned long long sd = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(seed >> 32), fl) << 32) |
-                                              (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)seed, fl);
-                unsigned long long best = 0;
-                for (uint32_t base = e0; base < e1; base += 64) {
-                    unsigned long long cand = 0;
-                    if (base + lane < e1) {
-                        const uint32_t csid = a.pair_vals[base + lane];
-                        const uint4 cc1 = reinterpret_cast<const uint4*>(a.crecs + csid)[1];
-                        const uint32_t bbx = cc1.x, bby = cc1.y;
-                        if (fx >= (bbx & 0xFFFF) && fx < (bbx >> 16) && fy >= (bby & 0xFFFF) && fy < (bby >> 16)) {
-                            unsigned long long P = ((unsigned long long)cc1.z << 32) | csid;
-                            Hit c;
-                            if (ZMODE) {
-                                if (hit_test<FMT8>(a, csid, fx, fy, c) && depth_prio(a, csid, c, P) && P < lim && P > sd) cand = P;
-                            } else if (P < lim && P > best && hit_test<FMT8>(a, csid, fx, fy, c)) cand = P;
-                        }
-                    }
-                    for (int off = 32; off > 0; off >>= 1) { const unsigned long long o = __shfl_xor(cand, off); cand = o > cand ? o : cand; }
-                    best = cand > best ? cand : best;
-                }
-                if ((int)lane == fl && best) { ok = hit_test<FMT8>(a, sid_of(best), px, py, h); t = best; }
-            }
-        }
-        // (Framebuffer::clear folded into the frame: pixels nobody draws get the clear colour here)
-        if (a.clear_on) { if (inA && !okA) a.fb[(size_t)pyA * W + px] = a.clear_rgba; if (inB && !okB) a.fb[(size_t)pyB * W + px] = a.clear_rgba; }
-        if (ZMODE && a.clear_depth) { if (inA && !okA) a.zbuf[(size_t)pyA * W + px] = __uint_as_float(0x7F7FFFFFu); if (inB && !okB) a.zbuf[(size_t)pyB * W + px] = __uint_as_float(0x7F7FFFFFu); }
-        if (okA) {
-            a.fb[(size_t)pyA * W + px] = colour<FMT8>(a, hA, shading, px, pyA);
-            if (ZMODE) { float z = zsort_val(~(uint32_t)(tA >> 32)); if (z == 0.0f) z = exact_depth_at(a, hA.sid, px, pyA); a.zbuf[(size_t)pyA * W + px] = z; }
-        }
-        if (okB) {
-            a.fb[(size_t)pyB * W + px] = colour<FMT8>(a, hB, shading, px, pyB);
-            if (ZMODE) { float z = zsort_val(~(uint32_t)(tB >> 32)); if (z == 0.0f) z = exact_depth_at(a, hB.sid, px, pyB); a.zbuf[(size_t)pyB * W + px] = z; }
         }
     }
+    if (lqn) drain();
 }
 
 // One 256-thread workgroup per 64x16 strip of a 64x64 tile; each wave shades a 64-pixel row segment at a time (256-B coalesced

@@ -89,8 +89,58 @@ def slots_case():
         print("   slots:", [(sc.name, st.use_zbuffer, tex8 is not None, bad) for sc, st, tex8, faces, bad in items], W, H, flush=True)
     return ok
 
+def batch_case():
+    """b32_frame_begin / _add_scene / _end with random meshes, per-mesh ambient / fog / backface_cull, random base settings (z-buffer or
+    painter's, lights or not, sometimes x-ray / 8-bit-free wireframe bases that force the mesh-by-mesh fallback) against the oracle's
+    sequential render_mesh_15 calls; two frames, the second with another camera (merged meshes come from the cache)."""
+    import copy
+    W, H = [(320, 240), (333, 197), (640, 480)][rng.integers(3)]
+    k = int(rng.integers(2, 9))
+    meshes = [scenegen.make_scene(str(rng.choice(["C1", "C2"])), n_tris=int(rng.choice([7, 300, 2500, 9000])), seed=int(rng.integers(1 << 30)),
+                                  variant=str(rng.choice(["bench", "gouraud", "gouraud", "blend", "blend5"])), width=W, height=H,
+                                  bbox_px=float(rng.choice([60.0, 400.0, 900.0]))) for _ in range(k)]
+    st = b32.RasterSettings.game()
+    st.use_zbuffer = bool(rng.integers(4) > 0)
+    st.shading = int(rng.integers(0, 3))
+    st.lights = [b32.Light.directional((-1.0, -1.0, -1.0), 0.7), b32.Light.point((0.0, -100.0, 1500.0), 3000.0, 1.2)][:int(rng.integers(0, 3))]
+    st.xray_mode = bool(rng.integers(12) == 0)
+    st.affine_textures = bool(rng.integers(4) > 0)
+    st.backface_wireframe = bool(rng.integers(10) == 0)
+    fogs = [None, (1500.0, 3000.0, 5800.0, b32.Color(40, 50, 70)), (800.0, 2500.0, 5000.0, b32.Color(90, 20, 20))]
+    per = [dict(ambient=float(rng.uniform(0.0, 0.6)), backface_cull=bool(rng.integers(4) > 0), fog=fogs[int(rng.integers(3))]) for _ in range(k)]
+    ctx.set_fragment_counting(int(rng.integers(2)))
+    fb = R.Framebuffer(W, H, ctx)
+    ofb = O.Framebuffer(W, H)
+    slots = [R.ResidentScene(fb, sc.vertices, sc.faces, sc.textures).detach() for sc in meshes]
+    ok = True
+    try:
+        for frame in range(2):
+            cam = b32.Camera(); cam.position = (float(rng.normal(0, 30)), float(rng.normal(0, 30)), float(rng.normal(0, 60)))
+            col = b32.Color(int(rng.integers(256)), int(rng.integers(256)), int(rng.integers(256)))
+            ofb.clear(col); fb.clear(col)
+            for sc, p in zip(meshes, per):
+                s2 = copy.copy(st); s2.ambient = p["ambient"]; s2.backface_cull = p["backface_cull"]
+                assert O.render_mesh_15(ofb, sc.vertices, sc.faces, sc.textures, cam, s2, p["fog"])[0] == 0
+            ctx.frame_begin(cam, st)
+            for rs, p in zip(slots, per):
+                ctx.frame_add(rs, **p)
+            ctx.frame_end(); ctx.finish()
+            ok = ok and np.array_equal(fb.pixels, ofb.pixels) and np.array_equal(fb.zbuffer.view(np.uint32), ofb.zbuffer.view(np.uint32))
+    finally:
+        for rs in slots:
+            rs.close()
+    if not ok:
+        print("   batch:", [(sc.name, sc.n_tris) for sc in meshes], W, H, "z", st.use_zbuffer, "xray", st.xray_mode, "wire", st.backface_wireframe, flush=True)
+    return ok
+
 while time.time() < t_end:
     n += 1
+    if rng.integers(10) == 0 and not os.environ.get("SOAK_FORCE"):
+        drawn += 1
+        if not batch_case():
+            fails += 1
+            print(f"FAIL #{n} batched frame", flush=True)
+        continue
     if rng.integers(10) == 0 and not os.environ.get("SOAK_FORCE"):
         drawn += 1
         if not slots_case():
