@@ -142,6 +142,7 @@ __device__ __forceinline__ bool texel_drawn(const Tri& t, float bcx, float bcy, 
 }
 
 // Colour pipeline (render.rs:1613-1661): modulate by interpolated vertex colour, shade, dither, quantize to RGB555.
+template <bool RGBA = false>
 __device__ __forceinline__ uint32_t shade15(uint32_t texel, float bcx, float bcy, float bcz, uint32_t vc1, uint32_t vc2, uint32_t vc3,
                                             uint32_t flags, int shading, const float* sh, uint32_t px, uint32_t py) {
     uint32_t q[3];
@@ -159,6 +160,11 @@ __device__ __forceinline__ uint32_t shade15(uint32_t texel, float bcx, float bcy
         }
         if (flags & F_DITHER) q[i] = (uint32_t)min(max(((int)m + off) >> K::DITHER_SHIFT, K::DITHER_LO), K::DITHER_HI); // dither_and_quantize :1173-1182
         else q[i] = m >> K::NODITHER_SHIFT;                                           // :1653
+    }
+    if (RGBA) {
+        // straight to the RGBA8 word set_pixel_15 stores (render.rs:445-454, Color15::to_rgba types.rs:220-226): the Color15 in between is
+        // never 0x0000 (an all-black result gets bit 15, :1659-1661), so its to_rgba is always the three expanded channels + alpha 255
+        return expand5(q[0]) | (expand5(q[1]) << 8) | (expand5(q[2]) << 16) | 0xFF000000u;
     }
     const bool all_black = (q[0] | q[1] | q[2]) == 0;                                 // :1659-1661
     return (q[0] << K::C15_R_SHIFT) | (q[1] << K::C15_G_SHIFT) | q[2] | (((texel & K::C15_SEMI_BIT) || all_black) ? K::C15_SEMI_BIT : 0u);
@@ -1284,7 +1290,7 @@ __device__ __forceinline__ uint32_t colour(const FillArgs& a, const Hit& h, int 
     if (shading != B32_SHADE_NONE) for (int j = 0; j < 9; ++j) shv[j] = a.shades[(size_t)h.sid * 9 + j];
     // 8-bit path: the overwrite pass only runs when no texel blends and every editor alpha is 255 -> set_pixel (render.rs:301-310)
     if (FMT8) return (shade8(h.texel, h.bcx, h.bcy, h.bcz, h.vc1, h.vc2, h.vc3, h.flags, shading, shv, px, py) & 0xFFFFFFu) | 0xFF000000u;
-    return c15_to_rgba(shade15(h.texel, h.bcx, h.bcy, h.bcz, h.vc1, h.vc2, h.vc3, h.flags, shading, shv, px, py));   // set_pixel_15
+    return shade15<true>(h.texel, h.bcx, h.bcy, h.bcz, h.vc1, h.vc2, h.vc3, h.flags, shading, shv, px, py);   // set_pixel_15 of the Color15 (see shade15)
 }
 
 // ------------------------------------------------------------------------------------------------ fused shading (P64 fast path)
@@ -1787,6 +1793,9 @@ __global__ __launch_bounds__(NT, 4) void k_blend(FillArgs a) {        // 4 waves
                 i_lo = row_trim(w0, w1, tr.a0, tr.a1, tr.inv_area, i_n);
                 w0 += tr.a0 * (float)i_lo; w1 += tr.a1 * (float)i_lo; slot += i_lo;
             }
+#ifdef B32_EXP_BLEND_NO_FRAG
+            i_n = 0;                                    // experiment builds only: no fragment is generated, to time the rest
+#endif
             const uint32_t i_end = i_lo + i_n;
             for (uint32_t i = i_lo; __ballot(i < i_end); ++i) {
                 if (i < i_end) {
@@ -1871,6 +1880,9 @@ __global__ __launch_bounds__(NT, 4) void k_blend(FillArgs a) {        // 4 waves
 
         // ---- phase 2: apply, in order, to the rows this wave owns (lanes = columns of the surface's box)
         unsigned long long mine = __ballot(in_chunk && max(by0, wy0) < min(by1, wy1));
+#ifdef B32_EXP_BLEND_NO_APPLY
+        mine = 0;                                       // experiment builds only (tools/exp_variants.py): phase 2 off, to time phase 1
+#endif
         while (mine) {
             const uint32_t t = (uint32_t)__builtin_ctzll(mine);
             mine &= mine - 1;
