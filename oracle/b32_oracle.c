@@ -1063,6 +1063,7 @@ struct Surface_;
 typedef struct {
     FB fb; const void* surfaces; const uint32_t* order; uint32_t ns, n_op;
     const B32Face* faces; const B32Texture15* textures; const B32Texture* textures8; uint32_t nt; const B32Settings* st; int rc;
+    const float* ylo; const float* yhi;         /* row extents per surface (all-cores schedule), or NULL */
 } DrawJob;
 static void* draw_range(void* arg);
 
@@ -1136,6 +1137,11 @@ static void* cull_range(void* arg) {
 
     return NULL;
 }
+/* per surface: its sort key (render.rs:2529), its class, and the rows its bounding box can touch -- compact arrays, so that the partition,
+ * the NaN scan and, in the all-cores schedule, every row band's walk of the sorted list do not drag the 200-byte surfaces through the
+ * cache (a band thread skips a surface whose rows lie outside its band: rasterize_triangle_15 would clip its box to nothing) */
+typedef struct { const void* surfaces; uint32_t i0, i1; float* key; uint8_t* tr; float* ylo; float* yhi; } PrepJob;
+static void* prep_range(void* arg);
 typedef struct { void* dst; const void* src; size_t n; } CopyJob;
 static void* copy_job(void* arg) { const CopyJob* c = (const CopyJob*)arg; if (c->n) memcpy(c->dst, c->src, c->n); return NULL; }
 
@@ -1218,9 +1224,19 @@ static int render_mesh_impl(uint8_t* fb_pixels, float* fb_zbuffer, uint32_t widt
         uint32_t* order = (uint32_t*)malloc(sizeof(uint32_t) * (ns ? ns : 1));
         uint32_t* tmp = (uint32_t*)malloc(sizeof(uint32_t) * (ns ? ns : 1));
         float* key = (float*)malloc(sizeof(float) * (ns ? ns : 1));
+        float* ylo = (float*)malloc(sizeof(float) * (ns ? ns : 1));
+        float* yhi = (float*)malloc(sizeof(float) * (ns ? ns : 1));
+        uint8_t* trc = (uint8_t*)malloc(ns ? ns : 1);
         uint32_t n_op = 0, n_tr = 0;
-        for (uint32_t i = 0; i < ns; ++i) { key[i] = center_z(&surfaces[i]); if (!surfaces[i].has_transparency) order[n_op++] = i; }
-        for (uint32_t i = 0; i < ns; ++i) if (surfaces[i].has_transparency) order[n_op + n_tr++] = i;
+        {
+            const uint32_t T = (g_threads > 1 && ns >= 8192) ? (uint32_t)(g_threads > 64 ? 64 : g_threads) : 1u;
+            PrepJob pj[64]; pthread_t pth[64];
+            for (uint32_t t = 0; t < T; ++t) { PrepJob q = { surfaces, (uint32_t)((uint64_t)ns * t / T), (uint32_t)((uint64_t)ns * (t + 1) / T), key, trc, ylo, yhi }; pj[t] = q; }
+            if (T == 1) prep_range(&pj[0]);
+            else { for (uint32_t t = 0; t < T; ++t) pthread_create(&pth[t], NULL, prep_range, &pj[t]); for (uint32_t t = 0; t < T; ++t) pthread_join(pth[t], NULL); }
+        }
+        for (uint32_t i = 0; i < ns; ++i) if (!trc[i]) order[n_op++] = i;                        /* partition(!has_transparency), :2522-2523 */
+        for (uint32_t i = 0; i < ns; ++i) if (trc[i]) order[n_op + n_tr++] = i;
         /* partial_cmp().unwrap() panics on NaN as soon as a comparison sees one (any list with >= 2 elements) */
         int nan_tr = 0, nan_op = 0;
         for (uint32_t i = 0; i < n_op; ++i) if (key[order[i]] != key[order[i]]) nan_op = 1;
@@ -1238,7 +1254,7 @@ static int render_mesh_impl(uint8_t* fb_pixels, float* fb_zbuffer, uint32_t widt
                 const uint32_t T = (g_threads > 1 && rows >= (uint32_t)g_threads && ns >= 64) ? (uint32_t)g_threads : 1u;
                 DrawJob jobs[256]; pthread_t th[256];
                 for (uint32_t t = 0; t < T; ++t) {
-                    DrawJob j = { fb, surfaces, order, ns, n_op, faces, textures, textures8, nt, st, B32_OK };
+                    DrawJob j = { fb, surfaces, order, ns, n_op, faces, textures, textures8, nt, st, B32_OK, T > 1 ? ylo : NULL, T > 1 ? yhi : NULL };
                     j.fb.fragments = 0;
                     if (T > 1) { j.fb.band_y0 = by0 + (uint32_t)((uint64_t)rows * t / T); j.fb.band_y1 = by0 + (uint32_t)((uint64_t)rows * (t + 1) / T); }
                     jobs[t] = j;
@@ -1251,7 +1267,7 @@ static int render_mesh_impl(uint8_t* fb_pixels, float* fb_zbuffer, uint32_t widt
                 for (uint32_t t = 0; t < T; ++t) { fb.fragments += jobs[t].fb.fragments; if (jobs[t].rc && !rc) rc = jobs[t].rc; }
             }
         }
-        free(order); free(tmp); free(key);
+        free(order); free(tmp); free(key); free(ylo); free(yhi); free(trc);
     }
     if (timings) timings->fragments = fb.fragments;
     /* WIREFRAME, :2574-2635 */
@@ -1274,12 +1290,30 @@ done:
     return rc;
 }
 
+static void* prep_range(void* arg) {
+    const PrepJob* j = (const PrepJob*)arg;
+    const Surface* surfaces = (const Surface*)j->surfaces;
+    for (uint32_t i = j->i0; i < j->i1; ++i) {
+        const Surface* s = &surfaces[i];
+        j->key[i] = center_z(s); j->tr[i] = s->has_transparency;
+        const float y1 = s->v1.y, y2 = s->v2.y, y3 = s->v3.y;
+        if (y1 - y1 == 0.0f && y2 - y2 == 0.0f && y3 - y3 == 0.0f) {          /* all finite */
+            j->ylo[i] = y1 < y2 ? (y1 < y3 ? y1 : y3) : (y2 < y3 ? y2 : y3);
+            j->yhi[i] = y1 > y2 ? (y1 > y3 ? y1 : y3) : (y2 > y3 ? y2 : y3);
+        } else { j->ylo[i] = -3.0e38f; j->yhi[i] = 3.0e38f; }                 /* (never skipped) */
+    }
+    return NULL;
+}
 static void* draw_range(void* arg) {
     DrawJob* j = (DrawJob*)arg;
     const Surface* surfaces = (const Surface*)j->surfaces;
     const int fmt8 = j->textures8 != NULL;
     for (uint32_t i = 0; i < j->ns && !j->rc; ++i) {
-        const Surface* s = &surfaces[j->order[i]];
+        const uint32_t si = j->order[i];
+        /* a row band of the all-cores schedule: boxes entirely above or below it draw nothing here (min_y = min(..).max(0) as usize,
+         * max_y = (max(..) + 1.0).min(h) as usize, render.rs:1457-1458, clipped to the band) */
+        if (j->ylo && (j->yhi[si] + 1.0f < (float)j->fb.band_y0 || j->ylo[si] >= (float)j->fb.band_y1)) continue;
+        const Surface* s = &surfaces[si];
         uint32_t tid = j->faces[s->face_idx].texture_id;
         if (fmt8) {
             const B32Texture* tex8 = (tid != B32_NO_TEXTURE && tid < j->nt) ? &j->textures8[tid] : NULL;       /* :2196-2198 */
