@@ -27,6 +27,9 @@
 #ifndef B32_TRIP
 #define B32_TRIP 4
 #endif
+#ifndef B32_DRAIN_TRIPS
+#define B32_DRAIN_TRIPS 2
+#endif
 #ifndef B32_P64_STRIDE
 #define B32_P64_STRIDE 66        // row stride (u64 entries) of the 64-bit winner planes: 64 + 2, so the rows a surface touches at one
                                  // column fall into different LDS banks (measured: 72 -> 133 us, 66 -> 128 us; must stay <= 72, the allocation)
@@ -682,9 +685,28 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
             uint32_t addr = ry * STR64 + rx;
             unsigned long long* top = reinterpret_cast<unsigned long long*>(tilebuf);
             unsigned long long* sec = top + TILE_H * STR64;
+#if B32_DRAIN_TRIPS > 0
+            // at most B32_DRAIN_TRIPS trips per entry and round; what is left of a long row goes back into the queue (a round used to last
+            // as long as its longest remainder: with the ~25-px rows of C5 most lanes idled behind the longest)
+            constexpr uint32_t DT = (uint32_t)B32_DRAIN_TRIPS * (uint32_t)B32_TRIP;
+#pragma unroll
+            for (uint32_t i = 0; i < DT; i += B32_TRIP)
+                cheap_trip<ZMODE>(top, sec, addr, w0, w1, sa0, sa1, sinv, i < n ? n - i : 0u, P, z1, z2, z3);
+            const bool more = n > DT;
+            const unsigned long long mm = __ballot(more);
+            const uint32_t cnt = (uint32_t)__builtin_popcountll(mm);
+            if (cnt) {
+                const uint32_t entry = s | (ry << 6) | ((rx + DT) << 12) | ((n - DT) << 19);
+                const uint32_t dst = more ? (uint32_t)__builtin_popcountll(mm & ((1ull << lane) - 1ull)) : (cnt & 63u);
+                const uint32_t got = (uint32_t)__builtin_amdgcn_ds_permute((int)(dst << 2), (int)(more ? entry : 0u));
+                if (lane < cnt) lq = got;
+            }
+            lqn = cnt;
+#else
             for (uint32_t i = 0; __ballot(i < n); i += B32_TRIP)
                 cheap_trip<ZMODE>(top, sec, addr, w0, w1, sa0, sa1, sinv, i < n ? n - i : 0u, P, z1, z2, z3);
             lqn = 0;
+#endif
         };
         for (uint32_t k0 = 0; k0 < R; k0 += 64) {
             // owner of item k0+lane: last surface s with h>0 and P[s] <= k
@@ -805,7 +827,7 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
                 const unsigned long long mm = __ballot(more);
                 if (mm) {
                     const uint32_t cnt = (uint32_t)__builtin_popcountll(mm);
-                    if (lqn + cnt > 64u) drain();
+                    while (lqn + cnt > 64u) drain();
                     // forward permute into the queue's free lanes [lqn, lqn + cnt); the lanes with nothing to push aim at the first lane
                     // behind them (lane 0 when that is 64: then every lane pushes or lqn + cnt == 64 and lane 0 is not taken from `got`)
                     const uint32_t entry = s | (ry << 6) | ((rx0 + (uint32_t)B32_TRIP) << 12) | ((n - (uint32_t)B32_TRIP) << 19);
@@ -836,7 +858,7 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
                 frags += (uint32_t)__builtin_amdgcn_readfirstlane((int)mine);
             }
         }
-        if (P64 && !EXACT && lqn) drain();             // (the row remainders of this batch: its registers are about to be reloaded)
+        if (P64 && !EXACT) while (lqn) drain();        // (the row remainders of this batch: its registers are about to be reloaded)
         // surfaces whose edge walk must be replayed literally: wave-cooperative slow path
         unsigned long long sm = __ballot(slow);
         while (sm) {

@@ -46,6 +46,7 @@ int main(void){
  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(B32Vertex), sizeof(B32Face), sizeof(B32Texture15), sizeof(B32IndexedTexture),
    sizeof(B32Camera), sizeof(B32Light), sizeof(B32Settings), sizeof(B32Fog), sizeof(B32Timings));
  printf("%zu %zu %zu %zu\n", offsetof(B32Settings, ambient), offsetof(B32Settings, lights), offsetof(B32Timings, fragments), offsetof(B32Vertex, r));
+ printf("%zu %zu %zu\n", sizeof(B32MeshParams), offsetof(B32MeshParams, has_fog), offsetof(B32MeshParams, fog));
  return 0; }'''
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "t.c"), "w").write(prog)
@@ -54,8 +55,9 @@ int main(void){
     sizes = [int(x) for x in out]
     assert sizes[:9] == [abi.VERTEX_DTYPE.itemsize, abi.FACE_DTYPE.itemsize, C.sizeof(abi.B32Texture15), C.sizeof(abi.B32IndexedTexture),
                          C.sizeof(abi.B32Camera), C.sizeof(abi.B32Light), C.sizeof(abi.B32Settings), C.sizeof(abi.B32Fog), C.sizeof(abi.B32Timings)]
-    assert sizes[9:] == [abi.B32Settings.ambient.offset, abi.B32Settings.lights.offset, abi.B32Timings.fragments.offset,
-                         abi.VERTEX_DTYPE.fields["r"][1]]
+    assert sizes[9:13] == [abi.B32Settings.ambient.offset, abi.B32Settings.lights.offset, abi.B32Timings.fragments.offset,
+                           abi.VERTEX_DTYPE.fields["r"][1]]
+    assert sizes[13:] == [C.sizeof(abi.B32MeshParams), abi.B32MeshParams.has_fog.offset, abi.B32MeshParams.fog.offset]
 
 
 def test_no_cpu_fallback(lib):
