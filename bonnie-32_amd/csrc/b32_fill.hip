@@ -669,6 +669,52 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
         // their own, whose lanes are all busy.  The remainders refer to lanes of THIS batch (parameters come over ds_bpermute again), so
         // the queue is drained before the next batch is loaded.
         uint32_t lq = 0, lqn = 0;                       // leftover queue and its length (wave-uniform)
+        // One trip of the sort-free EXACT coverage: four pixels -- the four texel addresses, their bits of the skip mask (LDS when the
+        // pool's mask fits, else global: 1/16 of the texels' bytes; no texel is fetched during coverage) -- then the (non-returning)
+        // atomics of the drawn fragments.  Returns the number of fragments drawn (the reference's pixel stores).
+        auto exact_trip = [&](const Tri& tr, uint32_t& addr, float& w0, float& w1, float sa0, float sa1, float sinv, uint32_t left, unsigned long long P) -> uint32_t {
+            unsigned long long* top = reinterpret_cast<unsigned long long*>(tilebuf);
+            const uint32_t* mask_l = reinterpret_cast<const uint32_t*>(ltex);           // LDS copy of the mask (k_cover stages it)
+            const bool mask_in_lds = a.mask_lds_words != 0;
+            uint32_t drawn = 0;
+            float wa[4], wb[4];
+            wa[0] = w0; wb[0] = w1;
+#pragma unroll
+            for (int j = 1; j < 4; ++j) { wa[j] = wa[j - 1] + sa0; wb[j] = wb[j - 1] + sa1; }
+            bool in[4]; int ta[4]; unsigned long long Pj[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float cx = wa[j] * sinv, cy = wb[j] * sinv;
+                const float cz = 1.0f - cx - cy;
+                in[j] = ((uint32_t)j < left) & (__builtin_fminf(__builtin_fminf(cx, cy), cz) >= ERR);        // (see the CHEAP trip)
+                Pj[j] = P; ta[j] = -1;
+                if (in[j]) {
+                    if (ZMODE) { uint32_t zkey; in[j] = frag_zkey(tr, cx, cy, cz, zkey); Pj[j] = ((unsigned long long)(~zkey) << 32) | (uint32_t)P; }
+                    ta[j] = tri_texel_addr(tr, cx, cy, cz, affine);
+                }
+            }
+            uint32_t mw[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                mw[j] = 0;
+                if (in[j] && ta[j] >= 0) mw[j] = mask_in_lds ? mask_l[(uint32_t)ta[j] >> 5] : a.texmask[(uint32_t)ta[j] >> 5];
+            }
+            bool any = false;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // skippable texel: the mask bit; a zero-size texture samples TRANSPARENT (-2), no texture samples WHITE (-1)
+                const bool blk = ta[j] == -2 ? true : (ta[j] >= 0 && ((mw[j] >> ((uint32_t)ta[j] & 31u)) & 1u));
+                in[j] = in[j] && !(FMT8 ? blk : (blk && (tr.flags & F_BLACK_TR)));       // render.rs:1591-1608 / 8-bit :1348-1352
+                any |= in[j];
+                drawn += in[j] ? 1u : 0u;
+            }
+            if (any) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) atomicMax(&top[addr + j], in[j] ? Pj[j] : 0ull);
+            }
+            addr += 4; w0 = wa[3] + sa0; w1 = wb[3] + sa1;
+            return drawn;
+        };
         auto drain = [&]() {
             const bool valid = lane < lqn;
             const uint32_t s = valid ? (lq & 63u) : lane;
@@ -689,6 +735,20 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
             // at most B32_DRAIN_TRIPS trips per entry and round; what is left of a long row goes back into the queue (a round used to last
             // as long as its longest remainder: with the ~25-px rows of C5 most lanes idled behind the longest)
             constexpr uint32_t DT = (uint32_t)B32_DRAIN_TRIPS * (uint32_t)B32_TRIP;
+            if (EXACT) {
+                Tri tr;
+                tr.u1 = bpermf(s, __uint_as_float(b.q2.y)); tr.u2 = bpermf(s, __uint_as_float(b.q2.z)); tr.u3 = bpermf(s, __uint_as_float(b.q2.w));
+                tr.v1 = bpermf(s, __uint_as_float(b.q3.x)); tr.v2 = bpermf(s, __uint_as_float(b.q3.y)); tr.v3 = bpermf(s, __uint_as_float(b.q3.z));
+                tr.flags = bperm(s, flags);
+                tr.tw = bperm(s, b.tw); tr.th = bperm(s, b.th); tr.toff = bperm(s, b.toff);
+                tr.iz1 = z1; tr.iz2 = z2; tr.iz3 = z3;
+                if (!affine && !ZMODE) { tr.iz1 = bpermf(s, __uint_as_float(b.q5.y)); tr.iz2 = bpermf(s, __uint_as_float(b.q5.z)); tr.iz3 = bpermf(s, __uint_as_float(b.q5.w)); }
+                uint32_t mine = 0;
+#pragma unroll
+                for (uint32_t i = 0; i < DT; i += 4) mine += exact_trip(tr, addr, w0, w1, sa0, sa1, sinv, i < n ? n - i : 0u, P);
+                for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
+                frags += (uint32_t)__builtin_amdgcn_readfirstlane((int)mine);
+            } else
 #pragma unroll
             for (uint32_t i = 0; i < DT; i += B32_TRIP)
                 cheap_trip<ZMODE>(top, sec, addr, w0, w1, sa0, sa1, sinv, i < n ? n - i : 0u, P, z1, z2, z3);
@@ -750,50 +810,23 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
                 // winner is a drawn fragment, so no runner-up is kept)
                 const unsigned long long P = P64 ? (((unsigned long long)bperm(s, my_key) << 32) | bperm(s, my_sid)) : 0ull;
                 if (P64 && EXACT && TEXMODE == 0) {
-                    // four pixels per trip: the four texel addresses, their bits of the skip mask (LDS when the pool's mask fits, else
-                    // global: 1/16 of the texels' bytes) -- no texel is fetched during coverage -- then the (non-returning) atomics of the
-                    // drawn fragments
-                    unsigned long long* top = reinterpret_cast<unsigned long long*>(tilebuf);
-                    const uint32_t* mask_l = reinterpret_cast<const uint32_t*>(ltex);           // LDS copy of the mask (k_cover stages it)
-                    const bool mask_in_lds = a.mask_lds_words != 0;
-                    for (uint32_t i = 0; __ballot(i < n); i += 4) {
-                        float wa[4], wb[4];
-                        wa[0] = w0; wb[0] = w1;
-#pragma unroll
-                        for (int j = 1; j < 4; ++j) { wa[j] = wa[j - 1] + sa0; wb[j] = wb[j - 1] + sa1; }
-                        bool in[4]; int ta[4]; unsigned long long Pj[4];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float cx = wa[j] * sinv, cy = wb[j] * sinv;
-                            const float cz = 1.0f - cx - cy;
-                            in[j] = (i + j < n) & (__builtin_fminf(__builtin_fminf(cx, cy), cz) >= ERR);        // (see the CHEAP trip below)
-                            Pj[j] = P; ta[j] = -1;
-                            if (in[j]) {
-                                if (ZMODE) { uint32_t zkey; in[j] = frag_zkey(tr, cx, cy, cz, zkey); Pj[j] = ((unsigned long long)(~zkey) << 32) | (uint32_t)P; }
-                                ta[j] = tri_texel_addr(tr, cx, cy, cz, affine);
-                            }
-                        }
-                        uint32_t mw[4];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            mw[j] = 0;
-                            if (in[j] && ta[j] >= 0) mw[j] = mask_in_lds ? mask_l[(uint32_t)ta[j] >> 5] : a.texmask[(uint32_t)ta[j] >> 5];
-                        }
-                        bool any = false;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            // skippable texel: the mask bit; a zero-size texture samples TRANSPARENT (-2), no texture samples WHITE (-1)
-                            const bool blk = ta[j] == -2 ? true : (ta[j] >= 0 && ((mw[j] >> ((uint32_t)ta[j] & 31u)) & 1u));
-                            in[j] = in[j] && !(FMT8 ? blk : (blk && (tr.flags & F_BLACK_TR)));       // render.rs:1591-1608 / 8-bit :1348-1352
-                            any |= in[j];
-                            mine += in[j] ? 1u : 0u;
-                        }
-                        if (any) {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) atomicMax(&top[addr + j], in[j] ? Pj[j] : 0ull);
-                        }
-                        addr += 4; w0 = wa[3] + sa0; w1 = wb[3] + sa1;
+#if B32_DRAIN_TRIPS > 0
+                    // one trip now; what is left of the row is queued like the CHEAP flavour's remainders (see `drain`)
+                    mine += exact_trip(tr, addr, w0, w1, sa0, sa1, sinv, n, P);
+                    const bool more = n > 4u;
+                    const unsigned long long mm = __ballot(more);
+                    if (mm) {
+                        const uint32_t cnt = (uint32_t)__builtin_popcountll(mm);
+                        while (lqn + cnt > 64u) drain();
+                        const uint32_t entry = s | (ry << 6) | ((rx0 + 4u) << 12) | ((n - 4u) << 19);
+                        const uint32_t dst = more ? lqn + (uint32_t)__builtin_popcountll(mm & ((1ull << lane) - 1ull)) : ((lqn + cnt) & 63u);
+                        const uint32_t got = (uint32_t)__builtin_amdgcn_ds_permute((int)(dst << 2), (int)(more ? entry : 0u));
+                        if (lane >= lqn && lane < lqn + cnt) lq = got;
+                        lqn += cnt;
                     }
+#else
+                    for (uint32_t i = 0; __ballot(i < n); i += 4) mine += exact_trip(tr, addr, w0, w1, sa0, sa1, sinv, i < n ? n - i : 0u, P);
+#endif
                 } else
                 for (uint32_t i = 0; __ballot(i < n); ++i) {
                     if (i < n) {
@@ -858,7 +891,7 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
                 frags += (uint32_t)__builtin_amdgcn_readfirstlane((int)mine);
             }
         }
-        if (P64 && !EXACT) while (lqn) drain();        // (the row remainders of this batch: its registers are about to be reloaded)
+        if (P64) while (lqn) drain();                  // (the row remainders of this batch: its registers are about to be reloaded)
         // surfaces whose edge walk must be replayed literally: wave-cooperative slow path
         unsigned long long sm = __ballot(slow);
         while (sm) {

@@ -133,8 +133,45 @@ def batch_case():
         print("   batch:", [(sc.name, sc.n_tris) for sc in meshes], W, H, "z", st.use_zbuffer, "xray", st.xray_mode, "wire", st.backface_wireframe, flush=True)
     return ok
 
+def pipeline_case():
+    """Two frames in flight: a frame with more tiles than workgroup slots (so that the setup kernel of frame i+1 goes to the side stream),
+    deep asynchronous mode, several cameras back to back without a clear in between (z-buffer: colour and depth accumulate; painter's:
+    later frames overwrite), random gate; against the oracle's sequential calls."""
+    W, H = [(2560, 1440), (1920, 1440), (2048, 2048)][rng.integers(3)]
+    sc = scenegen.make_scene("C3", n_tris=int(rng.choice([9000, 30000, 70000])), seed=int(rng.integers(1 << 30)),
+                             variant=str(rng.choice(["bench", "gouraud", "blend"])), width=W, height=H, bbox_px=float(rng.choice([60.0, 200.0, 700.0])))
+    st = sc.settings
+    st.use_zbuffer = bool(rng.integers(2)); st.backface_cull = bool(rng.integers(3) > 0)
+    cams = [b32.Camera(position=(float(rng.normal(0, 40)), float(rng.normal(0, 40)), float(rng.normal(0, 200)))) for _ in range(int(rng.integers(3, 7)))]
+    ofb = O.Framebuffer(W, H); ofb.clear(sc.clear_color)
+    for cam in cams:
+        assert O.render_mesh_15(ofb, sc.vertices, sc.faces, sc.textures, cam, st, None, fast=True)[0] == 0
+    c2 = R.Context(0)
+    try:
+        c2.set_async_depth(1); c2.set_pipeline_gate(int(rng.choice([0, 1, 300, 900, 1000])))
+        c2.set_fragment_counting(int(rng.integers(2)))
+        fb = R.Framebuffer(W, H, c2); fb.clear(sc.clear_color)
+        rs = R.ResidentScene(fb, sc.vertices, sc.faces, sc.textures)
+        rs.render_async(cams[0], st); rs.finish()               # (deep mode: list regions settled by a first synchronous frame)
+        for cam in cams[1:]:
+            rs.render_async(cam, st)
+        rs.finish()
+        ok = np.array_equal(fb.pixels, ofb.pixels) and (not st.use_zbuffer or np.array_equal(fb.zbuffer.view(np.uint32), ofb.zbuffer.view(np.uint32)))
+        ok = ok and c2.route_counts()["pipelined"] >= 1
+    finally:
+        c2.close()
+    if not ok:
+        print("   pipeline:", sc.name, W, H, "z", st.use_zbuffer, len(cams), flush=True)
+    return ok
+
 while time.time() < t_end:
     n += 1
+    if rng.integers(25) == 0 and not os.environ.get("SOAK_FORCE"):
+        drawn += 1
+        if not pipeline_case():
+            fails += 1
+            print(f"FAIL #{n} two frames in flight", flush=True)
+        continue
     if rng.integers(10) == 0 and not os.environ.get("SOAK_FORCE"):
         drawn += 1
         if not batch_case():
