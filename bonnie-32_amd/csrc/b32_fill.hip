@@ -1697,6 +1697,28 @@ __global__ __launch_bounds__(NT, 4) void k_blend(FillArgs a) {        // 4 waves
     const uint32_t e1 = a.tile_keys_only ? a.tile_mid[tile] : a.ranges[2 * tile + (a.ordered_all ? 0 : 1)];
     const uint32_t e2 = (a.inline_bin || a.direct_bin) ? (tile + 1) * a.list_stride : (a.tile_keys_only ? a.ranges[tile + 1] : a.ranges[2 * tile + 2]);
     if (e1 == e2) return;
+    const int zmode = (fp.zmode && !xray) ? 1 : 0;               // x-ray skips the depth test (render.rs:1553)
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const int shading = fp.shading;
+    const bool affine = fp.affine != 0;
+    const uint32_t txi = tile % fp.tiles_x;
+    const uint32_t x_lo = txi * TILE_W, x_hi = min(x_lo + TILE_W, fp.width);
+    uint32_t TH, ty_top;                            // 64, or 32 / 16 rows when the sort-free path runs on cut tiles (LDS layout unchanged)
+    tile_row_geom(fp, tile / fp.tiles_x, ty_top, TH);
+    const uint32_t y_lo = max(ty_top, fp.band_y0), y_hi = min(ty_top + TH, fp.band_y1);
+    // the tile's pixels (and depths) are REQUESTED before the sort prelude below and stored to LDS behind it: their latency passes behind
+    // the prelude's own chain of dependent global accesses (list -> keys -> sorted list)
+    constexpr int TILE_ITERS = TILE_W * TILE_H / NT;
+    uint32_t tpx[TILE_ITERS]; float tpz[TILE_ITERS];
+#pragma unroll
+    for (int it = 0; it < TILE_ITERS; ++it) {
+        const uint32_t p = tid + (uint32_t)it * NT, row = p >> 6, col = p & 63;
+        const uint32_t px = x_lo + col, py = ty_top + row;
+        const bool inb = row < TH && px < x_hi && py >= y_lo && py < y_hi;
+        tpx[it] = inb ? a.fb[(size_t)py * fp.width + px] : 0u;
+        tpz[it] = (zmode && inb) ? a.zbuf[(size_t)py * fp.width + px] : 0.0f;
+    }
     if (GATHER) {
         // sort-free binning left the transparent entries [e1, e2) in arbitrary order: put them in painter's order (descending depth,
         // ties in face order, render.rs:2527-2532) by ranking the 64-bit priorities (key << 32 | face id) -- all distinct -- in LDS
@@ -1712,22 +1734,10 @@ __global__ __launch_bounds__(NT, 4) void k_blend(FillArgs a) {        // 4 waves
         }
         __syncthreads();
     }
-    const int zmode = (fp.zmode && !xray) ? 1 : 0;               // x-ray skips the depth test (render.rs:1553)
-    const uint32_t tid = threadIdx.x, lane = tid & 63;
-    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
-    const int shading = fp.shading;
-    const bool affine = fp.affine != 0;
-    const uint32_t txi = tile % fp.tiles_x;
-    const uint32_t x_lo = txi * TILE_W, x_hi = min(x_lo + TILE_W, fp.width);
-    uint32_t TH, ty_top;                            // 64, or 32 / 16 rows when the sort-free path runs on cut tiles (LDS layout unchanged)
-    tile_row_geom(fp, tile / fp.tiles_x, ty_top, TH);
-    const uint32_t y_lo = max(ty_top, fp.band_y0), y_hi = min(ty_top + TH, fp.band_y1);
-    for (uint32_t p = tid; p < TILE_W * TH; p += NT) {
-        const uint32_t row = p >> 6, col = p & 63;
-        const uint32_t px = x_lo + col, py = ty_top + row;
-        const bool inb = px < x_hi && py >= y_lo && py < y_hi;
-        tilebuf[row * TILE_STRIDE + col] = inb ? a.fb[(size_t)py * fp.width + px] : 0u;
-        if (zmode) tilez[row * TILE_STRIDE + col] = inb ? a.zbuf[(size_t)py * fp.width + px] : 0.0f;
+#pragma unroll
+    for (int it = 0; it < TILE_ITERS; ++it) {
+        const uint32_t p = tid + (uint32_t)it * NT, row = p >> 6, col = p & 63;
+        if (row < TH) { tilebuf[row * TILE_STRIDE + col] = tpx[it]; if (zmode) tilez[row * TILE_STRIDE + col] = tpz[it]; }
     }
     __syncthreads();
     unsigned long long frag_count = 0;
