@@ -12,6 +12,9 @@
 #include <vector>
 
 using namespace b32;
+#ifndef B32_PIPELINE_BANDS
+#define B32_PIPELINE_BANDS 0      // experiment switch: two frames in flight for band-sharded frames too (measured: N=8 band 0.067 -> 0.071 ms: no)
+#endif
 #ifndef B32_MIN_TILE_H
 #define B32_MIN_TILE_H 8
 #endif
@@ -1183,7 +1186,7 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     // ... and a frame whose fused kernel has no more tiles than workgroup slots has no tail to fill: the cross-stream waits (~10 us
     // between two kernels) then cost more than the overlap returns (C2, 100 k triangles at 320x240: 0.052 against 0.048 ms).  The merged
     // runs of a batched frame are the exception: their kernels leave most of the GPU idle anyway (75 tiles for 256 CUs).
-    if (c->pipelined && !(r.direct_bin && (ntiles > 2u * (uint32_t)c->n_cu || c->frame_batched))) c->pipelined = false;
+    if (c->pipelined && !(r.direct_bin && (ntiles > 2u * (uint32_t)c->n_cu || c->frame_batched || (c->band_set && B32_PIPELINE_BANDS)))) c->pipelined = false;
     c->last_local_sort = r.local_sort || r.want_prio64;                         // the global draw order is not materialised
     c->last_exact = r.ordered_all ? true : (r.exact_cov && !fp.zmode);          // the ordered walk counts every store it performs
     c->last_direct = r.direct_bin;
@@ -1840,6 +1843,11 @@ extern "C" int b32_set_profiling(b32_ctx* c, int level) {
     if (!c) return B32_E_ARG;
     c->profile_level = level < 0 ? 0 : (level > 2 ? 2 : level);
     c->prof_seq = 0;
+    if (c->profile_level >= 1 && !c->ev_created) {      // (here, not in the first profiled frame: 384 hipEventCreate calls are ~0.2 ms of host time)
+        (void)hipSetDevice(c->device);
+        for (auto& fr : c->ev) for (auto& e : fr) HIPCHK(c, hipEventCreate(&e));
+        c->ev_created = true;
+    }
     return B32_OK;
 }
 extern "C" int b32_set_routes(b32_ctx* c, uint32_t off_mask) {

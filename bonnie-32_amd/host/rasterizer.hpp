@@ -19,6 +19,7 @@
 #include <stdexcept>
 #include <string>
 #include <tuple>
+#include <utility>
 #include <vector>
 
 #include "b32raster.h"
@@ -205,6 +206,51 @@ inline RasterTimings render_mesh(Framebuffer& fb, const std::vector<Vertex>& ver
     const B32Settings s = detail::pack(settings, l);
     B32Timings tm{};
     check(b32_render_mesh(fb.ctx(), v.data(), (uint32_t)v.size(), f.data(), (uint32_t)f.size(), t.data(), (uint32_t)t.size(), &c, &s, &tm), "render_mesh");
+    return { tm.transform_ms, tm.fog_ms, tm.cull_ms, tm.sort_ms, tm.draw_ms, tm.wireframe_ms, tm.triangles_drawn, tm.fragments };
+}
+
+// A mesh kept resident in HBM: uploaded once into a scene slot of the framebuffer's context, drawn many times.
+class ResidentMesh {
+public:
+    ResidentMesh(Framebuffer& fb, const std::vector<Vertex>& vertices, const std::vector<Face>& faces, const std::vector<Texture15>& textures) : ctx_(fb.ctx()) {
+        std::vector<B32Vertex> v; v.reserve(vertices.size());
+        for (const auto& x : vertices) v.push_back(detail::pack(x));
+        std::vector<B32Face> f; f.reserve(faces.size());
+        for (const auto& x : faces) f.push_back(detail::pack(x));
+        std::vector<B32Texture15> t; t.reserve(textures.size());
+        for (const auto& x : textures)
+            t.push_back({ (uint32_t)x.width, (uint32_t)x.height, (uint32_t)x.blend_mode, 0, x.pixels.size() >= x.width * x.height ? x.pixels.data() : nullptr });
+        check(b32_scene_upload(ctx_, v.data(), (uint32_t)v.size(), f.data(), (uint32_t)f.size(), t.data(), (uint32_t)t.size()), "scene_upload");
+        check(b32_scene_create(ctx_, &slot_), "scene_create");
+        check(b32_scene_swap(ctx_, slot_), "scene_swap");            // the slot now owns the mesh
+    }
+    ~ResidentMesh() { if (slot_) b32_scene_destroy(ctx_, slot_); }
+    ResidentMesh(const ResidentMesh&) = delete;
+    ResidentMesh& operator=(const ResidentMesh&) = delete;
+    b32_scene* slot() const { return slot_; }
+private:
+    b32_ctx* ctx_ = nullptr;
+    b32_scene* slot_ = nullptr;
+};
+
+// One frame of scene::render_scene (scene.rs:158-261): one camera, base settings and light list; per mesh the room's ambient and fog and
+// the part's backface culling.  The meshes are drawn as merged runs where their draws commute (b32_frame_begin / _add_scene / _end).
+struct MeshParams { float ambient; bool backface_cull, backface_wireframe; Fog fog; };
+inline RasterTimings render_frame(Framebuffer& fb, const std::vector<std::pair<const ResidentMesh*, MeshParams>>& meshes, const Camera& camera,
+                                  const RasterSettings& base) {
+    const std::vector<B32Light> l = detail::pack(base.lights);
+    const B32Camera c = detail::pack(camera);
+    const B32Settings s = detail::pack(base, l);
+    check(b32_frame_begin(fb.ctx(), &c, &s), "frame_begin");
+    for (const auto& m : meshes) {
+        B32MeshParams p{};
+        p.ambient = m.second.ambient; p.backface_cull = m.second.backface_cull; p.backface_wireframe = m.second.backface_wireframe;
+        p.has_fog = detail::pack(m.second.fog, p.fog) ? 1 : 0;
+        check(b32_frame_add_scene(fb.ctx(), m.first->slot(), &p), "frame_add_scene");
+    }
+    check(b32_frame_end(fb.ctx()), "frame_end");
+    B32Timings tm{};
+    check(b32_frame_finish(fb.ctx(), &tm), "frame_finish");
     return { tm.transform_ms, tm.fog_ms, tm.cull_ms, tm.sort_ms, tm.draw_ms, tm.wireframe_ms, tm.triangles_drawn, tm.fragments };
 }
 

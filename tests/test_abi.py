@@ -89,7 +89,8 @@ def test_cpp_host_mirror_compiles():
     hpp = os.path.join(ROOT, "bonnie-32_amd", "host", "rasterizer.hpp")
     if not os.path.exists(hpp):
         pytest.skip("host mirror not present")
-    src = '#include "rasterizer.hpp"\nint main(){ b32::RasterSettings s = b32::RasterSettings::game(); return s.use_zbuffer ? 0 : 1; }\n'
+    src = ('#include "rasterizer.hpp"\nint main(){ b32::RasterSettings s = b32::RasterSettings::game(); '
+           'std::vector<std::pair<const b32::ResidentMesh*, b32::MeshParams>> m; (void)&b32::render_frame; return s.use_zbuffer && m.empty() ? 0 : 1; }\n')
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "t.cpp"), "w").write(src)
         subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I", os.path.dirname(hpp), "-I", os.path.join(ROOT, "include"),

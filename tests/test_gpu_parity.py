@@ -1230,6 +1230,40 @@ def test_cpp_host_mirror_renders_scene_files(tmp_path):
     assert np.array_equal(got, np.load(os.path.join(GOLD, "cube_frame.npz"))["rgba"]) and "triangles_drawn 10" in r.stdout
 
 
+def test_cpp_host_mirror_batched_frame(tmp_path, oracle):
+    """b32::ResidentMesh + b32::render_frame of the C++ mirror (b32_frame_begin / _add_scene / _end behind them): six meshes from
+    .b32scene files -- per-mesh ambient, backface culling and fog travel in the files -- drawn as one frame on the GPU; framebuffer and
+    depth buffer must equal the oracle's sequential render_mesh_15 calls, and the frame must really have been drawn as merged runs."""
+    import subprocess
+    from bonnie32_amd import scenefile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "frame_harness"
+    lib_dir = os.path.join(root, "bonnie-32_amd", "csrc")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(root, "bonnie-32_amd", "host"), "-I", os.path.join(root, "include"),
+                    os.path.join(root, "tests", "cpp", "frame_harness.cpp"), "-o", str(exe), "-L", lib_dir, "-lb32raster",
+                    f"-Wl,-rpath,{lib_dir}"], check=True)
+    meshes = _console_meshes(6, 9100, blend_every=3)
+    base = b32.RasterSettings.game()
+    base.lights = [b32.Light.directional((-1.0, -1.0, -1.0), 0.7), b32.Light.point((0.0, -100.0, 1500.0), 3000.0, 1.2)]
+    cam = b32.Camera(position=(5.0, -8.0, -30.0))
+    fogs = [None, (1500.0, 3000.0, 5800.0, b32.Color(40, 50, 70))]
+    W, H = meshes[0].width, meshes[0].height
+    ofb = oracle.Framebuffer(W, H); ofb.clear(meshes[0].clear_color)
+    paths = []
+    for i, sc in enumerate(meshes):
+        st = copy.copy(base); st.ambient = 0.15 + 0.1 * i; st.backface_cull = (i != 1)
+        sc.settings = st; sc.camera = cam; sc.fog = fogs[i % 2]
+        assert oracle.render_mesh_15(ofb, sc.vertices, sc.faces, sc.textures, cam, st, sc.fog)[0] == 0
+        paths.append(str(tmp_path / f"m{i}.b32scene"))
+        scenefile.write_scene(paths[-1], sc)
+    r = subprocess.run([str(exe), str(tmp_path / "out.rgba"), str(tmp_path / "out.z")] + paths, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = np.frombuffer((tmp_path / "out.rgba").read_bytes(), np.uint8)
+    gz = np.frombuffer((tmp_path / "out.z").read_bytes(), np.uint32)
+    assert np.array_equal(got, ofb.pixels) and np.array_equal(gz, ofb.zbuffer.view(np.uint32))
+    assert "merged_draws 2" in r.stdout, r.stdout
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_hostile_geometry_every_path(gpu_ctx, oracle, seed):
     """Adversarial inputs through every scheduling path (sort-free fused painter's / z-buffer, transparent pass, instrumented,

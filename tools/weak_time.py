@@ -15,8 +15,10 @@ for N in (1, 2, 4, 8):
     for r in sorted({0, N // 2, N - 1}):
         y0, y1 = parallel.band_rows(sc.height, N, r)
         fb.set_band(y0, y1)
-        for _ in range(3):          # (the packed vertex streams are built on a resident mesh's second frame: warm-up, not timing)
-            fb.clear(sc.clear_color); rs.render(sc.camera, sc.settings)
+        fb.clear(sc.clear_color); rs.render(sc.camera, sc.settings)
+        for _ in range(20):         # (packed vertex streams, second frame set: built on the first frames in flight -- warm-up, not timing)
+            fb.clear(sc.clear_color); rs.render_async()
+        rs.finish()
         n = 100; ctx.synchronize(); t0 = time.perf_counter()
         for i in range(n):
             fb.clear(sc.clear_color); rs.render_async()
