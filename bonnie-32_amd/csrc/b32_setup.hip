@@ -677,6 +677,7 @@ __global__ void k_selftest(int op, const float* a, const float* b, const float* 
         case 0: r = a[i] * b[i] + c[i]; break;          // must round twice (no FMA contraction)
         case 1: r = a[i] / b[i]; break;                 // correctly rounded
         case 2: r = __builtin_sqrtf(a[i]); break;       // correctly rounded
+        case 4: r = acosf_musl(a[i]); break;            // f32::acos of the reference's wasm32 target (spot lights)
         default: r = (a[i] + b[i]) / c[i]; break;
     }
     out[i] = r;

@@ -350,7 +350,7 @@ int b32_project_fixed_batch(b32_ctx* ctx, const float* pos_xyz, uint32_t n,
 int b32_last_draw_order(b32_ctx* ctx, uint32_t* face_idx, uint32_t cap, uint32_t* n);
 /* IEEE-754 f32 self-test of the device arithmetic the pipeline relies on (no FMA contraction,
  * correctly rounded / and sqrt, denormals kept): evaluates op(a[i], b[i], c[i]) on the GPU.
- * op: 0 a*b+c (two roundings), 1 a/b, 2 sqrt(a), 3 (a+b)/c. */
+ * op: 0 a*b+c (two roundings), 1 a/b, 2 sqrt(a), 3 (a+b)/c, 4 acos(a) as the lighting code computes it (render.rs:1049). */
 int b32_selftest_f32(b32_ctx* ctx, int op, const float* a, const float* b, const float* c,
                      float* out, uint32_t n);
 
