@@ -4,10 +4,16 @@
  * TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * load this.  The product library (bonnie-32_amd/csrc) never links, calls or falls back to it.
  *
- * PARITY STATUS: "parity unpinned" at the pixel level by the reference itself — the reference holds no
- * test that pins a rendered pixel and it is Rust, which cannot be built in this image.
- * What pins this file instead: (1) the reference's own unit-test vectors for fixed.rs/math.rs
- * (tests/test_oracle_kats.py), (2) the psx-spx UNR table and dither matrix the reference's comments name,
+ * PARITY STATUS: pinned by the reference's own compiled code for everything the 8-bit-colour and the RGB555 path share, "parity
+ * unpinned" by the reference for the rest.  The reference is Rust (no toolchain here) and holds no test that pins a pixel (SURVEY §4,
+ * §8c); but its tree carries docs/bonnie-engine.wasm, an older build of the crate, which node runs: tests/golden/wasm_pin/ holds 14
+ * frames drawn by THAT module's render_mesh and 9 523 values of its acosf, and b32o_render_mesh / b32o_acosf reproduce every one of
+ * them bit for bit (tests/test_wasm_pin.py; README.md there lists what the old build and today's source define identically: camera
+ * transform, float / ortho projection, culling, bounding boxes, triangle setup, edge walk, inside test, affine UVs, Texture::sample,
+ * vertex colours, modulation, lighting incl. spot lights, blended stores, wireframe overlay -- the code render_mesh_15 shares).
+ * NOT reachable through that module, hence still unpinned by the reference: the fixed-point snap (fixed.rs), the RGB555 tail
+ * (Color15, dither_and_quantize, blend_rgb555), 1/z depth, fog, equal sort keys.  What pins those: (1) the reference's own unit-test
+ * vectors for fixed.rs/math.rs (tests/test_oracle_kats.py), (2) the psx-spx UNR table and dither matrix the reference's comments name,
  * (3) an independent numpy restatement (oracle/np_model.py) that must agree bit-for-bit on whole frames.
  *
  * Every function cites the reference file:line it follows (paths relative to /root/reference).

@@ -1,7 +1,8 @@
 """np_model.py — second, independent restatement of bonnie-32's `render_mesh_15` in numpy float32 / int64.
 
-TEST INFRASTRUCTURE.  Purpose: the reference is Rust and cannot run here, and it holds no test that pins a pixel
-("parity unpinned").  This file is a second reading of the same Rust text, written in a different style
+TEST INFRASTRUCTURE.  Purpose: the reference is Rust and cannot be built here, and it holds no test that pins a pixel; only an older
+compiled build (docs/bonnie-engine.wasm) runs, which pins what the 8-bit and the RGB555 path share (tests/golden/wasm_pin/, this file
+reproduces those frames too) and leaves the fixed-point snap and the RGB555 tail "parity unpinned" (SURVEY §8c).  This file is a second reading of the same Rust text, written in a different style
 from oracle/b32_oracle.c (whole-bbox vectorised per triangle, `np.add.accumulate` for the incremental edge walk,
 vectorised UNR division on int64 arrays, `argsort(kind="stable")` for the painter's order).  tests/ require the two
 restatements to agree bit-for-bit on whole frames; a misreading would have to be made identically in both to survive.

@@ -36,7 +36,7 @@ class PinScene:
 
 
 def make(name, seed, n_tris, width, height, *, bbox=40.0, shading=abi.SHADE_NONE, lights=(), ambient=0.3, cull=True, ntex=2, tex_size=32,
-         untextured_every=0, oob_every=0, blends=True, cam_pos=(0.0, 0.0, 0.0), clear=(20, 22, 28), rot=None, ortho=None, wire_front=False, near_faces=True):
+         untextured_every=0, oob_every=0, blends=True, cam_pos=(0.0, 0.0, 0.0), clear=(20, 22, 28), rot=None, ortho=None, wire_front=False, near_faces=True, edge=False, tex_shapes=None):
     """Random triangles in front of an identity camera.  Two things differ between the old build and today's source in painter's mode,
     and the depths are drawn so that neither can show: (1) the old build sorts by the LARGEST camera-space z of a face, today's source by
     the mean of z + 5 (render.rs:2155-2160 with math.rs:133); (2) the old build's stores still test and write the z-buffer after the sort
@@ -55,6 +55,13 @@ def make(name, seed, n_tris, width, height, *, bbox=40.0, shading=abi.SHADE_NONE
     cy = (rng.uniform(-0.1, 1.1, n_tris) * height - height / 2) / vs * (cz + 5) / 4
     r = bbox / vs * (cz + 5) / 4 / 2
     off = rng.uniform(-1, 1, (n_tris, 3, 3))
+    if edge:                                               # hostile geometry: what the saturating casts, the area reject and the walk must survive
+        kind = rng.random(n_tris)
+        off[kind < 0.05] *= 400.0                          # screen coordinates far outside the frame (bounding box clamps, `as usize` of negatives)
+        needle = (kind >= 0.05) & (kind < 0.09)
+        off[needle, 1] = off[needle, 0] + rng.uniform(-1e-3, 1e-3, (needle.sum(), 3))
+        flat = (kind >= 0.09) & (kind < 0.11)
+        off[flat, 2] = off[flat, 1] = off[flat, 0]          # zero area
     pos = np.stack([cx, cy, cz], 1)[:, None, :] + off * r[:, None, None]
     pos[..., 2] = cz[:, None] + offs
     near = (rng.random(n_tris) < 0.02) & near_faces                       # a few faces through the near plane (cam z <= 0.1 rejects, render.rs:2053)
@@ -72,6 +79,15 @@ def make(name, seed, n_tris, width, height, *, bbox=40.0, shading=abi.SHADE_NONE
         pos = pos @ basis                                   # world = sum_k cam_k * basis_k  (basis orthonormal up to f32 rounding)
     v["pos"] = pos.reshape(-1, 3).astype(np.float32) + np.float32(cam_pos)
     v["uv"] = rng.uniform(-1.0, 2.0, (3 * n_tris, 2)).astype(np.float32)
+    if edge:                                               # Texture::sample with NaN / infinite / huge / exactly integral coordinates
+        k2 = rng.random(3 * n_tris)
+        v["uv"][k2 < 0.01, 0] = np.nan
+        v["uv"][(k2 >= 0.01) & (k2 < 0.02), 1] = np.inf
+        v["uv"][(k2 >= 0.02) & (k2 < 0.03), 0] = -np.inf
+        big = (k2 >= 0.03) & (k2 < 0.06)
+        v["uv"][big] *= np.float32(3.0e8)
+        whole = (k2 >= 0.06) & (k2 < 0.10)
+        v["uv"][whole] = np.round(v["uv"][whole])
     nrm = rng.normal(size=(3 * n_tris, 3)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
     v["normal"] = nrm.astype(np.float32)
     v["r"], v["g"], v["b"] = (rng.integers(0, 256, 3 * n_tris, dtype=np.uint8) for _ in range(3))
@@ -85,10 +101,11 @@ def make(name, seed, n_tris, width, height, *, bbox=40.0, shading=abi.SHADE_NONE
     f["black_transparent"] = 0; f["blend_mode"] = 0; f["editor_alpha"] = 255
     texs = []
     for t in range(ntex):
-        px = rng.integers(0, 256, (tex_size * tex_size, 4), dtype=np.uint8)
+        tw, th = tex_shapes[t] if tex_shapes else (tex_size, tex_size)
+        px = rng.integers(0, 256, (tw * th, 4), dtype=np.uint8)
         # per-texel blend byte: texture 0 opaque with some Erase texels (skipped, Color::is_transparent), the others every mode
-        px[:, 3] = np.where(rng.random(tex_size * tex_size) < 0.1, T.ERASE, 0) if (t == 0 or not blends) else rng.integers(0, 6, tex_size * tex_size)
-        texs.append(T.Texture(tex_size, tex_size, px, T.OPAQUE, f"t{t}"))
+        px[:, 3] = np.where(rng.random(tw * th) < 0.1, T.ERASE, 0) if (t == 0 or not blends) else rng.integers(0, 6, tw * th)
+        texs.append(T.Texture(tw, th, px, T.OPAQUE, f"t{t}"))
     sc = PinScene()
     sc.name = name; sc.width, sc.height = width, height
     sc.vertices, sc.faces = v, f
@@ -112,7 +129,9 @@ def scenes():
     return [
         make("plain_64x48", 11, 60, 64, 48, bbox=24.0),
         make("plain_320x240", 12, 2000, 320, 240, bbox=40.0, untextured_every=7, oob_every=11),
-        make("two_sided_160x120", 13, 500, 160, 120, cull=False, bbox=50.0),
+        # (no scene with backface_cull = false: today's source swaps v2 / v3 of a rendered back face, render.rs:2085-2110, the old
+        # build keeps the order -- same pixels up to the rounding of the swapped sums, i.e. not bit for bit)
+        make("medium_160x120", 13, 500, 160, 120, bbox=50.0, ntex=3),
         make("flat_lights_320x240", 14, 1200, 320, 240, shading=abi.SHADE_FLAT, lights=[warm, blue, off], ambient=0.25, untextured_every=5),
         make("gouraud_lights_320x240", 15, 1200, 320, 240, shading=abi.SHADE_GOURAUD, lights=[warm, point], ambient=0.2),
         make("gouraud_spot_acos_320x240", 16, 1500, 320, 240, shading=abi.SHADE_GOURAUD, lights=[spot, point], ambient=0.1, bbox=60.0),
@@ -122,6 +141,9 @@ def scenes():
         # (today's source skips the near-plane test in ortho views, render.rs:2052; the old build does not: no face behind the plane)
         make("ortho_320x240", 20, 600, 320, 240, ortho=(2.5, 10.0, -4.0), bbox=50.0, near_faces=False),
         make("wire_overlay_160x120", 22, 60, 160, 120, wire_front=True, bbox=60.0),
+        make("hostile_320x240", 23, 2500, 320, 240, edge=True, ntex=4, tex_shapes=[(37, 19), (1, 1), (64, 8), (5, 128)], bbox=45.0, untextured_every=13),
+        make("small_tris_512x384", 24, 12000, 512, 384, bbox=7.0, ntex=3, tex_shapes=[(16, 16), (128, 128), (3, 7)]),
+        make("hostile_lit_256x192", 25, 1500, 256, 192, edge=True, shading=abi.SHADE_GOURAUD, lights=[warm, spot], ntex=2, tex_shapes=[(9, 9), (200, 3)]),
     ]
 
 

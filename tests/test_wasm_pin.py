@@ -32,7 +32,7 @@ def load(name):
 
 
 def test_every_fixture_is_listed():
-    assert sorted(os.path.basename(p)[:-9] for p in glob.glob(os.path.join(PIN, "*.b32scene"))) == NAMES and len(NAMES) >= 11
+    assert sorted(os.path.basename(p)[:-9] for p in glob.glob(os.path.join(PIN, "*.b32scene"))) == NAMES and len(NAMES) >= 14
 
 
 @pytest.mark.parametrize("name", NAMES)
@@ -47,7 +47,7 @@ def test_oracle_reproduces_the_reference_binarys_frame(oracle, name):
         assert np.array_equal(np.asarray(fb.pixels).reshape(sc.height, sc.width, 4), np.load(full))
 
 
-@pytest.mark.parametrize("name", ["plain_64x48", "wire_overlay_160x120", "two_sided_160x120"])
+@pytest.mark.parametrize("name", ["plain_64x48", "wire_overlay_160x120", "medium_160x120"])
 def test_numpy_restatement_reproduces_the_reference_binarys_frame(name):
     from oracle import np_model as M
     sc = load(name)
@@ -118,7 +118,7 @@ def test_gpu_reproduces_the_reference_binarys_frame(gpu_ctx, name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["plain_320x240", "gouraud_spot_acos_320x240", "rotated_camera_320x240"])
+@pytest.mark.parametrize("name", ["plain_320x240", "gouraud_spot_acos_320x240", "rotated_camera_320x240", "hostile_320x240"])
 def test_gpu_keyed_routes_reproduce_the_reference_binarys_frame(keyed_ctx, name):
     from bonnie32_amd import rasterizer as R
     sc = load(name)
