@@ -1662,31 +1662,48 @@ __device__ __forceinline__ bool blend_fragment(const FillArgs& a, const Tri& tr,
     return true;
 }
 
-// Fragment of the ordered pass, computed in phase 1 (order-free) and applied in phase 2 (in painter's order):
-//   RGB555 path: out15 | 1 << 16 when the fragment is drawn (inside, depth test against the read-only tile depth, texel rule)
-//   8-bit path : two words, colour r | g<<8 | b<<16 | blend<<24 | 1<<31 and the depth bits (its depth test needs the running depth)
-constexpr uint32_t FRAG_SLOTS = 4096;          // fragment buffer: 4096 words = 8192 fragments of 16 bits (RGB555, 16 KB of LDS), or 4096 fragments of two words (8-bit path, 32 KB)
-__host__ __device__ constexpr size_t blend_lds_bytes(bool fmt8, bool zmode) {
-    return (size_t)LDS_TILE_BYTES * (zmode ? 2 : 1) + (size_t)FRAG_SLOTS * (fmt8 ? 8 : 4) + 256 + 16 * 256 + 64 * 128;
+// The ordered pass, PIXEL-centric.  What must be ordered is, per pixel, the sequence of its own fragments -- nothing else: two surfaces
+// that do not share a pixel commute.  So a lane owns a pixel and walks, in painter's order, the surfaces of the batch whose clipped
+// bounding box holds it: the candidates of pixel (x, y) are `rowmask[y] & colmask[x]` -- one 64-bit word per tile row and per tile
+// column with a bit per surface of the batch (a box is an x-range times a y-range, so the AND is exact; 1 KB of LDS, built with
+// ballots).  A cheap loop finds the lane's next candidate that passes the reference's inside test (two LDS quads of the record, the
+// closed-form edge values or the literal replay), then the lanes that found one run the texel / colour pipeline and blend into the
+// pixel held in a register.  No fragment buffer, no chunks, no per-surface serial walk: the sequential depth of a wave's row is the
+// largest number of fragments any one of its 64 pixels receives, the blend chain never leaves the registers, and work is
+// proportional to fragments.  (Rounds 1-3 generated the fragments of a chunk into LDS slots and applied them surface after surface
+// per band of rows: every wave was busy for the SUM of the surfaces reaching its rows.)
+#ifndef B32_BLEND_NT
+#define B32_BLEND_NT 256
+#endif
+constexpr uint32_t BLEND_LIST_CAP = 8;    // fragments a lane notes per round (16 bits each: 1 KB of LDS per wave)
+constexpr uint32_t SREC_Q = 9;            // quads per staged record: 8 + 1 of padding (lanes read the records of DIFFERENT surfaces: a 128-byte stride puts them all on 8 banks)
+constexpr uint32_t BT_STRIDE = 64;        // the colour tile's row stride in words: a lane only ever touches column `lane`, whatever the row -- no padding needed
+constexpr size_t BLEND_TILE_BYTES = (size_t)TILE_H * BT_STRIDE * 4;
+constexpr int BLEND_NT = B32_BLEND_NT;        // 4-wave workgroups, four per CU (registers: 4 waves per SIMD): tiles in flight hide the list -> record -> texel latencies
+// (31 KB: five workgroups per CU, 1280 places for the 1200 tiles of a 2560x1920 frame -- with four, a second round of 176 workgroups
+// doubled the kernel's time; the depth tile only for the 8-bit path in z-buffer mode, whose depth test needs the running depth)
+__host__ __device__ constexpr size_t blend_lds_bytes(bool depth_tile) {
+    return 256 + 64 * SREC_Q * 16 + 1024 + (size_t)(BLEND_NT / 64) * BLEND_LIST_CAP * 64 * 2 + BLEND_TILE_BYTES * (depth_tile ? 2 : 1);
 }
 
 template <int NT, bool FMT8, bool GATHER = false>
-__global__ __launch_bounds__(NT, 4) void k_blend(FillArgs a) {        // 4 waves per SIMD = two workgroups per CU: at most 128 VGPRs
+__global__ __launch_bounds__(NT, 5) void k_blend(FillArgs a) {        // 5 waves per SIMD: at most 96 VGPRs
     constexpr int NW = NT / 64;
-    // fragment slots per chunk: the RGB555 path keeps a fragment in 16 bits (a drawn fragment's Color15 is never 0x0000: all-black sets
-    // bit 15, render.rs:1659-1661): 8192 in its 16 KB; the 8-bit path in two words: 4096 in 32 KB.  Either holds a whole 64x64 box.
-    constexpr uint32_t FCAP = FMT8 ? FRAG_SLOTS : FRAG_SLOTS * 2;
-    // dynamic LDS (blend_lds_bytes): [wf 256 B][row-scheduler marks 256 B per wave][frag][tile colours][tile depths, z-buffer mode only]
+    // dynamic LDS (blend_lds_bytes): [wf 256 B][the batch's 64 records 9 KB][row masks, column masks 1 KB][fragment lists 2 KB per wave]
+    // [tile colours][tile depths, z-buffer mode only]
     extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
     unsigned long long* wf = reinterpret_cast<unsigned long long*>(bsm);
-    uint4* srec = reinterpret_cast<uint4*>(bsm + 256 + 16 * 256);           // the chunk's 64 surface records: 8 x 16 B each (q0..q5, texture, id)
-    uint32_t* frag = reinterpret_cast<uint32_t*>(bsm + 256 + 16 * 256 + 64 * 128);
-    static_assert(NW <= 16, "row-scheduler marks");
-    static_assert(NT == 512, "the chunk loader maps 8 threads to each of the 64 surfaces");
-    uint16_t* frag16 = reinterpret_cast<uint16_t*>(frag);
-    uint32_t* tilebuf = frag + FRAG_SLOTS * (FMT8 ? 2 : 1);
-    float* tilez = reinterpret_cast<float*>(tilebuf + TILE_H * TILE_STRIDE);   // (the RGB555 transparent pass never writes it)
-    static_assert(!GATHER || BLEND_SORT_CAP * 2 <= FRAG_SLOTS, "the priority sort aliases the fragment buffer");
+    uint4* srec = reinterpret_cast<uint4*>(bsm + 256);                      // the batch's 64 surface records: 8 x 16 B each (q0..q5, texture, id)
+    unsigned long long* rowmask = reinterpret_cast<unsigned long long*>(bsm + 256 + 64 * SREC_Q * 16);
+    unsigned long long* colmask = rowmask + 64;
+    uint16_t* lists = reinterpret_cast<uint16_t*>(bsm + 256 + 64 * SREC_Q * 16 + 1024);        // per wave: BLEND_LIST_CAP x 64 entries
+    uint32_t* tilebuf = reinterpret_cast<uint32_t*>(bsm + 256 + 64 * SREC_Q * 16 + 1024 + NW * BLEND_LIST_CAP * 64 * 2);
+    float* tilez = reinterpret_cast<float*>(tilebuf + TILE_H * BT_STRIDE);   // 8-bit path in z-buffer mode only (the RGB555 transparent pass never writes depth:
+                                                                            // its test runs in loop (A) against the depth buffer itself)
+    constexpr bool DEPTH_TILE = FMT8;
+    static_assert(512 % NT == 0 && NT >= 64, "the batch loader deals 512 quads to the workgroup");
+    // the priority sort runs before the tile's pixels are stored to LDS: it uses the colour tile's space
+    static_assert(!GATHER || BLEND_SORT_CAP * 8 <= BLEND_TILE_BYTES, "the priority sort aliases the colour tile");
     static_assert(NW * 8 <= 256, "wf");
     if (a.ctrl->abort || a.ctrl->need_global_sort) return;
     const FrameParams& fp = a.fp;
@@ -1704,7 +1721,7 @@ __global__ __launch_bounds__(NT, 4) void k_blend(FillArgs a) {        // 4 waves
     const bool affine = fp.affine != 0;
     const uint32_t txi = tile % fp.tiles_x;
     const uint32_t x_lo = txi * TILE_W, x_hi = min(x_lo + TILE_W, fp.width);
-    uint32_t TH, ty_top;                            // 64, or 32 / 16 rows when the sort-free path runs on cut tiles (LDS layout unchanged)
+    uint32_t TH, ty_top;                            // 64, or fewer rows when the sort-free path runs on cut tiles (LDS layout unchanged)
     tile_row_geom(fp, tile / fp.tiles_x, ty_top, TH);
     const uint32_t y_lo = max(ty_top, fp.band_y0), y_hi = min(ty_top + TH, fp.band_y1);
     // the tile's pixels (and depths) are REQUESTED before the sort prelude below and stored to LDS behind it: their latency passes behind
@@ -1717,12 +1734,12 @@ __global__ __launch_bounds__(NT, 4) void k_blend(FillArgs a) {        // 4 waves
         const uint32_t px = x_lo + col, py = ty_top + row;
         const bool inb = row < TH && px < x_hi && py >= y_lo && py < y_hi;
         tpx[it] = inb ? a.fb[(size_t)py * fp.width + px] : 0u;
-        tpz[it] = (zmode && inb) ? a.zbuf[(size_t)py * fp.width + px] : 0.0f;
+        tpz[it] = (DEPTH_TILE && zmode && inb) ? a.zbuf[(size_t)py * fp.width + px] : 0.0f;
     }
     if (GATHER) {
         // sort-free binning left the transparent entries [e1, e2) in arbitrary order: put them in painter's order (descending depth,
         // ties in face order, render.rs:2527-2532) by ranking the 64-bit priorities (key << 32 | face id) -- all distinct -- in LDS
-        unsigned long long* gprio = reinterpret_cast<unsigned long long*>(frag);
+        unsigned long long* gprio = reinterpret_cast<unsigned long long*>(tilebuf);
         const uint32_t n = e2 - e1;                    // <= BLEND_SORT_CAP (k_place_spans raised need_global_sort otherwise)
         for (uint32_t i = threadIdx.x; i < n; i += NT) { const uint32_t sid = a.pair_vals[e1 + i]; gprio[i] = ((unsigned long long)a.keys[sid] << 32) | sid; }
         __syncthreads();
@@ -1737,24 +1754,19 @@ __global__ __launch_bounds__(NT, 4) void k_blend(FillArgs a) {        // 4 waves
 #pragma unroll
     for (int it = 0; it < TILE_ITERS; ++it) {
         const uint32_t p = tid + (uint32_t)it * NT, row = p >> 6, col = p & 63;
-        if (row < TH) { tilebuf[row * TILE_STRIDE + col] = tpx[it]; if (zmode) tilez[row * TILE_STRIDE + col] = tpz[it]; }
+        if (row < TH) { tilebuf[row * BT_STRIDE + col] = tpx[it]; if (DEPTH_TILE && zmode) tilez[row * BT_STRIDE + col] = tpz[it]; }
     }
     __syncthreads();
-    unsigned long long frag_count = 0;
+    uint32_t drawn = 0;                             // pixel stores of this lane (fragment counting)
+    uint16_t* mylist = lists + wave * (BLEND_LIST_CAP * 64);
     const TexDesc none = { 0, 0, 0, 0 };
     const uint32_t n_tr = e2 - e1;
-    const uint32_t RPW = (TH + NW - 1) / NW;        // tile rows owned by one wave in phase 2 (TH >= 16, NW = 8; any height up to 64)
-    const uint32_t wy0 = max(ty_top + wave * RPW, y_lo), wy1 = min(ty_top + wave * RPW + RPW, y_hi);
-    // The walk is split so that only what MUST be ordered is ordered.  A chunk = consecutive list entries whose clipped bounding
-    // boxes fit the fragment buffer.  Phase 1 (no order): the waves take the chunk's surfaces round-robin and evaluate every
-    // pixel of their bounding boxes -- inside test, texel, colour pipeline -- into fixed slots (16 texel-latency chains in flight
-    // per workgroup instead of one per row owner).  Phase 2 (painter's order): each wave owns a band of tile rows and applies the
-    // chunk's fragments to its rows surface after surface: LDS reads and the blend, no global memory.
     for (uint32_t cs = 0; cs < n_tr; cs += 64) {
         const uint32_t cnt = min(64u, n_tr - cs);
-        {   // stage the batch's records in LDS once per workgroup: 8 threads per surface; each assembles two quads of the surface's view
-            // (q0..q5, then the texture descriptor + face id, then a spare) from the compact records
-            const uint32_t sfc = tid >> 3, part = tid & 7;
+        // stage the batch's records in LDS once per workgroup: 512 quads, each assembled from the compact records (q0..q5 of the surface's
+        // view, then the texture descriptor + face id, then a spare)
+        for (uint32_t q = tid; q < 512u; q += NT) {
+            const uint32_t sfc = q >> 3, part = q & 7;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (sfc < cnt) {
                 const uint32_t sid = a.pair_vals[e1 + cs + sfc];
@@ -1778,238 +1790,141 @@ __global__ __launch_bounds__(NT, 4) void k_blend(FillArgs a) {        // 4 waves
                 else if (part == 6) {
                     const uint32_t txid = c1.w & F_TEX_MASK;
                     TexDesc d = none;
-                    if (txid != F_TEX_NONE) d = a.tex[txid];
+                    if (txid != F_TEX_NONE) { if (fp.nt == 1) d = a.tex0; else d = a.tex[txid]; }      // (one texture: no descriptor gather)
                     v = make_uint4(d.width, d.height, d.offset, sid);
                 }
             }
-            srec[sfc * 8 + part] = v;
+            srec[sfc * SREC_Q + part] = v;
         }
         __syncthreads();
-        // lane <-> surface view of the chunk (every wave computes the same prefix sums)
-        const uint4 mq1 = srec[lane * 8 + 1], mq2 = srec[lane * 8 + 2], mq3 = srec[lane * 8 + 3];
+        // lane <-> surface view of the batch: clipped bounding box in this tile (band rows only); editor_alpha == 0 draws nothing
+        // (render.rs:1664-1669)
+        const uint4 mq1 = srec[lane * SREC_Q + 1], mq2 = srec[lane * SREC_Q + 2], mq3 = srec[lane * SREC_Q + 3];
         const uint32_t my_flags = mq3.w;
-        // clipped bounding box of lane's surface in this tile (band rows only); editor_alpha == 0 draws nothing (render.rs:1664-1669)
         const uint32_t bx0 = max(mq1.w & 0xFFFF, x_lo), bx1 = min(mq1.w >> 16, x_hi);
         const uint32_t by0 = max(mq2.x & 0xFFFF, y_lo), by1 = min(mq2.x >> 16, y_hi);
         const bool live = lane < cnt && bx0 < bx1 && by0 < by1 && (my_flags >> F_ALPHA_SHIFT) != 0;
-        const uint32_t area_all = live ? (bx1 - bx0) * (by1 - by0) : 0u;
-        // The batch's 64 records are staged ONCE; its surfaces are then worked off in chunks of as many consecutive ones as fit the
-        // fragment buffer (a chunk used to restage 64 records to use the two or three that fit: ~20 chunks of a C3 tile, most waves idle
-        // in each).  `done` = surfaces of the batch already applied.
-        for (uint32_t done = 0; done < cnt; ) {
-        const uint32_t area = lane >= done ? area_all : 0u;
-        const uint32_t inc = dpp_add_scan(area);
-        // entries of this chunk: the longest run from `done` whose fragments fit (every wave computes the same answer; a whole 64x64 box
-        // fits on its own, so the run is never empty)
-        const unsigned long long nofit = __ballot(lane >= done && !(lane < cnt && inc <= FCAP));
-        const uint32_t take = nofit ? (uint32_t)__builtin_ctzll(nofit) : 64u;           // exclusive end of the chunk (lane index)
-        const uint32_t foff = inc - area;                                // fragment slot base of lane's surface
-        const uint32_t used = (uint32_t)__builtin_amdgcn_readlane((int)inc, (int)(take - 1));
-        // the chunk's slots start out as "not drawn": one cooperative pass instead of a zero-fill loop per row
-        for (uint32_t i = tid; i < (FMT8 ? used * 2 : (used + 1) / 2); i += NT) frag[i] = 0;
+        const unsigned long long slowmask = __ballot(live && (my_flags & F_SLOW));     // literal edge-walk replay (float / ortho projection, huge coordinates)
+        for (uint32_t r = wave; r < 128u; r += NW) {         // row masks [0, 64), column masks [64, 128): contiguous in LDS
+            unsigned long long mk;
+            if (r < 64u) { const uint32_t y = ty_top + r; mk = __ballot(live && by0 <= y && y < by1); }
+            else { const uint32_t x = x_lo + (r - 64u); mk = __ballot(live && bx0 <= x && x < bx1); }
+            if (lane == 0) rowmask[r] = mk;
+        }
         __syncthreads();
-
-        // ---- phase 1: fragments.  Same ROW-ITEM scheduling as the coverage kernel: the work items of the chunk are the rows of the
-        // clipped boxes; in rounds of 64 every lane takes one row of some surface (rounds are dealt to the waves round-robin),
-        // fetches that surface's parameters over ds_bpermute and walks the row, evaluating texel + colour pipeline per pixel.
-        const bool in_chunk = live && lane >= done && lane < take;
-        const bool slow = in_chunk && (my_flags & F_SLOW);
-        const uint32_t h = (in_chunk && !slow) ? by1 - by0 : 0u;
-        const uint32_t hinc = dpp_add_scan(h);
-        const uint32_t R = (uint32_t)__builtin_amdgcn_readlane((int)hinc, 63);
-        const uint32_t P = hinc - h;
-        const uint32_t box = (bx0 - x_lo) | ((bx1 - x_lo) << 8) | ((by0 - ty_top) << 16);
-        for (uint32_t k0 = wave * 64; k0 < R; k0 += NW * 64) {
-            const unsigned long long before = __ballot(h > 0 && P <= k0);
-            const uint32_t carry = before ? 64u - (uint32_t)__builtin_clzll(before) : 0u;
-            const bool starts = h > 0 && P > k0 && P < k0 + 64;       // forward permute of the row starts (see phase_a_rows)
-            const uint32_t mark = (uint32_t)__builtin_amdgcn_ds_permute((int)((starts ? P - k0 : 0u) << 2), (int)(starts ? lane + 1 : 0u));
-            const uint32_t own = max(dpp_max_scan(mark), carry);
-            const uint32_t k = k0 + lane;
-            const bool valid = k < R;
-            const uint32_t sl = valid ? own - 1 : lane;
-            Tri tr;
-            const uint32_t sbox = bperm(sl, box), sP = bperm(sl, P), sbase = bperm(sl, foff);
-            const uint4 r0 = srec[sl * 8], r1 = srec[sl * 8 + 1], r2 = srec[sl * 8 + 2], r3 = srec[sl * 8 + 3], r4 = srec[sl * 8 + 4], r6 = srec[sl * 8 + 6];
-            tr.x3 = __uint_as_float(r0.x); tr.y3 = __uint_as_float(r0.y); tr.a0 = __uint_as_float(r0.z); tr.b0 = __uint_as_float(r0.w);
-            tr.a1 = __uint_as_float(r1.x); tr.b1 = __uint_as_float(r1.y); tr.inv_area = __uint_as_float(r1.z);
-            tr.u1 = __uint_as_float(r2.y); tr.u2 = __uint_as_float(r2.z); tr.u3 = __uint_as_float(r2.w);
-            tr.v1 = __uint_as_float(r3.x); tr.v2 = __uint_as_float(r3.y); tr.v3 = __uint_as_float(r3.z);
-            tr.flags = r3.w;
-            tr.tw = r6.x; tr.th = r6.y; tr.toff = r6.z;
-            tr.iz1 = tr.iz2 = tr.iz3 = 0.0f;
-            if (!affine || zmode) { const uint4 r5 = srec[sl * 8 + 5]; tr.iz1 = __uint_as_float(r5.y); tr.iz2 = __uint_as_float(r5.z); tr.iz3 = __uint_as_float(r5.w); }
-            const uint32_t vc1 = r4.x, vc2 = r4.y, vc3 = r4.z;
-            float shv[9];
-            if (shading != B32_SHADE_NONE) {
-                const uint32_t ssid = r6.w;
-                for (int j = 0; j < 9; ++j) shv[j] = valid ? a.shades[(size_t)ssid * 9 + j] : 0.0f;
-            }
-            const uint32_t rx0 = sbox & 0xFF, rx1 = (sbox >> 8) & 0xFF, ry = (sbox >> 16) + (k - sP);       // tile-local
-            const uint32_t n = valid ? rx1 - rx0 : 0u;
-            const uint32_t py = ry + ty_top;
-            const float dx = (float)(rx0 + x_lo) - tr.x3, dy = (float)py - tr.y3;
-            float w0 = tr.a0 * dx + tr.b0 * dy, w1 = tr.a1 * dx + tr.b1 * dy;                              // exact integers (k_setup guard)
-            uint32_t slot = sbase + (k - sP) * (rx1 - rx0);
-            // every pixel of the clipped box owns a slot (zeroed with the chunk); only the interval of the row that can pass the inside
-            // test (row_trim) takes the texel / colour pipeline, and only drawn fragments are written
-            uint32_t i_lo = 0, i_n = n;
-            if (B32_ROW_TRIM) {
-                i_lo = row_trim(w0, w1, tr.a0, tr.a1, tr.inv_area, i_n);
-                w0 += tr.a0 * (float)i_lo; w1 += tr.a1 * (float)i_lo; slot += i_lo;
-            }
-#ifdef B32_EXP_BLEND_NO_FRAG
-            i_n = 0;                                    // experiment builds only: no fragment is generated, to time the rest
-#endif
-            const uint32_t i_end = i_lo + i_n;
-            for (uint32_t i = i_lo; __ballot(i < i_end); ++i) {
-                if (i < i_end) {
-                    const uint32_t px = rx0 + x_lo + i;
-                    float bcx, bcy, bcz;
-                    uint32_t v0 = 0, v1 = 0;
-                    if (inside_bc(tr, w0, w1, bcx, bcy, bcz)) {
-                        uint32_t texel;
-                        if (FMT8) {
-                            if (texel_drawn<0, true>(tr, bcx, bcy, bcz, reinterpret_cast<const uint16_t*>(a.texels32), nullptr, texel, affine)) {
-                                v0 = shade8(texel, bcx, bcy, bcz, vc1, vc2, vc3, tr.flags, shading, shv, px, py) | 0x80000000u;
-                                const float inv_z = bcx * tr.iz1 + bcy * tr.iz2 + bcz * tr.iz3;
-                                v1 = __float_as_uint(1.0f / inv_z);
-                            }
-                        } else if (ztest(tr, bcx, bcy, bcz, zmode, zmode ? tilez[ry * TILE_STRIDE + rx0 + i] : 0.0f) &&
-                                   texel_drawn<0>(tr, bcx, bcy, bcz, a.texels, nullptr, texel, affine)) {
-                            v0 = shade15(texel, bcx, bcy, bcz, vc1, vc2, vc3, tr.flags, shading, shv, px, py);      // (never 0: all-black sets bit 15)
-                        }
+        const unsigned long long cm = colmask[lane];
+        const uint32_t px = x_lo + lane;
+        // The lane owns column `lane` of the rows wave, wave + NW, ...  Two loops per round, so that neither waits for the other's
+        // stragglers: (A) every lane runs through its pixels' candidates, one inside test per step, and notes the fragments that pass
+        // (row index, surface) in its own list -- a column of a per-wave LDS array, 16 bits per entry; (B) step k of the colour
+        // pipeline takes every lane's k-th fragment: nobody searches there, and the wave's sequential depth is the largest number of
+        // fragments one lane's pixels receive in total (not, as with lanes in step per row, the sum over the rows of each row's
+        // busiest pixel).  A lane whose list is full resumes its search in the next round (ascending order is kept).
+        uint32_t rows = 0;                              // the lane's rows that have candidates, bit i <-> row wave + i * NW
+        for (uint32_t i = 0; i < (uint32_t)(TILE_H / NW); ++i) {
+            const uint32_t row = wave + i * NW;
+            if (row < TH && (rowmask[row] & cm) != 0ull) rows |= 1u << i;
+        }
+        unsigned long long m = 0ull;
+        uint32_t ri = 0;
+        const bool ztest_a = !FMT8 && zmode;            // RGB555: the depth buffer is read-only in this pass, so the test can run before the colour pipeline
+        float zrow = 0.0f;                              // depth of the lane's current pixel
+        for (;;) {
+            uint32_t n = 0;
+            for (;;) {                                      // (A)
+                const bool can = n < BLEND_LIST_CAP && (m != 0ull || rows != 0u);
+                if (!__ballot(can)) break;
+                if (can) {
+                    if (m == 0ull) {
+                        ri = (uint32_t)__builtin_ctz(rows); rows &= rows - 1u; m = rowmask[wave + ri * NW] & cm;
+                        if (ztest_a) zrow = a.zbuf[(size_t)(ty_top + wave + ri * NW) * fp.width + px];
                     }
-                    if (v0) { if (FMT8) { frag[2 * slot] = v0; frag[2 * slot + 1] = v1; } else frag16[slot] = (uint16_t)v0; }
-                    ++slot; w0 += tr.a0; w1 += tr.a1;
+                    const uint32_t j = (uint32_t)__builtin_ctzll(m);
+                    m &= m - 1ull;
+                    const uint4 r0 = srec[j * SREC_Q], r1 = srec[j * SREC_Q + 1];
+                    Tri t;
+                    t.x3 = __uint_as_float(r0.x); t.y3 = __uint_as_float(r0.y); t.a0 = __uint_as_float(r0.z); t.b0 = __uint_as_float(r0.w);
+                    t.a1 = __uint_as_float(r1.x); t.b1 = __uint_as_float(r1.y); t.inv_area = __uint_as_float(r1.z);
+                    const uint32_t py = ty_top + wave + ri * NW;
+                    float w0, w1, bcx, bcy, bcz;
+                    if (!((slowmask >> j) & 1ull)) {        // exact integers (k_setup guard): closed form == accumulation
+                        const float dx = (float)px - t.x3, dy = (float)py - t.y3;
+                        w0 = t.a0 * dx + t.b0 * dy; w1 = t.a1 * dx + t.b1 * dy;
+                    } else {
+                        t.min_x = r1.w & 0xFFFF; t.min_y = srec[j * SREC_Q + 2].x & 0xFFFF;
+                        t.w0_start = __uint_as_float(srec[j * SREC_Q + 4].w); t.w1_start = __uint_as_float(srec[j * SREC_Q + 5].x);
+                        replay_w(t, px, py, w0, w1);
+                    }
+                    bool pass = inside_bc(t, w0, w1, bcx, bcy, bcz);                                                          // render.rs:1536-1542
+                    if (pass && ztest_a) {
+                        const uint4 r5 = srec[j * SREC_Q + 5];
+                        t.iz1 = __uint_as_float(r5.y); t.iz2 = __uint_as_float(r5.z); t.iz3 = __uint_as_float(r5.w);
+                        t.flags = srec[j * SREC_Q + 3].w;
+                        pass = ztest(t, bcx, bcy, bcz, 1, zrow);
+                    }
+                    if (pass) { mylist[n * 64 + lane] = (uint16_t)((ri << 6) | j); ++n; }
                 }
             }
-        }
-        // surfaces whose edge walk must be replayed literally: one wave each, one lane per row
-        {
-            unsigned long long sm = __ballot(slow);
-            uint32_t idx = 0;
-            while (sm) {
-                const int t = __builtin_ctzll(sm);
-                sm &= sm - 1;
-                if ((idx++ % NW) != wave) continue;
-                Tri tr;
-                {
-                    const uint4 r0 = srec[t * 8], r1 = srec[t * 8 + 1], r2 = srec[t * 8 + 2], r3 = srec[t * 8 + 3], r4 = srec[t * 8 + 4], r5 = srec[t * 8 + 5], r6 = srec[t * 8 + 6];
+            const uint32_t nmax = (uint32_t)__builtin_amdgcn_readlane((int)dpp_max_scan(n), 63);
+            if (nmax == 0u) break;
+            for (uint32_t k = 0; k < nmax; ++k) {           // (B)
+                if (k < n) {
+                    const uint32_t e = mylist[k * 64 + lane], j = e & 63u, row = wave + (e >> 6) * NW;
+                    const uint32_t py = ty_top + row, ti = row * BT_STRIDE + lane;
+                    const uint4 r0 = srec[j * SREC_Q], r1 = srec[j * SREC_Q + 1], r2 = srec[j * SREC_Q + 2], r3 = srec[j * SREC_Q + 3], r4 = srec[j * SREC_Q + 4], r6 = srec[j * SREC_Q + 6];
+                    Tri tr;
                     tr.x3 = __uint_as_float(r0.x); tr.y3 = __uint_as_float(r0.y); tr.a0 = __uint_as_float(r0.z); tr.b0 = __uint_as_float(r0.w);
                     tr.a1 = __uint_as_float(r1.x); tr.b1 = __uint_as_float(r1.y); tr.inv_area = __uint_as_float(r1.z);
-                    tr.min_x = r1.w & 0xFFFF; tr.max_x = r1.w >> 16; tr.min_y = r2.x & 0xFFFF; tr.max_y = r2.x >> 16;
                     tr.u1 = __uint_as_float(r2.y); tr.u2 = __uint_as_float(r2.z); tr.u3 = __uint_as_float(r2.w);
                     tr.v1 = __uint_as_float(r3.x); tr.v2 = __uint_as_float(r3.y); tr.v3 = __uint_as_float(r3.z);
                     tr.flags = r3.w;
-                    tr.w0_start = __uint_as_float(r4.w); tr.w1_start = __uint_as_float(r5.x);
-                    tr.iz1 = __uint_as_float(r5.y); tr.iz2 = __uint_as_float(r5.z); tr.iz3 = __uint_as_float(r5.w);
                     tr.tw = r6.x; tr.th = r6.y; tr.toff = r6.z;
-                }
-                const uint32_t cx0 = bcu(bx0, t), cx1 = bcu(bx1, t), cy0 = bcu(by0, t), cy1 = bcu(by1, t);
-                const uint32_t base = bcu(foff, t), bw = cx1 - cx0;
-                const uint32_t vc1 = srec[t * 8 + 4].x, vc2 = srec[t * 8 + 4].y, vc3 = srec[t * 8 + 4].z;
-                const uint32_t sid = srec[t * 8 + 6].w;
-                float shv[9];
-                if (shading != B32_SHADE_NONE) for (int j = 0; j < 9; ++j) shv[j] = a.shades[(size_t)sid * 9 + j];
-                for (uint32_t ry = cy0; ry < cy1; ry += 64) {
-                    const uint32_t py = ry + lane;
-                    if (py < cy1) {
-                        float w0, w1;
-                        replay_w(tr, cx0, py, w0, w1);
-                        for (uint32_t px = cx0; px < cx1; ++px) {
-                            const uint32_t slot = base + (py - cy0) * bw + (px - cx0);
-                            float bcx, bcy, bcz;
-                            uint32_t v0 = 0, v1 = 0;
-                            if (inside_bc(tr, w0, w1, bcx, bcy, bcz)) {
-                                uint32_t texel;
-                                if (FMT8) {
-                                    if (texel_drawn<0, true>(tr, bcx, bcy, bcz, reinterpret_cast<const uint16_t*>(a.texels32), nullptr, texel, affine)) {
-                                        v0 = shade8(texel, bcx, bcy, bcz, vc1, vc2, vc3, tr.flags, shading, shv, px, py) | 0x80000000u;
-                                        const float inv_z = bcx * tr.iz1 + bcy * tr.iz2 + bcz * tr.iz3;
-                                        v1 = __float_as_uint(1.0f / inv_z);
-                                    }
-                                } else if (ztest(tr, bcx, bcy, bcz, zmode, zmode ? tilez[(py - ty_top) * TILE_STRIDE + (px - x_lo)] : 0.0f) &&
-                                           texel_drawn<0>(tr, bcx, bcy, bcz, a.texels, nullptr, texel, affine)) {
-                                    v0 = shade15(texel, bcx, bcy, bcz, vc1, vc2, vc3, tr.flags, shading, shv, px, py);
-                                }
-                            }
-                            if (v0) { if (FMT8) { frag[2 * slot] = v0; frag[2 * slot + 1] = v1; } else frag16[slot] = (uint16_t)v0; }
-                            w0 += tr.a0; w1 += tr.a1;
-                        }
+                    tr.iz1 = tr.iz2 = tr.iz3 = 0.0f;
+                    float w0, w1, bcx, bcy, bcz;
+                    if (!((slowmask >> j) & 1ull)) {
+                        const float dx = (float)px - tr.x3, dy = (float)py - tr.y3;
+                        w0 = tr.a0 * dx + tr.b0 * dy; w1 = tr.a1 * dx + tr.b1 * dy;
+                    } else {
+                        tr.min_x = r1.w & 0xFFFF; tr.min_y = r2.x & 0xFFFF;
+                        tr.w0_start = __uint_as_float(r4.w); tr.w1_start = __uint_as_float(srec[j * SREC_Q + 5].x);
+                        replay_w(tr, px, py, w0, w1);
+                    }
+                    (void)inside_bc(tr, w0, w1, bcx, bcy, bcz);          // (passed in (A): the barycentrics again)
+                    if (!affine || (FMT8 && zmode)) { const uint4 r5 = srec[j * SREC_Q + 5]; tr.iz1 = __uint_as_float(r5.y); tr.iz2 = __uint_as_float(r5.z); tr.iz3 = __uint_as_float(r5.w); }
+                    float shv[9];
+                    if (shading != B32_SHADE_NONE) for (int q = 0; q < 9; ++q) shv[q] = a.shades[(size_t)r6.w * 9 + q];
+                    uint32_t pix = tilebuf[ti];
+                    float zb = (DEPTH_TILE && zmode) ? tilez[ti] : 0.0f;
+                    if (blend_fragment<FMT8>(a, tr, bcx, bcy, bcz, px, py, r4.x, r4.y, r4.z, shading, shv, &pix, &zb, FMT8 ? zmode : 0 /* tested in (A) */, xray)) {
+                        tilebuf[ti] = pix;
+                        if (FMT8 && zmode) tilez[ti] = zb;           // the 8-bit path writes depth on every store
+                        ++drawn;
                     }
                 }
             }
         }
-        __syncthreads();
-
-        // ---- phase 2: apply, in order, to the rows this wave owns (lanes = columns of the surface's box)
-        unsigned long long mine = __ballot(in_chunk && max(by0, wy0) < min(by1, wy1));
-#ifdef B32_EXP_BLEND_NO_APPLY
-        mine = 0;                                       // experiment builds only (tools/exp_variants.py): phase 2 off, to time phase 1
-#endif
-        while (mine) {
-            const uint32_t t = (uint32_t)__builtin_ctzll(mine);
-            mine &= mine - 1;
-            const uint32_t cx0 = bcu(bx0, (int)t), cx1 = bcu(bx1, (int)t), cy0 = bcu(by0, (int)t), cy1 = bcu(by1, (int)t);
-            const uint32_t base = bcu(foff, (int)t), bw = cx1 - cx0, flags = bcu(my_flags, (int)t);
-            const uint32_t r0 = max(cy0, wy0), r1 = min(cy1, wy1);
-            // lanes = (row, column) of the box, 64 / 2^k rows per step with 2^k >= box width: a small triangle is one step
-            const uint32_t sh = bw <= 1 ? 0u : 32u - (uint32_t)__builtin_clz(bw - 1);      // log2 of the padded width
-            const uint32_t col = lane & ((1u << sh) - 1u), sub = lane >> sh, rows_per_step = 64u >> sh;
-            const uint32_t px = cx0 + col;
-            uint32_t drawn = 0;
-            for (uint32_t rb = r0; rb < r1; rb += rows_per_step) {
-                const uint32_t py = rb + sub;
-                const bool on = col < bw && py < r1;
-                const uint32_t slot = base + (py - cy0) * bw + col;
-                const uint32_t ti = (py - ty_top) * TILE_STRIDE + (px - x_lo);
-                if (FMT8) {
-                    const uint32_t colr = on ? frag[2 * slot] : 0u;
-                    if (!__ballot(colr & 0x80000000u)) continue;
-                    if (colr & 0x80000000u) {
-                        // rasterize_triangle (render.rs:1302-1424): the early reject and the store's own test collapse into one test
-                        // per store kind (they differ only for NaN depths); every store that passes writes the depth
-                        const uint32_t alpha = flags >> F_ALPHA_SHIFT;
-                        bool pass = true;
-                        if (zmode) {
-                            const float z = __uint_as_float(frag[2 * slot + 1]), zb = tilez[ti];
-                            pass = alpha < 255 ? !(z >= zb) : (z < zb);                  // render.rs:387 / :432, :1407
-                            if (pass) tilez[ti] = z;
-                        }
-                        if (pass) { tilebuf[ti] = store8(tilebuf[ti], colr & 0x7FFFFFFFu, alpha); ++drawn; }
-                    }
-                } else {
-                    const uint32_t v = on ? (uint32_t)frag16[slot] : 0u;
-                    if (!__ballot(v != 0u)) continue;
-                    if (v) { tilebuf[ti] = store_blend(tilebuf[ti], v, flags, xray); ++drawn; }
-                }
-            }
-            for (int off = 32; off > 0; off >>= 1) drawn += __shfl_down(drawn, off);
-            frag_count += (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)drawn);
-        }
-        __syncthreads();                                // the fragment buffer is reused by the next chunk
-        done = take;
-        }   // chunks of the batch
+        __syncthreads();                                // records and masks are restaged for the next batch
     }
     for (uint32_t p = tid; p < TILE_W * TH; p += NT) {      // finished tile back, one 256-B row segment per wave instruction
         const uint32_t row = p >> 6, col = p & 63;
         const uint32_t px = x_lo + col, py = ty_top + row;
         if (px < x_hi && py >= y_lo && py < y_hi) {
-            a.fb[(size_t)py * fp.width + px] = tilebuf[row * TILE_STRIDE + col];
-            if (FMT8 && zmode) a.zbuf[(size_t)py * fp.width + px] = tilez[row * TILE_STRIDE + col];     // the 8-bit path writes depth on every store
+            a.fb[(size_t)py * fp.width + px] = tilebuf[row * BT_STRIDE + col];
+            if (FMT8 && zmode) a.zbuf[(size_t)py * fp.width + px] = tilez[row * BT_STRIDE + col];
         }
     }
-    if (lane == 0) wf[wave] = frag_count;
-    __syncthreads();
-    if (tid == 0) {
-        unsigned long long t = 0;
-        for (int w = 0; w < NW; ++w) t += wf[w];
-        if (t) atomicAdd(&a.ctrl->fragments, t);
+    {
+        for (int off = 32; off > 0; off >>= 1) drawn += __shfl_down(drawn, off);
+        if (lane == 0) wf[wave] = drawn;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long t = 0;
+            for (int w = 0; w < NW; ++w) t += wf[w];
+            if (t) atomicAdd(&a.ctrl->fragments, t);
+        }
     }
 }
 
-constexpr int BLEND_NT = 512;        // 8 waves: with ~80 VGPRs three workgroups fit a CU (the 1024-thread form only ever fit one)
 // hipFuncSetAttribute is per device: remember, per kernel instantiation, on which devices the large-LDS opt-in has been made
 // (a process may own contexts on several GPUs)
 static bool first_launch_on_device(bool (&done)[64]) {
@@ -2022,11 +1937,12 @@ static bool first_launch_on_device(bool (&done)[64]) {
 
 template <bool FMT8, bool GATHER>
 static void launch_blend(hipStream_t s, const FillArgs& a, uint32_t ntiles) {
+    constexpr int NT = BLEND_NT;
     const bool zmode = a.fp.zmode && !a.fp.xray;
-    const size_t lds = blend_lds_bytes(FMT8, zmode);
+    const size_t lds = blend_lds_bytes(FMT8 && zmode);
     static bool attr[64] = {};
-    if (first_launch_on_device(attr)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_blend<BLEND_NT, FMT8, GATHER>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((k_blend<BLEND_NT, FMT8, GATHER>), dim3(ntiles), dim3(BLEND_NT), lds, s, a);
+    if (first_launch_on_device(attr)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_blend<NT, FMT8, GATHER>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((k_blend<NT, FMT8, GATHER>), dim3(ntiles), dim3(NT), lds, s, a);
 }
 
 #ifdef B32_TIMELINE
