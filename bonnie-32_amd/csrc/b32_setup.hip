@@ -213,8 +213,10 @@ __device__ __forceinline__ uint32_t agg_position(const AggSlot& g) {
 // SETUP_FPT = faces per thread (1 everywhere today: registers, i.e. waves per SIMD, are worth more than loads issued ahead)
 // PLAIN = the frame uses none of the optional stages (fixed-point snap, perspective, no fog, no lighting, no wireframe lists, no x-ray,
 // RGB555): those branches are compiled out -- fewer live scalars, less code in the instruction cache, no exec-mask juggling around them
+// (the plain form is compiled for 8 waves per SIMD: left to itself the register allocator lands on 57 ... 65 VGPRs depending on unrelated
+// code in this file, i.e. on 7 or 8 waves and on schedules between 46 and 63 us at 1 M faces -- measured; the general form keeps its 5)
 template <int SETUP_FPT, bool PLAIN>
-__global__ __launch_bounds__(256) void k_setup(FrameParams fp_in, const B32Vertex* __restrict__ verts, const B32Face* __restrict__ faces,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PLAIN ? 8 : 4, PLAIN ? 8 : 5))) void k_setup(FrameParams fp_in, const B32Vertex* __restrict__ verts, const B32Face* __restrict__ faces,
                                                const TexDesc* __restrict__ tex, const B32Light* __restrict__ lights_mem, LightSet lset, MeshTable mtab,
                                                RecArrays recs, DirectBin db, float* __restrict__ shades, uint32_t* __restrict__ keys,
                                                uint32_t* __restrict__ spans, uint32_t* __restrict__ partials, Ctrl* __restrict__ ctrl,
