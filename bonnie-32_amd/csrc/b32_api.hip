@@ -48,7 +48,7 @@ struct b32_ctx {
     FrameSet alt;                        // the other frame set (allocated on first use)
     hipEvent_t ev_setup = nullptr, ev_done = nullptr; bool set_in_flight = false;     // (members of the current set, see FrameSet)
     bool side_dirty = true;              // something k_setup reads was written on `stream` since the side stream last waited for it
-    uint32_t gate_permille = 300;        // b32_set_pipeline_gate: hold the next setup kernel until that share of the previous fill's tiles has started
+    uint32_t gate_permille = 1150;       // b32_set_pipeline_gate: hold the next setup kernel until the previous fill has handed out 15 % of the tiles behind its first round
     bool pipe_hint = true;               // the previous frame's route could use the second frame set
     uint32_t last_cover_tiles = 0, last_cover_groups = 0;   // tile count / workgroups of the previous frame's fused kernel (0: it had none)
     bool pipelined = false;              // the frame being enqueued runs its k_setup on the side stream
@@ -1213,7 +1213,9 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
             // passes tiles - groups when the last tile is handed out, and every fetch beyond that is a workgroup that found the queue
             // empty and has only the shading of its last tile left, i.e. is about to free its place on a CU.
             const uint32_t groups = c->last_cover_groups, tiles = c->last_cover_tiles;
-            const uint32_t need = (tiles > groups ? tiles - groups : 0u) + (uint32_t)((uint64_t)(c->gate_permille - 1u) * groups / 1000u);
+            const uint32_t pre = tiles > groups ? tiles - groups : 0u;      // cursor value when the last tile is handed out
+            const uint32_t need = c->gate_permille > 1000u ? (uint32_t)((uint64_t)(c->gate_permille - 1000u) * pre / 1000u)
+                                                           : pre + (uint32_t)((uint64_t)(c->gate_permille - 1u) * groups / 1000u);
             if (need) launch_gate(ss, c->alt.d_ctrl, need, 30000u /* 300 us */);
         }
     }
@@ -1868,7 +1870,7 @@ extern "C" int b32_set_cheap_threshold(b32_ctx* c, uint32_t den) {
     return B32_OK;
 }
 extern "C" int b32_set_pipeline_gate(b32_ctx* c, uint32_t permille) {
-    if (!c || permille > 1000u) return B32_E_ARG;
+    if (!c || permille > 2000u) return B32_E_ARG;
     c->gate_permille = permille;
     return B32_OK;
 }

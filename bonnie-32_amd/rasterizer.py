@@ -111,7 +111,7 @@ class Context:
         return {n: int(self.lib.b32_batch_count(self.h, i)) for i, n in enumerate(("merged_draws", "single_draws", "merged_built", "frames"))}
 
     def set_pipeline_gate(self, permille):
-        """b32_set_pipeline_gate: hold a pipelined setup kernel until that share of the previous fill's tiles has started."""
+        """b32_set_pipeline_gate: hold a pipelined setup kernel until the previous fill's tile cursor has come that far (include/b32raster.h)."""
         _chk(self.lib.b32_set_pipeline_gate(self.h, int(permille)), "b32_set_pipeline_gate")
 
     def set_routes(self, off_mask):

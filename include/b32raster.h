@@ -375,10 +375,13 @@ int b32_set_profiling(b32_ctx* ctx, int level);
 int b32_set_profiling_stride(b32_ctx* ctx, uint32_t every);
 /* Two frames in flight (no reference counterpart; see B32_ROUTE_PIPELINE): when a frame is enqueued while an earlier one is still
  * pending, its setup kernel runs on a second, low-priority stream of the context beside the earlier frame's fill kernel, on a second
- * set of per-face buffers.  permille > 0 holds that setup kernel back until the earlier fill has handed out its last tile and
- * (permille - 1) / 1000 of its workgroups have found the tile queue empty (they are about to leave their CUs), so that the setup kernel
- * runs in the fill's thinning tail instead of beside its busy start; 0 = no hold.  Results are identical either way.
- * permille > 1000: B32_E_ARG. */
+ * set of per-face buffers.  permille > 0 holds that setup kernel back so that it runs beside the fill's thinning second half rather than
+ * beside its busy start (started together the two kernels only slow each other down), measured on the fill's tile cursor:
+ *   1001 .. 2000: until (permille - 1000) / 1000 of the tiles BEHIND the workgroups' first round have been handed out (default 1150:
+ *                 the setup kernel then ends before the fill does, so the next fill starts without waiting for the cross-stream event);
+ *   1 .. 1000   : until the last tile has been handed out and (permille - 1) / 1000 of the workgroups have found the queue empty;
+ *   0           : no hold.
+ * Results are identical either way.  permille > 2000: B32_E_ARG. */
 int b32_set_pipeline_gate(b32_ctx* ctx, uint32_t permille);
 /* B32Timings.fragments (the reference's pixel-store count, render.rs:1671-1702) is instrumentation, not an output of
  * render_mesh_15.  on = 0 (default): not counted (B32Timings.fragments = 0 unless the textures force exact coverage); the fill

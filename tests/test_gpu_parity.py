@@ -405,7 +405,7 @@ def test_async_frames_are_never_silently_dropped(oracle):
     assert np.array_equal(fb3.pixels, o2.pixels)
 
 
-@pytest.mark.parametrize("gate,routes_off", [(300, 0), (0, 0), (1000, 0), (300, 64)])
+@pytest.mark.parametrize("gate,routes_off", [(1150, 0), (300, 0), (0, 0), (1000, 0), (2000, 0), (300, 64)])
 def test_two_frames_in_flight(oracle, gate, routes_off):
     """Frames enqueued back to back run their setup kernel on the context's second stream, on the other frame set, beside the previous
     frame's fill (B32_ROUTE_PIPELINE, b32_set_pipeline_gate).  Six frames of a large mesh (direct binning) with a moving camera in
