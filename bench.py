@@ -10,7 +10,7 @@ Prints ONE JSON line on rank 0 (see the driver contract), with
   roofline       dominant kernel vs the 8 TB/s HBM peak (HIP events on the kernel's own stream, inside the timed region)
   cpu_baseline   the CPU port of the reference (oracle/, release-profile build, 1 thread) timed on this box's host cores
   cpu_all_cores  the same port threaded (transform split by vertex range, draw split by row band)
-  configs        (N = 1) the other BASELINE configs -- C1, C2, C5 -- each with ms/frame, Mtri/s, Mpix/s, frame-level roofline
+  configs        (N = 1) the other BASELINE configs -- C1, C2, C5 -- and C3 with a transparent pass, each with ms/frame, Mtri/s, Mpix/s, frame-level roofline
                  fraction and a framebuffer SHA-256 checked against tests/golden/hashes.json
   protocol       SURVEY 8d extras: median of the per-step times, output-pixel rate, H2D of the scene, D2H of the frame
 """
@@ -437,13 +437,18 @@ def main():
     side = None
     if world == 1 and rank == 0 and not args.no_configs and args.config == "C3" and args.tris is None:
         side = {}
-        for name in ("C1", "C2", "C5"):
-            s2 = scenegen.make_scene(name)
+        for name in ("C1", "C2", "C5", "C3:blend"):
+            # ("C3:blend": the headline scene with 10 % of its faces in the transparent pass -- ordinary content for the reference,
+            # render.rs:2522-2532, 2563-2569 -- so that the ordered pass is tracked by the driver's line too)
+            s2 = scenegen.make_scene("C3", variant="blend") if name == "C3:blend" else scenegen.make_scene(name)
             c2 = R.Context(local_rank)
             c2.set_async_depth(1)
             c2.set_stream(stream.cuda_stream)
             f2 = R.Framebuffer(s2.width, s2.height, c2)
-            r2 = R.ResidentScene(f2, s2.vertices, s2.faces, indexed_textures=s2.indexed_textures)
+            if name == "C3:blend":
+                r2 = R.ResidentScene(f2, s2.vertices, s2.faces, s2.textures)
+            else:
+                r2 = R.ResidentScene(f2, s2.vertices, s2.faces, indexed_textures=s2.indexed_textures)
             c2.set_fragment_counting(1)
             f2.clear(s2.clear_color); r2.render_async(s2.camera, s2.settings, s2.fog)
             tm2 = r2.finish()
@@ -451,7 +456,7 @@ def main():
             for _ in range(5):
                 f2.clear(s2.clear_color); r2.render_async()
             r2.finish()
-            k2 = max(args.steps, 20) * (4 if name != "C5" else 1)
+            k2 = max(args.steps, 20) * (4 if name in ("C1", "C2") else 1)
             torch.cuda.synchronize(dev)
             q0 = time.perf_counter()
             for _ in range(k2):

@@ -159,6 +159,7 @@ SCENES = {
     "C5:20k": lambda: scenegen.make_scene("C5", n_tris=20_000),
     "C3": lambda: scenegen.make_scene("C3"),       # BASELINE configs[2] at full size (1 M triangles @ 2560x1920)
     "C5": lambda: scenegen.make_scene("C5"),       # BASELINE configs[4] at full size (65.5 M fragments)
+    "C3:blend": lambda: scenegen.make_scene("C3", variant="blend"),   # C3 with 10 % of its faces in the transparent pass (bench.py `configs`)
 }
 
 
