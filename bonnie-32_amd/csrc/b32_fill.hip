@@ -16,9 +16,11 @@
 //            colour pipeline (render.rs:1613-1661) -> RGBA8 store (Color15::to_rgba), 256-B coalesced per wave.  If the
 //            winner's texel is skipped (CHEAP only) the wave scans the tile list downward, 64 entries at a time, for
 //            the highest surface below it whose fragment is really drawn — identical result to EXACT coverage.
-//   k_blend  surfaces of the transparent pass (render.rs:2563-2569) blend against the framebuffer, so they are walked
-//            strictly in order, per tile, on an LDS copy of the tile: each wave owns a band of rows (no two waves touch
-//            the same pixel, no atomics, no barriers between surfaces): set_pixel_blended_15 / editor-alpha stores.
+//   k_blend  surfaces of the transparent pass (render.rs:2563-2569) blend against the framebuffer: what must be ordered
+//            is, per pixel, the sequence of that pixel's own fragments.  Per tile, on an LDS copy of it, a lane owns a
+//            pixel column and walks the surfaces whose box holds its pixels in painter's order (row / column masks of
+//            the batch's 64 surfaces): set_pixel_blended_15 / editor-alpha stores; no atomics, no ordering between
+//            surfaces that do not share a pixel.
 //
 // Bit-exactness: barycentrics use the reference's expression order; the edge functions are evaluated from exact integers
 // only for surfaces k_setup proved exact (integer coordinates, every intermediate < 2^24), otherwise the incremental
