@@ -1006,6 +1006,9 @@ static int plan_route(b32_ctx* c, FrameParams& fp, const SortScratch& sc, bool w
         // of 32 rows to 600 of 16; C2's 20 tiles prefer 150 of 8 rows -- 0.039 ms against 0.051 with 75 of 16 rows, 0.049 with 300 of 4)
         while (th > (uint32_t)B32_MIN_TILE_H && fp.tiles_x * ((c->band_y1 + th - 1) / th - c->band_y0 / th) < (th == TILE_H ? 2u : 1u) * (uint32_t)c->n_cu &&
                (c->band_y1 - c->band_y0) / (th / 2) + 2 <= 255 /* tile rows must fit the packed spans */) th /= 2;
+#ifdef B32_EXP_FORCE_TH
+        th = B32_EXP_FORCE_TH;
+#endif
         fp.tile_h = th;
         fp.tile_yb = (c->band_y0 / th) * th;
         fp.tiles_y = (c->band_y1 - fp.tile_yb + th - 1) / th;
