@@ -1,5 +1,5 @@
 """One of bench_modes.py's settings on the C3 scene, a dozen resident frames -- meant to run under rocprofv3 --kernel-trace.
-usage: mode_prof.py zbuffer|game|game8|blendz [routes_off]"""
+usage: mode_prof.py zbuffer|game|game8|blendz|default [routes_off]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bonnie32_amd as b32
@@ -8,7 +8,7 @@ mode = sys.argv[1]
 variant = "blend" if mode == "blendz" else "gouraud"
 sc = scenegen.make_scene("C3", variant=variant)
 st = {"zbuffer": b32.RasterSettings(shading=0, lights=[], backface_wireframe=False), "game": b32.RasterSettings.game(),
-      "game8": b32.RasterSettings(backface_wireframe=False, use_rgb555=False),
+      "game8": b32.RasterSettings(backface_wireframe=False, use_rgb555=False), "default": b32.RasterSettings(),
       "blendz": b32.RasterSettings(shading=0, lights=[], backface_wireframe=False)}[mode]
 ctx = R.Context(0)
 if len(sys.argv) > 2:

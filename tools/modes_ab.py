@@ -1,5 +1,5 @@
 """GPU ms per frame of the C3 scene under several settings, no CPU oracle: for A/B runs of experiment builds (B32_LIB) in one gpurun call.
-usage: modes_ab.py [mode ...]   modes: painter zbuffer game blend blendz game8"""
+usage: modes_ab.py [mode ...]   modes: painter zbuffer game blend blendz game8 default"""
 import os, sys, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bonnie32_amd as b32
@@ -15,7 +15,7 @@ for mode in modes:
     sc = scenes[variant]
     st = {"painter": b32.RasterSettings.benchmark(), "blend": b32.RasterSettings.benchmark(),
           "zbuffer": b32.RasterSettings(shading=0, lights=[], backface_wireframe=False), "game": b32.RasterSettings.game(),
-          "game8": b32.RasterSettings(backface_wireframe=False, use_rgb555=False),
+          "game8": b32.RasterSettings(backface_wireframe=False, use_rgb555=False), "default": b32.RasterSettings(),
           "blendz": b32.RasterSettings(shading=0, lights=[], backface_wireframe=False)}[mode]
     fb = R.Framebuffer(sc.width, sc.height, ctx)
     if mode == "game8":
