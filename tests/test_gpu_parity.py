@@ -405,6 +405,19 @@ def test_async_frames_are_never_silently_dropped(oracle):
     assert np.array_equal(fb3.pixels, o2.pixels)
 
 
+def test_pipeline_gate_argument_range():
+    """b32_set_pipeline_gate: 0 = no hold, 1 .. 1000 = the fill's tail, 1001 .. 2000 = a share of the tiles behind its first round;
+    anything above is refused and leaves the setting alone (include/b32raster.h)."""
+    from bonnie32_amd import rasterizer as R
+    ctx = R.Context(0)
+    for ok in (0, 1, 1000, 1001, 1150, 2000):
+        ctx.set_pipeline_gate(ok)
+    for bad in (2001, 5000, 0xFFFFFFFF):
+        with pytest.raises(R.B32Error) as e:
+            ctx.set_pipeline_gate(bad)
+        assert e.value.code == b32.abi.B32_E_ARG
+
+
 @pytest.mark.parametrize("gate,routes_off", [(1150, 0), (300, 0), (0, 0), (1000, 0), (2000, 0), (300, 64)])
 def test_two_frames_in_flight(oracle, gate, routes_off):
     """Frames enqueued back to back run their setup kernel on the context's second stream, on the other frame set, beside the previous
@@ -1095,6 +1108,29 @@ def test_fast_path_transparent_lists(fast_ctx, oracle):
     got, tm = gpu_render(fast_ctx, big, resident=True)
     assert np.array_equal(got, exp), f"{int((got != exp).sum())} bytes differ"
     assert tm.triangles_drawn == etm.triangles_drawn > 2 * 2048 * 2
+
+
+@pytest.mark.parametrize("zbuffer", [False, True])
+def test_transparent_pile_on_the_sort_free_path(fast_ctx, oracle, zbuffer):
+    """Every face in the transparent pass, large triangles on a small frame: ~70 blended fragments per pixel and ~150 list entries per
+    (cut) tile, still under what k_blend ranks in LDS -- so the frame stays on the sort-free path, and the pixel-centric ordered pass
+    runs several 64-surface batches per tile with every lane's fragment list overflowing round after round (all five blend modes,
+    editor alpha on some faces: render.rs:479-502, 567-591, 1093-1145)."""
+    sc = scenegen.make_scene("C1", n_tris=1500, bbox_px=120.0, seed=4242, variant="blend")
+    modes = np.array([b32.abi.AVERAGE, b32.abi.ADD, b32.abi.SUBTRACT, b32.abi.ADD_QUARTER], dtype=sc.faces["blend_mode"].dtype)
+    sc.faces["blend_mode"][:] = modes[np.arange(len(sc.faces)) % 4]
+    sc.faces["editor_alpha"][::7] = 150
+    sc.settings.use_zbuffer = zbuffer
+    ofb = oracle.Framebuffer(sc.width, sc.height); ofb.clear(sc.clear_color)
+    rc, etm = oracle.render_mesh_15(ofb, sc.vertices, sc.faces, sc.textures, sc.camera, sc.settings)
+    assert rc == 0
+    before = fast_ctx.route_counts()
+    for resident in (False, True):
+        got, tm = gpu_render(fast_ctx, sc, resident=resident)
+        assert np.array_equal(got, ofb.pixels), f"{int((got != ofb.pixels).sum())} bytes differ (zbuffer={zbuffer}, resident={resident})"
+        assert tm.triangles_drawn == etm.triangles_drawn
+    after = fast_ctx.route_counts()
+    assert after["redraw_global_sort"] == before["redraw_global_sort"] and after["keyed"] == before["keyed"], (before, after)
 
 
 @pytest.mark.parametrize("name", ["C3:100k", "C1:blend5", "C2:blend"])
