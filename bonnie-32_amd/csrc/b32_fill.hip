@@ -1008,9 +1008,9 @@ __device__ __forceinline__ void reduce_setup_counters(const FillArgs& a, uint32_
 #pragma unroll
         for (int k = 0; k < 5; ++k) acc[k] += a.partials[b * 8 + k];
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        for (int off = 32; off > 0; off >>= 1) acc[k] += __shfl_down(acc[k], off);
-        if (lane == 0 && acc[k]) atomicAdd(&misc[8 + k], acc[k]);
+    for (int k = 0; k < 5; ++k) {           // (DPP prefix sums: thirty dependent ds_bpermute round trips sat on every small frame's critical path)
+        const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)dpp_add_scan(acc[k]), 63);
+        if (lane == 0 && tot) atomicAdd(&misc[8 + k], tot);
     }
     __syncthreads();
     if (tid == 0) {
@@ -1068,6 +1068,15 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a_in) {
     const FrameParams& fp = a.fp;
     const uint32_t ntiles = fp.tiles_x * fp.tiles_y;
     phase_stamp(a.ctrl, ST_FILL);
+    // small meshes (inline_bin): the first NT spans (and class bits) are requested before the counters are reduced, and the skip mask is
+    // staged before it too -- a C1 workgroup used to start its tile 7 us into an 18-us kernel behind three dependent round trips
+    uint32_t pre_span = 0xFFFFFFFFu, pre_key = 0u;
+    if (P64 && a.inline_bin && tid < fp.nf) { pre_span = a.spans[tid]; if (a.gather_blend) pre_key = a.keys[tid]; }
+    if (P64 && EXACT && a.mask_lds_words) {     // the pool's skip mask into the (unused) runner-up plane, once per workgroup
+        uint32_t* ml = tilebuf + 2 * TILE_H * TILE_STRIDE;
+        for (uint32_t i = tid; i < a.mask_lds_words; i += NT) ml[i] = a.texmask[i];
+        ltex = reinterpret_cast<const uint16_t*>(ml);
+    }
     bool reduce_late = false;
     if (P64 && (a.inline_bin || a.direct_bin)) {
         // there was no binning launch, so nobody has reduced k_setup's per-block counters yet.  Small mesh (inline_bin): every workgroup
@@ -1118,11 +1127,6 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a_in) {
         uint4* dst = reinterpret_cast<uint4*>(smem + LDS_TEX_OFFSET);
         const uint32_t nq = (a.lds_tex_texels + 7) / 8;
         for (uint32_t i = tid; i < nq; i += NT) dst[i] = src[i];
-    }
-    if (P64 && EXACT && a.mask_lds_words) {     // the pool's skip mask into the (unused) runner-up plane, once per workgroup
-        uint32_t* ml = tilebuf + 2 * TILE_H * TILE_STRIDE;
-        for (uint32_t i = tid; i < a.mask_lds_words; i += NT) ml[i] = a.texmask[i];
-        ltex = reinterpret_cast<const uint16_t*>(ml);
     }
     unsigned long long frag_count = 0;
     // the first tile of a workgroup is its own index (no atomic: 512 same-address atomics serialise at ~12 ns each), later ones come
@@ -1184,9 +1188,9 @@ __global__ __launch_bounds__(NT) void k_cover(FillArgs a_in) {
                 const uint32_t f = f0 + tid;
                 bool hit = false, tr = false;
                 if (f < fp.nf) {
-                    const uint32_t span = a.spans[f];
+                    const uint32_t span = f0 == 0 ? pre_span : a.spans[f];
                     hit = span != 0xFFFFFFFFu && txi >= (span & 0xFF) && txi <= ((span >> 8) & 0xFF) && tyl >= ((span >> 16) & 0xFF) && tyl <= (span >> 24);
-                    if (hit && a.gather_blend) tr = (a.keys[f] >> 31) != 0;
+                    if (hit && a.gather_blend) tr = ((f0 == 0 ? pre_key : a.keys[f]) >> 31) != 0;
                 }
                 const unsigned long long mo = __ballot(hit && !tr), mt = __ballot(hit && tr);
                 uint32_t bo = 0, bt = 0;
