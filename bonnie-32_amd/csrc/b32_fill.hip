@@ -1045,7 +1045,10 @@ __device__ __forceinline__ void clear_band(const FillArgs& a) {
 // shading pass, fixed-point snapping, perspective camera, one texture, lists from the binning launch, no transparent pass.  The
 // compiler then drops the other branches of coverage and shading from this instantiation (102 -> 94 VGPRs, 45 -> 13 spilled SGPRs).
 template <int TEXMODE, bool EXACT, int NT, bool ZMODE, bool FMT8 = false, bool P64 = false, bool PLAIN = false>
-__global__ __launch_bounds__(NT) void k_cover(FillArgs a_in) {
+// (every form but the plain one is compiled for at least 4 waves per SIMD, i.e. at most 128 VGPRs: the EXACT z-buffer forms had drifted
+// to 129, which halves the 512-thread kernel's residency to one workgroup per CU -- game() settings with colour-keyed textures at
+// 2560x1920: 0.289 -> 0.242 ms; the plain form keeps the default bound of its block size, its code is byte-identical)
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PLAIN ? 2 : 4))) void k_cover(FillArgs a_in) {
     FillArgs a_plain = a_in;
     if (PLAIN) {
         a_plain.fp.affine = 1; a_plain.fp.shading = B32_SHADE_NONE; a_plain.fp.fixed_point = 1; a_plain.fp.ortho = 0; a_plain.fp.nt = 1;

@@ -1,5 +1,5 @@
 """GPU ms per frame of the C3 scene under several settings, no CPU oracle: for A/B runs of experiment builds (B32_LIB) in one gpurun call.
-usage: modes_ab.py [mode ...]   modes: painter zbuffer game blend blendz game8 default"""
+usage: modes_ab.py [mode ...]   modes: painter zbuffer game blend blendz game8 default gamex zx"""
 import os, sys, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bonnie32_amd as b32
@@ -17,8 +17,9 @@ for mode in modes:
     sc = scenes[variant]
     st = {"painter": b32.RasterSettings.benchmark(), "blend": b32.RasterSettings.benchmark(),
           "zbuffer": b32.RasterSettings(shading=0, lights=[], backface_wireframe=False), "game": b32.RasterSettings.game(),
-          "game8": b32.RasterSettings(backface_wireframe=False, use_rgb555=False), "default": b32.RasterSettings(),
+          "game8": b32.RasterSettings(backface_wireframe=False, use_rgb555=False), "default": b32.RasterSettings(), "gamex": b32.RasterSettings.game(), "zx": b32.RasterSettings(shading=0, lights=[], backface_wireframe=False),
           "blendz": b32.RasterSettings(shading=0, lights=[], backface_wireframe=False)}[mode]
+    ctx.set_fragment_counting(1 if mode in ("gamex", "zx") else 0)      # (gamex / zx: EXACT coverage, as colour-keyed textures force it)
     fb = R.Framebuffer(sc.width, sc.height, ctx)
     if mode == "game8":
         rs = R.ResidentScene(fb, sc.vertices, sc.faces, textures8=[b32.Texture.from_texture15(t) for t in sc.textures])
