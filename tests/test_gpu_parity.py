@@ -515,9 +515,9 @@ def test_clear_after_a_dropped_frame_in_deep_mode(oracle):
     ctx.close()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_band_ranks_share_one_gpu(world):
-    """BASELINE config C4's data path with real processes: `world` ranks (torch.distributed.run, gloo) share GPU 0, each binds the HIP
+    """BASELINE config C4's data path with real processes (world = 8: C4's own partition, eight 240-row bands): `world` ranks (torch.distributed.run, gloo) share GPU 0, each binds the HIP
     context to its band of the 2560x1920 frame, renders C3 at 100 k triangles and the full 1 M-triangle C3, and the rows are gathered
     by bonnie32_amd.parallel.gather_bands and by the pipelined two-framebuffer flow of bench.py (gather_bands_async); rank 0 compares
     every assembled frame with the CPU oracle's (tests/band_worker.py).  What this cannot cover is the RCCL transport itself (one GPU
