@@ -136,6 +136,7 @@ SYMBOLS = [
     ("b32_set_profiling", C.c_int, [_P, C.c_int]),
     ("b32_set_profiling_stride", C.c_int, [_P, C.c_uint32]),
     ("b32_set_pipeline_gate", C.c_int, [_P, C.c_uint32]),
+    ("b32_set_pipeline_depth", C.c_int, [_P, C.c_uint32]),
     ("b32_set_fragment_counting", C.c_int, [_P, C.c_int]),
 ]
 

@@ -26,7 +26,7 @@ constexpr int EV_PER_FRAME = 6; // start | setup | sort | bin | cover | shade+bl
 
 // Everything k_setup WRITES for one frame and the fill kernels read: a context owns two of these so that the setup kernel of frame
 // i + 1 can run on a second stream beside the fill of frame i (see pipeline_begin).  The context's own members of the same names are
-// the set of the frame being enqueued; `alt` holds the other one (swap_sets).
+// the set of the frame being enqueued; `alt` holds the other ones, oldest first (rotate_sets).
 struct FrameSet {
     uint32_t* keys0 = nullptr; CovRec* crecs = nullptr; ShadeRec* srecs = nullptr; AuxRec* xrecs = nullptr;
     uint32_t* spans = nullptr; uint32_t* face_of = nullptr; uint32_t* partials = nullptr; size_t cap_work = 0;
@@ -45,7 +45,10 @@ struct b32_ctx {
     hipStream_t own_stream = nullptr, stream = nullptr;
     // two frames in flight: the setup kernel of the next frame on `side` beside the fill of the current one on `stream`
     hipStream_t side = nullptr; hipEvent_t ev_main = nullptr;
-    FrameSet alt;                        // the other frame set (allocated on first use)
+    FrameSet alt[2];                     // the other frame sets, oldest first (allocated on first use; alt[1] only with three sets)
+    uint32_t n_sets = 2;                 // b32_set_pipeline_depth: 2 = setup(i+1) beside fill(i); 3 = setup(i+2) beside fill(i), so that the
+                                         // setup kernel a fill waits for ended a whole fill ago (fills back to back; measured slower: the two
+                                         // kernels then share the CUs all the time and the frame is bound by their summed VALU work)
     hipEvent_t ev_setup = nullptr, ev_done = nullptr; bool set_in_flight = false;     // (members of the current set, see FrameSet)
     bool side_dirty = true;              // something k_setup reads was written on `stream` since the side stream last waited for it
     uint32_t gate_permille = 1150;       // b32_set_pipeline_gate: hold the next setup kernel until the previous fill has handed out 15 % of the tiles behind its first round
@@ -220,8 +223,7 @@ static int ensure_plain(b32_ctx* c, T*& p, size_t count) {   // exact-size (re)a
 // anything enqueued on the main stream that k_setup reads (uploads, packed streams, light lists, list-space memsets) -> the next
 // setup (ev_main, only when `side_dirty`).  The main stream always waits for the frame's setup before enqueue_frame returns, so a
 // synchronisation of the main stream still covers everything this context has in flight.
-static void swap_sets(b32_ctx* c) {
-    FrameSet& a = c->alt;
+static void swap_with(b32_ctx* c, FrameSet& a) {
     std::swap(c->keys[0], a.keys0); std::swap(c->crecs, a.crecs); std::swap(c->srecs, a.srecs); std::swap(c->xrecs, a.xrecs);
     std::swap(c->spans, a.spans); std::swap(c->face_of, a.face_of); std::swap(c->partials, a.partials);
     std::swap(c->shades, a.shades); std::swap(c->cap_shades, a.cap_shades);
@@ -230,14 +232,23 @@ static void swap_sets(b32_ctx* c) {
     std::swap(c->d_ctrl, a.d_ctrl);
     std::swap(c->ev_setup, a.ev_setup); std::swap(c->ev_done, a.ev_done); std::swap(c->set_in_flight, a.in_flight);
 }
-static void free_alt(b32_ctx* c) {          // (the caller has drained both streams)
-    FrameSet& a = c->alt;
+// The frame being enqueued takes the OLDEST set; afterwards alt[n_sets - 2] is the previous frame's set and alt[0] the set of the frame
+// n_sets - 1 back -- the one whose fill the new frame's setup kernel is meant to run beside (its tile cursor is what the gate polls).
+static void rotate_sets(b32_ctx* c) {
+    swap_with(c, c->alt[0]);                                   // current <- oldest; alt[0] <- previous frame's
+    if (c->n_sets == 3) std::swap(c->alt[0], c->alt[1]);        // alt[0] <- two frames back, alt[1] <- previous frame's
+}
+static void unrotate_sets(b32_ctx* c) {      // (an enqueue that failed between rotate_sets and its launches)
+    if (c->n_sets == 3) std::swap(c->alt[0], c->alt[1]);
+    swap_with(c, c->alt[0]);
+}
+static void free_alt(b32_ctx* c, FrameSet& a) {          // (the caller has drained both streams)
     void* ptrs[] = { a.keys0, a.crecs, a.srecs, a.xrecs, a.spans, a.face_of, a.partials, a.shades, a.direct_lists, a.tile_fill };
     for (void* q : ptrs) if (q) (void)hipFree(q);
     a.keys0 = nullptr; a.crecs = nullptr; a.srecs = nullptr; a.xrecs = nullptr; a.spans = nullptr; a.face_of = nullptr; a.partials = nullptr;
     a.shades = nullptr; a.cap_shades = 0; a.direct_lists = nullptr; a.cap_direct = 0; a.tile_fill = nullptr; a.cap_tile_fill = 0; a.cap_work = 0;
 }
-// side stream, events and the second set's per-face buffers (sized like the current set's)
+// side stream, events and the other sets' per-face buffers (sized like the current set's)
 static int pipeline_ensure(b32_ctx* c) {
     if (!c->side) {
         // lowest priority: while the fill kernel has workgroups to place, they go first; the setup kernel takes what is left
@@ -247,28 +258,36 @@ static int pipeline_ensure(b32_ctx* c) {
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_setup, hipEventDisableTiming));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
-        HIPCHK(c, hipEventCreateWithFlags(&c->alt.ev_setup, hipEventDisableTiming));
-        HIPCHK(c, hipEventCreateWithFlags(&c->alt.ev_done, hipEventDisableTiming));
-    }
-    FrameSet& a = c->alt;
-    if (!a.d_ctrl) {
-        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&a.d_ctrl), sizeof(Ctrl) + sizeof(Stamps) + sizeof(Events)));
-        HIPCHK(c, hipMemsetAsync(a.d_ctrl, 0, sizeof(Ctrl) + sizeof(Stamps) + sizeof(Events), c->stream));
+        for (FrameSet& a : c->alt) {
+            HIPCHK(c, hipEventCreateWithFlags(&a.ev_setup, hipEventDisableTiming));
+            HIPCHK(c, hipEventCreateWithFlags(&a.ev_done, hipEventDisableTiming));
+        }
+        // the frames enqueued on the current set before the side stream existed recorded nothing: their fills end before this point of
+        // the main stream, which the first setup kernel on the side stream waits for (side_dirty) and the set's own event now marks too
+        HIPCHK(c, hipEventRecord(c->ev_done, c->stream));
         c->side_dirty = true;
     }
-    if (a.cap_work < c->cap_work || !a.crecs) {
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        free_alt(c);
-        const size_t n = c->cap_work;
-        int rc;
-        if ((rc = ensure_plain(c, a.keys0, n))) return rc;
-        if ((rc = ensure_plain(c, a.crecs, n))) return rc;
-        if ((rc = ensure_plain(c, a.srecs, n))) return rc;
-        if ((rc = ensure_plain(c, a.xrecs, n))) return rc;
-        if ((rc = ensure_plain(c, a.spans, n))) return rc;
-        if ((rc = ensure_plain(c, a.face_of, n))) return rc;
-        if ((rc = ensure_plain(c, a.partials, (size_t)((n + 255) / 256) * 8 + 8))) return rc;
-        a.cap_work = n;
+    for (uint32_t k = 0; k + 1 < c->n_sets; ++k) {
+        FrameSet& a = c->alt[k];
+        if (!a.d_ctrl) {
+            HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&a.d_ctrl), sizeof(Ctrl) + sizeof(Stamps) + sizeof(Events)));
+            HIPCHK(c, hipMemsetAsync(a.d_ctrl, 0, sizeof(Ctrl) + sizeof(Stamps) + sizeof(Events), c->stream));
+            c->side_dirty = true;
+        }
+        if (a.cap_work < c->cap_work || !a.crecs) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            free_alt(c, a);
+            const size_t n = c->cap_work;
+            int rc;
+            if ((rc = ensure_plain(c, a.keys0, n))) return rc;
+            if ((rc = ensure_plain(c, a.crecs, n))) return rc;
+            if ((rc = ensure_plain(c, a.srecs, n))) return rc;
+            if ((rc = ensure_plain(c, a.xrecs, n))) return rc;
+            if ((rc = ensure_plain(c, a.spans, n))) return rc;
+            if ((rc = ensure_plain(c, a.face_of, n))) return rc;
+            if ((rc = ensure_plain(c, a.partials, (size_t)((n + 255) / 256) * 8 + 8))) return rc;
+            a.cap_work = n;
+        }
     }
     return B32_OK;
 }
@@ -353,9 +372,8 @@ void b32_destroy(b32_ctx* c) {
     for (auto& r : c->merged_runs) if (r.merged) { void* mp[] = { r.merged->d_verts, r.merged->d_faces, r.merged->d_texels, r.merged->d_texels32, r.merged->d_tex,
                                                                     r.merged->d_consts, r.merged->d_texmask, r.merged->d_pos12 };
                                                    for (void* q : mp) if (q) (void)hipFree(q); delete r.merged; }
-    free_alt(c);
-    if (c->alt.d_ctrl) (void)hipFree(c->alt.d_ctrl);
-    for (hipEvent_t e : { c->ev_main, c->ev_setup, c->ev_done, c->alt.ev_setup, c->alt.ev_done }) if (e) (void)hipEventDestroy(e);
+    for (FrameSet& a : c->alt) { free_alt(c, a); if (a.d_ctrl) (void)hipFree(a.d_ctrl); }
+    for (hipEvent_t e : { c->ev_main, c->ev_setup, c->ev_done, c->alt[0].ev_setup, c->alt[0].ev_done, c->alt[1].ev_setup, c->alt[1].ev_done }) if (e) (void)hipEventDestroy(e);
     if (c->side) (void)hipStreamDestroy(c->side);
     if (c->ev_created) for (auto& fr : c->ev) for (auto& e : fr) if (e) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -1169,15 +1187,18 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     // the set swap and its event as well: 0.030 -> 0.028 ms on 20 k triangles at 320x240)
     if (c->frame_pending && c->pipe_hint && !c->redrawing && !fp.wire_collect && !prof_all && c->nf > 2048u && !(c->route_off & B32_ROUTE_PIPELINE)) {
         if ((rc = pipeline_ensure(c))) return rc;
-        swap_sets(c);
+        rotate_sets(c);
         c->pipelined = true;
     }
-    if ((rc = frame_lights(c, st, fp, lset))) return rc;
-    if ((rc = frame_buffers(c, fp, wire_back))) return rc;
+    // (an error return between the rotation and the launches puts the sets back: the pending frame stays the current set's)
+    bool rotated = c->pipelined;
+    auto fail = [&](int e) { if (rotated) { unrotate_sets(c); rotated = false; c->pipelined = false; } return e; };
+    if ((rc = frame_lights(c, st, fp, lset))) return fail(rc);
+    if ((rc = frame_buffers(c, fp, wire_back))) return fail(rc);
     hipEvent_t* ev = nullptr;
     if (prof_fill) {
         if (!c->ev_created) {
-            for (auto& fr : c->ev) for (auto& e : fr) HIPCHK(c, hipEventCreate(&e));
+            for (auto& fr : c->ev) for (auto& e : fr) if (hipEventCreate(&e) != hipSuccess) return fail(B32_E_HIP);
             c->ev_created = true;
         }
         ev = c->ev[c->ev_frames % EV_RING];
@@ -1185,7 +1206,7 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
 
     const SortScratch sc{ c->block_hist, c->hist_blocks, c->digit_total };
     Route r;
-    if ((rc = plan_route(c, fp, sc, wire_front, r))) return rc;
+    if ((rc = plan_route(c, fp, sc, wire_front, r))) return fail(rc);
     // (only large meshes: the frames of small ones are launch-latency bound and the cross-stream events cost them more than the overlap
     // returns -- a 12-room console frame 0.72 ms against 0.65; keyed routes have binning launches behind k_setup: one stream)
     const uint32_t ntiles = fp.tiles_x * fp.tiles_y;
@@ -1193,7 +1214,7 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     // between two kernels) then cost more than the overlap returns (C2, 100 k triangles at 320x240: 0.052 against 0.048 ms).  The merged
     // runs of a batched frame are the exception: their kernels leave most of the GPU idle anyway (75 tiles for 256 CUs).
     c->pipe_hint = r.direct_bin && (ntiles > 2u * (uint32_t)c->n_cu || c->frame_batched || (c->band_set && B32_PIPELINE_BANDS));
-    if (!c->pipe_hint) c->pipelined = false;
+    if (!c->pipe_hint) c->pipelined = false;       // (the frame keeps the set it rotated to -- the route's regions are that set's -- but runs on the main stream)
     c->last_local_sort = r.local_sort || r.want_prio64;                         // the global draw order is not materialised
     c->last_exact = r.ordered_all ? true : (r.exact_cov && !fp.zmode);          // the ordered walk counts every store it performs
     c->last_direct = r.direct_bin;
@@ -1202,7 +1223,7 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
         HIPCHK(c, hipMemsetAsync(&c->d_ctrl->fragments, 0, sizeof(unsigned long long), s));
     }
     const float *pos12 = nullptr, *attr12 = nullptr;
-    if ((rc = frame_positions(c, fp, pos12, attr12))) return rc;
+    if ((rc = frame_positions(c, fp, pos12, attr12))) return fail(rc);
 
     // ---- transform, cull, setup (+ tile binning of large meshes)
     hipStream_t ss = s;
@@ -1211,7 +1232,7 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
         HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_done, 0));     // the last fill that read this set (two frames ago)
         ss = c->side;
         c->pipelined_frames++;
-        if (c->gate_permille && c->last_cover_tiles && c->alt.d_ctrl) {
+        if (c->gate_permille && c->last_cover_tiles && c->alt[0].d_ctrl) {
             // The fused kernel's workgroups take their next tile from the cursor after the coverage of the current one: the cursor
             // passes tiles - groups when the last tile is handed out, and every fetch beyond that is a workgroup that found the queue
             // empty and has only the shading of its last tile left, i.e. is about to free its place on a CU.
@@ -1219,7 +1240,7 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
             const uint32_t pre = tiles > groups ? tiles - groups : 0u;      // cursor value when the last tile is handed out
             const uint32_t need = c->gate_permille > 1000u ? (uint32_t)((uint64_t)(c->gate_permille - 1000u) * pre / 1000u)
                                                            : pre + (uint32_t)((uint64_t)(c->gate_permille - 1u) * groups / 1000u);
-            if (need) launch_gate(ss, c->alt.d_ctrl, need, 30000u /* 300 us */);
+            if (need) launch_gate(ss, c->alt[0].d_ctrl, need, 30000u /* 300 us */);      // alt[0]: the frame n_sets - 1 back (rotate_sets)
         }
     }
     if (prof_all) HIPCHK(c, hipEventRecord(ev[0], s));
@@ -1414,19 +1435,21 @@ int b32_frame_finish(b32_ctx* c, B32Timings* out) {
     collect_events(c);
     uint32_t sticky = c->h_ctrl.sticky;                        // errors of every frame enqueued since the last finish
     if (sticky) HIPCHK(c, hipMemsetAsync(&c->d_ctrl->sticky, 0, sizeof(uint32_t), c->stream));
-    if (c->alt.in_flight && c->alt.d_ctrl) {
-        // two frames in flight: the frames of the other set since the last finish -- their sticky errors, and its last frame, which no
-        // later k_setup of that set has looked at: dropped (it ran out of list space and drew nothing) means lost
+    if (sticky) c->side_dirty = true;                           // (the next setup kernel on the side stream reads that word: after the memset)
+    for (FrameSet& o : c->alt) if (o.in_flight && o.d_ctrl) {
+        // several frames in flight: the frames of the other sets since the last finish -- their sticky errors, and each set's last frame,
+        // which no later k_setup of that set has looked at: dropped (it ran out of list space and drew nothing) means lost
         Ctrl other;
-        HIPCHK(c, hipMemcpy(&other, c->alt.d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost));      // (the main stream has drained)
-        c->alt.in_flight = false;
+        HIPCHK(c, hipMemcpy(&other, o.d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost));      // (the main stream has drained)
+        o.in_flight = false;
         uint32_t st2 = other.sticky;
         if (other.pairs_overflow || other.need_global_sort) st2 += 0x100u;
-        if (other.sticky) HIPCHK(c, hipMemsetAsync(&c->alt.d_ctrl->sticky, 0, sizeof(uint32_t), c->stream));
+        if (other.sticky) HIPCHK(c, hipMemsetAsync(&o.d_ctrl->sticky, 0, sizeof(uint32_t), c->stream));
         if (other.pairs_overflow || other.need_global_sort) {      // (not again at the next finish)
-            HIPCHK(c, hipMemsetAsync(&c->alt.d_ctrl->pairs_overflow, 0, sizeof(uint32_t), c->stream));
-            HIPCHK(c, hipMemsetAsync(&c->alt.d_ctrl->need_global_sort, 0, sizeof(uint32_t), c->stream));
+            HIPCHK(c, hipMemsetAsync(&o.d_ctrl->pairs_overflow, 0, sizeof(uint32_t), c->stream));
+            HIPCHK(c, hipMemsetAsync(&o.d_ctrl->need_global_sort, 0, sizeof(uint32_t), c->stream));
         }
+        if (other.sticky || other.pairs_overflow || other.need_global_sort) c->side_dirty = true;
         sticky = (sticky | (st2 & 0xFFu)) + (st2 & ~0xFFu);
     }
     if (c->deferred_rc) { const int d = c->deferred_rc; c->deferred_rc = 0; return d; }     // (an earlier mesh of this frame, settled by a swap)
@@ -1875,6 +1898,19 @@ extern "C" int b32_set_cheap_threshold(b32_ctx* c, uint32_t den) {
 extern "C" int b32_set_pipeline_gate(b32_ctx* c, uint32_t permille) {
     if (!c || permille > 2000u) return B32_E_ARG;
     c->gate_permille = permille;
+    return B32_OK;
+}
+extern "C" int b32_set_pipeline_depth(b32_ctx* c, uint32_t sets) {
+    if (!c || sets < 2u || sets > 3u) return B32_E_ARG;
+    if (sets == c->n_sets) return B32_OK;
+    (void)hipSetDevice(c->device);
+    // everything in flight ends first: the ring's order (alt[0] oldest) only means something for one depth
+    const int rc = b32_frame_finish(c, nullptr);
+    if (rc == B32_E_HIP || rc == B32_E_ARG) return rc;
+    if (rc && !c->deferred_rc) c->deferred_rc = rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->side) HIPCHK(c, hipStreamSynchronize(c->side));
+    c->n_sets = sets;
     return B32_OK;
 }
 extern "C" int b32_set_profiling_stride(b32_ctx* c, uint32_t every) {

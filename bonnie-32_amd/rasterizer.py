@@ -114,6 +114,10 @@ class Context:
         """b32_set_pipeline_gate: hold a pipelined setup kernel until the previous fill's tile cursor has come that far (include/b32raster.h)."""
         _chk(self.lib.b32_set_pipeline_gate(self.h, int(permille)), "b32_set_pipeline_gate")
 
+    def set_pipeline_depth(self, sets):
+        """b32_set_pipeline_depth: 2 or 3 frame sets -- the setup kernel one or two frames ahead of the fill (include/b32raster.h)."""
+        _chk(self.lib.b32_set_pipeline_depth(self.h, int(sets)), "b32_set_pipeline_depth")
+
     def set_routes(self, off_mask):
         """b32_set_routes: switch internal routes off (ROUTE_* bits); results are identical on every route."""
         _chk(self.lib.b32_set_routes(self.h, int(off_mask)), "b32_set_routes")

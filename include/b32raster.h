@@ -383,6 +383,14 @@ int b32_set_profiling_stride(b32_ctx* ctx, uint32_t every);
  *   0           : no hold.
  * Results are identical either way.  permille > 2000: B32_E_ARG. */
 int b32_set_pipeline_gate(b32_ctx* ctx, uint32_t permille);
+/* How far ahead of its fill a pipelined setup kernel runs (no reference counterpart; render.rs:2364-2547 is one sequential call):
+ *   sets = 2 (default): k_setup(i + 1) beside the fill of frame i -- the fill of frame i + 1 starts behind a cross-stream event that is
+ *             signalled only about when the fill before it ends (10-20 us per frame with little on the GPU);
+ *   sets = 3: k_setup(i + 2) beside the fill of frame i, on a third set of per-face buffers: the setup kernel a fill waits for ended
+ *             a whole fill earlier and fills run back to back on the main stream.  Measured on C3 (round 4): the hole closes, but the two
+ *             kernels then share every CU all the time and the frame is bound by their summed VALU work: 0.127 against 0.122 ms.
+ * Settles a pending frame first.  Results are identical either way.  Other values: B32_E_ARG. */
+int b32_set_pipeline_depth(b32_ctx* ctx, uint32_t sets);
 /* B32Timings.fragments (the reference's pixel-store count, render.rs:1671-1702) is instrumentation, not an output of
  * render_mesh_15.  on = 0 (default): not counted (B32Timings.fragments = 0 unless the textures force exact coverage); the fill
  * may then resolve opaque visibility without fetching the texel of every overdrawn fragment and without a global depth

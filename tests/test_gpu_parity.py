@@ -418,10 +418,24 @@ def test_pipeline_gate_argument_range():
         assert e.value.code == b32.abi.B32_E_ARG
 
 
-@pytest.mark.parametrize("gate,routes_off", [(1150, 0), (300, 0), (0, 0), (1000, 0), (2000, 0), (300, 64)])
-def test_two_frames_in_flight(oracle, gate, routes_off):
+def test_pipeline_depth_argument_range():
+    """b32_set_pipeline_depth: two or three frame sets, anything else is refused (include/b32raster.h)."""
+    from bonnie32_amd import rasterizer as R
+    ctx = R.Context(0)
+    for ok in (3, 2, 2, 3):
+        ctx.set_pipeline_depth(ok)
+    for bad in (0, 1, 4, 0xFFFFFFFF):
+        with pytest.raises(R.B32Error) as e:
+            ctx.set_pipeline_depth(bad)
+        assert e.value.code == b32.abi.B32_E_ARG
+
+
+@pytest.mark.parametrize("gate,routes_off,depth", [(1150, 0, 2), (300, 0, 2), (0, 0, 2), (1000, 0, 2), (2000, 0, 2), (300, 64, 2),
+                                                   (1150, 0, 3), (0, 0, 3), (1000, 0, 3), (300, 64, 3)])
+def test_two_frames_in_flight(oracle, gate, routes_off, depth):
     """Frames enqueued back to back run their setup kernel on the context's second stream, on the other frame set, beside the previous
-    frame's fill (B32_ROUTE_PIPELINE, b32_set_pipeline_gate).  Six frames of a large mesh (direct binning) with a moving camera in
+    frame's fill (B32_ROUTE_PIPELINE, b32_set_pipeline_gate) -- or, with three frame sets (b32_set_pipeline_depth), beside the fill of
+    the frame before that one.  Six frames of a large mesh (direct binning) with a moving camera in
     z-buffer mode without a clear in between -- colour AND depth accumulate, so every frame must have been drawn from its own records,
     in order -- then painter's frames with a clear each; and the same calls with a small mesh (whose frames stay on one stream)."""
     from bonnie32_amd import rasterizer as R
@@ -434,7 +448,7 @@ def test_two_frames_in_flight(oracle, gate, routes_off):
         for cam in cams:
             assert oracle.render_mesh_15(ofb, sc.vertices, sc.faces, sc.textures, cam, sc.settings)[0] == 0
         ctx = R.Context(0)
-        ctx.set_async_depth(deep); ctx.set_pipeline_gate(gate); ctx.set_routes(routes_off)
+        ctx.set_async_depth(deep); ctx.set_pipeline_gate(gate); ctx.set_routes(routes_off); ctx.set_pipeline_depth(depth)
         fb = R.Framebuffer(sc.width, sc.height, ctx); fb.clear(sc.clear_color)
         rs = R.ResidentScene(fb, sc.vertices, sc.faces, sc.textures)
         rs.render_async(cams[0], sc.settings); rs.finish()            # (deep mode: list regions settled by a first synchronous frame)

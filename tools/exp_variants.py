@@ -26,6 +26,8 @@ def one():
         ctx = R.Context(0); ctx.set_async_depth(1)
         if os.environ.get("EXP_GATE"):
             ctx.set_pipeline_gate(int(os.environ["EXP_GATE"]))
+        if os.environ.get("EXP_DEPTH"):
+            ctx.set_pipeline_depth(int(os.environ["EXP_DEPTH"]))
         if os.environ.get("EXP_ROUTES"):
             ctx.set_routes(int(os.environ["EXP_ROUTES"]))          # e.g. base@EXP_ROUTES=64: the product build without two frames in flight
         fb = R.Framebuffer(sc.width, sc.height, ctx)

@@ -12,6 +12,8 @@ def run(cfg, gate, routes):
     sc = scenegen.make_scene(cfg)
     ctx = R.Context(0); ctx.set_async_depth(1)
     ctx.set_pipeline_gate(gate)
+    if os.environ.get("EXP_DEPTH"):
+        ctx.set_pipeline_depth(int(os.environ["EXP_DEPTH"]))
     if routes:
         ctx.set_routes(routes)
     fb = R.Framebuffer(sc.width, sc.height, ctx)

@@ -148,7 +148,7 @@ def pipeline_case():
         assert O.render_mesh_15(ofb, sc.vertices, sc.faces, sc.textures, cam, st, None, fast=True)[0] == 0
     c2 = R.Context(0)
     try:
-        c2.set_async_depth(1); c2.set_pipeline_gate(int(rng.choice([0, 1, 300, 1000, 1150, 1600, 2000])))
+        c2.set_async_depth(1); c2.set_pipeline_gate(int(rng.choice([0, 1, 300, 1000, 1150, 1600, 2000]))); c2.set_pipeline_depth(int(rng.choice([2, 3])))
         c2.set_fragment_counting(int(rng.integers(2)))
         fb = R.Framebuffer(W, H, c2); fb.clear(sc.clear_color)
         rs = R.ResidentScene(fb, sc.vertices, sc.faces, sc.textures)
