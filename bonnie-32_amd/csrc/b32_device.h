@@ -239,23 +239,17 @@ struct WireTri { int32_t x[3], y[3]; float z[3]; uint32_t kind; };   // kind: 0 
 static_assert(sizeof(WireTri) == 40, "WireTri layout");
 
 // ---------------------------------------------------------------- Rust-semantics helpers (device)
-// `f as u32/usize` for the value ranges this path produces: NaN -> 0, negative -> 0, saturating.
-__device__ __forceinline__ uint32_t f2u_sat(float f) {
-    f = __builtin_fmaxf(f, 0.0f);                 // maxNum: NaN -> 0
-    f = __builtin_fminf(f, 4294967040.0f);
-    return (uint32_t)f;
-}
-__device__ __forceinline__ uint32_t f2u8_sat(float f) {
-    f = __builtin_fmaxf(f, 0.0f);
-    f = __builtin_fminf(f, 255.0f);
-    return (uint32_t)f;
-}
-__device__ __forceinline__ int32_t f2i32_sat(float f) {
-    if (f != f) return 0;
-    if (f >= 2147483648.0f) return INT32_MAX;
-    if (f <= -2147483648.0f) return INT32_MIN;
-    return (int32_t)f;
-}
+// Rust's `f as i32` / `f as u32` (NaN -> 0, out of range -> saturate, truncation toward zero) IS what gfx950's conversion instructions
+// do: v_cvt_i32_f32 / v_cvt_u32_f32 clamp and map NaN to 0 in hardware.  C++'s cast is undefined there, so the compiler may not assume it
+// and the explicit compare / select chains cost ~8 instructions and two exec-mask branches per conversion (nine of them per face in
+// k_setup): the instruction is named directly.  b32_selftest_f32 ops 5 / 6 prove the semantics on the device
+// (tests/test_gpu_parity.py::test_device_f32_semantics).
+__device__ __forceinline__ int32_t hw_cvt_i32(float f) { int32_t r; asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(f)); return r; }
+__device__ __forceinline__ uint32_t hw_cvt_u32(float f) { uint32_t r; asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(f)); return r; }
+// `f as u32/usize`: NaN -> 0, negative -> 0, saturating (a usize beyond u32 only ever meets a `.min(width - 1)` or an empty-box test)
+__device__ __forceinline__ uint32_t f2u_sat(float f) { return hw_cvt_u32(f); }
+__device__ __forceinline__ uint32_t f2u8_sat(float f) { return min(hw_cvt_u32(f), 255u); }
+__device__ __forceinline__ int32_t f2i32_sat(float f) { return hw_cvt_i32(f); }
 // f32::min / f32::max ignore NaN == IEEE minNum/maxNum == fminf/fmaxf.
 __device__ __forceinline__ float rmin(float a, float b) { return __builtin_fminf(a, b); }
 __device__ __forceinline__ float rmax(float a, float b) { return __builtin_fmaxf(a, b); }

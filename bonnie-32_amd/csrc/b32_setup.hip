@@ -26,7 +26,7 @@ __constant__ UnrTable g_unr = make_unr();
 __device__ __forceinline__ int32_t wadd(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
 __device__ __forceinline__ int32_t wsub(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
 __device__ __forceinline__ int32_t fx_from_f32(float f) { return f2i32_sat(f * K::ONE_F); }           // fixed.rs:125-127
-__device__ __forceinline__ int32_t fx_mul(int32_t a, int32_t b) { return (int32_t)(((int64_t)a * (int64_t)b) >> K::FRAC_BITS); }  // :161-165
+__device__ __forceinline__ int32_t fx_mul(int32_t a, int32_t b) { return (int32_t)(((int64_t)a * (int64_t)b) >> K::FRAC_BITS); }  // :161-165 (v_mad_i64_i32 + v_alignbit_b32)
 // Fixed32::div_unr, fixed.rs:178-230, split at the point where only the divisor has been used: project_to_screen divides x and
 // y by the same denominator (fixed.rs:411-412), so the table lookup and both Newton steps are done once per vertex.
 struct UnrRecip { uint64_t nr2; uint32_t shift; bool neg, zero; };
@@ -680,6 +680,9 @@ __global__ void k_selftest(int op, const float* a, const float* b, const float* 
         case 1: r = a[i] / b[i]; break;                 // correctly rounded
         case 2: r = __builtin_sqrtf(a[i]); break;       // correctly rounded
         case 4: r = acosf_musl(a[i]); break;            // f32::acos of the reference's wasm32 target (spot lights)
+        case 5: r = __int_as_float(f2i32_sat(a[i])); break;                  // Rust `as i32`: the bits of the result
+        case 6: r = __uint_as_float(f2u_sat(a[i])); break;                   // Rust `as u32`
+        case 7: r = __int_as_float(fx_mul(__float_as_int(a[i]), __float_as_int(b[i]))); break;   // Fixed32::mul_fixed on the operands' bits
         default: r = (a[i] + b[i]) / c[i]; break;
     }
     out[i] = r;

@@ -350,7 +350,9 @@ int b32_project_fixed_batch(b32_ctx* ctx, const float* pos_xyz, uint32_t n,
 int b32_last_draw_order(b32_ctx* ctx, uint32_t* face_idx, uint32_t cap, uint32_t* n);
 /* IEEE-754 f32 self-test of the device arithmetic the pipeline relies on (no FMA contraction,
  * correctly rounded / and sqrt, denormals kept): evaluates op(a[i], b[i], c[i]) on the GPU.
- * op: 0 a*b+c (two roundings), 1 a/b, 2 sqrt(a), 3 (a+b)/c, 4 acos(a) as the lighting code computes it (render.rs:1049). */
+ * op: 0 a*b+c (two roundings), 1 a/b, 2 sqrt(a), 3 (a+b)/c, 4 acos(a) as the lighting code computes it (render.rs:1049),
+ * 5 / 6 the bits of `a as i32` / `a as u32` with Rust's semantics (NaN -> 0, saturating; fixed.rs:126, render.rs:1455-1458, 1618),
+ * 7 Fixed32::mul_fixed (fixed.rs:161-165) on the operands' bit patterns. */
 int b32_selftest_f32(b32_ctx* ctx, int op, const float* a, const float* b, const float* c,
                      float* out, uint32_t n);
 

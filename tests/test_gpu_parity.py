@@ -51,6 +51,26 @@ def test_device_f32_semantics(gpu_ctx):
         assert np.array_equal(gpu_ctx.selftest_f32(1, a, b, c), a / b)
         assert np.array_equal(gpu_ctx.selftest_f32(2, np.abs(a), b, c), np.sqrt(np.abs(a)))
         assert np.array_equal(gpu_ctx.selftest_f32(3, a, b, c), (a + b) / c)
+    # Rust's `as i32` / `as u32` (NaN -> 0, saturating, toward zero) are gfx950's v_cvt_i32_f32 / v_cvt_u32_f32 as the kernels use them
+    edge = np.array([np.nan, -np.nan, np.inf, -np.inf, 2147483648.0, 2147483520.0, -2147483648.0, -2147483904.0, 4294967296.0, 4294967040.0,
+                     -0.0, 0.0, 0.99999994, -0.99999994, -1.0, 1.5, -1.5, 255.99998, 256.0, 1e-40, -1e-40, 3e9, -3e9, 1e30, -1e30, 16777217.0,
+                     8388607.5, -8388607.5], dtype=np.float32)
+    x = np.concatenate([edge, (rng.standard_normal(4096) * 3e9).astype(np.float32), (rng.standard_normal(4096) * 70000).astype(np.float32)])
+    with np.errstate(all="ignore"):
+        x64 = x.astype(np.float64)
+        want_i = np.where(np.isnan(x64), 0, np.clip(np.trunc(np.nan_to_num(x64, nan=0.0, posinf=1e300, neginf=-1e300)), -2147483648.0, 2147483647.0)).astype(np.int64)
+        want_u = np.where(np.isnan(x64), 0, np.clip(np.trunc(np.nan_to_num(x64, nan=0.0, posinf=1e300, neginf=-1e300)), 0.0, 4294967295.0)).astype(np.int64)
+    assert np.array_equal(gpu_ctx.selftest_f32(5, x, x, x).view(np.int32).astype(np.int64), want_i)
+    assert np.array_equal(gpu_ctx.selftest_f32(6, x, x, x).view(np.uint32).astype(np.int64), want_u)
+    # Fixed32::mul_fixed (fixed.rs:161-165) on raw words: bits 12 .. 43 of the signed 64-bit product
+    ia = np.concatenate([np.array([0, 1, -1, 4096, -4096, 2147483647, -2147483648, 2147483647, -2147483648, 123456789], dtype=np.int64),
+                         rng.integers(-2**31, 2**31, 8192)])
+    ib = np.concatenate([np.array([5, -1, -1, 4096, 4096, 2147483647, -2147483648, -2147483648, 1, -987654321], dtype=np.int64),
+                         rng.integers(-2**31, 2**31, 4096), rng.integers(-5000, 5000, 4096)])
+    prod = [(int(p) * int(q)) >> 12 for p, q in zip(ia, ib)]
+    want_m = np.array([((v + 2**31) % 2**32) - 2**31 for v in prod], dtype=np.int64)
+    got_m = gpu_ctx.selftest_f32(7, ia.astype(np.int32).view(np.float32), ib.astype(np.int32).view(np.float32), x[:len(ia)])
+    assert np.array_equal(got_m.view(np.int32).astype(np.int64), want_m)
 
 
 def test_device_constants_are_the_reference_text(gpu_ctx):
