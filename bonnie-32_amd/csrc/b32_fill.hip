@@ -175,6 +175,43 @@ __device__ __forceinline__ uint32_t shade15(uint32_t texel, float bcx, float bcy
     return (q[0] << K::C15_R_SHIFT) | (q[1] << K::C15_G_SHIFT) | q[2] | (((texel & K::C15_SEMI_BIT) || all_black) ? K::C15_SEMI_BIT : 0u);
 }
 
+// The same colour pipeline for TWO pixels at once (the fused kernel shades two pixels per lane), no shading pass (RasterSettings.shading
+// == None: the shade factor is x1.0, render.rs:1629-1645).  The arithmetic is the reference's, value for value; only the instructions are
+// packed -- the vertex-colour interpolation as v_pk_mul_f32 / v_pk_add_f32 over the pair (two f32 roundings per product and sum as in the
+// scalar form: contraction is off), the integer tail on 16-bit halves (v_pk_mul_lo_u16 ...: tex8 * vert <= 255 * 255 fits 16 bits).
+// A surface without needs_dither quantises with `>> 3`, which is the dither formula with offset 0: (m + 0) >> 3 <= 31 for m <= 255.
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef unsigned short v2us __attribute__((ext_vector_type(2)));
+typedef short v2ss __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void shade15_pair_rgba(uint32_t texelA, uint32_t texelB, const float bcA[3], const float bcB[3], const uint32_t vcA[3],
+                                                  const uint32_t vcB[3], uint32_t flagsA, uint32_t flagsB, uint32_t px, uint32_t pyA, uint32_t pyB,
+                                                  uint32_t& outA, uint32_t& outB) {
+    const v2f bcx = { bcA[0], bcB[0] }, bcy = { bcA[1], bcB[1] }, bcz = { bcA[2], bcB[2] };
+    const int offA = (flagsA & F_DITHER) ? dither_offset(px, pyA) : 0, offB = (flagsB & F_DITHER) ? dither_offset(px, pyB) : 0;
+    const v2ss off = { (short)offA, (short)offB };
+    const v2us tx = { (unsigned short)texelA, (unsigned short)texelB };
+    v2us e[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const unsigned short sh = (unsigned short)(i == 0 ? K::C15_R_SHIFT : (i == 1 ? K::C15_G_SHIFT : 0u));
+        const v2us c5 = (tx >> sh) & (unsigned short)K::C15_CHANNEL_MAX;
+        const v2us tex8 = ((c5 << (unsigned short)K::EXPAND5_SHL) | (c5 >> (unsigned short)K::EXPAND5_SHR));          // expand_5_to_8 :1161-1163 (<= 255)
+        const v2f f1 = { (float)((vcA[0] >> (8 * i)) & 255), (float)((vcB[0] >> (8 * i)) & 255) };
+        const v2f f2 = { (float)((vcA[1] >> (8 * i)) & 255), (float)((vcB[1] >> (8 * i)) & 255) };
+        const v2f f3 = { (float)((vcA[2] >> (8 * i)) & 255), (float)((vcB[2] >> (8 * i)) & 255) };
+        const v2f acc = bcx * f1 + bcy * f2 + bcz * f3;                                                              // :1618-1620
+        const v2us vert = { (unsigned short)f2u8_sat(acc.x), (unsigned short)f2u8_sat(acc.y) };
+        const v2us m = __builtin_elementwise_min((v2us)((tex8 * vert) >> (unsigned short)7), (v2us){ (unsigned short)K::MOD_MAX, (unsigned short)K::MOD_MAX });   // / 128, .min(255) :1624-1626
+        v2ss q = (__builtin_bit_cast(v2ss, m) + off) >> (short)K::DITHER_SHIFT;                                       // dither_and_quantize :1173-1182
+        q = __builtin_elementwise_min(__builtin_elementwise_max(q, (v2ss){ (short)K::DITHER_LO, (short)K::DITHER_LO }), (v2ss){ (short)K::DITHER_HI, (short)K::DITHER_HI });
+        const v2us qu = __builtin_bit_cast(v2us, q);
+        e[i] = (qu << (unsigned short)K::EXPAND5_SHL) | (qu >> (unsigned short)K::EXPAND5_SHR);                      // Color15::to_rgba types.rs:220-226 (see shade15<true>)
+    }
+    outA = (uint32_t)e[0].x | ((uint32_t)e[1].x << 8) | ((uint32_t)e[2].x << 16) | 0xFF000000u;
+    outB = (uint32_t)e[0].y | ((uint32_t)e[1].y << 8) | ((uint32_t)e[2].y << 16) | 0xFF000000u;
+}
+static_assert(K::MOD_DIV == 128 && K::MOD_MAX == 255 && K::DITHER_SHIFT == K::NODITHER_SHIFT, "shade15_pair_rgba: / 128 as a shift, no-dither == offset 0");
+
 // Pixel store of the transparent pass in painter's mode (render.rs:1674-1680, 1695-1702) on an RGBA8 word.
 __device__ __forceinline__ uint32_t store_blend(uint32_t back, uint32_t out15, uint32_t flags, bool xray) {
     const uint32_t mode = (flags >> F_BLEND_SHIFT) & 7u, alpha = flags >> F_ALPHA_SHIFT;
@@ -1543,8 +1580,18 @@ __device__ __forceinline__ void shade_tile_p64(const FillArgs& a, const uint32_t
             okB = okB && hit_finish<FMT8>(hB.flags, taB, fB, hB.texel);
             // (a covered pixel whose winner is skipped waits in the queue; everything else is final)
             mA = __ballot(cA && !okA); mB = __ballot(cB && !okB);
-            if (!(cA && !okA)) put(px, pyA, okA, hA, tA, inA);
-            if (!(cB && !okB)) put(px, pyB, okB, hB, tB, inB);
+            if (!FMT8 && !ZMODE && shading == B32_SHADE_NONE) {
+                // both colours in one packed pipeline (the results of lanes without a drawn pixel are never stored)
+                const float bA[3] = { hA.bcx, hA.bcy, hA.bcz }, bB[3] = { hB.bcx, hB.bcy, hB.bcz };
+                const uint32_t vA[3] = { hA.vc1, hA.vc2, hA.vc3 }, vB[3] = { hB.vc1, hB.vc2, hB.vc3 };
+                uint32_t colA, colB;
+                shade15_pair_rgba(hA.texel, hB.texel, bA, bB, vA, vB, hA.flags, hB.flags, px, pyA, pyB, colA, colB);
+                if (okA) a.fb[(size_t)pyA * W + px] = colA; else if (!cA && inA && a.clear_on) a.fb[(size_t)pyA * W + px] = a.clear_rgba;
+                if (okB) a.fb[(size_t)pyB * W + px] = colB; else if (!cB && inB && a.clear_on) a.fb[(size_t)pyB * W + px] = a.clear_rgba;
+            } else {
+                if (!(cA && !okA)) put(px, pyA, okA, hA, tA, inA);
+                if (!(cB && !okB)) put(px, pyB, okB, hB, tB, inB);
+            }
         }
         if (mA | mB) {
 #pragma unroll

@@ -52,8 +52,13 @@ __device__ __forceinline__ int32_t unr_apply(int32_t self, const UnrRecip& r) {
     const uint64_t num = (uint64_t)(self < 0 ? (0u - (uint32_t)self) : (uint32_t)self);
     const uint64_t raw = num * r.nr2;
     const uint64_t mag = (raw + (1ull << (r.shift - 1))) >> r.shift;
-    const int32_t clamped = (int32_t)(mag < (uint64_t)INT32_MAX ? mag : (uint64_t)INT32_MAX);
-    return neg ? -clamped : clamped;
+    // mag.min(i32::MAX) in 32 bits (mag >= 2^31 clamps, mag == 2^31 - 1 is the clamp value itself); the empty asm keeps the compiler from
+    // carrying the result as a sign-extended 64-bit value into the next mul_fixed (a 64 x 64 multiply of five instructions instead of
+    // v_mad_i64_i32, and 64-bit selects / negation here)
+    const uint32_t m32 = (uint32_t)(mag >> 31) ? 0x7FFFFFFFu : (uint32_t)mag;
+    int32_t r32 = neg ? -(int32_t)m32 : (int32_t)m32;
+    asm("" : "+v"(r32));
+    return r32;
 }
 __device__ __forceinline__ int32_t fx_div_unr(int32_t self, int32_t divisor) { return unr_apply(self, unr_recip(divisor, g_unr.v)); }
 
