@@ -73,6 +73,7 @@ struct b32_ctx {
     bool blend8 = false;                // 8-bit path: some texel blends or some face has editor_alpha < 255 -> ordered walk
     TexDesc* d_tex = nullptr; size_t cap_tex = 0;
     std::vector<TexDesc> h_tex;
+    uint8_t* d_atlas0 = nullptr; size_t cap_atlas0 = 0; uint32_t atlas_idx_bytes = 0;   // indexed upload of ONE texture: CLUT (512 B) + index bytes, kept for the LDS route
     uint32_t* d_texmask = nullptr; size_t cap_texmask = 0;       // skip mask of the texel pool (FillArgs.texmask), rebuilt when the pool changes
     uint32_t pool_texels = 0; bool mask_dirty = true;
     uint32_t nv = 0, nf = 0, nt = 0;
@@ -123,6 +124,7 @@ struct b32_ctx {
     // painter's mode on the same band, else by a clear launch before whatever touches the framebuffer next (flush_clear)
     bool clear_pending = false; uint32_t clear_rgba = 0, clear_y0 = 0, clear_y1 = 0;
     unsigned long long routes[8] = {};                            // b32_route_count
+    unsigned long long lds_atlas_frames = 0;
     uint32_t *pkeys[2] = { nullptr, nullptr }, *pvals[2] = { nullptr, nullptr };
     // sort scratch
     uint32_t* block_hist = nullptr; uint32_t hist_blocks = 0; uint32_t* digit_total = nullptr;
@@ -181,6 +183,7 @@ struct b32_scene {
     TexDesc* d_tex = nullptr; size_t cap_tex = 0;
     uint32_t* d_consts = nullptr;
     uint32_t* d_texmask = nullptr; size_t cap_texmask = 0; uint32_t pool_texels = 0; bool mask_dirty = true;
+    uint8_t* d_atlas0 = nullptr; size_t cap_atlas0 = 0; uint32_t atlas_idx_bytes = 0;
     std::vector<TexDesc> h_tex;
     uint32_t nv = 0, nf = 0, nt = 0;
     unsigned long long gen = 0;
@@ -366,11 +369,11 @@ void b32_destroy(b32_ctx* c) {
     void* ptrs[] = { c->fb_own, c->d_verts, c->d_faces, c->d_texels, c->d_tex, c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->crecs, c->srecs, c->xrecs,
                      c->shades, c->counts, c->block_sums, c->pkeys[0], c->pkeys[1], c->pvals[0], c->pvals[1], c->block_hist, c->ranges,
                      c->d_ctrl, c->d_consts, c->d_lights, c->digit_total, c->partials, c->vis, c->spans, c->tile_mid, c->zbuf,
-                     c->wire, c->wire_owner, c->wire_first, c->d_texels32, c->inline_lists, c->d_texmask, c->direct_lists, c->tile_fill, c->d_pos12, c->face_of };
+                     c->wire, c->wire_owner, c->wire_first, c->d_texels32, c->inline_lists, c->d_texmask, c->direct_lists, c->tile_fill, c->d_pos12, c->face_of, c->d_atlas0 };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->side) (void)hipStreamSynchronize(c->side);
     for (auto& r : c->merged_runs) if (r.merged) { void* mp[] = { r.merged->d_verts, r.merged->d_faces, r.merged->d_texels, r.merged->d_texels32, r.merged->d_tex,
-                                                                    r.merged->d_consts, r.merged->d_texmask, r.merged->d_pos12 };
+                                                                    r.merged->d_consts, r.merged->d_texmask, r.merged->d_pos12, r.merged->d_atlas0 };
                                                    for (void* q : mp) if (q) (void)hipFree(q); delete r.merged; }
     for (FrameSet& a : c->alt) { free_alt(c, a); if (a.d_ctrl) (void)hipFree(a.d_ctrl); }
     for (hipEvent_t e : { c->ev_main, c->ev_setup, c->ev_done, c->alt[0].ev_setup, c->alt[0].ev_done, c->alt[1].ev_setup, c->alt[1].ev_done }) if (e) (void)hipEventDestroy(e);
@@ -710,6 +713,7 @@ static int layout_textures(b32_ctx* c, uint32_t nt, const uint32_t* w, const uin
     if (nt > 65534) return B32_E_UNSUPPORTED;        // the surface record holds the texture slot in 16 bits
     c->h_tex.resize(nt);
     c->tex_blend_any = false;
+    c->atlas_idx_bytes = 0;                         // (only b32_scene_upload_indexed with one texture keeps the index atlas)
     size_t off = 0;
     for (uint32_t i = 0; i < nt; ++i) {
         if (w[i] > 65535 || h[i] > 65535) return B32_E_ARG;
@@ -855,8 +859,22 @@ int b32_scene_upload_indexed(b32_ctx* c, const B32Vertex* v, uint32_t nv, const 
         // the expansion kernel also counts the texels the black_transparent rule can skip (no walk over the texels on the host)
         uint8_t* d_idx = nullptr; uint16_t* d_clut = nullptr; uint32_t* d_cnt = nullptr;
         Scratch tmp(c);
-        if ((rc = tmp.upload(tex[i].indices, n, &d_idx))) return rc;
-        if ((rc = tmp.upload(tex[i].clut, (size_t)tex[i].clut_len, &d_clut))) return rc;
+        // ONE texture with at most 256 palette entries: index bytes and CLUT stay on the device behind each other -- 256 Color15 entries
+        // (zero behind the palette, which is what Clut::lookup returns for an index past it, types.rs:390-397), then the indices -- so that
+        // the fused kernel can stage them in LDS (B32_ROUTE_LDS_ATLAS); the expansion below reads the same copies
+        const bool keep = nt == 1 && tex[i].clut_len <= 256u && n <= (160u << 10);
+        if (keep) {
+            if ((rc = ensure(c, c->d_atlas0, c->cap_atlas0, (size_t)ATLAS_CLUT_BYTES + n + 32))) return rc;
+            HIPCHK(c, hipMemsetAsync(c->d_atlas0, 0, ATLAS_CLUT_BYTES, c->stream));
+            if ((rc = h2d(c, c->d_atlas0, tex[i].clut, (size_t)tex[i].clut_len * 2))) return rc;
+            if ((rc = h2d(c, c->d_atlas0 + ATLAS_CLUT_BYTES, tex[i].indices, n))) return rc;
+            HIPCHK(c, hipMemsetAsync(c->d_atlas0 + ATLAS_CLUT_BYTES + n, 0, 32, c->stream));      // (the staging copy reads whole 16-byte quads)
+            d_clut = reinterpret_cast<uint16_t*>(c->d_atlas0); d_idx = c->d_atlas0 + ATLAS_CLUT_BYTES;
+            c->atlas_idx_bytes = (uint32_t)n;
+        } else {
+            if ((rc = tmp.upload(tex[i].indices, n, &d_idx))) return rc;
+            if ((rc = tmp.upload(tex[i].clut, (size_t)tex[i].clut_len, &d_clut))) return rc;
+        }
         if ((rc = tmp.alloc(&d_cnt, 1))) return rc;
         HIPCHK(c, hipMemsetAsync(d_cnt, 0, 4, c->stream));
         launch_expand_indexed(c->stream, d_idx, (uint32_t)n, d_clut, tex[i].clut_len, c->d_texels + c->h_tex[i].offset, d_cnt);
@@ -1167,6 +1185,16 @@ static FillArgs fill_args(const b32_ctx* c, const FrameParams& fp, const Route& 
     fa.direct_bin = r.direct_bin ? 1u : 0u; fa.tile_fill = c->tile_fill; fa.epoch = c->epoch;
     if (r.direct_bin) fa.pair_vals = c->direct_lists;
     fa.gather_blend = (r.prio64 && r.with_class) ? 1u : 0u;
+    // index atlas + CLUT sampled from LDS: the fused kernel with one indexed texture, when they fit beside the tile planes of the
+    // workgroup form launch_fill is going to choose (16 waves, one workgroup per CU: ~84 KB; two 8-wave workgroups per CU: ~6 KB)
+    fa.atlas0 = c->d_atlas0; fa.atlas_idx_bytes = 0;
+    if (r.prio64 && !c->fmt8 && c->nt == 1 && c->atlas_idx_bytes && !(c->route_off & B32_ROUTE_LDS_ATLAS)) {
+        bool wide = fp.tiles_x * fp.tiles_y <= (uint32_t)c->n_cu && !(c->route_off & B32_ROUTE_WIDE_GROUPS);
+#ifdef B32_EXP_LDS_ATLAS
+        wide = true;                     // (experiment build: launch_p64 sends the plain frame through the 16-wave form)
+#endif
+        if (c->atlas_idx_bytes + ATLAS_CLUT_BYTES + 16u <= fill_lds_atlas_room(wide)) fa.atlas_idx_bytes = c->atlas_idx_bytes;
+    }
     if (c->fmt8) fa.fp.xray = 0;                        // render_mesh: x-ray only changes culling; its stores keep their own depth tests
     return fa;
 }
@@ -1293,6 +1321,7 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
             fa.clear_on = 1; fa.clear_rgba = c->clear_rgba; fa.clear_depth = (has_z && fp.zmode) ? 1u : 0u; c->clear_pending = false;
         } else if ((rc = flush_clear(c))) return rc;
     }
+    if (fa.atlas_idx_bytes && !wire_front && !r.ordered_all) c->lds_atlas_frames++;
     launch_fill(s, fa, c->n_cu, prof_fill ? ev[4] : nullptr);
 
     // ---- wireframe phases
@@ -1495,7 +1524,7 @@ void b32_scene_destroy(b32_ctx* c, b32_scene* sl) {
     if (!c || !sl) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    void* ptrs[] = { sl->d_verts, sl->d_faces, sl->d_texels, sl->d_texels32, sl->d_tex, sl->d_consts, sl->d_texmask, sl->d_pos12 };
+    void* ptrs[] = { sl->d_verts, sl->d_faces, sl->d_texels, sl->d_texels32, sl->d_tex, sl->d_consts, sl->d_texmask, sl->d_pos12, sl->d_atlas0 };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete sl;
 }
@@ -1513,6 +1542,7 @@ int b32_scene_swap(b32_ctx* c, b32_scene* sl) {
     std::swap(c->d_consts, sl->d_consts);
     std::swap(c->d_texmask, sl->d_texmask); std::swap(c->cap_texmask, sl->cap_texmask); std::swap(c->pool_texels, sl->pool_texels);
     std::swap(c->mask_dirty, sl->mask_dirty);
+    std::swap(c->d_atlas0, sl->d_atlas0); std::swap(c->cap_atlas0, sl->cap_atlas0); std::swap(c->atlas_idx_bytes, sl->atlas_idx_bytes);
     c->h_tex.swap(sl->h_tex);
     std::swap(c->nv, sl->nv); std::swap(c->nf, sl->nf); std::swap(c->nt, sl->nt);
     std::swap(c->fmt8, sl->fmt8); std::swap(c->blend8, sl->blend8); std::swap(c->have_scene, sl->have_scene); std::swap(c->gen, sl->gen); std::swap(c->blend_faces, sl->blend_faces);
@@ -1540,7 +1570,7 @@ int b32_scene_swap(b32_ctx* c, b32_scene* sl) {
 // The merged mesh (vertices, faces with the member number in their spare byte, texel pool, texture descriptors) is built on the device
 // from the slots and kept while the members' contents stay the same.
 static void release_scene_buffers(b32_scene* sl) {
-    void* ptrs[] = { sl->d_verts, sl->d_faces, sl->d_texels, sl->d_texels32, sl->d_tex, sl->d_consts, sl->d_texmask, sl->d_pos12 };
+    void* ptrs[] = { sl->d_verts, sl->d_faces, sl->d_texels, sl->d_texels32, sl->d_tex, sl->d_consts, sl->d_texmask, sl->d_pos12, sl->d_atlas0 };
     for (void* p : ptrs) if (p) (void)hipFree(p);
 }
 static int build_merged(b32_ctx* c, const b32_ctx::BatchEntry* e, uint32_t n, b32_scene* m) {
@@ -1863,6 +1893,7 @@ extern "C" int b32_set_fragment_counting(b32_ctx* c, int on) {
 }
 extern "C" unsigned long long b32_route_count(const b32_ctx* c, int which) {
     if (c && which == 7) return c->pipelined_frames;
+    if (c && which == 8) return c->lds_atlas_frames;
     return (c && which >= 0 && which < 8) ? c->routes[which] : 0ull;
 }
 extern "C" int b32_set_async_depth(b32_ctx* c, int deep) {

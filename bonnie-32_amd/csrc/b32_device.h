@@ -482,6 +482,11 @@ struct FillArgs {
     uint32_t clear_on, clear_rgba;
     uint32_t clear_depth;       // with clear_on in z-buffer mode: the clear resets the depth buffer too (every depth f32::MAX, render.rs:43)
     uint32_t narrow_only;       // 1: never the 16-wave workgroups of the fused kernel (b32_set_routes)
+    // One indexed texture (b32_scene_upload_indexed, nt == 1): 256 CLUT entries (zero behind the palette: an index past it looks up 0x0000,
+    // Clut::lookup types.rs:390-397) followed by width * height index bytes.  atlas_idx_bytes > 0: every workgroup of the fused kernel
+    // stages both in LDS behind its tile planes and the shading phase looks the texel up there instead of fetching the expanded texel
+    const uint8_t* atlas0;
+    uint32_t atlas_idx_bytes;
     uint32_t prio64;            // 1: sort-free coverage -- visibility is a 64-bit max of (painter's key << 32 | face id); `vis` holds
                                 //    two words per pixel: winner face id + 1, runner-up face id + 1 (0 = none)
 #ifdef B32_TIMELINE
@@ -490,5 +495,8 @@ struct FillArgs {
 };
 void launch_fill(hipStream_t s, const FillArgs& a, int n_cu, hipEvent_t after_cover = nullptr);   // k_cover [event] k_shade k_blend
 size_t fill_lds_tex_budget();   // bytes of LDS left for a staged texture
+constexpr uint32_t ATLAS_CLUT_BYTES = 512;   // 256 Color15 entries in front of the index bytes
+// LDS left for a staged index atlas (CLUT included) in the fused kernel: wide = 16-wave workgroups, one per CU; else two 8-wave workgroups
+uint32_t fill_lds_atlas_room(bool wide);
 
 }  // namespace b32

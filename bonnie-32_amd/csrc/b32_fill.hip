@@ -1030,7 +1030,8 @@ __device__ void tile_local_sort(uint32_t* sort_area, uint32_t* wcnt, uint32_t* d
 // ------------------------------------------------------------------------------------------------ k_cover
 template <bool FMT8, int NT, bool ZMODE>
 __device__ __forceinline__ void shade_tile_p64(const FillArgs& a, const uint32_t* tilebuf, uint32_t e0, uint32_t e1, uint32_t x_lo, uint32_t x_hi,
-                                               uint32_t y_lo, uint32_t y_hi, uint32_t ty_top, uint32_t tid, uint32_t lane, uint32_t TH, uint32_t* rq);
+                                               uint32_t y_lo, uint32_t y_hi, uint32_t ty_top, uint32_t tid, uint32_t lane, uint32_t TH, uint32_t* rq,
+                                               const uint8_t* latlas);
 
 // k_setup's per-block counters (visible, transparent, NaN keys per class, bad vertex index) -> the frame's abort decision in misc[6]
 // (the reference panics before drawing on a bad vertex index, render.rs:2375, or when a sort comparison sees NaN, render.rs:2531);
@@ -1100,6 +1101,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PLAIN ? 2 : 
     // these into FLAT accesses with a full vmcnt wait each)
     uint32_t* misc = reinterpret_cast<uint32_t*>(smem + TB);   // [0] tile, [2] list cursor
     uint32_t* wmarks = reinterpret_cast<uint32_t*>(smem + TB + LDS_MISC_BYTES);
+    // sort-free forms: 64 words of repair queue per wave, then (optionally) the staged index atlas
+    const uint8_t* latlas = nullptr;
+    if (P64 && !FMT8 && a.atlas_idx_bytes) {
+        uint4* dst = reinterpret_cast<uint4*>(smem + TB + LDS_MISC_BYTES + NW * 256);
+        const uint4* src = reinterpret_cast<const uint4*>(a.atlas0);
+        const uint32_t nq = (ATLAS_CLUT_BYTES + a.atlas_idx_bytes + 15u) / 16u;
+        for (uint32_t i = threadIdx.x; i < nq; i += NT) dst[i] = src[i];
+        latlas = reinterpret_cast<const uint8_t*>(dst);           // (first read behind the tile loop's barriers)
+    }
     const uint16_t* ltex = reinterpret_cast<const uint16_t*>(smem + LDS_TEX_OFFSET);    // LDS texture (TEXMODE 1) or LDS skip mask (P64 EXACT)
     uint32_t* sort_cnt = reinterpret_cast<uint32_t*>(smem + LDS_TEX_OFFSET);        // local sort only exists without an LDS texture
 
@@ -1295,7 +1305,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PLAIN ? 2 : 
 #ifdef B32_TIMELINE
             const unsigned long long tl1 = wall_clock64();
 #endif
-            if (n_op) shade_tile_p64<FMT8, NT, ZMODE>(a, tilebuf, e0, e1, x_lo, x_hi, y_lo, y_hi, ty_top, tid, lane, TH, wmarks + wave * 64);
+            if (n_op) shade_tile_p64<FMT8, NT, ZMODE>(a, tilebuf, e0, e1, x_lo, x_hi, y_lo, y_hi, ty_top, tid, lane, TH, wmarks + wave * 64, latlas);
             else if (a.clear_on) {      // nothing reaches this tile: it still gets the frame's clear colour
                 for (uint32_t p = tid; p < TILE_W * TH; p += NT) {
                     const uint32_t px = x_lo + (p & 63), py = ty_top + (p >> 6);
@@ -1455,6 +1465,12 @@ __device__ __forceinline__ bool hit_finish(uint32_t flags, int taddr, uint32_t f
     texel = c;
     return true;
 }
+// texel of the LDS-staged index atlas: [256 x Color15 CLUT][index bytes]; taddr is an address in the texel pool (texture 0 starts at off0)
+__device__ __forceinline__ uint32_t atlas_texel(const uint8_t* latlas, int taddr, uint32_t off0) {
+    if (taddr < 0) return 0;
+    const uint32_t idx = latlas[ATLAS_CLUT_BYTES + ((uint32_t)taddr - off0)];
+    return reinterpret_cast<const uint16_t*>(latlas)[idx];
+}
 template <bool FMT8>
 __device__ __forceinline__ uint32_t fetch_texel(const FillArgs& a, int taddr) {
     if (taddr < 0) return 0;
@@ -1524,7 +1540,8 @@ __device__ __forceinline__ void repair_pixel(const FillArgs& a, const unsigned l
 // of five on the benchmark scene -- but collected and repaired together: when 64 have gathered, and behind the tile's last row.
 template <bool FMT8, int NT, bool ZMODE>
 __device__ __forceinline__ void shade_tile_p64(const FillArgs& a, const uint32_t* tilebuf, uint32_t e0, uint32_t e1, uint32_t x_lo, uint32_t x_hi,
-                                               uint32_t y_lo, uint32_t y_hi, uint32_t ty_top, uint32_t tid, uint32_t lane, uint32_t TH, uint32_t* wq) {
+                                               uint32_t y_lo, uint32_t y_hi, uint32_t ty_top, uint32_t tid, uint32_t lane, uint32_t TH, uint32_t* wq,
+                                               const uint8_t* latlas) {
     const FrameParams& fp = a.fp;
     const unsigned long long* top = reinterpret_cast<const unsigned long long*>(tilebuf);
     const unsigned long long* sec = top + TILE_H * STR64;
@@ -1574,7 +1591,11 @@ __device__ __forceinline__ void shade_tile_p64(const FillArgs& a, const uint32_t
             int taA = -1, taB = -1;
             bool okA = cA && hit_prepare(a, ra, px, pyA, hA, taA);
             bool okB = cB && hit_prepare(a, rb, px, pyB, hB, taB);
-            const uint32_t fA = fetch_texel<FMT8>(a, okA ? taA : -1), fB = fetch_texel<FMT8>(a, okB ? taB : -1);
+            // (latlas: the one indexed texture's CLUT + index bytes staged in this workgroup's LDS -- Clut::lookup per shaded pixel,
+            // types.rs:390-397 -- instead of the expanded texel from global memory; wave-uniform choice)
+            uint32_t fA, fB;
+            if (!FMT8 && latlas) { fA = atlas_texel(latlas, okA ? taA : -1, a.tex0.offset); fB = atlas_texel(latlas, okB ? taB : -1, a.tex0.offset); }
+            else { fA = fetch_texel<FMT8>(a, okA ? taA : -1); fB = fetch_texel<FMT8>(a, okB ? taB : -1); }
             hA.sid = sid_of(tA); hB.sid = sid_of(tB);
             okA = okA && hit_finish<FMT8>(hA.flags, taA, fA, hA.texel);
             okB = okB && hit_finish<FMT8>(hB.flags, taB, fB, hB.texel);
@@ -2012,7 +2033,9 @@ extern "C" int b32_debug_timeline(unsigned long long* out, unsigned cap_words) {
 #endif
 template <bool EXACT, bool ZMODE, bool FMT8>
 static void launch_p64(hipStream_t s, const FillArgs& a, uint32_t ntiles, int n_cu, bool wide) {
-    const size_t lds64 = 4 * LDS_TILE_BYTES + LDS_MISC_BYTES + LDS_MARK_BYTES;
+    // tile planes, misc words, 64 words of repair queue per wave, then the staged index atlas (if any)
+    const size_t atlas = a.atlas_idx_bytes ? (((size_t)ATLAS_CLUT_BYTES + a.atlas_idx_bytes + 15) & ~(size_t)15) : 0;
+    const size_t lds_n = 4 * LDS_TILE_BYTES + LDS_MISC_BYTES + 8 * 256 + atlas, lds_w = 4 * LDS_TILE_BYTES + LDS_MISC_BYTES + 16 * 256 + atlas;
     static bool attr[64] = {};
     if (first_launch_on_device(attr)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<0, EXACT, 512, ZMODE, FMT8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -2029,13 +2052,24 @@ static void launch_p64(hipStream_t s, const FillArgs& a, uint32_t ntiles, int n_
     }
 #endif
     const bool plain = a.fp.affine && a.fp.shading == B32_SHADE_NONE && a.fp.fixed_point && !a.fp.ortho && a.fp.nt == 1 && !a.inline_bin && !a.gather_blend;
+#ifdef B32_EXP_LDS_ATLAS
+    // experiment build (tools/exp_variants.py build atlas -DB32_EXP_LDS_ATLAS): the benchmark's frame through ONE 16-wave workgroup per CU
+    // with the 64 KB index atlas + CLUT in LDS, against two 8-wave workgroups per CU fetching expanded texels through L1 / L2
+    if (plain && !wide && a.atlas_idx_bytes) {
+        static bool attr_x[64] = {};
+        if (first_launch_on_device(attr_x))
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<0, EXACT, 1024, ZMODE, FMT8, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL((k_cover<0, EXACT, 1024, ZMODE, FMT8, true, true>), dim3(min(ntiles, (uint32_t)n_cu)), dim3(1024), lds_w, s, a);
+        return;
+    }
+#endif
     if (plain && !wide) {
         static bool attr_plain[64] = {};
         if (first_launch_on_device(attr_plain))
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<0, EXACT, 512, ZMODE, FMT8, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL((k_cover<0, EXACT, 512, ZMODE, FMT8, true, true>), g, dim3(512), lds64, s, a);
-    } else if (wide) hipLaunchKernelGGL((k_cover<0, EXACT, 1024, ZMODE, FMT8, true>), g, dim3(1024), lds64, s, a);
-    else hipLaunchKernelGGL((k_cover<0, EXACT, 512, ZMODE, FMT8, true>), g, dim3(512), lds64, s, a);
+        hipLaunchKernelGGL((k_cover<0, EXACT, 512, ZMODE, FMT8, true, true>), g, dim3(512), lds_n, s, a);
+    } else if (wide) hipLaunchKernelGGL((k_cover<0, EXACT, 1024, ZMODE, FMT8, true>), g, dim3(1024), lds_w, s, a);
+    else hipLaunchKernelGGL((k_cover<0, EXACT, 512, ZMODE, FMT8, true>), g, dim3(512), lds_n, s, a);
 }
 
 void launch_fill(hipStream_t s, const FillArgs& a, int n_cu, hipEvent_t after_cover) {
@@ -2098,5 +2132,11 @@ void launch_fill(hipStream_t s, const FillArgs& a, int n_cu, hipEvent_t after_co
 }
 
 size_t fill_lds_tex_budget() { return 160 * 1024 - LDS_TEX_OFFSET - 16; }
+uint32_t fill_lds_atlas_room(bool wide) {
+    // 160 KB of LDS per CU, allocated in 512-byte granules: one 16-wave workgroup, or two 8-wave workgroups side by side
+    const uint32_t total = 160u * 1024u, gran = 512u;
+    if (wide) return total - (uint32_t)(4 * LDS_TILE_BYTES + LDS_MISC_BYTES + 16 * 256) - gran;
+    return total / 2u - (uint32_t)(4 * LDS_TILE_BYTES + LDS_MISC_BYTES + 8 * 256) - gran;
+}
 
 }  // namespace b32

@@ -244,7 +244,8 @@ int b32_set_async_depth(b32_ctx* ctx, int deep);
  * lists were collected inside the fill kernel (small meshes), 2 frames binned by the counting-sort launches, 3 frames through the
  * keyed pipeline (global depth sort), 4 frames redrawn because a tile region overflowed, 5 frames redrawn through the global depth
  * sort, 6 frames redrawn after a pair-buffer overflow, 7 frames whose setup kernel ran on the second stream beside the previous frame's
- * fill (two frames in flight).  Unknown `which` or null ctx: 0. */
+ * fill (two frames in flight), 8 frames whose fused kernel sampled the 4/8-bit index atlas + CLUT from LDS (B32_ROUTE_LDS_ATLAS).
+ * Unknown `which` or null ctx: 0. */
 unsigned long long b32_route_count(const b32_ctx* ctx, int which);
 /* Switch internal routes OFF for the frames enqueued from now on (no reference counterpart: the results are identical on every route;
  * the tests use it to keep the older pipelines covered, the timing tools to compare routes).  off_mask = 0 restores the default. */
@@ -256,6 +257,9 @@ unsigned long long b32_route_count(const b32_ctx* ctx, int which);
 #define B32_ROUTE_PACKED_STREAMS 32u /* resident large meshes: packed position / attribute streams for the setup kernel -> B32Vertex array */
 #define B32_ROUTE_TEX_CACHE   128u /* drop-in calls: texture cache by (pointer, size, blend mode, 64-bit content hash) -> texels uploaded on every call */
 #define B32_ROUTE_BATCH       256u /* b32_frame_end: runs of commuting meshes drawn as one merged mesh -> one draw per mesh           */
+#define B32_ROUTE_LDS_ATLAS   512u /* one indexed texture (b32_scene_upload_indexed): index atlas + CLUT staged in LDS by every workgroup of the fused
+                                    * kernel and looked up per shaded pixel (Clut::lookup, types.rs:390-397) whenever they fit beside the tile planes
+                                    * -> expanded Color15 texels fetched from global memory                                          */
 #define B32_ROUTE_PIPELINE    64u  /* setup kernel of the next frame on a second stream beside the fill of the current one -> one stream */
 int b32_set_routes(b32_ctx* ctx, uint32_t off_mask);
 /* CHEAP coverage (inside test only, texel rule applied to the winner) is used while every texture has at most 1/den skippable texels

@@ -799,6 +799,40 @@ def test_light_lists_change_between_async_frames(gpu_ctx, oracle):
     assert np.array_equal(fb.pixels, ofb.pixels) and np.array_equal(fb.zbuffer.view(np.uint32), ofb.zbuffer.view(np.uint32))
 
 
+@pytest.mark.parametrize("config,n_tris,width,height,expect_lds", [
+    ("C1", 2000, 320, 240, True),        # 64x64 4-bit atlas, 16-wave workgroups (small mesh: lists collected in the fill)
+    ("C2", 30_000, 320, 240, True),      # same atlas, direct binning
+    ("C1", 40_000, 1280, 960, True),     # more tiles than CUs: two 8-wave workgroups per CU, 4.6 KB of atlas in the ~6 KB beside their planes
+    ("C3", 20_000, 320, 240, True),      # 256x256 8-bit atlas (64.5 KB) beside ONE 16-wave workgroup's planes
+    ("C3", 60_000, 1280, 960, False),    # the same atlas does not fit beside two workgroups' planes: expanded texels from global memory
+])
+def test_index_atlas_and_clut_sampled_from_lds(oracle, config, n_tris, width, height, expect_lds):
+    """north_star's "LDS-staged 4/8-bit indexed texture tiles and palette" (B32_ROUTE_LDS_ATLAS): with ONE indexed texture the fused
+    kernel stages CLUT + index bytes in LDS and performs Clut::lookup (types.rs:390-397) per shaded pixel whenever they fit beside the
+    tile planes of the workgroup form in use.  Same frame as the oracle drawing the pre-expanded Texture15 (scene.rs:164), with the
+    route on (counted) and switched off."""
+    from bonnie32_amd import rasterizer as R
+    sc = scenegen.make_scene(config, n_tris=n_tris, width=width, height=height, seed=4242 + n_tris, bbox_px=90.0 if width > 320 else None)
+    at = sc.indexed_textures[0]
+    at.indices[::53] = 255                                     # (some indices past a 16-entry palette: 0x0000 -> transparent texels)
+    sc.textures = [at.to_texture15()]
+    exp, etm, _ = cpu_render(oracle, sc)
+    for off in (0, R.Context.ROUTE_LDS_ATLAS):
+        ctx = R.Context(0); ctx.set_routes(off)
+        for counting in (0, 1):
+            ctx.set_fragment_counting(counting)
+            before = ctx.route_counts()["lds_atlas"]
+            got, tm = gpu_render(ctx, sc, resident=True, indexed=True)
+            assert np.array_equal(got, exp), f"{int((got != exp).sum())} bytes differ (routes off {off}, counting {counting})"
+            assert tm.triangles_drawn == etm.triangles_drawn
+            assert (ctx.route_counts()["lds_atlas"] - before > 0) == (expect_lds and off == 0)
+        # a Texture15 upload of the same texels never takes the route
+        before = ctx.route_counts()["lds_atlas"]
+        got, _ = gpu_render(ctx, sc, resident=True, indexed=False)
+        assert np.array_equal(got, exp) and ctx.route_counts()["lds_atlas"] == before
+        ctx.close()
+
+
 def test_clut_indices_past_the_palette(gpu_ctx, oracle):
     """Clut::lookup (types.rs:390-397) returns 0x0000 for an index past the palette: a 4-bit CLUT (16 entries) under an atlas whose
     bytes run up to 255.  The device expansion of b32_scene_upload_indexed must give the texels of the oracle's expansion (and of
