@@ -260,6 +260,7 @@ def main():
         step()
     rs.finish()
     sync_all()
+    pipelined_before = ctx.route_counts().get("pipelined", 0)
     t0 = time.perf_counter()
     if pipelined:
         for i in range(args.steps):
@@ -280,7 +281,7 @@ def main():
     cover_ms_timed = ctx.last_kernel_times().get("cover", None)     # HIP events around k_cover on the stream it runs on (overlapped frames)
     ctx.set_profiling(0)
     ctx.set_profiling_stride(1)
-    pipelined_frames = ctx.route_counts().get("pipelined", 0)
+    pipelined_frames = ctx.route_counts().get("pipelined", 0) - pipelined_before      # frames of the timed region only
 
     frags = torch.tensor([float(exact_fragments)], dtype=torch.float64, device=rdev)
     if world > 1:
@@ -311,6 +312,7 @@ def main():
     # >= 20 samples; (b) events around every phase; an empty phase ("sort": nothing is launched between its two events on the default
     # path) is what an event pair itself costs.
     cover_ms, cover_samples, phases = None, 0, {}
+    shader_clock_ghz, shader_clock_ms = 0.0, 0.0
     if world == 1:
         ctx.set_routes(R.Context.ROUTE_PIPELINE)
         n_iso = min(max(args.steps, 24), 60)
@@ -319,6 +321,7 @@ def main():
             step()
         rs.finish()
         cover_ms = ctx.last_kernel_times().get("cover", None); cover_samples = n_iso
+        shader_clock_ghz, shader_clock_ms = ctx.last_shader_clock()    # measured inside the fill kernel of the pass's last frame (one stream)
         ctx.set_profiling(2)
         for _ in range(20):
             step()
@@ -516,10 +519,16 @@ def main():
             valu = None
             if ecov and ecov.get("valu_wave_instr"):
                 n_simd = 4 * torch.cuda.get_device_properties(dev).multi_processor_count
-                clk = ecov.get("shader_clock_ghz", 2.4)
-                issue_us = ecov["valu_wave_instr"] / n_simd * 4 / (clk * 1e3)
-                valu = {"wave_instr": ecov["valu_wave_instr"], "simds": n_simd, "cycles_per_wave_instr": 4, "clock_ghz": clk,
-                        "issue_peak_us": round(issue_us, 2), "frac": round(issue_us / (cover_ms * 1e3), 4),
+                # shader clock: measured by the kernel itself (cycle counter against the 100 MHz wall clock over workgroup 0's lifetime);
+                # issue cost: gfx950 issues add / sub / logic / right shift / mov / f32 add-mul-fma in ~2 cycles per wave64 and everything else
+                # (min / max / cvt / cmp / 3-operand integer / multiplies / packed) in ~4 -- measured, profiles/r04_instruction_rates.txt; the
+                # fused kernel's hot loops are ~35 % of the first kind (ISA mix), i.e. ~3.3 cycles per instruction; 4 is the upper bound
+                clk = shader_clock_ghz if shader_clock_ghz and shader_clock_ghz > 0.5 else ecov.get("shader_clock_ghz", 2.4)
+                issue_us = ecov["valu_wave_instr"] / n_simd * 3.3 / (clk * 1e3)
+                issue_us_hi = ecov["valu_wave_instr"] / n_simd * 4 / (clk * 1e3)
+                valu = {"wave_instr": ecov["valu_wave_instr"], "simds": n_simd, "cycles_per_wave_instr": 3.3, "cycles_per_wave_instr_upper": 4,
+                        "clock_ghz": round(clk, 3), "clock_source": "measured in the kernel (b32_last_shader_clock)" if shader_clock_ghz and shader_clock_ghz > 0.5 else "nominal",
+                        "issue_peak_us": round(issue_us, 2), "issue_peak_us_upper": round(issue_us_hi, 2), "frac": round(issue_us / (cover_ms * 1e3), 4),
                         "lds_bank_conflict_cycles": ecov.get("lds_bank_conflict"), "wait_any_share": ecov.get("wait_any_share")}
             roofline = {"kernel": "k_cover", "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": tsrc,

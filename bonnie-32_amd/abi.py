@@ -137,6 +137,8 @@ SYMBOLS = [
     ("b32_set_profiling_stride", C.c_int, [_P, C.c_uint32]),
     ("b32_set_pipeline_gate", C.c_int, [_P, C.c_uint32]),
     ("b32_set_pipeline_depth", C.c_int, [_P, C.c_uint32]),
+    ("b32_last_shader_clock", C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    ("b32_transparent_counts", C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("b32_set_fragment_counting", C.c_int, [_P, C.c_int]),
 ]
 

@@ -135,6 +135,9 @@ struct b32_ctx {
     // wireframe phases (allocated on first use)
     WireTri* wire = nullptr; size_t cap_wire = 0;
     uint32_t *wire_owner = nullptr, *wire_first = nullptr; size_t cap_wire_table = 0;
+    uint32_t *wire_fill = nullptr, *wire_lists = nullptr; size_t cap_wire_tiles = 0;     // tile route of the wireframe phases (WireArgs)
+    unsigned long long wire_grid = 0;                                                       // tile grid the (self-resetting) counters belong to
+    unsigned long long wire_tile_frames = 0;
     // control
     Ctrl* d_ctrl = nullptr; uint32_t* d_consts = nullptr; Ctrl h_ctrl{}; Stamps h_stamps{};   // (d_ctrl: Ctrl followed by Stamps)
     uint32_t h_consts[4] = { 0, 0, 0, 0 };   // staging for d_consts (outlives the async copy)
@@ -369,7 +372,7 @@ void b32_destroy(b32_ctx* c) {
     void* ptrs[] = { c->fb_own, c->d_verts, c->d_faces, c->d_texels, c->d_tex, c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->crecs, c->srecs, c->xrecs,
                      c->shades, c->counts, c->block_sums, c->pkeys[0], c->pkeys[1], c->pvals[0], c->pvals[1], c->block_hist, c->ranges,
                      c->d_ctrl, c->d_consts, c->d_lights, c->digit_total, c->partials, c->vis, c->spans, c->tile_mid, c->zbuf,
-                     c->wire, c->wire_owner, c->wire_first, c->d_texels32, c->inline_lists, c->d_texmask, c->direct_lists, c->tile_fill, c->d_pos12, c->face_of, c->d_atlas0 };
+                     c->wire, c->wire_owner, c->wire_first, c->wire_fill, c->wire_lists, c->d_texels32, c->inline_lists, c->d_texmask, c->direct_lists, c->tile_fill, c->d_pos12, c->face_of, c->d_atlas0 };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->side) (void)hipStreamSynchronize(c->side);
     for (auto& r : c->merged_runs) if (r.merged) { void* mp[] = { r.merged->d_verts, r.merged->d_faces, r.merged->d_texels, r.merged->d_texels32, r.merged->d_tex,
@@ -1019,6 +1022,22 @@ static int frame_buffers(b32_ctx* c, const FrameParams& fp, bool wire_back) {
             if ((rc = ensure_plain(c, c->wire_first, slots))) return rc;
             c->cap_wire_table = slots;
         }
+        // tile route: one counter and one list region per 64x64 tile of the band (+ the overflow flag and the big-edge count)
+        if (!(c->route_off & B32_ROUTE_WIRE_TILES) && c->band_y1 > c->band_y0) {
+            const size_t wt = (size_t)fp.tiles_x * ((c->band_y1 - (c->band_y0 / WIRE_TH) * WIRE_TH + WIRE_TH - 1) / WIRE_TH);
+            if (wt > c->cap_wire_tiles || !c->wire_fill) {
+                if ((rc = ensure_plain(c, c->wire_fill, (wt + 2) * FILL_PAD + 64))) return rc;
+                if ((rc = ensure_plain(c, c->wire_lists, wt * WIRE_TILE_CAP + 64))) return rc;
+                c->cap_wire_tiles = wt; c->wire_grid = 0;
+            }
+            // (the counters are zero between frames: k_wire_tile re-zeroes what k_wire_bin counted; a new allocation or another tile grid
+            // -- resize, band change -- starts from a cleared array)
+            const unsigned long long grid = ((unsigned long long)c->width << 40) ^ ((unsigned long long)c->band_y0 << 20) ^ c->band_y1;
+            if (grid != c->wire_grid || wt > c->cap_wire_tiles) {
+                HIPCHK(c, hipMemsetAsync(c->wire_fill, 0, ((c->cap_wire_tiles + 2) * FILL_PAD + 64) * sizeof(uint32_t), s));
+                c->wire_grid = grid;
+            }
+        }
     }
     return B32_OK;
 }
@@ -1331,6 +1350,11 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
         wa.table_mask = c->cap_wire_table ? (uint32_t)(c->cap_wire_table - 1) : 0;
         wa.fb = c->fb; wa.zbuf = (c->zbuf && c->zbuf_valid) ? c->zbuf : nullptr;
         wa.width = c->width; wa.height = c->height; wa.band_y0 = c->band_y0; wa.band_y1 = c->band_y1; wa.ctrl = c->d_ctrl;
+        if (!(c->route_off & B32_ROUTE_WIRE_TILES) && c->wire_fill && c->band_y1 > c->band_y0) {
+            wa.tile_yb = (c->band_y0 / WIRE_TH) * WIRE_TH; wa.tiles_x = (c->width + TILE_W - 1) / TILE_W;
+            wa.tiles_y = (c->band_y1 - wa.tile_yb + WIRE_TH - 1) / WIRE_TH;
+            if ((size_t)wa.tiles_x * wa.tiles_y <= c->cap_wire_tiles) { wa.tile_fill = c->wire_fill; wa.tile_lists = c->wire_lists; c->wire_tile_frames++; }
+        }
         launch_wire(s, wa, wire_back, wire_front);
     }
     if (prof_fill) { if (prof_all) HIPCHK(c, hipEventRecord(ev[5], s)); c->ev_frames++; }
@@ -1894,6 +1918,7 @@ extern "C" int b32_set_fragment_counting(b32_ctx* c, int on) {
 extern "C" unsigned long long b32_route_count(const b32_ctx* c, int which) {
     if (c && which == 7) return c->pipelined_frames;
     if (c && which == 8) return c->lds_atlas_frames;
+    if (c && which == 9) return c->wire_tile_frames;
     return (c && which >= 0 && which < 8) ? c->routes[which] : 0ull;
 }
 extern "C" int b32_set_async_depth(b32_ctx* c, int deep) {
@@ -1929,6 +1954,21 @@ extern "C" int b32_set_cheap_threshold(b32_ctx* c, uint32_t den) {
 extern "C" int b32_set_pipeline_gate(b32_ctx* c, uint32_t permille) {
     if (!c || permille > 2000u) return B32_E_ARG;
     c->gate_permille = permille;
+    return B32_OK;
+}
+extern "C" int b32_last_shader_clock(const b32_ctx* c, float* ghz, float* fill_ms) {
+    if (!c || !ghz) return B32_E_ARG;
+    *ghz = 0.0f; if (fill_ms) *fill_ms = 0.0f;
+    const unsigned long long* t = c->h_stamps.t;                      // of the last frame b32_frame_finish read back
+    if (!t[ST_FILL] || !t[ST_CLKW] || t[ST_CLKW] <= t[ST_FILL] || t[ST_CLK1] <= t[ST_CLK0]) return B32_OK;      // (no fused kernel in that frame)
+    const double ns = (double)(t[ST_CLKW] - t[ST_FILL]) * 10.0;       // wall_clock64: 100 MHz
+    *ghz = (float)((double)(t[ST_CLK1] - t[ST_CLK0]) / ns);
+    if (fill_ms) *fill_ms = (float)(ns * 1e-6);
+    return B32_OK;
+}
+extern "C" int b32_transparent_counts(const b32_ctx* c, uint32_t* host_bound, uint32_t* device_last) {
+    if (!c || !host_bound || !device_last) return B32_E_ARG;
+    *host_bound = c->blend_faces; *device_last = c->h_ctrl.n_transparent;
     return B32_OK;
 }
 extern "C" int b32_set_pipeline_depth(b32_ctx* c, uint32_t sets) {

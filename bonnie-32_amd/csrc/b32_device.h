@@ -178,7 +178,8 @@ struct Stamps { unsigned long long t[8]; };
 // event happened in, so nothing has to be reset between frames and k_setup's own frame-start reset of Ctrl cannot race with them.
 struct Events { uint32_t bad_index, nan_opaque, nan_transparent, overflow, long_transparent, _pad[3]; };
 __device__ __forceinline__ Events* events_of(Ctrl* ctrl) { return reinterpret_cast<Events*>(reinterpret_cast<unsigned char*>(ctrl) + 128); }
-enum { ST_SETUP = 0, ST_BIN = 1, ST_FILL = 2, ST_WIRE = 3, ST_END = 4 };
+enum { ST_SETUP = 0, ST_BIN = 1, ST_FILL = 2, ST_WIRE = 3, ST_END = 4,
+       ST_CLK0 = 5, ST_CLK1 = 6, ST_CLKW = 7 };   // shader-cycle counter at the start / end of workgroup 0 of the fused kernel, wall clock at its end
 __device__ __forceinline__ void phase_stamp(Ctrl* ctrl, int k) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         unsigned long long* t = reinterpret_cast<Stamps*>(ctrl + 1)->t;
@@ -418,7 +419,13 @@ struct WireArgs {
     uint32_t* fb; const float* zbuf;                                        // zbuf == nullptr: every depth is f32::MAX
     uint32_t width, height, band_y0, band_y1;
     Ctrl* ctrl;
+    // tile route (B32_ROUTE_WIRE_TILES; tile_fill == nullptr: off): 64 x WIRE_TH tiles over the band, first tile row at tile_yb; tile_fill holds
+    // one counter per tile, then the overflow flag and the count of edges left to the global kernels; lists of WIRE_TILE_CAP ids per tile
+    uint32_t* tile_fill; uint32_t* tile_lists;
+    uint32_t tiles_x, tiles_y, tile_yb;
 };
+constexpr uint32_t WIRE_TH = 16;               // wire tiles are 64 x WIRE_TH pixels: small enough that four workgroups share a CU's LDS
+constexpr uint32_t WIRE_TILE_CAP = 256;        // faces per tile list: one 256-lane workgroup de-duplicates their 768 edges in LDS
 void launch_wire(hipStream_t s, const WireArgs& a, bool back, bool front);
 // Sort-free fast path: tile lists (unordered) by a counting sort straight from k_setup's spans; false = not applicable (too many
 // tiles for the LDS histogram), the caller takes the keyed radix path.  With `keys` the lists are split by class

@@ -1118,6 +1118,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PLAIN ? 2 : 
     const FrameParams& fp = a.fp;
     const uint32_t ntiles = fp.tiles_x * fp.tiles_y;
     phase_stamp(a.ctrl, ST_FILL);
+    // (sort-free forms: workgroup 0 also notes the shader-cycle counter now and, with the wall clock, when it runs out of tiles -- the
+    // shader clock the fill really ran at, b32_last_shader_clock: under this kernel's load it sits below the device's nominal clock)
+    const unsigned long long clk_entry = (P64 && blockIdx.x == 0 && tid == 0) ? (unsigned long long)clock64() : 0ull;
     // small meshes (inline_bin): the first NT spans (and class bits) are requested before the counters are reduced, and the skip mask is
     // staged before it too -- a C1 workgroup used to start its tile 7 us into an 18-us kernel behind three dependent round trips
     uint32_t pre_span = 0xFFFFFFFFu, pre_key = 0u;
@@ -1347,6 +1350,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PLAIN ? 2 : 
             }
         }
         __syncthreads();   // everyone is done with misc / tilebuf before the next tile
+    }
+    if (P64 && blockIdx.x == 0 && tid == 0) {
+        unsigned long long* st = reinterpret_cast<Stamps*>(a.ctrl + 1)->t;
+        st[ST_CLK0] = clk_entry; st[ST_CLK1] = (unsigned long long)clock64(); st[ST_CLKW] = wall_clock64();
     }
     if (P64 && reduce_late) { __syncthreads(); reduce_setup_counters<NT>(a, misc, tid, lane); }
     if (EXACT && !ZMODE) { // fragment-store count (wave-uniform per wave): one same-address atomic per workgroup

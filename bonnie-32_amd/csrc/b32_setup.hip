@@ -207,7 +207,13 @@ __device__ __forceinline__ void agg_issue(uint32_t* fill, uint32_t slot, bool ac
         if (n < 2) { if (++misses >= 2) break; continue; }
         if (active && slot == s) { g.leader = (uint32_t)l; g.rank = (uint32_t)__builtin_popcountll(grp & below); if (lane == (uint32_t)l) cnt = n; }
     }
+#if defined(B32_EXP_BIN_WG_ATOMICS)          // experiment (frames are WRONG): the reservation as an L2-local atomic -- what per-XCD counters would cost
+    if (active && g.leader == lane) g.ret = __hip_atomic_fetch_add(fill + slot, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#elif defined(B32_EXP_BIN_NO_ATOMICS)        // experiment (frames are WRONG): no reservation at all
+    if (active && g.leader == lane) g.ret = (slot * 2654435761u) >> 26;
+#else
     if (active && g.leader == lane) g.ret = atomicAdd(fill + slot, cnt);
+#endif
 }
 // (every lane that was `active` in agg_issue must call this together)
 __device__ __forceinline__ uint32_t agg_position(const AggSlot& g) {
@@ -504,7 +510,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PLAIN ? 8 :
                 }
                 if (db.fill && n_tiles) {     // the face id into the list of every tile of the span (any order inside a list)
                     const uint32_t cap = db_cls ? db.cap_transparent : db.cap_opaque;
-                    const uint32_t tx0 = span & 0xFF, tx1 = (span >> 8) & 0xFF, ty0 = (span >> 16) & 0xFF, ty1 = span >> 24;
+                    const uint32_t tx0 = span & 0xFF, tx1 = (span >> 8) & 0xFF, ty0 = (span >> 16) & 0xFF;
                     bool over = false;
                     uint32_t tx = tx0, ty = ty0;
                     AggSlot g = db_first;
@@ -515,8 +521,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PLAIN ? 8 :
                         if (k) agg_issue(db.fill, tile * FILL_PAD + (db_cls ? 1u : 0u), act, threadIdx.x & 63u, g);
                         const uint32_t pos = agg_position(g);
                         if (act) {
+#ifdef B32_EXP_BIN_NO_LIST_STORE                                   // experiment (frames are WRONG): reservations without the 4-byte list stores
+                            if (pos >= cap) over = true;
+#else
                             if (pos < cap) db.lists[(size_t)tile * db.region + (db_cls ? db.region - 1u - pos : pos)] = rslot;
                             else over = true;
+#endif
                             if (++tx > tx1) { tx = tx0; ++ty; }
                         }
                     }

@@ -45,8 +45,18 @@ __device__ __forceinline__ uint32_t edge_hash(const Edge& e) {
 __device__ __forceinline__ bool same_edge(const Edge& a, const Edge& b) { return a.x0 == b.x0 && a.y0 == b.y0 && a.x1 == b.x1 && a.y1 == b.y1; }
 
 constexpr uint32_t SLOT_EMPTY = 0xFFFFFFFFu;
+__device__ __forceinline__ bool wire_global(const WireArgs& a, const Edge& e);     // (tile route: which edges are left to the global kernels)
+// (one 128-byte line per counter, like the surface binning's: device-scope atomics on words of one line serialise at the memory side --
+// packed counters: k_wire_bin 437 us on the 1 M-triangle scene, one line each: see profiles/r04_wire_*)
+__device__ __forceinline__ uint32_t* wire_counter(const WireArgs& a, uint32_t tile) { return a.tile_fill + (size_t)tile * FILL_PAD; }
+__device__ __forceinline__ uint32_t* wire_flag(const WireArgs& a, uint32_t which) { return a.tile_fill + (size_t)(a.tiles_x * a.tiles_y + which) * FILL_PAD; }   // 0 overflow, 1 big edges
+__device__ __forceinline__ bool wire_global_idle(const WireArgs& a) {               // tile route on, no list overflow, no big edge
+    if (!a.tile_fill) return false;
+    return !*wire_flag(a, 0) && !*wire_flag(a, 1);
+}
 
-__global__ void k_wire_table_clear(uint32_t* __restrict__ owner, uint32_t* __restrict__ first, uint32_t n) {
+__global__ void k_wire_table_clear(uint32_t* __restrict__ owner, uint32_t* __restrict__ first, uint32_t n, const uint32_t* __restrict__ tile_flags) {
+    if (tile_flags && !tile_flags[0] && !tile_flags[FILL_PAD]) return;          // tile route: no overflow, no big edge -- the global kernels have nothing to do
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { owner[i] = SLOT_EMPTY; first[i] = SLOT_EMPTY; }
 }
 
@@ -65,13 +75,15 @@ __device__ __forceinline__ uint32_t wire_slot(const WireArgs& a, const Edge& e, 
 
 __global__ void k_wire_insert(WireArgs a) {
     phase_stamp(a.ctrl, ST_WIRE);
-    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= a.nf * 3) return;
-    const uint32_t f = id / 3;
-    if (a.tris[f].kind != 1) return;
-    const Edge e = wire_edge(a.tris[f], (int)(id % 3));
-    const uint32_t h = wire_slot(a, e, id, true);
-    atomicMin(&a.table_first[h], id);
+    if (wire_global_idle(a)) return;
+    for (uint32_t id = blockIdx.x * blockDim.x + threadIdx.x; id < a.nf * 3; id += gridDim.x * blockDim.x) {     // (grid-stride: the launch is small when the tile route is on)
+        const uint32_t f = id / 3;
+        if (a.tris[f].kind != 1) continue;
+        const Edge e = wire_edge(a.tris[f], (int)(id % 3));
+        if (!wire_global(a, e)) continue;                             // (every occurrence of an edge decides alike: same coordinates)
+        const uint32_t h = wire_slot(a, e, id, true);
+        atomicMin(&a.table_first[h], id);
+    }
 }
 
 // Bresenham of draw_line / draw_line_3d_impl (render.rs:716-750, 771-817) in closed form.  With adx = |x1-x0|, ady = |y1-y0|,
@@ -80,69 +92,319 @@ __global__ void k_wire_insert(WireArgs a) {
 //   j(k) = floor((2*ady*k + adx) / (2*adx))      (round half up),
 // and symmetrically for a y-major line i(k) = floor((2*adx*k + ady) / (2*ady)).  The depth parameter `step` advances by
 // exactly 1.0 per iteration (saturating at 2^24 in f32).  tests/test_oracle_kats.py checks this against the literal loop.
-__device__ void draw_line_dev(const WireArgs& a, const Edge& e, bool depth_test, uint32_t rgba) {
+// The walk proper: every pixel of the line inside [cx0, cx1] x [cy0, cy1] (inclusive, already inside the frame and the band) that
+// passes the depth test goes to plot(x, y).  The closed form lets the walk start at the first step inside the rectangle's major-axis
+// range; the minor coordinate is tested per pixel.
+// steps of the line whose major coordinate lies inside the rectangle: [k_lo, k_hi] (false: none)
+__device__ __forceinline__ bool line_k_range(const Edge& e, long long cx0, long long cx1, long long cy0, long long cy1, long long& k_lo, long long& k_hi) {
     const long long adx = llabs((long long)e.x1 - e.x0), ady = llabs((long long)e.y1 - e.y0);
-    if (adx >= (1ll << 30) || ady >= (1ll << 30)) { atomicOr(&a.ctrl->wire_overflow, 1u); atomicOr(&a.ctrl->sticky, 4u); return; }   // 2*err overflows i32 in the reference
-    const int sx = e.x0 < e.x1 ? 1 : -1, sy = e.y0 < e.y1 ? 1 : -1;
-    const long long N = adx > ady ? adx : ady;
+    const bool xmajor = adx >= ady;
+    const long long N = xmajor ? adx : ady, m0 = xmajor ? e.x0 : e.y0, lo = xmajor ? cx0 : cy0, hi = xmajor ? cx1 : cy1;
+    const int sm = xmajor ? (e.x0 < e.x1 ? 1 : -1) : (e.y0 < e.y1 ? 1 : -1);
+    k_lo = 0; k_hi = N;
+    if (sm > 0) { if (lo - m0 > k_lo) k_lo = lo - m0; if (hi - m0 < k_hi) k_hi = hi - m0; }
+    else        { if (m0 - hi > k_lo) k_lo = m0 - hi; if (m0 - lo < k_hi) k_hi = m0 - lo; }
+    return k_lo <= k_hi;
+}
+// steps k_a ... k_b of the line (a sub-range of line_k_range's).  I = the integer type of the walk: every line with extents below 2^14
+// and start coordinates below 2^20 -- anything a sane mesh produces -- fits 32 bits (2 * dmin * k + dmaj < 2^29); the rest (coordinates
+// up to 2^31 after the saturating `as i32`) walks in 64 bits.  Same values either way.
+template <typename I, typename Depth, typename Plot>
+__device__ __forceinline__ void walk_line_range_t(const Edge& e, bool depth_test, I cx0, I cx1, I cy0, I cy1, I k_a, I k_b, Depth depth_at, Plot plot) {
+    const I dx = (I)e.x1 - (I)e.x0, dy = (I)e.y1 - (I)e.y0;
+    const I adx = dx < 0 ? -dx : dx, ady = dy < 0 ? -dy : dy;
+    const I sx = e.x0 < e.x1 ? 1 : -1, sy = e.y0 < e.y1 ? 1 : -1;
+    const I N = adx > ady ? adx : ady;
     const float total_steps = (float)(N > 1 ? N : 1);                   // dx.max((-dy).max(1)) as f32
     const bool xmajor = adx >= ady;
-    const long long m0 = xmajor ? e.x0 : e.y0, wmaj = xmajor ? a.width : a.height;
-    const int sm = xmajor ? sx : sy;
-    long long k_lo = 0, k_hi = N;
-    if (sm > 0) { if (-m0 > k_lo) k_lo = -m0; if (wmaj - 1 - m0 < k_hi) k_hi = wmaj - 1 - m0; }
-    else        { if (m0 - (wmaj - 1) > k_lo) k_lo = m0 - (wmaj - 1); if (m0 < k_hi) k_hi = m0; }
-    if (k_lo > k_hi) return;
-    const long long dmin = xmajor ? ady : adx, dmaj = xmajor ? adx : ady;       // dmaj > 0 unless N == 0
-    long long j = 0, r = 0;                                                         // minor steps so far, remainder of the division
-    if (dmaj > 0) { const long long num = 2 * dmin * k_lo + dmaj; j = num / (2 * dmaj); r = num % (2 * dmaj); }
-    const long long n0 = xmajor ? e.y0 : e.x0;
-    const int sn = xmajor ? sy : sx;
-    for (long long k = k_lo; k <= k_hi; ++k) {
-        const long long maj = m0 + sm * k, mnr = n0 + sn * j;
-        const long long x = xmajor ? maj : mnr, y = xmajor ? mnr : maj;
-        if (x >= 0 && x < (long long)a.width && y >= (long long)a.band_y0 && y < (long long)a.band_y1) {
+    const I m0 = xmajor ? (I)e.x0 : (I)e.y0;
+    const I sm = xmajor ? sx : sy;
+    const I dmin = xmajor ? ady : adx, dmaj = xmajor ? adx : ady;       // dmaj > 0 unless N == 0
+    I j = 0, r = 0;                                                      // minor steps so far, remainder of the division
+    if (dmaj > 0) { const I num = 2 * dmin * k_a + dmaj; j = num / (2 * dmaj); r = num - j * (2 * dmaj); }
+    const I n0 = xmajor ? (I)e.y0 : (I)e.x0;
+    const I sn = xmajor ? sy : sx;
+    for (I k = k_a; k <= k_b; ++k) {
+        const I maj = m0 + sm * k, mnr = n0 + sn * j;
+        const I x = xmajor ? maj : mnr, y = xmajor ? mnr : maj;
+        if (x >= cx0 && x <= cx1 && y >= cy0 && y <= cy1) {
             bool passes = true;
             if (depth_test) {
-                const float step = (float)(k < 16777216 ? k : 16777216);
+                const float step = (float)(k < (I)16777216 ? k : (I)16777216);
                 const float t = step / total_steps;
                 const float z = e.z0 + t * (e.z1 - e.z0);
-                const float zb = a.zbuf ? a.zbuf[(size_t)y * a.width + (size_t)x] : 3.40282347e+38f;
-                passes = z < zb;
+                passes = z < depth_at((uint32_t)x, (uint32_t)y);
             }
-            if (passes) a.fb[(size_t)y * a.width + (size_t)x] = rgba;                // set_pixel, render.rs:301-310
+            if (passes) plot((uint32_t)x, (uint32_t)y);
         }
         r += 2 * dmin;
         if (dmaj > 0 && r >= 2 * dmaj) { r -= 2 * dmaj; ++j; }
+    }
+}
+template <typename Depth, typename Plot>
+__device__ __forceinline__ void walk_line_range(const Edge& e, bool depth_test, long long cx0, long long cx1, long long cy0, long long cy1,
+                                                long long k_a, long long k_b, Depth depth_at, Plot plot) {
+    const long long adx = llabs((long long)e.x1 - e.x0), ady = llabs((long long)e.y1 - e.y0);
+    const bool narrow = adx < 16384 && ady < 16384 && e.x0 > -1048576 && e.x0 < 1048576 && e.y0 > -1048576 && e.y0 < 1048576;
+    if (narrow) walk_line_range_t<int>(e, depth_test, (int)cx0, (int)cx1, (int)cy0, (int)cy1, (int)k_a, (int)k_b, depth_at, plot);
+    else walk_line_range_t<long long>(e, depth_test, cx0, cx1, cy0, cy1, k_a, k_b, depth_at, plot);
+}
+template <typename Depth, typename Plot>
+__device__ __forceinline__ void walk_line(const Edge& e, bool depth_test, long long cx0, long long cx1, long long cy0, long long cy1, Depth depth_at, Plot plot) {
+    long long k_lo, k_hi;
+    if (line_k_range(e, cx0, cx1, cy0, cy1, k_lo, k_hi)) walk_line_range(e, depth_test, cx0, cx1, cy0, cy1, k_lo, k_hi, depth_at, plot);
+}
+__device__ __forceinline__ bool edge_overflows(const Edge& e) {          // 2*err overflows i32 in the reference (render.rs:735, 800)
+    const long long adx = llabs((long long)e.x1 - e.x0), ady = llabs((long long)e.y1 - e.y0);
+    return adx >= (1ll << 30) || ady >= (1ll << 30);
+}
+__device__ void draw_line_dev(const WireArgs& a, const Edge& e, bool depth_test, uint32_t rgba) {
+    if (edge_overflows(e)) { atomicOr(&a.ctrl->wire_overflow, 1u); atomicOr(&a.ctrl->sticky, 4u); return; }
+    if (a.band_y1 <= a.band_y0 || !a.width) return;
+    walk_line(e, depth_test, 0, (long long)a.width - 1, (long long)a.band_y0, (long long)a.band_y1 - 1,
+              [&](uint32_t x, uint32_t y) { return a.zbuf ? a.zbuf[(size_t)y * a.width + x] : 3.40282347e+38f; },
+              [&](uint32_t x, uint32_t y) { a.fb[(size_t)y * a.width + x] = rgba; });                     // set_pixel, render.rs:301-310
+}
+
+// ---------------------------------------------------------------- lines binned to screen tiles (B32_ROUTE_WIRE_TILES)
+// One lane walking one whole line reads depths and writes colours at scattered addresses all over the frame, and the first-occurrence
+// table is 3 M device-scope atomics (1 M faces: k_wire_insert 136 us + k_wire_draw 213 us).  Tile form: k_wire_bin appends every edge to
+// the list of each 64 x WIRE_TH tile its clipped box touches; k_wire_tile (one workgroup per tile) finds the first occurrences in an LDS
+// table -- every occurrence of an edge has the same coordinates, hence the same tiles, so the smallest id inside a tile is the smallest
+// id overall -- and walks each surviving line's pixels inside the tile into an LDS bit plane; the tile's hit pixels are then written
+// row by row.  Lines write one colour and never the depth buffer, so the order between lines does not matter (the front-face overlay,
+// drawn after the back-face edges by the reference, wins where both hit).  An edge whose box covers more than WIRE_BIG_TILES tiles,
+// and every edge of a frame in which some tile list overflowed, take the global kernels above instead (`wire_global`).
+constexpr uint32_t WIRE_TABLE_SLOTS = 2048, WIRE_BIG_TILES = 64;
+static_assert(WIRE_TABLE_SLOTS >= 2 * 3 * WIRE_TILE_CAP, "LDS table load factor");
+constexpr uint32_t COL_BACK = 80u | (80u << 8) | (100u << 16) | 0xFF000000u;      // Color::new(80, 80, 100), render.rs:2598
+constexpr uint32_t COL_FRONT = 200u | (200u << 8) | (220u << 16) | 0xFF000000u;   // Color::new(200, 200, 220), render.rs:2628
+
+struct WireBox { uint32_t tx0, tx1, ty0, ty1; bool visible, big; };
+// tiles of the edge's box clipped to the frame and the band (every pixel the walk can touch lies inside the box)
+__device__ __forceinline__ WireBox wire_box(const WireArgs& a, const Edge& e) {
+    WireBox b = { 0, 0, 0, 0, false, false };
+    const long long xl = e.x0 < e.x1 ? e.x0 : e.x1, xh = e.x0 < e.x1 ? e.x1 : e.x0, yl = e.y0 < e.y1 ? e.y0 : e.y1, yh = e.y0 < e.y1 ? e.y1 : e.y0;
+    const long long cx0 = xl > 0 ? xl : 0, cx1 = xh < (long long)a.width - 1 ? xh : (long long)a.width - 1;
+    const long long cy0 = yl > (long long)a.band_y0 ? yl : (long long)a.band_y0, cy1 = yh < (long long)a.band_y1 - 1 ? yh : (long long)a.band_y1 - 1;
+    if (cx0 > cx1 || cy0 > cy1) return b;
+    b.visible = true;
+    b.tx0 = (uint32_t)cx0 >> 6; b.tx1 = (uint32_t)cx1 >> 6; b.ty0 = ((uint32_t)cy0 - a.tile_yb) / WIRE_TH; b.ty1 = ((uint32_t)cy1 - a.tile_yb) / WIRE_TH;
+    b.big = (b.tx1 - b.tx0 + 1) * (b.ty1 - b.ty0 + 1) > WIRE_BIG_TILES;
+    return b;
+}
+// does this edge go through the global kernels?  (tile route off: all of them)
+__device__ __forceinline__ bool wire_global(const WireArgs& a, const Edge& e) {
+    if (!a.tile_fill) return true;
+    if (*wire_flag(a, 0)) return true;                   // a tile list overflowed (set by k_wire_bin, an earlier launch): the whole frame
+    const WireBox b = wire_box(a, e);
+    return b.visible && b.big;
+}
+
+// One lane per FACE: its (up to three) edges that take the tile route share one list entry per tile of the box around them -- a third of
+// the reservations an entry per edge would need (a returning device-scope atomic each).  k_wire_tile expands the entry again and lets
+// every edge take part only in the tiles of its OWN box, so all occurrences of an edge still meet in exactly the same tiles.
+__global__ void k_wire_bin(WireArgs a, uint32_t kinds) {           // kinds: bit 0 back-face edges, bit 1 front-face overlay
+    phase_stamp(a.ctrl, ST_WIRE);
+    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= a.nf || a.ctrl->abort) return;
+    const WireTri t = a.tris[f];
+    if (t.kind == 0 || !((kinds >> (t.kind - 1)) & 1u)) return;
+    uint32_t tx0 = 0xFFFFFFFFu, tx1 = 0, ty0 = 0xFFFFFFFFu, ty1 = 0, n_big = 0;
+    bool any = false, bad = false;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const Edge e = wire_edge(t, j);
+        if (edge_overflows(e)) { bad = true; continue; }
+        const WireBox b = wire_box(a, e);
+        if (!b.visible) continue;
+        if (b.big) { ++n_big; continue; }
+        any = true;
+        tx0 = min(tx0, b.tx0); tx1 = max(tx1, b.tx1); ty0 = min(ty0, b.ty0); ty1 = max(ty1, b.ty1);
+    }
+    if (bad) { atomicOr(&a.ctrl->wire_overflow, 1u); atomicOr(&a.ctrl->sticky, 4u); }
+    if (n_big) atomicAdd(wire_flag(a, 1), n_big);
+    if (!any) return;
+    for (uint32_t ty = ty0; ty <= ty1; ++ty)
+        for (uint32_t tx = tx0; tx <= tx1; ++tx) {
+            const uint32_t tile = ty * a.tiles_x + tx;
+            const uint32_t pos = atomicAdd(wire_counter(a, tile), 1u);
+            if (pos < WIRE_TILE_CAP) a.tile_lists[(size_t)tile * WIRE_TILE_CAP + pos] = f;
+            else atomicOr(wire_flag(a, 0), 1u);
+        }
+}
+
+// One 16-wave workgroup per tile, one lane per list entry (face).  LDS: the tile's depths (the walk tests every pixel against them), the
+// screen integers of every edge slot, the first-occurrence table, two bit planes of hit pixels.  The walks are NOT done edge by edge --
+// a wave would last as long as its longest line times three -- but as SEGMENTS of at most WIRE_SEG steps, dealt out evenly: every
+// surviving edge reports its step range inside the tile, a prefix sum over the 3072 edge slots numbers the segments, and lane t takes
+// segments t, t + 1024, ... (owner found by binary search in the prefix array; the closed form starts a walk at any step).
+constexpr uint32_t WIRE_EDGE_SLOTS = 3 * WIRE_TILE_CAP, WIRE_SEG = 16, WIRE_SEGS_PER_EDGE = 64 / WIRE_SEG;    // (at most 64 steps of a line lie inside a tile)
+constexpr uint32_t WIRE_THREADS = 256, WIRE_PX = 64 * WIRE_TH;
+static_assert(WIRE_TILE_CAP == WIRE_THREADS && WIRE_EDGE_SLOTS <= 4096 && WIRE_SEGS_PER_EDGE <= 16, "k_wire_tile: one lane per entry, 12 + 4 bits per segment word");
+struct WireSegRec { float z0, z1; uint32_t k_lo, n_steps_kind; };       // n_steps | kind << 31 (kind: 0 back-face, depth-tested; 1 overlay)
+static_assert(sizeof(WireSegRec) * WIRE_EDGE_SLOTS <= 2 * WIRE_TABLE_SLOTS * sizeof(uint32_t), "segment records reuse the table's LDS");
+__global__ __launch_bounds__(WIRE_THREADS) void k_wire_tile(WireArgs a) {
+    __shared__ int4 keys[WIRE_EDGE_SLOTS];               // 12 KB
+    __shared__ __attribute__((aligned(16))) uint32_t table[2 * WIRE_TABLE_SLOTS];   // [0, SLOTS): slot -> claiming edge slot; [SLOTS, 2 SLOTS): smallest id (16 KB)
+    __shared__ float zt[WIRE_PX];                        // Framebuffer::zbuffer of the tile (read-only here) (4 KB)
+    __shared__ uint16_t segs[WIRE_EDGE_SLOTS * WIRE_SEGS_PER_EDGE];   // segment -> edge slot | segment number << 12 (3 KB)
+    __shared__ uint32_t mask[2][WIRE_PX / 32];                    // hit pixels: [0] back-face colour, [1] front-face overlay
+    __shared__ uint32_t wsum[WIRE_THREADS / 64];
+    uint32_t* owner = table; uint32_t* first = table + WIRE_TABLE_SLOTS;
+    const uint32_t tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t n_all = *wire_counter(a, tile);
+    const bool overflowed = *wire_flag(a, 0) != 0;
+    __syncthreads();                                     // (everyone has read the counter)
+    if (tid == 0) *wire_counter(a, tile) = 0;            // zero again for the next frame's k_wire_bin
+    if (overflowed || n_all == 0 || a.ctrl->abort) return;
+    const uint32_t n = n_all < WIRE_TILE_CAP ? n_all : WIRE_TILE_CAP;
+    const uint32_t txi = tile % a.tiles_x, tyi = tile / a.tiles_x, x_lo = txi * 64u, y_top = a.tile_yb + tyi * WIRE_TH;
+    for (uint32_t i = tid; i < 2 * WIRE_TABLE_SLOTS; i += WIRE_THREADS) table[i] = SLOT_EMPTY;
+    if (tid < 2 * WIRE_PX / 32) (&mask[0][0])[tid] = 0;
+    for (uint32_t p = tid; p < WIRE_PX; p += WIRE_THREADS) {
+        const uint32_t x = x_lo + (p & 63u), y = y_top + (p >> 6);
+        zt[p] = (a.zbuf && x < a.width && y >= a.band_y0 && y < a.band_y1) ? a.zbuf[(size_t)y * a.width + x] : 3.40282347e+38f;
+    }
+    Edge e[3]; uint32_t slot[3] = { 0, 0, 0 }; bool on[3] = { false, false, false };
+    uint32_t f = 0, kind = 0;
+    if (tid < n) {
+        f = a.tile_lists[(size_t)tile * WIRE_TILE_CAP + tid];
+        const WireTri t = a.tris[f];
+        kind = t.kind;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            e[j] = wire_edge(t, j);
+            if (edge_overflows(e[j])) continue;
+            const WireBox b = wire_box(a, e[j]);
+            // the edge takes part here iff this tile lies in its OWN box (so does every other occurrence of it)
+            on[j] = b.visible && !b.big && txi >= b.tx0 && txi <= b.tx1 && tyi >= b.ty0 && tyi <= b.ty1;
+            if (on[j]) keys[tid * 3 + j] = make_int4(e[j].x0, e[j].y0, e[j].x1, e[j].y1);
+        }
+    }
+    __syncthreads();
+#if defined(B32_EXP_WIRE_STAGE) && B32_EXP_WIRE_STAGE <= 1
+    return;
+#endif
+    if (kind == 1) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            if (!on[j]) continue;
+            const uint32_t i = tid * 3 + j;
+            uint32_t h = edge_hash(e[j]) & (WIRE_TABLE_SLOTS - 1);
+            for (;;) {
+                const uint32_t cur = atomicCAS(&owner[h], SLOT_EMPTY, i);
+                if (cur == SLOT_EMPTY || cur == i) break;
+                const int4 o = keys[cur];
+                if (o.x == e[j].x0 && o.y == e[j].y0 && o.z == e[j].x1 && o.w == e[j].y1) break;
+                h = (h + 1) & (WIRE_TABLE_SLOTS - 1);
+            }
+            atomicMin(&first[h], f * 3u + (uint32_t)j);
+            slot[j] = h;
+        }
+    }
+    __syncthreads();
+#if defined(B32_EXP_WIRE_STAGE) && B32_EXP_WIRE_STAGE <= 2
+    return;
+#endif
+    // which of my edges are drawn, over which steps: segment counts
+    const long long cx0 = x_lo, cx1 = (x_lo + 63u < a.width - 1u) ? x_lo + 63u : a.width - 1u;
+    const long long cy0 = y_top > a.band_y0 ? y_top : a.band_y0, cy1 = (y_top + WIRE_TH - 1u < a.band_y1 - 1u) ? y_top + WIRE_TH - 1u : a.band_y1 - 1u;
+    uint32_t nseg[3] = { 0, 0, 0 }, klo[3] = { 0, 0, 0 }, nst[3] = { 0, 0, 0 };
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        if (!on[j] || !kind) continue;
+        if (kind == 1 && first[slot[j]] != f * 3u + (uint32_t)j) continue;               // an earlier occurrence of this edge draws it
+        long long k_lo, k_hi;
+        if (!line_k_range(e[j], cx0, cx1, cy0, cy1, k_lo, k_hi)) continue;               // (k_lo < 2^30, at most 64 steps inside a tile)
+        klo[j] = (uint32_t)k_lo; nst[j] = (uint32_t)(k_hi - k_lo + 1);
+        nseg[j] = (nst[j] + WIRE_SEG - 1) / WIRE_SEG;
+    }
+    __syncthreads();                                     // (everyone is done with the table: its LDS now holds the segment records)
+    WireSegRec* rec = reinterpret_cast<WireSegRec*>(table);
+    const uint32_t mine = nseg[0] + nseg[1] + nseg[2];
+    uint32_t inc = mine;                                 // inclusive scan over the workgroup: wave scan, wave totals, offsets
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t v = __shfl_up(inc, off); if (lane >= (uint32_t)off) inc += v; }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t base = inc - mine;
+    for (uint32_t w = 0; w < wave; ++w) base += wsum[w];
+    uint32_t total = 0;
+    for (uint32_t w = 0; w < WIRE_THREADS / 64; ++w) total += wsum[w];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const uint32_t i = tid * 3 + j;
+        if (nseg[j]) rec[i] = { e[j].z0, e[j].z1, klo[j], nst[j] | ((kind == 2 ? 1u : 0u) << 31) };
+        for (uint32_t q = 0; q < nseg[j]; ++q) segs[base + q] = (uint16_t)(i | (q << 12));      // (i < 768 < 2^12, q < 4)
+        base += nseg[j];
+    }
+    __syncthreads();
+#if defined(B32_EXP_WIRE_STAGE) && B32_EXP_WIRE_STAGE <= 3
+    return;
+#endif
+    for (uint32_t t = tid; t < total; t += WIRE_THREADS) {
+        const uint32_t sg = segs[t], lo = sg & 0xFFFu, q = sg >> 12;
+        const WireSegRec r = rec[lo];
+        const int4 kk = keys[lo];
+        const Edge ed = { kk.x, kk.y, kk.z, kk.w, r.z0, r.z1 };
+        const uint32_t steps = r.n_steps_kind & 0x7FFFFFFFu, which = r.n_steps_kind >> 31;
+        const long long k_a = (long long)r.k_lo + (long long)q * WIRE_SEG;
+        const long long k_b = (long long)r.k_lo + (long long)min((q + 1) * WIRE_SEG, steps) - 1;
+        walk_line_range(ed, which == 0, cx0, cx1, cy0, cy1, k_a, k_b,
+                        [&](uint32_t x, uint32_t y) { return zt[(y - y_top) * 64u + (x - x_lo)]; },
+                        [&](uint32_t x, uint32_t y) {
+                            const uint32_t bit = (y - y_top) * 64u + (x - x_lo);
+                            atomicOr(&mask[which][bit >> 5], 1u << (bit & 31u));
+                        });
+    }
+    __syncthreads();
+    for (uint32_t p = tid; p < WIRE_PX; p += WIRE_THREADS) {
+        const uint32_t w = p >> 5, b = 1u << (p & 31u);
+        const bool fr = (mask[1][w] & b) != 0, bk = (mask[0][w] & b) != 0;
+        if (fr | bk) a.fb[(size_t)(y_top + (p >> 6)) * a.width + x_lo + (p & 63u)] = fr ? COL_FRONT : COL_BACK;      // set_pixel, render.rs:301-310
     }
 }
 
 template <int KIND>
 __global__ void k_wire_draw(WireArgs a) {
     phase_stamp(a.ctrl, ST_WIRE);
-    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= a.nf * 3 || a.ctrl->abort) return;
-    const uint32_t f = id / 3;
-    if (a.tris[f].kind != (uint32_t)KIND) return;
-    const Edge e = wire_edge(a.tris[f], (int)(id % 3));
-    if (KIND == 1) {
-        const uint32_t h = wire_slot(a, e, id, false);
-        if (h == SLOT_EMPTY || a.table_first[h] != id) return;          // a previous occurrence of this edge draws it
-        draw_line_dev(a, e, true, 80u | (80u << 8) | (100u << 16) | 0xFF000000u);     // Color::new(80, 80, 100), render.rs:2598
-    } else {
-        draw_line_dev(a, e, false, 200u | (200u << 8) | (220u << 16) | 0xFF000000u);  // Color::new(200, 200, 220), render.rs:2628
+    if (a.ctrl->abort || wire_global_idle(a)) return;
+    for (uint32_t id = blockIdx.x * blockDim.x + threadIdx.x; id < a.nf * 3; id += gridDim.x * blockDim.x) {
+        const uint32_t f = id / 3;
+        if (a.tris[f].kind != (uint32_t)KIND) continue;
+        const Edge e = wire_edge(a.tris[f], (int)(id % 3));
+        if (!wire_global(a, e)) continue;
+        if (KIND == 1) {
+            const uint32_t h = wire_slot(a, e, id, false);
+            if (h == SLOT_EMPTY || a.table_first[h] != id) continue;    // a previous occurrence of this edge draws it
+            draw_line_dev(a, e, true, COL_BACK);
+        } else {
+            draw_line_dev(a, e, false, COL_FRONT);
+        }
     }
 }
 
 void launch_wire(hipStream_t s, const WireArgs& a, bool back, bool front) {
-    if (!a.nf) return;
+    if (!a.nf || !(back || front)) return;
     const uint32_t n = a.nf * 3, blocks = (n + 255) / 256;
-    if (back) {
-        hipLaunchKernelGGL(k_wire_table_clear, dim3(1024), dim3(256), 0, s, a.table_owner, a.table_first, a.table_mask + 1);
-        hipLaunchKernelGGL(k_wire_insert, dim3(blocks), dim3(256), 0, s, a);
-        hipLaunchKernelGGL(k_wire_draw<1>, dim3(blocks), dim3(256), 0, s, a);
+    const uint32_t ntiles = a.tiles_x * a.tiles_y;
+    if (a.tile_fill && ntiles) {
+        // tile route: bin, then one workgroup per tile; the global kernels behind them return at once unless a list overflowed or some
+        // edge's box covers more than WIRE_BIG_TILES tiles (then they draw exactly those edges -- or, after an overflow, all of them)
+        hipLaunchKernelGGL(k_wire_bin, dim3((a.nf + 255) / 256), dim3(256), 0, s, a, (back ? 1u : 0u) | (front ? 2u : 0u));
+        hipLaunchKernelGGL(k_wire_tile, dim3(ntiles), dim3(WIRE_THREADS), 0, s, a);
     }
-    if (front) hipLaunchKernelGGL(k_wire_draw<2>, dim3(blocks), dim3(256), 0, s, a);
+    const uint32_t* flags = (a.tile_fill && ntiles) ? a.tile_fill + (size_t)ntiles * FILL_PAD : nullptr;
+    // (tile route on: the global kernels usually have nothing to do -- 2048 workgroups that look at the flags and leave, or loop over
+    // the edges left to them; tile route off: one lane per edge as before)
+    const uint32_t gblocks = flags ? min(blocks, 2048u) : blocks;
+    if (back) {
+        hipLaunchKernelGGL(k_wire_table_clear, dim3(flags ? 256 : 1024), dim3(256), 0, s, a.table_owner, a.table_first, a.table_mask + 1, flags);
+        hipLaunchKernelGGL(k_wire_insert, dim3(gblocks), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(k_wire_draw<1>, dim3(gblocks), dim3(256), 0, s, a);
+    }
+    if (front) hipLaunchKernelGGL(k_wire_draw<2>, dim3(gblocks), dim3(256), 0, s, a);
+    if (flags) (void)hipMemsetAsync(a.tile_fill + (size_t)ntiles * FILL_PAD, 0, 2 * FILL_PAD * sizeof(uint32_t), s);      // overflow flag + big-edge count: zero between frames
 }
 
 }  // namespace b32

@@ -220,9 +220,14 @@ public:
         std::vector<B32Texture15> t; t.reserve(textures.size());
         for (const auto& x : textures)
             t.push_back({ (uint32_t)x.width, (uint32_t)x.height, (uint32_t)x.blend_mode, 0, x.pixels.size() >= x.width * x.height ? x.pixels.data() : nullptr });
-        check(b32_scene_upload(ctx_, v.data(), (uint32_t)v.size(), f.data(), (uint32_t)f.size(), t.data(), (uint32_t)t.size()), "scene_upload");
+        // The context keeps whatever scene it holds: its scene moves into the fresh slot, the mesh is uploaded into the (now empty)
+        // context, and a second exchange leaves the mesh in the slot and the context's own scene where it was -- also when the upload
+        // throws (render_scene-style calls and ResidentMesh can then share one Framebuffer).
         check(b32_scene_create(ctx_, &slot_), "scene_create");
-        check(b32_scene_swap(ctx_, slot_), "scene_swap");            // the slot now owns the mesh
+        check(b32_scene_swap(ctx_, slot_), "scene_swap");            // context's scene -> slot, context empty
+        const int rc = b32_scene_upload(ctx_, v.data(), (uint32_t)v.size(), f.data(), (uint32_t)f.size(), t.data(), (uint32_t)t.size());
+        const int rc2 = b32_scene_swap(ctx_, slot_);                 // mesh -> slot, context's scene back
+        if (rc || rc2) { b32_scene_destroy(ctx_, slot_); slot_ = nullptr; check(rc ? rc : rc2, rc ? "scene_upload" : "scene_swap"); }
     }
     ~ResidentMesh() { if (slot_) b32_scene_destroy(ctx_, slot_); }
     ResidentMesh(const ResidentMesh&) = delete;

@@ -72,9 +72,9 @@ class Context:
         """b32_set_async_depth: 0 = safe (default), 1 = large-scene frames back to back, a dropped one is reported by finish()."""
         _chk(self.lib.b32_set_async_depth(self.h, int(deep)), "b32_set_async_depth")
 
-    ROUTES = ("direct_bin", "inline_bin", "counting_sort", "keyed", "redraw_region", "redraw_global_sort", "redraw_pairs", "pipelined", "lds_atlas")
+    ROUTES = ("direct_bin", "inline_bin", "counting_sort", "keyed", "redraw_region", "redraw_global_sort", "redraw_pairs", "pipelined", "lds_atlas", "wire_tiles")
 
-    ROUTE_SORT_FREE, ROUTE_CUT_TILES, ROUTE_INLINE_BIN, ROUTE_DIRECT_BIN, ROUTE_WIDE_GROUPS, ROUTE_PACKED_STREAMS, ROUTE_PIPELINE, ROUTE_TEX_CACHE, ROUTE_BATCH, ROUTE_LDS_ATLAS = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
+    ROUTE_SORT_FREE, ROUTE_CUT_TILES, ROUTE_INLINE_BIN, ROUTE_DIRECT_BIN, ROUTE_WIDE_GROUPS, ROUTE_PACKED_STREAMS, ROUTE_PIPELINE, ROUTE_TEX_CACHE, ROUTE_BATCH, ROUTE_LDS_ATLAS, ROUTE_WIRE_TILES = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024
 
     # ---- a frame of several meshes (scene.rs:112-261): b32_frame_begin / _add_scene / _end
     def frame_begin(self, camera, settings):
@@ -113,6 +113,18 @@ class Context:
     def set_pipeline_gate(self, permille):
         """b32_set_pipeline_gate: hold a pipelined setup kernel until the previous fill's tile cursor has come that far (include/b32raster.h)."""
         _chk(self.lib.b32_set_pipeline_gate(self.h, int(permille)), "b32_set_pipeline_gate")
+
+    def last_shader_clock(self):
+        """b32_last_shader_clock: (GHz, ms) the fused kernel of the last finished frame ran at / over; (0, 0) if it had none."""
+        g, m = C.c_float(), C.c_float()
+        _chk(self.lib.b32_last_shader_clock(self.h, C.byref(g), C.byref(m)), "b32_last_shader_clock")
+        return float(g.value), float(m.value)
+
+    def transparent_counts(self):
+        """b32_transparent_counts: (host-side bound counted at upload, surfaces the last finished frame's setup kernel classified transparent)."""
+        a, b = C.c_uint32(), C.c_uint32()
+        _chk(self.lib.b32_transparent_counts(self.h, C.byref(a), C.byref(b)), "b32_transparent_counts")
+        return int(a.value), int(b.value)
 
     def set_pipeline_depth(self, sets):
         """b32_set_pipeline_depth: 2 or 3 frame sets -- the setup kernel one or two frames ahead of the fill (include/b32raster.h)."""

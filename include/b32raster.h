@@ -244,7 +244,8 @@ int b32_set_async_depth(b32_ctx* ctx, int deep);
  * lists were collected inside the fill kernel (small meshes), 2 frames binned by the counting-sort launches, 3 frames through the
  * keyed pipeline (global depth sort), 4 frames redrawn because a tile region overflowed, 5 frames redrawn through the global depth
  * sort, 6 frames redrawn after a pair-buffer overflow, 7 frames whose setup kernel ran on the second stream beside the previous frame's
- * fill (two frames in flight), 8 frames whose fused kernel sampled the 4/8-bit index atlas + CLUT from LDS (B32_ROUTE_LDS_ATLAS).
+ * fill (two frames in flight), 8 frames whose fused kernel sampled the 4/8-bit index atlas + CLUT from LDS (B32_ROUTE_LDS_ATLAS),
+ * 9 frames whose wireframe phases went through the tile route (B32_ROUTE_WIRE_TILES).
  * Unknown `which` or null ctx: 0. */
 unsigned long long b32_route_count(const b32_ctx* ctx, int which);
 /* Switch internal routes OFF for the frames enqueued from now on (no reference counterpart: the results are identical on every route;
@@ -260,6 +261,8 @@ unsigned long long b32_route_count(const b32_ctx* ctx, int which);
 #define B32_ROUTE_LDS_ATLAS   512u /* one indexed texture (b32_scene_upload_indexed): index atlas + CLUT staged in LDS by every workgroup of the fused
                                     * kernel and looked up per shaded pixel (Clut::lookup, types.rs:390-397) whenever they fit beside the tile planes
                                     * -> expanded Color15 texels fetched from global memory                                          */
+#define B32_ROUTE_WIRE_TILES  1024u /* wireframe phases (render.rs:2574-2635): edges binned to 64x64 tiles, first occurrences found in an LDS table per tile,
+                                    * lines walked into an LDS bit plane -> one global first-occurrence table + one lane per whole line        */
 #define B32_ROUTE_PIPELINE    64u  /* setup kernel of the next frame on a second stream beside the fill of the current one -> one stream */
 int b32_set_routes(b32_ctx* ctx, uint32_t off_mask);
 /* CHEAP coverage (inside test only, texel rule applied to the winner) is used while every texture has at most 1/den skippable texels
@@ -379,6 +382,15 @@ int b32_set_profiling(b32_ctx* ctx, int level);
 /* Instrument only every `every`-th frame (default 1: each one).  An event pair around a kernel costs the stream a few microseconds
  * per frame (the kernels of consecutive frames no longer run back to back); bench.py samples every 8th frame of its timed region. */
 int b32_set_profiling_stride(b32_ctx* ctx, uint32_t every);
+/* Shader clock the fused fill kernel of the last finished frame really ran at (no reference counterpart; instrumentation): workgroup 0
+ * reads the shader-cycle counter and the 100 MHz wall clock when it starts and when it runs out of tiles.  *ghz = 0 when that frame had
+ * no such kernel; *fill_ms (nullable) = the wall-clock span the cycles were counted over.  bench.py prices VALU issue with it. */
+int b32_last_shader_clock(const b32_ctx* ctx, float* ghz, float* fill_ms);
+/* Test tap (no reference counterpart): *host_bound = the faces of the resident scene that their own blend mode / editor alpha or their
+ * texture's blend mode can put in the transparent pass (render.rs:2403-2415), counted on the host at upload -- what decides whether a
+ * frame of a moderate mesh can ever need a redraw; *device_last = the surfaces the setup kernel of the last finished frame really
+ * classified as transparent.  device_last <= host_bound must hold for every frame. */
+int b32_transparent_counts(const b32_ctx* ctx, uint32_t* host_bound, uint32_t* device_last);
 /* Two frames in flight (no reference counterpart; see B32_ROUTE_PIPELINE): when a frame is enqueued while an earlier one is still
  * pending, its setup kernel runs on a second, low-priority stream of the context beside the earlier frame's fill kernel, on a second
  * set of per-face buffers.  permille > 0 holds that setup kernel back so that it runs beside the fill's thinning second half rather than

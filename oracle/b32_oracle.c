@@ -931,18 +931,24 @@ EXPORT int b32o_draw_line_3d(uint8_t* pixels, const float* zbuffer, uint32_t wid
 typedef struct { int32_t x0, y0; float z0; int32_t x1, y1; float z1; } WireEdge;
 typedef struct { V3 v1, v2, v3; } WireTri;
 /* unique-edge list of a wireframe phase, render.rs:2578-2596 / 2604-2626: first occurrence wins, compared on screen integers only */
-static WireEdge* unique_edges(const WireTri* tris, uint32_t n, uint32_t* n_out) {
+static inline WireEdge wire_edge_of(const WireTri* t, int j) {
+    const V3 p[3] = { t->v1, t->v2, t->v3 };
+    const V3 a = p[j], b = p[(j + 1) % 3];
+    WireEdge e = { f2i32_sat(a.x), f2i32_sat(a.y), a.z, f2i32_sat(b.x), f2i32_sat(b.y), b.z };
+    if (!(e.x0 < e.x1 || (e.x0 == e.x1 && e.y0 < e.y1))) {                                      /* (x0, y0) < (x1, y1) as tuples */
+        WireEdge r = { e.x1, e.y1, e.z1, e.x0, e.y0, e.z0 };
+        e = r;
+    }
+    return e;
+}
+/* the reference's own form: `unique_edges.iter().any(..)` before every push -- O(n^2), kept as the definition (small inputs and the
+ * self-check below) */
+static WireEdge* unique_edges_quadratic(const WireTri* tris, uint32_t n, uint32_t* n_out) {
     WireEdge* out = (WireEdge*)malloc(sizeof(WireEdge) * ((size_t)n * 3 + 1));
     uint32_t cnt = 0;
     for (uint32_t i = 0; i < n; ++i) {
-        const V3 p[3] = { tris[i].v1, tris[i].v2, tris[i].v3 };
         for (int j = 0; j < 3; ++j) {
-            const V3 a = p[j], b = p[(j + 1) % 3];
-            WireEdge e = { f2i32_sat(a.x), f2i32_sat(a.y), a.z, f2i32_sat(b.x), f2i32_sat(b.y), b.z };
-            if (!(e.x0 < e.x1 || (e.x0 == e.x1 && e.y0 < e.y1))) {                              /* (x0, y0) < (x1, y1) as tuples */
-                WireEdge t = { e.x1, e.y1, e.z1, e.x0, e.y0, e.z0 };
-                e = t;
-            }
+            const WireEdge e = wire_edge_of(&tris[i], j);
             int seen = 0;
             for (uint32_t k = 0; k < cnt && !seen; ++k)
                 seen = out[k].x0 == e.x0 && out[k].y0 == e.y0 && out[k].x1 == e.x1 && out[k].y1 == e.y1;
@@ -951,6 +957,57 @@ static WireEdge* unique_edges(const WireTri* tris, uint32_t n, uint32_t* n_out) 
     }
     *n_out = cnt;
     return out;
+}
+/* The same list through a hash set of the four screen integers (open addressing; a slot holds the index of the edge in `out`): an edge
+ * is pushed iff no equal edge was pushed before, in the same (face, edge) order -- the definition above, in O(n).  The 1 M-triangle
+ * frames of RasterSettings::default() need it: the quadratic scan takes minutes there.  b32o_unique_edges_selfcheck compares the two. */
+static WireEdge* unique_edges(const WireTri* tris, uint32_t n, uint32_t* n_out) {
+    if (n < 64) return unique_edges_quadratic(tris, n, n_out);
+    WireEdge* out = (WireEdge*)malloc(sizeof(WireEdge) * ((size_t)n * 3 + 1));
+    size_t slots = 1024;
+    while (slots < (size_t)n * 6) slots <<= 1;
+    uint32_t* table = (uint32_t*)malloc(sizeof(uint32_t) * slots);
+    memset(table, 0xFF, sizeof(uint32_t) * slots);
+    uint32_t cnt = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        for (int j = 0; j < 3; ++j) {
+            const WireEdge e = wire_edge_of(&tris[i], j);
+            uint64_t h = (uint64_t)(uint32_t)e.x0 * 0x9E3779B97F4A7C15ull;
+            h = (h ^ (h >> 29)) + (uint64_t)(uint32_t)e.y0 * 0xBF58476D1CE4E5B9ull;
+            h = (h ^ (h >> 31)) + (uint64_t)(uint32_t)e.x1 * 0x94D049BB133111EBull;
+            h = (h ^ (h >> 27)) + (uint64_t)(uint32_t)e.y1 * 0xD6E8FEB86659FD93ull;
+            size_t s = (size_t)(h ^ (h >> 32)) & (slots - 1);
+            int seen = 0;
+            while (table[s] != 0xFFFFFFFFu) {
+                const WireEdge* o = &out[table[s]];
+                if (o->x0 == e.x0 && o->y0 == e.y0 && o->x1 == e.x1 && o->y1 == e.y1) { seen = 1; break; }
+                s = (s + 1) & (slots - 1);
+            }
+            if (!seen) { table[s] = cnt; out[cnt++] = e; }
+        }
+    }
+    free(table);
+    *n_out = cnt;
+    return out;
+}
+/* test hook: n triangles as 9 floats each (three screen vertices x, y, z); 0 = the hash-set list equals the quadratic one, entry for
+ * entry (coordinates and depths), else 1 + index of the first difference (or of the shorter list's end) */
+EXPORT uint32_t b32o_unique_edges_selfcheck(const float* tri_xyz, uint32_t n) {
+    WireTri* t = (WireTri*)malloc(sizeof(WireTri) * (n ? n : 1));
+    for (uint32_t i = 0; i < n; ++i) {
+        const float* p = tri_xyz + (size_t)i * 9;
+        const V3 a = { p[0], p[1], p[2] }, b = { p[3], p[4], p[5] }, c = { p[6], p[7], p[8] };
+        t[i].v1 = a; t[i].v2 = b; t[i].v3 = c;
+    }
+    uint32_t na = 0, nb = 0, bad = 0;
+    WireEdge* a = unique_edges_quadratic(t, n, &na);
+    WireEdge* b = unique_edges(t, n, &nb);
+    const uint32_t m = na < nb ? na : nb;
+    for (uint32_t i = 0; i < m && !bad; ++i)
+        if (memcmp(&a[i], &b[i], sizeof(WireEdge)) != 0) bad = 1 + i;
+    if (!bad && na != nb) bad = 1 + m;
+    free(a); free(b); free(t);
+    return bad;
 }
 
 /* ------------------------------------------------------------------ stable descending sort (slice::sort_by, render.rs:2527-2542) */

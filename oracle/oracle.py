@@ -53,6 +53,7 @@ def _load(path):
         L.b32o_dither_offset.restype = C.c_int32; L.b32o_dither_offset.argtypes = [C.c_uint32, C.c_uint32]
         L.b32o_dither_and_quantize.restype = None
         L.b32o_dither_and_quantize.argtypes = [C.c_uint8] * 3 + [C.c_uint32, C.c_uint32, P]
+        L.b32o_unique_edges_selfcheck.restype = C.c_uint32; L.b32o_unique_edges_selfcheck.argtypes = [P, C.c_uint32]
         L.b32o_fb_clear.restype = None
         L.b32o_fb_clear.argtypes = [P, P, C.c_uint32, C.c_uint32] + [C.c_uint8] * 4
         L.b32o_render_mesh_15.restype = C.c_int
@@ -111,6 +112,13 @@ def constants():
     L = lib()
     names = [L.b32o_constant_name(i).decode() for i in range(L.b32o_constant_count())]
     return {n: L.b32o_constant(n.encode()) for n in names}
+
+
+def unique_edges_selfcheck(tri_xyz):
+    """0 when the hash-set edge de-duplication of the wireframe phases equals the reference's quadratic `any()` scan (render.rs:2589-2594)
+    on these triangles (n x 9 floats: three screen vertices x, y, z), entry for entry; else 1 + the first differing index."""
+    t = np.ascontiguousarray(tri_xyz, np.float32).reshape(-1, 9)
+    return int(lib().b32o_unique_edges_selfcheck(t.ctypes.data, t.shape[0]))
 
 
 def expand_indexed(indices, clut):

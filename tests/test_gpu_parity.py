@@ -327,7 +327,8 @@ def test_c1_against_committed_frame(gpu_ctx):
 
 @pytest.mark.parametrize("name", ["C3:100k", "C5:20k"])
 def test_frame_parity_large_frame(gpu_ctx, oracle, name):
-    """2560x1920 frames: resident scene, index atlas + CLUT expanded on the device, texture staged in LDS."""
+    """2560x1920 frames: resident scene, index atlas + CLUT expanded on the device; the fused kernel fetches the expanded texels through
+    L1 / L2 (a 64 KB atlas does not fit beside two workgroups' tile planes: see test_index_atlas_and_clut_sampled_from_lds)."""
     sc = SCENES[name]()
     got, tm = gpu_render(gpu_ctx, sc, resident=True, indexed=True)
     assert hashlib.sha256(got).hexdigest() == HASHES[name]["sha256"]
@@ -488,6 +489,38 @@ def test_two_frames_in_flight(oracle, gate, routes_off, depth):
         tm = rs2.finish()
         assert tm.triangles_drawn == otm.triangles_drawn and np.array_equal(fb2.pixels, o2.pixels)
         assert np.array_equal(ctx.last_draw_order(len(sc.faces)), dump["draw_order"])
+        ctx.close()
+
+
+def test_host_count_of_transparent_faces_bounds_the_device_classification(oracle):
+    """A moderate mesh's frame is left in flight (never settled, never redrawn) when its tile regions hold every face and the HOST's count
+    of faces that can be transparent fits what k_blend sorts per tile (enqueue_frame: direct_safe).  That count (upload_geometry: the
+    face's own blend mode / editor alpha, or its texture's blend mode, render.rs:2403-2415) must bound what the setup kernel classifies
+    on the device -- with nothing culled the two are equal."""
+    from bonnie32_amd import rasterizer as R
+    rng = np.random.default_rng(5)
+    for trial in range(6):
+        sc = scenegen.make_scene("C3", n_tris=20_000, width=640, height=480, bbox_px=50.0, seed=900 + trial, variant="blend" if trial % 2 else "bench")
+        n = len(sc.faces)
+        # three textures, one of them blending; texture ids partly out of range (untextured: only the face's own mode counts)
+        base = sc.textures[0]
+        sc.textures = [base, b32.Texture15(base.width, base.height, base.pixels.copy(), int(b32.abi.ADD)), b32.Texture15(8, 8, base.pixels[:64].copy(), int(b32.abi.OPAQUE))]
+        sc.faces["texture_id"] = rng.integers(0, 5, n).astype(np.uint32)
+        sc.faces["texture_id"][::17] = 0xFFFFFFFF
+        sc.faces["editor_alpha"][::29] = int(rng.choice([0, 128, 254]))
+        sc.faces["blend_mode"][::31] = int(b32.abi.SUBTRACT)
+        sc.settings.backface_cull = bool(trial % 3 == 0)
+        ctx = R.Context(0)
+        fb = R.Framebuffer(sc.width, sc.height, ctx); fb.clear(sc.clear_color)
+        rs = R.ResidentScene(fb, sc.vertices, sc.faces, sc.textures)
+        tm = rs.render(sc.camera, sc.settings)
+        host, dev = ctx.transparent_counts()
+        ofb = oracle.Framebuffer(sc.width, sc.height); ofb.clear(sc.clear_color)
+        rc, otm, d = oracle.render_mesh_15(ofb, sc.vertices, sc.faces, sc.textures, sc.camera, sc.settings, None, dump=True)
+        assert rc == 0 and np.array_equal(fb.pixels, ofb.pixels) and tm.triangles_drawn == otm.triangles_drawn
+        assert dev <= host, (trial, dev, host)
+        if not sc.settings.backface_cull and tm.triangles_drawn == n:
+            assert dev == host, (trial, dev, host)
         ctx.close()
 
 
@@ -1009,6 +1042,50 @@ def test_editor_modes_parity(gpu_ctx, oracle, name, counting):
         assert np.array_equal(gpu_ctx.last_draw_order(len(sc.faces)), d["draw_order"])
     finally:
         gpu_ctx.set_fragment_counting(1)
+
+
+@pytest.mark.parametrize("case", ["small", "medium", "long-lines", "crowded-tile", "overlay", "both-phases", "bands"])
+def test_wireframe_phases_through_screen_tiles(oracle, case):
+    """B32_ROUTE_WIRE_TILES: the edges of the wireframe phases (render.rs:2574-2635) binned to 64x64 tiles, first occurrences found in an
+    LDS table per tile, lines walked into an LDS bit plane.  Same frame as the oracle (and as the global kernels, route off):
+      long-lines    triangles of ~2500 px: edges whose box covers more than 16 tiles stay with the global kernels, the others go by tile
+      crowded-tile  a far camera puts every edge into a few tiles: their lists overflow and the whole frame falls back
+      both-phases   back-face wireframe AND front-face overlay in one frame (the overlay is drawn later: it wins where both hit)"""
+    from bonnie32_amd import rasterizer as R
+    cfg = {"small": (2_000, 320, 240, 64.0), "medium": (60_000, 1280, 960, 70.0), "long-lines": (6_000, 1280, 960, 2500.0),
+           "crowded-tile": (40_000, 640, 480, 60.0), "overlay": (30_000, 1280, 960, 90.0), "both-phases": (30_000, 640, 480, 120.0),
+           "bands": (50_000, 1280, 960, 150.0)}[case]
+    sc = scenegen.make_scene("C3", n_tris=cfg[0], width=cfg[1], height=cfg[2], bbox_px=cfg[3], seed=31 + cfg[0], variant="gouraud")
+    sc.settings = b32.RasterSettings()                                   # default(): z-buffer, Gouraud + light, back-face wireframe
+    if case == "crowded-tile":
+        sc.camera = b32.Camera(position=(0.0, 0.0, -60000.0))
+    if case == "overlay":
+        sc.settings.backface_wireframe = False; sc.settings.wireframe_overlay = True
+    if case == "both-phases":
+        sc.settings.wireframe_overlay = True
+    # shared and repeated edges: the second half of the mesh repeats the first half's triangles with other depths
+    half = len(sc.faces) // 2
+    sc.faces["v"][half:2 * half] = sc.faces["v"][:half]
+    sc.faces["v"][half:2 * half:2] = sc.faces["v"][half:2 * half:2][:, [1, 2, 0]]   # ... every other one with its edges in another order
+    bands = ((0, 301), (301, 700), (700, 960)) if case == "bands" else ((0, sc.height),)
+    fbo = oracle.Framebuffer(sc.width, sc.height); fbo.clear(sc.clear_color)
+    rc, etm = oracle.render_mesh_15(fbo, sc.vertices, sc.faces, sc.textures, sc.camera, sc.settings, sc.fog)
+    assert rc == 0
+    for off in (0, R.Context.ROUTE_WIRE_TILES):
+        ctx = R.Context(0); ctx.set_routes(off)
+        fb = R.Framebuffer(sc.width, sc.height, ctx)
+        rs = R.ResidentScene(fb, sc.vertices, sc.faces, sc.textures)
+        for _ in range(2):                                               # (twice: the tile counters must come back to zero by themselves)
+            for band in bands:
+                fb.set_band(*band)
+                fb.clear(sc.clear_color)
+                tm = rs.render(sc.camera, sc.settings, sc.fog)
+            fb.set_band(0, sc.height)
+            got = fb.pixels
+            assert np.array_equal(got, fbo.pixels), f"{case}: {int((got != fbo.pixels).sum())} bytes differ (routes off {off})"
+            assert tm.triangles_drawn == etm.triangles_drawn
+        assert (ctx.route_counts()["wire_tiles"] > 0) == (off == 0)
+        ctx.close()
 
 
 def test_editor_modes_large_frame_bands(gpu_ctx, oracle):

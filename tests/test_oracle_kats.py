@@ -275,3 +275,26 @@ def test_np_model_constants_are_the_reference_text():
     src = open(M.__file__).read()
     for lit in ("0.0001", "0.00001", "0x7FC0", "0x2000080", "0x101", "262144", "0x40000"):
         assert lit not in src, f"np_model.py still carries its own copy of {lit}"
+
+
+def test_wire_edge_hash_set_equals_the_quadratic_scan(oracle):
+    """The wireframe phases keep the FIRST occurrence of every screen-space edge, found by `unique_edges.iter().any(..)` before each push
+    (render.rs:2589-2594): O(n^2).  The oracle's hash set must produce the same list, entry for entry and with the first occurrence's
+    depths, so that RasterSettings::default() frames of a million triangles can be checked at all.  20 000 triangles on a coarse grid:
+    shared edges, reversed duplicates, degenerate edges, edges differing in one coordinate only, hostile coordinates."""
+    rng = np.random.default_rng(20)
+    n = 20_000
+    t = np.zeros((n, 9), np.float32)
+    t[:, [0, 1, 3, 4, 6, 7]] = rng.integers(-3, 40, (n, 6)).astype(np.float32)            # few distinct points: most edges repeat
+    t[:, [2, 5, 8]] = rng.uniform(5.0, 900.0, (n, 3)).astype(np.float32)                  # every occurrence has its own depths
+    t[::7, 3:6] = t[::7, 0:3]                                                               # zero-length edges
+    t[::11] = t[::11][:, [3, 4, 5, 0, 1, 2, 6, 7, 8]]                                       # the same triangle wound the other way
+    t[::501, 0] = [3e9, -3e9, np.nan, np.inf][0]                                            # `as i32` saturates
+    t[1::501, 1] = np.nan
+    t[2::501, 4] = -np.inf
+    assert oracle.unique_edges_selfcheck(t) == 0
+    assert oracle.unique_edges_selfcheck(t[:50]) == 0 and oracle.unique_edges_selfcheck(t[:0]) == 0
+    # every edge distinct, and every edge the same
+    u = t.copy(); u[:, 0] = np.arange(n, dtype=np.float32) * 3; u[:, 3] = u[:, 0] + 1; u[:, 6] = u[:, 0] + 2
+    assert oracle.unique_edges_selfcheck(u) == 0
+    assert oracle.unique_edges_selfcheck(np.tile(t[:1], (5000, 1))) == 0

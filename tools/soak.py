@@ -257,7 +257,13 @@ while time.time() < t_end:
     bands = [(0, H)] if rng.integers(3) else [(0, H // 3), (H // 3, H // 3 + 37), (H // 3 + 37, H)]
     desc = f"#{n} {cfg} {W}x{H} tris={ntri} {variant} fmt8={fmt8} z={st.use_zbuffer} xray={st.xray_mode} ortho={st.ortho_projection is not None} wire={st.backface_wireframe}/{st.wireframe_overlay} shading={st.shading} fog={fog is not None} counting={counting} bands={len(bands)}"
     try:
-        rs = R.ResidentScene(fb, sc.vertices, sc.faces, textures8=tex8) if fmt8 else R.ResidentScene(fb, sc.vertices, sc.faces, sc.textures)
+        # (half of the RGB555 scenes whose textures are the scene's own index atlases go up indexed: device-side CLUT expansion, and --
+        # with one texture -- CLUT + index bytes sampled from LDS wherever they fit beside the tile planes, B32_ROUTE_LDS_ATLAS)
+        as_indexed = (not fmt8) and len(sc.indexed_textures) == len(sc.textures) and rng.integers(2) == 0 and \
+            all(np.array_equal(a.to_texture15().pixels, t.pixels) and a.blend_mode == t.blend_mode for a, t in zip(sc.indexed_textures, sc.textures))
+        desc += f" indexed={as_indexed}"
+        rs = R.ResidentScene(fb, sc.vertices, sc.faces, textures8=tex8) if fmt8 else \
+            (R.ResidentScene(fb, sc.vertices, sc.faces, None, sc.indexed_textures) if as_indexed else R.ResidentScene(fb, sc.vertices, sc.faces, sc.textures))
         grc = 0
         for b0, b1 in bands:
             fb.set_band(b0, b1)
