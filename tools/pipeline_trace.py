@@ -20,9 +20,15 @@ def run(cfg, gate, routes):
     rs = R.ResidentScene(fb, sc.vertices, sc.faces, indexed_textures=sc.indexed_textures)
     for _ in range(3):
         fb.clear(sc.clear_color); rs.render_async(sc.camera, sc.settings); rs.finish()
-    for _ in range(24):
-        fb.clear(sc.clear_color); rs.render_async()
-    rs.finish()
+    n = int(os.environ.get("TRACE_FRAMES", "24"))
+    import time
+    for rep in range(2):                 # (the second region is the one to read: `show` prints the last kernels)
+        ctx.synchronize(); t0 = time.perf_counter()
+        for _ in range(n):
+            fb.clear(sc.clear_color); rs.render_async()
+        ctx.synchronize(); t1 = time.perf_counter()
+        print(f"host: {n} frames in {(t1 - t0) * 1e6:.1f} us = {(t1 - t0) / n * 1e6:.2f} us per frame")
+        rs.finish()
 
 
 def show(path, n):
