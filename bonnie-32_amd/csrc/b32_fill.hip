@@ -32,6 +32,9 @@
 #ifndef B32_DRAIN_TRIPS
 #define B32_DRAIN_TRIPS 2
 #endif
+#ifndef B32_P64_WAVES
+#define B32_P64_WAVES 4          // minimum waves per SIMD the general 8-wave forms of the fused kernel are compiled for
+#endif
 #ifndef B32_P64_STRIDE
 #define B32_P64_STRIDE 66        // row stride (u64 entries) of the 64-bit winner planes: 64 + 2, so the rows a surface touches at one
                                  // column fall into different LDS banks (measured: 72 -> 133 us, 66 -> 128 us; must stay <= 72, the allocation)
@@ -1089,7 +1092,7 @@ template <int TEXMODE, bool EXACT, int NT, bool ZMODE, bool FMT8 = false, bool P
 // (every form but the plain one is compiled for at least 4 waves per SIMD, i.e. at most 128 VGPRs: the EXACT z-buffer forms had drifted
 // to 129, which halves the 512-thread kernel's residency to one workgroup per CU -- game() settings with colour-keyed textures at
 // 2560x1920: 0.289 -> 0.242 ms; the plain form keeps the default bound of its block size, its code is byte-identical)
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PLAIN == 2 ? 5 : (PLAIN == 1 ? 2 : 4)))) void k_cover(FillArgs a_in) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PLAIN == 2 ? 5 : (PLAIN == 1 ? 2 : ((P64 && NT == 512) ? B32_P64_WAVES : 4))))) void k_cover(FillArgs a_in) {
     FillArgs a_plain = a_in;
     if (PLAIN) {
         a_plain.fp.affine = 1; a_plain.fp.shading = B32_SHADE_NONE; a_plain.fp.fixed_point = 1; a_plain.fp.ortho = 0; a_plain.fp.nt = 1;
