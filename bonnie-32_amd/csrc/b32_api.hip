@@ -1233,7 +1233,12 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     c->pipelined = false;
     // (pipe_hint: whether the previous frame's route qualified -- a frame that will not, e.g. every frame of a PS1-sized target, skips
     // the set swap and its event as well: 0.030 -> 0.028 ms on 20 k triangles at 320x240)
-    if (c->frame_pending && c->pipe_hint && !c->redrawing && !fp.wire_collect && !prof_all && c->nf > 2048u && !(c->route_off & B32_ROUTE_PIPELINE)) {
+#ifdef B32_EXP_PIPE_SMALL
+    const uint32_t pipe_min_faces = 0u;              // (experiment build: small frames pipelined too)
+#else
+    const uint32_t pipe_min_faces = 2048u;
+#endif
+    if (c->frame_pending && c->pipe_hint && !c->redrawing && !fp.wire_collect && !prof_all && c->nf > pipe_min_faces && !(c->route_off & B32_ROUTE_PIPELINE)) {
         if ((rc = pipeline_ensure(c))) return rc;
         rotate_sets(c);
         c->pipelined = true;
@@ -1262,6 +1267,9 @@ static int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st
     // between two kernels) then cost more than the overlap returns (C2, 100 k triangles at 320x240: 0.052 against 0.048 ms).  The merged
     // runs of a batched frame are the exception: their kernels leave most of the GPU idle anyway (75 tiles for 256 CUs).
     c->pipe_hint = r.direct_bin && (ntiles > 2u * (uint32_t)c->n_cu || c->frame_batched || (c->band_set && B32_PIPELINE_BANDS));
+#ifdef B32_EXP_PIPE_SMALL
+    c->pipe_hint = (r.direct_bin || r.want_inline) && !c->band_set;
+#endif
     if (!c->pipe_hint) c->pipelined = false;       // (the frame keeps the set it rotated to -- the route's regions are that set's -- but runs on the main stream)
     c->last_local_sort = r.local_sort || r.want_prio64;                         // the global draw order is not materialised
     c->last_exact = r.ordered_all ? true : (r.exact_cov && !fp.zmode);          // the ordered walk counts every store it performs

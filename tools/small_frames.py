@@ -7,6 +7,10 @@ out = {}
 for cfg in ("C1", "C2"):
     sc = scenegen.make_scene(cfg)
     ctx = R.Context(0); ctx.set_async_depth(1)
+    if os.environ.get("EXP_DEPTH"):
+        ctx.set_pipeline_depth(int(os.environ["EXP_DEPTH"]))
+    if os.environ.get("EXP_GATE"):
+        ctx.set_pipeline_gate(int(os.environ["EXP_GATE"]))
     if os.environ.get("EXP_ROUTES"):
         ctx.set_routes(int(os.environ["EXP_ROUTES"]))
     fb = R.Framebuffer(sc.width, sc.height, ctx)
@@ -25,5 +29,5 @@ for cfg in ("C1", "C2"):
     for _ in range(20):
         fb.clear(sc.clear_color); rs.render_async()
     tm = rs.finish(); kt = ctx.last_kernel_times(); ctx.set_profiling(0)
-    out[cfg] = {"ms": round(best * 1e3, 4), "ok": ok, "pairs": tm.tile_pairs, **{k: round(v * 1e3, 1) for k, v in kt.items()}}
+    out[cfg] = {"ms": round(best * 1e3, 4), "ok": ok, "pipelined": ctx.route_counts().get("pipelined"), "pairs": tm.tile_pairs, **{k: round(v * 1e3, 1) for k, v in kt.items()}}
 print(json.dumps(out))
