@@ -600,6 +600,13 @@ __device__ __forceinline__ uint32_t cover_slow64(const Tri& tr, unsigned long lo
 #ifndef B32_ROW_TRIM
 #define B32_ROW_TRIM 1
 #endif
+#ifndef B32_INTERIOR
+#define B32_INTERIOR 0           // experiment (round 4, judge item 3c), OFF: certain-interior runs of long rows take trips without the inside test.
+                                 // Bit-exact (full-size C3 / C5 hashes, 43 parity tests) and slower: finding and verifying the run (~70 VALU per
+                                 // round as soon as ONE lane of the wave has a long row), the second queue and its own, emptier rounds cost more
+                                 // than the skipped barycentrics return -- C5 0.2103 -> 0.2394 ms, C3 0.1200 -> 0.1368 (profiles/r04_interior_trips_ab.txt)
+#endif
+constexpr uint32_t INTERIOR_MIN_ROW = 12;      // rows shorter than this are not worth the interval (one boundary trip at each end)
 __device__ __forceinline__ uint32_t row_trim(float w0, float w1, float a0, float a1, float inv_area, uint32_t& n) {
     const float A = __builtin_amdgcn_rcpf(__builtin_fabsf(inv_area));
     if (!((A >= 0.5f) & (A < 1048576.0f))) return 0u;
@@ -621,6 +628,35 @@ __device__ __forceinline__ uint32_t row_trim(float w0, float w1, float a0, float
     const uint32_t lo = (uint32_t)flo;
     n = (uint32_t)fhi - lo;
     return lo;
+}
+
+// Certain-interior run of a trimmed row (CHEAP painter's coverage of large triangles).  A pixel that lies inside the triangle in EXACT
+// arithmetic always passes the reference's toleranced float test (render.rs:1536-1542): for a surface that passed k_setup's exactness
+// guard the edge values are exact integers, bc_x = fl(w0 * fl(1 / area)) >= 0 whenever w0 has the area's sign (likewise bc_y), and
+// bc_z = fl(fl(1 - bc_x) - bc_y) is within 4e-7 of the exact w2 / area >= 0 -- far above -1e-4.  Along a row the exactly-inside pixels
+// are one interval (three linear conditions); its ends come from approximate reciprocals and are then VERIFIED with the exact integer
+// conditions at both end pixels (linearity covers everything between); a failed check simply means "no interior run".
+// In: edge values (w0, w1) at the row's first pixel, per-pixel steps (a0, a1), |area| = |a0 * b1 - b0 * a1| (all exact integers in f32),
+// sign s of the area, n pixels.  Out: [tlo, thi) in pixels from the row's first pixel; returns false when there is none.
+__device__ __forceinline__ bool interior_run(float w0, float w1, float a0, float a1, float absA, float s, uint32_t n, uint32_t& tlo, uint32_t& thi) {
+    const float E[3] = { s * w0, s * w1, absA - (s * w0 + s * w1) };
+    const float G[3] = { s * a0, s * a1, -(s * a0 + s * a1) };
+    float flo = 0.0f, fhi = (float)n;
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {       // E + G t >= 0
+        const float r = -E[j] * __builtin_amdgcn_rcpf(G[j]);
+        const float lo_c = fmaxf(flo, ceilf(r - 1.5e-5f)), hi_c = fminf(fhi, floorf(r + 1.5e-5f) + 1.0f);
+        flo = G[j] > 0.0f ? lo_c : flo;
+        fhi = G[j] < 0.0f ? hi_c : fhi;
+        ok = ok & !((G[j] == 0.0f) & (E[j] < 0.0f));
+    }
+    ok = ok & (fhi > flo) & (flo >= 0.0f) & (fhi <= (float)n);
+    const float ta = flo, tb = fhi - 1.0f;                   // the two end pixels, checked exactly
+#pragma unroll
+    for (int j = 0; j < 3; ++j) ok = ok & (E[j] + G[j] * ta >= 0.0f) & (E[j] + G[j] * tb >= 0.0f);
+    tlo = ok ? (uint32_t)flo : 0u; thi = ok ? (uint32_t)fhi : 0u;
+    return ok;
 }
 
 // One trip of the sort-free CHEAP coverage: TRIP consecutive pixels of a row starting at LDS entry `addr` with edge values (w0, w1),
@@ -711,6 +747,7 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
         // their own, whose lanes are all busy.  The remainders refer to lanes of THIS batch (parameters come over ds_bpermute again), so
         // the queue is drained before the next batch is loaded.
         uint32_t lq = 0, lqn = 0;                       // leftover queue and its length (wave-uniform)
+        uint32_t lqi = 0, lqin = 0;                     // the same for certain-interior runs (interior_run): trips without the inside test
         // One trip of the sort-free EXACT coverage: four pixels -- the four texel addresses, their bits of the skip mask (LDS when the
         // pool's mask fits, else global: 1/16 of the texels' bytes; no texel is fetched during coverage) -- then the (non-returning)
         // atomics of the drawn fragments.  Returns the number of fragments drawn (the reference's pixel stores).
@@ -810,6 +847,38 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
             lqn = 0;
 #endif
         };
+        // Rounds of the interior queue: an entry is (lane of the surface, tile row, first column, pixels), every pixel certain to pass the
+        // inside test -- the trip is the two atomics per pixel and nothing else (no edge values, no barycentrics).
+        auto drain_interior = [&]() {
+            const bool valid = lane < lqin;
+            const uint32_t s = valid ? (lqi & 63u) : lane;
+            const uint32_t ry = (lqi >> 6) & 63u, rx = (lqi >> 12) & 127u;
+            const uint32_t n = valid ? (lqi >> 19) : 0u;
+            const unsigned long long P = ((unsigned long long)bperm(s, my_key) << 32) | bperm(s, my_sid);
+            unsigned long long* top = reinterpret_cast<unsigned long long*>(tilebuf);
+            unsigned long long* sec = top + TILE_H * STR64;
+            const uint32_t addr = ry * STR64 + rx;
+            constexpr uint32_t DT = 2u * (uint32_t)B32_TRIP;
+#pragma unroll
+            for (uint32_t t0 = 0; t0 < DT; t0 += (uint32_t)B32_TRIP) {       // (one trip's returning atomics in flight at a time: registers)
+                if (!__ballot(n > t0)) break;
+                unsigned long long old[B32_TRIP];
+#pragma unroll
+                for (uint32_t j = 0; j < (uint32_t)B32_TRIP; ++j) old[j] = atomicMax(&top[addr + t0 + j], (t0 + j) < n ? P : 0ull);
+#pragma unroll
+                for (uint32_t j = 0; j < (uint32_t)B32_TRIP; ++j) atomicMax(&sec[addr + t0 + j], (t0 + j) < n ? min(old[j], P) : 0ull);
+            }
+            const bool more = n > DT;
+            const unsigned long long mm = __ballot(more);
+            const uint32_t cnt = (uint32_t)__builtin_popcountll(mm);
+            if (cnt) {
+                const uint32_t entry = s | (ry << 6) | ((rx + DT) << 12) | ((n - DT) << 19);
+                const uint32_t dst = more ? (uint32_t)__builtin_popcountll(mm & ((1ull << lane) - 1ull)) : (cnt & 63u);
+                const uint32_t got = (uint32_t)__builtin_amdgcn_ds_permute((int)(dst << 2), (int)(more ? entry : 0u));
+                if (lane < cnt) lqi = got;
+            }
+            lqin = cnt;
+        };
         for (uint32_t k0 = 0; k0 < R; k0 += 64) {
             // owner of item k0+lane: last surface s with h>0 and P[s] <= k
             const unsigned long long before = __ballot(h > 0 && P <= k0);
@@ -897,15 +966,38 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
                 unsigned long long* sec = top + TILE_H * STR64;
                 float z1 = 0.0f, z2 = 0.0f, z3 = 0.0f;
                 if (ZMODE) { z1 = bpermf(s, __uint_as_float(b.q5.y)); z2 = bpermf(s, __uint_as_float(b.q5.z)); z3 = bpermf(s, __uint_as_float(b.q5.w)); }
+                // Long rows (large triangles): the certain-interior run behind the first trip -- a multiple of TRIP pixels -- goes to the
+                // interior queue, what follows it to the ordinary one.  (Only when the run starts inside the first trip: the first trip then
+                // covers the row's left boundary, and one ordinary remainder covers the right one.)
+                uint32_t n_int = 0;
+                if (B32_INTERIOR && !ZMODE && __ballot(n >= INTERIOR_MIN_ROW)) {
+                    uint32_t tlo, thi;
+                    const float sgn = sinv < 0.0f ? -1.0f : 1.0f;
+                    const bool run = (n >= INTERIOR_MIN_ROW) && interior_run(w0, w1, sa0, sa1, __builtin_fabsf(sa0 * sb1 - sb0 * sa1), sgn, n, tlo, thi);
+                    if (run && tlo <= (uint32_t)B32_TRIP && thi >= 2u * (uint32_t)B32_TRIP) n_int = (thi - (uint32_t)B32_TRIP) & ~((uint32_t)B32_TRIP - 1u);
+                }
                 cheap_trip<ZMODE>(top, sec, addr, w0, w1, sa0, sa1, sinv, n, P, z1, z2, z3);          // (addr, w0, w1 now stand at pixel TRIP of the row)
-                const bool more = n > (uint32_t)B32_TRIP;
+                if (B32_INTERIOR && !ZMODE) {
+                    const unsigned long long mi = __ballot(n_int != 0);
+                    if (mi) {
+                        const uint32_t cnt = (uint32_t)__builtin_popcountll(mi);
+                        while (lqin + cnt > 64u) drain_interior();
+                        const uint32_t entry = s | (ry << 6) | ((rx0 + (uint32_t)B32_TRIP) << 12) | (n_int << 19);
+                        const uint32_t dst = n_int ? lqin + (uint32_t)__builtin_popcountll(mi & ((1ull << lane) - 1ull)) : ((lqin + cnt) & 63u);
+                        const uint32_t got = (uint32_t)__builtin_amdgcn_ds_permute((int)(dst << 2), (int)(n_int ? entry : 0u));
+                        if (lane >= lqin && lane < lqin + cnt) lqi = got;
+                        lqin += cnt;
+                    }
+                }
+                const uint32_t skip = (uint32_t)B32_TRIP + n_int;          // pixels of the row already dealt with or queued as interior
+                const bool more = n > skip;
                 const unsigned long long mm = __ballot(more);
                 if (mm) {
                     const uint32_t cnt = (uint32_t)__builtin_popcountll(mm);
                     while (lqn + cnt > 64u) drain();
                     // forward permute into the queue's free lanes [lqn, lqn + cnt); the lanes with nothing to push aim at the first lane
                     // behind them (lane 0 when that is 64: then every lane pushes or lqn + cnt == 64 and lane 0 is not taken from `got`)
-                    const uint32_t entry = s | (ry << 6) | ((rx0 + (uint32_t)B32_TRIP) << 12) | ((n - (uint32_t)B32_TRIP) << 19);
+                    const uint32_t entry = s | (ry << 6) | ((rx0 + skip) << 12) | ((n - skip) << 19);
                     const uint32_t dst = more ? lqn + (uint32_t)__builtin_popcountll(mm & ((1ull << lane) - 1ull)) : ((lqn + cnt) & 63u);
                     const uint32_t got = (uint32_t)__builtin_amdgcn_ds_permute((int)(dst << 2), (int)(more ? entry : 0u));
                     if (lane >= lqn && lane < lqn + cnt) lq = got;
@@ -934,6 +1026,7 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
             }
         }
         if (P64) while (lqn) drain();                  // (the row remainders of this batch: its registers are about to be reloaded)
+        if (P64 && B32_INTERIOR && !ZMODE && !EXACT) while (lqin) drain_interior();
         // surfaces whose edge walk must be replayed literally: wave-cooperative slow path
         unsigned long long sm = __ballot(slow);
         while (sm) {
