@@ -424,6 +424,24 @@ def test_async_frames_are_never_silently_dropped(oracle):
     rs3.render_async(far, sc.settings)
     rs3.finish()                                                    # the most recent frame IS redrawn (regions grown), no error left over
     assert np.array_equal(fb3.pixels, o2.pixels)
+    # ---- deep mode with three frame sets (b32_set_pipeline_depth): the dropped frame sits in a set that is revisited only three frames
+    # later, or -- with fewer frames behind it -- only by b32_frame_finish reading the other sets' control blocks; reported either way
+    for n_after in (1, 2, 3, 4):
+        ctx5 = R.Context(0)
+        ctx5.set_async_depth(1); ctx5.set_pipeline_depth(3)
+        fb5 = R.Framebuffer(sc.width, sc.height, ctx5); fb5.clear(sc.clear_color)
+        rs5 = R.ResidentScene(fb5, sc.vertices, sc.faces, sc.textures)
+        for cam in (near, far) + (near,) * n_after:
+            rs5.render_async(cam, sc.settings)
+        with pytest.raises(R.B32Error) as e:
+            rs5.finish()
+        assert e.value.code == b32.abi.B32_E_FRAME_DROPPED, n_after
+        assert np.array_equal(fb5.pixels, only_near.pixels), n_after          # (opaque painter's frames: drawing `near` again changes nothing)
+        fb5.clear(sc.clear_color)
+        rs5.render_async(far, sc.settings)
+        rs5.finish()
+        assert np.array_equal(fb5.pixels, o2.pixels), n_after
+        ctx5.close()
 
 
 def test_pipeline_gate_argument_range():
