@@ -10,7 +10,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["b32_api.hip", "b32_setup.hip", "b32_sort.hip", "b32_bin.hip", "b32_fill.hip", "b32_wire.hip", "b32_sky.hip"]
+SOURCES = ["b32_api.hip", "b32_scene.hip", "b32_frame.hip", "b32_batch.hip", "b32_setup.hip", "b32_sort.hip", "b32_bin.hip", "b32_fill.hip", "b32_wire.hip", "b32_sky.hip"]
 OUT = os.path.join(CSRC, "libb32raster.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
          "-fno-gpu-flush-denormals-to-zero", "-fhip-fp32-correctly-rounded-divide-sqrt",
@@ -25,7 +25,7 @@ def needs_build():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "b32_device.h"),
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "b32_device.h"), os.path.join(CSRC, "b32_host.h"),
                                                        os.path.join(_HERE, "..", "include", "b32raster.h"), os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
 

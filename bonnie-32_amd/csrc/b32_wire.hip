@@ -388,21 +388,22 @@ void launch_wire(hipStream_t s, const WireArgs& a, bool back, bool front) {
     if (!a.nf || !(back || front)) return;
     const uint32_t n = a.nf * 3, blocks = (n + 255) / 256;
     const uint32_t ntiles = a.tiles_x * a.tiles_y;
-    if (a.tile_fill && ntiles) {
-        // tile route: bin, then one workgroup per tile; the global kernels behind them return at once unless a list overflowed or some
-        // edge's box covers more than WIRE_BIG_TILES tiles (then they draw exactly those edges -- or, after an overflow, all of them)
-        hipLaunchKernelGGL(k_wire_bin, dim3((a.nf + 255) / 256), dim3(256), 0, s, a, (back ? 1u : 0u) | (front ? 2u : 0u));
-        hipLaunchKernelGGL(k_wire_tile, dim3(ntiles), dim3(WIRE_THREADS), 0, s, a);
-    }
-    const uint32_t* flags = (a.tile_fill && ntiles) ? a.tile_fill + (size_t)ntiles * FILL_PAD : nullptr;
+    // Order (found by the round-4 soak): the reference draws ALL back-face edges, then ALL overlay edges, and the overlay's colour wins where
+    // both hit.  Back-face edges are order-independent among themselves (one colour, depths only read), so the ones left to the global
+    // kernels go FIRST, then the tile kernel (its own bit planes give the overlay precedence inside a tile), then the overlay edges left to
+    // the global kernel -- a big back-face edge drawn after the tile kernel would paint over a small overlay edge's pixels.
+    const bool tiles = a.tile_fill && ntiles;
+    const uint32_t* flags = tiles ? a.tile_fill + (size_t)ntiles * FILL_PAD : nullptr;
     // (tile route on: the global kernels usually have nothing to do -- 2048 workgroups that look at the flags and leave, or loop over
     // the edges left to them; tile route off: one lane per edge as before)
     const uint32_t gblocks = flags ? min(blocks, 2048u) : blocks;
+    if (tiles) hipLaunchKernelGGL(k_wire_bin, dim3((a.nf + 255) / 256), dim3(256), 0, s, a, (back ? 1u : 0u) | (front ? 2u : 0u));
     if (back) {
         hipLaunchKernelGGL(k_wire_table_clear, dim3(flags ? 256 : 1024), dim3(256), 0, s, a.table_owner, a.table_first, a.table_mask + 1, flags);
         hipLaunchKernelGGL(k_wire_insert, dim3(gblocks), dim3(256), 0, s, a);
         hipLaunchKernelGGL(k_wire_draw<1>, dim3(gblocks), dim3(256), 0, s, a);
     }
+    if (tiles) hipLaunchKernelGGL(k_wire_tile, dim3(ntiles), dim3(WIRE_THREADS), 0, s, a);
     if (front) hipLaunchKernelGGL(k_wire_draw<2>, dim3(gblocks), dim3(256), 0, s, a);
     if (flags) (void)hipMemsetAsync(a.tile_fill + (size_t)ntiles * FILL_PAD, 0, 2 * FILL_PAD * sizeof(uint32_t), s);      // overflow flag + big-edge count: zero between frames
 }

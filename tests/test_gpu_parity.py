@@ -1062,16 +1062,18 @@ def test_editor_modes_parity(gpu_ctx, oracle, name, counting):
         gpu_ctx.set_fragment_counting(1)
 
 
-@pytest.mark.parametrize("case", ["small", "medium", "long-lines", "crowded-tile", "overlay", "both-phases", "bands"])
+@pytest.mark.parametrize("case", ["small", "medium", "long-lines", "crowded-tile", "overlay", "both-phases", "both-phases-long", "bands"])
 def test_wireframe_phases_through_screen_tiles(oracle, case):
     """B32_ROUTE_WIRE_TILES: the edges of the wireframe phases (render.rs:2574-2635) binned to 64x64 tiles, first occurrences found in an
     LDS table per tile, lines walked into an LDS bit plane.  Same frame as the oracle (and as the global kernels, route off):
       long-lines    triangles of ~2500 px: edges whose box covers more than 16 tiles stay with the global kernels, the others go by tile
       crowded-tile  a far camera puts every edge into a few tiles: their lists overflow and the whole frame falls back
-      both-phases   back-face wireframe AND front-face overlay in one frame (the overlay is drawn later: it wins where both hit)"""
+      both-phases   back-face wireframe AND front-face overlay in one frame (the overlay is drawn later: it wins where both hit);
+                    -long: with edges of both kinds on both routes -- a big back-face edge (global kernels) must not paint over a small
+                    overlay edge's pixels (tile kernel): found by the round-4 soak, fixed by the order of the launches"""
     from bonnie32_amd import rasterizer as R
     cfg = {"small": (2_000, 320, 240, 64.0), "medium": (60_000, 1280, 960, 70.0), "long-lines": (6_000, 1280, 960, 2500.0),
-           "crowded-tile": (40_000, 640, 480, 60.0), "overlay": (30_000, 1280, 960, 90.0), "both-phases": (30_000, 640, 480, 120.0),
+           "crowded-tile": (40_000, 640, 480, 60.0), "overlay": (30_000, 1280, 960, 90.0), "both-phases": (30_000, 640, 480, 120.0), "both-phases-long": (8_000, 1280, 960, 1200.0),
            "bands": (50_000, 1280, 960, 150.0)}[case]
     sc = scenegen.make_scene("C3", n_tris=cfg[0], width=cfg[1], height=cfg[2], bbox_px=cfg[3], seed=31 + cfg[0], variant="gouraud")
     sc.settings = b32.RasterSettings()                                   # default(): z-buffer, Gouraud + light, back-face wireframe
@@ -1079,7 +1081,7 @@ def test_wireframe_phases_through_screen_tiles(oracle, case):
         sc.camera = b32.Camera(position=(0.0, 0.0, -60000.0))
     if case == "overlay":
         sc.settings.backface_wireframe = False; sc.settings.wireframe_overlay = True
-    if case == "both-phases":
+    if case.startswith("both-phases"):
         sc.settings.wireframe_overlay = True
     # shared and repeated edges: the second half of the mesh repeats the first half's triangles with other depths
     half = len(sc.faces) // 2
