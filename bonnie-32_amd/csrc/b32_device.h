@@ -426,6 +426,16 @@ struct WireArgs {
 };
 constexpr uint32_t WIRE_TH = 16;               // wire tiles are 64 x WIRE_TH pixels: small enough that four workgroups share a CU's LDS
 constexpr uint32_t WIRE_TILE_CAP = 256;        // faces per tile list: one 256-lane workgroup de-duplicates their 768 edges in LDS
+// The depth parameter of draw_line_3d, t = step / total_steps (render.rs:784), for integers 0 <= k <= N < WIRE_NARROW: with
+// rN = 1.0f / N (correctly rounded, once per line) one residual correction of k * rN IS the correctly rounded quotient (Markstein's
+// division theorem; N has at most 14 significant bits, far from the all-ones significand the theorem excepts).  Three instructions
+// per pixel instead of the ~11 of an IEEE division; b32_selftest_f32 op 8 compares it with `/` for every such pair on the device.
+constexpr int WIRE_NARROW = 16384;
+__device__ __forceinline__ float wire_t_fast(float kf, float Nf, float rN) {
+    const float q = kf * rN;
+    const float rem = __builtin_fmaf(-q, Nf, kf);
+    return __builtin_fmaf(rem, rN, q);
+}
 void launch_wire(hipStream_t s, const WireArgs& a, bool back, bool front);
 // Sort-free fast path: tile lists (unordered) by a counting sort straight from k_setup's spans; false = not applicable (too many
 // tiles for the LDS histogram), the caller takes the keyed radix path.  With `keys` the lists are split by class

@@ -698,6 +698,11 @@ __global__ void k_selftest(int op, const float* a, const float* b, const float* 
         case 5: r = __int_as_float(f2i32_sat(a[i])); break;                  // Rust `as i32`: the bits of the result
         case 6: r = __uint_as_float(f2u_sat(a[i])); break;                   // Rust `as u32`
         case 7: r = __int_as_float(fx_mul(__float_as_int(a[i]), __float_as_int(b[i]))); break;   // Fixed32::mul_fixed on the operands' bits
+        case 8: {                                       // wire_t_fast against `/`: a[i] = N; every k in [0, N]; the count of differing results
+            const float Nf = a[i], rN = 1.0f / Nf; uint32_t bad = 0;
+            for (float kf = 0.0f; kf <= Nf; kf += 1.0f) bad += __float_as_uint(wire_t_fast(kf, Nf, rN)) != __float_as_uint(kf / Nf);
+            r = (float)bad; break;
+        }
         default: r = (a[i] + b[i]) / c[i]; break;
     }
     out[i] = r;

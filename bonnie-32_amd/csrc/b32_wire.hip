@@ -96,14 +96,42 @@ __global__ void k_wire_insert(WireArgs a) {
 // passes the depth test goes to plot(x, y).  The closed form lets the walk start at the first step inside the rectangle's major-axis
 // range; the minor coordinate is tested per pixel.
 // steps of the line whose major coordinate lies inside the rectangle: [k_lo, k_hi] (false: none)
-__device__ __forceinline__ bool line_k_range(const Edge& e, long long cx0, long long cx1, long long cy0, long long cy1, long long& k_lo, long long& k_hi) {
-    const long long adx = llabs((long long)e.x1 - e.x0), ady = llabs((long long)e.y1 - e.y0);
+// (I: long long for any line, int for the ones edge_narrow() admits -- same values)
+template <typename I>
+__device__ __forceinline__ bool line_k_range_t(const Edge& e, I cx0, I cx1, I cy0, I cy1, I& k_lo, I& k_hi) {
+    const I dx = (I)e.x1 - (I)e.x0, dy = (I)e.y1 - (I)e.y0;
+    const I adx = dx < 0 ? -dx : dx, ady = dy < 0 ? -dy : dy;
     const bool xmajor = adx >= ady;
-    const long long N = xmajor ? adx : ady, m0 = xmajor ? e.x0 : e.y0, lo = xmajor ? cx0 : cy0, hi = xmajor ? cx1 : cy1;
+    const I N = xmajor ? adx : ady, m0 = xmajor ? (I)e.x0 : (I)e.y0, lo = xmajor ? cx0 : cy0, hi = xmajor ? cx1 : cy1;
     const int sm = xmajor ? (e.x0 < e.x1 ? 1 : -1) : (e.y0 < e.y1 ? 1 : -1);
     k_lo = 0; k_hi = N;
     if (sm > 0) { if (lo - m0 > k_lo) k_lo = lo - m0; if (hi - m0 < k_hi) k_hi = hi - m0; }
     else        { if (m0 - hi > k_lo) k_lo = m0 - hi; if (m0 - lo < k_hi) k_hi = m0 - lo; }
+    return k_lo <= k_hi;
+}
+__device__ __forceinline__ bool line_k_range(const Edge& e, long long cx0, long long cx1, long long cy0, long long cy1, long long& k_lo, long long& k_hi) {
+    return line_k_range_t<long long>(e, cx0, cx1, cy0, cy1, k_lo, k_hi);
+}
+// For a line edge_narrow() admits: the steps whose PIXEL lies inside the rectangle, both coordinates.  The minor coordinate after k steps
+// is n0 + sn * j(k), j(k) = floor((2 * dmin * k + dmaj) / (2 * dmaj)), which never decreases: j(k) >= J  <=>  k >= ceil(dmaj * (2J - 1) /
+// (2 * dmin)), so the steps with j(k) in [Ja, Jb] are an interval again.  Everything stays below 2^29.  (tools: the closed form was
+// checked against the literal loop of render.rs:771-817 on 200 000 random lines and rectangles before it went in; the GPU parity tests
+// and the soak compare whole frames.)
+__device__ __forceinline__ bool line_k_range_exact(const Edge& e, int cx0, int cx1, int cy0, int cy1, int& k_lo, int& k_hi) {
+    if (!line_k_range_t<int>(e, cx0, cx1, cy0, cy1, k_lo, k_hi)) return false;
+    const int dx = e.x1 - e.x0, dy = e.y1 - e.y0, adx = dx < 0 ? -dx : dx, ady = dy < 0 ? -dy : dy;
+    const bool xmajor = adx >= ady;
+    const int dmaj = xmajor ? adx : ady, dmin = xmajor ? ady : adx;
+    const int n0 = xmajor ? e.y0 : e.x0, nlo = xmajor ? cy0 : cx0, nhi = xmajor ? cy1 : cx1;
+    const bool up = xmajor ? e.y0 < e.y1 : e.x0 < e.x1;                  // sn > 0
+    int ja = up ? nlo - n0 : n0 - nhi, jb = up ? nhi - n0 : n0 - nlo;   // the minor steps that put the pixel inside: j in [ja, jb]
+    if (jb < 0 || ja > dmin) return false;
+    ja = max(ja, 0); jb = min(jb, dmin);
+    if (dmin > 0) {                                                      // (dmin == 0: j stays 0, every step qualifies)
+        const uint32_t d = 2u * (uint32_t)dmin;
+        if (ja >= 1) k_lo = max(k_lo, (int)(((uint32_t)dmaj * (uint32_t)(2 * ja - 1) + d - 1u) / d));
+        k_hi = min(k_hi, (int)(((uint32_t)dmaj * (uint32_t)(2 * jb + 1) + d - 1u) / d) - 1);
+    }
     return k_lo <= k_hi;
 }
 // steps k_a ... k_b of the line (a sub-range of line_k_range's).  I = the integer type of the walk: every line with extents below 2^14
@@ -154,9 +182,14 @@ __device__ __forceinline__ void walk_line(const Edge& e, bool depth_test, long l
     long long k_lo, k_hi;
     if (line_k_range(e, cx0, cx1, cy0, cy1, k_lo, k_hi)) walk_line_range(e, depth_test, cx0, cx1, cy0, cy1, k_lo, k_hi, depth_at, plot);
 }
+__device__ __forceinline__ uint32_t abs_diff(int p, int q) { return p < q ? (uint32_t)q - (uint32_t)p : (uint32_t)p - (uint32_t)q; }   // |p - q| of two i32, exact (< 2^32)
 __device__ __forceinline__ bool edge_overflows(const Edge& e) {          // 2*err overflows i32 in the reference (render.rs:735, 800)
-    const long long adx = llabs((long long)e.x1 - e.x0), ady = llabs((long long)e.y1 - e.y0);
-    return adx >= (1ll << 30) || ady >= (1ll << 30);
+    return abs_diff(e.x1, e.x0) >= (1u << 30) || abs_diff(e.y1, e.y0) >= (1u << 30);
+}
+// lines the tile kernel walks in 32-bit integers with the three-instruction depth parameter (the bounds of walk_line_range's `narrow`)
+__device__ __forceinline__ bool edge_narrow(const Edge& e) {
+    return abs_diff(e.x1, e.x0) < (uint32_t)WIRE_NARROW && abs_diff(e.y1, e.y0) < (uint32_t)WIRE_NARROW
+        && e.x0 > -1048576 && e.x0 < 1048576 && e.y0 > -1048576 && e.y0 < 1048576;
 }
 __device__ void draw_line_dev(const WireArgs& a, const Edge& e, bool depth_test, uint32_t rgba) {
     if (edge_overflows(e)) { atomicOr(&a.ctrl->wire_overflow, 1u); atomicOr(&a.ctrl->sticky, 4u); return; }
@@ -175,8 +208,8 @@ __device__ void draw_line_dev(const WireArgs& a, const Edge& e, bool depth_test,
 // row by row.  Lines write one colour and never the depth buffer, so the order between lines does not matter (the front-face overlay,
 // drawn after the back-face edges by the reference, wins where both hit).  An edge whose box covers more than WIRE_BIG_TILES tiles,
 // and every edge of a frame in which some tile list overflowed, take the global kernels above instead (`wire_global`).
-constexpr uint32_t WIRE_TABLE_SLOTS = 2048, WIRE_BIG_TILES = 64;
-static_assert(WIRE_TABLE_SLOTS >= 2 * 3 * WIRE_TILE_CAP, "LDS table load factor");
+constexpr uint32_t WIRE_TABLE_SLOTS = 1024, WIRE_BIG_TILES = 64;      // (at most 768 edges of one tile in 1024 slots; usually a third of that)
+static_assert(WIRE_TABLE_SLOTS >= 4 * WIRE_TILE_CAP, "LDS table load factor");
 constexpr uint32_t COL_BACK = 80u | (80u << 8) | (100u << 16) | 0xFF000000u;      // Color::new(80, 80, 100), render.rs:2598
 constexpr uint32_t COL_FRONT = 200u | (200u << 8) | (220u << 16) | 0xFF000000u;   // Color::new(200, 200, 220), render.rs:2628
 
@@ -184,9 +217,10 @@ struct WireBox { uint32_t tx0, tx1, ty0, ty1; bool visible, big; };
 // tiles of the edge's box clipped to the frame and the band (every pixel the walk can touch lies inside the box)
 __device__ __forceinline__ WireBox wire_box(const WireArgs& a, const Edge& e) {
     WireBox b = { 0, 0, 0, 0, false, false };
-    const long long xl = e.x0 < e.x1 ? e.x0 : e.x1, xh = e.x0 < e.x1 ? e.x1 : e.x0, yl = e.y0 < e.y1 ? e.y0 : e.y1, yh = e.y0 < e.y1 ? e.y1 : e.y0;
-    const long long cx0 = xl > 0 ? xl : 0, cx1 = xh < (long long)a.width - 1 ? xh : (long long)a.width - 1;
-    const long long cy0 = yl > (long long)a.band_y0 ? yl : (long long)a.band_y0, cy1 = yh < (long long)a.band_y1 - 1 ? yh : (long long)a.band_y1 - 1;
+    // (comparisons of i32 coordinates with the frame's bounds, which are at most 16384: nothing here leaves 32 bits)
+    const int xl = min(e.x0, e.x1), xh = max(e.x0, e.x1), yl = min(e.y0, e.y1), yh = max(e.y0, e.y1);
+    const int cx0 = max(xl, 0), cx1 = min(xh, (int)a.width - 1);
+    const int cy0 = max(yl, (int)a.band_y0), cy1 = min(yh, (int)a.band_y1 - 1);
     if (cx0 > cx1 || cy0 > cy1) return b;
     b.visible = true;
     b.tx0 = (uint32_t)cx0 >> 6; b.tx1 = (uint32_t)cx1 >> 6; b.ty0 = ((uint32_t)cy0 - a.tile_yb) / WIRE_TH; b.ty1 = ((uint32_t)cy1 - a.tile_yb) / WIRE_TH;
@@ -234,24 +268,46 @@ __global__ void k_wire_bin(WireArgs a, uint32_t kinds) {           // kinds: bit
         }
 }
 
-// One 16-wave workgroup per tile, one lane per list entry (face).  LDS: the tile's depths (the walk tests every pixel against them), the
-// screen integers of every edge slot, the first-occurrence table, two bit planes of hit pixels.  The walks are NOT done edge by edge --
-// a wave would last as long as its longest line times three -- but as SEGMENTS of at most WIRE_SEG steps, dealt out evenly: every
-// surviving edge reports its step range inside the tile, a prefix sum over the 3072 edge slots numbers the segments, and lane t takes
-// segments t, t + 1024, ... (owner found by binary search in the prefix array; the closed form starts a walk at any step).
-constexpr uint32_t WIRE_EDGE_SLOTS = 3 * WIRE_TILE_CAP, WIRE_SEG = 16, WIRE_SEGS_PER_EDGE = 64 / WIRE_SEG;    // (at most 64 steps of a line lie inside a tile)
+// One 4-wave workgroup per tile, one lane per list entry (face).  The kernel is latency-bound -- a chain of dependent global loads
+// (counter, list entry, face), LDS atomics that return, eight barriers -- and its time goes with 1 / (workgroups per CU) (measured by
+// padding the LDS: 4 per CU 75.7 us, 3: 92.1, 2: 127.6 = 21 us + 213 us / n), so the LDS is kept small: 20.3 KB = seven workgroups per CU.
+//   vxy / vz   the three screen vertices of every entry (9 KB; an edge is read back as two of them and direction-normalised again)
+//   scratch    first the first-occurrence table -- owner[WIRE_TABLE_SLOTS]: hash slot -> the edge slot that claimed it, then
+//              first[WIRE_EDGE_SLOTS]: claiming edge slot -> smallest global edge id among its occurrences (7 KB) -- later the
+//              segment words (WIRE_SEG_CAP x 2 B) and the step range of every drawn edge inside the tile (3 KB)
+//   zt         the tile's depths (the walk tests every pixel against them; read-only) (4 KB);  mask: two bit planes of hit pixels
+// The walks are NOT done edge by edge -- a wave would last as long as its longest line times three -- but as SEGMENTS of at most
+// WIRE_SEG steps, dealt out evenly: every surviving edge reports its step range inside the tile, a prefix sum over the edge slots
+// numbers the segments, and lane t takes segments t, t + 256, ... (the closed form starts a walk at any step).
+#ifndef B32_WIRE_SEG
+#define B32_WIRE_SEG 16
+#endif
+constexpr uint32_t WIRE_EDGE_SLOTS = 3 * WIRE_TILE_CAP, WIRE_SEG = B32_WIRE_SEG, WIRE_SEGS_PER_EDGE = 64 / WIRE_SEG;    // (at most 64 steps of a line lie inside a tile)
 constexpr uint32_t WIRE_THREADS = 256, WIRE_PX = 64 * WIRE_TH;
-static_assert(WIRE_TILE_CAP == WIRE_THREADS && WIRE_EDGE_SLOTS <= 4096 && WIRE_SEGS_PER_EDGE <= 16, "k_wire_tile: one lane per entry, 12 + 4 bits per segment word");
-struct WireSegRec { float z0, z1; uint32_t k_lo, n_steps_kind; };       // n_steps | kind << 31 (kind: 0 back-face, depth-tested; 1 overlay)
-static_assert(sizeof(WireSegRec) * WIRE_EDGE_SLOTS <= 2 * WIRE_TABLE_SLOTS * sizeof(uint32_t), "segment records reuse the table's LDS");
-__global__ __launch_bounds__(WIRE_THREADS) void k_wire_tile(WireArgs a) {
-    __shared__ int4 keys[WIRE_EDGE_SLOTS];               // 12 KB
-    __shared__ __attribute__((aligned(16))) uint32_t table[2 * WIRE_TABLE_SLOTS];   // [0, SLOTS): slot -> claiming edge slot; [SLOTS, 2 SLOTS): smallest id (16 KB)
-    __shared__ float zt[WIRE_PX];                        // Framebuffer::zbuffer of the tile (read-only here) (4 KB)
-    __shared__ uint16_t segs[WIRE_EDGE_SLOTS * WIRE_SEGS_PER_EDGE];   // segment -> edge slot | segment number << 12 (3 KB)
-    __shared__ uint32_t mask[2][WIRE_PX / 32];                    // hit pixels: [0] back-face colour, [1] front-face overlay
+static_assert(WIRE_TILE_CAP == WIRE_THREADS && WIRE_EDGE_SLOTS <= 1024 && WIRE_SEGS_PER_EDGE <= 16, "k_wire_tile: one lane per entry; segment word = 10 bits of edge slot, 4 of segment number, narrow, kind");
+#ifndef B32_WIRE_SEG_CAP
+#define B32_WIRE_SEG_CAP 1536
+#endif
+constexpr uint32_t WIRE_SEG_CAP = B32_WIRE_SEG_CAP;              // segments walked per pass (a tile with more -- 768 edges of 64 steps have 3072 -- takes another pass)
+static_assert(WIRE_SEG_CAP * sizeof(uint16_t) + WIRE_EDGE_SLOTS * sizeof(uint32_t) <= (WIRE_TABLE_SLOTS + WIRE_EDGE_SLOTS) * sizeof(uint32_t), "segment words and step ranges reuse the table's LDS");
+// edge `slot` (= entry * 3 + j) back from the vertices in LDS, direction-normalised like wire_edge
+__device__ __forceinline__ Edge wire_edge_lds(const int2* vxy, const float* vz, uint32_t slot, bool with_z) {
+    const uint32_t j = slot % 3u, other = j == 2u ? slot - 2u : slot + 1u;
+    const int2 p = vxy[slot], q = vxy[other];
+    const float zp = with_z ? vz[slot] : 0.0f, zq = with_z ? vz[other] : 0.0f;
+    const bool keep = p.x < q.x || (p.x == q.x && p.y < q.y);
+    return keep ? Edge{ p.x, p.y, q.x, q.y, zp, zq } : Edge{ q.x, q.y, p.x, p.y, zq, zp };
+}
+__global__ __launch_bounds__(WIRE_THREADS) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_wire_tile(WireArgs a) {     // (at most 72 VGPRs: seven waves per SIMD, like the LDS)
+    __shared__ int2 vxy[WIRE_EDGE_SLOTS];                // 6 KB
+    __shared__ float vz[WIRE_EDGE_SLOTS];                // 3 KB
+    __shared__ __attribute__((aligned(16))) uint32_t scratch[WIRE_TABLE_SLOTS + WIRE_EDGE_SLOTS];   // 7 KB
+    __shared__ float zt[WIRE_PX];                        // Framebuffer::zbuffer of the tile (4 KB)
+    __shared__ uint32_t mask[2][WIRE_PX / 32];           // hit pixels: [0] back-face colour, [1] front-face overlay
     __shared__ uint32_t wsum[WIRE_THREADS / 64];
-    uint32_t* owner = table; uint32_t* first = table + WIRE_TABLE_SLOTS;
+    uint32_t* owner = scratch; uint32_t* first = scratch + WIRE_TABLE_SLOTS;
+    uint16_t* segs = reinterpret_cast<uint16_t*>(scratch);                               // [0, WIRE_SEG_CAP)
+    uint32_t* krange = scratch + WIRE_SEG_CAP / 2;                                       // edge slot -> first step | (steps - 1) << 14
     const uint32_t tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t n_all = *wire_counter(a, tile);
     const bool overflowed = *wire_flag(a, 0) != 0;
@@ -260,13 +316,13 @@ __global__ __launch_bounds__(WIRE_THREADS) void k_wire_tile(WireArgs a) {
     if (overflowed || n_all == 0 || a.ctrl->abort) return;
     const uint32_t n = n_all < WIRE_TILE_CAP ? n_all : WIRE_TILE_CAP;
     const uint32_t txi = tile % a.tiles_x, tyi = tile / a.tiles_x, x_lo = txi * 64u, y_top = a.tile_yb + tyi * WIRE_TH;
-    for (uint32_t i = tid; i < 2 * WIRE_TABLE_SLOTS; i += WIRE_THREADS) table[i] = SLOT_EMPTY;
+    for (uint32_t i = tid; i < WIRE_TABLE_SLOTS + WIRE_EDGE_SLOTS; i += WIRE_THREADS) scratch[i] = SLOT_EMPTY;
     if (tid < 2 * WIRE_PX / 32) (&mask[0][0])[tid] = 0;
     for (uint32_t p = tid; p < WIRE_PX; p += WIRE_THREADS) {
         const uint32_t x = x_lo + (p & 63u), y = y_top + (p >> 6);
         zt[p] = (a.zbuf && x < a.width && y >= a.band_y0 && y < a.band_y1) ? a.zbuf[(size_t)y * a.width + x] : 3.40282347e+38f;
     }
-    Edge e[3]; uint32_t slot[3] = { 0, 0, 0 }; bool on[3] = { false, false, false };
+    Edge e[3]; uint32_t slot[3] = { 0, 0, 0 }; bool on[3] = { false, false, false }, narrow[3] = { false, false, false };
     uint32_t f = 0, kind = 0;
     if (tid < n) {
         f = a.tile_lists[(size_t)tile * WIRE_TILE_CAP + tid];
@@ -274,12 +330,13 @@ __global__ __launch_bounds__(WIRE_THREADS) void k_wire_tile(WireArgs a) {
         kind = t.kind;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
+            vxy[tid * 3 + j] = make_int2(t.x[j], t.y[j]); vz[tid * 3 + j] = t.z[j];
             e[j] = wire_edge(t, j);
             if (edge_overflows(e[j])) continue;
             const WireBox b = wire_box(a, e[j]);
             // the edge takes part here iff this tile lies in its OWN box (so does every other occurrence of it)
             on[j] = b.visible && !b.big && txi >= b.tx0 && txi <= b.tx1 && tyi >= b.ty0 && tyi <= b.ty1;
-            if (on[j]) keys[tid * 3 + j] = make_int4(e[j].x0, e[j].y0, e[j].x1, e[j].y1);
+            narrow[j] = edge_narrow(e[j]);
         }
     }
     __syncthreads();
@@ -291,37 +348,47 @@ __global__ __launch_bounds__(WIRE_THREADS) void k_wire_tile(WireArgs a) {
         for (int j = 0; j < 3; ++j) {
             if (!on[j]) continue;
             const uint32_t i = tid * 3 + j;
-            uint32_t h = edge_hash(e[j]) & (WIRE_TABLE_SLOTS - 1);
+            uint32_t h = edge_hash(e[j]) & (WIRE_TABLE_SLOTS - 1), claimer = i;
             for (;;) {
                 const uint32_t cur = atomicCAS(&owner[h], SLOT_EMPTY, i);
                 if (cur == SLOT_EMPTY || cur == i) break;
-                const int4 o = keys[cur];
-                if (o.x == e[j].x0 && o.y == e[j].y0 && o.z == e[j].x1 && o.w == e[j].y1) break;
+                if (same_edge(wire_edge_lds(vxy, vz, cur, false), e[j])) { claimer = cur; break; }
                 h = (h + 1) & (WIRE_TABLE_SLOTS - 1);
             }
-            atomicMin(&first[h], f * 3u + (uint32_t)j);
-            slot[j] = h;
+            atomicMin(&first[claimer], f * 3u + (uint32_t)j);
+            slot[j] = claimer;
         }
     }
     __syncthreads();
 #if defined(B32_EXP_WIRE_STAGE) && B32_EXP_WIRE_STAGE <= 2
     return;
 #endif
-    // which of my edges are drawn, over which steps: segment counts
-    const long long cx0 = x_lo, cx1 = (x_lo + 63u < a.width - 1u) ? x_lo + 63u : a.width - 1u;
-    const long long cy0 = y_top > a.band_y0 ? y_top : a.band_y0, cy1 = (y_top + WIRE_TH - 1u < a.band_y1 - 1u) ? y_top + WIRE_TH - 1u : a.band_y1 - 1u;
-    uint32_t nseg[3] = { 0, 0, 0 }, klo[3] = { 0, 0, 0 }, nst[3] = { 0, 0, 0 };
+    // which of my edges are drawn, over how many steps: segment counts
+    // the tile's rectangle inside the frame and the band (non-empty: a tile of the grid; all four below 16384)
+    const int cx0 = (int)x_lo, cx1 = (int)min(x_lo + 63u, a.width - 1u);
+    const int cy0 = (int)max(y_top, a.band_y0), cy1 = (int)min(y_top + WIRE_TH - 1u, a.band_y1 - 1u);
+    // steps of edge `ed` inside the rectangle: first step and count (0: none)
+    auto steps_inside = [&](const Edge& ed, bool nrw, uint32_t& k_first) -> uint32_t {
+        if (nrw) {
+            int k_lo, k_hi;
+            if (!line_k_range_exact(ed, cx0, cx1, cy0, cy1, k_lo, k_hi)) return 0u;
+            k_first = (uint32_t)k_lo; return (uint32_t)(k_hi - k_lo + 1);
+        }
+        long long k_lo, k_hi;
+        if (!line_k_range(ed, cx0, cx1, cy0, cy1, k_lo, k_hi)) return 0u;                   // (k_lo < 2^30, at most 64 steps inside a tile)
+        k_first = (uint32_t)k_lo; return (uint32_t)(k_hi - k_lo + 1);
+    };
+    uint32_t nseg[3] = { 0, 0, 0 }, kr[3] = { 0, 0, 0 };
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         if (!on[j] || !kind) continue;
         if (kind == 1 && first[slot[j]] != f * 3u + (uint32_t)j) continue;               // an earlier occurrence of this edge draws it
-        long long k_lo, k_hi;
-        if (!line_k_range(e[j], cx0, cx1, cy0, cy1, k_lo, k_hi)) continue;               // (k_lo < 2^30, at most 64 steps inside a tile)
-        klo[j] = (uint32_t)k_lo; nst[j] = (uint32_t)(k_hi - k_lo + 1);
-        nseg[j] = (nst[j] + WIRE_SEG - 1) / WIRE_SEG;
+        uint32_t k_first = 0;
+        const uint32_t steps = steps_inside(e[j], narrow[j], k_first);
+        nseg[j] = (steps + WIRE_SEG - 1) / WIRE_SEG;
+        kr[j] = k_first | ((steps - 1u) << 14);                                          // (narrow lines: k_first < 2^14; the others count again)
     }
-    __syncthreads();                                     // (everyone is done with the table: its LDS now holds the segment records)
-    WireSegRec* rec = reinterpret_cast<WireSegRec*>(table);
+    __syncthreads();                                     // (everyone is done with the table: its LDS now holds the segment words)
     const uint32_t mine = nseg[0] + nseg[1] + nseg[2];
     uint32_t inc = mine;                                 // inclusive scan over the workgroup: wave scan, wave totals, offsets
     for (int off = 1; off < 64; off <<= 1) { const uint32_t v = __shfl_up(inc, off); if (lane >= (uint32_t)off) inc += v; }
@@ -332,30 +399,68 @@ __global__ __launch_bounds__(WIRE_THREADS) void k_wire_tile(WireArgs a) {
     uint32_t total = 0;
     for (uint32_t w = 0; w < WIRE_THREADS / 64; ++w) total += wsum[w];
 #pragma unroll
+    for (int j = 0; j < 3; ++j) if (nseg[j] && narrow[j]) krange[tid * 3 + j] = kr[j];
+    for (uint32_t pass0 = 0; pass0 < total; pass0 += WIRE_SEG_CAP) {                      // (one pass unless the tile has more than WIRE_SEG_CAP segments)
+    if (pass0) __syncthreads();                          // (the previous pass has read its segment words)
+    uint32_t pos = base;
+#pragma unroll
     for (int j = 0; j < 3; ++j) {
-        const uint32_t i = tid * 3 + j;
-        if (nseg[j]) rec[i] = { e[j].z0, e[j].z1, klo[j], nst[j] | ((kind == 2 ? 1u : 0u) << 31) };
-        for (uint32_t q = 0; q < nseg[j]; ++q) segs[base + q] = (uint16_t)(i | (q << 12));      // (i < 768 < 2^12, q < 4)
-        base += nseg[j];
+        const uint32_t i = tid * 3 + j, flags = (narrow[j] ? 1u << 14 : 0u) | (kind == 2 ? 1u << 15 : 0u);
+        for (uint32_t q = 0; q < nseg[j]; ++q, ++pos)
+            if (pos >= pass0 && pos < pass0 + WIRE_SEG_CAP) segs[pos - pass0] = (uint16_t)(i | (q << 10) | flags);     // (i < 768 < 2^10, q < 16)
     }
     __syncthreads();
 #if defined(B32_EXP_WIRE_STAGE) && B32_EXP_WIRE_STAGE <= 3
     return;
 #endif
-    for (uint32_t t = tid; t < total; t += WIRE_THREADS) {
-        const uint32_t sg = segs[t], lo = sg & 0xFFFu, q = sg >> 12;
-        const WireSegRec r = rec[lo];
-        const int4 kk = keys[lo];
-        const Edge ed = { kk.x, kk.y, kk.z, kk.w, r.z0, r.z1 };
-        const uint32_t steps = r.n_steps_kind & 0x7FFFFFFFu, which = r.n_steps_kind >> 31;
-        const long long k_a = (long long)r.k_lo + (long long)q * WIRE_SEG;
-        const long long k_b = (long long)r.k_lo + (long long)min((q + 1) * WIRE_SEG, steps) - 1;
-        walk_line_range(ed, which == 0, cx0, cx1, cy0, cy1, k_a, k_b,
-                        [&](uint32_t x, uint32_t y) { return zt[(y - y_top) * 64u + (x - x_lo)]; },
-                        [&](uint32_t x, uint32_t y) {
-                            const uint32_t bit = (y - y_top) * 64u + (x - x_lo);
-                            atomicOr(&mask[which][bit >> 5], 1u << (bit & 31u));
-                        });
+    const uint32_t in_pass = min(total - pass0, WIRE_SEG_CAP);
+    for (uint32_t t = tid; t < in_pass; t += WIRE_THREADS) {
+        const uint32_t sg = segs[t], q = (sg >> 10) & 15u, which = sg >> 15;
+        const bool nrw = (sg >> 14) & 1u;
+        const Edge ed = wire_edge_lds(vxy, vz, sg & 1023u, true);
+        uint32_t k_first = 0, steps;
+        if (nrw) { const uint32_t w = krange[sg & 1023u]; k_first = w & 16383u; steps = (w >> 14) + 1u; }
+        else steps = steps_inside(ed, false, k_first);                                       // (as counted above: > q * WIRE_SEG)
+        const uint32_t s_a = q * WIRE_SEG, s_b = min((q + 1) * WIRE_SEG, steps) - 1u;       // steps of this segment, counted from k_first
+        if (!nrw) {                                          // (coordinates beyond +-2^20 or extents of 2^14 and more: the general walk)
+            walk_line_range_t<long long>(ed, which == 0, cx0, cx1, cy0, cy1, (long long)k_first + s_a, (long long)k_first + s_b,
+                            [&](uint32_t x, uint32_t y) { return zt[(y - y_top) * 64u + (x - x_lo)]; },
+                            [&](uint32_t x, uint32_t y) {
+                                const uint32_t bit = (y - y_top) * 64u + (x - x_lo);
+                                atomicOr(&mask[which][bit >> 5], 1u << (bit & 31u));
+                            });
+            continue;
+        }
+        // The same walk as walk_line_range_t for a narrow line, in tile coordinates and incrementally: every step of the range has its
+        // pixel inside the rectangle (line_k_range_exact), so nothing is tested per pixel but the depth; `idx` is the pixel's index in
+        // the tile's planes; the depth parameter k / N comes from wire_t_fast (k <= N < 2^14: no saturation at 2^24 to apply).
+        const int dx = ed.x1 - ed.x0, dy = ed.y1 - ed.y0, adx = dx < 0 ? -dx : dx, ady = dy < 0 ? -dy : dy;
+        const int sx = ed.x0 < ed.x1 ? 1 : -1, sy = ed.y0 < ed.y1 ? 1 : -1;
+        const bool xmajor = adx >= ady;
+        const uint32_t dmaj = (uint32_t)(xmajor ? adx : ady), dmin = (uint32_t)(xmajor ? ady : adx);
+        const uint32_t k_a = k_first + s_a;
+        uint32_t jm = 0, rr = 0;                             // minor steps before step k_a, remainder of that division
+        if (dmaj) { const uint32_t num = 2u * dmin * k_a + dmaj; jm = num / (2u * dmaj); rr = num - jm * (2u * dmaj); }
+        const uint32_t two_dmin = 2u * dmin, two_dmaj = dmaj ? 2u * dmaj : 0x7FFFFFFFu;          // (a point: never a minor step)
+        const int px = ed.x0 + sx * (int)(xmajor ? k_a : jm) - (int)x_lo, py = ed.y0 + sy * (int)(xmajor ? jm : k_a) - (int)y_top;
+        int idx = py * 64 + px;
+        const int d_maj = xmajor ? sx : sy * 64, d_min = xmajor ? sy * 64 : sx;
+        const float Nf = (float)(dmaj > 1u ? dmaj : 1u), rN = 1.0f / Nf, dz = ed.z1 - ed.z0;     // total_steps, render.rs:778
+        float kf = (float)k_a;
+        for (uint32_t n_left = s_b - s_a + 1u; n_left; --n_left) {
+            bool pass = true;
+            if (!which) {
+                const float tt = wire_t_fast(kf, Nf, rN);
+                const float z = ed.z0 + tt * dz;
+                pass = z < zt[idx];
+            }
+            if (pass) atomicOr(&mask[which][(uint32_t)idx >> 5], 1u << ((uint32_t)idx & 31u));
+            rr += two_dmin;
+            const bool minor = rr >= two_dmaj;
+            rr -= minor ? two_dmaj : 0u; idx += d_maj + (minor ? d_min : 0);
+            kf += 1.0f;
+        }
+    }
     }
     __syncthreads();
     for (uint32_t p = tid; p < WIRE_PX; p += WIRE_THREADS) {
@@ -403,7 +508,10 @@ void launch_wire(hipStream_t s, const WireArgs& a, bool back, bool front) {
         hipLaunchKernelGGL(k_wire_insert, dim3(gblocks), dim3(256), 0, s, a);
         hipLaunchKernelGGL(k_wire_draw<1>, dim3(gblocks), dim3(256), 0, s, a);
     }
-    if (tiles) hipLaunchKernelGGL(k_wire_tile, dim3(ntiles), dim3(WIRE_THREADS), 0, s, a);
+#ifndef B32_EXP_WIRE_PAD_LDS                               // experiment: dynamic LDS nobody uses = fewer workgroups per CU
+#define B32_EXP_WIRE_PAD_LDS 0
+#endif
+    if (tiles) hipLaunchKernelGGL(k_wire_tile, dim3(ntiles), dim3(WIRE_THREADS), B32_EXP_WIRE_PAD_LDS, s, a);
     if (front) hipLaunchKernelGGL(k_wire_draw<2>, dim3(gblocks), dim3(256), 0, s, a);
     if (flags) (void)hipMemsetAsync(a.tile_fill + (size_t)ntiles * FILL_PAD, 0, 2 * FILL_PAD * sizeof(uint32_t), s);      // overflow flag + big-edge count: zero between frames
 }

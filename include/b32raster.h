@@ -359,7 +359,9 @@ int b32_last_draw_order(b32_ctx* ctx, uint32_t* face_idx, uint32_t cap, uint32_t
  * correctly rounded / and sqrt, denormals kept): evaluates op(a[i], b[i], c[i]) on the GPU.
  * op: 0 a*b+c (two roundings), 1 a/b, 2 sqrt(a), 3 (a+b)/c, 4 acos(a) as the lighting code computes it (render.rs:1049),
  * 5 / 6 the bits of `a as i32` / `a as u32` with Rust's semantics (NaN -> 0, saturating; fixed.rs:126, render.rs:1455-1458, 1618),
- * 7 Fixed32::mul_fixed (fixed.rs:161-165) on the operands' bit patterns. */
+ * 7 Fixed32::mul_fixed (fixed.rs:161-165) on the operands' bit patterns,
+ * 8 the wireframe tile kernel's three-instruction depth parameter against k / N (render.rs:784): a[i] = N, out[i] = how many
+ *   k in [0, N] give different bits (the kernel uses it for N < 16384; the test runs every such N and expects zeros). */
 int b32_selftest_f32(b32_ctx* ctx, int op, const float* a, const float* b, const float* c,
                      float* out, uint32_t n);
 
