@@ -114,9 +114,9 @@ __device__ __forceinline__ bool line_k_range(const Edge& e, long long cx0, long 
 }
 // For a line edge_narrow() admits: the steps whose PIXEL lies inside the rectangle, both coordinates.  The minor coordinate after k steps
 // is n0 + sn * j(k), j(k) = floor((2 * dmin * k + dmaj) / (2 * dmaj)), which never decreases: j(k) >= J  <=>  k >= ceil(dmaj * (2J - 1) /
-// (2 * dmin)), so the steps with j(k) in [Ja, Jb] are an interval again.  Everything stays below 2^29.  (tools: the closed form was
-// checked against the literal loop of render.rs:771-817 on 200 000 random lines and rectangles before it went in; the GPU parity tests
-// and the soak compare whole frames.)
+// (2 * dmin)), so the steps with j(k) in [Ja, Jb] are an interval again.  Everything stays below 2^30.
+// tests/test_oracle_kats.py::test_wire_tile_clip_closed_form_equals_literal_loop restates these lines in Python integers and compares
+// them with the literal loop of render.rs:771-817 on 30 000 random lines and rectangles; the GPU parity tests compare whole frames.
 __device__ __forceinline__ bool line_k_range_exact(const Edge& e, int cx0, int cx1, int cy0, int cy1, int& k_lo, int& k_hi) {
     if (!line_k_range_t<int>(e, cx0, cx1, cy0, cy1, k_lo, k_hi)) return false;
     const int dx = e.x1 - e.x0, dy = e.y1 - e.y0, adx = dx < 0 ? -dx : dx, ady = dy < 0 ? -dy : dy;

@@ -218,6 +218,67 @@ def test_bresenham_closed_form_equals_literal_loop(oracle):
     assert L.b32o_draw_line(a.ctypes.data, W, H, -(1 << 30), 0, 5, 5, 1, 2, 3) == b32.abi.B32_E_UNSUPPORTED
 
 
+def _steps_inside_closed_form(e, cx0, cx1, cy0, cy1):
+    """line_k_range_exact of b32_wire.hip, statement by statement, in Python integers: the steps of the line whose pixel lies inside
+    the rectangle, as one interval (None: no step)"""
+    x0, y0, x1, y1 = e
+    adx, ady = abs(x1 - x0), abs(y1 - y0)
+    xmajor = adx >= ady
+    N, m0, lo, hi = (adx, x0, cx0, cx1) if xmajor else (ady, y0, cy0, cy1)
+    forward = (x0 < x1) if xmajor else (y0 < y1)
+    k_lo, k_hi = (max(0, lo - m0), min(N, hi - m0)) if forward else (max(0, m0 - hi), min(N, m0 - lo))
+    if k_lo > k_hi:
+        return None
+    dmaj, dmin = N, (ady if xmajor else adx)
+    n0, nlo, nhi = (y0, cy0, cy1) if xmajor else (x0, cx0, cx1)
+    up = (y0 < y1) if xmajor else (x0 < x1)
+    ja, jb = (nlo - n0, nhi - n0) if up else (n0 - nhi, n0 - nlo)
+    if jb < 0 or ja > dmin:
+        return None
+    ja, jb = max(ja, 0), min(jb, dmin)
+    if dmin > 0:
+        d = 2 * dmin
+        if ja >= 1:
+            k_lo = max(k_lo, (dmaj * (2 * ja - 1) + d - 1) // d)
+        k_hi = min(k_hi, (dmaj * (2 * jb + 1) + d - 1) // d - 1)
+        assert dmaj * (2 * jb + 1) + d - 1 < 2 ** 31                       # (the device computes this in 32 bits)
+    return (k_lo, k_hi) if k_lo <= k_hi else None
+
+
+def test_wire_tile_clip_closed_form_equals_literal_loop():
+    """k_wire_tile (b32_wire.hip) walks only the steps of a line whose pixel lies inside its tile, found in closed form from both axes;
+    the literal loop of draw_line / draw_line_3d (render.rs:716-750, 771-817) visits the same steps, and they are one interval.
+    Step numbers are the loop's iteration count = the reference's `step` (render.rs:779, 805-812)."""
+    import random
+    rnd = random.Random(5)
+    for it in range(30000):
+        R = rnd.choice([8, 40, 200, 1000, 16000])
+        x0, y0 = rnd.randint(-R, R + 64), rnd.randint(-R, R + 16)
+        x1, y1 = x0 + rnd.randint(-min(R, 16383), min(R, 16383)), y0 + rnd.randint(-min(R, 16383), min(R, 16383))
+        if rnd.random() < 0.1: x1 = x0
+        if rnd.random() < 0.1: y1 = y0
+        if rnd.random() < 0.05: y1 = y0 + (x1 - x0)
+        if (x0, y0) > (x1, y1) and it % 3:                                     # (wire_edge's direction, and the other one)
+            x0, y0, x1, y1 = x1, y1, x0, y0
+        cx0 = rnd.choice([0, 64, 640]); cx1 = cx0 + rnd.choice([63, 30, 0])
+        cy0 = rnd.choice([0, 16, 5, 480]); cy1 = cy0 + rnd.choice([15, 7, 0])
+        dx, dy = abs(x1 - x0), -abs(y1 - y0)
+        sx, sy = (1 if x0 < x1 else -1), (1 if y0 < y1 else -1)
+        err, x, y, k, ks = dx + dy, x0, y0, 0, []
+        while True:
+            if cx0 <= x <= cx1 and cy0 <= y <= cy1:
+                ks.append(k)
+            if x == x1 and y == y1:
+                break
+            e2 = 2 * err
+            if e2 >= dy: err += dy; x += sx
+            if e2 <= dx: err += dx; y += sy
+            k += 1
+        want = (ks[0], ks[-1]) if ks else None
+        assert not ks or ks == list(range(ks[0], ks[-1] + 1)), (x0, y0, x1, y1)
+        assert _steps_inside_closed_form((x0, y0, x1, y1), cx0, cx1, cy0, cy1) == want, ((x0, y0, x1, y1), (cx0, cx1, cy0, cy1))
+
+
 # ---------------------------------------------------------------------------------------------------------------------------
 # Constants pinned to the reference's own text (tests/golden/pin_constants.py -> tests/golden/ref_constants.json)
 def _ref_constants():
