@@ -450,8 +450,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PLAIN ? 8 :
                     V3 wn[3];
 #pragma unroll
                     for (int j = 0; j < 3; ++j) {
-                        const float* vp = reinterpret_cast<const float*>(verts) + (size_t)vi[j] * 9;
-                        wn[j] = { vp[5], vp[6], vp[7] };
+                        // (packed streams: the normals are the third one, behind the attributes)
+                        const float* np = pos12 ? attr12 + ((size_t)fp.nv + vi[j]) * 3 : reinterpret_cast<const float*>(verts) + (size_t)vi[j] * 9 + 5;
+                        wn[j] = { np[0], np[1], np[2] };
                         if (backface) wn[j] = scale3(wn[j], -1.0f);
                     }
                     float* sh = shades + (size_t)rslot * 9;
@@ -738,13 +739,17 @@ __global__ __launch_bounds__(256) void k_upload(const uint4* __restrict__ arena,
 }
 // Packed vertex streams of a resident scene (structure of arrays, built once from the uploaded B32Vertex array): positions, 12 bytes
 // each, which k_setup reads for EVERY face, and (u, v, rgba), 12 bytes each, which it reads only for the faces that survive the cull
-// (and, on a band-sharded frame, reach this rank's rows).  The 12 bytes of normal stay in the B32Vertex array (lit frames only).
+// (and, on a band-sharded frame, reach this rank's rows).  The normals, 12 bytes each, follow the attributes (attr12 + 3 * nv floats):
+// lit frames read them for the surviving faces -- out of the 36-byte B32Vertex a wave of neighbouring faces pulls every sector of the
+// vertex array for a third of its bytes.
 __global__ void k_pack_streams(const B32Vertex* __restrict__ verts, uint32_t nv, float* __restrict__ pos12, float* __restrict__ attr12) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nv) return;
     const float* vp = reinterpret_cast<const float*>(verts) + (size_t)i * 9;
+    float* nrm12 = attr12 + 3 * (size_t)nv;
     pos12[3 * (size_t)i] = vp[0]; pos12[3 * (size_t)i + 1] = vp[1]; pos12[3 * (size_t)i + 2] = vp[2];
     attr12[3 * (size_t)i] = vp[3]; attr12[3 * (size_t)i + 1] = vp[4]; attr12[3 * (size_t)i + 2] = vp[8];      // u, v, rgba (bit copy)
+    nrm12[3 * (size_t)i] = vp[5]; nrm12[3 * (size_t)i + 1] = vp[6]; nrm12[3 * (size_t)i + 2] = vp[7];
 }
 void launch_pack_streams(hipStream_t s, const B32Vertex* verts, uint32_t nv, float* pos12, float* attr12) {
     if (nv) hipLaunchKernelGGL(k_pack_streams, dim3((nv + 255) / 256), dim3(256), 0, s, verts, nv, pos12, attr12);
