@@ -1066,7 +1066,7 @@ def test_editor_modes_parity(gpu_ctx, oracle, name, counting):
         gpu_ctx.set_fragment_counting(1)
 
 
-@pytest.mark.parametrize("case", ["small", "medium", "long-lines", "crowded-tile", "overlay", "both-phases", "both-phases-long", "bands", "one-tile"])
+@pytest.mark.parametrize("case", ["small", "medium", "long-lines", "crowded-tile", "overlay", "both-phases", "both-phases-long", "bands", "one-tile", "huge-lines"])
 def test_wireframe_phases_through_screen_tiles(oracle, case):
     """B32_ROUTE_WIRE_TILES: the edges of the wireframe phases (render.rs:2574-2635) binned to 64x64 tiles, first occurrences found in an
     LDS table per tile, lines walked into an LDS bit plane.  Same frame as the oracle (and as the global kernels, route off):
@@ -1075,20 +1075,22 @@ def test_wireframe_phases_through_screen_tiles(oracle, case):
       both-phases   back-face wireframe AND front-face overlay in one frame (the overlay is drawn later: it wins where both hit);
                     -long: with edges of both kinds on both routes -- a big back-face edge (global kernels) must not paint over a small
                     overlay edge's pixels (tile kernel): found by the round-4 soak, fixed by the order of the launches
+      huge-lines    triangles of ~40 000 px over a 256 x 192 frame (48 wire tiles, so no box is "big"): extents of 2^14 and more take the
+                    tile kernel's general 64-bit walk instead of the incremental one
       one-tile      a 64 x 16 frame = one wire tile crossed by the edges of 250 big triangles: as many 16-step segments as one tile gets
                     (the kernel deals them out in passes of WIRE_SEG_CAP; a build with -DB32_WIRE_SEG_CAP=256 runs every case of this test
                     in several passes per tile: tools/r4_segcap.sh)"""
     from bonnie32_amd import rasterizer as R
     cfg = {"small": (2_000, 320, 240, 64.0), "medium": (60_000, 1280, 960, 70.0), "long-lines": (6_000, 1280, 960, 2500.0),
            "crowded-tile": (40_000, 640, 480, 60.0), "overlay": (30_000, 1280, 960, 90.0), "both-phases": (30_000, 640, 480, 120.0), "both-phases-long": (8_000, 1280, 960, 1200.0),
-           "bands": (50_000, 1280, 960, 150.0), "one-tile": (250, 64, 16, 150.0)}[case]
+           "bands": (50_000, 1280, 960, 150.0), "one-tile": (250, 64, 16, 150.0), "huge-lines": (400, 256, 192, 40000.0)}[case]
     sc = scenegen.make_scene("C3", n_tris=cfg[0], width=cfg[1], height=cfg[2], bbox_px=cfg[3], seed=31 + cfg[0], variant="gouraud")
     sc.settings = b32.RasterSettings()                                   # default(): z-buffer, Gouraud + light, back-face wireframe
     if case == "crowded-tile":
         sc.camera = b32.Camera(position=(0.0, 0.0, -60000.0))
     if case == "overlay":
         sc.settings.backface_wireframe = False; sc.settings.wireframe_overlay = True
-    if case.startswith("both-phases") or case == "one-tile":
+    if case.startswith("both-phases") or case in ("one-tile", "huge-lines"):
         sc.settings.wireframe_overlay = True
     # shared and repeated edges: the second half of the mesh repeats the first half's triangles with other depths
     half = len(sc.faces) // 2
