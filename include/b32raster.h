@@ -261,7 +261,7 @@ unsigned long long b32_route_count(const b32_ctx* ctx, int which);
 #define B32_ROUTE_LDS_ATLAS   512u /* one indexed texture (b32_scene_upload_indexed): index atlas + CLUT staged in LDS by every workgroup of the fused
                                     * kernel and looked up per shaded pixel (Clut::lookup, types.rs:390-397) whenever they fit beside the tile planes
                                     * -> expanded Color15 texels fetched from global memory                                          */
-#define B32_ROUTE_WIRE_TILES  1024u /* wireframe phases (render.rs:2574-2635): edges binned to 64x64 tiles, first occurrences found in an LDS table per tile,
+#define B32_ROUTE_WIRE_TILES  1024u /* wireframe phases (render.rs:2574-2635): edges binned to 64x16 tiles, first occurrences found in an LDS table per tile,
                                     * lines walked into an LDS bit plane -> one global first-occurrence table + one lane per whole line        */
 #define B32_ROUTE_PIPELINE    64u  /* setup kernel of the next frame on a second stream beside the fill of the current one -> one stream */
 int b32_set_routes(b32_ctx* ctx, uint32_t off_mask);

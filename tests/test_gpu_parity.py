@@ -1068,7 +1068,7 @@ def test_editor_modes_parity(gpu_ctx, oracle, name, counting):
 
 @pytest.mark.parametrize("case", ["small", "medium", "long-lines", "crowded-tile", "overlay", "both-phases", "both-phases-long", "bands", "one-tile", "huge-lines"])
 def test_wireframe_phases_through_screen_tiles(oracle, case):
-    """B32_ROUTE_WIRE_TILES: the edges of the wireframe phases (render.rs:2574-2635) binned to 64x64 tiles, first occurrences found in an
+    """B32_ROUTE_WIRE_TILES: the edges of the wireframe phases (render.rs:2574-2635) binned to 64x16 tiles, first occurrences found in an
     LDS table per tile, lines walked into an LDS bit plane.  Same frame as the oracle (and as the global kernels, route off):
       long-lines    triangles of ~2500 px: edges whose box covers more than 16 tiles stay with the global kernels, the others go by tile
       crowded-tile  a far camera puts every edge into a few tiles: their lists overflow and the whole frame falls back
