@@ -245,6 +245,24 @@ def _steps_inside_closed_form(e, cx0, cx1, cy0, cy1):
     return (k_lo, k_hi) if k_lo <= k_hi else None
 
 
+def test_wire_depth_parameter_by_reciprocal_equals_the_division():
+    """k_wire_tile computes draw_line_3d's `t = step / total_steps` (render.rs:784) as q = k * r, t = fma(fma(-q, N, k), r, q) with
+    r = 1.0f / N (wire_t_fast, b32_device.h).  Emulated here in float64 (every product below is exact in 53 bits; only the last sum is
+    rounded twice) for EVERY pair 0 <= k <= N < 16384 -- the range the kernel uses it for -- against numpy's correctly rounded float32
+    division.  The device itself is checked by b32_selftest_f32 op 8 (tests/test_gpu_parity.py::test_device_f32_semantics)."""
+    k_all = np.arange(0, 16384, dtype=np.float64)
+    for n0 in range(1, 16384, 128):
+        N = np.arange(n0, min(n0 + 128, 16384), dtype=np.float32)[:, None]
+        r = (np.float32(1.0) / N)
+        k = k_all[None, :]
+        q = (k * r.astype(np.float64)).astype(np.float32)
+        rem = (k - q.astype(np.float64) * N.astype(np.float64)).astype(np.float32)
+        t = (q.astype(np.float64) + rem.astype(np.float64) * r.astype(np.float64)).astype(np.float32)
+        want = k.astype(np.float32) / N
+        use = k <= N.astype(np.float64)
+        assert np.array_equal(t[use], want[use]), n0
+
+
 def test_wire_tile_clip_closed_form_equals_literal_loop():
     """k_wire_tile (b32_wire.hip) walks only the steps of a line whose pixel lies inside its tile, found in closed form from both axes;
     the literal loop of draw_line / draw_line_3d (render.rs:716-750, 771-817) visits the same steps, and they are one interval.
