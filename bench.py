@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the C1 / C2 / C5 side measurements (profiling runs)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--routes-off", type=lambda v: int(v, 0), default=0,
+                    help="B32_ROUTE_* bits to switch off for the whole run (A/B of one route under the profiler; 0 = the library's defaults)")
     ap.add_argument("--check", action="store_true", help="also verify the final frame against the oracle (slow at C3)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="one stream only: no setup kernel of the next frame beside the fill of the current one (b32_set_routes B32_ROUTE_PIPELINE; "
@@ -99,8 +101,8 @@ def main():
     ctx = R.Context(local_rank)
     ctx.set_async_depth(1)      # frames back to back without a host synchronisation (static camera, capacities settled by the warm-up
                                 # frames); a frame dropped for lack of buffer space would be REPORTED by finish(), never silent
-    if args.no_pipeline:
-        ctx.set_routes(R.Context.ROUTE_PIPELINE)
+    if args.no_pipeline or args.routes_off:
+        ctx.set_routes((R.Context.ROUTE_PIPELINE if args.no_pipeline else 0) | args.routes_off)
     # one explicit stream for everything of this rank: the rasterizer's kernels, torch's copies and the RCCL gather are ordered by it
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
@@ -314,7 +316,7 @@ def main():
     cover_ms, cover_samples, phases = None, 0, {}
     shader_clock_ghz, shader_clock_ms = 0.0, 0.0
     if world == 1:
-        ctx.set_routes(R.Context.ROUTE_PIPELINE)
+        ctx.set_routes(R.Context.ROUTE_PIPELINE | args.routes_off)
         n_iso = min(max(args.steps, 24), 60)
         ctx.set_profiling(1)
         for _ in range(n_iso):
@@ -343,7 +345,7 @@ def main():
         torch.cuda.synchronize(dev)
         one_stream_ms = (time.perf_counter() - q0) / args.steps * 1e3
         rs.finish()
-        ctx.set_routes(R.Context.ROUTE_PIPELINE if args.no_pipeline else 0)
+        ctx.set_routes((R.Context.ROUTE_PIPELINE if args.no_pipeline else 0) | args.routes_off)
         ctx.set_async_depth(0)
         torch.cuda.synchronize(dev)
         q0 = time.perf_counter()

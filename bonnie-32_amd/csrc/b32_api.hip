@@ -400,6 +400,7 @@ extern "C" unsigned long long b32_route_count(const b32_ctx* c, int which) {
     if (c && which == 7) return c->pipelined_frames;
     if (c && which == 8) return c->lds_atlas_frames;
     if (c && which == 9) return c->wire_tile_frames;
+    if (c && which == 10) return c->span_cover_frames;
     return (c && which >= 0 && which < 8) ? c->routes[which] : 0ull;
 }
 extern "C" int b32_set_async_depth(b32_ctx* c, int deep) {

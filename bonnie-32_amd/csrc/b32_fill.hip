@@ -344,10 +344,10 @@ __device__ __forceinline__ void load_full_view(const FillArgs& a, uint32_t sid, 
 // (EXACT coverage applies the texel rule); need_aux: also the 1/z terms (z-buffer depth, perspective-correct UVs).
 template <int TEXMODE>
 __device__ __forceinline__ void load_batch(Batch& b, const FillArgs& a, uint32_t entry, bool live, const TexDesc& lds_desc, bool need_uv,
-                                           bool need_aux, uint32_t& sid_out, uint32_t& key_out) {
+                                           bool need_aux, uint32_t& sid_out, uint32_t& key_out, bool& narrow_out) {
     b.q0 = b.q1 = b.q2 = b.q3 = b.q4 = b.q5 = make_uint4(0, 0, 0, 0);
     b.tw = b.th = b.toff = 0;
-    sid_out = 0; key_out = 0;
+    sid_out = 0; key_out = 0; narrow_out = false;
     if (live) {
         const uint32_t sid = a.pair_vals[entry];
         const uint4* cp = reinterpret_cast<const uint4*>(a.crecs + sid);
@@ -356,6 +356,7 @@ __device__ __forceinline__ void load_batch(Batch& b, const FillArgs& a, uint32_t
         RecView v;
         v.q0 = v.q1 = v.q2 = v.q3 = v.q4 = v.q5 = make_uint4(0, 0, 0, 0);
         const bool narrow = view_from_cov(v, c0, c1);
+        narrow_out = narrow;
         if (!narrow || need_uv) {
             const uint4* sp = reinterpret_cast<const uint4*>(a.srecs + sid);
             const uint4 s0 = sp[0], s1 = sp[1];
@@ -702,6 +703,52 @@ __device__ __forceinline__ void cheap_trip(unsigned long long* top, unsigned lon
     addr += TRIP; w0 = wa[TRIP - 1] + sa0; w1 = wb[TRIP - 1] + sa1;
 }
 
+// ---- span coverage (B32_ROUTE_SPAN_COVER; sort-free CHEAP painter's coverage)
+// For a surface with integer vertices, |area| = A <= 8192 and edge coefficients of at most SPAN_MAX_EXT, the reference's toleranced float
+// test (render.rs:1536-1542: bc_x, bc_y, bc_z >= -1e-4) passes EXACTLY on the pixels of the closed integer triangle
+//     E0 = s w0 >= 0,  E1 = s w1 >= 0,  E2 = A - E0 - E1 >= 0        (s = sign of the area; w0, w1 the edge values, exact integers)
+// because one unit of an edge value moves a barycentric by 1 / A >= 2^-13 = 1.22e-4, above the tolerance plus every rounding of the
+// float evaluation (proof and brute-force check: tests/test_span_cover.py).  Along a row every E_j is linear in x with an integer
+// step G_j, so the passing pixels are ONE interval whose ends are integer quotients: lo = max over G_j > 0 of ceil(-E_j / G_j),
+// hi = 1 + min over G_j < 0 of floor(E_j / |G_j|); a row with G_j == 0 passes edge j everywhere or nowhere.  The quotients come from
+// one fma with the reciprocal of G_j, shifted by half a step: (-E_j -+ 1/2) / G_j is at least 1 / (2 |G_j|) away from every
+// integer, which an approximate reciprocal (1 ulp) and the rounding of the fma cannot bridge while |E_j| < 2^21.
+// The row-item scheduler keeps its shape (one lane = one row of one surface, see phase_a_rows), but a lane's row is now its exact
+// interval: no inside test, no barycentrics per pixel -- a trip is the two atomics per pixel and nothing else, and what the surface's
+// lane hands its rows is the per-surface part of the quotients (edge values at the box origin, row steps, reciprocals).
+constexpr float SPAN_MAX_EXT = 512.0f;
+constexpr float SPAN_MIN_INV_AREA = 1.0f / 8192.0f;            // |inv_area| >= 2^-13  <=>  A <= 8192
+struct SpanEdge { float r, c; };
+// edge j of a surface: G = the (sign-corrected) step of E_j per pixel.  r > 0 (G > 0): ceil(fma(-E, r, c)) is the first passing x;
+// r < 0 (G < 0, or G == 0 where the row passes everywhere or nowhere): floor(fma(-E, r, c)) is one past the last passing x
+__device__ __forceinline__ SpanEdge span_edge(float G) {
+    SpanEdge e;
+    const float r = __builtin_amdgcn_rcpf(G);
+    e.r = G == 0.0f ? -1073741824.0f : r;                      // -2^30: E >= 0 -> far right of the tile, E <= -1 -> far left of it
+    e.c = G == 0.0f ? 64.0f : (G > 0.0f ? -0.5f * r : -0.5f * r + 1.0f);
+    return e;
+}
+// the passing interval [lo, hi) of a row, in pixels from the row's first (clipped) pixel, from the three edge values there
+__device__ __forceinline__ void span_interval(float E0, float E1, float E2, const SpanEdge& d0, const SpanEdge& d1, const SpanEdge& d2, float wlen,
+                                              float& lo, float& hi) {
+    const float v0 = __builtin_fmaf(-E0, d0.r, d0.c), v1 = __builtin_fmaf(-E1, d1.r, d1.c), v2 = __builtin_fmaf(-E2, d2.r, d2.c);
+    const bool l0 = d0.r > 0.0f, l1 = d1.r > 0.0f, l2 = d2.r > 0.0f;
+    lo = fmaxf(fmaxf(l0 ? ceilf(v0) : 0.0f, l1 ? ceilf(v1) : 0.0f), l2 ? ceilf(v2) : 0.0f);
+    hi = fminf(fminf(l0 ? wlen : floorf(v0), l1 ? wlen : floorf(v1)), fminf(l2 ? wlen : floorf(v2), wlen));
+}
+// One trip of the span coverage: TRIP consecutive pixels at LDS entry `addr`, the first `left` of them inside the row's interval
+// (exact top-2 per pixel, see cheap_trip; pixels beyond the interval contribute priority 0, a no-op for both maxima)
+__device__ __forceinline__ void span_trip(unsigned long long* top, unsigned long long* sec, uint32_t addr, uint32_t left, unsigned long long P) {
+    constexpr uint32_t TRIP = B32_TRIP;
+    if (left) {                 // (one predicated block for the whole trip, see cheap_trip; lanes without a pixel issue nothing)
+        unsigned long long old[TRIP];
+#pragma unroll
+        for (uint32_t j = 0; j < TRIP; ++j) old[j] = atomicMax(&top[addr + j], j < left ? P : 0ull);
+#pragma unroll
+        for (uint32_t j = 0; j < TRIP; ++j) atomicMax(&sec[addr + j], j < left ? min(old[j], P) : 0ull);
+    }
+}
+
 template <int TEXMODE, bool EXACT, int NW, bool ZMODE, bool FMT8, bool P64 = false>
 __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, uint32_t e0, uint32_t n_op, uint32_t lane, uint32_t wave,
                                                            uint32_t* cursor, uint32_t* wmark, const TexDesc& lds_desc,
@@ -727,13 +774,36 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
         // low word 0xFFFFFFFE - face id (first in face order wins a depth tie, like the sequential `z < zbuffer` test; all ones is
         // reserved for the z-buffer seed, which therefore wins every tie: `z < zbuffer` is strict)
         uint32_t my_sid = 0, my_key = 0;
-        load_batch<TEXMODE>(b, a, e0 + e, live, lds_desc, EXACT, ZMODE || (EXACT && !affine), my_sid, my_key);
+        bool narrow = false;
+        load_batch<TEXMODE>(b, a, e0 + e, live, lds_desc, EXACT, ZMODE || (EXACT && !affine), my_sid, my_key, narrow);
         if (ZMODE) { my_key = 0u; my_sid = 0xFFFFFFFEu - my_sid; }
         const uint32_t flags = b.q3.w;
         const uint32_t cx0 = max(b.q1.w & 0xFFFF, x_lo), cx1 = min(b.q1.w >> 16, x_hi);
         const uint32_t cy0 = max(b.q2.x & 0xFFFF, y_lo), cy1 = min(b.q2.x >> 16, y_hi);
         live = live && cx0 < cx1 && cy0 < cy1;
         const bool slow = live && (flags & F_SLOW);
+        // span coverage: what the rows of an eligible surface need (edge values at the first pixel of its clipped box, their steps per
+        // row, the reciprocal form of the steps per pixel); span_all: every surface of this batch is eligible -- the rounds below then
+        // take the span form, else the per-pixel form serves the whole batch (it is valid for every surface)
+        bool span_all = false;
+        float sE0 = 0.0f, sE1 = 0.0f, sH0 = 0.0f, sH1 = 0.0f, sA = 0.0f;
+        SpanEdge sd0 = { 0.0f, 0.0f }, sd1 = { 0.0f, 0.0f }, sd2 = { 0.0f, 0.0f };
+        if (P64 && !EXACT && !ZMODE && a.span_cover) {
+            const float fa0 = __uint_as_float(b.q0.z), fb0 = __uint_as_float(b.q0.w), fa1 = __uint_as_float(b.q1.x), fb1 = __uint_as_float(b.q1.y);
+            const float inv = __uint_as_float(b.q1.z);
+            const float sgn = inv < 0.0f ? -1.0f : 1.0f;
+            const float G0 = sgn * fa0, G1 = sgn * fa1, G2 = -(G0 + G1);           // steps per pixel of E0, E1, E2 (exact integers)
+            sH0 = sgn * fb0; sH1 = sgn * fb1;                                       // steps per row
+            const float H2 = -(sH0 + sH1);
+            const float ext = fmaxf(fmaxf(fmaxf(__builtin_fabsf(G0), __builtin_fabsf(G1)), fmaxf(__builtin_fabsf(sH0), __builtin_fabsf(sH1))),
+                                    fmaxf(__builtin_fabsf(G2), __builtin_fabsf(H2)));
+            sA = __builtin_fabsf(fa0 * fb1 - fb0 * fa1);                            // |area| (render.rs:1500 in exact integers)
+            const bool fast = narrow && !(flags & (F_EMPTY | F_SLOW)) && ext <= SPAN_MAX_EXT && __builtin_fabsf(inv) >= SPAN_MIN_INV_AREA && sA >= 1.0f;
+            span_all = !__ballot(live && !fast);
+            const float dx = (float)cx0 - __uint_as_float(b.q0.x), dy = (float)cy0 - __uint_as_float(b.q0.y);
+            sE0 = sgn * (fa0 * dx + fb0 * dy); sE1 = sgn * (fa1 * dx + fb1 * dy);   // at the first pixel of the clipped box
+            sd0 = span_edge(G0); sd1 = span_edge(G1); sd2 = span_edge(G2);
+        }
         const uint32_t h = (live && !slow) ? cy1 - cy0 : 0u;
         // exclusive prefix sum of the row counts
         const uint32_t inc = dpp_add_scan(h);
@@ -879,6 +949,75 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
             }
             lqin = cnt;
         };
+        // span form of the remainder rounds: an entry is (lane of the surface, tile row, first column, pixels left of the row's interval)
+        auto drain_span = [&]() {
+            const bool valid = lane < lqn;
+            const uint32_t s = valid ? (lq & 63u) : lane;
+            const uint32_t ry = (lq >> 6) & 63u, rx = (lq >> 12) & 127u;
+            const uint32_t n = valid ? (lq >> 19) : 0u;
+            const unsigned long long P = ((unsigned long long)bperm(s, my_key) << 32) | bperm(s, my_sid);
+            unsigned long long* top = reinterpret_cast<unsigned long long*>(tilebuf);
+            unsigned long long* sec = top + TILE_H * STR64;
+            const uint32_t addr = ry * STR64 + rx;
+            constexpr uint32_t DT = (uint32_t)(B32_DRAIN_TRIPS > 0 ? B32_DRAIN_TRIPS : 2) * (uint32_t)B32_TRIP;
+#pragma unroll
+            for (uint32_t t0 = 0; t0 < DT; t0 += (uint32_t)B32_TRIP) {
+                if (t0 && !__ballot(n > t0)) break;
+                span_trip(top, sec, addr + t0, n > t0 ? n - t0 : 0u, P);
+            }
+            const bool more = n > DT;
+            const unsigned long long mm = __ballot(more);
+            const uint32_t cnt = (uint32_t)__builtin_popcountll(mm);
+            if (cnt) {
+                const uint32_t entry = s | (ry << 6) | ((rx + DT) << 12) | ((n - DT) << 19);
+                const uint32_t dst = more ? (uint32_t)__builtin_popcountll(mm & ((1ull << lane) - 1ull)) : (cnt & 63u);
+                const uint32_t got = (uint32_t)__builtin_amdgcn_ds_permute((int)(dst << 2), (int)(more ? entry : 0u));
+                if (lane < cnt) lq = got;
+            }
+            lqn = cnt;
+        };
+        if (P64 && !EXACT && !ZMODE && span_all) {
+            // span rounds: same items (one lane = one row of one surface), the row is its exact interval
+            for (uint32_t k0 = 0; k0 < R; k0 += 64) {
+                const unsigned long long before = __ballot(h > 0 && P <= k0);
+                const uint32_t carry = before ? 64u - (uint32_t)__builtin_clzll(before) : 0u;
+                const bool starts = h > 0 && P > k0 && P < k0 + 64;
+                const uint32_t mark = (uint32_t)__builtin_amdgcn_ds_permute((int)((starts ? P - k0 : 0u) << 2), (int)(starts ? lane + 1 : 0u));
+                const uint32_t own = max(dpp_max_scan(mark), carry);
+                const uint32_t k = k0 + lane;
+                const bool valid = k < R;
+                const uint32_t s = valid ? own - 1 : lane;
+                const uint32_t sbox = bperm(s, box), sP = bperm(s, P);
+                const float rowf = (float)(k - sP);
+                const float hE0 = bpermf(s, sE0), hE1 = bpermf(s, sE1), hH0 = bpermf(s, sH0), hH1 = bpermf(s, sH1), hA = bpermf(s, sA);
+                SpanEdge e0, e1, e2;
+                e0.r = bpermf(s, sd0.r); e0.c = bpermf(s, sd0.c); e1.r = bpermf(s, sd1.r); e1.c = bpermf(s, sd1.c); e2.r = bpermf(s, sd2.r); e2.c = bpermf(s, sd2.c);
+                const float E0 = __builtin_fmaf(hH0, rowf, hE0), E1 = __builtin_fmaf(hH1, rowf, hE1);       // exact integers
+                const float E2 = hA - E0 - E1;
+                const uint32_t bx0 = sbox & 0xFF, bx1 = (sbox >> 8) & 0xFF, ry = (sbox >> 16) + (k - sP);   // tile-local
+                float lo, hi;
+                span_interval(E0, E1, E2, e0, e1, e2, (float)(bx1 - bx0), lo, hi);
+                const int len = valid ? hw_cvt_i32(hi - lo) : 0;
+                const uint32_t n = len > 0 ? (uint32_t)len : 0u;
+                const uint32_t rx0 = bx0 + hw_cvt_u32(lo);
+                const unsigned long long Pr = ((unsigned long long)bperm(s, my_key) << 32) | bperm(s, my_sid);
+                unsigned long long* top = reinterpret_cast<unsigned long long*>(tilebuf);
+                unsigned long long* sec = top + TILE_H * STR64;
+                span_trip(top, sec, ry * STR64 + rx0, n, Pr);
+                const bool more = n > (uint32_t)B32_TRIP;
+                const unsigned long long mm = __ballot(more);
+                if (mm) {
+                    const uint32_t cnt = (uint32_t)__builtin_popcountll(mm);
+                    while (lqn + cnt > 64u) drain_span();
+                    const uint32_t entry = s | (ry << 6) | ((rx0 + (uint32_t)B32_TRIP) << 12) | ((n - (uint32_t)B32_TRIP) << 19);
+                    const uint32_t dst = more ? lqn + (uint32_t)__builtin_popcountll(mm & ((1ull << lane) - 1ull)) : ((lqn + cnt) & 63u);
+                    const uint32_t got = (uint32_t)__builtin_amdgcn_ds_permute((int)(dst << 2), (int)(more ? entry : 0u));
+                    if (lane >= lqn && lane < lqn + cnt) lq = got;
+                    lqn += cnt;
+                }
+            }
+            while (lqn) drain_span();
+        } else
         for (uint32_t k0 = 0; k0 < R; k0 += 64) {
             // owner of item k0+lane: last surface s with h>0 and P[s] <= k
             const unsigned long long before = __ballot(h > 0 && P <= k0);
@@ -1378,7 +1517,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PLAIN == 2 ?
                 unsigned long long* t64 = reinterpret_cast<unsigned long long*>(tilebuf);
                 for (uint32_t i = tid; i < TH * STR64; i += NT) { t64[i] = 0ull; if (!EXACT) t64[TILE_H * STR64 + i] = 0ull; }
             } else
-            for (uint32_t i = tid; i < (P64 ? (EXACT ? 2 : 4) : (EXACT ? 1 : 2)) * TILE_H * TILE_STRIDE; i += NT) tilebuf[i] = 0;
+            if (P64 && !EXACT) {                            // both 64-bit planes, 16 bytes per store 
+                uint4* t128 = reinterpret_cast<uint4*>(tilebuf);
+                for (uint32_t i = tid; i < (uint32_t)(TILE_H * STR64); i += NT) t128[i] = make_uint4(0, 0, 0, 0);
+            } else
+            for (uint32_t i = tid; i < (P64 ? 2 : (EXACT ? 1 : 2)) * TILE_H * TILE_STRIDE; i += NT) tilebuf[i] = 0;
         }
         __syncthreads();
         if (P64 && a.direct_bin && tid == 0) {   // (everyone has read them) zero again for the next frame's k_setup

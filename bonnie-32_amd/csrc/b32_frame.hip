@@ -391,6 +391,7 @@ static FillArgs fill_args(const b32_ctx* c, const FrameParams& fp, const Route& 
     fa.direct_bin = r.direct_bin ? 1u : 0u; fa.tile_fill = c->tile_fill; fa.epoch = c->epoch;
     if (r.direct_bin) fa.pair_vals = c->direct_lists;
     fa.gather_blend = (r.prio64 && r.with_class) ? 1u : 0u;
+    fa.span_cover = (r.prio64 && !r.exact_cov && !fp.zmode && !(c->route_off & B32_ROUTE_SPAN_COVER)) ? 1u : 0u;
     fa.co_run = (c->pipelined || (c->deep_async && c->pipe_hint && c->nf > 2048u && !(c->route_off & B32_ROUTE_PIPELINE))) ? 1u : 0u;   // (this frame's or the next one's setup kernel beside a fill)
     // index atlas + CLUT sampled from LDS: the fused kernel with one indexed texture, when they fit beside the tile planes of the
     // workgroup form launch_fill is going to choose (16 waves, one workgroup per CU: ~84 KB; two 8-wave workgroups per CU: ~6 KB)
@@ -537,6 +538,7 @@ int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st, const
         } else if ((rc = flush_clear(c))) return rc;
     }
     if (fa.atlas_idx_bytes && !wire_front && !r.ordered_all) c->lds_atlas_frames++;
+    if (fa.span_cover && !wire_front && !r.ordered_all) c->span_cover_frames++;
     launch_fill(s, fa, c->n_cu, prof_fill ? ev[4] : nullptr);
 
     // ---- wireframe phases

@@ -139,6 +139,7 @@ struct b32_ctx {
     uint32_t *wire_fill = nullptr, *wire_lists = nullptr; size_t cap_wire_tiles = 0;     // tile route of the wireframe phases (WireArgs)
     unsigned long long wire_grid = 0;                                                       // tile grid the (self-resetting) counters belong to
     unsigned long long wire_tile_frames = 0;
+    unsigned long long span_cover_frames = 0;                     // frames whose opaque coverage used exact row intervals (B32_ROUTE_SPAN_COVER)
     // control
     Ctrl* d_ctrl = nullptr; uint32_t* d_consts = nullptr; Ctrl h_ctrl{}; Stamps h_stamps{};   // (d_ctrl: Ctrl followed by Stamps)
     uint32_t h_consts[4] = { 0, 0, 0, 0 };   // staging for d_consts (outlives the async copy)

@@ -245,7 +245,8 @@ int b32_set_async_depth(b32_ctx* ctx, int deep);
  * keyed pipeline (global depth sort), 4 frames redrawn because a tile region overflowed, 5 frames redrawn through the global depth
  * sort, 6 frames redrawn after a pair-buffer overflow, 7 frames whose setup kernel ran on the second stream beside the previous frame's
  * fill (two frames in flight), 8 frames whose fused kernel sampled the 4/8-bit index atlas + CLUT from LDS (B32_ROUTE_LDS_ATLAS),
- * 9 frames whose wireframe phases went through the tile route (B32_ROUTE_WIRE_TILES).
+ * 9 frames whose wireframe phases went through the tile route (B32_ROUTE_WIRE_TILES), 10 frames whose opaque coverage was decided by
+ * exact row intervals (B32_ROUTE_SPAN_COVER).
  * Unknown `which` or null ctx: 0. */
 unsigned long long b32_route_count(const b32_ctx* ctx, int which);
 /* Switch internal routes OFF for the frames enqueued from now on (no reference counterpart: the results are identical on every route;
@@ -263,6 +264,9 @@ unsigned long long b32_route_count(const b32_ctx* ctx, int which);
                                     * -> expanded Color15 texels fetched from global memory                                          */
 #define B32_ROUTE_WIRE_TILES  1024u /* wireframe phases (render.rs:2574-2635): edges binned to 64x16 tiles, first occurrences found in an LDS table per tile,
                                     * lines walked into an LDS bit plane -> one global first-occurrence table + one lane per whole line        */
+#define B32_ROUTE_SPAN_COVER  2048u /* sort-free CHEAP painter's coverage: for surfaces with integer vertices, |area| <= 8192 and edges <= 512 px the reference's
+                                    * toleranced inside test (render.rs:1536-1542) equals the closed integer triangle, so every row's passing pixels are one
+                                    * interval with integer-quotient ends -- no per-pixel test; other surfaces keep the per-pixel form -> per-pixel form for all */
 #define B32_ROUTE_PIPELINE    64u  /* setup kernel of the next frame on a second stream beside the fill of the current one -> one stream */
 int b32_set_routes(b32_ctx* ctx, uint32_t off_mask);
 /* CHEAP coverage (inside test only, texel rule applied to the winner) is used while every texture has at most 1/den skippable texels
