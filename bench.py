@@ -29,13 +29,9 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
 def csrc_digest():
-    """SHA-256 over the kernel sources: identifies the build a PMC measurement belongs to (profiles/pmc_traffic.json)."""
-    h = hashlib.sha256()
-    d = os.path.join(ROOT, "bonnie-32_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h")):
-            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
-    return h.hexdigest()[:16]
+    """Digest of the library's sources and flags (bonnie-32_amd/build.py): identifies the build a measurement belongs to."""
+    from bonnie32_amd import build as B
+    return B.csrc_digest()
 
 
 def main():
@@ -92,7 +88,8 @@ def main():
         g.build()
     if world > 1:
         dist.barrier()
-    from bonnie32_amd import rasterizer as R, scenegen, parallel
+    from bonnie32_amd import rasterizer as R, scenegen, parallel, abi
+    build_digest = abi.check_build_digest()      # refuses a library that was not compiled from this tree's sources
     HASHES = json.load(open(os.path.join(ROOT, "tests", "golden", "hashes.json")))
 
     sc = scenegen.make_scene(args.config, n_tris=args.tris)
@@ -626,6 +623,7 @@ def main():
                        "triangles_drawn": tm.triangles_drawn, "fragments": fragments,
                        "parallelism": (f"screen bands x{world}, RCCL gather " + ("overlapped with the next frame (two framebuffers)" if pipelined else "after every frame")) if world > 1 else "single GPU"},
             "frame_sha256": sha[:16], "bit_exact_vs_committed_hash": (sha == want) if want else None,
+            "build_digest": build_digest, "csrc_digest": csrc_digest(),     # the loaded library's own digest == the source tree's (checked at start)
             "protocol": {"ms_per_step_median": round(per_step[len(per_step) // 2], 5) if per_step else None,
                          "ms_per_step_min": round(per_step[0], 5) if per_step else None,
                          "median_over": len(per_step), "median_note": "HIP events between consecutive steps on the frame's stream (separate pass)",

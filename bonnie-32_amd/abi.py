@@ -140,6 +140,7 @@ SYMBOLS = [
     ("b32_last_shader_clock", C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     ("b32_transparent_counts", C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("b32_set_fragment_counting", C.c_int, [_P, C.c_int]),
+    ("b32_build_digest", C.c_char_p, []),
 ]
 
 _lib = None
@@ -163,6 +164,19 @@ def load_library(path=None):
     if path is None:
         _lib = lib
     return lib
+
+
+def check_build_digest(lib=None):
+    """The loaded library must have been compiled from THIS source tree (b32_build_digest() == build.csrc_digest()): a stale .so that
+    travelled with the snapshot would otherwise be timed / tested in place of the sources next to it.  Returns the digest.  An
+    experiment build named by B32_LIB (tools/exp_variants.py) is exempt: it is never the product."""
+    from . import build as B
+    lib = lib or load_library()
+    have = (lib.b32_build_digest() or b"").decode("ascii", "replace")
+    want = B.csrc_digest()
+    if have != want and not os.environ.get("B32_LIB"):
+        raise RuntimeError(f"libb32raster.so was built from other sources (library {have}, tree {want}): run __graft_entry__.build()")
+    return have
 
 
 def ptr(a):

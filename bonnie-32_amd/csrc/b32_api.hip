@@ -61,6 +61,12 @@ void b32_destroy(b32_ctx* c) {
 }
 
 int b32_last_hip_error(const b32_ctx* c) { return c ? c->last_hip : 0; }
+#ifndef B32_SRC_DIGEST
+#define B32_SRC_DIGEST "unknown-digest!!"
+#endif
+// (the marker in front lets build.py read the digest from the file without loading it)
+static const char g_build_digest[] = "B32-SRC-DIGEST:" B32_SRC_DIGEST;
+const char* b32_build_digest(void) { return g_build_digest + 15; }
 
 // A pending frame that may still need a redraw (pair overflow, long transparent lists) is settled before anything reads or rebinds
 // the framebuffer, so that no caller ever sees the cleared frame of an aborted attempt.  Its error, if any, is the frame's error: kept

@@ -8,6 +8,12 @@
 #include <stdint.h>
 #include "../../include/b32raster.h"
 
+// Experiment switches that produce WRONG frames on purpose (they isolate the cost of one mechanism; tools/exp_variants.py builds) may only
+// be compiled into an explicitly marked experiment build, never into the product library.
+#if (defined(B32_EXP_BIN_NO_ATOMICS) || defined(B32_EXP_BIN_WG_ATOMICS) || defined(B32_EXP_BIN_NO_LIST_STORE) || defined(B32_EXP_WIRE_STAGE)) && !defined(B32_EXPERIMENT)
+#error "B32_EXP_* switches that break the frame need -DB32_EXPERIMENT (an experiment build, loaded through B32_LIB only)"
+#endif
+
 namespace b32 {
 
 // ---------------------------------------------------------------- geometry constants

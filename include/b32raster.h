@@ -164,6 +164,9 @@ int         b32_create(int device, b32_ctx** out);
 void        b32_destroy(b32_ctx* ctx);
 const char* b32_strerror(int code);
 int         b32_last_hip_error(const b32_ctx* ctx);
+/* Digest (16 hex digits) of the sources and compiler flags this library was built from (bonnie-32_amd/build.py: csrc_digest; no
+ * reference counterpart).  bench.py and __graft_entry__.smoke() refuse to run a library whose digest is not the source tree's. */
+const char* b32_build_digest(void);
 /* Run on a caller-owned hipStream_t (e.g. torch's current stream); NULL = the ctx's own non-blocking stream.  The legacy default
  * stream is not NULL here: pass hipStreamLegacy ((hipStream_t)1) for it (torch reports its default stream as handle 0). */
 int         b32_set_stream(b32_ctx* ctx, void* hip_stream);

@@ -1336,6 +1336,39 @@ def test_every_route_of_the_sort_free_path_gives_the_same_frame(fast_ctx, oracle
         fast_ctx.set_routes(0)
 
 
+@pytest.mark.parametrize("name", ["C3:100k", "C5:20k", "C3:blend-100k", "span-mix"])
+def test_span_coverage_equals_the_per_pixel_inside_test(fast_ctx, oracle, name):
+    """B32_ROUTE_SPAN_COVER: painter's CHEAP coverage decides a row by its exact integer interval instead of the reference's per-pixel
+    toleranced test (render.rs:1536-1542; proof: tests/test_span_cover.py).  Same frame with the route on and off, the counter shows
+    which ran; "span-mix" puts triangles beyond the eligibility limits (|area| > 8192: their batches keep the per-pixel form, where the
+    tolerance admits pixels outside the integer triangle) into the same tiles as eligible ones, on a frame whose width is no multiple
+    of the tile's."""
+    from bonnie32_amd import rasterizer as R
+    if name == "span-mix":
+        sc = scenegen.make_scene("C3", n_tris=60_000, width=1000, height=700, seed=77)
+        big = scenegen.make_scene("C5", n_tris=3_000, width=1000, height=700, bbox_px=40_000.0, seed=78)
+        nv = len(sc.vertices)
+        faces = big.faces.copy(); faces["v"] += nv
+        sc.vertices = np.concatenate([sc.vertices, big.vertices]); sc.faces = np.concatenate([sc.faces, faces])
+        rng = np.random.default_rng(5); perm = rng.permutation(len(sc.faces)); sc.faces = sc.faces[perm]
+    elif name == "C3:blend-100k":        # a transparent pass beside it (the span form serves the opaque part of every tile list)
+        sc = scenegen.make_scene("C3", n_tris=100_000, variant="blend")
+    else:
+        sc = SCENES[name]()
+    exp, etm, d = cpu_render(oracle, sc)
+    try:
+        for off in (0, R.Context.ROUTE_SPAN_COVER):
+            fast_ctx.set_routes(off)
+            before = fast_ctx.route_counts()
+            got, tm = gpu_render(fast_ctx, sc, resident=True)
+            after = fast_ctx.route_counts()
+            assert np.array_equal(got, exp), f"{int((got != exp).sum())} bytes differ (routes off: {off})"
+            assert tm.triangles_drawn == etm.triangles_drawn
+            assert (after["span_cover"] > before["span_cover"]) == (off == 0)
+    finally:
+        fast_ctx.set_routes(0)
+
+
 @pytest.mark.parametrize("variant", ["bench", "blend"])
 def test_direct_binning_of_a_spatially_ordered_mesh(fast_ctx, oracle, variant):
     """A real mesh is spatially ordered: the faces of one wave of k_setup mostly land in the same tile, and the list append groups them
