@@ -1420,6 +1420,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PLAIN == 2 ?
         for (uint32_t i = tid; i < nq; i += NT) dst[i] = src[i];
     }
     unsigned long long frag_count = 0;
+    // Staggered start (FillArgs::stagger, 10-ns ticks; frames with more tiles than workgroup slots): the second workgroup of every CU
+    // begins a few microseconds late.  Started together, the two workgroups of a CU run their first tiles in step -- both in the
+    // LDS-latency bound coverage, then both in the memory bound shading -- and every CU of the chip does the same at the same time: the
+    // first tile of a workgroup took 36 us against 25-29 us for the later ones (tools/timeline.py).  Any delay between 3 and 8 us gives
+    // the same gain (C3 0.1285 -> 0.1213 ms per frame, C5 0.198 -> 0.192, profiles/r05_stagger.txt).
+    if (P64 && a.stagger && blockIdx.x >= gridDim.x / 2) {
+        const unsigned long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < (unsigned long long)a.stagger) __builtin_amdgcn_s_sleep(8);
+    }
     // the first tile of a workgroup is its own index (no atomic: 512 same-address atomics serialise at ~12 ns each), later ones come
     // from the shared cursor
     uint32_t next_tile = blockIdx.x;
@@ -2281,7 +2290,8 @@ extern "C" int b32_debug_timeline(unsigned long long* out, unsigned cap_words) {
 }
 #endif
 template <bool EXACT, bool ZMODE, bool FMT8>
-static void launch_p64(hipStream_t s, const FillArgs& a, uint32_t ntiles, int n_cu, bool wide) {
+static void launch_p64(hipStream_t s, const FillArgs& a_in, uint32_t ntiles, int n_cu, bool wide) {
+    FillArgs a = a_in;
     // tile planes, misc words, 64 words of repair queue per wave, then the staged index atlas (if any)
     const size_t atlas = a.atlas_idx_bytes ? (((size_t)ATLAS_CLUT_BYTES + a.atlas_idx_bytes + 15) & ~(size_t)15) : 0;
     const size_t lds_n = 4 * LDS_TILE_BYTES + LDS_MISC_BYTES + 8 * 256 + atlas, lds_w = 4 * LDS_TILE_BYTES + LDS_MISC_BYTES + 16 * 256 + atlas;
@@ -2291,12 +2301,17 @@ static void launch_p64(hipStream_t s, const FillArgs& a, uint32_t ntiles, int n_
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<0, EXACT, 1024, ZMODE, FMT8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
     const dim3 g(min(ntiles, (uint32_t)n_cu * 2));
+#ifndef B32_STAGGER_TICKS
+#define B32_STAGGER_TICKS 400
+#endif
+    // (two workgroups per CU and at least a second round of tiles: see `stagger` in k_cover)
+    a.stagger = (a_in.stagger && !wide && ntiles > (uint32_t)n_cu * 2u) ? (uint32_t)B32_STAGGER_TICKS : 0u;
 #ifdef B32_TIMELINE
     {
         static unsigned long long* dbg = nullptr;
         if (!dbg) (void)hipMalloc(reinterpret_cast<void**>(&dbg), (1 + 4 * 8192) * 8);
         (void)hipMemsetAsync(dbg, 0, 8, s);
-        const_cast<FillArgs&>(a).dbg = dbg;
+        a.dbg = dbg;
         g_timeline = dbg;
     }
 #endif

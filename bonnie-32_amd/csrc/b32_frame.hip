@@ -391,6 +391,7 @@ static FillArgs fill_args(const b32_ctx* c, const FrameParams& fp, const Route& 
     fa.direct_bin = r.direct_bin ? 1u : 0u; fa.tile_fill = c->tile_fill; fa.epoch = c->epoch;
     if (r.direct_bin) fa.pair_vals = c->direct_lists;
     fa.gather_blend = (r.prio64 && r.with_class) ? 1u : 0u;
+    fa.stagger = (c->route_off & B32_ROUTE_STAGGER) ? 0u : 1u;       // (launch_fill decides whether the frame qualifies)
     fa.span_cover = (r.prio64 && !r.exact_cov && !fp.zmode && !(c->route_off & B32_ROUTE_SPAN_COVER)) ? 1u : 0u;
     fa.co_run = (c->pipelined || (c->deep_async && c->pipe_hint && c->nf > 2048u && !(c->route_off & B32_ROUTE_PIPELINE))) ? 1u : 0u;   // (this frame's or the next one's setup kernel beside a fill)
     // index atlas + CLUT sampled from LDS: the fused kernel with one indexed texture, when they fit beside the tile planes of the

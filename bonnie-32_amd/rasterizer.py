@@ -74,7 +74,7 @@ class Context:
 
     ROUTES = ("direct_bin", "inline_bin", "counting_sort", "keyed", "redraw_region", "redraw_global_sort", "redraw_pairs", "pipelined", "lds_atlas", "wire_tiles", "span_cover")
 
-    ROUTE_SORT_FREE, ROUTE_CUT_TILES, ROUTE_INLINE_BIN, ROUTE_DIRECT_BIN, ROUTE_WIDE_GROUPS, ROUTE_PACKED_STREAMS, ROUTE_PIPELINE, ROUTE_TEX_CACHE, ROUTE_BATCH, ROUTE_LDS_ATLAS, ROUTE_WIRE_TILES, ROUTE_SPAN_COVER = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048
+    ROUTE_SORT_FREE, ROUTE_CUT_TILES, ROUTE_INLINE_BIN, ROUTE_DIRECT_BIN, ROUTE_WIDE_GROUPS, ROUTE_PACKED_STREAMS, ROUTE_PIPELINE, ROUTE_TEX_CACHE, ROUTE_BATCH, ROUTE_LDS_ATLAS, ROUTE_WIRE_TILES, ROUTE_SPAN_COVER, ROUTE_STAGGER = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096
 
     # ---- a frame of several meshes (scene.rs:112-261): b32_frame_begin / _add_scene / _end
     def frame_begin(self, camera, settings):

@@ -270,6 +270,8 @@ unsigned long long b32_route_count(const b32_ctx* ctx, int which);
 #define B32_ROUTE_SPAN_COVER  2048u /* sort-free CHEAP painter's coverage: for surfaces with integer vertices, |area| <= 8192 and edges <= 512 px the reference's
                                     * toleranced inside test (render.rs:1536-1542) equals the closed integer triangle, so every row's passing pixels are one
                                     * interval with integer-quotient ends -- no per-pixel test; other surfaces keep the per-pixel form -> per-pixel form for all */
+#define B32_ROUTE_STAGGER     4096u /* fused kernel, frames with more tiles than workgroup slots: the second workgroup of every CU starts 4 us late (the two then
+                                    * run coverage against shading instead of in step) -> all workgroups start together */
 #define B32_ROUTE_PIPELINE    64u  /* setup kernel of the next frame on a second stream beside the fill of the current one -> one stream */
 int b32_set_routes(b32_ctx* ctx, uint32_t off_mask);
 /* CHEAP coverage (inside test only, texel rule applied to the winner) is used while every texture has at most 1/den skippable texels
