@@ -1268,6 +1268,10 @@ __device__ __forceinline__ void shade_tile_p64(const FillArgs& a, const uint32_t
                                                uint32_t y_lo, uint32_t y_hi, uint32_t ty_top, uint32_t tid, uint32_t lane, uint32_t TH, uint32_t* rq,
                                                const uint8_t* latlas);
 
+template <int NT>
+__device__ __forceinline__ void shade_tile_plain(const FillArgs& a, const uint32_t* tilebuf, uint32_t e0, uint32_t e1, uint32_t x_lo, uint32_t x_hi,
+                                                 uint32_t y_lo, uint32_t y_hi, uint32_t ty_top, uint32_t tid, uint32_t lane, uint32_t TH, uint32_t* wq);
+
 // k_setup's per-block counters (visible, transparent, NaN keys per class, bad vertex index) -> the frame's abort decision in misc[6]
 // (the reference panics before drawing on a bad vertex index, render.rs:2375, or when a sort comparison sees NaN, render.rs:2531);
 // workgroup 0 publishes the sums in Ctrl for the host.  Per-thread sums, a wave reduction, then one LDS atomic per wave and counter.
@@ -1324,7 +1328,7 @@ template <int TEXMODE, bool EXACT, int NT, bool ZMODE, bool FMT8 = false, bool P
 // (every form but the plain one is compiled for at least 4 waves per SIMD, i.e. at most 128 VGPRs: the EXACT z-buffer forms had drifted
 // to 129, which halves the 512-thread kernel's residency to one workgroup per CU -- game() settings with colour-keyed textures at
 // 2560x1920: 0.289 -> 0.242 ms; the plain form keeps the default bound of its block size, its code is byte-identical)
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PLAIN == 2 ? 5 : (PLAIN == 1 ? 2 : ((P64 && NT == 512) ? B32_P64_WAVES : 4))))) void k_cover(FillArgs a_in) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PLAIN == 2 ? 5 : (PLAIN == 1 ? 4 : ((P64 && NT == 512) ? B32_P64_WAVES : 4))))) void k_cover(FillArgs a_in) {
     FillArgs a_plain = a_in;
     if (PLAIN) {
         a_plain.fp.affine = 1; a_plain.fp.shading = B32_SHADE_NONE; a_plain.fp.fixed_point = 1; a_plain.fp.ortho = 0; a_plain.fp.nt = 1;
@@ -1559,7 +1563,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PLAIN == 2 ?
 #ifdef B32_TIMELINE
             const unsigned long long tl1 = wall_clock64();
 #endif
-            if (n_op) shade_tile_p64<FMT8, NT, ZMODE>(a, tilebuf, e0, e1, x_lo, x_hi, y_lo, y_hi, ty_top, tid, lane, TH, wmarks + wave * 64, latlas);
+            if (n_op) {
+                // (the plain form's straight-line shading: one texture of non-zero size fetched from global memory)
+                if (PLAIN && !FMT8 && !ZMODE && !latlas && a.tex0.width && a.tex0.height) shade_tile_plain<NT>(a, tilebuf, e0, e1, x_lo, x_hi, y_lo, y_hi, ty_top, tid, lane, TH, wmarks + wave * 64);
+                else shade_tile_p64<FMT8, NT, ZMODE>(a, tilebuf, e0, e1, x_lo, x_hi, y_lo, y_hi, ty_top, tid, lane, TH, wmarks + wave * 64, latlas);
+            }
             else if (a.clear_on) {      // nothing reaches this tile: it still gets the frame's clear colour
                 for (uint32_t p = tid; p < TILE_W * TH; p += NT) {
                     const uint32_t px = x_lo + (p & 63), py = ty_top + (p >> 6);
@@ -1871,6 +1879,127 @@ __device__ __forceinline__ void shade_tile_p64(const FillArgs& a, const uint32_t
                 if (!(cA && !okA)) put(px, pyA, okA, hA, tA, inA);
                 if (!(cB && !okB)) put(px, pyB, okB, hB, tB, inB);
             }
+        }
+        if (mA | mB) {
+#pragma unroll
+            for (int which = 0; which < 2; ++which) {
+                const unsigned long long m = which ? mB : mA;
+                if (!m) continue;
+                const uint32_t n = (uint32_t)__builtin_popcountll(m);
+                if (lqn + n > 64u) drain();
+                if ((m >> lane) & 1ull) wq[lqn + (uint32_t)__builtin_popcountll(m & below)] = ((which ? rowB : rowA) << 6) | col;
+                lqn += n;
+            }
+        }
+    }
+    if (lqn) drain();
+}
+
+// The shading phase of the PLAIN form (the benchmark's settings: affine UVs, no shading pass, fixed-point snap, one texture fetched from
+// global memory, painter's mode, RGB555), written straight-line: the general shade_tile_p64 reaches the same arithmetic through
+// hit_prepare / hit_finish / colour, whose per-pixel branches (texture present?, zero-sized?, literal replay?, inside?) cost the
+// plain instantiation ~90 branches and ~470 VALU instructions per two-pixel step.  Here every lane runs the one path -- record view,
+// edge values in closed form, barycentrics, UVs, texel address (render.rs:1507-1583, types.rs:671-681), both texel fetches in flight, texel
+// rule (render.rs:1591-1608), packed colour pipeline -- on whatever its two pixels hold (an uncovered pixel computes on surface 0's
+// record and stores nothing of it).  The winner of a covered pixel passed the inside test during coverage (same arithmetic, or the
+// span form proven equal to it), so it is not evaluated again.  A step in which some winner must replay the edge walk literally
+// (SH_SLOW) takes the general per-pixel functions; skipped winners go to the wave's repair queue as in the general form.
+template <int NT>
+__device__ __forceinline__ void shade_tile_plain(const FillArgs& a, const uint32_t* tilebuf, uint32_t e0, uint32_t e1, uint32_t x_lo, uint32_t x_hi,
+                                                 uint32_t y_lo, uint32_t y_hi, uint32_t ty_top, uint32_t tid, uint32_t lane, uint32_t TH, uint32_t* wq) {
+    const FrameParams& fp = a.fp;
+    const unsigned long long* top = reinterpret_cast<const unsigned long long*>(tilebuf);
+    const unsigned long long* sec = top + TILE_H * STR64;
+    const uint32_t W = fp.width;
+    constexpr uint32_t ROWS_PER_STEP = NT / 64;
+    const TexDesc d = a.tex0;
+    const float twf = (float)d.width, thf = (float)d.height;
+    const uint32_t col = tid & 63, px = x_lo + col;
+    const float fx = (float)px;
+    const bool in_x = px < x_hi;
+    uint32_t lqn = 0;                                   // entries in this wave's repair queue (wave-uniform)
+    auto drain = [&]() {
+        const bool act = lane < lqn;
+        const uint32_t e = act ? wq[lane] : 0u;
+        const uint32_t row = e >> 6, c = e & 63u, qx = x_lo + c, qy = ty_top + row;
+        bool ok = false; Hit h; h.sid = 0;
+        unsigned long long t = 0;
+        repair_pixel<false, false>(a, sec, act, row, c, qx, qy, e0, e1, lane, ok, h, t);
+        if (act) {
+            if (ok) a.fb[(size_t)qy * W + qx] = colour<false>(a, h, B32_SHADE_NONE, qx, qy);
+            else if (a.clear_on) a.fb[(size_t)qy * W + qx] = a.clear_rgba;
+        }
+        lqn = 0;
+    };
+    const unsigned long long below = (1ull << lane) - 1ull;
+    auto f = [](uint32_t w) { return __uint_as_float(w); };
+    for (uint32_t r0 = 0; r0 < TH; r0 += 2 * ROWS_PER_STEP) {
+        const uint32_t rowA = r0 + (tid >> 6), rowB = rowA + ROWS_PER_STEP;
+        const uint32_t pyA = ty_top + rowA, pyB = ty_top + rowB;
+        const bool inA = rowA < TH && in_x && pyA >= y_lo && pyA < y_hi, inB = rowB < TH && in_x && pyB >= y_lo && pyB < y_hi;
+        const unsigned long long tA = inA ? top[rowA * STR64 + col] : 0ull, tB = inB ? top[rowB * STR64 + col] : 0ull;
+        const bool cA = tA != 0ull, cB = tB != 0ull;
+        uint32_t* outA = a.fb + (size_t)pyA * W + px;
+        uint32_t* outB = a.fb + (size_t)pyB * W + px;
+        if (!__ballot(cA || cB)) {
+            if (a.clear_on) { if (inA) *outA = a.clear_rgba; if (inB) *outB = a.clear_rgba; }
+            continue;
+        }
+        const uint4* spA = reinterpret_cast<const uint4*>(a.srecs + (uint32_t)tA);      // (surface 0's record for an uncovered pixel: read, never used)
+        const uint4* spB = reinterpret_cast<const uint4*>(a.srecs + (uint32_t)tB);
+        const uint4 a0q = spA[0], a1q = spA[1], a2q = spA[2], a3q = spA[3];
+        const uint4 b0q = spB[0], b1q = spB[1], b2q = spB[2], b3q = spB[3];
+        const uint32_t shA = a3q.w >> 24, shB = b3q.w >> 24;
+        unsigned long long mA, mB;
+        if (__ballot((cA && (shA & SH_SLOW)) || (cB && (shB & SH_SLOW)))) {
+            // rare: a winner whose edge walk is replayed literally -- the general per-pixel functions for this step
+            Hit hA, hB;
+            const bool okA = cA && hit_test<false>(a, (uint32_t)tA, px, pyA, hA);
+            const bool okB = cB && hit_test<false>(a, (uint32_t)tB, px, pyB, hB);
+            if (okA) *outA = colour<false>(a, hA, B32_SHADE_NONE, px, pyA); else if (!cA && inA && a.clear_on) *outA = a.clear_rgba;
+            if (okB) *outB = colour<false>(a, hB, B32_SHADE_NONE, px, pyB); else if (!cB && inB && a.clear_on) *outB = a.clear_rgba;
+            mA = __ballot(cA && !okA); mB = __ballot(cB && !okB);
+        } else {
+            float bA[3], bB[3];
+            uint32_t taA, taB;
+            {   // pixel A: render.rs:1507-1510 (edges), :1517-1518 / 1706-1712 in closed form (exact integers), :1536-1538, :1565-1566, types.rs:671-681
+                const float x3 = f(a1q.x), y3 = f(a1q.y), inv = f(a1q.z);
+                const float ea0 = f(a0q.w) - y3, eb0 = x3 - f(a0q.z), ea1 = y3 - f(a0q.y), eb1 = f(a0q.x) - x3;
+                const float dx = fx - x3, dy = (float)pyA - y3;
+                const float w0 = ea0 * dx + eb0 * dy, w1 = ea1 * dx + eb1 * dy;
+                bA[0] = w0 * inv; bA[1] = w1 * inv; bA[2] = 1.0f - bA[0] - bA[1];
+                const float u = bA[0] * f(a2q.x) + bA[1] * f(a2q.y) + bA[2] * f(a2q.z);
+                const float v = bA[0] * f(a2q.w) + bA[1] * f(a3q.x) + bA[2] * f(a3q.y);
+                const float uw = rem_euclid1(u), vw = rem_euclid1(1.0f - v);
+                const uint32_t tx = min(f2u_sat(uw * twf), d.width - 1), ty = min(f2u_sat(vw * thf), d.height - 1);
+                taA = cA ? d.offset + ty * d.width + tx : d.offset;
+            }
+            {
+                const float x3 = f(b1q.x), y3 = f(b1q.y), inv = f(b1q.z);
+                const float ea0 = f(b0q.w) - y3, eb0 = x3 - f(b0q.z), ea1 = y3 - f(b0q.y), eb1 = f(b0q.x) - x3;
+                const float dx = fx - x3, dy = (float)pyB - y3;
+                const float w0 = ea0 * dx + eb0 * dy, w1 = ea1 * dx + eb1 * dy;
+                bB[0] = w0 * inv; bB[1] = w1 * inv; bB[2] = 1.0f - bB[0] - bB[1];
+                const float u = bB[0] * f(b2q.x) + bB[1] * f(b2q.y) + bB[2] * f(b2q.z);
+                const float v = bB[0] * f(b2q.w) + bB[1] * f(b3q.x) + bB[2] * f(b3q.y);
+                const float uw = rem_euclid1(u), vw = rem_euclid1(1.0f - v);
+                const uint32_t tx = min(f2u_sat(uw * twf), d.width - 1), ty = min(f2u_sat(vw * thf), d.height - 1);
+                taB = cB ? d.offset + ty * d.width + tx : d.offset;
+            }
+            const uint32_t fetA = a.texels[taA], fetB = a.texels[taB];              // both fetches in flight
+            // texture slot 0xFFFF = untextured: Color15::WHITE (render.rs:1585); then the transparency rule (render.rs:1591-1608)
+            const bool noneA = ((a1q.w >> 24) | ((a3q.z >> 24) << 8)) == F_TEX_NONE, noneB = ((b1q.w >> 24) | ((b3q.z >> 24) << 8)) == F_TEX_NONE;
+            uint32_t cA15 = noneA ? K::C15_WHITE : fetA, cB15 = noneB ? K::C15_WHITE : fetB;
+            const bool btA = (shA & SH_BLACK_TR) != 0, btB = (shB & SH_BLACK_TR) != 0;
+            const bool skipA = btA && (cA15 & ~K::C15_SEMI_BIT & 0xFFFFu) == 0, skipB = btB && (cB15 & ~K::C15_SEMI_BIT & 0xFFFFu) == 0;     // 0x0000 or black with black_transparent
+            cA15 = cA15 == K::C15_TRANSPARENT ? K::C15_BLACK_DRAWABLE : cA15; cB15 = cB15 == K::C15_TRANSPARENT ? K::C15_BLACK_DRAWABLE : cB15;
+            const bool okA = cA && !skipA, okB = cB && !skipB;
+            const uint32_t vA[3] = { a1q.w & 0xFFFFFFu, a3q.z & 0xFFFFFFu, a3q.w & 0xFFFFFFu }, vB[3] = { b1q.w & 0xFFFFFFu, b3q.z & 0xFFFFFFu, b3q.w & 0xFFFFFFu };
+            uint32_t colA, colB;
+            shade15_pair_rgba(cA15, cB15, bA, bB, vA, vB, (shA & SH_DITHER) ? F_DITHER : 0u, (shB & SH_DITHER) ? F_DITHER : 0u, px, pyA, pyB, colA, colB);
+            if (okA) *outA = colA; else if (!cA && inA && a.clear_on) *outA = a.clear_rgba;
+            if (okB) *outB = colB; else if (!cB && inB && a.clear_on) *outB = a.clear_rgba;
+            mA = __ballot(cA && !okA); mB = __ballot(cB && !okB);
         }
         if (mA | mB) {
 #pragma unroll
@@ -2327,6 +2456,12 @@ static void launch_p64(hipStream_t s, const FillArgs& a_in, uint32_t ntiles, int
         return;
     }
 #endif
+#ifndef B32_CORUN_FORM
+#define B32_CORUN_FORM 0         // the 96-VGPR co-resident form of the plain fill (round 4: four of its waves leave a SIMD room for two waves of the next
+                                 // frame's setup kernel, +2 %).  OFF since round 5: with the straight-line plain shading the register cap costs 31 spilled
+                                 // VGPRs and the pipelined frame 0.140 ms against 0.117 (profiles/r05_corun_form_ab.txt)
+#endif
+#if B32_CORUN_FORM
     if (plain && !wide && a.co_run && !EXACT && !ZMODE && !FMT8) {
         static bool attr_co[64] = {};
         if (first_launch_on_device(attr_co))
@@ -2334,6 +2469,7 @@ static void launch_p64(hipStream_t s, const FillArgs& a_in, uint32_t ntiles, int
         hipLaunchKernelGGL((k_cover<0, false, 512, false, false, true, 2>), g, dim3(512), lds_n, s, a);
         return;
     }
+#endif
     if (plain && !wide) {
         static bool attr_plain[64] = {};
         if (first_launch_on_device(attr_plain))
