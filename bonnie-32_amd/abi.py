@@ -141,6 +141,16 @@ SYMBOLS = [
     ("b32_transparent_counts", C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("b32_set_fragment_counting", C.c_int, [_P, C.c_int]),
     ("b32_build_digest", C.c_char_p, []),
+    ("b32_band_export", C.c_int, [_P, C.c_void_p]),
+    ("b32_band_import", C.c_int, [_P, C.c_void_p, C.c_uint32]),
+    ("b32_band_attach", C.c_int, [_P, _P, C.c_uint32]),
+    ("b32_band_close", C.c_int, [_P]),
+    ("b32_band_publish", C.c_int, [_P, C.c_uint32]),
+    ("b32_band_wait", C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint32]),
+    ("b32_band_release", C.c_int, [_P, C.c_uint32]),
+    ("b32_band_acquire", C.c_int, [_P, C.c_uint32, C.c_uint32]),
+    ("b32_band_status", C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    ("b32_gather_bands_rccl", C.c_int, [_P, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
 ]
 
 _lib = None

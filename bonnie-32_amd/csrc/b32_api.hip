@@ -42,6 +42,7 @@ void b32_destroy(b32_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    band_close_any(c);
     void* ptrs[] = { c->fb_own, c->d_verts, c->d_faces, c->d_texels, c->d_tex, c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->crecs, c->srecs, c->xrecs,
                      c->shades, c->counts, c->block_sums, c->pkeys[0], c->pkeys[1], c->pvals[0], c->pvals[1], c->block_hist, c->ranges,
                      c->d_ctrl, c->d_consts, c->d_lights, c->digit_total, c->partials, c->vis, c->spans, c->tile_mid, c->zbuf,
@@ -126,7 +127,8 @@ static int fb_resize_any(b32_ctx* c, uint32_t w, uint32_t h, bool always_new) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (c->fb_own) HIPCHK(c, hipFree(c->fb_own));
         c->fb_own = nullptr;
-        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->fb_own), px * 4));
+        c->band_sync_own = nullptr;                                          // (the epoch words of an exported framebuffer lived in the old allocation)
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->fb_own), px * 4 + 4096 + FB_TAIL_BYTES));
         c->fb_own_px = px;
     }
     c->fb = c->fb_own;

@@ -65,6 +65,10 @@ struct b32_ctx {
     uint32_t band_y0 = 0, band_y1 = 0; bool band_set = false;
     float* zbuf = nullptr; size_t cap_zbuf = 0; bool zbuf_valid = false;   // Framebuffer::zbuffer; !valid == every entry f32::MAX
 
+    // multi-GPU band exchange (b32_gather.hip): mappings of the root's framebuffer / epoch words (band rank), or the root's own epoch words
+    void* band_fb_ipc = nullptr; uint32_t* band_sync_own = nullptr; uint32_t* band_sync = nullptr;      // (band_sync_own: inside fb_own's tail)
+    uint32_t band_rank = 0; bool band_attached = false;
+
     // resident scene
     B32Vertex* d_verts = nullptr; size_t cap_verts = 0;
     B32Face* d_faces = nullptr; size_t cap_faces = 0;
@@ -264,6 +268,8 @@ constexpr size_t STAGE_BYTES = (size_t)1 << 20, STAGE_CTRL_OFF = STAGE_BYTES - 1
 extern "C" {
 B32_INTERNAL int settle_pending(b32_ctx* c);                                      // b32_api.hip
 B32_INTERNAL int flush_clear(b32_ctx* c);                                         // b32_api.hip
+constexpr size_t FB_TAIL_BYTES = 8192;      // behind the pixels of a library-owned framebuffer: the epoch words of the band exchange (b32_gather.hip)
+B32_INTERNAL void band_close_any(b32_ctx* c);                                    // b32_gather.hip
 B32_INTERNAL void free_alt(b32_ctx* c, FrameSet& a);                              // b32_frame.hip
 B32_INTERNAL int h2d(b32_ctx* c, void* dst, const void* src, size_t bytes);       // b32_scene.hip
 B32_INTERNAL bool stage_ensure(b32_ctx* c);                                       // b32_scene.hip

@@ -10,12 +10,7 @@ import torch
 import torch.distributed as dist
 
 
-def band_rows(height, world_size, rank):
-    """Rows [y0, y1) owned by `rank`: a balanced contiguous partition (sizes differ by at most one row)."""
-    base, extra = divmod(height, world_size)
-    y0 = rank * base + min(rank, extra)
-    y1 = y0 + base + (1 if rank < extra else 0)
-    return y0, y1
+from .bands import band_rows  # noqa: E402,F401  (the row partition, torch-free)
 
 
 def gather_bands(frame: torch.Tensor, width, height, world_size, rank, dst=0, group=None):

@@ -151,6 +151,48 @@ class Context:
         n = self.lib.b32_last_kernel_times(self.h, names, ms, 8)
         return {names[i].decode(): float(ms[i]) for i in range(n)}
 
+    # ---- multi-GPU band exchange behind the C ABI (include/b32raster.h "multi-GPU", b32_gather.hip)
+    BAND_SHARE_BYTES = 96
+
+    def band_export(self) -> bytes:
+        """b32_band_export (root): the 96-byte share of this context's library-owned framebuffer + epoch words, for the other ranks."""
+        buf = C.create_string_buffer(self.BAND_SHARE_BYTES)
+        _chk(self.lib.b32_band_export(self.h, C.cast(buf, C.c_void_p)), "b32_band_export")
+        return buf.raw
+
+    def band_import(self, share: bytes, rank):
+        """b32_band_import (band rank, another process): map the root's framebuffer and draw into it; returns (width, height)."""
+        assert len(share) == self.BAND_SHARE_BYTES
+        buf = C.create_string_buffer(share, self.BAND_SHARE_BYTES)
+        rc = self.lib.b32_band_import(self.h, C.cast(buf, C.c_void_p), int(rank))
+        _chk(rc, f"b32_band_import (hip error {self.lib.b32_last_hip_error(self.h)})" if rc else "b32_band_import")
+        w, h = np.frombuffer(share, np.uint32, 2, 64)
+        return int(w), int(h)
+
+    def band_attach(self, root: "Context", rank):
+        _chk(self.lib.b32_band_attach(self.h, root.h, int(rank)), "b32_band_attach")
+
+    def band_close(self):
+        _chk(self.lib.b32_band_close(self.h), "b32_band_close")
+
+    def band_publish(self, frame_no):
+        _chk(self.lib.b32_band_publish(self.h, int(frame_no)), "b32_band_publish")
+
+    def band_wait(self, rank, frame_no, timeout_us=2_000_000):
+        _chk(self.lib.b32_band_wait(self.h, int(rank), int(frame_no), int(timeout_us)), "b32_band_wait")
+
+    def band_release(self, frame_no):
+        _chk(self.lib.b32_band_release(self.h, int(frame_no)), "b32_band_release")
+
+    def band_acquire(self, frame_no, timeout_us=2_000_000):
+        _chk(self.lib.b32_band_acquire(self.h, int(frame_no), int(timeout_us)), "b32_band_acquire")
+
+    def band_status(self):
+        """b32_band_status: (published frame per rank [64], released frame of the root, waits that timed out)."""
+        ep = (C.c_uint32 * 64)(); root = C.c_uint32(); to = C.c_uint32()
+        _chk(self.lib.b32_band_status(self.h, ep, C.byref(root), C.byref(to)), "b32_band_status")
+        return list(ep), int(root.value), int(to.value)
+
     # ---- stage taps -----------------------------------------------------------------
     def project_fixed_batch(self, pos, camera: T.Camera, width, height):
         pos = np.ascontiguousarray(pos, dtype=np.float32).reshape(-1, 3)

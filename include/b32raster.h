@@ -426,6 +426,58 @@ int b32_set_pipeline_depth(b32_ctx* ctx, uint32_t sets);
  * sort (identical framebuffer, see b32_fill.hip).  on = 1: every fragment is evaluated and counted exactly (painter's mode). */
 int b32_set_fragment_counting(b32_ctx* ctx, int on);
 
+/* ---- multi-GPU: the exchange step of a band-sharded frame (BASELINE config C4) ------------------------------------------------------
+ * No reference counterpart: the reference draws on one CPU thread; its presenter reads `fb.pixels` of ONE process
+ * (game/renderer.rs:179-214), so with the frame sharded by rows (b32_set_band, one rank per GPU) every band must end up in the ROOT
+ * rank's framebuffer.  Two transports:
+ *
+ * (1) Shared framebuffer.  The root exports its library-owned framebuffer; a band rank binds it AS ITS OWN framebuffer -- the fill
+ *     kernel of a band rank only writes the rows of its band, so they land directly in the root's HBM (over xGMI between two GPUs):
+ *     no copy, no gather launch.  What remains is ordering, carried by one epoch word per rank behind the pixels of the same allocation:
+ *
+ *         root, once:      b32_fb_new(root, w, h);  b32_band_export(root, &share);           -> hand `share` (96 bytes) to every rank
+ *         rank r, once:    b32_band_import(ctx, &share, r)      (another process)   or   b32_band_attach(ctx, root, r)   (same process)
+ *                          b32_set_band(ctx, y0_r, y1_r);       b32_scene_upload...(ctx, ...)
+ *         rank r, frame n: [b32_band_acquire(ctx, n - 1, us)]   b32_fb_clear(ctx, ...); b32_render_scene_15_async(ctx, ...);
+ *                          b32_band_publish(ctx, n)
+ *         root,  frame n:  b32_set_band(root, y0_0, y1_0) once; b32_fb_clear; b32_render_scene_15_async(root, ...);
+ *                          b32_band_wait(root, r, n, us) for every r;   ... present / b32_fb_download ...;   [b32_band_release(root, n)]
+ *
+ *     Everything is enqueued on the contexts' streams; no call blocks the host.  publish(n) takes effect behind every kernel the rank
+ *     enqueued before it; wait(r, n) holds the ROOT's stream until rank r has published a frame number >= n (wrap-safe compare) or
+ *     timeout_us has passed -- a timeout is counted in b32_band_status, never silent.  release / acquire are the same in the other
+ *     direction (the root has consumed frame n: a rank may overwrite its rows); a host that presents every frame before the ranks
+ *     start the next one (e.g. behind its own barrier) does not need them.  Frame numbers start at 1 (the words start at 0).
+ *     b32_frame_finish on a band rank still reports that rank's errors and counters; triangles_drawn is the whole mesh's on every rank.
+ *     A band rank must not call b32_fb_clear* / sky / present functions outside its band: those honour b32_set_band like the draw.
+ *
+ * (2) RCCL.  b32_gather_bands_rccl: every rank draws into its OWN framebuffer and the rows travel by ncclSend / ncclRecv (grouped, on the
+ *     context's stream) to `root`.  `nccl_comm` is the caller's ncclComm_t; librccl.so is loaded on first use (B32_E_UNSUPPORTED when
+ *     it is not there).  y0 / y1: the band of every rank, the same arrays on every rank.
+ *
+ * Status: transport (1) is exercised by real processes sharing ONE GPU (tests: test_band_ranks_share_one_gpu[*-ipc]) and by the C++
+ * harness inside one process; peer mappings between two GPUs and transport (2) are compiled and argument-checked but have not run. */
+typedef struct B32BandShare {
+    unsigned char mem[64];      /* HIP IPC handle of the root's framebuffer allocation (the epoch words sit in its tail) */
+    uint32_t width, height;     /* the root's framebuffer */
+    uint32_t device;            /* the root's HIP device ordinal (informational) */
+    uint32_t reserved;
+    uint64_t sync_offset;       /* byte offset of the epoch words inside the allocation */
+    uint64_t reserved2;
+} B32BandShare;
+int b32_band_export(b32_ctx* root, B32BandShare* out);                        /* root; its framebuffer must be library-owned (b32_fb_new / _resize) */
+int b32_band_import(b32_ctx* ctx, const B32BandShare* share, uint32_t rank);  /* band rank 1..63 in ANOTHER process: map + bind the root's framebuffer */
+int b32_band_attach(b32_ctx* ctx, b32_ctx* root, uint32_t rank);              /* the same inside one process (one process driving several contexts / GPUs) */
+int b32_band_close(b32_ctx* ctx);                                             /* unmap / unbind (also done by b32_destroy) */
+int b32_band_publish(b32_ctx* ctx, uint32_t frame_no);                        /* band rank: "my rows of frame_no are complete", in stream order */
+int b32_band_wait(b32_ctx* root, uint32_t rank, uint32_t frame_no, uint32_t timeout_us);   /* root: hold the stream until rank published >= frame_no */
+int b32_band_release(b32_ctx* root, uint32_t frame_no);                       /* root: "frame_no has been consumed", in stream order */
+int b32_band_acquire(b32_ctx* ctx, uint32_t frame_no, uint32_t timeout_us);   /* band rank: hold the stream until the root released >= frame_no */
+/* Host-side view of the epoch words (a blocking 4-KB copy): epochs[64] (nullable) = last published frame per rank, *root_epoch
+ * (nullable) = last released frame, *timeouts (nullable) = waits that gave up since the export. */
+int b32_band_status(b32_ctx* ctx, uint32_t* epochs, uint32_t* root_epoch, uint32_t* timeouts);
+int b32_gather_bands_rccl(b32_ctx* ctx, void* nccl_comm, int rank, int nranks, int root, const uint32_t* y0, const uint32_t* y1);
+
 #ifdef __cplusplus
 }
 #endif

@@ -622,6 +622,74 @@ def test_band_ranks_share_one_gpu(world):
     assert r.returncode == 0 and "BAND_WORKER_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
 
 
+@pytest.mark.parametrize("world,mode", [(2, "poll"), (8, "poll"), (8, "acquire")])
+def test_band_ranks_share_one_gpu_through_the_c_abi(world, mode, oracle, tmp_path):
+    """Config C4's exchange step behind the C boundary (include/b32raster.h "multi-GPU", b32_gather.hip), transport "shared framebuffer":
+    this process is the root -- it owns the 2560x1920 framebuffer, exports it (b32_band_export), draws band 0 and makes its stream wait
+    for the other ranks' epoch words (b32_band_wait); world - 1 worker PROCESSES (tests/band_worker_ipc.py: ctypes + numpy only, no
+    torch) map the framebuffer (b32_band_import), draw their bands straight into it and publish every frame (b32_band_publish).  Six
+    frames alternating between two scenes (a stale band would show), each compared with the CPU oracle's whole frame.  mode "poll": the
+    workers read the root's release word from the host before the next frame; mode "acquire": they never touch the host between frames
+    -- release / acquire order the frames on the device.  All ranks share GPU 0 (what is left untested is a peer mapping between two
+    GPUs)."""
+    import subprocess
+    import sys
+    from bonnie32_amd import rasterizer as R
+    from bonnie32_amd.bands import band_rows
+    W, H, NA, NB, FRAMES = 2560, 1920, 100_000, 60_000, 6
+    scs = [scenegen.make_scene("C3", n_tris=n, width=W, height=H) for n in (NA, NB)]
+    want = []
+    for sc in scs:
+        ofb = oracle.Framebuffer(W, H); ofb.clear(sc.clear_color)
+        rc, otm = oracle.render_mesh_15(ofb, sc.vertices, sc.faces, sc.textures, sc.camera, sc.settings, sc.fog, fast=True)
+        assert rc == 0
+        want.append((ofb.pixels.copy(), otm.triangles_drawn))
+    ctx = R.Context(0)
+    ctx.set_async_depth(1)
+    fb = R.Framebuffer(W, H, ctx)
+    share = ctx.band_export()
+    sf = tmp_path / "share.bin"
+    sf.write_bytes(share)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, "tests", "band_worker_ipc.py"), str(sf), str(r), str(world), str(NA), str(NB), str(FRAMES)] +
+                              (["acquire"] if mode == "acquire" else []), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+             for r in range(1, world)]
+    try:
+        y0, y1 = band_rows(H, world, 0)
+        fb.set_band(y0, y1)
+        res = [R.ResidentScene(fb, sc.vertices, sc.faces, indexed_textures=sc.indexed_textures).detach() for sc in scs]
+        for f in range(1, FRAMES + 1):
+            sc, rs = scs[f % 2], res[f % 2]
+            fb.clear(sc.clear_color)
+            rs.render_async(sc.camera, sc.settings, sc.fog)
+            for r in range(1, world):
+                ctx.band_wait(r, f, 60_000_000)
+            got = fb.pixels                                  # (b32_fb_download: behind this context's own band AND the waits on its stream)
+            exp, drawn = want[f % 2]
+            assert np.array_equal(got, exp), f"frame {f}: {int((got != exp).sum())} bytes differ (world={world}, mode={mode})"
+            ctx.band_release(f)
+        ctx.synchronize()
+        epochs, released, timeouts = ctx.band_status()
+        assert timeouts == 0 and released == FRAMES and all(e == FRAMES for e in epochs[1:world]), (epochs[:world], released, timeouts)
+        for p in procs:
+            out, err = p.communicate(timeout=120)
+            assert p.returncode == 0 and "BAND_IPC_WORKER_OK" in out, (out[-1500:], err[-3000:])
+    except AssertionError as e:
+        logs = []
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+            out, err = p.communicate()
+            logs.append((p.returncode, out[-600:], err[-1500:]))
+        raise AssertionError(f"{e}\nworkers: {logs}\nstatus: {ctx.band_status()[0][:world]}")
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        ctx.close()
+
+
 def _console_meshes(n_meshes, seed0, blend_every=4):
     rng = np.random.default_rng(seed0)
     meshes = []
@@ -1439,6 +1507,31 @@ def test_more_tiles_than_the_span_histogram_holds(gpu_ctx, oracle, counting):
                 assert tm.fragments == etm.fragments
         finally:
             gpu_ctx.set_fragment_counting(1)
+
+
+@pytest.mark.parametrize("name,ranks", [("C3:100k", 4), ("C1:zbuf", 3), ("C1:blend5", 2)])
+def test_cpp_host_drives_band_ranks_through_the_c_abi(tmp_path, name, ranks):
+    """tests/cpp/band_harness.cpp: compiled host code (g++, no Python, no torch) drives `ranks` contexts of ONE process through the C ABI
+    -- b32_band_attach, b32_set_band, b32_band_publish / _wait / _release / _acquire -- over three frames; the root's framebuffer must
+    carry the golden hash of the scene.  (Painter's frames, a z-buffer frame -- every rank keeps the depth rows of its band -- and a frame
+    with a transparent pass.)"""
+    import subprocess
+    from bonnie32_amd import scenefile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "band_harness"
+    lib_dir = os.path.join(root, "bonnie-32_amd", "csrc")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(root, "bonnie-32_amd", "host"), "-I", os.path.join(root, "include"),
+                    os.path.join(root, "tests", "cpp", "band_harness.cpp"), "-o", str(exe), "-L", lib_dir, "-lb32raster",
+                    f"-Wl,-rpath,{lib_dir}"], check=True)
+    H = json.load(open(os.path.join(GOLD, "hashes.json")))
+    sc = SCENES[name]()
+    path = str(tmp_path / "s.b32scene")
+    scenefile.write_scene(path, sc)
+    out = tmp_path / "out.rgba"
+    r = subprocess.run([str(exe), path, str(out), str(ranks), "3"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    assert f"triangles_drawn {H[name]['triangles_drawn']}" in r.stdout and "timeouts 0" in r.stdout, r.stdout
+    assert hashlib.sha256(out.read_bytes()).hexdigest() == H[name]["sha256"], name
 
 
 def test_cpp_host_mirror_renders_scene_files(tmp_path):
