@@ -268,6 +268,21 @@ __device__ __forceinline__ float rem_euclid1(float x) {
     return r < 0.0f ? r + 1.0f : r;
 }
 
+// 1.0f / x, correctly rounded, in three instructions where that is provable: v_rcp_f32 is accurate to 1 ulp, and one residual correction
+// r + r * (1 - x r), both steps fused, then IS the correctly rounded reciprocal (Markstein) -- checked on the device against `/` for EVERY
+// one of the 2^32 operands (b32_selftest_f32 ops 9 / 10, tests/test_gpu_parity.py::test_device_f32_semantics).  Operands whose reciprocal or
+// residual could leave the normal range (exponent field outside [RCP_EXP_LO, RCP_EXP_HI]: zeros, denormals, infinities, NaNs, the largest
+// and smallest binades) take the compiler's division sequence (11 instructions).  The fill's z-buffer coverage computes one such
+// reciprocal per fragment (render.rs:1546-1550).
+constexpr uint32_t RCP_EXP_LO = 3, RCP_EXP_HI = 250;
+__device__ __forceinline__ float rcp_exact(float x) {
+    const uint32_t ex = (__float_as_uint(x) >> 23) & 255u;
+    const float r = __builtin_amdgcn_rcpf(x);
+    const float e = __builtin_fmaf(-x, r, 1.0f);
+    const float q = __builtin_fmaf(e, r, r);
+    return (ex >= RCP_EXP_LO && ex <= RCP_EXP_HI) ? q : 1.0f / x;
+}
+
 // total order on non-NaN f32 as u32 (z-buffer keys for the 64-bit LDS atomicMin) and its inverse
 // -0.0 and +0.0 get ONE key (the reference's `z < zbuffer` sees them as equal, so the first fragment in order keeps the pixel);
 // a stored depth that decodes to zero has its sign recomputed from the winning surface (exact_depth_at).

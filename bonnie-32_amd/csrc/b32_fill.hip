@@ -419,7 +419,7 @@ __device__ __forceinline__ void commit_fragment(uint32_t* tilebuf, uint32_t addr
 // Depth of a fragment (render.rs:1546-1550) -> sortable key; false for NaN (never passes `z < zbuffer`).
 __device__ __forceinline__ bool frag_zkey(const Tri& t, float bcx, float bcy, float bcz, uint32_t& zkey) {
     const float inv_z = bcx * t.iz1 + bcy * t.iz2 + bcz * t.iz3;
-    const float z = 1.0f / inv_z;
+    const float z = rcp_exact(inv_z);
     zkey = zsort_key(z);
     return z == z;
 }
@@ -440,7 +440,7 @@ __device__ float exact_depth_at(const FillArgs& a, uint32_t sid, uint32_t px, ui
     edge_w(tr, px, py, w0, w1);
     (void)inside_bc(tr, w0, w1, bcx, bcy, bcz);
     const float inv_z = bcx * __uint_as_float(q5.y) + bcy * __uint_as_float(q5.z) + bcz * __uint_as_float(q5.w);
-    return 1.0f / inv_z;
+    return rcp_exact(inv_z);
 }
 
 // Phase A for one surface: coverage of the (tile-clipped) bbox [cx0,cx1) x [cy0,cy1), winner value li.
@@ -684,7 +684,7 @@ __device__ __forceinline__ void cheap_trip(unsigned long long* top, unsigned lon
         old[j] = 0; Pj[j] = P;
         if (ZMODE) {                            // fragment depth (render.rs:1546-1550); NaN never passes `z < zbuffer`
             const float inv_z = cx * z1 + cy * z2 + cz * z3;
-            const float z = 1.0f / inv_z;
+            const float z = rcp_exact(inv_z);
             in[j] = in[j] & (z == z);
             Pj[j] = ((unsigned long long)(~zsort_key(z)) << 32) | (uint32_t)P;
         }
@@ -1268,7 +1268,7 @@ __device__ __forceinline__ void shade_tile_p64(const FillArgs& a, const uint32_t
                                                uint32_t y_lo, uint32_t y_hi, uint32_t ty_top, uint32_t tid, uint32_t lane, uint32_t TH, uint32_t* rq,
                                                const uint8_t* latlas);
 
-template <int NT>
+template <int NT, bool ZMODE>
 __device__ __forceinline__ void shade_tile_plain(const FillArgs& a, const uint32_t* tilebuf, uint32_t e0, uint32_t e1, uint32_t x_lo, uint32_t x_hi,
                                                  uint32_t y_lo, uint32_t y_hi, uint32_t ty_top, uint32_t tid, uint32_t lane, uint32_t TH, uint32_t* wq);
 
@@ -1565,7 +1565,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PLAIN == 2 ?
 #endif
             if (n_op) {
                 // (the plain form's straight-line shading: one texture of non-zero size fetched from global memory)
-                if (PLAIN && !FMT8 && !ZMODE && !latlas && a.tex0.width && a.tex0.height) shade_tile_plain<NT>(a, tilebuf, e0, e1, x_lo, x_hi, y_lo, y_hi, ty_top, tid, lane, TH, wmarks + wave * 64);
+                // (the straight-line shading: RGB555, affine UVs, fixed-point snap, perspective camera, one texture of non-zero size fetched
+                // from global memory -- painter's or z-buffer mode, with or without a shading pass; wave-uniform choice)
+                if (!FMT8 && fp.affine && fp.fixed_point && !fp.ortho && fp.nt == 1 && !latlas && a.tex0.width && a.tex0.height &&
+                    (fp.shading == B32_SHADE_NONE || a.shades))
+                    shade_tile_plain<NT, ZMODE>(a, tilebuf, e0, e1, x_lo, x_hi, y_lo, y_hi, ty_top, tid, lane, TH, wmarks + wave * 64);
                 else shade_tile_p64<FMT8, NT, ZMODE>(a, tilebuf, e0, e1, x_lo, x_hi, y_lo, y_hi, ty_top, tid, lane, TH, wmarks + wave * 64, latlas);
             }
             else if (a.clear_on) {      // nothing reaches this tile: it still gets the frame's clear colour
@@ -1747,7 +1751,7 @@ __device__ __forceinline__ uint32_t fetch_texel(const FillArgs& a, int taddr) {
 __device__ __forceinline__ bool depth_prio(const FillArgs& a, uint32_t sid, const Hit& h, unsigned long long& P) {
     const uint4 x0 = reinterpret_cast<const uint4*>(a.xrecs + sid)[0];             // iz1, iz2, iz3
     const float inv_z = h.bcx * __uint_as_float(x0.x) + h.bcy * __uint_as_float(x0.y) + h.bcz * __uint_as_float(x0.z);
-    const float z = 1.0f / inv_z;
+    const float z = rcp_exact(inv_z);
     P = ((unsigned long long)(~zsort_key(z)) << 32) | (0xFFFFFFFEu - sid);
     return z == z;
 }
@@ -1895,28 +1899,44 @@ __device__ __forceinline__ void shade_tile_p64(const FillArgs& a, const uint32_t
     if (lqn) drain();
 }
 
-// The shading phase of the PLAIN form (the benchmark's settings: affine UVs, no shading pass, fixed-point snap, one texture fetched from
-// global memory, painter's mode, RGB555), written straight-line: the general shade_tile_p64 reaches the same arithmetic through
+// The straight-line shading phase (RGB555, affine UVs, fixed-point snap, perspective camera, ONE texture fetched from global memory;
+// painter's or z-buffer mode; with or without a shading pass): the general shade_tile_p64 reaches the same arithmetic through
 // hit_prepare / hit_finish / colour, whose per-pixel branches (texture present?, zero-sized?, literal replay?, inside?) cost the
-// plain instantiation ~90 branches and ~470 VALU instructions per two-pixel step.  Here every lane runs the one path -- record view,
-// edge values in closed form, barycentrics, UVs, texel address (render.rs:1507-1583, types.rs:671-681), both texel fetches in flight, texel
-// rule (render.rs:1591-1608), packed colour pipeline -- on whatever its two pixels hold (an uncovered pixel computes on surface 0's
-// record and stores nothing of it).  The winner of a covered pixel passed the inside test during coverage (same arithmetic, or the
-// span form proven equal to it), so it is not evaluated again.  A step in which some winner must replay the edge walk literally
-// (SH_SLOW) takes the general per-pixel functions; skipped winners go to the wave's repair queue as in the general form.
-template <int NT>
+// benchmark's instantiation ~90 branches and ~470 VALU instructions per two-pixel step.  Here every lane runs the one path -- record
+// view, edge values in closed form, barycentrics, UVs, texel address (render.rs:1507-1583, types.rs:671-681), both texel fetches in flight,
+// texel rule (render.rs:1591-1608), colour pipeline -- on whatever its two pixels hold (an uncovered pixel computes on surface 0's record
+// and stores nothing of it).  The winner of a covered pixel passed the inside test during coverage (same arithmetic, or the span form
+// proven equal to it), so it is not evaluated again.  A step in which some winner must replay the edge walk literally (SH_SLOW) takes
+// the general per-pixel functions; skipped winners go to the wave's repair queue as in the general form.
+template <int NT, bool ZMODE>
 __device__ __forceinline__ void shade_tile_plain(const FillArgs& a, const uint32_t* tilebuf, uint32_t e0, uint32_t e1, uint32_t x_lo, uint32_t x_hi,
                                                  uint32_t y_lo, uint32_t y_hi, uint32_t ty_top, uint32_t tid, uint32_t lane, uint32_t TH, uint32_t* wq) {
     const FrameParams& fp = a.fp;
     const unsigned long long* top = reinterpret_cast<const unsigned long long*>(tilebuf);
     const unsigned long long* sec = top + TILE_H * STR64;
     const uint32_t W = fp.width;
+    const int shading = fp.shading;
     constexpr uint32_t ROWS_PER_STEP = NT / 64;
     const TexDesc d = a.tex0;
     const float twf = (float)d.width, thf = (float)d.height;
     const uint32_t col = tid & 63, px = x_lo + col;
     const float fx = (float)px;
     const bool in_x = px < x_hi;
+    const float ZMAX = __uint_as_float(0x7F7FFFFFu);
+    // z-buffer mode: a winner exists when the low word is not the seed's all-ones; its face id is 0xFFFFFFFE - low word
+    auto covered = [](unsigned long long t) { return ZMODE ? ((uint32_t)t != 0xFFFFFFFFu) : (t != 0ull); };
+    auto sid_of = [](unsigned long long t) { return ZMODE ? 0xFFFFFFFEu - (uint32_t)t : (uint32_t)t; };
+    // a pixel nobody draws inside the band: the folded Framebuffer::clear (colour, and depth in z-buffer mode)
+    auto leave = [&](uint32_t py) {
+        if (a.clear_on) a.fb[(size_t)py * W + px] = a.clear_rgba;
+        if (ZMODE && a.clear_depth) a.zbuf[(size_t)py * W + px] = ZMAX;
+    };
+    // fb.zbuffer[idx] = z of the winner (render.rs:1686-1688); a key that decodes to zero does not carry the sign: recomputed
+    auto store_depth = [&](unsigned long long t, uint32_t sid, uint32_t py) {
+        float z = zsort_val(~(uint32_t)(t >> 32));
+        if (z == 0.0f) z = exact_depth_at(a, sid, px, py);
+        a.zbuf[(size_t)py * W + px] = z;
+    };
     uint32_t lqn = 0;                                   // entries in this wave's repair queue (wave-uniform)
     auto drain = [&]() {
         const bool act = lane < lqn;
@@ -1924,10 +1944,15 @@ __device__ __forceinline__ void shade_tile_plain(const FillArgs& a, const uint32
         const uint32_t row = e >> 6, c = e & 63u, qx = x_lo + c, qy = ty_top + row;
         bool ok = false; Hit h; h.sid = 0;
         unsigned long long t = 0;
-        repair_pixel<false, false>(a, sec, act, row, c, qx, qy, e0, e1, lane, ok, h, t);
+        repair_pixel<false, ZMODE>(a, sec, act, row, c, qx, qy, e0, e1, lane, ok, h, t);
         if (act) {
-            if (ok) a.fb[(size_t)qy * W + qx] = colour<false>(a, h, B32_SHADE_NONE, qx, qy);
-            else if (a.clear_on) a.fb[(size_t)qy * W + qx] = a.clear_rgba;
+            if (ok) {
+                a.fb[(size_t)qy * W + qx] = colour<false>(a, h, shading, qx, qy);
+                if (ZMODE) { float z = zsort_val(~(uint32_t)(t >> 32)); if (z == 0.0f) z = exact_depth_at(a, h.sid, qx, qy); a.zbuf[(size_t)qy * W + qx] = z; }
+            } else {
+                if (a.clear_on) a.fb[(size_t)qy * W + qx] = a.clear_rgba;
+                if (ZMODE && a.clear_depth) a.zbuf[(size_t)qy * W + qx] = ZMAX;
+            }
         }
         lqn = 0;
     };
@@ -1937,16 +1962,18 @@ __device__ __forceinline__ void shade_tile_plain(const FillArgs& a, const uint32
         const uint32_t rowA = r0 + (tid >> 6), rowB = rowA + ROWS_PER_STEP;
         const uint32_t pyA = ty_top + rowA, pyB = ty_top + rowB;
         const bool inA = rowA < TH && in_x && pyA >= y_lo && pyA < y_hi, inB = rowB < TH && in_x && pyB >= y_lo && pyB < y_hi;
-        const unsigned long long tA = inA ? top[rowA * STR64 + col] : 0ull, tB = inB ? top[rowB * STR64 + col] : 0ull;
-        const bool cA = tA != 0ull, cB = tB != 0ull;
+        const unsigned long long tA = inA ? top[rowA * STR64 + col] : (ZMODE ? ~0ull : 0ull), tB = inB ? top[rowB * STR64 + col] : (ZMODE ? ~0ull : 0ull);
+        const bool cA = covered(tA), cB = covered(tB);
         uint32_t* outA = a.fb + (size_t)pyA * W + px;
         uint32_t* outB = a.fb + (size_t)pyB * W + px;
         if (!__ballot(cA || cB)) {
-            if (a.clear_on) { if (inA) *outA = a.clear_rgba; if (inB) *outB = a.clear_rgba; }
+            if (inA) leave(pyA);
+            if (inB) leave(pyB);
             continue;
         }
-        const uint4* spA = reinterpret_cast<const uint4*>(a.srecs + (uint32_t)tA);      // (surface 0's record for an uncovered pixel: read, never used)
-        const uint4* spB = reinterpret_cast<const uint4*>(a.srecs + (uint32_t)tB);
+        const uint32_t sidA = cA ? sid_of(tA) : 0u, sidB = cB ? sid_of(tB) : 0u;      // (surface 0's record for an uncovered pixel: read, never used)
+        const uint4* spA = reinterpret_cast<const uint4*>(a.srecs + sidA);
+        const uint4* spB = reinterpret_cast<const uint4*>(a.srecs + sidB);
         const uint4 a0q = spA[0], a1q = spA[1], a2q = spA[2], a3q = spA[3];
         const uint4 b0q = spB[0], b1q = spB[1], b2q = spB[2], b3q = spB[3];
         const uint32_t shA = a3q.w >> 24, shB = b3q.w >> 24;
@@ -1954,10 +1981,10 @@ __device__ __forceinline__ void shade_tile_plain(const FillArgs& a, const uint32
         if (__ballot((cA && (shA & SH_SLOW)) || (cB && (shB & SH_SLOW)))) {
             // rare: a winner whose edge walk is replayed literally -- the general per-pixel functions for this step
             Hit hA, hB;
-            const bool okA = cA && hit_test<false>(a, (uint32_t)tA, px, pyA, hA);
-            const bool okB = cB && hit_test<false>(a, (uint32_t)tB, px, pyB, hB);
-            if (okA) *outA = colour<false>(a, hA, B32_SHADE_NONE, px, pyA); else if (!cA && inA && a.clear_on) *outA = a.clear_rgba;
-            if (okB) *outB = colour<false>(a, hB, B32_SHADE_NONE, px, pyB); else if (!cB && inB && a.clear_on) *outB = a.clear_rgba;
+            const bool okA = cA && hit_test<false>(a, sidA, px, pyA, hA);
+            const bool okB = cB && hit_test<false>(a, sidB, px, pyB, hB);
+            if (okA) { *outA = colour<false>(a, hA, shading, px, pyA); if (ZMODE) store_depth(tA, sidA, pyA); } else if (!cA && inA) leave(pyA);
+            if (okB) { *outB = colour<false>(a, hB, shading, px, pyB); if (ZMODE) store_depth(tB, sidB, pyB); } else if (!cB && inB) leave(pyB);
             mA = __ballot(cA && !okA); mB = __ballot(cB && !okB);
         } else {
             float bA[3], bB[3];
@@ -1995,10 +2022,19 @@ __device__ __forceinline__ void shade_tile_plain(const FillArgs& a, const uint32
             cA15 = cA15 == K::C15_TRANSPARENT ? K::C15_BLACK_DRAWABLE : cA15; cB15 = cB15 == K::C15_TRANSPARENT ? K::C15_BLACK_DRAWABLE : cB15;
             const bool okA = cA && !skipA, okB = cB && !skipB;
             const uint32_t vA[3] = { a1q.w & 0xFFFFFFu, a3q.z & 0xFFFFFFu, a3q.w & 0xFFFFFFu }, vB[3] = { b1q.w & 0xFFFFFFu, b3q.z & 0xFFFFFFu, b3q.w & 0xFFFFFFu };
+            const uint32_t flA = (shA & SH_DITHER) ? F_DITHER : 0u, flB = (shB & SH_DITHER) ? F_DITHER : 0u;
             uint32_t colA, colB;
-            shade15_pair_rgba(cA15, cB15, bA, bB, vA, vB, (shA & SH_DITHER) ? F_DITHER : 0u, (shB & SH_DITHER) ? F_DITHER : 0u, px, pyA, pyB, colA, colB);
-            if (okA) *outA = colA; else if (!cA && inA && a.clear_on) *outA = a.clear_rgba;
-            if (okB) *outB = colB; else if (!cB && inB && a.clear_on) *outB = a.clear_rgba;
+            if (shading == B32_SHADE_NONE) {
+                shade15_pair_rgba(cA15, cB15, bA, bB, vA, vB, flA, flB, px, pyA, pyB, colA, colB);
+            } else {          // flat / Gouraud: the surface's nine vertex shades (render.rs:1629-1645)
+                float sA[9], sB[9];
+#pragma unroll
+                for (int j = 0; j < 9; ++j) { sA[j] = a.shades[(size_t)sidA * 9 + j]; sB[j] = a.shades[(size_t)sidB * 9 + j]; }
+                colA = shade15<true>(cA15, bA[0], bA[1], bA[2], vA[0], vA[1], vA[2], flA, shading, sA, px, pyA);
+                colB = shade15<true>(cB15, bB[0], bB[1], bB[2], vB[0], vB[1], vB[2], flB, shading, sB, px, pyB);
+            }
+            if (okA) { *outA = colA; if (ZMODE) store_depth(tA, sidA, pyA); } else if (!cA && inA) leave(pyA);
+            if (okB) { *outB = colB; if (ZMODE) store_depth(tB, sidB, pyB); } else if (!cB && inB) leave(pyB);
             mA = __ballot(cA && !okA); mB = __ballot(cB && !okB);
         }
         if (mA | mB) {
@@ -2091,7 +2127,7 @@ __global__ __launch_bounds__(256) void k_shade(FillArgs a) {
 __device__ __forceinline__ bool ztest(const Tri& t, float bcx, float bcy, float bcz, int zmode, float zb) {
     if (!zmode) return true;
     const float inv_z = bcx * t.iz1 + bcy * t.iz2 + bcz * t.iz3;
-    const float z = 1.0f / inv_z;
+    const float z = rcp_exact(inv_z);
     return ((t.flags >> F_ALPHA_SHIFT) < 255) ? !(z >= zb) : (z < zb);
 }
 
@@ -2109,7 +2145,7 @@ __device__ __forceinline__ bool blend_fragment(const FillArgs& a, const Tri& tr,
         float z = 0.0f;
         if (zmode) {
             const float inv_z = bcx * tr.iz1 + bcy * tr.iz2 + bcz * tr.iz3;
-            z = 1.0f / inv_z;
+            z = rcp_exact(inv_z);
             const float zb = *zdst;
             if (alpha < 255 ? (z >= zb) : !(z < zb)) return false;               // render.rs:387 / :432, :1407
         }

@@ -704,6 +704,16 @@ __global__ void k_selftest(int op, const float* a, const float* b, const float* 
             for (float kf = 0.0f; kf <= Nf; kf += 1.0f) bad += __float_as_uint(wire_t_fast(kf, Nf, rN)) != __float_as_uint(kf / Nf);
             r = (float)bad; break;
         }
+        case 9: case 10: {                              // rcp_exact against `/` on the 65536 consecutive bit patterns from a[i]'s: count / first differing pattern
+            const uint32_t base = __float_as_uint(a[i]); uint32_t bad = 0, first = 0;
+            for (uint32_t k = 0; k < 65536u; ++k) {
+                const float x = __uint_as_float(base + k);
+                const uint32_t want = __float_as_uint(1.0f / x), got = __float_as_uint(rcp_exact(x));
+                const bool nan_w = (want & 0x7FFFFFFFu) > 0x7F800000u, nan_g = (got & 0x7FFFFFFFu) > 0x7F800000u;
+                if (nan_w ? !nan_g : want != got) { if (!bad) first = base + k; ++bad; }
+            }
+            r = op == 9 ? (float)bad : __uint_as_float(first); break;
+        }
         default: r = (a[i] + b[i]) / c[i]; break;
     }
     out[i] = r;

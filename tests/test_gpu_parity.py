@@ -75,6 +75,12 @@ def test_device_f32_semantics(gpu_ctx):
     # IEEE division for EVERY pair 0 <= k <= N < 16384 it is used for (134 M quotients; the device counts the differing ones per N)
     N = np.arange(1, 16384, dtype=np.float32)
     assert not gpu_ctx.selftest_f32(8, N, N, N).any()
+    # the z-buffer coverage's reciprocal (render.rs:1550: z = 1.0 / inv_z) by v_rcp_f32 + one fused residual correction (rcp_exact,
+    # b32_device.h): bit-equal to the IEEE division for EVERY f32 operand -- all 2^32 of them, 65536 per lane; NaN results only have to be NaN
+    base = (np.arange(65536, dtype=np.uint64) << 16).astype(np.uint32).view(np.float32)
+    bad = gpu_ctx.selftest_f32(9, base, base, base)
+    first = gpu_ctx.selftest_f32(10, base, base, base).view(np.uint32)
+    assert not bad.any(), [hex(int(v)) for v in first[bad > 0][:8]]
 
 
 def test_device_constants_are_the_reference_text(gpu_ctx):
@@ -1507,6 +1513,43 @@ def test_more_tiles_than_the_span_histogram_holds(gpu_ctx, oracle, counting):
                 assert tm.fragments == etm.fragments
         finally:
             gpu_ctx.set_fragment_counting(1)
+
+
+@pytest.mark.parametrize("shading", [1, 2])
+@pytest.mark.parametrize("zbuffer", [False, True])
+def test_lit_frames_of_large_meshes(gpu_ctx, oracle, shading, zbuffer):
+    """Lit frames of a mesh too large for the in-kernel list collection (100 000 faces at 2560x1920): flat and Gouraud shading
+    (render.rs:1013-1071, 1466-1483), a directional, a point and a spot light, painter's and z-buffer mode, drop-in and resident (packed
+    position / attribute / normal streams from the second frame on), whole frame and a band (surfaces outside the band carry no record
+    and no shades) -- through the straight-line shading phase of the fused kernel.  Frame and triangles_drawn against the oracle."""
+    from bonnie32_amd import rasterizer as R
+    sc = scenegen.make_scene("C3", n_tris=100_000, variant="gouraud", seed=31 + shading)
+    st = copy.copy(sc.settings)
+    st.shading = shading; st.use_zbuffer = zbuffer
+    st.lights = [b32.Light.directional((-1.0, -1.0, -1.0), 0.7), b32.Light.point((200.0, -100.0, 2500.0), 4000.0, 1.3),
+                 b32.Light.spot((0.0, 0.0, 0.0), (0.0, 0.0, 1.0), 0.6, 9000.0, 1.1)]
+    sc.settings = st
+    exp, etm, d = cpu_render(oracle, sc)
+    got, tm = gpu_render(gpu_ctx, sc)
+    assert np.array_equal(got, exp), f"{int((got != exp).sum())} bytes differ (drop-in)"
+    assert tm.triangles_drawn == etm.triangles_drawn
+    fb = R.Framebuffer(sc.width, sc.height, gpu_ctx)
+    rs = R.ResidentScene(fb, sc.vertices, sc.faces, sc.textures)
+    for rep in range(3):                                     # (from the second resident frame on: packed position / attribute / normal streams)
+        fb.clear(sc.clear_color)
+        tm = rs.render(sc.camera, sc.settings, sc.fog)
+        got = fb.pixels
+        assert np.array_equal(got, exp), f"{int((got != exp).sum())} bytes differ (resident, frame {rep})"
+        assert tm.triangles_drawn == etm.triangles_drawn
+    row = sc.width * 4
+    fb.set_band(700, 1300)
+    for rep in range(2):
+        fb.clear(b32.Color(1, 2, 3))
+        fb.clear(sc.clear_color)
+        rs.render(sc.camera, sc.settings, sc.fog)
+    part = fb.pixels
+    assert np.array_equal(part[700 * row:1300 * row], exp[700 * row:1300 * row])
+    fb.set_band(0, sc.height)
 
 
 @pytest.mark.parametrize("name,ranks", [("C3:100k", 4), ("C1:zbuf", 3), ("C1:blend5", 2)])
