@@ -11,7 +11,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["b32_api.hip", "b32_scene.hip", "b32_frame.hip", "b32_batch.hip", "b32_setup.hip", "b32_sort.hip", "b32_bin.hip", "b32_fill.hip", "b32_wire.hip", "b32_sky.hip", "b32_gather.hip"]
+SOURCES = ["b32_api.hip", "b32_scene.hip", "b32_frame.hip", "b32_batch.hip", "b32_setup.hip", "b32_sort.hip", "b32_bin.hip", "b32_fill.hip", "b32_shade.hip", "b32_blend.hip", "b32_wire.hip", "b32_sky.hip", "b32_gather.hip"]
 OUT = os.path.join(CSRC, "libb32raster.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
          "-fno-gpu-flush-denormals-to-zero", "-fhip-fp32-correctly-rounded-divide-sqrt",
