@@ -209,7 +209,7 @@ static int frame_buffers(b32_ctx* c, const FrameParams& fp, bool wire_back) {
             if ((rc = ensure_plain(c, c->wire_first, slots))) return rc;
             c->cap_wire_table = slots;
         }
-        // tile route: one counter and one list region per 64x64 tile of the band (+ the overflow flag and the big-edge count)
+        // tile route: one counter and one list region per 64 x 16 wire tile (WIRE_TH rows) of the band (+ the overflow flag and the big-edge count)
         if (!(c->route_off & B32_ROUTE_WIRE_TILES) && c->band_y1 > c->band_y0) {
             const size_t wt = (size_t)fp.tiles_x * ((c->band_y1 - (c->band_y0 / WIRE_TH) * WIRE_TH + WIRE_TH - 1) / WIRE_TH);
             if (wt > c->cap_wire_tiles || !c->wire_fill) {
@@ -220,7 +220,7 @@ static int frame_buffers(b32_ctx* c, const FrameParams& fp, bool wire_back) {
             // (the counters are zero between frames: k_wire_tile re-zeroes what k_wire_bin counted; a new allocation or another tile grid
             // -- resize, band change -- starts from a cleared array)
             const unsigned long long grid = ((unsigned long long)c->width << 40) ^ ((unsigned long long)c->band_y0 << 20) ^ c->band_y1;
-            if (grid != c->wire_grid || wt > c->cap_wire_tiles) {
+            if (grid != c->wire_grid) {
                 HIPCHK(c, hipMemsetAsync(c->wire_fill, 0, ((c->cap_wire_tiles + 2) * FILL_PAD + 64) * sizeof(uint32_t), s));
                 c->wire_grid = grid;
             }
@@ -466,6 +466,7 @@ int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st, const
     if (c->nf == 0) {                                                             // otherwise k_setup resets it (all but `sticky`)
         HIPCHK(c, hipMemsetAsync(c->d_ctrl, 0, offsetof(Ctrl, sticky), s));
         HIPCHK(c, hipMemsetAsync(&c->d_ctrl->fragments, 0, sizeof(unsigned long long), s));
+        HIPCHK(c, hipMemsetAsync(c->d_ctrl + 1, 0, sizeof(Stamps), s));          // (and the phase clock: b32_last_shader_clock of an empty frame is 0, not the frame before's)
     }
     const float *pos12 = nullptr, *attr12 = nullptr;
     if ((rc = frame_positions(c, fp, pos12, attr12))) return fail(rc);
@@ -477,11 +478,13 @@ int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st, const
         HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_done, 0));     // the last fill that read this set (two frames ago)
         ss = c->side;
         c->pipelined_frames++;
-        if (c->gate_permille && c->last_cover_tiles && c->alt[0].d_ctrl) {
+        uint32_t polled_tiles = 0, polled_groups = 0;       // the fused kernel of the frame whose cursor the gate polls (alt[0]: n_sets - 1 frames back)
+        for (const auto& co : c->cover_of) if (co.ctrl && co.ctrl == c->alt[0].d_ctrl) { polled_tiles = co.tiles; polled_groups = co.groups; }
+        if (c->gate_permille && polled_tiles && c->alt[0].d_ctrl) {
             // The fused kernel's workgroups take their next tile from the cursor after the coverage of the current one: the cursor
             // passes tiles - groups when the last tile is handed out, and every fetch beyond that is a workgroup that found the queue
             // empty and has only the shading of its last tile left, i.e. is about to free its place on a CU.
-            const uint32_t groups = c->last_cover_groups, tiles = c->last_cover_tiles;
+            const uint32_t groups = polled_groups, tiles = polled_tiles;
             const uint32_t pre = tiles > groups ? tiles - groups : 0u;      // cursor value when the last tile is handed out
             const uint32_t need = c->gate_permille > 1000u ? (uint32_t)((uint64_t)(c->gate_permille - 1000u) * pre / 1000u)
                                                            : pre + (uint32_t)((uint64_t)(c->gate_permille - 1u) * groups / 1000u);
@@ -560,6 +563,11 @@ int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st, const
     if (c->side) HIPCHK(c, hipEventRecord(c->ev_done, s));         // (the next setup kernel that writes this set waits for it)
     c->last_cover_tiles = (r.prio64 && !wire_front && !r.ordered_all) ? ntiles : 0u;
     c->last_cover_groups = std::min<uint32_t>(ntiles, (uint32_t)c->n_cu * 2u);
+    {   // remembered per frame set
+        b32_ctx::CoverOf* slot = &c->cover_of[0];
+        for (auto& co : c->cover_of) { if (co.ctrl == c->d_ctrl) { slot = &co; break; } if (!co.ctrl) slot = &co; }
+        *slot = { c->d_ctrl, c->last_cover_tiles, c->last_cover_groups };
+    }
     HIPCHK(c, hipGetLastError());
     return B32_OK;
 }

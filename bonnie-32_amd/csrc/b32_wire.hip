@@ -246,26 +246,49 @@ __global__ void k_wire_bin(WireArgs a, uint32_t kinds) {           // kinds: bit
     if (t.kind == 0 || !((kinds >> (t.kind - 1)) & 1u)) return;
     uint32_t tx0 = 0xFFFFFFFFu, tx1 = 0, ty0 = 0xFFFFFFFFu, ty1 = 0, n_big = 0;
     bool any = false, bad = false;
+    WireBox bx[3]; bool on[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
+        on[j] = false;
         const Edge e = wire_edge(t, j);
         if (edge_overflows(e)) { bad = true; continue; }
-        const WireBox b = wire_box(a, e);
-        if (!b.visible) continue;
-        if (b.big) { ++n_big; continue; }
-        any = true;
-        tx0 = min(tx0, b.tx0); tx1 = max(tx1, b.tx1); ty0 = min(ty0, b.ty0); ty1 = max(ty1, b.ty1);
+        bx[j] = wire_box(a, e);
+        if (!bx[j].visible) continue;
+        if (bx[j].big) { ++n_big; continue; }
+        any = on[j] = true;
+        tx0 = min(tx0, bx[j].tx0); tx1 = max(tx1, bx[j].tx1); ty0 = min(ty0, bx[j].ty0); ty1 = max(ty1, bx[j].ty1);
     }
     if (bad) { atomicOr(&a.ctrl->wire_overflow, 1u); atomicOr(&a.ctrl->sticky, 4u); }
     if (n_big) atomicAdd(wire_flag(a, 1), n_big);
     if (!any) return;
-    for (uint32_t ty = ty0; ty <= ty1; ++ty)
-        for (uint32_t tx = tx0; tx <= tx1; ++tx) {
-            const uint32_t tile = ty * a.tiles_x + tx;
-            const uint32_t pos = atomicAdd(wire_counter(a, tile), 1u);
-            if (pos < WIRE_TILE_CAP) a.tile_lists[(size_t)tile * WIRE_TILE_CAP + pos] = f;
-            else atomicOr(wire_flag(a, 0), 1u);
+    auto append = [&](uint32_t tx, uint32_t ty) {
+        const uint32_t tile = ty * a.tiles_x + tx;
+        const uint32_t pos = atomicAdd(wire_counter(a, tile), 1u);
+        if (pos < WIRE_TILE_CAP) a.tile_lists[(size_t)tile * WIRE_TILE_CAP + pos] = f;
+        else atomicOr(wire_flag(a, 0), 1u);
+    };
+    if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) <= 2u * WIRE_BIG_TILES) {
+        for (uint32_t ty = ty0; ty <= ty1; ++ty)
+            for (uint32_t tx = tx0; tx <= tx1; ++tx) append(tx, ty);
+    } else {
+        // The box AROUND the edges of a face is not bounded by the limit on each edge's own box: a long thin L -- one edge along a tile
+        // row, one along a tile column, the third one big and left to the global kernels -- has a union of up to WIRE_BIG_TILES^2 tiles,
+        // in nearly all of which no edge of the face takes part (4096 serial reservations by one lane, and entries that crowd the 256-entry
+        // lists into overflow).  Such a face is entered box by box instead: every tile of an edge's own box that no earlier edge's box
+        // of the face holds already -- one entry per tile as before, and every edge still finds the face in every tile of its own box.
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            if (!on[j]) continue;
+            for (uint32_t ty = bx[j].ty0; ty <= bx[j].ty1; ++ty)
+                for (uint32_t tx = bx[j].tx0; tx <= bx[j].tx1; ++tx) {
+                    bool dup = false;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+                        if (k < j && on[k] && tx >= bx[k].tx0 && tx <= bx[k].tx1 && ty >= bx[k].ty0 && ty <= bx[k].ty1) dup = true;
+                    if (!dup) append(tx, ty);
+                }
         }
+    }
 }
 
 // One 4-wave workgroup per tile, one lane per list entry (face).  The kernel is latency-bound -- a chain of dependent global loads

@@ -227,7 +227,16 @@ public:
         check(b32_scene_swap(ctx_, slot_), "scene_swap");            // context's scene -> slot, context empty
         const int rc = b32_scene_upload(ctx_, v.data(), (uint32_t)v.size(), f.data(), (uint32_t)f.size(), t.data(), (uint32_t)t.size());
         const int rc2 = b32_scene_swap(ctx_, slot_);                 // mesh -> slot, context's scene back
-        if (rc || rc2) { b32_scene_destroy(ctx_, slot_); slot_ = nullptr; check(rc ? rc : rc2, rc ? "scene_upload" : "scene_swap"); }
+        if (rc2) {
+            // the exchange back failed (a deferred error of an earlier frame surfaced in it): the slot still holds the CONTEXT's own scene
+            // and must not be destroyed with it -- one more attempt (the deferred error has been consumed), then leave the slot alive
+            // (leaked rather than the caller's scene freed) and report
+            const int rc3 = b32_scene_swap(ctx_, slot_);
+            if (rc3 == B32_OK) { b32_scene_destroy(ctx_, slot_); slot_ = nullptr; }
+            else slot_ = nullptr;
+            check(rc2, "scene_swap");
+        }
+        if (rc) { b32_scene_destroy(ctx_, slot_); slot_ = nullptr; check(rc, "scene_upload"); }
     }
     ~ResidentMesh() { if (slot_) b32_scene_destroy(ctx_, slot_); }
     ResidentMesh(const ResidentMesh&) = delete;

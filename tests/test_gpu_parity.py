@@ -1140,11 +1140,12 @@ def test_editor_modes_parity(gpu_ctx, oracle, name, counting):
         gpu_ctx.set_fragment_counting(1)
 
 
-@pytest.mark.parametrize("case", ["small", "medium", "long-lines", "crowded-tile", "overlay", "both-phases", "both-phases-long", "bands", "one-tile", "huge-lines"])
+@pytest.mark.parametrize("case", ["small", "medium", "long-lines", "crowded-tile", "overlay", "both-phases", "both-phases-long", "bands", "one-tile", "huge-lines", "thin-l"])
 def test_wireframe_phases_through_screen_tiles(oracle, case):
     """B32_ROUTE_WIRE_TILES: the edges of the wireframe phases (render.rs:2574-2635) binned to 64x16 tiles, first occurrences found in an
     LDS table per tile, lines walked into an LDS bit plane.  Same frame as the oracle (and as the global kernels, route off):
-      long-lines    triangles of ~2500 px: edges whose box covers more than 16 tiles stay with the global kernels, the others go by tile
+      long-lines    triangles of ~2500 px: edges whose box covers more than 64 wire tiles (WIRE_BIG_TILES) stay with the global kernels, the
+                    others go by tile
       crowded-tile  a far camera puts every edge into a few tiles: their lists overflow and the whole frame falls back
       both-phases   back-face wireframe AND front-face overlay in one frame (the overlay is drawn later: it wins where both hit);
                     -long: with edges of both kinds on both routes -- a big back-face edge (global kernels) must not paint over a small
@@ -1153,13 +1154,31 @@ def test_wireframe_phases_through_screen_tiles(oracle, case):
                     tile kernel's general 64-bit walk instead of the incremental one
       one-tile      a 64 x 16 frame = one wire tile crossed by the edges of 250 big triangles: as many 16-step segments as one tile gets
                     (the kernel deals them out in passes of WIRE_SEG_CAP; a build with -DB32_WIRE_SEG_CAP=256 runs every case of this test
-                    in several passes per tile: tools/r4_segcap.sh)"""
+                    in several passes per tile)
+      thin-l        long thin L-shaped triangles on a 2560 x 1920 frame: one edge along a tile row, one along a tile column (each within the
+                    64-tile limit), the hypotenuse big -- the box AROUND the two small edges spans thousands of tiles; the face is binned
+                    edge box by edge box instead (k_wire_bin), and the frame must stay on the tile route"""
     from bonnie32_amd import rasterizer as R
-    cfg = {"small": (2_000, 320, 240, 64.0), "medium": (60_000, 1280, 960, 70.0), "long-lines": (6_000, 1280, 960, 2500.0),
+    cfg = {"thin-l": (3_000, 2560, 1920, 64.0), "small": (2_000, 320, 240, 64.0), "medium": (60_000, 1280, 960, 70.0), "long-lines": (6_000, 1280, 960, 2500.0),
            "crowded-tile": (40_000, 640, 480, 60.0), "overlay": (30_000, 1280, 960, 90.0), "both-phases": (30_000, 640, 480, 120.0), "both-phases-long": (8_000, 1280, 960, 1200.0),
            "bands": (50_000, 1280, 960, 150.0), "one-tile": (250, 64, 16, 150.0), "huge-lines": (400, 256, 192, 40000.0)}[case]
     sc = scenegen.make_scene("C3", n_tris=cfg[0], width=cfg[1], height=cfg[2], bbox_px=cfg[3], seed=31 + cfg[0], variant="gouraud")
     sc.settings = b32.RasterSettings()                                   # default(): z-buffer, Gouraud + light, back-face wireframe
+    if case == "thin-l":
+        # every face: v0 -> v1 runs 1800 px to the right within one or two tile rows, v0 -> v2 440 px down within one or two tile columns
+        # (28 tile rows of 16 px): each edge's own box stays below the 64-tile limit; world coordinates from the screen ones at the face's own depth (camera at the origin, identity basis)
+        rng = np.random.default_rng(17)
+        pos = sc.vertices["pos"].reshape(-1, 3, 3)
+        z = pos[:, :, 2].mean(axis=1, keepdims=True).astype(np.float32)
+        vs = np.float32(min(sc.width, sc.height) / 2 * 0.75)
+        k = (z + np.float32(5.0)) / np.float32(4.0) / vs
+        x0 = rng.uniform(-1200, -900, (len(pos), 1)).astype(np.float32); y0 = rng.uniform(-900, -50, (len(pos), 1)).astype(np.float32)
+        flip = rng.integers(0, 2, (len(pos), 1)).astype(bool)                   # half of them wound the other way (back faces: the wireframe's own)
+        ax, ay = x0 + np.float32(1800.0), y0 + rng.uniform(-3, 3, (len(pos), 1)).astype(np.float32)
+        bx_, by_ = x0 + rng.uniform(-3, 3, (len(pos), 1)).astype(np.float32), y0 + np.float32(440.0)
+        sx = np.concatenate([x0, np.where(flip, bx_, ax), np.where(flip, ax, bx_)], axis=1); sy = np.concatenate([y0, np.where(flip, by_, ay), np.where(flip, ay, by_)], axis=1)
+        pos[:, :, 0] = sx * k; pos[:, :, 1] = sy * k; pos[:, :, 2] = z
+        sc.vertices["pos"] = pos.reshape(-1, 3)
     if case == "crowded-tile":
         sc.camera = b32.Camera(position=(0.0, 0.0, -60000.0))
     if case == "overlay":
@@ -1189,6 +1208,9 @@ def test_wireframe_phases_through_screen_tiles(oracle, case):
             assert tm.triangles_drawn == etm.triangles_drawn
         assert (ctx.route_counts()["wire_tiles"] > 0) == (off == 0)
         ctx.close()
+    if case == "thin-l":        # (sanity of the construction: the two small edges' boxes are far apart, so their union box is huge)
+        px = sc.vertices["pos"].reshape(-1, 3, 3)
+        assert np.ptp(px[:, :, 0] / px[:, :, 2], axis=1).min() * 720 * 4 > 1500
 
 
 def test_editor_modes_large_frame_bands(gpu_ctx, oracle):

@@ -372,7 +372,9 @@ def test_wire_edge_hash_set_equals_the_quadratic_scan(oracle):
     t[1::501, 1] = np.nan
     t[2::501, 4] = -np.inf
     assert oracle.unique_edges_selfcheck(t) == 0
-    assert oracle.unique_edges_selfcheck(t[:50]) == 0 and oracle.unique_edges_selfcheck(t[:0]) == 0
+    # (below 64 triangles unique_edges() IS the quadratic scan: sizes at and just above that threshold exercise the hash set)
+    for m in (0, 50, 63, 64, 65, 100):
+        assert oracle.unique_edges_selfcheck(t[:m]) == 0
     # every edge distinct, and every edge the same
     u = t.copy(); u[:, 0] = np.arange(n, dtype=np.float32) * 3; u[:, 3] = u[:, 0] + 1; u[:, 6] = u[:, 0] + 2
     assert oracle.unique_edges_selfcheck(u) == 0
