@@ -458,7 +458,7 @@ def main():
             for _ in range(5):
                 f2.clear(s2.clear_color); r2.render_async()
             r2.finish()
-            k2 = max(args.steps, 20) * (4 if name in ("C1", "C2") else 1)
+            k2 = max(args.steps, 100) * (4 if name in ("C1", "C2") else 1)       # (100 / 400 frames: a 20-frame region is a fifth pipeline fill and drain)
             torch.cuda.synchronize(dev)
             q0 = time.perf_counter()
             for _ in range(k2):
