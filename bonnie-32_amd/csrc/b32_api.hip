@@ -172,7 +172,13 @@ static int settle_before_write(b32_ctx* c) { return c->deep_async ? B32_OK : set
 int b32_fb_clear(b32_ctx* c, uint8_t r, uint8_t g, uint8_t b, uint8_t blend) {
     if (!c || !c->fb) return B32_E_ARG;
     (void)hipSetDevice(c->device);
-    { const int rc = settle_before_write(c); if (rc) return rc; }
+    // Safe mode settles a pending large-scene frame before anything writes the framebuffer -- except here: this clear covers every row the
+    // pending frame can have drawn (its band; a band change settles) and resets their depths, so whether that frame was dropped or not
+    // can no longer be seen.  It is marked superseded instead, and the draw that follows is enqueued behind it like in deep mode (the
+    // setup kernel of the new frame beside the fill of the old one): the reference's loop -- clear, draw, clear, draw -- runs without a
+    // host synchronisation per frame in the library's DEFAULT mode too.  Anything that reads the framebuffer in between still settles.
+    if (!c->deep_async && c->frame_pending && c->pending_may_redraw) c->pending_superseded = true;
+    else { const int rc = settle_before_write(c); if (rc) return rc; }
     const uint32_t a = blend == B32_BLEND_ERASE ? 0u : 255u;               // Color::to_bytes, types.rs:829-832
     const uint32_t rgba = r | (g << 8) | (b << 16) | (a << 24);
     // with a screen band set (multi-GPU sharding) only the rows this rank owns are cleared: the others belong to other ranks.

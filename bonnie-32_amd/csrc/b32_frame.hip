@@ -427,7 +427,11 @@ int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st, const
 #else
     const uint32_t pipe_min_faces = 2048u;
 #endif
-    if (c->frame_pending && c->pipe_hint && !c->redrawing && !fp.wire_collect && !prof_all && c->nf > pipe_min_faces && !(c->route_off & B32_ROUTE_PIPELINE)) {
+    // (not on the legacy default stream -- hipStreamLegacy, what torch's default stream maps to: it synchronises implicitly with every
+    // blocking stream, and recording / waiting cross-stream events on that handle crashed the runtime, found when safe mode began to
+    // leave superseded frames in flight)
+    if (c->frame_pending && c->pipe_hint && !c->redrawing && !fp.wire_collect && !prof_all && c->nf > pipe_min_faces && !(c->route_off & B32_ROUTE_PIPELINE) &&
+        c->stream != hipStreamLegacy) {
         if ((rc = pipeline_ensure(c))) return rc;
         rotate_sets(c);
         c->pipelined = true;
@@ -589,7 +593,9 @@ int render_scene_async_any(b32_ctx* c, const B32Camera* cam, const B32Settings* 
     if (rc) return rc;
     // keep a private copy of the lights so a redraw after overflow does not dereference a dead caller pointer
     // (safe mode) a pending frame that may still need a redraw is settled before the next one overwrites its control block
-    if (!c->deep_async && (rc = settle_pending(c))) return rc;
+    // (... unless a clear of the whole band has superseded it: b32_fb_clear)
+    if (!c->deep_async && !(c->pending_superseded && c->clear_pending) && (rc = settle_pending(c))) return rc;
+    c->pending_superseded = false;
     c->last_cam = *cam; c->last_settings = *st; c->last_has_fog = fog != nullptr;
     if (fog) c->last_fog = *fog;
     c->keep_lights.assign(st->lights, st->lights + (st->lights ? st->n_lights : 0));
@@ -690,6 +696,7 @@ int b32_frame_finish(b32_ctx* c, B32Timings* out) {
         if (rc) return rc;
     }
     c->frame_pending = false;
+    c->pending_superseded = false;
     c->set_in_flight = false;
     collect_events(c);
     uint32_t sticky = c->h_ctrl.sticky;                        // errors of every frame enqueued since the last finish
@@ -713,7 +720,9 @@ int b32_frame_finish(b32_ctx* c, B32Timings* out) {
     }
     if (c->deferred_rc) { const int d = c->deferred_rc; c->deferred_rc = 0; return d; }     // (an earlier mesh of this frame, settled by a swap)
     if (c->h_ctrl.pairs_overflow) return B32_E_HIP;
-    if (sticky >> 8) return B32_E_FRAME_DROPPED;              // deep asynchronous mode: an earlier frame was lost (the last one is good)
+    // deep asynchronous mode: an earlier frame was lost (the last one is good).  (Safe mode only ever leaves a frame behind when a clear of
+    // the whole band has overwritten whatever it drew: nothing observable was lost.)
+    if ((sticky >> 8) && c->deep_async) return B32_E_FRAME_DROPPED;
     if (c->h_ctrl.err_index || (sticky & 1u)) return B32_E_INDEX;
     if (c->h_ctrl.abort || (sticky & 2u)) return B32_E_NAN_KEY;
     if (c->h_ctrl.wire_overflow || (sticky & 4u)) return B32_E_UNSUPPORTED;     // an edge >= 2^30 px long: i32 overflow in the reference's Bresenham

@@ -166,6 +166,8 @@ struct b32_ctx {
     unsigned long long batch_stats[4] = {};      // merged draws, sequential draws, merged meshes built, frames
     // last enqueued frame (for redraw after a pair overflow)
     bool frame_pending = false;
+    bool pending_superseded = false;    // safe mode: a b32_fb_clear of the whole band was issued behind the pending frame -- every pixel (and depth) that frame
+                                        // drew is overwritten, so the NEXT frame may be enqueued without settling it (a redraw of it could not be seen)
     bool pending_may_redraw = false;    // the pending frame took a path that can overflow its buffers (not the small-mesh path)
     bool deep_async = false;            // b32_set_async_depth(1): large-scene frames are enqueued back to back, a dropped one is reported
     bool redrawing = false;             // enqueue_frame is repeating the pending frame (k_setup must not count it as lost)

@@ -234,7 +234,12 @@ int b32_frame_finish(b32_ctx* ctx, B32Timings* out /* nullable */);
  *   deep = 0 (default): safe.  Enqueueing another frame, or any call that reads, writes or rebinds the framebuffer (b32_fb_download,
  *            b32_zbuffer_download, b32_fb_upload, b32_fb_clear*, b32_render_skybox_mesh, b32_draw_star_diamonds, b32_fb_bind_device,
  *            b32_set_stream, b32_present_nearest, b32_scene_upload*, b32_scene_swap, b32_set_band), first settles the pending frame (one host synchronisation, redraw if needed): no
- *            frame is ever lost, and none is redrawn on top of a later clear.
+ *            frame is ever lost, and none is redrawn on top of a later clear.  One exception that cannot be observed (round 5): a
+ *            b32_fb_clear of the whole band behind a pending frame overwrites every pixel and depth that frame can have drawn, so the
+ *            frame is marked superseded instead of settled and the draw that follows is enqueued behind it like in deep mode -- the
+ *            reference's loop (clear, draw, clear, draw; game/renderer.rs:91-95) runs without a host synchronisation per frame in
+ *            this default mode too.  Any call that READS the framebuffer in between still settles; errors of a superseded frame are
+ *            still reported by the next b32_frame_finish.
  *   deep = 1: throughput.  Frames are enqueued back to back with no host synchronisation (bench.py and the tools that call
  *            b32_set_async_depth(ctx, 1): static camera, capacities settled by a warm-up frame).  Only the most recent frame can be redrawn; if an earlier one was dropped,
  *            b32_frame_finish reports B32_E_FRAME_DROPPED -- never silently.  Consumers outside the library that read the bound

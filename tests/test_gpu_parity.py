@@ -454,6 +454,55 @@ def test_async_frames_are_never_silently_dropped(oracle):
         ctx5.close()
 
 
+def test_safe_mode_clear_supersedes_a_pending_frame(oracle):
+    """Safe mode (the library default) settles a pending large-scene frame before anything writes the framebuffer -- except a
+    b32_fb_clear of the whole band, which overwrites every pixel and depth that frame can have drawn: the frame is marked superseded
+    and the next draw is enqueued behind it without a host synchronisation (the reference's loop is clear, draw, clear, draw).  A frame
+    that overflowed its tile regions and drew nothing may therefore be left behind -- but only where it can never be seen: the final
+    picture is the oracle's, b32_frame_finish reports no error, a download right after a draw still shows that draw (redrawn), and a
+    mesh error (vertex index out of range) in a superseded frame is still reported by the next b32_frame_finish."""
+    from bonnie32_amd import rasterizer as R
+    sc = scenegen.make_scene("C3", n_tris=120_000, width=640, height=480, bbox_px=60.0, seed=321)
+    far = b32.Camera(position=(0.0, 0.0, -45000.0)); near = sc.camera
+    far_shifted = b32.Camera(position=(3000.0, 0.0, -45000.0))
+
+    def want(cam, zbuffer=False):
+        o = oracle.Framebuffer(sc.width, sc.height); o.clear(sc.clear_color)
+        st = copy.copy(sc.settings); st.use_zbuffer = zbuffer
+        assert oracle.render_mesh_15(o, sc.vertices, sc.faces, sc.textures, cam, st)[0] == 0
+        return o.pixels
+    for zbuffer in (False, True):
+        st = copy.copy(sc.settings); st.use_zbuffer = zbuffer
+        ctx = R.Context(0)                                         # (fresh context: tile regions at their initial size, the far view overflows them)
+        fb = R.Framebuffer(sc.width, sc.height, ctx)
+        rs = R.ResidentScene(fb, sc.vertices, sc.faces, sc.textures)
+        before = ctx.route_counts()
+        for cam in (far, far_shifted, near, far):
+            fb.clear(sc.clear_color)
+            rs.render_async(cam, st)
+        got = fb.pixels                                            # the download settles (and redraws) the last frame only
+        assert np.array_equal(got, want(far, zbuffer)), f"{int((got != want(far, zbuffer)).sum())} bytes differ (zbuffer={zbuffer})"
+        rs.finish()                                                # no error: nothing observable was lost
+        after = ctx.route_counts()
+        assert after["redraw_region"] - before["redraw_region"] <= 2      # (not one redraw per overflowing frame)
+        fb.clear(sc.clear_color); rs.render_async(far_shifted, st)
+        assert np.array_equal(fb.pixels, want(far_shifted, zbuffer))     # no clear behind it: settled as ever
+        rs.finish()
+        ctx.close()
+    # an error of a superseded frame is not lost
+    bad = sc.faces.copy(); bad["v"][5, 1] = len(sc.vertices) + 7
+    ctx = R.Context(0)
+    fb = R.Framebuffer(sc.width, sc.height, ctx)
+    rs_bad = R.ResidentScene(fb, sc.vertices, bad, sc.textures).detach()
+    rs_ok = R.ResidentScene(fb, sc.vertices, sc.faces, sc.textures).detach()
+    fb.clear(sc.clear_color); rs_bad.render_async(near, sc.settings)
+    fb.clear(sc.clear_color); rs_ok.render_async(near, sc.settings)
+    with pytest.raises(R.B32Error) as e:
+        rs_ok.finish()
+    assert e.value.code == b32.abi.B32_E_INDEX
+    ctx.close()
+
+
 def test_pipeline_gate_argument_range():
     """b32_set_pipeline_gate: 0 = no hold, 1 .. 1000 = the fill's tail, 1001 .. 2000 = a share of the tiles behind its first round;
     anything above is refused and leaves the setting alone (include/b32raster.h)."""
