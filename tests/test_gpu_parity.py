@@ -1,6 +1,7 @@
 """Parity tests proper: the HIP path through the C ABI against the CPU oracle, bit-exact (integer/byte outputs and
 exact-order f32).  Every test needs a real MI355X and fails loudly if the HIP library or device is missing."""
 import copy
+import ctypes as C
 import hashlib
 import json
 import os
@@ -743,6 +744,41 @@ def test_band_ranks_share_one_gpu_through_the_c_abi(world, mode, oracle, tmp_pat
             if p.poll() is None:
                 p.kill()
         ctx.close()
+
+
+def test_band_exchange_argument_checks(gpu_ctx):
+    """The multi-GPU entry points refuse what they cannot do, without touching the device: a root whose framebuffer is caller-bound
+    memory cannot be exported, rank 0 / rank 64 cannot be imported or attached, publish / acquire need an imported context, wait /
+    release an exported one, a context cannot attach to itself, and the RCCL transport without a communicator is an argument error."""
+    from bonnie32_amd import rasterizer as R
+    E = b32.abi.B32_E_ARG
+    lib = gpu_ctx.lib
+    root = R.Context(0)
+    fb = R.Framebuffer(64, 48, root)
+    share = root.band_export()
+    assert len(share) == 96 and np.frombuffer(share, np.uint32, 2, 64).tolist() == [64, 48]
+    other = R.Context(0)
+    buf = C.create_string_buffer(share, 96)
+    for rank in (0, 64, 1000):
+        assert lib.b32_band_import(other.h, C.cast(buf, C.c_void_p), rank) == E
+        assert lib.b32_band_attach(other.h, root.h, rank) == E
+    assert lib.b32_band_attach(root.h, root.h, 1) == E
+    assert lib.b32_band_publish(other.h, 1) == E and lib.b32_band_acquire(other.h, 1, 10) == E       # not a band rank (yet)
+    assert lib.b32_band_wait(other.h, 1, 1, 10) == E and lib.b32_band_release(other.h, 1) == E       # not a root
+    assert lib.b32_band_wait(root.h, 0, 1, 10) == E
+    y = (C.c_uint32 * 2)(0, 24); y1 = (C.c_uint32 * 2)(24, 48)
+    assert lib.b32_gather_bands_rccl(root.h, None, 0, 2, 0, y, y1) == E                               # no communicator
+    assert lib.b32_gather_bands_rccl(root.h, C.c_void_p(1), 2, 2, 0, y, y1) == E                      # rank out of range
+    # attach inside this process works, and a wait on a rank that never publishes times out COUNTED, not silently
+    other.band_attach(root, 1)
+    root.band_wait(1, 1, timeout_us=2000)
+    root.synchronize()
+    epochs, released, timeouts = root.band_status()
+    assert epochs[1] == 0 and timeouts == 1
+    other.band_publish(1); other.synchronize()
+    root.band_wait(1, 1, timeout_us=2_000_000); root.synchronize()
+    assert root.band_status()[0][1] == 1 and root.band_status()[2] == 1
+    other.close(); root.close()
 
 
 def _console_meshes(n_meshes, seed0, blend_every=4):
