@@ -191,10 +191,16 @@ __device__ __forceinline__ void shade_tile_plain(const FillArgs& a, const uint32
     auto drain = [&]() {
         const bool act = lane < lqn;
         const uint32_t e = act ? wq[lane] : 0u;
-        const uint32_t row = e >> 6, c = e & 63u, qx = x_lo + c, qy = ty_top + row;
+        const uint32_t row = (e >> 6) & 63u, c = e & 63u, qx = x_lo + c, qy = ty_top + row;
         bool ok = false; Hit h; h.sid = 0;
         unsigned long long t = 0;
-        repair_pixel<false, ZMODE>(a, sec, act, row, c, qx, qy, e0, e1, lane, ok, h, t);
+        // (bit 12: the WINNER itself has not been evaluated -- its edge walk must be replayed literally (SH_SLOW), which the straight-line
+        // step does not do: the general per-pixel functions, here, where the rare cases meet)
+        const bool try_top = act && ((e >> 12) & 1u);
+        if (__ballot(try_top)) {
+            if (try_top) { t = top[row * STR64 + c]; ok = hit_test<false>(a, sid_of(t), qx, qy, h); }
+        }
+        repair_pixel<false, ZMODE>(a, sec, act && !ok, row, c, qx, qy, e0, e1, lane, ok, h, t);
         if (act) {
             if (ok) {
                 a.fb[(size_t)qy * W + qx] = colour<false>(a, h, shading, qx, qy);
@@ -228,15 +234,7 @@ __device__ __forceinline__ void shade_tile_plain(const FillArgs& a, const uint32
         const uint4 b0q = spB[0], b1q = spB[1], b2q = spB[2], b3q = spB[3];
         const uint32_t shA = a3q.w >> 24, shB = b3q.w >> 24;
         unsigned long long mA, mB;
-        if (__ballot((cA && (shA & SH_SLOW)) || (cB && (shB & SH_SLOW)))) {
-            // rare: a winner whose edge walk is replayed literally -- the general per-pixel functions for this step
-            Hit hA, hB;
-            const bool okA = cA && hit_test<false>(a, sidA, px, pyA, hA);
-            const bool okB = cB && hit_test<false>(a, sidB, px, pyB, hB);
-            if (okA) { *outA = colour<false>(a, hA, shading, px, pyA); if (ZMODE) store_depth(tA, sidA, pyA); } else if (!cA && inA) leave(pyA);
-            if (okB) { *outB = colour<false>(a, hB, shading, px, pyB); if (ZMODE) store_depth(tB, sidB, pyB); } else if (!cB && inB) leave(pyB);
-            mA = __ballot(cA && !okA); mB = __ballot(cB && !okB);
-        } else {
+        {
             float bA[3], bB[3];
             uint32_t taA, taB;
             {   // pixel A: render.rs:1507-1510 (edges), :1517-1518 / 1706-1712 in closed form (exact integers), :1536-1538, :1565-1566, types.rs:671-681
@@ -270,7 +268,9 @@ __device__ __forceinline__ void shade_tile_plain(const FillArgs& a, const uint32
             const bool btA = (shA & SH_BLACK_TR) != 0, btB = (shB & SH_BLACK_TR) != 0;
             const bool skipA = btA && (cA15 & ~K::C15_SEMI_BIT & 0xFFFFu) == 0, skipB = btB && (cB15 & ~K::C15_SEMI_BIT & 0xFFFFu) == 0;     // 0x0000 or black with black_transparent
             cA15 = cA15 == K::C15_TRANSPARENT ? K::C15_BLACK_DRAWABLE : cA15; cB15 = cB15 == K::C15_TRANSPARENT ? K::C15_BLACK_DRAWABLE : cB15;
-            const bool okA = cA && !skipA, okB = cB && !skipB;
+            // (a winner that must replay its edge walk literally is not evaluated here: it joins the repair queue with bit 12 set)
+            const bool slowA = (shA & SH_SLOW) != 0, slowB = (shB & SH_SLOW) != 0;
+            const bool okA = cA && !skipA && !slowA, okB = cB && !skipB && !slowB;
             const uint32_t vA[3] = { a1q.w & 0xFFFFFFu, a3q.z & 0xFFFFFFu, a3q.w & 0xFFFFFFu }, vB[3] = { b1q.w & 0xFFFFFFu, b3q.z & 0xFFFFFFu, b3q.w & 0xFFFFFFu };
             const uint32_t flA = (shA & SH_DITHER) ? F_DITHER : 0u, flB = (shB & SH_DITHER) ? F_DITHER : 0u;
             uint32_t colA, colB;
@@ -294,7 +294,7 @@ __device__ __forceinline__ void shade_tile_plain(const FillArgs& a, const uint32
                 if (!m) continue;
                 const uint32_t n = (uint32_t)__builtin_popcountll(m);
                 if (lqn + n > 64u) drain();
-                if ((m >> lane) & 1ull) wq[lqn + (uint32_t)__builtin_popcountll(m & below)] = ((which ? rowB : rowA) << 6) | col;
+                if ((m >> lane) & 1ull) wq[lqn + (uint32_t)__builtin_popcountll(m & below)] = ((which ? rowB : rowA) << 6) | col | (((which ? shB : shA) & SH_SLOW) ? 0x1000u : 0u);
                 lqn += n;
             }
         }
