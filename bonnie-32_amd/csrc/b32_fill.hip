@@ -68,17 +68,14 @@ __device__ __forceinline__ void clear_band(const FillArgs& a) {
     }
 }
 
-// PLAIN == 2: the plain form compiled for five waves per SIMD, i.e. 96 VGPRs (8 dwords of scratch) instead of 109: alone it is 1-2 us
-// slower, but four of its waves leave a SIMD 128 registers -- TWO waves of the next frame's setup kernel instead of one -- and the
-// pipelined frame gains ~2 % (C3 0.1219-0.1222 -> 0.1193-0.1211 ms); chosen only for frames whose setup kernel runs on the side stream.
 // PLAIN: the configuration BASELINE.json's metric is quoted on, with its run-time switches turned into constants -- affine UVs, no
 // shading pass, fixed-point snapping, perspective camera, one texture, lists from the binning launch, no transparent pass.  The
-// compiler then drops the other branches of coverage and shading from this instantiation (102 -> 94 VGPRs, 45 -> 13 spilled SGPRs).
-template <int TEXMODE, bool EXACT, int NT, bool ZMODE, bool FMT8 = false, bool P64 = false, int PLAIN = 0>
-// (every form but the plain one is compiled for at least 4 waves per SIMD, i.e. at most 128 VGPRs: the EXACT z-buffer forms had drifted
-// to 129, which halves the 512-thread kernel's residency to one workgroup per CU -- game() settings with colour-keyed textures at
-// 2560x1920: 0.289 -> 0.242 ms; the plain form keeps the default bound of its block size, its code is byte-identical)
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PLAIN == 2 ? 5 : (PLAIN == 1 ? 4 : ((P64 && NT == 512) ? B32_P64_WAVES : 4))))) void k_cover(FillArgs a_in) {
+// compiler then drops the other branches of coverage and shading from this instantiation.
+//   PLAIN == 1: RGB555 texels fetched from global memory, texture of non-zero size: the straight-line shading and nothing else;
+//   PLAIN == 2: the other plain frames (8-bit-per-channel target, the index atlas in LDS, a zero-sized texture): the general shading.
+// The body is a device function so that one instantiation can also be compiled under a register cap (k_cover_plain below).
+template <int TEXMODE, bool EXACT, int NT, bool ZMODE, bool FMT8, bool P64, int PLAIN>
+__device__ __forceinline__ void cover_body(const FillArgs& a_in) {
     FillArgs a_plain = a_in;
     if (PLAIN) {
         a_plain.fp.affine = 1; a_plain.fp.shading = B32_SHADE_NONE; a_plain.fp.fixed_point = 1; a_plain.fp.ortho = 0; a_plain.fp.nt = 1;
@@ -317,10 +314,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PLAIN == 2 ?
                 // (the plain form's straight-line shading: one texture of non-zero size fetched from global memory)
                 // (the straight-line shading: RGB555, affine UVs, fixed-point snap, perspective camera, one texture of non-zero size fetched
                 // from global memory -- painter's or z-buffer mode, with or without a shading pass; wave-uniform choice)
-                if (!FMT8 && fp.affine && fp.fixed_point && !fp.ortho && fp.nt == 1 && !latlas && a.tex0.width && a.tex0.height &&
-                    (fp.shading == B32_SHADE_NONE || a.shades))
+                if (PLAIN != 2 && (PLAIN == 1 || (!FMT8 && fp.affine && fp.fixed_point && !fp.ortho && fp.nt == 1 && !latlas && a.tex0.width && a.tex0.height &&
+                                                  (fp.shading == B32_SHADE_NONE || a.shades))))
                     shade_tile_plain<NT, ZMODE>(a, tilebuf, e0, e1, x_lo, x_hi, y_lo, y_hi, ty_top, tid, lane, TH, wmarks + wave * 64);
-                else shade_tile_p64<FMT8, NT, ZMODE>(a, tilebuf, e0, e1, x_lo, x_hi, y_lo, y_hi, ty_top, tid, lane, TH, wmarks + wave * 64, latlas);
+                else if (PLAIN != 1) shade_tile_p64<FMT8, NT, ZMODE>(a, tilebuf, e0, e1, x_lo, x_hi, y_lo, y_hi, ty_top, tid, lane, TH, wmarks + wave * 64, latlas);
             }
             else if (a.clear_on) {      // nothing reaches this tile: it still gets the frame's clear colour
                 for (uint32_t p = tid; p < TILE_W * TH; p += NT) {
@@ -383,6 +380,22 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PLAIN == 2 ?
     }
 }
 
+// (every form is compiled for at least 4 waves per SIMD, i.e. at most 128 VGPRs: the EXACT z-buffer forms had drifted to 129, which halves
+// the 512-thread kernel's residency to one workgroup per CU -- game() settings with colour-keyed textures at 2560x1920: 0.289 -> 0.242 ms)
+template <int TEXMODE, bool EXACT, int NT, bool ZMODE, bool FMT8 = false, bool P64 = false, int PLAIN = 0>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((P64 && NT == 512 && !PLAIN) ? B32_P64_WAVES : 4))) void k_cover(FillArgs a_in) {
+    cover_body<TEXMODE, EXACT, NT, ZMODE, FMT8, P64, PLAIN>(a_in);
+}
+
+// The benchmark's instantiation (painter's mode, CHEAP coverage, PLAIN == 1) under a cap of 112 VGPRs: four of its waves then leave a SIMD
+// 64 registers, one wave of the NEXT frame's 58-register setup kernel, which otherwise waits for a fill workgroup to retire (two frames in
+// flight: C3 0.1166 -> 0.1129 ms/frame, C5 0.196 -> 0.185 on the same box, profiles/r05_vgpr112_ab.txt).  The uncapped body allocates 113.
+// amdgpu_num_vgpr counts HALF the unified VGPR+AGPR file on gfx90a and later (56 -> 112); it does not take a template-dependent value,
+// hence a kernel of its own.
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4), amdgpu_num_vgpr(56))) void k_cover_plain(FillArgs a_in) {
+    cover_body<0, false, 512, false, false, true, 1>(a_in);
+}
+
 #ifdef B32_TIMELINE
 static unsigned long long* g_timeline = nullptr;
 extern "C" int b32_debug_timeline(unsigned long long* out, unsigned cap_words) {       // experiment builds only
@@ -425,30 +438,25 @@ static void launch_p64(hipStream_t s, const FillArgs& a_in, uint32_t ntiles, int
     if (plain && !wide && a.atlas_idx_bytes) {
         static bool attr_x[64] = {};
         if (first_launch_on_device(attr_x))
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<0, EXACT, 1024, ZMODE, FMT8, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL((k_cover<0, EXACT, 1024, ZMODE, FMT8, true, true>), dim3(min(ntiles, (uint32_t)n_cu)), dim3(1024), lds_w, s, a);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<0, EXACT, 1024, ZMODE, FMT8, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL((k_cover<0, EXACT, 1024, ZMODE, FMT8, true, 2>), dim3(min(ntiles, (uint32_t)n_cu)), dim3(1024), lds_w, s, a);
         return;
     }
 #endif
-#ifndef B32_CORUN_FORM
-#define B32_CORUN_FORM 0         // the 96-VGPR co-resident form of the plain fill (round 4: four of its waves leave a SIMD room for two waves of the next
-                                 // frame's setup kernel, +2 %).  OFF since round 5: with the straight-line plain shading the register cap costs 31 spilled
-                                 // VGPRs and the pipelined frame 0.140 ms against 0.117 (profiles/r05_corun_form_ab.txt)
-#endif
-#if B32_CORUN_FORM
-    if (plain && !wide && a.co_run && !EXACT && !ZMODE && !FMT8) {
-        static bool attr_co[64] = {};
-        if (first_launch_on_device(attr_co))
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<0, false, 512, false, false, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL((k_cover<0, false, 512, false, false, true, 2>), g, dim3(512), lds_n, s, a);
-        return;
-    }
-#endif
+    // (the straight-line shading's frames: see cover_body)
+    const bool straight = !FMT8 && !a.atlas_idx_bytes && a.tex0.width && a.tex0.height;
     if (plain && !wide) {
         static bool attr_plain[64] = {};
-        if (first_launch_on_device(attr_plain))
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<0, EXACT, 512, ZMODE, FMT8, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL((k_cover<0, EXACT, 512, ZMODE, FMT8, true, true>), g, dim3(512), lds_n, s, a);
+        const bool first = first_launch_on_device(attr_plain);
+        if (first) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<0, EXACT, 512, ZMODE, FMT8, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if constexpr (!EXACT && !ZMODE) {
+            if (first) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover_plain), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (straight) { hipLaunchKernelGGL(k_cover_plain, g, dim3(512), lds_n, s, a); return; }
+        } else {
+            if (first) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<0, EXACT, 512, ZMODE, false, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (straight) { hipLaunchKernelGGL((k_cover<0, EXACT, 512, ZMODE, false, true, 1>), g, dim3(512), lds_n, s, a); return; }
+        }
+        hipLaunchKernelGGL((k_cover<0, EXACT, 512, ZMODE, FMT8, true, 2>), g, dim3(512), lds_n, s, a);
     } else if (wide) hipLaunchKernelGGL((k_cover<0, EXACT, 1024, ZMODE, FMT8, true>), g, dim3(1024), lds_w, s, a);
     else hipLaunchKernelGGL((k_cover<0, EXACT, 512, ZMODE, FMT8, true>), g, dim3(512), lds_n, s, a);
 }

@@ -60,8 +60,10 @@ __device__ __forceinline__ void repair_pixel(const FillArgs& a, const unsigned l
 // of five on the benchmark scene -- but collected and repaired together: when 64 have gathered, and behind the tile's last row.
 template <bool FMT8, int NT, bool ZMODE>
 __device__ __forceinline__ void shade_tile_p64(const FillArgs& a, const uint32_t* tilebuf, uint32_t e0, uint32_t e1, uint32_t x_lo, uint32_t x_hi,
-                                               uint32_t y_lo, uint32_t y_hi, uint32_t ty_top, uint32_t tid, uint32_t lane, uint32_t TH, uint32_t* wq,
+                                               uint32_t y_lo, uint32_t y_hi, uint32_t ty_top, uint32_t tid_in, uint32_t lane_in, uint32_t TH, uint32_t* wq,
                                                const uint8_t* latlas) {
+    uint32_t tid = tid_in, lane = lane_in;              // (opaque copies: see shade_tile_plain)
+    asm volatile("" : "+v"(tid), "+v"(lane));
     const FrameParams& fp = a.fp;
     const unsigned long long* top = reinterpret_cast<const unsigned long long*>(tilebuf);
     const unsigned long long* sec = top + TILE_H * STR64;
@@ -160,7 +162,11 @@ __device__ __forceinline__ void shade_tile_p64(const FillArgs& a, const uint32_t
 // the general per-pixel functions; skipped winners go to the wave's repair queue as in the general form.
 template <int NT, bool ZMODE>
 __device__ __forceinline__ void shade_tile_plain(const FillArgs& a, const uint32_t* tilebuf, uint32_t e0, uint32_t e1, uint32_t x_lo, uint32_t x_hi,
-                                                 uint32_t y_lo, uint32_t y_hi, uint32_t ty_top, uint32_t tid, uint32_t lane, uint32_t TH, uint32_t* wq) {
+                                                 uint32_t y_lo, uint32_t y_hi, uint32_t ty_top, uint32_t tid_in, uint32_t lane_in, uint32_t TH, uint32_t* wq) {
+    // (the lane's constants of this phase -- column, x, masks -- are derived again per tile from an opaque copy of its index: hoisted out of the
+    // tile loop they would stay live through the coverage phase, which is the one that sets the kernel's register count)
+    uint32_t tid = tid_in, lane = lane_in;
+    asm volatile("" : "+v"(tid), "+v"(lane));
     const FrameParams& fp = a.fp;
     const unsigned long long* top = reinterpret_cast<const unsigned long long*>(tilebuf);
     const unsigned long long* sec = top + TILE_H * STR64;
@@ -222,18 +228,18 @@ __device__ __forceinline__ void shade_tile_plain(const FillArgs& a, const uint32
         const bool cA = covered(tA), cB = covered(tB);
         uint32_t* outA = a.fb + (size_t)pyA * W + px;
         uint32_t* outB = a.fb + (size_t)pyB * W + px;
+        unsigned long long mA = 0, mB = 0;
+        uint32_t shA = 0, shB = 0;
         if (!__ballot(cA || cB)) {
             if (inA) leave(pyA);
             if (inB) leave(pyB);
-            continue;
-        }
+        } else {
         const uint32_t sidA = cA ? sid_of(tA) : 0u, sidB = cB ? sid_of(tB) : 0u;      // (surface 0's record for an uncovered pixel: read, never used)
         const uint4* spA = reinterpret_cast<const uint4*>(a.srecs + sidA);
         const uint4* spB = reinterpret_cast<const uint4*>(a.srecs + sidB);
         const uint4 a0q = spA[0], a1q = spA[1], a2q = spA[2], a3q = spA[3];
         const uint4 b0q = spB[0], b1q = spB[1], b2q = spB[2], b3q = spB[3];
-        const uint32_t shA = a3q.w >> 24, shB = b3q.w >> 24;
-        unsigned long long mA, mB;
+        shA = a3q.w >> 24; shB = b3q.w >> 24;
         {
             float bA[3], bB[3];
             uint32_t taA, taB;
@@ -287,19 +293,21 @@ __device__ __forceinline__ void shade_tile_plain(const FillArgs& a, const uint32
             if (okB) { *outB = colB; if (ZMODE) store_depth(tB, sidB, pyB); } else if (!cB && inB) leave(pyB);
             mA = __ballot(cA && !okA); mB = __ballot(cB && !okB);
         }
-        if (mA | mB) {
-#pragma unroll
-            for (int which = 0; which < 2; ++which) {
-                const unsigned long long m = which ? mB : mA;
-                if (!m) continue;
+        }
+        // ONE drain site (the queue's code -- the general per-pixel functions -- exists once in the kernel): entries of pixel A, of pixel B, then
+        // the flush after the last step
+        const bool last = r0 + 2 * ROWS_PER_STEP >= TH;
+        if ((mA | mB) || (last && lqn)) {
+#pragma unroll 1
+            for (int which = 0; which < 3; ++which) {
+                const unsigned long long m = which == 0 ? mA : which == 1 ? mB : 0ull;
                 const uint32_t n = (uint32_t)__builtin_popcountll(m);
-                if (lqn + n > 64u) drain();
+                if (which == 2 ? (last && lqn) : (lqn + n > 64u)) drain();
                 if ((m >> lane) & 1ull) wq[lqn + (uint32_t)__builtin_popcountll(m & below)] = ((which ? rowB : rowA) << 6) | col | (((which ? shB : shA) & SH_SLOW) ? 0x1000u : 0u);
                 lqn += n;
             }
         }
     }
-    if (lqn) drain();
 }
 
 }  // namespace b32
