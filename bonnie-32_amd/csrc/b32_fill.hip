@@ -72,15 +72,15 @@ __device__ __forceinline__ void clear_band(const FillArgs& a) {
 // shading pass, fixed-point snapping, perspective camera, one texture, lists from the binning launch, no transparent pass.  The
 // compiler then drops the other branches of coverage and shading from this instantiation.
 //   PLAIN == 1: RGB555 texels fetched from global memory, texture of non-zero size: the straight-line shading and nothing else;
-//   PLAIN == 2: the other plain frames (8-bit-per-channel target, the index atlas in LDS, a zero-sized texture): the general shading.
+//   PLAIN == 2: the other plain frames (8-bit-per-channel target, the index atlas in LDS, a zero-sized texture): the general shading;
+//   PLAIN == 3: PLAIN == 1 with a shading pass (flat / Gouraud: the settings the reference's callers use, RasterSettings::game() and
+//               ::default(), types.rs:1455-1495): the shading mode stays a run-time value, the shades come from the setup kernel.
 // The body is a device function so that one instantiation can also be compiled under a register cap (k_cover_plain below).
 template <int TEXMODE, bool EXACT, int NT, bool ZMODE, bool FMT8, bool P64, int PLAIN>
 __device__ __forceinline__ void cover_body(const FillArgs& a_in) {
     FillArgs a_plain = a_in;
-    if (PLAIN) {
-        a_plain.fp.affine = 1; a_plain.fp.shading = B32_SHADE_NONE; a_plain.fp.fixed_point = 1; a_plain.fp.ortho = 0; a_plain.fp.nt = 1;
-        a_plain.fp.n_lights = 0; a_plain.inline_bin = 0; a_plain.gather_blend = 0; a_plain.shades = nullptr;
-    }
+    if (PLAIN) { a_plain.fp.affine = 1; a_plain.fp.fixed_point = 1; a_plain.fp.ortho = 0; a_plain.fp.nt = 1; a_plain.inline_bin = 0; a_plain.gather_blend = 0; }
+    if (PLAIN == 1 || PLAIN == 2) { a_plain.fp.shading = B32_SHADE_NONE; a_plain.fp.n_lights = 0; a_plain.shades = nullptr; }
     const FillArgs& a = a_plain;
     constexpr int NW = NT / 64;
     constexpr int TB = (P64 ? 4 : 2) * LDS_TILE_BYTES;          // tile buffers: top + runner-up, 32- or 64-bit entries
@@ -314,10 +314,10 @@ __device__ __forceinline__ void cover_body(const FillArgs& a_in) {
                 // (the plain form's straight-line shading: one texture of non-zero size fetched from global memory)
                 // (the straight-line shading: RGB555, affine UVs, fixed-point snap, perspective camera, one texture of non-zero size fetched
                 // from global memory -- painter's or z-buffer mode, with or without a shading pass; wave-uniform choice)
-                if (PLAIN != 2 && (PLAIN == 1 || (!FMT8 && fp.affine && fp.fixed_point && !fp.ortho && fp.nt == 1 && !latlas && a.tex0.width && a.tex0.height &&
+                if (PLAIN != 2 && (PLAIN == 1 || PLAIN == 3 || (!FMT8 && fp.affine && fp.fixed_point && !fp.ortho && fp.nt == 1 && !latlas && a.tex0.width && a.tex0.height &&
                                                   (fp.shading == B32_SHADE_NONE || a.shades))))
                     shade_tile_plain<NT, ZMODE>(a, tilebuf, e0, e1, x_lo, x_hi, y_lo, y_hi, ty_top, tid, lane, TH, wmarks + wave * 64);
-                else if (PLAIN != 1) shade_tile_p64<FMT8, NT, ZMODE>(a, tilebuf, e0, e1, x_lo, x_hi, y_lo, y_hi, ty_top, tid, lane, TH, wmarks + wave * 64, latlas);
+                else if (PLAIN == 0 || PLAIN == 2) shade_tile_p64<FMT8, NT, ZMODE>(a, tilebuf, e0, e1, x_lo, x_hi, y_lo, y_hi, ty_top, tid, lane, TH, wmarks + wave * 64, latlas);
             }
             else if (a.clear_on) {      // nothing reaches this tile: it still gets the frame's clear colour
                 for (uint32_t p = tid; p < TILE_W * TH; p += NT) {
@@ -395,6 +395,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((P64 && NT =
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4), amdgpu_num_vgpr(56))) void k_cover_plain(FillArgs a_in) {
     cover_body<0, false, 512, false, false, true, 1>(a_in);
 }
+// (game() / default() -- z-buffer mode with a shading pass -- in the straight-line form and under the same cap: 121 -> 112 VGPRs, 11 spilled.
+// Their setup kernel needs 70 registers, so nothing co-resides; the form itself and the cap are worth 1 % each, profiles/r05_lit_form_ab.txt)
+#ifndef B32_LIT_VGPR
+#define B32_LIT_VGPR 56
+#endif
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4), amdgpu_num_vgpr(B32_LIT_VGPR))) void k_cover_lit(FillArgs a_in) {
+    cover_body<0, false, 512, true, false, true, 3>(a_in);
+}
 
 #ifdef B32_TIMELINE
 static unsigned long long* g_timeline = nullptr;
@@ -445,6 +453,15 @@ static void launch_p64(hipStream_t s, const FillArgs& a_in, uint32_t ntiles, int
 #endif
     // (the straight-line shading's frames: see cover_body)
     const bool straight = !FMT8 && !a.atlas_idx_bytes && a.tex0.width && a.tex0.height;
+    const bool lit_plain = a.fp.affine && a.fp.shading != B32_SHADE_NONE && a.shades && a.fp.fixed_point && !a.fp.ortho && a.fp.nt == 1 && !a.inline_bin && !a.gather_blend;
+    if constexpr (!EXACT && ZMODE && !FMT8) {
+        if (lit_plain && straight && !wide) {
+            static bool attr_lit[64] = {};
+            if (first_launch_on_device(attr_lit)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover_lit), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipLaunchKernelGGL(k_cover_lit, g, dim3(512), lds_n, s, a);
+            return;
+        }
+    }
     if (plain && !wide) {
         static bool attr_plain[64] = {};
         const bool first = first_launch_on_device(attr_plain);

@@ -226,16 +226,24 @@ __device__ __forceinline__ uint32_t agg_position(const AggSlot& g) {
 // RGB555): those branches are compiled out -- fewer live scalars, less code in the instruction cache, no exec-mask juggling around them
 // (the plain form is compiled for 8 waves per SIMD: left to itself the register allocator lands on 57 ... 65 VGPRs depending on unrelated
 // code in this file, i.e. on 7 or 8 waves and on schedules between 46 and 63 us at 1 M faces -- measured; the general form keeps its 5)
-template <int SETUP_FPT, bool PLAIN>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PLAIN ? 8 : 4, PLAIN ? 8 : 5))) void k_setup(FrameParams fp_in, const B32Vertex* __restrict__ verts, const B32Face* __restrict__ faces,
+// PLAIN == 2 (round 5): the plain form with a shading pass -- RasterSettings::game() (types.rs:1455-1460): Gouraud or flat shades from the
+// frame's lights, everything else as in PLAIN == 1.  With the lighting moved behind the record stores (the record's values are dead by
+// then) it needs 70 VGPRs instead of 95 and is compiled for 7 waves per SIMD; the kernel gains 3 us of 81 at 1 M faces -- it is not
+// occupancy-bound (profiles/r05_lit_setup_ab.txt).  (Compiled for 8 waves -- 64 registers, what would let one of its waves sit beside four
+// waves of the capped z-buffer fill -- it spills 23-31 VGPRs and takes 105 us instead of 78: not done.)
+#ifndef B32_LIT_SETUP_WAVES
+#define B32_LIT_SETUP_WAVES 7
+#endif
+template <int SETUP_FPT, int PLAIN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PLAIN == 1 ? 8 : (PLAIN == 2 ? B32_LIT_SETUP_WAVES : 4), PLAIN == 1 ? 8 : (PLAIN == 2 ? B32_LIT_SETUP_WAVES : 5)))) void k_setup(FrameParams fp_in, const B32Vertex* __restrict__ verts, const B32Face* __restrict__ faces,
                                                const TexDesc* __restrict__ tex, const B32Light* __restrict__ lights_mem, LightSet lset, MeshTable mtab,
                                                RecArrays recs, DirectBin db, float* __restrict__ shades, uint32_t* __restrict__ keys,
                                                uint32_t* __restrict__ spans, uint32_t* __restrict__ partials, Ctrl* __restrict__ ctrl,
                                                WireTri* __restrict__ wire, const float* __restrict__ pos12, const float* __restrict__ attr12,
                                                uint32_t* __restrict__ face_of) {
     FrameParams fp_plain = fp_in;                 // (dead code unless PLAIN)
-    if (PLAIN) { fp_plain.ortho = 0; fp_plain.fixed_point = 1; fp_plain.has_fog = 0; fp_plain.wire_collect = 0; fp_plain.shading = B32_SHADE_NONE;
-                 fp_plain.xray = 0; fp_plain.fmt8 = 0; fp_plain.n_lights = 0; fp_plain.batched = 0; }
+    if (PLAIN) { fp_plain.ortho = 0; fp_plain.fixed_point = 1; fp_plain.has_fog = 0; fp_plain.wire_collect = 0; fp_plain.xray = 0; fp_plain.fmt8 = 0; fp_plain.batched = 0; }
+    if (PLAIN == 1) { fp_plain.shading = B32_SHADE_NONE; fp_plain.n_lights = 0; }
     const FrameParams& fp = PLAIN ? fp_plain : fp_in;
     __shared__ uint32_t wpart[4][6];
     __shared__ uint8_t unr_lds[K::UNR_ENTRIES + 3];          // UNR_TABLE in LDS: its lookup sits in every vertex's dependent chain
@@ -446,27 +454,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PLAIN ? 8 :
                           (needs_dither ? F_DITHER : 0) | (slow ? F_SLOW : 0) | (transparent ? F_TRANSP : 0) |
                           (empty ? F_EMPTY : 0) | (editor_alpha << F_ALPHA_SHIFT);
                 }   // need_rec
-                if (need_rec && fp.shading != B32_SHADE_NONE) {
-                    V3 wn[3];
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        // (packed streams: the normals are the third one, behind the attributes)
-                        const float* np = pos12 ? attr12 + ((size_t)fp.nv + vi[j]) * 3 : reinterpret_cast<const float*>(verts) + (size_t)vi[j] * 9 + 5;
-                        wn[j] = { np[0], np[1], np[2] };
-                        if (backface) wn[j] = scale3(wn[j], -1.0f);
-                    }
-                    float* sh = shades + (size_t)rslot * 9;
-                    if (fp.shading == B32_SHADE_FLAT) {                                             // :1466-1469
-                        V3 center = scale3(add3(add3(wpos[i1], wpos[i2]), wpos[i3]), 1.0f / 3.0f);
-                        V3 nrm = normalize3(scale3(add3(add3(wn[i1], wn[i2]), wn[i3]), 1.0f / 3.0f));
-                        float s[3]; shade_multi(nrm, center, lights, fp.n_lights, m_ambient, s);
-                        for (int j = 0; j < 9; ++j) sh[j] = s[j % 3];
-                    } else {                                                                        // :1475-1483
-                        shade_multi(wn[i1], wpos[i1], lights, fp.n_lights, m_ambient, sh);
-                        shade_multi(wn[i2], wpos[i2], lights, fp.n_lights, m_ambient, sh + 3);
-                        shade_multi(wn[i3], wpos[i3], lights, fp.n_lights, m_ambient, sh + 6);
-                    }
-                }
                 // painter's key, render.rs:2529-2531 / 2538-2540. Perspective keys are > 5 (cam z > 0.1), so the sign bit
                 // is free: bit 31 = transparent class, low 31 bits = 0x7FFFFFFF - bits(z) => ascending radix == descending z,
                 // stability of the LSD passes == stability of slice::sort_by.
@@ -533,6 +520,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PLAIN ? 8 :
                     }
                     if (over) { Events* ev = events_of(ctrl); if (db_cls) ev->long_transparent = db.epoch; else ev->overflow = db.epoch; }
                 }
+                // (the shades last: the record's values are stored and dead by now, the lighting has the registers to itself)
+                if (need_rec && fp.shading != B32_SHADE_NONE) {
+                    V3 wn[3];
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        // (packed streams: the normals are the third one, behind the attributes)
+                        const float* np = pos12 ? attr12 + ((size_t)fp.nv + vi[j]) * 3 : reinterpret_cast<const float*>(verts) + (size_t)vi[j] * 9 + 5;
+                        wn[j] = { np[0], np[1], np[2] };
+                        if (backface) wn[j] = scale3(wn[j], -1.0f);
+                    }
+                    float* sh = shades + (size_t)rslot * 9;
+                    if (fp.shading == B32_SHADE_FLAT) {                                             // :1466-1469
+                        V3 center = scale3(add3(add3(wpos[i1], wpos[i2]), wpos[i3]), 1.0f / 3.0f);
+                        V3 nrm = normalize3(scale3(add3(add3(wn[i1], wn[i2]), wn[i3]), 1.0f / 3.0f));
+                        float s[3]; shade_multi(nrm, center, lights, fp.n_lights, m_ambient, s);
+                        for (int j = 0; j < 9; ++j) sh[j] = s[j % 3];
+                    } else {                                                                        // :1475-1483
+                        shade_multi(wn[i1], wpos[i1], lights, fp.n_lights, m_ambient, sh);
+                        shade_multi(wn[i2], wpos[i2], lights, fp.n_lights, m_ambient, sh + 3);
+                        shade_multi(wn[i3], wpos[i3], lights, fp.n_lights, m_ambient, sh + 6);
+                    }
+                }
             }
         }
         if (fp.wire_collect && bad_index) wire[f].kind = 0;
@@ -580,8 +589,10 @@ void launch_setup(hipStream_t s, const FrameParams& fp, const B32Vertex* verts, 
     // one face per thread: 52 VGPRs in the plain form = 8 waves per SIMD (two faces per thread with their loads issued up front: 73 VGPRs,
     // 43 us instead of 39 at 1 M faces; three: 49 us)
     const dim3 g1((fp.nf + 255) / 256);
-    if (plain) hipLaunchKernelGGL((k_setup<1, true>), g1, dim3(256), 0, s, fp, verts, faces, tex, lights, ls, mt, recs, db, shades, keys, spans, partials, ctrl, wire, pos12, attr12, face_of);
-    else hipLaunchKernelGGL((k_setup<1, false>), g1, dim3(256), 0, s, fp, verts, faces, tex, lights, ls, mt, recs, db, shades, keys, spans, partials, ctrl, wire, pos12, attr12, face_of);
+    const bool lit = fp.fixed_point && !fp.ortho && !fp.has_fog && !fp.wire_collect && fp.shading != B32_SHADE_NONE && !fp.xray && !fp.fmt8 && !fp.batched;
+    if (lit) hipLaunchKernelGGL((k_setup<1, 2>), g1, dim3(256), 0, s, fp, verts, faces, tex, lights, ls, mt, recs, db, shades, keys, spans, partials, ctrl, wire, pos12, attr12, face_of);
+    else if (plain) hipLaunchKernelGGL((k_setup<1, 1>), g1, dim3(256), 0, s, fp, verts, faces, tex, lights, ls, mt, recs, db, shades, keys, spans, partials, ctrl, wire, pos12, attr12, face_of);
+    else hipLaunchKernelGGL((k_setup<1, 0>), g1, dim3(256), 0, s, fp, verts, faces, tex, lights, ls, mt, recs, db, shades, keys, spans, partials, ctrl, wire, pos12, attr12, face_of);
 }
 
 // ---------------------------------------------------------------- merged mesh of a batched frame
