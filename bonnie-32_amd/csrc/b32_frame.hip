@@ -10,12 +10,16 @@
 // anything enqueued on the main stream that k_setup reads (uploads, packed streams, light lists, list-space memsets) -> the next
 // setup (ev_main, only when `side_dirty`).  The main stream always waits for the frame's setup before enqueue_frame returns, so a
 // synchronisation of the main stream still covers everything this context has in flight.
+#ifndef B32_EXP_NO_WIRE_PIPE
+#define B32_EXP_NO_WIRE_PIPE 0          // (1: frames with wireframe phases are not pipelined, as before round 5 -- their wire list was not part of the frame set)
+#endif
 static void swap_with(b32_ctx* c, FrameSet& a) {
     std::swap(c->keys[0], a.keys0); std::swap(c->crecs, a.crecs); std::swap(c->srecs, a.srecs); std::swap(c->xrecs, a.xrecs);
     std::swap(c->spans, a.spans); std::swap(c->face_of, a.face_of); std::swap(c->partials, a.partials);
     std::swap(c->shades, a.shades); std::swap(c->cap_shades, a.cap_shades);
     std::swap(c->direct_lists, a.direct_lists); std::swap(c->cap_direct, a.cap_direct);
     std::swap(c->tile_fill, a.tile_fill); std::swap(c->cap_tile_fill, a.cap_tile_fill);
+    std::swap(c->wire, a.wire); std::swap(c->cap_wire, a.cap_wire);
     std::swap(c->d_ctrl, a.d_ctrl);
     std::swap(c->ev_setup, a.ev_setup); std::swap(c->ev_done, a.ev_done); std::swap(c->set_in_flight, a.in_flight);
 }
@@ -30,10 +34,11 @@ static void unrotate_sets(b32_ctx* c) {      // (an enqueue that failed between 
     swap_with(c, c->alt[0]);
 }
 extern "C" void free_alt(b32_ctx* c, FrameSet& a) {          // (the caller has drained both streams)
-    void* ptrs[] = { a.keys0, a.crecs, a.srecs, a.xrecs, a.spans, a.face_of, a.partials, a.shades, a.direct_lists, a.tile_fill };
+    void* ptrs[] = { a.keys0, a.crecs, a.srecs, a.xrecs, a.spans, a.face_of, a.partials, a.shades, a.direct_lists, a.tile_fill, a.wire };
     for (void* q : ptrs) if (q) (void)hipFree(q);
     a.keys0 = nullptr; a.crecs = nullptr; a.srecs = nullptr; a.xrecs = nullptr; a.spans = nullptr; a.face_of = nullptr; a.partials = nullptr;
     a.shades = nullptr; a.cap_shades = 0; a.direct_lists = nullptr; a.cap_direct = 0; a.tile_fill = nullptr; a.cap_tile_fill = 0; a.cap_work = 0;
+    a.wire = nullptr; a.cap_wire = 0;
 }
 // side stream, events and the other sets' per-face buffers (sized like the current set's)
 static int pipeline_ensure(b32_ctx* c) {
@@ -430,7 +435,7 @@ int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st, const
     // (not on the legacy default stream -- hipStreamLegacy, what torch's default stream maps to: it synchronises implicitly with every
     // blocking stream, and recording / waiting cross-stream events on that handle crashed the runtime, found when safe mode began to
     // leave superseded frames in flight)
-    if (c->frame_pending && c->pipe_hint && !c->redrawing && !fp.wire_collect && !prof_all && c->nf > pipe_min_faces && !(c->route_off & B32_ROUTE_PIPELINE) &&
+    if (c->frame_pending && c->pipe_hint && !c->redrawing && !(fp.wire_collect && B32_EXP_NO_WIRE_PIPE) && !prof_all && c->nf > pipe_min_faces && !(c->route_off & B32_ROUTE_PIPELINE) &&
         c->stream != hipStreamLegacy) {
         if ((rc = pipeline_ensure(c))) return rc;
         rotate_sets(c);

@@ -34,6 +34,7 @@ struct FrameSet {
     float* shades = nullptr; size_t cap_shades = 0;
     uint32_t* direct_lists = nullptr; size_t cap_direct = 0;
     uint32_t* tile_fill = nullptr; size_t cap_tile_fill = 0;
+    WireTri* wire = nullptr; size_t cap_wire = 0;           // (frames with wireframe phases: k_setup writes the wire list, the wire kernels behind the fill read it)
     Ctrl* d_ctrl = nullptr;
     hipEvent_t ev_setup = nullptr, ev_done = nullptr;      // k_setup finished (side stream) / last fill reading this set finished (main stream)
     bool in_flight = false;                                  // a frame was enqueued on this set since the last b32_frame_finish

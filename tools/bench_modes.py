@@ -15,6 +15,8 @@ import os
 if os.environ.get("EXP_ROUTES"):
     ctx.set_routes(int(os.environ["EXP_ROUTES"]))
 ctx.set_async_depth(1)      # timing loops: frames back to back (a dropped frame would be reported by finish())
+if os.environ.get("EXP_GATE"): ctx.set_pipeline_gate(int(os.environ["EXP_GATE"]))      # (experiments: see b32_set_pipeline_gate)
+if os.environ.get("EXP_DEPTH"): ctx.set_pipeline_depth(int(os.environ["EXP_DEPTH"]))
 base = scenegen.make_scene("C3", n_tris=N, variant="gouraud")
 tex8 = [b32.Texture.from_texture15(t) for t in base.textures]
 MODES = [
