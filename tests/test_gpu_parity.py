@@ -529,6 +529,32 @@ def test_pipeline_depth_argument_range():
         assert e.value.code == b32.abi.B32_E_ARG
 
 
+@pytest.mark.parametrize("depth", [2, 3])
+def test_wireframe_frames_two_in_flight(oracle, depth):
+    """RasterSettings::default() (back-face wireframe, types.rs:1475-1495) on a large mesh, frames back to back: since round 5 the wire list
+    k_setup writes is part of the frame set, so these frames run two in flight as well -- the next frame's setup kernel beside this
+    frame's fill and wireframe kernels.  Five cameras in z-buffer mode without a clear in between: colour, depth and the wire pixels of
+    every frame accumulate, so each frame's wire kernels must have read their OWN frame's list."""
+    from bonnie32_amd import rasterizer as R
+    sc = scenegen.make_scene("C3", n_tris=60_000, width=1920, height=1440, bbox_px=120.0, seed=4242, variant="gouraud")
+    st = b32.RasterSettings()                         # the reference's defaults
+    cams = [b32.Camera(position=(35.0 * i, -20.0 * i, -280.0 * i)) for i in range(5)]
+    ofb = oracle.Framebuffer(sc.width, sc.height); ofb.clear(sc.clear_color)
+    for cam in cams:
+        assert oracle.render_mesh_15(ofb, sc.vertices, sc.faces, sc.textures, cam, st)[0] == 0
+    ctx = R.Context(0)
+    ctx.set_async_depth(1); ctx.set_pipeline_depth(depth)
+    fb = R.Framebuffer(sc.width, sc.height, ctx); fb.clear(sc.clear_color)
+    rs = R.ResidentScene(fb, sc.vertices, sc.faces, sc.textures)
+    rs.render_async(cams[0], st); rs.finish()
+    for cam in cams[1:]:
+        rs.render_async(cam, st)
+    rs.finish()
+    assert ctx.route_counts()["pipelined"] == 3
+    assert np.array_equal(fb.pixels, ofb.pixels), f"{int((fb.pixels != ofb.pixels).sum())} bytes differ"
+    assert np.array_equal(fb.zbuffer.view(np.uint32), ofb.zbuffer.view(np.uint32))
+
+
 @pytest.mark.parametrize("gate,routes_off,depth", [(1150, 0, 2), (300, 0, 2), (0, 0, 2), (1000, 0, 2), (2000, 0, 2), (300, 64, 2),
                                                    (1150, 0, 3), (0, 0, 3), (1000, 0, 3), (300, 64, 3)])
 def test_two_frames_in_flight(oracle, gate, routes_off, depth):
