@@ -395,6 +395,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((P64 && NT =
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4), amdgpu_num_vgpr(56))) void k_cover_plain(FillArgs a_in) {
     cover_body<0, false, 512, false, false, true, 1>(a_in);
 }
+// (z-buffer mode without a shading pass: the plain setup kernel co-resides as on the painter's path)
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4), amdgpu_num_vgpr(56))) void k_cover_plain_z(FillArgs a_in) {
+    cover_body<0, false, 512, true, false, true, 1>(a_in);
+}
 // (game() / default() -- z-buffer mode with a shading pass -- in the straight-line form and under the same cap: 121 -> 112 VGPRs, 11 spilled.
 // Their setup kernel needs 70 registers, so nothing co-resides; the form itself and the cap are worth 1 % each, profiles/r05_lit_form_ab.txt)
 #ifndef B32_LIT_VGPR
@@ -469,6 +473,9 @@ static void launch_p64(hipStream_t s, const FillArgs& a_in, uint32_t ntiles, int
         if constexpr (!EXACT && !ZMODE) {
             if (first) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover_plain), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (straight) { hipLaunchKernelGGL(k_cover_plain, g, dim3(512), lds_n, s, a); return; }
+        } else if constexpr (!EXACT && ZMODE) {
+            if (first) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover_plain_z), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (straight) { hipLaunchKernelGGL(k_cover_plain_z, g, dim3(512), lds_n, s, a); return; }
         } else {
             if (first) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<0, EXACT, 512, ZMODE, false, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (straight) { hipLaunchKernelGGL((k_cover<0, EXACT, 512, ZMODE, false, true, 1>), g, dim3(512), lds_n, s, a); return; }
