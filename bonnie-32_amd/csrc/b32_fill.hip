@@ -392,7 +392,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((P64 && NT =
 // flight: C3 0.1166 -> 0.1129 ms/frame, C5 0.196 -> 0.185 on the same box, profiles/r05_vgpr112_ab.txt).  The uncapped body allocates 113.
 // amdgpu_num_vgpr counts HALF the unified VGPR+AGPR file on gfx90a and later (56 -> 112); it does not take a template-dependent value,
 // hence a kernel of its own.
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4), amdgpu_num_vgpr(56))) void k_cover_plain(FillArgs a_in) {
+#ifndef B32_PLAIN_CAP
+#define B32_PLAIN_CAP 56          // (48 = 96 VGPRs, room for two setup waves, 13 spilled: no different -- profiles/r05_vgpr_cap_96_104_112.txt)
+#endif
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4), amdgpu_num_vgpr(B32_PLAIN_CAP))) void k_cover_plain(FillArgs a_in) {
     cover_body<0, false, 512, false, false, true, 1>(a_in);
 }
 // (z-buffer mode without a shading pass: the plain setup kernel co-resides as on the painter's path)
