@@ -402,6 +402,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4), amdgpu_
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4), amdgpu_num_vgpr(56))) void k_cover_plain_z(FillArgs a_in) {
     cover_body<0, false, 512, true, false, true, 1>(a_in);
 }
+// (the 8-bit-per-channel target, render_mesh: painter's mode, general shading)
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4), amdgpu_num_vgpr(56))) void k_cover_plain8(FillArgs a_in) {
+    cover_body<0, false, 512, false, true, true, 2>(a_in);
+}
 // (game() / default() -- z-buffer mode with a shading pass -- in the straight-line form and under the same cap: 121 -> 112 VGPRs, 11 spilled.
 // Their setup kernel needs 70 registers, so nothing co-resides; the form itself and the cap are worth 1 % each, profiles/r05_lit_form_ab.txt)
 #ifndef B32_LIT_VGPR
@@ -482,6 +486,11 @@ static void launch_p64(hipStream_t s, const FillArgs& a_in, uint32_t ntiles, int
         } else {
             if (first) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<0, EXACT, 512, ZMODE, false, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (straight) { hipLaunchKernelGGL((k_cover<0, EXACT, 512, ZMODE, false, true, 1>), g, dim3(512), lds_n, s, a); return; }
+        }
+        if constexpr (!EXACT && !ZMODE && FMT8) {
+            if (first) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover_plain8), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipLaunchKernelGGL(k_cover_plain8, g, dim3(512), lds_n, s, a);
+            return;
         }
         hipLaunchKernelGGL((k_cover<0, EXACT, 512, ZMODE, FMT8, true, 2>), g, dim3(512), lds_n, s, a);
     } else if (wide) hipLaunchKernelGGL((k_cover<0, EXACT, 1024, ZMODE, FMT8, true>), g, dim3(1024), lds_w, s, a);

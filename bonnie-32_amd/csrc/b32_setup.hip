@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PLAIN == 1 
                                                WireTri* __restrict__ wire, const float* __restrict__ pos12, const float* __restrict__ attr12,
                                                uint32_t* __restrict__ face_of) {
     FrameParams fp_plain = fp_in;                 // (dead code unless PLAIN)
-    if (PLAIN) { fp_plain.ortho = 0; fp_plain.fixed_point = 1; fp_plain.has_fog = 0; fp_plain.wire_collect = 0; fp_plain.xray = 0; fp_plain.fmt8 = 0; fp_plain.batched = 0; }
+    if (PLAIN) { fp_plain.ortho = 0; fp_plain.fixed_point = 1; fp_plain.has_fog = 0; fp_plain.wire_collect = 0; fp_plain.xray = 0; fp_plain.batched = 0; }   // (fmt8 stays a run-time flag: one scalar test)
     if (PLAIN == 1) { fp_plain.shading = B32_SHADE_NONE; fp_plain.n_lights = 0; }
     const FrameParams& fp = PLAIN ? fp_plain : fp_in;
     __shared__ uint32_t wpart[4][6];
@@ -585,11 +585,11 @@ void launch_setup(hipStream_t s, const FrameParams& fp, const B32Vertex* verts, 
                   Ctrl* ctrl, WireTri* wire, int n_cu, const float* pos12, const float* attr12, uint32_t* face_of) {
     (void)n_cu;
     if (fp.nf == 0) return;
-    const bool plain = fp.fixed_point && !fp.ortho && !fp.has_fog && !fp.wire_collect && fp.shading == B32_SHADE_NONE && !fp.xray && !fp.fmt8 && !fp.batched;
+    const bool plain = fp.fixed_point && !fp.ortho && !fp.has_fog && !fp.wire_collect && fp.shading == B32_SHADE_NONE && !fp.xray && !fp.batched;
     // one face per thread: 52 VGPRs in the plain form = 8 waves per SIMD (two faces per thread with their loads issued up front: 73 VGPRs,
     // 43 us instead of 39 at 1 M faces; three: 49 us)
     const dim3 g1((fp.nf + 255) / 256);
-    const bool lit = fp.fixed_point && !fp.ortho && !fp.has_fog && !fp.wire_collect && fp.shading != B32_SHADE_NONE && !fp.xray && !fp.fmt8 && !fp.batched;
+    const bool lit = fp.fixed_point && !fp.ortho && !fp.has_fog && !fp.wire_collect && fp.shading != B32_SHADE_NONE && !fp.xray && !fp.batched;
     if (lit) hipLaunchKernelGGL((k_setup<1, 2>), g1, dim3(256), 0, s, fp, verts, faces, tex, lights, ls, mt, recs, db, shades, keys, spans, partials, ctrl, wire, pos12, attr12, face_of);
     else if (plain) hipLaunchKernelGGL((k_setup<1, 1>), g1, dim3(256), 0, s, fp, verts, faces, tex, lights, ls, mt, recs, db, shades, keys, spans, partials, ctrl, wire, pos12, attr12, face_of);
     else hipLaunchKernelGGL((k_setup<1, 0>), g1, dim3(256), 0, s, fp, verts, faces, tex, lights, ls, mt, recs, db, shades, keys, spans, partials, ctrl, wire, pos12, attr12, face_of);
