@@ -30,9 +30,9 @@ def one():
             ctx.set_pipeline_depth(int(os.environ["EXP_DEPTH"]))
         if os.environ.get("EXP_ROUTES"):
             ctx.set_routes(int(os.environ["EXP_ROUTES"]))          # e.g. base@EXP_ROUTES=64: the product build without two frames in flight
-        if os.environ.get("EXP_SETTINGS") == "game":               # base@EXP_SETTINGS=game: the reference's RasterSettings::game() (no golden hash: "ok" is false)
+        if os.environ.get("EXP_SETTINGS"):                         # base@EXP_SETTINGS=game | default: the reference's RasterSettings::game() / ::default() (no golden hash: "ok" is false)
             from bonnie32_amd import rtypes
-            sc.settings = rtypes.RasterSettings.game()
+            sc.settings = rtypes.RasterSettings.game() if os.environ["EXP_SETTINGS"] == "game" else rtypes.RasterSettings()
         fb = R.Framebuffer(sc.width, sc.height, ctx)
         rs = R.ResidentScene(fb, sc.vertices, sc.faces, indexed_textures=sc.indexed_textures)
         def fin():
