@@ -53,7 +53,7 @@ void b32_destroy(b32_ctx* c) {
                                                                     r.merged->d_consts, r.merged->d_texmask, r.merged->d_pos12, r.merged->d_atlas0 };
                                                    for (void* q : mp) if (q) (void)hipFree(q); delete r.merged; }
     for (FrameSet& a : c->alt) { free_alt(c, a); if (a.d_ctrl) (void)hipFree(a.d_ctrl); }
-    for (hipEvent_t e : { c->ev_main, c->ev_setup, c->ev_done, c->alt[0].ev_setup, c->alt[0].ev_done, c->alt[1].ev_setup, c->alt[1].ev_done }) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : { c->ev_main, c->ev_wbin, c->ev_setup, c->ev_done, c->alt[0].ev_setup, c->alt[0].ev_done, c->alt[1].ev_setup, c->alt[1].ev_done }) if (e) (void)hipEventDestroy(e);
     if (c->side) (void)hipStreamDestroy(c->side);
     if (c->ev_created) for (auto& fr : c->ev) for (auto& e : fr) if (e) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);

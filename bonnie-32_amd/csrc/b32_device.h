@@ -457,7 +457,8 @@ __device__ __forceinline__ float wire_t_fast(float kf, float Nf, float rN) {
     const float rem = __builtin_fmaf(-q, Nf, kf);
     return __builtin_fmaf(rem, rN, q);
 }
-void launch_wire(hipStream_t s, const WireArgs& a, bool back, bool front);
+void launch_wire(hipStream_t s, const WireArgs& a, bool back, bool front, bool binned = false);
+void launch_wire_bin(hipStream_t s, const WireArgs& a, bool back, bool front, bool early);
 // Sort-free fast path: tile lists (unordered) by a counting sort straight from k_setup's spans; false = not applicable (too many
 // tiles for the LDS histogram), the caller takes the keyed radix path.  With `keys` the lists are split by class
 // ([opaque..., transparent...], boundary in tile_mid) and a transparent part longer than blend_cap raises need_global_sort.

@@ -10,6 +10,9 @@
 // anything enqueued on the main stream that k_setup reads (uploads, packed streams, light lists, list-space memsets) -> the next
 // setup (ev_main, only when `side_dirty`).  The main stream always waits for the frame's setup before enqueue_frame returns, so a
 // synchronisation of the main stream still covers everything this context has in flight.
+#ifndef B32_WIRE_BIN_EARLY
+#define B32_WIRE_BIN_EARLY 1          // (0: k_wire_bin behind the fill on the main stream, as before)
+#endif
 #ifndef B32_EXP_NO_WIRE_PIPE
 #define B32_EXP_NO_WIRE_PIPE 0          // (1: frames with wireframe phases are not pipelined, as before round 5 -- their wire list was not part of the frame set)
 #endif
@@ -20,6 +23,7 @@ static void swap_with(b32_ctx* c, FrameSet& a) {
     std::swap(c->direct_lists, a.direct_lists); std::swap(c->cap_direct, a.cap_direct);
     std::swap(c->tile_fill, a.tile_fill); std::swap(c->cap_tile_fill, a.cap_tile_fill);
     std::swap(c->wire, a.wire); std::swap(c->cap_wire, a.cap_wire);
+    std::swap(c->wire_fill, a.wire_fill); std::swap(c->wire_lists, a.wire_lists); std::swap(c->cap_wire_tiles, a.cap_wire_tiles); std::swap(c->wire_grid, a.wire_grid);
     std::swap(c->d_ctrl, a.d_ctrl);
     std::swap(c->ev_setup, a.ev_setup); std::swap(c->ev_done, a.ev_done); std::swap(c->set_in_flight, a.in_flight);
 }
@@ -34,11 +38,11 @@ static void unrotate_sets(b32_ctx* c) {      // (an enqueue that failed between 
     swap_with(c, c->alt[0]);
 }
 extern "C" void free_alt(b32_ctx* c, FrameSet& a) {          // (the caller has drained both streams)
-    void* ptrs[] = { a.keys0, a.crecs, a.srecs, a.xrecs, a.spans, a.face_of, a.partials, a.shades, a.direct_lists, a.tile_fill, a.wire };
+    void* ptrs[] = { a.keys0, a.crecs, a.srecs, a.xrecs, a.spans, a.face_of, a.partials, a.shades, a.direct_lists, a.tile_fill, a.wire, a.wire_fill, a.wire_lists };
     for (void* q : ptrs) if (q) (void)hipFree(q);
     a.keys0 = nullptr; a.crecs = nullptr; a.srecs = nullptr; a.xrecs = nullptr; a.spans = nullptr; a.face_of = nullptr; a.partials = nullptr;
     a.shades = nullptr; a.cap_shades = 0; a.direct_lists = nullptr; a.cap_direct = 0; a.tile_fill = nullptr; a.cap_tile_fill = 0; a.cap_work = 0;
-    a.wire = nullptr; a.cap_wire = 0;
+    a.wire = nullptr; a.cap_wire = 0; a.wire_fill = nullptr; a.wire_lists = nullptr; a.cap_wire_tiles = 0; a.wire_grid = 0;
 }
 // side stream, events and the other sets' per-face buffers (sized like the current set's)
 static int pipeline_ensure(b32_ctx* c) {
@@ -48,6 +52,7 @@ static int pipeline_ensure(b32_ctx* c) {
         (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
         HIPCHK(c, hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, prio_least));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_wbin, hipEventDisableTiming));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_setup, hipEventDisableTiming));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
         for (FrameSet& a : c->alt) {
@@ -227,7 +232,7 @@ static int frame_buffers(b32_ctx* c, const FrameParams& fp, bool wire_back) {
             const unsigned long long grid = ((unsigned long long)c->width << 40) ^ ((unsigned long long)c->band_y0 << 20) ^ c->band_y1;
             if (grid != c->wire_grid) {
                 HIPCHK(c, hipMemsetAsync(c->wire_fill, 0, ((c->cap_wire_tiles + 2) * FILL_PAD + 64) * sizeof(uint32_t), s));
-                c->wire_grid = grid;
+                c->wire_grid = grid; c->side_dirty = true;          // (a pipelined frame bins on the side stream: behind this memset)
             }
         }
     }
@@ -500,6 +505,21 @@ int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st, const
             if (need) launch_gate(ss, c->alt[0].d_ctrl, need, 30000u /* 300 us */);      // alt[0]: the frame n_sets - 1 back (rotate_sets)
         }
     }
+    // (the wire kernels' arguments: known before the setup kernel is launched -- a pipelined frame bins its wire list on the side stream)
+    const bool wire_on = fp.wire_collect && c->nf;
+    bool wire_binned = false;
+    WireArgs wa{};
+    if (wire_on) {
+        wa.tris = c->wire; wa.nf = c->nf; wa.table_owner = c->wire_owner; wa.table_first = c->wire_first;
+        wa.table_mask = c->cap_wire_table ? (uint32_t)(c->cap_wire_table - 1) : 0;
+        wa.fb = c->fb; wa.zbuf = (c->zbuf && c->zbuf_valid) ? c->zbuf : nullptr;
+        wa.width = c->width; wa.height = c->height; wa.band_y0 = c->band_y0; wa.band_y1 = c->band_y1; wa.ctrl = c->d_ctrl;
+        if (!(c->route_off & B32_ROUTE_WIRE_TILES) && c->wire_fill && c->band_y1 > c->band_y0) {
+            wa.tile_yb = (c->band_y0 / WIRE_TH) * WIRE_TH; wa.tiles_x = (c->width + TILE_W - 1) / TILE_W;
+            wa.tiles_y = (c->band_y1 - wa.tile_yb + WIRE_TH - 1) / WIRE_TH;
+            if ((size_t)wa.tiles_x * wa.tiles_y <= c->cap_wire_tiles) { wa.tile_fill = c->wire_fill; wa.tile_lists = c->wire_lists; c->wire_tile_frames++; }
+        }
+    }
     if (prof_all) HIPCHK(c, hipEventRecord(ev[0], s));
     launch_setup(ss, fp, c->d_verts, c->d_faces, c->d_tex, c->d_lights, lset, c->frame_table, RecArrays{ c->crecs, c->srecs, c->xrecs }, r.db, c->shades, c->keys[0],
                  r.direct_bin ? nullptr : c->spans /* (direct binning: nobody reads the spans) */, c->partials, c->d_ctrl, c->wire, c->n_cu, pos12, attr12, c->face_of);
@@ -507,6 +527,11 @@ int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st, const
         hipError_t e1 = hipEventRecord(c->ev_setup, c->side);
         if (e1 == hipSuccess) e1 = hipStreamWaitEvent(s, c->ev_setup, 0);
         if (e1 != hipSuccess) { (void)hipStreamSynchronize(c->side); c->last_hip = (int)e1; return B32_E_HIP; }
+        if (wire_on && wa.tile_fill && B32_WIRE_BIN_EARLY) {       // (behind ev_setup: the fill does not wait for the binning)
+            launch_wire_bin(c->side, wa, wire_back, wire_front, true);
+            HIPCHK(c, hipEventRecord(c->ev_wbin, c->side));
+            wire_binned = true;
+        }
     }
     c->set_in_flight = true;
     if (prof_all) HIPCHK(c, hipEventRecord(ev[1], s));
@@ -555,18 +580,9 @@ int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st, const
     launch_fill(s, fa, c->n_cu, prof_fill ? ev[4] : nullptr);
 
     // ---- wireframe phases
-    if (fp.wire_collect && c->nf) {
-        WireArgs wa{};
-        wa.tris = c->wire; wa.nf = c->nf; wa.table_owner = c->wire_owner; wa.table_first = c->wire_first;
-        wa.table_mask = c->cap_wire_table ? (uint32_t)(c->cap_wire_table - 1) : 0;
-        wa.fb = c->fb; wa.zbuf = (c->zbuf && c->zbuf_valid) ? c->zbuf : nullptr;
-        wa.width = c->width; wa.height = c->height; wa.band_y0 = c->band_y0; wa.band_y1 = c->band_y1; wa.ctrl = c->d_ctrl;
-        if (!(c->route_off & B32_ROUTE_WIRE_TILES) && c->wire_fill && c->band_y1 > c->band_y0) {
-            wa.tile_yb = (c->band_y0 / WIRE_TH) * WIRE_TH; wa.tiles_x = (c->width + TILE_W - 1) / TILE_W;
-            wa.tiles_y = (c->band_y1 - wa.tile_yb + WIRE_TH - 1) / WIRE_TH;
-            if ((size_t)wa.tiles_x * wa.tiles_y <= c->cap_wire_tiles) { wa.tile_fill = c->wire_fill; wa.tile_lists = c->wire_lists; c->wire_tile_frames++; }
-        }
-        launch_wire(s, wa, wire_back, wire_front);
+    if (wire_on) {
+        if (wire_binned) HIPCHK(c, hipStreamWaitEvent(s, c->ev_wbin, 0));
+        launch_wire(s, wa, wire_back, wire_front, wire_binned);
     }
     if (prof_fill) { if (prof_all) HIPCHK(c, hipEventRecord(ev[5], s)); c->ev_frames++; }
     if (c->side) HIPCHK(c, hipEventRecord(c->ev_done, s));         // (the next setup kernel that writes this set waits for it)

@@ -35,6 +35,7 @@ struct FrameSet {
     uint32_t* direct_lists = nullptr; size_t cap_direct = 0;
     uint32_t* tile_fill = nullptr; size_t cap_tile_fill = 0;
     WireTri* wire = nullptr; size_t cap_wire = 0;           // (frames with wireframe phases: k_setup writes the wire list, the wire kernels behind the fill read it)
+    uint32_t *wire_fill = nullptr, *wire_lists = nullptr; size_t cap_wire_tiles = 0; unsigned long long wire_grid = 0;   // (... and its tile lists: binned beside the previous frame's fill)
     Ctrl* d_ctrl = nullptr;
     hipEvent_t ev_setup = nullptr, ev_done = nullptr;      // k_setup finished (side stream) / last fill reading this set finished (main stream)
     bool in_flight = false;                                  // a frame was enqueued on this set since the last b32_frame_finish
@@ -46,7 +47,7 @@ struct b32_ctx {
     int last_hip = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     // two frames in flight: the setup kernel of the next frame on `side` beside the fill of the current one on `stream`
-    hipStream_t side = nullptr; hipEvent_t ev_main = nullptr;
+    hipStream_t side = nullptr; hipEvent_t ev_main = nullptr, ev_wbin = nullptr;     // (ev_wbin: a pipelined frame's k_wire_bin finished on the side stream)
     FrameSet alt[2];                     // the other frame sets, oldest first (allocated on first use; alt[1] only with three sets)
     uint32_t n_sets = 2;                 // b32_set_pipeline_depth: 2 = setup(i+1) beside fill(i); 3 = setup(i+2) beside fill(i), so that the
                                          // setup kernel a fill waits for ended a whole fill ago (fills back to back; measured slower: the two

@@ -238,8 +238,8 @@ __device__ __forceinline__ bool wire_global(const WireArgs& a, const Edge& e) {
 // One lane per FACE: its (up to three) edges that take the tile route share one list entry per tile of the box around them -- a third of
 // the reservations an entry per edge would need (a returning device-scope atomic each).  k_wire_tile expands the entry again and lets
 // every edge take part only in the tiles of its OWN box, so all occurrences of an edge still meet in exactly the same tiles.
-__global__ void k_wire_bin(WireArgs a, uint32_t kinds) {           // kinds: bit 0 back-face edges, bit 1 front-face overlay
-    phase_stamp(a.ctrl, ST_WIRE);
+__global__ void k_wire_bin(WireArgs a, uint32_t kinds) {           // kinds: bit 0 back-face edges, bit 1 front-face overlay, bit 2: launched ahead of the fill (no phase stamp)
+    if (!(kinds & 4u)) phase_stamp(a.ctrl, ST_WIRE);
     const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= a.nf || a.ctrl->abort) return;
     const WireTri t = a.tris[f];
@@ -512,7 +512,15 @@ __global__ void k_wire_draw(WireArgs a) {
     }
 }
 
-void launch_wire(hipStream_t s, const WireArgs& a, bool back, bool front) {
+// The binning alone: it needs the wire list k_setup wrote and nothing of the fill, so a frame whose setup kernel runs on the side stream
+// bins there too, beside the previous frame's fill and wire kernels (early; launch_wire then skips it).  An abort the fill decides later
+// is harmless: k_wire_tile zeroes the counters again before it looks at the flag.
+void launch_wire_bin(hipStream_t s, const WireArgs& a, bool back, bool front, bool early) {
+    if (!a.nf || !(back || front) || !a.tile_fill || !(a.tiles_x * a.tiles_y)) return;
+    hipLaunchKernelGGL(k_wire_bin, dim3((a.nf + 255) / 256), dim3(256), 0, s, a, (back ? 1u : 0u) | (front ? 2u : 0u) | (early ? 4u : 0u));
+}
+
+void launch_wire(hipStream_t s, const WireArgs& a, bool back, bool front, bool binned) {
     if (!a.nf || !(back || front)) return;
     const uint32_t n = a.nf * 3, blocks = (n + 255) / 256;
     const uint32_t ntiles = a.tiles_x * a.tiles_y;
@@ -525,7 +533,7 @@ void launch_wire(hipStream_t s, const WireArgs& a, bool back, bool front) {
     // (tile route on: the global kernels usually have nothing to do -- 2048 workgroups that look at the flags and leave, or loop over
     // the edges left to them; tile route off: one lane per edge as before)
     const uint32_t gblocks = flags ? min(blocks, 2048u) : blocks;
-    if (tiles) hipLaunchKernelGGL(k_wire_bin, dim3((a.nf + 255) / 256), dim3(256), 0, s, a, (back ? 1u : 0u) | (front ? 2u : 0u));
+    if (tiles && !binned) launch_wire_bin(s, a, back, front, false);
     if (back) {
         hipLaunchKernelGGL(k_wire_table_clear, dim3(flags ? 256 : 1024), dim3(256), 0, s, a.table_owner, a.table_first, a.table_mask + 1, flags);
         hipLaunchKernelGGL(k_wire_insert, dim3(gblocks), dim3(256), 0, s, a);
