@@ -526,7 +526,6 @@ struct FillArgs {
     // stages both in LDS behind its tile planes and the shading phase looks the texel up there instead of fetching the expanded texel
     const uint8_t* atlas0;
     uint32_t atlas_idx_bytes;
-    uint32_t co_run;            // 1: a later frame's setup kernel is expected beside this fill (two frames in flight)
     uint32_t stagger;           // > 0: the second workgroup of every CU starts this many 10-ns ticks late (set by launch_fill, see k_cover)
     uint32_t span_cover;        // 1: sort-free CHEAP painter's coverage by exact row intervals (B32_ROUTE_SPAN_COVER, b32_fill.hip "span coverage")
     uint32_t prio64;            // 1: sort-free coverage -- visibility is a 64-bit max of (painter's key << 32 | face id); `vis` holds

@@ -403,7 +403,6 @@ static FillArgs fill_args(const b32_ctx* c, const FrameParams& fp, const Route& 
     fa.gather_blend = (r.prio64 && r.with_class) ? 1u : 0u;
     fa.stagger = (c->route_off & B32_ROUTE_STAGGER) ? 0u : 1u;       // (launch_fill decides whether the frame qualifies)
     fa.span_cover = (r.prio64 && !r.exact_cov && !fp.zmode && !(c->route_off & B32_ROUTE_SPAN_COVER)) ? 1u : 0u;
-    fa.co_run = (c->pipelined || (c->deep_async && c->pipe_hint && c->nf > 2048u && !(c->route_off & B32_ROUTE_PIPELINE))) ? 1u : 0u;   // (this frame's or the next one's setup kernel beside a fill)
     // index atlas + CLUT sampled from LDS: the fused kernel with one indexed texture, when they fit beside the tile planes of the
     // workgroup form launch_fill is going to choose (16 waves, one workgroup per CU: ~84 KB; two 8-wave workgroups per CU: ~6 KB)
     fa.atlas0 = c->d_atlas0; fa.atlas_idx_bytes = 0;
