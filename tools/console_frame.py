@@ -115,6 +115,23 @@ def gpu_frame_batched_nodl():
 t0 = time.perf_counter()
 for _ in range(N): gpu_frame_batched_nodl()
 t_bat2 = (time.perf_counter() - t0) / N
+# ... and without a host round trip per frame either (b32_set_async_depth(1): frames enqueued back to back, one b32_frame_finish at the end;
+# what a device-side presenter sees -- the host enqueues frame i + 1 while the GPU draws frame i)
+ctx.set_async_depth(1)
+def gpu_frame_batched_async():
+    fb.clear(clear)
+    ctx.frame_begin(meshes[0].camera, st)
+    for rs in slots:
+        ctx.frame_add(rs, fog=fog)
+    ctx.frame_end()
+for _ in range(3): gpu_frame_batched_async()
+ctx.finish()
+t0 = time.perf_counter()
+for _ in range(N): gpu_frame_batched_async()
+ctx.finish()
+t_bat3 = (time.perf_counter() - t0) / N
+ok_bat3 = np.array_equal(fb.pixels, ofb.pixels) and np.array_equal(fb.zbuffer.view(np.uint32), ofb.zbuffer.view(np.uint32))
+ctx.set_async_depth(0)
 gpu_frame()
 ok = np.array_equal(fb.pixels, ofb.pixels) and np.array_equal(fb.zbuffer.view(np.uint32), ofb.zbuffer.view(np.uint32))
 tris = sum(sc.n_tris for sc in meshes)
@@ -122,4 +139,4 @@ print(f"console frame: {n_meshes} meshes, {tris} triangles, {W}x{H}, game() + po
       f"GPU drop-in calls + frame download {t_gpu*1e3:.3f} ms ({t_cpu/t_gpu:.1f}x), {t_gpu/n_meshes*1e6:.0f} us per mesh, bit-exact: {ok}; "
       f"rooms resident in scene slots {t_res*1e3:.3f} ms ({t_cpu/t_res:.1f}x), {t_res/n_meshes*1e6:.0f} us per mesh, bit-exact: {ok_res}; "
       f"opaque runs merged ({len(groups)} draws) {t_mrg*1e3:.3f} ms ({t_cpu/t_mrg:.1f}x), bit-exact: {ok_mrg}; "
-      f"b32_frame_begin/add_scene/end ({bc['merged_draws'] // (N + 2)} merged draws per frame) {t_bat*1e3:.3f} ms with the frame download, {t_bat2*1e3:.3f} ms without ({t_cpu/t_bat2:.1f}x), bit-exact: {ok_bat}")
+      f"b32_frame_begin/add_scene/end ({bc['merged_draws'] // (N + 2)} merged draws per frame) {t_bat*1e3:.3f} ms with the frame download, {t_bat2*1e3:.3f} ms without ({t_cpu/t_bat2:.1f}x), bit-exact: {ok_bat}; frames back to back without a host round trip each {t_bat3*1e3:.3f} ms ({t_cpu/t_bat3:.1f}x), bit-exact: {ok_bat3}")
