@@ -529,6 +529,45 @@ def test_pipeline_depth_argument_range():
         assert e.value.code == b32.abi.B32_E_ARG
 
 
+@pytest.mark.parametrize("mode", ["8bit", "zbuffer", "game"])
+def test_capped_fill_forms_two_in_flight(oracle, mode):
+    """The fills that run under the 112-VGPR cap beside the next frame's setup kernel (round 5: k_cover_plain8, k_cover_plain_z,
+    k_cover_lit with k_setup<1, 2>), on a mesh large enough for direct binning and two frames in flight: the 8-bit path in painter's
+    mode (render_mesh, render.rs:1971-2264), z-buffer mode without a shading pass, and RasterSettings::game() (types.rs:1455-1460).
+    Five cameras back to back, a clear before each in painter's mode, none in the z-buffer modes (colour and depth accumulate)."""
+    from bonnie32_amd import rasterizer as R
+    sc = scenegen.make_scene("C3", n_tris=60_000, width=1920, height=1440, bbox_px=120.0, seed=515, variant="gouraud")
+    cams = [b32.Camera(position=(30.0 * i, -18.0 * i, -260.0 * i)) for i in range(5)]
+    if mode == "8bit":
+        st = b32.RasterSettings.benchmark(); st.use_rgb555 = False
+        tex8 = [b32.Texture.from_texture15(t) for t in sc.textures]
+    elif mode == "zbuffer":
+        st = b32.RasterSettings.benchmark(); st.use_zbuffer = True
+    else:
+        st = b32.RasterSettings.game()
+    ofb = oracle.Framebuffer(sc.width, sc.height); ofb.clear(sc.clear_color)
+    for cam in cams:
+        if mode == "8bit":
+            ofb.clear(sc.clear_color)
+            assert oracle.render_mesh(ofb, sc.vertices, sc.faces, tex8, cam, st)[0] == 0
+        else:
+            assert oracle.render_mesh_15(ofb, sc.vertices, sc.faces, sc.textures, cam, st)[0] == 0
+    ctx = R.Context(0)
+    ctx.set_async_depth(1)
+    fb = R.Framebuffer(sc.width, sc.height, ctx); fb.clear(sc.clear_color)
+    rs = R.ResidentScene(fb, sc.vertices, sc.faces, textures8=tex8) if mode == "8bit" else R.ResidentScene(fb, sc.vertices, sc.faces, sc.textures)
+    if mode == "8bit": fb.clear(sc.clear_color)
+    rs.render_async(cams[0], st); rs.finish()
+    for cam in cams[1:]:
+        if mode == "8bit": fb.clear(sc.clear_color)
+        rs.render_async(cam, st)
+    rs.finish()
+    assert ctx.route_counts()["pipelined"] == 3
+    assert np.array_equal(fb.pixels, ofb.pixels), f"{int((fb.pixels != ofb.pixels).sum())} bytes differ"
+    if mode != "8bit":
+        assert np.array_equal(fb.zbuffer.view(np.uint32), ofb.zbuffer.view(np.uint32))
+
+
 @pytest.mark.parametrize("depth", [2, 3])
 def test_wireframe_frames_two_in_flight(oracle, depth):
     """RasterSettings::default() (back-face wireframe, types.rs:1475-1495) on a large mesh, frames back to back: since round 5 the wire list
