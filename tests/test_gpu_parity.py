@@ -569,6 +569,38 @@ def test_capped_fill_forms_two_in_flight(oracle, mode):
 
 
 @pytest.mark.parametrize("depth", [2, 3])
+def test_mixed_settings_back_to_back(oracle, depth):
+    """Frames of one large resident mesh enqueued back to back with DIFFERENT settings from frame to frame -- default() (back-face
+    wireframe), game(), z-buffer without a shading pass, wireframe overlay, flat shading -- so that consecutive frames take different
+    forms of both kernels, frames with and without wire lists alternate on the frame sets, and the wire binning runs on the side stream
+    for some frames and not at all for others.  All in z-buffer mode without a clear: every frame's colour, depth and wire pixels stay."""
+    from bonnie32_amd import rasterizer as R
+    sc = scenegen.make_scene("C3", n_tris=60_000, width=1920, height=1440, bbox_px=120.0, seed=909, variant="gouraud")
+    def zb():
+        st = b32.RasterSettings.benchmark(); st.use_zbuffer = True; return st
+    def overlay():
+        st = b32.RasterSettings.game(); st.wireframe_overlay = True; return st
+    def flat():
+        st = b32.RasterSettings.game(); st.shading = b32.abi.SHADE_FLAT; return st
+    seq = [b32.RasterSettings(), b32.RasterSettings.game(), zb(), b32.RasterSettings(), overlay(), flat(), b32.RasterSettings(), zb()]
+    cams = [b32.Camera(position=(25.0 * i, -15.0 * i, -220.0 * i)) for i in range(len(seq))]
+    ofb = oracle.Framebuffer(sc.width, sc.height); ofb.clear(sc.clear_color)
+    for cam, st in zip(cams, seq):
+        assert oracle.render_mesh_15(ofb, sc.vertices, sc.faces, sc.textures, cam, st)[0] == 0
+    ctx = R.Context(0)
+    ctx.set_async_depth(1); ctx.set_pipeline_depth(depth)
+    fb = R.Framebuffer(sc.width, sc.height, ctx); fb.clear(sc.clear_color)
+    rs = R.ResidentScene(fb, sc.vertices, sc.faces, sc.textures)
+    rs.render_async(cams[0], seq[0]); rs.finish()
+    for cam, st in zip(cams[1:], seq[1:]):
+        rs.render_async(cam, st)
+    rs.finish()
+    assert ctx.route_counts()["pipelined"] >= 4
+    assert np.array_equal(fb.pixels, ofb.pixels), f"{int((fb.pixels != ofb.pixels).sum())} bytes differ"
+    assert np.array_equal(fb.zbuffer.view(np.uint32), ofb.zbuffer.view(np.uint32))
+
+
+@pytest.mark.parametrize("depth", [2, 3])
 def test_wireframe_frames_two_in_flight(oracle, depth):
     """RasterSettings::default() (back-face wireframe, types.rs:1475-1495) on a large mesh, frames back to back: since round 5 the wire list
     k_setup writes is part of the frame set, so these frames run two in flight as well -- the next frame's setup kernel beside this
