@@ -320,9 +320,9 @@ static int frame_positions(b32_ctx* c, const FrameParams& fp, const float*& pos1
     (void)fp;
     if (c->nv && c->nf > 8192u && !(c->route_off & B32_ROUTE_PACKED_STREAMS)) {
         if (!c->pos_valid && c->band_frames >= 1) {
-            if ((size_t)c->nv * 9 > c->cap_pos12 || !c->d_pos12) {       // three streams of 12 B per vertex, one behind the other
-                if ((rc = ensure_plain(c, c->d_pos12, (size_t)c->nv * 9 + 16))) return rc;
-                c->cap_pos12 = (size_t)c->nv * 9;
+            if ((size_t)c->nv * 12 > c->cap_pos12 || !c->d_pos12) {      // three streams per vertex, one behind the other: 12 B, 12 B, 24 B
+                if ((rc = ensure_plain(c, c->d_pos12, (size_t)c->nv * 12 + 16))) return rc;
+                c->cap_pos12 = (size_t)c->nv * 12;
             }
             launch_pack_streams(c->stream, c->d_verts, c->nv, c->d_pos12, c->d_pos12 + (size_t)c->nv * 3);
             c->pos_valid = true; c->side_dirty = true;

@@ -232,7 +232,7 @@ __device__ __forceinline__ uint32_t agg_position(const AggSlot& g) {
 // occupancy-bound (profiles/r05_lit_setup_ab.txt).  (Compiled for 8 waves -- 64 registers, what would let one of its waves sit beside four
 // waves of the capped z-buffer fill -- it spills 23-31 VGPRs and takes 105 us instead of 78: not done.)
 #ifndef B32_LIT_SETUP_WAVES
-#define B32_LIT_SETUP_WAVES 7
+#define B32_LIT_SETUP_WAVES 6
 #endif
 template <int SETUP_FPT, int PLAIN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PLAIN == 1 ? 8 : (PLAIN == 2 ? B32_LIT_SETUP_WAVES : 4), PLAIN == 1 ? 8 : (PLAIN == 2 ? B32_LIT_SETUP_WAVES : 5)))) void k_setup(FrameParams fp_in, const B32Vertex* __restrict__ verts, const B32Face* __restrict__ faces,
@@ -399,12 +399,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PLAIN == 1 
                 bool slow = !fp.fixed_point || fp.ortho;
                 bool needs_dither = false;
                 r.inv_area = 0.0f; r.w0_start = r.w1_start = 0.0f; r.flags = 0;
+                // (the world normals of a lit frame are requested HERE, with the attributes, and used at the very end: behind the record
+                // build their round trip is hidden -- requested where they are used it was 12 of the lit kernel's 77 us, measured by
+                // replacing them with a constant)
+                V3 wn[3] = { { 0.0f, 0.0f, 0.0f }, { 0.0f, 0.0f, 0.0f }, { 0.0f, 0.0f, 0.0f } };
                 if (need_rec) {
-                if (pos12) {          // packed streams: the survivor's UVs and vertex colours only now (12 B per vertex, culled faces never fetch them)
+                if (pos12 && fp.shading != B32_SHADE_NONE) {
+                    // packed streams, lit frame: attributes AND normal of a vertex from the 24-byte stream (one cache line per face instead
+                    // of one in the attribute stream and one in a normal stream of its own: 12 of the lit kernel's 77 us)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const float* lp = attr12 + (size_t)fp.nv * 3 + (size_t)vi[j] * 6;
+                        uvx[j] = lp[0]; uvy[j] = lp[1]; col[j] = reinterpret_cast<const uint32_t*>(lp)[2];
+                        wn[j] = { lp[3], lp[4], lp[5] };
+                    }
+                } else if (pos12) {   // packed streams: the survivor's UVs and vertex colours only now (12 B per vertex, culled faces never fetch them)
 #pragma unroll
                     for (int j = 0; j < 3; ++j) {
                         const float* ap = attr12 + (size_t)vi[j] * 3;
                         uvx[j] = ap[0]; uvy[j] = ap[1]; col[j] = reinterpret_cast<const uint32_t*>(ap)[2];
+                    }
+                } else if (fp.shading != B32_SHADE_NONE) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const float* np = reinterpret_cast<const float*>(verts) + (size_t)vi[j] * 9 + 5;
+                        wn[j] = { np[0], np[1], np[2] };
                     }
                 }
                 if (fp.has_fog && m_has_fog) {
@@ -522,14 +541,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PLAIN == 1 
                 }
                 // (the shades last: the record's values are stored and dead by now, the lighting has the registers to itself)
                 if (need_rec && fp.shading != B32_SHADE_NONE) {
-                    V3 wn[3];
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        // (packed streams: the normals are the third one, behind the attributes)
-                        const float* np = pos12 ? attr12 + ((size_t)fp.nv + vi[j]) * 3 : reinterpret_cast<const float*>(verts) + (size_t)vi[j] * 9 + 5;
-                        wn[j] = { np[0], np[1], np[2] };
-                        if (backface) wn[j] = scale3(wn[j], -1.0f);
-                    }
+                    for (int j = 0; j < 3; ++j) if (backface) wn[j] = scale3(wn[j], -1.0f);
                     float* sh = shades + (size_t)rslot * 9;
                     if (fp.shading == B32_SHADE_FLAT) {                                             // :1466-1469
                         V3 center = scale3(add3(add3(wpos[i1], wpos[i2]), wpos[i3]), 1.0f / 3.0f);
@@ -760,17 +773,17 @@ __global__ __launch_bounds__(256) void k_upload(const uint4* __restrict__ arena,
 }
 // Packed vertex streams of a resident scene (structure of arrays, built once from the uploaded B32Vertex array): positions, 12 bytes
 // each, which k_setup reads for EVERY face, and (u, v, rgba), 12 bytes each, which it reads only for the faces that survive the cull
-// (and, on a band-sharded frame, reach this rank's rows).  The normals, 12 bytes each, follow the attributes (attr12 + 3 * nv floats):
-// lit frames read them for the surviving faces -- out of the 36-byte B32Vertex a wave of neighbouring faces pulls every sector of the
+// (and, on a band-sharded frame, reach this rank's rows).  A third stream of 24 bytes per vertex follows the attributes (attr12 + 3 * nv
+// floats): attributes and normal together, what lit frames read for the surviving faces -- out of the 36-byte B32Vertex a wave of neighbouring faces pulls every sector of the
 // vertex array for a third of its bytes.
 __global__ void k_pack_streams(const B32Vertex* __restrict__ verts, uint32_t nv, float* __restrict__ pos12, float* __restrict__ attr12) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nv) return;
     const float* vp = reinterpret_cast<const float*>(verts) + (size_t)i * 9;
-    float* nrm12 = attr12 + 3 * (size_t)nv;
+    float* lit24 = attr12 + 3 * (size_t)nv + 6 * (size_t)i;
     pos12[3 * (size_t)i] = vp[0]; pos12[3 * (size_t)i + 1] = vp[1]; pos12[3 * (size_t)i + 2] = vp[2];
     attr12[3 * (size_t)i] = vp[3]; attr12[3 * (size_t)i + 1] = vp[4]; attr12[3 * (size_t)i + 2] = vp[8];      // u, v, rgba (bit copy)
-    nrm12[3 * (size_t)i] = vp[5]; nrm12[3 * (size_t)i + 1] = vp[6]; nrm12[3 * (size_t)i + 2] = vp[7];
+    lit24[0] = vp[3]; lit24[1] = vp[4]; lit24[2] = vp[8]; lit24[3] = vp[5]; lit24[4] = vp[6]; lit24[5] = vp[7];   // the same + the normal
 }
 void launch_pack_streams(hipStream_t s, const B32Vertex* verts, uint32_t nv, float* pos12, float* attr12) {
     if (nv) hipLaunchKernelGGL(k_pack_streams, dim3((nv + 255) / 256), dim3(256), 0, s, verts, nv, pos12, attr12);
