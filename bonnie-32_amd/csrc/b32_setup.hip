@@ -228,7 +228,7 @@ __device__ __forceinline__ uint32_t agg_position(const AggSlot& g) {
 // code in this file, i.e. on 7 or 8 waves and on schedules between 46 and 63 us at 1 M faces -- measured; the general form keeps its 5)
 // PLAIN == 2 (round 5): the plain form with a shading pass -- RasterSettings::game() (types.rs:1455-1460): Gouraud or flat shades from the
 // frame's lights, everything else as in PLAIN == 1.  With the lighting moved behind the record stores (the record's values are dead by
-// then) it needs 70 VGPRs instead of 95 and is compiled for 7 waves per SIMD; the kernel gains 3 us of 81 at 1 M faces -- it is not
+// then) it needs 70 VGPRs instead of 95 (80 with the normals requested early: compiled for 6 waves per SIMD); 3 us of 81 at 1 M faces -- it is not
 // occupancy-bound (profiles/r05_lit_setup_ab.txt).  (Compiled for 8 waves -- 64 registers, what would let one of its waves sit beside four
 // waves of the capped z-buffer fill -- it spills 23-31 VGPRs and takes 105 us instead of 78: not done.)
 #ifndef B32_LIT_SETUP_WAVES
