@@ -182,7 +182,7 @@ struct Ctrl {
 struct Stamps { unsigned long long t[8]; };
 // Rare events of k_setup under direct binning, behind Stamps: each word holds the EPOCH (frame number, never 0) of the last frame the
 // event happened in, so nothing has to be reset between frames and k_setup's own frame-start reset of Ctrl cannot race with them.
-struct Events { uint32_t bad_index, nan_opaque, nan_transparent, overflow, long_transparent, _pad[3]; };
+struct Events { uint32_t bad_index, nan_opaque, nan_transparent, overflow, long_transparent, setup_done /* k_flag -> k_join: epoch of the frame whose setup kernel has finished */, _pad[2]; };
 __device__ __forceinline__ Events* events_of(Ctrl* ctrl) { return reinterpret_cast<Events*>(reinterpret_cast<unsigned char*>(ctrl) + 128); }
 enum { ST_SETUP = 0, ST_BIN = 1, ST_FILL = 2, ST_WIRE = 3, ST_END = 4,
        ST_CLK0 = 5, ST_CLK1 = 6, ST_CLKW = 7 };   // shader-cycle counter at the start / end of workgroup 0 of the fused kernel, wall clock at its end
@@ -405,6 +405,8 @@ void launch_setup(hipStream_t s, const FrameParams& fp, const B32Vertex* verts, 
                   const B32Light* lights, const LightSet& inline_lights, const MeshTable& mesh_table, RecArrays recs, const DirectBin& direct, float* shades, uint32_t* keys, uint32_t* spans,
                   uint32_t* partials, Ctrl* ctrl, WireTri* wire, int n_cu, const float* pos12, const float* attr12, uint32_t* face_of);
 void launch_gate(hipStream_t s, const Ctrl* prev, uint32_t need, uint32_t patience_ticks);
+void launch_flag(hipStream_t s, Ctrl* ctrl, uint32_t epoch);
+void launch_join(hipStream_t s, Ctrl* ctrl, uint32_t epoch, uint32_t patience_ticks);
 void launch_pack_streams(hipStream_t s, const B32Vertex* verts, uint32_t nv, float* pos12, float* attr12);
 void launch_project_fixed(hipStream_t s, const float* pos, uint32_t n, B32Camera cam, uint32_t w, uint32_t h,
                           int32_t* sx, int32_t* sy, float* z);

@@ -10,6 +10,9 @@
 // anything enqueued on the main stream that k_setup reads (uploads, packed streams, light lists, list-space memsets) -> the next
 // setup (ev_main, only when `side_dirty`).  The main stream always waits for the frame's setup before enqueue_frame returns, so a
 // synchronisation of the main stream still covers everything this context has in flight.
+#ifndef B32_JOIN_KERNEL
+#define B32_JOIN_KERNEL 1            // (0: the fill waits for its setup kernel through a cross-stream event, as before)
+#endif
 #ifndef B32_WIRE_BIN_EARLY
 #define B32_WIRE_BIN_EARLY 1          // (0: k_wire_bin behind the fill on the main stream, as before)
 #endif
@@ -522,10 +525,23 @@ int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st, const
     if (prof_all) HIPCHK(c, hipEventRecord(ev[0], s));
     launch_setup(ss, fp, c->d_verts, c->d_faces, c->d_tex, c->d_lights, lset, c->frame_table, RecArrays{ c->crecs, c->srecs, c->xrecs }, r.db, c->shades, c->keys[0],
                  r.direct_bin ? nullptr : c->spans /* (direct binning: nobody reads the spans) */, c->partials, c->d_ctrl, c->wire, c->n_cu, pos12, attr12, c->face_of);
-    if (c->pipelined) {
+    if (c->pipelined && c->join_stream != s) {
+        // Streams of different priorities never share a hardware queue (the runtime pools its queues by priority); two streams of ONE
+        // priority may, and k_join in front of k_flag in the same queue would wait for its patience: those keep the event.
+        int pm = 0, ps = 0;
+        c->join_ok = hipStreamGetPriority(s, &pm) == hipSuccess && hipStreamGetPriority(c->side, &ps) == hipSuccess && pm != ps;
+        c->join_stream = s;
+    }
+    if (c->pipelined && B32_JOIN_KERNEL && r.direct_bin && c->join_ok) {
+        // (no cross-stream event on the fill's path: see k_flag / k_join)
+        launch_flag(c->side, c->d_ctrl, c->epoch);
+        launch_join(s, c->d_ctrl, c->epoch, 10000000u /* 100 ms */);
+    } else if (c->pipelined) {
         hipError_t e1 = hipEventRecord(c->ev_setup, c->side);
         if (e1 == hipSuccess) e1 = hipStreamWaitEvent(s, c->ev_setup, 0);
         if (e1 != hipSuccess) { (void)hipStreamSynchronize(c->side); c->last_hip = (int)e1; return B32_E_HIP; }
+    }
+    if (c->pipelined) {
         if (wire_on && wa.tile_fill && B32_WIRE_BIN_EARLY) {       // (behind ev_setup: the fill does not wait for the binning)
             launch_wire_bin(c->side, wa, wire_back, wire_front, true);
             HIPCHK(c, hipEventRecord(c->ev_wbin, c->side));
@@ -745,6 +761,7 @@ int b32_frame_finish(b32_ctx* c, B32Timings* out) {
     if ((sticky >> 8) && c->deep_async) return B32_E_FRAME_DROPPED;
     if (c->h_ctrl.err_index || (sticky & 1u)) return B32_E_INDEX;
     if (c->h_ctrl.abort || (sticky & 2u)) return B32_E_NAN_KEY;
+    if (sticky & 8u) return B32_E_HIP;                         // (k_join gave up on a setup kernel: internal)
     if (c->h_ctrl.wire_overflow || (sticky & 4u)) return B32_E_UNSUPPORTED;     // an edge >= 2^30 px long: i32 overflow in the reference's Bresenham
     if (out) {
         out->triangles_drawn = c->h_ctrl.n_visible;

@@ -54,6 +54,7 @@ struct b32_ctx {
                                          // kernels then share the CUs all the time and the frame is bound by their summed VALU work)
     hipEvent_t ev_setup = nullptr, ev_done = nullptr; bool set_in_flight = false;     // (members of the current set, see FrameSet)
     bool side_dirty = true;              // something k_setup reads was written on `stream` since the side stream last waited for it
+    hipStream_t join_stream = nullptr; bool join_ok = false;   // k_flag / k_join instead of an event: only while `stream` and `side` have DIFFERENT priorities (then they never share a hardware queue); checked per main stream
     uint32_t gate_permille = 1150;       // b32_set_pipeline_gate: hold the next setup kernel until the previous fill has handed out 15 % of the tiles behind its first round
     bool pipe_hint = true;               // the previous frame's route could use the second frame set
     struct CoverOf { const Ctrl* ctrl; uint32_t tiles, groups; } cover_of[3] = {};   // the same per frame set (keyed by its control block): the gate polls the

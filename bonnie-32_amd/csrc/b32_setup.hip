@@ -655,6 +655,24 @@ __global__ void k_gate(const Ctrl* __restrict__ prev, uint32_t need, uint32_t pa
         __builtin_amdgcn_s_sleep(64);
     }
 }
+// The hand-over setup(i + 1) -> fill(i + 1) between the two streams without a cross-stream event (whose barrier packet costs the main
+// stream ~12 us even when the event is long signalled): k_flag, one lane on the side stream BEHIND the setup kernel, publishes the frame's
+// epoch; k_join, one lane on the main stream in FRONT of the fill, returns when it reads that epoch.  Kernel boundaries do the cache
+// maintenance: k_flag starts after the setup kernel's end-of-kernel release, the fill starts with its own acquire after k_join.  Neither
+// holds anything the other needs (k_join follows the previous fill on its stream, so the GPU is the setup kernel's while it spins); a
+// setup kernel that never arrives (patience: 100 ms) aborts the frame and is reported by b32_frame_finish (sticky bit 3).
+__global__ void k_flag(Ctrl* __restrict__ ctrl, uint32_t epoch) {
+    __hip_atomic_exchange(&events_of(ctrl)->setup_done, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void k_join(Ctrl* __restrict__ ctrl, uint32_t epoch, uint32_t patience) {
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_fetch_add(&events_of(ctrl)->setup_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+        if (wall_clock64() - t0 > patience) { atomicOr(&ctrl->sticky, 8u); ctrl->abort = 1; return; }
+        __builtin_amdgcn_s_sleep(4);
+    }
+}
+void launch_flag(hipStream_t s, Ctrl* ctrl, uint32_t epoch) { hipLaunchKernelGGL(k_flag, dim3(1), dim3(1), 0, s, ctrl, epoch); }
+void launch_join(hipStream_t s, Ctrl* ctrl, uint32_t epoch, uint32_t patience) { hipLaunchKernelGGL(k_join, dim3(1), dim3(1), 0, s, ctrl, epoch, patience); }
 void launch_gate(hipStream_t s, const Ctrl* prev, uint32_t need, uint32_t patience) {
     hipLaunchKernelGGL(k_gate, dim3(1), dim3(1), 0, s, prev, need, patience);
 }
