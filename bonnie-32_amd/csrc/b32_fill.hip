@@ -407,7 +407,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4), amdgpu_
     cover_body<0, false, 512, false, true, true, 2>(a_in);
 }
 // (game() / default() -- z-buffer mode with a shading pass -- in the straight-line form and under the same cap: 121 -> 112 VGPRs, 11 spilled.
-// Their setup kernel needs 70 registers, so nothing co-resides; the form itself and the cap are worth 1 % each, profiles/r05_lit_form_ab.txt)
+// Their setup kernel needs 70-80 registers, so nothing co-resides; the form itself and the cap are worth 1 % each, profiles/r05_lit_form_ab.txt)
 #ifndef B32_LIT_VGPR
 #define B32_LIT_VGPR 56
 #endif

@@ -10,6 +10,10 @@
 // anything enqueued on the main stream that k_setup reads (uploads, packed streams, light lists, list-space memsets) -> the next
 // setup (ev_main, only when `side_dirty`).  The main stream always waits for the frame's setup before enqueue_frame returns, so a
 // synchronisation of the main stream still covers everything this context has in flight.
+#ifndef B32_JOIN_NOT_BATCHED
+#define B32_JOIN_NOT_BATCHED 1     // (the merged runs of a batched frame keep the event: their kernels are so short that the two extra launches cost what the
+                                   // barrier packet did -- console frame 0.268-0.275 against 0.264-0.265 ms)
+#endif
 #ifndef B32_JOIN_KERNEL
 #define B32_JOIN_KERNEL 1            // (0: the fill waits for its setup kernel through a cross-stream event, as before)
 #endif
@@ -532,7 +536,7 @@ int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st, const
         c->join_ok = hipStreamGetPriority(s, &pm) == hipSuccess && hipStreamGetPriority(c->side, &ps) == hipSuccess && pm != ps;
         c->join_stream = s;
     }
-    if (c->pipelined && B32_JOIN_KERNEL && r.direct_bin && c->join_ok) {
+    if (c->pipelined && B32_JOIN_KERNEL && r.direct_bin && c->join_ok && !(c->frame_batched && B32_JOIN_NOT_BATCHED)) {
         // (no cross-stream event on the fill's path: see k_flag / k_join)
         launch_flag(c->side, c->d_ctrl, c->epoch);
         launch_join(s, c->d_ctrl, c->epoch, 10000000u /* 100 ms */);
