@@ -539,7 +539,7 @@ int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st, const
     if (c->pipelined && B32_JOIN_KERNEL && r.direct_bin && c->join_ok && !(c->frame_batched && B32_JOIN_NOT_BATCHED)) {
         // (no cross-stream event on the fill's path: see k_flag / k_join)
         launch_flag(c->side, c->d_ctrl, c->epoch);
-        launch_join(s, c->d_ctrl, c->epoch, 10000000u /* 100 ms */);
+        launch_join(s, c->d_ctrl, c->epoch, 200000000u /* 2 s: a last resort -- queues of an oversubscribed GPU are time-sliced in milliseconds */);
     } else if (c->pipelined) {
         hipError_t e1 = hipEventRecord(c->ev_setup, c->side);
         if (e1 == hipSuccess) e1 = hipStreamWaitEvent(s, c->ev_setup, 0);
