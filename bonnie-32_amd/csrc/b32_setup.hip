@@ -660,7 +660,7 @@ __global__ void k_gate(const Ctrl* __restrict__ prev, uint32_t need, uint32_t pa
 // epoch; k_join, one lane on the main stream in FRONT of the fill, returns when it reads that epoch.  Kernel boundaries do the cache
 // maintenance: k_flag starts after the setup kernel's end-of-kernel release, the fill starts with its own acquire after k_join.  Neither
 // holds anything the other needs (k_join follows the previous fill on its stream, so the GPU is the setup kernel's while it spins); a
-// setup kernel that never arrives (patience: 100 ms) aborts the frame and is reported by b32_frame_finish (sticky bit 3).
+// setup kernel that never arrives (patience: 2 s) aborts the frame and is reported by b32_frame_finish (sticky bit 3).
 __global__ void k_flag(Ctrl* __restrict__ ctrl, uint32_t epoch) {
     __hip_atomic_exchange(&events_of(ctrl)->setup_done, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
