@@ -57,6 +57,12 @@ def main():
                          "gather of one overlaps the rendering of the next, after a run-time self-check against the synchronous frame)")
     ap.add_argument("--pipeline-debug", action="store_true",
                     help="with --dist-backend gloo: run the overlapped-gather logic too (band rows staged through the host)")
+    ap.add_argument("--transport", default="shm", choices=["shm", "rccl", "torch"],
+                    help="N > 1: how the band rows reach rank 0.  shm (default) = the library's shared-framebuffer transport (b32_band_export / _import, "
+                         "device-side epoch words: band ranks store their rows straight into rank 0's HBM); rccl = b32_gather_bands_rccl (grouped "
+                         "ncclSend / ncclRecv on the frame's stream, communicator from b32_rccl_comm_create); torch = torch.distributed gather "
+                         "(bonnie32_amd.parallel).  shm / rccl are what a host that only speaks the C ABI calls; either falls back to torch -- and the "
+                         "line says so -- when its set-up or its run-time self-check against the torch-gathered frame fails")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default). gloo = debug only: ranks may share one GPU, band rows are staged through the host")
     args = ap.parse_args()
@@ -88,7 +94,7 @@ def main():
         g.build()
     if world > 1:
         dist.barrier()
-    from bonnie32_amd import rasterizer as R, scenegen, parallel, abi
+    from bonnie32_amd import rasterizer as R, scenegen, parallel, abi, exchange as X
     build_digest = abi.check_build_digest()      # refuses a library that was not compiled from this tree's sources
     HASHES = json.load(open(os.path.join(ROOT, "tests", "golden", "hashes.json")))
 
@@ -118,20 +124,33 @@ def main():
     h2d_ms = (time.perf_counter() - u0) * 1e3
     h2d_bytes = sc.vertices.nbytes + sc.faces.nbytes + sum(t.indices.nbytes + t.clut.nbytes for t in sc.indexed_textures)
 
-    def step(first=False):
-        fb.clear(sc.clear_color)
+    ex = None       # N > 1: the exchange step behind the C ABI (bonnie32_amd.exchange), once its self-check has passed; None = torch.distributed
+
+    def torch_gather():
+        if args.dist_backend == "nccl":
+            parallel.gather_bands(frame, W, H, world, rank)
+        else:       # debug: same gather logic on a host copy
+            host = frame.cpu()
+            parallel.gather_bands(host, W, H, world, rank)
+            if rank == 0:
+                frame.copy_(host)
+
+    def draw(rsx, scene, first=False):
+        """One step of any resident scene: [exchange: begin] clear + render_mesh_15 [exchange: end | torch gather]"""
+        if ex is not None:
+            ex.begin()
+        fb.clear(scene.clear_color)
         if first:
-            rs.render_async(sc.camera, sc.settings, sc.fog)
+            rsx.render_async(scene.camera, scene.settings, scene.fog)
         else:
-            rs.render_async()
-        if world > 1:
-            if args.dist_backend == "nccl":
-                parallel.gather_bands(frame, W, H, world, rank)
-            else:       # debug: same gather logic on a host copy
-                host = frame.cpu()
-                parallel.gather_bands(host, W, H, world, rank)
-                if rank == 0:
-                    frame.copy_(host)
+            rsx.render_async()
+        if ex is not None:
+            ex.end()
+        elif world > 1:
+            torch_gather()
+
+    def step(first=False):
+        draw(rs, sc, first)
 
     ctx.set_fragment_counting(1)          # warmup frames count the reference's pixel stores exactly (Mpixels/s numerator)
     # warmup (also settles buffer capacities: finish() grows the pair buffers if the first frame overflowed them)
@@ -150,6 +169,76 @@ def main():
     exact_fragments = tm.fragments        # counted exactly during warmup (fragment counting on)
     ctx.set_fragment_counting(0)          # instrumentation off for the timed region (identical framebuffer)
     step(); rs.finish()
+
+    # ---- N > 1: the exchange step through the product's own boundary.  The torch gather above has assembled the
+    # reference frame on rank 0; the requested C-ABI transport is set up, the root's framebuffer is poisoned, two frames are drawn
+    # through the transport and the root's frame must equal the reference (a band that never arrived leaves poison, a band read too
+    # early leaves a half-drawn one) with no wait timed out.  Every rank takes part in both agreement rounds whatever happened to it.
+    rdev = dev if args.dist_backend == "nccl" else torch.device("cpu")
+
+    def all_agree(ok):
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=rdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(flag.item())
+
+    transport = {"requested": args.transport if world > 1 else None, "used": "torch" if world > 1 else None, "fallback_reason": None, "timeouts": None,
+                 "self_check": None}
+    if world > 1 and args.transport != "torch":
+        def bcast(payload):
+            box = [payload]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+        torch.cuda.synchronize(dev)
+        ref = frame.cpu().numpy().copy() if rank == 0 else None
+        cand, why = None, None
+        try:
+            if args.transport == "shm":
+                cand = X.SharedFramebufferExchange(ctx, W, H, rank, world, bcast)
+                fb.width, fb.height = W, H
+            else:
+                cand = X.RcclExchange(ctx, W, H, rank, world, bcast)
+            fb.set_band(y0, y1)
+        except Exception as e:                                    # noqa: BLE001
+            why = f"set-up on rank {rank}: {e!r}"
+        ok = all_agree(why is None)
+        if ok:
+            try:
+                if rank == 0:
+                    fb.upload(np.full(W * H * 4, 0xAB, np.uint8))
+                dist.barrier()
+                ex = cand
+                for i in range(2):
+                    step(first=(i == 0))
+                rs.finish()
+                torch.cuda.synchronize(dev)
+                if rank == 0 and not np.array_equal(fb.pixels, ref):
+                    why = "self-check: the frame assembled through the transport differs from the torch-gathered frame"
+                if ex.timeouts():
+                    why = f"self-check: {ex.timeouts()} exchange waits timed out"
+            except Exception as e:                                # noqa: BLE001
+                why = f"self-check on rank {rank}: {e!r}"
+            ok = all_agree(why is None)
+        if ok:
+            transport.update(used=cand.name, self_check="passed")
+        else:
+            reasons = [None] * world
+            dist.all_gather_object(reasons, why)
+            transport.update(fallback_reason="; ".join(r for r in reasons if r) or "another rank failed", self_check="failed")
+            if rank == 0:
+                print(f"# transport {args.transport} unavailable ({transport['fallback_reason']}): timing the torch.distributed gather", file=sys.stderr)
+            ex = None
+            try:
+                if cand is not None:
+                    cand.close()
+            except Exception:                                     # noqa: BLE001
+                pass
+            try:
+                ctx.finish()
+            except Exception:                                     # noqa: BLE001 -- (a band timeout of the failed attempt is not this run's error)
+                pass
+            fb.bind_device(frame.data_ptr(), W, H)
+            fb.set_band(y0, y1)
+            step(first=True); rs.finish()
 
     # ---- N > 1: overlap the band gather with the next frame.  Frames alternate between two framebuffers (two contexts on the same
     # stream, each with the scene resident); the gather of frame i is asynchronous (RCCL's own stream, started after frame i's kernels)
@@ -200,7 +289,7 @@ def main():
             if pending[k] is not None:
                 pending[k][0].wait(); pending[k] = None
 
-    if world > 1 and (args.dist_backend == "nccl" or args.pipeline_debug) and not args.sync_gather and H % world == 0:
+    if world > 1 and ex is None and (args.dist_backend == "nccl" or args.pipeline_debug) and not args.sync_gather and H % world == 0:
         ok = 1
         try:
             sets.append(make_second_set())
@@ -223,8 +312,6 @@ def main():
             pending[0] = pending[1] = None
             sets = sets[:1]
             step(); rs.finish()
-
-    rdev = dev if args.dist_backend == "nccl" else torch.device("cpu")
 
     def max_over_ranks(seconds):
         t = torch.tensor([seconds], dtype=torch.float64, device=rdev)
@@ -277,6 +364,8 @@ def main():
     tm = rs.finish()
     if pipelined:
         sets[1][1].finish()
+    if ex is not None:
+        transport["timeouts"] = ex.timeouts()       # (must be 0: a wait that gave up means a frame with stale rows was timed)
     cover_ms_timed = ctx.last_kernel_times().get("cover", None)     # HIP events around k_cover on the stream it runs on (overlapped frames)
     ctx.set_profiling(0)
     ctx.set_profiling_stride(1)
@@ -367,19 +456,7 @@ def main():
         wrs = R.ResidentScene(fb, wsc.vertices, wsc.faces, indexed_textures=wsc.indexed_textures)
 
         def wstep(first=False):
-            fb.clear(wsc.clear_color)
-            if first:
-                wrs.render_async(wsc.camera, wsc.settings, wsc.fog)
-            else:
-                wrs.render_async()
-            if world > 1:
-                if args.dist_backend == "nccl":
-                    parallel.gather_bands(frame, W, H, world, rank)
-                else:
-                    host = frame.cpu()
-                    parallel.gather_bands(host, W, H, world, rank)
-                    if rank == 0:
-                        frame.copy_(host)
+            draw(wrs, wsc, first)
 
         wsets = [(fb, wrs, frame)]
         if pipelined:       # the same overlap as the headline: the second framebuffer's context gets the weak scene too
@@ -621,7 +698,11 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.config}: {NF} tris @ {W}x{H}, 256x256 8-bit atlas, affine+snap+RGB555 dither, painter's",
                        "triangles_drawn": tm.triangles_drawn, "fragments": fragments,
-                       "parallelism": (f"screen bands x{world}, RCCL gather " + ("overlapped with the next frame (two framebuffers)" if pipelined else "after every frame")) if world > 1 else "single GPU"},
+                       "parallelism": (f"screen bands x{world}, " + (
+                           "shared framebuffer through the C ABI (b32_band_export / _import: band ranks store their rows straight into rank 0's HBM; device-side epoch words, b32_band_publish / _wait_all / _acquire)" if transport["used"] == "shm" else
+                           "b32_gather_bands_rccl through the C ABI (grouped ncclSend / ncclRecv on the frame's stream) after every frame" if transport["used"] == "rccl" else
+                           "torch.distributed gather " + ("overlapped with the next frame (two framebuffers)" if pipelined else "after every frame"))) if world > 1 else "single GPU"},
+            "transport": transport if world > 1 else None,
             "frame_sha256": sha[:16], "bit_exact_vs_committed_hash": (sha == want) if want else None,
             "build_digest": build_digest, "csrc_digest": csrc_digest(),     # the loaded library's own digest == the source tree's (checked at start)
             "protocol": {"ms_per_step_median": round(per_step[len(per_step) // 2], 5) if per_step else None,

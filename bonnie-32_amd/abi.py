@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libb32raster.so")
 
 # ---- error codes -----------------------------------------------------------
-B32_OK, B32_E_ARG, B32_E_INDEX, B32_E_NAN_KEY, B32_E_HIP, B32_E_UNSUPPORTED, B32_E_NO_DEVICE, B32_E_FRAME_DROPPED = 0, -1, -2, -3, -4, -5, -6, -7
+B32_OK, B32_E_ARG, B32_E_INDEX, B32_E_NAN_KEY, B32_E_HIP, B32_E_UNSUPPORTED, B32_E_NO_DEVICE, B32_E_FRAME_DROPPED, B32_E_BAND_TIMEOUT = 0, -1, -2, -3, -4, -5, -6, -7, -8
 NO_TEXTURE = 0xFFFFFFFF
 
 # BlendMode (types.rs:1380-1388)
@@ -148,9 +148,14 @@ SYMBOLS = [
     ("b32_band_publish", C.c_int, [_P, C.c_uint32]),
     ("b32_band_wait", C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint32]),
     ("b32_band_release", C.c_int, [_P, C.c_uint32]),
+    ("b32_band_wait_all", C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]),
     ("b32_band_acquire", C.c_int, [_P, C.c_uint32, C.c_uint32]),
     ("b32_band_status", C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("b32_gather_bands_rccl", C.c_int, [_P, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    ("b32_gather_bands_rccl_loopback", C.c_int, [_P, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint32]),
+    ("b32_rccl_unique_id", C.c_int, [C.c_void_p]),
+    ("b32_rccl_comm_create", C.c_int, [_P, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    ("b32_rccl_comm_destroy", C.c_int, [C.c_void_p]),
 ]
 
 _lib = None

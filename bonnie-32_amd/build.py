@@ -53,18 +53,60 @@ def needs_build():
     return built_digest() != csrc_digest()
 
 
+def _tu_digest(src, extra):
+    """What one translation unit is compiled from: its own text, every header of csrc/, the public header, the flags."""
+    h = hashlib.sha256()
+    h.update(open(os.path.join(CSRC, src), "rb").read())
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith(".h"):
+            h.update(f.encode()); h.update(open(os.path.join(CSRC, f), "rb").read())
+    h.update(open(os.path.join(_HERE, "..", "include", "b32raster.h"), "rb").read())
+    h.update(" ".join(FLAGS + list(extra)).encode())
+    return h.hexdigest()[:16]
+
+
 def build(force=False, verbose=False, out=None, extra=()):
-    """out / extra: an experiment build with more -D flags into another file (tools/exp_variants.py)"""
+    """Every source is compiled to an object of its own, in parallel, and only when its translation-unit digest changed (objects under
+    csrc/_obj/, git-ignored); the link always runs.  out / extra: an experiment build with more -D flags into another file
+    (tools/exp_variants.py; its objects live in a directory of their own)."""
     if out is None and not force and not needs_build():
         return OUT
-    cmd = [hipcc()] + FLAGS + [f'-DB32_SRC_DIGEST="{csrc_digest()}"'] + list(extra) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out or OUT]
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if verbose or r.returncode:
-        print(" ".join(cmd))
-        print(r.stdout)
-        print(r.stderr)
-    if r.returncode:
+    from concurrent.futures import ThreadPoolExecutor
+    cflags = [f for f in FLAGS if f != "-shared"]
+    objdir = os.path.join(CSRC, "_obj" if out is None else "_obj_" + hashlib.sha256((out + " ".join(extra)).encode()).hexdigest()[:8])
+    os.makedirs(objdir, exist_ok=True)
+    digest = csrc_digest()
+
+    def compile_one(src):
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        tag = obj + ".digest"
+        want = _tu_digest(src, extra)
+        # b32_api.hip carries the library digest (-DB32_SRC_DIGEST): it is recompiled whenever any source changes
+        if src == "b32_api.hip":
+            want += ":" + digest
+        if not force and os.path.exists(obj) and os.path.exists(tag) and open(tag).read() == want:
+            return src, 0, "", ""
+        cmd = [hipcc()] + cflags + list(extra) + (["-DB32_SRC_DIGEST=\"%s\"" % digest] if src == "b32_api.hip" else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode == 0:
+            open(tag, "w").write(want)
+        return src, r.returncode, " ".join(cmd), r.stdout + r.stderr
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        results = list(ex.map(compile_one, SOURCES))
+    bad = False
+    for src, rc, cmd, log in results:
+        if verbose or rc or log.strip():
+            print(cmd); print(log)
+        bad = bad or rc != 0
+    if bad:
         raise RuntimeError("hipcc failed")
+    link = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES] + ["-o", out or OUT]
+    r = subprocess.run(link, capture_output=True, text=True)
+    if verbose or r.returncode:
+        print(" ".join(link)); print(r.stdout); print(r.stderr)
+    if r.returncode:
+        raise RuntimeError("hipcc link failed")
     return out or OUT
 
 

@@ -14,6 +14,7 @@ const char* b32_strerror(int code) {
         case B32_E_UNSUPPORTED: return "setting outside the supported hot-path scope";
         case B32_E_NO_DEVICE: return "no HIP device (the rasterizer has no CPU fallback)";
         case B32_E_FRAME_DROPPED: return "an earlier frame in flight ran out of buffer space and drew nothing (deep asynchronous mode)";
+        case B32_E_BAND_TIMEOUT: return "a band exchange wait gave up: another rank did not publish / release its frame in time (the frame may hold stale rows)";
         default: return "unknown error";
     }
 }

@@ -766,6 +766,7 @@ int b32_frame_finish(b32_ctx* c, B32Timings* out) {
     if (c->h_ctrl.err_index || (sticky & 1u)) return B32_E_INDEX;
     if (c->h_ctrl.abort || (sticky & 2u)) return B32_E_NAN_KEY;
     if (sticky & 8u) return B32_E_HIP;                         // (k_join gave up on a setup kernel: internal)
+    if (sticky & 16u) return B32_E_BAND_TIMEOUT;               // (b32_band_wait / _wait_all / _acquire gave up on another rank's epoch word)
     if (c->h_ctrl.wire_overflow || (sticky & 4u)) return B32_E_UNSUPPORTED;     // an edge >= 2^30 px long: i32 overflow in the reference's Bresenham
     if (out) {
         out->triangles_drawn = c->h_ctrl.n_visible;

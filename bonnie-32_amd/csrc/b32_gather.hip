@@ -36,16 +36,36 @@ __global__ void k_band_publish(uint32_t* word, uint32_t value) {
     __threadfence_system();
     (void)__hip_atomic_exchange(word, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-// one wave polling an epoch word until it reaches `need` (wrap-safe), at most `patience` 10-ns ticks; a timeout is counted, never silent
-__global__ void k_band_wait(uint32_t* word, uint32_t need, unsigned long long patience, uint32_t* timeouts) {
+// one wave polling an epoch word until it reaches `need` (wrap-safe), at most `patience` 10-ns ticks; a timeout is counted in the shared
+// tail AND raised in the waiting context's sticky word (bit 4: b32_frame_finish returns B32_E_BAND_TIMEOUT), never silent
+__global__ void k_band_wait(uint32_t* word, uint32_t need, unsigned long long patience, uint32_t* timeouts, Ctrl* ctrl) {
     const unsigned long long t0 = wall_clock64();
     for (;;) {
         const uint32_t cur = __hip_atomic_fetch_add(word, 0u, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
         if ((int32_t)(cur - need) >= 0) break;
-        if (wall_clock64() - t0 > patience) { atomicAdd(timeouts, 1u); break; }
+        if (wall_clock64() - t0 > patience) { atomicAdd(timeouts, 1u); if (ctrl) atomicOr(&ctrl->sticky, 16u); break; }
         __builtin_amdgcn_s_sleep(32);
     }
     __threadfence_system();
+}
+// the root's whole side of a frame in ONE launch: lane r (1 <= r < nranks) polls rank r's word; when all have arrived (or given up,
+// counted) lane 0 optionally publishes the root's release word.  (Seven one-lane waits + a release are eight launches of ~5 us each on
+// the root's stream: more than the exchange itself.)
+__global__ void __launch_bounds__(64) k_band_wait_all(uint32_t* sync, uint32_t nranks, uint32_t need, unsigned long long patience, uint32_t release, Ctrl* ctrl) {
+    const uint32_t r = threadIdx.x;
+    bool done = !(r >= 1 && r < nranks);
+    const unsigned long long t0 = wall_clock64();
+    for (;;) {
+        if (!done) {
+            const uint32_t cur = __hip_atomic_fetch_add(sync + (size_t)r * BAND_STRIDE, 0u, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+            done = (int32_t)(cur - need) >= 0;
+        }
+        if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
+        if (wall_clock64() - t0 > patience) { if (!done) { atomicAdd(sync + BAND_TIMEOUT_WORD, 1u); if (ctrl) atomicOr(&ctrl->sticky, 16u); } break; }
+        __builtin_amdgcn_s_sleep(32);
+    }
+    __threadfence_system();
+    if (release && r == 0) (void)__hip_atomic_exchange(sync + BAND_ROOT_WORD, need, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 }  // namespace b32
@@ -154,7 +174,18 @@ int b32_band_wait(b32_ctx* c, uint32_t rank, uint32_t frame_no, uint32_t timeout
     if (!c || !c->band_sync_own || rank == 0 || rank >= BAND_RANKS) return B32_E_ARG;
     (void)hipSetDevice(c->device);
     hipLaunchKernelGGL(k_band_wait, dim3(1), dim3(1), 0, c->stream, c->band_sync_own + (size_t)rank * BAND_STRIDE, frame_no,
-                       (unsigned long long)timeout_us * 100ull, c->band_sync_own + BAND_TIMEOUT_WORD);
+                       (unsigned long long)timeout_us * 100ull, c->band_sync_own + BAND_TIMEOUT_WORD, c->d_ctrl);
+    HIPCHK(c, hipGetLastError());
+    return B32_OK;
+}
+
+int b32_band_wait_all(b32_ctx* c, uint32_t nranks, uint32_t frame_no, uint32_t timeout_us, int release_after) {
+    if (!c || !c->band_sync_own || nranks < 1 || nranks > BAND_RANKS) return B32_E_ARG;
+    (void)hipSetDevice(c->device);
+    if (release_after) { const int rc = flush_clear(c); if (rc) return rc; }      // (as b32_band_release)
+    if (nranks == 1 && !release_after) return B32_OK;
+    hipLaunchKernelGGL(k_band_wait_all, dim3(1), dim3(64), 0, c->stream, c->band_sync_own, nranks, frame_no, (unsigned long long)timeout_us * 100ull,
+                       release_after ? 1u : 0u, c->d_ctrl);
     HIPCHK(c, hipGetLastError());
     return B32_OK;
 }
@@ -172,7 +203,7 @@ int b32_band_acquire(b32_ctx* c, uint32_t frame_no, uint32_t timeout_us) {
     if (!c || !c->band_sync || c->band_rank == 0) return B32_E_ARG;
     (void)hipSetDevice(c->device);
     hipLaunchKernelGGL(k_band_wait, dim3(1), dim3(1), 0, c->stream, c->band_sync + BAND_ROOT_WORD, frame_no, (unsigned long long)timeout_us * 100ull,
-                       c->band_sync + BAND_TIMEOUT_WORD);
+                       c->band_sync + BAND_TIMEOUT_WORD, c->d_ctrl);
     HIPCHK(c, hipGetLastError());
     return B32_OK;
 }
@@ -188,32 +219,51 @@ int b32_band_status(b32_ctx* c, uint32_t* epochs, uint32_t* root_epoch, uint32_t
     return B32_OK;
 }
 
-// ---- RCCL transport.  The four entry points it needs are resolved from librccl.so on first use; the communicator is the caller's
-// (ncclCommInitRank in the host program).  Types as in <rccl/rccl.h>: ncclResult_t / ncclDataType_t are ints, ncclUint8 == 1.
+// ---- RCCL transport.  The entry points it needs are resolved from librccl.so on first use; the communicator is the caller's
+// (ncclCommInitRank in the host program, or b32_rccl_comm_create below, which makes it with the very library this file loaded).
+// Types as in <rccl/rccl.h>: ncclResult_t / ncclDataType_t are ints, ncclUint8 == 1, ncclUniqueId is 128 opaque bytes passed BY VALUE.
+struct NcclId { char internal[128]; };
 typedef int (*nccl_group_fn)(void);
 typedef int (*nccl_sendrecv_fn)(void*, size_t, int, int, void*, hipStream_t);
-static struct { void* lib; nccl_group_fn start, end; nccl_sendrecv_fn send, recv; bool tried; } g_rccl;
+typedef int (*nccl_get_id_fn)(NcclId*);
+typedef int (*nccl_init_rank_fn)(void**, int, NcclId, int);
+typedef int (*nccl_destroy_fn)(void*);
+static struct { void* lib; nccl_group_fn start, end; nccl_sendrecv_fn send, recv; nccl_get_id_fn get_id; nccl_init_rank_fn init_rank; nccl_destroy_fn destroy; bool tried; } g_rccl;
 static bool rccl_load() {
     if (g_rccl.tried) return g_rccl.lib != nullptr;
     g_rccl.tried = true;
-    for (const char* name : { "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so" }) {
+    // (a process that already holds an RCCL -- e.g. the copy PyTorch ships -- gets that very copy back for the same soname)
+    for (const char* name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so" }) {
         void* l = dlopen(name, RTLD_NOW | RTLD_LOCAL);
         if (!l) continue;
         g_rccl.start = reinterpret_cast<nccl_group_fn>(dlsym(l, "ncclGroupStart"));
         g_rccl.end = reinterpret_cast<nccl_group_fn>(dlsym(l, "ncclGroupEnd"));
         g_rccl.send = reinterpret_cast<nccl_sendrecv_fn>(dlsym(l, "ncclSend"));
         g_rccl.recv = reinterpret_cast<nccl_sendrecv_fn>(dlsym(l, "ncclRecv"));
-        if (g_rccl.start && g_rccl.end && g_rccl.send && g_rccl.recv) { g_rccl.lib = l; return true; }
+        g_rccl.get_id = reinterpret_cast<nccl_get_id_fn>(dlsym(l, "ncclGetUniqueId"));
+        g_rccl.init_rank = reinterpret_cast<nccl_init_rank_fn>(dlsym(l, "ncclCommInitRank"));
+        g_rccl.destroy = reinterpret_cast<nccl_destroy_fn>(dlsym(l, "ncclCommDestroy"));
+        if (g_rccl.start && g_rccl.end && g_rccl.send && g_rccl.recv && g_rccl.get_id && g_rccl.init_rank && g_rccl.destroy) { g_rccl.lib = l; return true; }
         dlclose(l);
     }
     return false;
 }
 
-int b32_gather_bands_rccl(b32_ctx* c, void* nccl_comm, int rank, int nranks, int root, const uint32_t* y0, const uint32_t* y1) {
+// self_dst_y0 != NO_LOOPBACK: the root ALSO sends its own band to itself and receives it at row self_dst_y0 (the loopback tap)
+constexpr uint32_t NO_LOOPBACK = 0xFFFFFFFFu;
+static int gather_bands_rccl_any(b32_ctx* c, void* nccl_comm, int rank, int nranks, int root, const uint32_t* y0, const uint32_t* y1, uint32_t self_dst_y0) {
     if (!c || !nccl_comm || !c->fb || !y0 || !y1 || nranks < 1 || rank < 0 || rank >= nranks || root < 0 || root >= nranks) return B32_E_ARG;
     for (int r = 0; r < nranks; ++r) if (y0[r] > y1[r] || y1[r] > c->height) return B32_E_ARG;
-    if (nranks == 1) return B32_OK;
+    const bool loop = self_dst_y0 != NO_LOOPBACK && rank == root && y1[root] > y0[root];
+    if (loop) {       // the destination rows must lie inside the framebuffer and must not overlap the rows that are being sent
+        const uint32_t n = y1[root] - y0[root];
+        if (self_dst_y0 > c->height || n > c->height - self_dst_y0 || (self_dst_y0 < y1[root] && y0[root] < self_dst_y0 + n)) return B32_E_ARG;
+    }
+    if (nranks == 1 && !loop) return B32_OK;
     (void)hipSetDevice(c->device);
+    // (safe mode: a pending frame that may still need a redraw is settled first -- its rows must be the frame's, not an aborted attempt's;
+    // deep mode never blocks the host: a dropped frame is reported by b32_frame_finish)
+    if (!c->deep_async) { const int rc = settle_pending(c); if (rc) return rc; }
     { const int rc = flush_clear(c); if (rc) return rc; }
     if (!rccl_load()) return B32_E_UNSUPPORTED;
     const size_t row = (size_t)c->width * 4;
@@ -223,12 +273,49 @@ int b32_gather_bands_rccl(b32_ctx* c, void* nccl_comm, int rank, int nranks, int
     if (rank == root) {
         for (int r = 0; r < nranks && !e; ++r)
             if (r != root && y1[r] > y0[r]) e = g_rccl.recv(base + (size_t)y0[r] * row, (size_t)(y1[r] - y0[r]) * row, NCCL_UINT8, r, nccl_comm, c->stream);
+        if (loop && !e) e = g_rccl.send(base + (size_t)y0[root] * row, (size_t)(y1[root] - y0[root]) * row, NCCL_UINT8, root, nccl_comm, c->stream);
+        if (loop && !e) e = g_rccl.recv(base + (size_t)self_dst_y0 * row, (size_t)(y1[root] - y0[root]) * row, NCCL_UINT8, root, nccl_comm, c->stream);
     } else if (y1[rank] > y0[rank]) {
         e = g_rccl.send(base + (size_t)y0[rank] * row, (size_t)(y1[rank] - y0[rank]) * row, NCCL_UINT8, root, nccl_comm, c->stream);
     }
     const int e2 = g_rccl.end();
     if (e || e2) { c->last_hip = e ? e : e2; return B32_E_HIP; }
     return B32_OK;
+}
+
+int b32_gather_bands_rccl(b32_ctx* c, void* nccl_comm, int rank, int nranks, int root, const uint32_t* y0, const uint32_t* y1) {
+    return gather_bands_rccl_any(c, nccl_comm, rank, nranks, root, y0, y1, NO_LOOPBACK);
+}
+int b32_gather_bands_rccl_loopback(b32_ctx* c, void* nccl_comm, int rank, int nranks, int root, const uint32_t* y0, const uint32_t* y1, uint32_t self_dst_y0) {
+    if (self_dst_y0 == NO_LOOPBACK) return B32_E_ARG;
+    return gather_bands_rccl_any(c, nccl_comm, rank, nranks, root, y0, y1, self_dst_y0);
+}
+
+int b32_rccl_unique_id(unsigned char* id128) {
+    if (!id128) return B32_E_ARG;
+    if (!rccl_load()) return B32_E_UNSUPPORTED;
+    NcclId id;
+    if (g_rccl.get_id(&id)) return B32_E_HIP;
+    memcpy(id128, id.internal, sizeof(id.internal));
+    return B32_OK;
+}
+int b32_rccl_comm_create(b32_ctx* c, const unsigned char* id128, int rank, int nranks, void** comm) {
+    if (!c || !id128 || !comm || nranks < 1 || rank < 0 || rank >= nranks) return B32_E_ARG;
+    *comm = nullptr;
+    if (!rccl_load()) return B32_E_UNSUPPORTED;
+    (void)hipSetDevice(c->device);                   // (the communicator belongs to the context's device)
+    NcclId id;
+    memcpy(id.internal, id128, sizeof(id.internal));
+    void* out = nullptr;
+    const int e = g_rccl.init_rank(&out, nranks, id, rank);
+    if (e || !out) { c->last_hip = e; return B32_E_HIP; }
+    *comm = out;
+    return B32_OK;
+}
+int b32_rccl_comm_destroy(void* comm) {
+    if (!comm) return B32_E_ARG;
+    if (!rccl_load()) return B32_E_UNSUPPORTED;
+    return g_rccl.destroy(comm) ? B32_E_HIP : B32_OK;
 }
 
 }  // extern "C"

@@ -181,6 +181,9 @@ class Context:
     def band_wait(self, rank, frame_no, timeout_us=2_000_000):
         _chk(self.lib.b32_band_wait(self.h, int(rank), int(frame_no), int(timeout_us)), "b32_band_wait")
 
+    def band_wait_all(self, nranks, frame_no, timeout_us=2_000_000, release_after=True):
+        _chk(self.lib.b32_band_wait_all(self.h, int(nranks), int(frame_no), int(timeout_us), 1 if release_after else 0), "b32_band_wait_all")
+
     def band_release(self, frame_no):
         _chk(self.lib.b32_band_release(self.h, int(frame_no)), "b32_band_release")
 
@@ -192,6 +195,38 @@ class Context:
         ep = (C.c_uint32 * 64)(); root = C.c_uint32(); to = C.c_uint32()
         _chk(self.lib.b32_band_status(self.h, ep, C.byref(root), C.byref(to)), "b32_band_status")
         return list(ep), int(root.value), int(to.value)
+
+    # transport (2): RCCL behind the C ABI.  The communicator is made by the library itself (the librccl it loaded), so the host needs
+    # no RCCL binding of its own.
+    @staticmethod
+    def rccl_unique_id() -> bytes:
+        """b32_rccl_unique_id: ncclGetUniqueId on ONE rank; hand the 128 bytes to every other rank."""
+        from . import abi
+        buf = C.create_string_buffer(128)
+        _chk(abi.load_library().b32_rccl_unique_id(C.cast(buf, C.c_void_p)), "b32_rccl_unique_id")
+        return buf.raw
+
+    def rccl_comm_create(self, unique_id: bytes, rank, nranks):
+        """b32_rccl_comm_create: ncclCommInitRank on this context's device (collective); returns the opaque ncclComm_t."""
+        assert len(unique_id) == 128
+        buf = C.create_string_buffer(unique_id, 128)
+        comm = C.c_void_p()
+        rc = self.lib.b32_rccl_comm_create(self.h, C.cast(buf, C.c_void_p), int(rank), int(nranks), C.byref(comm))
+        _chk(rc, f"b32_rccl_comm_create (ncclResult {self.lib.b32_last_hip_error(self.h)})" if rc else "b32_rccl_comm_create")
+        return comm
+
+    def rccl_comm_destroy(self, comm):
+        _chk(self.lib.b32_rccl_comm_destroy(comm), "b32_rccl_comm_destroy")
+
+    def gather_bands_rccl(self, comm, rank, nranks, root, bands, loopback_dst_y0=None):
+        """b32_gather_bands_rccl: bands = [(y0, y1)] of every rank; enqueued on the context's stream behind the frame's kernels.
+        loopback_dst_y0 (test tap): the root also sends its own band to itself, received at that row."""
+        y0 = (C.c_uint32 * nranks)(*[b[0] for b in bands]); y1 = (C.c_uint32 * nranks)(*[b[1] for b in bands])
+        if loopback_dst_y0 is None:
+            rc = self.lib.b32_gather_bands_rccl(self.h, comm, int(rank), int(nranks), int(root), y0, y1)
+        else:
+            rc = self.lib.b32_gather_bands_rccl_loopback(self.h, comm, int(rank), int(nranks), int(root), y0, y1, int(loopback_dst_y0))
+        _chk(rc, f"b32_gather_bands_rccl (ncclResult {self.lib.b32_last_hip_error(self.h)})" if rc == -4 else "b32_gather_bands_rccl")
 
     # ---- stage taps -----------------------------------------------------------------
     def project_fixed_batch(self, pos, camera: T.Camera, width, height):

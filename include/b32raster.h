@@ -34,6 +34,8 @@ extern "C" {
 #define B32_E_FRAME_DROPPED -7 /* deep asynchronous mode only (b32_set_async_depth): an EARLIER frame in flight ran out of buffer
                                   space and drew nothing (its framebuffer kept the cleared / previous contents); the most recent
                                   frame has been redrawn correctly */
+#define B32_E_BAND_TIMEOUT -8  /* multi-GPU band exchange: a b32_band_wait / _wait_all / _acquire since the last b32_frame_finish gave up
+                                  on another rank's epoch word (the frame may hold that rank's rows of an older frame) */
 
 /* ---- enums mirrored as integers ------------------------------------------ */
 /* BlendMode, types.rs:1380-1388 */
@@ -450,7 +452,8 @@ int b32_set_fragment_counting(b32_ctx* ctx, int on);
  *
  *     Everything is enqueued on the contexts' streams; no call blocks the host.  publish(n) takes effect behind every kernel the rank
  *     enqueued before it; wait(r, n) holds the ROOT's stream until rank r has published a frame number >= n (wrap-safe compare) or
- *     timeout_us has passed -- a timeout is counted in b32_band_status, never silent.  release / acquire are the same in the other
+ *     timeout_us has passed -- a timeout is counted in b32_band_status AND makes the waiting context's next b32_frame_finish return
+ *     B32_E_BAND_TIMEOUT, never silent.  release / acquire are the same in the other
  *     direction (the root has consumed frame n: a rank may overwrite its rows); a host that presents every frame before the ranks
  *     start the next one (e.g. behind its own barrier) does not need them.  Frame numbers start at 1 (the words start at 0).
  *     b32_frame_finish on a band rank still reports that rank's errors and counters; triangles_drawn is the whole mesh's on every rank.
@@ -477,11 +480,25 @@ int b32_band_close(b32_ctx* ctx);                                             /*
 int b32_band_publish(b32_ctx* ctx, uint32_t frame_no);                        /* band rank: "my rows of frame_no are complete", in stream order */
 int b32_band_wait(b32_ctx* root, uint32_t rank, uint32_t frame_no, uint32_t timeout_us);   /* root: hold the stream until rank published >= frame_no */
 int b32_band_release(b32_ctx* root, uint32_t frame_no);                       /* root: "frame_no has been consumed", in stream order */
+/* root: b32_band_wait for every rank 1 .. nranks-1 and (release_after != 0) b32_band_release(frame_no) behind them, as ONE launch */
+int b32_band_wait_all(b32_ctx* root, uint32_t nranks, uint32_t frame_no, uint32_t timeout_us, int release_after);
 int b32_band_acquire(b32_ctx* ctx, uint32_t frame_no, uint32_t timeout_us);   /* band rank: hold the stream until the root released >= frame_no */
 /* Host-side view of the epoch words (a blocking 4-KB copy): epochs[64] (nullable) = last published frame per rank, *root_epoch
  * (nullable) = last released frame, *timeouts (nullable) = waits that gave up since the export. */
 int b32_band_status(b32_ctx* ctx, uint32_t* epochs, uint32_t* root_epoch, uint32_t* timeouts);
 int b32_gather_bands_rccl(b32_ctx* ctx, void* nccl_comm, int rank, int nranks, int root, const uint32_t* y0, const uint32_t* y1);
+/* The communicator for transport (2) made with the very librccl the library loaded (a host that links RCCL itself may pass its own
+ * ncclComm_t instead): b32_rccl_unique_id = ncclGetUniqueId on ONE rank (128 bytes, handed to the others by whatever channel the host
+ * has), b32_rccl_comm_create = ncclCommInitRank on the context's device (collective: every rank calls it), _destroy = ncclCommDestroy.
+ * B32_E_UNSUPPORTED when librccl.so cannot be loaded; B32_E_HIP + b32_last_hip_error = the ncclResult_t otherwise. */
+int b32_rccl_unique_id(unsigned char* id128);
+int b32_rccl_comm_create(b32_ctx* ctx, const unsigned char* id128, int rank, int nranks, void** nccl_comm);
+int b32_rccl_comm_destroy(void* nccl_comm);
+/* Test tap (no reference counterpart): b32_gather_bands_rccl in which the root additionally sends its OWN band to itself and receives it
+ * at row self_dst_y0 of the same framebuffer (the rows must not overlap the band).  With a 1-rank communicator this executes the whole
+ * RCCL leg -- library load, the resolved entry points, the byte datatype, stream order behind the frame's kernels -- on a single GPU. */
+int b32_gather_bands_rccl_loopback(b32_ctx* ctx, void* nccl_comm, int rank, int nranks, int root, const uint32_t* y0, const uint32_t* y1,
+                                   uint32_t self_dst_y0);
 
 #ifdef __cplusplus
 }

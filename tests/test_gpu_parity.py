@@ -878,6 +878,98 @@ def test_band_exchange_argument_checks(gpu_ctx):
     other.close(); root.close()
 
 
+def test_band_wait_timeout_is_reported_by_frame_finish(oracle):
+    """a band-exchange wait that gives up must not only be counted in the shared tail -- the waiting context's next
+    b32_frame_finish returns B32_E_BAND_TIMEOUT (the presented frame may hold another rank's stale rows); the one after that is clean."""
+    from bonnie32_amd import rasterizer as R
+    sc = scenegen.make_scene("C1")
+    root = R.Context(0); root.set_async_depth(1)
+    fb = R.Framebuffer(sc.width, sc.height, root)
+    root.band_export()
+    rs = R.ResidentScene(fb, sc.vertices, sc.faces, sc.textures)
+    fb.clear(sc.clear_color); rs.render_async(sc.camera, sc.settings, sc.fog)
+    root.band_wait_all(3, 1, timeout_us=3000, release_after=True)        # ranks 1 and 2 do not exist
+    with pytest.raises(R.B32Error) as ei:
+        rs.finish()
+    assert ei.value.code == b32.abi.B32_E_BAND_TIMEOUT
+    epochs, released, timeouts = root.band_status()
+    assert timeouts == 2 and released == 1
+    fb.clear(sc.clear_color); rs.render_async()
+    tm = rs.finish()                                                      # the sticky bit was consumed
+    want, otm, _ = cpu_render(oracle, sc)
+    assert np.array_equal(fb.pixels, want) and tm.triangles_drawn == otm.triangles_drawn
+    root.close()
+
+
+def test_rccl_transport_loopback_on_one_gpu(oracle):
+    """Transport (2) of the exchange step EXECUTED: a one-rank RCCL communicator made through the C ABI
+    (b32_rccl_unique_id / _comm_create: the library's own dlopen of librccl and its resolved entry points), and
+    b32_gather_bands_rccl_loopback -- the gather in which the root additionally sends its own band to itself -- enqueued on the
+    context's stream right behind the frame's kernels: the upper half of the frame is drawn as a band, travels through ncclSend / ncclRecv
+    (ncclUint8, grouped) into the lower half, and both halves must equal the oracle's rows of the upper half.  What stays unexecuted is a
+    transfer between two physical GPUs."""
+    from bonnie32_amd import rasterizer as R
+    sc = scenegen.make_scene("C3", n_tris=60_000, width=640, height=480)
+    W, H = sc.width, sc.height
+    want, otm, _ = cpu_render(oracle, sc)
+    ctx = R.Context(0); ctx.set_async_depth(1)
+    fb = R.Framebuffer(W, H, ctx)
+    fb.upload(np.full(W * H * 4, 0xAB, np.uint8))
+    fb.set_band(0, H // 2)
+    rs = R.ResidentScene(fb, sc.vertices, sc.faces, indexed_textures=sc.indexed_textures)
+    comm = ctx.rccl_comm_create(R.Context.rccl_unique_id(), 0, 1)
+    E = b32.abi.B32_E_ARG
+    y0 = (C.c_uint32 * 1)(0); y1 = (C.c_uint32 * 1)(H // 2)
+    assert ctx.lib.b32_gather_bands_rccl_loopback(ctx.h, comm, 0, 1, 0, y0, y1, H // 4) == E             # destination overlaps the band
+    assert ctx.lib.b32_gather_bands_rccl_loopback(ctx.h, comm, 0, 1, 0, y0, y1, H // 2 + 1) == E         # ... or leaves the framebuffer
+    assert ctx.lib.b32_gather_bands_rccl_loopback(ctx.h, comm, 0, 1, 0, y0, y1, 0xFFFFFFFF) == E
+    for frame in range(3):                                          # (the transfer of one frame behind the kernels of the same frame, three times)
+        fb.clear(sc.clear_color)
+        rs.render_async(sc.camera, sc.settings, sc.fog)
+        ctx.gather_bands_rccl(comm, 0, 1, 0, [(0, H // 2)], loopback_dst_y0=H // 2)
+    ctx.gather_bands_rccl(comm, 0, 1, 0, [(0, H // 2)])             # one rank, no loopback: nothing to do
+    tm = rs.finish()
+    got = fb.pixels.reshape(H, W, 4)
+    top = want.reshape(H, W, 4)[:H // 2]
+    assert np.array_equal(got[:H // 2], top), "the band itself"
+    assert np.array_equal(got[H // 2:], top), "the band's rows after ncclSend / ncclRecv to self"
+    assert tm.triangles_drawn == otm.triangles_drawn
+    ctx.rccl_comm_destroy(comm)
+    ctx.close()
+
+
+@pytest.mark.parametrize("transport", ["shm", "rccl"])
+def test_bench_c4_through_the_c_abi(transport):
+    """BASELINE config C4 end to end through the product's own boundary: the driver's scaling command --
+    `torch.distributed.run ... bench.py --gpus 4` -- with the four ranks sharing GPU 0 (gloo carries only the set-up bytes and the
+    barriers).  `--transport shm`: every band rank maps rank 0's framebuffer (b32_band_import) and stores its rows of the 1 M-triangle
+    frame into it, ordered by the device-side epoch words; the run-time self-check against the torch-gathered frame passes, no wait times
+    out, and the timed frames' last one is bit-exact against the oracle (--check) and the committed hash.  `--transport rccl`: RCCL
+    refuses ranks that share a GPU, so the set-up fails on every rank, the line SAYS it fell back to torch.distributed, and the frame
+    is still right."""
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=4", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "6", "--warmup", "2",
+                        "--transport", transport, "--dist-backend", "gloo", "--check"], capture_output=True, text=True, timeout=1500, env=env)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert "parity vs oracle: bit-exact" in r.stderr, r.stderr[-3000:]
+    assert line["n_gpus"] == 4 and line["bit_exact_vs_committed_hash"] is True
+    t = line["transport"]
+    assert t["requested"] == transport
+    if transport == "shm":
+        assert t["used"] == "shm" and t["self_check"] == "passed" and t["timeouts"] == 0 and t["fallback_reason"] is None, t
+        assert "b32_band_export" in line["config"]["parallelism"]
+    else:
+        assert t["used"] == "torch" and t["self_check"] == "failed" and t["fallback_reason"], t
+    assert line["weak_series"]["tris"] == 500000
+
+
 def _console_meshes(n_meshes, seed0, blend_every=4):
     rng = np.random.default_rng(seed0)
     meshes = []
