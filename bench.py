@@ -432,18 +432,34 @@ def main():
         one_stream_ms = (time.perf_counter() - q0) / args.steps * 1e3
         rs.finish()
         ctx.set_routes((R.Context.ROUTE_PIPELINE if args.no_pipeline else 0) | args.routes_off)
+        # (twice: with the framebuffer this run draws into -- a torch tensor bound by b32_fb_bind_device, where a clear settles the pending
+        # frame because the tensor can be read behind the library's back -- and with the library's own framebuffer (b32_fb_new, what the
+        # drop-in Framebuffer::new gives a host), where a clear of the whole band supersedes the pending frame instead)
         ctx.set_async_depth(0)
         torch.cuda.synchronize(dev)
         q0 = time.perf_counter()
         for _ in range(args.steps):
             step()
         torch.cuda.synchronize(dev)
+        safe_bound_ms = (time.perf_counter() - q0) / args.steps * 1e3
+        rs.finish()
+        own = R.Framebuffer(W, H, ctx)                      # b32_fb_new: the context now draws into its own allocation
+        own.set_band(y0, y1)
+        for _ in range(3):
+            step()
+        rs.finish(); torch.cuda.synchronize(dev)
+        q0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize(dev)
         safe_ms = (time.perf_counter() - q0) / args.steps * 1e3
         rs.finish()
+        safe_sha = hashlib.sha256(own.pixels).hexdigest()
+        fb.bind_device(frame.data_ptr(), W, H); fb.set_band(y0, y1)
         ctx.set_async_depth(1)
     else:
         cover_ms, cover_samples = cover_ms_timed, (args.steps + EVENT_STRIDE - 1) // EVENT_STRIDE
-        latency_ms = one_stream_ms = safe_ms = None
+        latency_ms = one_stream_ms = safe_ms = safe_bound_ms = safe_sha = None
 
     # ---- weak-scaling point (north_star's >= 0.7 target): N x 125 k triangles on the same 2560x1920 frame, so every
     # rank's band keeps the fragments and binned triangles of the 1-GPU 125 k scene.  Reported beside the headline (which is the
@@ -717,7 +733,11 @@ def main():
                          "frame_latency_ms": round(latency_ms, 5) if latency_ms else None,
                          "ms_per_step_one_stream": round(one_stream_ms, 5) if one_stream_ms else None,
                          "ms_per_step_safe_mode": round(safe_ms, 5) if safe_ms else None,
-                         "safe_mode_note": "b32_set_async_depth(0), the library default: a large scene's pending frame is settled (host synchronisation) before the next is enqueued"},
+                         "ms_per_step_safe_mode_bound_fb": round(safe_bound_ms, 5) if safe_bound_ms else None,
+                         "safe_mode_frame_identical": (safe_sha == sha) if safe_sha else None,
+                         "safe_mode_note": "b32_set_async_depth(0), the library default.  ms_per_step_safe_mode: the library's own framebuffer (b32_fb_new) -- a clear of the "
+                                           "whole band supersedes the pending frame, no host synchronisation per frame; ..._bound_fb: caller-bound memory (b32_fb_bind_device, "
+                                           "this run's torch tensor) -- every clear settles the pending frame (one host synchronisation): it can be read behind the library's back"},
             "phases_ms": {k: round(v, 4) for k, v in phases.items()},
             "roofline": roofline,
             "cpu_baseline": cpu,

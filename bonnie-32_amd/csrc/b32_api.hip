@@ -123,6 +123,10 @@ static int fb_resize_any(b32_ctx* c, uint32_t w, uint32_t h, bool always_new) {
     { const int rcf = flush_clear(c); if (rcf) return rcf; }
     if (c->fb_external) { c->fb_external = false; c->fb = nullptr; c->width = c->height = 0; }
     if (!always_new && c->fb && c->width == w && c->height == h) return B32_OK;          // Framebuffer::resize: no-op on equal dims
+    // an exported framebuffer that changes size (or is made anew) is no longer the one the ranks mapped: the epoch words sit behind the
+    // pixels at an offset that depends on the size, and the old mapping may be freed below -- the root must b32_band_export again
+    // (until then b32_band_wait / _release / _status return B32_E_ARG instead of touching pixels or freed memory)
+    if (c->band_sync_own) { c->band_sync_own = nullptr; if (c->band_rank == 0) c->band_sync = nullptr; }
     const size_t px = (size_t)w * h;
     if (px > c->fb_own_px || !c->fb_own) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -178,7 +182,12 @@ int b32_fb_clear(b32_ctx* c, uint8_t r, uint8_t g, uint8_t b, uint8_t blend) {
     // can no longer be seen.  It is marked superseded instead, and the draw that follows is enqueued behind it like in deep mode (the
     // setup kernel of the new frame beside the fill of the old one): the reference's loop -- clear, draw, clear, draw -- runs without a
     // host synchronisation per frame in the library's DEFAULT mode too.  Anything that reads the framebuffer in between still settles.
-    if (!c->deep_async && c->frame_pending && c->pending_may_redraw) c->pending_superseded = true;
+    // Only for a framebuffer that can be read through this library alone (every such read settles): memory the caller bound
+    // (b32_fb_bind_device: a torch tensor, an RCCL gather) or shares with other ranks (b32_band_export / _import / _attach) is read behind
+    // the library's back -- there the pending frame is settled here as before, so that an overflowing first frame is redrawn and its
+    // capacities grow instead of every later frame of a clear / draw loop overflowing the same way unseen.
+    const bool only_ours = !c->fb_external && !c->band_sync && !c->band_sync_own;
+    if (!c->deep_async && c->frame_pending && c->pending_may_redraw && only_ours) c->pending_superseded = true;
     else { const int rc = settle_before_write(c); if (rc) return rc; }
     const uint32_t a = blend == B32_BLEND_ERASE ? 0u : 255u;               // Color::to_bytes, types.rs:829-832
     const uint32_t rgba = r | (g << 8) | (b << 16) | (a << 24);

@@ -677,6 +677,10 @@ int b32_frame_finish(b32_ctx* c, B32Timings* out) {
         b32_ctx* c; bool on; uint32_t rgba, y0, y1;
         ~ClearAfter() { if (on) { c->clear_pending = true; c->clear_rgba = rgba; c->clear_y0 = y0; c->clear_y1 = y1; (void)flush_clear(c); (void)hipStreamSynchronize(c->stream); } }
     } clear_after{ c, later_clear, lc_rgba, lc_y0, lc_y1 };
+    // A superseded frame (safe mode, b32_fb_clear) whose clear has ALREADY been executed -- something flushed it without settling:
+    // b32_synchronize -- must not be redrawn: its pixels would land on top of that clear.  It is retired instead: its counters and
+    // errors are read, the capacities it asked for are granted to the frames that follow, nothing is enqueued.
+    const bool no_redraw = c->frame_pending && c->pending_superseded && !later_clear;
     if (!later_clear) { const int rcf = flush_clear(c); if (rcf) return rcf; }
     if (!c->frame_pending) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -702,6 +706,7 @@ int b32_frame_finish(b32_ctx* c, B32Timings* out) {
             // direct binning: a tile region was too small and nothing was drawn; redraw this frame with regions a quarter above the
             // longest list it reported (enqueue_frame falls back to the compact counting sort if those would not fit)
             c->direct_cap_opaque = c->h_ctrl.list_demand + c->h_ctrl.list_demand / 4 + 64;
+            if (no_redraw) break;
             c->routes[4]++;
             c->ev_frames = 0;
             c->redrawing = true;
@@ -714,6 +719,7 @@ int b32_frame_finish(b32_ctx* c, B32Timings* out) {
             // a tile list was longer than the LDS sort handles: nothing was drawn; redraw this frame (and the following ones of
             // this scene) with the global depth sort
             c->local_sort_ok = false;
+            if (no_redraw) break;
             c->routes[5]++;
             c->ev_frames = 0;
             c->redrawing = true;
@@ -728,6 +734,7 @@ int b32_frame_finish(b32_ctx* c, B32Timings* out) {
         int rc;
         for (int i = 0; i < 2; ++i) { if ((rc = ensure_plain(c, c->pkeys[i], n))) return rc; if ((rc = ensure_plain(c, c->pvals[i], n))) return rc; }
         c->cap_pairs = n;
+        if (no_redraw) break;
         c->routes[6]++;
         c->ev_frames = 0;                              // the aborted frame must not enter the phase averages
         c->redrawing = true;
@@ -759,10 +766,12 @@ int b32_frame_finish(b32_ctx* c, B32Timings* out) {
         sticky = (sticky | (st2 & 0xFFu)) + (st2 & ~0xFFu);
     }
     if (c->deferred_rc) { const int d = c->deferred_rc; c->deferred_rc = 0; return d; }     // (an earlier mesh of this frame, settled by a swap)
-    if (c->h_ctrl.pairs_overflow) return B32_E_HIP;
+    if (c->h_ctrl.pairs_overflow && !no_redraw) return B32_E_HIP;
     // deep asynchronous mode: an earlier frame was lost (the last one is good).  (Safe mode only ever leaves a frame behind when a clear of
     // the whole band has overwritten whatever it drew: nothing observable was lost.)
-    if ((sticky >> 8) && c->deep_async) return B32_E_FRAME_DROPPED;
+    // (a framebuffer that is read behind the library's back -- caller-bound or shared with other ranks -- is never superseded; should a
+    // dropped frame be counted there all the same, it is reported)
+    if ((sticky >> 8) && (c->deep_async || c->fb_external || c->band_sync)) return B32_E_FRAME_DROPPED;
     if (c->h_ctrl.err_index || (sticky & 1u)) return B32_E_INDEX;
     if (c->h_ctrl.abort || (sticky & 2u)) return B32_E_NAN_KEY;
     if (sticky & 8u) return B32_E_HIP;                         // (k_join gave up on a setup kernel: internal)

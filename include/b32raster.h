@@ -241,7 +241,10 @@ int b32_frame_finish(b32_ctx* ctx, B32Timings* out /* nullable */);
  *            frame is marked superseded instead of settled and the draw that follows is enqueued behind it like in deep mode -- the
  *            reference's loop (clear, draw, clear, draw; game/renderer.rs:91-95) runs without a host synchronisation per frame in
  *            this default mode too.  Any call that READS the framebuffer in between still settles; errors of a superseded frame are
- *            still reported by the next b32_frame_finish.
+ *            still reported by the next b32_frame_finish.  The exception applies only to a framebuffer nobody can read behind the
+ *            library's back: the library's own allocation (b32_fb_new / _resize), not exported to other ranks.  With caller-bound memory
+ *            (b32_fb_bind_device) or a framebuffer shared by b32_band_export / _import / _attach the clear settles the pending frame as
+ *            every other write does.  A superseded frame whose clear has meanwhile been executed (b32_synchronize) is never redrawn.
  *   deep = 1: throughput.  Frames are enqueued back to back with no host synchronisation (bench.py and the tools that call
  *            b32_set_async_depth(ctx, 1): static camera, capacities settled by a warm-up frame).  Only the most recent frame can be redrawn; if an earlier one was dropped,
  *            b32_frame_finish reports B32_E_FRAME_DROPPED -- never silently.  Consumers outside the library that read the bound

@@ -504,6 +504,91 @@ def test_safe_mode_clear_supersedes_a_pending_frame(oracle):
     ctx.close()
 
 
+def test_superseded_frame_is_not_redrawn_over_an_executed_clear(oracle):
+    """ADVICE r5 (b32_frame.hip): draw A (overflows its tile regions on a fresh context: nothing drawn), b32_fb_clear (safe mode marks A
+    superseded, the clear stays deferred), b32_synchronize (flushes the clear WITHOUT settling: it now sits behind A on the stream), draw
+    B.  A must be retired, not redrawn -- a redraw would put A's pixels on top of the executed clear and B would be drawn over them.
+    Expected picture: the clear colour + B, exactly as the reference's sequence gives; A's capacities are still granted (B's view of the
+    same far mesh needs them) and no error is reported.  The same with a download in place of draw B: the cleared frame, nothing of A."""
+    from bonnie32_amd import rasterizer as R
+    sc = scenegen.make_scene("C3", n_tris=120_000, width=640, height=480, bbox_px=60.0, seed=321)
+    far = b32.Camera(position=(0.0, 0.0, -45000.0)); far_shifted = b32.Camera(position=(3000.0, 0.0, -45000.0))
+    red = b32.Color(200, 10, 10)
+    for tail in ("draw", "download"):
+        ctx = R.Context(0)
+        fb = R.Framebuffer(sc.width, sc.height, ctx)
+        rs = R.ResidentScene(fb, sc.vertices, sc.faces, sc.textures)
+        fb.clear(sc.clear_color); rs.render_async(far, sc.settings)          # A
+        fb.clear(red)
+        ctx.synchronize()
+        want = oracle.Framebuffer(sc.width, sc.height); want.clear(red)
+        if tail == "draw":
+            rs.render_async(far_shifted, sc.settings)                         # B, on the red frame
+            assert oracle.render_mesh_15(want, sc.vertices, sc.faces, sc.textures, far_shifted, sc.settings)[0] == 0
+        got = fb.pixels
+        assert np.array_equal(got, want.pixels), f"{tail}: {int((got != want.pixels).sum())} bytes differ"
+        rs.finish()
+        assert ctx.route_counts()["redraw_region"] <= (1 if tail == "draw" else 0)      # (A itself was never redrawn)
+        ctx.close()
+
+
+def test_safe_mode_settles_at_a_clear_when_the_framebuffer_is_read_elsewhere(oracle):
+    """ADVICE r5 (b32_api.hip): with caller-bound framebuffer memory (b32_fb_bind_device) the pixels are read behind the library's back,
+    so a b32_fb_clear must SETTLE the pending frame as it did before round 5, not supersede it: a clear / draw loop that never calls
+    b32_frame_finish and whose first frame overflows its tile regions (fresh context, far view) would otherwise overflow the same way
+    forever, unseen.  The bound memory here is another context's framebuffer (b32_band_attach: also the shared-framebuffer case); it is
+    read through THAT context, not through the one that draws."""
+    from bonnie32_amd import rasterizer as R
+    sc = scenegen.make_scene("C3", n_tris=120_000, width=640, height=480, bbox_px=60.0, seed=321)
+    far = b32.Camera(position=(0.0, 0.0, -45000.0))
+    owner = R.Context(0)
+    ofb = R.Framebuffer(sc.width, sc.height, owner)
+    ctx = R.Context(0)                                                         # safe mode (default), fresh capacities
+    ctx.band_attach(owner, 1)
+    fb = R.Framebuffer.__new__(R.Framebuffer); fb.ctx = ctx; fb.width, fb.height = sc.width, sc.height
+    fb.set_band(0, sc.height)
+    rs = R.ResidentScene(fb, sc.vertices, sc.faces, sc.textures)
+    for _ in range(3):
+        fb.clear(sc.clear_color)
+        rs.render_async(far, sc.settings)
+    ctx.synchronize()                                                          # (what an outside reader does: wait for the stream, nothing else)
+    assert ctx.route_counts()["redraw_region"] == 1                            # the first frame was settled -- and redrawn -- at the second clear
+    want = oracle.Framebuffer(sc.width, sc.height); want.clear(sc.clear_color)
+    assert oracle.render_mesh_15(want, sc.vertices, sc.faces, sc.textures, far, sc.settings)[0] == 0
+    got = ofb.pixels
+    assert np.array_equal(got, want.pixels), f"{int((got != want.pixels).sum())} bytes differ"
+    rs.finish()
+    ctx.close(); owner.close()
+
+
+def test_resized_root_must_export_again(gpu_ctx):
+    """ADVICE r5 (b32_api.hip): the epoch words of an exported framebuffer sit behind its pixels at an offset that depends on its size.
+    After any b32_fb_resize / _new of the root the old words are gone (inside the live pixels, or in freed memory): wait / release /
+    status refuse until the root exports again, and the new export works at the new size."""
+    from bonnie32_amd import rasterizer as R
+    E = b32.abi.B32_E_ARG
+    root = R.Context(0)
+    fb = R.Framebuffer(640, 480, root)
+    root.band_export()
+    root.band_release(1); root.synchronize()
+    assert root.band_status()[1] == 1
+    fb.resize(320, 240)                                                        # fits the old allocation
+    assert root.lib.b32_band_release(root.h, 2) == E and root.lib.b32_band_wait(root.h, 1, 1, 10) == E
+    assert root.lib.b32_band_status(root.h, None, None, None) == E
+    assert root.lib.b32_band_wait_all(root.h, 2, 1, 10, 1) == E
+    share = root.band_export()
+    assert np.frombuffer(share, np.uint32, 2, 64).tolist() == [320, 240]
+    other = R.Context(0); other.band_attach(root, 1); other.band_publish(5); other.synchronize()
+    root.band_wait(1, 5, 1_000_000); root.band_release(5); root.synchronize()
+    epochs, released, timeouts = root.band_status()
+    assert epochs[1] == 5 and released == 5 and timeouts == 0
+    other.band_close()
+    fb.resize(2048, 1024)                                                      # a new allocation
+    assert root.lib.b32_band_status(root.h, None, None, None) == E
+    root.band_export(); assert root.band_status()[1] == 0
+    other.close(); root.close()
+
+
 def test_pipeline_gate_argument_range():
     """b32_set_pipeline_gate: 0 = no hold, 1 .. 1000 = the fill's tail, 1001 .. 2000 = a share of the tiles behind its first round;
     anything above is refused and leaves the setting alone (include/b32raster.h)."""
