@@ -50,7 +50,7 @@ static int build_merged(b32_ctx* c, const b32_ctx::BatchEntry* e, uint32_t n, b3
     HIPCHK(c, hipGetLastError());
     m->nv = (uint32_t)nv; m->nf = (uint32_t)nf; m->nt = (uint32_t)nt; m->pool_texels = (uint32_t)pool; m->mask_dirty = true;
     m->fmt8 = false; m->blend8 = false; m->have_scene = true; m->local_sort_ok = true;
-    m->direct_cap_opaque = 0; m->direct_ntiles = 0; m->direct_ok = true; m->pos_valid = false; m->band_frames = 0;
+    m->direct_cap_opaque = 0; m->direct_ntiles = 0; m->direct_ok = true; m->pos_valid = false; m->lit_valid = false; m->band_frames = 0;
     m->tex_sig_valid = false; m->gen = ++c->gen_counter;
     c->side_dirty = true;
     return B32_OK;

@@ -407,7 +407,7 @@ void launch_setup(hipStream_t s, const FrameParams& fp, const B32Vertex* verts, 
 void launch_gate(hipStream_t s, const Ctrl* prev, uint32_t need, uint32_t patience_ticks);
 void launch_flag(hipStream_t s, Ctrl* ctrl, uint32_t epoch);
 void launch_join(hipStream_t s, Ctrl* ctrl, uint32_t epoch, uint32_t patience_ticks);
-void launch_pack_streams(hipStream_t s, const B32Vertex* verts, uint32_t nv, float* pos12, float* attr12);
+void launch_pack_streams(hipStream_t s, const B32Vertex* verts, uint32_t nv, float* pos12, float* attr12, bool with_lit);
 void launch_project_fixed(hipStream_t s, const float* pos, uint32_t n, B32Camera cam, uint32_t w, uint32_t h,
                           int32_t* sx, int32_t* sy, float* z);
 void launch_selftest(hipStream_t s, int op, const float* a, const float* b, const float* c, float* out, uint32_t n);

@@ -324,18 +324,22 @@ static int plan_route(b32_ctx* c, FrameParams& fp, const SortScratch& sc, bool w
 static int frame_positions(b32_ctx* c, const FrameParams& fp, const float*& pos12, const float*& attr12) {
     int rc;
     pos12 = attr12 = nullptr;
-    (void)fp;
     if (c->nv && c->nf > 8192u && !(c->route_off & B32_ROUTE_PACKED_STREAMS)) {
-        if (!c->pos_valid && c->band_frames >= 1) {
-            if ((size_t)c->nv * 12 > c->cap_pos12 || !c->d_pos12) {      // three streams per vertex, one behind the other: 12 B, 12 B, 24 B
-                if ((rc = ensure_plain(c, c->d_pos12, (size_t)c->nv * 12 + 16))) return rc;
-                c->cap_pos12 = (size_t)c->nv * 12;
+        // streams per vertex, one behind the other: 12 B positions, 12 B (u, v, rgba) and -- only once the mesh has been drawn with a
+        // shading pass -- 24 B (u, v, rgba, normal) for lit frames (floats: 3 + 3 [+ 6] per vertex)
+        const bool want_lit = fp.shading != B32_SHADE_NONE;
+        if ((!c->pos_valid || (want_lit && !c->lit_valid)) && c->band_frames >= 1) {
+            const bool with_lit = want_lit || c->lit_valid;
+            const size_t need = (size_t)c->nv * (with_lit ? 12 : 6);
+            if (need > c->cap_pos12 || !c->d_pos12) {
+                if ((rc = ensure_plain(c, c->d_pos12, need + 16))) return rc;
+                c->cap_pos12 = need;
             }
-            launch_pack_streams(c->stream, c->d_verts, c->nv, c->d_pos12, c->d_pos12 + (size_t)c->nv * 3);
-            c->pos_valid = true; c->side_dirty = true;
+            launch_pack_streams(c->stream, c->d_verts, c->nv, c->d_pos12, c->d_pos12 + (size_t)c->nv * 3, with_lit);
+            c->pos_valid = true; c->lit_valid = with_lit; c->side_dirty = true;
         }
         c->band_frames++;
-        if (c->pos_valid) { pos12 = c->d_pos12; attr12 = c->d_pos12 + (size_t)c->nv * 3; }
+        if (c->pos_valid && (!want_lit || c->lit_valid)) { pos12 = c->d_pos12; attr12 = c->d_pos12 + (size_t)c->nv * 3; }
     }
     return B32_OK;
 }

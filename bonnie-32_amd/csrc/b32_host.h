@@ -124,6 +124,7 @@ struct b32_ctx {
     // packed vertex streams of a resident mesh (k_pack_streams: nv positions of 12 B, then nv (u, v, rgba) of 12 B): built on the second
     // frame of an uploaded mesh too large for the in-kernel list collection
     float* d_pos12 = nullptr; size_t cap_pos12 = 0; bool pos_valid = false; uint32_t band_frames = 0;
+    bool lit_valid = false;             // ... and the 24-byte lit stream behind them (packed on the first frame with a shading pass)
     // (per scene, swapped with the scene slots:)
     uint32_t direct_cap_opaque = 0;                               // opaque entries per tile region (0: sized from the mesh on first use)
     uint32_t direct_ntiles = 0;                                   // the tile grid that size belongs to (another grid: sized again)
@@ -206,7 +207,7 @@ struct b32_scene {
     uint32_t blend_faces = 0;
     bool fmt8 = false, blend8 = false, have_scene = false, may_blend = true, cheap_ok = false, local_sort_ok = true, tex_blend_any = false;
     uint32_t direct_cap_opaque = 0, direct_ntiles = 0; bool direct_ok = true;
-    float* d_pos12 = nullptr; size_t cap_pos12 = 0; bool pos_valid = false; uint32_t band_frames = 0;
+    float* d_pos12 = nullptr; size_t cap_pos12 = 0; bool pos_valid = false; uint32_t band_frames = 0; bool lit_valid = false;
     std::vector<b32_ctx::TexSig> tex_sig; bool tex_sig_valid = false;
 };
 

@@ -93,7 +93,7 @@ static int upload_geometry(b32_ctx* c, const B32Vertex* v, uint32_t nv, const B3
     if (c->nf != nf) { c->direct_cap_opaque = 0; c->direct_ntiles = 0; c->direct_ok = true; }
     c->nv = nv; c->nf = nf;
     c->local_sort_ok = true;
-    c->pos_valid = false; c->band_frames = 0;
+    c->pos_valid = false; c->lit_valid = false; c->band_frames = 0;
     if ((rc = ensure_work(c, nf))) return rc;
     c->gen = ++c->gen_counter;
     c->h_consts[0] = nf;
@@ -325,7 +325,7 @@ int b32_scene_swap(b32_ctx* c, b32_scene* sl) {
     std::swap(c->may_blend, sl->may_blend); std::swap(c->cheap_ok, sl->cheap_ok); std::swap(c->local_sort_ok, sl->local_sort_ok);
     std::swap(c->tex_blend_any, sl->tex_blend_any);
     std::swap(c->direct_cap_opaque, sl->direct_cap_opaque); std::swap(c->direct_ntiles, sl->direct_ntiles); std::swap(c->direct_ok, sl->direct_ok);
-    std::swap(c->d_pos12, sl->d_pos12); std::swap(c->cap_pos12, sl->cap_pos12); std::swap(c->pos_valid, sl->pos_valid); std::swap(c->band_frames, sl->band_frames);
+    std::swap(c->d_pos12, sl->d_pos12); std::swap(c->cap_pos12, sl->cap_pos12); std::swap(c->pos_valid, sl->pos_valid); std::swap(c->band_frames, sl->band_frames); std::swap(c->lit_valid, sl->lit_valid);
     c->tex_sig.swap(sl->tex_sig); std::swap(c->tex_sig_valid, sl->tex_sig_valid);
     return B32_OK;
 }

@@ -794,17 +794,21 @@ __global__ __launch_bounds__(256) void k_upload(const uint4* __restrict__ arena,
 // (and, on a band-sharded frame, reach this rank's rows).  A third stream of 24 bytes per vertex follows the attributes (attr12 + 3 * nv
 // floats): attributes and normal together, what lit frames read for the surviving faces -- out of the 36-byte B32Vertex a wave of neighbouring faces pulls every sector of the
 // vertex array for a third of its bytes.
-__global__ void k_pack_streams(const B32Vertex* __restrict__ verts, uint32_t nv, float* __restrict__ pos12, float* __restrict__ attr12) {
+// with_lit == 0 (a mesh that has not been drawn lit so far): the 24-byte stream is neither allocated nor written -- 72 MB of HBM and of
+// write traffic less per 1 M-face mesh; the first lit frame packs again with it (frame_positions, b32_frame.hip).
+__global__ void k_pack_streams(const B32Vertex* __restrict__ verts, uint32_t nv, float* __restrict__ pos12, float* __restrict__ attr12, uint32_t with_lit) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nv) return;
     const float* vp = reinterpret_cast<const float*>(verts) + (size_t)i * 9;
-    float* lit24 = attr12 + 3 * (size_t)nv + 6 * (size_t)i;
     pos12[3 * (size_t)i] = vp[0]; pos12[3 * (size_t)i + 1] = vp[1]; pos12[3 * (size_t)i + 2] = vp[2];
     attr12[3 * (size_t)i] = vp[3]; attr12[3 * (size_t)i + 1] = vp[4]; attr12[3 * (size_t)i + 2] = vp[8];      // u, v, rgba (bit copy)
-    lit24[0] = vp[3]; lit24[1] = vp[4]; lit24[2] = vp[8]; lit24[3] = vp[5]; lit24[4] = vp[6]; lit24[5] = vp[7];   // the same + the normal
+    if (with_lit) {
+        float* lit24 = attr12 + 3 * (size_t)nv + 6 * (size_t)i;
+        lit24[0] = vp[3]; lit24[1] = vp[4]; lit24[2] = vp[8]; lit24[3] = vp[5]; lit24[4] = vp[6]; lit24[5] = vp[7];   // the same + the normal
+    }
 }
-void launch_pack_streams(hipStream_t s, const B32Vertex* verts, uint32_t nv, float* pos12, float* attr12) {
-    if (nv) hipLaunchKernelGGL(k_pack_streams, dim3((nv + 255) / 256), dim3(256), 0, s, verts, nv, pos12, attr12);
+void launch_pack_streams(hipStream_t s, const B32Vertex* verts, uint32_t nv, float* pos12, float* attr12, bool with_lit) {
+    if (nv) hipLaunchKernelGGL(k_pack_streams, dim3((nv + 255) / 256), dim3(256), 0, s, verts, nv, pos12, attr12, with_lit ? 1u : 0u);
 }
 __global__ void k_ctrl_out(Ctrl* __restrict__ ctrl, uint4* __restrict__ dst) {
     if (threadIdx.x == 0) { unsigned long long* t = reinterpret_cast<Stamps*>(ctrl + 1)->t; if (!t[ST_END]) t[ST_END] = wall_clock64(); }

@@ -1933,6 +1933,34 @@ def test_lit_frames_of_large_meshes(gpu_ctx, oracle, shading, zbuffer):
     fb.set_band(0, sc.height)
 
 
+def test_lit_stream_is_packed_on_the_first_lit_frame(oracle):
+    """The packed vertex streams of a resident large mesh (k_pack_streams): positions + attributes from its second frame on; the 24-byte
+    (u, v, rgba, normal) stream only once a frame with a shading pass is drawn -- the buffer is then reallocated and all three streams
+    packed again (an unlit mesh no longer pays 72 MB per million faces for a stream nobody reads).  Unlit, unlit,
+    unlit, Gouraud, Gouraud, unlit, flat: every frame against the oracle, in safe mode and back to back."""
+    from bonnie32_amd import rasterizer as R
+    sc = scenegen.make_scene("C3", n_tris=60_000, width=1280, height=960, variant="gouraud", seed=77)
+    lights = [b32.Light.directional((-1.0, -1.0, -1.0), 0.7), b32.Light.point((200.0, -100.0, 2500.0), 4000.0, 1.3)]
+    want = {}
+    for shading in (0, 1, 2):
+        st = copy.copy(sc.settings); st.shading = shading; st.lights = lights
+        o = oracle.Framebuffer(sc.width, sc.height); o.clear(sc.clear_color)
+        assert oracle.render_mesh_15(o, sc.vertices, sc.faces, sc.textures, sc.camera, st)[0] == 0
+        want[shading] = (st, o.pixels.copy())
+    for deep in (0, 1):
+        ctx = R.Context(0); ctx.set_async_depth(deep)
+        fb = R.Framebuffer(sc.width, sc.height, ctx)
+        rs = R.ResidentScene(fb, sc.vertices, sc.faces, sc.textures)
+        for i, shading in enumerate((0, 0, 0, 2, 2, 0, 1)):
+            st, exp = want[shading]
+            fb.clear(sc.clear_color)
+            rs.render_async(sc.camera, st)
+            got = fb.pixels
+            assert np.array_equal(got, exp), f"frame {i} (shading {shading}, deep {deep}): {int((got != exp).sum())} bytes differ"
+        rs.finish()
+        ctx.close()
+
+
 @pytest.mark.parametrize("name,ranks", [("C3:100k", 4), ("C1:zbuf", 3), ("C1:blend5", 2)])
 def test_cpp_host_drives_band_ranks_through_the_c_abi(tmp_path, name, ranks):
     """tests/cpp/band_harness.cpp: compiled host code (g++, no Python, no torch) drives `ranks` contexts of ONE process through the C ABI

@@ -9,7 +9,9 @@ uncalibrated for other patterns -- "calibrate on a known byte count in your own 
 the resident B32Vertex array exactly once, 36 B x Nv, with the dword loads k_setup and the fill kernel use too, so
 FETCH_SIZE(k_pack_streams) x 1024 / (36 Nv) is this run's read factor (k_setup's own compulsory reads -- 20 B x Nf faces, 36 B x Nf packed
 positions, 36 B x Nvis packed attributes -- give a second estimate, recorded beside it).  WRITE_SIZE measured exactly 1.000 against
-k_clear's 4 B x pixels in every run that had a k_clear launch (round 1 and 2); k_pack_streams' 24 B x Nv of writes re-check it here."""
+k_clear's 4 B x pixels in every run that had a k_clear launch (round 1 and 2); k_pack_streams' writes re-check it here: 24 B x Nv
+(positions + attributes) for a mesh that has never been drawn with a shading pass -- the profiled configs -- and 48 B x Nv once the 24-byte
+lit stream is packed too (round 5 always wrote all three streams: its passes' "24 B x Nv ... measure 2.000" was 48 B x Nv = 1.000)."""
 import json
 import os
 import re
