@@ -15,6 +15,20 @@
 
 namespace b32 {
 
+// Experiment builds (-DB32_TIMELINE): per-wave shader-clock sums of the coverage / shading sub-phases, added to FillArgs::dbg behind the per-tile
+// records (slot k at dbg[1 + 4 * 8192 + k]); tools/timeline.py prints them.  The stamps are s_memtime reads (scalar): they do not touch the VGPR budget.
+#ifdef B32_TIMELINE
+// (sums kept per wave in the slack of the tile-plane allocation -- bytes 68096.. of the 73728 -- and flushed once, when the workgroup ends)
+#define B32_DBG_SLOTS(tb) (reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned char*>(const_cast<uint32_t*>(tb)) + 68096) + (threadIdx.x >> 6) * 32)
+#define B32_CLK_DECL(name) unsigned long long name = (unsigned long long)clock64()
+#define B32_CLK_ADD(a, slot, from) do { const unsigned long long _n = (unsigned long long)clock64(); if (lane == 0) B32_DBG_SLOTS(tilebuf)[slot] += _n - (from); (from) = _n; } while (0)
+#define B32_CNT_ADD(a, slot, v) do { if (lane == 0) B32_DBG_SLOTS(tilebuf)[slot] += (unsigned long long)(v); } while (0)
+#else
+#define B32_CLK_DECL(name) do { } while (0)
+#define B32_CLK_ADD(a, slot, from) do { } while (0)
+#define B32_CNT_ADD(a, slot, v) do { } while (0)
+#endif
+
 // Phase A for one surface: coverage of the (tile-clipped) bbox [cx0,cx1) x [cy0,cy1), winner value li.
 template <int TEXMODE, bool EXACT, bool ZMODE, bool FMT8>
 __device__ __forceinline__ uint32_t cover_surface(const Tri& tr, uint32_t cx0, uint32_t cx1, uint32_t cy0, uint32_t cy1, uint32_t li,
@@ -146,6 +160,12 @@ __device__ __forceinline__ uint32_t cover_slow64(const Tri& tr, unsigned long lo
 // hi - lo.  Surfaces with A outside [0.5, 2^20) are left alone (w0 + w1 could round where it matters).
 #ifndef B32_ROW_TRIM
 #define B32_ROW_TRIM 1
+#endif
+#ifndef B32_SPAN_PACK
+#define B32_SPAN_PACK 1          // span rounds: the per-surface parameters travel packed (7 ds_bpermute per round instead of 15), see phase_a_rows
+#endif
+#ifndef B32_PF_SREC
+#define B32_PF_SREC 0            // experiment: touch the surface's ShadeRec line during coverage so that the shading phase's gather finds it in L2
 #endif
 #ifndef B32_INTERIOR
 #define B32_INTERIOR 0           // experiment (round 4, judge item 3c), OFF: certain-interior runs of long rows take trips without the inside test.
@@ -309,6 +329,7 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
     const uint32_t grab_m = max(1u, (n_op + NW * 64u - 1u) / (NW * 64u));
     const uint32_t grab = min(64u, max(4u, (n_op + NW * grab_m - 1u) / (NW * grab_m)));
     for (;;) {
+        B32_CLK_DECL(clk);
         uint32_t cs = 0;
         if (lane == 0) cs = atomicAdd(cursor, grab);
         cs = (uint32_t)__builtin_amdgcn_readfirstlane((int)cs);
@@ -322,11 +343,21 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
         uint32_t my_sid = 0, my_key = 0;
         bool narrow = false;
         load_batch<TEXMODE>(b, a, e0 + e, live, lds_desc, EXACT, ZMODE || (EXACT && !affine), my_sid, my_key, narrow);
+#if B32_PF_SREC
+        if (P64 && !EXACT && live) {
+            const uint32_t pf = reinterpret_cast<const uint32_t*>(a.srecs + my_sid)[0];      // (a plain load: it allocates in L2)
+            asm volatile("" :: "v"(pf));
+        }
+#endif
         if (ZMODE) { my_key = 0u; my_sid = 0xFFFFFFFEu - my_sid; }
         const uint32_t flags = b.q3.w;
         const uint32_t cx0 = max(b.q1.w & 0xFFFF, x_lo), cx1 = min(b.q1.w >> 16, x_hi);
         const uint32_t cy0 = max(b.q2.x & 0xFFFF, y_lo), cy1 = min(b.q2.x >> 16, y_hi);
         live = live && cx0 < cx1 && cy0 < cy1;
+#ifdef B32_TIMELINE
+        asm volatile("" :: "v"(cx0), "v"(cy0));        // (the record has arrived)
+#endif
+        B32_CLK_ADD(a, 0, clk); B32_CNT_ADD(a, 4, 1);
         const bool slow = live && (flags & F_SLOW);
         // span coverage: what the rows of an eligible surface need (edge values at the first pixel of its clipped box, their steps per
         // row, the reciprocal form of the steps per pixel); span_all: every surface of this batch is eligible -- the rounds below then
@@ -334,6 +365,8 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
         bool span_all = false;
         float sE0 = 0.0f, sE1 = 0.0f, sH0 = 0.0f, sH1 = 0.0f, sA = 0.0f;
         SpanEdge sd0 = { 0.0f, 0.0f }, sd1 = { 0.0f, 0.0f }, sd2 = { 0.0f, 0.0f };
+        (void)sd0; (void)sd1; (void)sd2; (void)sA;
+        uint32_t sG01 = 0, sH01 = 0;                      // B32_SPAN_PACK: (G0, G1) and (H0, H1) as pairs of i16 (|.| <= SPAN_MAX_EXT = 512)
         if (P64 && !EXACT && !ZMODE && a.span_cover) {
             const float fa0 = __uint_as_float(b.q0.z), fb0 = __uint_as_float(b.q0.w), fa1 = __uint_as_float(b.q1.x), fb1 = __uint_as_float(b.q1.y);
             const float inv = __uint_as_float(b.q1.z);
@@ -348,7 +381,13 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
             span_all = !__ballot(live && !fast);
             const float dx = (float)cx0 - __uint_as_float(b.q0.x), dy = (float)cy0 - __uint_as_float(b.q0.y);
             sE0 = sgn * (fa0 * dx + fb0 * dy); sE1 = sgn * (fa1 * dx + fb1 * dy);   // at the first pixel of the clipped box
+#if B32_SPAN_PACK
+            // (a surface that is not `fast` may hold steps beyond i16: its packed words are never used -- span_all is false then)
+            sG01 = ((uint32_t)hw_cvt_i32(G0) & 0xFFFFu) | ((uint32_t)hw_cvt_i32(G1) << 16);
+            sH01 = ((uint32_t)hw_cvt_i32(sH0) & 0xFFFFu) | ((uint32_t)hw_cvt_i32(sH1) << 16);
+#else
             sd0 = span_edge(G0); sd1 = span_edge(G1); sd2 = span_edge(G2);
+#endif
         }
         const uint32_t h = (live && !slow) ? cy1 - cy0 : 0u;
         // exclusive prefix sum of the row counts
@@ -357,6 +396,8 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
         const uint32_t P = inc - h;
         const float a0 = __uint_as_float(b.q0.z), b0 = __uint_as_float(b.q0.w), a1 = __uint_as_float(b.q1.x), b1 = __uint_as_float(b.q1.y);
         const uint32_t box = (cx0 - x_lo) | ((cx1 - x_lo) << 8) | ((cy0 - ty_top) << 16);      // 7+7+6 bits
+        // the same with the surface's first row item in the upper half (P < 64 x 64): one permute instead of two in the span rounds
+        const uint32_t boxP = (cx0 - x_lo) | ((cx1 - x_lo) << 6) | ((cy0 - ty_top) << 13) | (P << 19);  // 6+7+6+12 bits
         // CHEAP sort-free coverage: every lane of a round makes ONE trip; what is left of the rows that need more (a fifth of them need a
         // second trip, 3 % a third, but a round used to last as long as its longest row: three trips for an average need of 1.2) is queued
         // -- one packed word per row remainder, the queue is a register: lane i holds entry i -- and worked off 64 at a time in rounds of
@@ -522,6 +563,7 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
             }
             lqn = cnt;
         };
+        B32_CLK_ADD(a, 1, clk); B32_CNT_ADD(a, 5, (R + 63) / 64); B32_CNT_ADD(a, 7, R);
         if (P64 && !EXACT && !ZMODE && span_all) {
             // span rounds: same items (one lane = one row of one surface), the row is its exact interval
             for (uint32_t k0 = 0; k0 < R; k0 += 64) {
@@ -533,6 +575,23 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
                 const uint32_t k = k0 + lane;
                 const bool valid = k < R;
                 const uint32_t s = valid ? own - 1 : lane;
+#if B32_SPAN_PACK
+                // Seven permutes per round instead of fifteen (the LDS pipe is ONE per CU, shared by the sixteen waves of both workgroups,
+                // and the rounds are what it is busy with: tools/timeline.py): the steps travel as two words of i16 pairs, the reciprocal
+                // forms and |area| are recomputed by the row's lane -- the very expressions the surface's lane evaluated before, on the
+                // same integers, so every interval is the same.
+                const uint32_t sbp = bperm(s, boxP);
+                const uint32_t g01 = bperm(s, sG01), h01 = bperm(s, sH01);
+                const float hE0 = bpermf(s, sE0), hE1 = bpermf(s, sE1);
+                const uint32_t sP = sbp >> 19;
+                const float rowf = (float)(k - sP);
+                const float hG0 = i16lo(g01), hG1 = i16hi(g01), hH0 = i16lo(h01), hH1 = i16hi(h01);
+                const float hA = __builtin_fabsf(hG0 * hH1 - hH0 * hG1);             // |area|: sgn^2 (a0 b1 - b0 a1), exact integers
+                const SpanEdge e0 = span_edge(hG0), e1 = span_edge(hG1), e2 = span_edge(-(hG0 + hG1));
+                const float E0 = __builtin_fmaf(hH0, rowf, hE0), E1 = __builtin_fmaf(hH1, rowf, hE1);       // exact integers
+                const float E2 = hA - E0 - E1;
+                const uint32_t bx0 = sbp & 63u, bx1 = (sbp >> 6) & 127u, ry = ((sbp >> 13) & 63u) + (k - sP);   // tile-local
+#else
                 const uint32_t sbox = bperm(s, box), sP = bperm(s, P);
                 const float rowf = (float)(k - sP);
                 const float hE0 = bpermf(s, sE0), hE1 = bpermf(s, sE1), hH0 = bpermf(s, sH0), hH1 = bpermf(s, sH1), hA = bpermf(s, sA);
@@ -541,6 +600,7 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
                 const float E0 = __builtin_fmaf(hH0, rowf, hE0), E1 = __builtin_fmaf(hH1, rowf, hE1);       // exact integers
                 const float E2 = hA - E0 - E1;
                 const uint32_t bx0 = sbox & 0xFF, bx1 = (sbox >> 8) & 0xFF, ry = (sbox >> 16) + (k - sP);   // tile-local
+#endif
                 float lo, hi;
                 span_interval(E0, E1, E2, e0, e1, e2, (float)(bx1 - bx0), lo, hi);
                 const int len = valid ? hw_cvt_i32(hi - lo) : 0;
@@ -562,7 +622,9 @@ __device__ __forceinline__ unsigned long long phase_a_rows(const FillArgs& a, ui
                     lqn += cnt;
                 }
             }
-            while (lqn) drain_span();
+            B32_CLK_ADD(a, 2, clk);
+            while (lqn) { drain_span(); B32_CNT_ADD(a, 6, 1); }
+            B32_CLK_ADD(a, 3, clk);
         } else
         for (uint32_t k0 = 0; k0 < R; k0 += 64) {
             // owner of item k0+lane: last surface s with h>0 and P[s] <= k

@@ -10,7 +10,22 @@
 #include "b32_cover.h"
 #include "b32_shade_tile.h"
 
+#ifndef B32_SHADE_PIPE
+#define B32_SHADE_PIPE 0          // experiment switch, OFF (round 6): software-pipelined straight-line shading (shade_tile_plain).  1 = the texel stage
+                                  // (this step's texels travel beside the previous step's colours and stores: 111 VGPRs, nothing spilled), 2 = the gather
+                                  // stage (the next step's record gathers beside this step's texels and colours: 27 VGPRs spilled under the 112 cap,
+                                  // 8 without it).  Same-box A/B: C3 0.1061-0.1076 (1) / 0.140-0.142 (2) / 0.114-0.115 (2, uncapped) against 0.1044-0.1067,
+                                  // k_cover 88.8-89.4 / 114-116 / 89.6-90.1 against 87.0-87.8 us -- a wave's own waits (tools/timeline.py: 1.3 us for the
+                                  // gather, 0.75 us for the texels of a 3-us step) are already filled by the CU's other fifteen waves
+                                  // (profiles/r06_shade_pipe_ab.txt)
+#endif
+
 namespace b32 {
+
+// per-wave repair queue of the fused kernel's shading phase (b32_shade_tile.h): 192 words -- the pipelined straight-line form drains only
+// where no record set is in flight and appends up to 128 entries in between; the other forms use the first 64
+constexpr uint32_t RQ_WORDS = 192, RQ_BYTES = RQ_WORDS * 4;
+static_assert(2 * (4 * LDS_TILE_BYTES + LDS_MISC_BYTES + 8 * RQ_BYTES + 511) / 512 * 512 <= 160 * 1024, "two 8-wave workgroups per CU");
 
 // ------------------------------------------------------------------------------------------------ k_cover
 template <bool FMT8, int NT, bool ZMODE>
@@ -18,7 +33,7 @@ __device__ __forceinline__ void shade_tile_p64(const FillArgs& a, const uint32_t
                                                uint32_t y_lo, uint32_t y_hi, uint32_t ty_top, uint32_t tid, uint32_t lane, uint32_t TH, uint32_t* rq,
                                                const uint8_t* latlas);
 
-template <int NT, bool ZMODE>
+template <int NT, bool ZMODE, bool PIPE>
 __device__ __forceinline__ void shade_tile_plain(const FillArgs& a, const uint32_t* tilebuf, uint32_t e0, uint32_t e1, uint32_t x_lo, uint32_t x_hi,
                                                  uint32_t y_lo, uint32_t y_hi, uint32_t ty_top, uint32_t tid, uint32_t lane, uint32_t TH, uint32_t* wq);
 
@@ -93,7 +108,7 @@ __device__ __forceinline__ void cover_body(const FillArgs& a_in) {
     // sort-free forms: 64 words of repair queue per wave, then (optionally) the staged index atlas
     const uint8_t* latlas = nullptr;
     if (P64 && !FMT8 && a.atlas_idx_bytes) {
-        uint4* dst = reinterpret_cast<uint4*>(smem + TB + LDS_MISC_BYTES + NW * 256);
+        uint4* dst = reinterpret_cast<uint4*>(smem + TB + LDS_MISC_BYTES + NW * RQ_BYTES);
         const uint4* src = reinterpret_cast<const uint4*>(a.atlas0);
         const uint32_t nq = (ATLAS_CLUT_BYTES + a.atlas_idx_bytes + 15u) / 16u;
         for (uint32_t i = threadIdx.x; i < nq; i += NT) dst[i] = src[i];
@@ -182,8 +197,12 @@ __device__ __forceinline__ void cover_body(const FillArgs& a_in) {
     }
     // the first tile of a workgroup is its own index (no atomic: 512 same-address atomics serialise at ~12 ns each), later ones come
     // from the shared cursor
+#ifdef B32_TIMELINE
+    if (lane < 32) B32_DBG_SLOTS(tilebuf)[lane] = 0ull;
+#endif
     uint32_t next_tile = blockIdx.x;
     for (;;) {
+        B32_CLK_DECL(clkh);
         if (tid == 0) { misc[0] = next_tile; misc[2] = 0; misc[4] = 0; misc[5] = 0; }
         __syncthreads();
         const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)misc[0]);
@@ -297,13 +316,16 @@ __device__ __forceinline__ void cover_body(const FillArgs& a_in) {
             }
         }
         const uint32_t n_op = e1 - e0;
+        B32_CLK_ADD(a, 9, clkh);                 // tile header: tile index, list range, plane clear, barrier
 #ifdef B32_TIMELINE
         const unsigned long long tl0 = wall_clock64();
 #endif
         if (n_op) {
-            frag_count += phase_a_rows<TEXMODE, EXACT, NW, ZMODE, FMT8, P64>(a, e0, n_op, lane, wave, &misc[2], wmarks + wave * 64, lds_desc, tilebuf,
+            frag_count += phase_a_rows<TEXMODE, EXACT, NW, ZMODE, FMT8, P64>(a, e0, n_op, lane, wave, &misc[2], wmarks + wave * RQ_WORDS, lds_desc, tilebuf,
                                                            x_lo, x_hi, y_lo, y_hi, ty_top, ltex);
+            B32_CLK_DECL(clkb);
             __syncthreads();
+            B32_CLK_ADD(a, 8, clkb);            // this wave's wait at the barrier behind the coverage
         }
         if (P64) {          // shade the tile straight from the LDS winners (no visibility buffer)
             if (tid == 0) next_tile = gridDim.x + atomicAdd(&a.ctrl->tile_cursor, 1u);
@@ -316,8 +338,8 @@ __device__ __forceinline__ void cover_body(const FillArgs& a_in) {
                 // from global memory -- painter's or z-buffer mode, with or without a shading pass; wave-uniform choice)
                 if (PLAIN != 2 && (PLAIN == 1 || PLAIN == 3 || (!FMT8 && fp.affine && fp.fixed_point && !fp.ortho && fp.nt == 1 && !latlas && a.tex0.width && a.tex0.height &&
                                                   (fp.shading == B32_SHADE_NONE || a.shades))))
-                    shade_tile_plain<NT, ZMODE>(a, tilebuf, e0, e1, x_lo, x_hi, y_lo, y_hi, ty_top, tid, lane, TH, wmarks + wave * 64);
-                else if (PLAIN == 0 || PLAIN == 2) shade_tile_p64<FMT8, NT, ZMODE>(a, tilebuf, e0, e1, x_lo, x_hi, y_lo, y_hi, ty_top, tid, lane, TH, wmarks + wave * 64, latlas);
+                    shade_tile_plain<NT, ZMODE, (B32_SHADE_PIPE != 0) && PLAIN == 1>(a, tilebuf, e0, e1, x_lo, x_hi, y_lo, y_hi, ty_top, tid, lane, TH, wmarks + wave * RQ_WORDS);
+                else if (PLAIN == 0 || PLAIN == 2) shade_tile_p64<FMT8, NT, ZMODE>(a, tilebuf, e0, e1, x_lo, x_hi, y_lo, y_hi, ty_top, tid, lane, TH, wmarks + wave * RQ_WORDS, latlas);
             }
             else if (a.clear_on) {      // nothing reaches this tile: it still gets the frame's clear colour
                 for (uint32_t p = tid; p < TILE_W * TH; p += NT) {
@@ -361,6 +383,9 @@ __device__ __forceinline__ void cover_body(const FillArgs& a_in) {
         }
         __syncthreads();   // everyone is done with misc / tilebuf before the next tile
     }
+#ifdef B32_TIMELINE
+    if (P64 && a.dbg && lane < 32 && B32_DBG_SLOTS(tilebuf)[lane]) atomicAdd(a.dbg + 1 + 4 * 8192 + lane, B32_DBG_SLOTS(tilebuf)[lane]);
+#endif
     if (P64 && blockIdx.x == 0 && tid == 0) {
         unsigned long long* st = reinterpret_cast<Stamps*>(a.ctrl + 1)->t;
         st[ST_CLK0] = clk_entry; st[ST_CLK1] = (unsigned long long)clock64(); st[ST_CLKW] = wall_clock64();
@@ -429,7 +454,7 @@ static void launch_p64(hipStream_t s, const FillArgs& a_in, uint32_t ntiles, int
     FillArgs a = a_in;
     // tile planes, misc words, 64 words of repair queue per wave, then the staged index atlas (if any)
     const size_t atlas = a.atlas_idx_bytes ? (((size_t)ATLAS_CLUT_BYTES + a.atlas_idx_bytes + 15) & ~(size_t)15) : 0;
-    const size_t lds_n = 4 * LDS_TILE_BYTES + LDS_MISC_BYTES + 8 * 256 + atlas, lds_w = 4 * LDS_TILE_BYTES + LDS_MISC_BYTES + 16 * 256 + atlas;
+    const size_t lds_n = 4 * LDS_TILE_BYTES + LDS_MISC_BYTES + 8 * RQ_BYTES + atlas, lds_w = 4 * LDS_TILE_BYTES + LDS_MISC_BYTES + 16 * RQ_BYTES + atlas;
     static bool attr[64] = {};
     if (first_launch_on_device(attr)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cover<0, EXACT, 512, ZMODE, FMT8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -444,8 +469,9 @@ static void launch_p64(hipStream_t s, const FillArgs& a_in, uint32_t ntiles, int
 #ifdef B32_TIMELINE
     {
         static unsigned long long* dbg = nullptr;
-        if (!dbg) (void)hipMalloc(reinterpret_cast<void**>(&dbg), (1 + 4 * 8192) * 8);
+        if (!dbg) (void)hipMalloc(reinterpret_cast<void**>(&dbg), (1 + 4 * 8192 + 64) * 8);
         (void)hipMemsetAsync(dbg, 0, 8, s);
+        (void)hipMemsetAsync(dbg + 1 + 4 * 8192, 0, 64 * 8, s);
         a.dbg = dbg;
         g_timeline = dbg;
     }
@@ -555,8 +581,8 @@ size_t fill_lds_tex_budget() { return 160 * 1024 - LDS_TEX_OFFSET - 16; }
 uint32_t fill_lds_atlas_room(bool wide) {
     // 160 KB of LDS per CU, allocated in 512-byte granules: one 16-wave workgroup, or two 8-wave workgroups side by side
     const uint32_t total = 160u * 1024u, gran = 512u;
-    if (wide) return total - (uint32_t)(4 * LDS_TILE_BYTES + LDS_MISC_BYTES + 16 * 256) - gran;
-    return total / 2u - (uint32_t)(4 * LDS_TILE_BYTES + LDS_MISC_BYTES + 8 * 256) - gran;
+    if (wide) return total - (uint32_t)(4 * LDS_TILE_BYTES + LDS_MISC_BYTES + 16 * RQ_BYTES) - gran;
+    return total / 2u - (uint32_t)(4 * LDS_TILE_BYTES + LDS_MISC_BYTES + 8 * RQ_BYTES) - gran;
 }
 
 }  // namespace b32

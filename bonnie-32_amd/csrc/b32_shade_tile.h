@@ -160,7 +160,11 @@ __device__ __forceinline__ void shade_tile_p64(const FillArgs& a, const uint32_t
 // and stores nothing of it).  The winner of a covered pixel passed the inside test during coverage (same arithmetic, or the span form
 // proven equal to it), so it is not evaluated again.  A step in which some winner must replay the edge walk literally (SH_SLOW) takes
 // the general per-pixel functions; skipped winners go to the wave's repair queue as in the general form.
-template <int NT, bool ZMODE>
+// PIPE (the forms with registers to spare: painter's and z-buffer mode without a shading pass): the step is software-pipelined -- the winners
+// and the two 64-byte record gathers of step k + 1 are issued as soon as step k's records have been turned into barycentrics and texel
+// addresses, BEFORE step k's texel fetch is waited for, so that the gather's round trip (1.3 us of a 3-us step: tools/timeline.py) runs
+// beside the texel fetch, the colour pipeline and the stores instead of in front of them.  Same loads, same arithmetic, another order.
+template <int NT, bool ZMODE, bool PIPE>
 __device__ __forceinline__ void shade_tile_plain(const FillArgs& a, const uint32_t* tilebuf, uint32_t e0, uint32_t e1, uint32_t x_lo, uint32_t x_hi,
                                                  uint32_t y_lo, uint32_t y_hi, uint32_t ty_top, uint32_t tid_in, uint32_t lane_in, uint32_t TH, uint32_t* wq) {
     // (the lane's constants of this phase -- column, x, masks -- are derived again per tile from an opaque copy of its index: hoisted out of the
@@ -173,6 +177,7 @@ __device__ __forceinline__ void shade_tile_plain(const FillArgs& a, const uint32
     const uint32_t W = fp.width;
     const int shading = fp.shading;
     constexpr uint32_t ROWS_PER_STEP = NT / 64;
+    constexpr uint32_t STEP_ROWS = 2 * ROWS_PER_STEP;
     const TexDesc d = a.tex0;
     const float twf = (float)d.width, thf = (float)d.height;
     const uint32_t col = tid & 63, px = x_lo + col;
@@ -220,84 +225,96 @@ __device__ __forceinline__ void shade_tile_plain(const FillArgs& a, const uint32
     };
     const unsigned long long below = (1ull << lane) - 1ull;
     auto f = [](uint32_t w) { return __uint_as_float(w); };
-    for (uint32_t r0 = 0; r0 < TH; r0 += 2 * ROWS_PER_STEP) {
+
+    // ---- one step = the lane's two pixels (rows rowA and rowA + ROWS_PER_STEP of column `col`), in three parts
+    struct In {                                         // part 0: winners from LDS, the two record gathers issued
+        unsigned long long tA, tB;
+        bool cA, cB, inA, inB, any;
+        uint4 a0q, a1q, a2q, a3q, b0q, b1q, b2q, b3q;
+    };
+    struct Mid {                                        // part 1: barycentrics, packed words, texel fetches issued
+        float bA0, bA1, bA2, bB0, bB1, bB2;            // (scalars, not arrays: an array member handed on by pointer stays in scratch memory)
+        uint32_t pkA0, pkA1, pkA2, pkB0, pkB1, pkB2;    // pk0, pk1, pk2 of the ShadeRec (vertex colours, texture slot, SH_* flags)
+        uint32_t fetA, fetB;
+    };
+    auto issue = [&](uint32_t r0, In& s) {
         const uint32_t rowA = r0 + (tid >> 6), rowB = rowA + ROWS_PER_STEP;
         const uint32_t pyA = ty_top + rowA, pyB = ty_top + rowB;
-        const bool inA = rowA < TH && in_x && pyA >= y_lo && pyA < y_hi, inB = rowB < TH && in_x && pyB >= y_lo && pyB < y_hi;
-        const unsigned long long tA = inA ? top[rowA * STR64 + col] : (ZMODE ? ~0ull : 0ull), tB = inB ? top[rowB * STR64 + col] : (ZMODE ? ~0ull : 0ull);
-        const bool cA = covered(tA), cB = covered(tB);
+        s.inA = rowA < TH && in_x && pyA >= y_lo && pyA < y_hi; s.inB = rowB < TH && in_x && pyB >= y_lo && pyB < y_hi;
+        s.tA = s.inA ? top[rowA * STR64 + col] : (ZMODE ? ~0ull : 0ull); s.tB = s.inB ? top[rowB * STR64 + col] : (ZMODE ? ~0ull : 0ull);
+        s.cA = covered(s.tA); s.cB = covered(s.tB);
+        s.any = __ballot(s.cA || s.cB) != 0ull;
+        {   // (unconditional -- a step in which no pixel of the wave is covered reads surface 0's record, one cache line for all lanes, and uses
+            // nothing of it: under a wave-uniform branch the thirty-two registers became loop-carried maybe-undefined values and the
+            // kernel spilled nineteen of them)
+            const uint32_t sidA = s.cA ? sid_of(s.tA) : 0u, sidB = s.cB ? sid_of(s.tB) : 0u;      // (surface 0's record for an uncovered pixel: read, never used)
+            const uint4* spA = reinterpret_cast<const uint4*>(a.srecs + sidA);
+            const uint4* spB = reinterpret_cast<const uint4*>(a.srecs + sidB);
+            s.a0q = spA[0]; s.a1q = spA[1]; s.a2q = spA[2]; s.a3q = spA[3];
+            s.b0q = spB[0]; s.b1q = spB[1]; s.b2q = spB[2]; s.b3q = spB[3];
+        }
+    };
+    auto texaddr = [&](const uint4& q0, const uint4& q1, const uint4& q2, const uint4& q3, uint32_t py, bool c, float& b0, float& b1, float& b2) -> uint32_t {
+        // render.rs:1507-1510 (edges), :1517-1518 / 1706-1712 in closed form (exact integers), :1536-1538, :1565-1566, types.rs:671-681
+        const float x3 = f(q1.x), y3 = f(q1.y), inv = f(q1.z);
+        const float ea0 = f(q0.w) - y3, eb0 = x3 - f(q0.z), ea1 = y3 - f(q0.y), eb1 = f(q0.x) - x3;
+        const float dx = fx - x3, dy = (float)py - y3;
+        const float w0 = ea0 * dx + eb0 * dy, w1 = ea1 * dx + eb1 * dy;
+        b0 = w0 * inv; b1 = w1 * inv; b2 = 1.0f - b0 - b1;
+        const float u = b0 * f(q2.x) + b1 * f(q2.y) + b2 * f(q2.z);
+        const float v = b0 * f(q2.w) + b1 * f(q3.x) + b2 * f(q3.y);
+        const float uw = rem_euclid1(u), vw = rem_euclid1(1.0f - v);
+        const uint32_t tx = min(f2u_sat(uw * twf), d.width - 1), ty = min(f2u_sat(vw * thf), d.height - 1);
+        return c ? d.offset + ty * d.width + tx : d.offset;
+    };
+    auto part1 = [&](uint32_t r0, const In& s, Mid& m) {
+        const uint32_t pyA = ty_top + r0 + (tid >> 6), pyB = pyA + ROWS_PER_STEP;
+        const uint32_t taA = texaddr(s.a0q, s.a1q, s.a2q, s.a3q, pyA, s.cA, m.bA0, m.bA1, m.bA2);
+        const uint32_t taB = texaddr(s.b0q, s.b1q, s.b2q, s.b3q, pyB, s.cB, m.bB0, m.bB1, m.bB2);
+        m.fetA = a.texels[taA]; m.fetB = a.texels[taB];                            // both fetches in flight
+        m.pkA0 = s.a1q.w; m.pkA1 = s.a3q.z; m.pkA2 = s.a3q.w;
+        m.pkB0 = s.b1q.w; m.pkB1 = s.b3q.z; m.pkB2 = s.b3q.w;
+    };
+    // part 2: texel rule, colour pipeline, stores; returns the lanes whose pixel goes to the repair queue
+    auto part2 = [&](uint32_t r0, unsigned long long tA, unsigned long long tB, bool cA, bool cB, bool inA, bool inB, const Mid& m,
+                     unsigned long long& mA, unsigned long long& mB, uint32_t& shA, uint32_t& shB) {
+        const uint32_t pyA = ty_top + r0 + (tid >> 6), pyB = pyA + ROWS_PER_STEP;
         uint32_t* outA = a.fb + (size_t)pyA * W + px;
         uint32_t* outB = a.fb + (size_t)pyB * W + px;
-        unsigned long long mA = 0, mB = 0;
-        uint32_t shA = 0, shB = 0;
-        if (!__ballot(cA || cB)) {
-            if (inA) leave(pyA);
-            if (inB) leave(pyB);
-        } else {
-        const uint32_t sidA = cA ? sid_of(tA) : 0u, sidB = cB ? sid_of(tB) : 0u;      // (surface 0's record for an uncovered pixel: read, never used)
-        const uint4* spA = reinterpret_cast<const uint4*>(a.srecs + sidA);
-        const uint4* spB = reinterpret_cast<const uint4*>(a.srecs + sidB);
-        const uint4 a0q = spA[0], a1q = spA[1], a2q = spA[2], a3q = spA[3];
-        const uint4 b0q = spB[0], b1q = spB[1], b2q = spB[2], b3q = spB[3];
-        shA = a3q.w >> 24; shB = b3q.w >> 24;
-        {
-            float bA[3], bB[3];
-            uint32_t taA, taB;
-            {   // pixel A: render.rs:1507-1510 (edges), :1517-1518 / 1706-1712 in closed form (exact integers), :1536-1538, :1565-1566, types.rs:671-681
-                const float x3 = f(a1q.x), y3 = f(a1q.y), inv = f(a1q.z);
-                const float ea0 = f(a0q.w) - y3, eb0 = x3 - f(a0q.z), ea1 = y3 - f(a0q.y), eb1 = f(a0q.x) - x3;
-                const float dx = fx - x3, dy = (float)pyA - y3;
-                const float w0 = ea0 * dx + eb0 * dy, w1 = ea1 * dx + eb1 * dy;
-                bA[0] = w0 * inv; bA[1] = w1 * inv; bA[2] = 1.0f - bA[0] - bA[1];
-                const float u = bA[0] * f(a2q.x) + bA[1] * f(a2q.y) + bA[2] * f(a2q.z);
-                const float v = bA[0] * f(a2q.w) + bA[1] * f(a3q.x) + bA[2] * f(a3q.y);
-                const float uw = rem_euclid1(u), vw = rem_euclid1(1.0f - v);
-                const uint32_t tx = min(f2u_sat(uw * twf), d.width - 1), ty = min(f2u_sat(vw * thf), d.height - 1);
-                taA = cA ? d.offset + ty * d.width + tx : d.offset;
-            }
-            {
-                const float x3 = f(b1q.x), y3 = f(b1q.y), inv = f(b1q.z);
-                const float ea0 = f(b0q.w) - y3, eb0 = x3 - f(b0q.z), ea1 = y3 - f(b0q.y), eb1 = f(b0q.x) - x3;
-                const float dx = fx - x3, dy = (float)pyB - y3;
-                const float w0 = ea0 * dx + eb0 * dy, w1 = ea1 * dx + eb1 * dy;
-                bB[0] = w0 * inv; bB[1] = w1 * inv; bB[2] = 1.0f - bB[0] - bB[1];
-                const float u = bB[0] * f(b2q.x) + bB[1] * f(b2q.y) + bB[2] * f(b2q.z);
-                const float v = bB[0] * f(b2q.w) + bB[1] * f(b3q.x) + bB[2] * f(b3q.y);
-                const float uw = rem_euclid1(u), vw = rem_euclid1(1.0f - v);
-                const uint32_t tx = min(f2u_sat(uw * twf), d.width - 1), ty = min(f2u_sat(vw * thf), d.height - 1);
-                taB = cB ? d.offset + ty * d.width + tx : d.offset;
-            }
-            const uint32_t fetA = a.texels[taA], fetB = a.texels[taB];              // both fetches in flight
-            // texture slot 0xFFFF = untextured: Color15::WHITE (render.rs:1585); then the transparency rule (render.rs:1591-1608)
-            const bool noneA = ((a1q.w >> 24) | ((a3q.z >> 24) << 8)) == F_TEX_NONE, noneB = ((b1q.w >> 24) | ((b3q.z >> 24) << 8)) == F_TEX_NONE;
-            uint32_t cA15 = noneA ? K::C15_WHITE : fetA, cB15 = noneB ? K::C15_WHITE : fetB;
-            const bool btA = (shA & SH_BLACK_TR) != 0, btB = (shB & SH_BLACK_TR) != 0;
-            const bool skipA = btA && (cA15 & ~K::C15_SEMI_BIT & 0xFFFFu) == 0, skipB = btB && (cB15 & ~K::C15_SEMI_BIT & 0xFFFFu) == 0;     // 0x0000 or black with black_transparent
-            cA15 = cA15 == K::C15_TRANSPARENT ? K::C15_BLACK_DRAWABLE : cA15; cB15 = cB15 == K::C15_TRANSPARENT ? K::C15_BLACK_DRAWABLE : cB15;
-            // (a winner that must replay its edge walk literally is not evaluated here: it joins the repair queue with bit 12 set)
-            const bool slowA = (shA & SH_SLOW) != 0, slowB = (shB & SH_SLOW) != 0;
-            const bool okA = cA && !skipA && !slowA, okB = cB && !skipB && !slowB;
-            const uint32_t vA[3] = { a1q.w & 0xFFFFFFu, a3q.z & 0xFFFFFFu, a3q.w & 0xFFFFFFu }, vB[3] = { b1q.w & 0xFFFFFFu, b3q.z & 0xFFFFFFu, b3q.w & 0xFFFFFFu };
-            const uint32_t flA = (shA & SH_DITHER) ? F_DITHER : 0u, flB = (shB & SH_DITHER) ? F_DITHER : 0u;
-            uint32_t colA, colB;
-            if (shading == B32_SHADE_NONE) {
-                shade15_pair_rgba(cA15, cB15, bA, bB, vA, vB, flA, flB, px, pyA, pyB, colA, colB);
-            } else {          // flat / Gouraud: the surface's nine vertex shades (render.rs:1629-1645)
-                float sA[9], sB[9];
+        shA = m.pkA2 >> 24; shB = m.pkB2 >> 24;
+        const float bA[3] = { m.bA0, m.bA1, m.bA2 }, bB[3] = { m.bB0, m.bB1, m.bB2 };
+        // texture slot 0xFFFF = untextured: Color15::WHITE (render.rs:1585); then the transparency rule (render.rs:1591-1608)
+        const bool noneA = ((m.pkA0 >> 24) | ((m.pkA1 >> 24) << 8)) == F_TEX_NONE, noneB = ((m.pkB0 >> 24) | ((m.pkB1 >> 24) << 8)) == F_TEX_NONE;
+        uint32_t cA15 = noneA ? K::C15_WHITE : m.fetA, cB15 = noneB ? K::C15_WHITE : m.fetB;
+        const bool btA = (shA & SH_BLACK_TR) != 0, btB = (shB & SH_BLACK_TR) != 0;
+        const bool skipA = btA && (cA15 & ~K::C15_SEMI_BIT & 0xFFFFu) == 0, skipB = btB && (cB15 & ~K::C15_SEMI_BIT & 0xFFFFu) == 0;     // 0x0000 or black with black_transparent
+        cA15 = cA15 == K::C15_TRANSPARENT ? K::C15_BLACK_DRAWABLE : cA15; cB15 = cB15 == K::C15_TRANSPARENT ? K::C15_BLACK_DRAWABLE : cB15;
+        // (a winner that must replay its edge walk literally is not evaluated here: it joins the repair queue with bit 12 set)
+        const bool slowA = (shA & SH_SLOW) != 0, slowB = (shB & SH_SLOW) != 0;
+        const bool okA = cA && !skipA && !slowA, okB = cB && !skipB && !slowB;
+        const uint32_t vA[3] = { m.pkA0 & 0xFFFFFFu, m.pkA1 & 0xFFFFFFu, m.pkA2 & 0xFFFFFFu }, vB[3] = { m.pkB0 & 0xFFFFFFu, m.pkB1 & 0xFFFFFFu, m.pkB2 & 0xFFFFFFu };
+        const uint32_t flA = (shA & SH_DITHER) ? F_DITHER : 0u, flB = (shB & SH_DITHER) ? F_DITHER : 0u;
+        const uint32_t sidA = cA ? sid_of(tA) : 0u, sidB = cB ? sid_of(tB) : 0u;
+        uint32_t colA, colB;
+        if (shading == B32_SHADE_NONE) {
+            shade15_pair_rgba(cA15, cB15, bA, bB, vA, vB, flA, flB, px, pyA, pyB, colA, colB);
+        } else {          // flat / Gouraud: the surface's nine vertex shades (render.rs:1629-1645)
+            float sA[9], sB[9];
 #pragma unroll
-                for (int j = 0; j < 9; ++j) { sA[j] = a.shades[(size_t)sidA * 9 + j]; sB[j] = a.shades[(size_t)sidB * 9 + j]; }
-                colA = shade15<true>(cA15, bA[0], bA[1], bA[2], vA[0], vA[1], vA[2], flA, shading, sA, px, pyA);
-                colB = shade15<true>(cB15, bB[0], bB[1], bB[2], vB[0], vB[1], vB[2], flB, shading, sB, px, pyB);
-            }
-            if (okA) { *outA = colA; if (ZMODE) store_depth(tA, sidA, pyA); } else if (!cA && inA) leave(pyA);
-            if (okB) { *outB = colB; if (ZMODE) store_depth(tB, sidB, pyB); } else if (!cB && inB) leave(pyB);
-            mA = __ballot(cA && !okA); mB = __ballot(cB && !okB);
+            for (int j = 0; j < 9; ++j) { sA[j] = a.shades[(size_t)sidA * 9 + j]; sB[j] = a.shades[(size_t)sidB * 9 + j]; }
+            colA = shade15<true>(cA15, bA[0], bA[1], bA[2], vA[0], vA[1], vA[2], flA, shading, sA, px, pyA);
+            colB = shade15<true>(cB15, bB[0], bB[1], bB[2], vB[0], vB[1], vB[2], flB, shading, sB, px, pyB);
         }
-        }
-        // ONE drain site (the queue's code -- the general per-pixel functions -- exists once in the kernel): entries of pixel A, of pixel B, then
-        // the flush after the last step
-        const bool last = r0 + 2 * ROWS_PER_STEP >= TH;
+        if (okA) { *outA = colA; if (ZMODE) store_depth(tA, sidA, pyA); } else if (!cA && inA) leave(pyA);
+        if (okB) { *outB = colB; if (ZMODE) store_depth(tB, sidB, pyB); } else if (!cB && inB) leave(pyB);
+        mA = __ballot(cA && !okA); mB = __ballot(cB && !okB);
+    };
+    // ONE drain site (the queue's code -- the general per-pixel functions -- exists once in the kernel): entries of pixel A, of pixel B, then
+    // the flush after the last step
+    auto enqueue = [&](uint32_t r0, unsigned long long mA, unsigned long long mB, uint32_t shA, uint32_t shB) {
+        const bool last = r0 + STEP_ROWS >= TH;
         if ((mA | mB) || (last && lqn)) {
+            const uint32_t rowA = r0 + (tid >> 6), rowB = rowA + ROWS_PER_STEP;
 #pragma unroll 1
             for (int which = 0; which < 3; ++which) {
                 const unsigned long long m = which == 0 ? mA : which == 1 ? mB : 0ull;
@@ -306,6 +323,99 @@ __device__ __forceinline__ void shade_tile_plain(const FillArgs& a, const uint32
                 if ((m >> lane) & 1ull) wq[lqn + (uint32_t)__builtin_popcountll(m & below)] = ((which ? rowB : rowA) << 6) | col | (((which ? shB : shA) & SH_SLOW) ? 0x1000u : 0u);
                 lqn += n;
             }
+        }
+    };
+    auto nothing_here = [&](uint32_t r0, bool inA, bool inB) {       // a step in which none of the wave's pixels is covered
+        const uint32_t pyA = ty_top + r0 + (tid >> 6), pyB = pyA + ROWS_PER_STEP;
+        if (inA) leave(pyA);
+        if (inB) leave(pyB);
+    };
+
+    if (PIPE) {
+        // Iteration k: [flush point] -> gathers of step k issued -> texel rule, colours and stores of step k - 1 (its texels were requested at
+        // the end of the previous iteration) -> barycentrics and texel fetches of step k.  What crosses the loop's back edge is `Mid` (fourteen
+        // registers and the step's flags), never a record set.
+        // The repair queue holds up to RQ_WORDS = 192 entries here and is drained only at the top of an iteration, where nothing is in flight
+        // but the two texel fetches: a drain is the general per-pixel code -- about a hundred registers -- and a record set live across it
+        // would be spilled on every step, not only on the rare ones that drain.  A step appends at most 128 entries.
+        const uint32_t n_steps = (TH + STEP_ROWS - 1) / STEP_ROWS;
+        Mid m;
+        m.bA0 = m.bA1 = m.bA2 = m.bB0 = m.bB1 = m.bB2 = 0.0f;
+        m.pkA0 = m.pkA1 = m.pkA2 = m.pkB0 = m.pkB1 = m.pkB2 = 0u; m.fetA = m.fetB = 0u;
+        unsigned long long ptA = 0, ptB = 0;
+        bool pcA = false, pcB = false, pinA = false, pinB = false;
+        for (uint32_t k = 0;; ++k) {
+            const bool flush = k > n_steps;
+            while (lqn > (flush ? 0u : 64u)) {             // ONE drain site: the queue's last (up to) 64 entries, one per lane
+                const uint32_t base = lqn > 64u ? lqn - 64u : 0u;
+                uint32_t* q = wq;
+                lqn -= base; wq = q + base;
+                drain();                                    // (reads wq[lane] for lane < lqn, leaves lqn = 0)
+                wq = q; lqn = base;
+            }
+            if (flush) break;
+#if B32_SHADE_PIPE == 2
+            In cur;
+            if (k < n_steps) issue(k * STEP_ROWS, cur);
+            __builtin_amdgcn_sched_barrier(0);
+            if (k >= 1) {
+                const uint32_t r0 = (k - 1) * STEP_ROWS;
+                unsigned long long mA = 0, mB = 0;
+                uint32_t shA = 0, shB = 0;
+                part2(r0, ptA, ptB, pcA, pcB, pinA, pinB, m, mA, mB, shA, shB);
+                if (mA | mB) {                              // append (never drains: see above)
+                    const uint32_t rowA = r0 + (tid >> 6), rowB = rowA + ROWS_PER_STEP;
+                    if ((mA >> lane) & 1ull) wq[lqn + (uint32_t)__builtin_popcountll(mA & below)] = (rowA << 6) | col | ((shA & SH_SLOW) ? 0x1000u : 0u);
+                    lqn += (uint32_t)__builtin_popcountll(mA);
+                    if ((mB >> lane) & 1ull) wq[lqn + (uint32_t)__builtin_popcountll(mB & below)] = (rowB << 6) | col | ((shB & SH_SLOW) ? 0x1000u : 0u);
+                    lqn += (uint32_t)__builtin_popcountll(mB);
+                }
+            }
+            if (k < n_steps) {
+                part1(k * STEP_ROWS, cur, m);
+                ptA = cur.tA; ptB = cur.tB; pcA = cur.cA; pcB = cur.cB; pinA = cur.inA; pinB = cur.inB;
+            }
+        }
+#else
+            // texel stage only: the step's own gather is waited for, its texels are requested, and while they travel the PREVIOUS step's texel
+            // rule, colours and stores run
+            Mid mc = m;
+            unsigned long long ctA = 0, ctB = 0; bool ccA = false, ccB = false, cinA = false, cinB = false;
+            if (k < n_steps) {
+                In cur;
+                issue(k * STEP_ROWS, cur);
+                part1(k * STEP_ROWS, cur, mc);
+                ctA = cur.tA; ctB = cur.tB; ccA = cur.cA; ccB = cur.cB; cinA = cur.inA; cinB = cur.inB;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (k >= 1) {
+                const uint32_t r0 = (k - 1) * STEP_ROWS;
+                unsigned long long mA = 0, mB = 0;
+                uint32_t shA = 0, shB = 0;
+                part2(r0, ptA, ptB, pcA, pcB, pinA, pinB, m, mA, mB, shA, shB);
+                if (mA | mB) {                              // append (never drains: see above)
+                    const uint32_t rowA = r0 + (tid >> 6), rowB = rowA + ROWS_PER_STEP;
+                    if ((mA >> lane) & 1ull) wq[lqn + (uint32_t)__builtin_popcountll(mA & below)] = (rowA << 6) | col | ((shA & SH_SLOW) ? 0x1000u : 0u);
+                    lqn += (uint32_t)__builtin_popcountll(mA);
+                    if ((mB >> lane) & 1ull) wq[lqn + (uint32_t)__builtin_popcountll(mB & below)] = (rowB << 6) | col | ((shB & SH_SLOW) ? 0x1000u : 0u);
+                    lqn += (uint32_t)__builtin_popcountll(mB);
+                }
+            }
+            m = mc; ptA = ctA; ptB = ctB; pcA = ccA; pcB = ccB; pinA = cinA; pinB = cinB;
+        }
+#endif
+    } else {
+        for (uint32_t r0 = 0; r0 < TH; r0 += STEP_ROWS) {
+            In cur;
+            issue(r0, cur);
+            unsigned long long mA = 0, mB = 0;
+            uint32_t shA = 0, shB = 0;
+            if (cur.any) {
+                Mid m;
+                part1(r0, cur, m);
+                part2(r0, cur.tA, cur.tB, cur.cA, cur.cB, cur.inA, cur.inB, m, mA, mB, shA, shB);
+            } else nothing_here(r0, cur.inA, cur.inB);
+            enqueue(r0, mA, mB, shA, shB);
         }
     }
 }

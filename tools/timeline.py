@@ -13,7 +13,7 @@ rs = R.ResidentScene(fb, sc.vertices, sc.faces, indexed_textures=sc.indexed_text
 for i in range(6):
     fb.clear(sc.clear_color); rs.render_async(sc.camera, sc.settings)
 rs.finish()
-buf = np.zeros(1 + 4 * 8192, np.uint64)
+buf = np.zeros(1 + 4 * 8192 + 64, np.uint64)
 lib = ctx.lib
 lib.b32_debug_timeline.restype = C.c_int
 assert lib.b32_debug_timeline(C.c_void_p(buf.ctypes.data), C.c_uint(buf.size)) == 1
@@ -71,3 +71,19 @@ first = [min(a for a, b in v) for v in per_wg.values()]
 if gaps:
     g = np.array(gaps) * tick
     print(f"gap between a workgroup's tiles: mean {g.mean():.2f} us, median {np.median(g):.2f}, p90 {np.percentile(g, 90):.2f}; first tile starts {np.mean(first) * tick:.2f} us after the earliest")
+
+# ---- sub-phase shader-clock sums (per wave; -DB32_TIMELINE builds): averages per tile and per wave
+acc = buf[1 + 4 * 8192:].astype(np.float64)
+ghz = float(os.environ.get("B32_GHZ", "2.35"))
+if acc.sum() > 0:
+    tiles, waves = float(n), 8.0
+    us = lambda cyc: cyc / (ghz * 1e3)
+    b, rounds, drains, rows = acc[4], acc[5], acc[6], acc[7]
+    print(f"coverage, per wave and tile (us at {ghz} GHz): batches {b / tiles / waves:.2f}, rounds {rounds / tiles / waves:.2f}, drains {drains / tiles / waves:.2f}, row items {rows / tiles / waves:.1f}")
+    print(f"   grab -> record arrived {us(acc[0]) / tiles / waves:.2f}   setup + scan {us(acc[1]) / tiles / waves:.2f}   rounds {us(acc[2]) / tiles / waves:.2f}"
+          f"   drains {us(acc[3]) / tiles / waves:.2f}   wait at the barrier {us(acc[8]) / tiles / waves:.2f}   tile header {us(acc[9]) / tiles / waves:.2f}")
+    if rounds: print(f"   per round {us(acc[2]) / rounds:.3f} us, per drain {us(acc[3]) / max(drains, 1):.3f} us, per batch load {us(acc[0]) / max(b, 1):.3f} us")
+    steps = acc[20]
+    if steps:
+        print(f"shading, per step ({steps / tiles / waves:.2f} steps per wave and tile): winners + records arrived {us(acc[16]) / steps:.3f}   address math {us(acc[17]) / steps:.3f}"
+              f"   texels arrived {us(acc[18]) / steps:.3f}   colour + stores {us(acc[19]) / steps:.3f} us")
