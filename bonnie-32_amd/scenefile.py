@@ -75,6 +75,10 @@ def write_scene(path, sc, expect=None, fmt8=None):
 class LoadedScene:
     """What read_scene returns: the fields of scenegen.Scene (+ textures8 / fmt8 / expect)."""
 
+    @property
+    def n_tris(self):
+        return len(self.faces)
+
 
 def read_scene(path):
     b = open(path, "rb").read()

@@ -163,6 +163,26 @@ SCENES = {
 }
 
 
+# ---- real content: frames of the reference's OWN sample assets -- the five OBJ meshes as the OBJ importer's preview
+# submits them (shared vertices, computed normals, RasterSettings::default()) and rooms of the sample levels with their textures, UVs,
+# vertex colours, ambient and fog (RasterSettings::game() / painter's).  The scenes are DATA: tools/make_real_scenes.py laid them out in
+# the build container from /root/reference/assets following the reference's producers, and committed them as .b32scene files; here
+# they are only read back.
+REAL_DIR = os.path.join(OUT, "scenes", "real")
+
+
+def real_scene(name):
+    from bonnie32_amd import scenefile
+    sc = scenefile.read_scene(os.path.join(REAL_DIR, name + ".b32scene"))
+    sc.name = "real:" + name
+    return sc
+
+
+REAL = sorted(json.load(open(os.path.join(REAL_DIR, "manifest.json")))) if os.path.exists(os.path.join(REAL_DIR, "manifest.json")) else []
+for _n in REAL:
+    SCENES["real:" + _n] = (lambda n=_n: real_scene(n))
+
+
 def rgba_scene(name="C1", stp_blend=0, seed=61, variant="bench", settings=None, alpha_every=0, bbox_px=200.0, **kw):
     """A scenegen scene with its RGB555 atlas widened to the 8-bit path's Texture (per-texel blend modes on STP texels)."""
     sc = scenegen.make_scene(name, seed=seed, variant=variant, bbox_px=bbox_px, **kw)
@@ -232,7 +252,7 @@ def main():
                         "triangles_drawn": tm.triangles_drawn,
                         "fragments": tm.fragments, "width": sc.width, "height": sc.height,
                         "draw_order_sha256": hashlib.sha256(d["draw_order"].tobytes()).hexdigest(),
-                        "scene_sha256": hashlib.sha256(sc.vertices.tobytes() + sc.faces.tobytes() + sc.textures[0].pixels.tobytes()).hexdigest()}
+                        "scene_sha256": hashlib.sha256(sc.vertices.tobytes() + sc.faces.tobytes() + b"".join(t.pixels.tobytes() for t in sc.textures[:1])).hexdigest()}
         if name == "C1":
             np.savez_compressed(os.path.join(OUT, "c1_frame.npz"), rgba=fb.pixels, sx=d["sx"], sy=d["sy"],
                                 sz_bits=d["sz"].view(np.uint32), draw_order=d["draw_order"])

@@ -115,7 +115,10 @@ def test_project_fixed_stage(gpu_ctx, oracle):
         assert oracle.project_fixed(pos[i], cam, 2560, 1920)[:2] == (sx[i], sy[i])
 
 
-@pytest.mark.parametrize("name", ["C1", "C1:gouraud", "C1:blend", "C1:blend5", "C1:float", "C1:persp", "cube", "fog-flat-point-nocull", "C2", "C2:blend"])
+REAL = [n for n in SCENES if n.startswith("real:")]       # the reference's own sample meshes and level rooms (tests/golden/scenes/real/*.b32scene)
+
+
+@pytest.mark.parametrize("name", ["C1", "C1:gouraud", "C1:blend", "C1:blend5", "C1:float", "C1:persp", "cube", "fog-flat-point-nocull", "C2", "C2:blend"] + REAL)
 def test_frame_parity_small(gpu_ctx, oracle, name):
     sc = SCENES[name]()
     exp, etm, d = cpu_render(oracle, sc)
@@ -135,7 +138,7 @@ def fast_ctx(gpu_ctx):
 
 
 @pytest.mark.parametrize("name", ["C1", "C1:gouraud", "C1:blend", "C1:blend5", "C1:float", "C1:persp", "cube", "fog-flat-point-nocull", "C2", "C2:blend",
-                                  "C3:100k", "C5:20k"])
+                                  "C3:100k", "C5:20k"] + REAL)
 def test_fast_path_frame_parity(fast_ctx, oracle, name):
     """Same frames through the fast path (no global depth sort, inside-test-only coverage, top-2 visibility).  C2 has tile
     lists longer than the LDS sort capacity, so it also exercises the automatic redraw with the global sort."""

@@ -15,11 +15,14 @@ NEW_MODES = ["C1:ortho", "C1:xray", "C1:xray-zbuf", "C1:default-settings", "C1:w
 FAST = NEW_MODES + ["C1:spot-gouraud", "C1:spot-flat-zbuf", "needles", "C1", "C1:zbuf", "C1:zbuf-blend", "C1:zbuf-gouraud", "C1:blend5", "C1:zbuf-blend5", "C1:gouraud", "C1:blend", "C1:float", "C1:persp", "cube", "fog-flat-point-nocull", "C2", "C2:blend", "C3:100k", "C5:20k", "C3", "C5"]
 
 
-@pytest.mark.parametrize("name", FAST)
+REAL = [n for n in SCENES if n.startswith("real:")]       # frames of the reference's own sample assets (tools/make_real_scenes.py, committed as .b32scene data)
+
+
+@pytest.mark.parametrize("name", FAST + REAL)
 def test_oracle_matches_golden_hash(oracle, name):
     sc = SCENES[name]()
     g = HASHES[name]
-    scene_sha = hashlib.sha256(sc.vertices.tobytes() + sc.faces.tobytes() + sc.textures[0].pixels.tobytes()).hexdigest()
+    scene_sha = hashlib.sha256(sc.vertices.tobytes() + sc.faces.tobytes() + b"".join(t.pixels.tobytes() for t in sc.textures[:1])).hexdigest()
     assert scene_sha == g["scene_sha256"], "scene generator is not deterministic"
     fb, tm, d = render(sc)
     assert hashlib.sha256(fb.pixels).hexdigest() == g["sha256"]
@@ -44,7 +47,8 @@ def test_cube_fixture(oracle):
 
 
 @pytest.mark.parametrize("name", ["C1", "C1:gouraud", "C1:blend", "C1:float", "C1:persp", "cube", "fog-flat-point-nocull",
-                                  "C1:zbuf", "C1:zbuf-blend", "C1:zbuf-gouraud", "C1:blend5", "C1:zbuf-blend5", "C1:spot-gouraud", "C1:spot-flat-zbuf", "needles"] + NEW_MODES)
+                                  "C1:zbuf", "C1:zbuf-blend", "C1:zbuf-gouraud", "C1:blend5", "C1:zbuf-blend5", "C1:spot-gouraud", "C1:spot-flat-zbuf", "needles"] + NEW_MODES +
+                         [n for n in REAL if "2560" not in n and "640" not in n])
 def test_two_restatements_agree(oracle, name):
     """oracle/b32_oracle.c and oracle/np_model.py are two readings of the same Rust; whole frames must be identical."""
     from oracle import np_model as M
@@ -233,3 +237,28 @@ def test_all_cores_schedule_equals_the_single_thread(oracle, variant, zbuf):
     before = fb.pixels.copy()
     rc, tm = O.render_mesh_15(fb, sc.vertices, bad, sc.textures, sc.camera, sc.settings, sc.fog, threads=8)
     assert rc == b32.abi.B32_E_INDEX and np.array_equal(fb.pixels, before)
+
+
+def test_real_scene_files_are_the_committed_ones(oracle):
+    """tests/golden/scenes/real/*.b32scene (the reference's sample meshes and level rooms, laid out by tools/make_real_scenes.py in the
+    build container) are data: every file has the SHA-256 its manifest names, carries an expectation record, and the oracle draws
+    exactly that from it -- shared vertices (fewer vertices than 3 x faces in the OBJ previews), real UV ranges (room UVs leave [0, 1]),
+    several textures per call, vertex colours other than neutral grey, fog."""
+    from bonnie32_amd import scenefile
+    d = os.path.join(GOLD, "scenes", "real")
+    man = json.load(open(os.path.join(d, "manifest.json")))
+    assert len(man) >= 10
+    shared = wide_uv = multi_tex = fogged = 0
+    for name, m in man.items():
+        blob = open(os.path.join(d, m["file"]), "rb").read()
+        assert hashlib.sha256(blob).hexdigest() == m["file_sha256"], name
+        sc = scenefile.read_scene(os.path.join(d, m["file"]))
+        assert sc.expect and sc.expect["sha256"] == HASHES["real:" + name]["sha256"], name
+        fb, tm, _ = render(sc)
+        assert hashlib.sha256(fb.pixels).hexdigest() == sc.expect["sha256"] and tm.triangles_drawn == sc.expect["triangles_drawn"], name
+        assert m["pixels_drawn"] > 1000, name
+        shared += len(sc.vertices) < 3 * len(sc.faces) and name.startswith("obj-")
+        wide_uv += bool((sc.vertices["uv"] > 1.0).any() or (sc.vertices["uv"] < 0.0).any())
+        multi_tex += len(sc.textures) > 1
+        fogged += sc.fog is not None
+    assert shared >= 5 and wide_uv >= 3 and multi_tex >= 3
