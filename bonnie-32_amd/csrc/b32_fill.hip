@@ -22,9 +22,10 @@
 
 namespace b32 {
 
-// per-wave repair queue of the fused kernel's shading phase (b32_shade_tile.h): 192 words -- the pipelined straight-line form drains only
-// where no record set is in flight and appends up to 128 entries in between; the other forms use the first 64
-constexpr uint32_t RQ_WORDS = 192, RQ_BYTES = RQ_WORDS * 4;
+// per-wave repair queue of the fused kernel's shading phase (b32_shade_tile.h): 64 words; 192 in the experiment builds with the
+// software-pipelined shading step (it drains only where no record set is in flight and appends up to 128 entries in between), which
+// then leave ~2 KB instead of ~6 KB for a staged index atlas beside two workgroups' planes
+constexpr uint32_t RQ_WORDS = B32_SHADE_PIPE ? 192 : 64, RQ_BYTES = RQ_WORDS * 4;
 static_assert(2 * (4 * LDS_TILE_BYTES + LDS_MISC_BYTES + 8 * RQ_BYTES + 511) / 512 * 512 <= 160 * 1024, "two 8-wave workgroups per CU");
 
 // ------------------------------------------------------------------------------------------------ k_cover
