@@ -140,6 +140,7 @@ SYMBOLS = [
     ("b32_last_shader_clock", C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     ("b32_transparent_counts", C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("b32_set_fragment_counting", C.c_int, [_P, C.c_int]),
+    ("b32_debug_inject", C.c_int, [_P, C.c_uint32]),
     ("b32_build_digest", C.c_char_p, []),
     ("b32_band_export", C.c_int, [_P, C.c_void_p]),
     ("b32_band_import", C.c_int, [_P, C.c_void_p, C.c_uint32]),

@@ -425,6 +425,8 @@ extern "C" unsigned long long b32_route_count(const b32_ctx* c, int which) {
     if (c && which == 8) return c->lds_atlas_frames;
     if (c && which == 9) return c->wire_tile_frames;
     if (c && which == 10) return c->span_cover_frames;
+    if (c && which == 11) return c->flag_join_frames;
+    if (c && which == 12) return c->event_join_frames;
     return (c && which >= 0 && which < 8) ? c->routes[which] : 0ull;
 }
 extern "C" int b32_set_async_depth(b32_ctx* c, int deep) {
@@ -488,6 +490,11 @@ extern "C" int b32_set_pipeline_depth(b32_ctx* c, uint32_t sets) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->side) HIPCHK(c, hipStreamSynchronize(c->side));
     c->n_sets = sets;
+    return B32_OK;
+}
+extern "C" int b32_debug_inject(b32_ctx* c, uint32_t what) {
+    if (!c || (what & ~1u)) return B32_E_ARG;
+    c->inject |= what;
     return B32_OK;
 }
 extern "C" int b32_set_profiling_stride(b32_ctx* c, uint32_t every) {

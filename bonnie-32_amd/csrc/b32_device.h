@@ -182,7 +182,8 @@ struct Ctrl {
 struct Stamps { unsigned long long t[8]; };
 // Rare events of k_setup under direct binning, behind Stamps: each word holds the EPOCH (frame number, never 0) of the last frame the
 // event happened in, so nothing has to be reset between frames and k_setup's own frame-start reset of Ctrl cannot race with them.
-struct Events { uint32_t bad_index, nan_opaque, nan_transparent, overflow, long_transparent, setup_done /* k_flag -> k_join: epoch of the frame whose setup kernel has finished */, _pad[2]; };
+struct Events { uint32_t bad_index, nan_opaque, nan_transparent, overflow, long_transparent, setup_done /* k_flag -> k_join: epoch of the frame whose setup kernel has finished */,
+                join_abort /* k_join -> fill: epoch of the frame whose setup kernel never arrived (the fill draws nothing but the folded clear) */, _pad[1]; };
 __device__ __forceinline__ Events* events_of(Ctrl* ctrl) { return reinterpret_cast<Events*>(reinterpret_cast<unsigned char*>(ctrl) + 128); }
 enum { ST_SETUP = 0, ST_BIN = 1, ST_FILL = 2, ST_WIRE = 3, ST_END = 4,
        ST_CLK0 = 5, ST_CLK1 = 6, ST_CLKW = 7 };   // shader-cycle counter at the start / end of workgroup 0 of the fused kernel, wall clock at its end

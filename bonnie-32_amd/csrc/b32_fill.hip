@@ -142,12 +142,13 @@ __device__ __forceinline__ void cover_body(const FillArgs& a_in) {
         // when a sort comparison sees NaN, render.rs:2531); workgroup 0 publishes the counters in Ctrl for the host.  Direct binning:
         // k_setup left the epoch of this frame in Events when it met one of those, and only then does every workgroup pay for the
         // reduction; otherwise workgroup 0 alone does it, for the host's counters.
-        bool reduce = a.inline_bin != 0;
+        bool reduce = a.inline_bin != 0, join_abort = false;
         uint32_t redraw = 0;
         if (a.direct_bin) {
             const Events* ev = events_of(a.ctrl);
             reduce = ev->bad_index == a.epoch || ev->nan_opaque == a.epoch || ev->nan_transparent == a.epoch;
             redraw = (ev->overflow == a.epoch ? 2u : 0u) | (ev->long_transparent == a.epoch ? 1u : 0u);
+            join_abort = ev->join_abort == a.epoch;     // (k_join gave up on this frame's setup kernel: nothing of its output may be read)
             // (no such event: the frame is not aborted, and workgroup 0 reduces the counters for the host AFTER its tiles -- with a
             // million faces the reduction takes microseconds, and in a narrow band every workgroup has one tile: it was the kernel's
             // critical path)
@@ -155,7 +156,15 @@ __device__ __forceinline__ void cover_body(const FillArgs& a_in) {
         }
         if (tid == 0) misc[6] = 0;
         __syncthreads();
-        if (reduce) reduce_setup_counters<NT>(a, misc, tid, lane);
+        if (reduce && !join_abort) reduce_setup_counters<NT>(a, misc, tid, lane);
+        if (join_abort) {
+            // (the tile counters of a setup kernel that did finish -- only its flag was missed -- are zeroed for the next frame of this set, as the
+            // redraw path below does; what a setup kernel that is STILL running leaves behind is re-zeroed by b32_frame_finish, which reports the frame)
+            if (a.direct_bin)
+                for (uint32_t t = blockIdx.x * NT + tid; t < ntiles; t += gridDim.x * NT) { uint32_t* fl = a.tile_fill + (size_t)t * FILL_PAD; fl[0] = 0; fl[1] = 0; }
+            if (a.clear_on) clear_band<NT>(a);
+            return;
+        }
         if (misc[6] || redraw) {
             // nothing is drawn.  Direct binning: a region overflowed (the host redraws with larger regions: the longest list goes
             // back in Ctrl) or a transparent list is too long for k_blend's LDS sort (the host redraws with the global sort); either

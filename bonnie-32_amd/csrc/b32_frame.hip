@@ -542,12 +542,17 @@ int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st, const
     }
     if (c->pipelined && B32_JOIN_KERNEL && r.direct_bin && c->join_ok && !(c->frame_batched && B32_JOIN_NOT_BATCHED)) {
         // (no cross-stream event on the fill's path: see k_flag / k_join)
-        launch_flag(c->side, c->d_ctrl, c->epoch);
-        launch_join(s, c->d_ctrl, c->epoch, 200000000u /* 2 s: a last resort -- queues of an oversubscribed GPU are time-sliced in milliseconds */);
+        // (b32_debug_inject(ctx, 1): this frame's flag carries another epoch and the join's patience is 2 ms -- the "setup kernel never arrived" path)
+        const bool lose_flag = (c->inject & 1u) != 0;
+        c->inject &= ~1u;
+        launch_flag(c->side, c->d_ctrl, lose_flag ? c->epoch ^ 0x40000000u : c->epoch);
+        launch_join(s, c->d_ctrl, c->epoch, lose_flag ? 200000u : 200000000u /* 2 s: a last resort -- queues of an oversubscribed GPU are time-sliced in milliseconds */);
+        c->flag_join_frames++;
     } else if (c->pipelined) {
         hipError_t e1 = hipEventRecord(c->ev_setup, c->side);
         if (e1 == hipSuccess) e1 = hipStreamWaitEvent(s, c->ev_setup, 0);
         if (e1 != hipSuccess) { (void)hipStreamSynchronize(c->side); c->last_hip = (int)e1; return B32_E_HIP; }
+        c->event_join_frames++;
     }
     if (c->pipelined) {
         if (wire_on && wa.tile_fill && B32_WIRE_BIN_EARLY) {       // (behind ev_setup: the fill does not wait for the binning)
@@ -778,7 +783,16 @@ int b32_frame_finish(b32_ctx* c, B32Timings* out) {
     if ((sticky >> 8) && (c->deep_async || c->fb_external || c->band_sync)) return B32_E_FRAME_DROPPED;
     if (c->h_ctrl.err_index || (sticky & 1u)) return B32_E_INDEX;
     if (c->h_ctrl.abort || (sticky & 2u)) return B32_E_NAN_KEY;
-    if (sticky & 8u) return B32_E_HIP;                         // (k_join gave up on a setup kernel: internal)
+    if (sticky & 8u) {                                         // (k_join gave up on a setup kernel: internal.  Whatever that kernel left in the tile
+        // counters of its frame set -- it may have finished late, or not at all -- is cleared once both streams have drained, so that the
+        // frames that follow bin into empty lists again)
+        if (c->side) HIPCHK(c, hipStreamSynchronize(c->side));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->tile_fill) HIPCHK(c, hipMemsetAsync(c->tile_fill, 0, c->cap_tile_fill * sizeof(uint32_t), c->stream));
+        for (FrameSet& o : c->alt) if (o.tile_fill) HIPCHK(c, hipMemsetAsync(o.tile_fill, 0, o.cap_tile_fill * sizeof(uint32_t), c->stream));
+        c->side_dirty = true;
+        return B32_E_HIP;
+    }
     if (sticky & 16u) return B32_E_BAND_TIMEOUT;               // (b32_band_wait / _wait_all / _acquire gave up on another rank's epoch word)
     if (c->h_ctrl.wire_overflow || (sticky & 4u)) return B32_E_UNSUPPORTED;     // an edge >= 2^30 px long: i32 overflow in the reference's Bresenham
     if (out) {

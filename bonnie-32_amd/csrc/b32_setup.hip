@@ -660,14 +660,17 @@ __global__ void k_gate(const Ctrl* __restrict__ prev, uint32_t need, uint32_t pa
 // epoch; k_join, one lane on the main stream in FRONT of the fill, returns when it reads that epoch.  Kernel boundaries do the cache
 // maintenance: k_flag starts after the setup kernel's end-of-kernel release, the fill starts with its own acquire after k_join.  Neither
 // holds anything the other needs (k_join follows the previous fill on its stream, so the GPU is the setup kernel's while it spins); a
-// setup kernel that never arrives (patience: 2 s) aborts the frame and is reported by b32_frame_finish (sticky bit 3).
+// setup kernel that never arrives (patience: 2 s) aborts the frame -- Events::join_abort, read by the fill with the other event words: it draws
+// nothing but the folded clear -- and is reported by b32_frame_finish (sticky bit 3).
 __global__ void k_flag(Ctrl* __restrict__ ctrl, uint32_t epoch) {
     __hip_atomic_exchange(&events_of(ctrl)->setup_done, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __global__ void k_join(Ctrl* __restrict__ ctrl, uint32_t epoch, uint32_t patience) {
     const unsigned long long t0 = wall_clock64();
     while (__hip_atomic_fetch_add(&events_of(ctrl)->setup_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
-        if (wall_clock64() - t0 > patience) { atomicOr(&ctrl->sticky, 8u); ctrl->abort = 1; return; }
+        // (the epoch word lives in Events, which no kernel resets: a setup kernel that arrives AFTER the patience cannot take the abort back,
+        // as it could with Ctrl::abort, which it zeroes when it starts)
+        if (wall_clock64() - t0 > patience) { atomicOr(&ctrl->sticky, 8u); (void)__hip_atomic_exchange(&events_of(ctrl)->join_abort, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
         __builtin_amdgcn_s_sleep(4);
     }
 }

@@ -72,7 +72,8 @@ class Context:
         """b32_set_async_depth: 0 = safe (default), 1 = large-scene frames back to back, a dropped one is reported by finish()."""
         _chk(self.lib.b32_set_async_depth(self.h, int(deep)), "b32_set_async_depth")
 
-    ROUTES = ("direct_bin", "inline_bin", "counting_sort", "keyed", "redraw_region", "redraw_global_sort", "redraw_pairs", "pipelined", "lds_atlas", "wire_tiles", "span_cover")
+    ROUTES = ("direct_bin", "inline_bin", "counting_sort", "keyed", "redraw_region", "redraw_global_sort", "redraw_pairs", "pipelined", "lds_atlas", "wire_tiles", "span_cover",
+              "flag_join", "event_join")
 
     ROUTE_SORT_FREE, ROUTE_CUT_TILES, ROUTE_INLINE_BIN, ROUTE_DIRECT_BIN, ROUTE_WIDE_GROUPS, ROUTE_PACKED_STREAMS, ROUTE_PIPELINE, ROUTE_TEX_CACHE, ROUTE_BATCH, ROUTE_LDS_ATLAS, ROUTE_WIRE_TILES, ROUTE_SPAN_COVER, ROUTE_STAGGER = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096
 
@@ -141,6 +142,10 @@ class Context:
     def route_counts(self):
         """b32_route_count: how many frames of this context took each internal route (tests assert the targeted one ran)."""
         return {n: int(self.lib.b32_route_count(self.h, i)) for i, n in enumerate(self.ROUTES)}
+
+    def debug_inject(self, what):
+        """b32_debug_inject: fault injection (1 = the next flag / join hand-over loses its flag)."""
+        _chk(self.lib.b32_debug_inject(self.h, int(what)), "b32_debug_inject")
 
     def set_fragment_counting(self, on):
         _chk(self.lib.b32_set_fragment_counting(self.h, int(on)), "b32_set_fragment_counting")

@@ -259,7 +259,8 @@ int b32_set_async_depth(b32_ctx* ctx, int deep);
  * sort, 6 frames redrawn after a pair-buffer overflow, 7 frames whose setup kernel ran on the second stream beside the previous frame's
  * fill (two frames in flight), 8 frames whose fused kernel sampled the 4/8-bit index atlas + CLUT from LDS (B32_ROUTE_LDS_ATLAS),
  * 9 frames whose wireframe phases went through the tile route (B32_ROUTE_WIRE_TILES), 10 frames whose opaque coverage was decided by
- * exact row intervals (B32_ROUTE_SPAN_COVER).
+ * exact row intervals (B32_ROUTE_SPAN_COVER), 11 pipelined frames whose setup kernel was handed over to the fill by the flag / join kernel
+ * pair, 12 by a cross-stream event (main and side stream of one priority, batched frames).
  * Unknown `which` or null ctx: 0. */
 unsigned long long b32_route_count(const b32_ctx* ctx, int which);
 /* Switch internal routes OFF for the frames enqueued from now on (no reference counterpart: the results are identical on every route;
@@ -412,6 +413,11 @@ int b32_last_shader_clock(const b32_ctx* ctx, float* ghz, float* fill_ms);
  * frame of a moderate mesh can ever need a redraw; *device_last = the surfaces the setup kernel of the last finished frame really
  * classified as transparent.  device_last <= host_bound must hold for every frame. */
 int b32_transparent_counts(const b32_ctx* ctx, uint32_t* host_bound, uint32_t* device_last);
+/* Test tap (no reference counterpart): fault injection for the failure paths that cannot be provoked from outside.  what = 1: the NEXT
+ * frame that hands its setup kernel over by the flag / join kernel pair loses its flag (it publishes another epoch) and its join waits 2 ms
+ * instead of 2 s -- the "setup kernel never arrived" path: the fill draws nothing but the folded clear, b32_frame_finish returns
+ * B32_E_HIP, the frames after it are drawn normally.  Other bits: B32_E_ARG. */
+int b32_debug_inject(b32_ctx* ctx, uint32_t what);
 /* Two frames in flight (no reference counterpart; see B32_ROUTE_PIPELINE): when a frame is enqueued while an earlier one is still
  * pending, its setup kernel runs on a second, low-priority stream of the context beside the earlier frame's fill kernel, on a second
  * set of per-face buffers.  permille > 0 holds that setup kernel back so that it runs beside the fill's thinning second half rather than

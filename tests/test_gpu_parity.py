@@ -509,6 +509,85 @@ def test_safe_mode_clear_supersedes_a_pending_frame(oracle):
     ctx.close()
 
 
+def test_lost_setup_flag_aborts_one_frame_and_is_reported(oracle):
+    """The failure path of the flag / join hand-over (two frames in flight: k_flag on the side stream behind the setup kernel, k_join on
+    the main stream in front of the fill), forced by b32_debug_inject: the frame's flag never shows its epoch, the join gives up after its
+    patience, raises the sticky error bit and Events::join_abort; the fill of THAT frame reads nothing of the setup kernel's output and
+    writes only the folded clear; b32_frame_finish returns B32_E_HIP (never silent); the frames before and after it are drawn normally --
+    also the next frame on the SAME frame set, whose tile counters the aborted fill left zeroed."""
+    from bonnie32_amd import rasterizer as R
+    sc = scenegen.make_scene("C3", n_tris=200_000)                      # 1200 tiles, direct binning: frames run two in flight
+    want, otm, _ = cpu_render(oracle, sc)
+    red = b32.Color(200, 10, 10)
+    ctx = R.Context(0); ctx.set_async_depth(1)
+    fb = R.Framebuffer(sc.width, sc.height, ctx)
+    rs = R.ResidentScene(fb, sc.vertices, sc.faces, indexed_textures=sc.indexed_textures)
+    for _ in range(4):
+        fb.clear(sc.clear_color); rs.render_async(sc.camera, sc.settings, sc.fog)
+    rs.finish()
+    assert np.array_equal(fb.pixels, want)
+    base = ctx.route_counts()
+    assert base["flag_join"] >= 2 and base["event_join"] == 0
+    # (a) the LAST frame loses its flag: nothing but its clear colour on the screen, and the error
+    fb.clear(sc.clear_color); rs.render_async()
+    ctx.debug_inject(1)
+    fb.clear(red); rs.render_async()
+    with pytest.raises(R.B32Error) as ei:
+        rs.finish()
+    assert ei.value.code == b32.abi.B32_E_HIP
+    solid = np.tile(np.array([200, 10, 10, 255], np.uint8), sc.width * sc.height)
+    got = fb.pixels
+    assert np.array_equal(got, solid), f"{int((got != solid).sum())} bytes of the aborted frame are not its clear colour"
+    # (b) a frame in the MIDDLE loses its flag; four more follow (both frame sets are used again) and the last one is right
+    fb.clear(sc.clear_color); rs.render_async()
+    ctx.debug_inject(1)
+    fb.clear(red); rs.render_async()
+    for _ in range(4):
+        fb.clear(sc.clear_color); rs.render_async()
+    with pytest.raises(R.B32Error) as ei:
+        rs.finish()
+    assert ei.value.code == b32.abi.B32_E_HIP
+    assert np.array_equal(fb.pixels, want)
+    # and the context is clean again
+    fb.clear(sc.clear_color); rs.render_async()
+    tm = rs.finish()
+    assert np.array_equal(fb.pixels, want) and tm.triangles_drawn == otm.triangles_drawn
+    assert ctx.lib.b32_debug_inject(ctx.h, 2) == b32.abi.B32_E_ARG
+    ctx.close()
+
+
+def test_streams_of_one_priority_hand_over_by_event(oracle):
+    """The other branch of the hand-over (b32_frame.hip: `join_ok`): when the caller's stream has the SIDE stream's priority the two may
+    share a hardware queue, where k_join in front of k_flag would only end by its patience -- such frames keep the cross-stream event.
+    A stream of the lowest priority made with the HIP runtime directly; frames of a large mesh two in flight on it, each against the
+    oracle; the route counters say which hand-over ran."""
+    from bonnie32_amd import rasterizer as R
+    hip = C.CDLL("libamdhip64.so")
+    least, greatest = C.c_int(), C.c_int()
+    assert hip.hipDeviceGetStreamPriorityRange(C.byref(least), C.byref(greatest)) == 0
+    stream = C.c_void_p()
+    assert hip.hipStreamCreateWithPriority(C.byref(stream), C.c_uint(1), least) == 0      # hipStreamNonBlocking
+    sc = scenegen.make_scene("C3", n_tris=200_000, seed=7)
+    want = cpu_render(oracle, sc)[0]
+    ctx = R.Context(0); ctx.set_async_depth(1)
+    ctx.set_stream(stream.value)
+    fb = R.Framebuffer(sc.width, sc.height, ctx)
+    rs = R.ResidentScene(fb, sc.vertices, sc.faces, indexed_textures=sc.indexed_textures)
+    try:
+        for i in range(7):
+            fb.clear(b32.Color(9 * i, 3, 200) if i % 2 else sc.clear_color)      # (a frame that kept an older frame's pixels would show)
+            rs.render_async(sc.camera, sc.settings, sc.fog)
+            if i in (4, 6):
+                got = fb.pixels
+                assert np.array_equal(got, want), f"frame {i}: {int((got != want).sum())} bytes differ"
+        rs.finish()
+        rc = ctx.route_counts()
+        assert rc["pipelined"] >= 3 and rc["event_join"] == rc["pipelined"] and rc["flag_join"] == 0, rc
+    finally:
+        ctx.close()
+        hip.hipStreamDestroy(stream)
+
+
 def test_superseded_frame_is_not_redrawn_over_an_executed_clear(oracle):
     """ADVICE r5 (b32_frame.hip): draw A (overflows its tile regions on a fresh context: nothing drawn), b32_fb_clear (safe mode marks A
     superseded, the clear stays deferred), b32_synchronize (flushes the clear WITHOUT settling: it now sits behind A on the stream), draw
