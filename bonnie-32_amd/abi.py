@@ -101,6 +101,11 @@ SYMBOLS = [
     ("b32_fb_clear", C.c_int, [_P, C.c_uint8, C.c_uint8, C.c_uint8, C.c_uint8]),
     ("b32_fb_upload", C.c_int, [_P, _P]),
     ("b32_fb_download", C.c_int, [_P, _P]),
+    ("b32_host_alloc", C.c_void_p, [C.c_size_t]),
+    ("b32_host_free", None, [C.c_void_p]),
+    ("b32_fb_download_async", C.c_int, [_P, _P, C.POINTER(C.c_uint64)]),
+    ("b32_ticket_poll", C.c_int, [_P, C.c_uint64, C.POINTER(C.c_int)]),
+    ("b32_ticket_wait", C.c_int, [_P, C.c_uint64]),
     ("b32_zbuffer_download", C.c_int, [_P, _P]),
     ("b32_zbuffer_upload", C.c_int, [_P, _P]),
     ("b32_fb_bind_device", C.c_int, [_P, _P, C.c_uint32, C.c_uint32]),
@@ -118,6 +123,7 @@ SYMBOLS = [
     ("b32_frame_begin", C.c_int, [_P, _P, _P]),
     ("b32_frame_add_scene", C.c_int, [_P, _P, _P]),
     ("b32_frame_end", C.c_int, [_P]),
+    ("b32_frame_submit", C.c_int, [_P, _P, _P, C.POINTER(_P), _P, C.c_uint32]),
     ("b32_batch_count", C.c_ulonglong, [_P, C.c_int]),
     ("b32_fb_clear_gradient", C.c_int, [_P] + [C.c_uint8] * 8),
     ("b32_fb_clear_transparent", C.c_int, [_P]),

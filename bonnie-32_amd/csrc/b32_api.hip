@@ -59,6 +59,7 @@ void b32_destroy(b32_ctx* c) {
     if (c->ev_created) for (auto& fr : c->ev) for (auto& e : fr) if (e) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->stage_host) (void)hipHostFree(c->stage_host);
+    for (hipEvent_t e : c->dl_ev) if (e) (void)hipEventDestroy(e);
     delete c;
 }
 
@@ -299,6 +300,47 @@ int b32_fb_download(b32_ctx* c, uint8_t* rgba) {
     { const int rcf = flush_clear(c); if (rcf) return rcf; }
     HIPCHK(c, hipMemcpyAsync(rgba, c->fb, (size_t)c->width * c->height * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return B32_OK;
+}
+
+// The presenter's copy without a host round trip per frame: the reference hands fb.pixels to the screen EVERY frame
+// (game/renderer.rs:179-214); here the copy engine moves the frame into page-locked caller memory behind everything enqueued so far and
+// a ticket tells when it has landed, so the host can enqueue frame i + 1 while frame i is drawn and copied.
+void* b32_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (!bytes || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+void b32_host_free(void* p) { if (p) (void)hipHostFree(p); }
+int b32_fb_download_async(b32_ctx* c, uint8_t* rgba, uint64_t* ticket) {
+    if (!c || !c->fb || !rgba || !ticket) return B32_E_ARG;
+    (void)hipSetDevice(c->device);
+    // (safe mode: a pending frame that may still need a redraw is settled first, as b32_fb_download does -- the frames of small meshes, what
+    // a console frame is made of, never are; deep mode never blocks the host: a dropped frame is reported by b32_frame_finish)
+    if (!c->deep_async) { const int rc = settle_pending(c); if (rc) return rc; }
+    { const int rcf = flush_clear(c); if (rcf) return rcf; }
+    const unsigned long long t = c->dl_seq + 1;
+    hipEvent_t& ev = c->dl_ev[t % b32_ctx::DL_RING];
+    if (!ev) HIPCHK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    else if (t > b32_ctx::DL_RING) HIPCHK(c, hipEventSynchronize(ev));       // (the ticket that used this event, DL_RING downloads ago)
+    HIPCHK(c, hipMemcpyAsync(rgba, c->fb, (size_t)c->width * c->height * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipEventRecord(ev, c->stream));
+    c->dl_seq = t; *ticket = t;
+    return B32_OK;
+}
+int b32_ticket_poll(b32_ctx* c, uint64_t ticket, int* done) {
+    if (!c || !done || ticket == 0 || ticket > c->dl_seq) return B32_E_ARG;
+    *done = 1;
+    if (ticket + b32_ctx::DL_RING <= c->dl_seq) return B32_OK;               // (its event has been reused: it completed long ago)
+    const hipError_t e = hipEventQuery(c->dl_ev[ticket % b32_ctx::DL_RING]);
+    if (e == hipErrorNotReady) { *done = 0; (void)hipGetLastError(); return B32_OK; }
+    if (e != hipSuccess) { c->last_hip = (int)e; return B32_E_HIP; }
+    return B32_OK;
+}
+int b32_ticket_wait(b32_ctx* c, uint64_t ticket) {
+    if (!c || ticket == 0 || ticket > c->dl_seq) return B32_E_ARG;
+    if (ticket + b32_ctx::DL_RING <= c->dl_seq) return B32_OK;
+    HIPCHK(c, hipEventSynchronize(c->dl_ev[ticket % b32_ctx::DL_RING]));
     return B32_OK;
 }
 

@@ -162,6 +162,14 @@ int b32_frame_end(b32_ctx* c) {
     c->batch.clear();
     return rc;
 }
+// the whole frame in one call: what scene.rs:180-261 loops over, as a table
+int b32_frame_submit(b32_ctx* c, const B32Camera* cam, const B32Settings* st, b32_scene* const* slots, const B32MeshParams* params, uint32_t n) {
+    if (!c || (n && !slots)) return B32_E_ARG;
+    int rc = b32_frame_begin(c, cam, st);
+    for (uint32_t i = 0; i < n && !rc; ++i) rc = b32_frame_add_scene(c, slots[i], params ? &params[i] : nullptr);
+    if (rc) { c->batch_open = false; c->batch.clear(); return rc; }
+    return b32_frame_end(c);
+}
 unsigned long long b32_batch_count(const b32_ctx* c, int which) { return (c && which >= 0 && which < 4) ? c->batch_stats[which] : 0ull; }
 
 }  // extern "C"

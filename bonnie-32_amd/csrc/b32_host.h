@@ -181,6 +181,9 @@ struct b32_ctx {
     B32Camera last_cam{}; B32Settings last_settings{}; B32Fog last_fog{}; bool last_has_fog = false;
     int last_pair_buf = 0;
 
+    // asynchronous framebuffer downloads (b32_fb_download_async): ticket t completes with event dl_ev[t % DL_RING]
+    static constexpr uint32_t DL_RING = 8;
+    hipEvent_t dl_ev[DL_RING] = {}; unsigned long long dl_seq = 0;
     // profiling
     int profile_level = 0;
     uint32_t prof_stride = 1, prof_seq = 0;      // b32_set_profiling_stride: events on every prof_stride-th frame only

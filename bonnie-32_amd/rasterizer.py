@@ -102,6 +102,55 @@ class Context:
     def frame_end(self):
         _chk(self.lib.b32_frame_end(self.h), "b32_frame_end")
 
+    def frame_submit(self, table):
+        """b32_frame_submit: the frame recorded by make_frame_table, in one call."""
+        cam, st, _keep, slots, params, n = table
+        _chk(self.lib.b32_frame_submit(self.h, C.byref(cam), C.byref(st), slots, C.cast(params, C.c_void_p), n), "b32_frame_submit")
+
+    @staticmethod
+    def make_frame_table(camera, settings, scenes, fogs=None, ambients=None):
+        """Packs camera, base settings and a list of detached ResidentScenes (+ per-mesh fog / ambient) once, for frame_submit."""
+        cam = camera.pack()
+        st, keep = settings.pack()
+        n = len(scenes)
+        slots = (C.c_void_p * n)()
+        params = (abi.B32MeshParams * n)()
+        for i, sc in enumerate(scenes):
+            sc.detach()
+            slots[i] = sc._slot
+            params[i].ambient = float(st.ambient if ambients is None or ambients[i] is None else ambients[i])
+            params[i].backface_cull = int(st.backface_cull); params[i].backface_wireframe = int(st.backface_wireframe)
+            fg = T.pack_fog(fogs[i]) if fogs is not None else None
+            params[i].has_fog = 0 if fg is None else 1
+            if fg is not None:
+                params[i].fog = fg
+        return cam, st, keep, slots, params, n
+
+    # ---- the presenter's copy without a host round trip per frame (b32_fb_download_async + tickets)
+    def host_alloc(self, nbytes):
+        """b32_host_alloc: page-locked host memory as a numpy uint8 array (freed by host_free)."""
+        p = self.lib.b32_host_alloc(int(nbytes))
+        if not p:
+            raise MemoryError("b32_host_alloc")
+        arr = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(int(nbytes),))
+        return arr, p
+
+    def host_free(self, p):
+        self.lib.b32_host_free(p)
+
+    def download_async(self, host_ptr):
+        t = C.c_uint64()
+        _chk(self.lib.b32_fb_download_async(self.h, host_ptr, C.byref(t)), "b32_fb_download_async")
+        return int(t.value)
+
+    def ticket_wait(self, ticket):
+        _chk(self.lib.b32_ticket_wait(self.h, int(ticket)), "b32_ticket_wait")
+
+    def ticket_done(self, ticket):
+        d = C.c_int()
+        _chk(self.lib.b32_ticket_poll(self.h, int(ticket), C.byref(d)), "b32_ticket_poll")
+        return bool(d.value)
+
     def finish(self) -> T.RasterTimings:
         """b32_frame_finish of whatever this context has in flight."""
         tm = abi.B32Timings()

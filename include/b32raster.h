@@ -17,6 +17,7 @@
 #ifndef B32RASTER_H
 #define B32RASTER_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -186,6 +187,21 @@ int b32_fb_new(b32_ctx* ctx, uint32_t width, uint32_t height);              /* F
 int b32_fb_clear(b32_ctx* ctx, uint8_t r, uint8_t g, uint8_t b, uint8_t blend);
 int b32_fb_upload(b32_ctx* ctx, const uint8_t* rgba);                        /* host fb.pixels -> device */
 int b32_fb_download(b32_ctx* ctx, uint8_t* rgba);                            /* device -> host fb.pixels */
+/* The presenter's copy WITHOUT a host round trip per frame.  The reference hands fb.pixels to the screen every frame
+ * (game/renderer.rs:179-214); b32_fb_download blocks the host until the frame is there.  b32_fb_download_async only ENQUEUES the copy --
+ * behind everything enqueued on the context so far (a deferred clear is flushed; in safe mode a pending frame that may still need a
+ * redraw is settled first, which frames of small meshes never do) -- into page-locked memory of the caller, and hands out a ticket:
+ *     frame i:   b32_fb_clear; b32_frame_submit(...) or the draws; b32_fb_download_async(ctx, pinned[i & 1], &ticket[i & 1]);
+ *                b32_ticket_wait(ctx, ticket[(i - 1) & 1]);   present pinned[(i - 1) & 1]      (frame i is being drawn meanwhile)
+ * b32_ticket_poll never blocks (*done = 0 / 1); b32_ticket_wait blocks until the copy has landed.  At most 8 tickets are outstanding per
+ * context: a ninth download first waits for the oldest.  `rgba` must stay valid until its ticket is done; memory from b32_host_alloc
+ * (page-locked; NULL when it cannot be had) keeps the copy asynchronous, pageable memory works but may block the call.
+ * Errors of the frames are reported by b32_frame_finish as ever. */
+void* b32_host_alloc(size_t bytes);
+void b32_host_free(void* p);
+int b32_fb_download_async(b32_ctx* ctx, uint8_t* rgba, uint64_t* ticket);
+int b32_ticket_poll(b32_ctx* ctx, uint64_t ticket, int* done);
+int b32_ticket_wait(b32_ctx* ctx, uint64_t ticket);
 /* Framebuffer::zbuffer (render.rs:12), used when settings.use_zbuffer: f32 per pixel, f32::MAX after new/resize/clear. */
 int b32_zbuffer_download(b32_ctx* ctx, float* z);
 int b32_zbuffer_upload(b32_ctx* ctx, const float* z);
@@ -327,6 +343,9 @@ typedef struct B32MeshParams {
 int b32_frame_begin(b32_ctx* ctx, const B32Camera* camera, const B32Settings* base_settings);
 int b32_frame_add_scene(b32_ctx* ctx, b32_scene* slot, const B32MeshParams* params /* nullable */);
 int b32_frame_end(b32_ctx* ctx);
+/* The same frame in ONE call: begin, n x add_scene (params[i], or the base settings' values when params is NULL), end. */
+int b32_frame_submit(b32_ctx* ctx, const B32Camera* camera, const B32Settings* base_settings, b32_scene* const* slots,
+                     const B32MeshParams* params /* nullable */, uint32_t n);
 /* which: 0 merged draws, 1 mesh-by-mesh draws, 2 merged meshes built, 3 frames ended -- since the context was created (tests). */
 unsigned long long b32_batch_count(const b32_ctx* ctx, int which);
 

@@ -2102,6 +2102,66 @@ def test_cpp_host_mirror_renders_scene_files(tmp_path):
     assert np.array_equal(got, np.load(os.path.join(GOLD, "cube_frame.npz"))["rgba"]) and "triangles_drawn 10" in r.stdout
 
 
+def test_frames_delivered_by_ticket_without_a_host_round_trip(oracle):
+    """The console's render step as the reference runs it: every frame's pixels reach host memory (game/renderer.rs:179-214).
+    b32_frame_submit (the frame's mesh table in one call) + b32_fb_download_async into page-locked memory + tickets: the host enqueues
+    frame i + 1 while frame i is drawn and copied, the presenter waits for the previous frame's ticket.  Frames alternate between two
+    cameras and clear colours; EVERY delivered frame is compared with the oracle's; polling never blocks; a ninth outstanding ticket
+    reuses the first one's event; argument errors."""
+    from bonnie32_amd import rasterizer as R
+    rng = np.random.default_rng(11)
+    meshes = [scenegen.make_scene("C1", n_tris=int(rng.integers(300, 2500)), seed=500 + i, variant=("blend" if i % 3 == 2 else "gouraud"),
+                                  bbox_px=float(rng.choice([150.0, 400.0]))) for i in range(6)]
+    st = b32.RasterSettings.game()
+    st.lights = [b32.Light.directional((-1.0, -1.0, -1.0), 0.7), b32.Light.point((0.0, -100.0, 1500.0), 3000.0, 1.2)]
+    fog = (1500.0, 3000.0, 5800.0, b32.Color(40, 50, 70))
+    W, H = meshes[0].width, meshes[0].height
+    cams = [meshes[0].camera, b32.Camera(position=(40.0, -25.0, 60.0))]
+    clears = [b32.Color(10, 10, 30), b32.Color(90, 20, 20)]
+    want = []
+    for cam, cl in zip(cams, clears):
+        o = oracle.Framebuffer(W, H); o.clear(cl)
+        for sc in meshes:
+            assert oracle.render_mesh_15(o, sc.vertices, sc.faces, sc.textures, cam, st, fog)[0] == 0
+        want.append(o.pixels.copy())
+    ctx = R.Context(0)                                            # the library's default (safe) mode
+    fb = R.Framebuffer(W, H, ctx)
+    slots = [R.ResidentScene(fb, sc.vertices, sc.faces, sc.textures).detach() for sc in meshes]
+    tables = [ctx.make_frame_table(cam, st, slots, fogs=[fog] * len(slots)) for cam in cams]
+    bufs = [ctx.host_alloc(W * H * 4) for _ in range(2)]
+    tickets = [0, 0]
+    E = b32.abi.B32_E_ARG
+    d = C.c_int()
+    assert ctx.lib.b32_ticket_poll(ctx.h, 1, C.byref(d)) == E and ctx.lib.b32_ticket_wait(ctx.h, 0) == E      # no such ticket (yet)
+    assert ctx.lib.b32_fb_download_async(ctx.h, None, None) == E
+    try:
+        n_frames = 21
+        for i in range(n_frames):
+            fb.clear(clears[i & 1])
+            ctx.frame_submit(tables[i & 1])
+            tickets[i & 1] = ctx.download_async(bufs[i & 1][1])
+            assert isinstance(ctx.ticket_done(tickets[i & 1]), bool)              # (poll: no blocking, either answer is legal here)
+            if i > 0:
+                ctx.ticket_wait(tickets[(i - 1) & 1])
+                got = bufs[(i - 1) & 1][0]
+                assert np.array_equal(got, want[(i - 1) & 1]), f"frame {i - 1}: {int((got != want[(i - 1) & 1]).sum())} bytes differ"
+        ctx.ticket_wait(tickets[(n_frames - 1) & 1])
+        assert ctx.ticket_done(tickets[(n_frames - 1) & 1]) and ctx.ticket_done(1)   # (ticket 1: its event was reused long ago)
+        assert np.array_equal(bufs[(n_frames - 1) & 1][0], want[(n_frames - 1) & 1])
+        ctx.finish()
+        assert ctx.batch_counts()["merged_draws"] > 0
+        # pageable memory works too (the call may block)
+        plain = np.zeros(W * H * 4, np.uint8)
+        t = C.c_uint64()
+        assert ctx.lib.b32_fb_download_async(ctx.h, plain.ctypes.data, C.byref(t)) == 0
+        ctx.ticket_wait(t.value)
+        assert np.array_equal(plain, want[(n_frames - 1) & 1])
+    finally:
+        for _, p in bufs:
+            ctx.host_free(p)
+        ctx.close()
+
+
 def test_cpp_host_mirror_batched_frame(tmp_path, oracle):
     """b32::ResidentMesh + b32::render_frame of the C++ mirror (b32_frame_begin / _add_scene / _end behind them): six meshes from
     .b32scene files -- per-mesh ambient, backface culling and fog travel in the files -- drawn as one frame on the GPU; framebuffer and
