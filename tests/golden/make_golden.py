@@ -49,14 +49,14 @@ def spot_scene(flat=False, zbuf=False):
     return sc
 
 
-def needle_scene(n=160, seed=5):
+def needle_scene(n=160, seed=5, width=320, height=240):
     """Needles millions of pixels long with their tip on the screen (the far end sits next to the camera plane, where the projection
     blows up): doubled area up to 2^23, so the -1e-4 tolerance of the inside test (render.rs:1536-1542) is worth a few hundred edge
     units, and the pixels straight BEYOND the tip -- outside the triangle's own bounding box -- still pass it.  The reference never
     looks at them: its loops stop at the bounding box, which is therefore part of the semantics.  (Integer-snapped coordinates
     below 2^22 with products below 2^24: these surfaces take the closed-form walk, not the literal replay.)"""
     # (the 256-entry CLUT of C3 has too few black texels for EXACT coverage to be chosen: with fragment counting off this is CHEAP coverage)
-    sc = scenegen.make_scene("C3", n_tris=n, seed=seed, bbox_px=100.0, width=320, height=240)
+    sc = scenegen.make_scene("C3", n_tris=n, seed=seed, bbox_px=100.0, width=width, height=height)
     rng = np.random.default_rng(seed)
     W, H = sc.width, sc.height
     vs = np.float32((np.float32(min(W, H)) / np.float32(2.0)) * np.float32(0.75))
