@@ -622,7 +622,8 @@ def main():
                         "clock_ghz": round(clk, 3), "clock_source": "measured in the kernel (b32_last_shader_clock)" if shader_clock_ghz and shader_clock_ghz > 0.5 else "nominal",
                         "issue_peak_us": round(issue_us, 2), "issue_peak_us_upper": round(issue_us_hi, 2), "frac": round(issue_us / (cover_ms * 1e3), 4),
                         "lds_bank_conflict_cycles": ecov.get("lds_bank_conflict"), "wait_any_share": ecov.get("wait_any_share")}
-            roofline = {"kernel": "k_cover", "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            roofline = {"kernel": "k_cover_plain", "kernel_note": "cover_body<..., P64, PLAIN = 1> under a 112-VGPR cap (b32_fill.hip); `cover` in phases_ms; key `<config>:k_cover` of profiles/pmc_traffic.json",
+                        "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": tsrc,
                         "kernel_ms": round(cover_ms, 4), "kernel_ms_samples": cover_samples,
                         "kernel_ms_note": "HIP events around the kernel on its own stream, every frame of an untimed pass on ONE stream (no other kernel beside it)" if world == 1 else "timed region",
