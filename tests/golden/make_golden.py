@@ -175,6 +175,10 @@ def real_scene(name):
     from bonnie32_amd import scenefile
     sc = scenefile.read_scene(os.path.join(REAL_DIR, name + ".b32scene"))
     sc.name = "real:" + name
+    side = os.path.join(REAL_DIR, name + ".indexed.npz")       # (asset parts: the reference's 4-bit index bytes + palette beside the expanded texels)
+    if os.path.exists(side):
+        z = np.load(side)
+        sc.indexed_textures = [b32.IndexedTexture(int(z["width"]), int(z["height"]), z["indices"], z["clut"], int(z["blend_mode"]))]
     return sc
 
 

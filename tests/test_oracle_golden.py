@@ -247,7 +247,7 @@ def test_real_scene_files_are_the_committed_ones(oracle):
     from bonnie32_amd import scenefile
     d = os.path.join(GOLD, "scenes", "real")
     man = json.load(open(os.path.join(d, "manifest.json")))
-    assert len(man) >= 10
+    assert len(man) >= 17
     shared = wide_uv = multi_tex = fogged = 0
     for name, m in man.items():
         blob = open(os.path.join(d, m["file"]), "rb").read()

@@ -442,6 +442,78 @@ def inside(level_name, room_idx, gx, gz, eye=610.0):
     return (p["x"] + (gx + 0.5) * 1024.0, p["y"] + floor + eye, p["z"] + (gz + 0.5) * 1024.0)
 
 
+# ------------------------------------------------------------------ asset mesh parts with the reference's indexed user textures (scene.rs:75-170)
+def load_ron_file(path):
+    raw = open(path, "rb").read()
+    if raw[:1] not in (b"(", b" ", b"\n", b"\r", b"\t"):
+        raw = subprocess.run(["node", "-e", "process.stdout.write(require('zlib').brotliDecompressSync(require('fs').readFileSync(process.argv[1])))", path],
+                             capture_output=True, check=True).stdout
+    return parse_ron(raw.decode("utf-8"))
+
+
+def user_textures():
+    """assets/samples/textures/*.ron: UserTexture { id, width, height, depth, indices (one byte per texel), palette (Color15 words), blend_mode }"""
+    out = {}
+    d = os.path.join(REF, "assets", "samples", "textures")
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith(".ron"):
+            t = load_ron_file(os.path.join(d, fn))
+            out[t["id"]] = t
+    return out
+
+
+def asset_part_scene(part_idx, settings_of, yaw=0.8, pitch=0.3, width=320, height=240, texture_name=None, fog=None):
+    """One iteration of render_asset_parts (scene.rs:114-170): EditableMesh::to_render_data_textured (mesh_editor.rs:1623-1653: n-gon faces
+    fan-triangulated, texture_id Some(0)), resolve_part_texture (scene.rs:75-104: the UserTexture's indices + palette as IndexedAtlas + Clut),
+    `atlas.to_texture15(&clut, ..)` (mesh_editor.rs:669-682, Clut::lookup types.rs:390-397) -- here handed over as the INDEXED texture, the
+    expansion being the library's (b32_scene_upload_indexed) -- and per-part back-face settings (scene.rs:134-138).  texture_name: pair the
+    part with another of the sample textures (texture_001 / _002 carry STP palette entries; their own blend mode does not reach the
+    rasterizer: to_texture15 always says Opaque)."""
+    asset = load_ron_file(os.path.join(REF, "assets", "samples", "assets", "asset_003.ron"))
+    mesh_comp = next(c for c in asset["components"] if isinstance(c, dict) and c.get("__variant__") == "Mesh")
+    part = mesh_comp["value"]["parts"][part_idx]
+    texs = user_textures()
+    ref = part["texture_ref"]
+    tex = texs[ref["value"][0]] if isinstance(ref, dict) and ref.get("__variant__") == "Id" else None
+    if texture_name:
+        tex = next(t for t in texs.values() if t["name"] == texture_name)
+    assert tex is not None
+    mv = part["mesh"]["vertices"]
+    v = b32.rtypes.make_vertices(len(mv))
+    v["pos"] = np.array([[x["pos"]["x"], x["pos"]["y"], x["pos"]["z"]] for x in mv], f32)
+    v["uv"] = np.array([[x["uv"]["x"], x["uv"]["y"]] for x in mv], f32)
+    v["normal"] = np.array([[x["normal"]["x"], x["normal"]["y"], x["normal"]["z"]] for x in mv], f32)
+    v["r"] = [x["color"]["r"] for x in mv]; v["g"] = [x["color"]["g"] for x in mv]; v["b"] = [x["color"]["b"] for x in mv]
+    v["blend"] = [BLEND[x["color"]["blend"]] for x in mv]
+    tris = []
+    for fc in part["mesh"]["faces"]:                            # EditFace::triangulate, mesh_editor.rs:96-110
+        vs = fc["vertices"]
+        for i in range(1, len(vs) - 1):
+            tris.append((vs[0], vs[i], vs[i + 1], fc["texture_id"] if fc.get("texture_id") is not None else 0,
+                         1 if fc.get("black_transparent", True) else 0, BLEND[fc.get("blend_mode", "Opaque")]))
+    f = b32.rtypes.make_faces(len(tris))
+    ff = np.array(tris, np.int64)
+    f["v"] = ff[:, 0:3].astype(np.uint32); f["texture_id"] = ff[:, 3].astype(np.uint32)
+    f["black_transparent"] = ff[:, 4]; f["blend_mode"] = ff[:, 5]; f["editor_alpha"] = 255
+    st = settings_of()
+    double_sided = bool(part.get("double_sided", False))
+    st.backface_cull = (not double_sided) and st.backface_cull          # scene.rs:134-138
+    st.backface_wireframe = (not double_sided) and st.backface_wireframe
+    it = b32.IndexedTexture(int(tex["width"]), int(tex["height"]), np.array(tex["indices"], np.uint8), np.array(tex["palette"], np.uint16), b32.abi.OPAQUE)
+    P = v["pos"]
+    mn, mx = P.min(axis=0), P.max(axis=0)
+    center = (mn + mx) / f32(2)
+    dist = f32(max(float(np.sqrt(((mx - mn) ** 2).sum())), 2048.0)) * f32(1.2)
+    cp, sp_, cy, sy = f32(np.cos(f32(pitch))), f32(np.sin(f32(pitch))), f32(np.cos(f32(yaw))), f32(np.sin(f32(yaw)))
+    cam_pos = center + v3(f32(dist * cp) * sy, dist * sp_, f32(dist * cp) * cy)
+    d = center - cam_pos
+    n = d * f32(f32(1.0) / f32(np.sqrt(dot(d, d))))
+    cam = camera_from_rotation(cam_pos, f32(np.arcsin(-n[1])), f32(np.arctan2(n[0], n[2])))
+    sc = scenegen.Scene(f"real:asset3-part{part_idx}", width, height, v, f, [it.to_texture15()], [it], cam, st, clear_color=b32.Color(20, 22, 28))
+    sc.fog = fog
+    return sc
+
+
 def painter():
     return b32.RasterSettings.benchmark()
 
@@ -463,6 +535,12 @@ SCENES = {
     "cave-room0-game": lambda: room_scene("Cave", 0, inside("Cave", 0, 2, 2), 0.1, 0.9, b32.RasterSettings.game),
     "cathedral-room0-game-640": lambda: room_scene("Cathedral", 0, inside("Cathedral", 0, 4, 4), 0.05, 0.7, b32.RasterSettings.game, width=640, height=480),
     "sewers-room0-painter": lambda: room_scene("Sewers", 0, inside("Sewers", 0, 1, 1), 0.2, 1.3, painter),
+    # the sample asset's mesh parts (quads, fan-triangulated) with the reference's own 4-bit indexed textures + palettes, as render_asset_parts
+    # submits them: one call per part, per-part back-face settings; the texture reaches the library as index bytes + CLUT
+    "asset3-part0-game": lambda: asset_part_scene(0, b32.RasterSettings.game),
+    "asset3-part1-game": lambda: asset_part_scene(1, b32.RasterSettings.game, yaw=2.2, pitch=0.5),
+    "asset3-part2-painter": lambda: asset_part_scene(2, painter, yaw=-0.6, pitch=0.2, width=640, height=480),
+    "asset3-part0-stp-palette-painter": lambda: asset_part_scene(0, painter, yaw=1.4, pitch=0.4, texture_name="texture_001"),
 }
 
 
@@ -480,6 +558,9 @@ def main():
                "zbuffer_sha256": hashlib.sha256(fb.zbuffer.tobytes()).hexdigest()}
         fn = name + ".b32scene"
         digest = scenefile.write_scene(os.path.join(OUT, fn), sc, exp)
+        if sc.indexed_textures:        # the texture as the reference holds it -- index bytes + palette: a sidecar (the .b32scene carries the expanded Texture15)
+            it = sc.indexed_textures[0]
+            np.savez_compressed(os.path.join(OUT, name + ".indexed.npz"), width=it.width, height=it.height, indices=it.indices, clut=it.clut, blend_mode=it.blend_mode)
         lit = int((fb.pixels.reshape(-1, 4)[:, :3] != np.array([sc.clear_color.r, sc.clear_color.g, sc.clear_color.b], np.uint8)).any(axis=1).sum())
         manifest[name] = {"file": fn, "file_sha256": digest, "width": sc.width, "height": sc.height, "vertices": int(len(sc.vertices)), "faces": int(len(sc.faces)),
                           "textures": len(sc.textures), "triangles_drawn": tm.triangles_drawn, "fragments": tm.fragments, "pixels_drawn": lit, **{k: exp[k] for k in ("sha256",)}}
