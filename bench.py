@@ -5,6 +5,10 @@ One step = one whole frame of the hot path over a synthetic scene whose inputs a
 Framebuffer::clear + render_mesh_15 (vertex transform + snap, cull/setup, painter's visibility, tile binning, textured
 RGB555-dither fill) and, for N > 1, the gather of the screen bands to rank 0.
 Workload at N = 1: BASELINE.json configs[2] "C3" — 2560x1920, 1M-triangle synthetic scene, 8-bit 256x256 atlas.
+N > 1 (config C4): one process per GPU, the frame sharded by screen bands; the exchange step is the PRODUCT's own, through the C ABI
+(--transport shm: band ranks store their rows straight into rank 0's framebuffer over a HIP IPC mapping, ordered by device-side epoch
+words; rccl: b32_gather_bands_rccl; torch: torch.distributed gather) -- checked against the torch-gathered frame before anything is timed,
+with a fallback the line reports (`transport`).
 
 Prints ONE JSON line on rank 0 (see the driver contract), with
   roofline       dominant kernel vs the 8 TB/s HBM peak (HIP events on the kernel's own stream, inside the timed region)
@@ -22,6 +26,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # (dmabuf IPC: what the shared-framebuffer transport's hipIpcGetMemHandle / RCCL need on this host driver)
 EVENT_STRIDE = int(os.environ.get("B32_BENCH_EVENT_STRIDE", "8"))        # HIP events around the dominant kernel on every 8th step of the timed region
 sys.path.insert(0, ROOT)
 
