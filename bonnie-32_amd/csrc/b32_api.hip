@@ -60,6 +60,9 @@ void b32_destroy(b32_ctx* c) {
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->stage_host) (void)hipHostFree(c->stage_host);
     for (hipEvent_t e : c->dl_ev) if (e) (void)hipEventDestroy(e);
+    if (c->dl_stream) { (void)hipStreamSynchronize(c->dl_stream); (void)hipStreamDestroy(c->dl_stream); }
+    for (hipEvent_t e : c->dl_snap) if (e) (void)hipEventDestroy(e);
+    for (uint32_t* q : c->dl_stage) if (q) (void)hipFree(q);
     delete c;
 }
 
@@ -323,8 +326,26 @@ int b32_fb_download_async(b32_ctx* c, uint8_t* rgba, uint64_t* ticket) {
     hipEvent_t& ev = c->dl_ev[t % b32_ctx::DL_RING];
     if (!ev) HIPCHK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     else if (t > b32_ctx::DL_RING) HIPCHK(c, hipEventSynchronize(ev));       // (the ticket that used this event, DL_RING downloads ago)
-    HIPCHK(c, hipMemcpyAsync(rgba, c->fb, (size_t)c->width * c->height * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipEventRecord(ev, c->stream));
+    const size_t px = (size_t)c->width * c->height;
+    // a snapshot on the device first (two staging buffers, alternating): the frames that follow overwrite the framebuffer while the
+    // snapshot crosses PCIe on a stream of its own
+    if (!c->dl_stream) {
+        HIPCHK(c, hipStreamCreateWithFlags(&c->dl_stream, hipStreamNonBlocking));
+        for (hipEvent_t& e : c->dl_snap) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    if (px > c->dl_stage_px) {
+        HIPCHK(c, hipStreamSynchronize(c->dl_stream));
+        for (uint32_t*& q : c->dl_stage) { if (q) HIPCHK(c, hipFree(q)); q = nullptr; HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&q), px * 4)); }
+        c->dl_stage_px = px;
+    }
+    const int k = (int)(t & 1u);
+    // (the staging buffer's previous reader -- ticket t - 2's transfer -- must have left: the main stream waits for it, normally long done)
+    if (t > 2) HIPCHK(c, hipStreamWaitEvent(c->stream, c->dl_ev[(t - 2) % b32_ctx::DL_RING], 0));
+    HIPCHK(c, hipMemcpyAsync(c->dl_stage[k], c->fb, px * 4, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipEventRecord(c->dl_snap[k], c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->dl_stream, c->dl_snap[k], 0));
+    HIPCHK(c, hipMemcpyAsync(rgba, c->dl_stage[k], px * 4, hipMemcpyDeviceToHost, c->dl_stream));
+    HIPCHK(c, hipEventRecord(ev, c->dl_stream));
     c->dl_seq = t; *ticket = t;
     return B32_OK;
 }

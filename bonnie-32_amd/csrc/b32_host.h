@@ -184,6 +184,9 @@ struct b32_ctx {
     // asynchronous framebuffer downloads (b32_fb_download_async): ticket t completes with event dl_ev[t % DL_RING]
     static constexpr uint32_t DL_RING = 8;
     hipEvent_t dl_ev[DL_RING] = {}; unsigned long long dl_seq = 0;
+    // ... through a device-side snapshot: the frame is copied to dl_stage[t % 2] on the context's stream (microseconds) and leaves for the host
+    // from there on dl_stream, so that the NEXT frame's kernels do not wait for the PCIe transfer
+    hipStream_t dl_stream = nullptr; hipEvent_t dl_snap[2] = {}; uint32_t* dl_stage[2] = {}; size_t dl_stage_px = 0;
     // profiling
     int profile_level = 0;
     uint32_t prof_stride = 1, prof_seq = 0;      // b32_set_profiling_stride: events on every prof_stride-th frame only
