@@ -17,6 +17,9 @@
 #ifndef B32_JOIN_KERNEL
 #define B32_JOIN_KERNEL 1            // (0: the fill waits for its setup kernel through a cross-stream event, as before)
 #endif
+#ifndef B32_PIPE_FEW_TILES
+#define B32_PIPE_FEW_TILES 1          // (0: frames whose fused kernel has no more tiles than workgroup slots are not pipelined, as before round 6)
+#endif
 #ifndef B32_WIRE_BIN_EARLY
 #define B32_WIRE_BIN_EARLY 1          // (0: k_wire_bin behind the fill on the main stream, as before)
 #endif
@@ -455,6 +458,13 @@ int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st, const
         if ((rc = pipeline_ensure(c))) return rc;
         rotate_sets(c);
         c->pipelined = true;
+        if (c->join_stream != s) {
+            // Streams of different priorities never share a hardware queue (the runtime pools its queues by priority); two streams of ONE
+            // priority may, and k_join in front of k_flag in the same queue would wait for its patience: those keep the event.
+            int pm = 0, ps = 0;
+            c->join_ok = hipStreamGetPriority(s, &pm) == hipSuccess && hipStreamGetPriority(c->side, &ps) == hipSuccess && pm != ps;
+            c->join_stream = s;
+        }
     }
     // (an error return between the rotation and the launches puts the sets back: the pending frame stays the current set's)
     bool rotated = c->pipelined;
@@ -479,7 +489,14 @@ int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st, const
     // ... and a frame whose fused kernel has no more tiles than workgroup slots has no tail to fill: the cross-stream waits (~10 us
     // between two kernels) then cost more than the overlap returns (C2, 100 k triangles at 320x240: 0.052 against 0.048 ms).  The merged
     // runs of a batched frame are the exception: their kernels leave most of the GPU idle anyway (75 tiles for 256 CUs).
-    c->pipe_hint = r.direct_bin && (ntiles > 2u * (uint32_t)c->n_cu || c->frame_batched || (c->band_set && B32_PIPELINE_BANDS));
+    // Round 6: with the flag / join kernel pair (no cross-stream event: ~5 us instead of ~12) frames WITHOUT a tail pay too when their two
+    // kernels are of comparable length -- C2, 100 k triangles at 320x240: setup 15.7 + fill 21.9 us, 0.0375 -> 0.0339 ms per frame --
+    // but only on that hand-over (the small-mesh route keeps the event: C1 0.0235 -> 0.0281), i.e. while the caller's stream and the side
+    // stream have different priorities (unknown before the first pipelined frame of a stream: tried once, then decided).
+    // The same for the frames of a screen band (one rank of a sharded frame: 240 rows of C4 are 320 tiles of 32 rows) -- round 5 had measured
+    // them with the event (N = 8 band 0.067 -> 0.071: no); with the kernel pair the weak series' N = 8 point goes 0.054 -> 0.042 ms per rank.
+    const bool join_small = B32_JOIN_KERNEL && B32_PIPE_FEW_TILES && !c->frame_batched && (c->join_stream != s || c->join_ok);
+    c->pipe_hint = r.direct_bin && (ntiles > 2u * (uint32_t)c->n_cu || c->frame_batched || (c->band_set && B32_PIPELINE_BANDS) || join_small);
 #ifdef B32_EXP_PIPE_SMALL
     c->pipe_hint = (r.direct_bin || r.want_inline) && !c->band_set;
 #endif
@@ -533,13 +550,6 @@ int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st, const
     if (prof_all) HIPCHK(c, hipEventRecord(ev[0], s));
     launch_setup(ss, fp, c->d_verts, c->d_faces, c->d_tex, c->d_lights, lset, c->frame_table, RecArrays{ c->crecs, c->srecs, c->xrecs }, r.db, c->shades, c->keys[0],
                  r.direct_bin ? nullptr : c->spans /* (direct binning: nobody reads the spans) */, c->partials, c->d_ctrl, c->wire, c->n_cu, pos12, attr12, c->face_of);
-    if (c->pipelined && c->join_stream != s) {
-        // Streams of different priorities never share a hardware queue (the runtime pools its queues by priority); two streams of ONE
-        // priority may, and k_join in front of k_flag in the same queue would wait for its patience: those keep the event.
-        int pm = 0, ps = 0;
-        c->join_ok = hipStreamGetPriority(s, &pm) == hipSuccess && hipStreamGetPriority(c->side, &ps) == hipSuccess && pm != ps;
-        c->join_stream = s;
-    }
     if (c->pipelined && B32_JOIN_KERNEL && r.direct_bin && c->join_ok && !(c->frame_batched && B32_JOIN_NOT_BATCHED)) {
         // (no cross-stream event on the fill's path: see k_flag / k_join)
         // (b32_debug_inject(ctx, 1): this frame's flag carries another epoch and the join's patience is 2 ms -- the "setup kernel never arrived" path)
