@@ -268,6 +268,51 @@ inline RasterTimings render_frame(Framebuffer& fb, const std::vector<std::pair<c
     return { tm.transform_ms, tm.fog_ms, tm.cull_ms, tm.sort_ms, tm.draw_ms, tm.wireframe_ms, tm.triangles_drawn, tm.fragments };
 }
 
+// The console's loop as the reference runs it -- every frame drawn (scene::render_scene, scene.rs:158-261) AND handed to the presenter from host
+// memory (game/renderer.rs:179-214) -- without a host round trip per frame: submit() enqueues Framebuffer::clear, the frame's draws
+// (b32_frame_submit: the mesh table in one call) and the copy of the finished frame into page-locked memory (b32_fb_download_async), and
+// returns a ticket; wait(ticket) blocks until THAT frame's pixels are in the returned buffer.  Two buffers alternate, so the presenter reads
+// frame i while frame i + 1 is drawn: keep at most two tickets outstanding.
+class FrameLoop {
+public:
+    explicit FrameLoop(Framebuffer& fb) : fb_(fb) {
+        for (auto& b : buf_) { b = static_cast<uint8_t*>(b32_host_alloc(fb.width * fb.height * 4)); if (!b) throw Error(B32_E_HIP, "b32_host_alloc"); }
+    }
+    ~FrameLoop() { b32_synchronize(fb_.ctx()); for (auto b : buf_) b32_host_free(b); }
+    FrameLoop(const FrameLoop&) = delete;
+    FrameLoop& operator=(const FrameLoop&) = delete;
+    uint64_t submit(Color clear, const std::vector<std::pair<const ResidentMesh*, MeshParams>>& meshes, const Camera& camera, const RasterSettings& base) {
+        const std::vector<B32Light> l = detail::pack(base.lights);
+        const B32Camera c = detail::pack(camera);
+        const B32Settings s = detail::pack(base, l);
+        std::vector<b32_scene*> slots; std::vector<B32MeshParams> params;
+        for (const auto& m : meshes) {
+            B32MeshParams p{};
+            p.ambient = m.second.ambient; p.backface_cull = m.second.backface_cull; p.backface_wireframe = m.second.backface_wireframe;
+            p.has_fog = detail::pack(m.second.fog, p.fog) ? 1 : 0;
+            slots.push_back(m.first->slot()); params.push_back(p);
+        }
+        fb_.clear(clear);
+        check(b32_frame_submit(fb_.ctx(), &c, &s, slots.data(), params.data(), (uint32_t)slots.size()), "frame_submit");
+        const size_t k = n_++ & 1;
+        check(b32_fb_download_async(fb_.ctx(), buf_[k], &ticket_[k]), "fb_download_async");
+        return ticket_[k];
+    }
+    // the frame of `ticket`, once it has landed (valid until the submit after next)
+    const uint8_t* wait(uint64_t ticket) {
+        check(b32_ticket_wait(fb_.ctx(), ticket), "ticket_wait");
+        for (size_t k = 0; k < 2; ++k) if (ticket_[k] == ticket) return buf_[k];
+        throw Error(B32_E_ARG, "FrameLoop::wait: the ticket's buffer has been reused");
+    }
+    // errors of the frames enqueued so far (b32_frame_finish), like any asynchronous frame
+    void finish() { B32Timings tm{}; check(b32_frame_finish(fb_.ctx(), &tm), "frame_finish"); }
+private:
+    Framebuffer& fb_;
+    uint8_t* buf_[2] = { nullptr, nullptr };
+    uint64_t ticket_[2] = { 0, 0 };
+    size_t n_ = 0;
+};
+
 // Names used by BASELINE.json's north_star; the reference's real entry point is render_mesh_15 (SURVEY headline fact 3).
 inline RasterTimings draw_mesh(Framebuffer& fb, const std::vector<Vertex>& v, const std::vector<Face>& f, const std::vector<Texture15>& t,
                                const Camera& c, const RasterSettings& s, const Fog& fog = std::nullopt) { return render_mesh_15(fb, v, f, t, c, s, fog); }

@@ -7,6 +7,7 @@
 #include <memory>
 #include <vector>
 
+#include <cstring>
 #include "scenefile.hpp"
 
 int main(int argc, char** argv) {
@@ -31,7 +32,23 @@ int main(int argc, char** argv) {
         std::vector<float> z((size_t)first.width * first.height);
         b32::check(b32_zbuffer_download(fb.ctx(), z.data()), "zbuffer");
         std::ofstream(argv[2], std::ios::binary).write(reinterpret_cast<const char*>(z.data()), (std::streamsize)(z.size() * 4));
-        std::printf("triangles_drawn %u merged_draws %llu\n", tm.triangles_drawn, b32_batch_count(fb.ctx(), 0));
+        const unsigned long long merged = b32_batch_count(fb.ctx(), 0);
+        // the same frame three times through the console loop (b32::FrameLoop: clear + b32_frame_submit + b32_fb_download_async + tickets), the
+        // presenter one frame behind: every delivered frame must be the frame render_frame produced
+        unsigned presented = 0;
+        {
+            b32::FrameLoop loop(fb);
+            uint64_t prev = 0;
+            for (int i = 0; i < 3; ++i) {
+                const uint64_t t = loop.submit(first.clear, frame, first.camera, base);
+                if (prev) { if (std::memcmp(loop.wait(prev), px.data(), px.size()) != 0) return 11; ++presented; }
+                prev = t;
+            }
+            if (std::memcmp(loop.wait(prev), px.data(), px.size()) != 0) return 11;
+            ++presented;
+            loop.finish();
+        }
+        std::printf("triangles_drawn %u merged_draws %llu presented_frames %u\n", tm.triangles_drawn, merged, presented);
     } catch (const b32::Error& e) {
         std::fprintf(stderr, "b32::Error %d: %s\n", e.code, e.what());
         return 10;

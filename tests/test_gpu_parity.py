@@ -2194,6 +2194,8 @@ def test_cpp_host_mirror_batched_frame(tmp_path, oracle):
     gz = np.frombuffer((tmp_path / "out.z").read_bytes(), np.uint32)
     assert np.array_equal(got, ofb.pixels) and np.array_equal(gz, ofb.zbuffer.view(np.uint32))
     assert "merged_draws 2" in r.stdout, r.stdout
+    # ... and the console loop of the mirror (b32::FrameLoop: every frame delivered to page-locked memory by ticket) presented the same frame three times
+    assert "presented_frames 3" in r.stdout, r.stdout
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3])
