@@ -183,7 +183,9 @@ struct Stamps { unsigned long long t[8]; };
 // Rare events of k_setup under direct binning, behind Stamps: each word holds the EPOCH (frame number, never 0) of the last frame the
 // event happened in, so nothing has to be reset between frames and k_setup's own frame-start reset of Ctrl cannot race with them.
 struct Events { uint32_t bad_index, nan_opaque, nan_transparent, overflow, long_transparent, setup_done /* k_flag -> k_join: epoch of the frame whose setup kernel has finished */,
-                join_abort /* k_join -> fill: epoch of the frame whose setup kernel never arrived (the fill draws nothing but the folded clear) */, _pad[1]; };
+                join_abort /* k_join -> fill: epoch of the frame whose setup kernel never arrived (the fill draws nothing but the folded clear) */,
+                fill_started /* fused fill -> k_gate of a later frame's setup kernel: FillArgs::start_seq of the last fused kernel that STARTED on this control
+                                block (it started => everything in front of it on the main stream has ended) */; };
 __device__ __forceinline__ Events* events_of(Ctrl* ctrl) { return reinterpret_cast<Events*>(reinterpret_cast<unsigned char*>(ctrl) + 128); }
 enum { ST_SETUP = 0, ST_BIN = 1, ST_FILL = 2, ST_WIRE = 3, ST_END = 4,
        ST_CLK0 = 5, ST_CLK1 = 6, ST_CLKW = 7 };   // shader-cycle counter at the start / end of workgroup 0 of the fused kernel, wall clock at its end
@@ -405,7 +407,7 @@ void launch_offset_tex(hipStream_t s, const TexDesc* src, uint32_t nt, TexDesc* 
 void launch_setup(hipStream_t s, const FrameParams& fp, const B32Vertex* verts, const B32Face* faces, const TexDesc* tex,
                   const B32Light* lights, const LightSet& inline_lights, const MeshTable& mesh_table, RecArrays recs, const DirectBin& direct, float* shades, uint32_t* keys, uint32_t* spans,
                   uint32_t* partials, Ctrl* ctrl, WireTri* wire, int n_cu, const float* pos12, const float* attr12, uint32_t* face_of);
-void launch_gate(hipStream_t s, const Ctrl* prev, uint32_t need, uint32_t patience_ticks);
+void launch_gate(hipStream_t s, Ctrl* prev, uint32_t need, uint32_t patience_ticks, uint32_t start_seq, Ctrl* mine);
 void launch_flag(hipStream_t s, Ctrl* ctrl, uint32_t epoch);
 void launch_join(hipStream_t s, Ctrl* ctrl, uint32_t epoch, uint32_t patience_ticks);
 void launch_pack_streams(hipStream_t s, const B32Vertex* verts, uint32_t nv, float* pos12, float* attr12, bool with_lit);
@@ -531,6 +533,7 @@ struct FillArgs {
     uint32_t atlas_idx_bytes;
     uint32_t stagger;           // > 0: the second workgroup of every CU starts this many 10-ns ticks late (set by launch_fill, see k_cover)
     uint32_t span_cover;        // 1: sort-free CHEAP painter's coverage by exact row intervals (B32_ROUTE_SPAN_COVER, b32_fill.hip "span coverage")
+    uint32_t start_seq;         // != 0: workgroup 0 publishes it in Events::fill_started when the fused kernel starts (see k_gate)
     uint32_t prio64;            // 1: sort-free coverage -- visibility is a 64-bit max of (painter's key << 32 | face id); `vis` holds
                                 //    two words per pixel: winner face id + 1, runner-up face id + 1 (0 = none)
 #ifdef B32_TIMELINE

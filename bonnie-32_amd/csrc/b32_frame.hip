@@ -6,7 +6,8 @@
 // ------------------------------------------------------------------ two frames in flight
 // The fused fill kernel leaves most CUs idle in its last fifth (the tile queue's tail), and k_setup of the NEXT frame needs nothing
 // from it: with two frame sets (everything k_setup writes, FrameSet) the setup kernel of frame i + 1 runs on a second stream beside the
-// fill of frame i.  Orders kept by events: setup(i) -> fill(i) (ev_setup), fill(i) -> setup(i + 2) on the same set (ev_done), and
+// fill of frame i.  Orders kept by events: setup(i) -> fill(i) (ev_setup; or the k_flag / k_join kernels), fill(i) -> setup(i + 2) on the same set
+// (round 6: on the device, k_gate waits for fill(i + 1) to have STARTED; an event only where that frame launched no fused kernel), and
 // anything enqueued on the main stream that k_setup reads (uploads, packed streams, light lists, list-space memsets) -> the next
 // setup (ev_main, only when `side_dirty`).  The main stream always waits for the frame's setup before enqueue_frame returns, so a
 // synchronisation of the main stream still covers everything this context has in flight.
@@ -16,6 +17,9 @@
 #endif
 #ifndef B32_JOIN_KERNEL
 #define B32_JOIN_KERNEL 1            // (0: the fill waits for its setup kernel through a cross-stream event, as before)
+#endif
+#ifndef B32_START_GATE
+#define B32_START_GATE 1             // (0: a cross-stream event behind every fill orders it before the setup kernel that next writes its frame set, as before)
 #endif
 #ifndef B32_PIPE_FEW_TILES
 #define B32_PIPE_FEW_TILES 1          // (0: frames whose fused kernel has no more tiles than workgroup slots are not pipelined, as before round 6)
@@ -516,11 +520,20 @@ int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st, const
     hipStream_t ss = s;
     if (c->pipelined) {
         if (c->side_dirty) { HIPCHK(c, hipEventRecord(c->ev_main, s)); HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_main, 0)); c->side_dirty = false; }
-        HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_done, 0));     // the last fill that read this set (two frames ago)
         ss = c->side;
         c->pipelined_frames++;
-        uint32_t polled_tiles = 0, polled_groups = 0;       // the fused kernel of the frame whose cursor the gate polls (alt[0]: n_sets - 1 frames back)
-        for (const auto& co : c->cover_of) if (co.ctrl && co.ctrl == c->alt[0].d_ctrl) { polled_tiles = co.tiles; polled_groups = co.groups; }
+        uint32_t polled_tiles = 0, polled_groups = 0, polled_seq = 0;       // the fused kernel of the frame whose cursor the gate polls (alt[0]: n_sets - 1 frames back)
+        for (const auto& co : c->cover_of) if (co.ctrl && co.ctrl == c->alt[0].d_ctrl) { polled_tiles = co.tiles; polled_groups = co.groups; polled_seq = co.seq; }
+        // The set this frame's setup kernel writes was last read by the fill n_sets frames back.  That fill lies in front of alt[0]'s on the main
+        // stream: when alt[0]'s frame launched a fused kernel, "it has started" orders the two on the device (k_gate, no event on the main
+        // stream: B32_START_GATE); else the side stream waits for the main stream as it stands now.
+        const bool start_gate = B32_START_GATE && polled_tiles && polled_seq && c->alt[0].d_ctrl;
+#if B32_START_GATE
+        if (!start_gate) { HIPCHK(c, hipEventRecord(c->ev_main, s)); HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_main, 0)); }
+#else
+        HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_done, 0));     // the last fill that read this set (n_sets frames ago)
+#endif
+        uint32_t gate_need = 0;
         if (c->gate_permille && polled_tiles && c->alt[0].d_ctrl) {
             // The fused kernel's workgroups take their next tile from the cursor after the coverage of the current one: the cursor
             // passes tiles - groups when the last tile is handed out, and every fetch beyond that is a workgroup that found the queue
@@ -529,8 +542,9 @@ int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st, const
             const uint32_t pre = tiles > groups ? tiles - groups : 0u;      // cursor value when the last tile is handed out
             const uint32_t need = c->gate_permille > 1000u ? (uint32_t)((uint64_t)(c->gate_permille - 1000u) * pre / 1000u)
                                                            : pre + (uint32_t)((uint64_t)(c->gate_permille - 1u) * groups / 1000u);
-            if (need) launch_gate(ss, c->alt[0].d_ctrl, need, 30000u /* 300 us */);      // alt[0]: the frame n_sets - 1 back (rotate_sets)
+            gate_need = need;
         }
+        if (gate_need || start_gate) launch_gate(ss, c->alt[0].d_ctrl, gate_need, 30000u /* 300 us */, start_gate ? polled_seq : 0u, c->d_ctrl);      // alt[0]: the frame n_sets - 1 back (rotate_sets)
     }
     // (the wire kernels' arguments: known before the setup kernel is launched -- a pipelined frame bins its wire list on the side stream)
     const bool wire_on = fp.wire_collect && c->nf;
@@ -603,6 +617,8 @@ int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st, const
 
     // ---- coverage, shading, transparent pass
     FillArgs fa = fill_args(c, fp, r, cur, wire_front);
+    if (++c->fill_seq == 0) c->fill_seq = 1;
+    fa.start_seq = c->fill_seq;
     // a deferred Framebuffer::clear: folded into this frame's fused kernel when that kernel is the one that runs, the frame has no
     // depth buffer to reset and the clear was issued for this very band; else the clear launches go first
     if (c->clear_pending) {
@@ -623,13 +639,15 @@ int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st, const
         launch_wire(s, wa, wire_back, wire_front, wire_binned);
     }
     if (prof_fill) { if (prof_all) HIPCHK(c, hipEventRecord(ev[5], s)); c->ev_frames++; }
+#if !B32_START_GATE
     if (c->side) HIPCHK(c, hipEventRecord(c->ev_done, s));         // (the next setup kernel that writes this set waits for it)
+#endif
     c->last_cover_tiles = (r.prio64 && !wire_front && !r.ordered_all) ? ntiles : 0u;
     c->last_cover_groups = std::min<uint32_t>(ntiles, (uint32_t)c->n_cu * 2u);
     {   // remembered per frame set
         b32_ctx::CoverOf* slot = &c->cover_of[0];
         for (auto& co : c->cover_of) { if (co.ctrl == c->d_ctrl) { slot = &co; break; } if (!co.ctrl) slot = &co; }
-        *slot = { c->d_ctrl, c->last_cover_tiles, c->last_cover_groups };
+        *slot = { c->d_ctrl, c->last_cover_tiles, c->last_cover_groups, c->last_cover_tiles ? fa.start_seq : 0u };
     }
     HIPCHK(c, hipGetLastError());
     return B32_OK;

@@ -56,8 +56,9 @@ struct b32_ctx {
     bool side_dirty = true;              // something k_setup reads was written on `stream` since the side stream last waited for it
     hipStream_t join_stream = nullptr; bool join_ok = false;   // k_flag / k_join instead of an event: only while `stream` and `side` have DIFFERENT priorities (then they never share a hardware queue); checked per main stream
     uint32_t gate_permille = 1150;       // b32_set_pipeline_gate: hold the next setup kernel until the previous fill has handed out 15 % of the tiles behind its first round
+    uint32_t fill_seq = 0;               // FillArgs::start_seq of the last fused kernel launched (never 0)
     bool pipe_hint = true;               // the previous frame's route could use the second frame set
-    struct CoverOf { const Ctrl* ctrl; uint32_t tiles, groups; } cover_of[3] = {};   // the same per frame set (keyed by its control block): the gate polls the
+    struct CoverOf { const Ctrl* ctrl; uint32_t tiles, groups, seq; } cover_of[3] = {};   // the same per frame set (keyed by its control block): the gate polls the
                                                                                       // cursor of the frame n_sets - 1 back, whose grid may differ from the previous frame's
     uint32_t last_cover_tiles = 0, last_cover_groups = 0;   // tile count / workgroups of the previous frame's fused kernel (0: it had none)
     bool pipelined = false;              // the frame being enqueued runs its k_setup on the side stream

@@ -648,7 +648,20 @@ void launch_offset_tex(hipStream_t s, const TexDesc* src, uint32_t nt, TexDesc* 
 // One wave on the side stream, in front of the next frame's k_setup: it returns once the fill kernel of the frame before has handed
 // out `need` tiles from its cursor -- so that the setup kernel runs in that kernel's thinning tail instead of beside its busy start --
 // or after `patience` ticks of the 100 MHz wall clock (a fill that aborted, or was no tile kernel at all, never moves its cursor).
-__global__ void k_gate(const Ctrl* __restrict__ prev, uint32_t need, uint32_t patience) {
+// Round 6: the gate also carries the ORDER the frame sets need.  The setup kernel behind it overwrites a frame set (records, lists, counters,
+// control block) that the fill n_sets frames back read; that fill precedes the fill of `prev` on the main stream, so once the latter has STARTED
+// (Events::fill_started == start_seq, published by its workgroup 0 with a device-scope atomic) the former has ended, caches written back and all.
+// This used to be a cross-stream event recorded behind every fill -- ~6 us of the main stream per frame (its system-scope release and the
+// signal) whether anyone waited for it or not.  start_seq == 0: no such wait (the caller ordered the streams by an event).  This wait is for
+// correctness: its patience is 2 s, and running out of it is reported (sticky bit 3 of the waiting frame's control block: B32_E_HIP).
+__global__ void k_gate(Ctrl* __restrict__ prev, uint32_t need, uint32_t patience, uint32_t start_seq, Ctrl* __restrict__ mine) {
+    if (start_seq) {
+        const unsigned long long t0 = wall_clock64();
+        while ((int32_t)(__hip_atomic_fetch_add(&events_of(prev)->fill_started, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - start_seq) < 0) {
+            if (wall_clock64() - t0 > 200000000ull) { atomicOr(&mine->sticky, 8u); break; }
+            __builtin_amdgcn_s_sleep(16);
+        }
+    }
     const unsigned long long t0 = wall_clock64();
     while (__hip_atomic_load(&prev->tile_cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
         if (wall_clock64() - t0 > patience) break;
@@ -676,8 +689,8 @@ __global__ void k_join(Ctrl* __restrict__ ctrl, uint32_t epoch, uint32_t patienc
 }
 void launch_flag(hipStream_t s, Ctrl* ctrl, uint32_t epoch) { hipLaunchKernelGGL(k_flag, dim3(1), dim3(1), 0, s, ctrl, epoch); }
 void launch_join(hipStream_t s, Ctrl* ctrl, uint32_t epoch, uint32_t patience) { hipLaunchKernelGGL(k_join, dim3(1), dim3(1), 0, s, ctrl, epoch, patience); }
-void launch_gate(hipStream_t s, const Ctrl* prev, uint32_t need, uint32_t patience) {
-    hipLaunchKernelGGL(k_gate, dim3(1), dim3(1), 0, s, prev, need, patience);
+void launch_gate(hipStream_t s, Ctrl* prev, uint32_t need, uint32_t patience, uint32_t start_seq, Ctrl* mine) {
+    hipLaunchKernelGGL(k_gate, dim3(1), dim3(1), 0, s, prev, need, patience, start_seq, mine);
 }
 
 // ---------------------------------------------------------------- stage tap: project_fixed for n positions
