@@ -534,10 +534,6 @@ struct FillArgs {
     uint32_t stagger;           // > 0: the second workgroup of every CU starts this many 10-ns ticks late (set by launch_fill, see k_cover)
     uint32_t span_cover;        // 1: sort-free CHEAP painter's coverage by exact row intervals (B32_ROUTE_SPAN_COVER, b32_fill.hip "span coverage")
     uint32_t start_seq;         // != 0: workgroup 0 publishes it in Events::fill_started when the fused kernel starts (see k_gate)
-    // Few-tile frames two in flight (16-wave workgroups on at most half of the CUs): the hand-over from this frame's setup kernel on the side
-    // stream is polled INSIDE the fused kernel -- thread 0 of every workgroup reads Events::setup_done until it holds join_epoch (k_flag), then
-    // the workgroup acquires at device scope -- instead of by k_join, a launch of its own in front of the fill.  0: no wait.
-    uint32_t join_epoch, join_patience;     // patience in 10-ns ticks; when it runs out: Events::join_abort + sticky bit 3, as k_join does
     uint32_t prio64;            // 1: sort-free coverage -- visibility is a 64-bit max of (painter's key << 32 | face id); `vis` holds
                                 //    two words per pixel: winner face id + 1, runner-up face id + 1 (0 = none)
 #ifdef B32_TIMELINE

@@ -21,9 +21,6 @@
 #ifndef B32_START_GATE
 #define B32_START_GATE 1             // (0: a cross-stream event behind every fill orders it before the setup kernel that next writes its frame set, as before)
 #endif
-#ifndef B32_POLL_JOIN
-#define B32_POLL_JOIN 1              // (0: k_join in front of every pipelined fill, as before) frames of few 16-wave workgroups poll the hand-over inside the fused kernel
-#endif
 #ifndef B32_PIPE_FEW_TILES
 #define B32_PIPE_FEW_TILES 1          // (0: frames whose fused kernel has no more tiles than workgroup slots are not pipelined, as before round 6)
 #endif
@@ -504,11 +501,6 @@ int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st, const
     // them with the event (N = 8 band 0.067 -> 0.071: no); with the kernel pair the weak series' N = 8 point goes 0.054 -> 0.042 ms per rank.
     const bool join_small = B32_JOIN_KERNEL && B32_PIPE_FEW_TILES && !c->frame_batched && (c->join_stream != s || c->join_ok);
     c->pipe_hint = r.direct_bin && (ntiles > 2u * (uint32_t)c->n_cu || c->frame_batched || (c->band_set && B32_PIPELINE_BANDS) || join_small);
-    // Round 6, second step: a fused kernel of 16-wave workgroups on at most 5 / 8 of the CUs (a 320x240 frame is 150 tiles of 8 rows) polls the hand-over itself (FillArgs::join_epoch):
-    // there is no k_join launch in front of it, and the setup kernel it spins for has the rest of the GPU.  (With every CU taken by
-    // spinning fill workgroups the setup kernel starves: round 5, C3 0.104 -> 0.134.)
-    const bool poll_ok = B32_POLL_JOIN && join_small && ntiles && 8u * ntiles <= 5u * (uint32_t)c->n_cu && !(c->route_off & B32_ROUTE_WIDE_GROUPS) &&
-                         !wire_front && !r.ordered_all && r.direct_bin;
 #ifdef B32_EXP_PIPE_SMALL
     c->pipe_hint = (r.direct_bin || r.want_inline) && !c->band_set;
 #endif
@@ -572,15 +564,7 @@ int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st, const
     if (prof_all) HIPCHK(c, hipEventRecord(ev[0], s));
     launch_setup(ss, fp, c->d_verts, c->d_faces, c->d_tex, c->d_lights, lset, c->frame_table, RecArrays{ c->crecs, c->srecs, c->xrecs }, r.db, c->shades, c->keys[0],
                  r.direct_bin ? nullptr : c->spans /* (direct binning: nobody reads the spans) */, c->partials, c->d_ctrl, c->wire, c->n_cu, pos12, attr12, c->face_of);
-    uint32_t poll_epoch = 0, poll_patience = 0;
-    if (c->pipelined && poll_ok && c->join_ok) {
-        // (the flag alone: the fused kernel polls it.  b32_debug_inject(ctx, 1) as below: another epoch, 2 ms of patience)
-        const bool lose_flag = (c->inject & 1u) != 0;
-        c->inject &= ~1u;
-        launch_flag(c->side, c->d_ctrl, lose_flag ? c->epoch ^ 0x40000000u : c->epoch);
-        poll_epoch = c->epoch; poll_patience = lose_flag ? 200000u : 200000000u;
-        c->flag_join_frames++; c->poll_join_frames++;
-    } else if (c->pipelined && B32_JOIN_KERNEL && r.direct_bin && c->join_ok && !(c->frame_batched && B32_JOIN_NOT_BATCHED)) {
+    if (c->pipelined && B32_JOIN_KERNEL && r.direct_bin && c->join_ok && !(c->frame_batched && B32_JOIN_NOT_BATCHED)) {
         // (no cross-stream event on the fill's path: see k_flag / k_join)
         // (b32_debug_inject(ctx, 1): this frame's flag carries another epoch and the join's patience is 2 ms -- the "setup kernel never arrived" path)
         const bool lose_flag = (c->inject & 1u) != 0;
@@ -635,7 +619,6 @@ int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st, const
     FillArgs fa = fill_args(c, fp, r, cur, wire_front);
     if (++c->fill_seq == 0) c->fill_seq = 1;
     fa.start_seq = c->fill_seq;
-    fa.join_epoch = poll_epoch; fa.join_patience = poll_patience;
     // a deferred Framebuffer::clear: folded into this frame's fused kernel when that kernel is the one that runs, the frame has no
     // depth buffer to reset and the clear was issued for this very band; else the clear launches go first
     if (c->clear_pending) {

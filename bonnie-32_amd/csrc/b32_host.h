@@ -63,7 +63,7 @@ struct b32_ctx {
     uint32_t last_cover_tiles = 0, last_cover_groups = 0;   // tile count / workgroups of the previous frame's fused kernel (0: it had none)
     bool pipelined = false;              // the frame being enqueued runs its k_setup on the side stream
     unsigned long long pipelined_frames = 0;
-    unsigned long long flag_join_frames = 0, event_join_frames = 0, poll_join_frames = 0;    // ... handed over to the fill by k_flag / k_join, or by a cross-stream event
+    unsigned long long flag_join_frames = 0, event_join_frames = 0;    // ... handed over to the fill by k_flag / k_join, or by a cross-stream event
     uint32_t inject = 0;                 // b32_debug_inject: fault injection for the tests of the failure paths
 
     // framebuffer
