@@ -185,7 +185,8 @@ struct Stamps { unsigned long long t[8]; };
 struct Events { uint32_t bad_index, nan_opaque, nan_transparent, overflow, long_transparent, setup_done /* k_flag -> k_join: epoch of the frame whose setup kernel has finished */,
                 join_abort /* k_join -> fill: epoch of the frame whose setup kernel never arrived (the fill draws nothing but the folded clear) */,
                 fill_started /* fused fill -> k_gate of a later frame's setup kernel: FillArgs::start_seq of the last fused kernel that STARTED on this control
-                                block (it started => everything in front of it on the main stream has ended) */; };
+                                block (it started => everything in front of it on the main stream has ended) */,
+                wbin_done /* side stream -> first wire kernel on the main stream: WireArgs::epoch of the frame whose early k_wire_bin has finished */, _pad[7]; };
 __device__ __forceinline__ Events* events_of(Ctrl* ctrl) { return reinterpret_cast<Events*>(reinterpret_cast<unsigned char*>(ctrl) + 128); }
 enum { ST_SETUP = 0, ST_BIN = 1, ST_FILL = 2, ST_WIRE = 3, ST_END = 4,
        ST_CLK0 = 5, ST_CLK1 = 6, ST_CLKW = 7 };   // shader-cycle counter at the start / end of workgroup 0 of the fused kernel, wall clock at its end
@@ -409,6 +410,7 @@ void launch_setup(hipStream_t s, const FrameParams& fp, const B32Vertex* verts, 
                   uint32_t* partials, Ctrl* ctrl, WireTri* wire, int n_cu, const float* pos12, const float* attr12, uint32_t* face_of);
 void launch_gate(hipStream_t s, Ctrl* prev, uint32_t need, uint32_t patience_ticks, uint32_t start_seq, Ctrl* mine);
 void launch_flag(hipStream_t s, Ctrl* ctrl, uint32_t epoch);
+void launch_flag_wbin(hipStream_t s, Ctrl* ctrl, uint32_t epoch);      // Events::wbin_done = epoch, behind the early k_wire_bin on the side stream
 void launch_join(hipStream_t s, Ctrl* ctrl, uint32_t epoch, uint32_t patience_ticks);
 void launch_pack_streams(hipStream_t s, const B32Vertex* verts, uint32_t nv, float* pos12, float* attr12, bool with_lit);
 void launch_project_fixed(hipStream_t s, const float* pos, uint32_t n, B32Camera cam, uint32_t w, uint32_t h,
@@ -449,6 +451,7 @@ struct WireArgs {
     // one counter per tile, then the overflow flag and the count of edges left to the global kernels; lists of WIRE_TILE_CAP ids per tile
     uint32_t* tile_fill; uint32_t* tile_lists;
     uint32_t tiles_x, tiles_y, tile_yb;
+    uint32_t epoch;             // never 0: what the two flag words hold when THIS frame raised them (no zeroing between frames)
 };
 constexpr uint32_t WIRE_TH = 16;               // wire tiles are 64 x WIRE_TH pixels: small enough that four workgroups share a CU's LDS
 constexpr uint32_t WIRE_TILE_CAP = 256;        // faces per tile list: one 256-lane workgroup de-duplicates their 768 edges in LDS
@@ -462,7 +465,7 @@ __device__ __forceinline__ float wire_t_fast(float kf, float Nf, float rN) {
     const float rem = __builtin_fmaf(-q, Nf, kf);
     return __builtin_fmaf(rem, rN, q);
 }
-void launch_wire(hipStream_t s, const WireArgs& a, bool back, bool front, bool binned = false);
+void launch_wire(hipStream_t s, const WireArgs& a, bool back, bool front, bool binned = false, Ctrl* wait_ctrl = nullptr, uint32_t wait_epoch = 0);   // wait_ctrl: see k_wire_table_clear
 void launch_wire_bin(hipStream_t s, const WireArgs& a, bool back, bool front, bool early);
 // Sort-free fast path: tile lists (unordered) by a counting sort straight from k_setup's spans; false = not applicable (too many
 // tiles for the LDS histogram), the caller takes the keyed radix path.  With `keys` the lists are split by class

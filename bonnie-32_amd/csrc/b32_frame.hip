@@ -548,13 +548,15 @@ int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st, const
     }
     // (the wire kernels' arguments: known before the setup kernel is launched -- a pipelined frame bins its wire list on the side stream)
     const bool wire_on = fp.wire_collect && c->nf;
-    bool wire_binned = false;
+    bool wire_binned = false, wire_polled = false;
     WireArgs wa{};
     if (wire_on) {
         wa.tris = c->wire; wa.nf = c->nf; wa.table_owner = c->wire_owner; wa.table_first = c->wire_first;
         wa.table_mask = c->cap_wire_table ? (uint32_t)(c->cap_wire_table - 1) : 0;
         wa.fb = c->fb; wa.zbuf = (c->zbuf && c->zbuf_valid) ? c->zbuf : nullptr;
         wa.width = c->width; wa.height = c->height; wa.band_y0 = c->band_y0; wa.band_y1 = c->band_y1; wa.ctrl = c->d_ctrl;
+        if (++c->wire_seq == 0) c->wire_seq = 1;
+        wa.epoch = c->wire_seq;
         if (!(c->route_off & B32_ROUTE_WIRE_TILES) && c->wire_fill && c->band_y1 > c->band_y0) {
             wa.tile_yb = (c->band_y0 / WIRE_TH) * WIRE_TH; wa.tiles_x = (c->width + TILE_W - 1) / TILE_W;
             wa.tiles_y = (c->band_y1 - wa.tile_yb + WIRE_TH - 1) / WIRE_TH;
@@ -581,7 +583,10 @@ int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st, const
     if (c->pipelined) {
         if (wire_on && wa.tile_fill && B32_WIRE_BIN_EARLY) {       // (behind ev_setup: the fill does not wait for the binning)
             launch_wire_bin(c->side, wa, wire_back, wire_front, true);
-            HIPCHK(c, hipEventRecord(c->ev_wbin, c->side));
+            // (back-face edges: the first wire kernel on the main stream, k_wire_table_clear, looks at Events::wbin_done itself -- no event
+            // for the main stream to wait for; the overlay alone has no such kernel in front of k_wire_tile and keeps the event)
+            if (wire_back) { launch_flag_wbin(c->side, c->d_ctrl, wa.epoch); wire_polled = true; }
+            else HIPCHK(c, hipEventRecord(c->ev_wbin, c->side));
             wire_binned = true;
         }
     }
@@ -635,8 +640,8 @@ int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st, const
 
     // ---- wireframe phases
     if (wire_on) {
-        if (wire_binned) HIPCHK(c, hipStreamWaitEvent(s, c->ev_wbin, 0));
-        launch_wire(s, wa, wire_back, wire_front, wire_binned);
+        if (wire_binned && !wire_polled) HIPCHK(c, hipStreamWaitEvent(s, c->ev_wbin, 0));
+        launch_wire(s, wa, wire_back, wire_front, wire_binned, wire_polled ? c->d_ctrl : nullptr, wa.epoch);
     }
     if (prof_fill) { if (prof_all) HIPCHK(c, hipEventRecord(ev[5], s)); c->ev_frames++; }
 #if !B32_START_GATE

@@ -52,11 +52,27 @@ __device__ __forceinline__ uint32_t* wire_counter(const WireArgs& a, uint32_t ti
 __device__ __forceinline__ uint32_t* wire_flag(const WireArgs& a, uint32_t which) { return a.tile_fill + (size_t)(a.tiles_x * a.tiles_y + which) * FILL_PAD; }   // 0 overflow, 1 big edges
 __device__ __forceinline__ bool wire_global_idle(const WireArgs& a) {               // tile route on, no list overflow, no big edge
     if (!a.tile_fill) return false;
-    return !*wire_flag(a, 0) && !*wire_flag(a, 1);
+    return *wire_flag(a, 0) != a.epoch && *wire_flag(a, 1) != a.epoch;
 }
 
-__global__ void k_wire_table_clear(uint32_t* __restrict__ owner, uint32_t* __restrict__ first, uint32_t n, const uint32_t* __restrict__ tile_flags) {
-    if (tile_flags && !tile_flags[0] && !tile_flags[FILL_PAD]) return;          // tile route: no overflow, no big edge -- the global kernels have nothing to do
+// (The two flag words behind the tile counters -- a list overflowed, some edge is left to the global kernels -- hold the EPOCH of the frame
+// that raised them (WireArgs::epoch, never 0): nobody has to zero them between frames, which was a memset launch of ~5 us on the main stream.)
+// wait_ctrl != nullptr: this frame's k_wire_bin ran on the side stream (early binning); every workgroup of this kernel -- the first of the wire
+// phases on the main stream -- looks once at Events::wbin_done before it reads a flag, and waits (bounded) if the binning has not published
+// its epoch yet.  In place of a cross-stream event, whose wait costs the main stream ~6 us per frame even when the event fired long ago.
+__global__ void k_wire_table_clear(uint32_t* __restrict__ owner, uint32_t* __restrict__ first, uint32_t n, const uint32_t* __restrict__ tile_flags, uint32_t epoch,
+                                   Ctrl* __restrict__ wait_ctrl, uint32_t wait_epoch) {
+    if (wait_ctrl) {
+        if (threadIdx.x == 0) {
+            const unsigned long long t0 = wall_clock64();
+            while (__hip_atomic_fetch_add(&events_of(wait_ctrl)->wbin_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != wait_epoch) {
+                if (wall_clock64() - t0 > 200000000ull) { atomicOr(&wait_ctrl->sticky, 8u); break; }
+                __builtin_amdgcn_s_sleep(32);
+            }
+        }
+        __syncthreads();
+    }
+    if (tile_flags && tile_flags[0] != epoch && tile_flags[FILL_PAD] != epoch) return;          // tile route: no overflow, no big edge -- the global kernels have nothing to do
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { owner[i] = SLOT_EMPTY; first[i] = SLOT_EMPTY; }
 }
 
@@ -230,7 +246,7 @@ __device__ __forceinline__ WireBox wire_box(const WireArgs& a, const Edge& e) {
 // does this edge go through the global kernels?  (tile route off: all of them)
 __device__ __forceinline__ bool wire_global(const WireArgs& a, const Edge& e) {
     if (!a.tile_fill) return true;
-    if (*wire_flag(a, 0)) return true;                   // a tile list overflowed (set by k_wire_bin, an earlier launch): the whole frame
+    if (*wire_flag(a, 0) == a.epoch) return true;                   // a tile list overflowed (set by k_wire_bin, an earlier launch): the whole frame
     const WireBox b = wire_box(a, e);
     return b.visible && b.big;
 }
@@ -259,13 +275,13 @@ __global__ void k_wire_bin(WireArgs a, uint32_t kinds) {           // kinds: bit
         tx0 = min(tx0, bx[j].tx0); tx1 = max(tx1, bx[j].tx1); ty0 = min(ty0, bx[j].ty0); ty1 = max(ty1, bx[j].ty1);
     }
     if (bad) { atomicOr(&a.ctrl->wire_overflow, 1u); atomicOr(&a.ctrl->sticky, 4u); }
-    if (n_big) atomicAdd(wire_flag(a, 1), n_big);
+    if (n_big) (void)__hip_atomic_exchange(wire_flag(a, 1), a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (!any) return;
     auto append = [&](uint32_t tx, uint32_t ty) {
         const uint32_t tile = ty * a.tiles_x + tx;
         const uint32_t pos = atomicAdd(wire_counter(a, tile), 1u);
         if (pos < WIRE_TILE_CAP) a.tile_lists[(size_t)tile * WIRE_TILE_CAP + pos] = f;
-        else atomicOr(wire_flag(a, 0), 1u);
+        else (void)__hip_atomic_exchange(wire_flag(a, 0), a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) <= 2u * WIRE_BIG_TILES) {
         for (uint32_t ty = ty0; ty <= ty1; ++ty)
@@ -333,7 +349,7 @@ __global__ __launch_bounds__(WIRE_THREADS) __attribute__((amdgpu_waves_per_eu(7,
     uint32_t* krange = scratch + WIRE_SEG_CAP / 2;                                       // edge slot -> first step | (steps - 1) << 14
     const uint32_t tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t n_all = *wire_counter(a, tile);
-    const bool overflowed = *wire_flag(a, 0) != 0;
+    const bool overflowed = *wire_flag(a, 0) == a.epoch;
     __syncthreads();                                     // (everyone has read the counter)
     if (tid == 0) *wire_counter(a, tile) = 0;            // zero again for the next frame's k_wire_bin
     if (overflowed || n_all == 0 || a.ctrl->abort) return;
@@ -515,12 +531,15 @@ __global__ void k_wire_draw(WireArgs a) {
 // The binning alone: it needs the wire list k_setup wrote and nothing of the fill, so a frame whose setup kernel runs on the side stream
 // bins there too, beside the previous frame's fill and wire kernels (early; launch_wire then skips it).  An abort the fill decides later
 // is harmless: k_wire_tile zeroes the counters again before it looks at the flag.
+#ifndef B32_WIRE_IDLE_BLOCKS
+#define B32_WIRE_IDLE_BLOCKS 256
+#endif
 void launch_wire_bin(hipStream_t s, const WireArgs& a, bool back, bool front, bool early) {
     if (!a.nf || !(back || front) || !a.tile_fill || !(a.tiles_x * a.tiles_y)) return;
     hipLaunchKernelGGL(k_wire_bin, dim3((a.nf + 255) / 256), dim3(256), 0, s, a, (back ? 1u : 0u) | (front ? 2u : 0u) | (early ? 4u : 0u));
 }
 
-void launch_wire(hipStream_t s, const WireArgs& a, bool back, bool front, bool binned) {
+void launch_wire(hipStream_t s, const WireArgs& a, bool back, bool front, bool binned, Ctrl* wait_ctrl, uint32_t wait_epoch) {
     if (!a.nf || !(back || front)) return;
     const uint32_t n = a.nf * 3, blocks = (n + 255) / 256;
     const uint32_t ntiles = a.tiles_x * a.tiles_y;
@@ -532,10 +551,11 @@ void launch_wire(hipStream_t s, const WireArgs& a, bool back, bool front, bool b
     const uint32_t* flags = tiles ? a.tile_fill + (size_t)ntiles * FILL_PAD : nullptr;
     // (tile route on: the global kernels usually have nothing to do -- 2048 workgroups that look at the flags and leave, or loop over
     // the edges left to them; tile route off: one lane per edge as before)
-    const uint32_t gblocks = flags ? min(blocks, 2048u) : blocks;
+    // (256 workgroups: three launches that usually find nothing to do beside a busy setup kernel cost what their grids take to place)
+    const uint32_t gblocks = flags ? min(blocks, (uint32_t)B32_WIRE_IDLE_BLOCKS) : blocks;
     if (tiles && !binned) launch_wire_bin(s, a, back, front, false);
     if (back) {
-        hipLaunchKernelGGL(k_wire_table_clear, dim3(flags ? 256 : 1024), dim3(256), 0, s, a.table_owner, a.table_first, a.table_mask + 1, flags);
+        hipLaunchKernelGGL(k_wire_table_clear, dim3(flags ? 256 : 1024), dim3(256), 0, s, a.table_owner, a.table_first, a.table_mask + 1, flags, a.epoch, wait_ctrl, wait_epoch);
         hipLaunchKernelGGL(k_wire_insert, dim3(gblocks), dim3(256), 0, s, a);
         hipLaunchKernelGGL(k_wire_draw<1>, dim3(gblocks), dim3(256), 0, s, a);
     }
@@ -544,7 +564,6 @@ void launch_wire(hipStream_t s, const WireArgs& a, bool back, bool front, bool b
 #endif
     if (tiles) hipLaunchKernelGGL(k_wire_tile, dim3(ntiles), dim3(WIRE_THREADS), B32_EXP_WIRE_PAD_LDS, s, a);
     if (front) hipLaunchKernelGGL(k_wire_draw<2>, dim3(gblocks), dim3(256), 0, s, a);
-    if (flags) (void)hipMemsetAsync(a.tile_fill + (size_t)ntiles * FILL_PAD, 0, 2 * FILL_PAD * sizeof(uint32_t), s);      // overflow flag + big-edge count: zero between frames
 }
 
 }  // namespace b32
