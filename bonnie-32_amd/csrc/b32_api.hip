@@ -556,7 +556,7 @@ extern "C" int b32_set_pipeline_depth(b32_ctx* c, uint32_t sets) {
     return B32_OK;
 }
 extern "C" int b32_debug_inject(b32_ctx* c, uint32_t what) {
-    if (!c || (what & ~1u)) return B32_E_ARG;
+    if (!c || (what & ~3u)) return B32_E_ARG;
     c->inject |= what;
     return B32_OK;
 }

@@ -408,7 +408,7 @@ void launch_offset_tex(hipStream_t s, const TexDesc* src, uint32_t nt, TexDesc* 
 void launch_setup(hipStream_t s, const FrameParams& fp, const B32Vertex* verts, const B32Face* faces, const TexDesc* tex,
                   const B32Light* lights, const LightSet& inline_lights, const MeshTable& mesh_table, RecArrays recs, const DirectBin& direct, float* shades, uint32_t* keys, uint32_t* spans,
                   uint32_t* partials, Ctrl* ctrl, WireTri* wire, int n_cu, const float* pos12, const float* attr12, uint32_t* face_of);
-void launch_gate(hipStream_t s, Ctrl* prev, uint32_t need, uint32_t patience_ticks, uint32_t start_seq, Ctrl* mine);
+void launch_gate(hipStream_t s, Ctrl* prev, uint32_t need, uint32_t patience_ticks, uint32_t start_seq, Ctrl* mine, uint32_t start_patience_ticks = 200000000u);
 void launch_flag(hipStream_t s, Ctrl* ctrl, uint32_t epoch);
 void launch_flag_wbin(hipStream_t s, Ctrl* ctrl, uint32_t epoch);      // Events::wbin_done = epoch, behind the early k_wire_bin on the side stream
 void launch_join(hipStream_t s, Ctrl* ctrl, uint32_t epoch, uint32_t patience_ticks);

@@ -544,7 +544,10 @@ int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st, const
                                                            : pre + (uint32_t)((uint64_t)(c->gate_permille - 1u) * groups / 1000u);
             gate_need = need;
         }
-        if (gate_need || start_gate) launch_gate(ss, c->alt[0].d_ctrl, gate_need, 30000u /* 300 us */, start_gate ? polled_seq : 0u, c->d_ctrl);      // alt[0]: the frame n_sets - 1 back (rotate_sets)
+        // (b32_debug_inject(ctx, 2): the fill in front did not publish its start -- this gate's patience is 2 ms, then the error)
+        const uint32_t start_patience = c->start_lost ? 200000u : 200000000u;
+        if (start_gate) c->start_lost = false;
+        if (gate_need || start_gate) launch_gate(ss, c->alt[0].d_ctrl, gate_need, 30000u /* 300 us */, start_gate ? polled_seq : 0u, c->d_ctrl, start_patience);      // alt[0]: the frame n_sets - 1 back (rotate_sets)
     }
     // (the wire kernels' arguments: known before the setup kernel is launched -- a pipelined frame bins its wire list on the side stream)
     const bool wire_on = fp.wire_collect && c->nf;
@@ -624,6 +627,8 @@ int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st, const
     FillArgs fa = fill_args(c, fp, r, cur, wire_front);
     if (++c->fill_seq == 0) c->fill_seq = 1;
     fa.start_seq = c->fill_seq;
+    const uint32_t start_seq_meant = fa.start_seq;
+    if ((c->inject & 2u) && fa.prio64 && !wire_front && !r.ordered_all && ntiles) { c->inject &= ~2u; fa.start_seq = 0; c->start_lost = true; }    // (fault injection: see b32_debug_inject)
     // a deferred Framebuffer::clear: folded into this frame's fused kernel when that kernel is the one that runs, the frame has no
     // depth buffer to reset and the clear was issued for this very band; else the clear launches go first
     if (c->clear_pending) {
@@ -652,7 +657,7 @@ int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st, const
     {   // remembered per frame set
         b32_ctx::CoverOf* slot = &c->cover_of[0];
         for (auto& co : c->cover_of) { if (co.ctrl == c->d_ctrl) { slot = &co; break; } if (!co.ctrl) slot = &co; }
-        *slot = { c->d_ctrl, c->last_cover_tiles, c->last_cover_groups, c->last_cover_tiles ? fa.start_seq : 0u };
+        *slot = { c->d_ctrl, c->last_cover_tiles, c->last_cover_groups, c->last_cover_tiles ? start_seq_meant : 0u };
     }
     HIPCHK(c, hipGetLastError());
     return B32_OK;

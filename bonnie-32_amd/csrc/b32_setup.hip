@@ -653,12 +653,12 @@ void launch_offset_tex(hipStream_t s, const TexDesc* src, uint32_t nt, TexDesc* 
 // (Events::fill_started == start_seq, published by its workgroup 0 with a device-scope atomic) the former has ended, caches written back and all.
 // This used to be a cross-stream event recorded behind every fill -- ~6 us of the main stream per frame (its system-scope release and the
 // signal) whether anyone waited for it or not.  start_seq == 0: no such wait (the caller ordered the streams by an event).  This wait is for
-// correctness: its patience is 2 s, and running out of it is reported (sticky bit 3 of the waiting frame's control block: B32_E_HIP).
-__global__ void k_gate(Ctrl* __restrict__ prev, uint32_t need, uint32_t patience, uint32_t start_seq, Ctrl* __restrict__ mine) {
+// correctness: its patience is 2 s (start_patience, 10-ns ticks), and running out of it is reported (sticky bit 3 of the waiting frame's control block: B32_E_HIP).
+__global__ void k_gate(Ctrl* __restrict__ prev, uint32_t need, uint32_t patience, uint32_t start_seq, Ctrl* __restrict__ mine, uint32_t start_patience) {
     if (start_seq) {
         const unsigned long long t0 = wall_clock64();
         while ((int32_t)(__hip_atomic_fetch_add(&events_of(prev)->fill_started, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - start_seq) < 0) {
-            if (wall_clock64() - t0 > 200000000ull) { atomicOr(&mine->sticky, 8u); break; }
+            if (wall_clock64() - t0 > (unsigned long long)start_patience) { atomicOr(&mine->sticky, 8u); break; }
             __builtin_amdgcn_s_sleep(16);
         }
     }
@@ -693,8 +693,8 @@ __global__ void k_flag_wbin(Ctrl* __restrict__ ctrl, uint32_t epoch) {
 void launch_flag(hipStream_t s, Ctrl* ctrl, uint32_t epoch) { hipLaunchKernelGGL(k_flag, dim3(1), dim3(1), 0, s, ctrl, epoch); }
 void launch_flag_wbin(hipStream_t s, Ctrl* ctrl, uint32_t epoch) { hipLaunchKernelGGL(k_flag_wbin, dim3(1), dim3(1), 0, s, ctrl, epoch); }
 void launch_join(hipStream_t s, Ctrl* ctrl, uint32_t epoch, uint32_t patience) { hipLaunchKernelGGL(k_join, dim3(1), dim3(1), 0, s, ctrl, epoch, patience); }
-void launch_gate(hipStream_t s, Ctrl* prev, uint32_t need, uint32_t patience, uint32_t start_seq, Ctrl* mine) {
-    hipLaunchKernelGGL(k_gate, dim3(1), dim3(1), 0, s, prev, need, patience, start_seq, mine);
+void launch_gate(hipStream_t s, Ctrl* prev, uint32_t need, uint32_t patience, uint32_t start_seq, Ctrl* mine, uint32_t start_patience) {
+    hipLaunchKernelGGL(k_gate, dim3(1), dim3(1), 0, s, prev, need, patience, start_seq, mine, start_patience);
 }
 
 // ---------------------------------------------------------------- stage tap: project_fixed for n positions

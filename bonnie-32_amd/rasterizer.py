@@ -193,7 +193,7 @@ class Context:
         return {n: int(self.lib.b32_route_count(self.h, i)) for i, n in enumerate(self.ROUTES)}
 
     def debug_inject(self, what):
-        """b32_debug_inject: fault injection (1 = the next flag / join hand-over loses its flag)."""
+        """b32_debug_inject: fault injection (1 = the next flag / join hand-over loses its flag; 2 = the next fused kernel does not publish its start)."""
         _chk(self.lib.b32_debug_inject(self.h, int(what)), "b32_debug_inject")
 
     def set_fragment_counting(self, on):

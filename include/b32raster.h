@@ -435,7 +435,9 @@ int b32_transparent_counts(const b32_ctx* ctx, uint32_t* host_bound, uint32_t* d
 /* Test tap (no reference counterpart): fault injection for the failure paths that cannot be provoked from outside.  what = 1: the NEXT
  * frame that hands its setup kernel over by the flag / join kernel pair loses its flag (it publishes another epoch) and its join waits 2 ms
  * instead of 2 s -- the "setup kernel never arrived" path: the fill draws nothing but the folded clear, b32_frame_finish returns
- * B32_E_HIP, the frames after it are drawn normally.  Other bits: B32_E_ARG. */
+ * B32_E_HIP, the frames after it are drawn normally.  what = 2: the NEXT fused fill kernel does not publish that it has started, and the gate
+ * of the pipelined frame behind it -- which orders its setup kernel after the frame set's last reader by that word -- waits 2 ms instead of
+ * 2 s, gives up, goes on and raises the same error: reported once by b32_frame_finish, frames right.  Other bits: B32_E_ARG. */
 int b32_debug_inject(b32_ctx* ctx, uint32_t what);
 /* Two frames in flight (no reference counterpart; see B32_ROUTE_PIPELINE): when a frame is enqueued while an earlier one is still
  * pending, its setup kernel runs on a second, low-priority stream of the context beside the earlier frame's fill kernel, on a second

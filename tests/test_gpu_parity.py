@@ -552,7 +552,39 @@ def test_lost_setup_flag_aborts_one_frame_and_is_reported(oracle):
     fb.clear(sc.clear_color); rs.render_async()
     tm = rs.finish()
     assert np.array_equal(fb.pixels, want) and tm.triangles_drawn == otm.triangles_drawn
-    assert ctx.lib.b32_debug_inject(ctx.h, 2) == b32.abi.B32_E_ARG
+    assert ctx.lib.b32_debug_inject(ctx.h, 4) == b32.abi.B32_E_ARG
+    ctx.close()
+
+
+def test_lost_start_signal_is_reported_and_the_frames_are_right(oracle):
+    """The failure path of the device-side order between frame sets (round 6: the fused kernel publishes Events::fill_started, k_gate in front of
+    the setup kernel that next writes the frame set waits for it instead of for a cross-stream event), forced by b32_debug_inject(2): one fill
+    does not publish its start, the gate behind it gives up after 2 ms, raises the sticky error bit and lets its setup kernel go on (by then the
+    main stream is long past the set's last reader); b32_frame_finish returns B32_E_HIP once -- never silent -- every frame is drawn, and the
+    context is clean afterwards."""
+    from bonnie32_amd import rasterizer as R
+    sc = scenegen.make_scene("C3", n_tris=200_000)
+    want, otm, _ = cpu_render(oracle, sc)
+    ctx = R.Context(0); ctx.set_async_depth(1)
+    fb = R.Framebuffer(sc.width, sc.height, ctx)
+    rs = R.ResidentScene(fb, sc.vertices, sc.faces, indexed_textures=sc.indexed_textures)
+    for _ in range(4):
+        fb.clear(sc.clear_color); rs.render_async(sc.camera, sc.settings, sc.fog)
+    rs.finish()
+    assert np.array_equal(fb.pixels, want)
+    p0 = ctx.route_counts()["pipelined"]
+    ctx.debug_inject(2)
+    for _ in range(5):
+        fb.clear(sc.clear_color); rs.render_async()
+    with pytest.raises(R.B32Error) as ei:
+        rs.finish()
+    assert ei.value.code == b32.abi.B32_E_HIP
+    assert ctx.route_counts()["pipelined"] - p0 >= 4          # the frames behind the silent fill really took the gated route
+    assert np.array_equal(fb.pixels, want)
+    for _ in range(3):
+        fb.clear(sc.clear_color); rs.render_async()
+    tm = rs.finish()
+    assert np.array_equal(fb.pixels, want) and tm.triangles_drawn == otm.triangles_drawn
     ctx.close()
 
 
