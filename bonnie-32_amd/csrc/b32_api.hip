@@ -118,7 +118,7 @@ static int fb_set_dims(b32_ctx* c, uint32_t w, uint32_t h) {
     c->width = w; c->height = h;
     if (!c->band_set) { c->band_y0 = 0; c->band_y1 = h; }
     else { if (c->band_y1 > h) c->band_y1 = h; if (c->band_y0 > c->band_y1) c->band_y0 = c->band_y1; }
-    return B32_OK;
+    return c->n_sets_user ? B32_OK : apply_depth_auto(c);       // (the band's share of the frame decides the library's own pipeline depth)
 }
 static int fb_resize_any(b32_ctx* c, uint32_t w, uint32_t h, bool always_new) {
     if (!c || w == 0 || h == 0 || w > 16384 || h > 16384) return B32_E_ARG;
@@ -143,7 +143,7 @@ static int fb_resize_any(b32_ctx* c, uint32_t w, uint32_t h, bool always_new) {
     c->fb = c->fb_own;
     c->band_set = false;
     c->zbuf_valid = false;                                                  // vec![f32::MAX; w*h], render.rs:22,32
-    fb_set_dims(c, w, h);
+    { const int rcd = fb_set_dims(c, w, h); if (rcd) return rcd; }
     HIPCHK(c, hipMemsetAsync(c->fb, 0, px * 4, c->stream));                // vec![0; w*h*4], render.rs:18-33
     return B32_OK;
 }
@@ -172,6 +172,7 @@ int b32_set_band(b32_ctx* c, uint32_t y0, uint32_t y1) {
     { const int rcs = settle_pending(c); if (rcs) return rcs; }       // (a redraw of the pending frame belongs to the band it was enqueued for)
     { const int rcf = flush_clear(c); if (rcf) return rcf; }          // (a deferred clear belongs to the rows of the band it was issued for)
     c->band_y0 = y0; c->band_y1 = y1; c->band_set = !(y0 == 0 && y1 == c->height);
+    if (!c->n_sets_user) return apply_depth_auto(c);        // (a narrow band runs three frame sets: b32_set_pipeline_depth)
     return B32_OK;
 }
 // (safe mode) a pending large-scene frame that may still need a redraw is settled before anything else WRITES the framebuffer too:
@@ -542,8 +543,15 @@ extern "C" int b32_transparent_counts(const b32_ctx* c, uint32_t* host_bound, ui
     *host_bound = c->blend_faces; *device_last = c->h_ctrl.n_transparent;
     return B32_OK;
 }
-extern "C" int b32_set_pipeline_depth(b32_ctx* c, uint32_t sets) {
-    if (!c || sets < 2u || sets > 3u) return B32_E_ARG;
+// The depth the library picks itself (b32_set_pipeline_depth(ctx, 0), the default): two frame sets, three for a NARROW band -- at most a sixth
+// of the frame's rows, one rank of a frame sharded over six or more GPUs.  Such a rank still transforms the whole mesh and its frame is
+// bound by the setup kernel, not by the fill: with three sets the setup kernels run back to back on the side stream instead of each waiting
+// for the previous frame's fill to start (240 rows of C3, 1 of 8 ranks: 0.040 -> 0.034-0.035 ms per frame; 480 rows: the same either way; 960
+// rows and the whole frame: two sets are faster -- profiles/r06_band_depth.txt).
+static uint32_t auto_depth(const b32_ctx* c) {
+    return (c->band_set && c->height && (uint64_t)(c->band_y1 - c->band_y0) * 6u <= c->height) ? 3u : 2u;
+}
+static int apply_depth(b32_ctx* c, uint32_t sets) {
     if (sets == c->n_sets) return B32_OK;
     (void)hipSetDevice(c->device);
     // everything in flight ends first: the ring's order (alt[0] oldest) only means something for one depth
@@ -555,6 +563,12 @@ extern "C" int b32_set_pipeline_depth(b32_ctx* c, uint32_t sets) {
     c->n_sets = sets;
     return B32_OK;
 }
+extern "C" int b32_set_pipeline_depth(b32_ctx* c, uint32_t sets) {
+    if (!c || sets == 1u || sets > 3u) return B32_E_ARG;
+    c->n_sets_user = sets;
+    return apply_depth(c, sets ? sets : auto_depth(c));
+}
+extern "C" int apply_depth_auto(b32_ctx* c) { return apply_depth(c, auto_depth(c)); }
 extern "C" int b32_debug_inject(b32_ctx* c, uint32_t what) {
     if (!c || (what & ~3u)) return B32_E_ARG;
     c->inject |= what;

@@ -49,6 +49,7 @@ struct b32_ctx {
     // two frames in flight: the setup kernel of the next frame on `side` beside the fill of the current one on `stream`
     hipStream_t side = nullptr; hipEvent_t ev_main = nullptr, ev_wbin = nullptr;     // (ev_wbin: a pipelined frame's k_wire_bin finished on the side stream)
     FrameSet alt[2];                     // the other frame sets, oldest first (allocated on first use; alt[1] only with three sets)
+    uint32_t n_sets_user = 0;            // what b32_set_pipeline_depth asked for (0: the library's own choice, see auto_depth in b32_api.hip)
     uint32_t n_sets = 2;                 // b32_set_pipeline_depth: 2 = setup(i+1) beside fill(i); 3 = setup(i+2) beside fill(i), so that the
                                          // setup kernel a fill waits for ended a whole fill ago (fills back to back; measured slower: the two
                                          // kernels then share the CUs all the time and the frame is bound by their summed VALU work)
@@ -287,6 +288,7 @@ constexpr size_t STAGE_BYTES = (size_t)1 << 20, STAGE_CTRL_OFF = STAGE_BYTES - 1
 extern "C" {
 B32_INTERNAL int settle_pending(b32_ctx* c);                                      // b32_api.hip
 B32_INTERNAL int flush_clear(b32_ctx* c);                                         // b32_api.hip
+B32_INTERNAL int apply_depth_auto(b32_ctx* c);                                    // b32_api.hip (b32_set_pipeline_depth(ctx, 0): the depth the library picks)
 constexpr size_t FB_TAIL_BYTES = 8192;      // behind the pixels of a library-owned framebuffer: the epoch words of the band exchange (b32_gather.hip)
 B32_INTERNAL void band_close_any(b32_ctx* c);                                    // b32_gather.hip
 B32_INTERNAL void free_alt(b32_ctx* c, FrameSet& a);                              // b32_frame.hip

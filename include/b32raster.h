@@ -450,11 +450,15 @@ int b32_debug_inject(b32_ctx* ctx, uint32_t what);
  * Results are identical either way.  permille > 2000: B32_E_ARG. */
 int b32_set_pipeline_gate(b32_ctx* ctx, uint32_t permille);
 /* How far ahead of its fill a pipelined setup kernel runs (no reference counterpart; render.rs:2364-2547 is one sequential call):
- *   sets = 2 (default): k_setup(i + 1) beside the fill of frame i -- the fill of frame i + 1 starts behind a cross-stream event that is
+ *   sets = 2: k_setup(i + 1) beside the fill of frame i -- the fill of frame i + 1 starts behind a cross-stream event that is
  *             signalled only about when the fill before it ends (10-20 us per frame with little on the GPU);
  *   sets = 3: k_setup(i + 2) beside the fill of frame i, on a third set of per-face buffers: the setup kernel a fill waits for ended
  *             a whole fill earlier and fills run back to back on the main stream.  Measured on C3 (round 4): the hole closes, but the two
  *             kernels then share every CU all the time and the frame is bound by their summed VALU work: 0.127 against 0.122 ms.
+ *   sets = 0 (the library's choice, the default): two sets; three while the context draws a NARROW band (b32_set_band: at most a sixth of the
+ *             frame's rows -- one rank of a frame sharded over six or more GPUs): that rank still transforms the whole mesh, its frame is
+ *             bound by the setup kernel, and with three sets the setup kernels run back to back (240 rows of the 1 M-triangle frame: 0.040 ->
+ *             0.034-0.035 ms per frame).  b32_set_band switches when the band crosses that width (everything in flight ends first).
  * Settles a pending frame first.  Results are identical either way.  Other values: B32_E_ARG. */
 int b32_set_pipeline_depth(b32_ctx* ctx, uint32_t sets);
 /* B32Timings.fragments (the reference's pixel-store count, render.rs:1671-1702) is instrumentation, not an output of

@@ -556,6 +556,31 @@ def test_lost_setup_flag_aborts_one_frame_and_is_reported(oracle):
     ctx.close()
 
 
+def test_narrow_band_runs_three_frame_sets_by_itself(oracle):
+    """b32_set_pipeline_depth(0), the default: a band of at most a sixth of the frame's rows (one rank of a frame sharded over six or more GPUs)
+    switches the context to three frame sets, a wider band or the whole frame back to two; frames drawn across the switches, pipelined, equal
+    the oracle's rows of the band."""
+    from bonnie32_amd import rasterizer as R, parallel
+    sc = scenegen.make_scene("C3", n_tris=150_000)
+    want, _, _ = cpu_render(oracle, sc)
+    want = want.reshape(sc.height, sc.width, 4)
+    ctx = R.Context(0); ctx.set_async_depth(1)
+    fb = R.Framebuffer(sc.width, sc.height, ctx)
+    rs = R.ResidentScene(fb, sc.vertices, sc.faces, indexed_textures=sc.indexed_textures)
+    for N, r in ((8, 3), (2, 1), (8, 7), (1, 0), (6, 2)):
+        y0, y1 = parallel.band_rows(sc.height, N, r)
+        fb.set_band(y0, y1)
+        p0 = ctx.route_counts()["pipelined"]
+        fb.clear(sc.clear_color); rs.render_async(sc.camera, sc.settings, sc.fog)
+        for _ in range(6):
+            fb.clear(sc.clear_color); rs.render_async()
+        rs.finish()
+        assert ctx.route_counts()["pipelined"] - p0 >= 4
+        got = fb.pixels.reshape(sc.height, sc.width, 4)
+        assert np.array_equal(got[y0:y1], want[y0:y1]), (N, r)
+    ctx.close()
+
+
 def test_lost_start_signal_is_reported_and_the_frames_are_right(oracle):
     """The failure path of the device-side order between frame sets (round 6: the fused kernel publishes Events::fill_started, k_gate in front of
     the setup kernel that next writes the frame set waits for it instead of for a cross-stream event), forced by b32_debug_inject(2): one fill
@@ -719,12 +744,12 @@ def test_pipeline_gate_argument_range():
 
 
 def test_pipeline_depth_argument_range():
-    """b32_set_pipeline_depth: two or three frame sets, anything else is refused (include/b32raster.h)."""
+    """b32_set_pipeline_depth: two or three frame sets, or 0 = the library's own choice; anything else is refused (include/b32raster.h)."""
     from bonnie32_amd import rasterizer as R
     ctx = R.Context(0)
-    for ok in (3, 2, 2, 3):
+    for ok in (3, 2, 2, 3, 0, 0, 3, 0):
         ctx.set_pipeline_depth(ok)
-    for bad in (0, 1, 4, 0xFFFFFFFF):
+    for bad in (1, 4, 0xFFFFFFFF):
         with pytest.raises(R.B32Error) as e:
             ctx.set_pipeline_depth(bad)
         assert e.value.code == b32.abi.B32_E_ARG

@@ -5,6 +5,8 @@ from bonnie32_amd import rasterizer as R, scenegen, parallel
 sc = scenegen.make_scene("C3")
 ctx = R.Context(0)
 import os
+if os.environ.get("EXP_DEPTH"): ctx.set_pipeline_depth(int(os.environ["EXP_DEPTH"]))
+import os
 if os.environ.get("EXP_ROUTES"):
     ctx.set_routes(int(os.environ["EXP_ROUTES"]))
 ctx.set_async_depth(1)      # timing loops: frames back to back (a dropped frame would be reported by finish())
