@@ -56,7 +56,7 @@ struct b32_ctx {
     hipEvent_t ev_setup = nullptr, ev_done = nullptr; bool set_in_flight = false;     // (members of the current set, see FrameSet)
     bool side_dirty = true;              // something k_setup reads was written on `stream` since the side stream last waited for it
     hipStream_t join_stream = nullptr; bool join_ok = false;   // k_flag / k_join instead of an event: only while `stream` and `side` have DIFFERENT priorities (then they never share a hardware queue); checked per main stream
-    uint32_t gate_permille = 1150;       // b32_set_pipeline_gate: hold the next setup kernel until the previous fill has handed out 15 % of the tiles behind its first round
+    uint32_t gate_permille = 0;          // b32_set_pipeline_gate: hold the next setup kernel until the previous fill's tile cursor has got this far (0: only until that fill has started -- the frame sets' order, k_gate)
     uint32_t wire_seq = 0;               // WireArgs::epoch of the last frame with wireframe phases (never 0)
     bool start_lost = false;             // fault injection: the last fused kernel was told not to publish its start (the next start gate waits 2 ms only)
     uint32_t fill_seq = 0;               // FillArgs::start_seq of the last fused kernel launched (never 0)

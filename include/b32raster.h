@@ -443,10 +443,12 @@ int b32_debug_inject(b32_ctx* ctx, uint32_t what);
  * pending, its setup kernel runs on a second, low-priority stream of the context beside the earlier frame's fill kernel, on a second
  * set of per-face buffers.  permille > 0 holds that setup kernel back so that it runs beside the fill's thinning second half rather than
  * beside its busy start (started together the two kernels only slow each other down), measured on the fill's tile cursor:
- *   1001 .. 2000: until (permille - 1000) / 1000 of the tiles BEHIND the workgroups' first round have been handed out (default 1150:
- *                 the setup kernel then ends before the fill does, so the next fill starts without waiting for the cross-stream event);
+ *   1001 .. 2000: until (permille - 1000) / 1000 of the tiles BEHIND the workgroups' first round have been handed out (1150 was the default
+ *                 through round 5);
  *   1 .. 1000   : until the last tile has been handed out and (permille - 1) / 1000 of the workgroups have found the queue empty;
- *   0           : no hold.
+ *   0 (default) : no hold on the cursor.  Since round 6 the setup kernel waits anyway -- for the ORDER of the frame sets -- until the fill in
+ *                 front of it has started (Events::fill_started, k_gate), which keeps it off that fill's first microseconds; a hold on top
+ *                 of that only costs (C3 0.1007-0.1012 against 0.1024-0.1053 ms per frame with 1150, C5 0.1645-0.1653 against 0.1663-0.1670).
  * Results are identical either way.  permille > 2000: B32_E_ARG. */
 int b32_set_pipeline_gate(b32_ctx* ctx, uint32_t permille);
 /* How far ahead of its fill a pipelined setup kernel runs (no reference counterpart; render.rs:2364-2547 is one sequential call):

@@ -6,6 +6,8 @@ import bonnie32_amd as b32
 from bonnie32_amd import rasterizer as R, scenegen
 modes = sys.argv[1:] or ["painter", "zbuffer", "game"]
 ctx = R.Context(0); ctx.set_async_depth(1)
+if os.environ.get("EXP_DEPTH"):
+    ctx.set_pipeline_depth(int(os.environ["EXP_DEPTH"]))
 if os.environ.get("EXP_GATE"):
     ctx.set_pipeline_gate(int(os.environ["EXP_GATE"]))
 out = {}
