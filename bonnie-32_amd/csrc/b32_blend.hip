@@ -74,6 +74,9 @@ __host__ __device__ constexpr size_t blend_lds_bytes(bool depth_tile) {
 template <int NT, bool FMT8, bool GATHER = false>
 __global__ __launch_bounds__(NT, 5) void k_blend(FillArgs a) {        // 5 waves per SIMD: at most 96 VGPRs
     constexpr int NW = NT / 64;
+    // (the frame's "started" word, when the fill left it to this kernel: FillArgs::start_defer)
+    if (GATHER && a.start_seq && a.start_defer == 1u && blockIdx.x == 0 && threadIdx.x == 0)
+        (void)__hip_atomic_exchange(&events_of(a.ctrl)->fill_started, a.start_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // dynamic LDS (blend_lds_bytes): [wf 256 B][the batch's 64 records 9 KB][row masks, column masks 1 KB][fragment lists 2 KB per wave]
     // [tile colours][tile depths, z-buffer mode only]
     extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];

@@ -536,7 +536,9 @@ struct FillArgs {
     uint32_t atlas_idx_bytes;
     uint32_t stagger;           // > 0: the second workgroup of every CU starts this many 10-ns ticks late (set by launch_fill, see k_cover)
     uint32_t span_cover;        // 1: sort-free CHEAP painter's coverage by exact row intervals (B32_ROUTE_SPAN_COVER, b32_fill.hip "span coverage")
-    uint32_t start_seq;         // != 0: workgroup 0 publishes it in Events::fill_started when the fused kernel starts (see k_gate)
+    uint32_t start_seq;         // != 0: workgroup 0 publishes it in Events::fill_started when the fused kernel starts (see k_gate) ...
+    uint32_t start_defer;       // ... unless the frame's transparent pass does (1: k_blend).  The next frame's setup kernel then runs beside THAT kernel and
+                                //     the fill has the GPU to itself (b32_frame.hip)
     uint32_t prio64;            // 1: sort-free coverage -- visibility is a 64-bit max of (painter's key << 32 | face id); `vis` holds
                                 //    two words per pixel: winner face id + 1, runner-up face id + 1 (0 = none)
 #ifdef B32_TIMELINE

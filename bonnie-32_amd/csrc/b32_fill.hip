@@ -124,7 +124,7 @@ __device__ __forceinline__ void cover_body(const FillArgs& a_in) {
     const uint32_t ntiles = fp.tiles_x * fp.tiles_y;
     // "this kernel has started", for the setup kernel that will next write the frame set the PREVIOUS fill on this stream read (k_gate): a
     // device-scope atomic, visible to a poller on any XCD at once (a plain store would sit in this XCD's L2 until the kernel ends)
-    if (P64 && a.start_seq && blockIdx.x == 0 && tid == 0)
+    if (P64 && a.start_seq && !a_in.start_defer && blockIdx.x == 0 && tid == 0)
         (void)__hip_atomic_exchange(&events_of(a.ctrl)->fill_started, a.start_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     phase_stamp(a.ctrl, ST_FILL);
     // (sort-free forms: workgroup 0 also notes the shader-cycle counter now and, with the wall clock, when it runs out of tiles -- the

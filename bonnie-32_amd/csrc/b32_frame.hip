@@ -18,6 +18,9 @@
 #ifndef B32_JOIN_KERNEL
 #define B32_JOIN_KERNEL 1            // (0: the fill waits for its setup kernel through a cross-stream event, as before)
 #endif
+#ifndef B32_START_AT_BLEND
+#define B32_START_AT_BLEND 1         // (0: the fused kernel always publishes the frame's "started" word itself)
+#endif
 #ifndef B32_START_GATE
 #define B32_START_GATE 1             // (0: a cross-stream event behind every fill orders it before the setup kernel that next writes its frame set, as before)
 #endif
@@ -629,6 +632,14 @@ int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st, const
     fa.start_seq = c->fill_seq;
     const uint32_t start_seq_meant = fa.start_seq;
     if ((c->inject & 2u) && fa.prio64 && !wire_front && !r.ordered_all && ntiles) { c->inject &= ~2u; fa.start_seq = 0; c->start_lost = true; }    // (fault injection: see b32_debug_inject)
+    // Which kernel of the frame says "started": the fused kernel -- or, when the frame has a transparent pass, that pass (k_blend, the next
+    // kernel on the main stream).  The next frame's setup kernel is released by that word, i.e. it then runs beside the blend kernel and the
+    // fill has the GPU to itself: C3 with 10 % transparent faces 0.227 -> 0.192 ms per frame, the same in z-buffer mode 0.264 -> 0.222 (the fill
+    // is the kernel that suffers from company: 97 us beside a setup kernel, 82 alone; k_blend 127 either way).  The wire tile kernel of
+    // default() in that role: 0.284 -> 0.331 -- its setup kernel is the long one and then starts too late; not done.
+    // Only frames that fill the GPU (more tiles than workgroup slots): a console-sized draw leaves most CUs idle anyway and its setup kernel is
+    // a chain of round trips that wants to start as early as it may (12-room console frame with the deferral: 0.171 -> 0.213 ms).
+    fa.start_defer = (B32_START_AT_BLEND && fa.prio64 && !wire_front && !r.ordered_all && ntiles > 2u * (uint32_t)c->n_cu && fa.gather_blend) ? 1u : 0u;
     // a deferred Framebuffer::clear: folded into this frame's fused kernel when that kernel is the one that runs, the frame has no
     // depth buffer to reset and the clear was issued for this very band; else the clear launches go first
     if (c->clear_pending) {
