@@ -581,6 +581,39 @@ def test_narrow_band_runs_three_frame_sets_by_itself(oracle):
     ctx.close()
 
 
+@pytest.mark.parametrize("zbuffer", [False, True])
+def test_frames_with_a_transparent_pass_two_in_flight(oracle, zbuffer):
+    """Frames that fill the GPU (1200 tiles) and have a transparent pass, back to back: the next frame's setup kernel is released by k_blend's
+    start instead of the fill's (FillArgs::start_defer), so the order between the frame sets now hangs on a word the BLEND kernel publishes.
+    Six frames pipelined, painter's and z-buffer mode, camera moved between them so that a stale set would show: every second frame checked
+    against the oracle."""
+    from bonnie32_amd import rasterizer as R
+    sc = scenegen.make_scene("C3", n_tris=120_000, variant="blend", seed=31)
+    if zbuffer:
+        sc.settings = b32.RasterSettings(shading=0, lights=[], backface_wireframe=False)
+    cams = []
+    for k in range(3):
+        cam = copy.deepcopy(sc.camera)
+        cam.position = (cam.position[0] + 0.7 * k, cam.position[1] - 0.4 * k, cam.position[2])
+        cams.append(cam)
+    want = []
+    for cam in cams:
+        s2 = copy.copy(sc); s2.camera = cam
+        want.append(cpu_render(oracle, s2)[0])
+    ctx = R.Context(0); ctx.set_async_depth(1)
+    fb = R.Framebuffer(sc.width, sc.height, ctx)
+    rs = R.ResidentScene(fb, sc.vertices, sc.faces, sc.textures)
+    for k in (0, 1, 2, 0, 1, 2, 1, 0):
+        p0 = ctx.route_counts()["pipelined"]
+        for _ in range(3):                                   # three frames in a row with this camera, the last one is looked at
+            fb.clear(sc.clear_color); rs.render_async(cams[k], sc.settings, sc.fog)
+        rs.finish()
+        assert ctx.route_counts()["pipelined"] - p0 >= 2
+        got = fb.pixels
+        assert np.array_equal(got, want[k]), f"camera {k}: {int((got != want[k]).sum())} bytes differ"
+    ctx.close()
+
+
 def test_lost_start_signal_is_reported_and_the_frames_are_right(oracle):
     """The failure path of the device-side order between frame sets (round 6: the fused kernel publishes Events::fill_started, k_gate in front of
     the setup kernel that next writes the frame set waits for it instead of for a cross-stream event), forced by b32_debug_inject(2): one fill
