@@ -549,7 +549,7 @@ int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st, const
         }
         // (b32_debug_inject(ctx, 2): the fill in front did not publish its start -- this gate's patience is 2 ms, then the error)
         const uint32_t start_patience = c->start_lost ? 200000u : 200000000u;
-        if (start_gate) c->start_lost = false;
+        c->start_lost = false;                               // (one gate only, whichever way this frame is ordered)
         if (gate_need || start_gate) launch_gate(ss, c->alt[0].d_ctrl, gate_need, 30000u /* 300 us */, start_gate ? polled_seq : 0u, c->d_ctrl, start_patience);      // alt[0]: the frame n_sets - 1 back (rotate_sets)
     }
     // (the wire kernels' arguments: known before the setup kernel is launched -- a pipelined frame bins its wire list on the side stream)
