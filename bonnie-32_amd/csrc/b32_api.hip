@@ -491,6 +491,7 @@ extern "C" unsigned long long b32_route_count(const b32_ctx* c, int which) {
     if (c && which == 10) return c->span_cover_frames;
     if (c && which == 11) return c->flag_join_frames;
     if (c && which == 12) return c->event_join_frames;
+    if (c && which == 13) return c->poll_join_frames;
     return (c && which >= 0 && which < 8) ? c->routes[which] : 0ull;
 }
 extern "C" int b32_set_async_depth(b32_ctx* c, int deep) {

@@ -94,6 +94,9 @@ __global__ __launch_bounds__(NT, 5) void k_blend(FillArgs a) {        // 5 waves
     static_assert(!GATHER || BLEND_SORT_CAP * 8 <= BLEND_TILE_BYTES, "the priority sort aliases the colour tile");
     static_assert(NW * 8 <= 256, "wf");
     if (a.ctrl->abort || a.ctrl->need_global_sort) return;
+    // (the fill gave up on this draw's setup kernel -- polled hand-over, or k_join's Events::join_abort: there are no lists of this frame)
+    if (GATHER && a.join_seq && events_of(a.ctrl)->poll_lost == a.join_seq) return;
+    if (GATHER && a.direct_bin && events_of(a.ctrl)->join_abort == a.epoch) return;
     const FrameParams& fp = a.fp;
     const uint32_t tile = blockIdx.x;
     // x-ray: every surface blends (render.rs:1671-1673), so the ordered pass walks the opaque list too, then the transparent one

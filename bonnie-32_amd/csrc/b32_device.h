@@ -186,7 +186,9 @@ struct Events { uint32_t bad_index, nan_opaque, nan_transparent, overflow, long_
                 join_abort /* k_join -> fill: epoch of the frame whose setup kernel never arrived (the fill draws nothing but the folded clear) */,
                 fill_started /* fused fill -> k_gate of a later frame's setup kernel: FillArgs::start_seq of the last fused kernel that STARTED on this control
                                 block (it started => everything in front of it on the main stream has ended) */,
-                wbin_done /* side stream -> first wire kernel on the main stream: WireArgs::epoch of the frame whose early k_wire_bin has finished */, _pad[7]; };
+                wbin_done /* side stream -> first wire kernel on the main stream: WireArgs::epoch of the frame whose early k_wire_bin has finished */,
+                poll_done /* k_flag_poll -> the fused kernel itself (FillArgs::join_seq): the setup kernel of that hand-over has finished */,
+                poll_lost /* fused kernel -> the transparent pass behind it: join_seq of a hand-over the fill gave up on (nothing of that draw's lists exists) */, _pad[5]; };
 __device__ __forceinline__ Events* events_of(Ctrl* ctrl) { return reinterpret_cast<Events*>(reinterpret_cast<unsigned char*>(ctrl) + 128); }
 enum { ST_SETUP = 0, ST_BIN = 1, ST_FILL = 2, ST_WIRE = 3, ST_END = 4,
        ST_CLK0 = 5, ST_CLK1 = 6, ST_CLKW = 7 };   // shader-cycle counter at the start / end of workgroup 0 of the fused kernel, wall clock at its end
@@ -410,6 +412,7 @@ void launch_setup(hipStream_t s, const FrameParams& fp, const B32Vertex* verts, 
                   uint32_t* partials, Ctrl* ctrl, WireTri* wire, int n_cu, const float* pos12, const float* attr12, uint32_t* face_of);
 void launch_gate(hipStream_t s, Ctrl* prev, uint32_t need, uint32_t patience_ticks, uint32_t start_seq, Ctrl* mine, uint32_t start_patience_ticks = 200000000u);
 void launch_flag(hipStream_t s, Ctrl* ctrl, uint32_t epoch);
+void launch_flag_poll(hipStream_t s, Ctrl* ctrl, uint32_t seq);        // Events::poll_done = seq, behind the setup kernel of a polled hand-over
 void launch_flag_wbin(hipStream_t s, Ctrl* ctrl, uint32_t epoch);      // Events::wbin_done = epoch, behind the early k_wire_bin on the side stream
 void launch_join(hipStream_t s, Ctrl* ctrl, uint32_t epoch, uint32_t patience_ticks);
 void launch_pack_streams(hipStream_t s, const B32Vertex* verts, uint32_t nv, float* pos12, float* attr12, bool with_lit);
@@ -536,6 +539,10 @@ struct FillArgs {
     uint32_t atlas_idx_bytes;
     uint32_t stagger;           // > 0: the second workgroup of every CU starts this many 10-ns ticks late (set by launch_fill, see k_cover)
     uint32_t span_cover;        // 1: sort-free CHEAP painter's coverage by exact row intervals (B32_ROUTE_SPAN_COVER, b32_fill.hip "span coverage")
+    // The merged draws of a batched frame (console-sized: 16-wave workgroups on at most 5 / 8 of the CUs): the hand-over from the draw's setup kernel
+    // on the side stream is polled INSIDE the fused kernel -- thread 0 of every workgroup reads Events::poll_done until it holds join_seq, and only
+    // a workgroup that really waited acquires at device scope -- instead of by a cross-stream event (6.5 us of the main stream per draw).  0: no wait.
+    uint32_t join_seq, join_patience;       // patience in 10-ns ticks; when it runs out the workgroup draws nothing but the folded clear (sticky bit 3)
     uint32_t start_seq;         // != 0: workgroup 0 publishes it in Events::fill_started when the fused kernel starts (see k_gate) ...
     uint32_t start_defer;       // ... unless the frame's transparent pass does (1: k_blend).  The next frame's setup kernel then runs beside THAT kernel and
                                 //     the fill has the GPU to itself (b32_frame.hip)

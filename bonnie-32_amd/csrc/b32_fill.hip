@@ -126,14 +126,39 @@ __device__ __forceinline__ void cover_body(const FillArgs& a_in) {
     // device-scope atomic, visible to a poller on any XCD at once (a plain store would sit in this XCD's L2 until the kernel ends)
     if (P64 && a.start_seq && !a_in.start_defer && blockIdx.x == 0 && tid == 0)
         (void)__hip_atomic_exchange(&events_of(a.ctrl)->fill_started, a.start_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    phase_stamp(a.ctrl, ST_FILL);
     // (sort-free forms: workgroup 0 also notes the shader-cycle counter now and, with the wall clock, when it runs out of tiles -- the
     // shader clock the fill really ran at, b32_last_shader_clock: under this kernel's load it sits below the device's nominal clock)
     const unsigned long long clk_entry = (P64 && blockIdx.x == 0 && tid == 0) ? (unsigned long long)clock64() : 0ull;
     // small meshes (inline_bin): the first NT spans (and class bits) are requested before the counters are reduced, and the skip mask is
     // staged before it too -- a C1 workgroup used to start its tile 7 us into an 18-us kernel behind three dependent round trips
+    // The setup -> fill hand-over polled here (FillArgs::join_seq: the merged draws of a batched frame): everything above reads scene data
+    // only; nothing k_setup writes -- spans, counters, event words, records, the control block it resets when it starts -- is touched before
+    // this point.  The kernel boundaries still do the cache maintenance on the writer's side (k_flag_poll runs behind the setup kernel's
+    // end-of-kernel release).  The acquire only where the workgroup really waited: a value found at the first look was published before
+    // anything of this kernel could have cached a line the setup kernel wrote (the kernel's own start invalidated the caches), and the fence
+    // is not free -- it invalidates this CU's L1 and the XCD's whole L2 (by every wave of every workgroup it stretched C2's fill from 23 to
+    // 40 us: profiles/r06_poll_join_ab.txt).  One wave does it for the workgroup: the waves share the L1.
+    bool join_lost = false;
+    if (P64 && a.join_seq) {
+        if (tid == 0) {
+            Events* ev = events_of(a.ctrl);
+            const unsigned long long t0 = wall_clock64();
+            uint32_t lost = 0, waited = 0;
+            while (__hip_atomic_fetch_add(&ev->poll_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.join_seq) {
+                if (wall_clock64() - t0 > (unsigned long long)a.join_patience) { lost = 1; break; }
+                waited = 1;
+                __builtin_amdgcn_s_sleep(32);           // (every workgroup polls one word: a short sleep is a storm of atomics on one address)
+            }
+            if (lost) { atomicOr(&a.ctrl->sticky, 8u); (void)__hip_atomic_exchange(&ev->poll_lost, a.join_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            if (waited) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            misc[7] = lost;
+        }
+        __syncthreads();
+        join_lost = misc[7] != 0;
+    }
+    phase_stamp(a.ctrl, ST_FILL);
     uint32_t pre_span = 0xFFFFFFFFu, pre_key = 0u;
-    if (P64 && a.inline_bin && tid < fp.nf) { pre_span = a.spans[tid]; if (a.gather_blend) pre_key = a.keys[tid]; }
+    if (P64 && a.inline_bin && tid < fp.nf && !join_lost) { pre_span = a.spans[tid]; if (a.gather_blend) pre_key = a.keys[tid]; }
     if (P64 && EXACT && a.mask_lds_words) {     // the pool's skip mask into the (unused) runner-up plane, once per workgroup
         uint32_t* ml = tilebuf + 2 * TILE_H * TILE_STRIDE;
         for (uint32_t i = tid; i < a.mask_lds_words; i += NT) ml[i] = a.texmask[i];
@@ -146,13 +171,13 @@ __device__ __forceinline__ void cover_body(const FillArgs& a_in) {
         // when a sort comparison sees NaN, render.rs:2531); workgroup 0 publishes the counters in Ctrl for the host.  Direct binning:
         // k_setup left the epoch of this frame in Events when it met one of those, and only then does every workgroup pay for the
         // reduction; otherwise workgroup 0 alone does it, for the host's counters.
-        bool reduce = a.inline_bin != 0, join_abort = false;
+        bool reduce = a.inline_bin != 0, join_abort = join_lost;
         uint32_t redraw = 0;
         if (a.direct_bin) {
             const Events* ev = events_of(a.ctrl);
             reduce = ev->bad_index == a.epoch || ev->nan_opaque == a.epoch || ev->nan_transparent == a.epoch;
             redraw = (ev->overflow == a.epoch ? 2u : 0u) | (ev->long_transparent == a.epoch ? 1u : 0u);
-            join_abort = ev->join_abort == a.epoch;     // (k_join gave up on this frame's setup kernel: nothing of its output may be read)
+            join_abort = join_lost || ev->join_abort == a.epoch;     // (k_join gave up on this frame's setup kernel: nothing of its output may be read)
             // (no such event: the frame is not aborted, and workgroup 0 reduces the counters for the host AFTER its tiles -- with a
             // million faces the reduction takes microseconds, and in a narrow band every workgroup has one tile: it was the kernel's
             // critical path)

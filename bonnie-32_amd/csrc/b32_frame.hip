@@ -18,6 +18,9 @@
 #ifndef B32_JOIN_KERNEL
 #define B32_JOIN_KERNEL 1            // (0: the fill waits for its setup kernel through a cross-stream event, as before)
 #endif
+#ifndef B32_POLL_BATCHED
+#define B32_POLL_BATCHED 1            // (0: the merged draws of a batched frame wait for their setup kernels through a cross-stream event, as before)
+#endif
 #ifndef B32_START_AT_BLEND
 #define B32_START_AT_BLEND 1         // (0: the fused kernel always publishes the frame's "started" word itself)
 #endif
@@ -572,7 +575,22 @@ int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st, const
     if (prof_all) HIPCHK(c, hipEventRecord(ev[0], s));
     launch_setup(ss, fp, c->d_verts, c->d_faces, c->d_tex, c->d_lights, lset, c->frame_table, RecArrays{ c->crecs, c->srecs, c->xrecs }, r.db, c->shades, c->keys[0],
                  r.direct_bin ? nullptr : c->spans /* (direct binning: nobody reads the spans) */, c->partials, c->d_ctrl, c->wire, c->n_cu, pos12, attr12, c->face_of);
-    if (c->pipelined && B32_JOIN_KERNEL && r.direct_bin && c->join_ok && !(c->frame_batched && B32_JOIN_NOT_BATCHED)) {
+    // The merged draws of a batched frame: the hand-over polled by the fused kernel itself (FillArgs::join_seq) -- their fills are few 16-wave
+    // workgroups (at most 5 / 8 of the CUs: the setup kernel they may have to spin for keeps the rest of the GPU), the setup kernel of draw
+    // k + 1 has normally finished beside draw k's fill and blend pass, and what the cross-stream event cost the main stream per draw (6.5 us
+    // between k_blend's end and the next fill's start: tools/console_trace.sh) was most of what there was to save in a console frame.
+    uint32_t poll_seq = 0, poll_patience = 0;
+    const bool poll_batched = B32_POLL_BATCHED && c->pipelined && c->frame_batched && c->join_ok && (r.direct_bin || r.want_inline) && !wire_front && !r.ordered_all &&
+                              ntiles && 8u * ntiles <= 5u * (uint32_t)c->n_cu && !(c->route_off & B32_ROUTE_WIDE_GROUPS);
+    if (poll_batched) {
+        // (b32_debug_inject(ctx, 1) as below: the flag carries another value, the patience is 2 ms)
+        const bool lose_flag = (c->inject & 1u) != 0;
+        c->inject &= ~1u;
+        if (++c->join_seq == 0) c->join_seq = 1;
+        launch_flag_poll(c->side, c->d_ctrl, lose_flag ? c->join_seq ^ 0x40000000u : c->join_seq);
+        poll_seq = c->join_seq; poll_patience = lose_flag ? 200000u : 200000000u;
+        c->flag_join_frames++; c->poll_join_frames++;
+    } else if (c->pipelined && B32_JOIN_KERNEL && r.direct_bin && c->join_ok && !(c->frame_batched && B32_JOIN_NOT_BATCHED)) {
         // (no cross-stream event on the fill's path: see k_flag / k_join)
         // (b32_debug_inject(ctx, 1): this frame's flag carries another epoch and the join's patience is 2 ms -- the "setup kernel never arrived" path)
         const bool lose_flag = (c->inject & 1u) != 0;
@@ -630,6 +648,7 @@ int enqueue_frame(b32_ctx* c, const B32Camera* cam, const B32Settings* st, const
     FillArgs fa = fill_args(c, fp, r, cur, wire_front);
     if (++c->fill_seq == 0) c->fill_seq = 1;
     fa.start_seq = c->fill_seq;
+    fa.join_seq = poll_seq; fa.join_patience = poll_patience;
     const uint32_t start_seq_meant = fa.start_seq;
     if ((c->inject & 2u) && fa.prio64 && !wire_front && !r.ordered_all && ntiles) { c->inject &= ~2u; fa.start_seq = 0; c->start_lost = true; }    // (fault injection: see b32_debug_inject)
     // Which kernel of the frame says "started": the fused kernel -- or, when the frame has a transparent pass, that pass (k_blend, the next

@@ -59,6 +59,7 @@ struct b32_ctx {
     uint32_t gate_permille = 0;          // b32_set_pipeline_gate: hold the next setup kernel until the previous fill's tile cursor has got this far (0: only until that fill has started -- the frame sets' order, k_gate)
     uint32_t wire_seq = 0;               // WireArgs::epoch of the last frame with wireframe phases (never 0)
     bool start_lost = false;             // fault injection: the last fused kernel was told not to publish its start (the next start gate waits 2 ms only)
+    uint32_t join_seq = 0;               // FillArgs::join_seq of the last polled hand-over (never 0)
     uint32_t fill_seq = 0;               // FillArgs::start_seq of the last fused kernel launched (never 0)
     bool pipe_hint = true;               // the previous frame's route could use the second frame set
     struct CoverOf { const Ctrl* ctrl; uint32_t tiles, groups, seq; } cover_of[3] = {};   // the same per frame set (keyed by its control block): the gate polls the
@@ -66,7 +67,7 @@ struct b32_ctx {
     uint32_t last_cover_tiles = 0, last_cover_groups = 0;   // tile count / workgroups of the previous frame's fused kernel (0: it had none)
     bool pipelined = false;              // the frame being enqueued runs its k_setup on the side stream
     unsigned long long pipelined_frames = 0;
-    unsigned long long flag_join_frames = 0, event_join_frames = 0;    // ... handed over to the fill by k_flag / k_join, or by a cross-stream event
+    unsigned long long flag_join_frames = 0, event_join_frames = 0, poll_join_frames = 0;    // ... handed over to the fill by k_flag / k_join, or by a cross-stream event
     uint32_t inject = 0;                 // b32_debug_inject: fault injection for the tests of the failure paths
 
     // framebuffer

@@ -687,10 +687,14 @@ __global__ void k_join(Ctrl* __restrict__ ctrl, uint32_t epoch, uint32_t patienc
         __builtin_amdgcn_s_sleep(4);
     }
 }
+__global__ void k_flag_poll(Ctrl* __restrict__ ctrl, uint32_t seq) {
+    __hip_atomic_exchange(&events_of(ctrl)->poll_done, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __global__ void k_flag_wbin(Ctrl* __restrict__ ctrl, uint32_t epoch) {
     __hip_atomic_exchange(&events_of(ctrl)->wbin_done, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 void launch_flag(hipStream_t s, Ctrl* ctrl, uint32_t epoch) { hipLaunchKernelGGL(k_flag, dim3(1), dim3(1), 0, s, ctrl, epoch); }
+void launch_flag_poll(hipStream_t s, Ctrl* ctrl, uint32_t seq) { hipLaunchKernelGGL(k_flag_poll, dim3(1), dim3(1), 0, s, ctrl, seq); }
 void launch_flag_wbin(hipStream_t s, Ctrl* ctrl, uint32_t epoch) { hipLaunchKernelGGL(k_flag_wbin, dim3(1), dim3(1), 0, s, ctrl, epoch); }
 void launch_join(hipStream_t s, Ctrl* ctrl, uint32_t epoch, uint32_t patience) { hipLaunchKernelGGL(k_join, dim3(1), dim3(1), 0, s, ctrl, epoch, patience); }
 void launch_gate(hipStream_t s, Ctrl* prev, uint32_t need, uint32_t patience, uint32_t start_seq, Ctrl* mine, uint32_t start_patience) {

@@ -73,7 +73,7 @@ class Context:
         _chk(self.lib.b32_set_async_depth(self.h, int(deep)), "b32_set_async_depth")
 
     ROUTES = ("direct_bin", "inline_bin", "counting_sort", "keyed", "redraw_region", "redraw_global_sort", "redraw_pairs", "pipelined", "lds_atlas", "wire_tiles", "span_cover",
-              "flag_join", "event_join")
+              "flag_join", "event_join", "poll_join")
 
     ROUTE_SORT_FREE, ROUTE_CUT_TILES, ROUTE_INLINE_BIN, ROUTE_DIRECT_BIN, ROUTE_WIDE_GROUPS, ROUTE_PACKED_STREAMS, ROUTE_PIPELINE, ROUTE_TEX_CACHE, ROUTE_BATCH, ROUTE_LDS_ATLAS, ROUTE_WIRE_TILES, ROUTE_SPAN_COVER, ROUTE_STAGGER = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096
 

@@ -276,7 +276,8 @@ int b32_set_async_depth(b32_ctx* ctx, int deep);
  * fill (two frames in flight), 8 frames whose fused kernel sampled the 4/8-bit index atlas + CLUT from LDS (B32_ROUTE_LDS_ATLAS),
  * 9 frames whose wireframe phases went through the tile route (B32_ROUTE_WIRE_TILES), 10 frames whose opaque coverage was decided by
  * exact row intervals (B32_ROUTE_SPAN_COVER), 11 pipelined frames whose setup kernel was handed over to the fill by the flag / join kernel
- * pair, 12 by a cross-stream event (main and side stream of one priority, batched frames).
+ * pair, 12 by a cross-stream event (main and side stream of one priority), 13 those of 11 whose fused kernel polled the flag itself (the merged
+ * draws of a batched frame: no launch and no event in front of the fill).
  * Unknown `which` or null ctx: 0. */
 unsigned long long b32_route_count(const b32_ctx* ctx, int which);
 /* Switch internal routes OFF for the frames enqueued from now on (no reference counterpart: the results are identical on every route;

@@ -581,6 +581,53 @@ def test_narrow_band_runs_three_frame_sets_by_itself(oracle):
     ctx.close()
 
 
+def test_batched_draws_poll_their_hand_over_and_a_lost_flag_is_reported(oracle):
+    """The merged draws of a batched frame (b32_frame_begin / _add_scene / _end, frames back to back): the fused kernel polls the setup -> fill
+    hand-over itself (FillArgs::join_seq, route counter `poll_join`) -- no event, no join kernel in front of it.  Frames equal the oracle's
+    sequential calls; then b32_debug_inject(1) makes one draw's flag carry another value: its workgroups give up after 2 ms, that draw draws
+    nothing, b32_frame_finish returns B32_E_HIP (never silent), and the frames after it are right again."""
+    from bonnie32_amd import rasterizer as R
+    meshes = _console_meshes(12, 5100)
+    st = b32.RasterSettings.game()
+    st.lights = [b32.Light.directional((-1.0, -1.0, -1.0), 0.7), b32.Light.point((0.0, -100.0, 1500.0), 3000.0, 1.2)]
+    cam = b32.Camera(position=(15.0, -10.0, -40.0))
+    W, H = meshes[0].width, meshes[0].height
+    clear = b32.Color(10, 10, 30)
+    ofb = oracle.Framebuffer(W, H); ofb.clear(clear)
+    for sc in meshes:
+        assert oracle.render_mesh_15(ofb, sc.vertices, sc.faces, sc.textures, cam, st, None)[0] == 0
+    ctx = R.Context(0); ctx.set_async_depth(1)
+    fb = R.Framebuffer(W, H, ctx)
+    slots = [R.ResidentScene(fb, sc.vertices, sc.faces, sc.textures).detach() for sc in meshes]
+
+    def frame():
+        fb.clear(clear)
+        ctx.frame_begin(cam, st)
+        for rs in slots:
+            ctx.frame_add(rs)
+        ctx.frame_end()
+    for _ in range(4):
+        frame()
+    ctx.finish()
+    assert np.array_equal(fb.pixels, ofb.pixels) and np.array_equal(fb.zbuffer.view(np.uint32), ofb.zbuffer.view(np.uint32))
+    rc = ctx.route_counts()
+    assert rc["poll_join"] >= 6 and rc["event_join"] == 0, rc
+    frame()
+    ctx.debug_inject(1)
+    frame()                                   # its first pipelined draw loses its flag
+    frame(); frame()
+    with pytest.raises(R.B32Error) as ei:
+        ctx.finish()
+    assert ei.value.code == b32.abi.B32_E_HIP
+    assert np.array_equal(fb.pixels, ofb.pixels), "the frames behind the lost flag are drawn in full"
+    frame(); frame()
+    ctx.finish()
+    assert np.array_equal(fb.pixels, ofb.pixels) and np.array_equal(fb.zbuffer.view(np.uint32), ofb.zbuffer.view(np.uint32))
+    for rs in slots:
+        rs.close()
+    ctx.close()
+
+
 @pytest.mark.parametrize("zbuffer", [False, True])
 def test_frames_with_a_transparent_pass_two_in_flight(oracle, zbuffer):
     """Frames that fill the GPU (1200 tiles) and have a transparent pass, back to back: the next frame's setup kernel is released by k_blend's
