@@ -3,7 +3,7 @@
 # copy the ones to be judged into profiles/.
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-T=${1:-r06_v6}
+T=${1:-r06_v7}
 bash tools/pmc_passes.sh $T C3 > gpurun_out/${T}_passes.log 2>&1
 bash tools/pmc_passes.sh ${T}_C5 C5 >> gpurun_out/${T}_passes.log 2>&1
 bash tools/pmc_passes.sh ${T}_C2 C2 >> gpurun_out/${T}_passes.log 2>&1
